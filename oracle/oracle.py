@@ -1,0 +1,295 @@
+"""ctypes front-end of the CPU oracle (oracle/libslam_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/slam_oracle.h.  Imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product
+package.  Parity with the Julia reference is UNPINNED (argued from source, not
+measured): Julia is not installed and the reference ships no golden vectors.
+
+Array conventions follow the reference: images are H x W Float64 in Julia's
+column-major layout, which in numpy is ``np.asfortranarray(img)``; points are
+``(n, 2)`` C-contiguous ``(y, x)`` 1-based Float64.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+f64p = C.POINTER(C.c_double)
+u8p = C.POINTER(C.c_uint8)
+i64p = C.POINTER(C.c_int64)
+i32p = C.POINTER(C.c_int32)
+u64p = C.POINTER(C.c_uint64)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libslam_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("orc_image.c", "orc_lk.c", "orc_ba.c", "slam_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libslam_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_bilinear.restype = C.c_double
+        _LIB.orc_bilinear.argtypes = [f64p, C.c_int, C.c_int, C.c_double, C.c_double]
+        _LIB.orc_pyr_layout.restype = C.c_int64
+    return _LIB
+
+
+def _p(a, t=f64p):
+    return a.ctypes.data_as(t)
+
+
+def fimg(img):
+    """H x W array -> Fortran-ordered float64 (Julia memory layout)."""
+    return np.asfortranarray(img, dtype=np.float64)
+
+
+# ----------------------------------------------------------------------------
+def gaussian_taps(sigma):
+    w = np.zeros(4 * int(np.ceil(sigma)) + 1)
+    n = lib().orc_gaussian_taps(C.c_double(sigma), _p(w))
+    return w[:n]
+
+
+def imfilter_sep(img, k1, k2, border=0):
+    img = fimg(img)
+    H, W = img.shape
+    out = np.empty_like(img, order="F")
+    k1 = np.ascontiguousarray(k1, dtype=np.float64)
+    k2 = np.ascontiguousarray(k2, dtype=np.float64)
+    lib().orc_imfilter_sep(_p(out), _p(img), H, W, _p(k1), len(k1), _p(k2), len(k2), border)
+    return out
+
+
+def iir_gaussian(img, sigma, border=0):
+    img = fimg(img)
+    H, W = img.shape
+    out = np.empty_like(img, order="F")
+    lib().orc_iir_gaussian(_p(out), _p(img), H, W, C.c_double(sigma), border)
+    return out
+
+
+def iir_coeffs(sigma):
+    a = np.zeros(3); scale = C.c_double(); M = np.zeros(9); asum = C.c_double()
+    lib().orc_iir_coeffs(C.c_double(sigma), _p(a), C.byref(scale), _p(M), C.byref(asum))
+    return a, scale.value, M.reshape(3, 3), asum.value
+
+
+def imresize(img, Hd, Wd):
+    img = fimg(img)
+    H, W = img.shape
+    out = np.empty((Hd, Wd), order="F")
+    lib().orc_imresize(_p(out), Hd, Wd, _p(img), H, W)
+    return out
+
+
+def bilinear(img, r, c):
+    img = fimg(img)
+    return lib().orc_bilinear(_p(img), img.shape[0], img.shape[1], C.c_double(r), C.c_double(c))
+
+
+def get_mask(H, W, pts_yx, radius):
+    pts = np.ascontiguousarray(pts_yx, dtype=np.float64).reshape(-1, 2)
+    m = np.empty((H, W), order="F")
+    lib().orc_get_mask(_p(m), H, W, _p(pts), len(pts), radius)
+    return m
+
+
+def shi_tomasi(cell):
+    cell = fimg(cell)
+    h, w = cell.shape
+    out = np.empty((h, w), order="F")
+    lib().orc_shi_tomasi(_p(out), _p(cell), h, w, h)
+    return out
+
+
+def grid_resolution(H, W, cell_size):
+    """SlamManager: ceil.(Int, (H, W) ./ max_distance), src/SLAM.jl:150-151."""
+    return -(-H // cell_size), -(-W // cell_size)
+
+
+def detect(img, cur_yx, max_points=1000, radius=17, cell_size=35, sigma_mask=3.0, min_response=1e-4, grid=None):
+    img = fimg(img)
+    H, W = img.shape
+    gr, gc = grid if grid is not None else grid_resolution(H, W, cell_size)
+    cur = np.ascontiguousarray(cur_yx, dtype=np.float64).reshape(-1, 2)
+    n_cur = len(cur)
+    k = max(1, int(np.ceil(max(max_points - n_cur, 0) / (gr * gc))))
+    cap = gr * gc * k + 8
+    out = np.zeros((cap, 2), dtype=np.int64)
+    n = lib().orc_detect(_p(img), H, W, _p(cur), n_cur, max_points, radius, gr, gc, cell_size,
+                         C.c_double(sigma_mask), C.c_double(min_response), _p(out, i64p), cap)
+    assert n >= 0
+    return out[:n].copy()
+
+
+def describe(img, rc, pattern, sigma=np.sqrt(2.0), window=9):
+    img = fimg(img)
+    H, W = img.shape
+    rc = np.ascontiguousarray(rc, dtype=np.int64).reshape(-1, 2)
+    pattern = np.ascontiguousarray(pattern, dtype=np.int32).reshape(-1, 4)
+    nb = len(pattern)
+    bits = np.zeros((len(rc), nb // 64), dtype=np.uint64)
+    orc = np.zeros((len(rc), 2), dtype=np.int64)
+    n = lib().orc_describe(_p(img), H, W, _p(rc, i64p), len(rc), _p(pattern, i32p), nb,
+                           C.c_double(sigma), window, _p(bits, u64p), _p(orc, i64p))
+    return bits[:n].copy(), orc[:n].copy()
+
+
+# ----------------------------------------------------------------------------
+class Pyramid:
+    """Host mirror of LKPyramid (pyramid.jl:16-24) as six flat plane buffers."""
+    PLANES = ("layers", "Iy", "Ix", "Iyy", "Ixx", "Iyx")
+
+    def __init__(self, H, W, total_levels):
+        self.H0, self.W0, self.levels = H, W, total_levels
+        Hs = (C.c_int * 8)(); Ws = (C.c_int * 8)(); off = (C.c_int64 * 9)()
+        self.total = lib().orc_pyr_layout(H, W, total_levels, Hs, Ws, off)
+        self.Hs, self.Ws, self.off = list(Hs)[:total_levels], list(Ws)[:total_levels], list(off)[:total_levels + 1]
+        for n in self.PLANES:
+            setattr(self, n, np.zeros(self.total))
+
+    def plane(self, name, level):
+        """level is 0-based here; returns an H x W Fortran-ordered view."""
+        buf = getattr(self, name)
+        return buf[self.off[level]:self.off[level + 1]].reshape((self.Hs[level], self.Ws[level]), order="F")
+
+
+def pyr_build(img, pyramid_levels=3, sigma=1.0, mode=1):
+    img = fimg(img)
+    H, W = img.shape
+    p = Pyramid(H, W, pyramid_levels + 1)
+    lib().orc_pyr_build_flat(_p(img), H, W, p.levels, C.c_double(sigma), mode,
+                             _p(p.layers), _p(p.Iy), _p(p.Ix), _p(p.Iyy), _p(p.Ixx), _p(p.Iyx))
+    return p
+
+
+def fb_tracking(prev, cur, pts_yx, disp0=None, iterations=30, window=9, pyramid_levels=3,
+                eig_thr=1e-4, eps=1e-2, max_distance=1.0, sum_order=0, threads=1):
+    pts = np.ascontiguousarray(pts_yx, dtype=np.float64).reshape(-1, 2)
+    n = len(pts)
+    out = np.full((n, 2), np.nan)
+    status = np.zeros(n, dtype=np.uint8)
+    d0 = None if disp0 is None else np.ascontiguousarray(disp0, dtype=np.float64).reshape(-1, 2)
+    rc = lib().orc_fb_tracking_flat(
+        prev.H0, prev.W0, prev.levels,
+        _p(prev.layers), _p(prev.Iy), _p(prev.Ix), _p(prev.Iyy), _p(prev.Ixx), _p(prev.Iyx),
+        _p(cur.layers), _p(cur.Iy), _p(cur.Ix), _p(cur.Iyy), _p(cur.Ixx), _p(cur.Iyx),
+        _p(pts), None if d0 is None else _p(d0), n, iterations, window, pyramid_levels,
+        C.c_double(eig_thr), C.c_double(eps), C.c_double(max_distance), _p(out), _p(status, u8p),
+        sum_order, threads)
+    if rc != 0:
+        raise RuntimeError("Not enough layers in pyramids.")
+    return out, status.astype(bool)
+
+
+def svd2x2(M):
+    M = np.asfortranarray(M, dtype=np.float64)
+    U = np.zeros((2, 2), order="F"); S = np.zeros(2); V = np.zeros((2, 2), order="F")
+    lib().orc_svd2x2(_p(M), _p(U), _p(S), _p(V))
+    return U, S, V
+
+
+def pinv2x2(M):
+    M = np.asfortranarray(M, dtype=np.float64)
+    G = np.zeros((2, 2), order="F"); S = np.zeros(2)
+    lib().orc_pinv2x2(_p(M), _p(G), _p(S))
+    return G, S
+
+
+# ----------------------------------------------------------------------------
+def rotzyx(t1, t2, t3):
+    R = np.zeros(9)
+    lib().orc_rotzyx(C.c_double(t1), C.c_double(t2), C.c_double(t3), _p(R))
+    return R.reshape(3, 3)
+
+
+def rotzyx_angles(R):
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    lib().orc_rotzyx_angles(_p(R), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def bundle_adjustment(cam, theta, theta_const, pixels_yx, pose_ids, point_ids,
+                      iters_fast=5, iterations=10, repr_eps=5.0, solver=1):
+    """Returns (theta_new, outliers, stats dict).  cam = (fx, fy, cx, cy)."""
+    theta = np.array(theta, dtype=np.float64, copy=True)
+    tc = np.ascontiguousarray(theta_const, dtype=np.uint8)
+    px = np.ascontiguousarray(pixels_yx, dtype=np.float64).reshape(-1, 2)
+    pi = np.ascontiguousarray(pose_ids, dtype=np.int64)
+    li = np.ascontiguousarray(point_ids, dtype=np.int64)
+    P, O = len(tc), len(pi)
+    M = (len(theta) - 6 * P) // 3
+    outl = np.zeros(O, dtype=np.uint8)
+    st = np.zeros(8)
+    lib().orc_bundle_adjustment_flat(C.c_double(cam[0]), C.c_double(cam[1]), C.c_double(cam[2]), C.c_double(cam[3]),
+                                     P, M, O, _p(theta), _p(tc, u8p), _p(px), _p(pi, i64p), _p(li, i64p),
+                                     _p(outl, u8p), iters_fast, iterations, C.c_double(repr_eps), solver, _p(st))
+    stats = dict(ssr_init=st[0], ssr_pass1=st[1], ssr_final=st[2], iters_pass1=int(st[3]), iters_pass2=int(st[4]),
+                 n_outliers=int(st[5]), inner_iters=int(st[6]))
+    return theta, outl.astype(bool), stats
+
+
+class _BAProblem(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("P", C.c_int), ("M", C.c_int), ("O", C.c_int),
+                ("theta", f64p), ("theta_const", u8p), ("pixels_yx", f64p),
+                ("pose_ids", i64p), ("point_ids", i64p), ("outliers", u8p)]
+
+
+def ba_reduced_system(cam, theta, theta_const, pixels_yx, pose_ids, point_ids, outliers, ignore_outliers,
+                      inv_delta, m_begin, m_end):
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    tc = np.ascontiguousarray(theta_const, dtype=np.uint8)
+    px = np.ascontiguousarray(pixels_yx, dtype=np.float64).reshape(-1, 2)
+    pi = np.ascontiguousarray(pose_ids, dtype=np.int64)
+    li = np.ascontiguousarray(point_ids, dtype=np.int64)
+    ol = np.ascontiguousarray(outliers, dtype=np.uint8)
+    P, O = len(tc), len(pi)
+    M = (len(theta) - 6 * P) // 3
+    prob = _BAProblem(cam[0], cam[1], cam[2], cam[3], P, M, O, _p(theta), _p(tc, u8p), _p(px), _p(pi, i64p),
+                      _p(li, i64p), _p(ol, u8p))
+    n = 6 * P
+    S = np.zeros((n, n), order="F"); g2 = np.zeros(2 * n); ssr = C.c_double()
+    lib().orc_ba_reduced_system(C.byref(prob), _p(theta), int(ignore_outliers), C.c_double(inv_delta),
+                                m_begin, m_end, _p(S), _p(g2), C.byref(ssr))
+    return S, g2[:n], g2[n:], ssr.value
+
+
+def ba_residuals(cam, theta, theta_const, pixels_yx, pose_ids, point_ids):
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    tc = np.ascontiguousarray(theta_const, dtype=np.uint8)
+    px = np.ascontiguousarray(pixels_yx, dtype=np.float64).reshape(-1, 2)
+    pi = np.ascontiguousarray(pose_ids, dtype=np.int64)
+    li = np.ascontiguousarray(point_ids, dtype=np.int64)
+    P, O = len(tc), len(pi)
+    M = (len(theta) - 6 * P) // 3
+    ol = np.zeros(O, dtype=np.uint8)
+    prob = _BAProblem(cam[0], cam[1], cam[2], cam[3], P, M, O, _p(theta), _p(tc, u8p), _p(px), _p(pi, i64p),
+                      _p(li, i64p), _p(ol, u8p))
+    Y = np.zeros(2 * O)
+    lib().orc_ba_residuals(C.byref(prob), _p(theta), 0, _p(Y))
+    return Y
+
+
+def pnp_ba(cam, pose_cw, pixels_yx, points_xyz, iters_fast=5, iterations=10, depth_eps=1e-6, repr_eps=5.0):
+    pose = np.asfortranarray(pose_cw, dtype=np.float64)
+    px = np.ascontiguousarray(pixels_yx, dtype=np.float64).reshape(-1, 2)
+    pts = np.ascontiguousarray(points_xyz, dtype=np.float64).reshape(-1, 3)
+    n = len(px)
+    out = np.zeros((4, 4), order="F")
+    e0, e1, no = C.c_double(), C.c_double(), C.c_int()
+    outl = np.zeros(n, dtype=np.uint8)
+    lib().orc_pnp_ba(C.c_double(cam[0]), C.c_double(cam[1]), C.c_double(cam[2]), C.c_double(cam[3]), _p(pose),
+                     _p(px), _p(pts), n, iters_fast, iterations, C.c_double(depth_eps), C.c_double(repr_eps),
+                     _p(out), C.byref(e0), C.byref(e1), _p(outl, u8p), C.byref(no))
+    return np.array(out), e0.value, e1.value, outl.astype(bool), no.value
