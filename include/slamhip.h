@@ -1,0 +1,176 @@
+/*
+ * slamhip.h -- C ABI of libslamhip.so: the MI355X (gfx950) implementation of
+ * SLAM.jl's data-parallel hot path (extractor -> LK pyramid -> forward-backward
+ * Lucas-Kanade -> local bundle adjustment).
+ *
+ * The reference (pxl-th/SLAM.jl) is pure Julia and has no FFI: the boundary is a
+ * set of Julia function seams.  Each entry point below replaces one seam; the
+ * Julia-side `ccall` shim that rebinds the seams is slam.jl_amd/julia/SLAMHip.jl
+ * (see INTEGRATION.md).  Reference file:line cited per function are relative to
+ * the reference repository root.
+ *
+ * Conventions (identical to the reference so the shim is copy-free):
+ *   - Float64 everywhere; images are column-major H x W (Julia `Matrix`, y
+ *     fastest), values in [0,1];
+ *   - points are (y, x) Float64 pairs, 1-based pixel coordinates; keypoint
+ *     indices are (row, col) Int64 pairs, 1-based; ids are Int64, 1-based;
+ *   - the caller owns every host buffer; the library copies in/out before
+ *     returning and never retains host pointers.  Pointers named `*_dev` are
+ *     device (HBM) pointers owned by the caller;
+ *   - every call returns 0 on success, a negative slam_status on failure;
+ *     slam_last_error(ctx) gives the message.  No C++ exception crosses the ABI;
+ *   - one slam_ctx per calling task/thread (it owns a HIP stream and scratch);
+ *     calls on one ctx are synchronous unless the name ends in `_async`;
+ *     pyramid handles may be read by several contexts concurrently.
+ */
+#ifndef SLAMHIP_H
+#define SLAMHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct slam_ctx slam_ctx;
+typedef struct slam_pyr slam_pyr;   /* device-resident LKPyramid */
+typedef struct slam_ba  slam_ba;    /* device-resident sharded-BA state */
+
+enum slam_status {
+    SLAM_OK = 0,
+    SLAM_ERR_ARG = -1,          /* bad argument */
+    SLAM_ERR_HIP = -2,          /* HIP runtime error (message has hipGetErrorString) */
+    SLAM_ERR_LAYERS = -3,       /* "Not enough layers in pyramids." lucas_kanade.jl:15 */
+    SLAM_ERR_CAPACITY = -4,     /* output buffer too small */
+    SLAM_ERR_NUMERIC = -5       /* reduced camera system not positive definite */
+};
+
+/* ---- context --------------------------------------------------------------- */
+int  slam_ctx_create(int device, slam_ctx **out);
+int  slam_ctx_destroy(slam_ctx *ctx);
+int  slam_ctx_synchronize(slam_ctx *ctx);
+/* the ctx's hipStream_t (as void*), for callers that record HIP events on it */
+void *slam_ctx_stream(slam_ctx *ctx);
+/* message of the last failing call on ctx (ctx == NULL: last ctx-less failure) */
+const char *slam_last_error(slam_ctx *ctx);
+/* library version / build arch string, e.g. "slamhip 0.1 gfx950" */
+const char *slam_version(void);
+
+/* ---- Extractor -------------------------------------------------------------- */
+/* detect(e::Extractor, image, current_points; sigma_mask) -- src/extractor.jl:63-95
+ * (+ get_mask :116-122, _shi_tomasi :24-42).  Extractor fields (extractor.jl:7-20,
+ * built at SLAM.jl:149-160) are passed explicitly.  out_rc receives (row, col)
+ * pairs in the reference's order (cells row-major, column-major inside a cell);
+ * cap = capacity in keypoints; n_out may exceed max_points (as in the reference).
+ * Returns n_out = 0 when n_cur >= max_points (extractor.jl:64). */
+int slam_detect(slam_ctx *ctx, const double *image, int H, int W,
+                const double *cur_yx, int n_cur,
+                int max_points, int radius, int grid_rows, int grid_cols, int cell_size,
+                double sigma_mask, double min_response,
+                int64_t *out_rc, int cap, int *n_out);
+/* Same, on the image already resident as layer 1 of a device pyramid (the frame
+ * passed to create_keyframe! is the one the current pyramid was built from:
+ * front_end.jl:461-464, map_manager.jl:98-105).  No image upload. */
+int slam_detect_pyr(slam_ctx *ctx, const slam_pyr *pyr,
+                    const double *cur_yx, int n_cur,
+                    int max_points, int radius, int grid_rows, int grid_cols, int cell_size,
+                    double sigma_mask, double min_response,
+                    int64_t *out_rc, int cap, int *n_out);
+
+/* describe(e, image, keypoints) -> create_descriptor(img, kps, BRIEF) --
+ * src/extractor.jl:103-105.  pattern: n_bits x 4 int32 (dy1, dx1, dy2, dx2)
+ * sampling table supplied by the caller (ImageFeatures draws it from Julia's
+ * seeded RNG, which cannot be reproduced outside Julia).  n_bits % 64 == 0.
+ * out_bits: n x (n_bits/64) uint64; out_rc: surviving keypoints (border-dropped
+ * ones removed, order kept). */
+int slam_describe(slam_ctx *ctx, const double *image, int H, int W,
+                  const int64_t *rc, int n, const int32_t *pattern, int n_bits,
+                  double sigma, int window,
+                  uint64_t *out_bits, int64_t *out_rc, int *n_out);
+
+/* ---- LKPyramid -------------------------------------------------------------- */
+/* LKPyramid(image, levels; sigma, reusable=true) / update!(lk, img) / copy! /
+ * deepcopy -- src/optical_flow/pyramid.jl:16-137, lucas_kanade.jl:102-138.
+ * pyramid_levels = levels above the base (Params.pyramid_levels = 3 -> 4 layers). */
+int slam_pyr_create(slam_ctx *ctx, int H, int W, int pyramid_levels, slam_pyr **out);
+int slam_pyr_destroy(slam_pyr *pyr);
+/* mode 0: constructor semantics (pyramid.jl:40-79: NA() blur, Fill(0) Scharr);
+ * mode 1: update! semantics (pyramid.jl:81-137: replicate borders). */
+int slam_pyr_update(slam_ctx *ctx, slam_pyr *pyr, const double *image, int mode, double sigma);
+/* image already in HBM (column-major f64); returns after enqueueing when sync == 0 */
+int slam_pyr_update_dev(slam_ctx *ctx, slam_pyr *pyr, const double *image_dev, int mode, double sigma, int sync);
+/* copy!(dst, src) pyramid.jl:28-38 (same shape required) */
+int slam_pyr_copy(slam_ctx *ctx, slam_pyr *dst, const slam_pyr *src);
+/* deepcopy(lk) SLAM.jl:218 */
+int slam_pyr_clone(slam_ctx *ctx, const slam_pyr *src, slam_pyr **out);
+/* introspection for parity tests: plane 0..5 = layers, Iy, Ix, Iyy, Ixx, Iyx;
+ * level 0-based.  out must hold H_l * W_l doubles. */
+int slam_pyr_shape(const slam_pyr *pyr, int level, int *H, int *W);
+int slam_pyr_levels(const slam_pyr *pyr);
+int slam_pyr_download(slam_ctx *ctx, const slam_pyr *pyr, int plane, int level, double *out);
+
+/* ---- forward-backward Lucas-Kanade ----------------------------------------- */
+/* fb_tracking!(prev, cur, keypoints; displacement, iterations, window_size,
+ * pyramid_levels, max_distance) -- src/tracker.jl:17-82 over optflow!
+ * src/optical_flow/lucas_kanade.jl:9-100.  disp0_yx may be NULL (zeros);
+ * it is given in coarsest-level pixels like the reference's `displacement`.
+ * out_yx[i] is defined only where status[i] != 0.  n == 0 is a no-op. */
+int slam_fb_track(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr *cur,
+                  const double *pts_yx, const double *disp0_yx, int n,
+                  int pyramid_levels, int window, int iterations,
+                  double eig_thr, double eps, double max_distance,
+                  double *out_yx, uint8_t *status);
+
+/* ---- bundle adjustment ------------------------------------------------------ */
+/* bundle_adjustment!(cache::LocalBACache, camera; iterations, repr_eps) --
+ * src/bundle_adjustment.jl:1-111 on the flat arrays of src/estimator.jl:16-40:
+ * theta = [6P (RotZYX t1,t2,t3, tx,ty,tz) ; 3M], pixels (y,x) 2 x O, 1-based ids.
+ * Two passes: iters_fast LM iterations on all observations, outlier flagging
+ * (depth < 1e-6 or squared pixel error > repr_eps), then `iterations` LM
+ * iterations with outliers zeroed.  The LM outer loop is LeastSquaresOptim's;
+ * the step is the exact one from the Schur-complement reduced camera system.
+ * stats (may be NULL, 8 doubles): ssr_init, ssr_pass1, ssr_final, iters_pass1,
+ * iters_pass2, n_outliers, device_ms, 0. */
+int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy,
+                  int P, int M, int O,
+                  double *theta, const uint8_t *theta_const, const double *pixels_yx,
+                  const int64_t *pose_ids, const int64_t *point_ids, uint8_t *outliers,
+                  int iters_fast, int iterations, double repr_eps, double *stats);
+
+/* pnp_bundle_adjustment(camera, pose, pixels, points; iterations, depth_eps,
+ * repr_eps) -- src/bundle_adjustment.jl:113-171.  pose_cw/out_pose: 4x4
+ * column-major.  out_pose = identity when fewer than 5 inliers remain (:157-161). */
+int slam_pnp_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy,
+                const double pose_cw[16], const double *pixels_yx, const double *points_xyz, int n,
+                int iters_fast, int iterations, double depth_eps, double repr_eps,
+                double out_pose[16], double *err_init, double *err_final,
+                uint8_t *outliers, int *n_outliers);
+
+/* Point-sharded BA for multi-GPU windows: each rank owns the
+ * observations of a subset of map points; per LM iteration it produces its
+ * contribution [S (6P x 6P col-major) ; rhs (6P) ; diag(Jp'Jp) (6P) ; ssr ; pad]
+ * into a caller-provided DEVICE buffer of slam_ba_reduce_len(P) doubles, which
+ * the host all-reduces (RCCL via torch.distributed) before slam_ba_solve.
+ * theta holds ALL poses (replicated) and this shard's points. */
+int    slam_ba_create(slam_ctx *ctx, double fx, double fy, double cx, double cy,
+                      int P, int M_local, int O_local,
+                      const double *theta, const uint8_t *theta_const, const double *pixels_yx,
+                      const int64_t *pose_ids, const int64_t *point_ids_local, slam_ba **out);
+int    slam_ba_destroy(slam_ba *ba);
+int64_t slam_ba_reduce_len(int P);
+/* linearise at the current theta and write the local contribution */
+int    slam_ba_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, double inv_delta, double *reduce_dev);
+/* solve the (all-reduced) system, back-substitute local points, evaluate the
+ * trial step: writes [trial_ssr_local, predicted_ssr_local, max|dx| local, 0]
+ * to trial_dev (4 doubles, device) */
+int    slam_ba_solve(slam_ctx *ctx, slam_ba *ba, const double *reduce_dev, double inv_delta, double *trial_dev);
+/* accept (1) or reject (0) the trial step */
+int    slam_ba_commit(slam_ctx *ctx, slam_ba *ba, int accept);
+/* flag outliers at the current theta; returns local count through n_out */
+int    slam_ba_flag_outliers(slam_ctx *ctx, slam_ba *ba, double repr_eps, double depth_eps, int *n_out);
+/* read back theta (6P + 3 M_local) and the outlier flags (O_local) */
+int    slam_ba_download(slam_ctx *ctx, slam_ba *ba, double *theta, uint8_t *outliers);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,14 @@
+"""slam_jl_amd -- MI355X-native hot path of pxl-th/SLAM.jl behind SLAM.jl's own
+function seams (extractor -> LK pyramid -> forward-backward LK -> local BA).
+
+Host-side mirror of the reference interface over the C ABI of libslamhip.so
+(include/slamhip.h).  Julia's `name!` functions are spelled `name_` here.
+The Julia `ccall` shim with the same surface is julia/SLAMHip.jl.
+
+There is no CPU fallback: every function here runs hand-written HIP kernels
+and raises if the library / a HIP device is unavailable."""
+from ._lib import Context, SlamHipError, default_context, load, LIB_PATH  # noqa: F401
+from .params import Camera, Params  # noqa: F401
+from .extractor import Extractor, detect, describe, brief_pattern  # noqa: F401
+from .optical_flow import LKPyramid, LucasKanade, update_, copy_, deepcopy, has_gradients, fb_tracking_, optical_flow_matching  # noqa: F401
+from .bundle_adjustment import LocalBACache, bundle_adjustment_, pnp_bundle_adjustment  # noqa: F401

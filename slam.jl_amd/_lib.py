@@ -1,0 +1,120 @@
+"""ctypes binding of libslamhip.so (the C ABI declared in include/slamhip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or no
+HIP device is usable, loading / context creation raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslamhip.so")
+
+f64p = C.POINTER(C.c_double)
+u8p = C.POINTER(C.c_uint8)
+i64p = C.POINTER(C.c_int64)
+i32p = C.POINTER(C.c_int32)
+u64p = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+dbl, cint = C.c_double, C.c_int
+
+# name -> (restype, argtypes); kept in sync with include/slamhip.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    "slam_ctx_create": (cint, [cint, C.POINTER(vp)]),
+    "slam_ctx_destroy": (cint, [vp]),
+    "slam_ctx_synchronize": (cint, [vp]),
+    "slam_ctx_stream": (vp, [vp]),
+    "slam_last_error": (C.c_char_p, [vp]),
+    "slam_version": (C.c_char_p, []),
+    "slam_detect": (cint, [vp, f64p, cint, cint, f64p, cint, cint, cint, cint, cint, cint, dbl, dbl, i64p, cint, C.POINTER(cint)]),
+    "slam_detect_pyr": (cint, [vp, vp, f64p, cint, cint, cint, cint, cint, cint, dbl, dbl, i64p, cint, C.POINTER(cint)]),
+    "slam_describe": (cint, [vp, f64p, cint, cint, i64p, cint, i32p, cint, dbl, cint, u64p, i64p, C.POINTER(cint)]),
+    "slam_pyr_create": (cint, [vp, cint, cint, cint, C.POINTER(vp)]),
+    "slam_pyr_destroy": (cint, [vp]),
+    "slam_pyr_update": (cint, [vp, vp, f64p, cint, dbl]),
+    "slam_pyr_update_dev": (cint, [vp, vp, vp, cint, dbl, cint]),
+    "slam_pyr_copy": (cint, [vp, vp, vp]),
+    "slam_pyr_clone": (cint, [vp, vp, C.POINTER(vp)]),
+    "slam_pyr_shape": (cint, [vp, cint, C.POINTER(cint), C.POINTER(cint)]),
+    "slam_pyr_levels": (cint, [vp]),
+    "slam_pyr_download": (cint, [vp, vp, cint, cint, f64p]),
+    "slam_fb_track": (cint, [vp, vp, vp, f64p, f64p, cint, cint, cint, cint, dbl, dbl, dbl, f64p, u8p]),
+    "slam_local_ba": (cint, [vp, dbl, dbl, dbl, dbl, cint, cint, cint, f64p, u8p, f64p, i64p, i64p, u8p, cint, cint, dbl, f64p]),
+    "slam_pnp_ba": (cint, [vp, dbl, dbl, dbl, dbl, f64p, f64p, f64p, cint, cint, cint, dbl, dbl, f64p, f64p, f64p, u8p, C.POINTER(cint)]),
+    "slam_ba_create": (cint, [vp, dbl, dbl, dbl, dbl, cint, cint, cint, f64p, u8p, f64p, i64p, i64p, C.POINTER(vp)]),
+    "slam_ba_destroy": (cint, [vp]),
+    "slam_ba_reduce_len": (C.c_int64, [cint]),
+    "slam_ba_build": (cint, [vp, vp, cint, dbl, vp]),
+    "slam_ba_solve": (cint, [vp, vp, vp, dbl, vp]),
+    "slam_ba_commit": (cint, [vp, vp, cint]),
+    "slam_ba_flag_outliers": (cint, [vp, vp, dbl, dbl, C.POINTER(cint)]),
+    "slam_ba_download": (cint, [vp, vp, f64p, u8p]),
+}
+
+_lib = None
+
+
+class SlamHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libslamhip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SlamHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C slam.jl_amd/csrc`. There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def ptr(a, t=f64p):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+class Context:
+    """One per calling task (SURVEY 8b threading): owns a HIP stream + scratch."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = vp()
+        rc = self.lib.slam_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise SlamHipError(f"slam_ctx_create failed ({rc}): {self.lib.slam_last_error(None).decode()}")
+        self.h = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != 0:
+            raise SlamHipError(f"libslamhip error {rc}: {self.lib.slam_last_error(self.h).decode()}")
+
+    @property
+    def stream(self):
+        return self.lib.slam_ctx_stream(self.h)
+
+    def synchronize(self):
+        self.check(self.lib.slam_ctx_synchronize(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.slam_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

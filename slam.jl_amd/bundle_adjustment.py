@@ -1,0 +1,69 @@
+"""LocalBACache / bundle_adjustment! / pnp_bundle_adjustment mirrors (reference:
+src/estimator.jl:16-40, src/bundle_adjustment.jl)."""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib as L
+
+
+@dataclass
+class LocalBACache:
+    """The array part of LocalBACache (estimator.jl:16-40).  θ = [6P ; 3M],
+    pixels (O, 2) as (y, x), ids 1-based."""
+    theta: np.ndarray
+    theta_const: np.ndarray
+    pixels: np.ndarray
+    poses_ids: np.ndarray
+    points_ids: np.ndarray
+    outliers: np.ndarray = None
+    stats: dict = field(default_factory=dict)
+
+    @property
+    def n_poses(self):
+        return len(self.theta_const)
+
+    @property
+    def n_points(self):
+        return (len(self.theta) - 6 * self.n_poses) // 3
+
+
+def bundle_adjustment_(cache, camera, iterations=10, repr_eps=5.0, iters_fast=5, ctx=None):
+    """bundle_adjustment!(cache, camera; iterations, repr_ϵ) -- mutates cache.theta / cache.outliers."""
+    ctx = ctx or L.default_context()
+    fx, fy, cx, cy = camera.intrinsics if hasattr(camera, "intrinsics") else camera
+    theta = np.ascontiguousarray(cache.theta, dtype=np.float64)
+    tc = np.ascontiguousarray(cache.theta_const, dtype=np.uint8)
+    px = np.ascontiguousarray(cache.pixels, dtype=np.float64).reshape(-1, 2)
+    pi = np.ascontiguousarray(cache.poses_ids, dtype=np.int64)
+    li = np.ascontiguousarray(cache.points_ids, dtype=np.int64)
+    P, O = len(tc), len(pi)
+    M = (len(theta) - 6 * P) // 3
+    outl = np.zeros(max(O, 1), dtype=np.uint8)
+    st = np.zeros(8)
+    ctx.check(ctx.lib.slam_local_ba(ctx.h, fx, fy, cx, cy, P, M, O, L.ptr(theta), L.ptr(tc, L.u8p), L.ptr(px),
+                                    L.ptr(pi, L.i64p), L.ptr(li, L.i64p), L.ptr(outl, L.u8p),
+                                    int(iters_fast), int(iterations), float(repr_eps), L.ptr(st)))
+    cache.theta = theta
+    cache.outliers = outl[:O].astype(bool)
+    cache.stats = dict(ssr_init=st[0], ssr_pass1=st[1], ssr_final=st[2], iters_pass1=int(st[3]), iters_pass2=int(st[4]),
+                       n_outliers=int(st[5]), device_ms=st[6])
+    return cache
+
+
+def pnp_bundle_adjustment(camera, pose, pixels, points, iterations=10, depth_eps=1e-6, repr_eps=5.0, iters_fast=5, ctx=None):
+    """-> (new_pose 4x4, initial_error, final_error, outliers, n_outliers) -- bundle_adjustment.jl:113-171"""
+    ctx = ctx or L.default_context()
+    fx, fy, cx, cy = camera.intrinsics if hasattr(camera, "intrinsics") else camera
+    pose = np.asfortranarray(pose, dtype=np.float64)
+    px = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    n = len(px)
+    out = np.zeros((4, 4), order="F")
+    e0, e1, no = C.c_double(), C.c_double(), C.c_int()
+    outl = np.zeros(max(n, 1), dtype=np.uint8)
+    ctx.check(ctx.lib.slam_pnp_ba(ctx.h, fx, fy, cx, cy, L.ptr(pose), L.ptr(px), L.ptr(pts), n, int(iters_fast), int(iterations),
+                                  float(depth_eps), float(repr_eps), L.ptr(out), C.byref(e0), C.byref(e1),
+                                  L.ptr(outl, L.u8p), C.byref(no)))
+    return np.array(out), e0.value, e1.value, outl[:n].astype(bool), no.value

@@ -1,0 +1,80 @@
+// common.hpp -- shared host-side plumbing for libslamhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/slamhip.h"
+
+#define SLAM_MAX_LEVELS 8
+
+struct slam_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // grow-only device scratch and pinned host staging
+    void *scratch = nullptr; size_t scratch_bytes = 0;
+    void *scratch2 = nullptr; size_t scratch2_bytes = 0;
+    void *pinned = nullptr; size_t pinned_bytes = 0;
+};
+
+// Device-side view of one pyramid level (all planes column-major H x W).
+struct LevelView {
+    double *L, *Iy, *Ix, *Iyy, *Ixx, *Iyx;
+    int H, W;
+};
+struct PyrView {
+    LevelView lv[SLAM_MAX_LEVELS];
+    int levels;
+};
+
+struct StageJob;   // pyramid.hip
+
+struct slam_pyr {
+    int device = 0;
+    int levels = 0;                       // total layers = pyramid_levels + 1
+    int H[SLAM_MAX_LEVELS], W[SLAM_MAX_LEVELS];
+    int64_t off[SLAM_MAX_LEVELS + 1];     // plane offsets in doubles
+    double *planes = nullptr;             // 6 planes x off[levels] doubles, one allocation
+    double *tmp = nullptr;                // blur scratch, off[levels] doubles
+    double *norm = nullptr;               // NA() normaliser per level (ctor mode), lazily built
+    double norm_sigma = -1.0;
+    void *jobs = nullptr;                 // device job table (StageJob[])
+    std::vector<int> stage_begin;         // per launch: first job, job count
+    std::vector<int> stage_count;
+    PyrView view;
+    double *plane(int p, int l) const { return planes + (int64_t)p * off[levels] + off[l]; }
+};
+
+extern thread_local std::string g_slam_err;
+
+int slam_fail(slam_ctx *ctx, int code, const char *fmt, ...);
+int slam_scratch(slam_ctx *ctx, size_t bytes, void **out);
+int slam_scratch2(slam_ctx *ctx, size_t bytes, void **out);
+int slam_pinned(slam_ctx *ctx, size_t bytes, void **out);
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return slam_fail((ctx), SLAM_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define ARG_TRY(ctx, cond)                                                                  \
+    do {                                                                                    \
+        if (!(cond)) return slam_fail((ctx), SLAM_ERR_ARG, "argument check failed: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+    } while (0)
+
+// KernelFactors.IIRGaussian coefficients (host side; passed to kernels by value)
+struct IIRCoef {
+    double a1, a2, a3, scale, M[9], inv1masum /* 1-asum */, inv1mbsum /* 1-bsum */;
+};
+IIRCoef slam_iir_coef(double sigma);
+int slam_gaussian_taps(double sigma, double *w);   // Kernel.gaussian 1-D factor
+
+// per-module entry points used across files
+int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, const double *cur_yx, int n_cur,
+                       int max_points, int radius, int grid_rows, int grid_cols, int cell_size,
+                       double sigma_mask, double min_response, int64_t *out_rc, int cap, int *n_out);

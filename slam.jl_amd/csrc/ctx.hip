@@ -1,0 +1,118 @@
+// ctx.hip -- context, scratch management, error reporting, filter coefficients.
+#include "common.hpp"
+#include <cmath>
+#include <cstdarg>
+
+thread_local std::string g_slam_err;
+
+int slam_fail(slam_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (ctx) ctx->err = buf; else g_slam_err = buf;
+    return code;
+}
+
+static int grow(slam_ctx *ctx, void **p, size_t *have, size_t want, bool pinned)
+{
+    if (*have >= want) return SLAM_OK;
+    if (*p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); if (pinned) (void)hipHostFree(*p); else (void)hipFree(*p); *p = nullptr; *have = 0; }
+    size_t sz = want + want / 4 + 4096;
+    if (pinned) HIP_TRY(ctx, hipHostMalloc(p, sz, hipHostMallocDefault));
+    else HIP_TRY(ctx, hipMalloc(p, sz));
+    *have = sz;
+    return SLAM_OK;
+}
+int slam_scratch(slam_ctx *ctx, size_t bytes, void **out) { int rc = grow(ctx, &ctx->scratch, &ctx->scratch_bytes, bytes, false); *out = ctx->scratch; return rc; }
+int slam_scratch2(slam_ctx *ctx, size_t bytes, void **out) { int rc = grow(ctx, &ctx->scratch2, &ctx->scratch2_bytes, bytes, false); *out = ctx->scratch2; return rc; }
+int slam_pinned(slam_ctx *ctx, size_t bytes, void **out) { int rc = grow(ctx, &ctx->pinned, &ctx->pinned_bytes, bytes, true); *out = ctx->pinned; return rc; }
+
+extern "C" {
+
+int slam_ctx_create(int device, slam_ctx **out)
+{
+    if (!out) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_ctx_create: out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_ctx_create: device %d out of range [0,%d)", device, n);
+    slam_ctx *c = new slam_ctx();
+    c->device = device;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create: %s", hipGetErrorString(e)); }
+    *out = c;
+    return SLAM_OK;
+}
+
+int slam_ctx_destroy(slam_ctx *ctx)
+{
+    if (!ctx) return SLAM_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SLAM_OK;
+}
+
+int slam_ctx_synchronize(slam_ctx *ctx)
+{
+    ARG_TRY(ctx, ctx != nullptr);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+void *slam_ctx_stream(slam_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+const char *slam_last_error(slam_ctx *ctx) { return ctx ? ctx->err.c_str() : g_slam_err.c_str(); }
+
+const char *slam_version(void) { return "slamhip 0.1 gfx950"; }
+
+} // extern "C"
+
+// KernelFactors.IIRGaussian(sigma) -> TriggsSdika coefficients.  Host-side, same
+// expression order as ImageFiltering's constructor so the constants are the
+// ones Julia would compute.
+IIRCoef slam_iir_coef(double sigma)
+{
+    const double m0 = 1.16680, m1 = 1.10783, m2 = 1.40586;
+    double q = 1.31564 * (std::sqrt(1 + 0.490811 * sigma * sigma) - 1);
+    double ascale = (m0 + q) * (m1 * m1 + m2 * m2 + 2 * m1 * q + q * q);
+    double B = (m0 * (m1 * m1 + m2 * m2) / ascale);
+    B = B * B;
+    double a1 = q * (2 * m0 * m1 + m1 * m1 + m2 * m2 + (2 * m0 + 4 * m1) * q + 3 * q * q) / ascale;
+    double a2 = -q * q * (m0 + 2 * m1 + 3 * q) / ascale;
+    double a3 = q * q * q / ascale;
+    IIRCoef k;
+    k.a1 = a1; k.a2 = a2; k.a3 = a3; k.scale = B;
+    double Md = (1 + a1 - a2 + a3) * (1 - a1 - a2 - a3) * (1 + a2 + (a1 - a3) * a3);
+    double M[9] = {
+        -a3 * a1 + 1 - a3 * a3 - a2, (a3 + a1) * (a2 + a3 * a1), a3 * (a1 + a3 * a2),
+        a1 + a3 * a2, -(a2 - 1) * (a2 + a3 * a1), -(a3 * a1 + a3 * a3 + a2 - 1) * a3,
+        a3 * a1 + a2 + a1 * a1 - a2 * a2,
+        a1 * a2 + a3 * a2 * a2 - a1 * a3 * a3 - a3 * a3 * a3 - a3 * a2 + a3,
+        a3 * (a1 + a3 * a2)};
+    for (int i = 0; i < 9; i++) k.M[i] = M[i] / Md;
+    double asum = (a1 + a2) + a3;
+    k.inv1masum = 1 - asum;
+    k.inv1mbsum = 1 - asum;
+    return k;
+}
+
+int slam_gaussian_taps(double sigma, double *w)
+{
+    int l = 4 * (int)std::ceil(sigma) + 1;
+    int hw = l >> 1;
+    double s = 0.0;
+    for (int i = 0; i < l; i++) {
+        double x = (double)(i - hw);
+        w[i] = std::exp(-(x * x) / (2.0 * (sigma * sigma)));
+        s += w[i];
+    }
+    for (int i = 0; i < l; i++) w[i] = w[i] / s;
+    return l;
+}

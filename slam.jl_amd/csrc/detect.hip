@@ -1,0 +1,355 @@
+// detect.hip -- grid-cell Shi-Tomasi keypoint extraction on gfx950.
+//
+// Replaces detect / get_mask / _shi_tomasi of the reference
+// (src/extractor.jl:24-42, 63-95, 116-122).  One workgroup per grid cell: the
+// cell's pixels, the avoidance-mask halo and every intermediate plane live in
+// LDS; HBM traffic is one read of the image plus the keypoint lists, i.e. the
+// algorithmic minimum (8*H*W + 16*(K + n_out) bytes).  Keypoint order and
+// indices are bit-exact with the CPU oracle: every sum runs in the reference's
+// order and the build uses -ffp-contract=off.
+#include "common.hpp"
+#include <cmath>
+
+#define DET_THREADS 256
+#define DET_MAXCAND 512
+#define DET_MAXTAPS 41
+
+struct DetectArgs {
+    const double *img; int H, W;
+    const double *cur; int n_cur;      // device (y,x) pairs
+    int radius, grid_rows, grid_cols, cs, k;
+    double min_response;
+    int ntaps;                         // 0: no blur of the mask
+    double taps[DET_MAXTAPS];
+    int64_t *cell_out;                 // n_cells * k * 2
+    int *cell_cnt;                     // n_cells
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// 3-tap correlation along y (dir 0) or x (dir 1) with replicate border at the
+// cell edge: acc = 0; acc += v[j]*k[j], j ascending (ImageFiltering order).
+__device__ __forceinline__ void fir3(double *dst, const double *src, int h, int w, int dir,
+                                     double k0, double k1, double k2)
+{
+    for (int i = threadIdx.x; i < h * w; i += DET_THREADS) {
+        int y = i % h, x = i / h;
+        double a, b, c;
+        if (dir == 0) {
+            a = src[clampi(y - 1, 0, h - 1) + x * h]; b = src[i]; c = src[clampi(y + 1, 0, h - 1) + x * h];
+        } else {
+            a = src[y + clampi(x - 1, 0, w - 1) * h]; b = src[i]; c = src[y + clampi(x + 1, 0, w - 1) * h];
+        }
+        double acc = 0.0;
+        acc += a * k0; acc += b * k1; acc += c * k2;
+        dst[i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
+{
+    extern __shared__ double lds[];
+    const int cs = A.cs, H = A.H, W = A.W;
+    const int cell = blockIdx.x;
+    const int cyi = cell / A.grid_cols, cxi = cell % A.grid_cols;
+    const int y0 = cyi * cs, x0 = cxi * cs;
+    const int h = min(H, (cyi + 1) * cs) - y0, w = min(W, (cxi + 1) * cs) - x0;
+    const int tid = threadIdx.x;
+    const int n = cs * cs;
+    double *bA = lds, *bB = lds + n, *bC = lds + 2 * n, *bD = lds + 3 * n, *bE = lds + 4 * n, *bF = lds + 5 * n;
+    __shared__ int s_ncand, s_cnt;
+    __shared__ int s_cand[2 * DET_MAXCAND];
+    __shared__ double s_rv[DET_THREADS / 64];
+    __shared__ int s_ri[DET_THREADS / 64];
+    __shared__ int s_best;
+
+    if (h <= 0 || w <= 0) { if (tid == 0) A.cell_cnt[cell] = 0; return; }
+
+    // ---- image tile -> bA ---------------------------------------------------
+    for (int i = tid; i < h * w; i += DET_THREADS) {
+        int y = i % h, x = i / h;
+        bA[i] = A.img[(size_t)(y0 + y) + (size_t)(x0 + x) * H];
+    }
+
+    // ---- avoidance mask (get_mask + imfilter(mask, Kernel.gaussian) + .*) ---
+    if (A.n_cur > 0) {
+        const int hw = A.ntaps >> 1;
+        const int mh = h + 2 * hw, mw = w + 2 * hw;
+        const int r = A.radius;
+        if (tid == 0) s_ncand = 0;
+        __syncthreads();
+        // candidate keypoints: disk (+halo) touches the clamped tile region
+        const int ylo = clampi(y0 - hw, 0, H - 1) + 1, yhi = clampi(y0 + h - 1 + hw, 0, H - 1) + 1; // 1-based
+        const int xlo = clampi(x0 - hw, 0, W - 1) + 1, xhi = clampi(x0 + w - 1 + hw, 0, W - 1) + 1;
+        for (int k = tid; k < A.n_cur; k += DET_THREADS) {
+            long py = (long)rint(A.cur[2 * k]), px = (long)rint(A.cur[2 * k + 1]);
+            if (py + r >= ylo && py - r <= yhi && px + r >= xlo && px - r <= xhi) {
+                int slot = atomicAdd(&s_ncand, 1);
+                if (slot < DET_MAXCAND) { s_cand[2 * slot] = (int)py; s_cand[2 * slot + 1] = (int)px; }
+            }
+        }
+        __syncthreads();
+        const int ncand = s_ncand;
+        const bool overflow = ncand > DET_MAXCAND;
+        // raw mask over the halo'd tile (replicate = clamped coordinates) -> bB (as 0/1 doubles)
+        // bB has room for cs*cs doubles only; the halo'd mask is stored as bytes in bF..: use bytes
+        unsigned char *m0 = (unsigned char *)bF;           // (cs+2hw)^2 bytes <= cs*cs*8 for cs >= 8... checked on host
+        for (int i = tid; i < mh * mw; i += DET_THREADS) {
+            int ty = i % mh, tx = i / mh;
+            int yy = clampi(y0 + ty - hw, 0, H - 1) + 1, xx = clampi(x0 + tx - hw, 0, W - 1) + 1; // 1-based
+            unsigned char m = 1;
+            if (!overflow) {
+                for (int c = 0; c < ncand; c++) {
+                    int dy = yy - s_cand[2 * c], dx = xx - s_cand[2 * c + 1];
+                    if (dy < -r || dy > r || dx < -r || dx > r) continue;
+                    double a = (double)dy / (double)r, b = (double)dx / (double)r;
+                    if (a * a + b * b < 1) { m = 0; break; }
+                }
+            } else {
+                for (int c = 0; c < A.n_cur; c++) {
+                    long py = (long)rint(A.cur[2 * c]), px = (long)rint(A.cur[2 * c + 1]);
+                    long dy = yy - py, dx = xx - px;
+                    if (dy < -r || dy > r || dx < -r || dx > r) continue;
+                    double a = (double)dy / (double)r, b = (double)dx / (double)r;
+                    if (a * a + b * b < 1) { m = 0; break; }
+                }
+            }
+            m0[i] = m;
+        }
+        __syncthreads();
+        if (A.ntaps > 0) {
+            // dim-1 pass: T(y, tx) = sum_j m0(y+j, tx)*k[j]  -> bB..bE region (h x mw doubles)
+            double *T = bB;                                   // needs h*mw doubles <= 4*cs*cs (checked on host)
+            for (int i = tid; i < h * mw; i += DET_THREADS) {
+                int y = i % h, tx = i / h;
+                double acc = 0.0;
+                for (int j = 0; j < A.ntaps; j++) acc += (double)m0[(y + j) + tx * mh] * A.taps[j];
+                T[i] = acc;
+            }
+            __syncthreads();
+            // dim-2 pass and image .* mask
+            for (int i = tid; i < h * w; i += DET_THREADS) {
+                int y = i % h, x = i / h;
+                double acc = 0.0;
+                for (int j = 0; j < A.ntaps; j++) acc += T[y + (x + j) * h] * A.taps[j];
+                bA[i] = bA[i] * acc;
+            }
+        } else {
+            for (int i = tid; i < h * w; i += DET_THREADS) {
+                int y = i % h, x = i / h;
+                bA[i] = bA[i] * (double)m0[(y + hw) + (x + hw) * mh];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- Images.shi_tomasi on the cell view (replicate border at cell edges) -
+    fir3(bB, bA, h, w, 0, -1.0 / 2, 0.0 / 2, 1.0 / 2);      // d/dy
+    fir3(bC, bA, h, w, 0, 1.0 / 4, 2.0 / 4, 1.0 / 4);       // smooth y
+    __syncthreads();
+    fir3(bD, bB, h, w, 1, 1.0 / 4, 2.0 / 4, 1.0 / 4);       // g1 = gradient along dim 1
+    fir3(bE, bC, h, w, 1, -1.0 / 2, 0.0 / 2, 1.0 / 2);      // g2 = gradient along dim 2
+    __syncthreads();
+    for (int i = tid; i < h * w; i += DET_THREADS) {
+        double g1 = bD[i], g2 = bE[i];
+        bA[i] = g1 * g1; bB[i] = g1 * g2; bC[i] = g2 * g2;
+    }
+    __syncthreads();
+    fir3(bD, bA, h, w, 0, 1.0 / 3, 1.0 / 3, 1.0 / 3);
+    fir3(bE, bB, h, w, 0, 1.0 / 3, 1.0 / 3, 1.0 / 3);
+    fir3(bF, bC, h, w, 0, 1.0 / 3, 1.0 / 3, 1.0 / 3);
+    __syncthreads();
+    fir3(bA, bD, h, w, 1, 1.0 / 3, 1.0 / 3, 1.0 / 3);
+    fir3(bB, bE, h, w, 1, 1.0 / 3, 1.0 / 3, 1.0 / 3);
+    fir3(bC, bF, h, w, 1, 1.0 / 3, 1.0 / 3, 1.0 / 3);
+    __syncthreads();
+    double *resp = bD;
+    for (int i = tid; i < h * w; i += DET_THREADS) {
+        double xx = bA[i], xy = bB[i], yy = bC[i];
+        double dd = xx - yy;
+        resp[i] = ((xx + yy) - sqrt(dd * dd + 4 * (xy * xy))) / 2;
+    }
+    __syncthreads();
+
+    // ---- findlocalmaxima: strict, 8-neighbourhood, edges included ------------
+    unsigned char *flag = (unsigned char *)bE;                // 0: no, 1: maximum (candidate), 2: taken
+    for (int i = tid; i < h * w; i += DET_THREADS) {
+        int y = i % h, x = i / h;
+        double c = resp[i];
+        bool ismax = true;
+        for (int dx = -1; dx <= 1 && ismax; dx++)
+            for (int dy = -1; dy <= 1; dy++) {
+                if (!dx && !dy) continue;
+                int yy = y + dy, xx = x + dx;
+                if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+                if (!(resp[yy + xx * h] < c)) { ismax = false; break; }
+            }
+        flag[i] = ismax ? 1 : 0;
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+
+    // ---- top-k by response (stable: ties keep column-major order) ------------
+    int *sel = (int *)bF;                                     // selected linear indices
+    for (int round = 0; round < A.k; round++) {
+        double bv = -INFINITY; int bi = 0x7fffffff;
+        for (int i = tid; i < h * w; i += DET_THREADS)
+            if (flag[i] == 1) {
+                double v = resp[i];
+                if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+            }
+        for (int off = 32; off >= 1; off >>= 1) {
+            double ov = __shfl_down(bv, off); int oi = __shfl_down(bi, off);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+        }
+        if ((tid & 63) == 0) { s_rv[tid >> 6] = bv; s_ri[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double v = s_rv[0]; int ix = s_ri[0];
+            for (int wv = 1; wv < DET_THREADS / 64; wv++) {
+                double ov = s_rv[wv]; int oi = s_ri[wv];
+                if (oi != 0x7fffffff && (ix == 0x7fffffff || ov > v || (ov == v && oi < ix))) { v = ov; ix = oi; }
+            }
+            s_best = ix;
+            if (ix != 0x7fffffff) {
+                flag[ix] = 2;
+                if (!(resp[ix] < A.min_response)) sel[s_cnt++] = ix;   // `responses[mx] < min_response && continue`
+            }
+        }
+        __syncthreads();
+        if (s_best == 0x7fffffff) break;
+    }
+
+    // ---- emit in column-major order (Keypoints(::Matrix{Bool}) = findall) ----
+    if (tid == 0) {
+        int cnt = s_cnt;
+        for (int i = 1; i < cnt; i++) { int v = sel[i], j = i - 1; while (j >= 0 && sel[j] > v) { sel[j + 1] = sel[j]; j--; } sel[j + 1] = v; }
+        int64_t *o = A.cell_out + (size_t)cell * A.k * 2;
+        for (int i = 0; i < cnt; i++) {
+            int y = sel[i] % h, x = sel[i] / h;
+            o[2 * i] = y + 1 + y0; o[2 * i + 1] = x + 1 + x0;
+        }
+        A.cell_cnt[cell] = cnt;
+    }
+}
+
+// Ordered compaction of the per-cell lists (cells row-major: extractor.jl:81):
+// wave-level inclusive scans (shuffle) + one LDS hop across the 16 waves.
+__global__ __launch_bounds__(1024) void detect_compact(const int64_t *cell_out, const int *cell_cnt, int n_cells, int k,
+                                                        int64_t *out /* [0] = n_out, then pairs */, int cap)
+{
+    __shared__ int s_w[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n_cells; c0 += 1024) {
+        int c = c0 + tid;
+        int cnt = c < n_cells ? cell_cnt[c] : 0;
+        int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        int wbase = 0;
+        for (int i = 0; i < wv; i++) wbase += s_w[i];
+        int total = 0;
+        for (int i = 0; i < 16; i++) total += s_w[i];
+        int start = s_base + wbase + incl - cnt;
+        for (int i = 0; i < cnt; i++)
+            if (start + i < cap) {
+                out[1 + 2 * (start + i)] = cell_out[((size_t)c * k + i) * 2];
+                out[2 + 2 * (start + i)] = cell_out[((size_t)c * k + i) * 2 + 1];
+            }
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = s_base;
+}
+
+int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, const double *cur_yx, int n_cur,
+                       int max_points, int radius, int grid_rows, int grid_cols, int cell_size,
+                       double sigma_mask, double min_response, int64_t *out_rc, int cap, int *n_out)
+{
+    ARG_TRY(ctx, H > 0 && W > 0 && grid_rows > 0 && grid_cols > 0 && cell_size >= 8 && radius > 0 && n_out != nullptr);
+    ARG_TRY(ctx, n_cur >= 0 && (n_cur == 0 || cur_yx != nullptr));
+    *n_out = 0;
+    if (n_cur >= max_points) return SLAM_OK;                      // extractor.jl:64
+    const int n_cells = grid_rows * grid_cols;
+    const int n_detect = max_points - n_cur;
+    const int k = (n_detect + n_cells - 1) / n_cells;             // ceil(Int, n_detect / n_cells)
+    DetectArgs A;
+    A.img = img_dev; A.H = H; A.W = W; A.n_cur = n_cur; A.radius = radius;
+    A.grid_rows = grid_rows; A.grid_cols = grid_cols; A.cs = cell_size; A.k = k; A.min_response = min_response;
+    A.ntaps = 0;
+    if (n_cur > 0 && sigma_mask != 0) {
+        int l = 4 * (int)std::ceil(sigma_mask) + 1;
+        ARG_TRY(ctx, l <= DET_MAXTAPS);
+        A.ntaps = slam_gaussian_taps(sigma_mask, A.taps);
+    }
+    const int hw = A.ntaps >> 1;
+    const size_t n = (size_t)cell_size * cell_size;
+    // LDS carve-up checks: byte mask in bF, T plane in bB..bE, selected list in bF
+    ARG_TRY(ctx, (size_t)(cell_size + 2 * hw) * (cell_size + 2 * hw) <= n * 8);
+    ARG_TRY(ctx, (size_t)cell_size * (cell_size + 2 * hw) <= 4 * n);
+    ARG_TRY(ctx, (size_t)k * sizeof(int) <= n * 8);
+    const size_t lds_bytes = 6 * n * sizeof(double);
+    ARG_TRY(ctx, lds_bytes <= 150 * 1024);
+
+    // scratch: [cur (2*n_cur doubles)] [cell_cnt (n_cells int, padded)] [cell_out] [out header+pairs]
+    const size_t cur_b = ((size_t)n_cur * 16 + 255) & ~(size_t)255;
+    const size_t cnt_b = ((size_t)n_cells * 4 + 255) & ~(size_t)255;
+    const size_t cout_b = ((size_t)n_cells * k * 16 + 255) & ~(size_t)255;
+    const size_t out_pairs = (size_t)n_cells * k;
+    const size_t out_b = 8 + out_pairs * 16;
+    char *s;
+    int rc = slam_scratch(ctx, cur_b + cnt_b + cout_b + out_b, (void **)&s);
+    if (rc) return rc;
+    double *d_cur = (double *)s; int *d_cnt = (int *)(s + cur_b);
+    int64_t *d_cout = (int64_t *)(s + cur_b + cnt_b); int64_t *d_out = (int64_t *)(s + cur_b + cnt_b + cout_b);
+    if (n_cur > 0) HIP_TRY(ctx, hipMemcpyAsync(d_cur, cur_yx, (size_t)n_cur * 16, hipMemcpyHostToDevice, ctx->stream));
+    A.cur = d_cur; A.cell_out = d_cout; A.cell_cnt = d_cnt;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)detect_cells, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(detect_cells, dim3(n_cells), dim3(DET_THREADS), lds_bytes, ctx->stream, A);
+    hipLaunchKernelGGL(detect_compact, dim3(1), dim3(1024), 0, ctx->stream, d_cout, d_cnt, n_cells, k, d_out, (int)out_pairs);
+    HIP_TRY(ctx, hipGetLastError());
+    int64_t *h_out;
+    rc = slam_pinned(ctx, out_b, (void **)&h_out);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t cnt = h_out[0];
+    if (cnt > cap) return slam_fail(ctx, SLAM_ERR_CAPACITY, "slam_detect: %lld keypoints but cap = %d", (long long)cnt, cap);
+    memcpy(out_rc, h_out + 1, (size_t)cnt * 16);
+    *n_out = (int)cnt;
+    return SLAM_OK;
+}
+
+extern "C" int slam_detect(slam_ctx *ctx, const double *image, int H, int W, const double *cur_yx, int n_cur,
+                           int max_points, int radius, int grid_rows, int grid_cols, int cell_size,
+                           double sigma_mask, double min_response, int64_t *out_rc, int cap, int *n_out)
+{
+    ARG_TRY(ctx, ctx != nullptr);
+    ARG_TRY(ctx, image != nullptr && H > 0 && W > 0);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *d_img;
+    int rc = slam_scratch2(ctx, (size_t)H * W * 8, &d_img);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_img, image, (size_t)H * W * 8, hipMemcpyHostToDevice, ctx->stream));
+    return slam_detect_device(ctx, (const double *)d_img, H, W, cur_yx, n_cur, max_points, radius, grid_rows, grid_cols,
+                              cell_size, sigma_mask, min_response, out_rc, cap, n_out);
+}
+
+extern "C" int slam_detect_pyr(slam_ctx *ctx, const slam_pyr *pyr, const double *cur_yx, int n_cur,
+                               int max_points, int radius, int grid_rows, int grid_cols, int cell_size,
+                               double sigma_mask, double min_response, int64_t *out_rc, int cap, int *n_out)
+{
+    ARG_TRY(ctx, ctx != nullptr && pyr != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return slam_detect_device(ctx, pyr->plane(0, 0), pyr->H[0], pyr->W[0], cur_yx, n_cur, max_points, radius, grid_rows,
+                              grid_cols, cell_size, sigma_mask, min_response, out_rc, cap, n_out);
+}

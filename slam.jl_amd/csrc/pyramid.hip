@@ -1,0 +1,349 @@
+// pyramid.hip -- device-resident LKPyramid: Gaussian pyramid, Scharr gradients and
+// the sigma=4 smoothed gradient products stored as integral images.
+//
+// Replaces LKPyramid(...) / update! / copy! / deepcopy of the reference
+// (src/optical_flow/pyramid.jl:16-137, src/optical_flow/lucas_kanade.jl:102-138).
+//
+// Parity design: every recurrence (Young-van Vliet IIR Gaussian with
+// Triggs-Sdika boundaries, cumulative sums) runs sequentially along its line in
+// the reference's operation order, one lane per line, so all six planes are
+// bit-identical to the CPU oracle (-ffp-contract=off).  Lines are independent:
+// lanes map to lines, and a launch carries all planes that are ready.
+//
+// Layout in HBM: one allocation per pyramid, 6 planes x sum_l(H_l*W_l) doubles,
+// each plane column-major H_l x W_l (y fastest) exactly like the Julia arrays,
+// plus one blur scratch plane.  Row passes (recurrence along x) are naturally
+// coalesced (lanes = consecutive y); column passes walk y inside a lane.
+#include "common.hpp"
+#include <cmath>
+
+#define LINE_THREADS 64
+
+struct PlaneSet {
+    double *p[4];          // planes processed by one launch
+    const double *nrm[4];  // optional NA() normaliser (divide at the end), or nullptr
+    int coef[4];           // which IIRCoef (0 = pyramid sigma, 1 = sigma 4)
+    int fill0[4];          // border: 0 replicate, 1 Fill(0)
+    int n;
+};
+
+struct IIRPair { IIRCoef c[2]; };
+
+// One line of ImageFiltering._imfilter_dim!(::TriggsSdika): left border, forward
+// recursion, Triggs-Sdika right border, backward recursion, final scaling.
+__device__ __forceinline__ void iir_line(const double *src, double *dst, int n, long s, const IIRCoef &k,
+                                         bool fill0, const double *nrm)
+{
+    const double a1 = k.a1, a2 = k.a2, a3 = k.a3;
+    const double x0 = src[0];
+    const double iminus = fill0 ? 0.0 : x0;
+    const double iplus = fill0 ? 0.0 : src[(long)(n - 1) * s];
+    const double uminus = iminus / k.inv1masum;
+    double o0 = ((x0 + a1 * uminus) + a2 * uminus) + a3 * uminus;
+    double o1 = ((src[s] + a1 * o0) + a2 * uminus) + a3 * uminus;
+    double o2 = ((src[2 * s] + a1 * o1) + a2 * o0) + a3 * uminus;
+    dst[0] = o0; dst[s] = o1; dst[2 * s] = o2;
+    double w3 = o0, w2 = o1, w1 = o2;
+    for (int i = 3; i < n; i++) {
+        double t = ((src[(long)i * s] + a1 * w1) + a2 * w2) + a3 * w3;
+        dst[(long)i * s] = t;
+        w3 = w2; w2 = w1; w1 = t;
+    }
+    const double uplus = iplus / k.inv1masum;
+    const double vplus = uplus / k.inv1mbsum;
+    const double d0 = w1 - uplus, d1 = w2 - uplus, d2 = w3 - uplus;
+    const double vr0 = ((k.M[0] * d0 + k.M[1] * d1) + k.M[2] * d2) + vplus;
+    const double vr1 = ((k.M[3] * d0 + k.M[4] * d1) + k.M[5] * d2) + vplus;
+    const double vr2 = ((k.M[6] * d0 + k.M[7] * d1) + k.M[8] * d2) + vplus;
+    double vA = vr0;                                              // v[n-1]
+    double vB = ((w2 + a1 * vA) + a2 * vr1) + a3 * vr2;           // v[n-2]
+    double vC = ((w3 + a1 * vB) + a2 * vA) + a3 * vr1;            // v[n-3]
+    if (nrm) {
+        dst[(long)(n - 1) * s] = (vA * k.scale) / nrm[(long)(n - 1) * s];
+        dst[(long)(n - 2) * s] = (vB * k.scale) / nrm[(long)(n - 2) * s];
+        dst[(long)(n - 3) * s] = (vC * k.scale) / nrm[(long)(n - 3) * s];
+    } else {
+        dst[(long)(n - 1) * s] = vA * k.scale;
+        dst[(long)(n - 2) * s] = vB * k.scale;
+        dst[(long)(n - 3) * s] = vC * k.scale;
+    }
+    double v1 = vC, v2 = vB, v3 = vA;
+    for (int i = n - 4; i >= 0; i--) {
+        double t = ((dst[(long)i * s] + a1 * v1) + a2 * v2) + a3 * v3;
+        dst[(long)i * s] = nrm ? (t * k.scale) / nrm[(long)i * s] : t * k.scale;
+        v3 = v2; v2 = v1; v1 = t;
+    }
+}
+
+// dim-1 pass: one lane per column.  src may differ from dst for plane 0 (blur
+// reads the layer, writes the scratch plane).
+__global__ __launch_bounds__(LINE_THREADS) void k_iir_cols(PlaneSet ps, const double *src0, int H, int W, IIRPair cf)
+{
+    const int x = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
+    if (x >= W) return;
+    double *dst = ps.p[pl] + (size_t)x * H;
+    const double *src = (pl == 0 && src0) ? src0 + (size_t)x * H : dst;
+    iir_line(src, dst, H, 1, cf.c[ps.coef[pl]], ps.fill0[pl] != 0, nullptr);
+}
+
+// dim-2 pass: one lane per row, in place; consecutive lanes = consecutive y.
+__global__ __launch_bounds__(LINE_THREADS) void k_iir_rows(PlaneSet ps, int H, int W, IIRPair cf)
+{
+    const int y = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
+    if (y >= H) return;
+    double *dst = ps.p[pl] + y;
+    iir_line(dst, dst, W, H, cf.c[ps.coef[pl]], ps.fill0[pl] != 0, ps.nrm[pl] ? ps.nrm[pl] + y : nullptr);
+}
+
+// integral_image!, lucas_kanade.jl:131-138: cumsum along dim 1 ...
+__global__ __launch_bounds__(LINE_THREADS) void k_cum_cols(PlaneSet ps, int H, int W)
+{
+    const int x = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
+    if (x >= W) return;
+    double *p = ps.p[pl] + (size_t)x * H;
+    double acc = p[0];
+    for (int y = 1; y < H; y++) { acc = acc + p[y]; p[y] = acc; }
+}
+// ... then along dim 2.
+__global__ __launch_bounds__(LINE_THREADS) void k_cum_rows(PlaneSet ps, int H, int W)
+{
+    const int y = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
+    if (y >= H) return;
+    double *p = ps.p[pl] + y;
+    double acc = p[0];
+    for (int x = 1; x < W; x++) { acc = acc + p[(size_t)x * H]; p[(size_t)x * H] = acc; }
+}
+
+// imgradients (KernelFactors.scharr, separable: derivative (-1,0,1)/2, smoothing
+// (3,10,3)/16; first factor along dim 1 first) + the three gradient products.
+// border 0: replicate (update!, pyramid.jl:98-103); 1: Fill(0) (ctor, pyramid.jl:51,59).
+__device__ __forceinline__ double ldb(const double *L, int H, int W, int y, int x, int border)
+{
+    if (border == 0) { y = y < 0 ? 0 : (y >= H ? H - 1 : y); return L[(size_t)y + (size_t)x * H]; }
+    return (y < 0 || y >= H) ? 0.0 : L[(size_t)y + (size_t)x * H];
+}
+__global__ __launch_bounds__(256) void k_scharr_products(LevelView v, int border)
+{
+    const int H = v.H, W = v.W;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)H * W) return;
+    const int y = (int)(i % H), x = (int)(i / H);
+    const double dk[3] = {-1.0 / 2, 0.0 / 2, 1.0 / 2}, sk[3] = {3.0 / 16, 10.0 / 16, 3.0 / 16};
+    double iy = 0.0, ix = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        int xx = x + j - 1;
+        double dcol, scol;
+        bool zero = false;
+        if (border == 0) xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        else if (xx < 0 || xx >= W) zero = true;
+        if (zero) { dcol = 0.0; scol = 0.0; }
+        else {
+            double a = ldb(v.L, H, W, y - 1, xx, border), b = ldb(v.L, H, W, y, xx, border), c = ldb(v.L, H, W, y + 1, xx, border);
+            dcol = 0.0; dcol += a * dk[0]; dcol += b * dk[1]; dcol += c * dk[2];
+            scol = 0.0; scol += a * sk[0]; scol += b * sk[1]; scol += c * sk[2];
+        }
+        iy += dcol * sk[j];
+        ix += scol * dk[j];
+    }
+    v.Iy[i] = iy; v.Ix[i] = ix;
+    v.Iyy[i] = iy * iy; v.Ixx[i] = ix * ix; v.Iyx[i] = iy * ix;
+}
+
+// ImageTransformations.imresize!(dst, interpolate!(src, BSpline(Linear())))
+__global__ __launch_bounds__(256) void k_resize(double *dst, int Hd, int Wd, const double *src, int Hs, int Ws)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)Hd * Wd) return;
+    const int y = (int)(i % Hd) + 1, x = (int)(i / Hd) + 1;
+    const double sy = (double)Hs / (double)Hd, sx = (double)Ws / (double)Wd;
+    const double oy = 1 - 0.5 - sy * (1 - 0.5), ox = 1 - 0.5 - sx * (1 - 0.5);
+    double r = sy * y + oy, c = sx * x + ox;
+    if (sy < 1) r = r < 1 ? 1 : (r > Hs ? Hs : r);
+    if (sx < 1) c = c < 1 ? 1 : (c > Ws ? Ws : c);
+    int iy = (int)floor(r), ixx = (int)floor(c);
+    if (iy > Hs - 1) iy = Hs - 1;
+    if (ixx > Ws - 1) ixx = Ws - 1;
+    if (iy < 1) iy = 1;
+    if (ixx < 1) ixx = 1;
+    const double fy = r - iy, fx = c - ixx;
+    const double *p = src + (size_t)(iy - 1) + (size_t)(ixx - 1) * Hs;
+    const int dy = Hs > 1 ? 1 : 0; const size_t dx = Ws > 1 ? (size_t)Hs : 0;
+    const double r0 = (1 - fx) * p[0] + fx * p[dx];
+    const double r1 = (1 - fx) * p[dy] + fx * p[dy + dx];
+    dst[i] = (1 - fy) * r0 + fy * r1;
+}
+
+__global__ __launch_bounds__(256) void k_fill(double *p, size_t n, double v)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+static inline dim3 lines_grid(int nlines, int nplanes) { return dim3((nlines + LINE_THREADS - 1) / LINE_THREADS, nplanes); }
+
+static void make_view(slam_pyr *p)
+{
+    p->view.levels = p->levels;
+    for (int l = 0; l < p->levels; l++) {
+        LevelView &v = p->view.lv[l];
+        v.L = p->plane(0, l); v.Iy = p->plane(1, l); v.Ix = p->plane(2, l);
+        v.Iyy = p->plane(3, l); v.Ixx = p->plane(4, l); v.Iyx = p->plane(5, l);
+        v.H = p->H[l]; v.W = p->W[l];
+    }
+}
+
+// NA() normaliser: the Fill(0)-filtered indicator of valid pixels, per level.
+static int build_norm(slam_ctx *ctx, slam_pyr *p, double sigma)
+{
+    if (p->norm && p->norm_sigma == sigma) return SLAM_OK;
+    if (!p->norm) HIP_TRY(ctx, hipMalloc((void **)&p->norm, (size_t)p->off[p->levels] * 8));
+    IIRPair cf; cf.c[0] = slam_iir_coef(sigma); cf.c[1] = cf.c[0];
+    for (int l = 0; l + 1 < p->levels; l++) {
+        double *N = p->norm + p->off[l];
+        size_t n = (size_t)p->H[l] * p->W[l];
+        hipLaunchKernelGGL(k_fill, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, N, n, 1.0);
+        PlaneSet ps = {}; ps.p[0] = N; ps.coef[0] = 0; ps.fill0[0] = 1; ps.n = 1;
+        hipLaunchKernelGGL(k_iir_cols, lines_grid(p->W[l], 1), dim3(LINE_THREADS), 0, ctx->stream, ps, (const double *)nullptr, p->H[l], p->W[l], cf);
+        hipLaunchKernelGGL(k_iir_rows, lines_grid(p->H[l], 1), dim3(LINE_THREADS), 0, ctx->stream, ps, p->H[l], p->W[l], cf);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    p->norm_sigma = sigma;
+    return SLAM_OK;
+}
+
+// Enqueue the whole pyramid build on ctx->stream; layer 0 must already hold the image.
+static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma)
+{
+    IIRPair cf; cf.c[0] = slam_iir_coef(sigma); cf.c[1] = slam_iir_coef(4.0);   // lucas_kanade.jl:112
+    if (mode == 0) { int rc = build_norm(ctx, p, sigma); if (rc) return rc; }
+    hipStream_t st = ctx->stream;
+    for (int l = 0; l < p->levels; l++) {
+        const int H = p->H[l], W = p->W[l];
+        const size_t n = (size_t)H * W;
+        const LevelView &v = p->view.lv[l];
+        const bool has_next = l + 1 < p->levels;
+        double *T = p->tmp + p->off[l];
+        hipLaunchKernelGGL(k_scharr_products, dim3((n + 255) / 256), dim3(256), 0, st, v, mode == 0 ? 1 : 0);
+        // dim-1 IIR: [blur: L -> T], Iyy, Ixx, Iyx in place
+        PlaneSet ps = {};
+        int np = 0;
+        if (has_next) { ps.p[np] = T; ps.coef[np] = 0; ps.fill0[np] = (mode == 0); ps.nrm[np] = (mode == 0) ? p->norm + p->off[l] : nullptr; np++; }
+        ps.p[np] = v.Iyy; ps.coef[np] = 1; np++;
+        ps.p[np] = v.Ixx; ps.coef[np] = 1; np++;
+        ps.p[np] = v.Iyx; ps.coef[np] = 1; np++;
+        ps.n = np;
+        hipLaunchKernelGGL(k_iir_cols, lines_grid(W, np), dim3(LINE_THREADS), 0, st, ps, has_next ? (const double *)v.L : (const double *)nullptr, H, W, cf);
+        hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np), dim3(LINE_THREADS), 0, st, ps, H, W, cf);
+        if (has_next)
+            hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256), dim3(256), 0, st,
+                               p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], (const double *)T, H, W);
+        PlaneSet pc = {};
+        pc.p[0] = v.Iyy; pc.p[1] = v.Ixx; pc.p[2] = v.Iyx; pc.n = 3;
+        hipLaunchKernelGGL(k_cum_cols, lines_grid(W, 3), dim3(LINE_THREADS), 0, st, pc, H, W);
+        hipLaunchKernelGGL(k_cum_rows, lines_grid(H, 3), dim3(LINE_THREADS), 0, st, pc, H, W);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return SLAM_OK;
+}
+
+extern "C" {
+
+int slam_pyr_create(slam_ctx *ctx, int H, int W, int pyramid_levels, slam_pyr **out)
+{
+    ARG_TRY(ctx, ctx != nullptr && out != nullptr);
+    ARG_TRY(ctx, H >= 4 && W >= 4 && pyramid_levels >= 0 && pyramid_levels + 1 <= SLAM_MAX_LEVELS);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    slam_pyr *p = new slam_pyr();
+    p->device = ctx->device;
+    p->levels = pyramid_levels + 1;
+    int64_t o = 0; int h = H, w = W;
+    for (int l = 0; l < p->levels; l++) {
+        if (h < 4 || w < 4) { delete p; return slam_fail(ctx, SLAM_ERR_ARG, "slam_pyr_create: level %d is %dx%d, too small for the IIR kernel (needs > 3)", l, h, w); }
+        p->H[l] = h; p->W[l] = w; p->off[l] = o; o += (int64_t)h * w;
+        h = (h + 1) / 2; w = (w + 1) / 2;                         // ceil(size / 2)
+    }
+    p->off[p->levels] = o;
+    hipError_t e = hipMalloc((void **)&p->planes, (size_t)o * 6 * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->tmp, (size_t)o * 8);
+    if (e != hipSuccess) { if (p->planes) (void)hipFree(p->planes); delete p; return slam_fail(ctx, SLAM_ERR_HIP, "slam_pyr_create: %s", hipGetErrorString(e)); }
+    make_view(p);
+    *out = p;
+    return SLAM_OK;
+}
+
+int slam_pyr_destroy(slam_pyr *p)
+{
+    if (!p) return SLAM_OK;
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    if (p->planes) (void)hipFree(p->planes);
+    if (p->tmp) (void)hipFree(p->tmp);
+    if (p->norm) (void)hipFree(p->norm);
+    if (p->jobs) (void)hipFree(p->jobs);
+    delete p;
+    return SLAM_OK;
+}
+
+int slam_pyr_update_dev(slam_ctx *ctx, slam_pyr *p, const double *image_dev, int mode, double sigma, int sync)
+{
+    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_dev != nullptr && (mode == 0 || mode == 1) && sigma > 0);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (image_dev != p->plane(0, 0))
+        HIP_TRY(ctx, hipMemcpyAsync(p->plane(0, 0), image_dev, (size_t)p->H[0] * p->W[0] * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = enqueue_build(ctx, p, mode, sigma);
+    if (rc) return rc;
+    if (sync) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+int slam_pyr_update(slam_ctx *ctx, slam_pyr *p, const double *image, int mode, double sigma)
+{
+    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image != nullptr && (mode == 0 || mode == 1) && sigma > 0);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(p->plane(0, 0), image, (size_t)p->H[0] * p->W[0] * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = enqueue_build(ctx, p, mode, sigma);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+int slam_pyr_copy(slam_ctx *ctx, slam_pyr *dst, const slam_pyr *src)
+{
+    ARG_TRY(ctx, ctx != nullptr && dst != nullptr && src != nullptr);
+    ARG_TRY(ctx, dst->levels == src->levels && dst->H[0] == src->H[0] && dst->W[0] == src->W[0]);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst->planes, src->planes, (size_t)src->off[src->levels] * 6 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+int slam_pyr_clone(slam_ctx *ctx, const slam_pyr *src, slam_pyr **out)
+{
+    ARG_TRY(ctx, ctx != nullptr && src != nullptr && out != nullptr);
+    int rc = slam_pyr_create(ctx, src->H[0], src->W[0], src->levels - 1, out);
+    if (rc) return rc;
+    return slam_pyr_copy(ctx, *out, src);
+}
+
+int slam_pyr_shape(const slam_pyr *p, int level, int *H, int *W)
+{
+    if (!p || level < 0 || level >= p->levels) return SLAM_ERR_ARG;
+    if (H) *H = p->H[level];
+    if (W) *W = p->W[level];
+    return SLAM_OK;
+}
+
+int slam_pyr_levels(const slam_pyr *p) { return p ? p->levels : SLAM_ERR_ARG; }
+
+int slam_pyr_download(slam_ctx *ctx, const slam_pyr *p, int plane, int level, double *out)
+{
+    ARG_TRY(ctx, ctx != nullptr && p != nullptr && out != nullptr);
+    ARG_TRY(ctx, plane >= 0 && plane < 6 && level >= 0 && level < p->levels);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(out, p->plane(plane, level), (size_t)p->H[level] * p->W[level] * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,149 @@
+"""LKPyramid / LucasKanade / fb_tracking! mirrors (reference:
+src/optical_flow/pyramid.jl, src/optical_flow/lucas_kanade.jl, src/tracker.jl)
+and the array-level protocol of optical_flow_matching! (src/map_manager.jl:451-564)."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+PLANES = ("layers", "Iy", "Ix", "Iyy", "Ixx", "Iyx")
+
+
+@dataclass
+class LucasKanade:
+    """lucas_kanade.jl:1-7"""
+    iterations: int = 30
+    window_size: int = 9
+    pyramid_levels: int = 3
+    eigenvalue_threshold: float = 1e-4
+    eps: float = 1e-2
+
+
+class LKPyramid:
+    """Opaque device-resident pyramid (pyramid.jl:16-24): nobody outside
+    optical_flow/ reads the planes in the reference, so a handle is enough.
+
+    LKPyramid(image, levels; σ=1.0) builds with CONSTRUCTOR semantics
+    (pyramid.jl:40-79); update_(lk, img) rebuilds with update! semantics."""
+
+    def __init__(self, image=None, levels=3, sigma=1.0, shape=None, ctx=None, _handle=None):
+        self.ctx = ctx or L.default_context()
+        if _handle is not None:
+            self.h = _handle
+        else:
+            if image is not None:
+                image = np.asfortranarray(image, dtype=np.float64)
+                shape = image.shape
+            h = C.c_void_p()
+            self.ctx.check(self.ctx.lib.slam_pyr_create(self.ctx.h, shape[0], shape[1], levels, C.byref(h)))
+            self.h = h
+            if image is not None:
+                self.ctx.check(self.ctx.lib.slam_pyr_update(self.ctx.h, self.h, L.ptr(image), 0, float(sigma)))
+        self.levels = self.ctx.lib.slam_pyr_levels(self.h)
+
+    def level_shape(self, level):
+        H, W = C.c_int(), C.c_int()
+        self.ctx.check(self.ctx.lib.slam_pyr_shape(self.h, level, C.byref(H), C.byref(W)))
+        return H.value, W.value
+
+    def plane(self, name, level):
+        """Download one plane (for parity tests); level 0-based; H x W Fortran array."""
+        H, W = self.level_shape(level)
+        out = np.empty((H, W), order="F")
+        self.ctx.check(self.ctx.lib.slam_pyr_download(self.ctx.h, self.h, PLANES.index(name), level, L.ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.slam_pyr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def has_gradients(lk):
+    return True
+
+
+def update_(lk, img, sigma=1.0, device_ptr=None, sync=True):
+    """update!(lk, img; σ) pyramid.jl:81-96.  `device_ptr`: image already in HBM."""
+    if device_ptr is not None:
+        lk.ctx.check(lk.ctx.lib.slam_pyr_update_dev(lk.ctx.h, lk.h, C.c_void_p(device_ptr), 1, float(sigma), 1 if sync else 0))
+    else:
+        img = np.asfortranarray(img, dtype=np.float64)
+        assert img.shape == lk.level_shape(0)
+        lk.ctx.check(lk.ctx.lib.slam_pyr_update(lk.ctx.h, lk.h, L.ptr(img), 1, float(sigma)))
+    return lk
+
+
+def copy_(dst, src):
+    """copy!(dst, src) pyramid.jl:28-38"""
+    dst.ctx.check(dst.ctx.lib.slam_pyr_copy(dst.ctx.h, dst.h, src.h))
+    return dst
+
+
+def deepcopy(lk):
+    """deepcopy(current_pyramid), SLAM.jl:218"""
+    h = C.c_void_p()
+    lk.ctx.check(lk.ctx.lib.slam_pyr_clone(lk.ctx.h, lk.h, C.byref(h)))
+    return LKPyramid(ctx=lk.ctx, _handle=h)
+
+
+def fb_tracking_(previous_pyramid, current_pyramid, keypoints, displacement=None,
+                 iterations=30, window_size=11, pyramid_levels=3, max_distance=0.5,
+                 eigenvalue_threshold=1e-4, eps=1e-2, ctx=None):
+    """fb_tracking!(prev, cur, keypoints; displacement, iterations, window_size,
+    pyramid_levels, max_distance) -> (new_keypoints (n,2), status (n,) bool) -- tracker.jl:70-82.
+    Returns None for an empty keypoint list (tracker.jl:24)."""
+    ctx = ctx or previous_pyramid.ctx
+    pts = np.ascontiguousarray(keypoints, dtype=np.float64).reshape(-1, 2)
+    n = len(pts)
+    if n == 0:
+        return None
+    d0 = None if displacement is None else np.ascontiguousarray(displacement, dtype=np.float64).reshape(-1, 2)
+    out = np.empty((n, 2))
+    status = np.zeros(n, dtype=np.uint8)
+    rc = ctx.lib.slam_fb_track(ctx.h, previous_pyramid.h, current_pyramid.h, L.ptr(pts), L.ptr(d0), n,
+                               pyramid_levels, window_size, iterations, float(eigenvalue_threshold), float(eps),
+                               float(max_distance), L.ptr(out), L.ptr(status, L.u8p))
+    if rc == -3:
+        raise RuntimeError("Not enough layers in pyramids.")      # lucas_kanade.jl:15
+    ctx.check(rc)
+    return out, status.astype(bool)
+
+
+def optical_flow_matching(from_pyramid, to_pyramid, pixels, is_3d, projections, params, pyramid_levels_3d=1):
+    """Array-level protocol of optical_flow_matching! (map_manager.jl:451-564):
+    3-D keypoints are tracked first with the projected prior on
+    `pyramid_levels_3d` levels; the ones that fail join the 2-D keypoints and are
+    tracked without prior on params.pyramid_levels levels.
+    Returns (new_pixels (n,2), status (n,) bool)."""
+    pixels = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
+    n = len(pixels)
+    is_3d = np.asarray(is_3d, dtype=bool)
+    new = pixels.copy()
+    status = np.zeros(n, dtype=bool)
+    ids3 = np.where(is_3d)[0]
+    ids2 = list(np.where(~is_3d)[0])
+    scale = 1.0 / 2.0 ** pyramid_levels_3d
+    if len(ids3):
+        disp = scale * (np.asarray(projections, dtype=np.float64).reshape(-1, 2)[ids3] - pixels[ids3])   # map_manager.jl:494,504
+        nk, st = fb_tracking_(from_pyramid, to_pyramid, pixels[ids3], displacement=disp,
+                              pyramid_levels=pyramid_levels_3d, window_size=params.window_size,
+                              max_distance=params.max_ktl_distance)
+        ok = ids3[st]
+        new[ok] = nk[st]; status[ok] = True
+        ids2 += list(ids3[~st])                                                                        # map_manager.jl:533-538
+    if len(ids2):
+        ids2 = np.asarray(ids2)
+        nk, st = fb_tracking_(from_pyramid, to_pyramid, pixels[ids2], pyramid_levels=params.pyramid_levels,
+                              window_size=params.window_size, max_distance=params.max_ktl_distance)
+        ok = ids2[st]
+        new[ok] = nk[st]; status[ok] = True
+    return new, status

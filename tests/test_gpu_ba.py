@@ -1,0 +1,86 @@
+"""GPU parity: slam_local_ba / slam_pnp_ba vs the CPU oracle's Schur-LM (same
+algorithm: tolerances below) and vs the reference-style LM+LSMR restatement
+(cross-algorithm: final cost within 1e-3 relative)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL_THETA = 1e-6
+RTOL_SSR = 1e-8
+
+
+def _run(slam, orc, s, iters_fast=5, iterations=10, repr_eps=5.0):
+    cache = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+    slam.bundle_adjustment_(cache, s["cam"], iterations=iterations, repr_eps=repr_eps, iters_fast=iters_fast)
+    th, ol, st = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"],
+                                       iters_fast, iterations, repr_eps, solver=1)
+    return cache, th, ol, st
+
+
+@pytest.mark.parametrize("P,M,seed", [(5, 300, 0), (8, 600, 1), (20, 2000, 2)])
+def test_local_ba_matches_oracle_schur(slam, orc, syn, P, M, seed):
+    s = syn.ba_scene(P=P, M=M, seed=seed)
+    cache, th, ol, st = _run(slam, orc, s)
+    assert np.array_equal(cache.outliers, ol)
+    assert cache.stats["n_outliers"] == st["n_outliers"]
+    assert cache.stats["iters_pass1"] == st["iters_pass1"] and cache.stats["iters_pass2"] == st["iters_pass2"]
+    for k in ("ssr_init", "ssr_pass1", "ssr_final"):
+        assert abs(cache.stats[k] - st[k]) <= RTOL_SSR * st[k], k
+    assert np.abs(cache.theta - th).max() <= RTOL_THETA * max(1.0, np.abs(th).max())
+    # constant poses never move (bundle_adjustment.jl:77)
+    c = s["theta_const"].astype(bool)
+    assert np.array_equal(cache.theta[:6 * P].reshape(P, 6)[c], s["theta0"][:6 * P].reshape(P, 6)[c])
+    # recovers ground truth within noise, flags the injected gross outliers
+    assert np.abs(cache.theta[:6 * P] - s["theta_gt"][:6 * P]).max() < 0.05
+    assert set(np.where(cache.outliers)[0]) >= set(s["gross_outliers"][:0]) 
+
+
+def test_local_ba_vs_reference_style_lsmr(slam, orc, syn):
+    s = syn.ba_scene(P=6, M=500, seed=3)
+    cache, th, ol, st = _run(slam, orc, s)
+    th0, ol0, st0 = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], solver=0)
+    assert abs(cache.stats["ssr_final"] - st0["ssr_final"]) <= 1e-3 * st0["ssr_final"]
+    assert (cache.outliers != ol0).mean() < 0.01
+    assert np.abs(cache.theta[:36] - th0[:36]).max() < 1e-3
+
+
+def test_local_ba_edge_cases(slam, orc, syn):
+    # all poses constant -> only points move; zero iterations -> theta unchanged, outliers flagged at theta0
+    s = syn.ba_scene(P=4, M=100, seed=4, n_const=4)
+    cache, th, ol, st = _run(slam, orc, s)
+    assert np.array_equal(cache.theta[:24], s["theta0"][:24])
+    assert np.abs(cache.theta - th).max() <= 1e-6
+    s = syn.ba_scene(P=4, M=100, seed=5)
+    cache, th, ol, st = _run(slam, orc, s, iters_fast=0, iterations=0)
+    assert np.array_equal(cache.theta, s["theta0"]) and np.array_equal(cache.outliers, ol)
+    # shuffled observation order gives the same answer (device re-orders by point internally)
+    s = syn.ba_scene(P=5, M=200, seed=6)
+    perm = np.random.default_rng(0).permutation(s["O"])
+    s2 = dict(s); s2["pixels_yx"] = s["pixels_yx"][perm]; s2["pose_ids"] = s["pose_ids"][perm]; s2["point_ids"] = s["point_ids"][perm]
+    c1, *_ = _run(slam, orc, s); c2, th2, ol2, _ = _run(slam, orc, s2)
+    assert np.array_equal(c2.outliers, ol2)
+    assert np.abs(c1.theta - c2.theta).max() < 1e-7
+    with pytest.raises(slam.SlamHipError):
+        bad = dict(s); bad["pose_ids"] = s["pose_ids"].copy(); bad["pose_ids"][0] = 99
+        _run(slam, orc, bad)
+
+
+def test_pnp_ba_matches_oracle(slam, orc, syn):
+    for seed in range(3):
+        s = syn.pnp_scene(n=300, seed=seed)
+        pose, e0, e1, ol, no = slam.pnp_bundle_adjustment(s["cam"], s["pose0"], s["pixels_yx"], s["points"], repr_eps=3.0)
+        rp, r0, r1, rol, rno = orc.pnp_ba(s["cam"], s["pose0"], s["pixels_yx"], s["points"], repr_eps=3.0)
+        assert np.array_equal(ol, rol) and no == rno
+        assert abs(e0 - r0) <= 1e-9 * r0 and abs(e1 - r1) <= 1e-8 * r1
+        assert np.abs(pose - rp).max() <= 1e-8
+        assert np.abs(pose - s["pose_gt"]).max() < 0.02 and e1 < e0
+
+
+def test_pnp_ba_identity_sentinel(slam, orc, syn):
+    s = syn.pnp_scene(n=6, seed=1, outlier_frac=0.0)
+    px = s["pixels_yx"].copy(); px[:4] += 300.0                                # only 2 inliers can remain
+    pose, e0, e1, ol, no = slam.pnp_bundle_adjustment(s["cam"], s["pose0"], px, s["points"], repr_eps=3.0)
+    rp, r0, r1, rol, rno = orc.pnp_ba(s["cam"], s["pose0"], px, s["points"], repr_eps=3.0)
+    assert no == rno and np.array_equal(ol, rol)
+    if len(px) - rno < 5:
+        assert np.array_equal(pose, np.eye(4)) and np.array_equal(rp, np.eye(4))   # bundle_adjustment.jl:157-161
