@@ -217,7 +217,14 @@ __global__ __launch_bounds__(256) void k_points(BADev d, double inv_delta_host, 
 #pragma unroll
     for (int k = 0; k < 3; k++) d.bl[(size_t)k * M + j] = bl[k];
     for (int i = t0; i < t1; i++) {
-        if (!d.hasp[i]) continue;
+        if (!d.hasp[i]) {
+            // ignored outlier / constant pose: its pair-list entries must contribute nothing
+            if (!d.pconst[d.opose[i]]) {
+#pragma unroll
+                for (int k = 0; k < 18; k++) { d.Wm[(size_t)k * O + i] = 0.0; d.T[(size_t)k * O + i] = 0.0; }
+            }
+            continue;
+        }
         double jp[12], jl[6];
 #pragma unroll
         for (int k = 0; k < 12; k++) jp[k] = d.Jp[(size_t)k * O + i];
