@@ -54,6 +54,14 @@ void *slam_ctx_stream(slam_ctx *ctx);
 const char *slam_last_error(slam_ctx *ctx);
 /* library version / build arch string, e.g. "slamhip 0.1 gfx950" */
 const char *slam_version(void);
+/* Optional device-side timing: when enabled, named spans (e.g. "pyr_update",
+ * "k_iir_rows", "fb_track", "detect", "local_ba") are bracketed with hipEvents
+ * on the ctx stream; slam_prof_get synchronises and returns the accumulated
+ * device time and span count.  The reference's equivalent is its @debug
+ * time() prints (front_end.jl:82-114, mapper.jl:50-132, estimator.jl:90-106). */
+int  slam_prof_enable(slam_ctx *ctx, int on);
+int  slam_prof_reset(slam_ctx *ctx);
+int  slam_prof_get(slam_ctx *ctx, const char *name, double *total_ms, int64_t *count);
 
 /* ---- Extractor -------------------------------------------------------------- */
 /* detect(e::Extractor, image, current_points; sigma_mask) -- src/extractor.jl:63-95

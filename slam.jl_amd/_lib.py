@@ -24,6 +24,9 @@ SIGNATURES = {
     "slam_ctx_stream": (vp, [vp]),
     "slam_last_error": (C.c_char_p, [vp]),
     "slam_version": (C.c_char_p, []),
+    "slam_prof_enable": (cint, [vp, cint]),
+    "slam_prof_reset": (cint, [vp]),
+    "slam_prof_get": (cint, [vp, C.c_char_p, f64p, i64p]),
     "slam_detect": (cint, [vp, f64p, cint, cint, f64p, cint, cint, cint, cint, cint, cint, dbl, dbl, i64p, cint, C.POINTER(cint)]),
     "slam_detect_pyr": (cint, [vp, vp, f64p, cint, cint, cint, cint, cint, cint, dbl, dbl, i64p, cint, C.POINTER(cint)]),
     "slam_describe": (cint, [vp, f64p, cint, cint, i64p, cint, i32p, cint, dbl, cint, u64p, i64p, C.POINTER(cint)]),
@@ -95,6 +98,18 @@ class Context:
     @property
     def stream(self):
         return self.lib.slam_ctx_stream(self.h)
+
+    def prof_enable(self, on=True):
+        self.check(self.lib.slam_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self.check(self.lib.slam_prof_reset(self.h))
+
+    def prof_get(self, name):
+        """-> (total device ms, span count) of a named span since the last reset."""
+        ms, n = C.c_double(), C.c_int64()
+        self.check(self.lib.slam_prof_get(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def synchronize(self):
         self.check(self.lib.slam_ctx_synchronize(self.h))

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <map>
 #include "../../include/slamhip.h"
 
 #define SLAM_MAX_LEVELS 8
@@ -18,6 +19,21 @@ struct slam_ctx {
     void *scratch = nullptr; size_t scratch_bytes = 0;
     void *scratch2 = nullptr; size_t scratch2_bytes = 0;
     void *pinned = nullptr; size_t pinned_bytes = 0;
+    // optional device-side timing (hipEvents on ctx->stream), see slam_prof_*
+    bool prof_on = false;
+    struct ProfSpan { int id; hipEvent_t a, b; };
+    std::vector<ProfSpan> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    std::vector<std::string> prof_names;
+    std::vector<double> prof_ms;
+    std::vector<long long> prof_cnt;
+};
+
+// RAII span: records a hipEvent pair around the enclosed launches when profiling is on
+struct ProfScope {
+    slam_ctx *c; int idx;
+    ProfScope(slam_ctx *ctx, const char *name);
+    ~ProfScope();
 };
 
 // Device-side view of one pyramid level (all planes column-major H x W).

@@ -27,7 +27,66 @@ int slam_scratch(slam_ctx *ctx, size_t bytes, void **out) { int rc = grow(ctx, &
 int slam_scratch2(slam_ctx *ctx, size_t bytes, void **out) { int rc = grow(ctx, &ctx->scratch2, &ctx->scratch2_bytes, bytes, false); *out = ctx->scratch2; return rc; }
 int slam_pinned(slam_ctx *ctx, size_t bytes, void **out) { int rc = grow(ctx, &ctx->pinned, &ctx->pinned_bytes, bytes, true); *out = ctx->pinned; return rc; }
 
+static hipEvent_t prof_event(slam_ctx *c)
+{
+    if (!c->prof_pool.empty()) { hipEvent_t e = c->prof_pool.back(); c->prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+}
+static int prof_id(slam_ctx *c, const char *name)
+{
+    for (size_t i = 0; i < c->prof_names.size(); i++) if (c->prof_names[i] == name) return (int)i;
+    c->prof_names.push_back(name); c->prof_ms.push_back(0.0); c->prof_cnt.push_back(0);
+    return (int)c->prof_names.size() - 1;
+}
+ProfScope::ProfScope(slam_ctx *ctx, const char *name) : c(ctx), idx(-1)
+{
+    if (!c || !c->prof_on) return;
+    slam_ctx::ProfSpan sp; sp.id = prof_id(c, name); sp.a = prof_event(c); sp.b = prof_event(c);
+    (void)hipEventRecord(sp.a, c->stream);
+    c->prof_pending.push_back(sp); idx = (int)c->prof_pending.size() - 1;
+}
+ProfScope::~ProfScope()
+{
+    if (idx >= 0) (void)hipEventRecord(c->prof_pending[idx].b, c->stream);
+}
+static void prof_collect(slam_ctx *c)
+{
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &sp : c->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { c->prof_ms[sp.id] += ms; c->prof_cnt[sp.id]++; }
+        c->prof_pool.push_back(sp.a); c->prof_pool.push_back(sp.b);
+    }
+    c->prof_pending.clear();
+}
+
 extern "C" {
+
+int slam_prof_enable(slam_ctx *ctx, int on)
+{
+    ARG_TRY(ctx, ctx != nullptr);
+    if (!on && ctx->prof_on) prof_collect(ctx);
+    ctx->prof_on = on != 0;
+    return SLAM_OK;
+}
+int slam_prof_reset(slam_ctx *ctx)
+{
+    ARG_TRY(ctx, ctx != nullptr);
+    prof_collect(ctx);
+    for (auto &v : ctx->prof_ms) v = 0.0;
+    for (auto &v : ctx->prof_cnt) v = 0;
+    return SLAM_OK;
+}
+int slam_prof_get(slam_ctx *ctx, const char *name, double *total_ms, int64_t *count)
+{
+    ARG_TRY(ctx, ctx != nullptr && name != nullptr);
+    prof_collect(ctx);
+    double ms = 0.0; long long n = 0;
+    for (size_t i = 0; i < ctx->prof_names.size(); i++) if (ctx->prof_names[i] == name) { ms = ctx->prof_ms[i]; n = ctx->prof_cnt[i]; }
+    if (total_ms) *total_ms = ms;
+    if (count) *count = n;
+    return SLAM_OK;
+}
 
 int slam_ctx_create(int device, slam_ctx **out)
 {
@@ -54,6 +113,8 @@ int slam_ctx_destroy(slam_ctx *ctx)
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto &sp : ctx->prof_pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SLAM_OK;

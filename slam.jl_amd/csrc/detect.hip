@@ -314,8 +314,9 @@ int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, const
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)detect_cells, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(detect_cells, dim3(n_cells), dim3(DET_THREADS), lds_bytes, ctx->stream, A);
-    hipLaunchKernelGGL(detect_compact, dim3(1), dim3(1024), 0, ctx->stream, d_cout, d_cnt, n_cells, k, d_out, (int)out_pairs);
+    { ProfScope span(ctx, "detect");
+      hipLaunchKernelGGL(detect_cells, dim3(n_cells), dim3(DET_THREADS), lds_bytes, ctx->stream, A);
+      hipLaunchKernelGGL(detect_compact, dim3(1), dim3(1024), 0, ctx->stream, d_cout, d_cnt, n_cells, k, d_out, (int)out_pairs); }
     HIP_TRY(ctx, hipGetLastError());
     int64_t *h_out;
     rc = slam_pinned(ctx, out_b, (void **)&h_out);

@@ -205,7 +205,8 @@ extern "C" int slam_fb_track(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr
     A.pyramid_levels = pyramid_levels; A.window = window; A.iterations = iterations;
     A.eig_thr = eig_thr; A.eps = eps; A.max_distance = max_distance;
     A.out = d_out; A.status = d_st;
-    hipLaunchKernelGGL(k_fb_track, dim3(n), dim3(64), 0, ctx->stream, A);
+    { ProfScope span(ctx, "fb_track");
+      hipLaunchKernelGGL(k_fb_track, dim3(n), dim3(64), 0, ctx->stream, A); }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(out_yx, d_out, pb, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(status, d_st, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -29,26 +29,201 @@ struct PlaneSet {
 
 struct IIRPair { IIRCoef c[2]; };
 
+// Software-pipelined sequential sweep over `count` elements of a strided line:
+// element j lives at base[j*step] (step may be negative), out[j] = f(in[j]) with
+// f carrying the recurrence state.  The recurrence itself is inherently
+// sequential (its exact operation order is what makes the planes bit-identical
+// to the oracle); the memory traffic is not: inputs are fetched NB*C elements
+// ahead into a register ring so the dependent chain never waits on HBM/L2
+// latency, and results are stored behind it.
+template <int C, int NB, class F>
+__device__ __forceinline__ void stream_line(const double *src, double *dst, long step, int count, F f)
+{
+    double buf[NB][C];
+    const int nfull = count / C;
+    const long cstep = (long)C * step;
+    const double *lp = src;            // next chunk to load
+    double *sp = dst;                  // next chunk to store
+    int loaded = 0;
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+        if (b < nfull) {
+#pragma unroll
+            for (int c = 0; c < C; c++) buf[b][c] = lp[c * step];
+            lp += cstep; loaded++;
+        }
+    int done = 0;
+    while (done + NB <= nfull) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+#pragma unroll
+            for (int c = 0; c < C; c++) buf[b][c] = f(buf[b][c]);
+#pragma unroll
+            for (int c = 0; c < C; c++) sp[c * step] = buf[b][c];
+            sp += cstep;
+            if (loaded < nfull) {
+#pragma unroll
+                for (int c = 0; c < C; c++) buf[b][c] = lp[c * step];
+                lp += cstep; loaded++;
+            }
+        }
+        done += NB;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+        if (done + b < nfull) {
+#pragma unroll
+            for (int c = 0; c < C; c++) buf[b][c] = f(buf[b][c]);
+#pragma unroll
+            for (int c = 0; c < C; c++) sp[c * step] = buf[b][c];
+            sp += cstep;
+        }
+    for (int j = nfull * C; j < count; j++) dst[(long)j * step] = f(src[(long)j * step]);
+}
+
+// ---- line I/O policies ------------------------------------------------------
+// RowIO: the lane's line is strided (recurrence along x, lanes = consecutive y):
+// every access of the wave is one coalesced 512-byte segment.
+struct RowIO {
+    const double *src; double *dst; long s;
+    __device__ __forceinline__ double ld_src(int i) const { return src[(long)i * s]; }
+    __device__ __forceinline__ double ld_dst(int i) const { return dst[(long)i * s]; }
+    __device__ __forceinline__ void st(int i, double v) const { dst[(long)i * s] = v; }
+    // sweep `count` elements starting at i0 in direction dir (+1/-1); from_dst: read dst instead of src
+    template <class F> __device__ __forceinline__ void sweep(int i0, int count, int dir, bool from_dst, F f) const
+    {
+        stream_line<8, 4>((from_dst ? dst : src) + (long)i0 * s, dst + (long)i0 * s, dir * s, count, f);
+    }
+    __device__ __forceinline__ void fence() const {}
+};
+
+// ColIO: the lane's line is contiguous (recurrence along y, lanes = 64
+// consecutive columns).  Direct access would touch 64 cache lines per
+// wave-instruction; instead 8-row x 64-column tiles move between HBM and
+// registers in 64-byte row segments (8 lanes per column segment) and are
+// transposed through a 4.6 KB LDS tile, so each lane ends up with the 8
+// consecutive samples of its own column.  A ring of NB tiles is prefetched.
+#define COL_NB 4
+struct ColIO {
+    const double *src; double *dst;     // plane bases
+    int H, W, x0;                       // first column of this wave
+    double *lds;                        // 64 x 9 doubles
+    __device__ __forceinline__ int xown() const { int x = x0 + (int)(threadIdx.x & 63); return x < W ? x : W - 1; }
+    __device__ __forceinline__ bool valid() const { return x0 + (int)(threadIdx.x & 63) < W; }
+    __device__ __forceinline__ double ld_src(int i) const { return src[(size_t)i + (size_t)xown() * H]; }
+    __device__ __forceinline__ double ld_dst(int i) const { return dst[(size_t)i + (size_t)xown() * H]; }
+    __device__ __forceinline__ void st(int i, double v) const { if (valid()) dst[(size_t)i + (size_t)xown() * H] = v; }
+    __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
+    __device__ __forceinline__ void tile_load(const double *base, int r0, double t[8]) const
+    {
+        const int lane = threadIdx.x & 63, rr = lane & 7, cg = lane >> 3;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            int col = x0 + 8 * r + cg; col = col < W ? col : W - 1;
+            t[r] = base[(size_t)(r0 + rr) + (size_t)col * H];
+        }
+    }
+    __device__ __forceinline__ void tile_store(int r0, const double t[8]) const
+    {
+        const int lane = threadIdx.x & 63, rr = lane & 7, cg = lane >> 3;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int col = x0 + 8 * r + cg;
+            if (col < W) dst[(size_t)(r0 + rr) + (size_t)col * H] = t[r];
+        }
+    }
+    // tile registers -> the lane's own 8 samples (in sweep order)
+    __device__ __forceinline__ void to_own(const double t[8], double v[8], bool rev) const
+    {
+        const int lane = threadIdx.x & 63, rr = lane & 7, cg = lane >> 3;
+#pragma unroll
+        for (int r = 0; r < 8; r++) lds[(8 * r + cg) * 9 + rr] = t[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = lds[lane * 9 + (rev ? 7 - c : c)];
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void from_own(const double v[8], double t[8], bool rev) const
+    {
+        const int lane = threadIdx.x & 63, rr = lane & 7, cg = lane >> 3;
+#pragma unroll
+        for (int c = 0; c < 8; c++) lds[lane * 9 + (rev ? 7 - c : c)] = v[c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; r++) t[r] = lds[(8 * r + cg) * 9 + rr];
+        __builtin_amdgcn_wave_barrier();
+    }
+    template <class F> __device__ __forceinline__ void sweep(int i0, int count, int dir, bool from_dst, F f) const
+    {
+        const double *base = from_dst ? dst : src;
+        const bool rev = dir < 0;
+        const int nfull = count / 8;
+        double ring[COL_NB][8];
+        // tile k covers rows [lo(k), lo(k)+7]
+        auto lo = [&](int k) { return rev ? i0 - 8 * k - 7 : i0 + 8 * k; };
+        int loaded = 0;
+#pragma unroll
+        for (int b = 0; b < COL_NB; b++)
+            if (b < nfull) { tile_load(base, lo(loaded), ring[b]); loaded++; }
+        int done = 0;
+        while (done + COL_NB <= nfull) {
+#pragma unroll
+            for (int b = 0; b < COL_NB; b++) {
+                double v[8], t[8];
+                to_own(ring[b], v, rev);
+#pragma unroll
+                for (int c = 0; c < 8; c++) v[c] = f(v[c]);
+                from_own(v, t, rev);
+                tile_store(lo(done + b), t);
+                if (loaded < nfull) { tile_load(base, lo(loaded), ring[b]); loaded++; }
+            }
+            done += COL_NB;
+        }
+#pragma unroll
+        for (int b = 0; b < COL_NB; b++)
+            if (done + b < nfull) {
+                double v[8], t[8];
+                to_own(ring[b], v, rev);
+#pragma unroll
+                for (int c = 0; c < 8; c++) v[c] = f(v[c]);
+                from_own(v, t, rev);
+                tile_store(lo(done + b), t);
+            }
+        // tail rows: direct access by the owning lane.  The tile stores above were
+        // made by other lanes; order them before the direct accesses below.
+        fence();
+        const int x = xown();
+        for (int j = nfull * 8; j < count; j++) {
+            const int i = i0 + dir * j;
+            const double r = f(base[(size_t)i + (size_t)x * H]);
+            if (valid()) dst[(size_t)i + (size_t)x * H] = r;
+        }
+    }
+};
+
 // One line of ImageFiltering._imfilter_dim!(::TriggsSdika): left border, forward
 // recursion, Triggs-Sdika right border, backward recursion, final scaling.
-__device__ __forceinline__ void iir_line(const double *src, double *dst, int n, long s, const IIRCoef &k,
-                                         bool fill0, const double *nrm)
+template <class IO>
+__device__ __forceinline__ void iir_line(const IO &io, int n, const IIRCoef &k, bool fill0, const double *nrm, long nrm_s)
 {
     const double a1 = k.a1, a2 = k.a2, a3 = k.a3;
-    const double x0 = src[0];
+    const double x0 = io.ld_src(0);
     const double iminus = fill0 ? 0.0 : x0;
-    const double iplus = fill0 ? 0.0 : src[(long)(n - 1) * s];
+    const double iplus = fill0 ? 0.0 : io.ld_src(n - 1);
     const double uminus = iminus / k.inv1masum;
     double o0 = ((x0 + a1 * uminus) + a2 * uminus) + a3 * uminus;
-    double o1 = ((src[s] + a1 * o0) + a2 * uminus) + a3 * uminus;
-    double o2 = ((src[2 * s] + a1 * o1) + a2 * o0) + a3 * uminus;
-    dst[0] = o0; dst[s] = o1; dst[2 * s] = o2;
+    double o1 = ((io.ld_src(1) + a1 * o0) + a2 * uminus) + a3 * uminus;
+    double o2 = ((io.ld_src(2) + a1 * o1) + a2 * o0) + a3 * uminus;
+    io.st(0, o0); io.st(1, o1); io.st(2, o2);
     double w3 = o0, w2 = o1, w1 = o2;
-    for (int i = 3; i < n; i++) {
-        double t = ((src[(long)i * s] + a1 * w1) + a2 * w2) + a3 * w3;
-        dst[(long)i * s] = t;
+    io.sweep(3, n - 3, +1, false, [&](double x) {
+        const double t = ((x + a1 * w1) + a2 * w2) + a3 * w3;
         w3 = w2; w2 = w1; w1 = t;
-    }
+        return t;
+    });
     const double uplus = iplus / k.inv1masum;
     const double vplus = uplus / k.inv1mbsum;
     const double d0 = w1 - uplus, d1 = w2 - uplus, d2 = w3 - uplus;
@@ -58,32 +233,38 @@ __device__ __forceinline__ void iir_line(const double *src, double *dst, int n, 
     double vA = vr0;                                              // v[n-1]
     double vB = ((w2 + a1 * vA) + a2 * vr1) + a3 * vr2;           // v[n-2]
     double vC = ((w3 + a1 * vB) + a2 * vA) + a3 * vr1;            // v[n-3]
-    if (nrm) {
-        dst[(long)(n - 1) * s] = (vA * k.scale) / nrm[(long)(n - 1) * s];
-        dst[(long)(n - 2) * s] = (vB * k.scale) / nrm[(long)(n - 2) * s];
-        dst[(long)(n - 3) * s] = (vC * k.scale) / nrm[(long)(n - 3) * s];
-    } else {
-        dst[(long)(n - 1) * s] = vA * k.scale;
-        dst[(long)(n - 2) * s] = vB * k.scale;
-        dst[(long)(n - 3) * s] = vC * k.scale;
-    }
     double v1 = vC, v2 = vB, v3 = vA;
-    for (int i = n - 4; i >= 0; i--) {
-        double t = ((dst[(long)i * s] + a1 * v1) + a2 * v2) + a3 * v3;
-        dst[(long)i * s] = nrm ? (t * k.scale) / nrm[(long)i * s] : t * k.scale;
-        v3 = v2; v2 = v1; v1 = t;
+    const double scale = k.scale;
+    io.fence();                                                   // forward results visible to every lane of the wave
+    if (nrm) {   // NA() border (constructor semantics, frames 1-2 only): plain loop
+        io.st(n - 1, (vA * scale) / nrm[(long)(n - 1) * nrm_s]);
+        io.st(n - 2, (vB * scale) / nrm[(long)(n - 2) * nrm_s]);
+        io.st(n - 3, (vC * scale) / nrm[(long)(n - 3) * nrm_s]);
+        for (int i = n - 4; i >= 0; i--) {
+            const double t = ((io.ld_dst(i) + a1 * v1) + a2 * v2) + a3 * v3;
+            io.st(i, (t * scale) / nrm[(long)i * nrm_s]);
+            v3 = v2; v2 = v1; v1 = t;
+        }
+        return;
     }
+    io.st(n - 1, vA * scale); io.st(n - 2, vB * scale); io.st(n - 3, vC * scale);
+    io.sweep(n - 4, n - 3, -1, true, [&](double x) {
+        const double t = ((x + a1 * v1) + a2 * v2) + a3 * v3;
+        v3 = v2; v2 = v1; v1 = t;
+        return t * scale;
+    });
 }
 
-// dim-1 pass: one lane per column.  src may differ from dst for plane 0 (blur
-// reads the layer, writes the scratch plane).
+// dim-1 pass: one lane per column, LDS-transposed tile I/O.  src may differ from
+// dst for plane 0 (the blur reads the layer and writes the scratch plane).
 __global__ __launch_bounds__(LINE_THREADS) void k_iir_cols(PlaneSet ps, const double *src0, int H, int W, IIRPair cf)
 {
-    const int x = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
-    if (x >= W) return;
-    double *dst = ps.p[pl] + (size_t)x * H;
-    const double *src = (pl == 0 && src0) ? src0 + (size_t)x * H : dst;
-    iir_line(src, dst, H, 1, cf.c[ps.coef[pl]], ps.fill0[pl] != 0, nullptr);
+    __shared__ double tile[64 * 9];
+    const int pl = blockIdx.y;
+    ColIO io;
+    io.dst = ps.p[pl]; io.src = (pl == 0 && src0) ? src0 : ps.p[pl];
+    io.H = H; io.W = W; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile;
+    iir_line(io, H, cf.c[ps.coef[pl]], ps.fill0[pl] != 0, nullptr, 0);
 }
 
 // dim-2 pass: one lane per row, in place; consecutive lanes = consecutive y.
@@ -91,18 +272,18 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows(PlaneSet ps, int H, i
 {
     const int y = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
     if (y >= H) return;
-    double *dst = ps.p[pl] + y;
-    iir_line(dst, dst, W, H, cf.c[ps.coef[pl]], ps.fill0[pl] != 0, ps.nrm[pl] ? ps.nrm[pl] + y : nullptr);
+    RowIO io; io.src = ps.p[pl] + y; io.dst = ps.p[pl] + y; io.s = H;
+    iir_line(io, W, cf.c[ps.coef[pl]], ps.fill0[pl] != 0, ps.nrm[pl] ? ps.nrm[pl] + y : nullptr, H);
 }
 
 // integral_image!, lucas_kanade.jl:131-138: cumsum along dim 1 ...
 __global__ __launch_bounds__(LINE_THREADS) void k_cum_cols(PlaneSet ps, int H, int W)
 {
-    const int x = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
-    if (x >= W) return;
-    double *p = ps.p[pl] + (size_t)x * H;
-    double acc = p[0];
-    for (int y = 1; y < H; y++) { acc = acc + p[y]; p[y] = acc; }
+    __shared__ double tile[64 * 9];
+    const int pl = blockIdx.y;
+    ColIO io; io.dst = ps.p[pl]; io.src = ps.p[pl]; io.H = H; io.W = W; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile;
+    double acc = io.ld_src(0);
+    io.sweep(1, H - 1, +1, false, [&](double x) { acc = acc + x; return acc; });
 }
 // ... then along dim 2.
 __global__ __launch_bounds__(LINE_THREADS) void k_cum_rows(PlaneSet ps, int H, int W)
@@ -111,7 +292,7 @@ __global__ __launch_bounds__(LINE_THREADS) void k_cum_rows(PlaneSet ps, int H, i
     if (y >= H) return;
     double *p = ps.p[pl] + y;
     double acc = p[0];
-    for (int x = 1; x < W; x++) { acc = acc + p[(size_t)x * H]; p[(size_t)x * H] = acc; }
+    stream_line<8, 8>(p + H, p + H, H, W - 1, [&](double x) { acc = acc + x; return acc; });
 }
 
 // imgradients (KernelFactors.scharr, separable: derivative (-1,0,1)/2, smoothing
@@ -218,6 +399,7 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma)
     IIRPair cf; cf.c[0] = slam_iir_coef(sigma); cf.c[1] = slam_iir_coef(4.0);   // lucas_kanade.jl:112
     if (mode == 0) { int rc = build_norm(ctx, p, sigma); if (rc) return rc; }
     hipStream_t st = ctx->stream;
+    ProfScope span_all(ctx, "pyr_update");
     for (int l = 0; l < p->levels; l++) {
         const int H = p->H[l], W = p->W[l];
         const size_t n = (size_t)H * W;
@@ -234,7 +416,8 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma)
         ps.p[np] = v.Iyx; ps.coef[np] = 1; np++;
         ps.n = np;
         hipLaunchKernelGGL(k_iir_cols, lines_grid(W, np), dim3(LINE_THREADS), 0, st, ps, has_next ? (const double *)v.L : (const double *)nullptr, H, W, cf);
-        hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np), dim3(LINE_THREADS), 0, st, ps, H, W, cf);
+        { ProfScope span(ctx, "k_iir_rows");
+          hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np), dim3(LINE_THREADS), 0, st, ps, H, W, cf); }
         if (has_next)
             hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256), dim3(256), 0, st,
                                p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], (const double *)T, H, W);

@@ -1,0 +1,203 @@
+"""Point-sharded local bundle adjustment over N GPUs.
+
+One process per GPU.  Map points (with all their observations) are partitioned
+across ranks; every rank holds all poses.  Per LM iteration each rank builds its
+contribution to the reduced camera system on its GPU (libslamhip
+`slam_ba_build`), ONE `all_reduce(SUM)` over RCCL/xGMI combines
+[S (6P x 6P) ; rhs ; diag(Jp'Jp) ; ssr], every rank solves the small dense
+system redundantly and back-substitutes its own points (`slam_ba_solve`), and a
+4-double all-reduce combines the trial / predicted costs so that all ranks take
+the same accept/reject decision.  The LM outer loop is LeastSquaresOptim's
+(reference: src/bundle_adjustment.jl:35-54 and SURVEY Appendix A.8).
+
+The reference has no distributed path; its BA window is <= 5 free key-frames
+(src/estimator.jl:327-331), for which this path never pays off -- it exists for
+the 50/100-KF windows BASELINE.json names and is gated by `worth_sharding`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+LM_MAX_DELTA, LM_MIN_DELTA = 1e16, 1e-16
+LM_MIN_STEP_QUALITY = 1e-3
+LM_DELTA0 = 10.0
+LM_XTOL = LM_FTOL = 1e-8
+
+
+def worth_sharding(P, O, world_size):
+    """Gate (north_star: 'only when the window is large enough to amortise it').
+    The all-reduce moves 8*(6P)^2 bytes and costs >= ~30 us of latency per
+    iteration; a single GPU builds the system for O observations in roughly
+    O * 0.5 ns + a few launches.  Shard only when the per-GPU build saving
+    exceeds the collective."""
+    if world_size <= 1:
+        return False
+    build_us = O * 5e-4
+    allreduce_us = 30.0 + 8.0 * (6 * P) ** 2 / 100e3      # ~100 GB/s effective ring rate -> bytes/1e5 us
+    return build_us * (1.0 - 1.0 / world_size) > allreduce_us
+
+
+def partition_points(point_ids, M, world_size):
+    """Contiguous point ranges balanced by observation count.
+    Returns a list of (m_lo, m_hi) 0-based half-open ranges, one per rank."""
+    cnt = np.bincount(np.asarray(point_ids, dtype=np.int64) - 1, minlength=M).astype(np.int64)
+    cum = np.concatenate([[0], np.cumsum(cnt)])
+    total = cum[-1]
+    bounds = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        bounds.append(int(np.searchsorted(cum, target, side="left")))
+    bounds.append(M)
+    bounds = np.maximum.accumulate(np.minimum(bounds, M))
+    return [(int(bounds[r]), int(bounds[r + 1])) for r in range(world_size)]
+
+
+class HipShard:
+    """This rank's shard on its GPU (libslamhip slam_ba_*); buffers are torch CUDA tensors."""
+
+    def __init__(self, cam, P, theta_local, theta_const, pixels, pose_ids, point_ids_local, ctx=None):
+        import torch
+        self.torch = torch
+        self.ctx = ctx or L.default_context(torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        self.P = P
+        self.M = (len(theta_local) - 6 * P) // 3
+        self.O = len(pose_ids)
+        th = np.ascontiguousarray(theta_local, dtype=np.float64)
+        tc = np.ascontiguousarray(theta_const, dtype=np.uint8)
+        px = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
+        pi = np.ascontiguousarray(pose_ids, dtype=np.int64)
+        li = np.ascontiguousarray(point_ids_local, dtype=np.int64)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.slam_ba_create(self.ctx.h, cam[0], cam[1], cam[2], cam[3], P, self.M, self.O,
+                                                   L.ptr(th), L.ptr(tc, L.u8p), L.ptr(px), L.ptr(pi, L.i64p), L.ptr(li, L.i64p),
+                                                   C.byref(h)))
+        self.h = h
+        dev = torch.device("cuda", self.ctx.device)
+        self.red = torch.zeros(self.ctx.lib.slam_ba_reduce_len(P), dtype=torch.float64, device=dev)
+        self.trial = torch.zeros(4, dtype=torch.float64, device=dev)
+
+    def build(self, ignore_outliers, inv_delta):
+        self.ctx.check(self.ctx.lib.slam_ba_build(self.ctx.h, self.h, int(ignore_outliers), float(inv_delta), C.c_void_p(self.red.data_ptr())))
+        return self.red
+
+    def solve(self, red, inv_delta):
+        self.ctx.check(self.ctx.lib.slam_ba_solve(self.ctx.h, self.h, C.c_void_p(red.data_ptr()), float(inv_delta), C.c_void_p(self.trial.data_ptr())))
+        return self.trial
+
+    def commit(self, accept):
+        self.ctx.check(self.ctx.lib.slam_ba_commit(self.ctx.h, self.h, int(accept)))
+
+    def flag_outliers(self, repr_eps, depth_eps=1e-6):
+        n = C.c_int(0)
+        self.ctx.check(self.ctx.lib.slam_ba_flag_outliers(self.ctx.h, self.h, float(repr_eps), float(depth_eps), C.byref(n)))
+        return n.value
+
+    def download(self):
+        theta = np.zeros(6 * self.P + 3 * self.M)
+        outl = np.zeros(max(self.O, 1), dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.slam_ba_download(self.ctx.h, self.h, L.ptr(theta), L.ptr(outl, L.u8p)))
+        return theta, outl[:self.O].astype(bool)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.slam_ba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _all_reduce(t, op, group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def sharded_bundle_adjustment(cam, theta, theta_const, pixels, pose_ids, point_ids, iterations=10, repr_eps=5.0,
+                              iters_fast=5, group=None, shard_factory=HipShard, timings=None):
+    """bundle_adjustment! over all ranks of `group`.  Every rank passes the FULL
+    problem (as the single-GPU seam would receive it) and gets the FULL result:
+    (theta (6P+3M), outliers (O,), stats).  `shard_factory` builds this rank's
+    compute shard (HipShard in the product; the tests inject an oracle-backed
+    one to check the partition + collective logic on CPU/gloo)."""
+    import torch
+    import torch.distributed as dist
+    ws = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if ws > 1 else 0
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    tc = np.ascontiguousarray(theta_const, dtype=np.uint8)
+    px = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
+    pi = np.ascontiguousarray(pose_ids, dtype=np.int64)
+    li = np.ascontiguousarray(point_ids, dtype=np.int64)
+    P, O = len(tc), len(pi)
+    M = (len(theta) - 6 * P) // 3
+    n = 6 * P
+    parts = partition_points(li, M, ws)
+    m_lo, m_hi = parts[rank]
+    sel = np.where((li - 1 >= m_lo) & (li - 1 < m_hi))[0]
+    theta_local = np.concatenate([theta[:n], theta[n + 3 * m_lo:n + 3 * m_hi]])
+    shard = shard_factory(cam, P, theta_local, tc, px[sel], pi[sel], li[sel] - m_lo)
+    SUM, MAX = dist.ReduceOp.SUM, dist.ReduceOp.MAX
+
+    def run_pass(ignore, iters):
+        delta, decrease = LM_DELTA0, 2.0
+        red = _all_reduce(shard.build(ignore, 1.0 / delta), SUM, group)
+        ssr = float(red[n * n + 2 * n])
+        ssr0 = ssr
+        it, converged = 0, False
+        while not converged and it < iters:
+            it += 1
+            if it > 1:
+                red = _all_reduce(shard.build(ignore, 1.0 / delta), SUM, group)
+            tr = shard.solve(red, 1.0 / delta)
+            mx = tr[2:3].clone()
+            _all_reduce(tr[0:2], SUM, group)
+            _all_reduce(mx, MAX, group)
+            trial, pred, maxdx = float(tr[0]), float(tr[1]), float(mx[0])
+            if float(tr[3]) != 0.0:
+                raise L.SlamHipError("sharded BA: reduced camera system not positive definite")
+            rho = (trial - ssr) / (pred - ssr)
+            if rho > LM_MIN_STEP_QUALITY:
+                x_conv = maxdx <= LM_XTOL
+                f_conv = abs(ssr - trial) / (abs(ssr) + LM_FTOL) <= LM_FTOL
+                ssr = trial
+                u = 2.0 * rho - 1.0
+                delta = min(delta / max(1.0 / 3.0, 1.0 - u * u * u), LM_MAX_DELTA)
+                decrease = 2.0
+                shard.commit(1)
+                converged = x_conv or f_conv
+            else:
+                delta = max(delta / decrease, LM_MIN_DELTA)
+                decrease *= 2.0
+                shard.commit(0)
+                converged = maxdx <= LM_XTOL
+        return ssr0, ssr, it
+
+    ssr_init, ssr1, it1 = run_pass(0, iters_fast)
+    n_out = torch.tensor([shard.flag_outliers(repr_eps)], dtype=torch.float64, device=shard.red.device if hasattr(shard, "red") else "cpu")
+    _all_reduce(n_out, SUM, group)
+    _, ssr2, it2 = run_pass(1, iterations)
+    th_loc, ol_loc = shard.download()
+    # gather the full result on every rank (poses are identical everywhere)
+    theta_out = theta.copy()
+    outl = np.zeros(O, dtype=bool)
+    if ws > 1:
+        objs = [None] * ws
+        dist.all_gather_object(objs, (m_lo, m_hi, th_loc, sel, ol_loc), group=group)
+    else:
+        objs = [(m_lo, m_hi, th_loc, sel, ol_loc)]
+    for lo, hi, th, s, ol in objs:
+        theta_out[:n] = th[:n]
+        theta_out[n + 3 * lo:n + 3 * hi] = th[n:]
+        outl[s] = ol
+    stats = dict(ssr_init=ssr_init, ssr_pass1=ssr1, ssr_final=ssr2, iters_pass1=it1, iters_pass2=it2,
+                 n_outliers=int(n_out[0]), world_size=ws, points_local=m_hi - m_lo, obs_local=len(sel))
+    if hasattr(shard, "close"):
+        shard.close()
+    return theta_out, outl, stats

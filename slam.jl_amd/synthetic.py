@@ -53,59 +53,64 @@ def rotzyx(t1, t2, t3):
                      [-s2, c2 * s3, c2 * c3]])
 
 
+def _rot_batch(ang):
+    """RotZYX for an (n,3) array of angles -> (n,3,3)."""
+    s1, c1 = np.sin(ang[:, 0]), np.cos(ang[:, 0]); s2, c2 = np.sin(ang[:, 1]), np.cos(ang[:, 1]); s3, c3 = np.sin(ang[:, 2]), np.cos(ang[:, 2])
+    R = np.empty((len(ang), 3, 3))
+    R[:, 0, 0] = c1 * c2; R[:, 0, 1] = c1 * s2 * s3 - s1 * c3; R[:, 0, 2] = c1 * s2 * c3 + s1 * s3
+    R[:, 1, 0] = s1 * c2; R[:, 1, 1] = s1 * s2 * s3 + c1 * c3; R[:, 1, 2] = s1 * s2 * c3 - c1 * s3
+    R[:, 2, 0] = -s2; R[:, 2, 1] = c2 * s3; R[:, 2, 2] = c2 * c3
+    return R
+
+
 def ba_scene(P=5, M=800, obs_per_point=10, seed=0, cam=KITTI_CAM, H=376, W=1241,
              noise_px=0.5, outlier_frac=0.02, n_const=1, perturb=(2e-3, 2e-2, 5e-2)):
     """Windowed BA problem in the reference's flat layout (estimator.jl:16-40):
     theta = [6P (RotZYX t1,t2,t3, t) ; 3M], pixels (O,2) as (y,x), 1-based ids.
     Cameras move forward along +z with a slight curve; each point is seen by a
-    contiguous run of min(obs_per_point, P) key-frames.  Returns a dict."""
+    contiguous run of min(obs_per_point, P) key-frames; pixels = projection +
+    N(0, noise_px); a fraction of observations are wrong associations 4-12 px
+    away; the first n_const poses are constant; theta0 = ground truth perturbed
+    by N(0, perturb = (rad, m pose, m point)).  Observations are ordered by
+    point, then observer (the feeder's order, estimator.jl:186-227)."""
     rng = np.random.default_rng(0xBA00 + seed)
     fx, fy, cx, cy = cam
     k = min(obs_per_point, P)
-    poses = np.zeros((P, 6))
-    for p in range(P):
-        yaw = 0.01 * p
-        # world->camera: R = RotZYX(0, yaw, 0)-ish small rotation about y, camera centre advancing in z
-        R = rotzyx(0.002 * p, yaw, -0.001 * p)
-        c = np.array([0.05 * p * p * 0.01, 0.0, 0.8 * p])
-        poses[p, :3] = (0.002 * p, yaw, -0.001 * p)
-        poses[p, 3:] = -R @ c
-    pts = np.zeros((M, 3))
-    obs_pose, obs_point, pix = [], [], []
-    for m in range(M):
-        start = int(rng.integers(0, P - k + 1))
-        mid = start + k // 2
-        # sample a pixel + depth in the middle camera and back-project
-        for _ in range(50):
-            u = rng.uniform(40, W - 40); v = rng.uniform(40, H - 40); z = rng.uniform(6.0, 40.0) + 0.8 * k
-            Xc = np.array([(u - cx) / fx * z, (v - cy) / fy * z, z])
-            R = rotzyx(*poses[mid, :3])
-            Xw = R.T @ (Xc - poses[mid, 3:])
-            ok = True
-            proj = []
-            for p in range(start, start + k):
-                Rp = rotzyx(*poses[p, :3])
-                xc = Rp @ Xw + poses[p, 3:]
-                if xc[2] < 1.0:
-                    ok = False; break
-                py = fy * xc[1] / xc[2] + cy; px_ = fx * xc[0] / xc[2] + cx
-                if not (1 <= py <= H and 1 <= px_ <= W):
-                    ok = False; break
-                proj.append((py, px_))
-            if ok:
-                break
-        pts[m] = Xw
-        for j, p in enumerate(range(start, start + k)):
-            obs_pose.append(p + 1); obs_point.append(m + 1); pix.append(proj[j] if ok else (cy, cx))
-    pix = np.array(pix) + rng.normal(0, noise_px, (len(pix), 2))
+    idx = np.arange(P, dtype=np.float64)
+    ang = np.stack([0.002 * idx, 0.01 * idx, -0.001 * idx], 1)
+    Rp = _rot_batch(ang)
+    centre = np.stack([1e-4 * idx * idx, np.zeros(P), 0.8 * idx], 1)
+    tp = -np.einsum("pij,pj->pi", Rp, centre)
+    poses = np.concatenate([ang, tp], 1)
+    pts = np.zeros((M, 3)); start = np.zeros(M, dtype=np.int64)
+    todo = np.arange(M)
+    proj = np.zeros((M, k, 2))
+    for _ in range(60):
+        if len(todo) == 0:
+            break
+        n = len(todo)
+        st = rng.integers(0, P - k + 1, n)
+        mid = st + k // 2
+        u = rng.uniform(40, W - 40, n); v = rng.uniform(40, H - 40, n); z = rng.uniform(6.0, 40.0, n) + 0.8 * k
+        Xc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], 1)
+        Xw = np.einsum("nji,nj->ni", Rp[mid], Xc - tp[mid])            # R^T (Xc - t)
+        cams = st[:, None] + np.arange(k)[None, :]                       # (n, k)
+        xc = np.einsum("nkij,nj->nki", Rp[cams], Xw) + tp[cams]
+        py = fy * xc[..., 1] / xc[..., 2] + cy; pxx = fx * xc[..., 0] / xc[..., 2] + cx
+        ok = ((xc[..., 2] > 1.0) & (py >= 1) & (py <= H) & (pxx >= 1) & (pxx <= W)).all(1)
+        good = todo[ok]
+        pts[good] = Xw[ok]; start[good] = st[ok]
+        proj[good, :, 0] = py[ok]; proj[good, :, 1] = pxx[ok]
+        todo = todo[~ok]
+    assert len(todo) == 0, "could not place all points"
+    obs_point = np.repeat(np.arange(1, M + 1, dtype=np.int64), k)
+    obs_pose = (start[:, None] + np.arange(k)[None, :] + 1).reshape(-1).astype(np.int64)
+    pix = proj.reshape(-1, 2) + rng.normal(0, noise_px, (M * k, 2))
     O = len(pix)
     n_out = int(round(outlier_frac * O))
     out_idx = rng.choice(O, n_out, replace=False) if n_out else np.zeros(0, dtype=int)
-    # gross outliers = wrong associations a few px away (a tracker drifting onto a
-    # neighbouring corner), not uniform-in-image: the reference's first LM pass is
-    # not robust (bundle_adjustment.jl:41-45), so far outliers would swamp it.
-    ang = rng.uniform(0, 2 * np.pi, n_out); mag = rng.uniform(4.0, 12.0, n_out)
-    pix[out_idx, 0] += mag * np.sin(ang); pix[out_idx, 1] += mag * np.cos(ang)
+    a = rng.uniform(0, 2 * np.pi, n_out); mag = rng.uniform(4.0, 12.0, n_out)
+    pix[out_idx, 0] += mag * np.sin(a); pix[out_idx, 1] += mag * np.cos(a)
     theta_gt = np.concatenate([poses.ravel(), pts.ravel()])
     theta0 = theta_gt.copy()
     pp = theta0[:6 * P].reshape(P, 6); lp = theta0[6 * P:].reshape(M, 3)
@@ -114,10 +119,9 @@ def ba_scene(P=5, M=800, obs_per_point=10, seed=0, cam=KITTI_CAM, H=376, W=1241,
     pp[free, :3] += rng.normal(0, perturb[0], (free.sum(), 3))
     pp[free, 3:] += rng.normal(0, perturb[1], (free.sum(), 3))
     lp += rng.normal(0, perturb[2], lp.shape)
-    # shuffle observation order so that ids are not sorted (the feeder's order is by point, then observer)
     return dict(cam=cam, P=P, M=M, O=O, theta0=theta0, theta_gt=theta_gt, theta_const=const,
-                pixels_yx=np.ascontiguousarray(pix), pose_ids=np.array(obs_pose, dtype=np.int64),
-                point_ids=np.array(obs_point, dtype=np.int64), gross_outliers=np.sort(out_idx))
+                pixels_yx=np.ascontiguousarray(pix), pose_ids=obs_pose, point_ids=obs_point,
+                gross_outliers=np.sort(out_idx))
 
 
 def pnp_scene(n=300, seed=0, cam=KITTI_CAM, H=376, W=1241, noise_px=0.5, outlier_frac=0.05):
