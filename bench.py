@@ -26,6 +26,7 @@ if ROOT not in sys.path:
 
 KF_EVERY = 5
 N_KPTS = 1000
+CULL_FRACTION = 0.15              # share of tracked keypoints the map drops per key-frame
 SHAPE = "kitti05"
 N_FRAMES = 8                      # distinct rendered frames, played ping-pong
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
@@ -60,6 +61,11 @@ class Stream:
             self.kp, self.is3d = new[st], self.is3d[st]
             self.n_tracked += int(st.sum())
         if self.t % KF_EVERY == 0:
+            # map culling between key-frames (outlier observations dropped by BA, estimator.jl:283-292;
+            # failed triangulations, mapper.jl:142-263): the synthetic scene never loses tracks by itself
+            if len(self.kp):
+                keep = self.rng.random(len(self.kp)) >= CULL_FRACTION
+                self.kp, self.is3d = self.kp[keep], self.is3d[keep]
             fresh = be.detect(self.kp)
             if len(fresh):
                 self.kp = np.concatenate([self.kp, fresh.astype(np.float64)])
@@ -229,7 +235,8 @@ def main():
                                "left pyramid update + FB-LK (3-D prior pass + 2-D pass) per frame; "
                                "detect + right pyramid + stereo FB-LK per key-frame (BASELINE configs[1])",
                    "streams_per_gpu": 1, "parallelism": f"replicas x{world}", "tracked_kpts_per_frame": round(tracked_per_frame, 1),
-                   "window_size": params.window_size, "pyramid_levels": params.pyramid_levels},
+                   "window_size": params.window_size, "pyramid_levels": params.pyramid_levels,
+                   "cull_fraction_per_keyframe": CULL_FRACTION},
     }
     if pyr_n:
         pyr_bytes = pyramid_bytes(H, W, params.pyramid_levels)

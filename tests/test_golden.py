@@ -1,0 +1,48 @@
+"""Committed regression vectors (tests/golden/hotpath_v1.npz, oracle-generated --
+see make_golden.py for why they cannot be reference-generated) against the
+oracle on CPU and against the HIP path on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hotpath_v1.npz"))
+IMG0 = np.asfortranarray(G["img0_u8"].astype(np.float64) / 255)
+IMG1 = np.asfortranarray(G["img1_u8"].astype(np.float64) / 255)
+
+
+def test_oracle_reproduces_golden(orc):
+    assert np.array_equal(orc.detect(IMG0, np.zeros((0, 2)), max_points=60), G["kp_nomask"])
+    assert np.array_equal(orc.detect(IMG0, G["cur"], max_points=60), G["kp_mask"])
+    p0 = orc.pyr_build(IMG0, 2, 1.0, 1); p1 = orc.pyr_build(IMG1, 2, 1.0, 1); pc = orc.pyr_build(IMG0, 2, 1.0, 0)
+    assert np.array_equal(p0.plane("Iy", 1), G["upd_Iy_l1"]) and np.array_equal(p0.plane("Iyx", 2), G["upd_Iyx_l2"])
+    assert np.array_equal(p0.plane("layers", 2), G["upd_layer_l2"])
+    assert np.array_equal(pc.plane("Ixx", 1), G["ctor_Ixx_l1"]) and np.array_equal(pc.plane("layers", 1), G["ctor_layer_l1"])
+    out, st = orc.fb_tracking(p0, p1, G["kp_nomask"].astype(float), sum_order=1, pyramid_levels=2)
+    assert np.array_equal(st, G["lk_status"]) and np.allclose(out[st], G["lk_out"][st], rtol=0, atol=1e-12)
+    th, ol, stats = orc.bundle_adjustment(tuple(G["ba_cam"]), G["ba_theta0"], G["ba_const"], G["ba_pixels"], G["ba_pose_ids"], G["ba_point_ids"], solver=1)
+    assert np.array_equal(ol, G["ba_outliers"]) and np.allclose(th, G["ba_theta"], rtol=0, atol=1e-10)
+    bits, rc = orc.describe(IMG0, G["kp_nomask"], G["brief_pattern"])
+    assert np.array_equal(bits, G["brief_bits"]) and np.array_equal(rc, G["brief_rc"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden(slam):
+    H, W = IMG0.shape
+    e = slam.Extractor(60, 17, (-(-H // 35), -(-W // 35)), 35)
+    assert np.array_equal(slam.detect(e, IMG0, np.zeros((0, 2))), G["kp_nomask"])
+    assert np.array_equal(slam.detect(e, IMG0, G["cur"]), G["kp_mask"])
+    p0 = slam.LKPyramid(shape=(H, W), levels=2); slam.update_(p0, IMG0)
+    p1 = slam.LKPyramid(shape=(H, W), levels=2); slam.update_(p1, IMG1)
+    pc = slam.LKPyramid(IMG0, 2)
+    assert np.array_equal(p0.plane("Iy", 1), G["upd_Iy_l1"]) and np.array_equal(p0.plane("Iyx", 2), G["upd_Iyx_l2"])
+    assert np.array_equal(p0.plane("layers", 2), G["upd_layer_l2"])
+    assert np.array_equal(pc.plane("Ixx", 1), G["ctor_Ixx_l1"]) and np.array_equal(pc.plane("layers", 1), G["ctor_layer_l1"])
+    out, st = slam.fb_tracking_(p0, p1, G["kp_nomask"].astype(float), window_size=9, pyramid_levels=2, max_distance=1.0)
+    assert np.array_equal(st, G["lk_status"]) and np.abs(out[st] - G["lk_out"][st]).max() < 1e-9
+    cache = slam.LocalBACache(G["ba_theta0"].copy(), G["ba_const"], G["ba_pixels"], G["ba_pose_ids"], G["ba_point_ids"])
+    slam.bundle_adjustment_(cache, tuple(G["ba_cam"]))
+    assert np.array_equal(cache.outliers, G["ba_outliers"]) and np.abs(cache.theta - G["ba_theta"]).max() < 1e-6
+    assert abs(cache.stats["ssr_final"] - G["ba_ssr"][2]) < 1e-8 * G["ba_ssr"][2]
+    bits, rc = slam.describe(e, IMG0, G["kp_nomask"], pattern=G["brief_pattern"])
+    assert np.array_equal(bits, G["brief_bits"]) and np.array_equal(rc, G["brief_rc"])
