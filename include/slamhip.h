@@ -128,6 +128,19 @@ int slam_fb_track(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr *cur,
                   double eig_thr, double eps, double max_distance,
                   double *out_yx, uint8_t *status);
 
+/* The array-level body of optical_flow_matching!(map_manager, frame, from, to, stereo)
+ * -- src/map_manager.jl:451-564 -- in one call: keypoints flagged is_3d are first
+ * tracked with the prior displacement (proj - pt) / 2^pyramid_levels_3d on
+ * pyramid_levels_3d levels (:494,504,517-521); the ones that fail join the 2-D
+ * keypoints and are tracked without prior on pyramid_levels levels (:533-552).
+ * Results are identical to issuing the two slam_fb_track calls of the reference
+ * protocol (points are independent).  proj_yx is read only where is_3d != 0. */
+int slam_flow_match(slam_ctx *ctx, const slam_pyr *from, const slam_pyr *to,
+                    const double *pts_yx, const uint8_t *is_3d, const double *proj_yx, int n,
+                    int pyramid_levels, int pyramid_levels_3d, int window, int iterations,
+                    double eig_thr, double eps, double max_distance,
+                    double *out_yx, uint8_t *status);
+
 /* ---- bundle adjustment ------------------------------------------------------ */
 /* bundle_adjustment!(cache::LocalBACache, camera; iterations, repr_eps) --
  * src/bundle_adjustment.jl:1-111 on the flat arrays of src/estimator.jl:16-40:

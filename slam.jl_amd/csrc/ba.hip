@@ -52,10 +52,10 @@ struct BADev {
     const double *pix;           // SoA: py[O], px[O]
     const int *opose, *opoint, *pt_start;
     uint8_t *outl, *hasp;
-    double *f, *ft;              // SoA 2 x O
-    double *Jp, *Jl;             // SoA 12 x O, 6 x O
+    double *f, *ft;              // AoS O x 2
+    double *Jp, *Jl;             // AoS O x 12, O x 6 (a lane reads its observation's block contiguously)
     double *Vinv, *bl;           // SoA 6 x M, 3 x M
-    double *T, *Wm;              // SoA 18 x O each
+    double *T, *Wm;              // AoS O x 18 each
     const int2 *pairs; const int *blk_start; const int2 *blk_pq; int nblk;
     double *S, *g, *udiag;       // reduce buffer views
     double *Swork, *dp, *dl;
@@ -68,6 +68,8 @@ struct slam_ba {
     BADev d;
     void *arena = nullptr;       // one device allocation
     double *reduce = nullptr;    // internal reduce buffer (single-GPU path)
+    int *chol_flag = nullptr;    // device flag: a pivot was not positive
+    double *linv = nullptr;      // inverses of the factored diagonal tiles, nbc x 32 x 32
     std::vector<int> perm;       // sorted position -> original observation index
     int nblocks_obs = 0, nblocks_pts = 0;
 };
@@ -169,11 +171,11 @@ __global__ __launch_bounds__(256) void k_linearize(BADev d, int ignore_outliers,
             }
         }
         d.hasp[i] = hp ? 1 : 0;
-        d.f[i] = r[0]; d.f[O + i] = r[1];
+        d.f[2 * (size_t)i] = r[0]; d.f[2 * (size_t)i + 1] = r[1];
 #pragma unroll
-        for (int k = 0; k < 12; k++) d.Jp[(size_t)k * O + i] = Jp[k];
+        for (int k = 0; k < 12; k++) d.Jp[(size_t)i * 12 + k] = Jp[k];
 #pragma unroll
-        for (int k = 0; k < 6; k++) d.Jl[(size_t)k * O + i] = Jl[k];
+        for (int k = 0; k < 6; k++) d.Jl[(size_t)i * 6 + k] = Jl[k];
         ss = r[0] * r[0] + r[1] * r[1];
     }
     const double t = block_sum(ss, sh);
@@ -200,8 +202,8 @@ __global__ __launch_bounds__(256) void k_points(BADev d, double inv_delta_host, 
     for (int i = t0; i < t1; i++) {
         double jl[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) jl[k] = d.Jl[(size_t)k * O + i];
-        const double f0 = d.f[i], f1 = d.f[O + i];
+        for (int k = 0; k < 6; k++) jl[k] = d.Jl[(size_t)i * 6 + k];
+        const double f0 = d.f[2 * (size_t)i], f1 = d.f[2 * (size_t)i + 1];
         V[0] += jl[0] * jl[0] + jl[3] * jl[3]; V[1] += jl[0] * jl[1] + jl[3] * jl[4]; V[2] += jl[0] * jl[2] + jl[3] * jl[5];
         V[3] += jl[1] * jl[1] + jl[4] * jl[4]; V[4] += jl[1] * jl[2] + jl[4] * jl[5]; V[5] += jl[2] * jl[2] + jl[5] * jl[5];
 #pragma unroll
@@ -216,38 +218,45 @@ __global__ __launch_bounds__(256) void k_points(BADev d, double inv_delta_host, 
     for (int k = 0; k < 6; k++) d.Vinv[(size_t)k * M + j] = Vi[k];
 #pragma unroll
     for (int k = 0; k < 3; k++) d.bl[(size_t)k * M + j] = bl[k];
-    for (int i = t0; i < t1; i++) {
-        if (!d.hasp[i]) {
-            // ignored outlier / constant pose: its pair-list entries must contribute nothing
-            if (!d.pconst[d.opose[i]]) {
+}
+
+// per observation: W = Jp'Jl (6x3), T = W V^-1 of its point
+__global__ __launch_bounds__(256) void k_obs_factors(BADev d, int use_state)
+{
+    if (use_state && d.st->converged) return;
+    const int i = blockIdx.x * 256 + threadIdx.x, M = d.M;
+    if (i >= d.O) return;
+    if (d.pconst[d.opose[i]]) return;                 // never referenced by a pair list
+    double *Wo = d.Wm + (size_t)i * 18, *To = d.T + (size_t)i * 18;
+    if (!d.hasp[i]) {                                  // ignored outlier: its pair-list entries must contribute nothing
 #pragma unroll
-                for (int k = 0; k < 18; k++) { d.Wm[(size_t)k * O + i] = 0.0; d.T[(size_t)k * O + i] = 0.0; }
-            }
-            continue;
-        }
-        double jp[12], jl[6];
+        for (int k = 0; k < 18; k++) { Wo[k] = 0.0; To[k] = 0.0; }
+        return;
+    }
+    const int j = d.opoint[i];
+    double jp[12], jl[6], Vi[6];
 #pragma unroll
-        for (int k = 0; k < 12; k++) jp[k] = d.Jp[(size_t)k * O + i];
+    for (int k = 0; k < 12; k++) jp[k] = d.Jp[(size_t)i * 12 + k];
 #pragma unroll
-        for (int k = 0; k < 6; k++) jl[k] = d.Jl[(size_t)k * O + i];
+    for (int k = 0; k < 6; k++) { jl[k] = d.Jl[(size_t)i * 6 + k]; Vi[k] = d.Vinv[(size_t)k * M + j]; }
 #pragma unroll
-        for (int a = 0; a < 6; a++) {
-            const double w0 = jp[a] * jl[0] + jp[6 + a] * jl[3];
-            const double w1 = jp[a] * jl[1] + jp[6 + a] * jl[4];
-            const double w2 = jp[a] * jl[2] + jp[6 + a] * jl[5];
-            d.Wm[(size_t)(3 * a) * O + i] = w0; d.Wm[(size_t)(3 * a + 1) * O + i] = w1; d.Wm[(size_t)(3 * a + 2) * O + i] = w2;
-            d.T[(size_t)(3 * a) * O + i] = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
-            d.T[(size_t)(3 * a + 1) * O + i] = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
-            d.T[(size_t)(3 * a + 2) * O + i] = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
-        }
+    for (int a = 0; a < 6; a++) {
+        const double w0 = jp[a] * jl[0] + jp[6 + a] * jl[3];
+        const double w1 = jp[a] * jl[1] + jp[6 + a] * jl[4];
+        const double w2 = jp[a] * jl[2] + jp[6 + a] * jl[5];
+        Wo[3 * a] = w0; Wo[3 * a + 1] = w1; Wo[3 * a + 2] = w2;
+        To[3 * a] = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
+        To[3 * a + 1] = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
+        To[3 * a + 2] = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
     }
 }
 
 // One wave per non-zero upper block (p <= q) of the reduced camera system.
-__global__ __launch_bounds__(64) void k_blocks(BADev d, int use_state)
+__global__ __launch_bounds__(256) void k_blocks(BADev d, int use_state)
 {
+    __shared__ double s_red[4][48];
     if (use_state && d.st->converged) return;
-    const int b = blockIdx.x, lane = threadIdx.x, O = d.O, M = d.M, n = d.n;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, M = d.M, n = d.n;
     const int2 pq = d.blk_pq[b];
     const int e0 = d.blk_start[b], e1 = d.blk_start[b + 1];
     double acc[36], gg[6], ud[6];
@@ -255,11 +264,11 @@ __global__ __launch_bounds__(64) void k_blocks(BADev d, int use_state)
     for (int k = 0; k < 36; k++) acc[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; k++) { gg[k] = 0.0; ud[k] = 0.0; }
-    for (int e = e0 + lane; e < e1; e += 64) {
+    for (int e = e0 + tid; e < e1; e += 256) {
         const int2 tt = d.pairs[e];
         double T[18], W2[18];
 #pragma unroll
-        for (int k = 0; k < 18; k++) { T[k] = d.T[(size_t)k * O + tt.x]; W2[k] = d.Wm[(size_t)k * O + tt.y]; }
+        for (int k = 0; k < 18; k++) { T[k] = d.T[(size_t)tt.x * 18 + k]; W2[k] = d.Wm[(size_t)tt.y * 18 + k]; }
 #pragma unroll
         for (int a = 0; a < 6; a++)
 #pragma unroll
@@ -269,8 +278,8 @@ __global__ __launch_bounds__(64) void k_blocks(BADev d, int use_state)
             const int i = tt.x, j = d.opoint[i];
             double jp[12];
 #pragma unroll
-            for (int k = 0; k < 12; k++) jp[k] = d.Jp[(size_t)k * O + i];
-            const double f0 = d.f[i], f1 = d.f[O + i];
+            for (int k = 0; k < 12; k++) jp[k] = d.Jp[(size_t)i * 12 + k];
+            const double f0 = d.f[2 * (size_t)i], f1 = d.f[2 * (size_t)i + 1];
             const double b0 = d.bl[j], b1 = d.bl[(size_t)M + j], b2 = d.bl[(size_t)2 * M + j];
 #pragma unroll
             for (int a = 0; a < 6; a++) {
@@ -290,86 +299,241 @@ __global__ __launch_bounds__(64) void k_blocks(BADev d, int use_state)
             for (int k = 0; k < 6; k++) { gg[k] += __shfl_xor(gg[k], m); ud[k] += __shfl_xor(ud[k], m); }
         }
     }
-    if (lane < 36) {
-        const int a = lane % 6, c = lane / 6;
-        double v = 0.0;
+    // fold the 4 waves in a fixed order through LDS (deterministic)
+    if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 36; k++) if (k == lane) v = acc[k];
+        for (int k = 0; k < 36; k++) s_red[wv][k] = acc[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { s_red[wv][36 + k] = gg[k]; s_red[wv][42 + k] = ud[k]; }
+    }
+    __syncthreads();
+    if (tid < 36) {
+        const int a = tid % 6, c = tid / 6;
+        const double v = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
         d.S[(size_t)(6 * pq.x + a) + (size_t)(6 * pq.y + c) * n] = v;
         if (pq.x != pq.y) d.S[(size_t)(6 * pq.y + c) + (size_t)(6 * pq.x + a) * n] = v;
     }
-    if (pq.x == pq.y && lane < 6) {
-        double v = 0.0, u = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) if (k == lane) { v = gg[k]; u = ud[k]; }
-        d.g[6 * pq.x + lane] = v; d.udiag[6 * pq.x + lane] = u;
+    if (pq.x == pq.y && tid >= 64 && tid < 70) {
+        const int a = tid - 64;
+        d.g[6 * pq.x + a] = ((s_red[0][36 + a] + s_red[1][36 + a]) + s_red[2][36 + a]) + s_red[3][36 + a];
+        d.udiag[6 * pq.x + a] = ((s_red[0][42 + a] + s_red[1][42 + a]) + s_red[2][42 + a]) + s_red[3][42 + a];
     }
 }
 
-// Damped Cholesky solve of the reduced camera system by one workgroup.
-// S is symmetric n x n (col-major) in HBM/L2; right-looking, column by column.
-__global__ __launch_bounds__(1024) void k_solve(BADev d, const double *Sin, const double *gin, const double *udin,
-                                                double inv_delta_host, int use_state)
+// ---- damped solve of the reduced camera system ----------------------------------
+// Tiled right-looking Cholesky over 32x32 tiles, one launch per tile column, every
+// tile of the trailing matrix on its own workgroup.  The right-hand side rides
+// along as row n of the (n+1) x n working matrix, so the forward substitution
+// L y = g falls out of the factorisation (y' = last row of L); a single blocked
+// back-substitution kernel finishes L' dp = y.
+#define CT 32
+struct CholArgs { double *A; int n, ld; int *fail; };
+
+// copy S -> work (lower triangle + rhs row), add the LM damping to the diagonal
+__global__ __launch_bounds__(256) void k_chol_prepare(BADev d, const double *Sin, const double *gin, const double *udin,
+                                                      double inv_delta_host, int use_state)
 {
     if (use_state && d.st->converged) return;
-    const int n = d.n, tid = threadIdx.x, nt = blockDim.x;
+    const int n = d.n, ld = n + 1;
     const double inv_delta = use_state ? 1.0 / d.st->delta : inv_delta_host;
-    double *A = d.Swork;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)ld * n) return;
+    const int i = (int)(idx % ld), j = (int)(idx / ld);
+    double v;
+    if (i == n) v = gin[j];
+    else {
+        v = Sin[(size_t)i + (size_t)j * n];
+        if (i == j) v += fmin(fmax(udin[j], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+    }
+    d.Swork[idx] = v;
+}
+
+// Factor a diagonal tile and invert its triangle, by ONE wave, rows in registers.
+// t (LDS, 32x33): in = tile (lower part, h rows x w valid columns, rows >= w are
+// panel rows riding along), out = L.  inv (LDS): out = L^-1 (w x w lower).
+// Lane i owns row i; column j is exchanged through a 32-double LDS line.  Fully
+// unrolled and predicated (no branches): every lane op is a select on the
+// wave-uniform tile extents.
+__device__ __forceinline__ void tile_potrf_inv(double (*t)[CT + 1], double (*inv)[CT + 1], double *col, int h, int w, int *fail)
+{
+    const int lane = threadIdx.x & 63;
+    double row[CT], rdiag[CT];
+    bool bad = false;
+#pragma unroll
+    for (int m = 0; m < CT; m++) row[m] = (lane < CT) ? t[lane][m] : 0.0;
+#pragma unroll
+    for (int j = 0; j < CT; j++) {
+        const bool active = j < w;
+        double dj = __shfl(row[j], j);
+        bad = bad || (active && !(dj > 0));
+        dj = (active && dj > 0) ? dj : 1.0;
+        const double rd = rsqrt(dj);
+        rdiag[j] = rd;
+        const double l = (lane == j) ? dj * rd : row[j] * rd;
+        row[j] = active ? l : row[j];
+        if (lane < CT) col[lane] = l;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = j + 1; m < CT; m++) {
+            const double lm = col[m];
+            row[m] -= (active && m < w && lane >= m) ? l * lm : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < CT) {
+#pragma unroll
+        for (int m = 0; m < CT; m++) t[lane][m] = (m <= lane && m < w && lane < h) ? row[m] : 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // inverse: lane c solves L x = e_c (forward substitution), x in registers
+    double x[CT];
+#pragma unroll
+    for (int i = 0; i < CT; i++) {
+        double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int m = 0; m < i; m++) sacc -= t[i][m] * x[m];
+        x[i] = (i < w && lane <= i) ? sacc * rdiag[i] : 0.0;
+    }
+    if (lane < CT) {
+#pragma unroll
+        for (int i = 0; i < CT; i++) inv[i][lane] = (lane < w) ? x[i] : 0.0;
+    }
+    if (bad && lane == 0) *fail = 1;
+}
+
+__global__ __launch_bounds__(256) void k_chol_step(BADev d, CholArgs C, double *Linv, int k, int nbr, int use_state)
+{
+    if (use_state && d.st->converged) return;
+    __shared__ double Li[CT][CT + 1], Lr[CT][CT + 1], Lc[CT][CT + 1], Arc[CT][CT + 1], Tmp[CT][CT + 1];
+    __shared__ double col[CT];
+    const int n = C.n, ld = C.ld, tid = threadIdx.x;
+    int r, c;
+    {
+        int b = blockIdx.x, cc = k;
+        const int nbc = (n + CT - 1) / CT;
+        while (true) { const int cnt = nbr - cc; if (b < cnt || cc == nbc - 1) { r = cc + b; c = cc; break; } b -= cnt; cc++; }
+    }
+    if (r == k && c == k) return;                                   // the panel's diagonal tile is already factored
+    const int wk = min(CT, n - CT * k);
+    const int hr = min(CT, n + 1 - CT * r), hc = min(CT, n + 1 - CT * c);
+    const double *Lik = Linv + (size_t)k * CT * CT;
+    for (int e = tid; e < CT * CT; e += 256) {
+        const int i = e % CT, j = e / CT;
+        const int gj = CT * k + j;
+        Li[i][j] = Lik[i + CT * j];
+        const int ri = CT * r + i;
+        Lr[i][j] = (i < hr && j < wk) ? C.A[(size_t)ri + (size_t)gj * ld] : 0.0;
+        if (c > k) {
+            const int ci = CT * c + i;
+            Lc[i][j] = (c != r && i < hc && j < wk) ? C.A[(size_t)ci + (size_t)gj * ld] : 0.0;
+            const int aj = CT * c + j;
+            Arc[i][j] = (i < hr && aj < n && ri >= aj) ? C.A[(size_t)ri + (size_t)aj * ld] : 0.0;
+        }
+    }
+    __syncthreads();
+    // panel solves as small GEMMs: X[i][j] = sum_{m<=j} B[i][m] * Linv[j][m]
+    for (int e = tid; e < CT * CT; e += 256) {
+        const int i = e % CT, j = e / CT;
+        double s0 = 0.0;
+        for (int m = 0; m <= j; m++) s0 += Lr[i][m] * Li[j][m];
+        Tmp[i][j] = s0;
+    }
+    __syncthreads();
+    for (int e = tid; e < CT * CT; e += 256) { const int i = e % CT, j = e / CT; Lr[i][j] = Tmp[i][j]; }
+    if (c > k && c != r) {
+        __syncthreads();
+        for (int e = tid; e < CT * CT; e += 256) {
+            const int i = e % CT, j = e / CT;
+            double s0 = 0.0;
+            for (int m = 0; m <= j; m++) s0 += Lc[i][m] * Li[j][m];
+            Tmp[i][j] = s0;
+        }
+        __syncthreads();
+        for (int e = tid; e < CT * CT; e += 256) { const int i = e % CT, j = e / CT; Lc[i][j] = Tmp[i][j]; }
+    }
+    __syncthreads();
+    if (c == k) {                                                   // panel tile: store L_rk
+        for (int e = tid; e < CT * CT; e += 256) {
+            const int i = e % CT, j = e / CT;
+            if (i < hr && j < wk) C.A[(size_t)(CT * r + i) + (size_t)(CT * k + j) * ld] = Lr[i][j];
+        }
+        return;
+    }
+    const double (*Lcc)[CT + 1] = (c == r) ? Lr : Lc;
+    const int wc = min(CT, n - CT * c);
+    for (int e = tid; e < CT * CT; e += 256) {
+        const int i = e % CT, j = e / CT;
+        if (i < hr && j < wc && CT * r + i >= CT * c + j) {
+            double s0 = Arc[i][j];
+            for (int m = 0; m < wk; m++) s0 -= Lr[i][m] * Lcc[j][m];
+            Arc[i][j] = s0;
+        }
+    }
+    __syncthreads();
+    if (r == k + 1 && c == k + 1) {                                 // next panel's diagonal tile is final now
+        if (tid < 64) tile_potrf_inv(Arc, Tmp, col, hr, wc, C.fail);
+        __syncthreads();
+        double *Lo = Linv + (size_t)(k + 1) * CT * CT;
+        for (int e = tid; e < CT * CT; e += 256) { const int i = e % CT, j = e / CT; Lo[i + CT * j] = Tmp[i][j]; }
+    }
+    for (int e = tid; e < CT * CT; e += 256) {
+        const int i = e % CT, j = e / CT;
+        if (i < hr && j < wc && CT * r + i >= CT * c + j) C.A[(size_t)(CT * r + i) + (size_t)(CT * c + j) * ld] = Arc[i][j];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chol_first(BADev d, CholArgs C, double *Linv, int use_state)
+{
+    if (use_state && d.st->converged) return;
+    __shared__ double t[CT][CT + 1], inv[CT][CT + 1];
+    __shared__ double col[CT];
+    const int n = C.n, ld = C.ld, tid = threadIdx.x;
+    const int h = min(CT, n + 1), w = min(CT, n);
+    for (int e = tid; e < CT * CT; e += 256) { const int i = e % CT, j = e / CT; t[i][j] = (i < h && j < w && i >= j) ? C.A[(size_t)i + (size_t)j * ld] : 0.0; }
+    if (tid == 0) *C.fail = 0;
+    __syncthreads();
+    if (tid < 64) tile_potrf_inv(t, inv, col, h, w, C.fail);
+    __syncthreads();
+    for (int e = tid; e < CT * CT; e += 256) {
+        const int i = e % CT, j = e / CT;
+        if (i < h && j < w && i >= j) C.A[(size_t)i + (size_t)j * ld] = t[i][j];
+        Linv[i + CT * j] = inv[i][j];
+    }
+}
+
+// L' dp = y (y = row n of the factor), blocked from the last tile column upwards;
+// the diagonal solves are mat-vecs with the stored tile inverses.
+__global__ __launch_bounds__(256) void k_chol_backsolve(BADev d, CholArgs C, const double *Linv, int use_state)
+{
+    if (use_state && d.st->converged) return;
     __shared__ double x[SOLVE_MAX_N];
-    __shared__ double s_diag;
-    __shared__ int s_fail;
-    for (size_t i = tid; i < (size_t)n * n; i += nt) A[i] = Sin[i];
-    if (tid == 0) s_fail = 0;
+    __shared__ double xb[CT];
+    const int n = C.n, ld = C.ld, tid = threadIdx.x;
+    for (int a = tid; a < n; a += 256) x[a] = C.A[(size_t)n + (size_t)a * ld];
     __syncthreads();
-    for (int a = tid; a < n; a += nt) {
-        A[(size_t)a + (size_t)a * n] += fmin(fmax(udin[a], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
-        x[a] = gin[a];
-    }
-    __syncthreads();
-    for (int j = 0; j < n; j++) {
-        if (tid == 0) {
-            double dj = A[(size_t)j + (size_t)j * n];
-            if (!(dj > 0)) { s_fail = 1; dj = 1.0; }
-            s_diag = sqrt(dj);
+    const int nbc = (n + CT - 1) / CT;
+    for (int kb = nbc - 1; kb >= 0; kb--) {
+        const int j0 = CT * kb, w = min(CT, n - j0);
+        const double *Li = Linv + (size_t)kb * CT * CT;
+        if (tid < w) {                                              // x_k = Linv' y_k : x[a] = sum_{i>=a} Linv[i][a] y[i]
+            double s0 = 0.0;
+            for (int i = tid; i < w; i++) s0 += Li[i + CT * tid] * x[j0 + i];
+            xb[tid] = s0;
         }
         __syncthreads();
-        const double dj = s_diag;
-        for (int i = j + tid; i < n; i += nt) A[(size_t)i + (size_t)j * n] = (i == j) ? dj : A[(size_t)i + (size_t)j * n] / dj;
+        if (tid < w) x[j0 + tid] = xb[tid];
         __syncthreads();
-        // trailing update: A[i,k] -= L[i,j] L[k,j], j < k <= i < n  (lower triangle)
-        const int m = n - j - 1;
-        for (int idx = tid; idx < m * m; idx += nt) {
-            const int ii = idx % m, kk = idx / m;
-            if (ii < kk) continue;
-            const int i = j + 1 + ii, k = j + 1 + kk;
-            A[(size_t)i + (size_t)k * n] -= A[(size_t)i + (size_t)j * n] * A[(size_t)k + (size_t)j * n];
+        for (int a = tid; a < j0; a += 256) {                       // y_a -= sum_j L[j0+j][a] x[j0+j]
+            double s0 = 0.0;
+            for (int j = 0; j < w; j++) s0 += C.A[(size_t)(j0 + j) + (size_t)a * ld] * x[j0 + j];
+            x[a] -= s0;
         }
         __syncthreads();
     }
-    // forward / backward substitution (single wave, lane-strided dot products)
-    if (tid < 64) {
-        for (int i = 0; i < n; i++) {
-            double s = 0.0;
-            for (int k = tid; k < i; k += 64) s += A[(size_t)i + (size_t)k * n] * x[k];
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-            if (tid == 0) x[i] = (x[i] - s) / A[(size_t)i + (size_t)i * n];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-        }
-        for (int i = n - 1; i >= 0; i--) {
-            double s = 0.0;
-            for (int k = i + 1 + tid; k < n; k += 64) s += A[(size_t)k + (size_t)i * n] * x[k];
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-            if (tid == 0) x[i] = (x[i] - s) / A[(size_t)i + (size_t)i * n];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __syncthreads();
-    for (int a = tid; a < n; a += nt) d.dp[a] = x[a];
-    if (tid == 0 && s_fail) d.st->chol_fail = 1;
+    for (int a = tid; a < n; a += 256) d.dp[a] = x[a];
+    if (tid == 0 && *C.fail) d.st->chol_fail = 1;
 }
 
 __global__ __launch_bounds__(256) void k_backsub(BADev d, int use_state)
@@ -385,9 +549,9 @@ __global__ __launch_bounds__(256) void k_backsub(BADev d, int use_state)
             const double *dp = d.dp + 6 * d.opose[i];
             double a = 0.0, b = 0.0;
 #pragma unroll
-            for (int k = 0; k < 6; k++) { a += d.Jp[(size_t)k * O + i] * dp[k]; b += d.Jp[(size_t)(6 + k) * O + i] * dp[k]; }
+            for (int k = 0; k < 6; k++) { a += d.Jp[(size_t)i * 12 + k] * dp[k]; b += d.Jp[(size_t)i * 12 + 6 + k] * dp[k]; }
 #pragma unroll
-            for (int k = 0; k < 3; k++) bl[k] -= d.Jl[(size_t)k * O + i] * a + d.Jl[(size_t)(3 + k) * O + i] * b;
+            for (int k = 0; k < 3; k++) bl[k] -= d.Jl[(size_t)i * 6 + k] * a + d.Jl[(size_t)i * 6 + 3 + k] * b;
         }
         double Vi[6];
 #pragma unroll
@@ -420,14 +584,14 @@ __global__ __launch_bounds__(256) void k_trial(BADev d, int ignore_outliers, int
             for (int k = 0; k < 6; k++) pose[k] = d.pose_t[6 * p + k];
             obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, nullptr);
         }
-        d.ft[i] = r[0]; d.ft[O + i] = r[1];
+        d.ft[2 * (size_t)i] = r[0]; d.ft[2 * (size_t)i + 1] = r[1];
         double a = 0.0, b = 0.0;
         const double *dp = d.dp + 6 * p, *dl = d.dl + 3 * j;
 #pragma unroll
-        for (int k = 0; k < 6; k++) { a += d.Jp[(size_t)k * O + i] * dp[k]; b += d.Jp[(size_t)(6 + k) * O + i] * dp[k]; }
+        for (int k = 0; k < 6; k++) { a += d.Jp[(size_t)i * 12 + k] * dp[k]; b += d.Jp[(size_t)i * 12 + 6 + k] * dp[k]; }
 #pragma unroll
-        for (int k = 0; k < 3; k++) { a += d.Jl[(size_t)k * O + i] * dl[k]; b += d.Jl[(size_t)(3 + k) * O + i] * dl[k]; }
-        a -= d.f[i]; b -= d.f[O + i];
+        for (int k = 0; k < 3; k++) { a += d.Jl[(size_t)i * 6 + k] * dl[k]; b += d.Jl[(size_t)i * 6 + 3 + k] * dl[k]; }
+        a -= d.f[2 * (size_t)i]; b -= d.f[2 * (size_t)i + 1];
         st = r[0] * r[0] + r[1] * r[1];
         sp = a * a + b * b;
     }
@@ -439,21 +603,33 @@ __global__ __launch_bounds__(256) void k_trial(BADev d, int ignore_outliers, int
 // Sums the partials (fixed order) and, in the single-GPU path, runs the
 // LeastSquaresOptim accept/reject logic.  mode 0: ssr of the current residuals
 // (after k_linearize); mode 1: trial/predicted/maxdx -> state (+ LM decision if lm).
-__global__ void k_control(BADev d, int mode, int nb_obs, int nb_pts, int lm, double *out4)
+// fixed-order strided sum / max of a partials array by one 256-thread workgroup
+__device__ __forceinline__ double ctl_sum(const double *p, int n, int stride, double *sh)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double t = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) t += p[(size_t)i * stride];
+    return block_sum(t, sh);
+}
+__device__ __forceinline__ double ctl_max(const double *p, int n, double *sh)
+{
+    double t = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) t = fmax(t, p[i]);
+    return block_max(t, sh);
+}
+__global__ __launch_bounds__(256) void k_control(BADev d, int mode, int nb_obs, int nb_pts, int lm, double *out4)
+{
+    __shared__ double sh[4];
     LMState *s = d.st;
     if (mode == 0) {
-        double t = 0.0;
-        for (int i = 0; i < nb_obs; i++) t += d.part[i];
-        s->ssr = t;
-        if (out4) out4[0] = t;
+        const double t = ctl_sum(d.part, nb_obs, 1, sh);
+        if (threadIdx.x == 0) { s->ssr = t; if (out4) out4[0] = t; }
         return;
     }
     if (lm && s->converged) return;
-    double mx = 0.0, t = 0.0, p = 0.0;
-    for (int i = 0; i < nb_pts; i++) mx = fmax(mx, d.part[i]);
-    for (int i = 0; i < nb_obs; i++) { t += d.part[nb_pts + 2 * i]; p += d.part[nb_pts + 2 * i + 1]; }
+    const double mx = ctl_max(d.part, nb_pts, sh);
+    const double t = ctl_sum(d.part + nb_pts, nb_obs, 2, sh);
+    const double p = ctl_sum(d.part + nb_pts + 1, nb_obs, 2, sh);
+    if (threadIdx.x != 0) return;
     s->trial_ssr = t; s->pred_ssr = p; s->maxdx = mx;
     if (out4) { out4[0] = t; out4[1] = p; out4[2] = mx; out4[3] = (double)s->chol_fail; }
     if (!lm) return;
@@ -611,7 +787,8 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     const size_t o_Vinv = take((size_t)6 * M * 8 + 8), o_bl = take((size_t)3 * M * 8 + 8);
     const size_t o_T = take((size_t)18 * O * 8 + 8), o_W = take((size_t)18 * O * 8 + 8);
     const size_t o_pairs = take(npairs * 8 + 8), o_bs = take((size_t)(nblk + 1) * 4), o_bpq = take((size_t)nblk * 8 + 8);
-    const size_t o_red = take(((size_t)n * n + 2 * n + 8) * 8), o_Sw = take((size_t)n * n * 8), o_dp = take(n * 8), o_dl = take((size_t)3 * M * 8 + 8);
+    const size_t o_red = take(((size_t)n * n + 2 * n + 8) * 8), o_Sw = take((size_t)(n + 1) * n * 8), o_dp = take(n * 8), o_dl = take((size_t)3 * M * 8 + 8);
+    const size_t o_cf = take(64), o_li = take((size_t)((n + CT - 1) / CT) * CT * CT * 8);
     const size_t o_part = take(((size_t)ba->nblocks_pts + 2 * ba->nblocks_obs + 8) * 8), o_st = take(sizeof(LMState));
     char *A;
     hipError_t e = hipMalloc((void **)&A, off);
@@ -630,6 +807,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     d.S = ba->reduce; d.g = ba->reduce + (size_t)n * n; d.udiag = d.g + n;
     d.Swork = (double *)(A + o_Sw); d.dp = (double *)(A + o_dp); d.dl = (double *)(A + o_dl);
     d.part = (double *)(A + o_part); d.st = (LMState *)(A + o_st);
+    ba->chol_flag = (int *)(A + o_cf); ba->linv = (double *)(A + o_li);
     hipStream_t st = ctx->stream;
 #define UP(dst, src, bytes) do { if ((bytes) > 0) HIP_TRY(ctx, hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
     UP(d.pose, theta, (size_t)n * 8); UP(d.pts, theta + n, (size_t)3 * M * 8);
@@ -653,9 +831,10 @@ static int ba_enqueue_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, dou
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)n * n + 2 * n + 8) * 8, st));
     hipLaunchKernelGGL(k_linearize, dim3(ba->nblocks_obs), dim3(256), 0, st, d, ignore_outliers, use_state);
-    if (!use_state) hipLaunchKernelGGL(k_control, dim3(1), dim3(1), 0, st, d, 0, ba->nblocks_obs, ba->nblocks_pts, 0, red + (size_t)n * n + 2 * n);
+    if (!use_state) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 0, ba->nblocks_obs, ba->nblocks_pts, 0, red + (size_t)n * n + 2 * n);
     if (d.M > 0) hipLaunchKernelGGL(k_points, dim3((d.M + 255) / 256), dim3(256), 0, st, d, inv_delta, use_state);
-    if (d.nblk > 0) hipLaunchKernelGGL(k_blocks, dim3(d.nblk), dim3(64), 0, st, d, use_state);
+    if (d.O > 0) hipLaunchKernelGGL(k_obs_factors, dim3((d.O + 255) / 256), dim3(256), 0, st, d, use_state);
+    if (d.nblk > 0) hipLaunchKernelGGL(k_blocks, dim3(d.nblk), dim3(256), 0, st, d, use_state);
     return SLAM_OK;
 }
 
@@ -665,10 +844,22 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
     BADev d = ba->d;
     const int n = d.n;
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(1024), 0, st, d, red, red + (size_t)n * n, red + (size_t)n * n + n, inv_delta, use_state);
+    {
+        CholArgs C; C.A = d.Swork; C.n = n; C.ld = n + 1; C.fail = ba->chol_flag;
+        const size_t tot = (size_t)(n + 1) * n;
+        hipLaunchKernelGGL(k_chol_prepare, dim3((tot + 255) / 256), dim3(256), 0, st, d, red, red + (size_t)n * n, red + (size_t)n * n + n, inv_delta, use_state);
+        hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, st, d, C, ba->linv, use_state);
+        const int nbc = (n + CT - 1) / CT, nbr = (n + 1 + CT - 1) / CT;
+        for (int k = 0; k < nbc; k++) {
+            int tiles = 0;
+            for (int c = k; c < nbc; c++) tiles += nbr - c;
+            if (tiles > 1) hipLaunchKernelGGL(k_chol_step, dim3(tiles), dim3(256), 0, st, d, C, ba->linv, k, nbr, use_state);
+        }
+        hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(256), 0, st, d, C, (const double *)ba->linv, use_state);
+    }
     hipLaunchKernelGGL(k_backsub, dim3(ba->nblocks_pts), dim3(256), 0, st, d, use_state);
     hipLaunchKernelGGL(k_trial, dim3(ba->nblocks_obs), dim3(256), 0, st, d, ignore_outliers, use_state, ba->nblocks_pts);
-    hipLaunchKernelGGL(k_control, dim3(1), dim3(1), 0, st, d, 1, ba->nblocks_obs, ba->nblocks_pts, lm, out4);
+    hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 1, ba->nblocks_obs, ba->nblocks_pts, lm, out4);
     return SLAM_OK;
 }
 
@@ -784,7 +975,7 @@ int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy, int
     auto run_pass = [&](int ignore, int iters) {
         // f / ssr at the start of the pass (LeastSquaresOptim evaluates f!(fcur, x) first)
         hipLaunchKernelGGL(k_linearize, dim3(ba->nblocks_obs), dim3(256), 0, st, d, ignore, 0);
-        hipLaunchKernelGGL(k_control, dim3(1), dim3(1), 0, st, d, 0, ba->nblocks_obs, ba->nblocks_pts, 0, (double *)nullptr);
+        hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 0, ba->nblocks_obs, ba->nblocks_pts, 0, (double *)nullptr);
         hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, st, d, ignore ? 1 : 0);
         for (int it = 1; it <= iters; it++) {
             ba_enqueue_build(ctx, ba, ignore, 0.0, 1, ba->reduce);

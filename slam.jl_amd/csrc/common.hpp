@@ -46,8 +46,6 @@ struct PyrView {
     int levels;
 };
 
-struct StageJob;   // pyramid.hip
-
 struct slam_pyr {
     int device = 0;
     int levels = 0;                       // total layers = pyramid_levels + 1
@@ -57,9 +55,12 @@ struct slam_pyr {
     double *tmp = nullptr;                // blur scratch, off[levels] doubles
     double *norm = nullptr;               // NA() normaliser per level (ctor mode), lazily built
     double norm_sigma = -1.0;
-    void *jobs = nullptr;                 // device job table (StageJob[])
-    std::vector<int> stage_begin;         // per launch: first job, job count
-    std::vector<int> stage_count;
+    // hipGraph replay of the build (captured lazily per (mode, sigma)); aux = forked stream
+    struct Graph { int mode; double sigma; hipGraphExec_t exec; };
+    std::vector<Graph> graphs;
+    bool graph_failed = false;
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork[SLAM_MAX_LEVELS] = {}, ev_join = nullptr;
     PyrView view;
     double *plane(int p, int l) const { return planes + (int64_t)p * off[levels] + off[l]; }
 };

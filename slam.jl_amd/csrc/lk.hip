@@ -150,31 +150,104 @@ __device__ bool lk_level(const LevelView &first, const LevelView &second, int le
     return true;
 }
 
+// fb_tracking! for one point (tracker.jl:17-66): forward levels, level-1 backward
+// pass from the forward result, consistency test.  Wave-uniform.
+__device__ __forceinline__ bool fb_point(const PyrView &prev, const PyrView &cur, double py, double px, double dy, double dx,
+                                         int pyramid_levels, int window, int iterations, double eig_thr, double eps,
+                                         double max_distance, double &ny, double &nx)
+{
+    bool ok = true;
+    for (int level = pyramid_levels + 1; level >= 1 && ok; level--)
+        ok = lk_level(prev.lv[level - 1], cur.lv[level - 1], level, py, px, dy, dx, window, iterations, eig_thr, eps);
+    if (!ok) return false;
+    ny = py + dy; nx = px + dx;                           // tracker.jl:41-42
+    double by = -dy * 1.0, bx = -dx * 1.0;                // back_displacement, scale = 1/2^0
+    // backward: pyramid_levels = 0, default eps 1e-2 (tracker.jl:34,51-57)
+    ok = lk_level(cur.lv[0], prev.lv[0], 1, ny, nx, by, bx, window, iterations, eig_thr, 1e-2);
+    if (!ok) return false;
+    const double b0 = ny + by, b1 = nx + bx;
+    const double d0 = py - b0, d1 = px - b1;
+    return !(sqrt(d0 * d0 + d1 * d1) >= max_distance);
+}
+
 __global__ __launch_bounds__(64) void k_fb_track(LKArgs A)
 {
     const int i = blockIdx.x;
     const double py = A.pts[2 * i], px = A.pts[2 * i + 1];
-    double dy = A.disp0 ? A.disp0[2 * i] : 0.0, dx = A.disp0 ? A.disp0[2 * i + 1] : 0.0;
-    bool ok = true;
-    for (int level = A.pyramid_levels + 1; level >= 1 && ok; level--)
-        ok = lk_level(A.prev.lv[level - 1], A.cur.lv[level - 1], level, py, px, dy, dx,
-                      A.window, A.iterations, A.eig_thr, A.eps);
+    const double dy = A.disp0 ? A.disp0[2 * i] : 0.0, dx = A.disp0 ? A.disp0[2 * i + 1] : 0.0;
     double ny = nan(""), nx = nan("");
-    if (ok) {
-        ny = py + dy; nx = px + dx;                       // tracker.jl:41-42
-        double by = -dy * 1.0, bx = -dx * 1.0;            // back_displacement, scale = 1/2^0
-        // backward: pyramid_levels = 0, default eps 1e-2 (tracker.jl:34,51-57)
-        ok = lk_level(A.cur.lv[0], A.prev.lv[0], 1, ny, nx, by, bx, A.window, A.iterations, A.eig_thr, 1e-2);
-        if (ok) {
-            const double b0 = ny + by, b1 = nx + bx;
-            const double d0 = py - b0, d1 = px - b1;
-            if (sqrt(d0 * d0 + d1 * d1) >= A.max_distance) ok = false;
-        }
-    }
+    const bool ok = fb_point(A.prev, A.cur, py, px, dy, dx, A.pyramid_levels, A.window, A.iterations, A.eig_thr, A.eps,
+                             A.max_distance, ny, nx);
     if ((threadIdx.x & 63) == 0) {
         A.out[2 * i] = ny; A.out[2 * i + 1] = nx;
         A.status[i] = ok ? 1 : 0;
     }
+}
+
+// optical_flow_matching! on arrays (map_manager.jl:451-564) in ONE launch: a 3-D
+// keypoint is first tracked with its projected prior on `levels3d` levels
+// (:517-521); if that fails (or the point is 2-D) it is tracked without prior on
+// `pyramid_levels` levels (:533-552).  Points are independent, so the reference's
+// two fb_tracking! calls and the list surgery between them collapse into
+// per-point control flow.
+struct FlowArgs {
+    LKArgs lk;
+    const uint8_t *is3d; const double *proj; int levels3d;
+};
+__global__ __launch_bounds__(64) void k_flow_match(FlowArgs F)
+{
+    const LKArgs &A = F.lk;
+    const int i = blockIdx.x;
+    const double py = A.pts[2 * i], px = A.pts[2 * i + 1];
+    double ny = nan(""), nx = nan("");
+    bool ok = false;
+    if (F.is3d[i]) {
+        const double scale = 1.0 / (double)(1 << F.levels3d);
+        const double dy = scale * (F.proj[2 * i] - py), dx = scale * (F.proj[2 * i + 1] - px);      // map_manager.jl:494,504
+        ok = fb_point(A.prev, A.cur, py, px, dy, dx, F.levels3d, A.window, A.iterations, A.eig_thr, A.eps, A.max_distance, ny, nx);
+    }
+    if (!ok) ok = fb_point(A.prev, A.cur, py, px, 0.0, 0.0, A.pyramid_levels, A.window, A.iterations, A.eig_thr, A.eps, A.max_distance, ny, nx);
+    if ((threadIdx.x & 63) == 0) {
+        A.out[2 * i] = ok ? ny : nan(""); A.out[2 * i + 1] = ok ? nx : nan("");
+        A.status[i] = ok ? 1 : 0;
+    }
+}
+
+static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// shared host path: inputs packed into one pinned staging block -> one H2D, one launch, one D2H
+static int run_tracking(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr *cur, const double *pts_yx, const double *aux_yx,
+                        const uint8_t *is3d, int n, int pyramid_levels, int levels3d, int window, int iterations,
+                        double eig_thr, double eps, double max_distance, double *out_yx, uint8_t *status, bool flow)
+{
+    const size_t pb = al256((size_t)n * 16), sb = al256((size_t)n);
+    const size_t in_b = 2 * pb + sb, out_b = pb + sb;
+    char *d, *h;
+    int rc = slam_scratch(ctx, in_b + out_b, (void **)&d);
+    if (rc) return rc;
+    rc = slam_pinned(ctx, in_b + out_b, (void **)&h);
+    if (rc) return rc;
+    memcpy(h, pts_yx, (size_t)n * 16);
+    if (aux_yx) memcpy(h + pb, aux_yx, (size_t)n * 16);
+    if (is3d) memcpy(h + 2 * pb, is3d, (size_t)n);
+    HIP_TRY(ctx, hipMemcpyAsync(d, h, in_b, hipMemcpyHostToDevice, ctx->stream));
+    FlowArgs F;
+    LKArgs &A = F.lk;
+    A.prev = prev->view; A.cur = cur->view;
+    A.pts = (const double *)d; A.disp0 = aux_yx ? (const double *)(d + pb) : nullptr; A.n = n;
+    A.pyramid_levels = pyramid_levels; A.window = window; A.iterations = iterations;
+    A.eig_thr = eig_thr; A.eps = eps; A.max_distance = max_distance;
+    A.out = (double *)(d + in_b); A.status = (uint8_t *)(d + in_b + pb);
+    F.is3d = (const uint8_t *)(d + 2 * pb); F.proj = (const double *)(d + pb); F.levels3d = levels3d;
+    { ProfScope span(ctx, "fb_track");
+      if (flow) hipLaunchKernelGGL(k_flow_match, dim3(n), dim3(64), 0, ctx->stream, F);
+      else hipLaunchKernelGGL(k_fb_track, dim3(n), dim3(64), 0, ctx->stream, A); }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(h + in_b, d + in_b, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out_yx, h + in_b, (size_t)n * 16);
+    memcpy(status, h + in_b + pb, (size_t)n);
+    return SLAM_OK;
 }
 
 extern "C" int slam_fb_track(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr *cur,
@@ -191,25 +264,25 @@ extern "C" int slam_fb_track(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr
         return slam_fail(ctx, SLAM_ERR_LAYERS, "Not enough layers in pyramids.");   // lucas_kanade.jl:12-15
     ARG_TRY(ctx, prev->H[0] == cur->H[0] && prev->W[0] == cur->W[0]);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t pb = (size_t)n * 16, sb = ((size_t)n + 255) & ~(size_t)255;
-    char *s;
-    int rc = slam_scratch(ctx, 3 * pb + sb, (void **)&s);
-    if (rc) return rc;
-    double *d_pts = (double *)s, *d_disp = (double *)(s + pb), *d_out = (double *)(s + 2 * pb);
-    uint8_t *d_st = (uint8_t *)(s + 3 * pb);
-    HIP_TRY(ctx, hipMemcpyAsync(d_pts, pts_yx, pb, hipMemcpyHostToDevice, ctx->stream));
-    if (disp0_yx) HIP_TRY(ctx, hipMemcpyAsync(d_disp, disp0_yx, pb, hipMemcpyHostToDevice, ctx->stream));
-    LKArgs A;
-    A.prev = prev->view; A.cur = cur->view;
-    A.pts = d_pts; A.disp0 = disp0_yx ? d_disp : nullptr; A.n = n;
-    A.pyramid_levels = pyramid_levels; A.window = window; A.iterations = iterations;
-    A.eig_thr = eig_thr; A.eps = eps; A.max_distance = max_distance;
-    A.out = d_out; A.status = d_st;
-    { ProfScope span(ctx, "fb_track");
-      hipLaunchKernelGGL(k_fb_track, dim3(n), dim3(64), 0, ctx->stream, A); }
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(out_yx, d_out, pb, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(status, d_st, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return SLAM_OK;
+    return run_tracking(ctx, prev, cur, pts_yx, disp0_yx, nullptr, n, pyramid_levels, 0, window, iterations, eig_thr, eps,
+                        max_distance, out_yx, status, false);
+}
+
+extern "C" int slam_flow_match(slam_ctx *ctx, const slam_pyr *from, const slam_pyr *to,
+                               const double *pts_yx, const uint8_t *is_3d, const double *proj_yx, int n,
+                               int pyramid_levels, int pyramid_levels_3d, int window, int iterations,
+                               double eig_thr, double eps, double max_distance,
+                               double *out_yx, uint8_t *status)
+{
+    ARG_TRY(ctx, ctx != nullptr && from != nullptr && to != nullptr);
+    ARG_TRY(ctx, n >= 0 && pyramid_levels >= 0 && pyramid_levels_3d >= 0 && window >= 0 && iterations >= 0);
+    if (n == 0) return SLAM_OK;
+    ARG_TRY(ctx, pts_yx != nullptr && is_3d != nullptr && proj_yx != nullptr && out_yx != nullptr && status != nullptr);
+    const int need = pyramid_levels > pyramid_levels_3d ? pyramid_levels : pyramid_levels_3d;
+    if (!(from->levels > need && to->levels > need))
+        return slam_fail(ctx, SLAM_ERR_LAYERS, "Not enough layers in pyramids.");
+    ARG_TRY(ctx, from->H[0] == to->H[0] && from->W[0] == to->W[0]);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return run_tracking(ctx, from, to, pts_yx, proj_yx, is_3d, n, pyramid_levels, pyramid_levels_3d, window, iterations, eig_thr, eps,
+                        max_distance, out_yx, status, true);
 }

@@ -16,6 +16,7 @@
 // coalesced (lanes = consecutive y); column passes walk y inside a lane.
 #include "common.hpp"
 #include <cmath>
+#include <cstdlib>
 
 #define LINE_THREADS 64
 
@@ -394,12 +395,14 @@ static int build_norm(slam_ctx *ctx, slam_pyr *p, double sigma)
 }
 
 // Enqueue the whole pyramid build on ctx->stream; layer 0 must already hold the image.
-static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma)
+// Launch every kernel of one pyramid build.  `st` carries the dependent chain
+// (gradients -> IIR dim 1 -> IIR dim 2 -> resize -> next level); the integral-image
+// passes of level l only feed the LK kernel, so they run on `aux`, concurrently
+// with level l+1 (fork after the row pass, one join at the end).  With
+// aux == st everything is serial on one stream (profiling / fallback path).
+static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf, hipStream_t st, hipStream_t aux, bool spans)
 {
-    IIRPair cf; cf.c[0] = slam_iir_coef(sigma); cf.c[1] = slam_iir_coef(4.0);   // lucas_kanade.jl:112
-    if (mode == 0) { int rc = build_norm(ctx, p, sigma); if (rc) return rc; }
-    hipStream_t st = ctx->stream;
-    ProfScope span_all(ctx, "pyr_update");
+    const bool forked = aux != st;
     for (int l = 0; l < p->levels; l++) {
         const int H = p->H[l], W = p->W[l];
         const size_t n = (size_t)H * W;
@@ -416,16 +419,59 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma)
         ps.p[np] = v.Iyx; ps.coef[np] = 1; np++;
         ps.n = np;
         hipLaunchKernelGGL(k_iir_cols, lines_grid(W, np), dim3(LINE_THREADS), 0, st, ps, has_next ? (const double *)v.L : (const double *)nullptr, H, W, cf);
-        { ProfScope span(ctx, "k_iir_rows");
-          hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np), dim3(LINE_THREADS), 0, st, ps, H, W, cf); }
+        if (spans) { ProfScope span(ctx, "k_iir_rows");
+            hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np), dim3(LINE_THREADS), 0, st, ps, H, W, cf); }
+        else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np), dim3(LINE_THREADS), 0, st, ps, H, W, cf);
+        if (forked) { (void)hipEventRecord(p->ev_fork[l], st); (void)hipStreamWaitEvent(aux, p->ev_fork[l], 0); }
         if (has_next)
             hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256), dim3(256), 0, st,
                                p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], (const double *)T, H, W);
         PlaneSet pc = {};
         pc.p[0] = v.Iyy; pc.p[1] = v.Ixx; pc.p[2] = v.Iyx; pc.n = 3;
-        hipLaunchKernelGGL(k_cum_cols, lines_grid(W, 3), dim3(LINE_THREADS), 0, st, pc, H, W);
-        hipLaunchKernelGGL(k_cum_rows, lines_grid(H, 3), dim3(LINE_THREADS), 0, st, pc, H, W);
+        hipLaunchKernelGGL(k_cum_cols, lines_grid(W, 3), dim3(LINE_THREADS), 0, aux, pc, H, W);
+        hipLaunchKernelGGL(k_cum_rows, lines_grid(H, 3), dim3(LINE_THREADS), 0, aux, pc, H, W);
     }
+    if (forked) { (void)hipEventRecord(p->ev_join, aux); (void)hipStreamWaitEvent(st, p->ev_join, 0); }
+}
+
+// Enqueue the whole pyramid build on ctx->stream; layer 0 must already hold the image.
+// Normal path: one hipGraph replay (captured once per (mode, sigma): two-stream
+// fork/join DAG, ~25 kernel nodes) -> one host launch instead of ~25.  With
+// profiling spans enabled (or SLAMHIP_NO_GRAPH=1) the same kernels are launched
+// directly, serially, so that per-kernel hipEvent spans are meaningful.
+static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma)
+{
+    IIRPair cf; cf.c[0] = slam_iir_coef(sigma); cf.c[1] = slam_iir_coef(4.0);   // lucas_kanade.jl:112
+    if (mode == 0) { int rc = build_norm(ctx, p, sigma); if (rc) return rc; }
+    hipStream_t st = ctx->stream;
+    static const bool no_graph = getenv("SLAMHIP_NO_GRAPH") != nullptr;
+    if (ctx->prof_on || no_graph) {
+        ProfScope span_all(ctx, "pyr_update");
+        launch_build(ctx, p, mode, cf, st, st, ctx->prof_on);
+        HIP_TRY(ctx, hipGetLastError());
+        return SLAM_OK;
+    }
+    hipGraphExec_t exec = nullptr;
+    for (auto &g : p->graphs) if (g.mode == mode && g.sigma == sigma) exec = g.exec;
+    if (!exec && !p->graph_failed) {
+        if (!p->aux) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+            for (int l = 0; l < p->levels; l++) HIP_TRY(ctx, hipEventCreateWithFlags(&p->ev_fork[l], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+        }
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            launch_build(ctx, p, mode, cf, st, p->aux, false);
+            e = hipStreamEndCapture(st, &graph);
+        }
+        if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { (void)hipGetLastError(); p->graph_failed = true; exec = nullptr; }
+        else { slam_pyr::Graph g; g.mode = mode; g.sigma = sigma; g.exec = exec; p->graphs.push_back(g); }
+    }
+    if (exec) HIP_TRY(ctx, hipGraphLaunch(exec, st));
+    else launch_build(ctx, p, mode, cf, st, st, false);
     HIP_TRY(ctx, hipGetLastError());
     return SLAM_OK;
 }
@@ -463,7 +509,12 @@ int slam_pyr_destroy(slam_pyr *p)
     if (p->planes) (void)hipFree(p->planes);
     if (p->tmp) (void)hipFree(p->tmp);
     if (p->norm) (void)hipFree(p->norm);
-    if (p->jobs) (void)hipFree(p->jobs);
+    for (auto &g : p->graphs) (void)hipGraphExecDestroy(g.exec);
+    if (p->aux) {
+        (void)hipStreamDestroy(p->aux);
+        for (int l = 0; l < p->levels; l++) (void)hipEventDestroy(p->ev_fork[l]);
+        (void)hipEventDestroy(p->ev_join);
+    }
     delete p;
     return SLAM_OK;
 }

@@ -118,23 +118,43 @@ def fb_tracking_(previous_pyramid, current_pyramid, keypoints, displacement=None
     return out, status.astype(bool)
 
 
-def optical_flow_matching(from_pyramid, to_pyramid, pixels, is_3d, projections, params, pyramid_levels_3d=1):
+def optical_flow_matching(from_pyramid, to_pyramid, pixels, is_3d, projections, params, pyramid_levels_3d=1,
+                          iterations=30, fused=True, ctx=None):
     """Array-level protocol of optical_flow_matching! (map_manager.jl:451-564):
     3-D keypoints are tracked first with the projected prior on
     `pyramid_levels_3d` levels; the ones that fail join the 2-D keypoints and are
     tracked without prior on params.pyramid_levels levels.
-    Returns (new_pixels (n,2), status (n,) bool)."""
+    Returns (new_pixels (n,2), status (n,) bool).
+
+    fused=True issues ONE slam_flow_match launch; fused=False issues the
+    reference's two fb_tracking! calls (kept for the parity test: identical results)."""
     pixels = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
     n = len(pixels)
-    is_3d = np.asarray(is_3d, dtype=bool)
+    is_3d = np.ascontiguousarray(is_3d, dtype=np.uint8)
+    proj = np.ascontiguousarray(projections, dtype=np.float64).reshape(-1, 2)
+    if fused:
+        ctx = ctx or from_pyramid.ctx
+        if n == 0:
+            return pixels.copy(), np.zeros(0, dtype=bool)
+        out = np.empty((n, 2)); status = np.zeros(n, dtype=np.uint8)
+        rc = ctx.lib.slam_flow_match(ctx.h, from_pyramid.h, to_pyramid.h, L.ptr(pixels), L.ptr(is_3d, L.u8p), L.ptr(proj), n,
+                                     params.pyramid_levels, pyramid_levels_3d, params.window_size, iterations, 1e-4, 1e-2,
+                                     float(params.max_ktl_distance), L.ptr(out), L.ptr(status, L.u8p))
+        if rc == -3:
+            raise RuntimeError("Not enough layers in pyramids.")
+        ctx.check(rc)
+        st = status.astype(bool)
+        new = pixels.copy(); new[st] = out[st]
+        return new, st
+    is3 = is_3d.astype(bool)
     new = pixels.copy()
     status = np.zeros(n, dtype=bool)
-    ids3 = np.where(is_3d)[0]
-    ids2 = list(np.where(~is_3d)[0])
+    ids3 = np.where(is3)[0]
+    ids2 = list(np.where(~is3)[0])
     scale = 1.0 / 2.0 ** pyramid_levels_3d
     if len(ids3):
-        disp = scale * (np.asarray(projections, dtype=np.float64).reshape(-1, 2)[ids3] - pixels[ids3])   # map_manager.jl:494,504
-        nk, st = fb_tracking_(from_pyramid, to_pyramid, pixels[ids3], displacement=disp,
+        disp = scale * (proj[ids3] - pixels[ids3])                                                       # map_manager.jl:494,504
+        nk, st = fb_tracking_(from_pyramid, to_pyramid, pixels[ids3], displacement=disp, iterations=iterations,
                               pyramid_levels=pyramid_levels_3d, window_size=params.window_size,
                               max_distance=params.max_ktl_distance)
         ok = ids3[st]
@@ -142,7 +162,7 @@ def optical_flow_matching(from_pyramid, to_pyramid, pixels, is_3d, projections, 
         ids2 += list(ids3[~st])                                                                        # map_manager.jl:533-538
     if len(ids2):
         ids2 = np.asarray(ids2)
-        nk, st = fb_tracking_(from_pyramid, to_pyramid, pixels[ids2], pyramid_levels=params.pyramid_levels,
+        nk, st = fb_tracking_(from_pyramid, to_pyramid, pixels[ids2], iterations=iterations, pyramid_levels=params.pyramid_levels,
                               window_size=params.window_size, max_distance=params.max_ktl_distance)
         ok = ids2[st]
         new[ok] = nk[st]; status[ok] = True

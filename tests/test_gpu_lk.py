@@ -94,5 +94,7 @@ def test_optical_flow_matching_protocol(slam, orc, texture):
     proj = kp + np.array(flows[1])
     proj[::10] += 40.0                                                       # bad priors fall back to the 2-D pass
     new, st = slam.optical_flow_matching(g[0], g[1], kp, is3d, proj, slam.Params())
+    new2, st2 = slam.optical_flow_matching(g[0], g[1], kp, is3d, proj, slam.Params(), fused=False)
+    assert np.array_equal(st, st2) and np.array_equal(new, new2)             # one launch == the reference's two calls
     assert st.mean() > 0.6
     assert np.abs(np.median((new - kp)[st], 0) - np.array(flows[1])).max() < 0.05
