@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ba", action="store_true", help="skip the BA measurements")
+    ap.add_argument("--batch-streams", type=int, default=8, help="extra measurement: S concurrent streams per GPU (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -259,6 +260,49 @@ def main():
                                      "frac": pyr_bytes / (pyr_ms / pyr_n * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         out["device_ms_per_step"] = {"pyr_update_serial_launches": pyr_ms / prof_steps, "fb_track": fb_ms / prof_steps, "detect": det_ms / prof_steps,
                                      "spans_over_steps": prof_steps, "launches": {"pyr_update": pyr_n, "fb_track": fb_n, "detect": det_n}}
+
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_pyramid.json")
+    if "roofline" in out and SHAPE == "kitti05" and os.path.exists(pmc):
+        out["roofline"]["traffic"] = json.load(open(pmc))["summary"]["k_iir_rows_bytes_per_launch"]
+        out["roofline"]["traffic_source"] = "profiles/r01_pmc_pyramid.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 corrected)"
+
+    # ---- throughput mode: S independent stereo streams per GPU, one host thread + slam_ctx (HIP stream) each ----
+    if args.batch_streams > 1:
+        import threading
+        S = args.batch_streams
+        k_b = max(20, args.steps // 2)
+        ctxs = [slam.Context(local_rank) for _ in range(S)]
+        streams = []
+        for i in range(S):
+            b = GpuBackend(slam, ctxs[i], H, W, left_dev, right_dev, params, extractor)
+            st_i = Stream(b, flows, disparity, seed=100 + i)
+            b.swap_and_update_left(seq[0]); ctxs[i].synchronize()
+            for j in range(6):
+                st_i.step(seq[j], seq[j + 1])
+            streams.append(st_i)
+        gate = threading.Barrier(S + 1)
+
+        def work(st_i, c):
+            gate.wait()
+            for j in range(6, 6 + k_b):
+                st_i.step(seq[j], seq[j + 1])
+            c.synchronize()
+            gate.wait()
+        th = [threading.Thread(target=work, args=(streams[i], ctxs[i])) for i in range(S)]
+        for t in th:
+            t.start()
+        barrier(); gate.wait(); t0 = time.perf_counter(); gate.wait(); dtb = time.perf_counter() - t0
+        for t in th:
+            t.join()
+        if world > 1:
+            tt = torch.tensor([dtb], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtb = float(tt[0])
+        out["batched"] = {"streams_per_gpu": S, "steps_per_stream": k_b, "value": world * S * k_b / dtb, "unit": "frames/sec",
+                          "note": "S independent streams of the same workload per GPU (one host thread + HIP stream each); "
+                                  "the sequential recurrences leave most of the chip idle for one stream"}
+        for c in ctxs:
+            c.close()
 
     # ---- BA: 50-KF window (BASELINE metric), single GPU; sharded over all ranks when N > 1 -------------
     if not args.no_ba:

@@ -68,6 +68,14 @@ def load():
             raise SlamHipError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C slam.jl_amd/csrc`. There is no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64; two HIP runtimes in one process
+        # cannot both own the device.  Load torch's first so that libslamhip.so binds
+        # to the same runtime (needed anyway to exchange device pointers with torch
+        # tensors in bench.py / sharded_ba.py).  Harmless when torch is absent.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)      # AttributeError if the symbol is not exported

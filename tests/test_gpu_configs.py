@@ -1,0 +1,57 @@
+"""GPU parity on the other BASELINE.json shapes (configs[3] EuRoC-style 480x640 mono,
+configs[4] synthetic FHD 1080x1920 / 4000 kpts) and the sharded-BA entry points."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+PLANES = ("layers", "Iy", "Ix", "Iyy", "Ixx", "Iyx")
+
+
+@pytest.mark.parametrize("H,W,maxp", [(480, 640, 1000), (1080, 1920, 4000)])
+def test_front_end_shapes(slam, orc, texture, H, W, maxp):
+    L, R, flows = texture(H, W)
+    g = []
+    for im in L[:2]:
+        lk = slam.LKPyramid(shape=(H, W), levels=3); slam.update_(lk, im); g.append(lk)
+    ref = [orc.pyr_build(im, 3, 1.0, 1) for im in L[:2]]
+    for l in (0, 3):
+        for name in PLANES:
+            assert np.array_equal(g[1].plane(name, l), ref[1].plane(name, l)), (name, l)
+    e = slam.Extractor(maxp, 17, (-(-H // 35), -(-W // 35)), 35)
+    kp = slam.detect(e, g[0], np.zeros((0, 2)))
+    assert np.array_equal(kp, orc.detect(L[0], np.zeros((0, 2)), max_points=maxp))
+    pts = kp[:1500].astype(float)
+    out, st = slam.fb_tracking_(g[0], g[1], pts, window_size=9, pyramid_levels=3, max_distance=1.0)
+    ro, rs = orc.fb_tracking(ref[0], ref[1], pts, sum_order=1, threads=4)
+    assert np.array_equal(st, rs) and np.abs(out[st] - ro[st]).max() < 1e-9
+    assert st.mean() > 0.7
+
+
+def test_sharded_driver_on_one_gpu_matches_single_call(slam, syn):
+    """world_size 1 through the multi-GPU entry points (slam_ba_create/build/solve/
+    commit/flag_outliers/download) == slam_local_ba."""
+    from slam_jl_amd import sharded_ba
+    s = syn.ba_scene(P=12, M=1500, seed=21)
+    th, ol, st = sharded_ba.sharded_bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+    cache = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+    slam.bundle_adjustment_(cache, s["cam"])
+    assert np.array_equal(ol, cache.outliers)
+    assert st["iters_pass1"] == cache.stats["iters_pass1"] and st["iters_pass2"] == cache.stats["iters_pass2"]
+    assert abs(st["ssr_final"] - cache.stats["ssr_final"]) <= 1e-9 * cache.stats["ssr_final"]
+    assert np.abs(th - cache.theta).max() <= 1e-9 * max(1.0, np.abs(th).max())
+
+
+def test_profiling_spans(slam, texture):
+    ctx = slam.default_context(0)
+    L = texture(120, 160)[0]
+    lk = slam.LKPyramid(shape=(120, 160), levels=3)
+    ctx.prof_enable(True); ctx.prof_reset()
+    for _ in range(3):
+        slam.update_(lk, L[0])
+    ms, n = ctx.prof_get("pyr_update"); ms2, n2 = ctx.prof_get("k_iir_rows")
+    ctx.prof_enable(False)
+    assert n == 3 and n2 == 12 and 0 < ms2 < ms
+    slam.update_(lk, L[1])                                     # graph path gives the same planes as the span path
+    a = lk.plane("Iyx", 2)
+    ctx.prof_enable(True); slam.update_(lk, L[1]); ctx.prof_enable(False)
+    assert np.array_equal(a, lk.plane("Iyx", 2))
