@@ -51,16 +51,17 @@ class Stream:
         self.t = 0
         self.n_tracked = 0
 
-    def step(self, f_prev, f_cur):
+    def step(self, f_prev, f_cur, f_next=None):
         be = self.be
-        be.swap_and_update_left(f_cur)
+        kf = self.t % KF_EVERY == 0
+        be.begin_frame(f_cur, f_next, kf)
         if len(self.kp):
             flow = np.array(self.flows[f_cur]) - np.array(self.flows[f_prev])
             proj = self.kp + flow + self.rng.normal(0, 0.5, self.kp.shape)       # motion-model prior, ~0.5 px off
             new, st = be.match(False, self.kp, self.is3d, proj)
             self.kp, self.is3d = new[st], self.is3d[st]
             self.n_tracked += int(st.sum())
-        if self.t % KF_EVERY == 0:
+        if kf:
             # map culling between key-frames (outlier observations dropped by BA, estimator.jl:283-292;
             # failed triangulations, mapper.jl:142-263): the synthetic scene never loses tracks by itself
             if len(self.kp):
@@ -70,7 +71,6 @@ class Stream:
             if len(fresh):
                 self.kp = np.concatenate([self.kp, fresh.astype(np.float64)])
                 self.is3d = np.concatenate([self.is3d, np.zeros(len(fresh), dtype=bool)])
-            be.update_right(f_cur)
             proj = self.kp + np.array([0.0, -self.disparity])
             _, st = be.match(True, self.kp, self.is3d, proj)
             self.is3d = self.is3d | st                                            # stereo-matched -> triangulated
@@ -78,26 +78,53 @@ class Stream:
 
 
 class GpuBackend:
-    def __init__(self, slam, ctx, H, W, left_dev, right_dev, params, extractor):
-        self.slam, self.ctx, self.params, self.e = slam, ctx, params, extractor
-        self.left, self.right = left_dev, right_dev
-        self.prev = slam.LKPyramid(shape=(H, W), levels=params.pyramid_levels, ctx=ctx)
-        self.cur = slam.LKPyramid(shape=(H, W), levels=params.pyramid_levels, ctx=ctx)
+    """Two contexts (HIP streams) per stereo stream, like the reference's front-end and
+    mapper tasks: `ctx` tracks / detects, `ctx_pyr` builds pyramids.  The pyramid of
+    frame t+1 does not depend on the tracking result of frame t, so it is enqueued
+    before the (synchronous) tracking call of frame t and overlaps it on the GPU;
+    three left pyramids rotate so a build never overwrites planes still being read."""
+
+    def __init__(self, slam, ctx, ctx_pyr, ctx_right, H, W, left_dev, right_dev, params, extractor, pipelined=True):
+        self.slam, self.ctx, self.ctx_pyr, self.ctx_right, self.params, self.e = slam, ctx, ctx_pyr, ctx_right, params, extractor
+        self.left, self.right, self.pipelined = left_dev, right_dev, pipelined
+        self.pyr = [slam.LKPyramid(shape=(H, W), levels=params.pyramid_levels, ctx=ctx) for _ in range(3)]
         self.rpyr = slam.LKPyramid(shape=(H, W), levels=params.pyramid_levels, ctx=ctx)
+        self.i = 0                 # self.pyr[i] = current frame, [i-1] = previous, [i+1] = being built
+        self.next_built = None
 
-    def swap_and_update_left(self, f):
-        self.prev, self.cur = self.cur, self.prev        # copy!(prev, cur) as a handle swap (pyramid.jl:28)
-        self.slam.update_(self.cur, None, device_ptr=self.left[f].data_ptr(), sync=False)
+    @property
+    def cur(self):
+        return self.pyr[self.i % 3]
 
-    def update_right(self, f):
-        self.slam.update_(self.rpyr, None, device_ptr=self.right[f].data_ptr(), sync=False)
+    @property
+    def prev(self):
+        return self.pyr[(self.i - 1) % 3]
+
+    def prime(self, f):
+        self.slam.update_(self.cur, None, device_ptr=self.left[f].data_ptr(), sync=True, ctx=self.ctx_pyr)
+
+    def begin_frame(self, f_cur, f_next, kf):
+        self.i += 1                                       # copy!(prev, cur) as a handle rotation (pyramid.jl:28)
+        if self.next_built != f_cur or not self.pipelined:
+            self.slam.update_(self.cur, None, device_ptr=self.left[f_cur].data_ptr(), sync=False, ctx=self.ctx_pyr)
+        if kf:                                            # right image of a key-frame, on its own stream (mapper task, mapper.jl:52)
+            self.slam.update_(self.rpyr, None, device_ptr=self.right[f_cur].data_ptr(), sync=False, ctx=self.ctx_right)
+        self.ctx.wait_for(self.ctx_pyr)                   # tracking below needs the left builds enqueued so far
+        if self.pipelined and f_next is not None:
+            self.slam.update_(self.pyr[(self.i + 1) % 3], None, device_ptr=self.left[f_next].data_ptr(), sync=False, ctx=self.ctx_pyr)
+            self.next_built = f_next
 
     def match(self, stereo, kp, is3d, proj):
         a, b = (self.cur, self.rpyr) if stereo else (self.prev, self.cur)
-        return self.slam.optical_flow_matching(a, b, kp, is3d, proj, self.params)
+        if stereo:
+            self.ctx.wait_for(self.ctx_right)
+        return self.slam.optical_flow_matching(a, b, kp, is3d, proj, self.params, ctx=self.ctx)
 
     def detect(self, cur):
         return self.slam.detect(self.e, self.cur, cur, ctx=self.ctx)
+
+    def drain(self):
+        self.ctx_pyr.synchronize(); self.ctx_right.synchronize(); self.ctx.synchronize()
 
 
 class CpuBackend:
@@ -108,15 +135,15 @@ class CpuBackend:
         self.prev = self.cur = self.rpyr = None
         self.img = None
 
-    def swap_and_update_left(self, f):
-        self.prev = self.cur
-        self.img = self.left[f]
-        self.cur = self.orc.pyr_build(self.img, self.params.pyramid_levels, self.params.pyramid_sigma, 1)
-        if self.prev is None:
-            self.prev = self.cur
+    def prime(self, f):
+        self.cur = self.orc.pyr_build(self.left[f], self.params.pyramid_levels, self.params.pyramid_sigma, 1)
 
-    def update_right(self, f):
-        self.rpyr = self.orc.pyr_build(self.right[f], self.params.pyramid_levels, self.params.pyramid_sigma, 1)
+    def begin_frame(self, f_cur, f_next, kf):
+        self.prev = self.cur
+        self.img = self.left[f_cur]
+        self.cur = self.orc.pyr_build(self.img, self.params.pyramid_levels, self.params.pyramid_sigma, 1)
+        if kf:
+            self.rpyr = self.orc.pyr_build(self.right[f_cur], self.params.pyramid_levels, self.params.pyramid_sigma, 1)
 
     def _fb(self, a, b, pts, disp, levels):
         return self.orc.fb_tracking(a, b, pts, disp, 30, self.params.window_size, levels, 1e-4, 1e-2,
@@ -195,23 +222,24 @@ def main():
     right_dev = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in right]
     torch.cuda.synchronize()
 
-    be = GpuBackend(slam, ctx, H, W, left_dev, right_dev, params, extractor)
+    ctx_pyr = slam.Context(local_rank); ctx_right = slam.Context(local_rank)
+    be = GpuBackend(slam, ctx, ctx_pyr, ctx_right, H, W, left_dev, right_dev, params, extractor)
     stream = Stream(be, flows, disparity, seed=rank)
-    seq = frame_sequence(args.warmup + args.steps + 1)   # the ping-pong sequence is periodic: later passes re-index it
-    be.swap_and_update_left(seq[0]); ctx.synchronize()
+    seq = frame_sequence(args.warmup + args.steps + 202)   # the ping-pong sequence is periodic
+    be.prime(seq[0])
 
     def barrier():
-        ctx.synchronize(); torch.cuda.synchronize()
+        be.drain(); torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
     for i in range(args.warmup):
-        stream.step(seq[i], seq[i + 1])
+        stream.step(seq[i], seq[i + 1], seq[i + 2])
     kp_before = stream.n_tracked
     barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
-        stream.step(seq[i], seq[i + 1])
+        stream.step(seq[i], seq[i + 1], seq[i + 2])
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -223,16 +251,19 @@ def main():
     # the library stream.  Spans force the direct-launch path (the timed region above
     # replays the pyramid build as one hipGraph, which events cannot look inside).
     prof_steps = min(args.steps, 100)
-    ctx.prof_enable(True); ctx.prof_reset()
+    be.pipelined = False
+    for c in (ctx, ctx_pyr, ctx_right):
+        c.prof_enable(True); c.prof_reset()
     base = args.warmup + args.steps
-    seq2 = frame_sequence(base + prof_steps + 1)
     for i in range(base, base + prof_steps):
-        stream.step(seq2[i], seq2[i + 1])
-    pyr_ms, pyr_n = ctx.prof_get("pyr_update")
-    rows_ms, rows_n = ctx.prof_get("k_iir_rows")
+        stream.step(seq[i], seq[i + 1], seq[i + 2])
+    pyr_ms, pyr_n = [a + b for a, b in zip(ctx_pyr.prof_get("pyr_update"), ctx_right.prof_get("pyr_update"))]
+    rows_ms, rows_n = [a + b for a, b in zip(ctx_pyr.prof_get("k_iir_rows"), ctx_right.prof_get("k_iir_rows"))]
     fb_ms, fb_n = ctx.prof_get("fb_track")
     det_ms, det_n = ctx.prof_get("detect")
-    ctx.prof_enable(False)
+    for c in (ctx, ctx_pyr, ctx_right):
+        c.prof_enable(False)
+    be.pipelined = True
     tracked_per_frame = n_tracked_timed / max(args.steps, 1)
 
     out = {
@@ -244,7 +275,8 @@ def main():
         "config": {"workload": "KITTI-05-shaped stereo stream 370x1226 f64, 1000 kpts/frame, key-frame every 5th frame: "
                                "left pyramid update + FB-LK (3-D prior pass + 2-D pass) per frame; "
                                "detect + right pyramid + stereo FB-LK per key-frame (BASELINE configs[1])",
-                   "streams_per_gpu": 1, "parallelism": f"replicas x{world}", "tracked_kpts_per_frame": round(tracked_per_frame, 1),
+                   "streams_per_gpu": 1, "parallelism": f"replicas x{world}",
+                   "pipelining": "3 HIP streams per stereo stream (tracking/detect; left pyramids; right pyramids), like the reference's front-end / mapper tasks: the next frame's pyramid build (one hipGraph replay) overlaps the current frame's tracking", "tracked_kpts_per_frame": round(tracked_per_frame, 1),
                    "window_size": params.window_size, "pyramid_levels": params.pyramid_levels,
                    "cull_fraction_per_keyframe": CULL_FRACTION},
     }
@@ -271,24 +303,24 @@ def main():
         import threading
         S = args.batch_streams
         k_b = max(20, args.steps // 2)
-        ctxs = [slam.Context(local_rank) for _ in range(S)]
+        ctxs = [slam.Context(local_rank) for _ in range(3 * S)]
         streams = []
         for i in range(S):
-            b = GpuBackend(slam, ctxs[i], H, W, left_dev, right_dev, params, extractor)
+            b = GpuBackend(slam, ctxs[3 * i], ctxs[3 * i + 1], ctxs[3 * i + 2], H, W, left_dev, right_dev, params, extractor)
             st_i = Stream(b, flows, disparity, seed=100 + i)
-            b.swap_and_update_left(seq[0]); ctxs[i].synchronize()
+            b.prime(seq[0])
             for j in range(6):
-                st_i.step(seq[j], seq[j + 1])
+                st_i.step(seq[j], seq[j + 1], seq[j + 2])
             streams.append(st_i)
         gate = threading.Barrier(S + 1)
 
-        def work(st_i, c):
+        def work(st_i):
             gate.wait()
             for j in range(6, 6 + k_b):
-                st_i.step(seq[j], seq[j + 1])
-            c.synchronize()
+                st_i.step(seq[j], seq[j + 1], seq[j + 2])
+            st_i.be.drain()
             gate.wait()
-        th = [threading.Thread(target=work, args=(streams[i], ctxs[i])) for i in range(S)]
+        th = [threading.Thread(target=work, args=(streams[i],)) for i in range(S)]
         for t in th:
             t.start()
         barrier(); gate.wait(); t0 = time.perf_counter(); gate.wait(); dtb = time.perf_counter() - t0
@@ -333,10 +365,10 @@ def main():
         cbe = CpuBackend(orc, left, right, params, extractor, threads)
         cs = Stream(cbe, flows, disparity, seed=0)
         cseq = frame_sequence(16)
-        cbe.swap_and_update_left(cseq[0])
+        cbe.prime(cseq[0])
         n_cpu = 0; t0 = time.perf_counter()
         while n_cpu < 15 and (time.perf_counter() - t0 < 25 or n_cpu < 6):
-            cs.step(cseq[n_cpu], cseq[n_cpu + 1]); n_cpu += 1
+            cs.step(cseq[n_cpu], cseq[n_cpu + 1], None); n_cpu += 1
         cdt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": n_cpu / cdt, "unit": "frames/sec", "cores": threads, "kind": "port",
                                "sample": f"first {n_cpu} frames of the same stream (incl. {1 + (n_cpu - 1) // KF_EVERY} key-frames) through the C oracle "

@@ -48,6 +48,12 @@ enum slam_status {
 int  slam_ctx_create(int device, slam_ctx **out);
 int  slam_ctx_destroy(slam_ctx *ctx);
 int  slam_ctx_synchronize(slam_ctx *ctx);
+/* Device-side ordering between two contexts of one device: work enqueued on `ctx`
+ * after this call waits for everything enqueued on `other` so far (no host block).
+ * Lets a caller overlap asynchronous calls on two contexts the way the reference
+ * overlaps its front-end and mapper tasks (SLAM.jl:166, mapper.jl:37-66), e.g.
+ * slam_pyr_update_dev(other, next frame, sync=0) while `ctx` tracks the current one. */
+int  slam_ctx_wait_for(slam_ctx *ctx, slam_ctx *other);
 /* the ctx's hipStream_t (as void*), for callers that record HIP events on it */
 void *slam_ctx_stream(slam_ctx *ctx);
 /* message of the last failing call on ctx (ctx == NULL: last ctx-less failure) */

@@ -22,6 +22,7 @@ SIGNATURES = {
     "slam_ctx_destroy": (cint, [vp]),
     "slam_ctx_synchronize": (cint, [vp]),
     "slam_ctx_stream": (vp, [vp]),
+    "slam_ctx_wait_for": (cint, [vp, vp]),
     "slam_last_error": (C.c_char_p, [vp]),
     "slam_version": (C.c_char_p, []),
     "slam_prof_enable": (cint, [vp, cint]),
@@ -119,6 +120,10 @@ class Context:
         ms, n = C.c_double(), C.c_int64()
         self.check(self.lib.slam_prof_get(self.h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def wait_for(self, other):
+        """Device-side: later work on this context waits for what `other` has enqueued so far."""
+        self.check(self.lib.slam_ctx_wait_for(self.h, other.h))
 
     def synchronize(self):
         self.check(self.lib.slam_ctx_synchronize(self.h))

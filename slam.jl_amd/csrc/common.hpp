@@ -19,6 +19,7 @@ struct slam_ctx {
     void *scratch = nullptr; size_t scratch_bytes = 0;
     void *scratch2 = nullptr; size_t scratch2_bytes = 0;
     void *pinned = nullptr; size_t pinned_bytes = 0;
+    hipEvent_t wait_event = nullptr;      // slam_ctx_wait_for
     // optional device-side timing (hipEvents on ctx->stream), see slam_prof_*
     bool prof_on = false;
     struct ProfSpan { int id; hipEvent_t a, b; };

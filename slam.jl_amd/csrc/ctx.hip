@@ -113,6 +113,7 @@ int slam_ctx_destroy(slam_ctx *ctx)
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
     for (auto &sp : ctx->prof_pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
@@ -128,6 +129,16 @@ int slam_ctx_synchronize(slam_ctx *ctx)
 }
 
 void *slam_ctx_stream(slam_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int slam_ctx_wait_for(slam_ctx *ctx, slam_ctx *other)
+{
+    ARG_TRY(ctx, ctx != nullptr && other != nullptr && ctx->device == other->device);
+    if (ctx == other) return SLAM_OK;
+    if (!ctx->wait_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wait_event, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->wait_event, other->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->wait_event, 0));
+    return SLAM_OK;
+}
 
 const char *slam_last_error(slam_ctx *ctx) { return ctx ? ctx->err.c_str() : g_slam_err.c_str(); }
 

@@ -108,7 +108,7 @@ struct RowIO {
 struct ColIO {
     const double *src; double *dst;     // plane bases
     int H, W, x0;                       // first column of this wave
-    double *lds;                        // 64 x 9 doubles
+    double *lds;                        // 4 x (64 x 9) doubles: in[2], out[2]
     __device__ __forceinline__ int xown() const { int x = x0 + (int)(threadIdx.x & 63); return x < W ? x : W - 1; }
     __device__ __forceinline__ bool valid() const { return x0 + (int)(threadIdx.x & 63) < W; }
     __device__ __forceinline__ double ld_src(int i) const { return src[(size_t)i + (size_t)xown() * H]; }
@@ -134,28 +134,42 @@ struct ColIO {
             if (col < W) dst[(size_t)(r0 + rr) + (size_t)col * H] = t[r];
         }
     }
-    // tile registers -> the lane's own 8 samples (in sweep order)
-    __device__ __forceinline__ void to_own(const double t[8], double v[8], bool rev) const
+    // The transposes go through LDS: tile registers --ds_write--> [col][row] --ds_read--> the lane's own
+    // 8 samples (in sweep order), and back for the results.  Both round trips are software-pipelined
+    // against the recurrence: while the dependent f64 chain of chunk c runs, the input transpose of
+    // chunk c+1 and the output transpose of chunk c-1 are in flight (double-buffered LDS tiles), so
+    // the LDS latency never sits on the chain.  lds = 4 tiles of 64 x 9 doubles: in[2], out[2].
+    __device__ __forceinline__ void in_write(int buf, const double t[8]) const
     {
         const int lane = threadIdx.x & 63, rr = lane & 7, cg = lane >> 3;
+        double *L = lds + buf * 576;
 #pragma unroll
-        for (int r = 0; r < 8; r++) lds[(8 * r + cg) * 9 + rr] = t[r];
+        for (int r = 0; r < 8; r++) L[(8 * r + cg) * 9 + rr] = t[r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = 0; c < 8; c++) v[c] = lds[lane * 9 + (rev ? 7 - c : c)];
         __builtin_amdgcn_wave_barrier();
     }
-    __device__ __forceinline__ void from_own(const double v[8], double t[8], bool rev) const
+    __device__ __forceinline__ void in_read(int buf, double v[8], bool rev) const
     {
-        const int lane = threadIdx.x & 63, rr = lane & 7, cg = lane >> 3;
+        const int lane = threadIdx.x & 63;
+        const double *L = lds + buf * 576;
 #pragma unroll
-        for (int c = 0; c < 8; c++) lds[lane * 9 + (rev ? 7 - c : c)] = v[c];
+        for (int c = 0; c < 8; c++) v[c] = L[lane * 9 + (rev ? 7 - c : c)];
+    }
+    __device__ __forceinline__ void out_write(int buf, const double v[8], bool rev) const
+    {
+        const int lane = threadIdx.x & 63;
+        double *L = lds + (2 + buf) * 576;
+#pragma unroll
+        for (int c = 0; c < 8; c++) L[lane * 9 + (rev ? 7 - c : c)] = v[c];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void out_read(int buf, double t[8]) const
+    {
+        const int lane = threadIdx.x & 63, rr = lane & 7, cg = lane >> 3;
+        const double *L = lds + (2 + buf) * 576;
 #pragma unroll
-        for (int r = 0; r < 8; r++) t[r] = lds[(8 * r + cg) * 9 + rr];
-        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < 8; r++) t[r] = L[(8 * r + cg) * 9 + rr];
     }
     template <class F> __device__ __forceinline__ void sweep(int i0, int count, int dir, bool from_dst, F f) const
     {
@@ -163,36 +177,36 @@ struct ColIO {
         const bool rev = dir < 0;
         const int nfull = count / 8;
         double ring[COL_NB][8];
-        // tile k covers rows [lo(k), lo(k)+7]
-        auto lo = [&](int k) { return rev ? i0 - 8 * k - 7 : i0 + 8 * k; };
+        auto lo = [&](int k) { return rev ? i0 - 8 * k - 7 : i0 + 8 * k; };   // tile k covers rows [lo(k), lo(k)+7]
         int loaded = 0;
 #pragma unroll
         for (int b = 0; b < COL_NB; b++)
             if (b < nfull) { tile_load(base, lo(loaded), ring[b]); loaded++; }
+        double vcur[8], vnext[8], tprev[8];
+        if (nfull > 0) { in_write(0, ring[0]); in_read(0, vcur, rev); }
         int done = 0;
-        while (done + COL_NB <= nfull) {
+        while (done < nfull) {
 #pragma unroll
             for (int b = 0; b < COL_NB; b++) {
-                double v[8], t[8];
-                to_own(ring[b], v, rev);
+                const int c = done + b;
+                if (c < nfull) {
+                    // (1) input transpose of chunk c+1 (ring slot b+1), results consumed next iteration
+                    if (c + 1 < nfull) { in_write((c + 1) & 1, ring[(b + 1) % COL_NB]); in_read((c + 1) & 1, vnext, rev); }
+                    // (2) refill ring slot b (its tile went through the LDS one iteration ago)
+                    if (loaded < nfull) { tile_load(base, lo(loaded), ring[b]); loaded++; }
+                    // (3) the recurrence on chunk c
 #pragma unroll
-                for (int c = 0; c < 8; c++) v[c] = f(v[c]);
-                from_own(v, t, rev);
-                tile_store(lo(done + b), t);
-                if (loaded < nfull) { tile_load(base, lo(loaded), ring[b]); loaded++; }
+                    for (int e = 0; e < 8; e++) vcur[e] = f(vcur[e]);
+                    // (4) output transpose of chunk c; store chunk c-1 whose read-back was issued last iteration
+                    if (c > 0) tile_store(lo(c - 1), tprev);
+                    out_write(c & 1, vcur, rev); out_read(c & 1, tprev);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) vcur[e] = vnext[e];
+                }
             }
             done += COL_NB;
         }
-#pragma unroll
-        for (int b = 0; b < COL_NB; b++)
-            if (done + b < nfull) {
-                double v[8], t[8];
-                to_own(ring[b], v, rev);
-#pragma unroll
-                for (int c = 0; c < 8; c++) v[c] = f(v[c]);
-                from_own(v, t, rev);
-                tile_store(lo(done + b), t);
-            }
+        if (nfull > 0) tile_store(lo(nfull - 1), tprev);
         // tail rows: direct access by the owning lane.  The tile stores above were
         // made by other lanes; order them before the direct accesses below.
         fence();
@@ -260,7 +274,7 @@ __device__ __forceinline__ void iir_line(const IO &io, int n, const IIRCoef &k, 
 // dst for plane 0 (the blur reads the layer and writes the scratch plane).
 __global__ __launch_bounds__(LINE_THREADS) void k_iir_cols(PlaneSet ps, const double *src0, int H, int W, IIRPair cf)
 {
-    __shared__ double tile[64 * 9];
+    __shared__ double tile[4 * 64 * 9];
     const int pl = blockIdx.y;
     ColIO io;
     io.dst = ps.p[pl]; io.src = (pl == 0 && src0) ? src0 : ps.p[pl];
@@ -280,7 +294,7 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows(PlaneSet ps, int H, i
 // integral_image!, lucas_kanade.jl:131-138: cumsum along dim 1 ...
 __global__ __launch_bounds__(LINE_THREADS) void k_cum_cols(PlaneSet ps, int H, int W)
 {
-    __shared__ double tile[64 * 9];
+    __shared__ double tile[4 * 64 * 9];
     const int pl = blockIdx.y;
     ColIO io; io.dst = ps.p[pl]; io.src = ps.p[pl]; io.H = H; io.W = W; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile;
     double acc = io.ld_src(0);

@@ -71,10 +71,12 @@ def has_gradients(lk):
     return True
 
 
-def update_(lk, img, sigma=1.0, device_ptr=None, sync=True):
-    """update!(lk, img; σ) pyramid.jl:81-96.  `device_ptr`: image already in HBM."""
+def update_(lk, img, sigma=1.0, device_ptr=None, sync=True, ctx=None):
+    """update!(lk, img; σ) pyramid.jl:81-96.  `device_ptr`: image already in HBM;
+    `ctx`: enqueue on another context's stream (default: the pyramid's own)."""
     if device_ptr is not None:
-        lk.ctx.check(lk.ctx.lib.slam_pyr_update_dev(lk.ctx.h, lk.h, C.c_void_p(device_ptr), 1, float(sigma), 1 if sync else 0))
+        c = ctx or lk.ctx
+        c.check(c.lib.slam_pyr_update_dev(c.h, lk.h, C.c_void_p(device_ptr), 1, float(sigma), 1 if sync else 0))
     else:
         img = np.asfortranarray(img, dtype=np.float64)
         assert img.shape == lk.level_shape(0)
