@@ -108,7 +108,13 @@ int slam_describe(slam_ctx *ctx, const double *image, int H, int W,
 int slam_pyr_create(slam_ctx *ctx, int H, int W, int pyramid_levels, slam_pyr **out);
 int slam_pyr_destroy(slam_pyr *pyr);
 /* mode 0: constructor semantics (pyramid.jl:40-79: NA() blur, Fill(0) Scharr);
- * mode 1: update! semantics (pyramid.jl:81-137: replicate borders). */
+ * mode 1: update! semantics (pyramid.jl:81-137: replicate borders);
+ * mode 3: update! semantics with SEGMENTED recurrences: each IIR / cumulative-sum
+ *         line is cut into <= 16 segments whose entry states are obtained from
+ *         zero-state end states and powers of the filter's companion matrix.  Same
+ *         arithmetic inside a segment, different rounding of the entry states:
+ *         planes agree with mode 1 to ~1e-13 relative (mode 1 is bit-exact against
+ *         the sequential reference order and is what the parity tests pin). */
 int slam_pyr_update(slam_ctx *ctx, slam_pyr *pyr, const double *image, int mode, double sigma);
 /* image already in HBM (column-major f64); returns after enqueueing when sync == 0 */
 int slam_pyr_update_dev(slam_ctx *ctx, slam_pyr *pyr, const double *image_dev, int mode, double sigma, int sync);

@@ -82,6 +82,45 @@ __device__ __forceinline__ void stream_line(const double *src, double *dst, long
     for (int j = nfull * C; j < count; j++) dst[(long)j * step] = f(src[(long)j * step]);
 }
 
+// read-only variant (segment pre-pass of the tolerance-mode kernels): f consumes, nothing is stored
+template <int C, int NB, class F>
+__device__ __forceinline__ void stream_read(const double *src, long step, int count, F f)
+{
+    double buf[NB][C];
+    const int nfull = count / C;
+    const long cstep = (long)C * step;
+    const double *lp = src;
+    int loaded = 0;
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+        if (b < nfull) {
+#pragma unroll
+            for (int c = 0; c < C; c++) buf[b][c] = lp[c * step];
+            lp += cstep; loaded++;
+        }
+    int done = 0;
+    while (done + NB <= nfull) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+#pragma unroll
+            for (int c = 0; c < C; c++) f(buf[b][c]);
+            if (loaded < nfull) {
+#pragma unroll
+                for (int c = 0; c < C; c++) buf[b][c] = lp[c * step];
+                lp += cstep; loaded++;
+            }
+        }
+        done += NB;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+        if (done + b < nfull) {
+#pragma unroll
+            for (int c = 0; c < C; c++) f(buf[b][c]);
+        }
+    for (int j = nfull * C; j < count; j++) f(src[(long)j * step]);
+}
+
 // ---- line I/O policies ------------------------------------------------------
 // RowIO: the lane's line is strided (recurrence along x, lanes = consecutive y):
 // every access of the wave is one coalesced 512-byte segment.
@@ -310,6 +349,179 @@ __global__ __launch_bounds__(LINE_THREADS) void k_cum_rows(PlaneSet ps, int H, i
     stream_line<8, 8>(p + H, p + H, H, W - 1, [&](double x) { acc = acc + x; return acc; });
 }
 
+// ---- tolerance mode ("fast", mode 3): parallel recurrences -------------------------
+// The exact kernels above are bound by the dependent f64 chain: 68 cycles per IIR
+// step x line length (measured, scripts/ubench/dep_chain.hip), on the few CUs that a
+// few hundred lines can occupy.  Here a 1024-thread workgroup owns LPW lines and
+// cuts each into up to 1024/LPW segments of SL <= 16 samples, one per thread:
+//   (load) the thread reads its SL samples ONCE into registers;
+//   (A) runs the recurrence from a zero state, keeps the end state;
+//   (B) entry states by a two-level fold of the affine maps s -> M^SL s + z through
+//       LDS (powers of the 3x3 companion matrix M come from the host);
+//   (C) re-runs the SAME recurrence from the true entry state, in registers;
+// the backward pass repeats A-C right-to-left on the register-resident forward
+// values, then stores.  HBM traffic is exactly one read and one write per sample
+// (the algorithmic minimum) and lines spread over ~190 workgroups instead of 24.
+// Inside a segment the arithmetic is the sequential one; only the entry states are
+// rounded differently (tested: planes <= 1e-11 relative to the exact mode).
+#define PAR_T 1024
+#define PAR_SLMAX 16
+#define PAR_G 8
+struct SegPow { double P[2][PAR_G][9]; double Plast[2][9]; };   // M^(SL*q), q = 1..8; M^(len_last - 1)
+
+__device__ __forceinline__ void mv3(const double *P, double &a, double &b, double &c, double za, double zb, double zc)
+{
+    const double n1 = ((P[0] * a + P[1] * b) + P[2] * c) + za;
+    const double n2 = ((P[3] * a + P[4] * b) + P[5] * c) + zb;
+    const double n3 = ((P[6] * a + P[7] * b) + P[8] * c) + zc;
+    a = n1; b = n2; c = n3;
+}
+
+// entry state of segment index `k` (0-based in fold order) of line l: two-level fold.
+// Z: zero-state end states [3][nslots][LPW] indexed by fold order through `slot(k)`.
+template <int LPW, class Slot>
+__device__ __forceinline__ void fold_entry(const SegPow &sp, int cs, double (*Z)[PAR_T / LPW][LPW], double (*GT)[PAR_T / LPW / PAR_G + 1][LPW],
+                                           int l, int k, bool has, Slot slot, double s0a, double s0b, double s0c,
+                                           double &ea, double &eb, double &ec)
+{
+    const int q = k % PAR_G, grp = k / PAR_G;
+    const double *P1 = sp.P[cs][0], *P8 = sp.P[cs][PAR_G - 1];
+    double a = 0.0, b = 0.0, c = 0.0;
+    if (has) for (int i = 0; i < q; i++) { const int s = slot(grp * PAR_G + i); mv3(P1, a, b, c, Z[0][s][l], Z[1][s][l], Z[2][s][l]); }
+    if (has && q == PAR_G - 1) {
+        double ta = a, tb = b, tc = c; const int s = slot(k);
+        mv3(P1, ta, tb, tc, Z[0][s][l], Z[1][s][l], Z[2][s][l]);
+        GT[0][grp][l] = ta; GT[1][grp][l] = tb; GT[2][grp][l] = tc;
+    }
+    __syncthreads();
+    double Sa = s0a, Sb = s0b, Sc = s0c;
+    if (has) {
+        for (int h = 0; h < grp; h++) mv3(P8, Sa, Sb, Sc, GT[0][h][l], GT[1][h][l], GT[2][h][l]);
+        if (q > 0) mv3(sp.P[cs][q - 1], Sa, Sb, Sc, 0.0, 0.0, 0.0);
+    }
+    ea = Sa + a; eb = Sb + b; ec = Sc + c;
+}
+
+template <bool COLS>
+__global__ __launch_bounds__(PAR_T) void k_iir_seg(PlaneSet ps, const double *src0, int H, int W, IIRPair cf, SegPow sp, int SL)
+{
+    constexpr int LPW = 8, NSEG = PAR_T / LPW;
+    __shared__ double Z[3][NSEG][LPW];
+    __shared__ double GT[3][NSEG / PAR_G + 1][LPW];
+    __shared__ double Fin[3][LPW];
+    const int t = threadIdx.x, l = t % LPW, g = t / LPW, pl = blockIdx.y;
+    const int nlines = COLS ? W : H, n = COLS ? H : W;
+    const int line = blockIdx.x * LPW + l;
+    const bool valid = line < nlines;
+    const int lc = valid ? line : nlines - 1;              // idle lanes shadow the last line (reads only)
+    const long stride = COLS ? 1 : H;
+    const size_t off = COLS ? (size_t)lc * H : (size_t)lc;
+    double *dstp = ps.p[pl] + off;
+    const double *srcp = ((pl == 0 && src0) ? src0 : ps.p[pl]) + off;
+    const int cs = ps.coef[pl];
+    const IIRCoef &k = cf.c[cs];
+    const double a1 = k.a1, a2 = k.a2, a3 = k.a3, scale = k.scale;
+    const int nseg = (n + SL - 1) / SL;
+    const bool has = g < nseg;
+    const int b = g * SL, len = has ? min(n, b + SL) - b : 0;
+    const bool lastseg = has && g == nseg - 1;
+    double x[PAR_SLMAX];
+#pragma unroll
+    for (int j = 0; j < PAR_SLMAX; j++) x[j] = (j < len) ? srcp[(long)(b + j) * stride] : 0.0;
+    const double x0 = srcp[0], xlast = srcp[(long)(n - 1) * stride];
+    const double uminus = x0 / k.inv1masum;
+    // ---------------- forward: A ----------------
+    {
+        double w1 = 0.0, w2 = 0.0, w3 = 0.0;
+#pragma unroll
+        for (int j = 0; j < PAR_SLMAX; j++) if (j < len) { const double tt = ((x[j] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; }
+        if (has) { Z[0][g][l] = w1; Z[1][g][l] = w2; Z[2][g][l] = w3; }
+    }
+    __syncthreads();
+    // ---------------- forward: B, C ----------------
+    {
+        double w1, w2, w3;
+        fold_entry<LPW>(sp, cs, Z, GT, l, g, has, [](int kk) { return kk; }, uminus, uminus, uminus, w1, w2, w3);
+#pragma unroll
+        for (int j = 0; j < PAR_SLMAX; j++) if (j < len) { const double tt = ((x[j] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; x[j] = tt; }
+        if (lastseg) { Fin[0][l] = w1; Fin[1][l] = w2; Fin[2][l] = w3; }
+    }
+    __syncthreads();
+    // ---------------- Triggs-Sdika right boundary ----------------
+    const double f1 = Fin[0][l], f2 = Fin[1][l], f3 = Fin[2][l];
+    const double uplus = xlast / k.inv1masum, vplus = uplus / k.inv1mbsum;
+    const double d0 = f1 - uplus, d1 = f2 - uplus, d2 = f3 - uplus;
+    const double vr0 = ((k.M[0] * d0 + k.M[1] * d1) + k.M[2] * d2) + vplus;
+    const double vr1 = ((k.M[3] * d0 + k.M[4] * d1) + k.M[5] * d2) + vplus;
+    const double vr2 = ((k.M[6] * d0 + k.M[7] * d1) + k.M[8] * d2) + vplus;
+    // ---------------- backward: A' (sample n-1 is not part of the recurrence: v[n-1] = vr0) ----------------
+    const int blen = lastseg ? len - 1 : len;              // samples of this segment that the backward recurrence visits
+    {
+        double v1 = 0.0, v2 = 0.0, v3 = 0.0;
+#pragma unroll
+        for (int j = PAR_SLMAX - 1; j >= 0; j--) if (j < blen) { const double tt = ((x[j] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; }
+        if (has) { Z[0][g][l] = v1; Z[1][g][l] = v2; Z[2][g][l] = v3; }
+    }
+    __syncthreads();
+    // ---------------- backward: B', C' ----------------
+    {
+        // state after the (short) last segment, then fold the full segments right-to-left
+        double s0a = vr0, s0b = vr1, s0c = vr2;
+        mv3(sp.Plast[cs], s0a, s0b, s0c, Z[0][nseg - 1][l], Z[1][nseg - 1][l], Z[2][nseg - 1][l]);
+        double v1, v2, v3;
+        const int kq = nseg - 2 - g;                        // fold order of the full segments
+        const bool hasq = has && !lastseg;
+        fold_entry<LPW>(sp, cs, Z, GT, l, hasq ? kq : 0, hasq, [nseg](int kk) { return nseg - 2 - kk; }, s0a, s0b, s0c, v1, v2, v3);
+        if (lastseg) { v1 = vr0; v2 = vr1; v3 = vr2; }
+#pragma unroll
+        for (int j = PAR_SLMAX - 1; j >= 0; j--) if (j < blen) { const double tt = ((x[j] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; x[j] = tt * scale; }
+#pragma unroll
+        for (int j = 0; j < PAR_SLMAX; j++) if (lastseg && j == len - 1) x[j] = vr0 * scale;
+    }
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < PAR_SLMAX; j++) if (j < len) dstp[(long)(b + j) * stride] = x[j];
+    }
+}
+
+template <bool COLS>
+__global__ __launch_bounds__(PAR_T) void k_cum_seg(PlaneSet ps, int H, int W, int SL)
+{
+    constexpr int LPW = 8, NSEG = PAR_T / LPW;
+    __shared__ double Zs[NSEG][LPW];
+    __shared__ double Gs[NSEG / PAR_G + 1][LPW];
+    const int t = threadIdx.x, l = t % LPW, g = t / LPW, pl = blockIdx.y;
+    const int nlines = COLS ? W : H, n = COLS ? H : W;
+    const int line = blockIdx.x * LPW + l;
+    const bool valid = line < nlines;
+    const int lc = valid ? line : nlines - 1;
+    const long stride = COLS ? 1 : H;
+    double *p = ps.p[pl] + (COLS ? (size_t)lc * H : (size_t)lc);
+    const int nseg = (n + SL - 1) / SL;
+    const bool has = g < nseg;
+    const int b = g * SL, len = has ? min(n, b + SL) - b : 0;
+    double x[PAR_SLMAX];
+#pragma unroll
+    for (int j = 0; j < PAR_SLMAX; j++) x[j] = (j < len) ? p[(long)(b + j) * stride] : 0.0;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < PAR_SLMAX; j++) if (j < len) acc = acc + x[j];
+    if (has) Zs[g][l] = acc;
+    __syncthreads();
+    const int q = g % PAR_G, grp = g / PAR_G;
+    double pre = 0.0;
+    if (has) for (int i = 0; i < q; i++) pre = pre + Zs[grp * PAR_G + i][l];
+    if (has && q == PAR_G - 1) Gs[grp][l] = pre + Zs[g][l];
+    __syncthreads();
+    double base = 0.0;
+    if (has) for (int h = 0; h < grp; h++) base = base + Gs[h][l];
+    acc = base + pre;
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < PAR_SLMAX; j++) if (j < len) { acc = acc + x[j]; p[(long)(b + j) * stride] = acc; }
+    }
+}
+
 // imgradients (KernelFactors.scharr, separable: derivative (-1,0,1)/2, smoothing
 // (3,10,3)/16; first factor along dim 1 first) + the three gradient products.
 // border 0: replicate (update!, pyramid.jl:98-103); 1: Fill(0) (ctor, pyramid.jl:51,59).
@@ -414,16 +626,47 @@ static int build_norm(slam_ctx *ctx, slam_pyr *p, double sigma)
 // passes of level l only feed the LK kernel, so they run on `aux`, concurrently
 // with level l+1 (fork after the row pass, one join at the end).  With
 // aux == st everything is serial on one stream (profiling / fallback path).
+static void mat3_pow(const IIRCoef &k, int e, double P[9])
+{
+    double M[9] = {k.a1, k.a2, k.a3, 1, 0, 0, 0, 1, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, T[9];
+    auto mul = [&](const double *A, const double *B, double *C) {
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double t = 0; for (int m = 0; m < 3; m++) t += A[3 * i + m] * B[3 * m + j]; C[3 * i + j] = t; } };
+    while (e > 0) {
+        if (e & 1) { mul(R, M, T); memcpy(R, T, sizeof R); }
+        mul(M, M, T); memcpy(M, T, sizeof M);
+        e >>= 1;
+    }
+    memcpy(P, R, sizeof R);
+}
+static inline int seg_len(int n, int nseg_max) { int sl = (n + nseg_max - 1) / nseg_max; return sl < 4 ? 4 : sl; }
+static void seg_pow(const IIRPair &cf, int n, int SL, SegPow &sp)
+{
+    const int nseg = (n + SL - 1) / SL, len_last = n - (nseg - 1) * SL;
+    for (int c = 0; c < 2; c++) {
+        for (int q = 1; q <= PAR_G; q++) mat3_pow(cf.c[c], SL * q, sp.P[c][q - 1]);
+        mat3_pow(cf.c[c], len_last - 1, sp.Plast[c]);
+    }
+}
+
+// Launch every kernel of one pyramid build.  `st` carries the dependent chain
+// (gradients -> IIR dim 1 -> IIR dim 2 -> resize -> next level); the integral-image
+// passes of level l only feed the LK kernel, so they run on `aux`, concurrently
+// with level l+1 (fork after the row pass, one join at the end).  With
+// aux == st everything is serial on one stream (profiling / fallback path).
+// mode 3 ("fast") swaps the sequential line kernels for the segmented ones.
 static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf, hipStream_t st, hipStream_t aux, bool spans)
 {
     const bool forked = aux != st;
+    bool fast = mode == 3;
+    if (fast && (seg_len(p->H[0], PAR_T / 8) > PAR_SLMAX || seg_len(p->W[0], PAR_T / 8) > PAR_SLMAX)) fast = false;   // lines > 2048 samples: exact kernels
+    const int border_mode = (mode == 0) ? 1 : 0;
     for (int l = 0; l < p->levels; l++) {
         const int H = p->H[l], W = p->W[l];
         const size_t n = (size_t)H * W;
         const LevelView &v = p->view.lv[l];
         const bool has_next = l + 1 < p->levels;
         double *T = p->tmp + p->off[l];
-        hipLaunchKernelGGL(k_scharr_products, dim3((n + 255) / 256), dim3(256), 0, st, v, mode == 0 ? 1 : 0);
+        hipLaunchKernelGGL(k_scharr_products, dim3((n + 255) / 256), dim3(256), 0, st, v, border_mode);
         // dim-1 IIR: [blur: L -> T], Iyy, Ixx, Iyx in place
         PlaneSet ps = {};
         int np = 0;
@@ -432,7 +675,27 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         ps.p[np] = v.Ixx; ps.coef[np] = 1; np++;
         ps.p[np] = v.Iyx; ps.coef[np] = 1; np++;
         ps.n = np;
-        hipLaunchKernelGGL(k_iir_cols, lines_grid(W, np), dim3(LINE_THREADS), 0, st, ps, has_next ? (const double *)v.L : (const double *)nullptr, H, W, cf);
+        const double *src0 = has_next ? (const double *)v.L : (const double *)nullptr;
+        PlaneSet pc = {};
+        pc.p[0] = v.Iyy; pc.p[1] = v.Ixx; pc.p[2] = v.Iyx; pc.n = 3;
+        if (fast) {
+            const int slc = seg_len(H, PAR_T / 8), slr = seg_len(W, PAR_T / 8);
+            SegPow spc, spr;
+            seg_pow(cf, H, slc, spc); seg_pow(cf, W, slr, spr);
+            const dim3 gc((W + 7) / 8, np), gr((H + 7) / 8, np), gc3((W + 7) / 8, 3), gr3((H + 7) / 8, 3);
+            hipLaunchKernelGGL(k_iir_seg<true>, gc, dim3(PAR_T), 0, st, ps, src0, H, W, cf, spc, slc);
+            if (spans) { ProfScope span(ctx, "k_iir_rows");
+                hipLaunchKernelGGL(k_iir_seg<false>, gr, dim3(PAR_T), 0, st, ps, (const double *)nullptr, H, W, cf, spr, slr); }
+            else hipLaunchKernelGGL(k_iir_seg<false>, gr, dim3(PAR_T), 0, st, ps, (const double *)nullptr, H, W, cf, spr, slr);
+            if (forked) { (void)hipEventRecord(p->ev_fork[l], st); (void)hipStreamWaitEvent(aux, p->ev_fork[l], 0); }
+            if (has_next)
+                hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256), dim3(256), 0, st,
+                                   p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], (const double *)T, H, W);
+            hipLaunchKernelGGL(k_cum_seg<true>, gc3, dim3(PAR_T), 0, aux, pc, H, W, slc);
+            hipLaunchKernelGGL(k_cum_seg<false>, gr3, dim3(PAR_T), 0, aux, pc, H, W, slr);
+            continue;
+        }
+        hipLaunchKernelGGL(k_iir_cols, lines_grid(W, np), dim3(LINE_THREADS), 0, st, ps, src0, H, W, cf);
         if (spans) { ProfScope span(ctx, "k_iir_rows");
             hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np), dim3(LINE_THREADS), 0, st, ps, H, W, cf); }
         else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np), dim3(LINE_THREADS), 0, st, ps, H, W, cf);
@@ -440,8 +703,6 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         if (has_next)
             hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256), dim3(256), 0, st,
                                p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], (const double *)T, H, W);
-        PlaneSet pc = {};
-        pc.p[0] = v.Iyy; pc.p[1] = v.Ixx; pc.p[2] = v.Iyx; pc.n = 3;
         hipLaunchKernelGGL(k_cum_cols, lines_grid(W, 3), dim3(LINE_THREADS), 0, aux, pc, H, W);
         hipLaunchKernelGGL(k_cum_rows, lines_grid(H, 3), dim3(LINE_THREADS), 0, aux, pc, H, W);
     }
@@ -535,7 +796,7 @@ int slam_pyr_destroy(slam_pyr *p)
 
 int slam_pyr_update_dev(slam_ctx *ctx, slam_pyr *p, const double *image_dev, int mode, double sigma, int sync)
 {
-    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_dev != nullptr && (mode == 0 || mode == 1) && sigma > 0);
+    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_dev != nullptr && (mode == 0 || mode == 1 || mode == 3) && sigma > 0);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (image_dev != p->plane(0, 0))
         HIP_TRY(ctx, hipMemcpyAsync(p->plane(0, 0), image_dev, (size_t)p->H[0] * p->W[0] * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -547,7 +808,7 @@ int slam_pyr_update_dev(slam_ctx *ctx, slam_pyr *p, const double *image_dev, int
 
 int slam_pyr_update(slam_ctx *ctx, slam_pyr *p, const double *image, int mode, double sigma)
 {
-    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image != nullptr && (mode == 0 || mode == 1) && sigma > 0);
+    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image != nullptr && (mode == 0 || mode == 1 || mode == 3) && sigma > 0);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(p->plane(0, 0), image, (size_t)p->H[0] * p->W[0] * 8, hipMemcpyHostToDevice, ctx->stream));
     int rc = enqueue_build(ctx, p, mode, sigma);

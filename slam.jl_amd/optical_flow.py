@@ -71,16 +71,19 @@ def has_gradients(lk):
     return True
 
 
-def update_(lk, img, sigma=1.0, device_ptr=None, sync=True, ctx=None):
+def update_(lk, img, sigma=1.0, device_ptr=None, sync=True, ctx=None, fast=False):
     """update!(lk, img; σ) pyramid.jl:81-96.  `device_ptr`: image already in HBM;
-    `ctx`: enqueue on another context's stream (default: the pyramid's own)."""
+    `ctx`: enqueue on another context's stream (default: the pyramid's own);
+    `fast`: segmented recurrences (mode 3) -- planes agree with the sequential,
+    bit-exact mode to ~1e-13 relative instead of bit for bit."""
+    mode = 3 if fast else 1
     if device_ptr is not None:
         c = ctx or lk.ctx
-        c.check(c.lib.slam_pyr_update_dev(c.h, lk.h, C.c_void_p(device_ptr), 1, float(sigma), 1 if sync else 0))
+        c.check(c.lib.slam_pyr_update_dev(c.h, lk.h, C.c_void_p(device_ptr), mode, float(sigma), 1 if sync else 0))
     else:
         img = np.asfortranarray(img, dtype=np.float64)
         assert img.shape == lk.level_shape(0)
-        lk.ctx.check(lk.ctx.lib.slam_pyr_update(lk.ctx.h, lk.h, L.ptr(img), 1, float(sigma)))
+        lk.ctx.check(lk.ctx.lib.slam_pyr_update(lk.ctx.h, lk.h, L.ptr(img), mode, float(sigma)))
     return lk
 
 

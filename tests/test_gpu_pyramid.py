@@ -59,3 +59,31 @@ def test_pyramid_integral_property_full_size(slam, texture):
         assert I[-1, -1] > 0
         assert np.isfinite(I).all()
     assert np.array_equal(lk.plane("layers", 0), img)
+
+
+@pytest.mark.parametrize("H,W", [(37, 53), (101, 75), (370, 1226), (1080, 1920)])
+def test_fast_mode_within_tolerance(slam, orc, texture, H, W):
+    """mode 3 (segmented recurrences): same planes up to the rounding of the segment
+    entry states.  Tolerance: 1e-11 relative to the plane's max magnitude."""
+    L = texture(H, W)[0]
+    levels = 3 if min(H, W) > 60 else 2
+    lk = slam.LKPyramid(shape=(H, W), levels=levels)
+    slam.update_(lk, L[0], fast=True)
+    ref = orc.pyr_build(L[0], levels, 1.0, 1)
+    worst = 0.0
+    for l in range(levels + 1):
+        for name in PLANES:
+            g = lk.plane(name, l); r = ref.plane(name, l)
+            err = np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)
+            worst = max(worst, err)
+            assert err <= 1e-11, (name, l, err)
+    # and tracking on fast pyramids agrees with tracking on exact pyramids far below the reference's own eps (1e-2 px)
+    lk2 = slam.LKPyramid(shape=(H, W), levels=levels); slam.update_(lk2, L[1], fast=True)
+    e1 = slam.LKPyramid(shape=(H, W), levels=levels); slam.update_(e1, L[0])
+    e2 = slam.LKPyramid(shape=(H, W), levels=levels); slam.update_(e2, L[1])
+    kp = orc.detect(L[0], np.zeros((0, 2)), max_points=500).astype(float)
+    of, sf = slam.fb_tracking_(lk, lk2, kp, window_size=9, pyramid_levels=levels, max_distance=1.0)
+    oe, se = slam.fb_tracking_(e1, e2, kp, window_size=9, pyramid_levels=levels, max_distance=1.0)
+    assert (sf != se).sum() <= max(1, len(kp) // 200)
+    both = sf & se
+    assert np.abs(of[both] - oe[both]).max() < 1e-7
