@@ -18,7 +18,7 @@ static int grow(slam_ctx *ctx, void **p, size_t *have, size_t want, bool pinned)
     if (*have >= want) return SLAM_OK;
     if (*p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); if (pinned) (void)hipHostFree(*p); else (void)hipFree(*p); *p = nullptr; *have = 0; }
     size_t sz = want + want / 4 + 4096;
-    if (pinned) HIP_TRY(ctx, hipHostMalloc(p, sz, hipHostMallocDefault));
+    if (pinned) HIP_TRY(ctx, hipHostMalloc(p, sz, hipHostMallocMapped | hipHostMallocCoherent));   // device-visible, fine-grained
     else HIP_TRY(ctx, hipMalloc(p, sz));
     *have = sz;
     return SLAM_OK;
@@ -98,6 +98,9 @@ int slam_ctx_create(int device, slam_ctx **out)
     if (device < 0 || device >= n) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_ctx_create: device %d out of range [0,%d)", device, n);
     slam_ctx *c = new slam_ctx();
     c->device = device;
+    // synchronous seams return after a stream sync: spin instead of the interrupt-driven wait (tens of us per call)
+    (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+    (void)hipGetLastError();
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create: %s", hipGetErrorString(e)); }

@@ -215,22 +215,24 @@ __global__ __launch_bounds__(64) void k_flow_match(FlowArgs F)
 
 static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-// shared host path: inputs packed into one pinned staging block -> one H2D, one launch, one D2H
+// shared host path.  Keypoint lists are tiny (16-33 B per point): instead of staging
+// them through HBM (H2D copy -> kernel -> D2H copy: two extra dependent DMA hops per
+// call) the kernel reads its inputs from, and writes its results to, the context's
+// pinned, device-mapped, coherent host block directly over PCIe.  One launch + one
+// stream sync per call.
 static int run_tracking(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr *cur, const double *pts_yx, const double *aux_yx,
                         const uint8_t *is3d, int n, int pyramid_levels, int levels3d, int window, int iterations,
                         double eig_thr, double eps, double max_distance, double *out_yx, uint8_t *status, bool flow)
 {
     const size_t pb = al256((size_t)n * 16), sb = al256((size_t)n);
     const size_t in_b = 2 * pb + sb, out_b = pb + sb;
-    char *d, *h;
-    int rc = slam_scratch(ctx, in_b + out_b, (void **)&d);
+    char *h, *d;
+    int rc = slam_pinned(ctx, in_b + out_b, (void **)&h);
     if (rc) return rc;
-    rc = slam_pinned(ctx, in_b + out_b, (void **)&h);
-    if (rc) return rc;
+    HIP_TRY(ctx, hipHostGetDevicePointer((void **)&d, h, 0));
     memcpy(h, pts_yx, (size_t)n * 16);
     if (aux_yx) memcpy(h + pb, aux_yx, (size_t)n * 16);
     if (is3d) memcpy(h + 2 * pb, is3d, (size_t)n);
-    HIP_TRY(ctx, hipMemcpyAsync(d, h, in_b, hipMemcpyHostToDevice, ctx->stream));
     FlowArgs F;
     LKArgs &A = F.lk;
     A.prev = prev->view; A.cur = cur->view;
@@ -243,7 +245,6 @@ static int run_tracking(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr *cur
       if (flow) hipLaunchKernelGGL(k_flow_match, dim3(n), dim3(64), 0, ctx->stream, F);
       else hipLaunchKernelGGL(k_fb_track, dim3(n), dim3(64), 0, ctx->stream, A); }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(h + in_b, d + in_b, out_b, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out_yx, h + in_b, (size_t)n * 16);
     memcpy(status, h + in_b + pb, (size_t)n);
