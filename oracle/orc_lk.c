@@ -119,7 +119,7 @@ static void flow_vector(const orc_pyr *first, const orc_pyr *second, int lv, con
                 ay[e & 63] += dI * Iy[a];
                 ax[e & 63] += dI * Ix[a];
             }
-        for (int m = 32; m >= 1; m >>= 1) {
+        for (int m = 1; m <= 32; m <<= 1) {
             double ty[64], tx[64];
             for (int l = 0; l < 64; l++) { ty[l] = ay[l] + ay[l ^ m]; tx[l] = ax[l] + ax[l ^ m]; }
             memcpy(ay, ty, sizeof ay); memcpy(ax, tx, sizeof ax);

@@ -59,14 +59,23 @@ __device__ __forceinline__ double spatial_gradient(const LevelView &v, int p0, i
     const double E = (syy + sxx) / 2, F = (syy - sxx) / 2, G = (syx + syx) / 2, Hh = (syx - syx) / 2;
     const double Q = sqrt(E * E + Hh * Hh), R = sqrt(F * F + G * G);
     const double sx = Q + R, sy = Q - R;
+    const double S0 = sx, S1 = fabs(sy);
+    const double tol = 1.4901161193847656e-08;
+    const double cnt = (double)((long)(y2 - y1 + 1) * (long)(x2 - x1 + 1));
+    if (E > 0 && sy > tol) {
+        // Well-conditioned symmetric positive-definite case (every trackable window): both singular values pass
+        // pinv2x2's threshold, so U*D*V' is the plain inverse; the closed form agrees with the reference's
+        // atan/sincos construction to ~1e-16 relative and skips ~1500 instructions of f64 trigonometry.
+        const double det = syy * sxx - syx * syx, id = 1.0 / det;
+        Gi[0] = sxx * id; Gi[1] = -syx * id; Gi[2] = -syx * id; Gi[3] = syy * id;
+        return fmin(S0, S1) / cnt;
+    }
     const double a1 = atan2(G, F), a2 = atan2(Hh, E);
     const double th = (a2 - a1) / 2, ph = (a2 + a1) / 2;
     const double s = (double)((sy > 0) - (sy < 0));
     const double sp = sin(ph), cp = cos(ph), st = sin(th), ct = cos(th);
     const double U0 = cp, U1 = sp, U2 = -s * sp, U3 = s * cp;
-    const double S0 = sx, S1 = fabs(sy);
     const double V0 = ct, V1 = -st, V2 = st, V3 = ct;
-    const double tol = 1.4901161193847656e-08;
     const double d1 = S0 > tol ? 1.0 / S0 : 0.0, d2 = S1 > tol ? 1.0 / S1 : 0.0;
     const double ud11 = U0 * d1 + U2 * 0.0, ud21 = U1 * d1 + U3 * 0.0;
     const double ud12 = U0 * 0.0 + U2 * d2, ud22 = U1 * 0.0 + U3 * d2;
@@ -74,7 +83,6 @@ __device__ __forceinline__ double spatial_gradient(const LevelView &v, int p0, i
     Gi[1] = ud21 * V0 + ud22 * V2;
     Gi[2] = ud11 * V1 + ud12 * V3;
     Gi[3] = ud21 * V1 + ud22 * V3;
-    const double cnt = (double)((long)(y2 - y1 + 1) * (long)(x2 - x1 + 1));
     return fmin(S0, S1) / cnt;
 }
 
@@ -98,6 +106,57 @@ __device__ __forceinline__ bool lies_in(int H, int W, double a, double b)
     return 1.0 <= a && a <= (double)H && 1.0 <= b && b <= (double)W;
 }
 
+// Wave-wide sum in the fixed butterfly order a[l] += a[l ^ m], m = 1, 2, 4, 8, 16, 32 (restated in the CPU
+// oracle, sum_order = 1), without touching the LDS crossbar: the reduction sits on the critical path of every LK
+// iteration, and six dependent ds_bpermute round trips cost ~700 cycles.  m = 1, 2: DPP quad_perm; m = 4, 8:
+// row_half_mirror / row_mirror (the partner group already holds one uniform value, so mirroring == xor);
+// m = 16, 32: the four row sums are read with v_readlane and combined as (R0 + R1) + (R2 + R3) in every lane.
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v = v + dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]  : l ^ 1
+    v = v + dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]  : l ^ 2
+    v = v + dpp_f64<0x141>(v);     // row_half_mirror      : l ^ 4 (quads are uniform)
+    v = v + dpp_f64<0x140>(v);     // row_mirror           : l ^ 8 (octets are uniform)
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    const int row = (threadIdx.x & 63) >> 4;
+    const double a = (row & 1) ? r1 + r0 : r0 + r1, b = (row & 1) ? r3 + r2 : r2 + r3;   // own row first (commutative: same bits)
+    return (row & 2) ? b + a : a + b;
+}
+
+// The lane's share of the (2w+1)^2 template: element e = lane + 64*k of the reference's (q outer, p inner)
+// enumeration.  Template samples, gradients and the element's window offsets depend only on the window
+// geometry, so they are fetched once per geometry and stay in registers across the <= 30 iterations
+// (no integer div/mod and no template loads inside the iteration).
+#define LK_MAXE 9                     // 64 * 9 = 576 >= 23 * 23 (window_size <= 11)
+struct Tmpl { double A[LK_MAXE], Iy[LK_MAXE], Ix[LK_MAXE], dp[LK_MAXE], dq[LK_MAXE]; int ne; };
+
+__device__ __forceinline__ void load_template(Tmpl &T, const LevelView &first, int p0, int p1, Offs o)
+{
+    const int lane = threadIdx.x & 63, H = first.H;
+    const int P = o.up + o.down + 1, Q = o.left + o.right + 1, NE = P * Q;
+    T.ne = NE;
+#pragma unroll
+    for (int k = 0; k < LK_MAXE; k++) {
+        const int e = lane + 64 * k;
+        const bool in = e < NE;
+        const int p = in ? e % P : 0, q = in ? e / P : 0;
+        const size_t a = (size_t)(p0 - o.up + p - 1) + (size_t)(p1 - o.left + q - 1) * H;
+        T.A[k] = in ? first.L[a] : 0.0; T.Iy[k] = in ? first.Iy[a] : 0.0; T.Ix[k] = in ? first.Ix[a] : 0.0;
+        T.dp[k] = (double)(p - o.up); T.dq[k] = (double)(q - o.left);
+    }
+}
+
 // One pyramid level of optflow! for one point (lucas_kanade.jl:33-96).  All
 // control flow is wave-uniform.  Returns the point's status.
 __device__ bool lk_level(const LevelView &first, const LevelView &second, int level,
@@ -113,6 +172,9 @@ __device__ bool lk_level(const LevelView &first, const LevelView &second, int le
     double Gi[4];
     double min_eig = spatial_gradient(first, p0, p1, o, Gi);
     if (min_eig < eig_thr) return false;
+    const bool cached = (2 * window + 1) * (2 * window + 1) <= 64 * LK_MAXE;
+    Tmpl T;
+    if (cached) load_template(T, first, p0, p1, o);
     double c0 = 0.0, c1 = 0.0;
     for (int it = 0; it < iterations; it++) {
         const double f0 = dy + c0, f1 = dx + c1;
@@ -123,23 +185,30 @@ __device__ bool lk_level(const LevelView &first, const LevelView &second, int le
             o = no;
             min_eig = spatial_gradient(first, p0, p1, o, Gi);
             if (min_eig < eig_thr) return false;
+            if (cached) load_template(T, first, p0, p1, o);
         }
         // prepare_linear_system (lucas_kanade.jl:159-173), wave order
-        const int P = o.up + o.down + 1, Q = o.left + o.right + 1, NE = P * Q;
         double ay = 0.0, ax = 0.0;
-        for (int e = lane; e < NE; e += 64) {
-            const int p = e % P, q = e / P;
-            const double r = r0 + (double)(p - o.up), c = r1 + (double)(q - o.left);
-            const size_t a = (size_t)(p0 - o.up + p - 1) + (size_t)(p1 - o.left + q - 1) * H;
-            const double dI = first.L[a] - bilinear(second.L, H, W, r, c);
-            ay += dI * first.Iy[a];
-            ax += dI * first.Ix[a];
-        }
+        if (cached) {
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const double ty = __shfl_xor(ay, m), tx = __shfl_xor(ax, m);
-            ay = ay + ty; ax = ax + tx;
+            for (int k = 0; k < LK_MAXE; k++)
+                if (lane + 64 * k < T.ne) {
+                    const double dI = T.A[k] - bilinear(second.L, H, W, r0 + T.dp[k], r1 + T.dq[k]);
+                    ay += dI * T.Iy[k];
+                    ax += dI * T.Ix[k];
+                }
+        } else {
+            const int P = o.up + o.down + 1, Q = o.left + o.right + 1, NE = P * Q;
+            for (int e = lane; e < NE; e += 64) {
+                const int p = e % P, q = e / P;
+                const double r = r0 + (double)(p - o.up), c = r1 + (double)(q - o.left);
+                const size_t a = (size_t)(p0 - o.up + p - 1) + (size_t)(p1 - o.left + q - 1) * H;
+                const double dI = first.L[a] - bilinear(second.L, H, W, r, c);
+                ay += dI * first.Iy[a];
+                ax += dI * first.Ix[a];
+            }
         }
+        ay = wave_sum(ay); ax = wave_sum(ax);
         const double fl0 = Gi[0] * ay + Gi[2] * ax, fl1 = Gi[1] * ay + Gi[3] * ax;
         if (fabs(fl0) < eps && fabs(fl1) < eps) break;
         c0 += fl0; c1 += fl1;

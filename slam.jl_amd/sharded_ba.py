@@ -77,6 +77,8 @@ class HipShard:
         dev = torch.device("cuda", self.ctx.device)
         self.red = torch.zeros(self.ctx.lib.slam_ba_reduce_len(P), dtype=torch.float64, device=dev)
         self.trial = torch.zeros(4, dtype=torch.float64, device=dev)
+        # torch fills these on ITS stream; libslamhip runs on its own non-blocking stream
+        torch.cuda.synchronize(dev)
 
     def build(self, ignore_outliers, inv_delta):
         self.ctx.check(self.ctx.lib.slam_ba_build(self.ctx.h, self.h, int(ignore_outliers), float(inv_delta), C.c_void_p(self.red.data_ptr())))
@@ -116,6 +118,11 @@ def _all_reduce(t, op, group):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=op, group=group)
+        if t.is_cuda:
+            # RCCL runs on torch's streams, libslamhip on its own non-blocking stream: the
+            # reduced buffer must be complete before slam_ba_solve is enqueued
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
     return t
 
 

@@ -37,8 +37,8 @@ def test_sharded_driver_on_one_gpu_matches_single_call(slam, syn):
     slam.bundle_adjustment_(cache, s["cam"])
     assert np.array_equal(ol, cache.outliers)
     assert st["iters_pass1"] == cache.stats["iters_pass1"] and st["iters_pass2"] == cache.stats["iters_pass2"]
-    assert abs(st["ssr_final"] - cache.stats["ssr_final"]) <= 1e-9 * cache.stats["ssr_final"]
-    assert np.abs(th - cache.theta).max() <= 1e-9 * max(1.0, np.abs(th).max())
+    assert abs(st["ssr_final"] - cache.stats["ssr_final"]) <= 1e-7 * cache.stats["ssr_final"], (st, cache.stats)
+    assert np.abs(th - cache.theta).max() <= 1e-7 * max(1.0, np.abs(th).max())
 
 
 def test_profiling_spans(slam, texture):
