@@ -70,6 +70,7 @@ struct slam_ba {
     double *reduce = nullptr;    // internal reduce buffer (single-GPU path)
     int *chol_flag = nullptr;    // device flag: a pivot was not positive
     double *linv = nullptr;      // inverses of the factored diagonal tiles, nbc x 32 x 32
+    double *lfac = nullptr;      // finished factor tiles + forward-substituted rhs row, (n+1) x n
     std::vector<int> perm;       // sorted position -> original observation index
     int nblocks_obs = 0, nblocks_pts = 0;
 };
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void k_blocks(BADev d, int use_state)
 // L y = g falls out of the factorisation (y' = last row of L); a single blocked
 // back-substitution kernel finishes L' dp = y.
 #define CT 32
-struct CholArgs { double *A; int n, ld; int *fail; };
+struct CholArgs { double *A; double *Lf; int n, ld; int *fail; };   // A: working matrix (updated in place); Lf: finished factor tiles
 
 // copy S -> work (lower triangle + rhs row), add the LM damping to the diagonal
 __global__ __launch_bounds__(256) void k_chol_prepare(BADev d, const double *Sin, const double *gin, const double *udin,
@@ -457,7 +458,8 @@ __global__ __launch_bounds__(256) void k_chol_step(BADev d, CholArgs C, double *
     if (c == k) {                                                   // panel tile: store L_rk
         for (int e = tid; e < CT * CT; e += 256) {
             const int i = e % CT, j = e / CT;
-            if (i < hr && j < wk) C.A[(size_t)(CT * r + i) + (size_t)(CT * k + j) * ld] = Lr[i][j];
+            // NOT in place: other workgroups of this launch still read the un-solved panel from A
+            if (i < hr && j < wk) C.Lf[(size_t)(CT * r + i) + (size_t)(CT * k + j) * ld] = Lr[i][j];
         }
         return;
     }
@@ -478,9 +480,10 @@ __global__ __launch_bounds__(256) void k_chol_step(BADev d, CholArgs C, double *
         double *Lo = Linv + (size_t)(k + 1) * CT * CT;
         for (int e = tid; e < CT * CT; e += 256) { const int i = e % CT, j = e / CT; Lo[i + CT * j] = Tmp[i][j]; }
     }
+    double *dstm = (r == k + 1 && c == k + 1) ? C.Lf : C.A;        // a factored diagonal tile is final
     for (int e = tid; e < CT * CT; e += 256) {
         const int i = e % CT, j = e / CT;
-        if (i < hr && j < wc && CT * r + i >= CT * c + j) C.A[(size_t)(CT * r + i) + (size_t)(CT * c + j) * ld] = Arc[i][j];
+        if (i < hr && j < wc && CT * r + i >= CT * c + j) dstm[(size_t)(CT * r + i) + (size_t)(CT * c + j) * ld] = Arc[i][j];
     }
 }
 
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(256) void k_chol_first(BADev d, CholArgs C, double 
     __syncthreads();
     for (int e = tid; e < CT * CT; e += 256) {
         const int i = e % CT, j = e / CT;
-        if (i < h && j < w && i >= j) C.A[(size_t)i + (size_t)j * ld] = t[i][j];
+        if (i < h && j < w && i >= j) C.Lf[(size_t)i + (size_t)j * ld] = t[i][j];
         Linv[i + CT * j] = inv[i][j];
     }
 }
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(BADev d, CholArgs C, con
     __shared__ double x[SOLVE_MAX_N];
     __shared__ double xb[CT];
     const int n = C.n, ld = C.ld, tid = threadIdx.x;
-    for (int a = tid; a < n; a += 256) x[a] = C.A[(size_t)n + (size_t)a * ld];
+    for (int a = tid; a < n; a += 256) x[a] = C.Lf[(size_t)n + (size_t)a * ld];
     __syncthreads();
     const int nbc = (n + CT - 1) / CT;
     for (int kb = nbc - 1; kb >= 0; kb--) {
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(BADev d, CholArgs C, con
         __syncthreads();
         for (int a = tid; a < j0; a += 256) {                       // y_a -= sum_j L[j0+j][a] x[j0+j]
             double s0 = 0.0;
-            for (int j = 0; j < w; j++) s0 += C.A[(size_t)(j0 + j) + (size_t)a * ld] * x[j0 + j];
+            for (int j = 0; j < w; j++) s0 += C.Lf[(size_t)(j0 + j) + (size_t)a * ld] * x[j0 + j];
             x[a] -= s0;
         }
         __syncthreads();
@@ -788,7 +791,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     const size_t o_T = take((size_t)18 * O * 8 + 8), o_W = take((size_t)18 * O * 8 + 8);
     const size_t o_pairs = take(npairs * 8 + 8), o_bs = take((size_t)(nblk + 1) * 4), o_bpq = take((size_t)nblk * 8 + 8);
     const size_t o_red = take(((size_t)n * n + 2 * n + 8) * 8), o_Sw = take((size_t)(n + 1) * n * 8), o_dp = take(n * 8), o_dl = take((size_t)3 * M * 8 + 8);
-    const size_t o_cf = take(64), o_li = take((size_t)((n + CT - 1) / CT) * CT * CT * 8);
+    const size_t o_cf = take(64), o_li = take((size_t)((n + CT - 1) / CT) * CT * CT * 8), o_lf = take((size_t)(n + 1) * n * 8);
     const size_t o_part = take(((size_t)ba->nblocks_pts + 2 * ba->nblocks_obs + 8) * 8), o_st = take(sizeof(LMState));
     char *A;
     hipError_t e = hipMalloc((void **)&A, off);
@@ -807,7 +810,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     d.S = ba->reduce; d.g = ba->reduce + (size_t)n * n; d.udiag = d.g + n;
     d.Swork = (double *)(A + o_Sw); d.dp = (double *)(A + o_dp); d.dl = (double *)(A + o_dl);
     d.part = (double *)(A + o_part); d.st = (LMState *)(A + o_st);
-    ba->chol_flag = (int *)(A + o_cf); ba->linv = (double *)(A + o_li);
+    ba->chol_flag = (int *)(A + o_cf); ba->linv = (double *)(A + o_li); ba->lfac = (double *)(A + o_lf);
     hipStream_t st = ctx->stream;
 #define UP(dst, src, bytes) do { if ((bytes) > 0) HIP_TRY(ctx, hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
     UP(d.pose, theta, (size_t)n * 8); UP(d.pts, theta + n, (size_t)3 * M * 8);
@@ -845,7 +848,7 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
     const int n = d.n;
     hipStream_t st = ctx->stream;
     {
-        CholArgs C; C.A = d.Swork; C.n = n; C.ld = n + 1; C.fail = ba->chol_flag;
+        CholArgs C; C.A = d.Swork; C.Lf = ba->lfac; C.n = n; C.ld = n + 1; C.fail = ba->chol_flag;
         const size_t tot = (size_t)(n + 1) * n;
         hipLaunchKernelGGL(k_chol_prepare, dim3((tot + 255) / 256), dim3(256), 0, st, d, red, red + (size_t)n * n, red + (size_t)n * n + n, inv_delta, use_state);
         hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, st, d, C, ba->linv, use_state);
