@@ -118,6 +118,10 @@ int slam_pyr_destroy(slam_pyr *pyr);
 int slam_pyr_update(slam_ctx *ctx, slam_pyr *pyr, const double *image, int mode, double sigma);
 /* image already in HBM (column-major f64); returns after enqueueing when sync == 0 */
 int slam_pyr_update_dev(slam_ctx *ctx, slam_pyr *pyr, const double *image_dev, int mode, double sigma, int sync);
+/* Same, from the 8-bit image the KITTI reader decodes (example/kitty/kitty.jl:52-102) before
+ * `Gray{Float64}.(frame)` (example/kitty/main.jl:39-41): the conversion raw/255 runs on the device,
+ * so the host link carries 1 byte per pixel instead of 8. */
+int slam_pyr_update_u8(slam_ctx *ctx, slam_pyr *pyr, const uint8_t *image_u8, int mode, double sigma);
 /* copy!(dst, src) pyramid.jl:28-38 (same shape required) */
 int slam_pyr_copy(slam_ctx *ctx, slam_pyr *dst, const slam_pyr *src);
 /* deepcopy(lk) SLAM.jl:218 */

@@ -34,6 +34,7 @@ SIGNATURES = {
     "slam_pyr_create": (cint, [vp, cint, cint, cint, C.POINTER(vp)]),
     "slam_pyr_destroy": (cint, [vp]),
     "slam_pyr_update": (cint, [vp, vp, f64p, cint, dbl]),
+    "slam_pyr_update_u8": (cint, [vp, vp, u8p, cint, dbl]),
     "slam_pyr_update_dev": (cint, [vp, vp, vp, cint, dbl, cint]),
     "slam_pyr_copy": (cint, [vp, vp, vp]),
     "slam_pyr_clone": (cint, [vp, vp, C.POINTER(vp)]),

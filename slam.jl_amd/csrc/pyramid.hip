@@ -582,6 +582,14 @@ __global__ __launch_bounds__(256) void k_resize(double *dst, int Hd, int Wd, con
     dst[i] = (1 - fy) * r0 + fy * r1;
 }
 
+// Gray{Float64}.(img::Matrix{Gray{N0f8}}) of the KITTI reader (example/kitty/main.jl:39-41):
+// Float64(::N0f8) = raw / 255 (FixedPointNumbers >= 0.8 divides; correctly rounded)
+__global__ __launch_bounds__(256) void k_u8_to_f64(double *dst, const unsigned char *src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (double)src[i] / 255.0;
+}
+
 __global__ __launch_bounds__(256) void k_fill(double *p, size_t n, double v)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -812,6 +820,22 @@ int slam_pyr_update(slam_ctx *ctx, slam_pyr *p, const double *image, int mode, d
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(p->plane(0, 0), image, (size_t)p->H[0] * p->W[0] * 8, hipMemcpyHostToDevice, ctx->stream));
     int rc = enqueue_build(ctx, p, mode, sigma);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+int slam_pyr_update_u8(slam_ctx *ctx, slam_pyr *p, const uint8_t *image_u8, int mode, double sigma)
+{
+    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_u8 != nullptr && (mode == 0 || mode == 1 || mode == 3) && sigma > 0);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)p->H[0] * p->W[0];
+    void *d8;
+    int rc = slam_scratch2(ctx, n, &d8);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d8, image_u8, n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_u8_to_f64, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, p->plane(0, 0), (const unsigned char *)d8, n);
+    rc = enqueue_build(ctx, p, mode, sigma);
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLAM_OK;

@@ -80,6 +80,10 @@ def update_(lk, img, sigma=1.0, device_ptr=None, sync=True, ctx=None, fast=False
     if device_ptr is not None:
         c = ctx or lk.ctx
         c.check(c.lib.slam_pyr_update_dev(c.h, lk.h, C.c_void_p(device_ptr), mode, float(sigma), 1 if sync else 0))
+    elif np.asarray(img).dtype == np.uint8:
+        img = np.asfortranarray(img)                     # 8-bit frame: converted to Gray{Float64} (raw/255) on the device
+        assert img.shape == lk.level_shape(0)
+        lk.ctx.check(lk.ctx.lib.slam_pyr_update_u8(lk.ctx.h, lk.h, L.ptr(img, L.u8p), mode, float(sigma)))
     else:
         img = np.asfortranarray(img, dtype=np.float64)
         assert img.shape == lk.level_shape(0)

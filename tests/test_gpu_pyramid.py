@@ -87,3 +87,15 @@ def test_fast_mode_within_tolerance(slam, orc, texture, H, W):
     assert (sf != se).sum() <= max(1, len(kp) // 200)
     both = sf & se
     assert np.abs(of[both] - oe[both]).max() < 1e-7
+
+
+def test_u8_ingest_bit_exact(slam, orc, texture):
+    """8-bit frames (what the KITTI reader decodes): raw/255 on the device == Gray{Float64}.(img) on the host."""
+    img = texture(101, 75)[0][0]
+    u8 = np.asfortranarray(np.round(img * 255).astype(np.uint8))
+    lk = slam.LKPyramid(shape=u8.shape, levels=2)
+    slam.update_(lk, u8)
+    ref = orc.pyr_build(np.asfortranarray(u8.astype(np.float64) / 255.0), 2, 1.0, 1)
+    for name in PLANES:
+        for l in range(3):
+            assert np.array_equal(lk.plane(name, l), ref.plane(name, l)), (name, l)
