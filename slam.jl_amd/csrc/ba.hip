@@ -352,11 +352,17 @@ __global__ __launch_bounds__(256) void k_chol_prepare(BADev d, const double *Sin
 // Factor a diagonal tile and invert its triangle, by ONE wave, rows in registers.
 // t (LDS, 32x33): in = tile (lower part, h rows x w valid columns, rows >= w are
 // panel rows riding along), out = L.  inv (LDS): out = L^-1 (w x w lower).
-// Lane i owns row i; column j is exchanged through a 32-double LDS line.  Fully
-// unrolled and predicated (no branches): every lane op is a select on the
-// wave-uniform tile extents.
+// Lane i owns row i.  Everything another lane needs (the pivot, column j of L, row i
+// of L for the inverse) is a wave-uniform value, so it is fetched with v_readlane
+// into scalar registers -- no LDS round trip on the 32-step dependent chain.
+// Fully unrolled and predicated on the wave-uniform tile extents (no branches).
+__device__ __forceinline__ double rl64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ void tile_potrf_inv(double (*t)[CT + 1], double (*inv)[CT + 1], double *col, int h, int w, int *fail)
 {
+    (void)col;
     const int lane = threadIdx.x & 63;
     double row[CT], rdiag[CT];
     bool bad = false;
@@ -365,36 +371,30 @@ __device__ __forceinline__ void tile_potrf_inv(double (*t)[CT + 1], double (*inv
 #pragma unroll
     for (int j = 0; j < CT; j++) {
         const bool active = j < w;
-        double dj = __shfl(row[j], j);
+        double dj = rl64(row[j], j);
         bad = bad || (active && !(dj > 0));
         dj = (active && dj > 0) ? dj : 1.0;
         const double rd = rsqrt(dj);
         rdiag[j] = rd;
         const double l = (lane == j) ? dj * rd : row[j] * rd;
         row[j] = active ? l : row[j];
-        if (lane < CT) col[lane] = l;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int m = j + 1; m < CT; m++) {
-            const double lm = col[m];
+            const double lm = rl64(l, m);
             row[m] -= (active && m < w && lane >= m) ? l * lm : 0.0;
         }
-        __builtin_amdgcn_wave_barrier();
     }
     if (lane < CT) {
 #pragma unroll
         for (int m = 0; m < CT; m++) t[lane][m] = (m <= lane && m < w && lane < h) ? row[m] : 0.0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // inverse: lane c solves L x = e_c (forward substitution), x in registers
+    // inverse: lane c solves L x = e_c (forward substitution), x in registers; L[i][m] = row m of lane i
     double x[CT];
 #pragma unroll
     for (int i = 0; i < CT; i++) {
         double sacc = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
-        for (int m = 0; m < i; m++) sacc -= t[i][m] * x[m];
+        for (int m = 0; m < i; m++) sacc -= rl64(row[m], i) * x[m];
         x[i] = (i < w && lane <= i) ? sacc * rdiag[i] : 0.0;
     }
     if (lane < CT) {
