@@ -195,7 +195,7 @@ __device__ __forceinline__ void inv3_sym(const double V[6], double I[6])
 __global__ __launch_bounds__(256) void k_points(BADev d, double inv_delta_host, int use_state)
 {
     if (use_state && d.st->converged) return;
-    const int j = blockIdx.x * 256 + threadIdx.x, O = d.O, M = d.M;
+    const int j = blockIdx.x * 256 + threadIdx.x, M = d.M;
     if (j >= M) return;
     const double inv_delta = use_state ? 1.0 / d.st->delta : inv_delta_host;
     double V[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
@@ -360,9 +360,8 @@ __device__ __forceinline__ double rl64(double v, int lane)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
-__device__ __forceinline__ void tile_potrf_inv(double (*t)[CT + 1], double (*inv)[CT + 1], double *col, int h, int w, int *fail)
+__device__ __forceinline__ void tile_potrf_inv(double (*t)[CT + 1], double (*inv)[CT + 1], int h, int w, int *fail)
 {
-    (void)col;
     const int lane = threadIdx.x & 63;
     double row[CT], rdiag[CT];
     bool bad = false;
@@ -408,7 +407,6 @@ __global__ __launch_bounds__(256) void k_chol_step(BADev d, CholArgs C, double *
 {
     if (use_state && d.st->converged) return;
     __shared__ double Li[CT][CT + 1], Lr[CT][CT + 1], Lc[CT][CT + 1], Arc[CT][CT + 1], Tmp[CT][CT + 1];
-    __shared__ double col[CT];
     const int n = C.n, ld = C.ld, tid = threadIdx.x;
     int r, c;
     {
@@ -475,7 +473,7 @@ __global__ __launch_bounds__(256) void k_chol_step(BADev d, CholArgs C, double *
     }
     __syncthreads();
     if (r == k + 1 && c == k + 1) {                                 // next panel's diagonal tile is final now
-        if (tid < 64) tile_potrf_inv(Arc, Tmp, col, hr, wc, C.fail);
+        if (tid < 64) tile_potrf_inv(Arc, Tmp, hr, wc, C.fail);
         __syncthreads();
         double *Lo = Linv + (size_t)(k + 1) * CT * CT;
         for (int e = tid; e < CT * CT; e += 256) { const int i = e % CT, j = e / CT; Lo[i + CT * j] = Tmp[i][j]; }
@@ -491,13 +489,12 @@ __global__ __launch_bounds__(256) void k_chol_first(BADev d, CholArgs C, double 
 {
     if (use_state && d.st->converged) return;
     __shared__ double t[CT][CT + 1], inv[CT][CT + 1];
-    __shared__ double col[CT];
     const int n = C.n, ld = C.ld, tid = threadIdx.x;
     const int h = min(CT, n + 1), w = min(CT, n);
     for (int e = tid; e < CT * CT; e += 256) { const int i = e % CT, j = e / CT; t[i][j] = (i < h && j < w && i >= j) ? C.A[(size_t)i + (size_t)j * ld] : 0.0; }
     if (tid == 0) *C.fail = 0;
     __syncthreads();
-    if (tid < 64) tile_potrf_inv(t, inv, col, h, w, C.fail);
+    if (tid < 64) tile_potrf_inv(t, inv, h, w, C.fail);
     __syncthreads();
     for (int e = tid; e < CT * CT; e += 256) {
         const int i = e % CT, j = e / CT;
@@ -543,7 +540,7 @@ __global__ __launch_bounds__(256) void k_backsub(BADev d, int use_state)
 {
     __shared__ double sh[4];
     if (use_state && d.st->converged) return;
-    const int j = blockIdx.x * 256 + threadIdx.x, O = d.O, M = d.M;
+    const int j = blockIdx.x * 256 + threadIdx.x, M = d.M;
     double mx = 0.0;
     if (j < M) {
         double bl[3] = {d.bl[j], d.bl[(size_t)M + j], d.bl[(size_t)2 * M + j]};

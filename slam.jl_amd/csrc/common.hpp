@@ -6,7 +6,6 @@
 #include <cstring>
 #include <string>
 #include <vector>
-#include <map>
 #include "../../include/slamhip.h"
 
 #define SLAM_MAX_LEVELS 8

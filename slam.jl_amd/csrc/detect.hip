@@ -309,11 +309,8 @@ int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, const
     int64_t *d_cout = (int64_t *)(s + cur_b + cnt_b); int64_t *d_out = (int64_t *)(s + cur_b + cnt_b + cout_b);
     if (n_cur > 0) HIP_TRY(ctx, hipMemcpyAsync(d_cur, cur_yx, (size_t)n_cur * 16, hipMemcpyHostToDevice, ctx->stream));
     A.cur = d_cur; A.cell_out = d_cout; A.cell_cnt = d_cnt;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)detect_cells, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    // > 64 KB of dynamic LDS needs the opt-in; per device, so set it on every call (cheap host-side call)
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)detect_cells, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     { ProfScope span(ctx, "detect");
       hipLaunchKernelGGL(detect_cells, dim3(n_cells), dim3(DET_THREADS), lds_bytes, ctx->stream, A);
       hipLaunchKernelGGL(detect_compact, dim3(1), dim3(1024), 0, ctx->stream, d_cout, d_cnt, n_cells, k, d_out, (int)out_pairs); }
