@@ -213,7 +213,7 @@ def main():
 
     import slam_jl_amd as slam
     from slam_jl_amd import synthetic as syn
-    ctx = slam.Context(local_rank, high_priority=True)      # tracking / detect: latency-critical, results are read back synchronously
+    ctx = slam.Context(local_rank)
     H, W = syn.SHAPES[SHAPE]
     params = slam.Params(stereo=True, max_nb_keypoints=N_KPTS)
     cam = slam.Camera(*syn.KITTI_CAM, height=H, width=W)
@@ -342,7 +342,7 @@ def main():
 
     # ---- same stream with the tolerance-mode pyramid (mode 3: parallel recurrences, planes within 1e-11 rel.) ----
     if True:
-        fctx = [slam.Context(local_rank, high_priority=(i == 0)) for i in range(3)]
+        fctx = [slam.Context(local_rank) for _ in range(3)]
         fbe = GpuBackend(slam, fctx[0], fctx[1], fctx[2], H, W, left_dev, right_dev, params, extractor, fast=True)
         fs = Stream(fbe, flows, disparity, seed=rank)
         fbe.prime(seq[0])

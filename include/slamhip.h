@@ -46,9 +46,6 @@ enum slam_status {
 
 /* ---- context --------------------------------------------------------------- */
 int  slam_ctx_create(int device, slam_ctx **out);
-/* same, on a high-priority HIP stream (latency-critical task, e.g. the front-end's tracking calls while
- * another context streams pyramid builds; the reference's analogue is its dedicated front-end task) */
-int  slam_ctx_create_prio(int device, int high_priority, slam_ctx **out);
 int  slam_ctx_destroy(slam_ctx *ctx);
 int  slam_ctx_synchronize(slam_ctx *ctx);
 /* Device-side ordering between two contexts of one device: work enqueued on `ctx`

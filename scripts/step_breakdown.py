@@ -14,7 +14,7 @@ left, right, flows = syn.stereo_stream("kitti05", 8, seed=0, disparity=12.4)
 dev = torch.device("cuda", 0)
 ld = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in left]
 rd = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in right]
-ctxs = [slam.Context(0, high_priority=(i == 0)) for i in range(3)]
+ctxs = [slam.Context(0) for _ in range(3)]
 be = bench.GpuBackend(slam, ctxs[0], ctxs[1], ctxs[2], H, W, ld, rd, params, ex, fast=fast)
 T = collections.defaultdict(float); N = collections.defaultdict(int)
 def wrap(obj, name):

@@ -19,7 +19,6 @@ dbl, cint = C.c_double, C.c_int
 # name -> (restype, argtypes); kept in sync with include/slamhip.h (tests/test_abi.py checks it)
 SIGNATURES = {
     "slam_ctx_create": (cint, [cint, C.POINTER(vp)]),
-    "slam_ctx_create_prio": (cint, [cint, cint, C.POINTER(vp)]),
     "slam_ctx_destroy": (cint, [vp]),
     "slam_ctx_synchronize": (cint, [vp]),
     "slam_ctx_stream": (vp, [vp]),
@@ -94,10 +93,10 @@ def ptr(a, t=f64p):
 class Context:
     """One per calling task (SURVEY 8b threading): owns a HIP stream + scratch."""
 
-    def __init__(self, device=0, high_priority=False):
+    def __init__(self, device=0):
         self.lib = load()
         h = vp()
-        rc = self.lib.slam_ctx_create_prio(device, 1 if high_priority else 0, C.byref(h))
+        rc = self.lib.slam_ctx_create(device, C.byref(h))
         if rc != 0:
             raise SlamHipError(f"slam_ctx_create failed ({rc}): {self.lib.slam_last_error(None).decode()}")
         self.h = h

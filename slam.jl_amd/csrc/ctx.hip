@@ -88,7 +88,7 @@ int slam_prof_get(slam_ctx *ctx, const char *name, double *total_ms, int64_t *co
     return SLAM_OK;
 }
 
-static int ctx_create(int device, int high_priority, slam_ctx **out)
+int slam_ctx_create(int device, slam_ctx **out)
 {
     if (!out) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_ctx_create: out is NULL");
     int n = 0;
@@ -102,18 +102,11 @@ static int ctx_create(int device, int high_priority, slam_ctx **out)
     (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
     (void)hipGetLastError();
     e = hipSetDevice(device);
-    if (e == hipSuccess) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // numerically lower = higher priority
-        e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, high_priority ? hi : lo);
-    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create: %s", hipGetErrorString(e)); }
     *out = c;
     return SLAM_OK;
 }
-
-int slam_ctx_create(int device, slam_ctx **out) { return ctx_create(device, 0, out); }
-int slam_ctx_create_prio(int device, int high_priority, slam_ctx **out) { return ctx_create(device, high_priority, out); }
 
 int slam_ctx_destroy(slam_ctx *ctx)
 {
