@@ -157,6 +157,21 @@ int slam_flow_match(slam_ctx *ctx, const slam_pyr *from, const slam_pyr *to,
                     double eig_thr, double eps, double max_distance,
                     double *out_yx, uint8_t *status);
 
+/* ---- lock-stepped batches of streams --------------------------------------- */
+/* The recurrences of the pyramid build are latency-bound for one image; S independent images
+ * (left + right of a key-frame, or S camera streams) share every launch when their pyramids live in one batch.
+ * slam_pyr_create_batch fills out[0..S) with ordinary pyramid handles backed by one allocation; each can be used
+ * with every single-pyramid call above.  slam_pyr_update_batch_dev rebuilds all S in one launch set (pyrs must
+ * be the S members of one batch, in order; images already in HBM); slam_flow_match_batch tracks the keypoints
+ * of all S streams in one launch (img_index[i] = stream of point i; from0 / to0 = member 0 of two batches). */
+int slam_pyr_create_batch(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, slam_pyr **out);
+int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double *const *images_dev, int S,
+                              int mode, double sigma, int sync);
+int slam_flow_match_batch(slam_ctx *ctx, const slam_pyr *from0, const slam_pyr *to0, int S, const int32_t *img_index,
+                          const double *pts_yx, const uint8_t *is_3d, const double *proj_yx, int n,
+                          int pyramid_levels, int pyramid_levels_3d, int window, int iterations,
+                          double eig_thr, double eps, double max_distance, double *out_yx, uint8_t *status);
+
 /* ---- bundle adjustment ------------------------------------------------------ */
 /* bundle_adjustment!(cache::LocalBACache, camera; iterations, repr_eps) --
  * src/bundle_adjustment.jl:1-111 on the flat arrays of src/estimator.jl:16-40:

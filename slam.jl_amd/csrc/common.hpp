@@ -51,12 +51,16 @@ struct slam_pyr {
     int levels = 0;                       // total layers = pyramid_levels + 1
     int H[SLAM_MAX_LEVELS], W[SLAM_MAX_LEVELS];
     int64_t off[SLAM_MAX_LEVELS + 1];     // plane offsets in doubles
-    double *planes = nullptr;             // 6 planes x off[levels] doubles, one allocation
+    struct Alloc { double *base = nullptr; int refs = 0; };   // shared by the members of a batch
+    Alloc *alloc = nullptr;
+    size_t zstride = 0;                   // doubles between consecutive images of a batch (7 * off[levels])
+    int batch_index = 0, batch_size = 1;
+    double *planes = nullptr;             // 6 planes x off[levels] doubles (inside alloc)
     double *tmp = nullptr;                // blur scratch, off[levels] doubles
     double *norm = nullptr;               // NA() normaliser per level (ctor mode), lazily built
     double norm_sigma = -1.0;
     // hipGraph replay of the build (captured lazily per (mode, sigma)); aux = forked stream
-    struct Graph { int mode; double sigma; hipGraphExec_t exec; };
+    struct Graph { int mode; double sigma; int S; hipGraphExec_t exec; };
     std::vector<Graph> graphs;
     bool graph_failed = false;
     hipStream_t aux = nullptr;

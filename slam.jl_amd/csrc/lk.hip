@@ -221,18 +221,26 @@ __device__ bool lk_level(const LevelView &first, const LevelView &second, int le
 
 // fb_tracking! for one point (tracker.jl:17-66): forward levels, level-1 backward
 // pass from the forward result, consistency test.  Wave-uniform.
+__device__ __forceinline__ LevelView shifted(const LevelView &v, size_t off)
+{
+    LevelView r = v;
+    r.L += off; r.Iy += off; r.Ix += off; r.Iyy += off; r.Ixx += off; r.Iyx += off;
+    return r;
+}
+
+// offP / offC: plane offset (doubles) of this point's image inside a pyramid batch (0 for single pyramids)
 __device__ __forceinline__ bool fb_point(const PyrView &prev, const PyrView &cur, double py, double px, double dy, double dx,
                                          int pyramid_levels, int window, int iterations, double eig_thr, double eps,
-                                         double max_distance, double &ny, double &nx)
+                                         double max_distance, double &ny, double &nx, size_t offP = 0, size_t offC = 0)
 {
     bool ok = true;
     for (int level = pyramid_levels + 1; level >= 1 && ok; level--)
-        ok = lk_level(prev.lv[level - 1], cur.lv[level - 1], level, py, px, dy, dx, window, iterations, eig_thr, eps);
+        ok = lk_level(shifted(prev.lv[level - 1], offP), shifted(cur.lv[level - 1], offC), level, py, px, dy, dx, window, iterations, eig_thr, eps);
     if (!ok) return false;
     ny = py + dy; nx = px + dx;                           // tracker.jl:41-42
     double by = -dy * 1.0, bx = -dx * 1.0;                // back_displacement, scale = 1/2^0
     // backward: pyramid_levels = 0, default eps 1e-2 (tracker.jl:34,51-57)
-    ok = lk_level(cur.lv[0], prev.lv[0], 1, ny, nx, by, bx, window, iterations, eig_thr, 1e-2);
+    ok = lk_level(shifted(cur.lv[0], offC), shifted(prev.lv[0], offP), 1, ny, nx, by, bx, window, iterations, eig_thr, 1e-2);
     if (!ok) return false;
     const double b0 = ny + by, b1 = nx + bx;
     const double d0 = py - b0, d1 = px - b1;
@@ -262,6 +270,8 @@ __global__ __launch_bounds__(64) void k_fb_track(LKArgs A)
 struct FlowArgs {
     LKArgs lk;
     const uint8_t *is3d; const double *proj; int levels3d;
+    const int *img;            // batched call: image index of each point inside the pyramid batches (nullptr: single pyramids)
+    size_t zs_from, zs_to;     // batch strides (doubles) of the from / to pyramids
 };
 __global__ __launch_bounds__(64) void k_flow_match(FlowArgs F)
 {
@@ -270,12 +280,14 @@ __global__ __launch_bounds__(64) void k_flow_match(FlowArgs F)
     const double py = A.pts[2 * i], px = A.pts[2 * i + 1];
     double ny = nan(""), nx = nan("");
     bool ok = false;
+    const size_t zi = F.img ? (size_t)F.img[i] : 0;
+    const size_t offP = zi * F.zs_from, offC = zi * F.zs_to;
     if (F.is3d[i]) {
         const double scale = 1.0 / (double)(1 << F.levels3d);
         const double dy = scale * (F.proj[2 * i] - py), dx = scale * (F.proj[2 * i + 1] - px);      // map_manager.jl:494,504
-        ok = fb_point(A.prev, A.cur, py, px, dy, dx, F.levels3d, A.window, A.iterations, A.eig_thr, A.eps, A.max_distance, ny, nx);
+        ok = fb_point(A.prev, A.cur, py, px, dy, dx, F.levels3d, A.window, A.iterations, A.eig_thr, A.eps, A.max_distance, ny, nx, offP, offC);
     }
-    if (!ok) ok = fb_point(A.prev, A.cur, py, px, 0.0, 0.0, A.pyramid_levels, A.window, A.iterations, A.eig_thr, A.eps, A.max_distance, ny, nx);
+    if (!ok) ok = fb_point(A.prev, A.cur, py, px, 0.0, 0.0, A.pyramid_levels, A.window, A.iterations, A.eig_thr, A.eps, A.max_distance, ny, nx, offP, offC);
     if ((threadIdx.x & 63) == 0) {
         A.out[2 * i] = ok ? ny : nan(""); A.out[2 * i + 1] = ok ? nx : nan("");
         A.status[i] = ok ? 1 : 0;
@@ -291,10 +303,11 @@ static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 // stream sync per call.
 static int run_tracking(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr *cur, const double *pts_yx, const double *aux_yx,
                         const uint8_t *is3d, int n, int pyramid_levels, int levels3d, int window, int iterations,
-                        double eig_thr, double eps, double max_distance, double *out_yx, uint8_t *status, bool flow)
+                        double eig_thr, double eps, double max_distance, double *out_yx, uint8_t *status, bool flow,
+                        const int32_t *img_index = nullptr)
 {
-    const size_t pb = al256((size_t)n * 16), sb = al256((size_t)n);
-    const size_t in_b = 2 * pb + sb, out_b = pb + sb;
+    const size_t pb = al256((size_t)n * 16), sb = al256((size_t)n), ib = al256((size_t)n * 4);
+    const size_t in_b = 2 * pb + sb + ib, out_b = pb + sb;
     char *h, *d;
     int rc = slam_pinned(ctx, in_b + out_b, (void **)&h);
     if (rc) return rc;
@@ -302,6 +315,7 @@ static int run_tracking(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr *cur
     memcpy(h, pts_yx, (size_t)n * 16);
     if (aux_yx) memcpy(h + pb, aux_yx, (size_t)n * 16);
     if (is3d) memcpy(h + 2 * pb, is3d, (size_t)n);
+    if (img_index) memcpy(h + 2 * pb + sb, img_index, (size_t)n * 4);
     FlowArgs F;
     LKArgs &A = F.lk;
     A.prev = prev->view; A.cur = cur->view;
@@ -310,6 +324,7 @@ static int run_tracking(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr *cur
     A.eig_thr = eig_thr; A.eps = eps; A.max_distance = max_distance;
     A.out = (double *)(d + in_b); A.status = (uint8_t *)(d + in_b + pb);
     F.is3d = (const uint8_t *)(d + 2 * pb); F.proj = (const double *)(d + pb); F.levels3d = levels3d;
+    F.img = img_index ? (const int *)(d + 2 * pb + sb) : nullptr; F.zs_from = prev->zstride; F.zs_to = cur->zstride;
     { ProfScope span(ctx, "fb_track");
       if (flow) hipLaunchKernelGGL(k_flow_match, dim3(n), dim3(64), 0, ctx->stream, F);
       else hipLaunchKernelGGL(k_fb_track, dim3(n), dim3(64), 0, ctx->stream, A); }
@@ -355,4 +370,27 @@ extern "C" int slam_flow_match(slam_ctx *ctx, const slam_pyr *from, const slam_p
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return run_tracking(ctx, from, to, pts_yx, proj_yx, is_3d, n, pyramid_levels, pyramid_levels_3d, window, iterations, eig_thr, eps,
                         max_distance, out_yx, status, true);
+}
+
+// optical_flow_matching! for S lock-stepped streams in one launch: point i belongs to stream img_index[i]; from0 / to0 are
+// member 0 of two pyramid batches (slam_pyr_create_batch) of the same size.  Per point identical to slam_flow_match on that
+// stream's own pyramids (points are independent); one launch and one stream sync for all streams.
+extern "C" int slam_flow_match_batch(slam_ctx *ctx, const slam_pyr *from0, const slam_pyr *to0, int S, const int32_t *img_index,
+                                     const double *pts_yx, const uint8_t *is_3d, const double *proj_yx, int n,
+                                     int pyramid_levels, int pyramid_levels_3d, int window, int iterations,
+                                     double eig_thr, double eps, double max_distance, double *out_yx, uint8_t *status)
+{
+    ARG_TRY(ctx, ctx != nullptr && from0 != nullptr && to0 != nullptr && S >= 1);
+    ARG_TRY(ctx, from0->batch_index == 0 && to0->batch_index == 0 && from0->batch_size >= S && to0->batch_size >= S);
+    ARG_TRY(ctx, n >= 0 && pyramid_levels >= 0 && pyramid_levels_3d >= 0 && window >= 0 && iterations >= 0);
+    if (n == 0) return SLAM_OK;
+    ARG_TRY(ctx, img_index != nullptr && pts_yx != nullptr && is_3d != nullptr && proj_yx != nullptr && out_yx != nullptr && status != nullptr);
+    for (int i = 0; i < n; i++) if (img_index[i] < 0 || img_index[i] >= S) return slam_fail(ctx, SLAM_ERR_ARG, "slam_flow_match_batch: img_index[%d] = %d outside [0,%d)", i, img_index[i], S);
+    const int need = pyramid_levels > pyramid_levels_3d ? pyramid_levels : pyramid_levels_3d;
+    if (!(from0->levels > need && to0->levels > need))
+        return slam_fail(ctx, SLAM_ERR_LAYERS, "Not enough layers in pyramids.");
+    ARG_TRY(ctx, from0->H[0] == to0->H[0] && from0->W[0] == to0->W[0]);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return run_tracking(ctx, from0, to0, pts_yx, proj_yx, is_3d, n, pyramid_levels, pyramid_levels_3d, window, iterations, eig_thr, eps,
+                        max_distance, out_yx, status, true, img_index);
 }

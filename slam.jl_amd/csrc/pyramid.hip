@@ -26,7 +26,10 @@ struct PlaneSet {
     int coef[4];           // which IIRCoef (0 = pyramid sigma, 1 = sigma 4)
     int fill0[4];          // border: 0 replicate, 1 Fill(0)
     int n;
+    size_t zs;             // batch: image blockIdx.z lives zs doubles after image 0 (0 for a single pyramid)
 };
+// batched launches: grid.z = image index; every plane pointer of image z is image 0's + z * zs
+#define PS_Z(ps) do { const size_t _z = (size_t)blockIdx.z * (ps).zs; _Pragma("unroll") for (int _k = 0; _k < 4; _k++) if ((ps).p[_k]) (ps).p[_k] += _z; } while (0)
 
 struct IIRPair { IIRCoef c[2]; };
 
@@ -313,6 +316,7 @@ __device__ __forceinline__ void iir_line(const IO &io, int n, const IIRCoef &k, 
 // dst for plane 0 (the blur reads the layer and writes the scratch plane).
 __global__ __launch_bounds__(LINE_THREADS) void k_iir_cols(PlaneSet ps, const double *src0, int H, int W, IIRPair cf)
 {
+    PS_Z(ps); if (src0) src0 += (size_t)blockIdx.z * ps.zs;
     __shared__ double tile[4 * 64 * 9];
     const int pl = blockIdx.y;
     ColIO io;
@@ -324,6 +328,7 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_cols(PlaneSet ps, const do
 // dim-2 pass: one lane per row, in place; consecutive lanes = consecutive y.
 __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows(PlaneSet ps, int H, int W, IIRPair cf)
 {
+    PS_Z(ps);
     const int y = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
     if (y >= H) return;
     RowIO io; io.src = ps.p[pl] + y; io.dst = ps.p[pl] + y; io.s = H;
@@ -333,6 +338,7 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows(PlaneSet ps, int H, i
 // integral_image!, lucas_kanade.jl:131-138: cumsum along dim 1 ...
 __global__ __launch_bounds__(LINE_THREADS) void k_cum_cols(PlaneSet ps, int H, int W)
 {
+    PS_Z(ps);
     __shared__ double tile[4 * 64 * 9];
     const int pl = blockIdx.y;
     ColIO io; io.dst = ps.p[pl]; io.src = ps.p[pl]; io.H = H; io.W = W; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile;
@@ -342,6 +348,7 @@ __global__ __launch_bounds__(LINE_THREADS) void k_cum_cols(PlaneSet ps, int H, i
 // ... then along dim 2.
 __global__ __launch_bounds__(LINE_THREADS) void k_cum_rows(PlaneSet ps, int H, int W)
 {
+    PS_Z(ps);
     const int y = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
     if (y >= H) return;
     double *p = ps.p[pl] + y;
@@ -405,6 +412,7 @@ __device__ __forceinline__ void fold_entry(const SegPow &sp, int cs, double (*Z)
 template <bool COLS>
 __global__ __launch_bounds__(PAR_T) void k_iir_seg(PlaneSet ps, const double *src0, int H, int W, IIRPair cf, SegPow sp, int SL)
 {
+    PS_Z(ps); if (src0) src0 += (size_t)blockIdx.z * ps.zs;
     constexpr int LPW = 8, NSEG = PAR_T / LPW;
     __shared__ double Z[3][NSEG][LPW];
     __shared__ double GT[3][NSEG / PAR_G + 1][LPW];
@@ -487,6 +495,7 @@ __global__ __launch_bounds__(PAR_T) void k_iir_seg(PlaneSet ps, const double *sr
 template <bool COLS>
 __global__ __launch_bounds__(PAR_T) void k_cum_seg(PlaneSet ps, int H, int W, int SL)
 {
+    PS_Z(ps);
     constexpr int LPW = 8, NSEG = PAR_T / LPW;
     __shared__ double Zs[NSEG][LPW];
     __shared__ double Gs[NSEG / PAR_G + 1][LPW];
@@ -530,8 +539,9 @@ __device__ __forceinline__ double ldb(const double *L, int H, int W, int y, int 
     if (border == 0) { y = y < 0 ? 0 : (y >= H ? H - 1 : y); return L[(size_t)y + (size_t)x * H]; }
     return (y < 0 || y >= H) ? 0.0 : L[(size_t)y + (size_t)x * H];
 }
-__global__ __launch_bounds__(256) void k_scharr_products(LevelView v, int border)
+__global__ __launch_bounds__(256) void k_scharr_products(LevelView v, int border, size_t zs)
 {
+    { const size_t z = (size_t)blockIdx.z * zs; v.L += z; v.Iy += z; v.Ix += z; v.Iyy += z; v.Ixx += z; v.Iyx += z; }
     const int H = v.H, W = v.W;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)H * W) return;
@@ -559,8 +569,9 @@ __global__ __launch_bounds__(256) void k_scharr_products(LevelView v, int border
 }
 
 // ImageTransformations.imresize!(dst, interpolate!(src, BSpline(Linear())))
-__global__ __launch_bounds__(256) void k_resize(double *dst, int Hd, int Wd, const double *src, int Hs, int Ws)
+__global__ __launch_bounds__(256) void k_resize(double *dst, int Hd, int Wd, const double *src, int Hs, int Ws, size_t zs)
 {
+    dst += (size_t)blockIdx.z * zs; src += (size_t)blockIdx.z * zs;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)Hd * Wd) return;
     const int y = (int)(i % Hd) + 1, x = (int)(i / Hd) + 1;
@@ -590,13 +601,22 @@ __global__ __launch_bounds__(256) void k_u8_to_f64(double *dst, const unsigned c
     if (i < n) dst[i] = (double)src[i] / 255.0;
 }
 
+// batch ingest: image z of the batch is copied from its own device pointer into layer 0 of pyramid z
+#define BATCH_MAX 32
+struct ImgPtrs { const double *p[BATCH_MAX]; };
+__global__ __launch_bounds__(256) void k_gather_images(ImgPtrs src, double *dst, size_t n, size_t zs)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[(size_t)blockIdx.z * zs + i] = src.p[blockIdx.z][i];
+}
+
 __global__ __launch_bounds__(256) void k_fill(double *p, size_t n, double v)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
 }
 
-static inline dim3 lines_grid(int nlines, int nplanes) { return dim3((nlines + LINE_THREADS - 1) / LINE_THREADS, nplanes); }
+static inline dim3 lines_grid(int nlines, int nplanes, int S = 1) { return dim3((nlines + LINE_THREADS - 1) / LINE_THREADS, nplanes, S); }
 
 static void make_view(slam_pyr *p)
 {
@@ -662,8 +682,9 @@ static void seg_pow(const IIRPair &cf, int n, int SL, SegPow &sp)
 // with level l+1 (fork after the row pass, one join at the end).  With
 // aux == st everything is serial on one stream (profiling / fallback path).
 // mode 3 ("fast") swaps the sequential line kernels for the segmented ones.
-static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf, hipStream_t st, hipStream_t aux, bool spans)
+static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf, hipStream_t st, hipStream_t aux, bool spans, int S = 1)
 {
+    const size_t zs = p->zstride;
     const bool forked = aux != st;
     bool fast = mode == 3;
     if (fast && (seg_len(p->H[0], PAR_T / 8) > PAR_SLMAX || seg_len(p->W[0], PAR_T / 8) > PAR_SLMAX)) fast = false;   // lines > 2048 samples: exact kernels
@@ -674,7 +695,7 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         const LevelView &v = p->view.lv[l];
         const bool has_next = l + 1 < p->levels;
         double *T = p->tmp + p->off[l];
-        hipLaunchKernelGGL(k_scharr_products, dim3((n + 255) / 256), dim3(256), 0, st, v, border_mode);
+        hipLaunchKernelGGL(k_scharr_products, dim3((n + 255) / 256, 1, S), dim3(256), 0, st, v, border_mode, zs);
         // dim-1 IIR: [blur: L -> T], Iyy, Ixx, Iyx in place
         PlaneSet ps = {};
         int np = 0;
@@ -682,37 +703,37 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         ps.p[np] = v.Iyy; ps.coef[np] = 1; np++;
         ps.p[np] = v.Ixx; ps.coef[np] = 1; np++;
         ps.p[np] = v.Iyx; ps.coef[np] = 1; np++;
-        ps.n = np;
+        ps.n = np; ps.zs = zs;
         const double *src0 = has_next ? (const double *)v.L : (const double *)nullptr;
         PlaneSet pc = {};
-        pc.p[0] = v.Iyy; pc.p[1] = v.Ixx; pc.p[2] = v.Iyx; pc.n = 3;
+        pc.p[0] = v.Iyy; pc.p[1] = v.Ixx; pc.p[2] = v.Iyx; pc.n = 3; pc.zs = zs;
         if (fast) {
             const int slc = seg_len(H, PAR_T / 8), slr = seg_len(W, PAR_T / 8);
             SegPow spc, spr;
             seg_pow(cf, H, slc, spc); seg_pow(cf, W, slr, spr);
-            const dim3 gc((W + 7) / 8, np), gr((H + 7) / 8, np), gc3((W + 7) / 8, 3), gr3((H + 7) / 8, 3);
+            const dim3 gc((W + 7) / 8, np, S), gr((H + 7) / 8, np, S), gc3((W + 7) / 8, 3, S), gr3((H + 7) / 8, 3, S);
             hipLaunchKernelGGL(k_iir_seg<true>, gc, dim3(PAR_T), 0, st, ps, src0, H, W, cf, spc, slc);
             if (spans) { ProfScope span(ctx, "k_iir_rows");
                 hipLaunchKernelGGL(k_iir_seg<false>, gr, dim3(PAR_T), 0, st, ps, (const double *)nullptr, H, W, cf, spr, slr); }
             else hipLaunchKernelGGL(k_iir_seg<false>, gr, dim3(PAR_T), 0, st, ps, (const double *)nullptr, H, W, cf, spr, slr);
             if (forked) { (void)hipEventRecord(p->ev_fork[l], st); (void)hipStreamWaitEvent(aux, p->ev_fork[l], 0); }
             if (has_next)
-                hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256), dim3(256), 0, st,
-                                   p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], (const double *)T, H, W);
+                hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, st,
+                                   p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], (const double *)T, H, W, zs);
             hipLaunchKernelGGL(k_cum_seg<true>, gc3, dim3(PAR_T), 0, aux, pc, H, W, slc);
             hipLaunchKernelGGL(k_cum_seg<false>, gr3, dim3(PAR_T), 0, aux, pc, H, W, slr);
             continue;
         }
-        hipLaunchKernelGGL(k_iir_cols, lines_grid(W, np), dim3(LINE_THREADS), 0, st, ps, src0, H, W, cf);
+        hipLaunchKernelGGL(k_iir_cols, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, cf);
         if (spans) { ProfScope span(ctx, "k_iir_rows");
-            hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np), dim3(LINE_THREADS), 0, st, ps, H, W, cf); }
-        else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np), dim3(LINE_THREADS), 0, st, ps, H, W, cf);
+            hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, cf); }
+        else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, cf);
         if (forked) { (void)hipEventRecord(p->ev_fork[l], st); (void)hipStreamWaitEvent(aux, p->ev_fork[l], 0); }
         if (has_next)
-            hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256), dim3(256), 0, st,
-                               p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], (const double *)T, H, W);
-        hipLaunchKernelGGL(k_cum_cols, lines_grid(W, 3), dim3(LINE_THREADS), 0, aux, pc, H, W);
-        hipLaunchKernelGGL(k_cum_rows, lines_grid(H, 3), dim3(LINE_THREADS), 0, aux, pc, H, W);
+            hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, st,
+                               p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], (const double *)T, H, W, zs);
+        hipLaunchKernelGGL(k_cum_cols, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, aux, pc, H, W);
+        hipLaunchKernelGGL(k_cum_rows, lines_grid(H, 3, S), dim3(LINE_THREADS), 0, aux, pc, H, W);
     }
     if (forked) { (void)hipEventRecord(p->ev_join, aux); (void)hipStreamWaitEvent(st, p->ev_join, 0); }
 }
@@ -722,7 +743,7 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
 // fork/join DAG, ~25 kernel nodes) -> one host launch instead of ~25.  With
 // profiling spans enabled (or SLAMHIP_NO_GRAPH=1) the same kernels are launched
 // directly, serially, so that per-kernel hipEvent spans are meaningful.
-static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma)
+static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma, int S = 1)
 {
     IIRPair cf; cf.c[0] = slam_iir_coef(sigma); cf.c[1] = slam_iir_coef(4.0);   // lucas_kanade.jl:112
     if (mode == 0) { int rc = build_norm(ctx, p, sigma); if (rc) return rc; }
@@ -730,12 +751,12 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma)
     static const bool no_graph = getenv("SLAMHIP_NO_GRAPH") != nullptr;
     if (ctx->prof_on || no_graph) {
         ProfScope span_all(ctx, "pyr_update");
-        launch_build(ctx, p, mode, cf, st, st, ctx->prof_on);
+        launch_build(ctx, p, mode, cf, st, st, ctx->prof_on, S);
         HIP_TRY(ctx, hipGetLastError());
         return SLAM_OK;
     }
     hipGraphExec_t exec = nullptr;
-    for (auto &g : p->graphs) if (g.mode == mode && g.sigma == sigma) exec = g.exec;
+    for (auto &g : p->graphs) if (g.mode == mode && g.sigma == sigma && g.S == S) exec = g.exec;
     if (!exec && !p->graph_failed) {
         if (!p->aux) {
             HIP_TRY(ctx, hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
@@ -745,42 +766,82 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma)
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
-            launch_build(ctx, p, mode, cf, st, p->aux, false);
+            launch_build(ctx, p, mode, cf, st, p->aux, false, S);
             e = hipStreamEndCapture(st, &graph);
         }
         if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (graph) (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { (void)hipGetLastError(); p->graph_failed = true; exec = nullptr; }
-        else { slam_pyr::Graph g; g.mode = mode; g.sigma = sigma; g.exec = exec; p->graphs.push_back(g); }
+        else { slam_pyr::Graph g; g.mode = mode; g.sigma = sigma; g.S = S; g.exec = exec; p->graphs.push_back(g); }
     }
     if (exec) HIP_TRY(ctx, hipGraphLaunch(exec, st));
-    else launch_build(ctx, p, mode, cf, st, st, false);
+    else launch_build(ctx, p, mode, cf, st, st, false, S);
     HIP_TRY(ctx, hipGetLastError());
     return SLAM_OK;
 }
 
 extern "C" {
 
-int slam_pyr_create(slam_ctx *ctx, int H, int W, int pyramid_levels, slam_pyr **out)
+// One allocation holds S pyramids back to back: per image 6 planes + the blur scratch plane
+// (zstride = 7 * sum_l H_l W_l doubles).  S = 1 is the ordinary single pyramid.
+static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, slam_pyr **out)
 {
     ARG_TRY(ctx, ctx != nullptr && out != nullptr);
-    ARG_TRY(ctx, H >= 4 && W >= 4 && pyramid_levels >= 0 && pyramid_levels + 1 <= SLAM_MAX_LEVELS);
+    ARG_TRY(ctx, H >= 4 && W >= 4 && pyramid_levels >= 0 && pyramid_levels + 1 <= SLAM_MAX_LEVELS && S >= 1 && S <= BATCH_MAX);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    slam_pyr *p = new slam_pyr();
-    p->device = ctx->device;
-    p->levels = pyramid_levels + 1;
+    int Hs[SLAM_MAX_LEVELS], Ws[SLAM_MAX_LEVELS]; int64_t off[SLAM_MAX_LEVELS + 1];
     int64_t o = 0; int h = H, w = W;
-    for (int l = 0; l < p->levels; l++) {
-        if (h < 4 || w < 4) { delete p; return slam_fail(ctx, SLAM_ERR_ARG, "slam_pyr_create: level %d is %dx%d, too small for the IIR kernel (needs > 3)", l, h, w); }
-        p->H[l] = h; p->W[l] = w; p->off[l] = o; o += (int64_t)h * w;
+    const int levels = pyramid_levels + 1;
+    for (int l = 0; l < levels; l++) {
+        if (h < 4 || w < 4) return slam_fail(ctx, SLAM_ERR_ARG, "slam_pyr_create: level %d is %dx%d, too small for the IIR kernel (needs > 3)", l, h, w);
+        Hs[l] = h; Ws[l] = w; off[l] = o; o += (int64_t)h * w;
         h = (h + 1) / 2; w = (w + 1) / 2;                         // ceil(size / 2)
     }
-    p->off[p->levels] = o;
-    hipError_t e = hipMalloc((void **)&p->planes, (size_t)o * 6 * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->tmp, (size_t)o * 8);
-    if (e != hipSuccess) { if (p->planes) (void)hipFree(p->planes); delete p; return slam_fail(ctx, SLAM_ERR_HIP, "slam_pyr_create: %s", hipGetErrorString(e)); }
-    make_view(p);
-    *out = p;
+    off[levels] = o;
+    slam_pyr::Alloc *al = new slam_pyr::Alloc();
+    hipError_t e = hipMalloc((void **)&al->base, (size_t)o * 7 * 8 * S);
+    if (e != hipSuccess) { delete al; return slam_fail(ctx, SLAM_ERR_HIP, "slam_pyr_create: hipMalloc: %s", hipGetErrorString(e)); }
+    al->refs = S;
+    for (int s = 0; s < S; s++) {
+        slam_pyr *p = new slam_pyr();
+        p->device = ctx->device; p->levels = levels;
+        memcpy(p->H, Hs, sizeof Hs); memcpy(p->W, Ws, sizeof Ws); memcpy(p->off, off, sizeof off);
+        p->alloc = al;
+        p->zstride = (size_t)o * 7;
+        p->planes = al->base + (size_t)s * p->zstride;
+        p->tmp = p->planes + (size_t)o * 6;
+        p->batch_index = s; p->batch_size = S;
+        make_view(p);
+        out[s] = p;
+    }
+    return SLAM_OK;
+}
+
+int slam_pyr_create(slam_ctx *ctx, int H, int W, int pyramid_levels, slam_pyr **out)
+{
+    return pyr_create_n(ctx, H, W, pyramid_levels, 1, out);
+}
+
+int slam_pyr_create_batch(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, slam_pyr **out)
+{
+    return pyr_create_n(ctx, H, W, pyramid_levels, S, out);
+}
+
+// pyrs[0..S) must be the members of one slam_pyr_create_batch call, in order
+int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double *const *images_dev, int S, int mode, double sigma, int sync)
+{
+    ARG_TRY(ctx, ctx != nullptr && pyrs != nullptr && images_dev != nullptr && S >= 1 && S <= BATCH_MAX && (mode == 1 || mode == 3) && sigma > 0);
+    slam_pyr *p0 = pyrs[0];
+    ARG_TRY(ctx, p0 != nullptr && p0->batch_index == 0 && p0->batch_size == S);
+    for (int s = 0; s < S; s++) ARG_TRY(ctx, pyrs[s] != nullptr && pyrs[s]->alloc == p0->alloc && pyrs[s]->batch_index == s && images_dev[s] != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ImgPtrs ip;
+    for (int s = 0; s < BATCH_MAX; s++) ip.p[s] = s < S ? images_dev[s] : nullptr;
+    const size_t n = (size_t)p0->H[0] * p0->W[0];
+    hipLaunchKernelGGL(k_gather_images, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), n, p0->zstride);
+    int rc = enqueue_build(ctx, p0, mode, sigma, S);
+    if (rc) return rc;
+    if (sync) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLAM_OK;
 }
 
@@ -789,8 +850,7 @@ int slam_pyr_destroy(slam_pyr *p)
     if (!p) return SLAM_OK;
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
-    if (p->planes) (void)hipFree(p->planes);
-    if (p->tmp) (void)hipFree(p->tmp);
+    if (p->alloc && --p->alloc->refs == 0) { (void)hipFree(p->alloc->base); delete p->alloc; }
     if (p->norm) (void)hipFree(p->norm);
     for (auto &g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->aux) {

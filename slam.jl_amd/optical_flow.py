@@ -176,3 +176,49 @@ def optical_flow_matching(from_pyramid, to_pyramid, pixels, is_3d, projections, 
         ok = ids2[st]
         new[ok] = nk[st]; status[ok] = True
     return new, status
+
+
+class PyramidBatch:
+    """S pyramids backed by one allocation (slam_pyr_create_batch): every per-image kernel of the build takes the
+    image index from grid.z, so S independent images cost one launch set.  `self.pyramids[s]` are ordinary LKPyramid
+    handles."""
+
+    def __init__(self, shape, levels=3, S=2, ctx=None):
+        self.ctx = ctx or L.default_context()
+        self.S = S
+        hs = (C.c_void_p * S)()
+        self.ctx.check(self.ctx.lib.slam_pyr_create_batch(self.ctx.h, shape[0], shape[1], levels, S, hs))
+        self.pyramids = [LKPyramid(ctx=self.ctx, _handle=C.c_void_p(hs[s])) for s in range(S)]
+        self._handles = (C.c_void_p * S)(*[p.h for p in self.pyramids])
+
+    def update_(self, device_ptrs, sigma=1.0, sync=True, fast=False, ctx=None):
+        """update!() of all S pyramids from S device-resident images (list of device pointers)."""
+        c = ctx or self.ctx
+        imgs = (C.c_void_p * self.S)(*[C.c_void_p(p) for p in device_ptrs])
+        c.check(c.lib.slam_pyr_update_batch_dev(c.h, self._handles, imgs, self.S, 3 if fast else 1, float(sigma), 1 if sync else 0))
+        return self
+
+
+def optical_flow_matching_batch(from_batch, to_batch, stream_index, pixels, is_3d, projections, params,
+                                pyramid_levels_3d=1, iterations=30, ctx=None):
+    """optical_flow_matching! for S lock-stepped streams in one launch (slam_flow_match_batch): point i belongs to
+    stream stream_index[i]; pyramids from_batch.pyramids[s] -> to_batch.pyramids[s].  Returns (new_pixels, status)."""
+    ctx = ctx or from_batch.ctx
+    pixels = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
+    n = len(pixels)
+    if n == 0:
+        return pixels.copy(), np.zeros(0, dtype=bool)
+    idx = np.ascontiguousarray(stream_index, dtype=np.int32)
+    is3 = np.ascontiguousarray(is_3d, dtype=np.uint8)
+    proj = np.ascontiguousarray(projections, dtype=np.float64).reshape(-1, 2)
+    out = np.empty((n, 2)); status = np.zeros(n, dtype=np.uint8)
+    rc = ctx.lib.slam_flow_match_batch(ctx.h, from_batch.pyramids[0].h, to_batch.pyramids[0].h, from_batch.S, L.ptr(idx, L.i32p),
+                                       L.ptr(pixels), L.ptr(is3, L.u8p), L.ptr(proj), n, params.pyramid_levels, pyramid_levels_3d,
+                                       params.window_size, iterations, 1e-4, 1e-2, float(params.max_ktl_distance),
+                                       L.ptr(out), L.ptr(status, L.u8p))
+    if rc == -3:
+        raise RuntimeError("Not enough layers in pyramids.")
+    ctx.check(rc)
+    st = status.astype(bool)
+    new = pixels.copy(); new[st] = out[st]
+    return new, st

@@ -1,0 +1,61 @@
+"""GPU: lock-stepped batches (slam_pyr_create_batch / update_batch_dev / flow_match_batch) give results
+bit-identical to the single-image entry points -- batching only changes how many images share a launch."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+PLANES = ("layers", "Iy", "Ix", "Iyy", "Ixx", "Iyx")
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_batch_pyramids_equal_single(slam, orc, texture, fast):
+    import torch
+    H, W, S = 101, 75, 3
+    imgs = [texture(H, W, seed=s)[0][0] for s in range(S)] 
+    dev = [torch.from_numpy(np.ascontiguousarray(im.T)).cuda() for im in imgs]
+    torch.cuda.synchronize()
+    batch = slam.PyramidBatch((H, W), levels=2, S=S)
+    batch.update_([d.data_ptr() for d in dev], fast=fast)
+    for s in range(S):
+        single = slam.LKPyramid(shape=(H, W), levels=2)
+        slam.update_(single, imgs[s], fast=fast)
+        for l in range(3):
+            for name in PLANES:
+                assert np.array_equal(batch.pyramids[s].plane(name, l), single.plane(name, l)), (s, name, l)
+        if not fast:
+            ref = orc.pyr_build(imgs[s], 2, 1.0, 1)
+            assert np.array_equal(batch.pyramids[s].plane("Iyx", 2), ref.plane("Iyx", 2))
+    # members are ordinary handles: update one alone, the others keep their planes
+    before = batch.pyramids[1].plane("Iy", 1)
+    slam.update_(batch.pyramids[0], imgs[2], fast=fast)
+    assert np.array_equal(batch.pyramids[0].plane("Ixx", 1), batch.pyramids[2].plane("Ixx", 1))
+    assert np.array_equal(batch.pyramids[1].plane("Iy", 1), before)
+
+
+def test_batch_flow_match_equals_per_stream(slam, orc, texture):
+    import torch
+    H, W, S = 120, 160, 3
+    streams = [texture(H, W, seed=10 + s, step=(1.0 + 0.3 * s, -1.5)) for s in range(S)]
+    a = slam.PyramidBatch((H, W), levels=3, S=S); b = slam.PyramidBatch((H, W), levels=3, S=S)
+    d0 = [torch.from_numpy(np.ascontiguousarray(st[0][0].T)).cuda() for st in streams]
+    d1 = [torch.from_numpy(np.ascontiguousarray(st[0][1].T)).cuda() for st in streams]
+    torch.cuda.synchronize()
+    a.update_([d.data_ptr() for d in d0]); b.update_([d.data_ptr() for d in d1])
+    params = slam.Params()
+    pts, idx, is3, proj = [], [], [], []
+    ref_new, ref_st = [], []
+    for s in range(S):
+        kp = orc.detect(streams[s][0][0], np.zeros((0, 2)), max_points=150).astype(float)
+        i3 = np.arange(len(kp)) % 3 != 0
+        pr = kp + np.array(streams[s][2][1])
+        pts.append(kp); idx.append(np.full(len(kp), s)); is3.append(i3); proj.append(pr)
+        n1, s1 = slam.optical_flow_matching(a.pyramids[s], b.pyramids[s], kp, i3, pr, params)
+        ref_new.append(n1); ref_st.append(s1)
+    order = np.random.default_rng(0).permutation(sum(len(p) for p in pts))          # streams interleaved arbitrarily
+    P = np.concatenate(pts)[order]; I = np.concatenate(idx)[order]; T = np.concatenate(is3)[order]; R = np.concatenate(proj)[order]
+    new, st = slam.optical_flow_matching_batch(a, b, I, P, T, R, params)
+    inv = np.argsort(order)
+    assert np.array_equal(st[inv], np.concatenate(ref_st))
+    assert np.array_equal(new[inv], np.concatenate(ref_new))
+    with pytest.raises(slam.SlamHipError):
+        slam.optical_flow_matching_batch(a, b, np.full(len(P), S), P, T, R, params)      # stream index out of range
