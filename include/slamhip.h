@@ -89,6 +89,17 @@ int slam_detect_pyr(slam_ctx *ctx, const slam_pyr *pyr,
                     int max_points, int radius, int grid_rows, int grid_cols, int cell_size,
                     double sigma_mask, double min_response,
                     int64_t *out_rc, int cap, int *n_out);
+/* detect() for the S members of a pyramid batch (slam_pyr_create_batch) in one launch:
+ * cur_yx holds the current keypoints of all streams back to back, stream s owning
+ * [cur_off[s], cur_off[s+1]) (cur_off[0] = 0); the new keypoints of stream s are
+ * out_rc[out_off[s] .. out_off[s+1]).  cap = total capacity in keypoints.  Per stream
+ * identical to slam_detect_pyr on that stream's pyramid (map_manager.jl:105 called for S
+ * independent streams). */
+int slam_detect_batch(slam_ctx *ctx, const slam_pyr *pyr0, int S,
+                      const double *cur_yx, const int32_t *cur_off,
+                      int max_points, int radius, int grid_rows, int grid_cols, int cell_size,
+                      double sigma_mask, double min_response,
+                      int64_t *out_rc, int cap, int32_t *out_off);
 
 /* describe(e, image, keypoints) -> create_descriptor(img, kps, BRIEF) --
  * src/extractor.jl:103-105.  pattern: n_bits x 4 int32 (dy1, dx1, dy2, dx2)

@@ -36,10 +36,11 @@ struct ProfScope {
     ~ProfScope();
 };
 
-// Device-side view of one pyramid level (all planes column-major H x W).
+// Device-side view of one pyramid level: planes are column-major H x W (y fastest) with a column
+// pitch of P >= H doubles, P a multiple of 16 (every column starts on a 128-byte line).
 struct LevelView {
     double *L, *Iy, *Ix, *Iyy, *Ixx, *Iyx;
-    int H, W;
+    int H, W, P;
 };
 struct PyrView {
     LevelView lv[SLAM_MAX_LEVELS];
@@ -50,7 +51,8 @@ struct slam_pyr {
     int device = 0;
     int levels = 0;                       // total layers = pyramid_levels + 1
     int H[SLAM_MAX_LEVELS], W[SLAM_MAX_LEVELS];
-    int64_t off[SLAM_MAX_LEVELS + 1];     // plane offsets in doubles
+    int P[SLAM_MAX_LEVELS];               // column pitch in doubles (H rounded up to 16)
+    int64_t off[SLAM_MAX_LEVELS + 1];     // plane offsets in doubles (sum of P_l * W_l)
     struct Alloc { double *base = nullptr; int refs = 0; };   // shared by the members of a batch
     Alloc *alloc = nullptr;
     size_t zstride = 0;                   // doubles between consecutive images of a batch (7 * off[levels])
@@ -96,6 +98,6 @@ IIRCoef slam_iir_coef(double sigma);
 int slam_gaussian_taps(double sigma, double *w);   // Kernel.gaussian 1-D factor
 
 // per-module entry points used across files
-int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, const double *cur_yx, int n_cur,
+int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, int pitch, const double *cur_yx, int n_cur,
                        int max_points, int radius, int grid_rows, int grid_cols, int cell_size,
                        double sigma_mask, double min_response, int64_t *out_rc, int cap, int *n_out);

@@ -15,7 +15,7 @@
 #define DET_MAXTAPS 41
 
 struct DetectArgs {
-    const double *img; int H, W;
+    const double *img; int H, W, pitch;
     const double *cur; int n_cur;      // device (y,x) pairs
     int radius, grid_rows, grid_cols, cs, k;
     double min_response;
@@ -23,6 +23,8 @@ struct DetectArgs {
     double taps[DET_MAXTAPS];
     int64_t *cell_out;                 // n_cells * k * 2
     int *cell_cnt;                     // n_cells
+    // batched launch (grid.y = stream): per-stream image offset, slice of `cur` and k; nullptr for a single image
+    const int *cur_off, *k_s; size_t zs; int kmax;
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -49,6 +51,11 @@ __device__ __forceinline__ void fir3(double *dst, const double *src, int h, int 
 __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
 {
     extern __shared__ double lds[];
+    if (A.cur_off) {
+        const int z = blockIdx.y, o = A.cur_off[z], nc = A.grid_rows * A.grid_cols;
+        A.img += (size_t)z * A.zs; A.cur += 2 * (size_t)o; A.n_cur = A.cur_off[z + 1] - o; A.k = A.k_s[z];
+        A.cell_out += (size_t)z * nc * A.kmax * 2; A.cell_cnt += (size_t)z * nc;
+    }
     const int cs = A.cs, H = A.H, W = A.W;
     const int cell = blockIdx.x;
     const int cyi = cell / A.grid_cols, cxi = cell % A.grid_cols;
@@ -63,12 +70,12 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     __shared__ int s_ri[DET_THREADS / 64];
     __shared__ int s_best;
 
-    if (h <= 0 || w <= 0) { if (tid == 0) A.cell_cnt[cell] = 0; return; }
+    if (h <= 0 || w <= 0 || A.k <= 0) { if (tid == 0) A.cell_cnt[cell] = 0; return; }
 
     // ---- image tile -> bA ---------------------------------------------------
     for (int i = tid; i < h * w; i += DET_THREADS) {
         int y = i % h, x = i / h;
-        bA[i] = A.img[(size_t)(y0 + y) + (size_t)(x0 + x) * H];
+        bA[i] = A.img[(size_t)(y0 + y) + (size_t)(x0 + x) * A.pitch];
     }
 
     // ---- avoidance mask (get_mask + imfilter(mask, Kernel.gaussian) + .*) ---
@@ -236,8 +243,14 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
 // Ordered compaction of the per-cell lists (cells row-major: extractor.jl:81):
 // wave-level inclusive scans (shuffle) + one LDS hop across the 16 waves.
 __global__ __launch_bounds__(1024) void detect_compact(const int64_t *cell_out, const int *cell_cnt, int n_cells, int k,
-                                                        int64_t *out /* [0] = n_out, then pairs */, int cap)
+                                                        int64_t *out /* [0] = n_out, then pairs */, int cap,
+                                                        const int *k_s /* batched: grid.x = stream, per-stream k, lists strided by kmax = k */)
 {
+    if (k_s) {
+        const int z = blockIdx.x;
+        cell_out += (size_t)z * n_cells * k * 2; cell_cnt += (size_t)z * n_cells; out += (size_t)z * (1 + 2 * (size_t)cap);
+        k = k_s[z];
+    }
     __shared__ int s_w[16];
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(1024) void detect_compact(const int64_t *cell_out, 
     if (tid == 0) out[0] = s_base;
 }
 
-int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, const double *cur_yx, int n_cur,
+int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, int pitch, const double *cur_yx, int n_cur,
                        int max_points, int radius, int grid_rows, int grid_cols, int cell_size,
                        double sigma_mask, double min_response, int64_t *out_rc, int cap, int *n_out)
 {
@@ -279,9 +292,9 @@ int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, const
     const int n_detect = max_points - n_cur;
     const int k = (n_detect + n_cells - 1) / n_cells;             // ceil(Int, n_detect / n_cells)
     DetectArgs A;
-    A.img = img_dev; A.H = H; A.W = W; A.n_cur = n_cur; A.radius = radius;
+    A.img = img_dev; A.H = H; A.W = W; A.pitch = pitch; A.n_cur = n_cur; A.radius = radius;
     A.grid_rows = grid_rows; A.grid_cols = grid_cols; A.cs = cell_size; A.k = k; A.min_response = min_response;
-    A.ntaps = 0;
+    A.ntaps = 0; A.cur_off = nullptr; A.k_s = nullptr; A.zs = 0; A.kmax = k;
     if (n_cur > 0 && sigma_mask != 0) {
         int l = 4 * (int)std::ceil(sigma_mask) + 1;
         ARG_TRY(ctx, l <= DET_MAXTAPS);
@@ -313,7 +326,7 @@ int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, const
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)detect_cells, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     { ProfScope span(ctx, "detect");
       hipLaunchKernelGGL(detect_cells, dim3(n_cells), dim3(DET_THREADS), lds_bytes, ctx->stream, A);
-      hipLaunchKernelGGL(detect_compact, dim3(1), dim3(1024), 0, ctx->stream, d_cout, d_cnt, n_cells, k, d_out, (int)out_pairs); }
+      hipLaunchKernelGGL(detect_compact, dim3(1), dim3(1024), 0, ctx->stream, d_cout, d_cnt, n_cells, k, d_out, (int)out_pairs, (const int *)nullptr); }
     HIP_TRY(ctx, hipGetLastError());
     int64_t *h_out;
     rc = slam_pinned(ctx, out_b, (void **)&h_out);
@@ -338,7 +351,7 @@ extern "C" int slam_detect(slam_ctx *ctx, const double *image, int H, int W, con
     int rc = slam_scratch2(ctx, (size_t)H * W * 8, &d_img);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_img, image, (size_t)H * W * 8, hipMemcpyHostToDevice, ctx->stream));
-    return slam_detect_device(ctx, (const double *)d_img, H, W, cur_yx, n_cur, max_points, radius, grid_rows, grid_cols,
+    return slam_detect_device(ctx, (const double *)d_img, H, W, H, cur_yx, n_cur, max_points, radius, grid_rows, grid_cols,
                               cell_size, sigma_mask, min_response, out_rc, cap, n_out);
 }
 
@@ -348,6 +361,81 @@ extern "C" int slam_detect_pyr(slam_ctx *ctx, const slam_pyr *pyr, const double 
 {
     ARG_TRY(ctx, ctx != nullptr && pyr != nullptr);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return slam_detect_device(ctx, pyr->plane(0, 0), pyr->H[0], pyr->W[0], cur_yx, n_cur, max_points, radius, grid_rows,
+    return slam_detect_device(ctx, pyr->plane(0, 0), pyr->H[0], pyr->W[0], pyr->P[0], cur_yx, n_cur, max_points, radius, grid_rows,
                               grid_cols, cell_size, sigma_mask, min_response, out_rc, cap, n_out);
+}
+
+// detect() for the S members of a pyramid batch in one launch (grid.y = stream).  cur_yx holds the current
+// keypoints of all streams back to back, cur_off[s] .. cur_off[s+1] those of stream s; the new keypoints come
+// back the same way (out_off[S+1]).  Per stream identical to slam_detect_pyr on that stream's pyramid.
+extern "C" int slam_detect_batch(slam_ctx *ctx, const slam_pyr *pyr0, int S, const double *cur_yx, const int32_t *cur_off,
+                                 int max_points, int radius, int grid_rows, int grid_cols, int cell_size,
+                                 double sigma_mask, double min_response, int64_t *out_rc, int cap, int32_t *out_off)
+{
+    ARG_TRY(ctx, ctx != nullptr && pyr0 != nullptr && S >= 1 && S <= 32 && cur_off != nullptr && out_off != nullptr);
+    ARG_TRY(ctx, pyr0->batch_index == 0 && pyr0->batch_size == S);
+    ARG_TRY(ctx, grid_rows > 0 && grid_cols > 0 && cell_size >= 8 && radius > 0 && cap >= 0 && (cap == 0 || out_rc != nullptr));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int n_cells = grid_rows * grid_cols, n_tot = cur_off[S];
+    ARG_TRY(ctx, cur_off[0] == 0 && n_tot >= 0 && (n_tot == 0 || cur_yx != nullptr));
+    int ks[32], kmax = 0;
+    for (int s = 0; s < S; s++) {
+        const int nc = cur_off[s + 1] - cur_off[s];
+        ARG_TRY(ctx, nc >= 0);
+        ks[s] = nc >= max_points ? 0 : (max_points - nc + n_cells - 1) / n_cells;     // extractor.jl:64-66
+        kmax = ks[s] > kmax ? ks[s] : kmax;
+    }
+    for (int s = 0; s <= S; s++) out_off[s] = 0;
+    if (kmax == 0) return SLAM_OK;
+    DetectArgs A;
+    A.img = pyr0->plane(0, 0); A.H = pyr0->H[0]; A.W = pyr0->W[0]; A.pitch = pyr0->P[0]; A.zs = pyr0->zstride;
+    A.n_cur = 0; A.radius = radius; A.grid_rows = grid_rows; A.grid_cols = grid_cols; A.cs = cell_size; A.k = 0; A.kmax = kmax;
+    A.min_response = min_response; A.ntaps = 0;
+    if (sigma_mask != 0) {
+        ARG_TRY(ctx, 4 * (int)std::ceil(sigma_mask) + 1 <= DET_MAXTAPS);
+        A.ntaps = slam_gaussian_taps(sigma_mask, A.taps);
+    }
+    const int hw = A.ntaps >> 1;
+    const size_t n = (size_t)cell_size * cell_size;
+    ARG_TRY(ctx, (size_t)(cell_size + 2 * hw) * (cell_size + 2 * hw) <= n * 8);
+    ARG_TRY(ctx, (size_t)cell_size * (cell_size + 2 * hw) <= 4 * n);
+    ARG_TRY(ctx, (size_t)kmax * sizeof(int) <= n * 8);
+    const size_t lds_bytes = 6 * n * sizeof(double);
+    ARG_TRY(ctx, lds_bytes <= 150 * 1024);
+
+    // host -> device in one copy: [cur_off (S+1)] [k_s (S)] [cur (2 * n_tot doubles)]
+    const size_t hdr_b = 256, cur_b = ((size_t)n_tot * 16 + 255) & ~(size_t)255;
+    const size_t cnt_b = ((size_t)S * n_cells * 4 + 255) & ~(size_t)255;
+    const size_t cout_b = ((size_t)S * n_cells * kmax * 16 + 255) & ~(size_t)255;
+    const size_t pairs = (size_t)n_cells * kmax, out_b = (size_t)S * (8 + pairs * 16);
+    char *d, *h;
+    int rc = slam_scratch(ctx, hdr_b + cur_b + cnt_b + cout_b + out_b, (void **)&d);
+    if (rc) return rc;
+    rc = slam_pinned(ctx, hdr_b + cur_b + out_b, (void **)&h);
+    if (rc) return rc;
+    memcpy(h, cur_off, (size_t)(S + 1) * 4); memcpy(h + 128, ks, (size_t)S * 4);
+    if (n_tot > 0) memcpy(h + hdr_b, cur_yx, (size_t)n_tot * 16);
+    HIP_TRY(ctx, hipMemcpyAsync(d, h, hdr_b + (size_t)n_tot * 16, hipMemcpyHostToDevice, ctx->stream));
+    A.cur_off = (const int *)d; A.k_s = (const int *)(d + 128); A.cur = (const double *)(d + hdr_b);
+    A.cell_cnt = (int *)(d + hdr_b + cur_b); A.cell_out = (int64_t *)(d + hdr_b + cur_b + cnt_b);
+    int64_t *d_out = (int64_t *)(d + hdr_b + cur_b + cnt_b + cout_b);
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)detect_cells, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    { ProfScope span(ctx, "detect");
+      hipLaunchKernelGGL(detect_cells, dim3(n_cells, S), dim3(DET_THREADS), lds_bytes, ctx->stream, A);
+      hipLaunchKernelGGL(detect_compact, dim3(S), dim3(1024), 0, ctx->stream, (const int64_t *)A.cell_out, (const int *)A.cell_cnt, n_cells, kmax,
+                         d_out, (int)pairs, A.k_s); }
+    HIP_TRY(ctx, hipGetLastError());
+    int64_t *h_out = (int64_t *)(h + hdr_b + cur_b);
+    HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    size_t tot = 0;
+    for (int s = 0; s < S; s++) tot += (size_t)h_out[(size_t)s * (1 + 2 * pairs)];
+    if (tot > (size_t)cap) return slam_fail(ctx, SLAM_ERR_CAPACITY, "slam_detect_batch: %zu keypoints but cap = %d", tot, cap);
+    size_t o = 0;
+    for (int s = 0; s < S; s++) {
+        const int64_t *hs = h_out + (size_t)s * (1 + 2 * pairs);
+        memcpy(out_rc + 2 * o, hs + 1, (size_t)hs[0] * 16);
+        o += (size_t)hs[0]; out_off[s + 1] = (int32_t)o;
+    }
+    return SLAM_OK;
 }

@@ -52,9 +52,9 @@ __device__ __forceinline__ double boxdiff(const double *I, int H, int y1, int y2
 __device__ __forceinline__ double spatial_gradient(const LevelView &v, int p0, int p1, Offs o, double Gi[4])
 {
     const int y1 = p0 - o.up, y2 = p0 + o.down, x1 = p1 - o.left, x2 = p1 + o.right;
-    const double syy = boxdiff(v.Iyy, v.H, y1, y2, x1, x2);
-    const double sxx = boxdiff(v.Ixx, v.H, y1, y2, x1, x2);
-    const double syx = boxdiff(v.Iyx, v.H, y1, y2, x1, x2);
+    const double syy = boxdiff(v.Iyy, v.P, y1, y2, x1, x2);
+    const double sxx = boxdiff(v.Ixx, v.P, y1, y2, x1, x2);
+    const double syx = boxdiff(v.Iyx, v.P, y1, y2, x1, x2);
     // M col-major: M11 = syy, M21 = syx, M12 = syx, M22 = sxx
     const double E = (syy + sxx) / 2, F = (syy - sxx) / 2, G = (syx + syx) / 2, Hh = (syx - syx) / 2;
     const double Q = sqrt(E * E + Hh * Hh), R = sqrt(F * F + G * G);
@@ -86,7 +86,7 @@ __device__ __forceinline__ double spatial_gradient(const LevelView &v, int p0, i
     return fmin(S0, S1) / cnt;
 }
 
-__device__ __forceinline__ double bilinear(const double *img, int H, int W, double r, double c)
+__device__ __forceinline__ double bilinear(const double *img, int H, int W, int P, double r, double c)
 {
     int iy = (int)floor(r), ix = (int)floor(c);
     if (iy > H - 1) iy = H - 1;
@@ -94,8 +94,8 @@ __device__ __forceinline__ double bilinear(const double *img, int H, int W, doub
     if (iy < 1) iy = 1;
     if (ix < 1) ix = 1;
     const double fy = r - iy, fx = c - ix;
-    const double *p = img + (size_t)(iy - 1) + (size_t)(ix - 1) * H;
-    const int dy = H > 1 ? 1 : 0; const size_t dx = W > 1 ? (size_t)H : 0;
+    const double *p = img + (size_t)(iy - 1) + (size_t)(ix - 1) * P;
+    const int dy = H > 1 ? 1 : 0; const size_t dx = W > 1 ? (size_t)P : 0;
     const double r0 = (1 - fx) * p[0] + fx * p[dx];
     const double r1 = (1 - fx) * p[dy] + fx * p[dy + dx];
     return (1 - fy) * r0 + fy * r1;
@@ -143,7 +143,7 @@ struct Tmpl { double A[LK_MAXE], Iy[LK_MAXE], Ix[LK_MAXE], dp[LK_MAXE], dq[LK_MA
 
 __device__ __forceinline__ void load_template(Tmpl &T, const LevelView &first, int p0, int p1, Offs o)
 {
-    const int lane = threadIdx.x & 63, H = first.H;
+    const int lane = threadIdx.x & 63, pitch = first.P;
     const int P = o.up + o.down + 1, Q = o.left + o.right + 1, NE = P * Q;
     T.ne = NE;
 #pragma unroll
@@ -151,7 +151,7 @@ __device__ __forceinline__ void load_template(Tmpl &T, const LevelView &first, i
         const int e = lane + 64 * k;
         const bool in = e < NE;
         const int p = in ? e % P : 0, q = in ? e / P : 0;
-        const size_t a = (size_t)(p0 - o.up + p - 1) + (size_t)(p1 - o.left + q - 1) * H;
+        const size_t a = (size_t)(p0 - o.up + p - 1) + (size_t)(p1 - o.left + q - 1) * pitch;
         T.A[k] = in ? first.L[a] : 0.0; T.Iy[k] = in ? first.Iy[a] : 0.0; T.Ix[k] = in ? first.Ix[a] : 0.0;
         T.dp[k] = (double)(p - o.up); T.dq[k] = (double)(q - o.left);
     }
@@ -164,7 +164,7 @@ __device__ bool lk_level(const LevelView &first, const LevelView &second, int le
                          int window, int iterations, double eig_thr, double eps)
 {
     const int lane = threadIdx.x & 63;
-    const int H = first.H, W = first.W;
+    const int H = first.H, W = first.W, pitch = first.P;
     const double scale = (double)(1 << (level - 1));
     const int p0 = (int)floor(pty / scale), p1 = (int)floor(ptx / scale);
     const double pf0 = (double)p0, pf1 = (double)p1;
@@ -193,7 +193,7 @@ __device__ bool lk_level(const LevelView &first, const LevelView &second, int le
 #pragma unroll
             for (int k = 0; k < LK_MAXE; k++)
                 if (lane + 64 * k < T.ne) {
-                    const double dI = T.A[k] - bilinear(second.L, H, W, r0 + T.dp[k], r1 + T.dq[k]);
+                    const double dI = T.A[k] - bilinear(second.L, H, W, pitch, r0 + T.dp[k], r1 + T.dq[k]);
                     ay += dI * T.Iy[k];
                     ax += dI * T.Ix[k];
                 }
@@ -202,8 +202,8 @@ __device__ bool lk_level(const LevelView &first, const LevelView &second, int le
             for (int e = lane; e < NE; e += 64) {
                 const int p = e % P, q = e / P;
                 const double r = r0 + (double)(p - o.up), c = r1 + (double)(q - o.left);
-                const size_t a = (size_t)(p0 - o.up + p - 1) + (size_t)(p1 - o.left + q - 1) * H;
-                const double dI = first.L[a] - bilinear(second.L, H, W, r, c);
+                const size_t a = (size_t)(p0 - o.up + p - 1) + (size_t)(p1 - o.left + q - 1) * pitch;
+                const double dI = first.L[a] - bilinear(second.L, H, W, pitch, r, c);
                 ay += dI * first.Iy[a];
                 ax += dI * first.Ix[a];
             }

@@ -29,7 +29,13 @@ struct PlaneSet {
     size_t zs;             // batch: image blockIdx.z lives zs doubles after image 0 (0 for a single pyramid)
 };
 // batched launches: grid.z = image index; every plane pointer of image z is image 0's + z * zs
-#define PS_Z(ps) do { const size_t _z = (size_t)blockIdx.z * (ps).zs; _Pragma("unroll") for (int _k = 0; _k < 4; _k++) if ((ps).p[_k]) (ps).p[_k] += _z; } while (0)
+// Plane attributes are picked with wave-uniform selects (never by indexing the kernel argument with
+// blockIdx.y, which would move the struct to scratch and the plane pointer into vector registers).
+#define PS_PICK(ps, f, pl) ((pl) == 0 ? (ps).f[0] : (pl) == 1 ? (ps).f[1] : (pl) == 2 ? (ps).f[2] : (ps).f[3])
+__device__ __forceinline__ double *ps_plane(const PlaneSet &ps, int pl) { return PS_PICK(ps, p, pl) + (size_t)blockIdx.z * ps.zs; }
+__device__ __forceinline__ const double *ps_nrm(const PlaneSet &ps, int pl) { return PS_PICK(ps, nrm, pl); }
+__device__ __forceinline__ int ps_coef(const PlaneSet &ps, int pl) { return PS_PICK(ps, coef, pl); }
+__device__ __forceinline__ bool ps_fill0(const PlaneSet &ps, int pl) { return PS_PICK(ps, fill0, pl) != 0; }
 
 struct IIRPair { IIRCoef c[2]; };
 
@@ -132,132 +138,156 @@ struct RowIO {
     __device__ __forceinline__ double ld_src(int i) const { return src[(long)i * s]; }
     __device__ __forceinline__ double ld_dst(int i) const { return dst[(long)i * s]; }
     __device__ __forceinline__ void st(int i, double v) const { dst[(long)i * s] = v; }
-    // sweep `count` elements starting at i0 in direction dir (+1/-1); from_dst: read dst instead of src
-    template <class F> __device__ __forceinline__ void sweep(int i0, int count, int dir, bool from_dst, F f) const
+    // sweep `count` elements starting at i0 in direction DIR (+1/-1); from_dst: read dst instead of src
+    template <int DIR, class F> __device__ __forceinline__ void sweep(int i0, int count, bool from_dst, F f) const
     {
-        stream_line<8, 4>((from_dst ? dst : src) + (long)i0 * s, dst + (long)i0 * s, dir * s, count, f);
+        stream_line<8, 4>((from_dst ? dst : src) + (long)i0 * s, dst + (long)i0 * s, DIR * s, count, f);
     }
     __device__ __forceinline__ void fence() const {}
 };
 
 // ColIO: the lane's line is contiguous (recurrence along y, lanes = 64
 // consecutive columns).  Direct access would touch 64 cache lines per
-// wave-instruction; instead 8-row x 64-column tiles move between HBM and
-// registers in 64-byte row segments (8 lanes per column segment) and are
-// transposed through a 4.6 KB LDS tile, so each lane ends up with the 8
-// consecutive samples of its own column.  A ring of NB tiles is prefetched.
-#define COL_NB 4
-struct ColIO {
+// wave-instruction; instead 16-row x 64-column tiles move between HBM and
+// registers as whole 128-byte lines (8 lanes x 16 bytes per column; the column
+// pitch is a multiple of 16 doubles and tiles start on multiples of 16 rows, so
+// every global access is a full, aligned line) and are transposed through one
+// 9 KB LDS tile, so each lane ends up with the 16 consecutive samples of its own
+// column.  A ring of NB tiles is prefetched (NB = 3 for a single image, where the wave is alone on
+// its SIMD and the dependent chain must never wait for HBM; NB = 2 for batched launches, which keeps
+// the kernel under 256 VGPRs so that two waves share a SIMD).  Rows of the first / last tile
+// that lie outside the swept range are carried through untouched and not stored.
+#define COL_LS 18                       // LDS column stride in doubles: 16 + 2 keeps ds_*_b128 aligned and conflict-free
+template <int COL_NB> struct ColIO {
     const double *src; double *dst;     // plane bases
-    int H, W, x0;                       // first column of this wave
-    double *lds;                        // 4 x (64 x 9) doubles: in[2], out[2]
+    int H, W, P, x0;                    // rows, columns, column pitch, first column of this wave
+    double *lds;                        // 64 x COL_LS doubles
     __device__ __forceinline__ int xown() const { int x = x0 + (int)(threadIdx.x & 63); return x < W ? x : W - 1; }
     __device__ __forceinline__ bool valid() const { return x0 + (int)(threadIdx.x & 63) < W; }
-    __device__ __forceinline__ double ld_src(int i) const { return src[(size_t)i + (size_t)xown() * H]; }
-    __device__ __forceinline__ double ld_dst(int i) const { return dst[(size_t)i + (size_t)xown() * H]; }
-    __device__ __forceinline__ void st(int i, double v) const { if (valid()) dst[(size_t)i + (size_t)xown() * H] = v; }
+    __device__ __forceinline__ double ld_src(int i) const { return src[(size_t)i + (size_t)xown() * P]; }
+    __device__ __forceinline__ double ld_dst(int i) const { return dst[(size_t)i + (size_t)xown() * P]; }
+    __device__ __forceinline__ void st(int i, double v) const { if (valid()) dst[(size_t)i + (size_t)xown() * P] = v; }
     __device__ __forceinline__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
-    __device__ __forceinline__ void tile_load(const double *base, int r0, double t[8]) const
+    // tile registers: t[2r], t[2r+1] = rows rb + 2*rp, +1 of column x0 + 8r + cg   (rp = lane & 7, cg = lane >> 3)
+    // Addresses are (wave-uniform base of column group r) + (32-bit lane offset shared by all r): the
+    // loads/stores take the SGPR-base form and no per-column address registers.  Loads of the last
+    // workgroup may run past column W-1 into the next plane / the allocation's tail padding (values of
+    // lanes without a column are never stored).
+    __device__ __forceinline__ void tile_load(const double *base, int rb, double t[16]) const
     {
-        const int lane = threadIdx.x & 63, rr = lane & 7, cg = lane >> 3;
+        const int lane = threadIdx.x & 63, rp = lane & 7, cg = lane >> 3;
+        const unsigned voff = (unsigned)(cg * P + 2 * rp);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            int col = x0 + 8 * r + cg; col = col < W ? col : W - 1;
-            t[r] = base[(size_t)(r0 + rr) + (size_t)col * H];
+            const double *cb = base + ((size_t)(x0 + 8 * r) * P + rb);
+            const double2 q = *(const double2 *)(cb + voff);
+            t[2 * r] = q.x; t[2 * r + 1] = q.y;
         }
     }
-    __device__ __forceinline__ void tile_store(int r0, const double t[8]) const
+    __device__ __forceinline__ void tile_store(int rb, const double t[16], int lo, int hi, bool partial) const
     {
-        const int lane = threadIdx.x & 63, rr = lane & 7, cg = lane >> 3;
+        const int lane = threadIdx.x & 63, rp = lane & 7, cg = lane >> 3;
+        const int row = rb + 2 * rp;
+        const unsigned voff = (unsigned)(cg * P + 2 * rp);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int col = x0 + 8 * r + cg;
-            if (col < W) dst[(size_t)(r0 + rr) + (size_t)col * H] = t[r];
+            if (col < W) {
+                double *q = dst + ((size_t)(x0 + 8 * r) * P + rb) + voff;
+                if (!partial) *(double2 *)q = make_double2(t[2 * r], t[2 * r + 1]);
+                else {
+                    if (row >= lo && row <= hi) q[0] = t[2 * r];
+                    if (row + 1 >= lo && row + 1 <= hi) q[1] = t[2 * r + 1];
+                }
+            }
         }
     }
-    // The transposes go through LDS: tile registers --ds_write--> [col][row] --ds_read--> the lane's own
-    // 8 samples (in sweep order), and back for the results.  Both round trips are software-pipelined
-    // against the recurrence: while the dependent f64 chain of chunk c runs, the input transpose of
-    // chunk c+1 and the output transpose of chunk c-1 are in flight (double-buffered LDS tiles), so
-    // the LDS latency never sits on the chain.  lds = 4 tiles of 64 x 9 doubles: in[2], out[2].
-    __device__ __forceinline__ void in_write(int buf, const double t[8]) const
+    // The transposes go through LDS: tile registers --ds_write_b128--> [col][row] --ds_read_b128--> the lane's own
+    // 16 samples, and back for the results.  Both round trips are software-pipelined against the recurrence:
+    // while the dependent f64 chain of chunk c runs, the input transpose of chunk c+1 and the output transpose
+    // of chunk c are in flight, so the LDS latency never sits on the chain.  One tile serves both directions:
+    // the workgroup is a single wave and the LDS executes a wave's DS instructions in program order.
+    __device__ __forceinline__ void lds_put_tile(const double t[16]) const
     {
-        const int lane = threadIdx.x & 63, rr = lane & 7, cg = lane >> 3;
-        double *L = lds + buf * 576;
+        const int lane = threadIdx.x & 63, rp = lane & 7, cg = lane >> 3;
 #pragma unroll
-        for (int r = 0; r < 8; r++) L[(8 * r + cg) * 9 + rr] = t[r];
+        for (int r = 0; r < 8; r++) *(double2 *)(lds + (8 * r + cg) * COL_LS + 2 * rp) = make_double2(t[2 * r], t[2 * r + 1]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    __device__ __forceinline__ void in_read(int buf, double v[8], bool rev) const
+    __device__ __forceinline__ void lds_get_tile(double t[16]) const
     {
-        const int lane = threadIdx.x & 63;
-        const double *L = lds + buf * 576;
+        const int lane = threadIdx.x & 63, rp = lane & 7, cg = lane >> 3;
 #pragma unroll
-        for (int c = 0; c < 8; c++) v[c] = L[lane * 9 + (rev ? 7 - c : c)];
+        for (int r = 0; r < 8; r++) { const double2 q = *(const double2 *)(lds + (8 * r + cg) * COL_LS + 2 * rp); t[2 * r] = q.x; t[2 * r + 1] = q.y; }
+        __builtin_amdgcn_wave_barrier();
     }
-    __device__ __forceinline__ void out_write(int buf, const double v[8], bool rev) const
+    // the lane's own column, in sweep order (DIR < 0: v[e] = row rb + 15 - e)
+    template <int DIR> __device__ __forceinline__ void lds_get_col(double v[16]) const
     {
-        const int lane = threadIdx.x & 63;
-        double *L = lds + (2 + buf) * 576;
+        const double *L = lds + (threadIdx.x & 63) * COL_LS;
 #pragma unroll
-        for (int c = 0; c < 8; c++) L[lane * 9 + (rev ? 7 - c : c)] = v[c];
+        for (int j = 0; j < 8; j++) {
+            const double2 q = *(const double2 *)(L + 2 * j);
+            if (DIR > 0) { v[2 * j] = q.x; v[2 * j + 1] = q.y; } else { v[15 - 2 * j] = q.x; v[14 - 2 * j] = q.y; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    template <int DIR> __device__ __forceinline__ void lds_put_col(const double v[16]) const
+    {
+        double *L = lds + (threadIdx.x & 63) * COL_LS;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            *(double2 *)(L + 2 * j) = DIR > 0 ? make_double2(v[2 * j], v[2 * j + 1]) : make_double2(v[15 - 2 * j], v[14 - 2 * j]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    __device__ __forceinline__ void out_read(int buf, double t[8]) const
+    // sweep `count` elements starting at row i0 in direction DIR (+1/-1); from_dst: read dst instead of src
+    template <int DIR, class F> __device__ __forceinline__ void sweep(int i0, int count, bool from_dst, F f) const
     {
-        const int lane = threadIdx.x & 63, rr = lane & 7, cg = lane >> 3;
-        const double *L = lds + (2 + buf) * 576;
-#pragma unroll
-        for (int r = 0; r < 8; r++) t[r] = L[(8 * r + cg) * 9 + rr];
-    }
-    template <class F> __device__ __forceinline__ void sweep(int i0, int count, int dir, bool from_dst, F f) const
-    {
+        if (count <= 0) return;
         const double *base = from_dst ? dst : src;
-        const bool rev = dir < 0;
-        const int nfull = count / 8;
-        double ring[COL_NB][8];
-        auto lo = [&](int k) { return rev ? i0 - 8 * k - 7 : i0 + 8 * k; };   // tile k covers rows [lo(k), lo(k)+7]
+        const int lo = DIR > 0 ? i0 : i0 - count + 1, hi = DIR > 0 ? i0 + count - 1 : i0;    // rows [lo, hi]
+        const int ta = lo >> 4, tb = hi >> 4, NT = tb - ta + 1;
+        auto rbase = [&](int k) { return (DIR > 0 ? ta + k : tb - k) << 4; };
+        double ring[COL_NB][16];
         int loaded = 0;
 #pragma unroll
         for (int b = 0; b < COL_NB; b++)
-            if (b < nfull) { tile_load(base, lo(loaded), ring[b]); loaded++; }
-        double vcur[8], vnext[8], tprev[8];
-        if (nfull > 0) { in_write(0, ring[0]); in_read(0, vcur, rev); }
-        int done = 0;
-        while (done < nfull) {
+            if (b < NT) { tile_load(base, rbase(loaded), ring[b]); loaded++; }
+        double vcur[16], vnext[16], tprev[16];
+        lds_put_tile(ring[0]); lds_get_col<DIR>(vcur);
+        int prev_rb = 0; bool prev_partial = false;
+        for (int k0 = 0; k0 < NT; k0 += COL_NB) {
 #pragma unroll
-            for (int b = 0; b < COL_NB; b++) {
-                const int c = done + b;
-                if (c < nfull) {
-                    // (1) input transpose of chunk c+1 (ring slot b+1), results consumed next iteration
-                    if (c + 1 < nfull) { in_write((c + 1) & 1, ring[(b + 1) % COL_NB]); in_read((c + 1) & 1, vnext, rev); }
-                    // (2) refill ring slot b (its tile went through the LDS one iteration ago)
-                    if (loaded < nfull) { tile_load(base, lo(loaded), ring[b]); loaded++; }
-                    // (3) the recurrence on chunk c
+            for (int s = 0; s < COL_NB; s++) {
+                const int k = k0 + s;
+                if (k < NT) {
+                    const int rb = rbase(k);
+                    // (1) input transpose of chunk k+1 (ring slot s+1), consumed next iteration
+                    if (k + 1 < NT) { lds_put_tile(ring[(s + 1) % COL_NB]); lds_get_col<DIR>(vnext); }
+                    // (2) refill ring slot s (its tile went through the LDS one iteration ago)
+                    if (loaded < NT) { tile_load(base, rbase(loaded), ring[s]); loaded++; }
+                    // (3) the recurrence on chunk k
+                    const bool partial = rb < lo || rb + 15 > hi;
+                    if (!partial) {
 #pragma unroll
-                    for (int e = 0; e < 8; e++) vcur[e] = f(vcur[e]);
-                    // (4) output transpose of chunk c; store chunk c-1 whose read-back was issued last iteration
-                    if (c > 0) tile_store(lo(c - 1), tprev);
-                    out_write(c & 1, vcur, rev); out_read(c & 1, tprev);
+                        for (int e = 0; e < 16; e++) vcur[e] = f(vcur[e]);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 8; e++) vcur[e] = vnext[e];
+                        for (int e = 0; e < 16; e++) { const int row = DIR > 0 ? rb + e : rb + 15 - e; if (row >= lo && row <= hi) vcur[e] = f(vcur[e]); }
+                    }
+                    // (4) store chunk k-1 (its read-back was issued last iteration); output transpose of chunk k
+                    if (k > 0) tile_store(prev_rb, tprev, lo, hi, prev_partial);
+                    lds_put_col<DIR>(vcur); lds_get_tile(tprev);
+                    prev_rb = rb; prev_partial = partial;
+#pragma unroll
+                    for (int e = 0; e < 16; e++) vcur[e] = vnext[e];
                 }
             }
-            done += COL_NB;
         }
-        if (nfull > 0) tile_store(lo(nfull - 1), tprev);
-        // tail rows: direct access by the owning lane.  The tile stores above were
-        // made by other lanes; order them before the direct accesses below.
-        fence();
-        const int x = xown();
-        for (int j = nfull * 8; j < count; j++) {
-            const int i = i0 + dir * j;
-            const double r = f(base[(size_t)i + (size_t)x * H]);
-            if (valid()) dst[(size_t)i + (size_t)x * H] = r;
-        }
+        tile_store(prev_rb, tprev, lo, hi, prev_partial);
     }
 };
 
@@ -276,7 +306,7 @@ __device__ __forceinline__ void iir_line(const IO &io, int n, const IIRCoef &k, 
     double o2 = ((io.ld_src(2) + a1 * o1) + a2 * o0) + a3 * uminus;
     io.st(0, o0); io.st(1, o1); io.st(2, o2);
     double w3 = o0, w2 = o1, w1 = o2;
-    io.sweep(3, n - 3, +1, false, [&](double x) {
+    io.template sweep<+1>(3, n - 3, false, [&](double x) {
         const double t = ((x + a1 * w1) + a2 * w2) + a3 * w3;
         w3 = w2; w2 = w1; w1 = t;
         return t;
@@ -305,7 +335,7 @@ __device__ __forceinline__ void iir_line(const IO &io, int n, const IIRCoef &k, 
         return;
     }
     io.st(n - 1, vA * scale); io.st(n - 2, vB * scale); io.st(n - 3, vC * scale);
-    io.sweep(n - 4, n - 3, -1, true, [&](double x) {
+    io.template sweep<-1>(n - 4, n - 3, true, [&](double x) {
         const double t = ((x + a1 * v1) + a2 * v2) + a3 * v3;
         v3 = v2; v2 = v1; v1 = t;
         return t * scale;
@@ -314,46 +344,46 @@ __device__ __forceinline__ void iir_line(const IO &io, int n, const IIRCoef &k, 
 
 // dim-1 pass: one lane per column, LDS-transposed tile I/O.  src may differ from
 // dst for plane 0 (the blur reads the layer and writes the scratch plane).
-__global__ __launch_bounds__(LINE_THREADS) void k_iir_cols(PlaneSet ps, const double *src0, int H, int W, IIRPair cf)
+template <int NB>
+__global__ __launch_bounds__(LINE_THREADS) void k_iir_cols(PlaneSet ps, const double *src0, int H, int W, int P, IIRPair cf)
 {
-    PS_Z(ps); if (src0) src0 += (size_t)blockIdx.z * ps.zs;
-    __shared__ double tile[4 * 64 * 9];
+    if (src0) src0 += (size_t)blockIdx.z * ps.zs;
+    __shared__ __attribute__((aligned(16))) double tile[64 * COL_LS];
     const int pl = blockIdx.y;
-    ColIO io;
-    io.dst = ps.p[pl]; io.src = (pl == 0 && src0) ? src0 : ps.p[pl];
-    io.H = H; io.W = W; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile;
-    iir_line(io, H, cf.c[ps.coef[pl]], ps.fill0[pl] != 0, nullptr, 0);
+    ColIO<NB> io;
+    io.dst = ps_plane(ps, pl); io.src = (pl == 0 && src0) ? src0 : io.dst;
+    io.H = H; io.W = W; io.P = P; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile;
+    iir_line(io, H, ps_coef(ps, pl) == 0 ? cf.c[0] : cf.c[1], ps_fill0(ps, pl), nullptr, 0);
 }
 
 // dim-2 pass: one lane per row, in place; consecutive lanes = consecutive y.
-__global__ __launch_bounds__(LINE_THREADS) void k_iir_rows(PlaneSet ps, int H, int W, IIRPair cf)
+__global__ __launch_bounds__(LINE_THREADS) void k_iir_rows(PlaneSet ps, int H, int W, int P, IIRPair cf)
 {
-    PS_Z(ps);
     const int y = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
     if (y >= H) return;
-    RowIO io; io.src = ps.p[pl] + y; io.dst = ps.p[pl] + y; io.s = H;
-    iir_line(io, W, cf.c[ps.coef[pl]], ps.fill0[pl] != 0, ps.nrm[pl] ? ps.nrm[pl] + y : nullptr, H);
+    RowIO io; io.src = ps_plane(ps, pl) + y; io.dst = ps_plane(ps, pl) + y; io.s = P;
+    const double *nrm = ps_nrm(ps, pl);
+    iir_line(io, W, ps_coef(ps, pl) == 0 ? cf.c[0] : cf.c[1], ps_fill0(ps, pl), nrm ? nrm + y : nullptr, P);
 }
 
 // integral_image!, lucas_kanade.jl:131-138: cumsum along dim 1 ...
-__global__ __launch_bounds__(LINE_THREADS) void k_cum_cols(PlaneSet ps, int H, int W)
+template <int NB>
+__global__ __launch_bounds__(LINE_THREADS) void k_cum_cols(PlaneSet ps, int H, int W, int P)
 {
-    PS_Z(ps);
-    __shared__ double tile[4 * 64 * 9];
+    __shared__ __attribute__((aligned(16))) double tile[64 * COL_LS];
     const int pl = blockIdx.y;
-    ColIO io; io.dst = ps.p[pl]; io.src = ps.p[pl]; io.H = H; io.W = W; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile;
+    ColIO<NB> io; io.dst = ps_plane(ps, pl); io.src = io.dst; io.H = H; io.W = W; io.P = P; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile;
     double acc = io.ld_src(0);
-    io.sweep(1, H - 1, +1, false, [&](double x) { acc = acc + x; return acc; });
+    io.template sweep<+1>(1, H - 1, false, [&](double x) { acc = acc + x; return acc; });
 }
 // ... then along dim 2.
-__global__ __launch_bounds__(LINE_THREADS) void k_cum_rows(PlaneSet ps, int H, int W)
+__global__ __launch_bounds__(LINE_THREADS) void k_cum_rows(PlaneSet ps, int H, int W, int P)
 {
-    PS_Z(ps);
     const int y = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
     if (y >= H) return;
-    double *p = ps.p[pl] + y;
+    double *p = ps_plane(ps, pl) + y;
     double acc = p[0];
-    stream_line<8, 8>(p + H, p + H, H, W - 1, [&](double x) { acc = acc + x; return acc; });
+    stream_line<8, 8>(p + P, p + P, P, W - 1, [&](double x) { acc = acc + x; return acc; });
 }
 
 // ---- tolerance mode ("fast", mode 3): parallel recurrences -------------------------
@@ -410,9 +440,9 @@ __device__ __forceinline__ void fold_entry(const SegPow &sp, int cs, double (*Z)
 }
 
 template <bool COLS>
-__global__ __launch_bounds__(PAR_T) void k_iir_seg(PlaneSet ps, const double *src0, int H, int W, IIRPair cf, SegPow sp, int SL)
+__global__ __launch_bounds__(PAR_T) void k_iir_seg(PlaneSet ps, const double *src0, int H, int W, int P, IIRPair cf, SegPow sp, int SL)
 {
-    PS_Z(ps); if (src0) src0 += (size_t)blockIdx.z * ps.zs;
+    if (src0) src0 += (size_t)blockIdx.z * ps.zs;
     constexpr int LPW = 8, NSEG = PAR_T / LPW;
     __shared__ double Z[3][NSEG][LPW];
     __shared__ double GT[3][NSEG / PAR_G + 1][LPW];
@@ -422,11 +452,11 @@ __global__ __launch_bounds__(PAR_T) void k_iir_seg(PlaneSet ps, const double *sr
     const int line = blockIdx.x * LPW + l;
     const bool valid = line < nlines;
     const int lc = valid ? line : nlines - 1;              // idle lanes shadow the last line (reads only)
-    const long stride = COLS ? 1 : H;
-    const size_t off = COLS ? (size_t)lc * H : (size_t)lc;
-    double *dstp = ps.p[pl] + off;
-    const double *srcp = ((pl == 0 && src0) ? src0 : ps.p[pl]) + off;
-    const int cs = ps.coef[pl];
+    const long stride = COLS ? 1 : P;
+    const size_t off = COLS ? (size_t)lc * P : (size_t)lc;
+    double *dstp = ps_plane(ps, pl) + off;
+    const double *srcp = ((pl == 0 && src0) ? src0 : ps_plane(ps, pl)) + off;
+    const int cs = ps_coef(ps, pl);
     const IIRCoef &k = cf.c[cs];
     const double a1 = k.a1, a2 = k.a2, a3 = k.a3, scale = k.scale;
     const int nseg = (n + SL - 1) / SL;
@@ -493,9 +523,8 @@ __global__ __launch_bounds__(PAR_T) void k_iir_seg(PlaneSet ps, const double *sr
 }
 
 template <bool COLS>
-__global__ __launch_bounds__(PAR_T) void k_cum_seg(PlaneSet ps, int H, int W, int SL)
+__global__ __launch_bounds__(PAR_T) void k_cum_seg(PlaneSet ps, int H, int W, int P, int SL)
 {
-    PS_Z(ps);
     constexpr int LPW = 8, NSEG = PAR_T / LPW;
     __shared__ double Zs[NSEG][LPW];
     __shared__ double Gs[NSEG / PAR_G + 1][LPW];
@@ -504,8 +533,8 @@ __global__ __launch_bounds__(PAR_T) void k_cum_seg(PlaneSet ps, int H, int W, in
     const int line = blockIdx.x * LPW + l;
     const bool valid = line < nlines;
     const int lc = valid ? line : nlines - 1;
-    const long stride = COLS ? 1 : H;
-    double *p = ps.p[pl] + (COLS ? (size_t)lc * H : (size_t)lc);
+    const long stride = COLS ? 1 : P;
+    double *p = ps_plane(ps, pl) + (COLS ? (size_t)lc * P : (size_t)lc);
     const int nseg = (n + SL - 1) / SL;
     const bool has = g < nseg;
     const int b = g * SL, len = has ? min(n, b + SL) - b : 0;
@@ -534,42 +563,49 @@ __global__ __launch_bounds__(PAR_T) void k_cum_seg(PlaneSet ps, int H, int W, in
 // imgradients (KernelFactors.scharr, separable: derivative (-1,0,1)/2, smoothing
 // (3,10,3)/16; first factor along dim 1 first) + the three gradient products.
 // border 0: replicate (update!, pyramid.jl:98-103); 1: Fill(0) (ctor, pyramid.jl:51,59).
-__device__ __forceinline__ double ldb(const double *L, int H, int W, int y, int x, int border)
+// One thread per row y of a strip of SCH_XC columns: the per-column terms (derivative and smoothing
+// factor applied along dim 1) slide along x in registers, so each layer sample is fetched from HBM
+// once per strip (+2 halo columns) instead of once per output column and XCD.
+#define SCH_XC 16
+struct ColTerm { double d, s; };
+__device__ __forceinline__ ColTerm scharr_col(const double *L, int H, int W, int P, int y, int xx, int border)
 {
-    if (border == 0) { y = y < 0 ? 0 : (y >= H ? H - 1 : y); return L[(size_t)y + (size_t)x * H]; }
-    return (y < 0 || y >= H) ? 0.0 : L[(size_t)y + (size_t)x * H];
+    const double dk[3] = {-1.0 / 2, 0.0 / 2, 1.0 / 2}, sk[3] = {3.0 / 16, 10.0 / 16, 3.0 / 16};
+    ColTerm t; t.d = 0.0; t.s = 0.0;
+    if (border == 0) xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+    else if (xx < 0 || xx >= W) return t;
+    const double *c0 = L + (size_t)xx * P;
+    double a, b, c;
+    b = c0[y];
+    if (border == 0) { a = c0[y > 0 ? y - 1 : 0]; c = c0[y + 1 < H ? y + 1 : H - 1]; }
+    else { a = y > 0 ? c0[y - 1] : 0.0; c = y + 1 < H ? c0[y + 1] : 0.0; }
+    t.d += a * dk[0]; t.d += b * dk[1]; t.d += c * dk[2];
+    t.s += a * sk[0]; t.s += b * sk[1]; t.s += c * sk[2];
+    return t;
 }
-__global__ __launch_bounds__(256) void k_scharr_products(LevelView v, int border, size_t zs)
+__global__ __launch_bounds__(64) void k_scharr_products(LevelView v, int border, size_t zs)
 {
     { const size_t z = (size_t)blockIdx.z * zs; v.L += z; v.Iy += z; v.Ix += z; v.Iyy += z; v.Ixx += z; v.Iyx += z; }
-    const int H = v.H, W = v.W;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)H * W) return;
-    const int y = (int)(i % H), x = (int)(i / H);
+    const int H = v.H, W = v.W, P = v.P;
+    const int y = blockIdx.x * 64 + threadIdx.x;
+    if (y >= H) return;
+    const int xs = blockIdx.y * SCH_XC, xe = min(W, xs + SCH_XC);
     const double dk[3] = {-1.0 / 2, 0.0 / 2, 1.0 / 2}, sk[3] = {3.0 / 16, 10.0 / 16, 3.0 / 16};
-    double iy = 0.0, ix = 0.0;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        int xx = x + j - 1;
-        double dcol, scol;
-        bool zero = false;
-        if (border == 0) xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-        else if (xx < 0 || xx >= W) zero = true;
-        if (zero) { dcol = 0.0; scol = 0.0; }
-        else {
-            double a = ldb(v.L, H, W, y - 1, xx, border), b = ldb(v.L, H, W, y, xx, border), c = ldb(v.L, H, W, y + 1, xx, border);
-            dcol = 0.0; dcol += a * dk[0]; dcol += b * dk[1]; dcol += c * dk[2];
-            scol = 0.0; scol += a * sk[0]; scol += b * sk[1]; scol += c * sk[2];
-        }
-        iy += dcol * sk[j];
-        ix += scol * dk[j];
+    ColTerm t0 = scharr_col(v.L, H, W, P, y, xs - 1, border), t1 = scharr_col(v.L, H, W, P, y, xs, border);
+    for (int x = xs; x < xe; x++) {
+        const ColTerm t2 = scharr_col(v.L, H, W, P, y, x + 1, border);
+        double iy = 0.0, ix = 0.0;
+        iy += t0.d * sk[0]; iy += t1.d * sk[1]; iy += t2.d * sk[2];
+        ix += t0.s * dk[0]; ix += t1.s * dk[1]; ix += t2.s * dk[2];
+        const size_t i = (size_t)y + (size_t)x * P;
+        v.Iy[i] = iy; v.Ix[i] = ix;
+        v.Iyy[i] = iy * iy; v.Ixx[i] = ix * ix; v.Iyx[i] = iy * ix;
+        t0 = t1; t1 = t2;
     }
-    v.Iy[i] = iy; v.Ix[i] = ix;
-    v.Iyy[i] = iy * iy; v.Ixx[i] = ix * ix; v.Iyx[i] = iy * ix;
 }
 
 // ImageTransformations.imresize!(dst, interpolate!(src, BSpline(Linear())))
-__global__ __launch_bounds__(256) void k_resize(double *dst, int Hd, int Wd, const double *src, int Hs, int Ws, size_t zs)
+__global__ __launch_bounds__(256) void k_resize(double *dst, int Hd, int Wd, int Pd, const double *src, int Hs, int Ws, int Ps, size_t zs)
 {
     dst += (size_t)blockIdx.z * zs; src += (size_t)blockIdx.z * zs;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -586,28 +622,34 @@ __global__ __launch_bounds__(256) void k_resize(double *dst, int Hd, int Wd, con
     if (iy < 1) iy = 1;
     if (ixx < 1) ixx = 1;
     const double fy = r - iy, fx = c - ixx;
-    const double *p = src + (size_t)(iy - 1) + (size_t)(ixx - 1) * Hs;
-    const int dy = Hs > 1 ? 1 : 0; const size_t dx = Ws > 1 ? (size_t)Hs : 0;
+    const double *p = src + (size_t)(iy - 1) + (size_t)(ixx - 1) * Ps;
+    const int dy = Hs > 1 ? 1 : 0; const size_t dx = Ws > 1 ? (size_t)Ps : 0;
     const double r0 = (1 - fx) * p[0] + fx * p[dx];
     const double r1 = (1 - fx) * p[dy] + fx * p[dy + dx];
-    dst[i] = (1 - fy) * r0 + fy * r1;
+    dst[(size_t)(y - 1) + (size_t)(x - 1) * Pd] = (1 - fy) * r0 + fy * r1;
 }
 
 // Gray{Float64}.(img::Matrix{Gray{N0f8}}) of the KITTI reader (example/kitty/main.jl:39-41):
 // Float64(::N0f8) = raw / 255 (FixedPointNumbers >= 0.8 divides; correctly rounded)
-__global__ __launch_bounds__(256) void k_u8_to_f64(double *dst, const unsigned char *src, size_t n)
+__global__ __launch_bounds__(256) void k_u8_to_f64(double *dst, const unsigned char *src, int H, int W, int P)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = (double)src[i] / 255.0;
+    if (i < (size_t)H * W) dst[i % H + (i / H) * P] = (double)src[i] / 255.0;
 }
 
-// batch ingest: image z of the batch is copied from its own device pointer into layer 0 of pyramid z
+// ingest: the dense H x W image z (its own device pointer) is copied into the pitched layer 0 of pyramid z
 #define BATCH_MAX 32
 struct ImgPtrs { const double *p[BATCH_MAX]; };
-__global__ __launch_bounds__(256) void k_gather_images(ImgPtrs src, double *dst, size_t n, size_t zs)
+__global__ __launch_bounds__(256) void k_gather_images(ImgPtrs src, double *dst, int H, int W, int P, size_t zs)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[(size_t)blockIdx.z * zs + i] = src.p[blockIdx.z][i];
+    if (i < (size_t)H * W) dst[(size_t)blockIdx.z * zs + i % H + (i / H) * P] = src.p[blockIdx.z][i];
+}
+// device -> host staging of one plane: pitched -> dense
+__global__ __launch_bounds__(256) void k_unpitch(double *dst, const double *src, int H, int W, int P)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)H * W) dst[i] = src[i % H + (i / H) * P];
 }
 
 __global__ __launch_bounds__(256) void k_fill(double *p, size_t n, double v)
@@ -625,7 +667,7 @@ static void make_view(slam_pyr *p)
         LevelView &v = p->view.lv[l];
         v.L = p->plane(0, l); v.Iy = p->plane(1, l); v.Ix = p->plane(2, l);
         v.Iyy = p->plane(3, l); v.Ixx = p->plane(4, l); v.Iyx = p->plane(5, l);
-        v.H = p->H[l]; v.W = p->W[l];
+        v.H = p->H[l]; v.W = p->W[l]; v.P = p->P[l];
     }
 }
 
@@ -633,15 +675,15 @@ static void make_view(slam_pyr *p)
 static int build_norm(slam_ctx *ctx, slam_pyr *p, double sigma)
 {
     if (p->norm && p->norm_sigma == sigma) return SLAM_OK;
-    if (!p->norm) HIP_TRY(ctx, hipMalloc((void **)&p->norm, (size_t)p->off[p->levels] * 8));
+    if (!p->norm) HIP_TRY(ctx, hipMalloc((void **)&p->norm, ((size_t)p->off[p->levels] + (size_t)64 * p->P[0]) * 8));
     IIRPair cf; cf.c[0] = slam_iir_coef(sigma); cf.c[1] = cf.c[0];
     for (int l = 0; l + 1 < p->levels; l++) {
         double *N = p->norm + p->off[l];
-        size_t n = (size_t)p->H[l] * p->W[l];
+        size_t n = (size_t)p->P[l] * p->W[l];
         hipLaunchKernelGGL(k_fill, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, N, n, 1.0);
         PlaneSet ps = {}; ps.p[0] = N; ps.coef[0] = 0; ps.fill0[0] = 1; ps.n = 1;
-        hipLaunchKernelGGL(k_iir_cols, lines_grid(p->W[l], 1), dim3(LINE_THREADS), 0, ctx->stream, ps, (const double *)nullptr, p->H[l], p->W[l], cf);
-        hipLaunchKernelGGL(k_iir_rows, lines_grid(p->H[l], 1), dim3(LINE_THREADS), 0, ctx->stream, ps, p->H[l], p->W[l], cf);
+        hipLaunchKernelGGL(k_iir_cols<3>, lines_grid(p->W[l], 1), dim3(LINE_THREADS), 0, ctx->stream, ps, (const double *)nullptr, p->H[l], p->W[l], p->P[l], cf);
+        hipLaunchKernelGGL(k_iir_rows, lines_grid(p->H[l], 1), dim3(LINE_THREADS), 0, ctx->stream, ps, p->H[l], p->W[l], p->P[l], cf);
     }
     HIP_TRY(ctx, hipGetLastError());
     p->norm_sigma = sigma;
@@ -690,12 +732,11 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
     if (fast && (seg_len(p->H[0], PAR_T / 8) > PAR_SLMAX || seg_len(p->W[0], PAR_T / 8) > PAR_SLMAX)) fast = false;   // lines > 2048 samples: exact kernels
     const int border_mode = (mode == 0) ? 1 : 0;
     for (int l = 0; l < p->levels; l++) {
-        const int H = p->H[l], W = p->W[l];
-        const size_t n = (size_t)H * W;
+        const int H = p->H[l], W = p->W[l], P = p->P[l];
         const LevelView &v = p->view.lv[l];
         const bool has_next = l + 1 < p->levels;
         double *T = p->tmp + p->off[l];
-        hipLaunchKernelGGL(k_scharr_products, dim3((n + 255) / 256, 1, S), dim3(256), 0, st, v, border_mode, zs);
+        hipLaunchKernelGGL(k_scharr_products, dim3((H + 63) / 64, (W + SCH_XC - 1) / SCH_XC, S), dim3(64), 0, st, v, border_mode, zs);
         // dim-1 IIR: [blur: L -> T], Iyy, Ixx, Iyx in place
         PlaneSet ps = {};
         int np = 0;
@@ -712,28 +753,30 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             SegPow spc, spr;
             seg_pow(cf, H, slc, spc); seg_pow(cf, W, slr, spr);
             const dim3 gc((W + 7) / 8, np, S), gr((H + 7) / 8, np, S), gc3((W + 7) / 8, 3, S), gr3((H + 7) / 8, 3, S);
-            hipLaunchKernelGGL(k_iir_seg<true>, gc, dim3(PAR_T), 0, st, ps, src0, H, W, cf, spc, slc);
+            hipLaunchKernelGGL(k_iir_seg<true>, gc, dim3(PAR_T), 0, st, ps, src0, H, W, P, cf, spc, slc);
             if (spans) { ProfScope span(ctx, "k_iir_rows");
-                hipLaunchKernelGGL(k_iir_seg<false>, gr, dim3(PAR_T), 0, st, ps, (const double *)nullptr, H, W, cf, spr, slr); }
-            else hipLaunchKernelGGL(k_iir_seg<false>, gr, dim3(PAR_T), 0, st, ps, (const double *)nullptr, H, W, cf, spr, slr);
+                hipLaunchKernelGGL(k_iir_seg<false>, gr, dim3(PAR_T), 0, st, ps, (const double *)nullptr, H, W, P, cf, spr, slr); }
+            else hipLaunchKernelGGL(k_iir_seg<false>, gr, dim3(PAR_T), 0, st, ps, (const double *)nullptr, H, W, P, cf, spr, slr);
             if (forked) { (void)hipEventRecord(p->ev_fork[l], st); (void)hipStreamWaitEvent(aux, p->ev_fork[l], 0); }
             if (has_next)
                 hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, st,
-                                   p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], (const double *)T, H, W, zs);
-            hipLaunchKernelGGL(k_cum_seg<true>, gc3, dim3(PAR_T), 0, aux, pc, H, W, slc);
-            hipLaunchKernelGGL(k_cum_seg<false>, gr3, dim3(PAR_T), 0, aux, pc, H, W, slr);
+                                   p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
+            hipLaunchKernelGGL(k_cum_seg<true>, gc3, dim3(PAR_T), 0, aux, pc, H, W, P, slc);
+            hipLaunchKernelGGL(k_cum_seg<false>, gr3, dim3(PAR_T), 0, aux, pc, H, W, P, slr);
             continue;
         }
-        hipLaunchKernelGGL(k_iir_cols, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, cf);
+        if (S == 1) hipLaunchKernelGGL(k_iir_cols<3>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
+        else hipLaunchKernelGGL(k_iir_cols<2>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
         if (spans) { ProfScope span(ctx, "k_iir_rows");
-            hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, cf); }
-        else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, cf);
+            hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf); }
+        else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf);
         if (forked) { (void)hipEventRecord(p->ev_fork[l], st); (void)hipStreamWaitEvent(aux, p->ev_fork[l], 0); }
         if (has_next)
             hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, st,
-                               p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], (const double *)T, H, W, zs);
-        hipLaunchKernelGGL(k_cum_cols, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, aux, pc, H, W);
-        hipLaunchKernelGGL(k_cum_rows, lines_grid(H, 3, S), dim3(LINE_THREADS), 0, aux, pc, H, W);
+                               p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
+        if (S == 1) hipLaunchKernelGGL(k_cum_cols<3>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, aux, pc, H, W, P);
+        else hipLaunchKernelGGL(k_cum_cols<2>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, aux, pc, H, W, P);
+        hipLaunchKernelGGL(k_cum_rows, lines_grid(H, 3, S), dim3(LINE_THREADS), 0, aux, pc, H, W, P);
     }
     if (forked) { (void)hipEventRecord(p->ev_join, aux); (void)hipStreamWaitEvent(st, p->ev_join, 0); }
 }
@@ -780,32 +823,42 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma, int
     return SLAM_OK;
 }
 
+// dense column-major H x W image (device) -> pitched layer 0
+static void ingest_dense(slam_ctx *ctx, slam_pyr *p, const double *image_dev)
+{
+    ImgPtrs ip = {}; ip.p[0] = image_dev;
+    const size_t n = (size_t)p->H[0] * p->W[0];
+    hipLaunchKernelGGL(k_gather_images, dim3((n + 255) / 256, 1, 1), dim3(256), 0, ctx->stream, ip, p->plane(0, 0), p->H[0], p->W[0], p->P[0], (size_t)0);
+}
+
 extern "C" {
 
 // One allocation holds S pyramids back to back: per image 6 planes + the blur scratch plane
-// (zstride = 7 * sum_l H_l W_l doubles).  S = 1 is the ordinary single pyramid.
+// (zstride = 7 * sum_l P_l W_l doubles, P_l = H_l rounded up to 16).  S = 1 is the ordinary single pyramid.
 static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, slam_pyr **out)
 {
     ARG_TRY(ctx, ctx != nullptr && out != nullptr);
     ARG_TRY(ctx, H >= 4 && W >= 4 && pyramid_levels >= 0 && pyramid_levels + 1 <= SLAM_MAX_LEVELS && S >= 1 && S <= BATCH_MAX);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int Hs[SLAM_MAX_LEVELS], Ws[SLAM_MAX_LEVELS]; int64_t off[SLAM_MAX_LEVELS + 1];
+    int Hs[SLAM_MAX_LEVELS], Ws[SLAM_MAX_LEVELS], Ps[SLAM_MAX_LEVELS]; int64_t off[SLAM_MAX_LEVELS + 1];
     int64_t o = 0; int h = H, w = W;
     const int levels = pyramid_levels + 1;
     for (int l = 0; l < levels; l++) {
         if (h < 4 || w < 4) return slam_fail(ctx, SLAM_ERR_ARG, "slam_pyr_create: level %d is %dx%d, too small for the IIR kernel (needs > 3)", l, h, w);
-        Hs[l] = h; Ws[l] = w; off[l] = o; o += (int64_t)h * w;
+        Hs[l] = h; Ws[l] = w; Ps[l] = (h + 15) & ~15; off[l] = o; o += (int64_t)Ps[l] * w;
         h = (h + 1) / 2; w = (w + 1) / 2;                         // ceil(size / 2)
     }
     off[levels] = o;
     slam_pyr::Alloc *al = new slam_pyr::Alloc();
-    hipError_t e = hipMalloc((void **)&al->base, (size_t)o * 7 * 8 * S);
+    const size_t tail = (size_t)64 * Ps[0];                                  // column tiles of the last workgroup read up to 63 columns past W
+    hipError_t e = hipMalloc((void **)&al->base, ((size_t)o * 7 * S + tail) * 8);
     if (e != hipSuccess) { delete al; return slam_fail(ctx, SLAM_ERR_HIP, "slam_pyr_create: hipMalloc: %s", hipGetErrorString(e)); }
+    (void)hipMemsetAsync(al->base, 0, ((size_t)o * 7 * S + tail) * 8, ctx->stream);   // pitch padding rows are never used; keep them defined
     al->refs = S;
     for (int s = 0; s < S; s++) {
         slam_pyr *p = new slam_pyr();
         p->device = ctx->device; p->levels = levels;
-        memcpy(p->H, Hs, sizeof Hs); memcpy(p->W, Ws, sizeof Ws); memcpy(p->off, off, sizeof off);
+        memcpy(p->H, Hs, sizeof Hs); memcpy(p->W, Ws, sizeof Ws); memcpy(p->P, Ps, sizeof Ps); memcpy(p->off, off, sizeof off);
         p->alloc = al;
         p->zstride = (size_t)o * 7;
         p->planes = al->base + (size_t)s * p->zstride;
@@ -838,7 +891,7 @@ int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double
     ImgPtrs ip;
     for (int s = 0; s < BATCH_MAX; s++) ip.p[s] = s < S ? images_dev[s] : nullptr;
     const size_t n = (size_t)p0->H[0] * p0->W[0];
-    hipLaunchKernelGGL(k_gather_images, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), n, p0->zstride);
+    hipLaunchKernelGGL(k_gather_images, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
     int rc = enqueue_build(ctx, p0, mode, sigma, S);
     if (rc) return rc;
     if (sync) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -866,8 +919,7 @@ int slam_pyr_update_dev(slam_ctx *ctx, slam_pyr *p, const double *image_dev, int
 {
     ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_dev != nullptr && (mode == 0 || mode == 1 || mode == 3) && sigma > 0);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (image_dev != p->plane(0, 0))
-        HIP_TRY(ctx, hipMemcpyAsync(p->plane(0, 0), image_dev, (size_t)p->H[0] * p->W[0] * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    ingest_dense(ctx, p, image_dev);
     int rc = enqueue_build(ctx, p, mode, sigma);
     if (rc) return rc;
     if (sync) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -878,8 +930,12 @@ int slam_pyr_update(slam_ctx *ctx, slam_pyr *p, const double *image, int mode, d
 {
     ARG_TRY(ctx, ctx != nullptr && p != nullptr && image != nullptr && (mode == 0 || mode == 1 || mode == 3) && sigma > 0);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(p->plane(0, 0), image, (size_t)p->H[0] * p->W[0] * 8, hipMemcpyHostToDevice, ctx->stream));
-    int rc = enqueue_build(ctx, p, mode, sigma);
+    void *stage;
+    int rc = slam_scratch2(ctx, (size_t)p->H[0] * p->W[0] * 8, &stage);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(stage, image, (size_t)p->H[0] * p->W[0] * 8, hipMemcpyHostToDevice, ctx->stream));
+    ingest_dense(ctx, p, (const double *)stage);
+    rc = enqueue_build(ctx, p, mode, sigma);
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLAM_OK;
@@ -894,7 +950,7 @@ int slam_pyr_update_u8(slam_ctx *ctx, slam_pyr *p, const uint8_t *image_u8, int 
     int rc = slam_scratch2(ctx, n, &d8);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d8, image_u8, n, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_u8_to_f64, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, p->plane(0, 0), (const unsigned char *)d8, n);
+    hipLaunchKernelGGL(k_u8_to_f64, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, p->plane(0, 0), (const unsigned char *)d8, p->H[0], p->W[0], p->P[0]);
     rc = enqueue_build(ctx, p, mode, sigma);
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -934,7 +990,12 @@ int slam_pyr_download(slam_ctx *ctx, const slam_pyr *p, int plane, int level, do
     ARG_TRY(ctx, ctx != nullptr && p != nullptr && out != nullptr);
     ARG_TRY(ctx, plane >= 0 && plane < 6 && level >= 0 && level < p->levels);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(out, p->plane(plane, level), (size_t)p->H[level] * p->W[level] * 8, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t n = (size_t)p->H[level] * p->W[level];
+    void *stage;
+    int rc = slam_scratch2(ctx, n * 8, &stage);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_unpitch, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (double *)stage, (const double *)p->plane(plane, level), p->H[level], p->W[level], p->P[level]);
+    HIP_TRY(ctx, hipMemcpyAsync(out, stage, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLAM_OK;
 }

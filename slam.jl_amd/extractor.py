@@ -53,6 +53,29 @@ def detect(e, image, current_points, sigma_mask=3.0, min_response=1e-4, ctx=None
     return out[:n.value].copy()
 
 
+def detect_batch(e, batch, current_points, stream_index, sigma_mask=3.0, min_response=1e-4, ctx=None):
+    """detect() for every stream of a PyramidBatch in one launch (slam_detect_batch).
+
+    current_points (n, 2) with stream_index (n,) sorted ascending (points of stream s contiguous).
+    Returns (keypoints (m, 2) int64, stream_index (m,) int32), grouped by stream."""
+    ctx = ctx or batch.ctx
+    S = batch.S
+    cur = np.ascontiguousarray(current_points, dtype=np.float64).reshape(-1, 2)
+    sid = np.asarray(stream_index, dtype=np.int64)
+    if len(sid) > 1 and np.any(np.diff(sid) < 0):
+        raise ValueError("detect_batch: current_points must be grouped by ascending stream_index")
+    cur_off = np.zeros(S + 1, dtype=np.int32)
+    cur_off[1:] = np.cumsum(np.bincount(sid, minlength=S)[:S])
+    cap = S * _cap(e, 0)
+    out = np.empty((cap, 2), dtype=np.int64)
+    out_off = np.zeros(S + 1, dtype=np.int32)
+    ctx.check(ctx.lib.slam_detect_batch(ctx.h, batch.pyramids[0].h, S, L.ptr(cur), L.ptr(cur_off, L.i32p), e.max_points, e.radius,
+                                        e.grid_resolution[0], e.grid_resolution[1], e.cell_size, float(sigma_mask),
+                                        float(min_response), L.ptr(out, L.i64p), cap, L.ptr(out_off, L.i32p)))
+    m = int(out_off[S])
+    return out[:m].copy(), np.repeat(np.arange(S, dtype=np.int32), np.diff(out_off))
+
+
 def brief_pattern(size=256, window=9, seed=123):
     """A BRIEF sampling table (size x 4: dy1, dx1, dy2, dx2), Gaussian sampling
     N(0, window^2/25) clipped to the window like ImageFeatures' gaussian

@@ -152,9 +152,8 @@ def optical_flow_matching(from_pyramid, to_pyramid, pixels, is_3d, projections, 
         if rc == -3:
             raise RuntimeError("Not enough layers in pyramids.")
         ctx.check(rc)
-        st = status.astype(bool)
-        new = pixels.copy(); new[st] = out[st]
-        return new, st
+        st = status.view(np.bool_)
+        return np.where(st[:, None], out, pixels), st
     is3 = is_3d.astype(bool)
     new = pixels.copy()
     status = np.zeros(n, dtype=bool)
@@ -219,6 +218,5 @@ def optical_flow_matching_batch(from_batch, to_batch, stream_index, pixels, is_3
     if rc == -3:
         raise RuntimeError("Not enough layers in pyramids.")
     ctx.check(rc)
-    st = status.astype(bool)
-    new = pixels.copy(); new[st] = out[st]
-    return new, st
+    st = status.view(np.bool_)
+    return np.where(st[:, None], out, pixels), st
