@@ -6,11 +6,15 @@ ms/iteration, against the HBM roofline, with the CPU oracle timed beside it.
     python bench.py --gpus N --steps K --warmup W
 
 One process per GPU (the driver launches N>1 through torch.distributed.run).
-A step = one frame of a synthetic KITTI-05-shaped stereo stream (370 x 1226,
-1000 keypoints, key-frame every 5th frame) through the hot path, images
-already resident in HBM as Float64.  N>1 = N independent replicas of the stream
-(the front-end does not shard: SURVEY 8e) -> weak scaling, no collective in the
-data path.  Rank 0 prints ONE JSON line.
+A step = one frame of EACH of S lock-stepped, independent synthetic
+KITTI-05-shaped stereo streams (370 x 1226, 1000 keypoints, key-frame every
+5th frame) through the hot path -- one batch of S frames per pass, every launch
+shared by the S streams (slam_pyr_update_batch_dev / slam_flow_match_batch /
+slam_detect_batch), images already resident in HBM as Float64, all planes
+bit-exact.  value = frames/s over all streams and GPUs.  The single-stream
+(latency) numbers of the same workload are reported beside it.  N>1 = N
+independent replicas (the front-end does not shard: SURVEY 8e) -> weak scaling,
+no collective in the data path.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -183,14 +187,14 @@ def iir_rows_bytes(H, W, levels):
     return tot
 
 
-def run_lockstep(slam, torch, local_rank, S, steps, H, W, left_dev, right_dev, flows, disparity, params, extractor, fast, world, dist, dev):
+def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, right_dev, flows, disparity, params, extractor, fast, world, dist, dev):
     """S streams in lock-step through the batch entry points.  Stream s plays the same ping-pong sequence shifted
     by s frames (so the S images of a step differ); key-frames fall on the same step for all streams."""
     ctx, ctx_pyr, ctx_right = slam.Context(local_rank), slam.Context(local_rank), slam.Context(local_rank)
     levels = params.pyramid_levels
     lb = [slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx) for _ in range(3)]
     rb = slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx)
-    seq = frame_sequence(steps + 60 + S)
+    seq = frame_sequence(steps + warmup + 60 + S)
     rng = np.random.default_rng(1234)
     noise_pool = rng.normal(0, 0.5, (1 << 17, 2))          # prior noise, drawn once (synthetic-input generation, not SLAM work)
     lptr = lambda i: [left_dev[seq[i + s]].data_ptr() for s in range(S)]
@@ -243,7 +247,7 @@ def run_lockstep(slam, torch, local_rank, S, steps, H, W, left_dev, right_dev, f
         if world > 1:
             dist.barrier()
 
-    warm = 11
+    warm = max(warmup, 6)
     for i in range(1, 1 + warm):
         step(i)
     state["tracked"] = 0
@@ -270,7 +274,7 @@ def run_lockstep(slam, torch, local_rank, S, steps, H, W, left_dev, right_dev, f
     for c in (ctx_pyr, ctx_right):
         c.prof_enable(False)
     rb_bytes = S * iir_rows_bytes(H, W, levels) / (levels + 1)
-    res = {"streams_per_gpu": S, "steps": steps, "value": world * S * steps / dt, "unit": "frames/sec",
+    res = {"streams_per_gpu": S, "steps": steps, "value": world * S * steps / dt, "unit": "frames/sec", "seconds": dt,
            "ms_per_step_of_S_frames": dt / steps * 1e3, "tracked_kpts_per_frame": round(tracked, 1),
            "roofline": {"bound": "hbm", "kernel": "k_iir_seg<rows>" if fast else "k_iir_rows", "achieved": rb_bytes / (rows_ms / max(rows_n, 1) * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rb_bytes / (rows_ms / max(rows_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -288,7 +292,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ba", action="store_true", help="skip the BA measurements")
-    ap.add_argument("--batch-streams", type=int, default=8, help="extra measurement: S concurrent streams per GPU (0 = skip)")
+    ap.add_argument("--streams", type=int, default=16, help="S: independent stereo streams per GPU advancing in lock-step (one batch of S frames per step)")
+    ap.add_argument("--no-tolerance", action="store_true", help="skip the tolerance-mode measurements")
     args = ap.parse_args()
 
     import torch
@@ -323,11 +328,48 @@ def main():
     left_dev = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in left]
     right_dev = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in right]
     torch.cuda.synchronize()
+    S = args.streams
+    levels = params.pyramid_levels
 
+    # ---- headline: S lock-stepped streams per GPU, bit-exact planes, every launch shared by the S streams ----
+    head = run_lockstep(slam, torch, local_rank, S, args.steps, args.warmup, H, W, left_dev, right_dev, flows, disparity,
+                        params, extractor, False, world, dist, dev)
+    out = {
+        "metric": "frames/sec KITTI-05 stereo @1k kpts; local-BA ms/iter for 50-KF window",
+        "value": head["value"], "unit": "frames/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step_of_S_frames"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "KITTI-05-shaped stereo streams 370x1226 f64, 1000 kpts/frame, key-frame every 5th frame: "
+                               "left pyramid update + FB-LK (3-D prior pass + 2-D pass) per frame; "
+                               "detect + right pyramid + stereo FB-LK per key-frame (BASELINE configs[1]); "
+                               f"one step = one frame of each of {S} independent streams",
+                   "streams_per_gpu": S, "frames_per_step": S, "parallelism": f"replicas x{world}",
+                   "pyramid_mode": "bit-exact (slam_pyr_update mode 1 arithmetic; planes identical to the CPU oracle)",
+                   "batching": "the S streams advance in lock-step and share every launch: pyramids live in slam_pyr_create_batch batches "
+                               "(grid.z = stream), all keypoints are tracked by one slam_flow_match_batch launch, key-frame detection is one "
+                               "slam_detect_batch launch; 3 HIP streams (tracking/detect; left pyramids; right pyramids), the next frame's "
+                               "pyramid build (one hipGraph replay) overlaps the current frame's tracking",
+                   "tracked_kpts_per_frame": head["tracked_kpts_per_frame"],
+                   "window_size": params.window_size, "pyramid_levels": levels,
+                   "cull_fraction_per_keyframe": CULL_FRACTION},
+        "roofline": dict(head["roofline"], kernel="k_iir_rows (dim-2 IIR Gaussian pass of the LK pyramid, one launch for the S images of a step; "
+                                                  "the pyramid build is ~70 % of the device time of a step, this is its largest kernel)"),
+        "pyramid_batch_update_serial_us": head["pyramid_batch_update_serial_us"],
+    }
+    pmc = os.path.join(ROOT, "profiles", "r01d_pmc_pyramid_batch.json")
+    if SHAPE == "kitti05" and os.path.exists(pmc):
+        j = json.load(open(pmc))
+        if j.get("streams") == S:
+            out["roofline"]["traffic"] = j["summary"]["k_iir_rows_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/r01d_pmc_pyramid_batch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 corrected)"
+
+    # ---- the same workload as ONE stream (latency view): 3 contexts, pipelined next-frame pyramid ----
+    n1 = min(args.steps, 300)
     ctx_pyr = slam.Context(local_rank); ctx_right = slam.Context(local_rank)
     be = GpuBackend(slam, ctx, ctx_pyr, ctx_right, H, W, left_dev, right_dev, params, extractor)
     stream = Stream(be, flows, disparity, seed=rank)
-    seq = frame_sequence(args.warmup + args.steps + 202)   # the ping-pong sequence is periodic
+    seq = frame_sequence(args.warmup + n1 + 202)   # the ping-pong sequence is periodic
     be.prime(seq[0])
 
     def barrier():
@@ -335,28 +377,31 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def max_over_ranks(dt):
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt[0])
+        return dt
+
     for i in range(args.warmup):
         stream.step(seq[i], seq[i + 1], seq[i + 2])
     kp_before = stream.n_tracked
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
+    for i in range(args.warmup, args.warmup + n1):
         stream.step(seq[i], seq[i + 1], seq[i + 2])
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+    dt = max_over_ranks(time.perf_counter() - t0)
     n_tracked_timed = stream.n_tracked - kp_before
     # per-kernel device time: a second pass over the same stream with hipEvent spans on
     # the library stream.  Spans force the direct-launch path (the timed region above
     # replays the pyramid build as one hipGraph, which events cannot look inside).
-    prof_steps = min(args.steps, 100)
+    prof_steps = min(n1, 100)
     be.pipelined = False
     for c in (ctx, ctx_pyr, ctx_right):
         c.prof_enable(True); c.prof_reset()
-    base = args.warmup + args.steps
+    base = args.warmup + n1
     for i in range(base, base + prof_steps):
         stream.step(seq[i], seq[i + 1], seq[i + 2])
     pyr_ms, pyr_n = [a + b for a, b in zip(ctx_pyr.prof_get("pyr_update"), ctx_right.prof_get("pyr_update"))]
@@ -366,54 +411,34 @@ def main():
     for c in (ctx, ctx_pyr, ctx_right):
         c.prof_enable(False)
     be.pipelined = True
-    tracked_per_frame = n_tracked_timed / max(args.steps, 1)
-
-    out = {
-        "metric": "frames/sec KITTI-05 stereo @1k kpts; local-BA ms/iter for 50-KF window",
-        "value": world * args.steps / dt, "unit": "frames/sec",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "KITTI-05-shaped stereo stream 370x1226 f64, 1000 kpts/frame, key-frame every 5th frame: "
-                               "left pyramid update + FB-LK (3-D prior pass + 2-D pass) per frame; "
-                               "detect + right pyramid + stereo FB-LK per key-frame (BASELINE configs[1])",
-                   "streams_per_gpu": 1, "parallelism": f"replicas x{world}",
-                   "pipelining": "3 HIP streams per stereo stream (tracking/detect; left pyramids; right pyramids), like the reference's front-end / mapper tasks: the next frame's pyramid build (one hipGraph replay) overlaps the current frame's tracking", "tracked_kpts_per_frame": round(tracked_per_frame, 1),
-                   "window_size": params.window_size, "pyramid_levels": params.pyramid_levels,
-                   "cull_fraction_per_keyframe": CULL_FRACTION},
-    }
+    single = {"value": world * n1 / dt, "unit": "frames/sec", "steps": n1, "ms_per_frame": dt / n1 * 1e3, "streams_per_gpu": 1,
+              "tracked_kpts_per_frame": round(n_tracked_timed / max(n1, 1), 1),
+              "note": "the same workload as one stream per GPU through the single-image entry points (frame latency view)"}
     if pyr_n:
-        pyr_bytes = pyramid_bytes(H, W, params.pyramid_levels)
-        rows_bytes = iir_rows_bytes(H, W, params.pyramid_levels) / (params.pyramid_levels + 1)   # per launch (4 launches / pyramid)
+        pyr_bytes = pyramid_bytes(H, W, levels)
+        rows_bytes = iir_rows_bytes(H, W, levels) / (levels + 1)   # per launch (4 launches / pyramid)
         a = rows_bytes / (rows_ms / rows_n * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_iir_rows (dim-2 IIR Gaussian pass of the LK pyramid; largest share of device time)",
-                           "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None,
-                           "avg_launch_us": rows_ms / rows_n * 1e3, "algorithmic_bytes_per_launch": rows_bytes,
-                           "stage": {"name": "pyramid update (all kernels of one image)", "algorithmic_bytes": pyr_bytes,
-                                     "avg_us": pyr_ms / pyr_n * 1e3, "achieved": pyr_bytes / (pyr_ms / pyr_n * 1e-3) / 1e9,
-                                     "frac": pyr_bytes / (pyr_ms / pyr_n * 1e-3) / 1e9 / HBM_PEAK_GBS}}
-        out["device_ms_per_step"] = {"pyr_update_serial_launches": pyr_ms / prof_steps, "fb_track": fb_ms / prof_steps, "detect": det_ms / prof_steps,
-                                     "spans_over_steps": prof_steps, "launches": {"pyr_update": pyr_n, "fb_track": fb_n, "detect": det_n}}
+        single["roofline"] = {"bound": "hbm", "kernel": "k_iir_rows, one image per launch (bound by the dependent f64 chain of the recurrence, not by HBM)",
+                              "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None,
+                              "avg_launch_us": rows_ms / rows_n * 1e3, "algorithmic_bytes_per_launch": rows_bytes,
+                              "stage": {"name": "pyramid update (all kernels of one image)", "algorithmic_bytes": pyr_bytes,
+                                        "avg_us": pyr_ms / pyr_n * 1e3, "achieved": pyr_bytes / (pyr_ms / pyr_n * 1e-3) / 1e9,
+                                        "frac": pyr_bytes / (pyr_ms / pyr_n * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        single["device_ms_per_frame"] = {"pyr_update_serial_launches": pyr_ms / prof_steps, "fb_track": fb_ms / prof_steps, "detect": det_ms / prof_steps,
+                                         "spans_over_steps": prof_steps, "launches": {"pyr_update": pyr_n, "fb_track": fb_n, "detect": det_n}}
+        pmc1 = os.path.join(ROOT, "profiles", "r01_pmc_pyramid.json")
+        if SHAPE == "kitti05" and os.path.exists(pmc1):
+            single["roofline"]["traffic"] = json.load(open(pmc1))["summary"]["k_iir_rows_bytes_per_launch"]
+            single["roofline"]["traffic_source"] = "profiles/r01_pmc_pyramid.json"
+    out["single_stream"] = single
 
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_pyramid.json")
-    if "roofline" in out and SHAPE == "kitti05" and os.path.exists(pmc):
-        out["roofline"]["traffic"] = json.load(open(pmc))["summary"]["k_iir_rows_bytes_per_launch"]
-        out["roofline"]["traffic_source"] = "profiles/r01_pmc_pyramid.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 corrected)"
-
-    # ---- throughput mode: S lock-stepped stereo streams per GPU sharing every launch (batch APIs) ----
-    if args.batch_streams > 1:
-        S = args.batch_streams
-        out["batched"] = {}
-        for label, fast in (("bit_exact", False), ("tolerance_mode", True)):
-            r = run_lockstep(slam, torch, local_rank, S, max(40, args.steps // 4), H, W, left_dev, right_dev, flows, disparity,
-                             params, extractor, fast, world, dist, dev)
-            out["batched"][label] = r
-        out["batched"]["note"] = ("S independent stereo streams of the same workload advance in lock-step and share every launch: "
-                                  "pyramids live in slam_pyr_create_batch batches (grid.z = stream), all keypoints are tracked by one "
-                                  "slam_flow_match_batch launch; value = total frames/s over the S streams")
-
-    # ---- same stream with the tolerance-mode pyramid (mode 3: parallel recurrences, planes within 1e-11 rel.) ----
-    if True:
+    # ---- tolerance-mode pyramid (mode 3: parallel recurrences, planes within 1e-11 rel.): batched and single ----
+    if not args.no_tolerance:
+        tol = run_lockstep(slam, torch, local_rank, S, max(40, args.steps // 4), min(args.warmup, 10), H, W, left_dev, right_dev, flows, disparity,
+                           params, extractor, True, world, dist, dev)
+        out["tolerance_mode"] = dict(tol, pyramid="slam_pyr_update mode 3 (parallel recurrences; planes <= 1e-11 relative, tracked positions <= 1e-7 px vs "
+                                                  "the bit-exact mode: tests/test_gpu_pyramid.py::test_fast_mode_within_tolerance); built for single-image "
+                                                  "latency, slower than the bit-exact kernels once S images share a launch")
         fctx = [slam.Context(local_rank) for _ in range(3)]
         fbe = GpuBackend(slam, fctx[0], fctx[1], fctx[2], H, W, left_dev, right_dev, params, extractor, fast=True)
         fs = Stream(fbe, flows, disparity, seed=rank)
@@ -424,31 +449,13 @@ def main():
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        for i in range(args.warmup, args.warmup + args.steps):
+        for i in range(args.warmup, args.warmup + n1):
             fs.step(seq[i], seq[i + 1], seq[i + 2])
         fbe.drain(); torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        dtf = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dtf], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dtf = float(tt[0])
-        fbe.pipelined = False
-        fctx[1].prof_enable(True); fctx[1].prof_reset()
-        for i in range(args.warmup + args.steps, args.warmup + args.steps + 40):
-            fs.step(seq[i], seq[i + 1], seq[i + 2])
-        frow_ms, frow_n = fctx[1].prof_get("k_iir_rows")
-        fpyr_ms, fpyr_n = fctx[1].prof_get("pyr_update")
-        fctx[1].prof_enable(False)
-        rb = iir_rows_bytes(H, W, params.pyramid_levels) / (params.pyramid_levels + 1)
-        out["tolerance_mode"] = {
-            "value": world * args.steps / dtf, "unit": "frames/sec", "ms_per_step": dtf / args.steps * 1e3,
-            "pyramid": "slam_pyr_update mode 3 (parallel recurrences; planes <= 1e-11 relative, tracked positions <= 1e-7 px vs the bit-exact mode: tests/test_gpu_pyramid.py::test_fast_mode_within_tolerance)",
-            "roofline": {"bound": "hbm", "kernel": "k_iir_seg<rows>", "achieved": rb / (frow_ms / max(frow_n, 1) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": rb / (frow_ms / max(frow_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": frow_ms / max(frow_n, 1) * 1e3,
-                         "algorithmic_bytes_per_launch": rb, "traffic": None},
-            "pyramid_update_serial_us": fpyr_ms / max(fpyr_n, 1) * 1e3}
+        dtf = max_over_ranks(time.perf_counter() - t0)
+        out["tolerance_mode"]["single_stream"] = {"value": world * n1 / dtf, "unit": "frames/sec", "ms_per_frame": dtf / n1 * 1e3}
         for c in fctx:
             c.close()
 

@@ -50,3 +50,9 @@ def glue():
     p = kp + fl[sid] + rng.normal(0, 0.5, kp.shape)
     a, b, c = kp[ok], is3d[ok], sid[ok]
 print("numpy glue us", t(glue))
+for its in (1, 2, 3, 5, 10, 20, 30):
+    print("iterations", its, "flow batch us", t(lambda: slam.optical_flow_matching_batch(pb[0], pb[1], sid, kp, is3d, proj, params, iterations=its, ctx=ctx), n=10))
+none3d = np.zeros(len(kp), dtype=bool)
+print("all-2D (3 levels, no prior) us", t(lambda: slam.optical_flow_matching_batch(pb[0], pb[1], sid, kp, none3d, proj, params, ctx=ctx), n=10))
+all3d = np.ones(len(kp), dtype=bool)
+print("all-3D us", t(lambda: slam.optical_flow_matching_batch(pb[0], pb[1], sid, kp, all3d, proj, params, ctx=ctx), n=10))

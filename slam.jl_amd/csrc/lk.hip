@@ -26,6 +26,22 @@ struct LKArgs {
     uint8_t *status;
 };
 
+// -DLK_TRACE: per-phase tick totals (100 MHz wall clock, summed over waves) for scripts/lk_trace.py; off in the product build
+#ifdef LK_TRACE
+__device__ unsigned long long g_lk_ticks[8];
+#define LKT_BEGIN unsigned long long _t0 = wall_clock64()
+#define LKT(k) do { const unsigned long long _t1 = wall_clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_lk_ticks[k], _t1 - _t0); _t0 = _t1; } while (0)
+extern "C" int slam_debug_lk_ticks(unsigned long long *out)
+{
+    unsigned long long z[8] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lk_ticks), sizeof z) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lk_ticks), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#else
+#define LKT_BEGIN
+#define LKT(k)
+#endif
+
 struct Offs { int up, down, left, right; };
 
 __device__ __forceinline__ Offs get_offsets(int p0, int p1, double n0, double n1, int window, int H, int W)
@@ -138,28 +154,47 @@ __device__ __forceinline__ double wave_sum(double v)
 // enumeration.  Template samples, gradients and the element's window offsets depend only on the window
 // geometry, so they are fetched once per geometry and stay in registers across the <= 30 iterations
 // (no integer div/mod and no template loads inside the iteration).
-#define LK_MAXE 9                     // 64 * 9 = 576 >= 23 * 23 (window_size <= 11)
-struct Tmpl { double A[LK_MAXE], Iy[LK_MAXE], Ix[LK_MAXE], dp[LK_MAXE], dq[LK_MAXE]; int ne; };
+// LK_MAXE slots per lane: the kernels are instantiated for 3 (window_size <= 6), 6 (<= 9, the default 19 x 19
+// window) and 9 (<= 11) slots so that the register footprint follows the window; larger windows take the
+// uncached path.
+// The template samples live in LDS (a private [plane][slot][lane] spill area of the single-wave workgroup, 9 KB
+// for 6 slots, no barriers); only the packed window coordinates stay in registers (163 VGPRs -> 3 waves per SIMD
+// for the default window).  Measured (scripts/lk_trace.py, rocprofv3 --pmc): a point executes ~6k wave
+// instructions as one dependent stream (~16 cycles each); L1-miss latency averages 400 cycles with only 2-3
+// misses outstanding per wave, so the kernel is bound by that instruction stream, not by HBM or the L1.
+template <int LK_MAXE> struct Tmpl {
+    double (*s)[LK_MAXE][64];      // LDS: s[0] = template samples, s[1] = Iy, s[2] = Ix
+    int pq[LK_MAXE];               // window coordinates p | q << 16 of slot k (0 | 0 past the window)
+    int ne, kmax;
+};
+struct __attribute__((packed, aligned(8))) D2 { double a, b; };   // two vertically adjacent samples, one 16-byte load
 
-__device__ __forceinline__ void load_template(Tmpl &T, const LevelView &first, int p0, int p1, Offs o)
+template <int LK_MAXE>
+__device__ __forceinline__ void load_template(Tmpl<LK_MAXE> &T, const LevelView &first, int p0, int p1, Offs o)
 {
     const int lane = threadIdx.x & 63, pitch = first.P;
     const int P = o.up + o.down + 1, Q = o.left + o.right + 1, NE = P * Q;
-    T.ne = NE;
+    T.ne = NE; T.kmax = (NE + 63) >> 6;
+    // element e = lane + 64 k -> (p, q) = (e % P, e / P), advanced incrementally (one division per template)
+    int pe = lane % P, qe = lane / P;
+    const int sp = 64 % P, sq = 64 / P;
 #pragma unroll
     for (int k = 0; k < LK_MAXE; k++) {
         const int e = lane + 64 * k;
         const bool in = e < NE;
-        const int p = in ? e % P : 0, q = in ? e / P : 0;
+        const int p = in ? pe : 0, q = in ? qe : 0;
+        pe += sp; qe += sq;
+        if (pe >= P) { pe -= P; qe++; }
         const size_t a = (size_t)(p0 - o.up + p - 1) + (size_t)(p1 - o.left + q - 1) * pitch;
-        T.A[k] = in ? first.L[a] : 0.0; T.Iy[k] = in ? first.Iy[a] : 0.0; T.Ix[k] = in ? first.Ix[a] : 0.0;
-        T.dp[k] = (double)(p - o.up); T.dq[k] = (double)(q - o.left);
+        T.s[0][k][lane] = in ? first.L[a] : 0.0; T.s[1][k][lane] = in ? first.Iy[a] : 0.0; T.s[2][k][lane] = in ? first.Ix[a] : 0.0;
+        T.pq[k] = p | (q << 16);
     }
 }
 
 // One pyramid level of optflow! for one point (lucas_kanade.jl:33-96).  All
 // control flow is wave-uniform.  Returns the point's status.
-__device__ bool lk_level(const LevelView &first, const LevelView &second, int level,
+template <int LK_MAXE>
+__device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView &second, int level,
                          double pty, double ptx, double &dy, double &dx,
                          int window, int iterations, double eig_thr, double eps)
 {
@@ -168,34 +203,63 @@ __device__ bool lk_level(const LevelView &first, const LevelView &second, int le
     const double scale = (double)(1 << (level - 1));
     const int p0 = (int)floor(pty / scale), p1 = (int)floor(ptx / scale);
     const double pf0 = (double)p0, pf1 = (double)p1;
-    Offs o = get_offsets(p0, p1, pf0, pf1, window, H, W);
-    double Gi[4];
-    double min_eig = spatial_gradient(first, p0, p1, o, Gi);
-    if (min_eig < eig_thr) return false;
+    LKT_BEGIN;
     const bool cached = (2 * window + 1) * (2 * window + 1) <= 64 * LK_MAXE;
-    Tmpl T;
-    if (cached) load_template(T, first, p0, p1, o);
+    __shared__ double lds_tmpl[3][LK_MAXE][64];
+    Tmpl<LK_MAXE> T; T.s = lds_tmpl;
+    Offs o = {0, 0, 0, 0};
+    double Gi[4];
     double c0 = 0.0, c1 = 0.0;
-    for (int it = 0; it < iterations; it++) {
-        const double f0 = dy + c0, f1 = dx + c1;
-        const double r0 = pf0 + f0, r1 = pf1 + f1;
-        if (!lies_in(H, W, r0, r1)) return false;
-        Offs no = get_offsets(p0, p1, r0, r1, window, H, W);
-        if (no.up != o.up || no.down != o.down || no.left != o.left || no.right != o.right) {
+    // it = -1 is the set-up of lucas_kanade.jl:44-52 (window geometry at the integer position, spatial gradient,
+    // template); inside the iteration the same code runs again whenever the clipped window changes (:60-66).
+    // One site for both keeps the kernel small enough for the instruction cache.
+    for (int it = -1; it < iterations; it++) {
+        double r0 = pf0, r1 = pf1;
+        if (it >= 0) {
+            const double f0 = dy + c0, f1 = dx + c1;
+            r0 = pf0 + f0; r1 = pf1 + f1;
+            if (!lies_in(H, W, r0, r1)) return false;
+        }
+        const Offs no = get_offsets(p0, p1, r0, r1, window, H, W);
+        if (it < 0 || no.up != o.up || no.down != o.down || no.left != o.left || no.right != o.right) {
             o = no;
-            min_eig = spatial_gradient(first, p0, p1, o, Gi);
+            const double min_eig = spatial_gradient(first, p0, p1, o, Gi);
+            LKT(1);
             if (min_eig < eig_thr) return false;
             if (cached) load_template(T, first, p0, p1, o);
+            LKT(2);
         }
+        if (it < 0) continue;
         // prepare_linear_system (lucas_kanade.jl:159-173), wave order
         double ay = 0.0, ax = 0.0;
-        if (cached) {
+        // Footprint strictly inside the image (always, except when r0 + down == H or r1 + right == W exactly):
+        // element (p, q) reads rows iy0+dp-1, iy0+dp of columns ix0+dq-1, ix0+dq, i.e. a fixed offset from
+        // the wave-uniform window origin; floor(r0 + dp) == floor(r0) + dp (and where rounding makes the left side
+        // one larger, fy == 1 selects the same samples), so the results equal bilinear()'s bit for bit.
+        const double fr0 = floor(r0), fr1 = floor(r1);
+        const int iy0 = (int)fr0, ix0 = (int)fr1;
+        if (cached && iy0 - o.up >= 1 && iy0 + o.down <= H - 1 && ix0 - o.left >= 1 && ix0 + o.right <= W - 1) {
+            // Two phases so that every footprint load of the iteration is in flight before the first one is used
+            // (k < kmax is wave-uniform; slots past the window hold a zero template and re-read element (0, 0)).
+            // bilinear(): rows iy-1, iy of columns ix-1, ix -> two 16-byte loads.
+            D2 c0v[LK_MAXE], c1v[LK_MAXE];
+            const char *wbase = (const char *)(second.L + ((size_t)(iy0 - o.up - 1) + (size_t)(ix0 - o.left - 1) * pitch));
 #pragma unroll
             for (int k = 0; k < LK_MAXE; k++)
-                if (lane + 64 * k < T.ne) {
-                    const double dI = T.A[k] - bilinear(second.L, H, W, pitch, r0 + T.dp[k], r1 + T.dq[k]);
-                    ay += dI * T.Iy[k];
-                    ax += dI * T.Ix[k];
+                if (k < T.kmax) {
+                    const char *ptr = wbase + (unsigned)((T.pq[k] & 0xffff) + (T.pq[k] >> 16) * pitch) * 8u;
+                    c0v[k] = *(const D2 *)ptr; c1v[k] = *(const D2 *)(ptr + (size_t)pitch * 8);
+                }
+#pragma unroll
+            for (int k = 0; k < LK_MAXE; k++)
+                if (k < T.kmax) {
+                    const double dp = (double)((T.pq[k] & 0xffff) - o.up), dq = (double)((T.pq[k] >> 16) - o.left);
+                    const double fy = (r0 + dp) - (fr0 + dp), fx = (r1 + dq) - (fr1 + dq);
+                    const double t0 = (1 - fx) * c0v[k].a + fx * c1v[k].a;
+                    const double t1 = (1 - fx) * c0v[k].b + fx * c1v[k].b;
+                    const double dI = T.s[0][k][lane] - ((1 - fy) * t0 + fy * t1);
+                    ay += dI * T.s[1][k][lane];
+                    ax += dI * T.s[2][k][lane];
                 }
         } else {
             const int P = o.up + o.down + 1, Q = o.left + o.right + 1, NE = P * Q;
@@ -208,11 +272,13 @@ __device__ bool lk_level(const LevelView &first, const LevelView &second, int le
                 ax += dI * first.Ix[a];
             }
         }
+        LKT(3);
         ay = wave_sum(ay); ax = wave_sum(ax);
         const double fl0 = Gi[0] * ay + Gi[2] * ax, fl1 = Gi[1] * ay + Gi[3] * ax;
         if (fabs(fl0) < eps && fabs(fl1) < eps) break;
         c0 += fl0; c1 += fl1;
         if (!lies_in(H, W, r0 + fl0, r1 + fl1)) return false;
+        LKT(4);
     }
     dy += c0; dx += c1;
     if (level > 1) { dy *= 2.0; dx *= 2.0; }
@@ -228,32 +294,54 @@ __device__ __forceinline__ LevelView shifted(const LevelView &v, size_t off)
     return r;
 }
 
-// offP / offC: plane offset (doubles) of this point's image inside a pyramid batch (0 for single pyramids)
+// offP / offC: plane offset (doubles) of this point's image inside a pyramid batch (0 for single pyramids).
+// The forward levels and the backward pass run through ONE inlined copy of lk_level (a loop over passes with the
+// roles of the two pyramids swapped for the last one): the tracking kernels are a few KB instead of ~100 KB.
+template <int LK_MAXE>
 __device__ __forceinline__ bool fb_point(const PyrView &prev, const PyrView &cur, double py, double px, double dy, double dx,
                                          int pyramid_levels, int window, int iterations, double eig_thr, double eps,
                                          double max_distance, double &ny, double &nx, size_t offP = 0, size_t offC = 0)
 {
-    bool ok = true;
-    for (int level = pyramid_levels + 1; level >= 1 && ok; level--)
-        ok = lk_level(shifted(prev.lv[level - 1], offP), shifted(cur.lv[level - 1], offC), level, py, px, dy, dx, window, iterations, eig_thr, eps);
-    if (!ok) return false;
-    ny = py + dy; nx = px + dx;                           // tracker.jl:41-42
-    double by = -dy * 1.0, bx = -dx * 1.0;                // back_displacement, scale = 1/2^0
-    // backward: pyramid_levels = 0, default eps 1e-2 (tracker.jl:34,51-57)
-    ok = lk_level(shifted(cur.lv[0], offC), shifted(prev.lv[0], offP), 1, ny, nx, by, bx, window, iterations, eig_thr, 1e-2);
-    if (!ok) return false;
-    const double b0 = ny + by, b1 = nx + bx;
+    double qy = py, qx = px, cy = dy, cx = dx;
+    for (int k = 0; k <= pyramid_levels + 1; k++) {
+        const bool back = k == pyramid_levels + 1;
+        const int level = back ? 1 : pyramid_levels + 1 - k;
+        if (back) {
+            ny = py + cy; nx = px + cx;                       // tracker.jl:41-42
+            qy = ny; qx = nx;
+            cy = -cy * 1.0; cx = -cx * 1.0;                   // back_displacement, scale = 1/2^0
+        }
+        // backward: pyramid_levels = 0, default eps 1e-2 (tracker.jl:34,51-57)
+        const PyrView *pf = back ? &cur : &prev, *ps = back ? &prev : &cur;
+        const bool ok = lk_level<LK_MAXE>(shifted(pf->lv[level - 1], back ? offC : offP), shifted(ps->lv[level - 1], back ? offP : offC),
+                                          level, qy, qx, cy, cx, window, iterations, eig_thr, back ? 1e-2 : eps);
+        if (!ok) return false;
+    }
+    const double b0 = ny + cy, b1 = nx + cx;
     const double d0 = py - b0, d1 = px - b1;
     return !(sqrt(d0 * d0 + d1 * d1) >= max_distance);
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8) and every XCD has its own L2.
+// Keypoint lists are spatially ordered (grid cells, row-major), and neighbouring points share cache lines of
+// their windows: give each XCD one contiguous eighth of the list instead of every eighth point.
+#define LK_XCDS 8
+__device__ __forceinline__ int xcd_point(int n)
+{
+    const int per = (n + LK_XCDS - 1) / LK_XCDS;
+    return (int)(blockIdx.x % LK_XCDS) * per + (int)(blockIdx.x / LK_XCDS);
+}
+static inline unsigned lk_grid(int n) { return (unsigned)((n + LK_XCDS - 1) / LK_XCDS) * LK_XCDS; }
+
+template <int LK_MAXE>
 __global__ __launch_bounds__(64) void k_fb_track(LKArgs A)
 {
-    const int i = blockIdx.x;
+    const int i = xcd_point(A.n);
+    if (i >= A.n) return;
     const double py = A.pts[2 * i], px = A.pts[2 * i + 1];
     const double dy = A.disp0 ? A.disp0[2 * i] : 0.0, dx = A.disp0 ? A.disp0[2 * i + 1] : 0.0;
     double ny = nan(""), nx = nan("");
-    const bool ok = fb_point(A.prev, A.cur, py, px, dy, dx, A.pyramid_levels, A.window, A.iterations, A.eig_thr, A.eps,
+    const bool ok = fb_point<LK_MAXE>(A.prev, A.cur, py, px, dy, dx, A.pyramid_levels, A.window, A.iterations, A.eig_thr, A.eps,
                              A.max_distance, ny, nx);
     if ((threadIdx.x & 63) == 0) {
         A.out[2 * i] = ny; A.out[2 * i + 1] = nx;
@@ -273,21 +361,29 @@ struct FlowArgs {
     const int *img;            // batched call: image index of each point inside the pyramid batches (nullptr: single pyramids)
     size_t zs_from, zs_to;     // batch strides (doubles) of the from / to pyramids
 };
+template <int LK_MAXE>
 __global__ __launch_bounds__(64) void k_flow_match(FlowArgs F)
 {
     const LKArgs &A = F.lk;
-    const int i = blockIdx.x;
+    const int i = xcd_point(A.n);
+    if (i >= A.n) return;
+    LKT_BEGIN;
     const double py = A.pts[2 * i], px = A.pts[2 * i + 1];
     double ny = nan(""), nx = nan("");
     bool ok = false;
     const size_t zi = F.img ? (size_t)F.img[i] : 0;
     const size_t offP = zi * F.zs_from, offC = zi * F.zs_to;
-    if (F.is3d[i]) {
-        const double scale = 1.0 / (double)(1 << F.levels3d);
-        const double dy = scale * (F.proj[2 * i] - py), dx = scale * (F.proj[2 * i + 1] - px);      // map_manager.jl:494,504
-        ok = fb_point(A.prev, A.cur, py, px, dy, dx, F.levels3d, A.window, A.iterations, A.eig_thr, A.eps, A.max_distance, ny, nx, offP, offC);
+    // attempt 0: 3-D point with its projected prior; attempt 1: no prior, all levels (one inlined fb_point)
+    for (int att = F.is3d[i] ? 0 : 1; att < 2 && !ok; att++) {
+        double dy = 0.0, dx = 0.0;
+        if (att == 0) {
+            const double scale = 1.0 / (double)(1 << F.levels3d);
+            dy = scale * (F.proj[2 * i] - py); dx = scale * (F.proj[2 * i + 1] - px);                // map_manager.jl:494,504
+        }
+        ok = fb_point<LK_MAXE>(A.prev, A.cur, py, px, dy, dx, att == 0 ? F.levels3d : A.pyramid_levels, A.window, A.iterations, A.eig_thr, A.eps,
+                               A.max_distance, ny, nx, offP, offC);
     }
-    if (!ok) ok = fb_point(A.prev, A.cur, py, px, 0.0, 0.0, A.pyramid_levels, A.window, A.iterations, A.eig_thr, A.eps, A.max_distance, ny, nx, offP, offC);
+    LKT(0);
     if ((threadIdx.x & 63) == 0) {
         A.out[2 * i] = ok ? ny : nan(""); A.out[2 * i + 1] = ok ? nx : nan("");
         A.status[i] = ok ? 1 : 0;
@@ -295,6 +391,7 @@ __global__ __launch_bounds__(64) void k_flow_match(FlowArgs F)
 }
 
 static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+#define LK_STAGE_MIN_POINTS 4096
 
 // shared host path.  Keypoint lists are tiny (16-33 B per point): instead of staging
 // them through HBM (H2D copy -> kernel -> D2H copy: two extra dependent DMA hops per
@@ -316,6 +413,16 @@ static int run_tracking(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr *cur
     if (aux_yx) memcpy(h + pb, aux_yx, (size_t)n * 16);
     if (is3d) memcpy(h + 2 * pb, is3d, (size_t)n);
     if (img_index) memcpy(h + 2 * pb + sb, img_index, (size_t)n * 4);
+    // Large batches: tens of thousands of 8-byte reads and writes over PCIe (every wave starts with dependent
+    // reads of its point and ends with three small stores) are slower than one DMA of the whole block each way.
+    const bool staged = n >= LK_STAGE_MIN_POINTS;
+    if (staged) {
+        void *dbuf;
+        rc = slam_scratch(ctx, in_b + out_b, &dbuf);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(dbuf, h, in_b, hipMemcpyHostToDevice, ctx->stream));
+        d = (char *)dbuf;
+    }
     FlowArgs F;
     LKArgs &A = F.lk;
     A.prev = prev->view; A.cur = cur->view;
@@ -326,9 +433,18 @@ static int run_tracking(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr *cur
     F.is3d = (const uint8_t *)(d + 2 * pb); F.proj = (const double *)(d + pb); F.levels3d = levels3d;
     F.img = img_index ? (const int *)(d + 2 * pb + sb) : nullptr; F.zs_from = prev->zstride; F.zs_to = cur->zstride;
     { ProfScope span(ctx, "fb_track");
-      if (flow) hipLaunchKernelGGL(k_flow_match, dim3(n), dim3(64), 0, ctx->stream, F);
-      else hipLaunchKernelGGL(k_fb_track, dim3(n), dim3(64), 0, ctx->stream, A); }
+      const int ne = (2 * window + 1) * (2 * window + 1);
+      if (flow) {
+          if (ne <= 192) hipLaunchKernelGGL(k_flow_match<3>, dim3(lk_grid(n)), dim3(64), 0, ctx->stream, F);
+          else if (ne <= 384) hipLaunchKernelGGL(k_flow_match<6>, dim3(lk_grid(n)), dim3(64), 0, ctx->stream, F);
+          else hipLaunchKernelGGL(k_flow_match<9>, dim3(lk_grid(n)), dim3(64), 0, ctx->stream, F);
+      } else {
+          if (ne <= 192) hipLaunchKernelGGL(k_fb_track<3>, dim3(lk_grid(n)), dim3(64), 0, ctx->stream, A);
+          else if (ne <= 384) hipLaunchKernelGGL(k_fb_track<6>, dim3(lk_grid(n)), dim3(64), 0, ctx->stream, A);
+          else hipLaunchKernelGGL(k_fb_track<9>, dim3(lk_grid(n)), dim3(64), 0, ctx->stream, A);
+      } }
     HIP_TRY(ctx, hipGetLastError());
+    if (staged) HIP_TRY(ctx, hipMemcpyAsync(h + in_b, d + in_b, out_b, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out_yx, h + in_b, (size_t)n * 16);
     memcpy(status, h + in_b + pb, (size_t)n);
