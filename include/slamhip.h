@@ -184,6 +184,21 @@ int slam_flow_match_batch(slam_ctx *ctx, const slam_pyr *from0, const slam_pyr *
                           double eig_thr, double eps, double max_distance, double *out_yx, uint8_t *status);
 
 /* ---- bundle adjustment ------------------------------------------------------ */
+/* Array-level body of triangulate_stereo! (parallax == NULL: every gate applies, src/mapper.jl:142-183) and
+ * triangulate_temporal! (a gate removes the observation only when parallax[i] > min_parallax, :185-262), for n
+ * keypoints in one launch: DLT triangulation from the two undistorted pixels (RecoverPose.triangulate, :162,242),
+ * division by the 4th component, depth gates in both cameras (min_depth = 0.1), reprojection gates against
+ * max_error in both images.  P1, P2 (projection matrices), T21 (camera 1 -> camera 2: right_camera.Ti0 or
+ * inv(rel_pose)): 4x4 column-major as Julia SMatrix{4,4}; cam = (fx, fy, cx, cy); pixels (y, x).
+ * out_xyz[3 i..]: the point in camera-1 coordinates (the caller applies project_camera_to_world);
+ * status[i] = 1: update the map point, 0: remove the keypoint / observation. */
+int slam_triangulate(slam_ctx *ctx, const double *P1, const double *P2, const double *T21,
+                     const double *cam1, const double *cam2,
+                     const double *px1_yx, const double *px2_yx, int n,
+                     double max_error, double min_depth,
+                     const double *parallax, double min_parallax,
+                     double *out_xyz, uint8_t *status);
+
 /* bundle_adjustment!(cache::LocalBACache, camera; iterations, repr_eps) --
  * src/bundle_adjustment.jl:1-111 on the flat arrays of src/estimator.jl:16-40:
  * theta = [6P (RotZYX t1,t2,t3, tx,ty,tz) ; 3M], pixels (y,x) 2 x O, 1-based ids.

@@ -27,7 +27,7 @@ u64p = C.POINTER(C.c_uint64)
 
 def build(force=False):
     so = os.path.join(_HERE, "libslam_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orc_image.c", "orc_lk.c", "orc_ba.c", "slam_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_image.c", "orc_lk.c", "orc_ba.c", "orc_tri.c", "slam_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libslam_oracle.so"])
     return so
@@ -293,3 +293,24 @@ def pnp_ba(cam, pose_cw, pixels_yx, points_xyz, iters_fast=5, iterations=10, dep
                      _p(px), _p(pts), n, iters_fast, iterations, C.c_double(depth_eps), C.c_double(repr_eps),
                      _p(out), C.byref(e0), C.byref(e1), _p(outl, u8p), C.byref(no))
     return np.array(out), e0.value, e1.value, outl.astype(bool), no.value
+
+
+def triangulate(P1, P2, T21, cam1, cam2, px1_yx, px2_yx, max_error, min_depth=0.1, parallax=None, min_parallax=20.0):
+    """Array-level body of triangulate_stereo! (parallax=None) / triangulate_temporal! (mapper.jl:142-262).
+    P1, P2, T21: 4x4; cam = (fx, fy, cx, cy); pixels (n, 2) (y, x).  Returns (xyz (n, 3) in camera-1 coordinates, status)."""
+    P1 = np.asfortranarray(P1, dtype=np.float64); P2 = np.asfortranarray(P2, dtype=np.float64); T = np.asfortranarray(T21, dtype=np.float64)
+    c1 = np.ascontiguousarray(cam1, dtype=np.float64); c2 = np.ascontiguousarray(cam2, dtype=np.float64)
+    a = np.ascontiguousarray(px1_yx, dtype=np.float64).reshape(-1, 2); b = np.ascontiguousarray(px2_yx, dtype=np.float64).reshape(-1, 2)
+    n = len(a)
+    out = np.zeros((n, 3)); st = np.zeros(n, dtype=np.uint8)
+    par = None if parallax is None else np.ascontiguousarray(parallax, dtype=np.float64)
+    lib().orc_triangulate(_p(P1), _p(P2), _p(T), _p(c1), _p(c2), _p(a), _p(b), n, C.c_double(max_error), C.c_double(min_depth),
+                          _p(par) if par is not None else None, C.c_double(min_parallax), _p(out), _p(st, u8p))
+    return out, st.astype(bool)
+
+
+def sym4_min_eigvec(S):
+    S = np.array(S, dtype=np.float64, order="C").copy()
+    v = np.zeros(4)
+    lib().orc_sym4_min_eigvec(_p(S), _p(v))
+    return v

@@ -168,6 +168,15 @@ int  orc_pnp_ba(double fx, double fy, double cx, double cy, const double pose_cw
                 double depth_eps, double repr_eps, double out_pose[16],
                 double *err_init, double *err_final, uint8_t *outliers, int *n_outliers);
 
+/* ---- two-view triangulation + gating (mapper.jl:142-262; RecoverPose.triangulate restated) -- orc_tri.c ---- */
+void orc_sym4_min_eigvec(double S[16], double v[4]);
+int  orc_triangulate_point(const double *P1, const double *P2, const double *T21, const double *cam1, const double *cam2,
+                           const double *px1_yx, const double *px2_yx, double max_error, double min_depth,
+                           int gate_always, double parallax, double min_parallax, double *xyz);
+int  orc_triangulate(const double *P1, const double *P2, const double *T21, const double *cam1, const double *cam2,
+                     const double *px1_yx, const double *px2_yx, int n, double max_error, double min_depth,
+                     const double *parallax, double min_parallax, double *out_xyz, unsigned char *status);
+
 #ifdef __cplusplus
 }
 #endif

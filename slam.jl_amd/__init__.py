@@ -13,3 +13,4 @@ from .extractor import Extractor, detect, detect_batch, describe, brief_pattern 
 from .optical_flow import (LKPyramid, LucasKanade, update_, copy_, deepcopy, has_gradients, fb_tracking_,  # noqa: F401
                            optical_flow_matching, PyramidBatch, optical_flow_matching_batch)
 from .bundle_adjustment import LocalBACache, bundle_adjustment_, pnp_bundle_adjustment  # noqa: F401
+from .triangulation import triangulate, projection_matrices  # noqa: F401

@@ -13,6 +13,7 @@
 #define DET_THREADS 256
 #define DET_MAXCAND 512
 #define DET_MAXTAPS 41
+#define DET_MAXR 64                // disk radius of the avoidance mask (extractor radius, SLAM.jl:158: 17)
 
 struct DetectArgs {
     const double *img; int H, W, pitch;
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     __shared__ double s_rv[DET_THREADS / 64];
     __shared__ int s_ri[DET_THREADS / 64];
     __shared__ int s_best;
+    __shared__ int s_lim[DET_MAXR + 1];
 
     if (h <= 0 || w <= 0 || A.k <= 0) { if (tid == 0) A.cell_cnt[cell] = 0; return; }
 
@@ -84,6 +86,15 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         const int mh = h + 2 * hw, mw = w + 2 * hw;
         const int r = A.radius;
         if (tid == 0) s_ncand = 0;
+        // ImageDraw's disk test ((dy/r)^2 + (dx/r)^2 < 1, f64) as a table: s_lim[|dy|] = largest |dx| inside the
+        // disk (-1: none).  Same operations on the same operands as the per-pixel test, evaluated once per cell
+        // instead of two f64 divisions per (pixel, keypoint) pair.
+        if (tid <= r) {
+            const double a = (double)tid / (double)r;
+            int lim = -1;
+            for (int dx = 0; dx <= r; dx++) { const double b = (double)dx / (double)r; if (a * a + b * b < 1) lim = dx; else break; }
+            s_lim[tid] = lim;
+        }
         __syncthreads();
         // candidate keypoints: disk (+halo) touches the clamped tile region
         const int ylo = clampi(y0 - hw, 0, H - 1) + 1, yhi = clampi(y0 + h - 1 + hw, 0, H - 1) + 1; // 1-based
@@ -107,18 +118,14 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
             unsigned char m = 1;
             if (!overflow) {
                 for (int c = 0; c < ncand; c++) {
-                    int dy = yy - s_cand[2 * c], dx = xx - s_cand[2 * c + 1];
-                    if (dy < -r || dy > r || dx < -r || dx > r) continue;
-                    double a = (double)dy / (double)r, b = (double)dx / (double)r;
-                    if (a * a + b * b < 1) { m = 0; break; }
+                    const int dy = abs(yy - s_cand[2 * c]), dx = abs(xx - s_cand[2 * c + 1]);
+                    if (dy <= r && dx <= s_lim[dy]) { m = 0; break; }
                 }
             } else {
                 for (int c = 0; c < A.n_cur; c++) {
                     long py = (long)rint(A.cur[2 * c]), px = (long)rint(A.cur[2 * c + 1]);
-                    long dy = yy - py, dx = xx - px;
-                    if (dy < -r || dy > r || dx < -r || dx > r) continue;
-                    double a = (double)dy / (double)r, b = (double)dx / (double)r;
-                    if (a * a + b * b < 1) { m = 0; break; }
+                    const long dy = labs(yy - py), dx = labs(xx - px);
+                    if (dy <= r && dx <= s_lim[dy]) { m = 0; break; }
                 }
             }
             m0[i] = m;
@@ -284,7 +291,7 @@ int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, int p
                        int max_points, int radius, int grid_rows, int grid_cols, int cell_size,
                        double sigma_mask, double min_response, int64_t *out_rc, int cap, int *n_out)
 {
-    ARG_TRY(ctx, H > 0 && W > 0 && grid_rows > 0 && grid_cols > 0 && cell_size >= 8 && radius > 0 && n_out != nullptr);
+    ARG_TRY(ctx, H > 0 && W > 0 && grid_rows > 0 && grid_cols > 0 && cell_size >= 8 && radius > 0 && radius <= DET_MAXR && n_out != nullptr);
     ARG_TRY(ctx, n_cur >= 0 && (n_cur == 0 || cur_yx != nullptr));
     *n_out = 0;
     if (n_cur >= max_points) return SLAM_OK;                      // extractor.jl:64
@@ -374,7 +381,7 @@ extern "C" int slam_detect_batch(slam_ctx *ctx, const slam_pyr *pyr0, int S, con
 {
     ARG_TRY(ctx, ctx != nullptr && pyr0 != nullptr && S >= 1 && S <= 32 && cur_off != nullptr && out_off != nullptr);
     ARG_TRY(ctx, pyr0->batch_index == 0 && pyr0->batch_size == S);
-    ARG_TRY(ctx, grid_rows > 0 && grid_cols > 0 && cell_size >= 8 && radius > 0 && cap >= 0 && (cap == 0 || out_rc != nullptr));
+    ARG_TRY(ctx, grid_rows > 0 && grid_cols > 0 && cell_size >= 8 && radius > 0 && radius <= DET_MAXR && cap >= 0 && (cap == 0 || out_rc != nullptr));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int n_cells = grid_rows * grid_cols, n_tot = cur_off[S];
     ARG_TRY(ctx, cur_off[0] == 0 && n_tot >= 0 && (n_tot == 0 || cur_yx != nullptr));

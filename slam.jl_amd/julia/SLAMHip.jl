@@ -194,6 +194,26 @@ function hip_pnp_bundle_adjustment(camera::Camera, pose::SMatrix{4, 4, Float64},
     SMatrix{4, 4, Float64}(pout), e0[], e1[], Bool[o != 0 for o in outl[1:n]], Int(no[])
 end
 
+# Array-level body of triangulate_stereo! / triangulate_temporal! (mapper.jl:142-262): the per-keypoint
+# `triangulate` + gates for a whole keypoint list in one launch.  Not bound by activate!: the reference interleaves
+# map surgery with the per-keypoint arithmetic, so a maintainer calls this once per key-frame from a vectorised
+# triangulate_stereo! (collect the candidate keypoints, call, then apply update_mappoint! / remove_* from `status`).
+# `parallax = nothing`: stereo semantics; otherwise per-keypoint parallax values (temporal semantics).
+function hip_triangulate(cam1::Camera, cam2::Camera, P1::SMatrix{4, 4, Float64}, P2::SMatrix{4, 4, Float64}, T21::SMatrix{4, 4, Float64},
+        px1, px2, max_error; min_depth = 0.1, parallax = nothing, min_parallax = 20.0)
+    n = length(px1)
+    a = collect(reinterpret(Float64, collect(px1))); b = collect(reinterpret(Float64, collect(px2)))   # (y, x) pairs
+    p1 = Vector{Float64}(vec(P1)); p2 = Vector{Float64}(vec(P2)); t = Vector{Float64}(vec(T21))
+    c1 = Float64[cam1.fx, cam1.fy, cam1.cx, cam1.cy]; c2 = Float64[cam2.fx, cam2.fy, cam2.cx, cam2.cy]
+    par = parallax === nothing ? C_NULL : pointer(parallax)
+    out = Vector{Float64}(undef, 3 * max(n, 1)); st = Vector{UInt8}(undef, max(n, 1))
+    GC.@preserve a b p1 p2 t c1 c2 parallax out st check(ccall((:slam_triangulate, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint,
+         Cdouble, Cdouble, Ptr{Float64}, Cdouble, Ptr{Float64}, Ptr{UInt8}),
+        ctx(), p1, p2, t, c1, c2, a, b, n, Float64(max_error), Float64(min_depth), par, Float64(min_parallax), out, st))
+    [SVector{3, Float64}(out[3i - 2], out[3i - 1], out[3i]) for i in 1:n], Bool[s != 0 for s in st[1:n]]
+end
+
 """
     activate!(libpath)
 

@@ -139,3 +139,34 @@ def pnp_scene(n=300, seed=0, cam=KITTI_CAM, H=376, W=1241, noise_px=0.5, outlier
     pose_gt = np.eye(4); pose_gt[:3, :3] = R; pose_gt[:3, 3] = t
     pose0 = np.eye(4); pose0[:3, :3] = rotzyx(ang[0] + 0.01, ang[1] - 0.012, ang[2] + 0.008); pose0[:3, 3] = t + (0.05, -0.04, 0.08)
     return dict(cam=cam, pose0=pose0, pose_gt=pose_gt, pixels_yx=pix, points=Xw, gross_outliers=np.sort(idx))
+
+
+def triangulation_scene(n=500, seed=0, baseline=0.54, noise_px=0.0, n_behind=0, n_gross=0, temporal=False):
+    """Two pinhole views of n points in front of camera 1 (KITTI intrinsics).  stereo: camera 2 = camera 1 shifted
+    by `baseline` along x (T21 = right_camera.Ti0); temporal: a general small rigid motion.  Returns a dict with
+    cam (fx, fy, cx, cy), T21 (4x4), px1 / px2 (n, 2) (y, x), xyz (n, 3) ground truth in camera-1 coordinates and
+    index sets `behind` (points given a pixel pair that triangulates behind the cameras) and `gross`
+    (second-view pixel displaced by 30-60 px)."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(0x7121 + seed)
+    fx, fy, cx, cy = KITTI_CAM
+    X = np.stack([rng.uniform(-12, 12, n), rng.uniform(-3, 3, n), rng.uniform(4, 60, n)], axis=1)
+    T = np.eye(4)
+    if temporal:
+        T[:3, :3] = Rotation.from_euler("ZYX", [0.01, -0.03, 0.005]).as_matrix()
+        T[:3, 3] = [0.3, -0.05, -1.1]
+    else:
+        T[0, 3] = -baseline
+    def proj(P):
+        return np.stack([fy * P[:, 1] / P[:, 2] + cy, fx * P[:, 0] / P[:, 2] + cx], axis=1)
+    X2 = X @ T[:3, :3].T + T[:3, 3]
+    px1 = proj(X) + rng.normal(0, noise_px, (n, 2)) if noise_px else proj(X)
+    px2 = proj(X2) + rng.normal(0, noise_px, (n, 2)) if noise_px else proj(X2)
+    idx = rng.permutation(n)
+    behind, gross = idx[:n_behind], idx[n_behind:n_behind + n_gross]
+    if n_behind:                                  # swap the disparity sign: the rays meet behind the cameras
+        d = px1[behind, 1] - px2[behind, 1]
+        px2[behind, 1] = px1[behind, 1] + d
+    if n_gross:
+        px2[gross, 0] += rng.choice([-1.0, 1.0], n_gross) * rng.uniform(30, 60, n_gross)
+    return dict(cam=(fx, fy, cx, cy), T21=T, px1=px1, px2=px2, xyz=X, behind=behind, gross=gross)

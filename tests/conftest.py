@@ -35,6 +35,13 @@ def slam():
     return slam_jl_amd
 
 
+@pytest.fixture(scope="session")
+def slam_host():
+    """The product package WITHOUT a HIP context: host-side helpers only (CPU tests)."""
+    import slam_jl_amd
+    return slam_jl_amd
+
+
 _TEX = {}
 
 
