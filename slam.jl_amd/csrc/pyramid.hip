@@ -366,6 +366,120 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows(PlaneSet ps, int H, i
     iir_line(io, W, ps_coef(ps, pl) == 0 ? cf.c[0] : cf.c[1], ps_fill0(ps, pl), nrm ? nrm + y : nullptr, P);
 }
 
+// dim-2 pass for batched, bandwidth-bound launches.  The backward sweep needs the forward results of the whole
+// line, which do not fit on chip (64 lines x 1226 samples = 628 KB per wave); k_iir_rows writes them to HBM and
+// reads them back (2 reads + 2 writes per sample).  Here the forward sweep only reads: it keeps its state every
+// CK_B samples (3 doubles per block and line in a scratch buffer), and the backward sweep walks the blocks right to
+// left, re-reads a block's input, recomputes its forward values in registers from the checkpoint (the same
+// operations from the same state: bit-identical), runs the backward recurrence on them and stores once:
+// 2 reads + 1 write per sample for 1.5x the arithmetic, which a bandwidth-bound launch has to spare.
+#define CK_B 32
+__global__ __launch_bounds__(LINE_THREADS) void k_iir_rows_ck(PlaneSet ps, int H, int W, int P, IIRPair cf, double *ck)
+{
+    const int y = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
+    if (y >= H) return;
+    const size_t nlines = (size_t)gridDim.z * gridDim.y * gridDim.x * LINE_THREADS;
+    const size_t lineid = ((size_t)blockIdx.z * gridDim.y + pl) * gridDim.x * LINE_THREADS + y;
+    double *p = ps_plane(ps, pl) + y;
+    const long s = P;
+    const int n = W;
+    const IIRCoef &k = ps_coef(ps, pl) == 0 ? cf.c[0] : cf.c[1];
+    const bool fill0 = ps_fill0(ps, pl);
+    const double a1 = k.a1, a2 = k.a2, a3 = k.a3, scale = k.scale;
+    const double x0 = p[0];
+    const double iminus = fill0 ? 0.0 : x0, iplus = fill0 ? 0.0 : p[(long)(n - 1) * s];
+    const double uminus = iminus / k.inv1masum;
+    const double o0 = ((x0 + a1 * uminus) + a2 * uminus) + a3 * uminus;
+    const double o1 = ((p[s] + a1 * o0) + a2 * uminus) + a3 * uminus;
+    const double o2 = ((p[2 * s] + a1 * o1) + a2 * o0) + a3 * uminus;
+    // ---- pass A: forward over i = 3 .. n-1, read only, block by block (next block prefetched while the current
+    //      one runs); the state before block j >= 1 is its checkpoint.  The last block absorbs the 3 trailing
+    //      samples (n-3 .. n-1), which only the boundary computation needs. ----
+    const int m = n - 6, nb = (m + CK_B - 1) / CK_B;            // the backward sweep needs forward values on [3, n-4]
+    double w3 = o0, w2 = o1, w1 = o2;
+    double cur[CK_B], nxt[CK_B];
+    auto load_x = [&](int j, double *buf) {                     // block j = samples [3 + j CK_B, ...), CK_B of them (clamped reads)
+        const double *q = p + (long)(3 + j * CK_B) * s;
+        const int len = n - (3 + j * CK_B);                     // samples left in the line
+        if (len >= CK_B) {
+#pragma unroll
+            for (int e = 0; e < CK_B; e++) buf[e] = q[(long)e * s];
+        } else {
+#pragma unroll
+            for (int e = 0; e < CK_B; e++) buf[e] = e < len ? q[(long)e * s] : 0.0;
+        }
+    };
+    const int nfull = (n - 3) / CK_B;                           // blocks of pass A that are complete
+    if (nfull > 0) load_x(0, cur);
+    for (int j = 0; j < nfull; j++) {
+        if (j + 1 < nfull) load_x(j + 1, nxt);
+        if (j > 0 && j < nb) { double *c = ck + ((size_t)j * 3) * nlines + lineid; c[0] = w1; c[nlines] = w2; c[2 * nlines] = w3; }
+#pragma unroll
+        for (int e = 0; e < CK_B; e++) { const double t = ((cur[e] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = t; }
+#pragma unroll
+        for (int e = 0; e < CK_B; e++) cur[e] = nxt[e];
+    }
+    {   // remainder (< CK_B samples): its start may still be a checkpoint
+        const int a = 3 + nfull * CK_B;
+        if (nfull > 0 && nfull < nb) { double *c = ck + ((size_t)nfull * 3) * nlines + lineid; c[0] = w1; c[nlines] = w2; c[2 * nlines] = w3; }
+        for (int i = a; i < n; i++) { const double t = ((p[(long)i * s] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = t; }
+    }
+    // ---- Triggs-Sdika right boundary (as iir_line) ----
+    const double uplus = iplus / k.inv1masum, vplus = uplus / k.inv1mbsum;
+    const double d0 = w1 - uplus, d1 = w2 - uplus, d2 = w3 - uplus;
+    const double vr0 = ((k.M[0] * d0 + k.M[1] * d1) + k.M[2] * d2) + vplus;
+    const double vr1 = ((k.M[3] * d0 + k.M[4] * d1) + k.M[5] * d2) + vplus;
+    const double vr2 = ((k.M[6] * d0 + k.M[7] * d1) + k.M[8] * d2) + vplus;
+    const double vA = vr0;
+    const double vB = ((w2 + a1 * vA) + a2 * vr1) + a3 * vr2;
+    const double vC = ((w3 + a1 * vB) + a2 * vA) + a3 * vr1;
+    double v1 = vC, v2 = vB, v3 = vA;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // own checkpoints visible
+    p[(long)(n - 1) * s] = vA * scale; p[(long)(n - 2) * s] = vB * scale; p[(long)(n - 3) * s] = vC * scale;
+    // ---- pass B: blocks right to left; block j covers i in [3 + j CK_B, 3 + min((j+1) CK_B, m)) ----
+    double f1n = 0, f2n = 0, f3n = 0, f1 = 0, f2 = 0, f3 = 0;
+    auto load_ck = [&](int j, double &g1, double &g2, double &g3) {
+        if (j > 0) { const double *c = ck + ((size_t)j * 3) * nlines + lineid; g1 = c[0]; g2 = c[nlines]; g3 = c[2 * nlines]; }
+        else { g1 = o2; g2 = o1; g3 = o0; }
+    };
+    if (nb > 0) {
+        // rightmost block: possibly partial (1 .. CK_B samples), predicated
+        const int j = nb - 1, a = 3 + j * CK_B, len = m - j * CK_B;
+        load_x(j, cur); load_ck(j, f1, f2, f3);
+        if (j > 0) { load_x(j - 1, nxt); load_ck(j - 1, f1n, f2n, f3n); }
+#pragma unroll
+        for (int e = 0; e < CK_B; e++)
+            if (e < len) { const double t = ((cur[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = t; cur[e] = t; }
+#pragma unroll
+        for (int e = CK_B - 1; e >= 0; e--)
+            if (e < len) { const double t = ((cur[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = t; cur[e] = t * scale; }
+        double *q = p + (long)a * s;
+#pragma unroll
+        for (int e = 0; e < CK_B; e++) if (e < len) q[(long)e * s] = cur[e];
+#pragma unroll
+        for (int e = 0; e < CK_B; e++) cur[e] = nxt[e];
+        f1 = f1n; f2 = f2n; f3 = f3n;
+    }
+    for (int j = nb - 2; j >= 0; j--) {                          // full blocks: straight-line code
+        if (j > 0) { load_x(j - 1, nxt); load_ck(j - 1, f1n, f2n, f3n); }
+#pragma unroll
+        for (int e = 0; e < CK_B; e++) { const double t = ((cur[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = t; cur[e] = t; }
+#pragma unroll
+        for (int e = CK_B - 1; e >= 0; e--) { const double t = ((cur[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = t; cur[e] = t * scale; }
+        double *q = p + (long)(3 + j * CK_B) * s;
+#pragma unroll
+        for (int e = 0; e < CK_B; e++) q[(long)e * s] = cur[e];
+#pragma unroll
+        for (int e = 0; e < CK_B; e++) cur[e] = nxt[e];
+        f1 = f1n; f2 = f2n; f3 = f3n;
+    }
+    {   // i = 2, 1, 0: forward values o2, o1, o0
+        double t = ((o2 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = t; p[2 * s] = t * scale;
+        t = ((o1 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = t; p[s] = t * scale;
+        t = ((o0 + a1 * v1) + a2 * v2) + a3 * v3; p[0] = t * scale;
+    }
+}
+
 // integral_image!, lucas_kanade.jl:131-138: cumsum along dim 1 ...
 template <int NB>
 __global__ __launch_bounds__(LINE_THREADS) void k_cum_cols(PlaneSet ps, int H, int W, int P)
@@ -658,6 +772,11 @@ __global__ __launch_bounds__(256) void k_fill(double *p, size_t n, double v)
     if (i < n) p[i] = v;
 }
 
+static inline size_t ck_min_bytes()
+{
+    const char *e = getenv("SLAMHIP_CK_MIN_MB");          // test / tuning hook; read per build (graphs are keyed on it below)
+    return e ? (size_t)atol(e) << 20 : (size_t)96 << 20;
+}
 static inline dim3 lines_grid(int nlines, int nplanes, int S = 1) { return dim3((nlines + LINE_THREADS - 1) / LINE_THREADS, nplanes, S); }
 
 static void make_view(slam_pyr *p)
@@ -767,8 +886,12 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         }
         if (S == 1) hipLaunchKernelGGL(k_iir_cols<3>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
         else hipLaunchKernelGGL(k_iir_cols<2>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
+        // bandwidth-bound launches (many images x a large level) take the checkpointed row kernel (2R+1W instead of 2R+2W)
+        const bool ck_rows = p->ck != nullptr && mode != 0 && W >= 64 && (size_t)S * np * H * W * 8 >= ck_min_bytes();
         if (spans) { ProfScope span(ctx, "k_iir_rows");
-            hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf); }
+            if (ck_rows) hipLaunchKernelGGL(k_iir_rows_ck, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf, p->ck);
+            else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf); }
+        else if (ck_rows) hipLaunchKernelGGL(k_iir_rows_ck, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf, p->ck);
         else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf);
         if (forked) { (void)hipEventRecord(p->ev_fork[l], st); (void)hipStreamWaitEvent(aux, p->ev_fork[l], 0); }
         if (has_next)
@@ -799,7 +922,8 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma, int
         return SLAM_OK;
     }
     hipGraphExec_t exec = nullptr;
-    for (auto &g : p->graphs) if (g.mode == mode && g.sigma == sigma && g.S == S) exec = g.exec;
+    const size_t ckmin = ck_min_bytes();
+    for (auto &g : p->graphs) if (g.mode == mode && g.sigma == sigma && g.S == S && g.ckmin == ckmin) exec = g.exec;
     if (!exec && !p->graph_failed) {
         if (!p->aux) {
             HIP_TRY(ctx, hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
@@ -815,7 +939,7 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma, int
         if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (graph) (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { (void)hipGetLastError(); p->graph_failed = true; exec = nullptr; }
-        else { slam_pyr::Graph g; g.mode = mode; g.sigma = sigma; g.S = S; g.exec = exec; p->graphs.push_back(g); }
+        else { slam_pyr::Graph g; g.mode = mode; g.sigma = sigma; g.S = S; g.ckmin = ckmin; g.exec = exec; p->graphs.push_back(g); }
     }
     if (exec) HIP_TRY(ctx, hipGraphLaunch(exec, st));
     else launch_build(ctx, p, mode, cf, st, st, false, S);
@@ -855,6 +979,13 @@ static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, 
     if (e != hipSuccess) { delete al; return slam_fail(ctx, SLAM_ERR_HIP, "slam_pyr_create: hipMalloc: %s", hipGetErrorString(e)); }
     (void)hipMemsetAsync(al->base, 0, ((size_t)o * 7 * S + tail) * 8, ctx->stream);   // pitch padding rows are never used; keep them defined
     al->refs = S;
+    double *ckbuf = nullptr;
+    if (S > 1) {   // checkpoint scratch of k_iir_rows_ck: (blocks x 3) doubles per line of the widest launch (level 0, 4 planes)
+        const size_t lines = (size_t)S * 4 * (((size_t)Hs[0] + LINE_THREADS - 1) / LINE_THREADS) * LINE_THREADS;
+        const size_t nbk = ((size_t)Ws[0] + CK_B - 1) / CK_B;
+        if (hipMalloc((void **)&ckbuf, lines * nbk * 3 * 8) != hipSuccess) { (void)hipGetLastError(); ckbuf = nullptr; }
+        al->ck = ckbuf;
+    }
     for (int s = 0; s < S; s++) {
         slam_pyr *p = new slam_pyr();
         p->device = ctx->device; p->levels = levels;
@@ -863,7 +994,7 @@ static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, 
         p->zstride = (size_t)o * 7;
         p->planes = al->base + (size_t)s * p->zstride;
         p->tmp = p->planes + (size_t)o * 6;
-        p->batch_index = s; p->batch_size = S;
+        p->batch_index = s; p->batch_size = S; p->ck = ckbuf;
         make_view(p);
         out[s] = p;
     }
@@ -903,7 +1034,7 @@ int slam_pyr_destroy(slam_pyr *p)
     if (!p) return SLAM_OK;
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
-    if (p->alloc && --p->alloc->refs == 0) { (void)hipFree(p->alloc->base); delete p->alloc; }
+    if (p->alloc && --p->alloc->refs == 0) { (void)hipFree(p->alloc->base); if (p->alloc->ck) (void)hipFree(p->alloc->ck); delete p->alloc; }
     if (p->norm) (void)hipFree(p->norm);
     for (auto &g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->aux) {

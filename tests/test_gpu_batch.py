@@ -59,3 +59,26 @@ def test_batch_flow_match_equals_per_stream(slam, orc, texture):
     assert np.array_equal(new[inv], np.concatenate(ref_new))
     with pytest.raises(slam.SlamHipError):
         slam.optical_flow_matching_batch(a, b, np.full(len(P), S), P, T, R, params)      # stream index out of range
+
+
+def test_checkpointed_row_kernel_is_bit_exact(slam, monkeypatch):
+    """Bandwidth-bound batched launches switch the dim-2 IIR pass to k_iir_rows_ck (forward state checkpoints +
+    recomputation instead of a stored forward plane).  Forced here on a small batch: every plane must stay
+    bit-identical to the single-image kernels (several block counts, incl. a last block of 1 and of 32 samples)."""
+    import torch
+    for (H, W) in ((70, 71), (33, 102), (130, 64 + 6 + 1)):
+        S = 2
+        rng = np.random.default_rng(H * W)
+        imgs = [np.asfortranarray(rng.random((H, W))) for _ in range(S)]
+        dev = [torch.from_numpy(np.ascontiguousarray(im.T)).cuda() for im in imgs]
+        torch.cuda.synchronize()
+        monkeypatch.setenv("SLAMHIP_CK_MIN_MB", "0")
+        batch = slam.PyramidBatch((H, W), levels=1, S=S)
+        batch.update_([d.data_ptr() for d in dev])
+        monkeypatch.delenv("SLAMHIP_CK_MIN_MB")
+        for s in range(S):
+            single = slam.LKPyramid(shape=(H, W), levels=1)
+            slam.update_(single, imgs[s])
+            for name in PLANES:
+                assert np.array_equal(batch.pyramids[s].plane(name, 0), single.plane(name, 0)), (H, W, s, name)
+            assert np.array_equal(batch.pyramids[s].plane("layers", 1), single.plane("layers", 1))
