@@ -3,7 +3,9 @@
 // Replaces detect / get_mask / _shi_tomasi of the reference
 // (src/extractor.jl:24-42, 63-95, 116-122).  One workgroup per grid cell: the
 // cell's pixels, the avoidance-mask halo and every intermediate plane live in
-// LDS; HBM traffic is one read of the image plus the keypoint lists, i.e. the
+// LDS (four cell-sized planes: the separable Sobel and box stages are evaluated
+// per pixel from the 3x3 neighbourhood with exactly the two-stage arithmetic,
+// so no intermediate plane is stored and four workgroups share a CU); HBM traffic is one read of the image plus the keypoint lists, i.e. the
 // algorithmic minimum (8*H*W + 16*(K + n_out) bytes).  Keypoint order and
 // indices are bit-exact with the CPU oracle: every sum runs in the reference's
 // order and the build uses -ffp-contract=off.
@@ -30,23 +32,25 @@ struct DetectArgs {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// 3-tap correlation along y (dir 0) or x (dir 1) with replicate border at the
-// cell edge: acc = 0; acc += v[j]*k[j], j ascending (ImageFiltering order).
-__device__ __forceinline__ void fir3(double *dst, const double *src, int h, int w, int dir,
-                                     double k0, double k1, double k2)
+// Separable 3x3 correlation evaluated at one pixel with the arithmetic of the two-pass form (ImageFiltering:
+// first factor along dim 1 into an intermediate, second factor along dim 2; acc = 0; acc += v[j]*k[j], j ascending;
+// replicate border at the cell edge): the three intermediate values of columns x-1, x, x+1 are recomputed in
+// registers instead of being stored as a plane.
+__device__ __forceinline__ double sep3(const double *src, int h, int w, int y, int x,
+                                       double ky0, double ky1, double ky2, double kx0, double kx1, double kx2)
 {
-    for (int i = threadIdx.x; i < h * w; i += DET_THREADS) {
-        int y = i % h, x = i / h;
-        double a, b, c;
-        if (dir == 0) {
-            a = src[clampi(y - 1, 0, h - 1) + x * h]; b = src[i]; c = src[clampi(y + 1, 0, h - 1) + x * h];
-        } else {
-            a = src[y + clampi(x - 1, 0, w - 1) * h]; b = src[i]; c = src[y + clampi(x + 1, 0, w - 1) * h];
-        }
+    const int ym = clampi(y - 1, 0, h - 1), yp = clampi(y + 1, 0, h - 1);
+    double t[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int xx = clampi(x + j - 1, 0, w - 1);
         double acc = 0.0;
-        acc += a * k0; acc += b * k1; acc += c * k2;
-        dst[i] = acc;
+        acc += src[ym + xx * h] * ky0; acc += src[y + xx * h] * ky1; acc += src[yp + xx * h] * ky2;
+        t[j] = acc;
     }
+    double acc = 0.0;
+    acc += t[0] * kx0; acc += t[1] * kx1; acc += t[2] * kx2;
+    return acc;
 }
 
 __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     const int h = min(H, (cyi + 1) * cs) - y0, w = min(W, (cxi + 1) * cs) - x0;
     const int tid = threadIdx.x;
     const int n = cs * cs;
-    double *bA = lds, *bB = lds + n, *bC = lds + 2 * n, *bD = lds + 3 * n, *bE = lds + 4 * n, *bF = lds + 5 * n;
+    double *bA = lds, *bB = lds + n, *bC = lds + 2 * n, *bD = lds + 3 * n;
     __shared__ int s_ncand, s_cnt;
     __shared__ int s_cand[2 * DET_MAXCAND];
     __shared__ double s_rv[DET_THREADS / 64];
@@ -110,8 +114,8 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         const int ncand = s_ncand;
         const bool overflow = ncand > DET_MAXCAND;
         // raw mask over the halo'd tile (replicate = clamped coordinates) -> bB (as 0/1 doubles)
-        // bB has room for cs*cs doubles only; the halo'd mask is stored as bytes in bF..: use bytes
-        unsigned char *m0 = (unsigned char *)bF;           // (cs+2hw)^2 bytes <= cs*cs*8 for cs >= 8... checked on host
+        // the halo'd raw mask is stored as bytes
+        unsigned char *m0 = (unsigned char *)(lds + 4 * n) - ((mh * mw + 7) & ~7);   // byte mask at the tail of bD (sizes checked on host)
         for (int i = tid; i < mh * mw; i += DET_THREADS) {
             int ty = i % mh, tx = i / mh;
             int yy = clampi(y0 + ty - hw, 0, H - 1) + 1, xx = clampi(x0 + tx - hw, 0, W - 1) + 1; // 1-based
@@ -132,8 +136,8 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         }
         __syncthreads();
         if (A.ntaps > 0) {
-            // dim-1 pass: T(y, tx) = sum_j m0(y+j, tx)*k[j]  -> bB..bE region (h x mw doubles)
-            double *T = bB;                                   // needs h*mw doubles <= 4*cs*cs (checked on host)
+            // dim-1 pass: T(y, tx) = sum_j m0(y+j, tx)*k[j]  -> T (h x mw doubles)
+            double *T = bB;                                   // h*mw doubles: bB, bC and the part of bD below the byte mask (checked on host)
             for (int i = tid; i < h * mw; i += DET_THREADS) {
                 int y = i % h, tx = i / h;
                 double acc = 0.0;
@@ -158,35 +162,29 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     __syncthreads();
 
     // ---- Images.shi_tomasi on the cell view (replicate border at cell edges) -
-    fir3(bB, bA, h, w, 0, -1.0 / 2, 0.0 / 2, 1.0 / 2);      // d/dy
-    fir3(bC, bA, h, w, 0, 1.0 / 4, 2.0 / 4, 1.0 / 4);       // smooth y
-    __syncthreads();
-    fir3(bD, bB, h, w, 1, 1.0 / 4, 2.0 / 4, 1.0 / 4);       // g1 = gradient along dim 1
-    fir3(bE, bC, h, w, 1, -1.0 / 2, 0.0 / 2, 1.0 / 2);      // g2 = gradient along dim 2
-    __syncthreads();
+    // imgradients(cell, KernelFactors.sobel): g1 = (d/dy along dim 1, then (1,2,1)/4 along dim 2),
+    // g2 = ((1,2,1)/4 along dim 1, then d/dx along dim 2); products -> bB, bC, bD
     for (int i = tid; i < h * w; i += DET_THREADS) {
-        double g1 = bD[i], g2 = bE[i];
-        bA[i] = g1 * g1; bB[i] = g1 * g2; bC[i] = g2 * g2;
+        const int y = i % h, x = i / h;
+        const double g1 = sep3(bA, h, w, y, x, -1.0 / 2, 0.0 / 2, 1.0 / 2, 1.0 / 4, 2.0 / 4, 1.0 / 4);
+        const double g2 = sep3(bA, h, w, y, x, 1.0 / 4, 2.0 / 4, 1.0 / 4, -1.0 / 2, 0.0 / 2, 1.0 / 2);
+        bB[i] = g1 * g1; bC[i] = g1 * g2; bD[i] = g2 * g2;
     }
     __syncthreads();
-    fir3(bD, bA, h, w, 0, 1.0 / 3, 1.0 / 3, 1.0 / 3);
-    fir3(bE, bB, h, w, 0, 1.0 / 3, 1.0 / 3, 1.0 / 3);
-    fir3(bF, bC, h, w, 0, 1.0 / 3, 1.0 / 3, 1.0 / 3);
-    __syncthreads();
-    fir3(bA, bD, h, w, 1, 1.0 / 3, 1.0 / 3, 1.0 / 3);
-    fir3(bB, bE, h, w, 1, 1.0 / 3, 1.0 / 3, 1.0 / 3);
-    fir3(bC, bF, h, w, 1, 1.0 / 3, 1.0 / 3, 1.0 / 3);
-    __syncthreads();
-    double *resp = bD;
+    // 3x3 box mean of the products (1/3 x 1/3, two-pass arithmetic) and the min-eigenvalue response -> bA
+    double *resp = bA;
     for (int i = tid; i < h * w; i += DET_THREADS) {
-        double xx = bA[i], xy = bB[i], yy = bC[i];
-        double dd = xx - yy;
+        const int y = i % h, x = i / h;
+        const double xx = sep3(bB, h, w, y, x, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3);
+        const double xy = sep3(bC, h, w, y, x, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3);
+        const double yy = sep3(bD, h, w, y, x, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3);
+        const double dd = xx - yy;
         resp[i] = ((xx + yy) - sqrt(dd * dd + 4 * (xy * xy))) / 2;
     }
     __syncthreads();
 
     // ---- findlocalmaxima: strict, 8-neighbourhood, edges included ------------
-    unsigned char *flag = (unsigned char *)bE;                // 0: no, 1: maximum (candidate), 2: taken
+    unsigned char *flag = (unsigned char *)bB;                // 0: no, 1: maximum (candidate), 2: taken
     for (int i = tid; i < h * w; i += DET_THREADS) {
         int y = i % h, x = i / h;
         double c = resp[i];
@@ -204,7 +202,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     __syncthreads();
 
     // ---- top-k by response (stable: ties keep column-major order) ------------
-    int *sel = (int *)bF;                                     // selected linear indices
+    int *sel = (int *)bC;                                     // selected linear indices
     for (int round = 0; round < A.k; round++) {
         double bv = -INFINITY; int bi = 0x7fffffff;
         for (int i = tid; i < h * w; i += DET_THREADS)
@@ -309,11 +307,13 @@ int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, int p
     }
     const int hw = A.ntaps >> 1;
     const size_t n = (size_t)cell_size * cell_size;
-    // LDS carve-up checks: byte mask in bF, T plane in bB..bE, selected list in bF
-    ARG_TRY(ctx, (size_t)(cell_size + 2 * hw) * (cell_size + 2 * hw) <= n * 8);
-    ARG_TRY(ctx, (size_t)cell_size * (cell_size + 2 * hw) <= 4 * n);
+    // LDS carve-up checks (4 planes of cell_size^2 doubles)
+    {   // byte mask at the tail of the 4th plane, blur intermediate in planes 2..4 below it
+        const size_t mbytes = ((size_t)(cell_size + 2 * hw) * (cell_size + 2 * hw) + 7) & ~(size_t)7;
+        ARG_TRY(ctx, mbytes <= n * 8 && (size_t)cell_size * (cell_size + 2 * hw) * 8 + mbytes <= 3 * n * 8);
+    }
     ARG_TRY(ctx, (size_t)k * sizeof(int) <= n * 8);
-    const size_t lds_bytes = 6 * n * sizeof(double);
+    const size_t lds_bytes = 4 * n * sizeof(double);
     ARG_TRY(ctx, lds_bytes <= 150 * 1024);
 
     // scratch: [cur (2*n_cur doubles)] [cell_cnt (n_cells int, padded)] [cell_out] [out header+pairs]
@@ -404,10 +404,12 @@ extern "C" int slam_detect_batch(slam_ctx *ctx, const slam_pyr *pyr0, int S, con
     }
     const int hw = A.ntaps >> 1;
     const size_t n = (size_t)cell_size * cell_size;
-    ARG_TRY(ctx, (size_t)(cell_size + 2 * hw) * (cell_size + 2 * hw) <= n * 8);
-    ARG_TRY(ctx, (size_t)cell_size * (cell_size + 2 * hw) <= 4 * n);
+    {   // byte mask at the tail of the 4th plane, blur intermediate in planes 2..4 below it
+        const size_t mbytes = ((size_t)(cell_size + 2 * hw) * (cell_size + 2 * hw) + 7) & ~(size_t)7;
+        ARG_TRY(ctx, mbytes <= n * 8 && (size_t)cell_size * (cell_size + 2 * hw) * 8 + mbytes <= 3 * n * 8);
+    }
     ARG_TRY(ctx, (size_t)kmax * sizeof(int) <= n * 8);
-    const size_t lds_bytes = 6 * n * sizeof(double);
+    const size_t lds_bytes = 4 * n * sizeof(double);
     ARG_TRY(ctx, lds_bytes <= 150 * 1024);
 
     // host -> device in one copy: [cur_off (S+1)] [k_s (S)] [cur (2 * n_tot doubles)]
