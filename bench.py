@@ -292,7 +292,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ba", action="store_true", help="skip the BA measurements")
-    ap.add_argument("--streams", type=int, default=16, help="S: independent stereo streams per GPU advancing in lock-step (one batch of S frames per step)")
+    ap.add_argument("--streams", type=int, default=32, help="S: independent stereo streams per GPU advancing in lock-step (one batch of S frames per step)")
     ap.add_argument("--no-tolerance", action="store_true", help="skip the tolerance-mode measurements")
     args = ap.parse_args()
 
@@ -357,12 +357,12 @@ def main():
                                                   "the pyramid build is ~70 % of the device time of a step, this is its largest kernel)"),
         "pyramid_batch_update_serial_us": head["pyramid_batch_update_serial_us"],
     }
-    pmc = os.path.join(ROOT, "profiles", "r01d_pmc_pyramid_batch.json")
+    pmc = os.path.join(ROOT, "profiles", "r01e_pmc_pyramid_batch.json")
     if SHAPE == "kitti05" and os.path.exists(pmc):
         j = json.load(open(pmc))
         if j.get("streams") == S:
             out["roofline"]["traffic"] = j["summary"]["k_iir_rows_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r01d_pmc_pyramid_batch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 corrected)"
+            out["roofline"]["traffic_source"] = "profiles/r01e_pmc_pyramid_batch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 corrected)"
 
     # ---- the same workload as ONE stream (latency view): 3 contexts, pipelined next-frame pyramid ----
     n1 = min(args.steps, 300)
