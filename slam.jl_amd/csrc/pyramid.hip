@@ -480,6 +480,106 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows_ck(PlaneSet ps, int H
     }
 }
 
+// dim-1 pass for bandwidth-bound batched launches: the checkpoint scheme of k_iir_rows_ck on column tiles.  Blocks
+// are 32 rows = two aligned 16-row tiles; the forward sweep saves its state before every block, the backward sweep
+// takes a block's two input tiles through the LDS transpose, recomputes the forward values of the lane's 32 samples
+// in registers, runs the backward recurrence on them and stores the two tiles: 2R+1W instead of 2R+2W.  The next
+// block's tiles are requested as soon as the current ones have gone through the transpose (no extra registers).
+__global__ __launch_bounds__(LINE_THREADS) void k_iir_cols_ck(PlaneSet ps, const double *src0, int H, int W, int P, IIRPair cf, double *ck)
+{
+    if (src0) src0 += (size_t)blockIdx.z * ps.zs;
+    __shared__ __attribute__((aligned(16))) double tile[64 * COL_LS];
+    const int pl = blockIdx.y, lane = threadIdx.x & 63;
+    ColIO<2> io;
+    io.dst = ps_plane(ps, pl); io.src = (pl == 0 && src0) ? src0 : io.dst;
+    io.H = H; io.W = W; io.P = P; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile;
+    const size_t nlines = (size_t)gridDim.z * gridDim.y * gridDim.x * LINE_THREADS;
+    const size_t lineid = (((size_t)blockIdx.z * gridDim.y + pl) * gridDim.x + blockIdx.x) * LINE_THREADS + lane;
+    const int n = H;
+    const IIRCoef &k = ps_coef(ps, pl) == 0 ? cf.c[0] : cf.c[1];
+    const bool fill0 = ps_fill0(ps, pl);
+    const double a1 = k.a1, a2 = k.a2, a3 = k.a3, scale = k.scale;
+    const double x0 = io.ld_src(0);
+    const double iminus = fill0 ? 0.0 : x0, iplus = fill0 ? 0.0 : io.ld_src(n - 1);
+    const double uminus = iminus / k.inv1masum;
+    const double o0 = ((x0 + a1 * uminus) + a2 * uminus) + a3 * uminus;
+    const double o1 = ((io.ld_src(1) + a1 * o0) + a2 * uminus) + a3 * uminus;
+    const double o2 = ((io.ld_src(2) + a1 * o1) + a2 * o0) + a3 * uminus;
+    double w3 = o0, w2 = o1, w1 = o2;
+    double raw[32], x[32];
+    // ---- pass A: forward over rows 3 .. n-1, read only; checkpoint before rows 32 b (b >= 1) ----
+    {
+        const int NT = ((n - 1) >> 4) + 1;
+        io.tile_load(io.src, 0, raw);
+        for (int t = 0; t < NT; t++) {
+            const int rb = t << 4;
+            io.lds_put_tile(raw); io.template lds_get_col<+1>(x);
+            if (t + 1 < NT) io.tile_load(io.src, rb + 16, raw);
+            if ((t & 1) == 0 && t >= 2) { double *c = ck + ((size_t)(t >> 1) * 3) * nlines + lineid; c[0] = w1; c[nlines] = w2; c[2 * nlines] = w3; }
+            if (rb >= 3 && rb + 15 <= n - 1) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) { const double tt = ((x[e] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; e++) { const int row = rb + e; if (row >= 3 && row <= n - 1) { const double tt = ((x[e] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; } }
+            }
+        }
+    }
+    // ---- Triggs-Sdika right boundary (as iir_line) ----
+    const double uplus = iplus / k.inv1masum, vplus = uplus / k.inv1mbsum;
+    const double d0 = w1 - uplus, d1 = w2 - uplus, d2 = w3 - uplus;
+    const double vr0 = ((k.M[0] * d0 + k.M[1] * d1) + k.M[2] * d2) + vplus;
+    const double vr1 = ((k.M[3] * d0 + k.M[4] * d1) + k.M[5] * d2) + vplus;
+    const double vr2 = ((k.M[6] * d0 + k.M[7] * d1) + k.M[8] * d2) + vplus;
+    const double vA = vr0;
+    const double vB = ((w2 + a1 * vA) + a2 * vr1) + a3 * vr2;
+    const double vC = ((w3 + a1 * vB) + a2 * vA) + a3 * vr1;
+    double v1 = vC, v2 = vB, v3 = vA;
+    io.fence();
+    // ---- pass B: blocks of 32 rows, bottom to top; rows [3, n-4] carry the recurrence, n-3 .. n-1 and 2 .. 0 are direct ----
+    const int NBk = ((n - 4) >> 5) + 1;
+    const int ntile = P >> 4;                                     // tiles that exist in the pitched plane
+    auto load_block = [&](int b) {
+        io.tile_load(io.src, b << 5, raw);
+        if (2 * b + 1 < ntile) io.tile_load(io.src, (b << 5) + 16, raw + 16);
+    };
+    if (n - 4 >= 3) load_block(NBk - 1);
+    io.st(n - 1, vA * scale); io.st(n - 2, vB * scale); io.st(n - 3, vC * scale);
+    for (int b = NBk - 1; b >= 0 && n - 4 >= 3; b--) {
+        const int rb = b << 5, lo = rb > 3 ? rb : 3, hi = rb + 31 < n - 4 ? rb + 31 : n - 4;
+        const bool two = 2 * b + 1 < ntile;
+        io.lds_put_tile(raw); io.template lds_get_col<+1>(x);
+        if (two) { io.lds_put_tile(raw + 16); io.template lds_get_col<+1>(x + 16); }
+        if (b > 0) load_block(b - 1);
+        double f1, f2, f3;
+        if (b > 0) { const double *c = ck + ((size_t)b * 3) * nlines + lineid; f1 = c[0]; f2 = c[nlines]; f3 = c[2 * nlines]; }
+        else { f1 = o2; f2 = o1; f3 = o0; }
+        if (lo == rb && hi == rb + 31) {
+#pragma unroll
+            for (int e = 0; e < 32; e++) { const double tt = ((x[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = tt; x[e] = tt; }
+#pragma unroll
+            for (int e = 31; e >= 0; e--) { const double tt = ((x[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; x[e] = tt * scale; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 32; e++) { const int row = rb + e; if (row >= lo && row <= hi) { const double tt = ((x[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = tt; x[e] = tt; } }
+#pragma unroll
+            for (int e = 31; e >= 0; e--) { const int row = rb + e; if (row >= lo && row <= hi) { const double tt = ((x[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; x[e] = tt * scale; } }
+        }
+        double u[16];
+        io.template lds_put_col<+1>(x); io.lds_get_tile(u);
+        io.tile_store(rb, u, lo, hi, !(lo <= rb && hi >= rb + 15));
+        if (two && hi >= rb + 16) {
+            io.template lds_put_col<+1>(x + 16); io.lds_get_tile(u);
+            io.tile_store(rb + 16, u, lo, hi, !(lo <= rb + 16 && hi >= rb + 31));
+        }
+    }
+    {   // rows 2, 1, 0: forward values o2, o1, o0
+        double tt = ((o2 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(2, tt * scale);
+        tt = ((o1 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(1, tt * scale);
+        tt = ((o0 + a1 * v1) + a2 * v2) + a3 * v3; io.st(0, tt * scale);
+    }
+}
+
 // integral_image!, lucas_kanade.jl:131-138: cumsum along dim 1 ...
 template <int NB>
 __global__ __launch_bounds__(LINE_THREADS) void k_cum_cols(PlaneSet ps, int H, int W, int P)
@@ -884,7 +984,9 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             hipLaunchKernelGGL(k_cum_seg<false>, gr3, dim3(PAR_T), 0, aux, pc, H, W, P, slr);
             continue;
         }
-        if (S == 1) hipLaunchKernelGGL(k_iir_cols<3>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
+        const bool ck_cols = p->ck != nullptr && mode != 0 && H >= 64 && (size_t)S * np * H * W * 8 >= ck_min_bytes() && getenv("SLAMHIP_NO_CK_COLS") == nullptr;
+        if (ck_cols) hipLaunchKernelGGL(k_iir_cols_ck, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf, p->ck);
+        else if (S == 1) hipLaunchKernelGGL(k_iir_cols<3>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
         else hipLaunchKernelGGL(k_iir_cols<2>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
         // bandwidth-bound launches (many images x a large level) take the checkpointed row kernel (2R+1W instead of 2R+2W)
         const bool ck_rows = p->ck != nullptr && mode != 0 && W >= 64 && (size_t)S * np * H * W * 8 >= ck_min_bytes();
@@ -983,7 +1085,10 @@ static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, 
     if (S > 1) {   // checkpoint scratch of k_iir_rows_ck: (blocks x 3) doubles per line of the widest launch (level 0, 4 planes)
         const size_t lines = (size_t)S * 4 * (((size_t)Hs[0] + LINE_THREADS - 1) / LINE_THREADS) * LINE_THREADS;
         const size_t nbk = ((size_t)Ws[0] + CK_B - 1) / CK_B;
-        if (hipMalloc((void **)&ckbuf, lines * nbk * 3 * 8) != hipSuccess) { (void)hipGetLastError(); ckbuf = nullptr; }
+        const size_t lines_c = (size_t)S * 4 * (((size_t)Ws[0] + LINE_THREADS - 1) / LINE_THREADS) * LINE_THREADS;      // column pass: lines = columns
+        const size_t nbk_c = ((size_t)Hs[0] + 31) / 32 + 1;
+        const size_t need = lines * nbk > lines_c * nbk_c ? lines * nbk : lines_c * nbk_c;
+        if (hipMalloc((void **)&ckbuf, need * 3 * 8) != hipSuccess) { (void)hipGetLastError(); ckbuf = nullptr; }
         al->ck = ckbuf;
     }
     for (int s = 0; s < S; s++) {

@@ -62,11 +62,12 @@ def test_batch_flow_match_equals_per_stream(slam, orc, texture):
 
 
 def test_checkpointed_row_kernel_is_bit_exact(slam, monkeypatch):
-    """Bandwidth-bound batched launches switch the dim-2 IIR pass to k_iir_rows_ck (forward state checkpoints +
-    recomputation instead of a stored forward plane).  Forced here on a small batch: every plane must stay
-    bit-identical to the single-image kernels (several block counts, incl. a last block of 1 and of 32 samples)."""
+    """Bandwidth-bound batched launches switch both IIR passes to the checkpointed kernels (k_iir_rows_ck,
+    k_iir_cols_ck: forward state checkpoints + recomputation instead of a stored forward plane).  Forced here on
+    small batches: every plane must stay bit-identical to the single-image kernels (several block counts, incl.
+    last blocks of 1 and of 32 samples, heights around the tile / block boundaries)."""
     import torch
-    for (H, W) in ((70, 71), (33, 102), (130, 64 + 6 + 1)):
+    for (H, W) in ((70, 71), (33, 102), (130, 64 + 6 + 1), (97, 80), (64, 66), (65, 64), (69, 75), (100, 70)):
         S = 2
         rng = np.random.default_rng(H * W)
         imgs = [np.asfortranarray(rng.random((H, W))) for _ in range(S)]
