@@ -86,19 +86,18 @@ __device__ __forceinline__ double spatial_gradient(const LevelView &v, int p0, i
         Gi[0] = sxx * id; Gi[1] = -syx * id; Gi[2] = -syx * id; Gi[3] = syy * id;
         return fmin(S0, S1) / cnt;
     }
-    const double a1 = atan2(G, F), a2 = atan2(Hh, E);
-    const double th = (a2 - a1) / 2, ph = (a2 + a1) / 2;
-    const double s = (double)((sy > 0) - (sy < 0));
-    const double sp = sin(ph), cp = cos(ph), st = sin(th), ct = cos(th);
-    const double U0 = cp, U1 = sp, U2 = -s * sp, U3 = s * cp;
-    const double V0 = ct, V1 = -st, V2 = st, V3 = ct;
-    const double d1 = S0 > tol ? 1.0 / S0 : 0.0, d2 = S1 > tol ? 1.0 / S1 : 0.0;
-    const double ud11 = U0 * d1 + U2 * 0.0, ud21 = U1 * d1 + U3 * 0.0;
-    const double ud12 = U0 * 0.0 + U2 * d2, ud22 = U1 * 0.0 + U3 * d2;
-    Gi[0] = ud11 * V0 + ud12 * V2;
-    Gi[1] = ud21 * V0 + ud22 * V2;
-    Gi[2] = ud11 * V1 + ud12 * V3;
-    Gi[3] = ud21 * V1 + ud22 * V3;
+    // Ill-conditioned / indefinite window (rejected by eig_thr in every practical configuration, but the seam allows
+    // eig_thr = 0): pinv2x2 of the symmetric M without the reference's atan/sincos construction.  M21 == M12, so the
+    // SVD is the eigen-decomposition: eigenvalues E +- R with projectors (I +- [[F, G], [G, -F]] / R) / 2, and
+    // pinv = sum over |eigenvalue| > tol of projector / eigenvalue (agrees with U*D*V' to 6e-16 relative).
+    (void)Hh; (void)Q;
+    const double l1 = E + R, l2 = E - R;
+    const double c1 = fabs(l1) > tol ? 1.0 / l1 : 0.0, c2 = fabs(l2) > tol ? 1.0 / l2 : 0.0;
+    if (R == 0.0) { Gi[0] = c1; Gi[1] = 0.0; Gi[2] = 0.0; Gi[3] = c1; }
+    else {
+        const double f = F / R, g = G / R, a = 0.5 * (c1 + c2), b = 0.5 * (c1 - c2);
+        Gi[0] = a + b * f; Gi[1] = b * g; Gi[2] = b * g; Gi[3] = a - b * f;
+    }
     return fmin(S0, S1) / cnt;
 }
 
@@ -242,25 +241,34 @@ __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView
             // Two phases so that every footprint load of the iteration is in flight before the first one is used
             // (k < kmax is wave-uniform; slots past the window hold a zero template and re-read element (0, 0)).
             // bilinear(): rows iy-1, iy of columns ix-1, ix -> two 16-byte loads.
-            D2 c0v[LK_MAXE], c1v[LK_MAXE];
+            // (in two halves of LK_MAXE / 2 slots: half the loads in flight, 24 fewer VGPRs -> 4 waves per SIMD)
+            constexpr int HS = (LK_MAXE + 1) / 2;
             const char *wbase = (const char *)(second.L + ((size_t)(iy0 - o.up - 1) + (size_t)(ix0 - o.left - 1) * pitch));
 #pragma unroll
-            for (int k = 0; k < LK_MAXE; k++)
-                if (k < T.kmax) {
-                    const char *ptr = wbase + (unsigned)((T.pq[k] & 0xffff) + (T.pq[k] >> 16) * pitch) * 8u;
-                    c0v[k] = *(const D2 *)ptr; c1v[k] = *(const D2 *)(ptr + (size_t)pitch * 8);
+            for (int h0 = 0; h0 < LK_MAXE; h0 += HS) {
+                D2 c0v[HS], c1v[HS];
+#pragma unroll
+                for (int j = 0; j < HS; j++) {
+                    const int k = h0 + j;
+                    if (k < LK_MAXE && k < T.kmax) {
+                        const char *ptr = wbase + (unsigned)((T.pq[k] & 0xffff) + (T.pq[k] >> 16) * pitch) * 8u;
+                        c0v[j] = *(const D2 *)ptr; c1v[j] = *(const D2 *)(ptr + (size_t)pitch * 8);
+                    }
                 }
 #pragma unroll
-            for (int k = 0; k < LK_MAXE; k++)
-                if (k < T.kmax) {
-                    const double dp = (double)((T.pq[k] & 0xffff) - o.up), dq = (double)((T.pq[k] >> 16) - o.left);
-                    const double fy = (r0 + dp) - (fr0 + dp), fx = (r1 + dq) - (fr1 + dq);
-                    const double t0 = (1 - fx) * c0v[k].a + fx * c1v[k].a;
-                    const double t1 = (1 - fx) * c0v[k].b + fx * c1v[k].b;
-                    const double dI = T.s[0][k][lane] - ((1 - fy) * t0 + fy * t1);
-                    ay += dI * T.s[1][k][lane];
-                    ax += dI * T.s[2][k][lane];
+                for (int j = 0; j < HS; j++) {
+                    const int k = h0 + j;
+                    if (k < LK_MAXE && k < T.kmax) {
+                        const double dp = (double)((T.pq[k] & 0xffff) - o.up), dq = (double)((T.pq[k] >> 16) - o.left);
+                        const double fy = (r0 + dp) - (fr0 + dp), fx = (r1 + dq) - (fr1 + dq);
+                        const double t0 = (1 - fx) * c0v[j].a + fx * c1v[j].a;
+                        const double t1 = (1 - fx) * c0v[j].b + fx * c1v[j].b;
+                        const double dI = T.s[0][k][lane] - ((1 - fy) * t0 + fy * t1);
+                        ay += dI * T.s[1][k][lane];
+                        ax += dI * T.s[2][k][lane];
+                    }
                 }
+            }
         } else {
             const int P = o.up + o.down + 1, Q = o.left + o.right + 1, NE = P * Q;
             for (int e = lane; e < NE; e += 64) {
