@@ -83,3 +83,23 @@ def test_checkpointed_row_kernel_is_bit_exact(slam, monkeypatch):
             for name in PLANES:
                 assert np.array_equal(batch.pyramids[s].plane(name, 0), single.plane(name, 0)), (H, W, s, name)
             assert np.array_equal(batch.pyramids[s].plane("layers", 1), single.plane("layers", 1))
+
+
+def test_batch_at_kitti_size_uses_checkpointed_kernels_and_stays_exact(slam, syn):
+    """8 images of 370 x 1226 per launch is above the bandwidth threshold (116 MB of plane data at level 0), so this
+    batch runs k_iir_cols_ck / k_iir_rows_ck with their real block counts; members must equal single-image pyramids."""
+    import torch
+    H, W, S = 370, 1226, 8
+    rng = np.random.default_rng(77)
+    base = syn.texture_canvas(H, W, seed=5, margin=0)
+    imgs = [np.asfortranarray(np.clip(base + 0.02 * rng.standard_normal((H, W)), 0, 1)) for _ in range(S)]
+    dev = [torch.from_numpy(np.ascontiguousarray(im.T)).cuda() for im in imgs]
+    torch.cuda.synchronize()
+    batch = slam.PyramidBatch((H, W), levels=3, S=S)
+    batch.update_([d.data_ptr() for d in dev])
+    for s in (0, S - 1):
+        single = slam.LKPyramid(shape=(H, W), levels=3)
+        slam.update_(single, imgs[s])
+        for l in range(4):
+            for name in PLANES:
+                assert np.array_equal(batch.pyramids[s].plane(name, l), single.plane(name, l)), (s, name, l)
