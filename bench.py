@@ -437,8 +437,8 @@ def main():
         tol = run_lockstep(slam, torch, local_rank, S, max(40, args.steps // 4), min(args.warmup, 10), H, W, left_dev, right_dev, flows, disparity,
                            params, extractor, True, world, dist, dev)
         out["tolerance_mode"] = dict(tol, pyramid="slam_pyr_update mode 3 (parallel recurrences; planes <= 1e-11 relative, tracked positions <= 1e-7 px vs "
-                                                  "the bit-exact mode: tests/test_gpu_pyramid.py::test_fast_mode_within_tolerance); built for single-image "
-                                                  "latency, slower than the bit-exact kernels once S images share a launch")
+                                                  "the bit-exact mode: tests/test_gpu_pyramid.py::test_fast_mode_within_tolerance); the segmented kernels serve "
+                                                  "single-image latency - batches of >= 4 images take the bit-exact kernels in this mode too")
         fctx = [slam.Context(local_rank) for _ in range(3)]
         fbe = GpuBackend(slam, fctx[0], fctx[1], fctx[2], H, W, left_dev, right_dev, params, extractor, fast=True)
         fs = Stream(fbe, flows, disparity, seed=rank)

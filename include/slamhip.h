@@ -174,7 +174,11 @@ int slam_flow_match(slam_ctx *ctx, const slam_pyr *from, const slam_pyr *to,
  * slam_pyr_create_batch fills out[0..S) with ordinary pyramid handles backed by one allocation; each can be used
  * with every single-pyramid call above.  slam_pyr_update_batch_dev rebuilds all S in one launch set (pyrs must
  * be the S members of one batch, in order; images already in HBM); slam_flow_match_batch tracks the keypoints
- * of all S streams in one launch (img_index[i] = stream of point i; from0 / to0 = member 0 of two batches). */
+ * of all S streams in one launch (img_index[i] = stream of point i; from0 / to0 = member 0 of two batches).
+ * Batch updates: mode 1 or 3 as for slam_pyr_update; with S >= 4 both modes run the bit-exact kernels (the segmented
+ * ones of mode 3 only pay for a single image); launches with >= 96 MB of plane data use the checkpointed IIR kernels
+ * (forward state every 32 samples, forward values recomputed: 2 reads + 1 write per sample instead of 2 + 2), still
+ * bit-identical to mode 1 on a single pyramid. */
 int slam_pyr_create_batch(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, slam_pyr **out);
 int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double *const *images_dev, int S,
                               int mode, double sigma, int sync);

@@ -949,6 +949,7 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
     const bool forked = aux != st;
     bool fast = mode == 3;
     if (fast && (seg_len(p->H[0], PAR_T / 8) > PAR_SLMAX || seg_len(p->W[0], PAR_T / 8) > PAR_SLMAX)) fast = false;   // lines > 2048 samples: exact kernels
+    if (fast && S >= 4) fast = false;   // the segmented kernels buy latency for ONE image; with several images per launch the exact kernels are faster (and trivially within the tolerance)
     const int border_mode = (mode == 0) ? 1 : 0;
     for (int l = 0; l < p->levels; l++) {
         const int H = p->H[l], W = p->W[l], P = p->P[l];
