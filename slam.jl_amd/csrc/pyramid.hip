@@ -600,6 +600,130 @@ __global__ __launch_bounds__(LINE_THREADS) void k_cum_rows(PlaneSet ps, int H, i
     stream_line<8, 8>(p + P, p + P, P, W - 1, [&](double x) { acc = acc + x; return acc; });
 }
 
+// integral_image! in ONE pass for batched launches (one read + one write per sample instead of two of each).
+// One workgroup owns a plane; wave w owns the 64-row band [64 w, 64 w + 63] and walks it left to right in blocks of
+// 32 columns through its own LDS block Cb[column][row]: (a) the block arrives as aligned 128-byte lines (16 bytes per
+// lane) and is written to Cb; (b) lanes = columns: each lane adds its column's 64 samples onto the column's running
+// sum, which enters from the band above (wave w-1 publishes the sums of its bottom row per block in LDS, with a
+// ready counter; double-buffered with a consumed counter as back-pressure) and leaves to the band below; (c) lanes =
+// rows: each lane adds its row's 32 column sums left to right onto the row's carry (a register: the wave keeps its
+// rows for the whole plane); (d) the block is stored as aligned lines.  The bands form a pipeline (wave w runs one
+// block behind wave w-1), so a plane takes (blocks + bands) block-times instead of blocks x bands.  Every sum is
+// formed exactly as by k_cum_cols followed by k_cum_rows (dim 1 first, each element added to its predecessor's
+// result).  Bound by its dependent adds, not by bandwidth (~100 workgroups at S = 32): it runs on the forked stream
+// next to the following level's kernels and leaves the HBM to them.
+#define CF_LS 66                         // Cb column stride in doubles (even: ds_*_b128 alignment)
+#define CF_W 32                          // columns per block
+#define CF_MAXW 8                        // bands (waves) per workgroup: H <= 512 (2 waves per SIMD -> 256 VGPRs each)
+// block of 64 rows x 32 columns as aligned lines: sub-tile s, column group r -> rows 2rp, 2rp+1 of column 8r + cg.  Rows past
+// H inside the pitch and columns past W are read as well (in-bounds by the layout, never stored).
+__device__ __forceinline__ void cf_load_block(const double *plane, int P, int x0, int r0, unsigned voff, double (&raw)[4][8])
+{
+#pragma unroll
+    for (int sub = 0; sub < 4; sub++) {
+        const int rb = min(r0 + sub * 16, P - 16);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const double2 q = *(const double2 *)(plane + ((size_t)(x0 + 8 * r) * P + rb) + voff); raw[sub][2 * r] = q.x; raw[sub][2 * r + 1] = q.y; }
+    }
+}
+__global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, int W, int P)
+{
+    extern __shared__ __attribute__((aligned(16))) double cf_lds[];          // [nw][CF_W * CF_LS] blocks, then [nw][2][CF_W] column carries
+    __shared__ volatile int s_ready[CF_MAXW], s_done[CF_MAXW];
+    const int pl = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int rp = lane & 7, cg = lane >> 3;
+    double *plane = ps_plane(ps, pl);
+    double *Cb = cf_lds + (size_t)w * CF_W * CF_LS;
+    double *carry_out = cf_lds + (size_t)nw * CF_W * CF_LS + (size_t)w * 2 * CF_W;      // published by this wave
+    const double *carry_in = carry_out - 2 * CF_W;                                        // published by wave w - 1
+    if (lane == 0) { s_ready[w] = 0; s_done[w] = 0; }
+    __syncthreads();
+    const int r0 = w * 64, hr = H - r0 < 64 ? H - r0 : 64;       // rows of this band that exist (>= 1 by the launch)
+    const int ncb = (W + CF_W - 1) / CF_W;
+    const unsigned voff = (unsigned)(cg * P + 2 * rp);
+    double raw[4][8];
+    double rcarry = 0.0;                                          // this lane's row: running sum along x
+    cf_load_block(plane, P, 0, r0, voff, raw);
+    for (int cb = 0; cb < ncb; cb++) {
+        const int x0 = cb * CF_W, wc = W - x0 < CF_W ? W - x0 : CF_W;
+        // (a) block -> Cb[column][row]
+#pragma unroll
+        for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) *(double2 *)(Cb + (8 * r + cg) * CF_LS + sub * 16 + 2 * rp) = make_double2(raw[sub][2 * r], raw[sub][2 * r + 1]);
+        cf_load_block(plane, P, cb + 1 < ncb ? x0 + CF_W : x0, r0, voff, raw);       // next block (the last iteration re-reads, unused)
+        // column sums of the band above
+        double acc = 0.0;
+        if (w > 0) {
+            while (s_ready[w - 1] <= cb) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane < CF_W) acc = carry_in[(cb & 1) * CF_W + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) s_done[w] = cb + 1;                    // slot cb & 1 may be overwritten with block cb + 2
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        // (b) column sums, lane = column
+        if (lane < CF_W) {
+            double *c = Cb + lane * CF_LS;
+            if (hr == 64 && w > 0) {
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    double v[32];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) { const double2 q = *(const double2 *)(c + 32 * half + 2 * j); v[2 * j] = q.x; v[2 * j + 1] = q.y; }
+#pragma unroll
+                    for (int e = 0; e < 32; e++) { acc = acc + v[e]; v[e] = acc; }
+#pragma unroll
+                    for (int j = 0; j < 16; j++) *(double2 *)(c + 32 * half + 2 * j) = make_double2(v[2 * j], v[2 * j + 1]);
+                }
+            } else {
+                for (int e = 0; e < hr; e++) { acc = (r0 + e == 0) ? c[e] : acc + c[e]; c[e] = acc; }
+            }
+        }
+        if (w + 1 < nw) {                                         // publish the bottom row's sums to the band below
+            while (s_done[w + 1] + 2 <= cb) __builtin_amdgcn_s_sleep(1);
+            if (lane < CF_W) carry_out[(cb & 1) * CF_W + lane] = acc;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) s_ready[w] = cb + 1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        // (c) row sums across the block's columns, lane = row
+        if (lane < hr) {
+            double *c = Cb + lane;
+            if (wc == CF_W && cb > 0) {
+                double v[CF_W];
+#pragma unroll
+                for (int j = 0; j < CF_W; j++) v[j] = c[j * CF_LS];
+#pragma unroll
+                for (int j = 0; j < CF_W; j++) { rcarry = rcarry + v[j]; v[j] = rcarry; }
+#pragma unroll
+                for (int j = 0; j < CF_W; j++) c[j * CF_LS] = v[j];
+            } else {
+                for (int j = 0; j < wc; j++) { rcarry = (cb == 0 && j == 0) ? c[j * CF_LS] : rcarry + c[j * CF_LS]; c[j * CF_LS] = rcarry; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        // (d) store as aligned lines (rows >= H and columns >= W masked)
+#pragma unroll
+        for (int sub = 0; sub < 4; sub++) {
+            const int rb = r0 + sub * 16;
+            if (rb < H) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int col = x0 + 8 * r + cg, row = rb + 2 * rp;
+                    const double2 q = *(const double2 *)(Cb + (8 * r + cg) * CF_LS + sub * 16 + 2 * rp);
+                    double *g = plane + ((size_t)(x0 + 8 * r) * P + rb) + voff;
+                    if (col < W) {
+                        if (row + 1 < H) *(double2 *)g = q;
+                        else if (row < H) g[0] = q.x;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- tolerance mode ("fast", mode 3): parallel recurrences -------------------------
 // The exact kernels above are bound by the dependent f64 chain: 68 cycles per IIR
 // step x line length (measured, scripts/ubench/dep_chain.hip), on the few CUs that a
@@ -1000,6 +1124,14 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         if (has_next)
             hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, st,
                                p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
+        static const bool no_fused_cum = getenv("SLAMHIP_NO_FUSED_CUM") != nullptr;
+        if (S >= 8 && !no_fused_cum && H <= CF_MAXW * 64) {                 // batches: one-pass integral image
+            const int nw = (H + 63) / 64;
+            const size_t lds = ((size_t)nw * CF_W * CF_LS + (size_t)nw * 2 * CF_W) * sizeof(double);
+            (void)hipFuncSetAttribute((const void *)k_cum_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            hipLaunchKernelGGL(k_cum_fused, dim3(1, 3, S), dim3(nw * 64), lds, aux, pc, H, W, P);
+            continue;
+        }
         if (S == 1) hipLaunchKernelGGL(k_cum_cols<3>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, aux, pc, H, W, P);
         else hipLaunchKernelGGL(k_cum_cols<2>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, aux, pc, H, W, P);
         hipLaunchKernelGGL(k_cum_rows, lines_grid(H, 3, S), dim3(LINE_THREADS), 0, aux, pc, H, W, P);

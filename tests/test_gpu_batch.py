@@ -103,3 +103,24 @@ def test_batch_at_kitti_size_uses_checkpointed_kernels_and_stays_exact(slam, syn
         for l in range(4):
             for name in PLANES:
                 assert np.array_equal(batch.pyramids[s].plane(name, l), single.plane(name, l)), (s, name, l)
+
+
+@pytest.mark.parametrize("shape", [(70, 71), (33, 102), (130, 135), (64, 64), (65, 129), (16, 200), (200, 17)])
+def test_fused_integral_image_kernel_is_bit_exact(slam, shape):
+    """Batches of >= 8 images build the integral images with the one-pass kernel (k_cum_fused: 64 x 64 tiles, column
+    sums then row sums with carries); planes must equal the two-pass single-image kernels bit for bit."""
+    import torch
+    H, W = shape
+    S = 8
+    rng = np.random.default_rng(H * 1000 + W)
+    imgs = [np.asfortranarray(rng.random((H, W))) for _ in range(S)]
+    dev = [torch.from_numpy(np.ascontiguousarray(im.T)).cuda() for im in imgs]
+    torch.cuda.synchronize()
+    batch = slam.PyramidBatch((H, W), levels=1, S=S)
+    batch.update_([d.data_ptr() for d in dev])
+    for s in (0, 3, S - 1):
+        single = slam.LKPyramid(shape=(H, W), levels=1)
+        slam.update_(single, imgs[s])
+        for l in range(2):
+            for name in PLANES:
+                assert np.array_equal(batch.pyramids[s].plane(name, l), single.plane(name, l)), (shape, s, name, l)
