@@ -10,10 +10,14 @@
 // bit-identical to the CPU oracle (-ffp-contract=off).  Lines are independent:
 // lanes map to lines, and a launch carries all planes that are ready.
 //
-// Layout in HBM: one allocation per pyramid, 6 planes x sum_l(H_l*W_l) doubles,
-// each plane column-major H_l x W_l (y fastest) exactly like the Julia arrays,
-// plus one blur scratch plane.  Row passes (recurrence along x) are naturally
-// coalesced (lanes = consecutive y); column passes walk y inside a lane.
+// Layout in HBM: one allocation per pyramid (or per batch of S pyramids), 6 planes x
+// sum_l(P_l*W_l) doubles, each plane column-major H_l x W_l (y fastest) like the Julia
+// arrays but with a column pitch P_l = H_l rounded up to 16 doubles (every column starts
+// on a 128-byte line), plus one blur scratch plane.  Row passes (recurrence along x) are
+// naturally coalesced (lanes = consecutive y); column passes walk y inside a lane and move
+// whole aligned lines through an LDS transpose.  Batched launches take the image index
+// from blockIdx.z; bandwidth-bound ones switch to the checkpointed IIR kernels
+// (k_iir_*_ck) and the one-pass integral image (k_cum_fused), all bit-identical.
 #include "common.hpp"
 #include <cmath>
 #include <cstdlib>
