@@ -182,6 +182,10 @@ int slam_flow_match(slam_ctx *ctx, const slam_pyr *from, const slam_pyr *to,
 int slam_pyr_create_batch(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, slam_pyr **out);
 int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double *const *images_dev, int S,
                               int mode, double sigma, int sync);
+/* Same from 8-bit frames resident in HBM (column-major H x W bytes, the KITTI reader's decode before
+ * `Gray{Float64}.(frame)`, example/kitty/main.jl:39-41): raw / 255 on the device. */
+int slam_pyr_update_batch_u8_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const uint8_t *const *images_u8_dev, int S,
+                                 int mode, double sigma, int sync);
 int slam_flow_match_batch(slam_ctx *ctx, const slam_pyr *from0, const slam_pyr *to0, int S, const int32_t *img_index,
                           const double *pts_yx, const uint8_t *is_3d, const double *proj_yx, int n,
                           int pyramid_levels, int pyramid_levels_3d, int window, int iterations,

@@ -47,6 +47,7 @@ SIGNATURES = {
     "slam_flow_match": (cint, [vp, vp, vp, f64p, u8p, f64p, cint, cint, cint, cint, cint, dbl, dbl, dbl, f64p, u8p]),
     "slam_pyr_create_batch": (cint, [vp, cint, cint, cint, cint, C.POINTER(vp)]),
     "slam_pyr_update_batch_dev": (cint, [vp, C.POINTER(vp), C.POINTER(vp), cint, cint, dbl, cint]),
+    "slam_pyr_update_batch_u8_dev": (cint, [vp, C.POINTER(vp), C.POINTER(vp), cint, cint, dbl, cint]),
     "slam_flow_match_batch": (cint, [vp, vp, vp, cint, i32p, f64p, u8p, f64p, cint, cint, cint, cint, cint, dbl, dbl, dbl, f64p, u8p]),
     "slam_local_ba": (cint, [vp, dbl, dbl, dbl, dbl, cint, cint, cint, f64p, u8p, f64p, i64p, i64p, u8p, cint, cint, dbl, f64p]),
     "slam_pnp_ba": (cint, [vp, dbl, dbl, dbl, dbl, f64p, f64p, f64p, cint, cint, cint, dbl, dbl, f64p, f64p, f64p, u8p, C.POINTER(cint)]),

@@ -987,6 +987,13 @@ __global__ __launch_bounds__(256) void k_gather_images(ImgPtrs src, double *dst,
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < (size_t)H * W) dst[(size_t)blockIdx.z * zs + i % H + (i / H) * P] = src.p[blockIdx.z][i];
 }
+// same from 8-bit frames: Float64(::N0f8) = raw / 255 on the way into the pitched layer
+struct ImgPtrsU8 { const unsigned char *p[BATCH_MAX]; };
+__global__ __launch_bounds__(256) void k_gather_images_u8(ImgPtrsU8 src, double *dst, int H, int W, int P, size_t zs)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)H * W) dst[(size_t)blockIdx.z * zs + i % H + (i / H) * P] = (double)src.p[blockIdx.z][i] / 255.0;
+}
 // device -> host staging of one plane: pitched -> dense
 __global__ __launch_bounds__(256) void k_unpitch(double *dst, const double *src, int H, int W, int P)
 {
@@ -1265,6 +1272,24 @@ int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double
     for (int s = 0; s < BATCH_MAX; s++) ip.p[s] = s < S ? images_dev[s] : nullptr;
     const size_t n = (size_t)p0->H[0] * p0->W[0];
     hipLaunchKernelGGL(k_gather_images, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
+    int rc = enqueue_build(ctx, p0, mode, sigma, S);
+    if (rc) return rc;
+    if (sync) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+// 8-bit frames already in HBM (column-major H x W bytes, as the KITTI reader decodes them): converted on the device
+int slam_pyr_update_batch_u8_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const uint8_t *const *images_u8_dev, int S, int mode, double sigma, int sync)
+{
+    ARG_TRY(ctx, ctx != nullptr && pyrs != nullptr && images_u8_dev != nullptr && S >= 1 && S <= BATCH_MAX && (mode == 1 || mode == 3) && sigma > 0);
+    slam_pyr *p0 = pyrs[0];
+    ARG_TRY(ctx, p0 != nullptr && p0->batch_index == 0 && p0->batch_size == S);
+    for (int s = 0; s < S; s++) ARG_TRY(ctx, pyrs[s] != nullptr && pyrs[s]->alloc == p0->alloc && pyrs[s]->batch_index == s && images_u8_dev[s] != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ImgPtrsU8 ip;
+    for (int s = 0; s < BATCH_MAX; s++) ip.p[s] = s < S ? images_u8_dev[s] : nullptr;
+    const size_t n = (size_t)p0->H[0] * p0->W[0];
+    hipLaunchKernelGGL(k_gather_images_u8, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
     int rc = enqueue_build(ctx, p0, mode, sigma, S);
     if (rc) return rc;
     if (sync) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

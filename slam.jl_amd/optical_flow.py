@@ -190,11 +190,13 @@ class PyramidBatch:
         self.pyramids = [LKPyramid(ctx=self.ctx, _handle=C.c_void_p(hs[s])) for s in range(S)]
         self._handles = (C.c_void_p * S)(*[p.h for p in self.pyramids])
 
-    def update_(self, device_ptrs, sigma=1.0, sync=True, fast=False, ctx=None):
-        """update!() of all S pyramids from S device-resident images (list of device pointers)."""
+    def update_(self, device_ptrs, sigma=1.0, sync=True, fast=False, ctx=None, u8=False):
+        """update!() of all S pyramids from S device-resident images (list of device pointers to column-major
+        H x W Float64 images, or to 8-bit frames when u8=True: converted raw / 255 on the device)."""
         c = ctx or self.ctx
         imgs = (C.c_void_p * self.S)(*[C.c_void_p(p) for p in device_ptrs])
-        c.check(c.lib.slam_pyr_update_batch_dev(c.h, self._handles, imgs, self.S, 3 if fast else 1, float(sigma), 1 if sync else 0))
+        fn = c.lib.slam_pyr_update_batch_u8_dev if u8 else c.lib.slam_pyr_update_batch_dev
+        c.check(fn(c.h, self._handles, imgs, self.S, 3 if fast else 1, float(sigma), 1 if sync else 0))
         return self
 
 

@@ -124,3 +124,21 @@ def test_fused_integral_image_kernel_is_bit_exact(slam, shape):
         for l in range(2):
             for name in PLANES:
                 assert np.array_equal(batch.pyramids[s].plane(name, l), single.plane(name, l)), (shape, s, name, l)
+
+
+def test_batch_u8_ingest_equals_float_ingest(slam, syn):
+    """8-bit frames converted on the device (raw / 255, correctly rounded) == Float64 frames Gray{Float64}.(img)."""
+    import torch
+    H, W, S = 90, 121, 4
+    rng = np.random.default_rng(4)
+    u8 = [np.asfortranarray(rng.integers(0, 256, (H, W), dtype=np.uint8)) for _ in range(S)]
+    d8 = [torch.from_numpy(np.ascontiguousarray(im.T)).cuda() for im in u8]
+    f64 = [torch.from_numpy(np.ascontiguousarray((im.astype(np.float64) / 255.0).T)).cuda() for im in u8]
+    torch.cuda.synchronize()
+    a = slam.PyramidBatch((H, W), levels=2, S=S); b = slam.PyramidBatch((H, W), levels=2, S=S)
+    a.update_([d.data_ptr() for d in d8], u8=True)
+    b.update_([d.data_ptr() for d in f64])
+    for s in range(S):
+        for l in range(3):
+            for name in PLANES:
+                assert np.array_equal(a.pyramids[s].plane(name, l), b.pyramids[s].plane(name, l)), (s, name, l)
