@@ -142,3 +142,26 @@ def test_batch_u8_ingest_equals_float_ingest(slam, syn):
         for l in range(3):
             for name in PLANES:
                 assert np.array_equal(a.pyramids[s].plane(name, l), b.pyramids[s].plane(name, l)), (s, name, l)
+
+
+def test_batch_at_fhd_size_stays_exact(slam):
+    """BASELINE config 5 shape (1080 x 1920): above the 512-row limit of the one-pass integral kernel (falls back to
+    k_cum_cols + k_cum_rows) and far above the bandwidth threshold (checkpointed IIR kernels at levels 0-2)."""
+    import torch
+    H, W, S = 1080, 1920, 8
+    rng = np.random.default_rng(5)
+    base = rng.random((H // 8 + 2, W // 8 + 2))
+    imgs = []
+    for s in range(S):
+        up = np.kron(base, np.ones((8, 8)))[s:s + H, s:s + W]
+        imgs.append(np.asfortranarray(0.5 * up + 0.5 * rng.random((H, W))))
+    dev = [torch.from_numpy(np.ascontiguousarray(im.T)).cuda() for im in imgs]
+    torch.cuda.synchronize()
+    batch = slam.PyramidBatch((H, W), levels=3, S=S)
+    batch.update_([d.data_ptr() for d in dev])
+    for s in (0, S - 1):
+        single = slam.LKPyramid(shape=(H, W), levels=3)
+        slam.update_(single, imgs[s])
+        for l in range(4):
+            for name in PLANES:
+                assert np.array_equal(batch.pyramids[s].plane(name, l), single.plane(name, l)), (s, name, l)
