@@ -980,7 +980,7 @@ __global__ __launch_bounds__(256) void k_u8_to_f64(double *dst, const unsigned c
 }
 
 // ingest: the dense H x W image z (its own device pointer) is copied into the pitched layer 0 of pyramid z
-#define BATCH_MAX 32
+#define BATCH_MAX 64
 struct ImgPtrs { const double *p[BATCH_MAX]; };
 __global__ __launch_bounds__(256) void k_gather_images(ImgPtrs src, double *dst, int H, int W, int P, size_t zs)
 {
