@@ -352,48 +352,50 @@ __global__ __launch_bounds__(256) void k_chol_prepare(BADev d, const double *Sin
 // Factor a diagonal tile and invert its triangle, by ONE wave, rows in registers.
 // t (LDS, 32x33): in = tile (lower part, h rows x w valid columns, rows >= w are
 // panel rows riding along), out = L.  inv (LDS): out = L^-1 (w x w lower).
-// Lane i owns row i.  Everything another lane needs (the pivot, column j of L, row i
-// of L for the inverse) is a wave-uniform value, so it is fetched with v_readlane
-// into scalar registers -- no LDS round trip on the 32-step dependent chain.
-// Fully unrolled and predicated on the wave-uniform tile extents (no branches).
-__device__ __forceinline__ double rl64(double v, int lane)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
+// Lane i owns row i of the tile, which stays in LDS: at step j every lane forms its element of column j
+// left-looking, l_ij = (a_ij - sum_{m<j} l_im l_jm) / l_jj, with its own l_im in registers and the l_jm
+// (and a_jj) fetched as LDS broadcast reads, which issue back to back -- the v_readlane form of the same
+// algorithm paid the scalar-register hazard on every one of its ~1000 broadcasts and was 3x slower.  The
+// subtractions run in the order of the right-looking update, so the factor is unchanged to the last bit.
+// Every lane recomputes the pivot l_jj from row j (no communication).  Fully unrolled; tile extents
+// (h rows, w columns, wave-uniform) are predicates.
 __device__ __forceinline__ void tile_potrf_inv(double (*t)[CT + 1], double (*inv)[CT + 1], int h, int w, int *fail)
 {
-    const int lane = threadIdx.x & 63;
-    double row[CT], rdiag[CT];
+    const int lane = threadIdx.x & 63, li = lane < CT ? lane : CT - 1;
+    double lrow[CT], rdiag[CT];
     bool bad = false;
-#pragma unroll
-    for (int m = 0; m < CT; m++) row[m] = (lane < CT) ? t[lane][m] : 0.0;
 #pragma unroll
     for (int j = 0; j < CT; j++) {
         const bool active = j < w;
-        double dj = rl64(row[j], j);
+        double acc = t[li][j];                                   // a_ij
+        double dj = t[j][j];                                     // a_jj (broadcast)
+#pragma unroll
+        for (int m = 0; m < j; m++) {
+            const double ljm = t[j][m];                          // broadcast, final since step m
+            acc -= lrow[m] * ljm;
+            dj -= ljm * ljm;
+        }
         bad = bad || (active && !(dj > 0));
         dj = (active && dj > 0) ? dj : 1.0;
         const double rd = rsqrt(dj);
         rdiag[j] = rd;
-        const double l = (lane == j) ? dj * rd : row[j] * rd;
-        row[j] = active ? l : row[j];
-#pragma unroll
-        for (int m = j + 1; m < CT; m++) {
-            const double lm = rl64(l, m);
-            row[m] -= (active && m < w && lane >= m) ? l * lm : 0.0;
-        }
+        const double l = (lane == j) ? dj * rd : acc * rd;
+        lrow[j] = l;
+        if (active && lane >= j && lane < CT) t[lane][j] = l;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
     if (lane < CT) {
 #pragma unroll
-        for (int m = 0; m < CT; m++) t[lane][m] = (m <= lane && m < w && lane < h) ? row[m] : 0.0;
+        for (int m = 0; m < CT; m++) if (!(m <= lane && m < w && lane < h)) t[lane][m] = 0.0;
     }
-    // inverse: lane c solves L x = e_c (forward substitution), x in registers; L[i][m] = row m of lane i
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    // inverse: lane c solves L x = e_c by forward substitution, x in registers, row i of L as broadcast reads
     double x[CT];
 #pragma unroll
     for (int i = 0; i < CT; i++) {
         double sacc = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
-        for (int m = 0; m < i; m++) sacc -= rl64(row[m], i) * x[m];
+        for (int m = 0; m < i; m++) sacc -= t[i][m] * x[m];
         x[i] = (i < w && lane <= i) ? sacc * rdiag[i] : 0.0;
     }
     if (lane < CT) {
