@@ -512,27 +512,65 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(BADev d, CholArgs C, con
     if (use_state && d.st->converged) return;
     __shared__ double x[SOLVE_MAX_N];
     __shared__ double xb[CT];
+    __shared__ double Lis[CT][CT + 1];
     const int n = C.n, ld = C.ld, tid = threadIdx.x;
     for (int a = tid; a < n; a += 256) x[a] = C.Lf[(size_t)n + (size_t)a * ld];
-    __syncthreads();
     const int nbc = (n + CT - 1) / CT;
-    for (int kb = nbc - 1; kb >= 0; kb--) {
+    // The 10 block steps are a dependent chain through x, but what they read from HBM (the tile inverse and the block
+    // row of L) does not depend on x: the data of step kb-1 is requested before step kb is computed, so the chain
+    // only pays LDS latency and barriers instead of two global round trips per step.
+    constexpr int RPT = 2;                                       // prefetched rows per thread (a < 512); larger systems read the rest directly
+    double lf[RPT][CT], lfn[RPT][CT], li[4], lin[4];
+    auto fetch = [&](int kb, double (&rf)[RPT][CT], double (&ri)[4]) {
         const int j0 = CT * kb, w = min(CT, n - j0);
         const double *Li = Linv + (size_t)kb * CT * CT;
+#pragma unroll
+        for (int q = 0; q < 4; q++) ri[q] = Li[tid + 256 * q];
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            const int a = tid + 256 * r;
+#pragma unroll
+            for (int j = 0; j < CT; j++) rf[r][j] = (a < j0 && j < w) ? C.Lf[(size_t)(j0 + j) + (size_t)a * ld] : 0.0;
+        }
+    };
+    fetch(nbc - 1, lf, li);
+    __syncthreads();
+    for (int kb = nbc - 1; kb >= 0; kb--) {
+        const int j0 = CT * kb, w = min(CT, n - j0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int e = tid + 256 * q; Lis[e % CT][e / CT] = li[q]; }      // Linv tile, [i][j] = Li[i + CT j]
+        if (kb > 0) fetch(kb - 1, lfn, lin);
+        __syncthreads();
         if (tid < w) {                                              // x_k = Linv' y_k : x[a] = sum_{i>=a} Linv[i][a] y[i]
             double s0 = 0.0;
-            for (int i = tid; i < w; i++) s0 += Li[i + CT * tid] * x[j0 + i];
+            for (int i = tid; i < w; i++) s0 += Lis[i][tid] * x[j0 + i];
             xb[tid] = s0;
         }
         __syncthreads();
         if (tid < w) x[j0 + tid] = xb[tid];
         __syncthreads();
-        for (int a = tid; a < j0; a += 256) {                       // y_a -= sum_j L[j0+j][a] x[j0+j]
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {                             // y_a -= sum_j L[j0+j][a] x[j0+j]
+            const int a = tid + 256 * r;
+            if (a < j0) {
+                double s0 = 0.0;
+#pragma unroll
+                for (int j = 0; j < CT; j++) s0 += lf[r][j] * x[j0 + j < n ? j0 + j : n - 1];
+                x[a] -= s0;
+            }
+        }
+        for (int a = tid + 256 * RPT; a < j0; a += 256) {            // rows beyond the prefetched ones (n > 512)
             double s0 = 0.0;
             for (int j = 0; j < w; j++) s0 += C.Lf[(size_t)(j0 + j) + (size_t)a * ld] * x[j0 + j];
             x[a] -= s0;
         }
         __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RPT; r++)
+#pragma unroll
+            for (int j = 0; j < CT; j++) lf[r][j] = lfn[r][j];
+#pragma unroll
+        for (int q = 0; q < 4; q++) li[q] = lin[q];
     }
     for (int a = tid; a < n; a += 256) d.dp[a] = x[a];
     if (tid == 0 && *C.fail) d.st->chol_fail = 1;
