@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_chol_prepare(BADev d, const double *Sin
 // left-looking, l_ij = (a_ij - sum_{m<j} l_im l_jm) / l_jj, with its own l_im in registers and the l_jm
 // (and a_jj) fetched as LDS broadcast reads, which issue back to back -- the v_readlane form of the same
 // algorithm paid the scalar-register hazard on every one of its ~1000 broadcasts and was 3x slower.  The
-// subtractions run in the order of the right-looking update, so the factor is unchanged to the last bit.
+// dot products are formed as four interleaved partial sums (dependent chain j / 4 instead of j).
 // Every lane recomputes the pivot l_jj from row j (no communication).  Fully unrolled; tile extents
 // (h rows, w columns, wave-uniform) are predicates.
 __device__ __forceinline__ void tile_potrf_inv(double (*t)[CT + 1], double (*inv)[CT + 1], int h, int w, int *fail)
@@ -369,11 +369,16 @@ __device__ __forceinline__ void tile_potrf_inv(double (*t)[CT + 1], double (*inv
         const bool active = j < w;
         double acc = t[li][j];                                   // a_ij
         double dj = t[j][j];                                     // a_jj (broadcast)
+        {   // four interleaved partial sums each: the dependent chain is j / 4 adds instead of j
+            double pa[4] = {0.0, 0.0, 0.0, 0.0}, pd[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int m = 0; m < j; m++) {
-            const double ljm = t[j][m];                          // broadcast, final since step m
-            acc -= lrow[m] * ljm;
-            dj -= ljm * ljm;
+            for (int m = 0; m < j; m++) {
+                const double ljm = t[j][m];                      // broadcast, final since step m
+                pa[m & 3] += lrow[m] * ljm;
+                pd[m & 3] += ljm * ljm;
+            }
+            acc -= (pa[0] + pa[1]) + (pa[2] + pa[3]);
+            dj -= (pd[0] + pd[1]) + (pd[2] + pd[3]);
         }
         bad = bad || (active && !(dj > 0));
         dj = (active && dj > 0) ? dj : 1.0;
@@ -393,9 +398,10 @@ __device__ __forceinline__ void tile_potrf_inv(double (*t)[CT + 1], double (*inv
     double x[CT];
 #pragma unroll
     for (int i = 0; i < CT; i++) {
-        double sacc = (i == lane) ? 1.0 : 0.0;
+        double ps[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int m = 0; m < i; m++) sacc -= t[i][m] * x[m];
+        for (int m = 0; m < i; m++) ps[m & 3] += t[i][m] * x[m];
+        const double sacc = ((i == lane) ? 1.0 : 0.0) - ((ps[0] + ps[1]) + (ps[2] + ps[3]));
         x[i] = (i < w && lane <= i) ? sacc * rdiag[i] : 0.0;
     }
     if (lane < CT) {
