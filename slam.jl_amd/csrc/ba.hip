@@ -359,56 +359,72 @@ __global__ __launch_bounds__(256) void k_chol_prepare(BADev d, const double *Sin
 // dot products are formed as four interleaved partial sums (dependent chain j / 4 instead of j).
 // Every lane recomputes the pivot l_jj from row j (no communication).  Fully unrolled; tile extents
 // (h rows, w columns, wave-uniform) are predicates.
+// Called by ALL threads of the workgroup (it contains a barrier); the first two waves work: wave 0 factors, wave 1 inverts one step behind it
+// (row i of L and 1 / l_ii are final after factor step i; published through LDS with a step counter), so the
+// forward substitution hides behind the factorisation instead of following it.
 __device__ __forceinline__ void tile_potrf_inv(double (*t)[CT + 1], double (*inv)[CT + 1], int h, int w, int *fail)
 {
-    const int lane = threadIdx.x & 63, li = lane < CT ? lane : CT - 1;
-    double lrow[CT], rdiag[CT];
-    bool bad = false;
+    __shared__ double s_rdiag[CT];
+    __shared__ volatile int s_prog;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane < CT ? lane : CT - 1;
+    if (threadIdx.x == 0) s_prog = 0;
+    __syncthreads();
+    if (wv == 0) {
+        double lrow[CT];
+        bool bad = false;
 #pragma unroll
-    for (int j = 0; j < CT; j++) {
-        const bool active = j < w;
-        double acc = t[li][j];                                   // a_ij
-        double dj = t[j][j];                                     // a_jj (broadcast)
-        {   // four interleaved partial sums each: the dependent chain is j / 4 adds instead of j
-            double pa[4] = {0.0, 0.0, 0.0, 0.0}, pd[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < CT; j++) {
+            const bool active = j < w;
+            double acc = t[li][j];                                   // a_ij
+            double dj = t[j][j];                                     // a_jj (broadcast)
+            {   // four interleaved partial sums each: the dependent chain is j / 4 adds instead of j
+                double pa[4] = {0.0, 0.0, 0.0, 0.0}, pd[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int m = 0; m < j; m++) {
-                const double ljm = t[j][m];                      // broadcast, final since step m
-                pa[m & 3] += lrow[m] * ljm;
-                pd[m & 3] += ljm * ljm;
+                for (int m = 0; m < j; m++) {
+                    const double ljm = t[j][m];                      // broadcast, final since step m
+                    pa[m & 3] += lrow[m] * ljm;
+                    pd[m & 3] += ljm * ljm;
+                }
+                acc -= (pa[0] + pa[1]) + (pa[2] + pa[3]);
+                dj -= (pd[0] + pd[1]) + (pd[2] + pd[3]);
             }
-            acc -= (pa[0] + pa[1]) + (pa[2] + pa[3]);
-            dj -= (pd[0] + pd[1]) + (pd[2] + pd[3]);
+            bad = bad || (active && !(dj > 0));
+            dj = (active && dj > 0) ? dj : 1.0;
+            const double rd = rsqrt(dj);
+            const double l = (lane == j) ? dj * rd : acc * rd;
+            lrow[j] = l;
+            if (active && lane >= j && lane < CT) t[lane][j] = l;
+            if (lane == 0) s_rdiag[j] = rd;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if (lane == 0) s_prog = j + 1;
         }
-        bad = bad || (active && !(dj > 0));
-        dj = (active && dj > 0) ? dj : 1.0;
-        const double rd = rsqrt(dj);
-        rdiag[j] = rd;
-        const double l = (lane == j) ? dj * rd : acc * rd;
-        lrow[j] = l;
-        if (active && lane >= j && lane < CT) t[lane][j] = l;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    }
-    if (lane < CT) {
+        if (bad && lane == 0) *fail = 1;
+    } else if (wv == 1) {
+        // inverse: lane c solves L x = e_c by forward substitution, x in registers, row i of L as broadcast reads
+        double x[CT];
 #pragma unroll
-        for (int m = 0; m < CT; m++) if (!(m <= lane && m < w && lane < h)) t[lane][m] = 0.0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    // inverse: lane c solves L x = e_c by forward substitution, x in registers, row i of L as broadcast reads
-    double x[CT];
+        for (int i = 0; i < CT; i++) {
+            while (s_prog <= i) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            double ps[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < CT; i++) {
-        double ps[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int m = 0; m < i; m++) ps[m & 3] += t[i][m] * x[m];
+            const double sacc = ((i == lane) ? 1.0 : 0.0) - ((ps[0] + ps[1]) + (ps[2] + ps[3]));
+            x[i] = (i < w && lane <= i) ? sacc * s_rdiag[i] : 0.0;
+        }
+        if (lane < CT) {
 #pragma unroll
-        for (int m = 0; m < i; m++) ps[m & 3] += t[i][m] * x[m];
-        const double sacc = ((i == lane) ? 1.0 : 0.0) - ((ps[0] + ps[1]) + (ps[2] + ps[3]));
-        x[i] = (i < w && lane <= i) ? sacc * rdiag[i] : 0.0;
+            for (int i = 0; i < CT; i++) inv[i][lane] = (lane < w) ? x[i] : 0.0;
+        }
     }
-    if (lane < CT) {
-#pragma unroll
-        for (int i = 0; i < CT; i++) inv[i][lane] = (lane < w) ? x[i] : 0.0;
+}
+// zero everything outside the factor's lower-triangular extent (after both waves are done with the tile)
+__device__ __forceinline__ void tile_mask_lower(double (*t)[CT + 1], int h, int w)
+{
+    for (int e = threadIdx.x; e < CT * CT; e += blockDim.x) {
+        const int i = e % CT, m = e / CT;
+        if (!(m <= i && m < w && i < h)) t[i][m] = 0.0;
     }
-    if (bad && lane == 0) *fail = 1;
 }
 
 __global__ __launch_bounds__(256) void k_chol_step(BADev d, CholArgs C, double *Linv, int k, int nbr, int use_state)
@@ -481,7 +497,9 @@ __global__ __launch_bounds__(256) void k_chol_step(BADev d, CholArgs C, double *
     }
     __syncthreads();
     if (r == k + 1 && c == k + 1) {                                 // next panel's diagonal tile is final now
-        if (tid < 64) tile_potrf_inv(Arc, Tmp, hr, wc, C.fail);
+        tile_potrf_inv(Arc, Tmp, hr, wc, C.fail);
+        __syncthreads();
+        tile_mask_lower(Arc, hr, wc);
         __syncthreads();
         double *Lo = Linv + (size_t)(k + 1) * CT * CT;
         for (int e = tid; e < CT * CT; e += 256) { const int i = e % CT, j = e / CT; Lo[i + CT * j] = Tmp[i][j]; }
@@ -502,7 +520,9 @@ __global__ __launch_bounds__(256) void k_chol_first(BADev d, CholArgs C, double 
     for (int e = tid; e < CT * CT; e += 256) { const int i = e % CT, j = e / CT; t[i][j] = (i < h && j < w && i >= j) ? C.A[(size_t)i + (size_t)j * ld] : 0.0; }
     if (tid == 0) *C.fail = 0;
     __syncthreads();
-    if (tid < 64) tile_potrf_inv(t, inv, h, w, C.fail);
+    tile_potrf_inv(t, inv, h, w, C.fail);
+    __syncthreads();
+    tile_mask_lower(t, h, w);
     __syncthreads();
     for (int e = tid; e < CT * CT; e += 256) {
         const int i = e % CT, j = e / CT;
