@@ -54,6 +54,14 @@ int  slam_ctx_synchronize(slam_ctx *ctx);
  * overlaps its front-end and mapper tasks (SLAM.jl:166, mapper.jl:37-66), e.g.
  * slam_pyr_update_dev(other, next frame, sync=0) while `ctx` tracks the current one. */
 int  slam_ctx_wait_for(slam_ctx *ctx, slam_ctx *other);
+/* Markers for deeper pipelines: slam_event_record(ctx, e) marks what `ctx` has enqueued so far; slam_ctx_wait_event(ctx2, e)
+ * makes later work of ctx2 wait (on the device) for that point, even after more work has been enqueued on `ctx`
+ * (e.g. the pyramid builds of frames t+1 and t+2 are both in flight while tracking waits for t+1 only). */
+typedef struct slam_event slam_event;
+int  slam_event_create(slam_ctx *ctx, slam_event **out);
+int  slam_event_record(slam_ctx *ctx, slam_event *e);
+int  slam_ctx_wait_event(slam_ctx *ctx, slam_event *e);
+int  slam_event_destroy(slam_event *e);
 /* the ctx's hipStream_t (as void*), for callers that record HIP events on it */
 void *slam_ctx_stream(slam_ctx *ctx);
 /* message of the last failing call on ctx (ctx == NULL: last ctx-less failure) */

@@ -23,6 +23,10 @@ SIGNATURES = {
     "slam_ctx_synchronize": (cint, [vp]),
     "slam_ctx_stream": (vp, [vp]),
     "slam_ctx_wait_for": (cint, [vp, vp]),
+    "slam_event_create": (cint, [vp, C.POINTER(vp)]),
+    "slam_event_record": (cint, [vp, vp]),
+    "slam_ctx_wait_event": (cint, [vp, vp]),
+    "slam_event_destroy": (cint, [vp]),
     "slam_last_error": (C.c_char_p, [vp]),
     "slam_version": (C.c_char_p, []),
     "slam_prof_enable": (cint, [vp, cint]),
@@ -132,6 +136,16 @@ class Context:
         """Device-side: later work on this context waits for what `other` has enqueued so far."""
         self.check(self.lib.slam_ctx_wait_for(self.h, other.h))
 
+    def record(self, event=None):
+        """Marks what this context has enqueued so far; returns the Event (re-records `event` if given)."""
+        ev = event or Event(self)
+        self.check(self.lib.slam_event_record(self.h, ev.h))
+        return ev
+
+    def wait_event(self, event):
+        """Device-side: later work on this context waits for the point `event` marks on its own context."""
+        self.check(self.lib.slam_ctx_wait_event(self.h, event.h))
+
     def synchronize(self):
         self.check(self.lib.slam_ctx_synchronize(self.h))
 
@@ -154,3 +168,24 @@ def default_context(device=0):
     if device not in _default_ctx:
         _default_ctx[device] = Context(device)
     return _default_ctx[device]
+
+
+class Event:
+    """slam_event: a point in a context's stream that other contexts can wait on (Context.record / wait_event)."""
+
+    def __init__(self, ctx):
+        self.lib = ctx.lib
+        h = C.c_void_p()
+        ctx.check(ctx.lib.slam_event_create(ctx.h, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.slam_event_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

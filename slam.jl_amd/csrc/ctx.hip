@@ -143,6 +143,41 @@ int slam_ctx_wait_for(slam_ctx *ctx, slam_ctx *other)
     return SLAM_OK;
 }
 
+// Markers: "what `ctx` has enqueued up to here" as a handle another context can wait on later, after more work has been
+// enqueued on `ctx` (slam_ctx_wait_for can only name the current tail of the other stream).
+struct slam_event { hipEvent_t ev; int device; };
+int slam_event_create(slam_ctx *ctx, slam_event **out)
+{
+    ARG_TRY(ctx, ctx != nullptr && out != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    slam_event *e = new slam_event();
+    e->device = ctx->device;
+    hipError_t rc = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);
+    if (rc != hipSuccess) { delete e; return slam_fail(ctx, SLAM_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(rc)); }
+    *out = e;
+    return SLAM_OK;
+}
+int slam_event_record(slam_ctx *ctx, slam_event *e)
+{
+    ARG_TRY(ctx, ctx != nullptr && e != nullptr && e->device == ctx->device);
+    HIP_TRY(ctx, hipEventRecord(e->ev, ctx->stream));
+    return SLAM_OK;
+}
+int slam_ctx_wait_event(slam_ctx *ctx, slam_event *e)
+{
+    ARG_TRY(ctx, ctx != nullptr && e != nullptr && e->device == ctx->device);
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e->ev, 0));
+    return SLAM_OK;
+}
+int slam_event_destroy(slam_event *e)
+{
+    if (!e) return SLAM_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipEventDestroy(e->ev);
+    delete e;
+    return SLAM_OK;
+}
+
 const char *slam_last_error(slam_ctx *ctx) { return ctx ? ctx->err.c_str() : g_slam_err.c_str(); }
 
 const char *slam_version(void) { return "slamhip 0.1 gfx950"; }
