@@ -193,7 +193,7 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
     by s frames (so the S images of a step differ); key-frames fall on the same step for all streams."""
     ctx, ctx_pyr, ctx_right = slam.Context(local_rank), slam.Context(local_rank), slam.Context(local_rank)
     levels = params.pyramid_levels
-    AHEAD = int(os.environ.get("SLAM_BENCH_AHEAD", "1"))   # pyramid builds kept in flight ahead of the step being tracked (2 measured 5 % slower: two builds + LK contend for the HBM)
+    AHEAD = max(1, int(os.environ.get("SLAM_BENCH_AHEAD", "1")))   # pyramid builds kept in flight ahead of the step being tracked (2 measured 5 % slower: two builds + LK contend for the HBM)
     NLB = AHEAD + 2                                         # rotating left batches: previous, current, AHEAD in flight
     lb = [slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx) for _ in range(NLB)]
     built = [None] * NLB       # marker on the pyramid stream: "the build into this slot is complete"
@@ -207,14 +207,20 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
     kp = np.zeros((0, 2)); is3d = np.zeros(0, dtype=bool); sid = np.zeros(0, dtype=np.int32)
     cur = 0
 
+    nxt = [0]                  # next frame whose left build has not been enqueued yet
+
     def enqueue_build(frame):
         slot = frame % NLB
         lb[slot].update_(lptr(frame), sync=False, fast=fast, ctx=ctx_pyr)
         built[slot] = ctx_pyr.record(built[slot])
 
-    for f in range(AHEAD + 1):
-        enqueue_build(f)
+    def build_up_to(frame):
+        while nxt[0] <= frame:
+            enqueue_build(nxt[0]); nxt[0] += 1
+
+    build_up_to(AHEAD)
     ctx_pyr.synchronize()
+    kf_tail = os.environ.get("SLAM_BENCH_KF_TAIL", "0") != "0"     # measured 5 % slower when on
     state = dict(kp=kp, is3d=is3d, sid=sid, cur=cur, tracked=0)
 
     def step(i, pipelined=True):
@@ -222,12 +228,12 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
         st_ = state
         prevb, curb = lb[(i - 1) % NLB], lb[i % NLB]
         if not pipelined:                                   # span pass: build this step's pyramids now, serially
-            enqueue_build(i)
+            enqueue_build(i); nxt[0] = max(nxt[0], i + 1)
         if kf:
             rb.update_(rptr(i), sync=False, fast=fast, ctx=ctx_right)
         ctx.wait_event(built[i % NLB])                      # tracking needs the build of frame i only (i+1.. stay in flight)
         if pipelined:
-            enqueue_build(i + AHEAD)                        # overwrites the slot of frame i-2, which nothing reads any more
+            build_up_to(i + AHEAD)                          # overwrites the slot of a frame nothing reads any more
         kp, is3d, sid = st_["kp"], st_["is3d"], st_["sid"]
         if len(kp):
             o = (i * 7919) % (len(noise_pool) - len(kp))
@@ -246,6 +252,11 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
                 kp = np.concatenate([x for s_ in range(S) for x in (kp[a[s_]:a[s_ + 1]], fresh[b[s_]:b[s_ + 1]])])
                 is3d = np.concatenate([x for s_ in range(S) for x in (is3d[a[s_]:a[s_ + 1]], np.zeros(b[s_ + 1] - b[s_], dtype=bool))])
                 sid = np.concatenate([x for s_ in range(S) for x in (sid[a[s_]:a[s_ + 1]], fsid[b[s_]:b[s_ + 1]])])
+            if pipelined and kf_tail:
+                # the stereo match below is the tail of a key-frame step: the left / right builds are (nearly) done and the
+                # match alone does not fill the GPU, so the build of frame i+AHEAD+1 starts now (its slot held frame i-1,
+                # which the temporal match above was the last to read)
+                build_up_to(i + AHEAD + 1)
             ctx.wait_for(ctx_right)
             proj = kp + np.array([0.0, -disparity])
             _, ok = slam.optical_flow_matching_batch(curb, rb, sid, kp, is3d, proj, params, ctx=ctx)
