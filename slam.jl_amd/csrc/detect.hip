@@ -53,6 +53,31 @@ __device__ __forceinline__ double sep3(const double *src, int h, int w, int y, i
     return acc;
 }
 
+// imfilter(mask, Kernel.gaussian(sigma)) as two separable passes over the halo'd byte mask, then image .* mask.
+// acc = 0; acc += v[j] * k[j], j ascending (ImageFiltering order) in both passes.  NT > 0: tap count known at compile time.
+template <int NT>
+__device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned char *m0, const double *taps, int h, int w, int mh, int mw, int tid, int ntaps = NT)
+{
+    const int nt = NT > 0 ? NT : ntaps;
+    // dim-1 pass: T(y, tx) = sum_j m0(y+j, tx) * k[j]
+    for (int i = tid; i < h * mw; i += DET_THREADS) {
+        const int y = i % h, tx = i / h;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < nt; j++) acc += (double)m0[(y + j) + tx * mh] * taps[j];
+        T[i] = acc;
+    }
+    __syncthreads();
+    // dim-2 pass and image .* mask
+    for (int i = tid; i < h * w; i += DET_THREADS) {
+        const int y = i % h, x = i / h;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < nt; j++) acc += T[y + (x + j) * h] * taps[j];
+        bA[i] = bA[i] * acc;
+    }
+}
+
 __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
 {
     extern __shared__ double lds[];
@@ -75,6 +100,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     __shared__ int s_ri[DET_THREADS / 64];
     __shared__ int s_best;
     __shared__ int s_lim[DET_MAXR + 1];
+    __shared__ double s_taps[DET_MAXTAPS];
 
     if (h <= 0 || w <= 0 || A.k <= 0) { if (tid == 0) A.cell_cnt[cell] = 0; return; }
 
@@ -136,22 +162,12 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         }
         __syncthreads();
         if (A.ntaps > 0) {
-            // dim-1 pass: T(y, tx) = sum_j m0(y+j, tx)*k[j]  -> T (h x mw doubles)
-            double *T = bB;                                   // h*mw doubles: bB, bC and the part of bD below the byte mask (checked on host)
-            for (int i = tid; i < h * mw; i += DET_THREADS) {
-                int y = i % h, tx = i / h;
-                double acc = 0.0;
-                for (int j = 0; j < A.ntaps; j++) acc += (double)m0[(y + j) + tx * mh] * A.taps[j];
-                T[i] = acc;
-            }
+            // taps -> LDS once (indexing the kernel argument inside the tap loops costs a scalar load per tap)
+            if (tid < A.ntaps) s_taps[tid] = A.taps[tid];
             __syncthreads();
-            // dim-2 pass and image .* mask
-            for (int i = tid; i < h * w; i += DET_THREADS) {
-                int y = i % h, x = i / h;
-                double acc = 0.0;
-                for (int j = 0; j < A.ntaps; j++) acc += T[y + (x + j) * h] * A.taps[j];
-                bA[i] = bA[i] * acc;
-            }
+            double *T = bB;                                   // h*mw doubles: bB, bC and the part of bD below the byte mask (checked on host)
+            if (A.ntaps == 13) blur_mask<13>(bA, T, m0, s_taps, h, w, mh, mw, tid);      // sigma_mask = 3 (the default): unrolled
+            else blur_mask<0>(bA, T, m0, s_taps, h, w, mh, mw, tid, A.ntaps);
         } else {
             for (int i = tid; i < h * w; i += DET_THREADS) {
                 int y = i % h, x = i / h;
