@@ -302,6 +302,12 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
                         "frac_of_achievable": rb_bytes / (rows_ms / max(rows_n, 1) * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, "achievable_peak": HBM_ACHIEVABLE_GBS,
                         "avg_launch_us": rows_ms / max(rows_n, 1) * 1e3, "algorithmic_bytes_per_launch": rb_bytes, "traffic": None},
            "pyramid_batch_update_serial_us": pyr_ms / max(pyr_n, 1) * 1e3}
+    pb = S * pyramid_bytes(H, W, levels)
+    res["roofline"]["stage"] = {"name": f"pyramid update of {S} images (all kernels, serial launches)", "algorithmic_bytes": pb,
+                                "avg_us": pyr_ms / max(pyr_n, 1) * 1e3, "achieved": pb / (pyr_ms / max(pyr_n, 1) * 1e-3) / 1e9,
+                                "frac": pb / (pyr_ms / max(pyr_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "algorithmic = read the layer + write the 6 planes of every level once (SURVEY 8d); the separable filters and the "
+                                        "two-dimensional recurrences need ~40 plane passes per level, which is what the kernels are bound by"}
     for c in (ctx, ctx_pyr, ctx_right):
         c.close()
     return res
