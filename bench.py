@@ -237,14 +237,14 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
         kp, is3d, sid = st_["kp"], st_["is3d"], st_["sid"]
         if len(kp):
             o = (i * 7919) % (len(noise_pool) - len(kp))
-            proj = kp + flow_at(i)[sid] + noise_pool[o:o + len(kp)]
-            new, ok = slam.optical_flow_matching_batch(prevb, curb, sid, kp, is3d, proj, params, ctx=ctx)
-            kp, is3d, sid = new[ok], is3d[ok], sid[ok]
-            st_["tracked"] += int(ok.sum())
+            proj = flow_at(i).take(sid, axis=0); proj += kp; proj += noise_pool[o:o + len(kp)]
+            # track + drop the keypoints whose tracking failed (map_manager.jl:523-560) in one call
+            kp, is3d, sid, _ = slam.optical_flow_matching_batch_kept(prevb, curb, sid, kp, is3d, proj, params, ctx=ctx)
+            st_["tracked"] += len(kp)
         if kf:
             if len(kp):
-                keep = rng.random(len(kp)) >= CULL_FRACTION
-                kp, is3d, sid = kp[keep], is3d[keep], sid[keep]
+                keep = np.flatnonzero(rng.random(len(kp)) >= CULL_FRACTION)
+                kp, is3d, sid = kp.take(keep, axis=0), is3d.take(keep), sid.take(keep)
             fresh, fsid = slam.detect_batch(extractor, curb, kp, sid, ctx=ctx)       # kp is kept grouped by stream
             if len(fresh):
                 a = np.searchsorted(sid, np.arange(S + 1)); b = np.searchsorted(fsid, np.arange(S + 1))
@@ -259,7 +259,7 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
                 build_up_to(i + AHEAD + 1)
             ctx.wait_for(ctx_right)
             proj = kp + np.array([0.0, -disparity])
-            _, ok = slam.optical_flow_matching_batch(curb, rb, sid, kp, is3d, proj, params, ctx=ctx)
+            _, ok = slam.optical_flow_matching_batch(curb, rb, sid, kp, is3d, proj, params, ctx=ctx, status_only=True)
             is3d = is3d | ok
         st_["kp"], st_["is3d"], st_["sid"] = kp, is3d, sid
 

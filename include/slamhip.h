@@ -198,6 +198,15 @@ int slam_flow_match_batch(slam_ctx *ctx, const slam_pyr *from0, const slam_pyr *
                           const double *pts_yx, const uint8_t *is_3d, const double *proj_yx, int n,
                           int pyramid_levels, int pyramid_levels_3d, int window, int iterations,
                           double eig_thr, double eps, double max_distance, double *out_yx, uint8_t *status);
+/* slam_flow_match_batch followed by the list surgery of optical_flow_matching! (map_manager.jl:523-560): the keypoints
+ * whose tracking succeeded, in input order, with their new positions (kept_yx), 3-D flags, stream indices and input
+ * indices (kept_src); arrays sized for n entries.  status (n, nullable) reports every input keypoint. */
+int slam_flow_match_batch_kept(slam_ctx *ctx, const slam_pyr *from0, const slam_pyr *to0, int S, const int32_t *img_index,
+                               const double *pts_yx, const uint8_t *is_3d, const double *proj_yx, int n,
+                               int pyramid_levels, int pyramid_levels_3d, int window, int iterations,
+                               double eig_thr, double eps, double max_distance,
+                               double *kept_yx, uint8_t *kept_is3d, int32_t *kept_img, int32_t *kept_src, int *n_kept,
+                               uint8_t *status);
 
 /* ---- bundle adjustment ------------------------------------------------------ */
 /* Array-level body of triangulate_stereo! (parallax == NULL: every gate applies, src/mapper.jl:142-183) and

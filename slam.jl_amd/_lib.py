@@ -53,6 +53,7 @@ SIGNATURES = {
     "slam_pyr_update_batch_dev": (cint, [vp, C.POINTER(vp), C.POINTER(vp), cint, cint, dbl, cint]),
     "slam_pyr_update_batch_u8_dev": (cint, [vp, C.POINTER(vp), C.POINTER(vp), cint, cint, dbl, cint]),
     "slam_flow_match_batch": (cint, [vp, vp, vp, cint, i32p, f64p, u8p, f64p, cint, cint, cint, cint, cint, dbl, dbl, dbl, f64p, u8p]),
+    "slam_flow_match_batch_kept": (cint, [vp, vp, vp, cint, i32p, f64p, u8p, f64p, cint, cint, cint, cint, cint, dbl, dbl, dbl, f64p, u8p, i32p, i32p, C.POINTER(cint), u8p]),
     "slam_local_ba": (cint, [vp, dbl, dbl, dbl, dbl, cint, cint, cint, f64p, u8p, f64p, i64p, i64p, u8p, cint, cint, dbl, f64p]),
     "slam_pnp_ba": (cint, [vp, dbl, dbl, dbl, dbl, f64p, f64p, f64p, cint, cint, cint, dbl, dbl, f64p, f64p, f64p, u8p, C.POINTER(cint)]),
     "slam_ba_create": (cint, [vp, dbl, dbl, dbl, dbl, cint, cint, cint, f64p, u8p, f64p, i64p, i64p, C.POINTER(vp)]),

@@ -15,6 +15,7 @@
 // CPU oracle (sum_order = 1) and is bit-reproducible; it differs from the
 // reference's single-accumulator order only in rounding (<= 1e-12 px observed).
 #include "common.hpp"
+#include <vector>
 #include <cmath>
 
 struct LKArgs {
@@ -517,4 +518,36 @@ extern "C" int slam_flow_match_batch(slam_ctx *ctx, const slam_pyr *from0, const
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return run_tracking(ctx, from0, to0, pts_yx, proj_yx, is_3d, n, pyramid_levels, pyramid_levels_3d, window, iterations, eig_thr, eps,
                         max_distance, out_yx, status, true, img_index);
+}
+
+// slam_flow_match_batch followed by the list surgery of optical_flow_matching! (map_manager.jl:523-560: keypoints whose
+// tracking failed are removed, the others take their new position), as a stable compaction on the host side of the
+// call: kept_* hold the surviving keypoints in input order (kept_src[k] = their index in the input lists).  The
+// arrays must have room for n entries.  status (n bytes, nullable) still reports every input keypoint.
+extern "C" int slam_flow_match_batch_kept(slam_ctx *ctx, const slam_pyr *from0, const slam_pyr *to0, int S, const int32_t *img_index,
+                                          const double *pts_yx, const uint8_t *is_3d, const double *proj_yx, int n,
+                                          int pyramid_levels, int pyramid_levels_3d, int window, int iterations,
+                                          double eig_thr, double eps, double max_distance,
+                                          double *kept_yx, uint8_t *kept_is3d, int32_t *kept_img, int32_t *kept_src, int *n_kept, uint8_t *status)
+{
+    ARG_TRY(ctx, ctx != nullptr && n_kept != nullptr);
+    *n_kept = 0;
+    if (n == 0) return SLAM_OK;
+    ARG_TRY(ctx, n > 0 && kept_yx != nullptr && kept_is3d != nullptr && kept_img != nullptr && kept_src != nullptr);
+    // run_tracking leaves positions and status in the context's pinned block; compact straight out of it
+    std::vector<uint8_t> st_local;
+    uint8_t *st = status;
+    if (!st) { st_local.resize((size_t)n); st = st_local.data(); }
+    int rc = slam_flow_match_batch(ctx, from0, to0, S, img_index, pts_yx, is_3d, proj_yx, n, pyramid_levels, pyramid_levels_3d, window, iterations,
+                                   eig_thr, eps, max_distance, kept_yx, st);
+    if (rc) return rc;
+    int k = 0;
+    for (int i = 0; i < n; i++)
+        if (st[i]) {
+            kept_yx[2 * k] = kept_yx[2 * i]; kept_yx[2 * k + 1] = kept_yx[2 * i + 1];      // k <= i: in-place stable compaction
+            kept_is3d[k] = is_3d[i]; kept_img[k] = img_index[i]; kept_src[k] = i;
+            k++;
+        }
+    *n_kept = k;
+    return SLAM_OK;
 }

@@ -201,7 +201,7 @@ class PyramidBatch:
 
 
 def optical_flow_matching_batch(from_batch, to_batch, stream_index, pixels, is_3d, projections, params,
-                                pyramid_levels_3d=1, iterations=30, ctx=None):
+                                pyramid_levels_3d=1, iterations=30, ctx=None, status_only=False):
     """optical_flow_matching! for S lock-stepped streams in one launch (slam_flow_match_batch): point i belongs to
     stream stream_index[i]; pyramids from_batch.pyramids[s] -> to_batch.pyramids[s].  Returns (new_pixels, status)."""
     ctx = ctx or from_batch.ctx
@@ -221,4 +221,31 @@ def optical_flow_matching_batch(from_batch, to_batch, stream_index, pixels, is_3
         raise RuntimeError("Not enough layers in pyramids.")
     ctx.check(rc)
     st = status.view(np.bool_)
+    if status_only:                                   # e.g. stereo matching: only the flags are used (mapper.jl:58-66)
+        return None, st
     return np.where(st[:, None], out, pixels), st
+
+
+def optical_flow_matching_batch_kept(from_batch, to_batch, stream_index, pixels, is_3d, projections, params,
+                                     pyramid_levels_3d=1, iterations=30, ctx=None):
+    """optical_flow_matching_batch + removal of the keypoints whose tracking failed (slam_flow_match_batch_kept): returns
+    (new_pixels (k, 2), is_3d (k,) bool, stream_index (k,) int32, source_index (k,) int32) of the survivors, in input order."""
+    ctx = ctx or from_batch.ctx
+    pixels = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
+    n = len(pixels)
+    if n == 0:
+        return pixels.copy(), np.zeros(0, dtype=bool), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32)
+    idx = np.ascontiguousarray(stream_index, dtype=np.int32)
+    is3 = np.ascontiguousarray(is_3d, dtype=np.uint8) if np.asarray(is_3d).dtype != np.bool_ else np.ascontiguousarray(is_3d).view(np.uint8)
+    proj = np.ascontiguousarray(projections, dtype=np.float64).reshape(-1, 2)
+    out = np.empty((n, 2)); k3 = np.empty(n, dtype=np.uint8); kimg = np.empty(n, dtype=np.int32); ksrc = np.empty(n, dtype=np.int32)
+    nk = C.c_int(0)
+    rc = ctx.lib.slam_flow_match_batch_kept(ctx.h, from_batch.pyramids[0].h, to_batch.pyramids[0].h, from_batch.S, L.ptr(idx, L.i32p),
+                                            L.ptr(pixels), L.ptr(is3, L.u8p), L.ptr(proj), n, params.pyramid_levels, pyramid_levels_3d,
+                                            params.window_size, iterations, 1e-4, 1e-2, float(params.max_ktl_distance),
+                                            L.ptr(out), L.ptr(k3, L.u8p), L.ptr(kimg, L.i32p), L.ptr(ksrc, L.i32p), C.byref(nk), None)
+    if rc == -3:
+        raise RuntimeError("Not enough layers in pyramids.")
+    ctx.check(rc)
+    k = nk.value
+    return out[:k], k3[:k].view(np.bool_), kimg[:k], ksrc[:k]

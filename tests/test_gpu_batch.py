@@ -165,3 +165,28 @@ def test_batch_at_fhd_size_stays_exact(slam):
         for l in range(4):
             for name in PLANES:
                 assert np.array_equal(batch.pyramids[s].plane(name, l), single.plane(name, l)), (s, name, l)
+
+
+def test_flow_match_batch_kept_is_the_compaction_of_flow_match_batch(slam, texture):
+    import torch
+    H, W, S = 120, 160, 3
+    streams = [texture(H, W, seed=10 + s, step=(1.0 + 0.3 * s, -1.5)) for s in range(S)]
+    a = slam.PyramidBatch((H, W), levels=3, S=S); b = slam.PyramidBatch((H, W), levels=3, S=S)
+    d0 = [torch.from_numpy(np.ascontiguousarray(st[0][0].T)).cuda() for st in streams]
+    d1 = [torch.from_numpy(np.ascontiguousarray(st[0][1].T)).cuda() for st in streams]
+    torch.cuda.synchronize()
+    a.update_([d.data_ptr() for d in d0]); b.update_([d.data_ptr() for d in d1])
+    params = slam.Params()
+    rng = np.random.default_rng(8)
+    n = 400
+    pts = np.stack([rng.uniform(1, H, n), rng.uniform(1, W, n)], axis=1)      # many of these fail (borders, flat areas)
+    idx = np.sort(rng.integers(0, S, n)).astype(np.int32)
+    is3 = rng.random(n) < 0.6
+    proj = pts + np.array([1.0, -1.5])
+    new, ok = slam.optical_flow_matching_batch(a, b, idx, pts, is3, proj, params)
+    kp, k3, kidx, src = slam.optical_flow_matching_batch_kept(a, b, idx, pts, is3, proj, params)
+    assert 0 < ok.sum() < n
+    assert np.array_equal(src, np.flatnonzero(ok))
+    assert np.array_equal(kp, new[ok]) and np.array_equal(k3, is3[ok]) and np.array_equal(kidx, idx[ok])
+    _, ok2 = slam.optical_flow_matching_batch(a, b, idx, pts, is3, proj, params, status_only=True)
+    assert np.array_equal(ok2, ok)
