@@ -201,9 +201,11 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
     seq = frame_sequence(steps + warmup + 60 + S)
     rng = np.random.default_rng(1234)
     noise_pool = rng.normal(0, 0.5, (1 << 17, 2))          # prior noise, drawn once (synthetic-input generation, not SLAM work)
-    lptr = lambda i: [left_dev[seq[i + s]].data_ptr() for s in range(S)]
-    rptr = lambda i: [right_dev[seq[i + s]].data_ptr() for s in range(S)]
-    flow_at = lambda i: np.array([np.array(flows[seq[i + s]]) - np.array(flows[seq[i - 1 + s]]) for s in range(S)])
+    seq_a = np.asarray(seq); flows_a = np.asarray(flows, dtype=np.float64)
+    lp = [t.data_ptr() for t in left_dev]; rp = [t.data_ptr() for t in right_dev]
+    lptr = lambda i: [lp[f] for f in seq[i:i + S]]
+    rptr = lambda i: [rp[f] for f in seq[i:i + S]]
+    flow_at = lambda i: flows_a[seq_a[i:i + S]] - flows_a[seq_a[i - 1:i - 1 + S]]
     kp = np.zeros((0, 2)); is3d = np.zeros(0, dtype=bool); sid = np.zeros(0, dtype=np.int32)
     cur = 0
 
