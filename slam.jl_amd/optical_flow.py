@@ -48,11 +48,12 @@ class LKPyramid:
         self.ctx.check(self.ctx.lib.slam_pyr_shape(self.h, level, C.byref(H), C.byref(W)))
         return H.value, W.value
 
-    def plane(self, name, level):
-        """Download one plane (for parity tests); level 0-based; H x W Fortran array."""
+    def plane(self, name, level, ctx=None):
+        """Download one plane (for parity tests); level 0-based; H x W Fortran array.  `ctx`: the context whose stream does the copy."""
         H, W = self.level_shape(level)
         out = np.empty((H, W), order="F")
-        self.ctx.check(self.ctx.lib.slam_pyr_download(self.ctx.h, self.h, PLANES.index(name), level, L.ptr(out)))
+        c = ctx or self.ctx
+        c.check(c.lib.slam_pyr_download(c.h, self.h, PLANES.index(name), level, L.ptr(out)))
         return out
 
     def close(self):

@@ -190,3 +190,31 @@ def test_flow_match_batch_kept_is_the_compaction_of_flow_match_batch(slam, textu
     assert np.array_equal(kp, new[ok]) and np.array_equal(k3, is3[ok]) and np.array_equal(kidx, idx[ok])
     _, ok2 = slam.optical_flow_matching_batch(a, b, idx, pts, is3, proj, params, status_only=True)
     assert np.array_equal(ok2, ok)
+
+
+def test_event_markers_order_two_contexts(slam, texture):
+    """slam_event_record / slam_ctx_wait_event: a consumer context waits for a marked point of a producer context's
+    stream although more work has been enqueued behind it."""
+    import torch
+    H, W = 200, 300
+    imgs = [texture(H, W, seed=s)[0][0] for s in range(3)]
+    dev = [torch.from_numpy(np.ascontiguousarray(im.T)).cuda() for im in imgs]
+    torch.cuda.synchronize()
+    prod, cons = slam.Context(0), slam.Context(0)
+    pyr = [slam.LKPyramid(shape=(H, W), levels=3, ctx=prod) for _ in range(3)]
+    marks = []
+    for k in range(3):                                   # three asynchronous builds, one marker each
+        slam.update_(pyr[k], None, device_ptr=dev[k].data_ptr(), sync=False, ctx=prod)
+        marks.append(prod.record())
+    cons.wait_event(marks[0])
+    got0 = pyr[0].plane("Iyx", 3, ctx=cons)           # copied on the consumer's stream, ordered by the marker only
+    prod.synchronize()
+    for k in range(3):
+        ref = slam.LKPyramid(shape=(H, W), levels=3)
+        slam.update_(ref, imgs[k])
+        assert np.array_equal(pyr[k].plane("Iyx", 3), ref.plane("Iyx", 3))
+        if k == 0:
+            assert np.array_equal(got0, ref.plane("Iyx", 3))
+    for m in marks:
+        m.close()
+    prod.close(); cons.close()
