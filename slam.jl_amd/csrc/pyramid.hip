@@ -29,6 +29,7 @@ struct PlaneSet {
     const double *nrm[4];  // optional NA() normaliser (divide at the end), or nullptr
     int coef[4];           // which IIRCoef (0 = pyramid sigma, 1 = sigma 4)
     int fill0[4];          // border: 0 replicate, 1 Fill(0)
+    const double *sq[4];   // k_iir_cols_ck only: if set, the plane's input is sq[k] squared (Iyy = Iy * Iy, Ixx = Ix * Ix formed on the fly)
     int n;
     size_t zs;             // batch: image blockIdx.z lives zs doubles after image 0 (0 for a single pyramid)
 };
@@ -40,6 +41,7 @@ __device__ __forceinline__ double *ps_plane(const PlaneSet &ps, int pl) { return
 __device__ __forceinline__ const double *ps_nrm(const PlaneSet &ps, int pl) { return PS_PICK(ps, nrm, pl); }
 __device__ __forceinline__ int ps_coef(const PlaneSet &ps, int pl) { return PS_PICK(ps, coef, pl); }
 __device__ __forceinline__ bool ps_fill0(const PlaneSet &ps, int pl) { return PS_PICK(ps, fill0, pl) != 0; }
+__device__ __forceinline__ const double *ps_sq(const PlaneSet &ps, int pl) { const double *q = PS_PICK(ps, sq, pl); return q ? q + (size_t)blockIdx.z * ps.zs : nullptr; }
 
 struct IIRPair { IIRCoef c[2]; };
 
@@ -495,7 +497,9 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_cols_ck(PlaneSet ps, const
     __shared__ __attribute__((aligned(16))) double tile[64 * COL_LS];
     const int pl = blockIdx.y, lane = threadIdx.x & 63;
     ColIO<2> io;
-    io.dst = ps_plane(ps, pl); io.src = (pl == 0 && src0) ? src0 : io.dst;
+    const double *sqsrc = ps_sq(ps, pl);                       // squared input (Iy -> Iyy, Ix -> Ixx), or nullptr
+    const bool sq = sqsrc != nullptr;
+    io.dst = ps_plane(ps, pl); io.src = sq ? sqsrc : ((pl == 0 && src0) ? src0 : io.dst);
     io.H = H; io.W = W; io.P = P; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile;
     const size_t nlines = (size_t)gridDim.z * gridDim.y * gridDim.x * LINE_THREADS;
     const size_t lineid = (((size_t)blockIdx.z * gridDim.y + pl) * gridDim.x + blockIdx.x) * LINE_THREADS + lane;
@@ -503,12 +507,13 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_cols_ck(PlaneSet ps, const
     const IIRCoef &k = ps_coef(ps, pl) == 0 ? cf.c[0] : cf.c[1];
     const bool fill0 = ps_fill0(ps, pl);
     const double a1 = k.a1, a2 = k.a2, a3 = k.a3, scale = k.scale;
-    const double x0 = io.ld_src(0);
-    const double iminus = fill0 ? 0.0 : x0, iplus = fill0 ? 0.0 : io.ld_src(n - 1);
+    auto in = [&](double v) { return sq ? v * v : v; };
+    const double x0 = in(io.ld_src(0));
+    const double iminus = fill0 ? 0.0 : x0, iplus = fill0 ? 0.0 : in(io.ld_src(n - 1));
     const double uminus = iminus / k.inv1masum;
     const double o0 = ((x0 + a1 * uminus) + a2 * uminus) + a3 * uminus;
-    const double o1 = ((io.ld_src(1) + a1 * o0) + a2 * uminus) + a3 * uminus;
-    const double o2 = ((io.ld_src(2) + a1 * o1) + a2 * o0) + a3 * uminus;
+    const double o1 = ((in(io.ld_src(1)) + a1 * o0) + a2 * uminus) + a3 * uminus;
+    const double o2 = ((in(io.ld_src(2)) + a1 * o1) + a2 * o0) + a3 * uminus;
     double w3 = o0, w2 = o1, w1 = o2;
     double raw[32], x[32];
     // ---- pass A: forward over rows 3 .. n-1, read only; checkpoint before rows 32 b (b >= 1) ----
@@ -518,6 +523,10 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_cols_ck(PlaneSet ps, const
         for (int t = 0; t < NT; t++) {
             const int rb = t << 4;
             io.lds_put_tile(raw); io.template lds_get_col<+1>(x);
+            if (sq) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) x[e] = x[e] * x[e];
+            }
             if (t + 1 < NT) io.tile_load(io.src, rb + 16, raw);
             if ((t & 1) == 0 && t >= 2) { double *c = ck + ((size_t)(t >> 1) * 3) * nlines + lineid; c[0] = w1; c[nlines] = w2; c[2 * nlines] = w3; }
             if (rb >= 3 && rb + 15 <= n - 1) {
@@ -554,6 +563,10 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_cols_ck(PlaneSet ps, const
         const bool two = 2 * b + 1 < ntile;
         io.lds_put_tile(raw); io.template lds_get_col<+1>(x);
         if (two) { io.lds_put_tile(raw + 16); io.template lds_get_col<+1>(x + 16); }
+        if (sq) {
+#pragma unroll
+            for (int e = 0; e < 32; e++) x[e] = x[e] * x[e];
+        }
         if (b > 0) load_block(b - 1);
         double f1, f2, f3;
         if (b > 0) { const double *c = ck + ((size_t)b * 3) * nlines + lineid; f1 = c[0]; f2 = c[nlines]; f3 = c[2 * nlines]; }
@@ -925,7 +938,7 @@ __device__ __forceinline__ ColTerm scharr_col(const double *L, int H, int W, int
     t.s += a * sk[0]; t.s += b * sk[1]; t.s += c * sk[2];
     return t;
 }
-__global__ __launch_bounds__(64) void k_scharr_products(LevelView v, int border, size_t zs)
+__global__ __launch_bounds__(64) void k_scharr_products(LevelView v, int border, size_t zs, int squares)
 {
     { const size_t z = (size_t)blockIdx.z * zs; v.L += z; v.Iy += z; v.Ix += z; v.Iyy += z; v.Ixx += z; v.Iyx += z; }
     const int H = v.H, W = v.W, P = v.P;
@@ -941,7 +954,8 @@ __global__ __launch_bounds__(64) void k_scharr_products(LevelView v, int border,
         ix += t0.s * dk[0]; ix += t1.s * dk[1]; ix += t2.s * dk[2];
         const size_t i = (size_t)y + (size_t)x * P;
         v.Iy[i] = iy; v.Ix[i] = ix;
-        v.Iyy[i] = iy * iy; v.Ixx[i] = ix * ix; v.Iyx[i] = iy * ix;
+        if (squares) { v.Iyy[i] = iy * iy; v.Ixx[i] = ix * ix; }      // 0: the checkpointed column kernel squares Iy / Ix itself
+        v.Iyx[i] = iy * ix;
         t0 = t1; t1 = t2;
     }
 }
@@ -1091,13 +1105,19 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         const LevelView &v = p->view.lv[l];
         const bool has_next = l + 1 < p->levels;
         double *T = p->tmp + p->off[l];
-        hipLaunchKernelGGL(k_scharr_products, dim3((H + 63) / 64, (W + SCH_XC - 1) / SCH_XC, S), dim3(64), 0, st, v, border_mode, zs);
+        // bandwidth-bound launches (many images x a large level) take the checkpointed IIR kernels; the column one squares
+        // Iy / Ix itself, so the gradient kernel does not write (and the filter does not re-read) the Iyy / Ixx inputs
+        const int np_ = has_next ? 4 : 3;
+        const bool ck_cols = !fast && p->ck != nullptr && mode != 0 && H >= 64 && (size_t)S * np_ * H * W * 8 >= ck_min_bytes() && getenv("SLAMHIP_NO_CK_COLS") == nullptr;
+        static const bool no_sq = getenv("SLAMHIP_NO_SQ_FUSE") != nullptr;
+        const bool fuse_sq = ck_cols && !no_sq;
+        hipLaunchKernelGGL(k_scharr_products, dim3((H + 63) / 64, (W + SCH_XC - 1) / SCH_XC, S), dim3(64), 0, st, v, border_mode, zs, fuse_sq ? 0 : 1);
         // dim-1 IIR: [blur: L -> T], Iyy, Ixx, Iyx in place
         PlaneSet ps = {};
         int np = 0;
         if (has_next) { ps.p[np] = T; ps.coef[np] = 0; ps.fill0[np] = (mode == 0); ps.nrm[np] = (mode == 0) ? p->norm + p->off[l] : nullptr; np++; }
-        ps.p[np] = v.Iyy; ps.coef[np] = 1; np++;
-        ps.p[np] = v.Ixx; ps.coef[np] = 1; np++;
+        ps.p[np] = v.Iyy; ps.coef[np] = 1; ps.sq[np] = fuse_sq ? v.Iy : nullptr; np++;
+        ps.p[np] = v.Ixx; ps.coef[np] = 1; ps.sq[np] = fuse_sq ? v.Ix : nullptr; np++;
         ps.p[np] = v.Iyx; ps.coef[np] = 1; np++;
         ps.n = np; ps.zs = zs;
         const double *src0 = has_next ? (const double *)v.L : (const double *)nullptr;
@@ -1120,7 +1140,6 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             hipLaunchKernelGGL(k_cum_seg<false>, gr3, dim3(PAR_T), 0, aux, pc, H, W, P, slr);
             continue;
         }
-        const bool ck_cols = p->ck != nullptr && mode != 0 && H >= 64 && (size_t)S * np * H * W * 8 >= ck_min_bytes() && getenv("SLAMHIP_NO_CK_COLS") == nullptr;
         if (ck_cols) hipLaunchKernelGGL(k_iir_cols_ck, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf, p->ck);
         else if (S == 1) hipLaunchKernelGGL(k_iir_cols<3>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
         else hipLaunchKernelGGL(k_iir_cols<2>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
