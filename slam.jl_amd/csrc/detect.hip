@@ -142,23 +142,42 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         // raw mask over the halo'd tile (replicate = clamped coordinates) -> bB (as 0/1 doubles)
         // the halo'd raw mask is stored as bytes
         unsigned char *m0 = (unsigned char *)(lds + 4 * n) - ((mh * mw + 7) & ~7);   // byte mask at the tail of bD (sizes checked on host)
-        for (int i = tid; i < mh * mw; i += DET_THREADS) {
-            int ty = i % mh, tx = i / mh;
-            int yy = clampi(y0 + ty - hw, 0, H - 1) + 1, xx = clampi(x0 + tx - hw, 0, W - 1) + 1; // 1-based
-            unsigned char m = 1;
-            if (!overflow) {
-                for (int c = 0; c < ncand; c++) {
-                    const int dy = abs(yy - s_cand[2 * c]), dx = abs(xx - s_cand[2 * c + 1]);
-                    if (dy <= r && dx <= s_lim[dy]) { m = 0; break; }
+        if (!overflow) {
+            // Rasterised: the mask starts as ones, every (candidate, disk row) pair clears its x-interval (ImageDraw draws
+            // in-image pixels only), then halo pixels outside the image replicate the border pixel they clamp to.  Same
+            // mask as testing every pixel against every candidate, ~5x fewer LDS operations.
+            for (int i = tid; i < mh * mw; i += DET_THREADS) m0[i] = 1;
+            __syncthreads();
+            const int nrow = 2 * r + 1, ty0 = y0 - hw, tx0 = x0 - hw;
+            for (int q = tid; q < ncand * nrow; q += DET_THREADS) {
+                const int c = q / nrow, dyi = q % nrow - r;
+                const int yy = s_cand[2 * c] + dyi, px = s_cand[2 * c + 1];      // 1-based image coordinates
+                const int lim = s_lim[abs(dyi)];
+                const int ty = (yy - 1) - ty0;
+                if (yy < 1 || yy > H || lim < 0 || ty < 0 || ty >= mh) continue;
+                int txa = (max(px - lim, 1) - 1) - tx0, txb = (min(px + lim, W) - 1) - tx0;
+                txa = txa < 0 ? 0 : txa; txb = txb > mw - 1 ? mw - 1 : txb;
+                for (int tx = txa; tx <= txb; tx++) m0[ty + tx * mh] = 0;
+            }
+            __syncthreads();
+            if (ty0 < 0 || ty0 + mh - 1 > H - 1 || tx0 < 0 || tx0 + mw - 1 > W - 1) {        // border cell: replicate
+                for (int i = tid; i < mh * mw; i += DET_THREADS) {
+                    const int uy = ty0 + i % mh, ux = tx0 + i / mh;
+                    if (uy < 0 || uy > H - 1 || ux < 0 || ux > W - 1)
+                        m0[i] = m0[(clampi(uy, 0, H - 1) - ty0) + (clampi(ux, 0, W - 1) - tx0) * mh];
                 }
-            } else {
+            }
+        } else {
+            for (int i = tid; i < mh * mw; i += DET_THREADS) {
+                const int yy = clampi(y0 + i % mh - hw, 0, H - 1) + 1, xx = clampi(x0 + i / mh - hw, 0, W - 1) + 1; // 1-based
+                unsigned char m = 1;
                 for (int c = 0; c < A.n_cur; c++) {
                     long py = (long)rint(A.cur[2 * c]), px = (long)rint(A.cur[2 * c + 1]);
                     const long dy = labs(yy - py), dx = labs(xx - px);
                     if (dy <= r && dx <= s_lim[dy]) { m = 0; break; }
                 }
+                m0[i] = m;
             }
-            m0[i] = m;
         }
         __syncthreads();
         if (A.ntaps > 0) {
