@@ -3,7 +3,7 @@
 // Replaces detect / get_mask / _shi_tomasi of the reference
 // (src/extractor.jl:24-42, 63-95, 116-122).  One workgroup per grid cell: the
 // cell's pixels, the avoidance-mask halo and every intermediate plane live in
-// LDS (four cell-sized planes: the separable Sobel and box stages are evaluated
+// LDS (four cell-sized planes; the avoidance mask is rasterised per disk row; the separable Sobel and box stages are evaluated
 // per pixel from the 3x3 neighbourhood with exactly the two-stage arithmetic,
 // so no intermediate plane is stored and four workgroups share a CU); HBM traffic is one read of the image plus the keypoint lists, i.e. the
 // algorithmic minimum (8*H*W + 16*(K + n_out) bytes).  Keypoint order and
