@@ -98,3 +98,35 @@ def test_optical_flow_matching_protocol(slam, orc, texture):
     assert np.array_equal(st, st2) and np.array_equal(new, new2)             # one launch == the reference's two calls
     assert st.mean() > 0.6
     assert np.abs(np.median((new - kp)[st], 0) - np.array(flows[1])).max() < 0.05
+
+
+@pytest.mark.parametrize("window", [2, 5, 6, 7, 12])
+def test_fb_tracking_other_window_sizes(slam, orc, texture, window):
+    """Kernel instantiations: <= 6 -> 3 slots per lane, <= 9 -> 6, <= 11 -> 9, larger -> uncached path."""
+    H, W = 120, 160
+    L, R, flows = texture(H, W)
+    g, r = _pyrs(slam, orc, L)
+    kp = orc.detect(L[0], np.zeros((0, 2)), max_points=200).astype(float)
+    kp = kp + np.random.default_rng(window).uniform(0, 0.99, kp.shape)
+    kp = np.clip(kp, 1, [H, W])
+    out, st = _check(slam, orc, g, r, kp, window=window)
+    assert st.any()
+
+
+def test_ill_conditioned_windows_with_zero_eigenvalue_threshold(slam, orc):
+    """eig_thr = 0 lets rank-deficient windows through to pinv2x2: an image that varies along x only has Iy = 0, so
+    every window's G is singular.  The device evaluates the pseudo-inverse in closed form (projectors), the oracle
+    with the reference's atan/sincos construction: same tracks."""
+    H, W = 90, 140
+    x = np.arange(W)[None, :] * np.ones((H, 1))
+    imgs = [np.asfortranarray(0.5 + 0.4 * np.sin(0.23 * (x - s))) for s in (0.0, 0.6)]
+    g, r = _pyrs(slam, orc, imgs, levels=2)
+    rng = np.random.default_rng(3)
+    pts = np.stack([rng.uniform(15, H - 15, 60), rng.uniform(15, W - 15, 60)], axis=1)
+    out, st = slam.fb_tracking_(g[0], g[1], pts, pyramid_levels=2, window_size=9, max_distance=1.0, eigenvalue_threshold=0.0)
+    o1, s1 = orc.fb_tracking(r[0], r[1], pts, None, 30, 9, 2, 0.0, 1e-2, 1.0, sum_order=1)
+    assert np.array_equal(st, s1)
+    assert st.any()
+    assert np.abs(out[st] - o1[st]).max() <= 1e-7
+    assert np.abs((out - pts)[st][:, 1].mean() - 0.6) < 0.05       # the shift along x is recovered, nothing along y
+    assert np.abs((out - pts)[st][:, 0]).max() < 1e-6
