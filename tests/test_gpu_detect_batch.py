@@ -5,7 +5,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("S", [1, 3, 8])
+@pytest.mark.parametrize("S", [1, 3, 8, 40])
 def test_detect_batch_equals_per_stream(slam, syn, S):
     H, W = 188, 620
     imgs = [np.asfortranarray(syn.texture_canvas(H, W, seed=50 + s, margin=0)) for s in range(S)]
