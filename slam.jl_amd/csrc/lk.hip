@@ -158,10 +158,11 @@ __device__ __forceinline__ double wave_sum(double v)
 // window) and 9 (<= 11) slots so that the register footprint follows the window; larger windows take the
 // uncached path.
 // The template samples live in LDS (a private [plane][slot][lane] spill area of the single-wave workgroup, 9 KB
-// for 6 slots, no barriers); only the packed window coordinates stay in registers (163 VGPRs -> 3 waves per SIMD
-// for the default window).  Measured (scripts/lk_trace.py, rocprofv3 --pmc): a point executes ~6k wave
-// instructions as one dependent stream (~16 cycles each); L1-miss latency averages 400 cycles with only 2-3
-// misses outstanding per wave, so the kernel is bound by that instruction stream, not by HBM or the L1.
+// for 6 slots, no barriers); only the packed window coordinates stay in registers.  With the footprint loads issued in two
+// halves and pinv2x2's fallback in closed form the default-window kernel needs 115 VGPRs -> 4 waves per SIMD (16 per CU,
+// which is also what the 9 KB of LDS per wave allow).  Measured (scripts/lk_trace.py, rocprofv3 --pmc): a point executes
+// ~5k wave instructions as one dependent stream (~18 cycles each), VALU 33 % busy; L1-miss latency averages 400
+// cycles with only 2-3 misses outstanding per wave, so the kernel is bound by that instruction stream, not by HBM or L1.
 template <int LK_MAXE> struct Tmpl {
     double (*s)[LK_MAXE][64];      // LDS: s[0] = template samples, s[1] = Iy, s[2] = Ix
     int pq[LK_MAXE];               // window coordinates p | q << 16 of slot k (0 | 0 past the window)
