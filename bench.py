@@ -511,6 +511,23 @@ def main():
                                  "ms_per_iter_wall": wall * 1e3 / max(st["iters_pass1"] + st["iters_pass2"], 1),
                                  "worth_sharding": bool(sharded_ba.worth_sharding(100, s2["O"], world)), "ssr_final": st["ssr_final"]}
 
+    # ---- compute_pose! arithmetic (front_end.jl:164-206): P3P RANSAC (256 triples, 1000 map points) + PnP refinement ----
+    if not args.no_ba:
+        ps = syn.p3p_scene(n=1000, seed=3, noise_px=0.4, outlier_frac=0.25, iters=256)
+        Kc = ps["K"]; camp = (Kc[0, 0], Kc[1, 1], Kc[0, 2], Kc[1, 2])
+        def pose_once():
+            cnt, (KP, inl, err, Rt, bi) = slam.p3p_ransac(ps["pts3d"], ps["px_xy"], ps["pdn"], Kc, threshold=3.0,
+                                                            samples=ps["samples"], return_pose=True, ctx=ctx)
+            T0 = np.eye(4); T0[:3] = Rt
+            slam.pnp_bundle_adjustment(camp, T0, ps["px_xy"][inl][:, ::-1], ps["pts3d"][inl], repr_eps=3.0, ctx=ctx)
+            return cnt
+        pose_once()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            cnt = pose_once()
+        out["pose"] = {"points": 1000, "ransac_triples": 256, "inliers": int(cnt), "ms_per_call": (time.perf_counter() - t0) / 20 * 1e3,
+                       "what": "slam_p3p_ransac + slam_pnp_ba, host arrays in and out (wall clock)"}
+
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----------
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import oracle as orc
@@ -538,6 +555,14 @@ def main():
             out["ba"]["cpu_ms_per_iter_reference_style_lm_lsmr"] = c0
             out["ba"]["cpu_ms_per_iter_schur"] = c1
             out["ba"]["cpu_cores"] = 1
+            ps = syn.p3p_scene(n=1000, seed=3, noise_px=0.4, outlier_frac=0.25, iters=256)
+            t0 = time.perf_counter()
+            cnt, KP, Rt, inl, err, bi = orc.p3p_ransac(ps["pts3d"], ps["px_xy"], ps["pdn"], ps["K"], 3.0, ps["samples"])
+            T0 = np.eye(4); T0[:3] = Rt
+            Kc = ps["K"]
+            orc.pnp_ba((Kc[0, 0], Kc[1, 1], Kc[0, 2], Kc[1, 2]), T0, ps["px_xy"][inl][:, ::-1], ps["pts3d"][inl], repr_eps=3.0)
+            out["pose"]["cpu_ms_per_call"] = (time.perf_counter() - t0) * 1e3
+            out["pose"]["cpu_cores"] = 1
 
     if rank == 0:
         print(json.dumps(out))

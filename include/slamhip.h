@@ -224,6 +224,20 @@ int slam_triangulate(slam_ctx *ctx, const double *P1, const double *P2, const do
                      const double *parallax, double min_parallax,
                      double *out_xyz, uint8_t *status);
 
+/* p3p_ransac(points, pixels, pdn, K; threshold) of compute_pose! (src/front_end.jl:164-167; result consumed at
+ * :174-186: n_inliers, (KP, inliers, error)).  pts3d n x 3 map points, px_xy n x 2 undistorted pixels in (x, y)
+ * order (front_end.jl:150-151), pdn n x 3 bearing vectors normalize(kp.position) (:149), K 3x3 column-major.
+ * `samples`: iters x 3 point indices, 0-BASED, drawn by the caller (the reference's RNG stream cannot be
+ * reproduced outside Julia; same convention as the BRIEF pattern) -- every triple is solved (Grunert P3P, up to
+ * 4 poses) and scored on the GPU, one workgroup per triple; triples with a repeated or out-of-range index are
+ * skipped.  Winner: most inliers (depth > 0 and reprojection error < threshold), ties to the lower iteration.
+ * KP = K [R | t] (3x4 column-major; the reference recovers the pose as iK * KP, :182), Rt = [R | t] itself (may be
+ * NULL), inliers n bytes, *error = sum of the inliers' reprojection errors (may be NULL), *best_iter (may be NULL).
+ * *n_inliers = 0 (and zeros elsewhere) when no triple gave a pose -- the reference's `res === nothing` branch. */
+int slam_p3p_ransac(slam_ctx *ctx, const double *pts3d, const double *px_xy, const double *pdn, int n,
+                    const double *K, double threshold, const int32_t *samples, int iters,
+                    double *KP, double *Rt, uint8_t *inliers, int *n_inliers, double *error, int *best_iter);
+
 /* bundle_adjustment!(cache::LocalBACache, camera; iterations, repr_eps) --
  * src/bundle_adjustment.jl:1-111 on the flat arrays of src/estimator.jl:16-40:
  * theta = [6P (RotZYX t1,t2,t3, tx,ty,tz) ; 3M], pixels (y,x) 2 x O, 1-based ids.

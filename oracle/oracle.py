@@ -27,7 +27,7 @@ u64p = C.POINTER(C.c_uint64)
 
 def build(force=False):
     so = os.path.join(_HERE, "libslam_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orc_image.c", "orc_lk.c", "orc_ba.c", "orc_tri.c", "slam_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_image.c", "orc_lk.c", "orc_ba.c", "orc_tri.c", "orc_p3p.c", "slam_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libslam_oracle.so"])
     return so
@@ -314,3 +314,35 @@ def sym4_min_eigvec(S):
     v = np.zeros(4)
     lib().orc_sym4_min_eigvec(_p(S), _p(v))
     return v
+
+
+def quartic_real_roots(A):
+    """Real roots of A[4] x^4 + ... + A[0] (orc_p3p.c)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    r = np.zeros(4)
+    n = lib().orc_quartic_real_roots(_p(A), _p(r))
+    return r[:n]
+
+
+def p3p_solve(X, F):
+    """Minimal solver: X 3x3 world points (rows), F 3x3 bearing vectors (rows) -> list of 3x4 [R | t]."""
+    X = np.ascontiguousarray(X, dtype=np.float64); F = np.ascontiguousarray(F, dtype=np.float64)
+    Rt = np.zeros(48)
+    ns = lib().orc_p3p_solve(_p(X), _p(F), _p(Rt))
+    return [Rt[12 * s:12 * s + 12].reshape(4, 3).T.copy() for s in range(ns)]
+
+
+def p3p_ransac(pts3d, px_xy, pdn, K, threshold, samples):
+    """p3p_ransac of compute_pose! (front_end.jl:164-167) over caller-supplied 0-based sample triples.
+    Returns (n_inliers, KP 3x4, Rt 3x4, inliers bool, error, best_iter)."""
+    pts = np.ascontiguousarray(pts3d, dtype=np.float64).reshape(-1, 3)
+    px = np.ascontiguousarray(px_xy, dtype=np.float64).reshape(-1, 2)
+    bd = np.ascontiguousarray(pdn, dtype=np.float64).reshape(-1, 3)
+    Kf = np.asfortranarray(K, dtype=np.float64)
+    sm = np.ascontiguousarray(samples, dtype=np.int32).reshape(-1, 3)
+    n = len(pts)
+    KP = np.zeros((3, 4), order="F"); Rt = np.zeros((3, 4), order="F")
+    inl = np.zeros(n, dtype=np.uint8); err = C.c_double(); bi = C.c_int()
+    cnt = lib().orc_p3p_ransac(_p(pts), _p(px), _p(bd), n, _p(Kf), C.c_double(threshold), _p(sm, i32p), len(sm),
+                               _p(KP), _p(Rt), _p(inl, u8p), C.byref(err), C.byref(bi))
+    return cnt, np.array(KP), np.array(Rt), inl.astype(bool), err.value, bi.value

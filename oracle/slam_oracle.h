@@ -177,6 +177,13 @@ int  orc_triangulate(const double *P1, const double *P2, const double *T21, cons
                      const double *px1_yx, const double *px2_yx, int n, double max_error, double min_depth,
                      const double *parallax, double min_parallax, double *out_xyz, unsigned char *status);
 
+/* ---- P3P RANSAC of compute_pose! (front_end.jl:132-219; RecoverPose.p3p_ransac restated) -- orc_p3p.c ---- */
+int  orc_quartic_real_roots(const double A[5], double roots[4]);
+int  orc_p3p_solve(const double X[9], const double F[9], double Rt[48]);
+int  orc_p3p_ransac(const double *pts3d, const double *px_xy, const double *pdn, int n, const double *K, double threshold,
+                    const int32_t *samples, int iters, double *KP, double *Rt_out, unsigned char *inliers, double *error,
+                    int *best_iter);
+
 #ifdef __cplusplus
 }
 #endif

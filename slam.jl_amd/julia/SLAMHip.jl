@@ -22,6 +22,7 @@ using SLAM
 using SLAM: Extractor, LKPyramid, LKCache, Point2f, Camera
 using StaticArrays
 using Images: Gray
+using Random: randperm
 
 const LIB = Ref{String}("libslamhip.so")
 
@@ -212,6 +213,29 @@ function hip_triangulate(cam1::Camera, cam2::Camera, P1::SMatrix{4, 4, Float64},
          Cdouble, Cdouble, Ptr{Float64}, Cdouble, Ptr{Float64}, Ptr{UInt8}),
         ctx(), p1, p2, t, c1, c2, a, b, n, Float64(max_error), Float64(min_depth), par, Float64(min_parallax), out, st))
     [SVector{3, Float64}(out[3i - 2], out[3i - 1], out[3i]) for i in 1:n], Bool[s != 0 for s in st[1:n]]
+end
+
+# p3p_ransac of compute_pose! (front_end.jl:164-167): same positional arguments and result shape as
+# RecoverPose.p3p_ransac -- `(n_inliers, (KP, inliers, error))`, or `nothing` when no sample gave a pose.  The
+# sample triples are drawn here (Julia's RNG) and handed to the library 0-based; `iterations` triples are all scored.
+function hip_p3p_ransac(points, pixels, pdn_positions, K; threshold = 1.0, iterations = 256)
+    n = length(points)
+    pts = collect(reinterpret(Float64, collect(SVector{3, Float64}.(points))))
+    px = collect(reinterpret(Float64, collect(SVector{2, Float64}.(pixels))))       # already (x, y), front_end.jl:151
+    pdn = collect(reinterpret(Float64, collect(SVector{3, Float64}.(pdn_positions))))
+    k = Vector{Float64}(vec(SMatrix{3, 3, Float64}(K)))
+    smp = Vector{Int32}(undef, 3 * iterations)
+    for it in 0:iterations - 1
+        smp[3it + 1:3it + 3] .= Int32.(randperm(n)[1:3] .- 1)
+    end
+    kp = Vector{Float64}(undef, 12); inl = Vector{UInt8}(undef, max(n, 1))
+    cnt = Ref{Cint}(0); err = Ref{Cdouble}(0.0)
+    GC.@preserve pts px pdn k smp kp inl check(ccall((:slam_p3p_ransac, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Cdouble, Ptr{Int32}, Cint,
+         Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Ref{Cint}, Ref{Cdouble}, Ptr{Cint}),
+        ctx(), pts, px, pdn, n, k, Float64(threshold), smp, iterations, kp, C_NULL, inl, cnt, err, C_NULL))
+    cnt[] == 0 && return nothing
+    Int(cnt[]), (SMatrix{3, 4, Float64}(kp), Bool[i != 0 for i in inl[1:n]], err[])
 end
 
 """

@@ -170,3 +170,28 @@ def triangulation_scene(n=500, seed=0, baseline=0.54, noise_px=0.0, n_behind=0, 
     if n_gross:
         px2[gross, 0] += rng.choice([-1.0, 1.0], n_gross) * rng.uniform(30, 60, n_gross)
     return dict(cam=(fx, fy, cx, cy), T21=T, px1=px1, px2=px2, xyz=X, behind=behind, gross=gross)
+
+
+def p3p_scene(n=400, seed=0, noise_px=0.3, outlier_frac=0.2, iters=256):
+    """Input of compute_pose! (front_end.jl:138-167): n map points seen by a KITTI camera at a known pose.
+    Returns pts3d (n, 3) world, px_xy (n, 2) (x, y) as P3P expects, pdn (n, 3) normalised bearing vectors of the
+    (noisy) pixels, K (3x3), Rt_gt (3x4, x_cam = R X + t), `gross` (indices given a 15-60 px displacement) and
+    `samples` (iters, 3) int32 0-based distinct triples (the caller-side RNG draw)."""
+    rng = np.random.default_rng(0xB3B + seed)
+    fx, fy, cx, cy = KITTI_CAM
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    R = rotzyx(0.04, -0.07, 0.025); t = np.array([0.4, -0.15, 0.8])
+    u = rng.uniform(20, 1221, n); v = rng.uniform(20, 356, n); z = rng.uniform(4, 50, n)
+    Xc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], 1)
+    Xw = (Xc - t) @ R
+    px = np.stack([u, v], 1)
+    if noise_px:
+        px = px + rng.normal(0, noise_px, (n, 2))
+    gross = np.sort(rng.choice(n, int(round(outlier_frac * n)), replace=False))
+    ang = rng.uniform(0, 2 * np.pi, len(gross)); mag = rng.uniform(15.0, 60.0, len(gross))
+    px[gross, 0] += mag * np.cos(ang); px[gross, 1] += mag * np.sin(ang)
+    bear = np.stack([(px[:, 0] - cx) / fx, (px[:, 1] - cy) / fy, np.ones(n)], 1)
+    pdn = bear / np.linalg.norm(bear, axis=1, keepdims=True)
+    samples = np.stack([rng.permutation(n)[:3] for _ in range(iters)]).astype(np.int32)
+    return dict(pts3d=np.ascontiguousarray(Xw), px_xy=np.ascontiguousarray(px), pdn=np.ascontiguousarray(pdn), K=K,
+                Rt_gt=np.concatenate([R, t[:, None]], 1), gross=gross, samples=samples)
