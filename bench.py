@@ -527,6 +527,17 @@ def main():
             cnt = pose_once()
         out["pose"] = {"points": 1000, "ransac_triples": 256, "inliers": int(cnt), "ms_per_call": (time.perf_counter() - t0) / 20 * 1e3,
                        "what": "slam_p3p_ransac + slam_pnp_ba, host arrays in and out (wall clock)"}
+        # compute_pose_5pt! arithmetic (front_end.jl:305-308): five-point RANSAC, 128 5-tuples, 1000 correspondences
+        fs = syn.five_point_scene(n=1000, seed=3, noise_px=0.4, outlier_frac=0.25, iters=128)
+        def fp_once():
+            return slam.five_point_ransac(fs["px1"], fs["px2"], fs["pd1"], fs["pd2"], fs["K"], fs["K"], max_repr_error=3.0,
+                                          samples=fs["samples"], ctx=ctx)[0]
+        fp_once()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            cnt5 = fp_once()
+        out["pose"]["five_point"] = {"points": 1000, "ransac_tuples": 128, "inliers": int(cnt5),
+                                     "ms_per_call": (time.perf_counter() - t0) / 10 * 1e3}
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----------
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -534,10 +545,10 @@ def main():
         threads = max(1, min(4, os.cpu_count() or 1))                 # the reference recommends -t4 (docs/src/index.md:60-64)
         cbe = CpuBackend(orc, left, right, params, extractor, threads)
         cs = Stream(cbe, flows, disparity, seed=0)
-        cseq = frame_sequence(16)
+        cseq = frame_sequence(600)
         cbe.prime(cseq[0])
         n_cpu = 0; t0 = time.perf_counter()
-        while n_cpu < 15 and (time.perf_counter() - t0 < 25 or n_cpu < 6):
+        while n_cpu < 600 and (time.perf_counter() - t0 < 12 or n_cpu < 6):      # ~12 s of CPU work
             cs.step(cseq[n_cpu], cseq[n_cpu + 1], None); n_cpu += 1
         cdt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": n_cpu / cdt, "unit": "frames/sec", "cores": threads, "kind": "port",
@@ -563,6 +574,10 @@ def main():
             orc.pnp_ba((Kc[0, 0], Kc[1, 1], Kc[0, 2], Kc[1, 2]), T0, ps["px_xy"][inl][:, ::-1], ps["pts3d"][inl], repr_eps=3.0)
             out["pose"]["cpu_ms_per_call"] = (time.perf_counter() - t0) * 1e3
             out["pose"]["cpu_cores"] = 1
+            fs = syn.five_point_scene(n=1000, seed=3, noise_px=0.4, outlier_frac=0.25, iters=128)
+            t0 = time.perf_counter()
+            orc.five_point_ransac(fs["px1"], fs["px2"], fs["pd1"], fs["pd2"], fs["K"], fs["K"], 3.0, fs["samples"])
+            out["pose"]["five_point"]["cpu_ms_per_call"] = (time.perf_counter() - t0) * 1e3
 
     if rank == 0:
         print(json.dumps(out))

@@ -238,6 +238,22 @@ int slam_p3p_ransac(slam_ctx *ctx, const double *pts3d, const double *px_xy, con
                     const double *K, double threshold, const int32_t *samples, int iters,
                     double *KP, double *Rt, uint8_t *inliers, int *n_inliers, double *error, int *best_iter);
 
+/* five_point_ransac(previous_points, current_points, previous_pd, current_pd, K, K, cache; max_repr_error) of
+ * compute_pose_5pt! (src/front_end.jl:305-308; result consumed at :305-331: n_inliers, (_, P, inliers, _)).
+ * px1/px2: n x 2 undistorted pixels (x, y) of the previous key-frame / the current frame (:271-272), pd1/pd2:
+ * n x 2 normalised coordinates position[[1, 2]] (:273-274), K1/K2 3x3 column-major.  `samples`: iters x 5 point
+ * indices, 0-BASED, drawn by the caller; every 5-tuple is solved (Nister's five-point algorithm, <= 10 essential
+ * matrices; pose of each by Horn's closed form + cheirality on the five points) and scored on the GPU: a
+ * correspondence is an inlier iff its DLT triangulation lies in front of both cameras and both reprojection
+ * errors are < max_repr_error.  Winner: most inliers, ties to the earlier tuple.
+ * E: 3x3 column-major (may be NULL), P = [R | t] 3x4 column-major, previous -> current, |t| = 1 (the caller
+ * rescales t, front_end.jl:321-329), inliers n bytes, *error = sum of both errors over the inliers (may be
+ * NULL), *best_iter (may be NULL).  *n_inliers = 0 when no tuple gave a pose. */
+int slam_five_point_ransac(slam_ctx *ctx, const double *px1_xy, const double *px2_xy, const double *pd1_xy,
+                           const double *pd2_xy, int n, const double *K1, const double *K2, double max_repr_error,
+                           const int32_t *samples, int iters, double *E, double *P, uint8_t *inliers,
+                           int *n_inliers, double *error, int *best_iter);
+
 /* bundle_adjustment!(cache::LocalBACache, camera; iterations, repr_eps) --
  * src/bundle_adjustment.jl:1-111 on the flat arrays of src/estimator.jl:16-40:
  * theta = [6P (RotZYX t1,t2,t3, tx,ty,tz) ; 3M], pixels (y,x) 2 x O, 1-based ids.

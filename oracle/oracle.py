@@ -27,7 +27,7 @@ u64p = C.POINTER(C.c_uint64)
 
 def build(force=False):
     so = os.path.join(_HERE, "libslam_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orc_image.c", "orc_lk.c", "orc_ba.c", "orc_tri.c", "orc_p3p.c", "slam_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_image.c", "orc_lk.c", "orc_ba.c", "orc_tri.c", "orc_p3p.c", "orc_5pt.c", "slam_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libslam_oracle.so"])
     return so
@@ -346,3 +346,42 @@ def p3p_ransac(pts3d, px_xy, pdn, K, threshold, samples):
     cnt = lib().orc_p3p_ransac(_p(pts), _p(px), _p(bd), n, _p(Kf), C.c_double(threshold), _p(sm, i32p), len(sm),
                                _p(KP), _p(Rt), _p(inl, u8p), C.byref(err), C.byref(bi))
     return cnt, np.array(KP), np.array(Rt), inl.astype(bool), err.value, bi.value
+
+
+def poly_real_roots(p):
+    """Ascending real roots of p[0] + p[1] x + ... (degree <= 10; orc_5pt.c)."""
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    r = np.zeros(10)
+    n = lib().orc_poly_real_roots(_p(p), len(p) - 1, _p(r))
+    return r[:n]
+
+
+def five_point_solve(q1, q2):
+    """Nister's minimal solver: q1, q2 (5, 2) normalised (x, y) with q2' E q1 = 0 -> list of 3x3 E."""
+    a = np.ascontiguousarray(q1, dtype=np.float64).reshape(5, 2); b = np.ascontiguousarray(q2, dtype=np.float64).reshape(5, 2)
+    Es = np.zeros(90)
+    ne = lib().orc_five_point_solve(_p(a), _p(b), _p(Es))
+    return [Es[9 * i:9 * i + 9].reshape(3, 3).copy() for i in range(ne)]
+
+
+def essential_poses(E):
+    """The four [R | t] (3x4) of an essential matrix."""
+    E = np.ascontiguousarray(E, dtype=np.float64)
+    Rt = np.zeros(48)
+    k = lib().orc_essential_poses(_p(E), _p(Rt))
+    return [Rt[12 * i:12 * i + 12].reshape(4, 3).T.copy() for i in range(k)]
+
+
+def five_point_ransac(px1_xy, px2_xy, pd1_xy, pd2_xy, K1, K2, max_repr_error, samples):
+    """five_point_ransac of compute_pose_5pt! (front_end.jl:305-308) over caller-supplied 0-based 5-tuples.
+    Returns (n_inliers, E 3x3, P 3x4, inliers bool, error, best_iter)."""
+    a = np.ascontiguousarray(px1_xy, dtype=np.float64).reshape(-1, 2); b = np.ascontiguousarray(px2_xy, dtype=np.float64).reshape(-1, 2)
+    c = np.ascontiguousarray(pd1_xy, dtype=np.float64).reshape(-1, 2); d = np.ascontiguousarray(pd2_xy, dtype=np.float64).reshape(-1, 2)
+    k1 = np.asfortranarray(K1, dtype=np.float64); k2 = np.asfortranarray(K2, dtype=np.float64)
+    sm = np.ascontiguousarray(samples, dtype=np.int32).reshape(-1, 5)
+    n = len(a)
+    E = np.zeros((3, 3), order="F"); P = np.zeros((3, 4), order="F")
+    inl = np.zeros(max(n, 1), dtype=np.uint8); err = C.c_double(); bi = C.c_int()
+    cnt = lib().orc_five_point_ransac(_p(a), _p(b), _p(c), _p(d), n, _p(k1), _p(k2), C.c_double(max_repr_error), _p(sm, i32p), len(sm),
+                                      _p(E), _p(P), _p(inl, u8p), C.byref(err), C.byref(bi))
+    return cnt, np.array(E), np.array(P), inl[:n].astype(bool), err.value, bi.value

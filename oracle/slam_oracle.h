@@ -184,6 +184,15 @@ int  orc_p3p_ransac(const double *pts3d, const double *px_xy, const double *pdn,
                     const int32_t *samples, int iters, double *KP, double *Rt_out, unsigned char *inliers, double *error,
                     int *best_iter);
 
+/* ---- five-point RANSAC of compute_pose_5pt! (front_end.jl:243-332; RecoverPose.five_point_ransac restated) -- orc_5pt.c ---- */
+int  orc_poly_real_roots(const double *p, int deg, double *roots);
+int  orc_five_point_solve(const double q1[10], const double q2[10], double Es[90]);
+int  orc_essential_poses(const double E[9], double Rt[48]);
+int  orc_essential_pose_cheirality(const double E[9], const double q1[10], const double q2[10], double Rt[12]);
+int  orc_five_point_ransac(const double *px1, const double *px2, const double *pd1, const double *pd2, int n,
+                           const double *K1, const double *K2, double max_repr_error, const int32_t *samples, int iters,
+                           double *E_out, double *P_out, unsigned char *inliers, double *error, int *best_iter);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,4 +15,4 @@ from .optical_flow import (LKPyramid, LucasKanade, update_, copy_, deepcopy, has
                            optical_flow_matching_batch_kept)
 from .bundle_adjustment import LocalBACache, bundle_adjustment_, pnp_bundle_adjustment  # noqa: F401
 from .triangulation import triangulate, projection_matrices  # noqa: F401
-from .pose import p3p_ransac, draw_samples  # noqa: F401
+from .pose import p3p_ransac, five_point_ransac, draw_samples  # noqa: F401

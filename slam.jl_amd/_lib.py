@@ -37,6 +37,7 @@ SIGNATURES = {
     "slam_detect_batch": (cint, [vp, vp, cint, f64p, i32p, cint, cint, cint, cint, cint, dbl, dbl, i64p, cint, i32p]),
     "slam_triangulate": (cint, [vp, f64p, f64p, f64p, f64p, f64p, f64p, f64p, cint, dbl, dbl, f64p, dbl, f64p, u8p]),
     "slam_p3p_ransac": (cint, [vp, f64p, f64p, f64p, cint, f64p, dbl, i32p, cint, f64p, f64p, u8p, C.POINTER(cint), f64p, C.POINTER(cint)]),
+    "slam_five_point_ransac": (cint, [vp, f64p, f64p, f64p, f64p, cint, f64p, f64p, dbl, i32p, cint, f64p, f64p, u8p, C.POINTER(cint), f64p, C.POINTER(cint)]),
     "slam_describe": (cint, [vp, f64p, cint, cint, i64p, cint, i32p, cint, dbl, cint, u64p, i64p, C.POINTER(cint)]),
     "slam_pyr_create": (cint, [vp, cint, cint, cint, C.POINTER(vp)]),
     "slam_pyr_destroy": (cint, [vp]),

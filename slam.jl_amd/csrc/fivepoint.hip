@@ -1,0 +1,686 @@
+// fivepoint.hip -- five-point essential-matrix RANSAC of compute_pose_5pt! (src/front_end.jl:243-332; the call
+// five_point_ransac(previous_points, current_points, previous_pd, current_pd, K, K, cache; max_repr_error) at :305-308).
+//
+// Three kernels on the context's stream:
+//   k_5pt_solve   one 16-lane team per caller-supplied 5-tuple (lane 0 owns the sequential phases, the team shares
+//                 the root search, one bracketing interval per lane): Nister's minimal solver (null space of the 5x9 system,
+//                 the ten cubics by polynomial arithmetic, Gauss-Jordan in Nister's monomial order, det B(z) of
+//                 degree 10, real roots bracketed between the derivative's roots), then Horn's closed-form pose of
+//                 each essential matrix with cheirality on the five sample points.  Only + - * / sqrt: the
+//                 hypotheses are bit-identical to the CPU statement.  The 10x20 elimination matrix and the
+//                 derivative table live in LDS, one column of doubles per thread.
+//   k_5pt_score   one 256-thread workgroup per (5-tuple, pose): the threads stride over the correspondences -- DLT
+//                 triangulation (4x4 Jacobi, the mapper's `triangulate`), both depths > 0, both reprojection
+//                 errors < max_repr_error -- and a butterfly + LDS add the inlier counts.
+//   k_5pt_select  one workgroup: winner (most inliers, ties to the earlier tuple, then root), inlier mask, summed
+//                 error, E and [R | t].
+// ~iters x 5 x n triangulations of ~3 kflop each (256 x 5 x 1000: 4 Gflop f64): compute-bound on the f64 VALU.
+#include "common.hpp"
+#include "tri_device.hpp"
+#include <cmath>
+
+#define FP_TEAM 16                      // lanes per 5-tuple in the solver (one bracketing interval each in the root search)
+#define FP_TPB 4                        // 5-tuples per solver workgroup (one 64-lane wave)
+#define FP_MAXE 10
+#define FP_SCORE_T 256                 // scoring threads per (5-tuple, pose)
+#define FP_SEL_T 512                   // threads of the select kernel
+#define FP_ERR_LDS 4096                 // correspondences whose errors the select kernel stages in LDS
+
+struct FPArgs {
+    const double *px1, *px2, *pd1, *pd2;   // n x 2 each, (x, y)
+    const int32_t *samples;                // iters x 5, 0-based
+    int n, iters;
+    double k1[4], k2[4];                   // fx, fy, cx, cy
+    double thr;
+    int *ne;                               // iters: number of poses of the tuple
+    double *Es;                            // iters x 10 x 9 (row-major E)
+    double *poses;                         // iters x 10 x 12
+    int *counts;                           // iters x 10
+    double *errs;                          // n
+    double *E_out, *P_out, *error;         // outputs (mapped host)
+    uint8_t *inliers;
+    int *n_inliers, *best_iter;
+};
+
+// per-thread array in LDS: element i of thread t at base[i * FP_TPB + t]
+struct Col {
+    double *b;
+    __device__ double &operator[](int i) const { return b[i * FP_TPB]; }
+    __device__ Col at(int off) const { return Col{b + off * FP_TPB}; }
+};
+
+static __device__ const int c_T2[4][4] = {{0, 1, 2, 6}, {1, 3, 4, 7}, {2, 4, 5, 8}, {6, 7, 8, 9}};
+static __device__ const int c_T3[10][4] = {{0, 2, 4, 5}, {2, 3, 8, 9}, {4, 8, 10, 11}, {3, 1, 6, 7}, {8, 6, 13, 14},
+                                {10, 13, 16, 17}, {5, 9, 11, 12}, {9, 7, 14, 15}, {11, 14, 17, 18}, {12, 15, 18, 19}};
+
+template <class A, class B, class O> __device__ static inline void mul11(const A &a, const B &b, O &o)
+{
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) o[c_T2[i][j]] += a[i] * b[j];
+}
+template <class A, class B, class O> __device__ static inline void mul21(const A &a, const B &b, O &o)
+{
+    for (int i = 0; i < 10; i++) for (int j = 0; j < 4; j++) o[c_T3[i][j]] += a[i] * b[j];
+}
+template <class A> __device__ static inline void minor2(const A &a, const A &b, const A &c, const A &d, double *o)
+{
+    double t1[10], t2[10];
+    for (int i = 0; i < 10; i++) { t1[i] = 0.0; t2[i] = 0.0; }
+    mul11(a, b, t1); mul11(c, d, t2);
+    for (int i = 0; i < 10; i++) o[i] = t1[i] - t2[i];
+}
+__device__ static inline void pmul(const double *a, int na, const double *b, int nb, double *o)
+{
+    for (int i = 0; i < na + nb - 1; i++) o[i] = 0.0;
+    for (int i = 0; i < na; i++) for (int j = 0; j < nb; j++) o[i + j] += a[i] * b[j];
+}
+template <class P> __device__ static inline double peval(const P &p, int deg, double x)
+{
+    double f = p[deg];
+    for (int i = deg - 1; i >= 0; i--) f = f * x + p[i];
+    return f;
+}
+
+// Horner with the coefficients in registers: p[deg] ... p[0], deg <= 10 (same operations as peval)
+__device__ static inline double peval_r(const double (&p)[11], int deg, double x)
+{
+    double f = 0.0;
+#pragma unroll
+    for (int i = 10; i >= 0; i--) {
+        if (i == deg) f = p[i];
+        else if (i < deg) f = f * x + p[i];
+    }
+    return f;
+}
+
+__device__ static double bracket_root(const double (&p)[11], const double (&dp)[11], int deg, double lo, double hi, double flo)
+{
+    double x = 0.5 * (lo + hi);
+    for (int it = 0; it < 200; it++) {
+        const double f = peval_r(p, deg, x);
+        if (f == 0.0) return x;
+        if ((f < 0.0) == (flo < 0.0)) lo = x; else hi = x;
+        const double df = peval_r(dp, deg - 1, x);
+        double xn = x - f / df;
+        if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
+        if (xn == x || xn == lo || xn == hi) return xn;
+        x = xn;
+    }
+    return x;
+}
+
+// Owner part of the root finder: derivative table D (11 x 11, row k = k-th derivative) and the root of the linear
+// derivative in crit = D.at(121); the effective degree goes to D[143] (0: nothing to solve).
+__device__ static void roots_prepare(const double *p, int deg, Col D)
+{
+    D[143] = 0.0;
+    while (deg > 0 && p[deg] == 0.0) deg--;
+    if (deg <= 0 || deg > 10) return;
+    for (int i = 0; i <= deg; i++) D[i] = p[i];
+    for (int k = 1; k < deg; k++)
+        for (int i = 0; i <= deg - k; i++) D[11 * k + i] = (double)(i + 1) * D[11 * (k - 1) + i + 1];
+    const double c0 = -D[11 * (deg - 1)] / D[11 * (deg - 1) + 1];
+    D[121] = c0;
+    if (isfinite(c0)) D[143] = (double)deg;
+}
+
+// Team part: the FP_TEAM lanes of a 5-tuple take one bracketing interval each, level by level (the roots of the
+// (k+1)-th derivative bracket those of the k-th).  Every lane performs exactly the operations the sequential
+// statement performs for its interval, and the roots are compacted in interval order, so the result is the same
+// list.  Must be called by all threads of the workgroup (it synchronises).  Returns the number of real roots of
+// the polynomial, left ascending in crit = D.at(121).
+__device__ static int team_real_roots(Col D, int l, int team)
+{
+    const Col crit = D.at(121);
+    int deg = (int)D[143];
+    int nc = deg > 0 ? 1 : 0;
+    for (int k = 8; k >= 0; k--) {
+        const bool act = deg >= 2 && k <= deg - 2;        // team-uniform
+        bool found = false, fail = false;
+        double root = 0.0;
+        if (act && l <= nc) {
+            const int d = deg - k, j = l;
+            double q[11], dq[11];
+#pragma unroll
+            for (int i = 0; i < 11; i++) { q[i] = i <= d ? D[11 * k + i] : 0.0; dq[i] = i < d ? D[11 * (k + 1) + i] : 0.0; }
+            double qd = 0.0;
+#pragma unroll
+            for (int i = 0; i < 11; i++) if (i == d) qd = q[i];
+            double bound = 0.0;
+#pragma unroll
+            for (int i = 0; i < 10; i++) if (i < d) { const double c = fabs(q[i] / qd); if (c > bound) bound = c; }
+            bound = bound + 1.0;
+            if (!isfinite(bound)) fail = true;
+            else {
+                double lo = -bound;                       // the sequential scan's `lo`: running maximum of the accepted ends
+                for (int i = 0; i < j; i++) { const double c = crit[i]; if (c > lo) lo = c; }
+                const double hi = j < nc ? crit[j] : bound;
+                if (hi > lo) {
+                    const double flo = peval_r(q, d, lo), fhi = peval_r(q, d, hi);
+                    if (flo != 0.0 && fhi != 0.0 && (flo < 0.0) != (fhi < 0.0)) {
+                        // an end that is only the Cauchy bound can be astronomically far from the root: walk towards
+                        // it from the finite end with doubling steps until the sign change is enclosed
+                        double a = lo, fa = flo, b = hi;
+                        bool a_far = j == 0, b_far = j == nc, hit = false;
+                        if (a_far && b_far) {
+                            const double f0 = peval_r(q, d, 0.0);
+                            if (f0 == 0.0) hit = true;
+                            else if ((f0 < 0.0) == (fa < 0.0)) { a = 0.0; fa = f0; a_far = false; }
+                            else { b = 0.0; b_far = false; }
+                        }
+                        if (!hit && a_far) {
+                            double h = fabs(b) > 1.0 ? fabs(b) : 1.0;
+                            for (int it = 0; it < 1100; it++) {
+                                const double x = b - h;
+                                if (!(x > a)) break;
+                                const double fx = peval_r(q, d, x);
+                                if (fx == 0.0) { hit = true; root = x; break; }
+                                if ((fx < 0.0) == (fa < 0.0)) { a = x; fa = fx; break; }
+                                b = x; h = 2.0 * h;
+                            }
+                        } else if (!hit && b_far) {
+                            double h = fabs(a) > 1.0 ? fabs(a) : 1.0;
+                            for (int it = 0; it < 1100; it++) {
+                                const double x = a + h;
+                                if (!(x < b)) break;
+                                const double fx = peval_r(q, d, x);
+                                if (fx == 0.0) { hit = true; root = x; break; }
+                                if ((fx < 0.0) != (fa < 0.0)) { b = x; break; }
+                                a = x; fa = fx; h = 2.0 * h;
+                            }
+                        }
+                        if (!hit) root = bracket_root(q, dq, d, a, b, fa);
+                        found = true;
+                    }
+                    else if (fhi == 0.0 && j < nc) { found = true; root = hi; }
+                }
+            }
+        }
+        const unsigned long long mf = __ballot(found), mx = __ballot(fail);
+        const unsigned tf = (unsigned)(mf >> (FP_TEAM * team)) & ((1u << FP_TEAM) - 1u);
+        const bool tfail = ((mx >> (FP_TEAM * team)) & ((1ull << FP_TEAM) - 1ull)) != 0;
+        __syncthreads();                                  // every lane has read crit
+        if (found && !tfail) crit[__popc(tf & ((1u << l) - 1u))] = root;
+        if (act) nc = tfail ? 0 : __popc(tf);
+        if (tfail) deg = 0;
+        __syncthreads();
+    }
+    return nc;
+}
+
+// A: 5 x 9 (LDS), N: 4 x 9 (LDS)
+__device__ static bool nullspace_5x9(Col A, Col N)
+{
+    int piv[5]; unsigned used = 0;
+    for (int s = 0; s < 5; s++) {
+        int pr = -1, pc = -1; double best = 0.0;
+        for (int r = s; r < 5; r++)
+            for (int c = 0; c < 9; c++)
+                if (!((used >> c) & 1) && fabs(A[9 * r + c]) > best) { best = fabs(A[9 * r + c]); pr = r; pc = c; }
+        if (pr < 0) return false;
+        if (pr != s) for (int c = 0; c < 9; c++) { const double t = A[9 * s + c]; A[9 * s + c] = A[9 * pr + c]; A[9 * pr + c] = t; }
+        piv[s] = pc; used |= 1u << pc;
+        const double inv = 1.0 / A[9 * s + pc];
+        for (int c = 0; c < 9; c++) A[9 * s + c] *= inv;
+        A[9 * s + pc] = 1.0;
+        for (int r = 0; r < 5; r++) {
+            if (r == s) continue;
+            const double f = A[9 * r + pc];
+            if (f == 0.0) continue;
+            for (int c = 0; c < 9; c++) A[9 * r + c] -= f * A[9 * s + c];
+            A[9 * r + pc] = 0.0;
+        }
+    }
+    int k = 0;
+    for (int f = 0; f < 9; f++) {
+        if ((used >> f) & 1) continue;
+        for (int c = 0; c < 9; c++) N[9 * k + c] = 0.0;
+        N[9 * k + f] = 1.0;
+        for (int s = 0; s < 5; s++) {
+            int pc = 0;
+            for (int t = 0; t < 5; t++) if (t == s) pc = piv[t];       // piv stays in registers (no dynamic indexing)
+            N[9 * k + pc] = -A[9 * s + f];
+        }
+        k++;
+    }
+    for (int a = 0; a < 4; a++) {
+        for (int b = 0; b < a; b++) {
+            double d = 0.0;
+            for (int c = 0; c < 9; c++) d += N[9 * a + c] * N[9 * b + c];
+            for (int c = 0; c < 9; c++) N[9 * a + c] -= d * N[9 * b + c];
+        }
+        double nn = 0.0;
+        for (int c = 0; c < 9; c++) nn += N[9 * a + c] * N[9 * a + c];
+        if (!(nn > 0.0)) return false;
+        const double inv = 1.0 / sqrt(nn);
+        for (int c = 0; c < 9; c++) N[9 * a + c] *= inv;
+    }
+    return true;
+}
+
+// LDS per 5-tuple (doubles): M 200 | N 36 | Ep 36 | W 144 (A 45, then EEt 90 + tr 10, then D 121 + crit 11 + spare 11 + degree 1)
+#define FP_LDS_PER_THREAD (200 + 36 + 36 + 144)
+
+// Called by all threads of the workgroup (it synchronises).  Lane l == 0 of each team owns the short sequential
+// phases; the cubic constraints, the Gauss-Jordan elimination and the root search are shared by the team's lanes --
+// one output polynomial / one matrix row / one bracketing interval per lane, each computed with exactly the
+// operations of the sequential statement.  Returns (to the owner) the number of essential matrices written to Es.
+__device__ static int five_point_solve(const double *q1, const double *q2, double *Es, Col L, int l, int team, bool valid)
+{
+    Col M = L, N = L.at(200), Ep = L.at(236), W = L.at(272);
+    const bool owner = l == 0;
+    // W[142]: 1.0 while the tuple is alive; W[143]: degree for the root search
+    if (owner) {
+        W[143] = 0.0;
+        bool ok = valid;
+        if (ok) {
+            Col A = W;
+            for (int i = 0; i < 5; i++) {
+                const double x = q1[2 * i], y = q1[2 * i + 1], u = q2[2 * i], v = q2[2 * i + 1];
+                A[9 * i] = u * x; A[9 * i + 1] = u * y; A[9 * i + 2] = u; A[9 * i + 3] = v * x; A[9 * i + 4] = v * y; A[9 * i + 5] = v;
+                A[9 * i + 6] = x; A[9 * i + 7] = y; A[9 * i + 8] = 1.0;
+            }
+            ok = nullspace_5x9(A, N);
+        }
+        if (ok) for (int e = 0; e < 9; e++) for (int m = 0; m < 4; m++) Ep[4 * e + m] = N[9 * m + e];
+        W[142] = ok ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    bool alive = W[142] != 0.0;
+    {   // E E' (nine quadratics, one per lane), tr/2, the nine cubics (E E' - tr/2 I) E and det E (one per lane)
+        Col EEt = W, tr = W.at(90);
+        if (alive && l < 9) {
+            const int r = l / 3, c = l % 3;
+            Col o = EEt.at(10 * l);
+            for (int i = 0; i < 10; i++) o[i] = 0.0;
+            for (int k = 0; k < 3; k++) { const Col a = Ep.at(4 * (3 * r + k)), b = Ep.at(4 * (3 * c + k)); mul11(a, b, o); }
+        }
+        __syncthreads();
+        if (alive && l < 10) tr[l] = 0.5 * ((EEt[l] + EEt[40 + l]) + EEt[80 + l]);
+        __syncthreads();
+        if (alive && l < 10) for (int d = 0; d < 3; d++) EEt[40 * d + l] -= tr[l];
+        __syncthreads();
+        if (alive && l < 9) {
+            const int r = l / 3, c = l % 3;
+            Col o = M.at(20 * l);
+            for (int i = 0; i < 20; i++) o[i] = 0.0;
+            for (int k = 0; k < 3; k++) { const Col a = EEt.at(10 * (3 * r + k)), b = Ep.at(4 * (3 * k + c)); mul21(a, b, o); }
+        }
+        if (alive && l == 9) {
+            double m0[10], m1[10], m2[10], t[20];
+            minor2(Ep.at(16), Ep.at(32), Ep.at(20), Ep.at(28), m0);
+            minor2(Ep.at(12), Ep.at(32), Ep.at(20), Ep.at(24), m1);
+            minor2(Ep.at(12), Ep.at(28), Ep.at(16), Ep.at(24), m2);
+            Col o = M.at(180);
+            for (int i = 0; i < 20; i++) o[i] = 0.0;
+            { const Col e0 = Ep.at(0); mul21(m0, e0, o); }
+            for (int i = 0; i < 20; i++) t[i] = 0.0;
+            { const Col e1 = Ep.at(4); mul21(m1, e1, t); }
+            for (int i = 0; i < 20; i++) o[i] -= t[i];
+            for (int i = 0; i < 20; i++) t[i] = 0.0;
+            { const Col e2 = Ep.at(8); mul21(m2, e2, t); }
+            for (int i = 0; i < 20; i++) o[i] += t[i];
+        }
+        __syncthreads();
+    }
+    for (int s = 0; s < 10; s++) {                      // Gauss-Jordan on the first ten columns, row pivoting
+        int pr = s; double best = 0.0;
+        if (alive) {
+            best = fabs(M[20 * s + s]);
+            for (int r = s + 1; r < 10; r++) if (fabs(M[20 * r + s]) > best) { best = fabs(M[20 * r + s]); pr = r; }
+            if (!(best > 0.0)) alive = false;             // every lane of the team reads the same column
+        }
+        __syncthreads();
+        if (alive && pr != s)
+            for (int c = l; c < 20; c += FP_TEAM) { const double t = M[20 * s + c]; M[20 * s + c] = M[20 * pr + c]; M[20 * pr + c] = t; }
+        __syncthreads();
+        const double inv = alive ? 1.0 / M[20 * s + s] : 0.0;
+        __syncthreads();
+        if (alive) for (int c = l; c < 20; c += FP_TEAM) M[20 * s + c] = c == s ? 1.0 : M[20 * s + c] * inv;
+        __syncthreads();
+        if (alive && l < 10 && l != s) {
+            const int r = l;
+            const double f = M[20 * r + s];
+            if (f != 0.0) {
+                for (int c = 0; c < 20; c++) M[20 * r + c] -= f * M[20 * s + c];
+                M[20 * r + s] = 0.0;
+            }
+        }
+        __syncthreads();
+    }
+    double Ba[3][4], Bb[3][4], Bc[3][5];
+    if (owner && alive) {
+        for (int r = 0; r < 3; r++) {
+            const Col e = M.at(20 * (4 + 2 * r)), f = M.at(20 * (5 + 2 * r));
+            Ba[r][0] = e[12]; Ba[r][1] = e[11] - f[12]; Ba[r][2] = e[10] - f[11]; Ba[r][3] = -f[10];
+            Bb[r][0] = e[15]; Bb[r][1] = e[14] - f[15]; Bb[r][2] = e[13] - f[14]; Bb[r][3] = -f[13];
+            Bc[r][0] = e[19]; Bc[r][1] = e[18] - f[19]; Bc[r][2] = e[17] - f[18]; Bc[r][3] = e[16] - f[17]; Bc[r][4] = -f[16];
+        }
+        double P[11];
+        {
+            double t1[8], t2[8], u[8], w[11];
+            pmul(Bb[1], 4, Bc[2], 5, t1); pmul(Bc[1], 5, Bb[2], 4, t2);
+            for (int i = 0; i < 8; i++) u[i] = t1[i] - t2[i];
+            pmul(Ba[0], 4, u, 8, P);
+            pmul(Ba[1], 4, Bc[2], 5, t1); pmul(Bc[1], 5, Ba[2], 4, t2);
+            for (int i = 0; i < 8; i++) u[i] = t1[i] - t2[i];
+            pmul(Bb[0], 4, u, 8, w);
+            for (int i = 0; i < 11; i++) P[i] -= w[i];
+            pmul(Ba[1], 4, Bb[2], 4, t1); pmul(Bb[1], 4, Ba[2], 4, t2);
+            for (int i = 0; i < 7; i++) u[i] = t1[i] - t2[i];
+            pmul(Bc[0], 5, u, 7, w);
+            for (int i = 0; i < 11; i++) P[i] += w[i];
+        }
+        bool fin = true;
+        for (int i = 0; i < 11; i++) fin = fin && isfinite(P[i]);
+        if (fin) roots_prepare(P, 10, W);
+    }
+    __syncthreads();
+    const int nr = team_real_roots(W, l, team);
+    if (!owner || !alive) return 0;
+    const Col zr = W.at(121);
+    int ne = 0;
+    for (int i = 0; i < nr; i++) {
+        const double z = zr[i];
+        double R[3][3];
+        for (int r = 0; r < 3; r++) { R[r][0] = peval(Ba[r], 3, z); R[r][1] = peval(Bb[r], 3, z); R[r][2] = peval(Bc[r], 4, z); }
+        double best = 0.0, nx = 0.0, ny = 0.0, nz = 0.0;
+        for (int a = 0; a < 2; a++)
+            for (int b = a + 1; b < 3; b++) {
+                const double c0 = R[a][1] * R[b][2] - R[a][2] * R[b][1];
+                const double c1 = R[a][2] * R[b][0] - R[a][0] * R[b][2];
+                const double c2 = R[a][0] * R[b][1] - R[a][1] * R[b][0];
+                if (fabs(c2) > best) { best = fabs(c2); nx = c0; ny = c1; nz = c2; }
+            }
+        if (!(best > 0.0)) continue;
+        const double x = nx / nz, y = ny / nz;
+        double *E = Es + 9 * ne;
+        bool fin = true;
+        for (int e = 0; e < 9; e++) {
+            E[e] = ((x * N[e] + y * N[9 + e]) + z * N[18 + e]) + N[27 + e];
+            fin = fin && isfinite(E[e]);
+        }
+        if (fin) ne++;
+    }
+    return ne;
+}
+
+__device__ static bool essential_poses(const double *E, double *Rt)
+{
+    double G[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) G[3 * r + c] = (E[3 * r] * E[3 * c] + E[3 * r + 1] * E[3 * c + 1]) + E[3 * r + 2] * E[3 * c + 2];
+    const double h = 0.5 * ((G[0] + G[4]) + G[8]);
+    for (int i = 0; i < 9; i++) G[i] = -G[i];
+    G[0] += h; G[4] += h; G[8] += h;
+    int m = 0;
+    if (G[4] > G[0]) m = 1;
+    if (G[8] > (m == 1 ? G[4] : G[0])) m = 2;
+    const double gm = m == 0 ? G[0] : (m == 1 ? G[4] : G[8]);
+    if (!(gm > 0.0)) return false;
+    const double s = 1.0 / sqrt(gm);
+    double b[3];
+    for (int j = 0; j < 3; j++) b[j] = (m == 0 ? G[j] : (m == 1 ? G[3 + j] : G[6 + j])) * s;
+    const double bb = (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
+    if (!(bb > 0.0) || !isfinite(bb)) return false;
+    double C[9], BE[9];
+    for (int r = 0; r < 3; r++) {
+        const double *p = E + 3 * ((r + 1) % 3), *q = E + 3 * ((r + 2) % 3);
+        C[3 * r] = p[1] * q[2] - p[2] * q[1]; C[3 * r + 1] = p[2] * q[0] - p[0] * q[2]; C[3 * r + 2] = p[0] * q[1] - p[1] * q[0];
+    }
+    for (int c = 0; c < 3; c++) {
+        BE[c] = b[1] * E[6 + c] - b[2] * E[3 + c];
+        BE[3 + c] = b[2] * E[c] - b[0] * E[6 + c];
+        BE[6 + c] = b[0] * E[3 + c] - b[1] * E[c];
+    }
+    const double ib = 1.0 / bb, in = 1.0 / sqrt(bb);
+    const double t[3] = {b[0] * in, b[1] * in, b[2] * in};
+    for (int k = 0; k < 4; k++) {
+        double *P = Rt + 12 * k;
+        const double sg = (k & 1) ? -1.0 : 1.0;
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++)
+                P[r + 3 * c] = (k < 2 ? C[3 * r + c] - BE[3 * r + c] : C[3 * r + c] + BE[3 * r + c]) * ib;
+            P[9 + r] = sg * t[r];
+        }
+    }
+    return true;
+}
+
+__device__ static inline bool tri_two_view(const double *k1, const double *k2, const double *Rt, const double *a, const double *b, double *X, double *Y)
+{
+    double P1[12], P2[12];
+    for (int i = 0; i < 12; i++) P1[i] = 0.0;
+    P1[0] = k1[0]; P1[2] = k1[2]; P1[5] = k1[1]; P1[6] = k1[3]; P1[10] = 1.0;
+    for (int c = 0; c < 4; c++) {
+        const double r0 = Rt[3 * c], r1 = Rt[3 * c + 1], r2 = Rt[3 * c + 2];
+        P2[c] = k2[0] * r0 + k2[2] * r2; P2[4 + c] = k2[1] * r1 + k2[3] * r2; P2[8 + c] = r2;
+    }
+    double A[16], S[16], v[4];
+    for (int j = 0; j < 4; j++) {
+        A[j] = a[0] * P1[8 + j] - P1[j]; A[4 + j] = a[1] * P1[8 + j] - P1[4 + j];
+        A[8 + j] = b[0] * P2[8 + j] - P2[j]; A[12 + j] = b[1] * P2[8 + j] - P2[4 + j];
+    }
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; k++) acc += A[4 * k + i] * A[4 * k + j];
+            S[4 * i + j] = acc;
+        }
+    sym4_min_eigvec(S, v);
+    const double iw = 1.0 / v[3];
+    X[0] = v[0] * iw; X[1] = v[1] * iw; X[2] = v[2] * iw;
+    for (int r = 0; r < 3; r++) Y[r] = ((Rt[r] * X[0] + Rt[3 + r] * X[1]) + Rt[6 + r] * X[2]) + Rt[9 + r];
+    return isfinite(X[0]) && isfinite(X[1]) && isfinite(X[2]);
+}
+
+__device__ static inline bool two_view_errors(const double *k1, const double *k2, const double *Rt, const double *a, const double *b, double *e1, double *e2)
+{
+    double X[3], Y[3];
+    if (!tri_two_view(k1, k2, Rt, a, b, X, Y)) return false;
+    if (!(X[2] > 0.0) || !(Y[2] > 0.0)) return false;
+    const double i1 = 1.0 / X[2], i2 = 1.0 / Y[2];
+    const double dx1 = a[0] - (k1[0] * X[0] * i1 + k1[2]), dy1 = a[1] - (k1[1] * X[1] * i1 + k1[3]);
+    const double dx2 = b[0] - (k2[0] * Y[0] * i2 + k2[2]), dy2 = b[1] - (k2[1] * Y[1] * i2 + k2[3]);
+    *e1 = sqrt(dx1 * dx1 + dy1 * dy1); *e2 = sqrt(dx2 * dx2 + dy2 * dy2);
+    return true;
+}
+
+// depths along the two rays under x2 = R x1 + t (normalised coordinates), see the oracle's ray_depths
+__device__ static inline void ray_depths(const double *Rt, const double *q1, const double *q2, double *l1, double *l2)
+{
+    const double r0 = (Rt[0] * q1[0] + Rt[3] * q1[1]) + Rt[6], r1 = (Rt[1] * q1[0] + Rt[4] * q1[1]) + Rt[7],
+                 r2 = (Rt[2] * q1[0] + Rt[5] * q1[1]) + Rt[8];
+    const double a0 = q2[1] * r2 - r1, a1 = r0 - q2[0] * r2, a2 = q2[0] * r1 - q2[1] * r0;
+    const double b0 = q2[1] * Rt[11] - Rt[10], b1 = Rt[9] - q2[0] * Rt[11], b2 = q2[0] * Rt[10] - q2[1] * Rt[9];
+    const double num = (a0 * b0 + a1 * b1) + a2 * b2, den = (a0 * a0 + a1 * a1) + a2 * a2;
+    *l1 = -num / den;
+    *l2 = *l1 * r2 + Rt[11];
+}
+
+__global__ __launch_bounds__(FP_TPB * FP_TEAM) void k_5pt_solve(FPArgs T)
+{
+    extern __shared__ double s_fp[];
+    const int team = threadIdx.x / FP_TEAM, l = threadIdx.x % FP_TEAM;
+    const int it = blockIdx.x * FP_TPB + team;
+    const Col L{s_fp + team};
+    bool ok = it < T.iters;
+    int ids[5] = {0, 0, 0, 0, 0};
+    if (ok) {
+        const int32_t *sm = T.samples + 5 * it;
+        for (int a = 0; a < 5; a++) {
+            ids[a] = sm[a];
+            if (ids[a] < 0 || ids[a] >= T.n) ok = false;
+            for (int b = 0; b < a; b++) if (ids[a] == ids[b]) ok = false;
+        }
+    }
+    double q1[10], q2[10], Es[9 * FP_MAXE];
+    for (int a = 0; a < 5; a++) {
+        const int id = ok ? ids[a] : 0;
+        q1[2 * a] = T.pd1[2 * id]; q1[2 * a + 1] = T.pd1[2 * id + 1];
+        q2[2 * a] = T.pd2[2 * id]; q2[2 * a + 1] = T.pd2[2 * id + 1];
+    }
+    const int ne = five_point_solve(q1, q2, Es, L, l, team, ok);      // all threads: it synchronises
+    if (l != 0 || it >= T.iters) return;
+    int np = 0;
+    for (int e = 0; e < ne; e++) {
+        double C[48];
+        if (!essential_poses(Es + 9 * e, C)) continue;
+        int best = -1, bk = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int cnt = 0;
+            for (int i = 0; i < 5; i++) {
+                double l1, l2;
+                ray_depths(C + 12 * k, q1 + 2 * i, q2 + 2 * i, &l1, &l2);
+                cnt += (l1 > 0.0 && l2 > 0.0) ? 1 : 0;
+            }
+            if (cnt > best) { best = cnt; bk = k; }
+        }
+        double Rb[12];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k == bk) for (int j = 0; j < 12; j++) Rb[j] = C[12 * k + j];
+        double *po = T.poses + ((size_t)it * FP_MAXE + np) * 12, *eo = T.Es + ((size_t)it * FP_MAXE + np) * 9;
+        for (int j = 0; j < 12; j++) po[j] = Rb[j];
+        for (int j = 0; j < 9; j++) eo[j] = Es[9 * e + j];
+        np++;
+    }
+    T.ne[it] = np;
+}
+
+__global__ __launch_bounds__(FP_SCORE_T) void k_5pt_score(FPArgs T)
+{
+    __shared__ int s_part[FP_SCORE_T / 64];
+    const int it = blockIdx.x, e = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (e >= T.ne[it]) {                                  // workgroup-uniform
+        if (tid == 0) T.counts[it * FP_MAXE + e] = 0;
+        return;
+    }
+    int cnt = 0;
+    double Rt[12];
+    for (int j = 0; j < 12; j++) Rt[j] = T.poses[((size_t)it * FP_MAXE + e) * 12 + j];
+    for (int i = tid; i < T.n; i += FP_SCORE_T) {
+        const double a[2] = {T.px1[2 * i], T.px1[2 * i + 1]}, b[2] = {T.px2[2 * i], T.px2[2 * i + 1]};
+        double e1, e2;
+        if (two_view_errors(T.k1, T.k2, Rt, a, b, &e1, &e2)) cnt += (e1 < T.thr && e2 < T.thr) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) s_part[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        for (int w = 0; w < FP_SCORE_T / 64; w++) c += s_part[w];
+        T.counts[it * FP_MAXE + e] = c;
+    }
+}
+
+__global__ __launch_bounds__(FP_SEL_T) void k_5pt_select(FPArgs T)
+{
+    __shared__ int s_cnt[FP_SEL_T], s_idx[FP_SEL_T];
+    __shared__ double s_P[12];
+    __shared__ double s_err[FP_ERR_LDS];
+    const int tid = threadIdx.x, ne = FP_MAXE * T.iters;
+    const bool in_lds = T.n <= FP_ERR_LDS;
+    int bc = 0, bi = -1;
+    for (int e = tid; e < ne; e += FP_SEL_T) {
+        const int c = T.counts[e];
+        if (c > bc) { bc = c; bi = e; }
+    }
+    s_cnt[tid] = bc; s_idx[tid] = bi;
+    __syncthreads();
+    for (int o = FP_SEL_T / 2; o > 0; o >>= 1) {
+        if (tid < o) {
+            const int c2 = s_cnt[tid + o], i2 = s_idx[tid + o];
+            if (c2 > s_cnt[tid] || (c2 == s_cnt[tid] && c2 > 0 && i2 < s_idx[tid])) { s_cnt[tid] = c2; s_idx[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    const int best = s_cnt[0], be = s_idx[0];
+    if (tid < 12) s_P[tid] = best > 0 ? T.poses[(size_t)be * 12 + tid] : 0.0;
+    __syncthreads();
+    for (int i = tid; i < T.n; i += FP_SEL_T) {
+        double e1 = 0.0, e2 = 0.0;
+        bool in = false;
+        if (best > 0) {
+            const double a[2] = {T.px1[2 * i], T.px1[2 * i + 1]}, b[2] = {T.px2[2 * i], T.px2[2 * i + 1]};
+            in = two_view_errors(T.k1, T.k2, s_P, a, b, &e1, &e2) && e1 < T.thr && e2 < T.thr;
+        }
+        T.inliers[i] = in ? 1 : 0;
+        if (in_lds) s_err[i] = in ? e1 + e2 : -1.0; else T.errs[i] = in ? e1 + e2 : -1.0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        double esum = 0.0;
+        for (int i = 0; i < T.n; i++) { const double e = in_lds ? s_err[i] : T.errs[i]; if (e >= 0.0) esum += e; }
+        *T.error = esum;
+        *T.n_inliers = best;
+        *T.best_iter = best > 0 ? be / FP_MAXE : -1;
+        for (int j = 0; j < 12; j++) T.P_out[j] = s_P[j];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) T.E_out[r + 3 * c] = best > 0 ? T.Es[(size_t)be * 9 + 3 * r + c] : 0.0;
+    }
+}
+
+extern "C" int slam_five_point_ransac(slam_ctx *ctx, const double *px1_xy, const double *px2_xy, const double *pd1_xy,
+                                      const double *pd2_xy, int n, const double *K1, const double *K2, double max_repr_error,
+                                      const int32_t *samples, int iters, double *E, double *P, uint8_t *inliers,
+                                      int *n_inliers, double *error, int *best_iter)
+{
+    ARG_TRY(ctx, ctx != nullptr && n >= 0 && iters >= 0);
+    ARG_TRY(ctx, K1 && K2 && P && n_inliers);
+    ARG_TRY(ctx, n == 0 || (px1_xy && px2_xy && pd1_xy && pd2_xy && inliers));
+    ARG_TRY(ctx, iters == 0 || samples);
+    if (n < 5 || iters == 0) {
+        *n_inliers = 0;
+        for (int j = 0; j < 12; j++) P[j] = 0.0;
+        if (E) for (int j = 0; j < 9; j++) E[j] = 0.0;
+        for (int i = 0; i < n; i++) inliers[i] = 0;
+        if (error) *error = 0.0;
+        if (best_iter) *best_iter = -1;
+        return SLAM_OK;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t pb = up((size_t)n * 16);
+    const size_t o_smp = 4 * pb, o_out = o_smp + up((size_t)iters * 20), o_inl = o_out + 256, total = o_inl + up((size_t)n);
+    char *h, *d;
+    int rc = slam_pinned(ctx, total, (void **)&h);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipHostGetDevicePointer((void **)&d, h, 0));
+    memcpy(h, px1_xy, (size_t)n * 16); memcpy(h + pb, px2_xy, (size_t)n * 16);
+    memcpy(h + 2 * pb, pd1_xy, (size_t)n * 16); memcpy(h + 3 * pb, pd2_xy, (size_t)n * 16);
+    memcpy(h + o_smp, samples, (size_t)iters * 20);
+    const size_t s_ne = up((size_t)iters * 4), s_es = up((size_t)iters * FP_MAXE * 72), s_po = up((size_t)iters * FP_MAXE * 96);
+    const size_t s_cn = up((size_t)iters * FP_MAXE * 4), s_er = up((size_t)n * 8);
+    char *scr;
+    rc = slam_scratch(ctx, s_ne + s_es + s_po + s_cn + s_er, (void **)&scr);
+    if (rc) return rc;
+    FPArgs T;
+    T.px1 = (const double *)d; T.px2 = (const double *)(d + pb); T.pd1 = (const double *)(d + 2 * pb); T.pd2 = (const double *)(d + 3 * pb);
+    T.samples = (const int32_t *)(d + o_smp); T.n = n; T.iters = iters;
+    T.k1[0] = K1[0]; T.k1[1] = K1[4]; T.k1[2] = K1[6]; T.k1[3] = K1[7];
+    T.k2[0] = K2[0]; T.k2[1] = K2[4]; T.k2[2] = K2[6]; T.k2[3] = K2[7];
+    T.thr = max_repr_error;
+    T.ne = (int *)scr; T.Es = (double *)(scr + s_ne); T.poses = (double *)(scr + s_ne + s_es);
+    T.counts = (int *)(scr + s_ne + s_es + s_po); T.errs = (double *)(scr + s_ne + s_es + s_po + s_cn);
+    // output block: P [0,96) E [96,168) error [168,176) n_inliers [176,180) best_iter [180,184)
+    T.P_out = (double *)(d + o_out); T.E_out = (double *)(d + o_out + 96); T.error = (double *)(d + o_out + 168);
+    T.n_inliers = (int *)(d + o_out + 176); T.best_iter = (int *)(d + o_out + 180);
+    T.inliers = (uint8_t *)(d + o_inl);
+    const size_t lds = (size_t)FP_LDS_PER_THREAD * FP_TPB * sizeof(double);
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_5pt_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { ProfScope span(ctx, "five_point_ransac");
+      hipLaunchKernelGGL(k_5pt_solve, dim3((iters + FP_TPB - 1) / FP_TPB), dim3(FP_TPB * FP_TEAM), lds, ctx->stream, T);
+      hipLaunchKernelGGL(k_5pt_score, dim3(iters, FP_MAXE), dim3(FP_SCORE_T), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_5pt_select, dim3(1), dim3(FP_SEL_T), 0, ctx->stream, T); }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(P, h + o_out, 96);
+    if (E) memcpy(E, h + o_out + 96, 72);
+    if (error) memcpy(error, h + o_out + 168, 8);
+    memcpy(n_inliers, h + o_out + 176, 4);
+    if (best_iter) memcpy(best_iter, h + o_out + 180, 4);
+    memcpy(inliers, h + o_inl, (size_t)n);
+    return SLAM_OK;
+}

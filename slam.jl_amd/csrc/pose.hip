@@ -10,6 +10,8 @@
 #include "common.hpp"
 #include <cmath>
 
+#define P3P_ERR_LDS 4096                // map points whose errors the select kernel stages in LDS
+
 struct P3PArgs {
     const double *pts, *px, *pdn;   // n x 3, n x 2 (x, y), n x 3
     const int32_t *samples;         // iters x 3, 0-based
@@ -225,7 +227,9 @@ __global__ __launch_bounds__(256) void k_p3p_select(P3PArgs T)
 {
     __shared__ int s_cnt[256], s_idx[256];
     __shared__ double s_P[12];
+    __shared__ double s_err[P3P_ERR_LDS];
     const int tid = threadIdx.x, ne = 4 * T.iters;
+    const bool in_lds = T.n <= P3P_ERR_LDS;
     int bc = 0, bi = -1;
     for (int e = tid; e < ne; e += 256) {
         const int c = T.counts[e];
@@ -252,13 +256,13 @@ __global__ __launch_bounds__(256) void k_p3p_select(P3PArgs T)
         }
         const bool in = best > 0 && e >= 0.0 && e < T.thr;
         T.inliers[i] = in ? 1 : 0;
-        T.errs[i] = in ? e : -1.0;
+        if (in_lds) s_err[i] = in ? e : -1.0; else T.errs[i] = in ? e : -1.0;
     }
     __threadfence_block();
     __syncthreads();
     if (tid == 0) {
         double esum = 0.0;
-        for (int i = 0; i < T.n; i++) { const double e = T.errs[i]; if (e >= 0.0) esum += e; }
+        for (int i = 0; i < T.n; i++) { const double e = in_lds ? s_err[i] : T.errs[i]; if (e >= 0.0) esum += e; }
         *T.error = esum;
         *T.n_inliers = best;
         *T.best_iter = best > 0 ? be / 4 : -1;

@@ -7,6 +7,7 @@
 // One thread per keypoint: a few hundred flops each, the call is bound by its launch + the PCIe round trip of the
 // keypoint lists (zero-copy mapped host block, like the tracking kernels).
 #include "common.hpp"
+#include "tri_device.hpp"
 #include <cmath>
 
 struct TriArgs {
@@ -19,32 +20,6 @@ struct TriArgs {
     double *out;                      // n x 3
     uint8_t *status;
 };
-
-// eigenvector of the symmetric 4x4 S (row-major) for its smallest eigenvalue: cyclic Jacobi, same operation
-// order as the oracle (orc_sym4_min_eigvec)
-__device__ void sym4_min_eigvec(double *S, double *v)
-{
-    double V[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    for (int sweep = 0; sweep < 32; sweep++) {
-        double off = 0.0, dg = 0.0;
-        for (int p = 0; p < 4; p++) { dg += S[5 * p] * S[5 * p]; for (int q = p + 1; q < 4; q++) off += S[4 * p + q] * S[4 * p + q]; }
-        if (off <= 1e-60 * dg || off == 0.0) break;
-        for (int p = 0; p < 3; p++)
-            for (int q = p + 1; q < 4; q++) {
-                const double apq = S[4 * p + q];
-                if (apq == 0.0) continue;
-                const double theta = (S[5 * q] - S[5 * p]) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < 4; k++) { const double a = S[4 * k + p], b = S[4 * k + q]; S[4 * k + p] = c * a - s * b; S[4 * k + q] = s * a + c * b; }
-                for (int k = 0; k < 4; k++) { const double a = S[4 * p + k], b = S[4 * q + k]; S[4 * p + k] = c * a - s * b; S[4 * q + k] = s * a + c * b; }
-                for (int k = 0; k < 4; k++) { const double a = V[4 * k + p], b = V[4 * k + q]; V[4 * k + p] = c * a - s * b; V[4 * k + q] = s * a + c * b; }
-            }
-    }
-    int m = 0;
-    for (int p = 1; p < 4; p++) if (S[5 * p] < S[5 * m]) m = p;
-    for (int k = 0; k < 4; k++) v[k] = V[4 * k + m];
-}
 
 __global__ __launch_bounds__(64) void k_triangulate(TriArgs T)
 {

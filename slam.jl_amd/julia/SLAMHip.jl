@@ -238,6 +238,28 @@ function hip_p3p_ransac(points, pixels, pdn_positions, K; threshold = 1.0, itera
     Int(cnt[]), (SMatrix{3, 4, Float64}(kp), Bool[i != 0 for i in inl[1:n]], err[])
 end
 
+# five_point_ransac of compute_pose_5pt! (front_end.jl:305-308): same positional arguments as
+# RecoverPose.five_point_ransac (the GEEV cache is not needed) and the result shape the caller destructures,
+# `n_inliers, (E, P, inliers, error)`; P = [R | t] (3x4, previous key-frame -> current frame, |t| = 1).
+function hip_five_point_ransac(previous_points, current_points, previous_pd, current_pd, K1, K2, cache = nothing;
+        max_repr_error = 1.0, iterations = 128)
+    n = length(previous_points)
+    flat(v) = collect(reinterpret(Float64, collect(SVector{2, Float64}.(v))))
+    a = flat(previous_points); b = flat(current_points); c = flat(previous_pd); d = flat(current_pd)   # already (x, y)
+    k1 = Vector{Float64}(vec(SMatrix{3, 3, Float64}(K1))); k2 = Vector{Float64}(vec(SMatrix{3, 3, Float64}(K2)))
+    smp = Vector{Int32}(undef, 5 * iterations)
+    for it in 0:iterations - 1
+        smp[5it + 1:5it + 5] .= Int32.(randperm(n)[1:5] .- 1)
+    end
+    E = Vector{Float64}(undef, 9); P = Vector{Float64}(undef, 12); inl = Vector{UInt8}(undef, max(n, 1))
+    cnt = Ref{Cint}(0); err = Ref{Cdouble}(0.0)
+    GC.@preserve a b c d k1 k2 smp E P inl check(ccall((:slam_five_point_ransac, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Cdouble,
+         Ptr{Int32}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Ref{Cint}, Ref{Cdouble}, Ptr{Cint}),
+        ctx(), a, b, c, d, n, k1, k2, Float64(max_repr_error), smp, iterations, E, P, inl, cnt, err, C_NULL))
+    Int(cnt[]), (SMatrix{3, 3, Float64}(E), SMatrix{3, 4, Float64}(P), Bool[i != 0 for i in inl[1:n]], err[])
+end
+
 """
     activate!(libpath)
 

@@ -10,10 +10,13 @@ import numpy as np
 from . import _lib as L
 
 
-def draw_samples(n, iters, seed=0):
-    """iters distinct 0-based index triples out of n points (host-side stand-in for the RANSAC sampler)."""
-    if n < 3:
-        return np.zeros((0, 3), dtype=np.int32)
+def draw_samples(n, iters, seed=0, k=3):
+    """iters 0-based k-tuples of distinct indices out of n points (host-side stand-in for the RANSAC sampler)."""
+    if n < k:
+        return np.zeros((0, k), dtype=np.int32)
+    if k != 3:
+        rng = np.random.default_rng(seed)
+        return np.argsort(rng.random((iters, n)), axis=1)[:, :k].astype(np.int32) if n <= 64 else _distinct(rng, n, iters, k)
     rng = np.random.default_rng(seed)
     s = rng.integers(0, n, size=(iters, 3), dtype=np.int64)
     s[:, 1] = (s[:, 0] + 1 + rng.integers(0, n - 1, iters)) % n                      # != s0
@@ -21,6 +24,17 @@ def draw_samples(n, iters, seed=0):
     lo, hi = np.minimum(s[:, 0], s[:, 1]), np.maximum(s[:, 0], s[:, 1])
     third = third + (third >= lo); third = third + (third >= hi)                    # skip both earlier picks
     s[:, 2] = third
+    return s.astype(np.int32)
+
+
+def _distinct(rng, n, iters, k):
+    s = rng.integers(0, n, size=(iters, k))
+    for _ in range(64):                                   # redraw the (rare) tuples with a repeated index
+        srt = np.sort(s, axis=1)
+        bad = (srt[:, 1:] == srt[:, :-1]).any(axis=1)
+        if not bad.any():
+            break
+        s[bad] = rng.integers(0, n, size=(int(bad.sum()), k))
     return s.astype(np.int32)
 
 
@@ -51,4 +65,34 @@ def p3p_ransac(points, pixels_xy, pdn_positions, K, threshold=1.0, samples=None,
     model = (np.array(KP), inl.view(np.bool_), err.value)
     if return_pose:
         model = model + (np.array(Rt), bi.value)
+    return cnt.value, model
+
+
+def five_point_ransac(previous_points_xy, current_points_xy, previous_pd, current_pd, K1, K2, max_repr_error=1.0,
+                      samples=None, iterations=128, seed=0, ctx=None, return_extra=False):
+    """five_point_ransac of compute_pose_5pt! (front_end.jl:305-308): pixels (n, 2) in (x, y) order, normalised
+    coordinates (n, 2), K1 / K2 3x3.  Returns `(n_inliers, (E, P, inliers, error))` -- P = [R | t] 3x4, previous ->
+    current, |t| = 1 -- with n_inliers = 0 and zero matrices when no sample gave a pose (the reference then fails its
+    `n_inliers < 5` test, :309)."""
+    ctx = ctx or L.default_context()
+    a = np.ascontiguousarray(previous_points_xy, dtype=np.float64).reshape(-1, 2)
+    b = np.ascontiguousarray(current_points_xy, dtype=np.float64).reshape(-1, 2)
+    c = np.ascontiguousarray(previous_pd, dtype=np.float64).reshape(-1, 2)
+    d = np.ascontiguousarray(current_pd, dtype=np.float64).reshape(-1, 2)
+    n = len(a)
+    if not (len(b) == len(c) == len(d) == n):
+        raise ValueError("the four point lists must have the same length")
+    k1 = np.asfortranarray(K1, dtype=np.float64); k2 = np.asfortranarray(K2, dtype=np.float64)
+    if k1.shape != (3, 3) or k2.shape != (3, 3):
+        raise ValueError("K1, K2 must be 3x3")
+    sm = draw_samples(n, iterations, seed, k=5) if samples is None else np.ascontiguousarray(samples, dtype=np.int32).reshape(-1, 5)
+    E = np.zeros((3, 3), order="F"); P = np.zeros((3, 4), order="F")
+    inl = np.zeros(max(n, 1), dtype=np.uint8)
+    cnt, bi, err = C.c_int(), C.c_int(), C.c_double()
+    ctx.check(ctx.lib.slam_five_point_ransac(ctx.h, L.ptr(a), L.ptr(b), L.ptr(c), L.ptr(d), n, L.ptr(k1), L.ptr(k2),
+                                             float(max_repr_error), L.ptr(sm, L.i32p), len(sm), L.ptr(E), L.ptr(P),
+                                             L.ptr(inl, L.u8p), C.byref(cnt), C.cast(C.byref(err), L.f64p), C.byref(bi)))
+    model = (np.array(E), np.array(P), inl[:n].view(np.bool_), err.value)
+    if return_extra:
+        model = model + (bi.value,)
     return cnt.value, model

@@ -195,3 +195,27 @@ def p3p_scene(n=400, seed=0, noise_px=0.3, outlier_frac=0.2, iters=256):
     samples = np.stack([rng.permutation(n)[:3] for _ in range(iters)]).astype(np.int32)
     return dict(pts3d=np.ascontiguousarray(Xw), px_xy=np.ascontiguousarray(px), pdn=np.ascontiguousarray(pdn), K=K,
                 Rt_gt=np.concatenate([R, t[:, None]], 1), gross=gross, samples=samples)
+
+
+def five_point_scene(n=400, seed=0, noise_px=0.3, outlier_frac=0.2, iters=128):
+    """Input of compute_pose_5pt! (front_end.jl:258-308): n keypoints seen in the previous key-frame and in the
+    current frame (KITTI intrinsics, a general small rigid motion).  px1 / px2 (n, 2) pixels in (x, y) order as the
+    five-point solver expects, pd1 / pd2 (n, 2) the matching normalised coordinates, K, Rt_gt (3x4, previous ->
+    current, translation scaled to unit length), `gross` (second-view pixels displaced by 15-60 px) and `samples`
+    (iters, 5) int32 0-based distinct 5-tuples."""
+    s = triangulation_scene(n=n, seed=100 + seed, temporal=True)
+    rng = np.random.default_rng(0x5F5 + seed)
+    fx, fy, cx, cy = s["cam"]
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    px1 = s["px1"][:, ::-1].copy(); px2 = s["px2"][:, ::-1].copy()
+    if noise_px:
+        px1 += rng.normal(0, noise_px, px1.shape); px2 += rng.normal(0, noise_px, px2.shape)
+    gross = np.sort(rng.choice(n, int(round(outlier_frac * n)), replace=False))
+    ang = rng.uniform(0, 2 * np.pi, len(gross)); mag = rng.uniform(15.0, 60.0, len(gross))
+    px2[gross, 0] += mag * np.cos(ang); px2[gross, 1] += mag * np.sin(ang)
+    pd1 = (px1 - [cx, cy]) / [fx, fy]; pd2 = (px2 - [cx, cy]) / [fx, fy]
+    T = s["T21"]
+    Rt = np.concatenate([T[:3, :3], (T[:3, 3] / np.linalg.norm(T[:3, 3]))[:, None]], 1)
+    samples = np.stack([rng.permutation(n)[:5] for _ in range(iters)]).astype(np.int32)
+    return dict(px1=np.ascontiguousarray(px1), px2=np.ascontiguousarray(px2), pd1=np.ascontiguousarray(pd1), pd2=np.ascontiguousarray(pd2),
+                K=K, Rt_gt=Rt, gross=gross, samples=samples)
