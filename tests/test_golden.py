@@ -46,3 +46,33 @@ def test_hip_reproduces_golden(slam):
     assert abs(cache.stats["ssr_final"] - G["ba_ssr"][2]) < 1e-8 * G["ba_ssr"][2]
     bits, rc = slam.describe(e, IMG0, G["kp_nomask"], pattern=G["brief_pattern"])
     assert np.array_equal(bits, G["brief_bits"]) and np.array_equal(rc, G["brief_rc"])
+
+
+GP = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_v1.npz"))
+
+
+def test_oracle_reproduces_pose_golden(orc, slam_host):
+    P1, P2 = slam_host.projection_matrices(GP["tri_cam"], GP["tri_cam"], GP["tri_T21"])
+    xyz, st = orc.triangulate(P1, P2, GP["tri_T21"], GP["tri_cam"], GP["tri_cam"], GP["tri_px1"], GP["tri_px2"], 3.0)
+    assert np.array_equal(st, GP["tri_status"]) and np.array_equal(xyz, GP["tri_xyz"])
+    cnt, KP, Rt, inl, err, bi = orc.p3p_ransac(GP["p3p_pts"], GP["p3p_px"], GP["p3p_pdn"], GP["p3p_K"], 3.0, GP["p3p_samples"])
+    assert cnt == GP["p3p_n"] and bi == GP["p3p_best"] and err == GP["p3p_error"]
+    assert np.array_equal(inl, GP["p3p_inliers"]) and np.array_equal(Rt, GP["p3p_Rt"]) and np.array_equal(KP, GP["p3p_KP"])
+    cnt, E, P, inl, err, bi = orc.five_point_ransac(GP["fp_px1"], GP["fp_px2"], GP["fp_pd1"], GP["fp_pd2"], GP["fp_K"], GP["fp_K"], 3.0, GP["fp_samples"])
+    assert cnt == GP["fp_n"] and bi == GP["fp_best"] and err == GP["fp_error"]
+    assert np.array_equal(inl, GP["fp_inliers"]) and np.array_equal(P, GP["fp_P"]) and np.array_equal(E, GP["fp_E"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_pose_golden(slam):
+    xyz, st = slam.triangulate(GP["tri_cam"], GP["tri_cam"], GP["tri_T21"], GP["tri_px1"], GP["tri_px2"], 3.0)
+    assert np.array_equal(st, GP["tri_status"])
+    assert np.max(np.abs(xyz - GP["tri_xyz"]) / np.abs(GP["tri_xyz"]).max(axis=1, keepdims=True)) < 1e-12
+    cnt, (KP, inl, err, Rt, bi) = slam.p3p_ransac(GP["p3p_pts"], GP["p3p_px"], GP["p3p_pdn"], GP["p3p_K"], threshold=3.0,
+                                                    samples=GP["p3p_samples"], return_pose=True)
+    assert cnt == GP["p3p_n"] and bi == GP["p3p_best"] and err == GP["p3p_error"]
+    assert np.array_equal(inl, GP["p3p_inliers"]) and np.array_equal(Rt, GP["p3p_Rt"]) and np.array_equal(KP, GP["p3p_KP"])
+    cnt, (E, P, inl, err, bi) = slam.five_point_ransac(GP["fp_px1"], GP["fp_px2"], GP["fp_pd1"], GP["fp_pd2"], GP["fp_K"], GP["fp_K"],
+                                                        max_repr_error=3.0, samples=GP["fp_samples"], return_extra=True)
+    assert cnt == GP["fp_n"] and bi == GP["fp_best"] and err == GP["fp_error"]
+    assert np.array_equal(inl, GP["fp_inliers"]) and np.array_equal(P, GP["fp_P"]) and np.array_equal(E, GP["fp_E"])
