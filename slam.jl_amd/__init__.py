@@ -16,3 +16,4 @@ from .optical_flow import (LKPyramid, LucasKanade, update_, copy_, deepcopy, has
 from .bundle_adjustment import LocalBACache, bundle_adjustment_, pnp_bundle_adjustment  # noqa: F401
 from .triangulation import triangulate, projection_matrices  # noqa: F401
 from .pose import p3p_ransac, five_point_ransac, draw_samples  # noqa: F401
+from .kitti import KittyDataset  # noqa: F401
