@@ -80,26 +80,23 @@ template <class P> __device__ static inline double peval(const P &p, int deg, do
     return f;
 }
 
-// Horner with the coefficients in registers: p[deg] ... p[0], deg <= 10 (same operations as peval)
-__device__ static inline double peval_r(const double (&p)[11], int deg, double x)
+// Horner with the coefficients in registers, degree known at compile time (same operations as peval)
+template <int D> __device__ static inline double peval_d(const double (&p)[11], double x)
 {
-    double f = 0.0;
+    double f = p[D];
 #pragma unroll
-    for (int i = 10; i >= 0; i--) {
-        if (i == deg) f = p[i];
-        else if (i < deg) f = f * x + p[i];
-    }
+    for (int i = D - 1; i >= 0; i--) f = f * x + p[i];
     return f;
 }
 
-__device__ static double bracket_root(const double (&p)[11], const double (&dp)[11], int deg, double lo, double hi, double flo)
+template <int D> __device__ static double bracket_root(const double (&p)[11], const double (&dp)[11], double lo, double hi, double flo)
 {
     double x = 0.5 * (lo + hi);
     for (int it = 0; it < 200; it++) {
-        const double f = peval_r(p, deg, x);
+        const double f = peval_d<D>(p, x);
         if (f == 0.0) return x;
         if ((f < 0.0) == (flo < 0.0)) lo = x; else hi = x;
-        const double df = peval_r(dp, deg - 1, x);
+        const double df = peval_d<D - 1>(dp, x);
         double xn = x - f / df;
         if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
         if (xn == x || xn == lo || xn == hi) return xn;
@@ -123,6 +120,64 @@ __device__ static void roots_prepare(const double *p, int deg, Col D)
     if (isfinite(c0)) D[143] = (double)deg;
 }
 
+// One lane's interval j of the degree-D polynomial in row k of the table: exactly the sequential statement's
+// operations for that interval.  nc critical points in crit.
+template <int D> __device__ static void interval_root(Col Dt, int k, int j, int nc, bool &found, bool &fail, double &root)
+{
+    const Col crit = Dt.at(121);
+    double q[11], dq[11];
+#pragma unroll
+    for (int i = 0; i <= D; i++) q[i] = Dt[11 * k + i];
+#pragma unroll
+    for (int i = 0; i < D; i++) dq[i] = Dt[11 * (k + 1) + i];
+    double bound = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; i++) { const double c = fabs(q[i] / q[D]); if (c > bound) bound = c; }
+    bound = bound + 1.0;
+    if (!isfinite(bound)) { fail = true; return; }
+    double lo = -bound;                                   // the sequential scan's `lo`: running maximum of the accepted ends
+    for (int i = 0; i < j; i++) { const double c = crit[i]; if (c > lo) lo = c; }
+    const double hi = j < nc ? crit[j] : bound;
+    if (!(hi > lo)) return;
+    const double flo = peval_d<D>(q, lo), fhi = peval_d<D>(q, hi);
+    if (flo != 0.0 && fhi != 0.0 && (flo < 0.0) != (fhi < 0.0)) {
+        // an end that is only the Cauchy bound can be astronomically far from the root: walk towards it from the
+        // finite end with doubling steps until the sign change is enclosed
+        double a = lo, fa = flo, b = hi;
+        bool a_far = j == 0, b_far = j == nc, hit = false;
+        if (a_far && b_far) {
+            const double f0 = peval_d<D>(q, 0.0);
+            if (f0 == 0.0) hit = true;
+            else if ((f0 < 0.0) == (fa < 0.0)) { a = 0.0; fa = f0; a_far = false; }
+            else { b = 0.0; b_far = false; }
+        }
+        if (!hit && a_far) {
+            double h = fabs(b) > 1.0 ? fabs(b) : 1.0;
+            for (int it = 0; it < 1100; it++) {
+                const double x = b - h;
+                if (!(x > a)) break;
+                const double fx = peval_d<D>(q, x);
+                if (fx == 0.0) { hit = true; root = x; break; }
+                if ((fx < 0.0) == (fa < 0.0)) { a = x; fa = fx; break; }
+                b = x; h = 2.0 * h;
+            }
+        } else if (!hit && b_far) {
+            double h = fabs(a) > 1.0 ? fabs(a) : 1.0;
+            for (int it = 0; it < 1100; it++) {
+                const double x = a + h;
+                if (!(x < b)) break;
+                const double fx = peval_d<D>(q, x);
+                if (fx == 0.0) { hit = true; root = x; break; }
+                if ((fx < 0.0) != (fa < 0.0)) { b = x; break; }
+                a = x; fa = fx; h = 2.0 * h;
+            }
+        }
+        if (!hit) root = bracket_root<D>(q, dq, a, b, fa);
+        found = true;
+    }
+    else if (fhi == 0.0 && j < nc) { found = true; root = hi; }
+}
+
 // Team part: the FP_TEAM lanes of a 5-tuple take one bracketing interval each, level by level (the roots of the
 // (k+1)-th derivative bracket those of the k-th).  Every lane performs exactly the operations the sequential
 // statement performs for its interval, and the roots are compacted in interval order, so the result is the same
@@ -138,61 +193,16 @@ __device__ static int team_real_roots(Col D, int l, int team)
         bool found = false, fail = false;
         double root = 0.0;
         if (act && l <= nc) {
-            const int d = deg - k, j = l;
-            double q[11], dq[11];
-#pragma unroll
-            for (int i = 0; i < 11; i++) { q[i] = i <= d ? D[11 * k + i] : 0.0; dq[i] = i < d ? D[11 * (k + 1) + i] : 0.0; }
-            double qd = 0.0;
-#pragma unroll
-            for (int i = 0; i < 11; i++) if (i == d) qd = q[i];
-            double bound = 0.0;
-#pragma unroll
-            for (int i = 0; i < 10; i++) if (i < d) { const double c = fabs(q[i] / qd); if (c > bound) bound = c; }
-            bound = bound + 1.0;
-            if (!isfinite(bound)) fail = true;
-            else {
-                double lo = -bound;                       // the sequential scan's `lo`: running maximum of the accepted ends
-                for (int i = 0; i < j; i++) { const double c = crit[i]; if (c > lo) lo = c; }
-                const double hi = j < nc ? crit[j] : bound;
-                if (hi > lo) {
-                    const double flo = peval_r(q, d, lo), fhi = peval_r(q, d, hi);
-                    if (flo != 0.0 && fhi != 0.0 && (flo < 0.0) != (fhi < 0.0)) {
-                        // an end that is only the Cauchy bound can be astronomically far from the root: walk towards
-                        // it from the finite end with doubling steps until the sign change is enclosed
-                        double a = lo, fa = flo, b = hi;
-                        bool a_far = j == 0, b_far = j == nc, hit = false;
-                        if (a_far && b_far) {
-                            const double f0 = peval_r(q, d, 0.0);
-                            if (f0 == 0.0) hit = true;
-                            else if ((f0 < 0.0) == (fa < 0.0)) { a = 0.0; fa = f0; a_far = false; }
-                            else { b = 0.0; b_far = false; }
-                        }
-                        if (!hit && a_far) {
-                            double h = fabs(b) > 1.0 ? fabs(b) : 1.0;
-                            for (int it = 0; it < 1100; it++) {
-                                const double x = b - h;
-                                if (!(x > a)) break;
-                                const double fx = peval_r(q, d, x);
-                                if (fx == 0.0) { hit = true; root = x; break; }
-                                if ((fx < 0.0) == (fa < 0.0)) { a = x; fa = fx; break; }
-                                b = x; h = 2.0 * h;
-                            }
-                        } else if (!hit && b_far) {
-                            double h = fabs(a) > 1.0 ? fabs(a) : 1.0;
-                            for (int it = 0; it < 1100; it++) {
-                                const double x = a + h;
-                                if (!(x < b)) break;
-                                const double fx = peval_r(q, d, x);
-                                if (fx == 0.0) { hit = true; root = x; break; }
-                                if ((fx < 0.0) != (fa < 0.0)) { b = x; break; }
-                                a = x; fa = fx; h = 2.0 * h;
-                            }
-                        }
-                        if (!hit) root = bracket_root(q, dq, d, a, b, fa);
-                        found = true;
-                    }
-                    else if (fhi == 0.0 && j < nc) { found = true; root = hi; }
-                }
+            switch (deg - k) {                            // degree of this level's polynomial (team-uniform)
+            case 2: interval_root<2>(D, k, l, nc, found, fail, root); break;
+            case 3: interval_root<3>(D, k, l, nc, found, fail, root); break;
+            case 4: interval_root<4>(D, k, l, nc, found, fail, root); break;
+            case 5: interval_root<5>(D, k, l, nc, found, fail, root); break;
+            case 6: interval_root<6>(D, k, l, nc, found, fail, root); break;
+            case 7: interval_root<7>(D, k, l, nc, found, fail, root); break;
+            case 8: interval_root<8>(D, k, l, nc, found, fail, root); break;
+            case 9: interval_root<9>(D, k, l, nc, found, fail, root); break;
+            default: interval_root<10>(D, k, l, nc, found, fail, root); break;
             }
         }
         const unsigned long long mf = __ballot(found), mx = __ballot(fail);
