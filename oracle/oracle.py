@@ -309,10 +309,10 @@ def triangulate(P1, P2, T21, cam1, cam2, px1_yx, px2_yx, max_error, min_depth=0.
     return out, st.astype(bool)
 
 
-def sym4_min_eigvec(S):
+def sym4_min_eigvec(S, inverse_iteration=False):
     S = np.array(S, dtype=np.float64, order="C").copy()
     v = np.zeros(4)
-    lib().orc_sym4_min_eigvec(_p(S), _p(v))
+    (lib().orc_sym4_min_eigvec_invit if inverse_iteration else lib().orc_sym4_min_eigvec)(_p(S), _p(v))
     return v
 
 

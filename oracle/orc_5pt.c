@@ -13,7 +13,8 @@
  *     (safeguarded Newton/bisection), back-substitution -- only + - * / sqrt throughout;
  *   - pose from E in closed form (Horn 1990: b b' = tr(E E')/2 I - E E', (b.b) R = cof(E) -/+ [b]x E), the four
  *     (R, +-t) candidates disambiguated by cheirality (closed-form ray depths) on the five sample points;
- *   - scoring: DLT triangulation of every correspondence (the mapper's `triangulate`, orc_tri.c), inlier iff both
+ *   - scoring: DLT triangulation of every correspondence (the mapper's `triangulate`, orc_tri.c, its eigenvector by
+ *     inverse iteration instead of Jacobi sweeps: orc_sym4_min_eigvec_invit), inlier iff both
  *     depths > 0 and both reprojection errors < max_repr_error;
  *   - sample 5-tuples are SUPPLIED BY THE CALLER, all are evaluated; winner = most inliers, ties to the lower
  *     sample, then the lower root.
@@ -347,7 +348,7 @@ int orc_essential_poses(const double E[9], double Rt[48])
 }
 
 /* DLT triangulation of one correspondence under P1 = K1 [I | 0], P2 = K2 [R | t] (K: fx, fy, cx, cy; pixels
- * (x, y)); same A'A / smallest-eigenvector construction as orc_triangulate_point.  X: point in camera-1
+ * (x, y)); same A'A / smallest-eigenvector construction as orc_triangulate_point (inverse iteration).  X: point in camera-1
  * coordinates, Y: in camera-2 coordinates.  Returns 0 when the homogeneous scale vanishes. */
 static int tri_two_view(const double *k1, const double *k2, const double *Rt, const double *a, const double *b, double *X, double *Y)
 {
@@ -369,7 +370,7 @@ static int tri_two_view(const double *k1, const double *k2, const double *Rt, co
             for (int k = 0; k < 4; k++) acc += A[4 * k + i] * A[4 * k + j];
             S[4 * i + j] = acc;
         }
-    orc_sym4_min_eigvec(S, v);
+    orc_sym4_min_eigvec_invit(S, v);
     const double iw = 1.0 / v[3];
     X[0] = v[0] * iw; X[1] = v[1] * iw; X[2] = v[2] * iw;
     for (int r = 0; r < 3; r++) Y[r] = ((Rt[r] * X[0] + Rt[3 + r] * X[1]) + Rt[6 + r] * X[2]) + Rt[9 + r];

@@ -170,6 +170,7 @@ int  orc_pnp_ba(double fx, double fy, double cx, double cy, const double pose_cw
 
 /* ---- two-view triangulation + gating (mapper.jl:142-262; RecoverPose.triangulate restated) -- orc_tri.c ---- */
 void orc_sym4_min_eigvec(double S[16], double v[4]);
+void orc_sym4_min_eigvec_invit(const double S[16], double v[4]);
 int  orc_triangulate_point(const double *P1, const double *P2, const double *T21, const double *cam1, const double *cam2,
                            const double *px1_yx, const double *px2_yx, double max_error, double min_depth,
                            int gate_always, double parallax, double min_parallax, double *xyz);

@@ -10,11 +10,12 @@
 //                 hypotheses are bit-identical to the CPU statement.  The 10x20 elimination matrix and the
 //                 derivative table live in LDS, one column of doubles per thread.
 //   k_5pt_score   one 256-thread workgroup per (5-tuple, pose): the threads stride over the correspondences -- DLT
-//                 triangulation (4x4 Jacobi, the mapper's `triangulate`), both depths > 0, both reprojection
+//                 triangulation (the mapper's 4x4 system, eigenvector by inverse iteration), both depths > 0, both reprojection
 //                 errors < max_repr_error -- and a butterfly + LDS add the inlier counts.
 //   k_5pt_select  one workgroup: winner (most inliers, ties to the earlier tuple, then root), inlier mask, summed
 //                 error, E and [R | t].
-// ~iters x 5 x n triangulations of ~3 kflop each (256 x 5 x 1000: 4 Gflop f64): compute-bound on the f64 VALU.
+// The solver is a latency chain (0.2 ms for any tuple count that fits the GPU); scoring is ~iters x 6 x n triangulations
+// of ~0.4 kflop each.
 #include "common.hpp"
 #include "tri_device.hpp"
 #include <cmath>
@@ -476,7 +477,7 @@ __device__ static inline bool tri_two_view(const double *k1, const double *k2, c
             for (int k = 0; k < 4; k++) acc += A[4 * k + i] * A[4 * k + j];
             S[4 * i + j] = acc;
         }
-    sym4_min_eigvec(S, v);
+    sym4_min_eigvec_invit(S, v);
     const double iw = 1.0 / v[3];
     X[0] = v[0] * iw; X[1] = v[1] * iw; X[2] = v[2] * iw;
     for (int r = 0; r < 3; r++) Y[r] = ((Rt[r] * X[0] + Rt[3 + r] * X[1]) + Rt[6 + r] * X[2]) + Rt[9 + r];
@@ -616,13 +617,19 @@ __global__ __launch_bounds__(FP_SEL_T) void k_5pt_select(FPArgs T)
             in = two_view_errors(T.k1, T.k2, s_P, a, b, &e1, &e2) && e1 < T.thr && e2 < T.thr;
         }
         T.inliers[i] = in ? 1 : 0;
-        if (in_lds) s_err[i] = in ? e1 + e2 : -1.0; else T.errs[i] = in ? e1 + e2 : -1.0;
+        if (in_lds) s_err[i] = in ? e1 + e2 : 0.0; else T.errs[i] = in ? e1 + e2 : 0.0;   // + 0.0 leaves the sum unchanged
     }
     __threadfence_block();
     __syncthreads();
     if (tid == 0) {
         double esum = 0.0;
-        for (int i = 0; i < T.n; i++) { const double e = in_lds ? s_err[i] : T.errs[i]; if (e >= 0.0) esum += e; }
+        if (in_lds) {
+#pragma unroll 16
+            for (int i = 0; i < T.n; i++) esum += s_err[i];           // index order; the reads pipeline, the adds are the chain
+        } else {
+#pragma unroll 16
+            for (int i = 0; i < T.n; i++) esum += T.errs[i];
+        }
         *T.error = esum;
         *T.n_inliers = best;
         *T.best_iter = best > 0 ? be / FP_MAXE : -1;

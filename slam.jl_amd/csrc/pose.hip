@@ -256,13 +256,19 @@ __global__ __launch_bounds__(256) void k_p3p_select(P3PArgs T)
         }
         const bool in = best > 0 && e >= 0.0 && e < T.thr;
         T.inliers[i] = in ? 1 : 0;
-        if (in_lds) s_err[i] = in ? e : -1.0; else T.errs[i] = in ? e : -1.0;
+        if (in_lds) s_err[i] = in ? e : 0.0; else T.errs[i] = in ? e : 0.0;   // + 0.0 leaves the sum unchanged
     }
     __threadfence_block();
     __syncthreads();
     if (tid == 0) {
         double esum = 0.0;
-        for (int i = 0; i < T.n; i++) { const double e = in_lds ? s_err[i] : T.errs[i]; if (e >= 0.0) esum += e; }
+        if (in_lds) {
+#pragma unroll 16
+            for (int i = 0; i < T.n; i++) esum += s_err[i];           // index order; the reads pipeline, the adds are the chain
+        } else {
+#pragma unroll 16
+            for (int i = 0; i < T.n; i++) esum += T.errs[i];
+        }
         *T.error = esum;
         *T.n_inliers = best;
         *T.best_iter = best > 0 ? be / 4 : -1;

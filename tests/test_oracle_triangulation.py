@@ -49,3 +49,23 @@ def test_gates(orc, syn, slam_host):
     _, st_t = orc.triangulate(P1, P2, s["T21"], s["cam"], s["cam"], s["px1"], s["px2"], max_error=3.0, parallax=par, min_parallax=20.0)
     assert not st_t[s["gross"][:10]].any()
     assert st_t[s["gross"][10:]].all() and st_t[s["behind"]].all()
+
+
+def test_inverse_iteration_eigvec_matches_jacobi_and_numpy(orc, syn, slam_host):
+    """orc_sym4_min_eigvec_invit (hypothesis scoring) against the Jacobi routine and numpy on real DLT matrices."""
+    s = syn.triangulation_scene(n=600, seed=8, noise_px=0.5, temporal=True)
+    P1, P2 = slam_host.projection_matrices(s["cam"], s["cam"], s["T21"])
+    worst = 0.0
+    for i in range(600):
+        A = _dlt(P1, P2, s["px1"][i], s["px2"][i])
+        S = A.T @ A
+        v1 = orc.sym4_min_eigvec(S); v2 = orc.sym4_min_eigvec(S, inverse_iteration=True)
+        X1, X2 = v1[:3] / v1[3], v2[:3] / v2[3]
+        worst = max(worst, np.abs(X1 - X2).max() / np.abs(X1).max())
+        if i % 50 == 0:
+            w, V = np.linalg.eigh(S)
+            ref = V[:3, 0] / V[3, 0]
+            assert np.allclose(X2, ref, rtol=1e-6)
+    assert worst < 1e-7
+    v = orc.sym4_min_eigvec(np.zeros((4, 4)), inverse_iteration=True)               # degenerate input: finite output
+    assert np.isfinite(v).all()
