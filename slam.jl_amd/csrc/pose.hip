@@ -1,9 +1,9 @@
 // pose.hip -- P3P RANSAC of compute_pose! (src/front_end.jl:132-219; the call p3p_ransac(...) at :164-167).
 //
-// One 64-lane workgroup per caller-supplied sample triple: every lane runs the (wave-uniform) minimal solver --
+// One 256-thread workgroup per caller-supplied sample triple: every wave runs the (wave-uniform) minimal solver --
 // Grunert's quartic by polynomial arithmetic, Ferrari's factorisation with a safeguarded-Newton resolvent root,
-// i.e. only + - * / sqrt, so the hypotheses are bit-identical to the CPU statement -- then the lanes stride over
-// the map points and count inliers per solution.  A second single-workgroup kernel picks the winner (most inliers,
+// i.e. only + - * / sqrt, so the hypotheses are bit-identical to the CPU statement -- then wave s strides over
+// the map points and counts the inliers of solution s.  A second single-workgroup kernel picks the winner (most inliers,
 // ties to the lower iteration then solution), writes its inlier mask, the summed inlier error (index order) and
 // K [R | t].  Inputs/outputs live in the context's mapped pinned block (a few tens of KB), scores in device scratch.
 // The work is ~iters x 4 x n reprojections (256 x 4 x 1000 = 1 M): launch- and latency-bound, not HBM-bound.
@@ -183,12 +183,13 @@ __device__ static inline double p3p_reproj(const double *P, const double *K, con
     return sqrt(dx * dx + dy * dy);
 }
 
-__global__ __launch_bounds__(64) void k_p3p_score(P3PArgs T)
+__global__ __launch_bounds__(256) void k_p3p_score(P3PArgs T)
 {
-    __shared__ double s_rt[48];
-    const int it = blockIdx.x, lane = threadIdx.x;
+    // four waves per triple: each runs the (wave-uniform) solver, wave s then scores pose s with its 64 lanes
+    const int it = blockIdx.x, lane = threadIdx.x & 63, s = threadIdx.x >> 6;
     const int i0 = T.samples[3 * it], i1 = T.samples[3 * it + 1], i2 = T.samples[3 * it + 2];
     int ns = 0;
+    double P[12];
     const bool valid = !(i0 < 0 || i1 < 0 || i2 < 0 || i0 >= T.n || i1 >= T.n || i2 >= T.n || i0 == i1 || i0 == i2 || i1 == i2);
     if (valid) {
         double X[9], F[9];
@@ -197,29 +198,25 @@ __global__ __launch_bounds__(64) void k_p3p_score(P3PArgs T)
             F[j] = T.pdn[3 * i0 + j]; F[3 + j] = T.pdn[3 * i1 + j]; F[6 + j] = T.pdn[3 * i2 + j];
         }
         double Rt[48];
-        ns = p3p_solve(X, F, Rt);          // wave-uniform: every lane computes the same poses
-        if (lane == 0)
-            for (int j = 0; j < 12 * ns; j++) s_rt[j] = Rt[j];
+        ns = p3p_solve(X, F, Rt);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k == s) for (int j = 0; j < 12; j++) P[j] = Rt[12 * k + j];
     }
-    __syncthreads();
-    for (int s = 0; s < 4; s++) {
-        int cnt = 0;
-        if (s < ns) {
-            double P[12];
-            for (int j = 0; j < 12; j++) P[j] = s_rt[12 * s + j];
-            for (int i = lane; i < T.n; i += 64) {
-                const double X[3] = {T.pts[3 * i], T.pts[3 * i + 1], T.pts[3 * i + 2]};
-                const double px[2] = {T.px[2 * i], T.px[2 * i + 1]};
-                const double e = p3p_reproj(P, T.K, X, px);
-                cnt += (e >= 0.0 && e < T.thr) ? 1 : 0;
-            }
-            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    int cnt = 0;
+    if (s < ns) {
+        for (int i = lane; i < T.n; i += 64) {
+            const double X[3] = {T.pts[3 * i], T.pts[3 * i + 1], T.pts[3 * i + 2]};
+            const double px[2] = {T.px[2 * i], T.px[2 * i + 1]};
+            const double e = p3p_reproj(P, T.K, X, px);
+            cnt += (e >= 0.0 && e < T.thr) ? 1 : 0;
         }
-        if (lane == 0) {
-            T.counts[4 * it + s] = cnt;
-            if (s < ns)
-                for (int j = 0; j < 12; j++) T.poses[(size_t)(4 * it + s) * 12 + j] = s_rt[12 * s + j];
-        }
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    }
+    if (lane == 0) {
+        T.counts[4 * it + s] = cnt;
+        if (s < ns)
+            for (int j = 0; j < 12; j++) T.poses[(size_t)(4 * it + s) * 12 + j] = P[j];
     }
 }
 
@@ -320,7 +317,7 @@ extern "C" int slam_p3p_ransac(slam_ctx *ctx, const double *pts3d, const double 
     T.n_inliers = (int *)(d + o_out + 200); T.best_iter = (int *)(d + o_out + 204);
     T.inliers = (uint8_t *)(d + o_inl);
     { ProfScope span(ctx, "p3p_ransac");
-      hipLaunchKernelGGL(k_p3p_score, dim3(iters), dim3(64), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_p3p_score, dim3(iters), dim3(256), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_p3p_select, dim3(1), dim3(256), 0, ctx->stream, T); }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
