@@ -6,7 +6,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,iters,noise,outl", [(300, 64, 0.3, 0.25), (1000, 96, 0.5, 0.4), (40, 32, 0.0, 0.0), (8, 16, 0.2, 0.0)])
+@pytest.mark.parametrize("n,iters,noise,outl", [(300, 64, 0.3, 0.25), (1000, 96, 0.5, 0.4), (40, 32, 0.0, 0.0), (8, 16, 0.2, 0.0),
+                                                 (4500, 12, 0.4, 0.3)])    # > 4096 correspondences: global-memory error path
 def test_five_point_matches_oracle(slam, orc, syn, n, iters, noise, outl):
     sc = syn.five_point_scene(n=n, seed=n, noise_px=noise, outlier_frac=outl, iters=iters)
     ref = orc.five_point_ransac(sc["px1"], sc["px2"], sc["pd1"], sc["pd2"], sc["K"], sc["K"], 3.0, sc["samples"])
