@@ -538,6 +538,27 @@ def main():
             cnt5 = fp_once()
         out["pose"]["five_point"] = {"points": 1000, "ransac_tuples": 128, "inliers": int(cnt5),
                                      "ms_per_call": (time.perf_counter() - t0) / 10 * 1e3}
+        # the same three seams for 32 lock-stepped streams: one launch set each (slam_*_batch)
+        SB = 32
+        pss = [syn.p3p_scene(n=1000, seed=40 + z, noise_px=0.4, outlier_frac=0.25, iters=256) for z in range(SB)]
+        fss = [syn.five_point_scene(n=1000, seed=40 + z, noise_px=0.4, outlier_frac=0.25, iters=128) for z in range(SB)]
+        def pose_batch_once():
+            r5 = slam.five_point_ransac_batch([f["px1"] for f in fss], [f["px2"] for f in fss], [f["pd1"] for f in fss], [f["pd2"] for f in fss],
+                                              Kc, Kc, max_repr_error=3.0, samples=[f["samples"] for f in fss], ctx=ctx)
+            r3 = slam.p3p_ransac_batch([q["pts3d"] for q in pss], [q["px_xy"] for q in pss], [q["pdn"] for q in pss], Kc, threshold=3.0,
+                                       samples=[q["samples"] for q in pss], ctx=ctx)
+            poses, pix, pts = [], [], []
+            for q, r in zip(pss, r3):
+                T0 = np.eye(4); T0[:3] = r[1][3]
+                poses.append(T0); pix.append(q["px_xy"][r[1][1]][:, ::-1]); pts.append(q["pts3d"][r[1][1]])
+            slam.pnp_bundle_adjustment_batch(camp, poses, pix, pts, repr_eps=3.0, ctx=ctx)
+            return sum(r[0] for r in r5)
+        pose_batch_once()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pose_batch_once()
+        out["pose"]["batch"] = {"streams": SB, "ms_per_step": (time.perf_counter() - t0) / 5 * 1e3,
+                                "what": "five-point RANSAC + P3P RANSAC + PnP refinement for 32 streams (3 launch sets), host lists in and out"}
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----------
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -254,6 +254,25 @@ int slam_five_point_ransac(slam_ctx *ctx, const double *px1_xy, const double *px
                            const int32_t *samples, int iters, double *E, double *P, uint8_t *inliers,
                            int *n_inliers, double *error, int *best_iter);
 
+/* The pose seams for S lock-stepped streams (no reference counterpart, like the other *_batch entry points): S
+ * independent problems in one set of launches, results identical to S single calls.  Problem z owns the elements
+ * [offsets[z], offsets[z+1]) of the concatenated point arrays (offsets[0] = 0; offsets has S + 1 entries; empty
+ * problems are allowed and report n_inliers = 0); per-problem matrices are stored back to back (K: S x 9, KP / Rt /
+ * P: S x 12, E: S x 9, poses: S x 16, cams: S x 4 as fx, fy, cx, cy); samples are S x iters x 3 (x 5), indices
+ * local to their problem. */
+int slam_p3p_ransac_batch(slam_ctx *ctx, int S, const int32_t *offsets, const double *pts3d, const double *px_xy,
+                          const double *pdn, const double *K, double threshold, const int32_t *samples, int iters,
+                          double *KP, double *Rt, uint8_t *inliers, int *n_inliers, double *error, int *best_iter);
+int slam_five_point_ransac_batch(slam_ctx *ctx, int S, const int32_t *offsets, const double *px1_xy, const double *px2_xy,
+                                 const double *pd1_xy, const double *pd2_xy, const double *K1, const double *K2,
+                                 double max_repr_error, const int32_t *samples, int iters, double *E, double *P,
+                                 uint8_t *inliers, int *n_inliers, double *error, int *best_iter);
+/* slam_pnp_ba for S poses, one workgroup per problem */
+int slam_pnp_ba_batch(slam_ctx *ctx, int S, const int32_t *offsets, const double *cams, const double *poses_cw,
+                      const double *pixels_yx, const double *points_xyz, int iters_fast, int iterations,
+                      double depth_eps, double repr_eps, double *out_poses, double *err_init, double *err_final,
+                      uint8_t *outliers, int *n_outliers);
+
 /* bundle_adjustment!(cache::LocalBACache, camera; iterations, repr_eps) --
  * src/bundle_adjustment.jl:1-111 on the flat arrays of src/estimator.jl:16-40:
  * theta = [6P (RotZYX t1,t2,t3, tx,ty,tz) ; 3M], pixels (y,x) 2 x O, 1-based ids.

@@ -38,6 +38,9 @@ SIGNATURES = {
     "slam_triangulate": (cint, [vp, f64p, f64p, f64p, f64p, f64p, f64p, f64p, cint, dbl, dbl, f64p, dbl, f64p, u8p]),
     "slam_p3p_ransac": (cint, [vp, f64p, f64p, f64p, cint, f64p, dbl, i32p, cint, f64p, f64p, u8p, C.POINTER(cint), f64p, C.POINTER(cint)]),
     "slam_five_point_ransac": (cint, [vp, f64p, f64p, f64p, f64p, cint, f64p, f64p, dbl, i32p, cint, f64p, f64p, u8p, C.POINTER(cint), f64p, C.POINTER(cint)]),
+    "slam_p3p_ransac_batch": (cint, [vp, cint, i32p, f64p, f64p, f64p, f64p, dbl, i32p, cint, f64p, f64p, u8p, i32p, f64p, i32p]),
+    "slam_five_point_ransac_batch": (cint, [vp, cint, i32p, f64p, f64p, f64p, f64p, f64p, f64p, dbl, i32p, cint, f64p, f64p, u8p, i32p, f64p, i32p]),
+    "slam_pnp_ba_batch": (cint, [vp, cint, i32p, f64p, f64p, f64p, f64p, cint, cint, dbl, dbl, f64p, f64p, f64p, u8p, i32p]),
     "slam_describe": (cint, [vp, f64p, cint, cint, i64p, cint, i32p, cint, dbl, cint, u64p, i64p, C.POINTER(cint)]),
     "slam_pyr_create": (cint, [vp, cint, cint, cint, C.POINTER(vp)]),
     "slam_pyr_destroy": (cint, [vp]),

@@ -67,3 +67,23 @@ def pnp_bundle_adjustment(camera, pose, pixels, points, iterations=10, depth_eps
                                   float(depth_eps), float(repr_eps), L.ptr(out), C.byref(e0), C.byref(e1),
                                   L.ptr(outl, L.u8p), C.byref(no)))
     return np.array(out), e0.value, e1.value, outl[:n].astype(bool), no.value
+
+
+def pnp_bundle_adjustment_batch(cameras, poses, pixels, points, iterations=10, depth_eps=1e-6, repr_eps=5.0, iters_fast=5, ctx=None):
+    """S single-pose refinements in one launch (lists of per-stream arrays; cameras: one (fx, fy, cx, cy) or S of them).
+    Returns a list of `(new_pose 4x4, initial_error, final_error, outliers, n_outliers)`."""
+    ctx = ctx or L.default_context()
+    S = len(poses)
+    px = [np.ascontiguousarray(p, dtype=np.float64).reshape(-1, 2) for p in pixels]
+    pt = [np.ascontiguousarray(p, dtype=np.float64).reshape(-1, 3) for p in points]
+    off = np.zeros(S + 1, dtype=np.int32); off[1:] = np.cumsum([len(p) for p in px])
+    if [len(p) for p in px] != [len(p) for p in pt]:
+        raise ValueError("pixels and points must have matching lengths")
+    cams = np.asarray([c.intrinsics if hasattr(c, "intrinsics") else c for c in (cameras if np.ndim(cameras[0]) else [cameras] * S)], dtype=np.float64).reshape(S, 4)
+    pin = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float64).T for p in poses])) if S else np.zeros((0, 4, 4))   # column-major
+    pxa = np.concatenate(px) if S else np.zeros((0, 2)); pta = np.concatenate(pt) if S else np.zeros((0, 3))
+    out = np.zeros((S, 16)); e0 = np.zeros(S); e1 = np.zeros(S); no = np.zeros(S, dtype=np.int32)
+    outl = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
+    ctx.check(ctx.lib.slam_pnp_ba_batch(ctx.h, S, L.ptr(off, L.i32p), L.ptr(cams), L.ptr(pin), L.ptr(pxa), L.ptr(pta), int(iters_fast), int(iterations),
+                                        float(depth_eps), float(repr_eps), L.ptr(out), L.ptr(e0), L.ptr(e1), L.ptr(outl, L.u8p), L.ptr(no, L.i32p)))
+    return [(out[z].reshape(4, 4).T.copy(), float(e0[z]), float(e1[z]), outl[off[z]:off[z + 1]].astype(bool), int(no[z])) for z in range(S)]

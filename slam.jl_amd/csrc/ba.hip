@@ -1206,7 +1206,7 @@ __device__ int pnp_lm(const PnPArgs &A, double *X /*shared 6*/, int ignore, int 
     return iter;
 }
 
-__global__ __launch_bounds__(PNP_T) void k_pnp(PnPArgs A)
+__device__ void pnp_body(const PnPArgs &A)
 {
     __shared__ double X[6], Xt[6], dxs[6], sh[4 * 28], red[40];
     __shared__ int flags[4];
@@ -1245,6 +1245,88 @@ __global__ __launch_bounds__(PNP_T) void k_pnp(PnPArgs A)
     }
 }
 
+__global__ __launch_bounds__(PNP_T) void k_pnp(PnPArgs A) { pnp_body(A); }
+// S independent problems, one workgroup each (slam_pnp_ba_batch); the argument blocks live in mapped host memory
+__global__ __launch_bounds__(PNP_T) void k_pnp_batch(const PnPArgs *args)
+{
+    __shared__ PnPArgs A;
+    if (threadIdx.x == 0) A = args[blockIdx.x];
+    __syncthreads();
+    pnp_body(A);
+}
+
+// RotZYX(pose[1:3,1:3]) -> angles (Rotations.jl), pose column-major: R[i][j] = pose[i + 4j]
+static void pnp_pose_to_x(const double *pose_cw, double *X0)
+{
+    const double R11 = pose_cw[0], R21 = pose_cw[1], R31 = pose_cw[2], R12 = pose_cw[4], R22 = pose_cw[5], R13 = pose_cw[8], R23 = pose_cw[9];
+    const double t1 = std::atan2(R21, R11), s1 = std::sin(t1), c1 = std::cos(t1);
+    X0[0] = t1; X0[1] = std::atan2(-R31, std::sqrt(R11 * R11 + R21 * R21)); X0[2] = std::atan2(R13 * s1 - R23 * c1, R22 * c1 - R12 * s1);
+    X0[3] = pose_cw[12]; X0[4] = pose_cw[13]; X0[5] = pose_cw[14];
+}
+static void pnp_x_to_pose(const double *res, double *out_pose)
+{
+    for (int k = 0; k < 16; k++) out_pose[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    if (res[9] == 0.0) {
+        const double s1 = std::sin(res[0]), c1 = std::cos(res[0]), s2 = std::sin(res[1]), c2 = std::cos(res[1]), s3 = std::sin(res[2]), c3 = std::cos(res[2]);
+        const double R[9] = {c1 * c2, c1 * s2 * s3 - s1 * c3, c1 * s2 * c3 + s1 * s3, s1 * c2, s1 * s2 * s3 + c1 * c3, s1 * s2 * c3 - c1 * s3, -s2, c2 * s3, c2 * c3};
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out_pose[i + 4 * j] = R[3 * i + j];
+        out_pose[12] = res[3]; out_pose[13] = res[4]; out_pose[14] = res[5];
+    }
+}
+
+// S single-pose refinements in one launch: problem z owns points [offsets[z], offsets[z+1]); cams S x 4 (fx, fy,
+// cx, cy), poses_cw / out_poses S x 16 column-major
+extern "C" int slam_pnp_ba_batch(slam_ctx *ctx, int S, const int32_t *offsets, const double *cams, const double *poses_cw,
+                                 const double *pixels_yx, const double *points_xyz, int iters_fast, int iterations,
+                                 double depth_eps, double repr_eps, double *out_poses, double *err_init, double *err_final,
+                                 uint8_t *outliers, int *n_outliers)
+{
+    ARG_TRY(ctx, ctx != nullptr && S >= 0);
+    if (S == 0) return SLAM_OK;
+    ARG_TRY(ctx, offsets && cams && poses_cw && out_poses && offsets[0] == 0);
+    for (int z = 0; z < S; z++) ARG_TRY(ctx, offsets[z + 1] >= offsets[z]);
+    const int ntot = offsets[S];
+    ARG_TRY(ctx, ntot == 0 || (pixels_yx && points_xyz && outliers));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t pxb = al((size_t)ntot * 16 + 8), ptb = al((size_t)ntot * 24 + 8), ob = al((size_t)ntot + 8), rb = al((size_t)S * 128);
+    char *s;
+    int rc = slam_scratch(ctx, pxb + ptb + ob + rb, (void **)&s);
+    if (rc) return rc;
+    double *d_px = (double *)s, *d_pts = (double *)(s + pxb); uint8_t *d_o = (uint8_t *)(s + pxb + ptb); double *d_res = (double *)(s + pxb + ptb + ob);
+    char *h, *d;
+    rc = slam_pinned(ctx, (size_t)S * sizeof(PnPArgs) + (size_t)S * 128, (void **)&h);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipHostGetDevicePointer((void **)&d, h, 0));
+    PnPArgs *args = (PnPArgs *)h;
+    for (int z = 0; z < S; z++) {
+        PnPArgs &A = args[z];
+        A.cam = {cams[4 * z], cams[4 * z + 1], cams[4 * z + 2], cams[4 * z + 3]};
+        A.n = offsets[z + 1] - offsets[z]; A.iters_fast = iters_fast; A.iterations = iterations;
+        A.depth_eps = depth_eps; A.repr_eps = repr_eps;
+        pnp_pose_to_x(poses_cw + 16 * z, A.X0);
+        A.px = d_px + 2 * (size_t)offsets[z]; A.pts = d_pts + 3 * (size_t)offsets[z]; A.outl = d_o + offsets[z]; A.result = d_res + 16 * z;
+    }
+    if (ntot > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_px, pixels_yx, (size_t)ntot * 16, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_pts, points_xyz, (size_t)ntot * 24, hipMemcpyHostToDevice, ctx->stream));
+    }
+    { ProfScope span(ctx, "pnp_ba");
+      hipLaunchKernelGGL(k_pnp_batch, dim3(S), dim3(PNP_T), 0, ctx->stream, (const PnPArgs *)d); }
+    HIP_TRY(ctx, hipGetLastError());
+    double *res = (double *)(h + (size_t)S * sizeof(PnPArgs));
+    HIP_TRY(ctx, hipMemcpyAsync(res, d_res, (size_t)S * 128, hipMemcpyDeviceToHost, ctx->stream));
+    if (ntot > 0) HIP_TRY(ctx, hipMemcpyAsync(outliers, d_o, (size_t)ntot, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int z = 0; z < S; z++) {
+        const double *r = res + 16 * z;
+        if (err_init) err_init[z] = r[6];
+        if (err_final) err_final[z] = r[7];
+        if (n_outliers) n_outliers[z] = (int)r[8];
+        pnp_x_to_pose(r, out_poses + 16 * z);
+    }
+    return SLAM_OK;
+}
+
 extern "C" int slam_pnp_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy,
                            const double pose_cw[16], const double *pixels_yx, const double *points_xyz, int n,
                            int iters_fast, int iterations, double depth_eps, double repr_eps,
@@ -1256,11 +1338,7 @@ extern "C" int slam_pnp_ba(slam_ctx *ctx, double fx, double fy, double cx, doubl
     PnPArgs A;
     A.cam = {fx, fy, cx, cy}; A.n = n; A.iters_fast = iters_fast; A.iterations = iterations;
     A.depth_eps = depth_eps; A.repr_eps = repr_eps;
-    // RotZYX(pose[1:3,1:3]) -> angles (Rotations.jl), pose column-major: R[i][j] = pose[i + 4j]
-    { const double R11 = pose_cw[0], R21 = pose_cw[1], R31 = pose_cw[2], R12 = pose_cw[4], R22 = pose_cw[5], R13 = pose_cw[8], R23 = pose_cw[9];
-      const double t1 = std::atan2(R21, R11), s1 = std::sin(t1), c1 = std::cos(t1);
-      A.X0[0] = t1; A.X0[1] = std::atan2(-R31, std::sqrt(R11 * R11 + R21 * R21)); A.X0[2] = std::atan2(R13 * s1 - R23 * c1, R22 * c1 - R12 * s1);
-      A.X0[3] = pose_cw[12]; A.X0[4] = pose_cw[13]; A.X0[5] = pose_cw[14]; }
+    pnp_pose_to_x(pose_cw, A.X0);
     const size_t pxb = al((size_t)n * 16 + 8), ptb = al((size_t)n * 24 + 8), ob = al((size_t)n + 8);
     char *s;
     int rc = slam_scratch(ctx, pxb + ptb + ob + 256, (void **)&s);
@@ -1280,12 +1358,6 @@ extern "C" int slam_pnp_ba(slam_ctx *ctx, double fx, double fy, double cx, doubl
     if (err_init) *err_init = res[6];
     if (err_final) *err_final = res[7];
     if (n_outliers) *n_outliers = (int)res[8];
-    for (int k = 0; k < 16; k++) out_pose[k] = (k % 5 == 0) ? 1.0 : 0.0;
-    if (res[9] == 0.0) {
-        const double s1 = std::sin(res[0]), c1 = std::cos(res[0]), s2 = std::sin(res[1]), c2 = std::cos(res[1]), s3 = std::sin(res[2]), c3 = std::cos(res[2]);
-        const double R[9] = {c1 * c2, c1 * s2 * s3 - s1 * c3, c1 * s2 * c3 + s1 * s3, s1 * c2, s1 * s2 * s3 + c1 * c3, s1 * s2 * c3 - c1 * s3, -s2, c2 * s3, c2 * c3};
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out_pose[i + 4 * j] = R[3 * i + j];
-        out_pose[12] = res[3]; out_pose[13] = res[4]; out_pose[14] = res[5];
-    }
+    pnp_x_to_pose(res, out_pose);
     return SLAM_OK;
 }

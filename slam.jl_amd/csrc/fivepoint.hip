@@ -27,20 +27,20 @@
 #define FP_SEL_T 512                   // threads of the select kernel
 #define FP_ERR_LDS 4096                 // correspondences whose errors the select kernel stages in LDS
 
-struct FPArgs {
-    const double *px1, *px2, *pd1, *pd2;   // n x 2 each, (x, y)
-    const int32_t *samples;                // iters x 5, 0-based
-    int n, iters;
-    double k1[4], k2[4];                   // fx, fy, cx, cy
+struct FPArgs {                            // S independent problems (S = 1: slam_five_point_ransac); problem z owns [off[z], off[z+1])
+    const double *px1, *px2, *pd1, *pd2;   // concatenated, n x 2 each, (x, y)
+    const int32_t *samples;                // S x iters x 5, 0-based, local to the problem
+    const int *off;                        // S + 1
+    const double *ks;                      // S x 8: fx, fy, cx, cy of camera 1 then of camera 2
+    int iters;
     double thr;
-    int *ne;                               // iters: number of poses of the tuple
-    double *Es;                            // iters x 10 x 9 (row-major E)
-    double *poses;                         // iters x 10 x 12
-    int *counts;                           // iters x 10
-    double *errs;                          // n
-    double *E_out, *P_out, *error;         // outputs (mapped host)
-    uint8_t *inliers;
-    int *n_inliers, *best_iter;
+    int *ne;                               // S x iters: number of poses of the tuple
+    double *Es;                            // S x iters x 10 x 9 (row-major E)
+    double *poses;                         // S x iters x 10 x 12
+    int *counts;                           // S x iters x 10
+    double *errs;                          // off[S]
+    double *out;                           // S x 32 (mapped host): P 12 | E 9 | error | {n_inliers, best_iter} as two ints
+    uint8_t *inliers;                      // off[S] (mapped host)
 };
 
 // per-thread array in LDS: element i of thread t at base[i * FP_TPB + t]
@@ -511,27 +511,30 @@ __device__ static inline void ray_depths(const double *Rt, const double *q1, con
 __global__ __launch_bounds__(FP_TPB * FP_TEAM) void k_5pt_solve(FPArgs T)
 {
     extern __shared__ double s_fp[];
-    const int team = threadIdx.x / FP_TEAM, l = threadIdx.x % FP_TEAM;
+    const int team = threadIdx.x / FP_TEAM, l = threadIdx.x % FP_TEAM, z = blockIdx.y;
     const int it = blockIdx.x * FP_TPB + team;
+    const int base = T.off[z], n = T.off[z + 1] - base;
+    const double *pd1 = T.pd1 + 2 * (size_t)base, *pd2 = T.pd2 + 2 * (size_t)base;
     const Col L{s_fp + team};
     bool ok = it < T.iters;
     int ids[5] = {0, 0, 0, 0, 0};
     if (ok) {
-        const int32_t *sm = T.samples + 5 * it;
+        const int32_t *sm = T.samples + 5 * ((size_t)z * T.iters + it);
         for (int a = 0; a < 5; a++) {
             ids[a] = sm[a];
-            if (ids[a] < 0 || ids[a] >= T.n) ok = false;
+            if (ids[a] < 0 || ids[a] >= n) ok = false;
             for (int b = 0; b < a; b++) if (ids[a] == ids[b]) ok = false;
         }
     }
     double q1[10], q2[10], Es[9 * FP_MAXE];
     for (int a = 0; a < 5; a++) {
         const int id = ok ? ids[a] : 0;
-        q1[2 * a] = T.pd1[2 * id]; q1[2 * a + 1] = T.pd1[2 * id + 1];
-        q2[2 * a] = T.pd2[2 * id]; q2[2 * a + 1] = T.pd2[2 * id + 1];
+        q1[2 * a] = ok ? pd1[2 * id] : 0.0; q1[2 * a + 1] = ok ? pd1[2 * id + 1] : 0.0;
+        q2[2 * a] = ok ? pd2[2 * id] : 0.0; q2[2 * a + 1] = ok ? pd2[2 * id + 1] : 0.0;
     }
     const int ne = five_point_solve(q1, q2, Es, L, l, team, ok);      // all threads: it synchronises
     if (l != 0 || it >= T.iters) return;
+    const size_t slot = (size_t)z * T.iters + it;
     int np = 0;
     for (int e = 0; e < ne; e++) {
         double C[48];
@@ -551,29 +554,34 @@ __global__ __launch_bounds__(FP_TPB * FP_TEAM) void k_5pt_solve(FPArgs T)
 #pragma unroll
         for (int k = 0; k < 4; k++)
             if (k == bk) for (int j = 0; j < 12; j++) Rb[j] = C[12 * k + j];
-        double *po = T.poses + ((size_t)it * FP_MAXE + np) * 12, *eo = T.Es + ((size_t)it * FP_MAXE + np) * 9;
+        double *po = T.poses + (slot * FP_MAXE + np) * 12, *eo = T.Es + (slot * FP_MAXE + np) * 9;
         for (int j = 0; j < 12; j++) po[j] = Rb[j];
         for (int j = 0; j < 9; j++) eo[j] = Es[9 * e + j];
         np++;
     }
-    T.ne[it] = np;
+    T.ne[slot] = np;
 }
 
 __global__ __launch_bounds__(FP_SCORE_T) void k_5pt_score(FPArgs T)
 {
     __shared__ int s_part[FP_SCORE_T / 64];
-    const int it = blockIdx.x, e = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (e >= T.ne[it]) {                                  // workgroup-uniform
-        if (tid == 0) T.counts[it * FP_MAXE + e] = 0;
+    const int it = blockIdx.x, e = blockIdx.y, z = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t slot = (size_t)z * T.iters + it;
+    if (e >= T.ne[slot]) {                                // workgroup-uniform
+        if (tid == 0) T.counts[slot * FP_MAXE + e] = 0;
         return;
     }
+    const int base = T.off[z], n = T.off[z + 1] - base;
+    const double *px1 = T.px1 + 2 * (size_t)base, *px2 = T.px2 + 2 * (size_t)base;
+    double k1[4], k2[4];
+    for (int j = 0; j < 4; j++) { k1[j] = T.ks[8 * z + j]; k2[j] = T.ks[8 * z + 4 + j]; }
     int cnt = 0;
     double Rt[12];
-    for (int j = 0; j < 12; j++) Rt[j] = T.poses[((size_t)it * FP_MAXE + e) * 12 + j];
-    for (int i = tid; i < T.n; i += FP_SCORE_T) {
-        const double a[2] = {T.px1[2 * i], T.px1[2 * i + 1]}, b[2] = {T.px2[2 * i], T.px2[2 * i + 1]};
+    for (int j = 0; j < 12; j++) Rt[j] = T.poses[(slot * FP_MAXE + e) * 12 + j];
+    for (int i = tid; i < n; i += FP_SCORE_T) {
+        const double a[2] = {px1[2 * i], px1[2 * i + 1]}, b[2] = {px2[2 * i], px2[2 * i + 1]};
         double e1, e2;
-        if (two_view_errors(T.k1, T.k2, Rt, a, b, &e1, &e2)) cnt += (e1 < T.thr && e2 < T.thr) ? 1 : 0;
+        if (two_view_errors(k1, k2, Rt, a, b, &e1, &e2)) cnt += (e1 < T.thr && e2 < T.thr) ? 1 : 0;
     }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     if (lane == 0) s_part[wave] = cnt;
@@ -581,20 +589,27 @@ __global__ __launch_bounds__(FP_SCORE_T) void k_5pt_score(FPArgs T)
     if (tid == 0) {
         int c = 0;
         for (int w = 0; w < FP_SCORE_T / 64; w++) c += s_part[w];
-        T.counts[it * FP_MAXE + e] = c;
+        T.counts[slot * FP_MAXE + e] = c;
     }
 }
 
 __global__ __launch_bounds__(FP_SEL_T) void k_5pt_select(FPArgs T)
 {
     __shared__ int s_cnt[FP_SEL_T], s_idx[FP_SEL_T];
-    __shared__ double s_P[12];
+    __shared__ double s_P[12], s_k[8];
     __shared__ double s_err[FP_ERR_LDS];
-    const int tid = threadIdx.x, ne = FP_MAXE * T.iters;
-    const bool in_lds = T.n <= FP_ERR_LDS;
+    const int tid = threadIdx.x, z = blockIdx.x, ne = FP_MAXE * T.iters;
+    const int base = T.off[z], n = T.off[z + 1] - base;
+    const double *px1 = T.px1 + 2 * (size_t)base, *px2 = T.px2 + 2 * (size_t)base;
+    const int *counts = T.counts + (size_t)z * ne;
+    const double *poses = T.poses + (size_t)z * ne * 12, *Es = T.Es + (size_t)z * ne * 9;
+    double *errs = T.errs + base, *out = T.out + 32 * (size_t)z;
+    uint8_t *inliers = T.inliers + base;
+    const bool in_lds = n <= FP_ERR_LDS;
+    if (tid < 8) s_k[tid] = T.ks[8 * z + tid];
     int bc = 0, bi = -1;
     for (int e = tid; e < ne; e += FP_SEL_T) {
-        const int c = T.counts[e];
+        const int c = counts[e];
         if (c > bc) { bc = c; bi = e; }
     }
     s_cnt[tid] = bc; s_idx[tid] = bi;
@@ -607,17 +622,17 @@ __global__ __launch_bounds__(FP_SEL_T) void k_5pt_select(FPArgs T)
         __syncthreads();
     }
     const int best = s_cnt[0], be = s_idx[0];
-    if (tid < 12) s_P[tid] = best > 0 ? T.poses[(size_t)be * 12 + tid] : 0.0;
+    if (tid < 12) s_P[tid] = best > 0 ? poses[(size_t)be * 12 + tid] : 0.0;
     __syncthreads();
-    for (int i = tid; i < T.n; i += FP_SEL_T) {
+    for (int i = tid; i < n; i += FP_SEL_T) {
         double e1 = 0.0, e2 = 0.0;
         bool in = false;
         if (best > 0) {
-            const double a[2] = {T.px1[2 * i], T.px1[2 * i + 1]}, b[2] = {T.px2[2 * i], T.px2[2 * i + 1]};
-            in = two_view_errors(T.k1, T.k2, s_P, a, b, &e1, &e2) && e1 < T.thr && e2 < T.thr;
+            const double a[2] = {px1[2 * i], px1[2 * i + 1]}, b[2] = {px2[2 * i], px2[2 * i + 1]};
+            in = two_view_errors(s_k, s_k + 4, s_P, a, b, &e1, &e2) && e1 < T.thr && e2 < T.thr;
         }
-        T.inliers[i] = in ? 1 : 0;
-        if (in_lds) s_err[i] = in ? e1 + e2 : 0.0; else T.errs[i] = in ? e1 + e2 : 0.0;   // + 0.0 leaves the sum unchanged
+        inliers[i] = in ? 1 : 0;
+        if (in_lds) s_err[i] = in ? e1 + e2 : 0.0; else errs[i] = in ? e1 + e2 : 0.0;   // + 0.0 leaves the sum unchanged
     }
     __threadfence_block();
     __syncthreads();
@@ -625,18 +640,76 @@ __global__ __launch_bounds__(FP_SEL_T) void k_5pt_select(FPArgs T)
         double esum = 0.0;
         if (in_lds) {
 #pragma unroll 16
-            for (int i = 0; i < T.n; i++) esum += s_err[i];           // index order; the reads pipeline, the adds are the chain
+            for (int i = 0; i < n; i++) esum += s_err[i];             // index order; the reads pipeline, the adds are the chain
         } else {
 #pragma unroll 16
-            for (int i = 0; i < T.n; i++) esum += T.errs[i];
+            for (int i = 0; i < n; i++) esum += errs[i];
         }
-        *T.error = esum;
-        *T.n_inliers = best;
-        *T.best_iter = best > 0 ? be / FP_MAXE : -1;
-        for (int j = 0; j < 12; j++) T.P_out[j] = s_P[j];
+        out[21] = esum;
+        int *oi = (int *)(out + 22);
+        oi[0] = best; oi[1] = best > 0 ? be / FP_MAXE : -1;
+        for (int j = 0; j < 12; j++) out[j] = s_P[j];
         for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 3; c++) T.E_out[r + 3 * c] = best > 0 ? T.Es[(size_t)be * 9 + 3 * r + c] : 0.0;
+            for (int c = 0; c < 3; c++) out[12 + r + 3 * c] = best > 0 ? Es[(size_t)be * 9 + 3 * r + c] : 0.0;
     }
+}
+
+// S problems in three launches (grid.y / grid.z / grid.x = problem)
+static int fp_run(slam_ctx *ctx, int S, const int32_t *off, const double *px1_xy, const double *px2_xy, const double *pd1_xy,
+                  const double *pd2_xy, const double *K1, const double *K2, double max_repr_error, const int32_t *samples, int iters,
+                  double *E, double *P, uint8_t *inliers, int *n_inliers, double *error, int *best_iter)
+{
+    const int ntot = off[S];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t pb = up((size_t)ntot * 16);
+    const size_t o_off = 4 * pb, o_k = o_off + up((size_t)(S + 1) * 4), o_smp = o_k + up((size_t)S * 64);
+    const size_t o_out = o_smp + up((size_t)S * iters * 20), o_inl = o_out + (size_t)S * 256, total = o_inl + up((size_t)ntot);
+    char *h, *d;
+    int rc = slam_pinned(ctx, total, (void **)&h);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipHostGetDevicePointer((void **)&d, h, 0));
+    memcpy(h, px1_xy, (size_t)ntot * 16); memcpy(h + pb, px2_xy, (size_t)ntot * 16);
+    memcpy(h + 2 * pb, pd1_xy, (size_t)ntot * 16); memcpy(h + 3 * pb, pd2_xy, (size_t)ntot * 16);
+    memcpy(h + o_off, off, (size_t)(S + 1) * 4);
+    double *ks = (double *)(h + o_k);
+    for (int z = 0; z < S; z++) {
+        const double *a = K1 + 9 * z, *b = K2 + 9 * z;
+        ks[8 * z] = a[0]; ks[8 * z + 1] = a[4]; ks[8 * z + 2] = a[6]; ks[8 * z + 3] = a[7];
+        ks[8 * z + 4] = b[0]; ks[8 * z + 5] = b[4]; ks[8 * z + 6] = b[6]; ks[8 * z + 7] = b[7];
+    }
+    memcpy(h + o_smp, samples, (size_t)S * iters * 20);
+    const size_t slots = (size_t)S * iters;
+    const size_t s_ne = up(slots * 4), s_es = up(slots * FP_MAXE * 72), s_po = up(slots * FP_MAXE * 96);
+    const size_t s_cn = up(slots * FP_MAXE * 4), s_er = up((size_t)ntot * 8);
+    char *scr;
+    rc = slam_scratch(ctx, s_ne + s_es + s_po + s_cn + s_er, (void **)&scr);
+    if (rc) return rc;
+    FPArgs T;
+    T.px1 = (const double *)d; T.px2 = (const double *)(d + pb); T.pd1 = (const double *)(d + 2 * pb); T.pd2 = (const double *)(d + 3 * pb);
+    T.samples = (const int32_t *)(d + o_smp); T.off = (const int *)(d + o_off); T.ks = (const double *)(d + o_k);
+    T.iters = iters; T.thr = max_repr_error;
+    T.ne = (int *)scr; T.Es = (double *)(scr + s_ne); T.poses = (double *)(scr + s_ne + s_es);
+    T.counts = (int *)(scr + s_ne + s_es + s_po); T.errs = (double *)(scr + s_ne + s_es + s_po + s_cn);
+    T.out = (double *)(d + o_out); T.inliers = (uint8_t *)(d + o_inl);
+    const size_t lds = (size_t)FP_LDS_PER_THREAD * FP_TPB * sizeof(double);
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_5pt_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { ProfScope span(ctx, "five_point_ransac");
+      hipLaunchKernelGGL(k_5pt_solve, dim3((iters + FP_TPB - 1) / FP_TPB, S), dim3(FP_TPB * FP_TEAM), lds, ctx->stream, T);
+      hipLaunchKernelGGL(k_5pt_score, dim3(iters, FP_MAXE, S), dim3(FP_SCORE_T), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_5pt_select, dim3(S), dim3(FP_SEL_T), 0, ctx->stream, T); }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int z = 0; z < S; z++) {
+        const char *o = h + o_out + (size_t)z * 256;      // P [0,96) E [96,168) error [168,176) n_inliers [176,180) best_iter [180,184)
+        memcpy(P + 12 * z, o, 96);
+        if (E) memcpy(E + 9 * z, o + 96, 72);
+        if (error) memcpy(error + z, o + 168, 8);
+        memcpy(n_inliers + z, o + 176, 4);
+        if (best_iter) memcpy(best_iter + z, o + 180, 4);
+    }
+    memcpy(inliers, h + o_inl, (size_t)ntot);
+    return SLAM_OK;
 }
 
 extern "C" int slam_five_point_ransac(slam_ctx *ctx, const double *px1_xy, const double *px2_xy, const double *pd1_xy,
@@ -657,47 +730,32 @@ extern "C" int slam_five_point_ransac(slam_ctx *ctx, const double *px1_xy, const
         if (best_iter) *best_iter = -1;
         return SLAM_OK;
     }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t pb = up((size_t)n * 16);
-    const size_t o_smp = 4 * pb, o_out = o_smp + up((size_t)iters * 20), o_inl = o_out + 256, total = o_inl + up((size_t)n);
-    char *h, *d;
-    int rc = slam_pinned(ctx, total, (void **)&h);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipHostGetDevicePointer((void **)&d, h, 0));
-    memcpy(h, px1_xy, (size_t)n * 16); memcpy(h + pb, px2_xy, (size_t)n * 16);
-    memcpy(h + 2 * pb, pd1_xy, (size_t)n * 16); memcpy(h + 3 * pb, pd2_xy, (size_t)n * 16);
-    memcpy(h + o_smp, samples, (size_t)iters * 20);
-    const size_t s_ne = up((size_t)iters * 4), s_es = up((size_t)iters * FP_MAXE * 72), s_po = up((size_t)iters * FP_MAXE * 96);
-    const size_t s_cn = up((size_t)iters * FP_MAXE * 4), s_er = up((size_t)n * 8);
-    char *scr;
-    rc = slam_scratch(ctx, s_ne + s_es + s_po + s_cn + s_er, (void **)&scr);
-    if (rc) return rc;
-    FPArgs T;
-    T.px1 = (const double *)d; T.px2 = (const double *)(d + pb); T.pd1 = (const double *)(d + 2 * pb); T.pd2 = (const double *)(d + 3 * pb);
-    T.samples = (const int32_t *)(d + o_smp); T.n = n; T.iters = iters;
-    T.k1[0] = K1[0]; T.k1[1] = K1[4]; T.k1[2] = K1[6]; T.k1[3] = K1[7];
-    T.k2[0] = K2[0]; T.k2[1] = K2[4]; T.k2[2] = K2[6]; T.k2[3] = K2[7];
-    T.thr = max_repr_error;
-    T.ne = (int *)scr; T.Es = (double *)(scr + s_ne); T.poses = (double *)(scr + s_ne + s_es);
-    T.counts = (int *)(scr + s_ne + s_es + s_po); T.errs = (double *)(scr + s_ne + s_es + s_po + s_cn);
-    // output block: P [0,96) E [96,168) error [168,176) n_inliers [176,180) best_iter [180,184)
-    T.P_out = (double *)(d + o_out); T.E_out = (double *)(d + o_out + 96); T.error = (double *)(d + o_out + 168);
-    T.n_inliers = (int *)(d + o_out + 176); T.best_iter = (int *)(d + o_out + 180);
-    T.inliers = (uint8_t *)(d + o_inl);
-    const size_t lds = (size_t)FP_LDS_PER_THREAD * FP_TPB * sizeof(double);
-    HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_5pt_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    { ProfScope span(ctx, "five_point_ransac");
-      hipLaunchKernelGGL(k_5pt_solve, dim3((iters + FP_TPB - 1) / FP_TPB), dim3(FP_TPB * FP_TEAM), lds, ctx->stream, T);
-      hipLaunchKernelGGL(k_5pt_score, dim3(iters, FP_MAXE), dim3(FP_SCORE_T), 0, ctx->stream, T);
-      hipLaunchKernelGGL(k_5pt_select, dim3(1), dim3(FP_SEL_T), 0, ctx->stream, T); }
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(P, h + o_out, 96);
-    if (E) memcpy(E, h + o_out + 96, 72);
-    if (error) memcpy(error, h + o_out + 168, 8);
-    memcpy(n_inliers, h + o_out + 176, 4);
-    if (best_iter) memcpy(best_iter, h + o_out + 180, 4);
-    memcpy(inliers, h + o_inl, (size_t)n);
-    return SLAM_OK;
+    const int32_t off[2] = {0, n};
+    return fp_run(ctx, 1, off, px1_xy, px2_xy, pd1_xy, pd2_xy, K1, K2, max_repr_error, samples, iters, E, P, inliers, n_inliers, error, best_iter);
+}
+
+extern "C" int slam_five_point_ransac_batch(slam_ctx *ctx, int S, const int32_t *offsets, const double *px1_xy, const double *px2_xy,
+                                            const double *pd1_xy, const double *pd2_xy, const double *K1, const double *K2,
+                                            double max_repr_error, const int32_t *samples, int iters, double *E, double *P,
+                                            uint8_t *inliers, int *n_inliers, double *error, int *best_iter)
+{
+    ARG_TRY(ctx, ctx != nullptr && S >= 0 && iters >= 0);
+    if (S == 0) return SLAM_OK;
+    ARG_TRY(ctx, offsets && K1 && K2 && P && n_inliers && offsets[0] == 0);
+    for (int z = 0; z < S; z++) ARG_TRY(ctx, offsets[z + 1] >= offsets[z]);
+    const int ntot = offsets[S];
+    ARG_TRY(ctx, ntot == 0 || (px1_xy && px2_xy && pd1_xy && pd2_xy && inliers));
+    ARG_TRY(ctx, iters == 0 || samples);
+    if (ntot == 0 || iters == 0) {
+        for (int z = 0; z < S; z++) {
+            n_inliers[z] = 0;
+            for (int j = 0; j < 12; j++) P[12 * z + j] = 0.0;
+            if (E) for (int j = 0; j < 9; j++) E[9 * z + j] = 0.0;
+            if (error) error[z] = 0.0;
+            if (best_iter) best_iter[z] = -1;
+        }
+        for (int i = 0; i < ntot; i++) inliers[i] = 0;
+        return SLAM_OK;
+    }
+    return fp_run(ctx, S, offsets, px1_xy, px2_xy, pd1_xy, pd2_xy, K1, K2, max_repr_error, samples, iters, E, P, inliers, n_inliers, error, best_iter);
 }

@@ -12,18 +12,18 @@
 
 #define P3P_ERR_LDS 4096                // map points whose errors the select kernel stages in LDS
 
-struct P3PArgs {
-    const double *pts, *px, *pdn;   // n x 3, n x 2 (x, y), n x 3
-    const int32_t *samples;         // iters x 3, 0-based
-    int n, iters;
-    double K[9];                    // column-major 3x3
+struct P3PArgs {                    // S independent problems (S = 1: slam_p3p_ransac); problem z owns points [off[z], off[z+1])
+    const double *pts, *px, *pdn;   // concatenated: n x 3, n x 2 (x, y), n x 3
+    const int32_t *samples;         // S x iters x 3, 0-based, local to the problem
+    const int *off;                 // S + 1
+    const double *Ks;               // S x 9, column-major 3x3
+    int iters;
     double thr;
-    int *counts;                    // iters x 4
-    double *poses;                  // iters x 4 x 12
-    double *errs;                   // n
-    double *KP, *Rt, *error;        // outputs (mapped host)
-    uint8_t *inliers;
-    int *n_inliers, *best_iter;
+    int *counts;                    // S x iters x 4
+    double *poses;                  // S x iters x 4 x 12
+    double *errs;                   // off[S] (only read back when a problem has more than P3P_ERR_LDS points)
+    double *out;                    // S x 32 (mapped host): KP 12 | Rt 12 | error | {n_inliers, best_iter} as two ints
+    uint8_t *inliers;               // off[S] (mapped host)
 };
 
 __device__ static double cubic_root_nonneg(double B, double C, double D)
@@ -186,16 +186,21 @@ __device__ static inline double p3p_reproj(const double *P, const double *K, con
 __global__ __launch_bounds__(256) void k_p3p_score(P3PArgs T)
 {
     // four waves per triple: each runs the (wave-uniform) solver, wave s then scores pose s with its 64 lanes
-    const int it = blockIdx.x, lane = threadIdx.x & 63, s = threadIdx.x >> 6;
-    const int i0 = T.samples[3 * it], i1 = T.samples[3 * it + 1], i2 = T.samples[3 * it + 2];
+    const int it = blockIdx.x, z = blockIdx.y, lane = threadIdx.x & 63, s = threadIdx.x >> 6;
+    const int base = T.off[z], n = T.off[z + 1] - base;
+    const double *pts = T.pts + 3 * (size_t)base, *px = T.px + 2 * (size_t)base, *pdn = T.pdn + 3 * (size_t)base;
+    const int32_t *sm = T.samples + 3 * ((size_t)z * T.iters + it);
+    const int i0 = sm[0], i1 = sm[1], i2 = sm[2];
+    double K[9];
+    for (int j = 0; j < 9; j++) K[j] = T.Ks[9 * z + j];
     int ns = 0;
     double P[12];
-    const bool valid = !(i0 < 0 || i1 < 0 || i2 < 0 || i0 >= T.n || i1 >= T.n || i2 >= T.n || i0 == i1 || i0 == i2 || i1 == i2);
+    const bool valid = !(i0 < 0 || i1 < 0 || i2 < 0 || i0 >= n || i1 >= n || i2 >= n || i0 == i1 || i0 == i2 || i1 == i2);
     if (valid) {
         double X[9], F[9];
         for (int j = 0; j < 3; j++) {
-            X[j] = T.pts[3 * i0 + j]; X[3 + j] = T.pts[3 * i1 + j]; X[6 + j] = T.pts[3 * i2 + j];
-            F[j] = T.pdn[3 * i0 + j]; F[3 + j] = T.pdn[3 * i1 + j]; F[6 + j] = T.pdn[3 * i2 + j];
+            X[j] = pts[3 * i0 + j]; X[3 + j] = pts[3 * i1 + j]; X[6 + j] = pts[3 * i2 + j];
+            F[j] = pdn[3 * i0 + j]; F[3 + j] = pdn[3 * i1 + j]; F[6 + j] = pdn[3 * i2 + j];
         }
         double Rt[48];
         ns = p3p_solve(X, F, Rt);
@@ -205,31 +210,39 @@ __global__ __launch_bounds__(256) void k_p3p_score(P3PArgs T)
     }
     int cnt = 0;
     if (s < ns) {
-        for (int i = lane; i < T.n; i += 64) {
-            const double X[3] = {T.pts[3 * i], T.pts[3 * i + 1], T.pts[3 * i + 2]};
-            const double px[2] = {T.px[2 * i], T.px[2 * i + 1]};
-            const double e = p3p_reproj(P, T.K, X, px);
+        for (int i = lane; i < n; i += 64) {
+            const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+            const double q[2] = {px[2 * i], px[2 * i + 1]};
+            const double e = p3p_reproj(P, K, X, q);
             cnt += (e >= 0.0 && e < T.thr) ? 1 : 0;
         }
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     }
     if (lane == 0) {
-        T.counts[4 * it + s] = cnt;
+        const size_t e = ((size_t)z * T.iters + it) * 4 + s;
+        T.counts[e] = cnt;
         if (s < ns)
-            for (int j = 0; j < 12; j++) T.poses[(size_t)(4 * it + s) * 12 + j] = P[j];
+            for (int j = 0; j < 12; j++) T.poses[e * 12 + j] = P[j];
     }
 }
 
 __global__ __launch_bounds__(256) void k_p3p_select(P3PArgs T)
 {
     __shared__ int s_cnt[256], s_idx[256];
-    __shared__ double s_P[12];
+    __shared__ double s_P[12], s_K[9];
     __shared__ double s_err[P3P_ERR_LDS];
-    const int tid = threadIdx.x, ne = 4 * T.iters;
-    const bool in_lds = T.n <= P3P_ERR_LDS;
+    const int tid = threadIdx.x, z = blockIdx.x, ne = 4 * T.iters;
+    const int base = T.off[z], n = T.off[z + 1] - base;
+    const double *pts = T.pts + 3 * (size_t)base, *px = T.px + 2 * (size_t)base;
+    const int *counts = T.counts + (size_t)z * ne;
+    const double *poses = T.poses + (size_t)z * ne * 12;
+    double *errs = T.errs + base, *out = T.out + 32 * (size_t)z;
+    uint8_t *inliers = T.inliers + base;
+    const bool in_lds = n <= P3P_ERR_LDS;
+    if (tid < 9) s_K[tid] = T.Ks[9 * z + tid];
     int bc = 0, bi = -1;
     for (int e = tid; e < ne; e += 256) {
-        const int c = T.counts[e];
+        const int c = counts[e];
         if (c > bc) { bc = c; bi = e; }        // ascending e: the first maximum is kept
     }
     s_cnt[tid] = bc; s_idx[tid] = bi;
@@ -242,18 +255,18 @@ __global__ __launch_bounds__(256) void k_p3p_select(P3PArgs T)
         __syncthreads();
     }
     const int best = s_cnt[0], be = s_idx[0];
-    if (tid < 12) s_P[tid] = best > 0 ? T.poses[(size_t)be * 12 + tid] : 0.0;
+    if (tid < 12) s_P[tid] = best > 0 ? poses[(size_t)be * 12 + tid] : 0.0;
     __syncthreads();
-    for (int i = tid; i < T.n; i += 256) {
+    for (int i = tid; i < n; i += 256) {
         double e = -1.0;
         if (best > 0) {
-            const double X[3] = {T.pts[3 * i], T.pts[3 * i + 1], T.pts[3 * i + 2]};
-            const double px[2] = {T.px[2 * i], T.px[2 * i + 1]};
-            e = p3p_reproj(s_P, T.K, X, px);
+            const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+            const double q[2] = {px[2 * i], px[2 * i + 1]};
+            e = p3p_reproj(s_P, s_K, X, q);
         }
         const bool in = best > 0 && e >= 0.0 && e < T.thr;
-        T.inliers[i] = in ? 1 : 0;
-        if (in_lds) s_err[i] = in ? e : 0.0; else T.errs[i] = in ? e : 0.0;   // + 0.0 leaves the sum unchanged
+        inliers[i] = in ? 1 : 0;
+        if (in_lds) s_err[i] = in ? e : 0.0; else errs[i] = in ? e : 0.0;   // + 0.0 leaves the sum unchanged
     }
     __threadfence_block();
     __syncthreads();
@@ -261,20 +274,66 @@ __global__ __launch_bounds__(256) void k_p3p_select(P3PArgs T)
         double esum = 0.0;
         if (in_lds) {
 #pragma unroll 16
-            for (int i = 0; i < T.n; i++) esum += s_err[i];           // index order; the reads pipeline, the adds are the chain
+            for (int i = 0; i < n; i++) esum += s_err[i];             // index order; the reads pipeline, the adds are the chain
         } else {
 #pragma unroll 16
-            for (int i = 0; i < T.n; i++) esum += T.errs[i];
+            for (int i = 0; i < n; i++) esum += errs[i];
         }
-        *T.error = esum;
-        *T.n_inliers = best;
-        *T.best_iter = best > 0 ? be / 4 : -1;
+        out[24] = esum;
+        int *oi = (int *)(out + 25);
+        oi[0] = best; oi[1] = best > 0 ? be / 4 : -1;
         for (int c = 0; c < 4; c++)
             for (int r = 0; r < 3; r++) {
-                T.KP[r + 3 * c] = (T.K[r] * s_P[3 * c] + T.K[r + 3] * s_P[3 * c + 1]) + T.K[r + 6] * s_P[3 * c + 2];
-                T.Rt[r + 3 * c] = s_P[r + 3 * c];
+                out[r + 3 * c] = (s_K[r] * s_P[3 * c] + s_K[r + 3] * s_P[3 * c + 1]) + s_K[r + 6] * s_P[3 * c + 2];
+                out[12 + r + 3 * c] = s_P[r + 3 * c];
             }
     }
+}
+
+// S problems in one pair of launches (grid.y / grid.x = problem); offsets, intrinsics, inputs and outputs go through
+// the context's mapped pinned block
+static int p3p_run(slam_ctx *ctx, int S, const int32_t *off, const double *pts3d, const double *px_xy, const double *pdn,
+                   const double *K, double threshold, const int32_t *samples, int iters,
+                   double *KP, double *Rt, uint8_t *inliers, int *n_inliers, double *error, int *best_iter)
+{
+    const int ntot = off[S];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_off = 0, o_K = o_off + up((size_t)(S + 1) * 4), o_pts = o_K + up((size_t)S * 72);
+    const size_t o_px = o_pts + up((size_t)ntot * 24), o_pdn = o_px + up((size_t)ntot * 16), o_smp = o_pdn + up((size_t)ntot * 24);
+    const size_t o_out = o_smp + up((size_t)S * iters * 12), o_inl = o_out + (size_t)S * 256, total = o_inl + up((size_t)ntot);
+    char *h, *d;
+    int rc = slam_pinned(ctx, total, (void **)&h);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipHostGetDevicePointer((void **)&d, h, 0));
+    memcpy(h + o_off, off, (size_t)(S + 1) * 4); memcpy(h + o_K, K, (size_t)S * 72);
+    memcpy(h + o_pts, pts3d, (size_t)ntot * 24); memcpy(h + o_px, px_xy, (size_t)ntot * 16); memcpy(h + o_pdn, pdn, (size_t)ntot * 24);
+    memcpy(h + o_smp, samples, (size_t)S * iters * 12);
+    const size_t s_cnt = up((size_t)S * iters * 16), s_pose = up((size_t)S * iters * 4 * 96), s_err = up((size_t)ntot * 8);
+    char *scr;
+    rc = slam_scratch(ctx, s_cnt + s_pose + s_err, (void **)&scr);
+    if (rc) return rc;
+    P3PArgs T;
+    T.pts = (const double *)(d + o_pts); T.px = (const double *)(d + o_px); T.pdn = (const double *)(d + o_pdn);
+    T.samples = (const int32_t *)(d + o_smp); T.off = (const int *)(d + o_off); T.Ks = (const double *)(d + o_K);
+    T.iters = iters; T.thr = threshold;
+    T.counts = (int *)scr; T.poses = (double *)(scr + s_cnt); T.errs = (double *)(scr + s_cnt + s_pose);
+    T.out = (double *)(d + o_out); T.inliers = (uint8_t *)(d + o_inl);
+    { ProfScope span(ctx, "p3p_ransac");
+      hipLaunchKernelGGL(k_p3p_score, dim3(iters, S), dim3(256), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_p3p_select, dim3(S), dim3(256), 0, ctx->stream, T); }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int z = 0; z < S; z++) {
+        const char *o = h + o_out + (size_t)z * 256;
+        memcpy(KP + 12 * z, o, 96);
+        if (Rt) memcpy(Rt + 12 * z, o + 96, 96);
+        if (error) memcpy(error + z, o + 192, 8);
+        memcpy(n_inliers + z, o + 200, 4);
+        if (best_iter) memcpy(best_iter + z, o + 204, 4);
+    }
+    memcpy(inliers, h + o_inl, (size_t)ntot);
+    return SLAM_OK;
 }
 
 extern "C" int slam_p3p_ransac(slam_ctx *ctx, const double *pts3d, const double *px_xy, const double *pdn, int n,
@@ -293,39 +352,30 @@ extern "C" int slam_p3p_ransac(slam_ctx *ctx, const double *pts3d, const double 
         if (best_iter) *best_iter = -1;
         return SLAM_OK;
     }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t o_pts = 0, o_px = o_pts + up((size_t)n * 24), o_pdn = o_px + up((size_t)n * 16), o_smp = o_pdn + up((size_t)n * 24);
-    const size_t o_out = o_smp + up((size_t)iters * 12), o_inl = o_out + 256, total = o_inl + up((size_t)n);
-    char *h, *d;
-    int rc = slam_pinned(ctx, total, (void **)&h);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipHostGetDevicePointer((void **)&d, h, 0));
-    memcpy(h + o_pts, pts3d, (size_t)n * 24); memcpy(h + o_px, px_xy, (size_t)n * 16); memcpy(h + o_pdn, pdn, (size_t)n * 24);
-    memcpy(h + o_smp, samples, (size_t)iters * 12);
-    const size_t s_cnt = up((size_t)iters * 16), s_pose = up((size_t)iters * 4 * 96), s_err = up((size_t)n * 8);
-    char *scr;
-    rc = slam_scratch(ctx, s_cnt + s_pose + s_err, (void **)&scr);
-    if (rc) return rc;
-    P3PArgs T;
-    T.pts = (const double *)(d + o_pts); T.px = (const double *)(d + o_px); T.pdn = (const double *)(d + o_pdn);
-    T.samples = (const int32_t *)(d + o_smp); T.n = n; T.iters = iters;
-    memcpy(T.K, K, sizeof T.K); T.thr = threshold;
-    T.counts = (int *)scr; T.poses = (double *)(scr + s_cnt); T.errs = (double *)(scr + s_cnt + s_pose);
-    // output block: KP [0,96) Rt [96,192) error [192,200) n_inliers [200,204) best_iter [204,208)
-    T.KP = (double *)(d + o_out); T.Rt = (double *)(d + o_out + 96); T.error = (double *)(d + o_out + 192);
-    T.n_inliers = (int *)(d + o_out + 200); T.best_iter = (int *)(d + o_out + 204);
-    T.inliers = (uint8_t *)(d + o_inl);
-    { ProfScope span(ctx, "p3p_ransac");
-      hipLaunchKernelGGL(k_p3p_score, dim3(iters), dim3(256), 0, ctx->stream, T);
-      hipLaunchKernelGGL(k_p3p_select, dim3(1), dim3(256), 0, ctx->stream, T); }
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(KP, h + o_out, 96);
-    if (Rt) memcpy(Rt, h + o_out + 96, 96);
-    if (error) memcpy(error, h + o_out + 192, 8);
-    memcpy(n_inliers, h + o_out + 200, 4);
-    if (best_iter) memcpy(best_iter, h + o_out + 204, 4);
-    memcpy(inliers, h + o_inl, (size_t)n);
-    return SLAM_OK;
+    const int32_t off[2] = {0, n};
+    return p3p_run(ctx, 1, off, pts3d, px_xy, pdn, K, threshold, samples, iters, KP, Rt, inliers, n_inliers, error, best_iter);
+}
+
+extern "C" int slam_p3p_ransac_batch(slam_ctx *ctx, int S, const int32_t *offsets, const double *pts3d, const double *px_xy,
+                                     const double *pdn, const double *K, double threshold, const int32_t *samples, int iters,
+                                     double *KP, double *Rt, uint8_t *inliers, int *n_inliers, double *error, int *best_iter)
+{
+    ARG_TRY(ctx, ctx != nullptr && S >= 0 && iters >= 0);
+    if (S == 0) return SLAM_OK;
+    ARG_TRY(ctx, offsets && K && KP && n_inliers && offsets[0] == 0);
+    for (int z = 0; z < S; z++) ARG_TRY(ctx, offsets[z + 1] >= offsets[z]);
+    const int ntot = offsets[S];
+    ARG_TRY(ctx, ntot == 0 || (pts3d && px_xy && pdn && inliers));
+    ARG_TRY(ctx, iters == 0 || samples);
+    if (ntot == 0 || iters == 0) {
+        for (int z = 0; z < S; z++) {
+            n_inliers[z] = 0;
+            for (int j = 0; j < 12; j++) { KP[12 * z + j] = 0.0; if (Rt) Rt[12 * z + j] = 0.0; }
+            if (error) error[z] = 0.0;
+            if (best_iter) best_iter[z] = -1;
+        }
+        for (int i = 0; i < ntot; i++) inliers[i] = 0;
+        return SLAM_OK;
+    }
+    return p3p_run(ctx, S, offsets, pts3d, px_xy, pdn, K, threshold, samples, iters, KP, Rt, inliers, n_inliers, error, best_iter);
 }

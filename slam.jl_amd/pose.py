@@ -96,3 +96,70 @@ def five_point_ransac(previous_points_xy, current_points_xy, previous_pd, curren
     if return_extra:
         model = model + (bi.value,)
     return cnt.value, model
+
+
+# ---- S lock-stepped streams: one set of launches for all of them -------------------------------------------------
+def _concat(lists, width):
+    arrs = [np.ascontiguousarray(a, dtype=np.float64).reshape(-1, width) for a in lists]
+    off = np.zeros(len(arrs) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(a) for a in arrs])
+    return (np.concatenate(arrs) if arrs else np.zeros((0, width))), off
+
+
+def p3p_ransac_batch(points, pixels_xy, pdn_positions, K, threshold=1.0, samples=None, iterations=256, seed=0, ctx=None):
+    """S problems at once (lists of per-stream arrays; K: one 3x3 or a list of S).  Returns a list of S results shaped
+    like p3p_ransac(..., return_pose=True): `(n_inliers, (KP, inliers, error, Rt, best_iter))` or None."""
+    ctx = ctx or L.default_context()
+    S = len(points)
+    pts, off = _concat(points, 3); px, off2 = _concat(pixels_xy, 2); bd, off3 = _concat(pdn_positions, 3)
+    if not (np.array_equal(off, off2) and np.array_equal(off, off3)):
+        raise ValueError("per-stream lists must have matching lengths")
+    Ks = np.asarray(K, dtype=np.float64)
+    Ks = np.broadcast_to(Ks, (S, 3, 3)) if Ks.ndim == 2 else Ks
+    Kf = np.ascontiguousarray(np.transpose(Ks, (0, 2, 1)))                          # column-major per problem
+    if samples is None:
+        samples = [draw_samples(off[z + 1] - off[z], iterations, seed + z) for z in range(S)]
+        samples = [s if len(s) else np.full((iterations, 3), -1, np.int32) for s in samples]
+    sm = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.int32).reshape(-1, 3) for s in samples])) if S else np.zeros((0, 0, 3), np.int32)
+    iters = sm.shape[1] if S else 0
+    KP = np.zeros((S, 12)); Rt = np.zeros((S, 12)); inl = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
+    cnt = np.zeros(S, dtype=np.int32); bi = np.zeros(S, dtype=np.int32); err = np.zeros(S)
+    ctx.check(ctx.lib.slam_p3p_ransac_batch(ctx.h, S, L.ptr(off, L.i32p), L.ptr(pts), L.ptr(px), L.ptr(bd), L.ptr(Kf), float(threshold),
+                                            L.ptr(sm, L.i32p), iters, L.ptr(KP), L.ptr(Rt), L.ptr(inl, L.u8p), L.ptr(cnt, L.i32p),
+                                            L.ptr(err), L.ptr(bi, L.i32p)))
+    out = []
+    for z in range(S):
+        if cnt[z] == 0:
+            out.append(None)
+        else:
+            out.append((int(cnt[z]), (KP[z].reshape(4, 3).T.copy(), inl[off[z]:off[z + 1]].view(np.bool_).copy(), float(err[z]),
+                                      Rt[z].reshape(4, 3).T.copy(), int(bi[z]))))
+    return out
+
+
+def five_point_ransac_batch(previous_points_xy, current_points_xy, previous_pd, current_pd, K1, K2, max_repr_error=1.0,
+                            samples=None, iterations=128, seed=0, ctx=None):
+    """S problems at once; returns a list of `(n_inliers, (E, P, inliers, error, best_iter))`."""
+    ctx = ctx or L.default_context()
+    S = len(previous_points_xy)
+    a, off = _concat(previous_points_xy, 2); b, o2 = _concat(current_points_xy, 2)
+    c, o3 = _concat(previous_pd, 2); d, o4 = _concat(current_pd, 2)
+    if not (np.array_equal(off, o2) and np.array_equal(off, o3) and np.array_equal(off, o4)):
+        raise ValueError("per-stream lists must have matching lengths")
+    def kk(K):
+        Ks = np.asarray(K, dtype=np.float64)
+        Ks = np.broadcast_to(Ks, (S, 3, 3)) if Ks.ndim == 2 else Ks
+        return np.ascontiguousarray(np.transpose(Ks, (0, 2, 1)))
+    k1, k2 = kk(K1), kk(K2)
+    if samples is None:
+        samples = [draw_samples(off[z + 1] - off[z], iterations, seed + z, k=5) for z in range(S)]
+        samples = [s if len(s) else np.full((iterations, 5), -1, np.int32) for s in samples]
+    sm = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.int32).reshape(-1, 5) for s in samples])) if S else np.zeros((0, 0, 5), np.int32)
+    iters = sm.shape[1] if S else 0
+    E = np.zeros((S, 9)); P = np.zeros((S, 12)); inl = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
+    cnt = np.zeros(S, dtype=np.int32); bi = np.zeros(S, dtype=np.int32); err = np.zeros(S)
+    ctx.check(ctx.lib.slam_five_point_ransac_batch(ctx.h, S, L.ptr(off, L.i32p), L.ptr(a), L.ptr(b), L.ptr(c), L.ptr(d), L.ptr(k1), L.ptr(k2),
+                                                   float(max_repr_error), L.ptr(sm, L.i32p), iters, L.ptr(E), L.ptr(P), L.ptr(inl, L.u8p),
+                                                   L.ptr(cnt, L.i32p), L.ptr(err), L.ptr(bi, L.i32p)))
+    return [(int(cnt[z]), (E[z].reshape(3, 3).T.copy(), P[z].reshape(4, 3).T.copy(), inl[off[z]:off[z + 1]].view(np.bool_).copy(),
+                           float(err[z]), int(bi[z]))) for z in range(S)]
