@@ -188,7 +188,7 @@ def iir_rows_bytes(H, W, levels):
     return tot
 
 
-def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, right_dev, flows, disparity, params, extractor, fast, world, dist, dev):
+def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, right_dev, flows, disparity, params, extractor, fast, world, dist, dev, hook=None):
     """S streams in lock-step through the batch entry points.  Stream s plays the same ping-pong sequence shifted
     by s frames (so the S images of a step differ); key-frames fall on the same step for all streams."""
     ctx, ctx_pyr, ctx_right = slam.Context(local_rank), slam.Context(local_rank), slam.Context(local_rank)
@@ -264,6 +264,8 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
             _, ok = slam.optical_flow_matching_batch(curb, rb, sid, kp, is3d, proj, params, ctx=ctx, status_only=True)
             is3d = is3d | ok
         st_["kp"], st_["is3d"], st_["sid"] = kp, is3d, sid
+        if hook is not None and pipelined:
+            hook()                                          # e.g. the pose seams of the step (synchronous, own context)
 
     def drain():
         ctx_pyr.synchronize(); ctx_right.synchronize(); ctx.synchronize(); torch.cuda.synchronize()
@@ -559,6 +561,13 @@ def main():
             pose_batch_once()
         out["pose"]["batch"] = {"streams": SB, "ms_per_step": (time.perf_counter() - t0) / 5 * 1e3,
                                 "what": "five-point RANSAC + P3P RANSAC + PnP refinement for 32 streams (3 launch sets), host lists in and out"}
+        if S == SB:
+            # the tracked workload with the pose seams of all streams run after every step (pose inputs are independent
+            # synthetic scenes of the same size: 1000 correspondences / map points per stream)
+            wp = run_lockstep(slam, torch, local_rank, S, max(20, args.steps // 4), min(args.warmup, 10), H, W, left_dev, right_dev, flows, disparity,
+                              params, extractor, False, world, dist, dev, hook=pose_batch_once)
+            out["pose"]["frontend_with_pose"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": wp["ms_per_step_of_S_frames"],
+                                                 "what": "headline workload + slam_five_point_ransac_batch + slam_p3p_ransac_batch + slam_pnp_ba_batch every step"}
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----------
     if rank == 0 and world == 1 and not args.no_cpu:
