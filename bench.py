@@ -389,12 +389,12 @@ def main():
                                                   "the pyramid build is ~70 % of the device time of a step, this is its largest kernel)"),
         "pyramid_batch_update_serial_us": head["pyramid_batch_update_serial_us"],
     }
-    pmc = os.path.join(ROOT, "profiles", "r01k_pmc_pyramid_batch.json")
+    pmc = os.path.join(ROOT, "profiles", "r01m_pmc_pyramid_batch.json")
     if SHAPE == "kitti05" and os.path.exists(pmc):
         j = json.load(open(pmc))
         if j.get("streams") == S:
             out["roofline"]["traffic"] = j["summary"]["k_iir_rows_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r01k_pmc_pyramid_batch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 corrected)"
+            out["roofline"]["traffic_source"] = "profiles/r01m_pmc_pyramid_batch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 corrected)"
 
     # ---- the same workload as ONE stream (latency view): 3 contexts, pipelined next-frame pyramid ----
     n1 = min(args.steps, 300)
