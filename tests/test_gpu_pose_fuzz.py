@@ -13,7 +13,7 @@ def _same(a, b):
 
 @pytest.mark.parametrize("kind", ["collinear", "coincident", "huge", "tiny", "nan", "random"])
 def test_p3p_hostile_inputs_match_oracle(slam, orc, syn, kind):
-    rng = np.random.default_rng(hash(kind) % 1000)
+    rng = np.random.default_rng(len(kind) * 131 + 7)
     sc = syn.p3p_scene(n=80, seed=3, iters=40)
     pts, px, pdn = sc["pts3d"].copy(), sc["px_xy"].copy(), sc["pdn"].copy()
     if kind == "collinear":
@@ -39,7 +39,7 @@ def test_p3p_hostile_inputs_match_oracle(slam, orc, syn, kind):
 
 @pytest.mark.parametrize("kind", ["zero_motion", "coincident", "collinear", "huge", "nan", "random"])
 def test_five_point_hostile_inputs_match_oracle(slam, orc, syn, kind):
-    rng = np.random.default_rng(hash(kind) % 1000)
+    rng = np.random.default_rng(len(kind) * 131 + 7)
     sc = syn.five_point_scene(n=70, seed=5, iters=24)
     a, b, c, d = sc["px1"].copy(), sc["px2"].copy(), sc["pd1"].copy(), sc["pd2"].copy()
     if kind == "zero_motion":
