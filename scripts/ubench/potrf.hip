@@ -19,6 +19,11 @@ __global__ __launch_bounds__(256) void k_bench(const double *A, double *out, lon
 }
 
 
+__device__ __forceinline__ double bcast_lane(double v, int srclane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane), hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
 // ---- experimental variants -------------------------------------------------------------------------------------
 #ifndef RSQ
 #define RSQ(x) rsqrt(x)
@@ -32,13 +37,20 @@ template <int MODE> __device__ __forceinline__ void potrf_var(double (*t)[CT + 1
     __syncthreads();
     if (wv == 0) {
         double lrow[CT];
+        double dsq = 0.0;
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < CT; j++) {
             const bool active = j < w;
             double acc = t[li][j];
             double dj = t[j][j];
-            {
+            if (MODE & 2) {
+                double pa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int m = 0; m < j; m++) pa[m & 3] += lrow[m] * t[j][m];
+                acc -= (pa[0] + pa[1]) + (pa[2] + pa[3]);
+                dj -= bcast_lane(dsq, j);                            // sum of squares of row j so far, kept by lane j
+            } else {
                 double pa[4] = {0.0, 0.0, 0.0, 0.0}, pd[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int m = 0; m < j; m++) {
@@ -54,6 +66,7 @@ template <int MODE> __device__ __forceinline__ void potrf_var(double (*t)[CT + 1
             const double rd = RSQ(dj);
             const double l = (lane == j) ? dj * rd : acc * rd;
             lrow[j] = l;
+            dsq += l * l;
             if (active && lane >= j && lane < CT) t[lane][j] = l;
             if (MODE & 1) {
                 if (lane == 0) s_rdiag[j] = rd;
@@ -99,11 +112,6 @@ template <int MODE> __global__ __launch_bounds__(256) void k_var(const double *A
 
 // ---- pipelined variant: wave 0 factors with the broadcast row prefetched one step ahead (its newest element through
 // a constant-lane readlane), then inverts from the finished rows
-__device__ __forceinline__ double bcast_lane(double v, int srclane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane), hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
-    return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ void potrf_pipe(double (*t)[CT + 1], double (*inv)[CT + 1], int h, int w, int *fail)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane < CT ? lane : CT - 1;
@@ -210,11 +218,22 @@ int main()
         for (int i = 0; i < CT; i++) for (int j = 0; j <= i; j++) { dl = fmax(dl, fabs(Q[i + CT * j] - R[i + CT * j])); di = fmax(di, fabs(Q[CT * CT + i + CT * j] - R[CT * CT + i + CT * j])); }
         printf("pipelined: %lld cycles; max |L - L_ref| = %.3e, max |inv - inv_ref| = %.3e\n", cv, dl, di);
     }
-    for (int mode = 0; mode < 2; mode++) {
-        for (int it = 0; it < 3; it++) { if (mode == 0) hipLaunchKernelGGL(k_var<0>, dim3(1), dim3(256), 0, 0, dA, dO, dC, dF); else hipLaunchKernelGGL(k_var<1>, dim3(1), dim3(256), 0, 0, dA, dO, dC, dF); }
+    for (int mode = 0; mode < 4; mode++) {
+        for (int it = 0; it < 3; it++) {
+            if (mode == 0) hipLaunchKernelGGL(k_var<0>, dim3(1), dim3(256), 0, 0, dA, dO, dC, dF);
+            else if (mode == 1) hipLaunchKernelGGL(k_var<1>, dim3(1), dim3(256), 0, 0, dA, dO, dC, dF);
+            else if (mode == 2) hipLaunchKernelGGL(k_var<2>, dim3(1), dim3(256), 0, 0, dA, dO, dC, dF);
+            else hipLaunchKernelGGL(k_var<3>, dim3(1), dim3(256), 0, 0, dA, dO, dC, dF);
+        }
         hipDeviceSynchronize();
         long long cv; hipMemcpy(&cv, dC, 8, hipMemcpyDeviceToHost);
-        printf("variant mode %d (bit0: with the inverse wave): %lld cycles\n", mode, cv);
+        {
+            std::vector<double> Q(2 * CT * CT);
+            hipMemcpy(Q.data(), dO, sizeof(double) * 2 * CT * CT, hipMemcpyDeviceToHost);
+            double e2 = 0.0;
+            for (int i = 0; i < CT; i++) for (int j = 0; j <= i; j++) { double s2 = 0.0; for (int k = 0; k <= j; k++) s2 += Q[i + CT * k] * Q[j + CT * k]; e2 = fmax(e2, fabs(s2 - A[i + CT * j])); }
+            printf("variant mode %d (bit0: inverse wave, bit1: incremental pivots): %lld cycles, |LL'-A|max = %.3e\n", mode, cv, e2);
+        }
     }
     printf("tile_potrf_inv: %lld cycles (s_memtime ticks) per call, |LL'-A|max = %.3e\n", c, err);
     return 0;
