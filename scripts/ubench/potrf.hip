@@ -191,6 +191,62 @@ __global__ __launch_bounds__(256) void k_pipe(const double *A, double *out, long
     if (threadIdx.x == 0) *cycles = c1 - c0;
 }
 
+
+// ---- one-wave variant: the inverse advances inside the factor loop (row j of L is already in registers for the dot
+// products), pivots from running sums of squares
+__device__ __forceinline__ void potrf_fused(double (*t)[CT + 1], double (*inv)[CT + 1], int h, int w, int *fail)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane < CT ? lane : CT - 1;
+    __syncthreads();
+    if (wv == 0) {
+        double lrow[CT], x[CT];
+        double dsq = 0.0;
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < CT; j++) {
+            const bool active = j < w;
+            double acc = t[li][j];
+            double dj = t[j][j] - bcast_lane(dsq, j);
+            double pa[4] = {0.0, 0.0, 0.0, 0.0}, ps[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int m = 0; m < j; m++) {
+                const double ljm = t[j][m];                          // broadcast, final since step m
+                pa[m & 3] += lrow[m] * ljm;
+                ps[m & 3] += ljm * x[m];
+            }
+            acc -= (pa[0] + pa[1]) + (pa[2] + pa[3]);
+            bad = bad || (active && !(dj > 0));
+            dj = (active && dj > 0) ? dj : 1.0;
+            const double rd = rsqrt(dj);
+            const double l = (lane == j) ? dj * rd : acc * rd;
+            lrow[j] = l;
+            dsq += l * l;
+            const double sacc = ((j == lane) ? 1.0 : 0.0) - ((ps[0] + ps[1]) + (ps[2] + ps[3]));
+            x[j] = (active && lane <= j) ? sacc * rd : 0.0;
+            if (active && lane >= j && lane < CT) t[lane][j] = l;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (bad && lane == 0) *fail = 1;
+        if (lane < CT) {
+#pragma unroll
+            for (int i = 0; i < CT; i++) inv[i][lane] = (lane < w) ? x[i] : 0.0;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_fused(const double *A, double *out, long long *cycles, int *fail)
+{
+    __shared__ double t[CT][CT + 1], inv[CT][CT + 1];
+    for (int e = threadIdx.x; e < CT * CT; e += 256) { const int i = e % CT, j = e / CT; t[i][j] = i >= j ? A[i + CT * j] : 0.0; }
+    __syncthreads();
+    const long long c0 = clock64();
+    potrf_fused(t, inv, CT, CT, fail);
+    __syncthreads();
+    const long long c1 = clock64();
+    for (int e = threadIdx.x; e < CT * CT; e += 256) { const int i = e % CT, j = e / CT; out[e] = t[i][j]; out[CT * CT + e] = inv[i][j]; }
+    if (threadIdx.x == 0) *cycles = c1 - c0;
+}
+
 int main()
 {
     std::vector<double> B(CT * CT), A(CT * CT, 0.0);
@@ -217,6 +273,18 @@ int main()
         double dl = 0.0, di = 0.0;
         for (int i = 0; i < CT; i++) for (int j = 0; j <= i; j++) { dl = fmax(dl, fabs(Q[i + CT * j] - R[i + CT * j])); di = fmax(di, fabs(Q[CT * CT + i + CT * j] - R[CT * CT + i + CT * j])); }
         printf("pipelined: %lld cycles; max |L - L_ref| = %.3e, max |inv - inv_ref| = %.3e\n", cv, dl, di);
+        for (int it = 0; it < 3; it++) hipLaunchKernelGGL(k_fused, dim3(1), dim3(256), 0, 0, dA, dO, dC, dF);
+        hipDeviceSynchronize();
+        hipMemcpy(&cv, dC, 8, hipMemcpyDeviceToHost);
+        hipMemcpy(Q.data(), dO, sizeof(double) * 2 * CT * CT, hipMemcpyDeviceToHost);
+        dl = 0.0; di = 0.0;
+        double li_err = 0.0;                              // || L inv - I ||_max
+        for (int i = 0; i < CT; i++) for (int j = 0; j <= i; j++) {
+            dl = fmax(dl, fabs(Q[i + CT * j] - R[i + CT * j])); di = fmax(di, fabs(Q[CT * CT + i + CT * j] - R[CT * CT + i + CT * j]));
+            double s2 = 0.0; for (int k = j; k <= i; k++) s2 += Q[i + CT * k] * Q[CT * CT + k + CT * j];
+            li_err = fmax(li_err, fabs(s2 - (i == j ? 1.0 : 0.0)));
+        }
+        printf("fused one-wave: %lld cycles; max |L - L_ref| = %.3e, max |inv - inv_ref| = %.3e, |L inv - I|max = %.3e\n", cv, dl, di, li_err);
     }
     for (int mode = 0; mode < 4; mode++) {
         for (int it = 0; it < 3; it++) {
