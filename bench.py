@@ -593,6 +593,16 @@ def main():
             t0 = time.perf_counter()
             _, _, st1 = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], 2, 3, 5.0, solver=1)
             c1 = (time.perf_counter() - t0) * 1e3 / max(st1["iters_pass1"] + st1["iters_pass2"], 1)
+            # the measured GPU solver against the oracle on the same 50-KF problem and iteration budget (parity, not timing)
+            chk = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+            slam.bundle_adjustment_(chk, s["cam"], iterations=3, iters_fast=2, ctx=ctx)
+            rel = abs(chk.stats["ssr_final"] - st1["ssr_final"]) / st1["ssr_final"]
+            rel0 = abs(chk.stats["ssr_final"] - st0["ssr_final"]) / st0["ssr_final"]
+            assert rel <= 1e-8 and chk.stats["n_outliers"] == st1["n_outliers"], ("BA parity vs oracle Schur-LM", rel, chk.stats, st1)
+            assert rel0 <= 1e-2, ("BA cost vs reference-style LM+LSMR", rel0)
+            out["ba"]["parity_vs_oracle"] = {"iters": [2, 3], "ssr_final_gpu": chk.stats["ssr_final"], "ssr_final_oracle_schur": st1["ssr_final"],
+                                             "rel_diff_schur": rel, "ssr_final_oracle_lm_lsmr": st0["ssr_final"], "rel_diff_lm_lsmr": rel0,
+                                             "outliers_equal": True}
             out["ba"]["cpu_ms_per_iter_reference_style_lm_lsmr"] = c0
             out["ba"]["cpu_ms_per_iter_schur"] = c1
             out["ba"]["cpu_cores"] = 1

@@ -385,3 +385,88 @@ def five_point_ransac(px1_xy, px2_xy, pd1_xy, pd2_xy, K1, K2, max_repr_error, sa
     cnt = lib().orc_five_point_ransac(_p(a), _p(b), _p(c), _p(d), n, _p(k1), _p(k2), C.c_double(max_repr_error), _p(sm, i32p), len(sm),
                                       _p(E), _p(P), _p(inl, u8p), C.byref(err), C.byref(bi))
     return cnt, np.array(E), np.array(P), inl[:n].astype(bool), err.value, bi.value
+
+
+# ----------------------------------------------------------------------------
+def undistort_point(cam, dist, p_yx):
+    """undistort_point / undistort_pdn_point, src/camera.jl:98-125 (applies the lens model to a (y, x) pixel).
+    cam = (fx, fy, cx, cy); dist = (k1, k2, p1, p2)."""
+    fx, fy, cx, cy = cam
+    k1, k2, p1, p2 = dist
+    ny = (p_yx[0] - cy) / fy; nx = (p_yx[1] - cx) / fx                     # :99-101
+    s0 = ny * ny; s1 = nx * nx
+    r2 = s0 + s1                                                           # :114
+    rd = 1.0 + k1 * r2 + k2 * r2 ** 2                                      # :116
+    p = ny * nx                                                            # :118
+    dtx = 2 * p1 * p + p2 * (r2 + 2 * s0)                                  # :119
+    dty = p1 * (r2 + 2 * s1) + 2 * p2 * p                                  # :120
+    dy = rd * ny + dty; dx = rd * nx + dtx                                 # :122
+    return np.array([dy * fy + cy, dx * fx + cx])                          # :124
+
+
+def optical_flow_matching(prev, cur, pixels, is_3d, projections, image_size, stereo=False,
+                          undistorted_left=None, right_cam=None, right_dist=(0.0, 0.0, 0.0, 0.0),
+                          pyramid_levels=3, window_size=9, max_distance=1.0, epipolar_error=2.0,
+                          sum_order=0, threads=1):
+    """Array-level restatement of optical_flow_matching!(map_manager, frame, from, to, stereo)
+    -- src/map_manager.jl:451-564 with maybe_stereo_update! :579-590.
+
+    Keypoint j has `pixels[j]` (y, x), flag `is_3d[j]`, and for 3-D keypoints the projection of its map point into
+    the target image `projections[j]` (project_world_to_image_distort / ..._right_image_distort, :485-488).
+    image_size = (height, width) of in_image / in_right_image (camera.jl:90-92).
+
+    Returns a dict of arrays over the input keypoints:
+      new_pixels  (n, 2)  position written by update_keypoint! / update_stereo_keypoint!  (input pixel elsewhere)
+      updated     (n,)    keypoint was updated  (:526-531, :554-558)
+      removed     (n,)    observation removed   (:496-497 stereo out-of-image, :559 failed 2-D track of a temporal match)
+    A 3-D keypoint whose projection is outside the image is skipped entirely in the temporal case (:501-506:
+    neither tracked, updated nor removed) and removed in the stereo case (:491-498).
+    """
+    px = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
+    n = len(px)
+    is3 = np.asarray(is_3d).astype(bool)
+    proj = np.ascontiguousarray(projections, dtype=np.float64).reshape(-1, 2)
+    Himg, Wimg = image_size if image_size is not None else (np.inf, np.inf)     # None: every projection counts as inside
+    new = px.copy(); updated = np.zeros(n, bool); removed = np.zeros(n, bool)
+    pyramid_levels_3d = 1                                                   # :458
+    scale = 1.0 / 2.0 ** pyramid_levels_3d                                  # :466
+    ids, ids3d, disp3d = [], [], []
+    for j in range(n):                                                      # :471-508
+        if not is3[j]:
+            ids.append(j); continue
+        inside = image_size is None or ((1 <= proj[j, 0] <= Himg) and (1 <= proj[j, 1] <= Wimg))   # camera.jl:91
+        if inside:
+            ids3d.append(j); disp3d.append(scale * (proj[j] - px[j]))       # :494 / :504
+        elif stereo:
+            removed[j] = True                                               # :496-497
+
+    def stereo_update(j, new_pos):                                          # maybe_stereo_update! :579-590
+        right_pixel = undistort_point(right_cam, right_dist, new_pos)
+        if abs(undistorted_left[j, 0] - right_pixel[0]) > epipolar_error:
+            return False
+        new[j] = (px[j, 0], new_pos[1]); updated[j] = True                  # :587-588
+        return True
+
+    if ids3d:                                                               # :516-540
+        nk, st = fb_tracking(prev, cur, px[ids3d], disp0=np.array(disp3d), pyramid_levels=pyramid_levels_3d,
+                             window=window_size, max_distance=max_distance, sum_order=sum_order, threads=threads)
+        for k, j in enumerate(ids3d):
+            if st[k]:
+                if stereo:
+                    stereo_update(j, nk[k])
+                else:
+                    new[j] = nk[k]; updated[j] = True                       # :530
+            else:
+                ids.append(j)                                               # :533-537: re-tracked with the 2-D set, no prior
+    if ids:                                                                 # :546-562
+        nk, st = fb_tracking(prev, cur, px[ids], pyramid_levels=pyramid_levels, window=window_size,
+                             max_distance=max_distance, sum_order=sum_order, threads=threads)
+        for k, j in enumerate(ids):
+            if stereo:
+                if st[k]:
+                    stereo_update(j, nk[k])
+            elif st[k]:
+                new[j] = nk[k]; updated[j] = True                           # :558
+            else:
+                removed[j] = True                                           # :559
+    return dict(new_pixels=new, updated=updated, removed=removed)

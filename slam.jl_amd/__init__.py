@@ -11,7 +11,7 @@ from ._lib import Context, SlamHipError, default_context, load, LIB_PATH  # noqa
 from .params import Camera, Params  # noqa: F401
 from .extractor import Extractor, detect, detect_batch, describe, brief_pattern  # noqa: F401
 from .optical_flow import (LKPyramid, LucasKanade, update_, copy_, deepcopy, has_gradients, fb_tracking_,  # noqa: F401
-                           optical_flow_matching, PyramidBatch, optical_flow_matching_batch,
+                           optical_flow_matching, optical_flow_matching_frame, PyramidBatch, optical_flow_matching_batch,
                            optical_flow_matching_batch_kept)
 from .bundle_adjustment import LocalBACache, bundle_adjustment_, pnp_bundle_adjustment, pnp_bundle_adjustment_batch  # noqa: F401
 from .triangulation import triangulate, projection_matrices  # noqa: F401

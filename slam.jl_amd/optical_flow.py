@@ -178,6 +178,55 @@ def optical_flow_matching(from_pyramid, to_pyramid, pixels, is_3d, projections, 
     return new, status
 
 
+def undistort_point(cam, dist, p_yx):
+    """undistort_point (camera.jl:98-125) for an (n, 2) array of (y, x) pixels; cam = (fx, fy, cx, cy), dist = (k1, k2, p1, p2)."""
+    fx, fy, cx, cy = cam
+    k1, k2, p1, p2 = dist
+    p = np.asarray(p_yx, dtype=np.float64).reshape(-1, 2)
+    ny = (p[:, 0] - cy) / fy; nx = (p[:, 1] - cx) / fx
+    s0 = ny * ny; s1 = nx * nx
+    r2 = s0 + s1
+    rd = 1.0 + k1 * r2 + k2 * r2 ** 2
+    pr = ny * nx
+    dtx = 2 * p1 * pr + p2 * (r2 + 2 * s0)
+    dty = p1 * (r2 + 2 * s1) + 2 * p2 * pr
+    return np.stack([(rd * ny + dty) * fy + cy, (rd * nx + dtx) * fx + cx], axis=1)
+
+
+def optical_flow_matching_frame(from_pyramid, to_pyramid, pixels, is_3d, projections, params, image_size, stereo=False,
+                                undistorted_left=None, right_cam=None, right_dist=(0.0, 0.0, 0.0, 0.0),
+                                epipolar_error=2.0, ctx=None):
+    """optical_flow_matching!(map_manager, frame, from, to, stereo) on the frame's keypoint arrays, with the gates the
+    reference applies around the two fb_tracking! calls (map_manager.jl:451-564): 3-D keypoints whose projection is
+    outside the target image are skipped (temporal, :501-506) or removed (stereo, :491-498); a stereo match must pass
+    maybe_stereo_update! (:579-590: row difference of the undistorted pixels <= epipolar_error; the row of the left
+    keypoint is kept).  The tracking itself is ONE slam_flow_match launch.
+    Returns dict(new_pixels, updated, removed) over the input keypoints."""
+    px = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
+    n = len(px)
+    is3 = np.asarray(is_3d).astype(bool)
+    proj = np.ascontiguousarray(projections, dtype=np.float64).reshape(-1, 2)
+    Himg, Wimg = image_size
+    inside = (proj[:, 0] >= 1) & (proj[:, 0] <= Himg) & (proj[:, 1] >= 1) & (proj[:, 1] <= Wimg)      # camera.jl:91
+    skipped = is3 & ~inside
+    sel = np.where(~skipped)[0]
+    new = px.copy(); updated = np.zeros(n, bool); removed = np.zeros(n, bool)
+    if stereo:
+        removed[skipped] = True
+    if len(sel):
+        out, st = optical_flow_matching(from_pyramid, to_pyramid, px[sel], is3[sel], proj[sel], params, ctx=ctx)
+        if stereo:
+            right_pixel = undistort_point(right_cam, right_dist, out)
+            ok = st & ~(np.abs(np.asarray(undistorted_left)[sel, 0] - right_pixel[:, 0]) > epipolar_error)
+            good = sel[ok]
+            new[good, 1] = out[ok, 1]                                                                 # :587: row of the left keypoint kept
+            updated[good] = True
+        else:
+            new[sel[st]] = out[st]; updated[sel[st]] = True
+            removed[sel[~st]] = True                                                                  # :559
+    return dict(new_pixels=new, updated=updated, removed=removed)
+
+
 class PyramidBatch:
     """S pyramids backed by one allocation (slam_pyr_create_batch): every per-image kernel of the build takes the
     image index from grid.z, so S independent images cost one launch set.  `self.pyramids[s]` are ordinary LKPyramid

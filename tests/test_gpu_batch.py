@@ -59,6 +59,14 @@ def test_batch_flow_match_equals_per_stream(slam, orc, texture):
     assert np.array_equal(new[inv], np.concatenate(ref_new))
     with pytest.raises(slam.SlamHipError):
         slam.optical_flow_matching_batch(a, b, np.full(len(P), S), P, T, R, params)      # stream index out of range
+    # the batched kernel against the CPU oracle's optical_flow_matching! directly
+    for s in range(S):
+        ra, rb = orc.pyr_build(streams[s][0][0], 3, 1.0, 1), orc.pyr_build(streams[s][0][1], 3, 1.0, 1)
+        ref = orc.optical_flow_matching(ra, rb, pts[s], is3[s], proj[s], None, sum_order=1)
+        sel = np.concatenate(idx) == s
+        got_st, got_new = st[inv][sel], new[inv][sel]
+        assert np.array_equal(got_st, ref["updated"])
+        assert np.abs(got_new - ref["new_pixels"])[got_st].max() <= 1e-9
 
 
 def test_checkpointed_row_kernel_is_bit_exact(slam, monkeypatch):
@@ -85,7 +93,7 @@ def test_checkpointed_row_kernel_is_bit_exact(slam, monkeypatch):
             assert np.array_equal(batch.pyramids[s].plane("layers", 1), single.plane("layers", 1))
 
 
-def test_batch_at_kitti_size_uses_checkpointed_kernels_and_stays_exact(slam, syn):
+def test_batch_at_kitti_size_uses_checkpointed_kernels_and_stays_exact(slam, syn, orc):
     """8 images of 370 x 1226 per launch is above the bandwidth threshold (116 MB of plane data at level 0), so this
     batch runs k_iir_cols_ck / k_iir_rows_ck with their real block counts; members must equal single-image pyramids."""
     import torch
@@ -100,13 +108,15 @@ def test_batch_at_kitti_size_uses_checkpointed_kernels_and_stays_exact(slam, syn
     for s in (0, S - 1):
         single = slam.LKPyramid(shape=(H, W), levels=3)
         slam.update_(single, imgs[s])
+        ref = orc.pyr_build(imgs[s], 3, 1.0, 1)                  # the batched kernels against the CPU oracle directly
         for l in range(4):
             for name in PLANES:
                 assert np.array_equal(batch.pyramids[s].plane(name, l), single.plane(name, l)), (s, name, l)
+                assert np.array_equal(batch.pyramids[s].plane(name, l), ref.plane(name, l)), ("oracle", s, name, l)
 
 
 @pytest.mark.parametrize("shape", [(70, 71), (33, 102), (130, 135), (64, 64), (65, 129), (16, 200), (200, 17)])
-def test_fused_integral_image_kernel_is_bit_exact(slam, shape):
+def test_fused_integral_image_kernel_is_bit_exact(slam, shape, orc):
     """Batches of >= 8 images build the integral images with the one-pass kernel (k_cum_fused: 64 x 64 tiles, column
     sums then row sums with carries); planes must equal the two-pass single-image kernels bit for bit."""
     import torch
@@ -124,6 +134,10 @@ def test_fused_integral_image_kernel_is_bit_exact(slam, shape):
         for l in range(2):
             for name in PLANES:
                 assert np.array_equal(batch.pyramids[s].plane(name, l), single.plane(name, l)), (shape, s, name, l)
+    ref = orc.pyr_build(imgs[3], 1, 1.0, 1)
+    for l in range(2):
+        for name in PLANES:
+            assert np.array_equal(batch.pyramids[3].plane(name, l), ref.plane(name, l)), ("oracle", shape, name, l)
 
 
 def test_batch_u8_ingest_equals_float_ingest(slam, syn):

@@ -6,7 +6,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("S", [1, 3, 8, 40])
-def test_detect_batch_equals_per_stream(slam, syn, S):
+def test_detect_batch_equals_per_stream(slam, syn, orc, S):
     H, W = 188, 620
     imgs = [np.asfortranarray(syn.texture_canvas(H, W, seed=50 + s, margin=0)) for s in range(S)]
     params = slam.Params(stereo=True, max_nb_keypoints=400)
@@ -31,6 +31,9 @@ def test_detect_batch_equals_per_stream(slam, syn, S):
         ref = slam.detect(e, batch.pyramids[s], cur[s])
         got = kp[ksid == s]
         assert np.array_equal(got, ref), f"stream {s}"
+        if s in (0, 1, S - 2):                                   # the batched kernel against the CPU oracle directly
+            oref = orc.detect(imgs[s], cur[s], max_points=params.max_nb_keypoints)
+            assert np.array_equal(got, oref), f"oracle, stream {s}"
         total += len(ref)
     assert total == len(kp) and total > 0
     if S > 1:

@@ -31,11 +31,13 @@ def _check(slam, orc, g, r, pts, disp=None, levels=3, window=9, maxd=1.0):
     return out, st
 
 
-@pytest.mark.parametrize("H,W", [(120, 160), (370, 1226)])
-def test_fb_tracking_matches_oracle(slam, orc, texture, H, W):
+@pytest.mark.parametrize("H,W,maxp", [(120, 160, 1000), (370, 1226, 1000), (376, 1241, 2000)])
+def test_fb_tracking_matches_oracle(slam, orc, texture, H, W, maxp):
+    """incl. BASELINE configs[1] (370 x 1226, 1000 kpts) and configs[2] (376 x 1241, 2000 kpts)"""
     L, R, flows = texture(H, W)
     g, r = _pyrs(slam, orc, L)
-    kp = orc.detect(L[0], np.zeros((0, 2)), max_points=1000).astype(float)
+    kp = orc.detect(L[0], np.zeros((0, 2)), max_points=maxp).astype(float)
+    assert len(kp) >= 0.9 * maxp or H < 300
     kp = kp + np.random.default_rng(1).uniform(0, 0.99, kp.shape)          # sub-pixel keypoints
     kp = np.clip(kp, 1, [H, W])
     out, st = _check(slam, orc, g, r, kp)
@@ -98,6 +100,54 @@ def test_optical_flow_matching_protocol(slam, orc, texture):
     assert np.array_equal(st, st2) and np.array_equal(new, new2)             # one launch == the reference's two calls
     assert st.mean() > 0.6
     assert np.abs(np.median((new - kp)[st], 0) - np.array(flows[1])).max() < 0.05
+
+
+def _match_vs_oracle(slam, orc, g, r, kp, is3d, proj, size, **kw):
+    got = slam.optical_flow_matching_frame(g[0], g[1], kp, is3d, proj, slam.Params(), size, **kw)
+    ref = orc.optical_flow_matching(r[0], r[1], kp, is3d, proj, size, sum_order=1, **kw)
+    assert np.array_equal(got["updated"], ref["updated"]) and np.array_equal(got["removed"], ref["removed"])
+    assert np.abs(got["new_pixels"] - ref["new_pixels"]).max() <= TOL_SAME_ORDER
+    ref0 = orc.optical_flow_matching(r[0], r[1], kp, is3d, proj, size, sum_order=0, **kw)       # the reference's summation order
+    assert (got["updated"] != ref0["updated"]).sum() <= max(1, len(kp) // 200)
+    both = got["updated"] & ref0["updated"]
+    assert np.abs(got["new_pixels"] - ref0["new_pixels"])[both].max() <= TOL_REF_ORDER
+    return got
+
+
+@pytest.mark.parametrize("H,W,maxp", [(120, 160, 200), (370, 1226, 1000)])
+def test_optical_flow_matching_vs_oracle_temporal(slam, orc, texture, H, W, maxp):
+    """slam_flow_match (ONE launch) against the oracle's restatement of map_manager.jl:451-564: priors (proj - px) / 2 on
+    pyramid_levels_3d = 1, failed 3-D keypoints re-joined to the 2-D set, out-of-image projections skipped."""
+    L, R, flows = texture(H, W)
+    g, r = _pyrs(slam, orc, L)
+    kp = orc.detect(L[0], np.zeros((0, 2)), max_points=maxp).astype(float)
+    rng = np.random.default_rng(5)
+    is3d = rng.random(len(kp)) < 0.6
+    proj = kp + np.array(flows[1]) + rng.normal(0, 0.3, kp.shape)
+    proj[::10] += 40.0                                                       # bad priors fall back to the 2-D pass
+    proj[3] = (H + 2.0, 5.0); is3d[3] = True                                 # outside the image: skipped
+    got = _match_vs_oracle(slam, orc, g, r, kp, is3d, proj, (H, W))
+    assert not got["updated"][3] and not got["removed"][3]
+    assert got["updated"].mean() > 0.6 and got["removed"].any()
+
+
+def test_optical_flow_matching_vs_oracle_stereo(slam, orc, texture, syn):
+    """stereo = true: out-of-image projections are removed, matches pass maybe_stereo_update! (map_manager.jl:579-590)."""
+    H, W = 120, 160
+    L, R, flows = texture(H, W, disparity=6.3)
+    g, r = [], []
+    for im in (L[0], R[0]):
+        lk = slam.LKPyramid(shape=im.shape, levels=3); slam.update_(lk, im); g.append(lk); r.append(orc.pyr_build(im, 3, 1.0, 1))
+    kp = orc.detect(L[0], np.zeros((0, 2)), max_points=300).astype(float)
+    rng = np.random.default_rng(6)
+    is3d = rng.random(len(kp)) < 0.5
+    proj = kp + np.array([0.0, -6.3])
+    und = kp + rng.normal(0, 0.9, kp.shape)                                  # some rows differ by more than 2 px from the match
+    und[::7, 0] += 3.0
+    got = _match_vs_oracle(slam, orc, g, r, kp, is3d, proj, (H, W), stereo=True, undistorted_left=und, right_cam=syn.KITTI_CAM)
+    up = got["updated"]
+    assert 0.3 < up.mean() < 0.95
+    assert np.array_equal(got["new_pixels"][up][:, 0], kp[up][:, 0])
 
 
 @pytest.mark.parametrize("window", [2, 5, 6, 7, 12])
