@@ -860,6 +860,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     hipError_t e = hipMalloc((void **)&A, off);
     if (e != hipSuccess) { delete ba; return slam_fail(ctx, SLAM_ERR_HIP, "slam_ba: hipMalloc(%zu): %s", off, hipGetErrorString(e)); }
     ba->arena = A;
+    struct Guard { slam_ba *b; ~Guard() { if (b) { if (b->arena) (void)hipFree(b->arena); delete b; } } } guard{ba};   // a failing upload frees the arena
     BADev &d = ba->d;
     d.cam = {fx, fy, cx, cy}; d.P = P; d.M = M; d.O = O; d.n = n;
     d.pose = (double *)(A + o_pose); d.pose_t = (double *)(A + o_pose_t); d.pts = (double *)(A + o_pts); d.pts_t = (double *)(A + o_pts_t);
@@ -883,7 +884,8 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
 #undef UP
     HIP_TRY(ctx, hipMemsetAsync(d.outl, 0, (size_t)O + 1, st));
     HIP_TRY(ctx, hipMemsetAsync(d.st, 0, sizeof(LMState), st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));   // host vectors go out of scope
+    HIP_TRY(ctx, slam_stream_wait(st));   // host vectors go out of scope
+    guard.b = nullptr;
     *out = ba;
     return SLAM_OK;
 }
@@ -967,7 +969,7 @@ int slam_ba_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, double inv_de
     int rc = ba_enqueue_build(ctx, ba, ignore_outliers, inv_delta, 0, reduce_dev);
     if (rc) return rc;
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
 }
 
@@ -979,7 +981,7 @@ int slam_ba_solve(slam_ctx *ctx, slam_ba *ba, const double *reduce_dev, double i
     int rc = ba_enqueue_solve(ctx, ba, reduce_dev, 1, inv_delta, 0, 0, trial_dev);
     if (rc) return rc;
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
 }
 
@@ -989,7 +991,7 @@ int slam_ba_commit(slam_ctx *ctx, slam_ba *ba, int accept)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ba_enqueue_commit(ctx, ba, accept, 0, 0);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
 }
 
@@ -1002,7 +1004,7 @@ int slam_ba_flag_outliers(slam_ctx *ctx, slam_ba *ba, double repr_eps, double de
     HIP_TRY(ctx, hipGetLastError());
     LMState h;
     HIP_TRY(ctx, hipMemcpyAsync(&h, ba->d.st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     if (n_out) *n_out = h.n_outliers;
     return SLAM_OK;
 }
@@ -1018,7 +1020,7 @@ int slam_ba_download(slam_ctx *ctx, slam_ba *ba, double *theta, uint8_t *outlier
     }
     std::vector<uint8_t> tmp;
     if (outliers && d.O > 0) { tmp.resize(d.O); HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), d.outl, (size_t)d.O, hipMemcpyDeviceToHost, ctx->stream)); }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     if (outliers) for (int s = 0; s < d.O; s++) outliers[ba->perm[s]] = tmp[s];
     return SLAM_OK;
 }
@@ -1060,18 +1062,21 @@ int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy, int
     LMState h;
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&h, d.st, sizeof h, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { slam_ba_destroy(ba); return slam_fail(ctx, SLAM_ERR_HIP, "slam_local_ba: %s", hipGetErrorString(e)); }
-    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess) e = slam_stream_wait(st);
+    float ms = 0;
+    if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    rc = slam_ba_download(ctx, ba, theta, outliers);
+    if (e != hipSuccess) { slam_ba_destroy(ba); return slam_fail(ctx, SLAM_ERR_HIP, "slam_local_ba: %s", hipGetErrorString(e)); }
+    // A failed factorisation leaves the caller's theta and outliers untouched (the reference's LSMR step cannot fail and
+    // never leaves cache.theta half-updated): the state is only copied back from a run that completed.
+    rc = h.chol_fail ? SLAM_OK : slam_ba_download(ctx, ba, theta, outliers);
     slam_ba_destroy(ba);
     if (rc) return rc;
     if (stats) {
         stats[0] = h.ssr_init; stats[1] = h.ssr_pass1; stats[2] = h.ssr_final; stats[3] = h.iters_pass1; stats[4] = h.iters_pass2;
         stats[5] = h.n_outliers; stats[6] = ms; stats[7] = h.chol_fail;
     }
-    if (h.chol_fail) return slam_fail(ctx, SLAM_ERR_NUMERIC, "slam_local_ba: reduced camera system not positive definite");
+    if (h.chol_fail) return slam_fail(ctx, SLAM_ERR_NUMERIC, "slam_local_ba: reduced camera system not positive definite (theta and outliers left unchanged)");
     return SLAM_OK;
 }
 
@@ -1316,7 +1321,7 @@ extern "C" int slam_pnp_ba_batch(slam_ctx *ctx, int S, const int32_t *offsets, c
     double *res = (double *)(h + (size_t)S * sizeof(PnPArgs));
     HIP_TRY(ctx, hipMemcpyAsync(res, d_res, (size_t)S * 128, hipMemcpyDeviceToHost, ctx->stream));
     if (ntot > 0) HIP_TRY(ctx, hipMemcpyAsync(outliers, d_o, (size_t)ntot, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     for (int z = 0; z < S; z++) {
         const double *r = res + 16 * z;
         if (err_init) err_init[z] = r[6];
@@ -1354,7 +1359,7 @@ extern "C" int slam_pnp_ba(slam_ctx *ctx, double fx, double fy, double cx, doubl
     double res[12];
     HIP_TRY(ctx, hipMemcpyAsync(res, d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
     if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(outliers, d_o, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     if (err_init) *err_init = res[6];
     if (err_final) *err_final = res[7];
     if (n_outliers) *n_outliers = (int)res[8];

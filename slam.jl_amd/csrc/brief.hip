@@ -86,7 +86,7 @@ extern "C" int slam_describe(slam_ctx *ctx, const double *image, int H, int W, c
     hipLaunchKernelGGL(k_brief, dim3(m), dim3(64), 0, ctx->stream, (const double *)d_a, H, (const int64_t *)d_rc, (const int32_t *)d_pat, n_bits, d_out);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(out_bits, d_out, (size_t)m * words * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     memcpy(out_rc, keep.data(), (size_t)m * 16);
     *n_out = m;
     return SLAM_OK;

@@ -74,6 +74,12 @@ struct slam_pyr {
 
 extern thread_local std::string g_slam_err;
 
+// The synchronous seams end with a wait for the context's stream.  The interrupt-driven hipStreamSynchronize costs tens of
+// microseconds per call; instead of switching the whole DEVICE to hipDeviceScheduleSpin (process-wide: torch and every other
+// user of the runtime would spin too), only the library's own waits poll -- for at most SLAMHIP_SPIN_US microseconds
+// (default 2000, 0 = never), then they block.
+hipError_t slam_stream_wait(hipStream_t s);
+
 int slam_fail(slam_ctx *ctx, int code, const char *fmt, ...);
 int slam_scratch(slam_ctx *ctx, size_t bytes, void **out);
 int slam_scratch2(slam_ctx *ctx, size_t bytes, void **out);

@@ -1,5 +1,7 @@
 // ctx.hip -- context, scratch management, error reporting, filter coefficients.
 #include "common.hpp"
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdarg>
 
@@ -16,7 +18,7 @@ int slam_fail(slam_ctx *ctx, int code, const char *fmt, ...)
 static int grow(slam_ctx *ctx, void **p, size_t *have, size_t want, bool pinned)
 {
     if (*have >= want) return SLAM_OK;
-    if (*p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); if (pinned) (void)hipHostFree(*p); else (void)hipFree(*p); *p = nullptr; *have = 0; }
+    if (*p) { HIP_TRY(ctx, slam_stream_wait(ctx->stream)); if (pinned) (void)hipHostFree(*p); else (void)hipFree(*p); *p = nullptr; *have = 0; }
     size_t sz = want + want / 4 + 4096;
     if (pinned) HIP_TRY(ctx, hipHostMalloc(p, sz, hipHostMallocMapped | hipHostMallocCoherent));   // device-visible, fine-grained
     else HIP_TRY(ctx, hipMalloc(p, sz));
@@ -51,13 +53,27 @@ ProfScope::~ProfScope()
 }
 static void prof_collect(slam_ctx *c)
 {
-    (void)hipStreamSynchronize(c->stream);
+    (void)slam_stream_wait(c->stream);
     for (auto &sp : c->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { c->prof_ms[sp.id] += ms; c->prof_cnt[sp.id]++; }
         c->prof_pool.push_back(sp.a); c->prof_pool.push_back(sp.b);
     }
     c->prof_pending.clear();
+}
+
+hipError_t slam_stream_wait(hipStream_t s)
+{
+    static const long spin_us = [] { const char *v = getenv("SLAMHIP_SPIN_US"); return v ? atol(v) : 2000L; }();
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0;; k++) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e != hipErrorNotReady) return e;
+            if ((k & 63) == 63 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+        }
+    }
+    return hipStreamSynchronize(s);
 }
 
 extern "C" {
@@ -98,9 +114,6 @@ int slam_ctx_create(int device, slam_ctx **out)
     if (device < 0 || device >= n) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_ctx_create: device %d out of range [0,%d)", device, n);
     slam_ctx *c = new slam_ctx();
     c->device = device;
-    // synchronous seams return after a stream sync: spin instead of the interrupt-driven wait (tens of us per call)
-    (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
-    (void)hipGetLastError();
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create: %s", hipGetErrorString(e)); }
@@ -112,7 +125,7 @@ int slam_ctx_destroy(slam_ctx *ctx)
 {
     if (!ctx) return SLAM_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)slam_stream_wait(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -127,7 +140,7 @@ int slam_ctx_destroy(slam_ctx *ctx)
 int slam_ctx_synchronize(slam_ctx *ctx)
 {
     ARG_TRY(ctx, ctx != nullptr);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
 }
 

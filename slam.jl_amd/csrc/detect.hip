@@ -374,7 +374,7 @@ int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, int p
     rc = slam_pinned(ctx, out_b, (void **)&h_out);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     int64_t cnt = h_out[0];
     if (cnt > cap) return slam_fail(ctx, SLAM_ERR_CAPACITY, "slam_detect: %lld keypoints but cap = %d", (long long)cnt, cap);
     memcpy(out_rc, h_out + 1, (size_t)cnt * 16);
@@ -471,7 +471,7 @@ extern "C" int slam_detect_batch(slam_ctx *ctx, const slam_pyr *pyr0, int S, con
     HIP_TRY(ctx, hipGetLastError());
     int64_t *h_out = (int64_t *)(h + hdr_b + cur_b);
     HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     size_t tot = 0;
     for (int s = 0; s < S; s++) tot += (size_t)h_out[(size_t)s * (1 + 2 * pairs)];
     if (tot > (size_t)cap) return slam_fail(ctx, SLAM_ERR_CAPACITY, "slam_detect_batch: %zu keypoints but cap = %d", tot, cap);

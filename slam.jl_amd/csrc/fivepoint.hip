@@ -699,7 +699,7 @@ static int fp_run(slam_ctx *ctx, int S, const int32_t *off, const double *px1_xy
       hipLaunchKernelGGL(k_5pt_score, dim3(iters, FP_MAXE, S), dim3(FP_SCORE_T), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_5pt_select, dim3(S), dim3(FP_SEL_T), 0, ctx->stream, T); }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     for (int z = 0; z < S; z++) {
         const char *o = h + o_out + (size_t)z * 256;      // P [0,96) E [96,168) error [168,176) n_inliers [176,180) best_iter [180,184)
         memcpy(P + 12 * z, o, 96);

@@ -455,7 +455,7 @@ static int run_tracking(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr *cur
       } }
     HIP_TRY(ctx, hipGetLastError());
     if (staged) HIP_TRY(ctx, hipMemcpyAsync(h + in_b, d + in_b, out_b, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     memcpy(out_yx, h + in_b, (size_t)n * 16);
     memcpy(status, h + in_b + pb, (size_t)n);
     return SLAM_OK;

@@ -323,7 +323,7 @@ static int p3p_run(slam_ctx *ctx, int S, const int32_t *off, const double *pts3d
       hipLaunchKernelGGL(k_p3p_score, dim3(iters, S), dim3(256), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_p3p_select, dim3(S), dim3(256), 0, ctx->stream, T); }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     for (int z = 0; z < S; z++) {
         const char *o = h + o_out + (size_t)z * 256;
         memcpy(KP + 12 * z, o, 96);

@@ -1242,7 +1242,11 @@ static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, 
     const size_t tail = (size_t)64 * Ps[0];                                  // column tiles of the last workgroup read up to 63 columns past W
     hipError_t e = hipMalloc((void **)&al->base, ((size_t)o * 7 * S + tail) * 8);
     if (e != hipSuccess) { delete al; return slam_fail(ctx, SLAM_ERR_HIP, "slam_pyr_create: hipMalloc: %s", hipGetErrorString(e)); }
-    (void)hipMemsetAsync(al->base, 0, ((size_t)o * 7 * S + tail) * 8, ctx->stream);   // pitch padding rows are never used; keep them defined
+    // pitch padding rows are never used; keep them defined.  Creation is not on the hot path: the memset is complete before the
+    // handle exists, so a build enqueued through ANOTHER context's (non-blocking) stream can never be overtaken by it.
+    e = hipMemsetAsync(al->base, 0, ((size_t)o * 7 * S + tail) * 8, ctx->stream);
+    if (e == hipSuccess) e = slam_stream_wait(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(al->base); delete al; return slam_fail(ctx, SLAM_ERR_HIP, "slam_pyr_create: memset: %s", hipGetErrorString(e)); }
     al->refs = S;
     double *ckbuf = nullptr;
     if (S > 1) {   // checkpoint scratch of k_iir_rows_ck: (blocks x 3) doubles per line of the widest launch (level 0, 4 planes)
@@ -1293,7 +1297,7 @@ int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double
     hipLaunchKernelGGL(k_gather_images, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
     int rc = enqueue_build(ctx, p0, mode, sigma, S);
     if (rc) return rc;
-    if (sync) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (sync) HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
 }
 
@@ -1311,7 +1315,7 @@ int slam_pyr_update_batch_u8_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const uin
     hipLaunchKernelGGL(k_gather_images_u8, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
     int rc = enqueue_build(ctx, p0, mode, sigma, S);
     if (rc) return rc;
-    if (sync) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (sync) HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
 }
 
@@ -1339,7 +1343,7 @@ int slam_pyr_update_dev(slam_ctx *ctx, slam_pyr *p, const double *image_dev, int
     ingest_dense(ctx, p, image_dev);
     int rc = enqueue_build(ctx, p, mode, sigma);
     if (rc) return rc;
-    if (sync) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (sync) HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
 }
 
@@ -1354,7 +1358,7 @@ int slam_pyr_update(slam_ctx *ctx, slam_pyr *p, const double *image, int mode, d
     ingest_dense(ctx, p, (const double *)stage);
     rc = enqueue_build(ctx, p, mode, sigma);
     if (rc) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
 }
 
@@ -1370,7 +1374,7 @@ int slam_pyr_update_u8(slam_ctx *ctx, slam_pyr *p, const uint8_t *image_u8, int 
     hipLaunchKernelGGL(k_u8_to_f64, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, p->plane(0, 0), (const unsigned char *)d8, p->H[0], p->W[0], p->P[0]);
     rc = enqueue_build(ctx, p, mode, sigma);
     if (rc) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
 }
 
@@ -1380,7 +1384,7 @@ int slam_pyr_copy(slam_ctx *ctx, slam_pyr *dst, const slam_pyr *src)
     ARG_TRY(ctx, dst->levels == src->levels && dst->H[0] == src->H[0] && dst->W[0] == src->W[0]);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(dst->planes, src->planes, (size_t)src->off[src->levels] * 6 * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
 }
 
@@ -1413,7 +1417,7 @@ int slam_pyr_download(slam_ctx *ctx, const slam_pyr *p, int plane, int level, do
     if (rc) return rc;
     hipLaunchKernelGGL(k_unpitch, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (double *)stage, (const double *)p->plane(plane, level), p->H[level], p->W[level], p->P[level]);
     HIP_TRY(ctx, hipMemcpyAsync(out, stage, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
 }
 

@@ -89,7 +89,7 @@ extern "C" int slam_triangulate(slam_ctx *ctx, const double *P1, const double *P
     { ProfScope span(ctx, "triangulate");
       hipLaunchKernelGGL(k_triangulate, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, T); }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     memcpy(out_xyz, h + 2 * pb + qb, (size_t)n * 24);
     memcpy(status, h + 2 * pb + qb + ob, (size_t)n);
     return SLAM_OK;

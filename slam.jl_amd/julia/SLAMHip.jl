@@ -11,7 +11,7 @@
 # untyped BA `cache`.  Nobody outside src/optical_flow/ reads the pyramid planes
 # (grep-verified: only pyramid.jl and lucas_kanade.jl touch .layers/.Iy/...), so
 # the Julia-side pyramid keeps its (small, unused) host planes and the device
-# pyramid lives in a side table keyed by `objectid`.  No AMDGPU.jl, no Julia GPU
+# pyramid lives in a side table keyed by the identity of `lk.layers`.  No AMDGPU.jl, no Julia GPU
 # codegen: every call below is a plain C call with host pointers.
 #
 # NOTE: Julia is not installed in the build container, so this file has been
@@ -102,24 +102,66 @@ function hip_describe(e::Extractor, image, keypoints)
 end
 
 # ---- LKPyramid (src/optical_flow/pyramid.jl) ------------------------------------
-const PYR_LOCK = ReentrantLock()
-const PYRS = Dict{UInt, Ptr{Cvoid}}()      # objectid(lk) -> slam_pyr*
+# Device twins.  `LKPyramid` is an immutable struct, so the device pyramid is tied to the IDENTITY of its (mutable)
+# `layers` vector: side table objectid(lk.layers) => (WeakRef(lk.layers), handle) -- the WeakRef guards against a
+# recycled objectid -- and a finalizer on the layers vector.  Finalizers must not block or switch tasks, so the finalizer
+# (a closure over the handle and the key only, never over `lk`) just pushes the pair onto a queue under a try-locked spin
+# lock, re-registering itself when the lock is busy; the queue is drained -- slam_pyr_destroy called, table entry
+# removed -- from ordinary code (`register!`).
+const PYR_LOCK = ReentrantLock()                    # ordinary code only, never taken in a finalizer
+const PYRS = Dict{UInt, Tuple{WeakRef, Ptr{Cvoid}}}()
+const DEAD = Tuple{UInt, Ptr{Cvoid}}[]
+const DEAD_LOCK = Threads.SpinLock()
+
+function release(layers, key::UInt, h::Ptr{Cvoid})
+    if trylock(DEAD_LOCK)
+        try
+            push!(DEAD, (key, h))
+        finally
+            unlock(DEAD_LOCK)
+        end
+    else
+        finalizer(l -> release(l, key, h), layers)  # lock busy (possibly on this very thread): try again at a later GC
+    end
+    nothing
+end
+
+function drain_dead()
+    isempty(DEAD) && return
+    dead = Tuple{UInt, Ptr{Cvoid}}[]
+    GC.enable_finalizers(false)                     # `release` must not run on this thread while it holds the spin lock
+    lock(DEAD_LOCK)
+    try
+        append!(dead, DEAD); empty!(DEAD)
+    finally
+        unlock(DEAD_LOCK)
+        GC.enable_finalizers(true)
+    end
+    lock(PYR_LOCK) do
+        for (key, h) in dead
+            e = get(PYRS, key, nothing)
+            e ≢ nothing && e[2] == h && delete!(PYRS, key)
+            ccall((:slam_pyr_destroy, LIB[]), Cint, (Ptr{Cvoid},), h)
+        end
+    end
+end
+
+function register!(lk::LKPyramid, h::Ptr{Cvoid})
+    drain_dead()
+    layers = lk.layers
+    key = objectid(layers)
+    lock(() -> (PYRS[key] = (WeakRef(layers), h)), PYR_LOCK)
+    finalizer(l -> release(l, key, h), layers)
+    h
+end
 
 function handle(lk::LKPyramid; create_shape = nothing)
-    lock(PYR_LOCK) do
-        h = get(PYRS, objectid(lk), C_NULL)
-        if h == C_NULL
-            H, W = create_shape ≡ nothing ? size(lk.layers[1]) : create_shape
-            r = Ref{Ptr{Cvoid}}(C_NULL)
-            check(ccall((:slam_pyr_create, LIB[]), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), ctx(), H, W, length(lk.layers) - 1, r))
-            h = r[]; PYRS[objectid(lk)] = h
-            finalizer(lk.layers) do _    # the struct is immutable; tie the device memory to its layers vector
-                ccall((:slam_pyr_destroy, LIB[]), Cint, (Ptr{Cvoid},), h)
-                lock(() -> delete!(PYRS, objectid(lk)), PYR_LOCK)
-            end
-        end
-        h
-    end
+    e = lock(() -> get(PYRS, objectid(lk.layers), nothing), PYR_LOCK)
+    e ≢ nothing && e[1].value ≡ lk.layers && return e[2]
+    H, W = create_shape ≡ nothing ? size(lk.layers[1]) : create_shape
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:slam_pyr_create, LIB[]), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), ctx(), H, W, length(lk.layers) - 1, r))
+    register!(lk, r[])
 end
 
 # LKPyramid(image, levels; σ, reusable): keep the Julia constructor for the host
@@ -146,10 +188,10 @@ function hip_copy!(dst::LKPyramid, src::LKPyramid)
 end
 
 function hip_deepcopy(lk::LKPyramid)                          # SLAM.jl:218: KF snapshot for the mapper task
-    new = LKPyramid(map(copy, lk.layers), lk.Iy, lk.Ix, lk.Iyy, lk.Ixx, lk.Iyx, lk.cache)
+    new = LKPyramid(map(copy, lk.layers), lk.Iy, lk.Ix, lk.Iyy, lk.Ixx, lk.Iyx, lk.cache)     # fresh `layers` vector = fresh identity
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:slam_pyr_clone, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx(), handle(lk), r))
-    lock(() -> (PYRS[objectid(new)] = r[]), PYR_LOCK)
+    register!(new, r[])                                        # the clone is released with its layers vector like every other device pyramid
     new
 end
 
@@ -160,11 +202,12 @@ function hip_fb_tracking!(previous_pyramid::LKPyramid, current_pyramid::LKPyrami
     isempty(keypoints) && return
     n = length(keypoints)
     pts = collect(reinterpret(Float64, collect(keypoints)))
-    d0 = displacement ≡ nothing ? Ptr{Float64}(C_NULL) : pointer(collect(reinterpret(Float64, collect(displacement))))
+    d0buf = displacement ≡ nothing ? Float64[] : collect(reinterpret(Float64, collect(displacement)))   # rooted below
     out = Vector{Point2f}(undef, n); st = Vector{UInt8}(undef, n)
-    GC.@preserve pts out st check(ccall((:slam_fb_track, LIB[]), Cint,
+    GC.@preserve pts d0buf out st check(ccall((:slam_fb_track, LIB[]), Cint,
         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Cint, Cint, Cdouble, Cdouble, Cdouble, Ptr{Float64}, Ptr{UInt8}),
-        ctx(), handle(previous_pyramid), handle(current_pyramid), pts, d0, n, pyramid_levels, window_size, iterations,
+        ctx(), handle(previous_pyramid), handle(current_pyramid), pts,
+        displacement ≡ nothing ? Ptr{Float64}(C_NULL) : pointer(d0buf), n, pyramid_levels, window_size, iterations,
         1e-4, 1e-2, Float64(max_distance), Ptr{Float64}(pointer(out)), st))
     out, BitVector(st .!= 0)
 end
