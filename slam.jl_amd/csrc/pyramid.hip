@@ -167,9 +167,10 @@ struct RowIO {
 template <int COL_NB> struct ColIO {
     const double *src; double *dst;     // plane bases
     int H, W, P, x0;                    // rows, columns, column pitch, first column of this wave
+    int slo, shi;                       // columns this wave may store: [slo, shi] (whole image: 0, W - 1; the fused column kernel: its 62 own columns)
     double *lds;                        // 64 x COL_LS doubles
     __device__ __forceinline__ int xown() const { int x = x0 + (int)(threadIdx.x & 63); return x < W ? x : W - 1; }
-    __device__ __forceinline__ bool valid() const { return x0 + (int)(threadIdx.x & 63) < W; }
+    __device__ __forceinline__ bool valid() const { const int c = x0 + (int)(threadIdx.x & 63); return c >= slo && c <= shi; }
     __device__ __forceinline__ double ld_src(int i) const { return src[(size_t)i + (size_t)xown() * P]; }
     __device__ __forceinline__ double ld_dst(int i) const { return dst[(size_t)i + (size_t)xown() * P]; }
     __device__ __forceinline__ void st(int i, double v) const { if (valid()) dst[(size_t)i + (size_t)xown() * P] = v; }
@@ -199,7 +200,7 @@ template <int COL_NB> struct ColIO {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int col = x0 + 8 * r + cg;
-            if (col < W) {
+            if (col >= slo && col <= shi) {
                 double *q = dst + ((size_t)(x0 + 8 * r) * P + rb) + voff;
                 if (!partial) *(double2 *)q = make_double2(t[2 * r], t[2 * r + 1]);
                 else {
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_cols(PlaneSet ps, const do
     const int pl = blockIdx.y;
     ColIO<NB> io;
     io.dst = ps_plane(ps, pl); io.src = (pl == 0 && src0) ? src0 : io.dst;
-    io.H = H; io.W = W; io.P = P; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile;
+    io.H = H; io.W = W; io.P = P; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile; io.slo = 0; io.shi = W - 1;
     iir_line(io, H, ps_coef(ps, pl) == 0 ? cf.c[0] : cf.c[1], ps_fill0(ps, pl), nullptr, 0);
 }
 
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_cols_ck(PlaneSet ps, const
     const double *sqsrc = ps_sq(ps, pl);                       // squared input (Iy -> Iyy, Ix -> Ixx), or nullptr
     const bool sq = sqsrc != nullptr;
     io.dst = ps_plane(ps, pl); io.src = sq ? sqsrc : ((pl == 0 && src0) ? src0 : io.dst);
-    io.H = H; io.W = W; io.P = P; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile;
+    io.H = H; io.W = W; io.P = P; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile; io.slo = 0; io.shi = W - 1;
     const size_t nlines = (size_t)gridDim.z * gridDim.y * gridDim.x * LINE_THREADS;
     const size_t lineid = (((size_t)blockIdx.z * gridDim.y + pl) * gridDim.x + blockIdx.x) * LINE_THREADS + lane;
     const int n = H;
@@ -597,13 +598,285 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_cols_ck(PlaneSet ps, const
     }
 }
 
+// ---- the whole dim-1 stage of a level in ONE kernel (bandwidth-bound batches) -----------------------------------
+// k_scharr_products + k_iir_cols_ck read the layer 1.1 + 2 times, write Iy / Ix / Iy Ix, and read Iy, Ix, Iy Ix twice
+// each (16 plane passes per level).  Here a 256-thread workgroup owns a strip of 62 columns and its four waves run the
+// four dim-1 recurrences of the level -- wave 0: the sigma-1 blur of the layer, waves 1-3: the sigma-4 filter of Iy^2,
+// Ix^2, Iy Ix -- straight from the LAYER: every wave takes the layer tiles through its own LDS transpose (lanes =
+// columns x_l .. x_l + 63, x_l = first own column - 1: one halo column on each side), forms the Scharr terms of its
+// 16 / 32 rows in registers (vertical taps from the lane's own samples + one halo row above and below, horizontal taps
+// from the neighbour lanes: the arithmetic of k_scharr_products term by term), and feeds the products to the
+// checkpointed recurrence of k_iir_cols_ck.  Waves 1 and 2 also store Iy / Ix on the way.  The four waves sweep the
+// strip together (one barrier per block keeps them within a block of each other), so the layer is fetched from HBM once
+// per pass and served to the other three waves by the L2: 2 reads + 6 writes of a plane per level instead of 9 + 7.
+#define CF4_COLS 62
+struct ColsFusedArgs {
+    const double *L;                    // the level's layer (image 0 of the batch)
+    double *T;                          // dim-1 blurred layer (scratch plane), nullptr at the last level
+    double *Iy, *Ix, *Qyy, *Qxx, *Qyx;  // gradient planes; product planes (dim-1 filtered here, finished by the row pass)
+    int H, W, P; size_t zs;
+};
+
+// x[0..N) holds the lane's layer samples of rows rb .. rb+N-1 on entry, the recurrence inputs of its role on exit
+// (ROLE 1: Iy^2, 2: Ix^2, 3: Iy Ix); g receives Iy (ROLE 1) / Ix (ROLE 2).  top / bot: the layer at rows rb-1 / rb+N.
+template <int ROLE, int N>
+__device__ __forceinline__ void cf4_inputs(double *x, double top, double bot, int rb, int H, bool edgeL, bool edgeR, double *g)
+{
+    const double dk[3] = {-1.0 / 2, 0.0 / 2, 1.0 / 2}, sk[3] = {3.0 / 16, 10.0 / 16, 3.0 / 16};
+    double a = top;
+#pragma unroll
+    for (int e = 0; e < N; e++) {
+        const int row = rb + e;
+        const double b = x[e];
+        double c = e + 1 < N ? x[e + 1] : bot;
+        const double aa = row == 0 ? b : a;                       // replicate border (scharr_col, border 0)
+        c = row == H - 1 ? b : c;
+        double iy = 0.0, ix = 0.0;
+        if (ROLE == 1 || ROLE == 3) {
+            double d = 0.0; d += aa * dk[0]; d += b * dk[1]; d += c * dk[2];
+            double dl = __shfl_up(d, 1), dr = __shfl_down(d, 1);
+            dl = edgeL ? d : dl; dr = edgeR ? d : dr;
+            iy += dl * sk[0]; iy += d * sk[1]; iy += dr * sk[2];
+        }
+        if (ROLE == 2 || ROLE == 3) {
+            double s = 0.0; s += aa * sk[0]; s += b * sk[1]; s += c * sk[2];
+            double sl = __shfl_up(s, 1), sr = __shfl_down(s, 1);
+            sl = edgeL ? s : sl; sr = edgeR ? s : sr;
+            ix += sl * dk[0]; ix += s * dk[1]; ix += sr * dk[2];
+        }
+        double prod;
+        if (ROLE == 1) { prod = iy * iy; g[e] = iy; }
+        else if (ROLE == 2) { prod = ix * ix; g[e] = ix; }
+        else prod = iy * ix;
+        asm volatile("" : "+v"(prod));          // materialise the row's input HERE: otherwise the arithmetic behind the shuffles sinks to
+        x[e] = prod;                            // its use in the recurrence and all 32 rows' shuffle results stay live (500 registers)
+        a = b;
+    }
+}
+
+// Shared LDS blocks of a workgroup, [column][row] with strides chosen so that a lane = column access of consecutive rows
+// (ds_*_b128) is conflict-free: LB = layer rows rb-2 .. rb+35 of the 64 columns (row rb at index 2), IYB / IXB = Iy / Ix
+// of rows rb .. rb+31, QB = output staging of wave 3.  After the inputs have been consumed LB / IYB / IXB are the output
+// staging of waves 0 / 1 / 2.
+#define CF4_LS 38
+#define CF4_GS 34
+#define CF4_LDS_DOUBLES (64 * CF4_LS + 3 * 64 * CF4_GS)
+
+// phase 2: wave w forms Iy, Ix of rows rb + 8w .. rb + 8w + 7 for the 64 columns (lane = column) from the shared layer block
+__device__ __forceinline__ void cf4_scharr8(const double *LB, double *IYB, double *IXB, int w, int rb, int H, bool edgeL, bool edgeR)
+{
+    const double dk[3] = {-1.0 / 2, 0.0 / 2, 1.0 / 2}, sk[3] = {3.0 / 16, 10.0 / 16, 3.0 / 16};
+    const int lane = threadIdx.x & 63;
+    double v[12];                                                 // layer rows rb + 8w - 2 .. rb + 8w + 9
+    const double *q = LB + lane * CF4_LS + 8 * w;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { const double2 t = *(const double2 *)(q + 2 * j); v[2 * j] = t.x; v[2 * j + 1] = t.y; }
+    double iy8[8], ix8[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int row = rb + 8 * w + e;
+        const double b = v[2 + e];
+        const double a = row == 0 ? b : v[1 + e];                 // replicate border (scharr_col, border 0)
+        const double c = row == H - 1 ? b : v[3 + e];
+        double d = 0.0; d += a * dk[0]; d += b * dk[1]; d += c * dk[2];
+        double s = 0.0; s += a * sk[0]; s += b * sk[1]; s += c * sk[2];
+        double dl = __shfl_up(d, 1), dr = __shfl_down(d, 1), sl = __shfl_up(s, 1), sr = __shfl_down(s, 1);
+        dl = edgeL ? d : dl; dr = edgeR ? d : dr; sl = edgeL ? s : sl; sr = edgeR ? s : sr;
+        double iy = 0.0, ix = 0.0;
+        iy += dl * sk[0]; iy += d * sk[1]; iy += dr * sk[2];
+        ix += sl * dk[0]; ix += s * dk[1]; ix += sr * dk[2];
+        asm volatile("" : "+v"(iy), "+v"(ix));                    // finish the row here (keeps the shuffle results from piling up in registers)
+        iy8[e] = iy; ix8[e] = ix;
+    }
+    double *py = IYB + lane * CF4_GS + 8 * w, *px = IXB + lane * CF4_GS + 8 * w;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { *(double2 *)(py + 2 * j) = make_double2(iy8[2 * j], iy8[2 * j + 1]); *(double2 *)(px + 2 * j) = make_double2(ix8[2 * j], ix8[2 * j + 1]); }
+}
+
+template <int ROLE>
+__device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const IIRCoef &k, double *ck, double *LB, double *IYB, double *IXB, double *QB)
+{
+    const int lane = threadIdx.x & 63, rp = lane & 7, cg = lane >> 3;
+    const int H = A.H, W = A.W, P = A.P, n = H;
+    const int own0 = CF4_COLS * (int)blockIdx.x;
+    const int xl = own0 > 0 ? own0 - 1 : 0;                      // first column of the workgroup (lane 0)
+    const size_t z = (size_t)blockIdx.z * A.zs;
+    const bool active = ROLE != 0 || A.T != nullptr;              // last level: no blur, wave 0 only helps with the shared phases
+    const int nroles = A.T != nullptr ? 4 : 3;
+    double *stage = ROLE == 0 ? LB : ROLE == 1 ? IYB : ROLE == 2 ? IXB : QB;
+    ColIO<2> io;                                                  // global tile addressing (lanes <-> aligned 128-byte lines)
+    io.src = A.L + z;
+    io.dst = (ROLE == 0 ? A.T : ROLE == 1 ? A.Qyy : ROLE == 2 ? A.Qxx : A.Qyx) + z;
+    io.H = H; io.W = W; io.P = P; io.x0 = xl; io.lds = stage;
+    io.slo = own0; io.shi = own0 + CF4_COLS - 1 < W - 1 ? own0 + CF4_COLS - 1 : W - 1;
+    ColIO<2> iog = io;                                            // gradient plane written on the way (ROLE 1: Iy, ROLE 2: Ix)
+    iog.dst = (ROLE == 1 ? A.Iy : A.Ix) + z;
+    const int col = xl + lane;
+    const bool edgeL = col == 0, edgeR = col == W - 1;
+    const size_t nlines = (size_t)gridDim.z * nroles * gridDim.x * LINE_THREADS;
+    const size_t lineid = (((size_t)blockIdx.z * nroles + (ROLE - (4 - nroles))) * gridDim.x + blockIdx.x) * LINE_THREADS + lane;
+    const double a1 = k.a1, a2 = k.a2, a3 = k.a3, scale = k.scale;
+    const int w = ROLE;                                           // wave index inside the workgroup
+    // recurrence input of a single row (boundary rows of the filter): the same arithmetic on scalar loads
+    auto in_row = [&](int y) {
+        double v[1] = {io.ld_src(y)};
+        if (ROLE != 0) { double gdummy[1]; cf4_inputs<ROLE, 1>(v, io.ld_src(y > 0 ? y - 1 : 0), io.ld_src(y + 1 < H ? y + 1 : H - 1), y, H, edgeL, edgeR, gdummy); }
+        return v[0];
+    };
+    const double x0 = in_row(0);
+    const double iminus = x0, iplus = in_row(n - 1);
+    const double uminus = iminus / k.inv1masum;
+    const double o0 = ((x0 + a1 * uminus) + a2 * uminus) + a3 * uminus;
+    const double o1 = ((in_row(1) + a1 * o0) + a2 * uminus) + a3 * uminus;
+    const double o2 = ((in_row(2) + a1 * o1) + a2 * o0) + a3 * uminus;
+    double w3 = o0, w2 = o1, w1 = o2;
+    const int NBk = ((n - 1) >> 5) + 1;                           // 32-row blocks of the plane
+    const int ntile = P >> 4;
+    double pre[16], x[32], u[16];
+    // phase 1 operands of block b, requested a block ahead: wave 0 the block's first tile, wave 1 its second tile, wave 2 the
+    // layer row above the block, wave 3 the row below it
+    auto prefetch = [&](int b) {
+        const int rb = b << 5;
+        if (ROLE == 0) io.tile_load(io.src, rb, pre);
+        else if (ROLE == 1) {
+            if (2 * b + 1 < ntile) io.tile_load(io.src, rb + 16, pre);
+            else {
+#pragma unroll
+                for (int e = 0; e < 16; e++) pre[e] = 0.0;
+            }
+        }
+        else if (ROLE == 2) pre[0] = io.ld_src(rb > 0 ? rb - 1 : 0);
+        else pre[0] = io.ld_src(rb + 32 < H ? rb + 32 : H - 1);
+    };
+    auto publish = [&]() {                                        // phase 1: operands -> shared layer block
+        if (ROLE <= 1) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) *(double2 *)(LB + (8 * r + cg) * CF4_LS + 2 + 16 * ROLE + 2 * rp) = make_double2(pre[2 * r], pre[2 * r + 1]);
+        } else LB[lane * CF4_LS + (ROLE == 2 ? 1 : 34)] = pre[0];
+    };
+    auto read_inputs = [&]() {                                    // phase 3: the lane's 32 recurrence inputs
+        if (ROLE == 0) {
+            const double *q = LB + lane * CF4_LS + 2;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { const double2 t = *(const double2 *)(q + 2 * j); x[2 * j] = t.x; x[2 * j + 1] = t.y; }
+        } else if (ROLE == 1 || ROLE == 2) {
+            const double *q = (ROLE == 1 ? IYB : IXB) + lane * CF4_GS;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { const double2 t = *(const double2 *)(q + 2 * j); x[2 * j] = t.x * t.x; x[2 * j + 1] = t.y * t.y; }
+        } else {
+            const double *q = IYB + lane * CF4_GS, *r = IXB + lane * CF4_GS;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { const double2 t = *(const double2 *)(q + 2 * j), v = *(const double2 *)(r + 2 * j); x[2 * j] = t.x * v.x; x[2 * j + 1] = t.y * v.y; }
+        }
+    };
+    auto get_tile = [&](const double *blk, int t, double *uu) {   // rows 16 t .. 16 t + 15 of a [column][CF4_GS] block in global tile layout
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const double2 q = *(const double2 *)(blk + (8 * r + cg) * CF4_GS + 16 * t + 2 * rp); uu[2 * r] = q.x; uu[2 * r + 1] = q.y; }
+    };
+    // ---- pass A: forward over rows 3 .. n-1, read only; checkpoint before rows 32 b (b >= 1) ----
+    prefetch(0);
+    for (int b = 0; b < NBk; b++) {
+        const int rb = b << 5;
+        __syncthreads();                                          // the previous block's shared data has been consumed
+        publish();
+        __syncthreads();
+        if (b + 1 < NBk) prefetch(b + 1);
+        cf4_scharr8(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
+        __syncthreads();
+        if (!active) continue;
+        read_inputs();
+        if (b >= 1) { double *c = ck + ((size_t)b * 3) * nlines + lineid; c[0] = w1; c[nlines] = w2; c[2 * nlines] = w3; }
+        if (rb >= 3 && rb + 31 <= n - 1) {
+#pragma unroll
+            for (int e = 0; e < 32; e++) { const double tt = ((x[e] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 32; e++) { const int row = rb + e; if (row >= 3 && row <= n - 1) { const double tt = ((x[e] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; } }
+        }
+    }
+    // ---- Triggs-Sdika right boundary (as iir_line) ----
+    const double uplus = iplus / k.inv1masum, vplus = uplus / k.inv1mbsum;
+    const double d0 = w1 - uplus, d1 = w2 - uplus, d2 = w3 - uplus;
+    const double vr0 = ((k.M[0] * d0 + k.M[1] * d1) + k.M[2] * d2) + vplus;
+    const double vr1 = ((k.M[3] * d0 + k.M[4] * d1) + k.M[5] * d2) + vplus;
+    const double vr2 = ((k.M[6] * d0 + k.M[7] * d1) + k.M[8] * d2) + vplus;
+    const double vA = vr0;
+    const double vB = ((w2 + a1 * vA) + a2 * vr1) + a3 * vr2;
+    const double vC = ((w3 + a1 * vB) + a2 * vA) + a3 * vr1;
+    double v1 = vC, v2 = vB, v3 = vA;
+    io.fence();
+    // ---- pass B: blocks bottom to top.  Every block is visited (the gradient planes need all rows); rows [3, n-4] carry the
+    //      recurrence, n-3 .. n-1 and 2 .. 0 are direct ----
+    prefetch(NBk - 1);
+    if (active) { io.st(n - 1, vA * scale); io.st(n - 2, vB * scale); io.st(n - 3, vC * scale); }
+    for (int b = NBk - 1; b >= 0; b--) {
+        const int rb = b << 5, lo = rb > 3 ? rb : 3, hi = rb + 31 < n - 4 ? rb + 31 : n - 4;     // recurrence rows of the block (may be empty: lo > hi)
+        const bool two = 2 * b + 1 < ntile;
+        __syncthreads();
+        publish();
+        __syncthreads();
+        cf4_scharr8(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
+        __syncthreads();
+        if (active) read_inputs();
+        if (ROLE == 1 || ROLE == 2) {                             // Iy / Ix of the block -> their planes
+            const double *blk = ROLE == 1 ? IYB : IXB;
+            const int ghi = H - 1;
+            get_tile(blk, 0, u); iog.tile_store(rb, u, rb, ghi, rb + 15 > ghi);
+            if (two && rb + 16 <= ghi) { get_tile(blk, 1, u); iog.tile_store(rb + 16, u, rb + 16, ghi, rb + 31 > ghi); }
+        }
+        __syncthreads();                                          // inputs consumed: the shared blocks become output staging
+        if (b > 0) prefetch(b - 1);
+        if (!active || lo > hi) continue;                         // (a trailing block may hold rows n-3 .. n-1 only)
+        double f1, f2, f3;
+        if (b > 0) { const double *c = ck + ((size_t)b * 3) * nlines + lineid; f1 = c[0]; f2 = c[nlines]; f3 = c[2 * nlines]; }
+        else { f1 = o2; f2 = o1; f3 = o0; }
+        if (lo == rb && hi == rb + 31) {
+#pragma unroll
+            for (int e = 0; e < 32; e++) { const double tt = ((x[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = tt; x[e] = tt; }
+#pragma unroll
+            for (int e = 31; e >= 0; e--) { const double tt = ((x[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; x[e] = tt * scale; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 32; e++) { const int row = rb + e; if (row >= lo && row <= hi) { const double tt = ((x[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = tt; x[e] = tt; } }
+#pragma unroll
+            for (int e = 31; e >= 0; e--) { const int row = rb + e; if (row >= lo && row <= hi) { const double tt = ((x[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; x[e] = tt * scale; } }
+        }
+        {   // outputs -> own staging block (lane = column), back in tile layout, stored as aligned lines
+            double *q = stage + lane * CF4_GS;
+#pragma unroll
+            for (int j = 0; j < 16; j++) *(double2 *)(q + 2 * j) = make_double2(x[2 * j], x[2 * j + 1]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            get_tile(stage, 0, u);
+            io.tile_store(rb, u, lo, hi, !(lo <= rb && hi >= rb + 15));
+            if (two && hi >= rb + 16) { get_tile(stage, 1, u); io.tile_store(rb + 16, u, lo, hi, !(lo <= rb + 16 && hi >= rb + 31)); }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (active) {   // rows 2, 1, 0: forward values o2, o1, o0
+        double tt = ((o2 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(2, tt * scale);
+        tt = ((o1 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(1, tt * scale);
+        tt = ((o0 + a1 * v1) + a2 * v2) + a3 * v3; io.st(0, tt * scale);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_cols_fused(ColsFusedArgs A, IIRPair cf, double *ck)
+{
+    __shared__ __attribute__((aligned(16))) double sh[CF4_LDS_DOUBLES];
+    double *LB = sh, *IYB = sh + 64 * CF4_LS, *IXB = IYB + 64 * CF4_GS, *QB = IXB + 64 * CF4_GS;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (w == 0) cols_fused_wave<0>(A, cf.c[0], ck, LB, IYB, IXB, QB);
+    else if (w == 1) cols_fused_wave<1>(A, cf.c[1], ck, LB, IYB, IXB, QB);
+    else if (w == 2) cols_fused_wave<2>(A, cf.c[1], ck, LB, IYB, IXB, QB);
+    else cols_fused_wave<3>(A, cf.c[1], ck, LB, IYB, IXB, QB);
+}
+
 // integral_image!, lucas_kanade.jl:131-138: cumsum along dim 1 ...
 template <int NB>
 __global__ __launch_bounds__(LINE_THREADS) void k_cum_cols(PlaneSet ps, int H, int W, int P)
 {
     __shared__ __attribute__((aligned(16))) double tile[64 * COL_LS];
     const int pl = blockIdx.y;
-    ColIO<NB> io; io.dst = ps_plane(ps, pl); io.src = io.dst; io.H = H; io.W = W; io.P = P; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile;
+    ColIO<NB> io; io.dst = ps_plane(ps, pl); io.src = io.dst; io.H = H; io.W = W; io.P = P; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile; io.slo = 0; io.shi = W - 1;
     double acc = io.ld_src(0);
     io.template sweep<+1>(1, H - 1, false, [&](double x) { acc = acc + x; return acc; });
 }
@@ -1111,7 +1384,11 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         const bool ck_cols = !fast && p->ck != nullptr && mode != 0 && H >= 64 && (size_t)S * np_ * H * W * 8 >= ck_min_bytes() && getenv("SLAMHIP_NO_CK_COLS") == nullptr;
         static const bool no_sq = getenv("SLAMHIP_NO_SQ_FUSE") != nullptr;
         const bool fuse_sq = ck_cols && !no_sq;
-        hipLaunchKernelGGL(k_scharr_products, dim3((H + 63) / 64, (W + SCH_XC - 1) / SCH_XC, S), dim3(64), 0, st, v, border_mode, zs, fuse_sq ? 0 : 1);
+        // ... and the fully fused dim-1 stage (Scharr + products + the four dim-1 recurrences straight from the layer)
+        static const bool no_cols_fused = getenv("SLAMHIP_NO_COLS_FUSED") != nullptr;
+        const bool cols_fused = fuse_sq && !no_cols_fused;
+        if (!cols_fused)
+            hipLaunchKernelGGL(k_scharr_products, dim3((H + 63) / 64, (W + SCH_XC - 1) / SCH_XC, S), dim3(64), 0, st, v, border_mode, zs, fuse_sq ? 0 : 1);
         // dim-1 IIR: [blur: L -> T], Iyy, Ixx, Iyx in place
         PlaneSet ps = {};
         int np = 0;
@@ -1140,7 +1417,13 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             hipLaunchKernelGGL(k_cum_seg<false>, gr3, dim3(PAR_T), 0, aux, pc, H, W, P, slr);
             continue;
         }
-        if (ck_cols) hipLaunchKernelGGL(k_iir_cols_ck, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf, p->ck);
+        if (cols_fused) {
+            ColsFusedArgs ca;
+            ca.L = v.L; ca.T = has_next ? T : nullptr; ca.Iy = v.Iy; ca.Ix = v.Ix; ca.Qyy = v.Iyy; ca.Qxx = v.Ixx; ca.Qyx = v.Iyx;
+            ca.H = H; ca.W = W; ca.P = P; ca.zs = zs;
+            hipLaunchKernelGGL(k_cols_fused, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, st, ca, cf, p->ck);
+        }
+        else if (ck_cols) hipLaunchKernelGGL(k_iir_cols_ck, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf, p->ck);
         else if (S == 1) hipLaunchKernelGGL(k_iir_cols<3>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
         else hipLaunchKernelGGL(k_iir_cols<2>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
         // bandwidth-bound launches (many images x a large level) take the checkpointed row kernel (2R+1W instead of 2R+2W)
@@ -1252,7 +1535,7 @@ static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, 
     if (S > 1) {   // checkpoint scratch of k_iir_rows_ck: (blocks x 3) doubles per line of the widest launch (level 0, 4 planes)
         const size_t lines = (size_t)S * 4 * (((size_t)Hs[0] + LINE_THREADS - 1) / LINE_THREADS) * LINE_THREADS;
         const size_t nbk = ((size_t)Ws[0] + CK_B - 1) / CK_B;
-        const size_t lines_c = (size_t)S * 4 * (((size_t)Ws[0] + LINE_THREADS - 1) / LINE_THREADS) * LINE_THREADS;      // column pass: lines = columns
+        const size_t lines_c = (size_t)S * 4 * (((size_t)Ws[0] + CF4_COLS - 1) / CF4_COLS) * LINE_THREADS;      // column pass: lines = columns (62 own columns per wave in k_cols_fused)
         const size_t nbk_c = ((size_t)Hs[0] + 31) / 32 + 1;
         const size_t need = lines * nbk > lines_c * nbk_c ? lines * nbk : lines_c * nbk_c;
         if (hipMalloc((void **)&ckbuf, need * 3 * 8) != hipSuccess) { (void)hipGetLastError(); ckbuf = nullptr; }

@@ -75,7 +75,8 @@ def test_checkpointed_row_kernel_is_bit_exact(slam, monkeypatch):
     small batches: every plane must stay bit-identical to the single-image kernels (several block counts, incl.
     last blocks of 1 and of 32 samples, heights around the tile / block boundaries)."""
     import torch
-    for (H, W) in ((70, 71), (33, 102), (130, 64 + 6 + 1), (97, 80), (64, 66), (65, 64), (69, 75), (100, 70)):
+    for (H, W) in ((70, 71), (33, 102), (130, 64 + 6 + 1), (97, 80), (64, 66), (65, 64), (69, 75), (100, 70),
+                   (80, 62), (81, 63), (96, 124), (95, 125), (66, 187), (128, 61), (67, 8), (131, 250)):      # strip boundaries of the fused column kernel (62 own columns per workgroup)
         S = 2
         rng = np.random.default_rng(H * W)
         imgs = [np.asfortranarray(rng.random((H, W))) for _ in range(S)]
