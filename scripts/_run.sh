@@ -1,8 +1,7 @@
-python -m pytest tests/test_gpu_batch.py tests/test_gpu_pyramid.py -x -q 2>&1 | tail -15
-python scripts/prof_pyr_batch.py 32
-python scripts/prof_pyr_batch.py 16
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_fused -o fused -- python3 $R/scripts/prof_pyr_batch.py 32 10 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_f -o f -- python3 $R/scripts/pmc_probe_batch.py 32 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_w -o w -- python3 $R/scripts/pmc_probe_batch.py 32 > /dev/null 2>&1
 cd $R
-for f in $(find gpurun_out/prof_fused -name "*kernel_stats.csv"); do echo == $f; head -12 $f | cut -c1-200; done
+python scripts/pmc_batch_json.py gpurun_out/pmc_f gpurun_out/pmc_w 32 gpurun_out/r02a_pmc_pyramid_batch.json
+rm -rf gpurun_out/pmc_f gpurun_out/pmc_w

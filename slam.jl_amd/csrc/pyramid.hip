@@ -381,10 +381,51 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows(PlaneSet ps, int H, i
 // operations from the same state: bit-identical), runs the backward recurrence on them and stores once:
 // 2 reads + 1 write per sample for 1.5x the arithmetic, which a bandwidth-bound launch has to spare.
 #define CK_B 32
-__global__ __launch_bounds__(LINE_THREADS) void k_iir_rows_ck(PlaneSet ps, int H, int W, int P, IIRPair cf, double *ck)
+// Fused imresize! (even H only): plane 0 of a level with a successor is the blurred layer, whose only reader is k_resize.  With
+// `rz.dst` set, the backward sweep of plane 0 does not store its results: every lane interpolates its row horizontally as the
+// samples appear (right to left; the source column and weight of the current output column are wave-uniform), row pairs
+// (2k, 2k+1) -- lanes (2k, 2k+1) of one wave -- are averaged through a shuffle and the even lanes store the next level's
+// layer: the arithmetic of k_resize for an exact 2:1 row ratio, term by term.
+struct RowResize { double *dst; int Hd, Wd, Pd; };
+__device__ __forceinline__ double dpp_pair_next(double v)        // lanes 2k and 2k+1 both receive lane 2k+1's value (quad_perm [1,1,3,3])
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xF5, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xF5, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(LINE_THREADS) void k_iir_rows_ck(PlaneSet ps, int H, int W, int P, IIRPair cf, double *ck, RowResize rz)
 {
     const int y = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
     if (y >= H) return;
+    const bool resize = pl == 0 && rz.dst != nullptr;
+    // resize state: xo = current output column (1-based, descending), c0 = 0-based source column of its left sample, fx = weight
+    const double rsx = (double)W / (double)(rz.Wd > 0 ? rz.Wd : 1), rox = 1 - 0.5 - rsx * (1 - 0.5);
+    int xo = rz.Wd, c0 = -1; double fx = 0.0, tprev = 0.0;
+    double *rzp = resize ? rz.dst + (size_t)blockIdx.z * ps.zs + (y >> 1) : nullptr;
+    const bool exact2 = 2 * rz.Wd == W;                           // exact 2:1 columns: c = 2 xo - 0.5 -> ixx = 2 xo - 1, fx = 0.5 (what the general path computes, without the floor)
+    auto rz_target = [&]() {                                     // k_resize: c = sx * x + ox; ixx = floor(c) clamped to [1, Ws - 1]; fx = c - ixx
+        if (xo < 1) { c0 = -1; return; }
+        if (exact2) { c0 = 2 * xo - 2; fx = 0.5; return; }
+        const double c = rsx * xo + rox;
+        int ixx = (int)floor(c);
+        if (ixx > W - 1) ixx = W - 1;
+        if (ixx < 1) ixx = 1;
+        fx = c - ixx;
+        c0 = __builtin_amdgcn_readfirstlane(ixx - 1);
+    };
+    if (resize) rz_target();
+    auto emit = [&](int x, double val) {                         // called for x = W-1 .. 0 in descending order with the finished sample T[y, x]
+        if (x == c0) {
+            const double h = (1 - fx) * val + fx * tprev;        // r0 / r1 of k_resize for this lane's row
+            const double hn = dpp_pair_next(h);                   // h of row y + 1 (the odd lane of the pair), no LDS round trip
+            const double fy = 0.5;
+            const double o = (1 - fy) * h + fy * hn;
+            if ((y & 1) == 0) rzp[(size_t)(xo - 1) * rz.Pd] = o;
+            xo--; rz_target();
+        }
+        tprev = val;
+    };
     const size_t nlines = (size_t)gridDim.z * gridDim.y * gridDim.x * LINE_THREADS;
     const size_t lineid = ((size_t)blockIdx.z * gridDim.y + pl) * gridDim.x * LINE_THREADS + y;
     double *p = ps_plane(ps, pl) + y;
@@ -442,7 +483,8 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows_ck(PlaneSet ps, int H
     const double vC = ((w3 + a1 * vB) + a2 * vA) + a3 * vr1;
     double v1 = vC, v2 = vB, v3 = vA;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // own checkpoints visible
-    p[(long)(n - 1) * s] = vA * scale; p[(long)(n - 2) * s] = vB * scale; p[(long)(n - 3) * s] = vC * scale;
+    if (resize) { emit(n - 1, vA * scale); emit(n - 2, vB * scale); emit(n - 3, vC * scale); }
+    else { p[(long)(n - 1) * s] = vA * scale; p[(long)(n - 2) * s] = vB * scale; p[(long)(n - 3) * s] = vC * scale; }
     // ---- pass B: blocks right to left; block j covers i in [3 + j CK_B, 3 + min((j+1) CK_B, m)) ----
     double f1n = 0, f2n = 0, f3n = 0, f1 = 0, f2 = 0, f3 = 0;
     auto load_ck = [&](int j, double &g1, double &g2, double &g3) {
@@ -459,10 +501,12 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows_ck(PlaneSet ps, int H
             if (e < len) { const double t = ((cur[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = t; cur[e] = t; }
 #pragma unroll
         for (int e = CK_B - 1; e >= 0; e--)
-            if (e < len) { const double t = ((cur[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = t; cur[e] = t * scale; }
+            if (e < len) { const double t = ((cur[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = t; cur[e] = t * scale; if (resize) emit(a + e, cur[e]); }
         double *q = p + (long)a * s;
+        if (!resize) {
 #pragma unroll
-        for (int e = 0; e < CK_B; e++) if (e < len) q[(long)e * s] = cur[e];
+            for (int e = 0; e < CK_B; e++) if (e < len) q[(long)e * s] = cur[e];
+        }
 #pragma unroll
         for (int e = 0; e < CK_B; e++) cur[e] = nxt[e];
         f1 = f1n; f2 = f2n; f3 = f3n;
@@ -472,18 +516,20 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows_ck(PlaneSet ps, int H
 #pragma unroll
         for (int e = 0; e < CK_B; e++) { const double t = ((cur[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = t; cur[e] = t; }
 #pragma unroll
-        for (int e = CK_B - 1; e >= 0; e--) { const double t = ((cur[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = t; cur[e] = t * scale; }
+        for (int e = CK_B - 1; e >= 0; e--) { const double t = ((cur[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = t; cur[e] = t * scale; if (resize) emit(3 + j * CK_B + e, cur[e]); }
         double *q = p + (long)(3 + j * CK_B) * s;
+        if (!resize) {
 #pragma unroll
-        for (int e = 0; e < CK_B; e++) q[(long)e * s] = cur[e];
+            for (int e = 0; e < CK_B; e++) q[(long)e * s] = cur[e];
+        }
 #pragma unroll
         for (int e = 0; e < CK_B; e++) cur[e] = nxt[e];
         f1 = f1n; f2 = f2n; f3 = f3n;
     }
     {   // i = 2, 1, 0: forward values o2, o1, o0
-        double t = ((o2 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = t; p[2 * s] = t * scale;
-        t = ((o1 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = t; p[s] = t * scale;
-        t = ((o0 + a1 * v1) + a2 * v2) + a3 * v3; p[0] = t * scale;
+        double t = ((o2 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = t; if (resize) emit(2, t * scale); else p[2 * s] = t * scale;
+        t = ((o1 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = t; if (resize) emit(1, t * scale); else p[s] = t * scale;
+        t = ((o0 + a1 * v1) + a2 * v2) + a3 * v3; if (resize) emit(0, t * scale); else p[0] = t * scale;
     }
 }
 
@@ -1428,13 +1474,18 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         else hipLaunchKernelGGL(k_iir_cols<2>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
         // bandwidth-bound launches (many images x a large level) take the checkpointed row kernel (2R+1W instead of 2R+2W)
         const bool ck_rows = p->ck != nullptr && mode != 0 && W >= 64 && (size_t)S * np * H * W * 8 >= ck_min_bytes();
+        // ... with the imresize! into the next level fused into the blurred layer's backward sweep when the row ratio is exactly 2:1
+        static const bool no_rows_resize = getenv("SLAMHIP_NO_ROWS_RESIZE") != nullptr;
+        const bool rows_resize = ck_rows && has_next && (H & 1) == 0 && !no_rows_resize;
+        RowResize rz = {};
+        if (rows_resize) { rz.dst = p->view.lv[l + 1].L; rz.Hd = p->H[l + 1]; rz.Wd = p->W[l + 1]; rz.Pd = p->P[l + 1]; }
         if (spans) { ProfScope span(ctx, "k_iir_rows");
-            if (ck_rows) hipLaunchKernelGGL(k_iir_rows_ck, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf, p->ck);
+            if (ck_rows) hipLaunchKernelGGL(k_iir_rows_ck, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf, p->ck, rz);
             else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf); }
-        else if (ck_rows) hipLaunchKernelGGL(k_iir_rows_ck, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf, p->ck);
+        else if (ck_rows) hipLaunchKernelGGL(k_iir_rows_ck, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf, p->ck, rz);
         else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf);
         if (forked) { (void)hipEventRecord(p->ev_fork[l], st); (void)hipStreamWaitEvent(aux, p->ev_fork[l], 0); }
-        if (has_next)
+        if (has_next && !rows_resize)
             hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, st,
                                p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
         static const bool no_fused_cum = getenv("SLAMHIP_NO_FUSED_CUM") != nullptr;
