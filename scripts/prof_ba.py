@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

@@ -71,6 +71,8 @@ struct slam_ba {
     int *chol_flag = nullptr;    // device flag: a pivot was not positive
     double *linv = nullptr;      // inverses of the factored diagonal tiles, nbc x 32 x 32
     double *lfac = nullptr;      // finished factor tiles + forward-substituted rhs row, (n+1) x n
+    int hb = 0;                  // block half-bandwidth of the reduced system: S_pq = 0 for |p - q| > hb
+    double *band = nullptr;      // factor store of k_band_solve, P x ((hb + 1) x 36 + 8)
     std::vector<int> perm;       // sorted position -> original observation index
     int nblocks_obs = 0, nblocks_pts = 0;
 };
@@ -257,7 +259,13 @@ __global__ __launch_bounds__(256) void k_blocks(BADev d, int use_state)
 {
     __shared__ double s_red[4][48];
     if (use_state && d.st->converged) return;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, M = d.M, n = d.n;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The blocks are sorted by (p, q) and the blocks of
+    // one pose row p read the same T records (and neighbouring rows the same W records): give every XCD one contiguous
+    // eighth of the block list, so that those re-reads are L2 hits instead of 8 separate fetches of the T / W arrays.
+    const int per = (d.nblk + 7) / 8;
+    const int b = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+    if (b >= d.nblk) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, M = d.M, n = d.n;
     const int2 pq = d.blk_pq[b];
     const int e0 = d.blk_start[b], e1 = d.blk_start[b + 1];
     double acc[36], gg[6], ud[6];
@@ -602,6 +610,433 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(BADev d, CholArgs C, con
     if (tid == 0 && *C.fail) d.st->chol_fail = 1;
 }
 
+// ---- banded solve of the reduced camera system in ONE launch --------------------------------------------------------
+// A windowed problem couples pose p only with poses p - hb .. p + hb (a map point is seen by a run of consecutive
+// key-frames: hb = 9 for the 10-observer scenes): S is block-banded, and the factorisation of block column k only touches
+// the (hb+1) x (hb+1) window of 6x6 blocks below / right of it.  One 256-thread workgroup keeps that window in LDS as a
+// ring (block (i, j) in slot [i mod (hb+1)][j mod (hb+1)]), walks the block columns left to right and replaces the
+// launch chain k_chol_prepare / k_chol_first / k_chol_step x nbc / k_chol_backsolve:
+//   P1  every thread factors the 6x6 diagonal block D_k = L L' and inverts L in registers (redundantly: no hand-off),
+//       then thread (i, r) forms row r of L_ik = A_ik L^-T for the <= hb blocks below it; the right-hand side rides along
+//       as one more row (forward substitution for free); the panel goes to LDS and to the global factor store;
+//   P2  trailing update A_ij -= L_ik L_jk' of the window (<= hb (hb+1) / 2 block pairs), the block row k + hb + 1
+//       (requested from S one step earlier, damping added on the way) enters the slot row k just vacated.
+// Back-substitution L' dp = y then walks the block columns right to left with the stored L_ik and L_kk^-1.
+// Systems whose half-bandwidth exceeds BS_MAXHB blocks (dense windows of > 21 poses) keep the tiled path.
+#define BS_MAXHB 20
+struct BandArgs { const double *S, *g, *ud; double *Lg; int nb, hb; double inv_delta_host; int *fail; long long *trace; };
+#define BS_PF 6      // prefetch registers per prefetch thread: ceil(((BS_MAXHB + 1) * 36 + 6) / BS_PT)
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the outstanding global loads / stores (the
+// prefetch of the next block row, the factor store), which put a full memory round trip into every step
+__device__ __forceinline__ void bs_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#define BS_T 512      /* waves 0-4: panel / trailing update, wave 5: factors the next diagonal block one step ahead, waves 6-7: ring prefetch (8 waves = 2 per SIMD: 256 registers each, no spills) */
+#define BS_PT 128     /* threads of the prefetch waves */
+#define BS_UT 320     /* threads of the update waves */
+__global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int use_state)
+{
+    if (use_state && d.st->converged) return;
+    extern __shared__ __attribute__((aligned(16))) double bs_sm[];
+    __shared__ int s_bad;
+    const int hb = B.hb, hb1 = hb + 1, nb = B.nb, n = d.n, tid = threadIdx.x;
+    double *Wn = bs_sm;                                  // [hb1][hb1][36] window ring, blocks row-major 6x6
+    double *rhs = Wn + (size_t)hb1 * hb1 * 36;           // [hb1][6]
+    double *Lp = rhs + hb1 * 6;                          // [hb1][36]: Lp[0] = L_kk^-1, Lp[di] = L_{k+di,k}
+    double *yk = Lp + hb1 * 36;                          // [8]
+    double *part = yk + 8;                               // [hb1][6] partial sums of the back-substitution
+    double *x = part + hb1 * 6;                          // [n]: y, then dp
+    double *damp = x + n;                                // [n]: LM damping of the diagonal (k_chol_prepare)
+    double *LiS = damp + n;                              // [2][36]: L_kk^-1 of the current / next block column (from the factor wave)
+    double *Dn = LiS + 72;                               // [36]: the next diagonal block, updated
+    unsigned char *ptab = (unsigned char *)(Dn + 36);    // [hb (hb+1) / 2][2] pair table (di, dj), dj <= di, ordered by di
+    const double inv_delta = use_state ? 1.0 / d.st->delta : B.inv_delta_host;
+    const size_t lgs = (size_t)hb1 * 36 + 8;             // doubles per block column in the global factor store
+    if (tid == 0) {
+        s_bad = 0;
+        int q = 0;
+        for (int di = 1; di <= hb; di++) for (int dj = 1; dj <= di; dj++) { ptab[2 * q] = (unsigned char)di; ptab[2 * q + 1] = (unsigned char)dj; q++; }
+    }
+    // element e of block row i: blocks (i, i - jj), jj = 0 .. min(i, hb), then the 6 right-hand-side entries
+    auto row_count = [&](int i) { return ((i < hb ? i : hb) + 1) * 36 + 6; };
+    // e = r * (6 nj) + t: row r of the block row, t = 6 (j - j0) + c its column inside the band; S is symmetric and k_blocks
+    // writes both halves, so the entry is read as S[6 j + c, 6 i + r]: consecutive e are consecutive addresses
+    auto fetch1 = [&](int i, int e) -> double {
+        const int nj = (i < hb ? i : hb) + 1, nbk = nj * 36, j0 = i - (nj - 1);
+        if (e >= nbk) return B.g[6 * i + (e - nbk)];
+        const int r = e / (6 * nj), t = e - r * 6 * nj;
+        return B.S[(size_t)(6 * j0 + t) + (size_t)(6 * i + r) * n];
+    };
+    auto put1 = [&](int i, int e, double v) {
+        const int nj = (i < hb ? i : hb) + 1, nbk = nj * 36, j0 = i - (nj - 1);
+        const int ri = i % hb1;
+        if (e >= nbk) { rhs[ri * 6 + (e - nbk)] = v; return; }
+        const int r = e / (6 * nj), t = e - r * 6 * nj, jb = t / 6, c = t - 6 * jb;
+        if (jb == nj - 1 && r == c) v += damp[6 * i + r];      // the diagonal block's diagonal
+        Wn[((size_t)ri * hb1 + ((j0 + jb) % hb1)) * 36 + r * 6 + c] = v;
+    };
+    for (int a = tid; a < n; a += BS_T) damp[a] = fmin(fmax(B.ud[a], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+    __syncthreads();
+    // initial window: block rows 0 .. min(hb, nb - 1)
+    for (int i = 0; i <= hb && i < nb; i++) {
+        const int cnt = row_count(i);
+        for (int e = tid; e < cnt; e += BS_T) put1(i, e, fetch1(i, e));
+    }
+    // Rows i > hb all have hb + 1 blocks: the element -> (row r, band column t, block jb, column c) maps of this thread's
+    // elements are computed once (run-time integer divisions cost ~50 instructions each), per row only the ring slot moves.
+    double pf[BS_PF];
+    int el_r[BS_PF], el_t[BS_PF], el_w[BS_PF];               // el_w: jb * 36 + r * 6 + c, or -(1 + c) for a right-hand-side entry, INT_MIN: none
+    {
+        const int cnt = hb1 * 36 + 6;
+#pragma unroll
+        for (int q = 0; q < BS_PF; q++) {
+            const int e = tid >= BS_UT + 64 ? (tid - BS_UT - 64) + BS_PT * q : 1 << 30;
+            el_r[q] = 0; el_t[q] = 0; el_w[q] = -1000;
+            if (e < hb1 * 36) { const int r = e / (6 * hb1), t = e - r * 6 * hb1, jb = t / 6, c = t - 6 * jb; el_r[q] = r; el_t[q] = t; el_w[q] = jb * 64 + r * 6 + c; }
+            else if (e < cnt) el_w[q] = -(1 + (e - hb1 * 36));
+        }
+    }
+    auto fetch_row = [&](int i) {                             // i > hb
+        const double *Srow = B.S + (size_t)6 * (i - hb) + (size_t)(6 * i) * n;
+#pragma unroll
+        for (int q = 0; q < BS_PF; q++) {
+            pf[q] = 0.0;
+            if (el_w[q] >= 0) pf[q] = Srow[(size_t)el_t[q] + (size_t)el_r[q] * n];
+            else if (el_w[q] > -1000) pf[q] = B.g[6 * i - 1 - el_w[q]];
+        }
+    };
+    auto put_row = [&](int i, int ri) {                       // i > hb, ri = i mod (hb + 1)
+#pragma unroll
+        for (int q = 0; q < BS_PF; q++) {
+            if (el_w[q] >= 0) {
+                const int jb = el_w[q] >> 6, rc = el_w[q] & 63;
+                int sl = ri + 1 + jb; if (sl >= hb1) sl -= hb1;            // (i - hb + jb) mod (hb + 1)
+                double v = pf[q];
+                if (jb == hb && el_r[q] * 7 == rc) v += damp[6 * i + el_r[q]];
+                Wn[((size_t)ri * hb1 + sl) * 36 + rc] = v;
+            } else if (el_w[q] > -1000) rhs[ri * 6 - 1 - el_w[q]] = pf[q];
+        }
+    };
+    if (hb + 1 < nb) fetch_row(hb + 1);
+    {   // Pull the rest of the band into this XCD's L2 now.  k_blocks wrote S from all eight XCDs, so the first touch of a line
+        // is an HBM round trip (~2.5 us, longer than a factorisation step): with the lines resident, the one-step-ahead request
+        // of the prefetch wave is an L2 hit.
+        double acc = 0.0;
+        const int per_row = 6 * 6 * hb1;
+        for (int e = tid; e < (nb - hb - 2) * per_row; e += BS_T) {
+            const int i = hb + 2 + e / per_row, q = e - (e / per_row) * per_row, r = q / (6 * hb1), t = q - r * 6 * hb1;
+            acc += B.S[(size_t)(6 * (i - hb) + t) + (size_t)(6 * i + r) * n];
+        }
+        if (acc == 1.2345e-300) d.dp[0] = acc;                 // keeps the loads alive; never true in practice and harmless if it were (dp is rewritten below)
+    }
+    __syncthreads();
+    bool bad = false;
+    long long tr0 = B.trace ? clock64() : 0, trP1 = 0, trP2 = 0, trT = tr0, trA = 0, trB = 0, trC = 0, trD = 0;
+#define BS_TR(acc) if (B.trace) { const long long t_ = clock64(); acc += t_ - trT; trT = t_; }
+    const bool fwave = tid >= BS_UT && tid < BS_UT + 64;         // the factor wave
+    const bool pwave = tid >= BS_UT + 64;                        // the prefetch wave
+    const int flane = tid - BS_UT;
+    // Factor wave.  Every lane holds L_kk^-1 (Li) of the block column being eliminated.  Step k, before the first barrier:
+    // lane (r, c) forms rows r and c of L_{k+1,k} = A_{k+1,k} L_kk^-T itself and its entry of D_{k+1} = A_{k+1,k+1} - L L';
+    // between the barriers (while the update waves work on the window) it factors D_{k+1} and publishes L_{k+1,k+1}^-1 in the
+    // other LiS slot.  The critical path of a step never leaves this wave's registers.
+    double Li[6][6];
+    auto factor = [&](const double *D, double *LiOut) {
+        double L[6][6], rd[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double sd = D[j * 6 + j];
+#pragma unroll
+            for (int m = 0; m < j; m++) sd -= L[j][m] * L[j][m];
+            bad = bad || !(sd > 0);
+            sd = sd > 0 ? sd : 1.0;
+            rd[j] = rsqrt(sd);
+            L[j][j] = sd * rd[j];
+#pragma unroll
+            for (int i = j + 1; i < 6; i++) {
+                double a = D[i * 6 + j];
+#pragma unroll
+                for (int m = 0; m < j; m++) a -= L[i][m] * L[j][m];
+                L[i][j] = a * rd[j];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) {                        // column c of L^-1 by forward substitution
+            Li[c][c] = rd[c];
+#pragma unroll
+            for (int i = c + 1; i < 6; i++) {
+                double a = 0.0;
+#pragma unroll
+                for (int m = c; m < i; m++) a += L[i][m] * Li[m][c];
+                Li[i][c] = -a * rd[i];
+            }
+        }
+        if (flane == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) LiOut[i * 6 + c] = c <= i ? Li[i][c] : 0.0;
+        }
+    };
+    if (fwave) factor(Wn, LiS);                                  // D_0 = block (0, 0), ring slot [0][0]
+    bs_barrier();
+    for (int k = 0; k < nb; k++) {
+        const int kk = k % hb1, np = nb - 1 - k < hb ? nb - 1 - k : hb;      // blocks below the diagonal in this column
+        const double *LiK = LiS + 36 * (k & 1);                 // L_kk^-1 (the factor wave writes the other slot during this step)
+        // ---- P1: the panel rows L_ik = A_ik L_kk^-T and the right-hand side ----
+        double *Lgk = B.Lg + (size_t)k * lgs;
+        if (tid < np * 6 + 1) {
+            const bool is_rhs = tid == np * 6;
+            const int di = tid / 6 + 1, r = tid - 6 * (di - 1);
+            int ri = kk + di; if (ri >= hb1) ri -= hb1;
+            const double *Arow = is_rhs ? rhs + kk * 6 : Wn + ((size_t)ri * hb1 + kk) * 36 + r * 6;
+            double a[6], o[6], li[21];
+#pragma unroll
+            for (int m = 0; m < 6; m++) a[m] = Arow[m];
+            {
+                int q = 0;
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+#pragma unroll
+                    for (int m = 0; m <= c; m++) li[q++] = LiK[c * 6 + m];
+            }
+            {
+                int q = 0;
+#pragma unroll
+                for (int c = 0; c < 6; c++) {                    // X = A L^-T: X[r][c] = sum_{m <= c} A[r][m] Linv[c][m]
+                    double t = 0.0;
+#pragma unroll
+                    for (int m = 0; m <= c; m++) t += a[m] * li[q++];
+                    o[c] = t;
+                }
+            }
+            if (is_rhs) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) { yk[c] = o[c]; x[6 * k + c] = o[c]; }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; c++) { Lp[di * 36 + r * 6 + c] = o[c]; Lgk[di * 36 + r * 6 + c] = o[c]; }
+            }
+        } else if (tid >= 128 && tid < 164) Lgk[tid - 128] = LiK[tid - 128];
+        else if (fwave && k + 1 < nb) {
+            int r1 = kk + 1; if (r1 >= hb1) r1 -= hb1;
+            if (flane < 36) {
+                const int r = flane / 6, c = flane - 6 * r;
+                const double *Ar = Wn + ((size_t)r1 * hb1 + kk) * 36 + r * 6, *Ac = Wn + ((size_t)r1 * hb1 + kk) * 36 + c * 6;
+                double ar[6], ac[6], xr[6], xc[6];
+#pragma unroll
+                for (int m = 0; m < 6; m++) { ar[m] = Ar[m]; ac[m] = Ac[m]; }
+                const double dv = Wn[((size_t)r1 * hb1 + r1) * 36 + flane];
+#pragma unroll
+                for (int q = 0; q < 6; q++) {                    // rows r and c of L_{k+1,k} (the same sums the panel threads form)
+                    double tr = 0.0, tc = 0.0;
+#pragma unroll
+                    for (int m = 0; m <= q; m++) { tr += ar[m] * Li[q][m]; tc += ac[m] * Li[q][m]; }
+                    xr[q] = tr; xc[q] = tc;
+                }
+                double t = 0.0;
+#pragma unroll
+                for (int m = 0; m < 6; m++) t += xr[m] * xc[m];
+                Dn[flane] = dv - t;
+            }
+        }
+        BS_TR(trB)
+        bs_barrier();
+        if (B.trace) { const long long t = clock64(); trP1 += t - trT; trT = t; }
+        // ---- P2: trailing update of the window (update waves); the next block row enters (prefetch wave); D_{k+1} is factored ----
+        if (tid < BS_UT) {
+            const int npair = np * (np + 1) / 2, nwork = npair * 6 + np;
+            for (int wk = tid + 6; wk < nwork; wk += BS_UT) {    // work items 0 .. 5 = pair (1, 1) = the next diagonal block: the factor wave's
+                if (wk < npair * 6) {
+                    const int pr = wk / 6, r = wk - 6 * pr;
+                    const int di = ptab[2 * pr], dj = ptab[2 * pr + 1];
+                    int ri = kk + di; if (ri >= hb1) ri -= hb1;
+                    int rj = kk + dj; if (rj >= hb1) rj -= hb1;
+                    double a[6], lj[36], wb[6];                   // all operands into registers first: one LDS wait per work item
+#pragma unroll
+                    for (int m = 0; m < 6; m++) a[m] = Lp[di * 36 + r * 6 + m];
+                    double *Wb = Wn + ((size_t)ri * hb1 + rj) * 36 + r * 6;
+                    const double *Lj = Lp + dj * 36;
+#pragma unroll
+                    for (int q = 0; q < 36; q++) lj[q] = Lj[q];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) wb[c] = Wb[c];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int m = 0; m < 6; m++) t += a[m] * lj[c * 6 + m];
+                        wb[c] -= t;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 6; c++) Wb[c] = wb[c];
+                } else {
+                    const int dj = wk - npair * 6 + 1;
+                    int rj = kk + dj; if (rj >= hb1) rj -= hb1;
+                    const double *Lj = Lp + dj * 36;
+                    double a[6], lj[36], wb[6];
+#pragma unroll
+                    for (int m = 0; m < 6; m++) a[m] = yk[m];
+#pragma unroll
+                    for (int q = 0; q < 36; q++) lj[q] = Lj[q];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) wb[c] = rhs[rj * 6 + c];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int m = 0; m < 6; m++) t += a[m] * lj[c * 6 + m];
+                        wb[c] -= t;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 6; c++) rhs[rj * 6 + c] = wb[c];
+                }
+            }
+            BS_TR(trC)
+        } else if (pwave) {
+            const long long t0_ = B.trace ? clock64() : 0;
+            if (k + 1 + hb < nb) put_row(k + 1 + hb, kk);    // into the ring row that block row k vacated: (k + 1 + hb) mod (hb + 1) = k mod (hb + 1)
+            if (k + 2 + hb < nb) fetch_row(k + 2 + hb);
+            if (B.trace) trA += clock64() - t0_;
+        } else if (k + 1 < nb) {
+            const long long t0_ = B.trace ? clock64() : 0;
+            factor(Dn, LiS + 36 * ((k + 1) & 1));
+            if (B.trace) trA += clock64() - t0_;
+        }
+        BS_TR(trD)
+        bs_barrier();
+        if (B.trace) { const long long t = clock64(); trP2 += t - trT; trT = t; }
+    }
+    if (bad) s_bad = 1;
+    __threadfence();                                         // the factor store is re-read below by other threads
+    __syncthreads();
+    // ---- back-substitution L' dp = y, block columns right to left ----
+    // step k: (A) thread (di, c): sum_r L_{k+di,k}[r][c] x_{k+di}[r]; (B) thread c: t_c = y_k[c] - the partial sums, in fixed order;
+    // (C) thread c: x_k[c] = sum_{m >= c} L_kk^-1[m][c] t_m.  The factor blocks of step k - 1 are requested while step k computes.
+    double lreg[6], lic[6];
+    auto fetch_back = [&](int k) {
+        const int np = nb - 1 - k < hb ? nb - 1 - k : hb;
+        const double *Lgk = B.Lg + (size_t)k * lgs;
+        if (tid < np * 6) {
+            const int di = tid / 6 + 1, c = tid - 6 * (di - 1);
+#pragma unroll
+            for (int r = 0; r < 6; r++) lreg[r] = Lgk[di * 36 + r * 6 + c];
+        }
+        if (tid >= BS_T - 6) {
+            const int c = tid - (BS_T - 6);
+#pragma unroll
+            for (int m = 0; m < 6; m++) lic[m] = Lgk[m * 6 + c];          // column c of L_kk^-1 (zero above the diagonal)
+        }
+    };
+    double *tv = yk;                                         // [6] t of the current step
+    if (hb * 6 <= 58) {
+        // narrow bands: one wave runs the whole back-substitution (lanes 0 .. 6 np - 1 = (di, c), lanes 58 .. 63 = the six columns
+        // of L_kk^-1); its LDS traffic is ordered by program order, so the three phases need no workgroup barrier
+        if (tid < 64) {
+            const int lane = tid;
+            auto fetch_back1 = [&](int k, double (&lr)[6], double (&lc)[6]) {
+                if (k < 0) return;
+                const int np = nb - 1 - k < hb ? nb - 1 - k : hb;
+                const double *Lgk = B.Lg + (size_t)k * lgs;
+                if (lane < np * 6) {
+                    const int di = lane / 6 + 1, c = lane - 6 * (di - 1);
+#pragma unroll
+                    for (int r = 0; r < 6; r++) lr[r] = Lgk[di * 36 + r * 6 + c];
+                }
+                if (lane >= 58) {
+                    const int c = lane - 58;
+#pragma unroll
+                    for (int m = 0; m < 6; m++) lc[m] = Lgk[m * 6 + c];
+                }
+            };
+            auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+            // the factor blocks of a step are requested three steps ahead (a step is shorter than an L2 round trip)
+            double lrA[6], lrB[6], lrC[6], lcA[6], lcB[6], lcC[6];
+            auto step = [&](int k, double (&lr)[6], double (&lc)[6]) {
+                if (k < 0) return;
+                const int np = nb - 1 - k < hb ? nb - 1 - k : hb;
+                if (lane < np * 6) {
+                    const int di = lane / 6 + 1;
+                    double t = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 6; r++) t += lr[r] * x[6 * (k + di) + r];
+                    part[lane] = t;
+                }
+                double li[6];
+#pragma unroll
+                for (int m = 0; m < 6; m++) li[m] = lc[m];
+                fetch_back1(k - 3, lr, lc);
+                wave_sync();
+                if (lane >= 58) {
+                    const int c = lane - 58;
+                    double a = x[6 * k + c], pv[9];
+#pragma unroll
+                    for (int di = 0; di < 9; di++) pv[di] = di < np ? part[di * 6 + c] : 0.0;
+#pragma unroll
+                    for (int di = 0; di < 9; di++) if (di < np) a -= pv[di];
+                    tv[c] = a;
+                }
+                wave_sync();
+                if (lane >= 58) {
+                    const int c = lane - 58;
+                    double a = 0.0;
+#pragma unroll
+                    for (int m = 0; m < 6; m++) a += (m >= c ? li[m] : 0.0) * tv[m];
+                    x[6 * k + c] = a;
+                }
+                wave_sync();
+            };
+            fetch_back1(nb - 1, lrA, lcA); fetch_back1(nb - 2, lrB, lcB); fetch_back1(nb - 3, lrC, lcC);
+            for (int k = nb - 1; k >= 0; k -= 3) { step(k, lrA, lcA); step(k - 1, lrB, lcB); step(k - 2, lrC, lcC); }
+        }
+        bs_barrier();
+    } else {
+    if (nb > 0) fetch_back(nb - 1);
+    for (int k = nb - 1; k >= 0; k--) {
+        const int np = nb - 1 - k < hb ? nb - 1 - k : hb;
+        if (tid < np * 6) {
+            const int di = tid / 6 + 1;
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) t += lreg[r] * x[6 * (k + di) + r];
+            part[tid] = t;                                   // [(di - 1) * 6 + c]
+        }
+        double li[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) li[m] = lic[m];
+        if (k > 0) fetch_back(k - 1);
+        bs_barrier();
+        if (tid >= BS_T - 6) {
+            const int c = tid - (BS_T - 6);
+            double a = x[6 * k + c], pv[BS_MAXHB];
+#pragma unroll
+            for (int di = 0; di < BS_MAXHB; di++) pv[di] = di < np ? part[di * 6 + c] : 0.0;    // all reads in flight, then the ordered sum
+#pragma unroll
+            for (int di = 0; di < BS_MAXHB; di++) if (di < np) a -= pv[di];
+            tv[c] = a;
+        }
+        bs_barrier();
+        if (tid >= BS_T - 6) {
+            const int c = tid - (BS_T - 6);
+            double a = 0.0;
+#pragma unroll
+            for (int m = 0; m < 6; m++) a += (m >= c ? li[m] : 0.0) * tv[m];
+            x[6 * k + c] = a;
+        }
+        bs_barrier();
+    }
+    }
+    for (int a = tid; a < n; a += BS_T) d.dp[a] = x[a];
+    if (tid == 0) { *B.fail = s_bad; if (s_bad) d.st->chol_fail = 1; }
+    if (B.trace && tid == BS_UT) B.trace[8] = trA;
+    if (B.trace && tid == BS_UT + 64) B.trace[9] = trA;
+    if (B.trace && tid == 0) { B.trace[0] = tr0; B.trace[1] = trP1; B.trace[2] = trP2; B.trace[3] = clock64() - trT; B.trace[4] = trA; B.trace[5] = trB; B.trace[6] = trC; B.trace[7] = trD; }
+}
+
 __global__ __launch_bounds__(256) void k_backsub(BADev d, int use_state)
 {
     __shared__ double sh[4];
@@ -839,6 +1274,9 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
         }
     blk_start.push_back((int)npairs);
     const int nblk = (int)blk_pq.size();
+    int hb = 0;
+    for (const int2 &pq : blk_pq) hb = std::max(hb, pq.y - pq.x);
+    ba->hb = hb;
 
     const int nbo = (O + 255) / 256, nbp = (std::max(M, n) + 255) / 256;
     ba->nblocks_obs = std::max(nbo, 1); ba->nblocks_pts = std::max(nbp, 1);
@@ -856,6 +1294,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     const size_t o_red = take(((size_t)n * n + 2 * n + 8) * 8), o_Sw = take((size_t)(n + 1) * n * 8), o_dp = take(n * 8), o_dl = take((size_t)3 * M * 8 + 8);
     const size_t o_cf = take(64), o_li = take((size_t)((n + CT - 1) / CT) * CT * CT * 8), o_lf = take((size_t)(n + 1) * n * 8);
     const size_t o_part = take(((size_t)ba->nblocks_pts + 2 * ba->nblocks_obs + 8) * 8), o_st = take(sizeof(LMState));
+    const size_t o_band = take((size_t)P * ((size_t)(BS_MAXHB + 1) * 36 + 8) * 8);
     char *A;
     hipError_t e = hipMalloc((void **)&A, off);
     if (e != hipSuccess) { delete ba; return slam_fail(ctx, SLAM_ERR_HIP, "slam_ba: hipMalloc(%zu): %s", off, hipGetErrorString(e)); }
@@ -874,7 +1313,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     d.S = ba->reduce; d.g = ba->reduce + (size_t)n * n; d.udiag = d.g + n;
     d.Swork = (double *)(A + o_Sw); d.dp = (double *)(A + o_dp); d.dl = (double *)(A + o_dl);
     d.part = (double *)(A + o_part); d.st = (LMState *)(A + o_st);
-    ba->chol_flag = (int *)(A + o_cf); ba->linv = (double *)(A + o_li); ba->lfac = (double *)(A + o_lf);
+    ba->chol_flag = (int *)(A + o_cf); ba->linv = (double *)(A + o_li); ba->lfac = (double *)(A + o_lf); ba->band = (double *)(A + o_band);
     hipStream_t st = ctx->stream;
 #define UP(dst, src, bytes) do { if ((bytes) > 0) HIP_TRY(ctx, hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
     UP(d.pose, theta, (size_t)n * 8); UP(d.pts, theta + n, (size_t)3 * M * 8);
@@ -902,7 +1341,7 @@ static int ba_enqueue_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, dou
     if (!use_state) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 0, ba->nblocks_obs, ba->nblocks_pts, 0, red + (size_t)n * n + 2 * n);
     if (d.M > 0) hipLaunchKernelGGL(k_points, dim3((d.M + 255) / 256), dim3(256), 0, st, d, inv_delta, use_state);
     if (d.O > 0) hipLaunchKernelGGL(k_obs_factors, dim3((d.O + 255) / 256), dim3(256), 0, st, d, use_state);
-    if (d.nblk > 0) hipLaunchKernelGGL(k_blocks, dim3(d.nblk), dim3(256), 0, st, d, use_state);
+    if (d.nblk > 0) hipLaunchKernelGGL(k_blocks, dim3(((d.nblk + 7) / 8) * 8), dim3(256), 0, st, d, use_state);
     return SLAM_OK;
 }
 
@@ -912,7 +1351,21 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
     BADev d = ba->d;
     const int n = d.n;
     hipStream_t st = ctx->stream;
-    {
+    static const bool no_band = getenv("SLAMHIP_NO_BAND") != nullptr;
+    const int hb = std::min(std::max(ba->hb, 1), d.P - 1);      // >= 1: the factor wave reads block row k + 1 while row k + 1 + hb enters the ring
+    const size_t band_lds = ((size_t)(hb + 1) * (hb + 1) * 36 + (size_t)(hb + 1) * (6 + 36 + 6) + 8 + 108 + 2 * (size_t)n) * 8 + (size_t)hb * (hb + 1) + 16;
+    if (!no_band && hb <= BS_MAXHB && band_lds <= 150 * 1024) {
+        BandArgs B; B.S = red; B.g = red + (size_t)n * n; B.ud = red + (size_t)n * n + n; B.Lg = ba->band; B.nb = d.P; B.hb = hb;
+        B.inv_delta_host = inv_delta; B.fail = ba->chol_flag;
+        static long long *trace_dev = nullptr; static int trace_n = 0;
+        static const bool trace_on = getenv("SLAMHIP_BAND_TRACE") != nullptr;
+        if (trace_on && !trace_dev) (void)hipHostMalloc((void **)&trace_dev, 128);
+        B.trace = trace_dev;
+        if (trace_on && trace_n++ == 8) { (void)hipStreamSynchronize(st); fprintf(stderr, "band trace (cycles): P1 barrier wait %lld P2 barrier wait %lld backsub %lld | potrf+inv %lld panel %lld update %lld put/fetch %lld | factor wave %lld prefetch wave %lld\n", trace_dev[1], trace_dev[2], trace_dev[3], trace_dev[4], trace_dev[5], trace_dev[6], trace_dev[7], trace_dev[8], trace_dev[9]); }
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(k_band_solve, dim3(1), dim3(BS_T), band_lds, st, d, B, use_state);
+    } else {
         CholArgs C; C.A = d.Swork; C.Lf = ba->lfac; C.n = n; C.ld = n + 1; C.fail = ba->chol_flag;
         const size_t tot = (size_t)(n + 1) * n;
         hipLaunchKernelGGL(k_chol_prepare, dim3((tot + 255) / 256), dim3(256), 0, st, d, red, red + (size_t)n * n, red + (size_t)n * n + n, inv_delta, use_state);
