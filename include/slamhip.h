@@ -321,6 +321,44 @@ int    slam_ba_commit(slam_ctx *ctx, slam_ba *ba, int accept);
 int    slam_ba_flag_outliers(slam_ctx *ctx, slam_ba *ba, double repr_eps, double depth_eps, int *n_out);
 /* read back theta (6P + 3 M_local) and the outlier flags (O_local) */
 int    slam_ba_download(slam_ctx *ctx, slam_ba *ba, double *theta, uint8_t *outliers);
+/* Block half-bandwidth of the shard's reduced system (S_pq = 0 for |p - q| > hb).  The all-reduced system has the maximum
+ * over the ranks: the driver sets that on every rank before the first solve (single-launch banded solver). */
+int    slam_ba_halfband(const slam_ba *ba);
+int    slam_ba_set_halfband(slam_ba *ba, int hb);
+
+/* Device-paced LM pass of the sharded path.  Every call below returns after ENQUEUEING on ctx's stream; the accept / reject
+ * decision of LeastSquaresOptim's outer loop (bundle_adjustment.jl:35-54) is taken on the device from the
+ * gathered trial costs, identically on every rank, so a pass contains no host synchronisation.  Protocol per pass:
+ *     slam_ba_lm_begin(ignore, red);  slam_comm_allreduce_sum(red);  slam_ba_lm_start(red, first_pass);
+ *     for it = 1 .. iters:
+ *         if (it > 1) { slam_ba_lm_build(ignore, red);  slam_comm_allreduce_sum(red); }
+ *         slam_ba_lm_solve(red, ignore, trial);  slam_comm_allgather(trial -> gathered, 4);
+ *         slam_ba_lm_step(gathered, nranks, it);
+ *     slam_ba_lm_state(out8);                       -- the only synchronising call
+ * Once the device-side state says "converged" the remaining iterations are no-ops (every kernel early-outs). */
+int    slam_ba_lm_begin(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, double *reduce_dev);
+int    slam_ba_lm_start(slam_ctx *ctx, slam_ba *ba, const double *reduce_dev, int first_pass);
+int    slam_ba_lm_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, double *reduce_dev);
+int    slam_ba_lm_solve(slam_ctx *ctx, slam_ba *ba, const double *reduce_dev, int ignore_outliers, double *trial_dev);
+int    slam_ba_lm_step(slam_ctx *ctx, slam_ba *ba, const double *gathered_dev, int nranks, int iter_tag);
+/* synchronises; out8 = {ssr, iterations, converged, delta, chol_fail, ssr at the start of the first pass, trial ssr, max|dx|} */
+int    slam_ba_lm_state(slam_ctx *ctx, slam_ba *ba, double *out8);
+
+/* ---- RCCL collectives for the sharded BA ("ncclAllReduce(sum, f64) of [S ; g ; cost] over xGMI") -----------
+ * One communicator per process / GPU.  Rank 0 obtains a 128-byte id (slam_comm_unique_id) and hands it to the other
+ * ranks through the host's own channel (the Julia side: MPI.jl / Distributed / a file); every rank then calls
+ * slam_comm_create.  The collectives are enqueued on ctx's stream (device-ordered with the slam_ba_lm_* calls) and
+ * return immediately.  librccl is bound at run time: a process that never creates a communicator does not load it. */
+typedef struct slam_comm slam_comm;
+int    slam_comm_unique_id(void *id128);
+int    slam_comm_create(slam_ctx *ctx, int nranks, int rank, const void *id128, slam_comm **out);
+int    slam_comm_destroy(slam_comm *comm);
+int    slam_comm_size(const slam_comm *comm);
+int    slam_comm_rank(const slam_comm *comm);
+/* in-place sum of buf_dev[0 .. count) (Float64) over all ranks */
+int    slam_comm_allreduce_sum(slam_ctx *ctx, slam_comm *comm, double *buf_dev, int64_t count);
+/* recv_dev[r * count .. (r + 1) * count) = rank r's send_dev[0 .. count) */
+int    slam_comm_allgather(slam_ctx *ctx, slam_comm *comm, const double *send_dev, double *recv_dev, int64_t count);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,21 @@ SIGNATURES = {
     "slam_ba_commit": (cint, [vp, vp, cint]),
     "slam_ba_flag_outliers": (cint, [vp, vp, dbl, dbl, C.POINTER(cint)]),
     "slam_ba_download": (cint, [vp, vp, f64p, u8p]),
+    "slam_ba_halfband": (cint, [vp]),
+    "slam_ba_set_halfband": (cint, [vp, cint]),
+    "slam_ba_lm_begin": (cint, [vp, vp, cint, vp]),
+    "slam_ba_lm_start": (cint, [vp, vp, vp, cint]),
+    "slam_ba_lm_build": (cint, [vp, vp, cint, vp]),
+    "slam_ba_lm_solve": (cint, [vp, vp, vp, cint, vp]),
+    "slam_ba_lm_step": (cint, [vp, vp, vp, cint, cint]),
+    "slam_ba_lm_state": (cint, [vp, vp, f64p]),
+    "slam_comm_unique_id": (cint, [vp]),
+    "slam_comm_create": (cint, [vp, cint, cint, vp, C.POINTER(vp)]),
+    "slam_comm_destroy": (cint, [vp]),
+    "slam_comm_size": (cint, [vp]),
+    "slam_comm_rank": (cint, [vp]),
+    "slam_comm_allreduce_sum": (cint, [vp, vp, vp, C.c_int64]),
+    "slam_comm_allgather": (cint, [vp, vp, vp, vp, C.c_int64]),
 }
 
 _lib = None

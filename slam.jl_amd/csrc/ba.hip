@@ -1117,23 +1117,10 @@ __device__ __forceinline__ double ctl_max(const double *p, int n, double *sh)
     for (int i = threadIdx.x; i < n; i += 256) t = fmax(t, p[i]);
     return block_max(t, sh);
 }
-__global__ __launch_bounds__(256) void k_control(BADev d, int mode, int nb_obs, int nb_pts, int lm, double *out4)
+// LeastSquaresOptim's accept / reject of a trial step (trust-region radius update, step-quality test): t = trial cost,
+// p = predicted cost, mx = max |dx|
+__device__ __forceinline__ void lm_decide(LMState *s, double t, double p, double mx)
 {
-    __shared__ double sh[4];
-    LMState *s = d.st;
-    if (mode == 0) {
-        const double t = ctl_sum(d.part, nb_obs, 1, sh);
-        if (threadIdx.x == 0) { s->ssr = t; if (out4) out4[0] = t; }
-        return;
-    }
-    if (lm && s->converged) return;
-    const double mx = ctl_max(d.part, nb_pts, sh);
-    const double t = ctl_sum(d.part + nb_pts, nb_obs, 2, sh);
-    const double p = ctl_sum(d.part + nb_pts + 1, nb_obs, 2, sh);
-    if (threadIdx.x != 0) return;
-    s->trial_ssr = t; s->pred_ssr = p; s->maxdx = mx;
-    if (out4) { out4[0] = t; out4[1] = p; out4[2] = mx; out4[3] = (double)s->chol_fail; }
-    if (!lm) return;
     s->iters++;
     if (s->chol_fail) { s->converged = 1; s->accept = 0; return; }
     const double ssr = s->ssr;
@@ -1153,6 +1140,48 @@ __global__ __launch_bounds__(256) void k_control(BADev d, int mode, int nb_obs, 
         s->accept = 0;
         s->converged = mx <= LM_XTOL;
     }
+}
+__global__ __launch_bounds__(256) void k_control(BADev d, int mode, int nb_obs, int nb_pts, int lm, double *out4)
+{
+    __shared__ double sh[4];
+    LMState *s = d.st;
+    if (mode == 0) {
+        const double t = ctl_sum(d.part, nb_obs, 1, sh);
+        if (threadIdx.x == 0) { s->ssr = t; if (out4) out4[0] = t; }
+        return;
+    }
+    if (lm && s->converged) return;
+    const double mx = ctl_max(d.part, nb_pts, sh);
+    const double t = ctl_sum(d.part + nb_pts, nb_obs, 2, sh);
+    const double p = ctl_sum(d.part + nb_pts + 1, nb_obs, 2, sh);
+    if (threadIdx.x != 0) return;
+    s->trial_ssr = t; s->pred_ssr = p; s->maxdx = mx;
+    if (out4) { out4[0] = t; out4[1] = p; out4[2] = mx; out4[3] = (double)s->chol_fail; }
+    if (!lm) return;
+    lm_decide(s, t, p, mx);
+}
+
+// The sharded path: every rank's [trial_ssr, pred_ssr, max|dx|, chol_fail] gathered into g (nranks x 4).  Sums / maxima in
+// rank order, then the same decision as the single-GPU path -- identical on every rank, taken on the device.
+__global__ void k_control_gathered(BADev d, const double *g, int nranks)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    LMState *s = d.st;
+    if (s->converged) return;
+    double t = 0.0, p = 0.0, mx = 0.0, cf = 0.0;
+    for (int r = 0; r < nranks; r++) { t += g[4 * r]; p += g[4 * r + 1]; mx = fmax(mx, g[4 * r + 2]); cf = fmax(cf, g[4 * r + 3]); }
+    s->trial_ssr = t; s->pred_ssr = p; s->maxdx = mx;
+    if (cf != 0.0) s->chol_fail = 1;
+    lm_decide(s, t, p, mx);
+}
+// start of an LM pass in the sharded path: the all-reduced cost of the current parameters comes from the reduce buffer
+__global__ void k_lm_start(BADev d, const double *ssr_slot, int first_pass)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    LMState *s = d.st;
+    s->ssr = *ssr_slot;
+    if (first_pass) { s->ssr_init = s->ssr; s->chol_fail = 0; }
+    s->delta = LM_DELTA0; s->decrease_factor = 2.0; s->converged = 0; s->accept = 0; s->iters = 0;
 }
 
 // note: must run even when `converged` was set by THIS iteration's k_control
@@ -1447,6 +1476,70 @@ int slam_ba_commit(slam_ctx *ctx, slam_ba *ba, int accept)
     HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
 }
+
+// ---- device-paced LM for the sharded path: every call returns after enqueueing on ctx's stream; the accept / reject decision
+// is taken on the device from the gathered trial costs, so a pass needs no host synchronisation (slam.h has the protocol) ----
+int slam_ba_lm_begin(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, double *reduce_dev)
+{
+    ARG_TRY(ctx, ctx != nullptr && ba != nullptr && reduce_dev != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ba_enqueue_build(ctx, ba, ignore_outliers, 1.0 / LM_DELTA0, 0, reduce_dev);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipGetLastError());
+    return SLAM_OK;
+}
+int slam_ba_lm_start(slam_ctx *ctx, slam_ba *ba, const double *reduce_dev, int first_pass)
+{
+    ARG_TRY(ctx, ctx != nullptr && ba != nullptr && reduce_dev != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int n = ba->d.n;
+    hipLaunchKernelGGL(k_lm_start, dim3(1), dim3(1), 0, ctx->stream, ba->d, reduce_dev + (size_t)n * n + 2 * n, first_pass);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLAM_OK;
+}
+int slam_ba_lm_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, double *reduce_dev)
+{
+    ARG_TRY(ctx, ctx != nullptr && ba != nullptr && reduce_dev != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ba_enqueue_build(ctx, ba, ignore_outliers, 0.0, 1, reduce_dev);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipGetLastError());
+    return SLAM_OK;
+}
+int slam_ba_lm_solve(slam_ctx *ctx, slam_ba *ba, const double *reduce_dev, int ignore_outliers, double *trial_dev)
+{
+    ARG_TRY(ctx, ctx != nullptr && ba != nullptr && reduce_dev != nullptr && trial_dev != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ba_enqueue_solve(ctx, ba, reduce_dev, ignore_outliers, 0.0, 1, 0, trial_dev);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipGetLastError());
+    return SLAM_OK;
+}
+int slam_ba_lm_step(slam_ctx *ctx, slam_ba *ba, const double *gathered_dev, int nranks, int iter_tag)
+{
+    ARG_TRY(ctx, ctx != nullptr && ba != nullptr && gathered_dev != nullptr && nranks >= 1);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_control_gathered, dim3(1), dim3(1), 0, ctx->stream, ba->d, gathered_dev, nranks);
+    ba_enqueue_commit(ctx, ba, 0, 1, iter_tag);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLAM_OK;
+}
+// synchronises; out8 = {ssr, iters, converged, delta, chol_fail, ssr_init, trial_ssr, max|dx|}
+int slam_ba_lm_state(slam_ctx *ctx, slam_ba *ba, double *out8)
+{
+    ARG_TRY(ctx, ctx != nullptr && ba != nullptr && out8 != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LMState h;
+    HIP_TRY(ctx, hipMemcpyAsync(&h, ba->d.st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    out8[0] = h.ssr; out8[1] = h.iters; out8[2] = h.converged; out8[3] = h.delta; out8[4] = h.chol_fail; out8[5] = h.ssr_init;
+    out8[6] = h.trial_ssr; out8[7] = h.maxdx;
+    return SLAM_OK;
+}
+// block half-bandwidth of this shard's reduced system (S_pq = 0 for |p - q| > hb); the all-reduced system has the maximum over
+// the ranks, which the driver sets on every rank before the first solve
+int slam_ba_halfband(const slam_ba *ba) { return ba ? ba->hb : SLAM_ERR_ARG; }
+int slam_ba_set_halfband(slam_ba *ba, int hb) { if (!ba || hb < 0) return SLAM_ERR_ARG; ba->hb = hb; return SLAM_OK; }
 
 int slam_ba_flag_outliers(slam_ctx *ctx, slam_ba *ba, double repr_eps, double depth_eps, int *n_out)
 {

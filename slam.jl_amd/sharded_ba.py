@@ -27,16 +27,19 @@ LM_XTOL = LM_FTOL = 1e-8
 
 
 def worth_sharding(P, O, world_size):
-    """Gate (north_star: 'only when the window is large enough to amortise it').
-    The all-reduce moves 8*(6P)^2 bytes and costs >= ~30 us of latency per
-    iteration; a single GPU builds the system for O observations in roughly
-    O * 0.5 ns + a few launches.  Shard only when the per-GPU build saving
-    exceeds the collective."""
+    """Gate (north_star: 'only when the window is large enough to amortise it'), calibrated on round-2 measurements of one
+    MI355X (profiles/r02*_ba_kernel_stats.csv, P = 50, O = 1e5): per LM iteration the observation-proportional part
+    (k_linearize, k_points, k_obs_factors, k_blocks, k_backsub, k_trial) takes ~1.45 us per 1000 observations and is what
+    sharding divides by the world size; the reduced-system solve (~3 us per key-frame, banded) is repeated on every rank;
+    the exchange costs one all-reduce of 8 (6P)^2 bytes (ring: 2 (N-1)/N of the bytes over one ~150 GB/s xGMI link,
+    ~25 us floor), one 32-byte all-gather (~15 us) and ~10 extra launches (~20 us) per iteration."""
     if world_size <= 1:
         return False
-    build_us = O * 5e-4
-    allreduce_us = 30.0 + 8.0 * (6 * P) ** 2 / 100e3      # ~100 GB/s effective ring rate -> bytes/1e5 us
-    return build_us * (1.0 - 1.0 / world_size) > allreduce_us
+    build_us = 1.45e-3 * O
+    saved_us = build_us * (1.0 - 1.0 / world_size)
+    allreduce_us = 25.0 + 2.0 * (world_size - 1) / world_size * 8.0 * (6 * P) ** 2 / 150e3
+    overhead_us = allreduce_us + 15.0 + 20.0
+    return saved_us > 1.5 * overhead_us          # margin: the model is per iteration, set-up (pair lists, upload) is not sharded away
 
 
 def partition_points(point_ids, M, world_size):
@@ -96,6 +99,58 @@ class HipShard:
         self.ctx.check(self.ctx.lib.slam_ba_flag_outliers(self.ctx.h, self.h, float(repr_eps), float(depth_eps), C.byref(n)))
         return n.value
 
+    # ---- device-paced pass (slam_ba_lm_* + slam_comm_*): no host synchronisation inside a pass ----
+    def make_comm(self, group=None):
+        """RCCL communicator over the ranks of `group` through the C ABI (slam_comm_*); the 128-byte id travels over
+        torch.distributed's object broadcast (any backend) -- a Julia host would use its own channel."""
+        import torch.distributed as dist
+        lib = self.ctx.lib
+        ws = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank(group) if ws > 1 else 0
+        idbuf = C.create_string_buffer(128)
+        if rank == 0:
+            self.ctx.check(lib.slam_comm_unique_id(idbuf))
+        if ws > 1:
+            box = [bytes(idbuf.raw)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            idbuf = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        self.ctx.check(lib.slam_comm_create(self.ctx.h, ws, rank, idbuf, C.byref(h)))
+        self.comm, self.ws = h, ws
+        self.gathered = self.torch.zeros(4 * ws, dtype=self.torch.float64, device=self.red.device)
+        self.torch.cuda.synchronize(self.red.device)
+        # the all-reduced system is as wide as the widest shard's
+        hb = self.torch.tensor([lib.slam_ba_halfband(self.h)], dtype=self.torch.int32, device=self.red.device)
+        if ws > 1:
+            dist.all_reduce(hb, op=dist.ReduceOp.MAX, group=group)
+        self.ctx.check(lib.slam_ba_set_halfband(self.h, int(hb[0])))
+        return self
+
+    def lm_pass(self, ignore, iters, first_pass):
+        """One LM pass (bundle_adjustment.jl:35-54): returns (ssr at the start, ssr at the end, iterations)."""
+        lib, c, red = self.ctx.lib, self.ctx, C.c_void_p(self.red.data_ptr())
+        n_red = self.red.numel()
+        c.check(lib.slam_ba_lm_begin(c.h, self.h, int(ignore), red))
+        c.check(lib.slam_comm_allreduce_sum(c.h, self.comm, red, n_red))
+        c.check(lib.slam_ba_lm_start(c.h, self.h, red, int(first_pass)))
+        st0 = np.zeros(8)
+        if iters == 0:
+            c.check(lib.slam_ba_lm_state(c.h, self.h, L.ptr(st0)))
+            return st0[0], st0[0], 0
+        trial, gath = C.c_void_p(self.trial.data_ptr()), C.c_void_p(self.gathered.data_ptr())
+        for it in range(1, iters + 1):
+            if it > 1:
+                c.check(lib.slam_ba_lm_build(c.h, self.h, int(ignore), red))
+                c.check(lib.slam_comm_allreduce_sum(c.h, self.comm, red, n_red))
+            c.check(lib.slam_ba_lm_solve(c.h, self.h, red, int(ignore), trial))
+            c.check(lib.slam_comm_allgather(c.h, self.comm, trial, gath, 4))
+            c.check(lib.slam_ba_lm_step(c.h, self.h, gath, self.ws, it))
+        st = np.zeros(8)
+        c.check(lib.slam_ba_lm_state(c.h, self.h, L.ptr(st)))
+        if st[4] != 0.0:
+            raise L.SlamHipError("sharded BA: reduced camera system not positive definite")
+        return None, st[0], int(st[1])
+
     def download(self):
         theta = np.zeros(6 * self.P + 3 * self.M)
         outl = np.zeros(max(self.O, 1), dtype=np.uint8)
@@ -103,6 +158,10 @@ class HipShard:
         return theta, outl[:self.O].astype(bool)
 
     def close(self):
+        if getattr(self, "comm", None):
+            self.ctx.synchronize()
+            self.ctx.lib.slam_comm_destroy(self.comm)
+            self.comm = None
         if getattr(self, "h", None):
             self.ctx.lib.slam_ba_destroy(self.h)
             self.h = None
@@ -127,12 +186,14 @@ def _all_reduce(t, op, group):
 
 
 def sharded_bundle_adjustment(cam, theta, theta_const, pixels, pose_ids, point_ids, iterations=10, repr_eps=5.0,
-                              iters_fast=5, group=None, shard_factory=HipShard, timings=None):
+                              iters_fast=5, group=None, shard_factory=HipShard, timings=None, host_paced=None):
     """bundle_adjustment! over all ranks of `group`.  Every rank passes the FULL
     problem (as the single-GPU seam would receive it) and gets the FULL result:
     (theta (6P+3M), outliers (O,), stats).  `shard_factory` builds this rank's
     compute shard (HipShard in the product; the tests inject an oracle-backed
-    one to check the partition + collective logic on CPU/gloo)."""
+    one to check the partition + collective logic on CPU/gloo).  With the product's HipShard the pass runs device-paced
+    (slam_ba_lm_* + RCCL through slam_comm_*: no host synchronisation inside a pass); `host_paced=True` forces the
+    host-driven loop over torch.distributed that the CPU shards use."""
     import torch
     import torch.distributed as dist
     ws = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -186,10 +247,21 @@ def sharded_bundle_adjustment(cam, theta, theta_const, pixels, pose_ids, point_i
                 converged = maxdx <= LM_XTOL
         return ssr0, ssr, it
 
-    ssr_init, ssr1, it1 = run_pass(0, iters_fast)
+    device_paced = hasattr(shard, "lm_pass") and host_paced is not True
+    if device_paced:
+        # product path: RCCL through the C ABI on the library's own stream, LM decisions on the device
+        shard.make_comm(group)
+        _, ssr1, it1 = shard.lm_pass(0, iters_fast, True)
+        st0 = np.zeros(8); shard.ctx.check(shard.ctx.lib.slam_ba_lm_state(shard.ctx.h, shard.h, L.ptr(st0)))
+        ssr_init = st0[5]
+    else:
+        ssr_init, ssr1, it1 = run_pass(0, iters_fast)
     n_out = torch.tensor([shard.flag_outliers(repr_eps)], dtype=torch.float64, device=shard.red.device if hasattr(shard, "red") else "cpu")
     _all_reduce(n_out, SUM, group)
-    _, ssr2, it2 = run_pass(1, iterations)
+    if device_paced:
+        _, ssr2, it2 = shard.lm_pass(1, iterations, False)
+    else:
+        _, ssr2, it2 = run_pass(1, iterations)
     th_loc, ol_loc = shard.download()
     # gather the full result on every rank (poses are identical everywhere)
     theta_out = theta.copy()

@@ -41,6 +41,39 @@ def test_sharded_driver_on_one_gpu_matches_single_call(slam, syn):
     assert np.abs(th - cache.theta).max() <= 1e-7 * max(1.0, np.abs(th).max())
 
 
+def test_sharded_device_paced_equals_host_paced(slam, syn):
+    """The device-paced pass (slam_ba_lm_* with the LM decision on the device, RCCL through slam_comm_* on the library's stream)
+    against the host-paced loop over the same entry points: same iterations, outliers, cost and parameters."""
+    from slam_jl_amd import sharded_ba
+    s = syn.ba_scene(P=20, M=2000, seed=22)
+    a = sharded_ba.sharded_bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+    b = sharded_ba.sharded_bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], host_paced=True)
+    assert np.array_equal(a[1], b[1])
+    assert a[2]["iters_pass1"] == b[2]["iters_pass1"] and a[2]["iters_pass2"] == b[2]["iters_pass2"]
+    for k in ("ssr_init", "ssr_pass1", "ssr_final"):
+        assert abs(a[2][k] - b[2][k]) <= 1e-9 * b[2][k], k
+    assert np.abs(a[0] - b[0]).max() <= 1e-9 * max(1.0, np.abs(b[0]).max())
+
+
+def test_comm_collectives_single_rank(slam):
+    """slam_comm_* (RCCL bound at run time) with one rank: all-reduce and all-gather are identities."""
+    import ctypes as C
+    import torch
+    ctx = slam.default_context(0)
+    idbuf = C.create_string_buffer(128)
+    ctx.check(ctx.lib.slam_comm_unique_id(idbuf))
+    h = C.c_void_p()
+    ctx.check(ctx.lib.slam_comm_create(ctx.h, 1, 0, idbuf, C.byref(h)))
+    assert ctx.lib.slam_comm_size(h) == 1 and ctx.lib.slam_comm_rank(h) == 0
+    a = torch.arange(1000, dtype=torch.float64, device="cuda"); b = torch.zeros(4, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.slam_comm_allreduce_sum(ctx.h, h, C.c_void_p(a.data_ptr()), 1000))
+    ctx.check(ctx.lib.slam_comm_allgather(ctx.h, h, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), 4))
+    ctx.synchronize()
+    assert torch.equal(a.cpu(), torch.arange(1000, dtype=torch.float64)) and torch.equal(b.cpu(), torch.arange(4, dtype=torch.float64))
+    ctx.check(ctx.lib.slam_comm_destroy(h))
+
+
 def test_profiling_spans(slam, texture):
     ctx = slam.default_context(0)
     L = texture(120, 160)[0]
