@@ -208,6 +208,54 @@ int slam_flow_match_batch_kept(slam_ctx *ctx, const slam_pyr *from0, const slam_
                                double *kept_yx, uint8_t *kept_is3d, int32_t *kept_img, int32_t *kept_src, int *n_kept,
                                uint8_t *status);
 
+/* ---- device-resident keypoint lists --------------------------------------------------------------
+ * The reference keeps a frame's keypoints in a Dict and optical_flow_matching! (map_manager.jl:451-564) copies them into
+ * arrays per call; here the lists of S lock-stepped streams live in HBM: stream s owns slots [s cap, s cap + count[s]) of
+ * every per-keypoint array (pixel, is_3d, map point, id, stereo pixel / flag).  Tracking, removal of lost keypoints, map
+ * culling, the avoidance list and merge of key-frame detection, stereo matching and triangulation read and write those
+ * arrays; compaction is stable and runs on the device (wave ballot + prefix counts).  Every call except create / upload /
+ * download / counts returns after ENQUEUEING on ctx's stream; slam_kpset_counts is the one small device -> host copy a step
+ * needs.  n_bound: an upper bound of the number of live keypoints known to the host (sizes launches; <= 0: S x cap).
+ * Per-stream call parameters `params`: S x 32 doubles, [0..15] Tcw of the target camera (column-major 4x4), [16..19] fx fy cx
+ * cy and [20..23] k1 k2 p1 p2 of the target camera, [24..25] prior shift (y, x); prior = 0: none, 1: projection of the map
+ * point through Tcw and the lens model (project_world_to_image_distort, frame.jl:478-484), 2: pixel + shift. */
+typedef struct slam_kpset slam_kpset;
+int slam_kpset_create(slam_ctx *ctx, int S, int cap, slam_kpset **out);
+int slam_kpset_destroy(slam_kpset *ks);
+int slam_kpset_streams(const slam_kpset *ks);
+int slam_kpset_capacity(const slam_kpset *ks);
+/* replace / read stream s's list (initialisation, tests, host consumers); NULL arrays are skipped; ids == NULL: 0 .. n-1 */
+int slam_kpset_upload(slam_ctx *ctx, slam_kpset *ks, int s, const double *yx, const uint8_t *is_3d, const double *xyz,
+                      const int64_t *ids, int n);
+int slam_kpset_download(slam_ctx *ctx, slam_kpset *ks, int s, double *yx, uint8_t *is_3d, double *xyz, int64_t *ids,
+                        double *stereo_yx, uint8_t *has_stereo, int cap_out, int *n_out);
+int slam_kpset_counts(slam_ctx *ctx, slam_kpset *ks, int32_t *counts /* S */);
+/* optical_flow_matching!(map_manager, frame, from, to, false): 3-D keypoints first with their prior on pyramid_levels_3d
+ * levels, failures and 2-D keypoints without prior on pyramid_levels levels (map_manager.jl:517-552); 3-D keypoints whose
+ * projection is outside the image are left as they are (:501-506); lost keypoints are removed (:559), the others take
+ * their new position.  from0 / to0: member 0 of two pyramid batches with >= S members. */
+int slam_kpset_flow_match(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *from0, const slam_pyr *to0, const double *params, int prior,
+                          int pyramid_levels, int pyramid_levels_3d, int window, int iterations, double eig_thr, double eps,
+                          double max_distance, int n_bound);
+/* optical_flow_matching!(..., true) left0 -> right0 (params: the RIGHT camera): a match passes maybe_stereo_update!
+ * (map_manager.jl:579-590: |left row - undistorted right row| <= epipolar_error; the left row is kept) and is stored as the
+ * keypoint's stereo pixel; 3-D keypoints projected outside the right image are removed (:491-498).  The left camera is taken as
+ * rectified (its undistorted row = the pixel row). */
+int slam_kpset_stereo_match(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *left0, const slam_pyr *right0, const double *params, int prior,
+                            int pyramid_levels, int pyramid_levels_3d, int window, int iterations, double eig_thr, double eps,
+                            double max_distance, double epipolar_error, int n_bound);
+/* remove the keypoints whose flag is set (flags_dev: S x cap bytes in HBM, slot order): map culling, outliers of the pose
+ * estimators (estimator.jl:283-292, front_end.jl:174-219) */
+int slam_kpset_remove(slam_ctx *ctx, slam_kpset *ks, const uint8_t *flags_dev);
+/* extract_keypoints! (map_manager.jl:98-113) for every stream: detect() with the stream's own list as avoidance list; the
+ * new keypoints are appended (is_3d = 0, fresh ids).  Needs cap >= max_points + grid_rows x grid_cols. */
+int slam_kpset_detect(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *pyr0, int max_points, int radius, int grid_rows, int grid_cols,
+                      int cell_size, double sigma_mask, double min_response);
+/* triangulate_stereo! (mapper.jl:142-183) for every 2-D keypoint with a stereo match: success -> map point Twc[s] X and
+ * is_3d = 1, failure -> the stereo observation is dropped.  P1, P2, T21, cam1, cam2 as slam_triangulate; Twc: S x 16. */
+int slam_kpset_triangulate(slam_ctx *ctx, slam_kpset *ks, const double *P1, const double *P2, const double *T21,
+                           const double *cam1, const double *cam2, const double *Twc, double max_error, double min_depth, int n_bound);
+
 /* ---- bundle adjustment ------------------------------------------------------ */
 /* Array-level body of triangulate_stereo! (parallax == NULL: every gate applies, src/mapper.jl:142-183) and
  * triangulate_temporal! (a gate removes the observation only when parallax[i] > min_parallax, :185-262), for n

@@ -59,6 +59,18 @@ SIGNATURES = {
     "slam_pyr_update_batch_u8_dev": (cint, [vp, C.POINTER(vp), C.POINTER(vp), cint, cint, dbl, cint]),
     "slam_flow_match_batch": (cint, [vp, vp, vp, cint, i32p, f64p, u8p, f64p, cint, cint, cint, cint, cint, dbl, dbl, dbl, f64p, u8p]),
     "slam_flow_match_batch_kept": (cint, [vp, vp, vp, cint, i32p, f64p, u8p, f64p, cint, cint, cint, cint, cint, dbl, dbl, dbl, f64p, u8p, i32p, i32p, C.POINTER(cint), u8p]),
+    "slam_kpset_create": (cint, [vp, cint, cint, C.POINTER(vp)]),
+    "slam_kpset_destroy": (cint, [vp]),
+    "slam_kpset_streams": (cint, [vp]),
+    "slam_kpset_capacity": (cint, [vp]),
+    "slam_kpset_upload": (cint, [vp, vp, cint, f64p, u8p, f64p, i64p, cint]),
+    "slam_kpset_download": (cint, [vp, vp, cint, f64p, u8p, f64p, i64p, f64p, u8p, cint, C.POINTER(cint)]),
+    "slam_kpset_counts": (cint, [vp, vp, i32p]),
+    "slam_kpset_flow_match": (cint, [vp, vp, vp, vp, f64p, cint, cint, cint, cint, cint, dbl, dbl, dbl, cint]),
+    "slam_kpset_stereo_match": (cint, [vp, vp, vp, vp, f64p, cint, cint, cint, cint, cint, dbl, dbl, dbl, dbl, cint]),
+    "slam_kpset_remove": (cint, [vp, vp, vp]),
+    "slam_kpset_detect": (cint, [vp, vp, vp, cint, cint, cint, cint, cint, dbl, dbl]),
+    "slam_kpset_triangulate": (cint, [vp, vp, f64p, f64p, f64p, f64p, f64p, f64p, dbl, dbl, cint]),
     "slam_local_ba": (cint, [vp, dbl, dbl, dbl, dbl, cint, cint, cint, f64p, u8p, f64p, i64p, i64p, u8p, cint, cint, dbl, f64p]),
     "slam_pnp_ba": (cint, [vp, dbl, dbl, dbl, dbl, f64p, f64p, f64p, cint, cint, cint, dbl, dbl, f64p, f64p, f64p, u8p, C.POINTER(cint)]),
     "slam_ba_create": (cint, [vp, dbl, dbl, dbl, dbl, cint, cint, cint, f64p, u8p, f64p, i64p, i64p, C.POINTER(vp)]),

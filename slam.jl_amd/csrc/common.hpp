@@ -72,6 +72,30 @@ struct slam_pyr {
     double *plane(int p, int l) const { return planes + (int64_t)p * off[levels] + off[l]; }
 };
 
+// Device-resident keypoint lists of S lock-stepped streams: stream s owns the slots
+// [s * cap, s * cap + count[s]) of every per-keypoint array; all of it lives in one allocation.
+struct slam_kpset {
+    int device = 0, S = 0, cap = 0;
+    char *base = nullptr;
+    double *yx = nullptr;        // [S cap][2] pixel (y, x) in the current left image
+    double *oyx = nullptr;       // [S cap][2] positions returned by the last temporal match (scratch)
+    double *syx = nullptr;       // [S cap][2] stereo pixel (right image), valid where stereo != 0
+    double *xyz = nullptr;       // [S cap][3] map point, valid where is3d != 0
+    int64_t *id = nullptr;       // [S cap] keypoint id (per stream, ascending in creation order)
+    uint8_t *is3d = nullptr, *stereo = nullptr, *st = nullptr;   // flags; st: status of the last match (0 lost, 1 tracked, 2 skipped)
+    int *count = nullptr;        // [S]
+    int *work = nullptr;         // [S cap] live slots, streams back to back
+    int *ntot = nullptr;         // [4]: number of live slots, ...
+    int64_t *next_id = nullptr;  // [S]
+    // per-stream parameters of a call (prior shift / pose): ring of 8 slots of S x 32 doubles, staged through pinned host
+    // memory with an event per slot, so that the enqueue-only calls never wait for an earlier call's copy
+    double *par = nullptr, *par_host = nullptr;
+    hipEvent_t par_ev[8] = {};
+    int par_slot = 0;
+};
+// stage `n` doubles (<= S x 32) of per-stream parameters into the next ring slot; returns the device pointer
+int kpset_stage_params(slam_ctx *ctx, slam_kpset *ks, const double *host, size_t n, const double **dev_out);
+
 extern thread_local std::string g_slam_err;
 
 // The synchronous seams end with a wait for the context's stream.  The interrupt-driven hipStreamSynchronize costs tens of
@@ -104,6 +128,9 @@ struct IIRCoef {
 IIRCoef slam_iir_coef(double sigma);
 int slam_gaussian_taps(double sigma, double *w);   // Kernel.gaussian 1-D factor
 
+// kpset plumbing shared by kpset.hip / lk.hip / detect.hip
+int kpset_build_worklist(slam_ctx *ctx, slam_kpset *ks);
+int kpset_compact(slam_ctx *ctx, slam_kpset *ks, int mode, const uint8_t *flags_dev);
 // per-module entry points used across files
 int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, int pitch, const double *cur_yx, int n_cur,
                        int max_points, int radius, int grid_rows, int grid_cols, int cell_size,

@@ -28,6 +28,9 @@ struct DetectArgs {
     int *cell_cnt;                     // n_cells
     // batched launch (grid.y = stream): per-stream image offset, slice of `cur` and k; nullptr for a single image
     const int *cur_off, *k_s; size_t zs; int kmax;
+    // keypoint-set launch (slam_kpset_detect): stream z's current keypoints are cur[2 * z * cur_stride ..], cur_cnt[z] of them
+    // (device-side count), k follows from it
+    const int *cur_cnt; int cur_stride, max_points;
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -81,7 +84,12 @@ __device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned 
 __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
 {
     extern __shared__ double lds[];
-    if (A.cur_off) {
+    if (A.cur_cnt) {
+        const int z = blockIdx.y, nc = A.grid_rows * A.grid_cols, ncur = A.cur_cnt[z];
+        A.img += (size_t)z * A.zs; A.cur += 2 * (size_t)z * A.cur_stride; A.n_cur = ncur;
+        A.k = ncur >= A.max_points ? 0 : (A.max_points - ncur + nc - 1) / nc;                 // extractor.jl:64-66, 74-76
+        A.cell_out += (size_t)z * nc * A.kmax * 2; A.cell_cnt += (size_t)z * nc;
+    } else if (A.cur_off) {
         const int z = blockIdx.y, o = A.cur_off[z], nc = A.grid_rows * A.grid_cols;
         A.img += (size_t)z * A.zs; A.cur += 2 * (size_t)o; A.n_cur = A.cur_off[z + 1] - o; A.k = A.k_s[z];
         A.cell_out += (size_t)z * nc * A.kmax * 2; A.cell_cnt += (size_t)z * nc;
@@ -334,7 +342,7 @@ int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, int p
     DetectArgs A;
     A.img = img_dev; A.H = H; A.W = W; A.pitch = pitch; A.n_cur = n_cur; A.radius = radius;
     A.grid_rows = grid_rows; A.grid_cols = grid_cols; A.cs = cell_size; A.k = k; A.min_response = min_response;
-    A.ntaps = 0; A.cur_off = nullptr; A.k_s = nullptr; A.zs = 0; A.kmax = k;
+    A.ntaps = 0; A.cur_off = nullptr; A.k_s = nullptr; A.zs = 0; A.kmax = k; A.cur_cnt = nullptr; A.cur_stride = 0; A.max_points = max_points;
     if (n_cur > 0 && sigma_mask != 0) {
         int l = 4 * (int)std::ceil(sigma_mask) + 1;
         ARG_TRY(ctx, l <= DET_MAXTAPS);
@@ -432,7 +440,7 @@ extern "C" int slam_detect_batch(slam_ctx *ctx, const slam_pyr *pyr0, int S, con
     DetectArgs A;
     A.img = pyr0->plane(0, 0); A.H = pyr0->H[0]; A.W = pyr0->W[0]; A.pitch = pyr0->P[0]; A.zs = pyr0->zstride;
     A.n_cur = 0; A.radius = radius; A.grid_rows = grid_rows; A.grid_cols = grid_cols; A.cs = cell_size; A.k = 0; A.kmax = kmax;
-    A.min_response = min_response; A.ntaps = 0;
+    A.min_response = min_response; A.ntaps = 0; A.cur_cnt = nullptr; A.cur_stride = 0; A.max_points = max_points;
     if (sigma_mask != 0) {
         ARG_TRY(ctx, 4 * (int)std::ceil(sigma_mask) + 1 <= DET_MAXTAPS);
         A.ntaps = slam_gaussian_taps(sigma_mask, A.taps);
@@ -481,5 +489,98 @@ extern "C" int slam_detect_batch(slam_ctx *ctx, const slam_pyr *pyr0, int S, con
         memcpy(out_rc + 2 * o, hs + 1, (size_t)hs[0] * 16);
         o += (size_t)hs[0]; out_off[s + 1] = (int32_t)o;
     }
+    return SLAM_OK;
+}
+
+
+// detect() into a device-resident keypoint set: the avoidance list of stream z is its current list in the set, the new
+// keypoints (cells row-major, column-major inside a cell: extractor.jl:81-91) are appended behind it as (row, col) Float64
+// pixels with is_3d = 0 and fresh ids -- extract_keypoints! + add_keypoints_to_frame! (map_manager.jl:98-113) on arrays.
+// One 1024-thread workgroup per stream: wave-level inclusive scans + one LDS hop (as detect_compact).
+__global__ __launch_bounds__(1024) void detect_append(const int64_t *cell_out, const int *cell_cnt, int n_cells, int kmax, int max_points,
+                                                       double *yx, double *syx, double *xyz, int64_t *id, uint8_t *is3d, uint8_t *stereo,
+                                                       int *count, int64_t *next_id, int cap)
+{
+    const int z = blockIdx.x;
+    cell_out += (size_t)z * n_cells * kmax * 2; cell_cnt += (size_t)z * n_cells;
+    const size_t b = (size_t)z * cap;
+    const int n0 = count[z];
+    const int64_t id0 = next_id[z];
+    __shared__ int s_w[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    if (n0 >= max_points) return;                                 // extractor.jl:64: nothing detected (cell counts are zero as well)
+    const int kz = (max_points - n0 + n_cells - 1) / n_cells;      // this stream's per-cell quota = the stride of its cell lists (detect_cells)
+    for (int c0 = 0; c0 < n_cells; c0 += 1024) {
+        const int c = c0 + tid;
+        const int cnt = c < n_cells ? cell_cnt[c] : 0;
+        int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        int wbase = 0;
+        for (int i = 0; i < wv; i++) wbase += s_w[i];
+        int total = 0;
+        for (int i = 0; i < 16; i++) total += s_w[i];
+        const int start = s_base + wbase + incl - cnt;
+        for (int i = 0; i < cnt; i++) {
+            const int j = n0 + start + i;
+            if (j < cap) {
+                const size_t q = b + j;
+                yx[2 * q] = (double)cell_out[((size_t)c * kz + i) * 2]; yx[2 * q + 1] = (double)cell_out[((size_t)c * kz + i) * 2 + 1];
+                syx[2 * q] = 0.0; syx[2 * q + 1] = 0.0; xyz[3 * q] = 0.0; xyz[3 * q + 1] = 0.0; xyz[3 * q + 2] = 0.0;
+                id[q] = id0 + start + i; is3d[q] = 0; stereo[q] = 0;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    if (tid == 0) { const int n1 = n0 + s_base; count[z] = n1 < cap ? n1 : cap; next_id[z] = id0 + s_base; }
+}
+
+extern "C" int slam_kpset_detect(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *pyr0, int max_points, int radius, int grid_rows, int grid_cols,
+                                 int cell_size, double sigma_mask, double min_response)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && pyr0 != nullptr);
+    const int S = ks->S;
+    ARG_TRY(ctx, pyr0->batch_index == 0 && pyr0->batch_size >= S);
+    ARG_TRY(ctx, grid_rows > 0 && grid_cols > 0 && cell_size >= 8 && radius > 0 && radius <= DET_MAXR && max_points > 0);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int n_cells = grid_rows * grid_cols;
+    const int kmax = (max_points + n_cells - 1) / n_cells;         // n_cur = 0
+    ARG_TRY(ctx, ks->cap >= max_points + n_cells);                  // a stream below max_points may receive up to n_cells * k > max_points - n_cur keypoints
+    DetectArgs A;
+    A.img = pyr0->plane(0, 0); A.H = pyr0->H[0]; A.W = pyr0->W[0]; A.pitch = pyr0->P[0]; A.zs = pyr0->zstride;
+    A.n_cur = 0; A.radius = radius; A.grid_rows = grid_rows; A.grid_cols = grid_cols; A.cs = cell_size; A.k = 0; A.kmax = kmax;
+    A.min_response = min_response; A.ntaps = 0; A.cur_off = nullptr; A.k_s = nullptr;
+    A.cur = ks->yx; A.cur_cnt = ks->count; A.cur_stride = ks->cap; A.max_points = max_points;
+    if (sigma_mask != 0) {
+        ARG_TRY(ctx, 4 * (int)std::ceil(sigma_mask) + 1 <= DET_MAXTAPS);
+        A.ntaps = slam_gaussian_taps(sigma_mask, A.taps);
+    }
+    const int hw = A.ntaps >> 1;
+    const size_t n = (size_t)cell_size * cell_size;
+    {
+        const size_t mbytes = ((size_t)(cell_size + 2 * hw) * (cell_size + 2 * hw) + 7) & ~(size_t)7;
+        ARG_TRY(ctx, mbytes <= n * 8 && (size_t)cell_size * (cell_size + 2 * hw) * 8 + mbytes <= 3 * n * 8);
+    }
+    ARG_TRY(ctx, (size_t)kmax * sizeof(int) <= n * 8);
+    const size_t lds_bytes = 4 * n * sizeof(double);
+    ARG_TRY(ctx, lds_bytes <= 150 * 1024);
+    const size_t cnt_b = ((size_t)S * n_cells * 4 + 255) & ~(size_t)255;
+    const size_t cout_b = ((size_t)S * n_cells * kmax * 16 + 255) & ~(size_t)255;
+    char *d;
+    int rc = slam_scratch(ctx, cnt_b + cout_b, (void **)&d);
+    if (rc) return rc;
+    A.cell_cnt = (int *)d; A.cell_out = (int64_t *)(d + cnt_b);
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)detect_cells, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    { ProfScope span(ctx, "detect");
+      hipLaunchKernelGGL(detect_cells, dim3(n_cells, S), dim3(DET_THREADS), lds_bytes, ctx->stream, A);
+      hipLaunchKernelGGL(detect_append, dim3(S), dim3(1024), 0, ctx->stream, (const int64_t *)A.cell_out, (const int *)A.cell_cnt, n_cells, kmax, max_points,
+                         ks->yx, ks->syx, ks->xyz, ks->id, ks->is3d, ks->stereo, ks->count, ks->next_id, ks->cap); }
+    HIP_TRY(ctx, hipGetLastError());
     return SLAM_OK;
 }

@@ -1,0 +1,301 @@
+// kpset.hip -- device-resident keypoint lists for S lock-stepped streams.
+//
+// In the reference the keypoints of a frame live in a Dict (src/frame.jl) and optical_flow_matching!
+// (src/map_manager.jl:451-564) copies them into arrays, tracks, and applies updates / removals one by one; the
+// round-1 batch seams kept that list on the HOST and crossed PCIe with it at every call.  Here the list stays in HBM:
+// tracking (slam_kpset_flow_match), the removal of lost keypoints, map culling (slam_kpset_remove), the avoidance list
+// and the merge of fresh keypoints in key-frame detection (slam_kpset_detect), stereo matching
+// (slam_kpset_stereo_match) and triangulation (slam_kpset_triangulate) all read and write the same device arrays; the
+// host sees one small copy of the per-stream counts per step (slam_kpset_counts).  Compaction is stable (a stream's
+// keypoints keep their order) and is done with wave ballots + prefix counts, one workgroup per stream.
+#include "common.hpp"
+#include "tri_device.hpp"
+#include <cmath>
+
+static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// live slots of all streams back to back + their number
+__global__ __launch_bounds__(1024) void k_kpset_worklist(const int *count, int S, int cap, int *work, int *ntot)
+{
+    __shared__ int off[65];
+    if (threadIdx.x == 0) { int o = 0; for (int s = 0; s < S; s++) { off[s] = o; o += count[s]; } off[S] = o; ntot[0] = o; }
+    __syncthreads();
+    for (int s = 0; s < S; s++) {
+        const int n = off[s + 1] - off[s];
+        for (int j = threadIdx.x; j < n; j += 1024) work[off[s] + j] = s * cap + j;
+    }
+}
+
+int kpset_build_worklist(slam_ctx *ctx, slam_kpset *ks)
+{
+    hipLaunchKernelGGL(k_kpset_worklist, dim3(1), dim3(1024), 0, ctx->stream, (const int *)ks->count, ks->S, ks->cap, ks->work, ks->ntot);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLAM_OK;
+}
+
+// Stable in-place compaction of every stream's list, one 256-thread workgroup per stream.
+// mode 0 (after a temporal match): keep st != 0; a tracked keypoint (st == 1) takes its new position from oyx.
+// mode 1 (removal by flags): keep flags[slot] == 0.
+// Chunks of 256 slots are read (all fields into registers), ranked with a wave ballot + the popcount of the lower lanes,
+// and written back after a barrier: destinations never lie to the right of their sources, so in place is safe.
+struct KpsetView {
+    double *yx, *oyx, *syx, *xyz; int64_t *id; uint8_t *is3d, *stereo, *st; int *count; int cap;
+};
+__global__ __launch_bounds__(256) void k_kpset_compact(KpsetView K, int mode, const uint8_t *flags)
+{
+    __shared__ int s_w[4], s_base;
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t b = (size_t)s * K.cap;
+    const int n = K.count[s];
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int j = c0 + tid;
+        bool keep = false;
+        double y = 0, x = 0, sy = 0, sx = 0, X0 = 0, X1 = 0, X2 = 0; int64_t id = 0; uint8_t f3 = 0, fs = 0;
+        if (j < n) {
+            const size_t q = b + j;
+            if (mode == 0) { const uint8_t t = K.st[q]; keep = t != 0; if (t == 1) { y = K.oyx[2 * q]; x = K.oyx[2 * q + 1]; } else { y = K.yx[2 * q]; x = K.yx[2 * q + 1]; } }
+            else { keep = flags[q] == 0; y = K.yx[2 * q]; x = K.yx[2 * q + 1]; }
+            if (keep) { sy = K.syx[2 * q]; sx = K.syx[2 * q + 1]; X0 = K.xyz[3 * q]; X1 = K.xyz[3 * q + 1]; X2 = K.xyz[3 * q + 2]; id = K.id[q]; f3 = K.is3d[q]; fs = K.stereo[q]; }
+        }
+        const unsigned long long m = __ballot(keep);
+        const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_w[wv] = __builtin_popcountll(m);
+        __syncthreads();                                        // all reads of the chunk done; wave totals visible
+        int wbase = 0;
+        for (int i = 0; i < wv; i++) wbase += s_w[i];
+        const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (keep) {
+            const size_t q = b + s_base + wbase + rank;
+            K.yx[2 * q] = y; K.yx[2 * q + 1] = x; K.syx[2 * q] = sy; K.syx[2 * q + 1] = sx;
+            K.xyz[3 * q] = X0; K.xyz[3 * q + 1] = X1; K.xyz[3 * q + 2] = X2; K.id[q] = id; K.is3d[q] = f3; K.stereo[q] = fs;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    if (tid == 0) K.count[s] = s_base;
+}
+
+static KpsetView view_of(slam_kpset *ks)
+{
+    KpsetView K; K.yx = ks->yx; K.oyx = ks->oyx; K.syx = ks->syx; K.xyz = ks->xyz; K.id = ks->id; K.is3d = ks->is3d; K.stereo = ks->stereo;
+    K.st = ks->st; K.count = ks->count; K.cap = ks->cap;
+    return K;
+}
+
+int kpset_stage_params(slam_ctx *ctx, slam_kpset *ks, const double *host, size_t n, const double **dev_out)
+{
+    const size_t slot_d = (size_t)ks->S * 32;
+    ARG_TRY(ctx, n <= slot_d);
+    const int sl = ks->par_slot; ks->par_slot = (sl + 1) & 7;
+    HIP_TRY(ctx, hipEventSynchronize(ks->par_ev[sl]));           // the copy that last used this slot (8 calls ago) has long completed
+    double *h = ks->par_host + (size_t)sl * slot_d, *dv = ks->par + (size_t)sl * slot_d;
+    memcpy(h, host, n * 8);
+    HIP_TRY(ctx, hipMemcpyAsync(dv, h, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ks->par_ev[sl], ctx->stream));
+    *dev_out = dv;
+    return SLAM_OK;
+}
+
+int kpset_compact(slam_ctx *ctx, slam_kpset *ks, int mode, const uint8_t *flags_dev)
+{
+    hipLaunchKernelGGL(k_kpset_compact, dim3(ks->S), dim3(256), 0, ctx->stream, view_of(ks), mode, flags_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLAM_OK;
+}
+
+// Array-level body of triangulate_stereo! (src/mapper.jl:142-183) on the set: every 2-D keypoint with a stereo match is
+// triangulated (the DLT of slam_triangulate, same gates); success -> map point Twc[s] * X, is3d = 1; failure -> the stereo
+// observation is dropped (remove_stereo_keypoint!).
+struct KTriArgs {
+    double P1[16], P2[16], T21[16], cam1[4], cam2[4];
+    const double *Twc;                 // [S][16] column-major camera-1 -> world, device
+    double max_error, min_depth;
+};
+__global__ __launch_bounds__(64) void k_kpset_triangulate(KpsetView K, KTriArgs T, const int *work, const int *ntot)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= ntot[0]) return;
+    const size_t q = (size_t)work[i];
+    if (!K.stereo[q] || K.is3d[q]) return;
+    const int s = (int)(q / K.cap);
+    const double x1 = K.yx[2 * q + 1], y1 = K.yx[2 * q], x2 = K.syx[2 * q + 1], y2 = K.syx[2 * q];
+    double A[16], S[16], v[4];
+    for (int j = 0; j < 4; j++) {
+        A[0 + j] = x1 * T.P1[2 + 4 * j] - T.P1[0 + 4 * j];
+        A[4 + j] = y1 * T.P1[2 + 4 * j] - T.P1[1 + 4 * j];
+        A[8 + j] = x2 * T.P2[2 + 4 * j] - T.P2[0 + 4 * j];
+        A[12 + j] = y2 * T.P2[2 + 4 * j] - T.P2[1 + 4 * j];
+    }
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; k++) acc += A[4 * k + r] * A[4 * k + c];
+            S[4 * r + c] = acc;
+        }
+    sym4_min_eigvec(S, v);
+    const double iw = 1.0 / v[3];
+    const double L0 = v[0] * iw, L1 = v[1] * iw, L2 = v[2] * iw, L3 = v[3] * iw;
+    bool ok = !(L2 < T.min_depth);
+    double R[3];
+    for (int r = 0; r < 3; r++) R[r] = ((T.T21[r] * L0 + T.T21[r + 4] * L1) + T.T21[r + 8] * L2) + T.T21[r + 12] * L3;
+    if (ok && R[2] < T.min_depth) ok = false;
+    if (ok) {
+        const double iz = 1.0 / L2;
+        const double py = T.cam1[1] * L1 * iz + T.cam1[3], px = T.cam1[0] * L0 * iz + T.cam1[2];
+        const double dy = y1 - py, dx = x1 - px;
+        if (sqrt(dy * dy + dx * dx) > T.max_error) ok = false;
+    }
+    if (ok) {
+        const double iz = 1.0 / R[2];
+        const double py = T.cam2[1] * R[1] * iz + T.cam2[3], px = T.cam2[0] * R[0] * iz + T.cam2[2];
+        const double dy = y2 - py, dx = x2 - px;
+        if (sqrt(dy * dy + dx * dx) > T.max_error) ok = false;
+    }
+    if (ok) {
+        const double *W = T.Twc + 16 * (size_t)s;                // project_camera_to_world (frame.jl): Twc * X
+        for (int r = 0; r < 3; r++) K.xyz[3 * q + r] = ((W[r] * L0 + W[r + 4] * L1) + W[r + 8] * L2) + W[r + 12] * L3;
+        K.is3d[q] = 1;
+    } else K.stereo[q] = 0;
+}
+
+extern "C" {
+
+int slam_kpset_destroy(slam_kpset *ks);
+
+int slam_kpset_create(slam_ctx *ctx, int S, int cap, slam_kpset **out)
+{
+    ARG_TRY(ctx, ctx != nullptr && out != nullptr && S >= 1 && S <= 64 && cap >= 1 && (size_t)S * cap < (1u << 30));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)S * cap;
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off += al256(b); return o; };
+    const size_t o_yx = take(n * 16), o_oyx = take(n * 16), o_syx = take(n * 16), o_xyz = take(n * 24), o_id = take(n * 8);
+    const size_t o_3d = take(n), o_st = take(n), o_ss = take(n), o_cnt = take((size_t)S * 4), o_work = take(n * 4), o_nt = take(64);
+    const size_t o_nid = take((size_t)S * 8), o_par = take((size_t)8 * S * 32 * 8);
+    slam_kpset *ks = new slam_kpset();
+    ks->device = ctx->device; ks->S = S; ks->cap = cap;
+    hipError_t e = hipMalloc((void **)&ks->base, off);
+    if (e == hipSuccess) e = hipMemsetAsync(ks->base, 0, off, ctx->stream);
+    if (e == hipSuccess) e = slam_stream_wait(ctx->stream);
+    if (e != hipSuccess) { if (ks->base) (void)hipFree(ks->base); delete ks; return slam_fail(ctx, SLAM_ERR_HIP, "slam_kpset_create: %s", hipGetErrorString(e)); }
+    char *B = ks->base;
+    ks->yx = (double *)(B + o_yx); ks->oyx = (double *)(B + o_oyx); ks->syx = (double *)(B + o_syx); ks->xyz = (double *)(B + o_xyz);
+    ks->id = (int64_t *)(B + o_id); ks->is3d = (uint8_t *)(B + o_3d); ks->stereo = (uint8_t *)(B + o_st); ks->st = (uint8_t *)(B + o_ss);
+    ks->count = (int *)(B + o_cnt); ks->work = (int *)(B + o_work); ks->ntot = (int *)(B + o_nt); ks->next_id = (int64_t *)(B + o_nid);
+    ks->par = (double *)(B + o_par);
+    e = hipHostMalloc((void **)&ks->par_host, (size_t)8 * S * 32 * 8);
+    for (int i = 0; i < 8 && e == hipSuccess; i++) { e = hipEventCreateWithFlags(&ks->par_ev[i], hipEventDisableTiming); if (e == hipSuccess) e = hipEventRecord(ks->par_ev[i], ctx->stream); }
+    if (e != hipSuccess) { slam_kpset_destroy(ks); return slam_fail(ctx, SLAM_ERR_HIP, "slam_kpset_create: %s", hipGetErrorString(e)); }
+    *out = ks;
+    return SLAM_OK;
+}
+
+int slam_kpset_destroy(slam_kpset *ks)
+{
+    if (!ks) return SLAM_OK;
+    (void)hipSetDevice(ks->device);
+    (void)hipDeviceSynchronize();
+    if (ks->base) (void)hipFree(ks->base);
+    if (ks->par_host) (void)hipHostFree(ks->par_host);
+    for (int i = 0; i < 8; i++) if (ks->par_ev[i]) (void)hipEventDestroy(ks->par_ev[i]);
+    delete ks;
+    return SLAM_OK;
+}
+
+int slam_kpset_streams(const slam_kpset *ks) { return ks ? ks->S : SLAM_ERR_ARG; }
+int slam_kpset_capacity(const slam_kpset *ks) { return ks ? ks->cap : SLAM_ERR_ARG; }
+
+// replace stream s's list (initialisation, tests); ids == NULL: 0 .. n-1, the stream's id counter moves past them
+int slam_kpset_upload(slam_ctx *ctx, slam_kpset *ks, int s, const double *yx, const uint8_t *is3d, const double *xyz, const int64_t *ids, int n)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && s >= 0 && s < ks->S && n >= 0 && n <= ks->cap && (n == 0 || (yx != nullptr && is3d != nullptr)));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t b = (size_t)s * ks->cap;
+    std::vector<int64_t> idv((size_t)n);
+    int64_t mx = -1;
+    for (int i = 0; i < n; i++) { idv[i] = ids ? ids[i] : i; mx = idv[i] > mx ? idv[i] : mx; }
+    const int64_t next = mx + 1;
+    if (n > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(ks->yx + 2 * b, yx, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ks->is3d + b, is3d, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        if (xyz) HIP_TRY(ctx, hipMemcpyAsync(ks->xyz + 3 * b, xyz, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+        else HIP_TRY(ctx, hipMemsetAsync(ks->xyz + 3 * b, 0, (size_t)n * 24, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ks->id + b, idv.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ks->stereo + b, 0, (size_t)n, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ks->count + s, &n, 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ks->next_id + s, &next, 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    return SLAM_OK;
+}
+
+// read stream s's list back (every output may be NULL); cap_out = capacity of the caller's arrays in keypoints
+int slam_kpset_download(slam_ctx *ctx, slam_kpset *ks, int s, double *yx, uint8_t *is3d, double *xyz, int64_t *ids,
+                        double *stereo_yx, uint8_t *has_stereo, int cap_out, int *n_out)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && s >= 0 && s < ks->S && n_out != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int n = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n, ks->count + s, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    *n_out = n;
+    if (n > cap_out) return slam_fail(ctx, SLAM_ERR_CAPACITY, "slam_kpset_download: %d keypoints but cap = %d", n, cap_out);
+    const size_t b = (size_t)s * ks->cap;
+    if (n > 0) {
+        if (yx) HIP_TRY(ctx, hipMemcpyAsync(yx, ks->yx + 2 * b, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (is3d) HIP_TRY(ctx, hipMemcpyAsync(is3d, ks->is3d + b, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        if (xyz) HIP_TRY(ctx, hipMemcpyAsync(xyz, ks->xyz + 3 * b, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+        if (ids) HIP_TRY(ctx, hipMemcpyAsync(ids, ks->id + b, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (stereo_yx) HIP_TRY(ctx, hipMemcpyAsync(stereo_yx, ks->syx + 2 * b, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (has_stereo) HIP_TRY(ctx, hipMemcpyAsync(has_stereo, ks->stereo + b, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    }
+    return SLAM_OK;
+}
+
+// the one small device -> host copy of a step: the S list lengths (synchronises ctx's stream)
+int slam_kpset_counts(slam_ctx *ctx, slam_kpset *ks, int32_t *counts)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && counts != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *h;
+    int rc = slam_pinned(ctx, 256, &h);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(h, ks->count, (size_t)ks->S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    memcpy(counts, h, (size_t)ks->S * 4);
+    return SLAM_OK;
+}
+
+// remove the keypoints whose flag is set (flags_dev: S x cap bytes in HBM, slot order): map culling, outliers of the pose
+// estimators, ... -- stable compaction on the device, returns after enqueueing
+int slam_kpset_remove(slam_ctx *ctx, slam_kpset *ks, const uint8_t *flags_dev)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && flags_dev != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return kpset_compact(ctx, ks, 1, flags_dev);
+}
+
+int slam_kpset_triangulate(slam_ctx *ctx, slam_kpset *ks, const double *P1, const double *P2, const double *T21,
+                           const double *cam1, const double *cam2, const double *Twc, double max_error, double min_depth, int n_bound)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && P1 && P2 && T21 && cam1 && cam2 && Twc);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    KTriArgs T;
+    memcpy(T.P1, P1, sizeof T.P1); memcpy(T.P2, P2, sizeof T.P2); memcpy(T.T21, T21, sizeof T.T21);
+    memcpy(T.cam1, cam1, sizeof T.cam1); memcpy(T.cam2, cam2, sizeof T.cam2);
+    T.max_error = max_error; T.min_depth = min_depth;
+    int rc = kpset_stage_params(ctx, ks, Twc, (size_t)ks->S * 16, &T.Twc);
+    if (rc) return rc;
+    rc = kpset_build_worklist(ctx, ks);
+    if (rc) return rc;
+    const int nb = n_bound > 0 && n_bound < ks->S * ks->cap ? n_bound : ks->S * ks->cap;
+    hipLaunchKernelGGL(k_kpset_triangulate, dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, view_of(ks), T, (const int *)ks->work, (const int *)ks->ntot);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLAM_OK;
+}
+
+}  // extern "C"

@@ -400,6 +400,142 @@ __global__ __launch_bounds__(64) void k_flow_match(FlowArgs F)
     }
 }
 
+// ---- optical_flow_matching! on a device-resident keypoint set (slam_kpset, kpset.hip) ------------------------------
+// The per-point body is k_flow_match's; inputs come from, and results go to, the set's device arrays (no host lists):
+//   temporal (map_manager.jl:451-564, stereo = false): a 3-D keypoint whose projection lies outside the image is skipped
+//     (st = 2: kept as it is); otherwise 3-D prior attempt on `levels3d` levels, then the 2-D attempt; st = 1 + new
+//     position in oyx, or st = 0 (lost: removed by the compaction that follows);
+//   stereo (stereo = true): a 3-D keypoint projected outside the right image loses its observation (st = 0); a match must
+//     pass maybe_stereo_update! (:579-590: |row - undistorted right row| <= epipolar_error) and is stored as
+//     (left row, right column) in syx with stereo = 1; the keypoint itself always stays (st = 2).
+// Per-stream parameters (32 doubles per stream, staged by the host): [0..15] Tcw of the TARGET camera (column-major),
+// [16..19] fx fy cx cy, [20..23] k1 k2 p1 p2 of the target camera, [24..25] prior shift (y, x).
+struct KpMatchArgs {
+    PyrView from, to; size_t zs_from, zs_to;
+    int pyramid_levels, levels3d, window, iterations; double eig_thr, eps, max_distance;
+    double *yx, *oyx, *syx; const double *xyz; const uint8_t *is3d; uint8_t *st, *stereo; int cap;
+    const int *work, *ntot;
+    int prior;                 // 0: prior = the pixel itself, 1: projection of the map point (pose-based), 2: pixel + per-stream shift
+    const double *par;
+    int H, W, stereo_mode; double epipolar;
+};
+// undistort_pdn_point (camera.jl:111-125): normalised (y, x) -> pixel through the lens model
+__device__ __forceinline__ void pdn_to_pixel(const double *cam, const double *dist, double ny, double nx, double &oy, double &ox)
+{
+    const double s0 = ny * ny, s1 = nx * nx, r2 = s0 + s1;
+    const double rd = 1.0 + dist[0] * r2 + dist[1] * (r2 * r2);
+    const double p = ny * nx;
+    const double dtx = 2 * dist[2] * p + dist[3] * (r2 + 2 * s0);
+    const double dty = dist[2] * (r2 + 2 * s1) + 2 * dist[3] * p;
+    oy = (rd * ny + dty) * cam[1] + cam[3]; ox = (rd * nx + dtx) * cam[0] + cam[2];
+}
+template <int LK_MAXE>
+__global__ __launch_bounds__(64) void k_kpset_match(KpMatchArgs M)
+{
+    const int ntot = M.ntot[0], per = (ntot + LK_XCDS - 1) / LK_XCDS;
+    const int slotx = (int)(blockIdx.x / LK_XCDS);
+    const int idx = (int)(blockIdx.x % LK_XCDS) * per + slotx;     // each XCD a contiguous eighth of the (spatially ordered) list
+    if (slotx >= per || idx >= ntot) return;
+    const size_t q = (size_t)M.work[idx];
+    const int s = (int)(q / M.cap);
+    const double *P = M.par + 32 * (size_t)s;
+    const double py = M.yx[2 * q], px = M.yx[2 * q + 1];
+    const bool is3 = M.is3d[q] != 0;
+    double pry = py, prx = px;
+    if (is3) {
+        if (M.prior == 1) {
+            const double X0 = M.xyz[3 * q], X1 = M.xyz[3 * q + 1], X2 = M.xyz[3 * q + 2];
+            const double cx = ((P[0] * X0 + P[4] * X1) + P[8] * X2) + P[12];
+            const double cy = ((P[1] * X0 + P[5] * X1) + P[9] * X2) + P[13];
+            const double cz = ((P[2] * X0 + P[6] * X1) + P[10] * X2) + P[14];
+            pdn_to_pixel(P + 16, P + 20, cy / cz, cx / cz, pry, prx);                  // project_undistort (camera.jl:79-82)
+        } else if (M.prior == 2) { pry = py + P[24]; prx = px + P[25]; }
+    }
+    const bool inside = 1 <= pry && pry <= (double)M.H && 1 <= prx && prx <= (double)M.W;   // in_image (camera.jl:90-92)
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    if (is3 && !inside) {
+        if (lane0) { M.st[q] = M.stereo_mode ? 0 : 2; if (M.stereo_mode) M.stereo[q] = 0; }
+        return;
+    }
+    const size_t offF = (size_t)s * M.zs_from, offT = (size_t)s * M.zs_to;
+    double ny = nan(""), nx = nan("");
+    bool ok = false;
+    for (int att = is3 ? 0 : 1; att < 2 && !ok; att++) {
+        double dy = 0.0, dx = 0.0;
+        if (att == 0) {
+            const double scale = 1.0 / (double)(1 << M.levels3d);
+            dy = scale * (pry - py); dx = scale * (prx - px);                                        // map_manager.jl:494,504
+        }
+        ok = fb_point<LK_MAXE>(M.from, M.to, py, px, dy, dx, att == 0 ? M.levels3d : M.pyramid_levels, M.window, M.iterations, M.eig_thr, M.eps,
+                               M.max_distance, ny, nx, offF, offT);
+    }
+    if (!lane0) return;
+    if (!M.stereo_mode) {
+        M.oyx[2 * q] = ok ? ny : nan(""); M.oyx[2 * q + 1] = ok ? nx : nan("");
+        M.st[q] = ok ? 1 : 0;
+    } else {
+        if (ok) {                                                                                    // maybe_stereo_update!
+            double uy, ux;
+            pdn_to_pixel(P + 16, P + 20, (ny - P[19]) / P[17], (nx - P[18]) / P[16], uy, ux);      // undistort_point (camera.jl:98-103)
+            if (fabs(py - uy) > M.epipolar) ok = false;
+        }
+        if (ok) { M.syx[2 * q] = py; M.syx[2 * q + 1] = nx; }
+        M.stereo[q] = ok ? 1 : 0;
+        M.st[q] = 2;
+    }
+}
+
+static int kpset_match(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *from0, const slam_pyr *to0, const double *params,
+                       int prior, int pyramid_levels, int levels3d, int window, int iterations, double eig_thr, double eps,
+                       double max_distance, int stereo_mode, double epipolar, int n_bound)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && from0 != nullptr && to0 != nullptr);
+    ARG_TRY(ctx, from0->batch_index == 0 && to0->batch_index == 0 && from0->batch_size >= ks->S && to0->batch_size >= ks->S);
+    ARG_TRY(ctx, pyramid_levels >= 0 && levels3d >= 0 && window >= 0 && iterations >= 0 && prior >= 0 && prior <= 2 && (prior == 0 || params != nullptr));
+    const int need = pyramid_levels > levels3d ? pyramid_levels : levels3d;
+    if (!(from0->levels > need && to0->levels > need)) return slam_fail(ctx, SLAM_ERR_LAYERS, "Not enough layers in pyramids.");
+    ARG_TRY(ctx, from0->H[0] == to0->H[0] && from0->W[0] == to0->W[0]);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    KpMatchArgs M;
+    M.from = from0->view; M.to = to0->view; M.zs_from = from0->zstride; M.zs_to = to0->zstride;
+    M.pyramid_levels = pyramid_levels; M.levels3d = levels3d; M.window = window; M.iterations = iterations;
+    M.eig_thr = eig_thr; M.eps = eps; M.max_distance = max_distance;
+    M.yx = ks->yx; M.oyx = ks->oyx; M.syx = ks->syx; M.xyz = ks->xyz; M.is3d = ks->is3d; M.st = ks->st; M.stereo = ks->stereo; M.cap = ks->cap;
+    M.work = ks->work; M.ntot = ks->ntot; M.prior = prior; M.H = from0->H[0]; M.W = from0->W[0]; M.stereo_mode = stereo_mode; M.epipolar = epipolar;
+    std::vector<double> zero;
+    if (!params) { zero.assign((size_t)ks->S * 32, 0.0); for (int s = 0; s < ks->S; s++) { zero[32 * s + 16] = zero[32 * s + 17] = 1.0; } params = zero.data(); }
+    int rc = kpset_stage_params(ctx, ks, params, (size_t)ks->S * 32, &M.par);
+    if (rc) return rc;
+    rc = kpset_build_worklist(ctx, ks);
+    if (rc) return rc;
+    const int nmax = ks->S * ks->cap;
+    const int nb = n_bound > 0 && n_bound < nmax ? n_bound : nmax;
+    { ProfScope span(ctx, "fb_track");
+      const int ne = (2 * window + 1) * (2 * window + 1);
+      if (ne <= 192) hipLaunchKernelGGL(k_kpset_match<3>, dim3(lk_grid(nb)), dim3(64), 0, ctx->stream, M);
+      else if (ne <= 384) hipLaunchKernelGGL(k_kpset_match<6>, dim3(lk_grid(nb)), dim3(64), 0, ctx->stream, M);
+      else hipLaunchKernelGGL(k_kpset_match<9>, dim3(lk_grid(nb)), dim3(64), 0, ctx->stream, M); }
+    HIP_TRY(ctx, hipGetLastError());
+    return kpset_compact(ctx, ks, 0, nullptr);                   // lost keypoints (st = 0) leave the lists; stable
+}
+
+// optical_flow_matching!(map_manager, frame, from, to, false) for the S streams of the set (enqueue only).
+// params: S x 32 doubles (layout above) or NULL (prior 0); n_bound: an upper bound of the number of live keypoints known to the
+// host (sizes the launch; <= 0: S x cap)
+extern "C" int slam_kpset_flow_match(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *from0, const slam_pyr *to0, const double *params, int prior,
+                                     int pyramid_levels, int pyramid_levels_3d, int window, int iterations, double eig_thr, double eps,
+                                     double max_distance, int n_bound)
+{
+    return kpset_match(ctx, ks, from0, to0, params, prior, pyramid_levels, pyramid_levels_3d, window, iterations, eig_thr, eps, max_distance, 0, 0.0, n_bound);
+}
+// optical_flow_matching!(..., stereo = true): left0 -> right0; params describe the RIGHT camera
+extern "C" int slam_kpset_stereo_match(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *left0, const slam_pyr *right0, const double *params, int prior,
+                                       int pyramid_levels, int pyramid_levels_3d, int window, int iterations, double eig_thr, double eps,
+                                       double max_distance, double epipolar_error, int n_bound)
+{
+    return kpset_match(ctx, ks, left0, right0, params, prior, pyramid_levels, pyramid_levels_3d, window, iterations, eig_thr, eps, max_distance, 1, epipolar_error, n_bound);
+}
+
 static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 #define LK_STAGE_MIN_POINTS 4096
 

@@ -1,0 +1,117 @@
+"""Device-resident keypoint lists of S lock-stepped streams (slam_kpset, include/slamhip.h): the arrays behind
+Frame.keypoints (src/frame.jl) for the calls of the front-end / mapper hot path -- optical_flow_matching!
+(src/map_manager.jl:451-564), extract_keypoints! (:98-113), triangulate_stereo! (src/mapper.jl:142-183) -- kept in HBM
+between calls.  Only `counts()`, `upload()` and `download()` touch the host."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def stream_params(S, Tcw=None, cam=None, dist=None, shift_yx=None):
+    """S x 32 per-stream call parameters: [0..15] Tcw (column-major), [16..19] fx fy cx cy, [20..23] k1 k2 p1 p2, [24..25] shift."""
+    p = np.zeros((S, 32))
+    p[:, 16:18] = 1.0
+    if Tcw is not None:
+        T = np.asarray(Tcw, dtype=np.float64).reshape(-1, 4, 4)
+        p[:, :16] = np.broadcast_to(T, (S, 4, 4)).transpose(0, 2, 1).reshape(S, 16)       # column-major
+    if cam is not None:
+        p[:, 16:20] = np.asarray(cam, dtype=np.float64)
+    if dist is not None:
+        p[:, 20:24] = np.asarray(dist, dtype=np.float64)
+    if shift_yx is not None:
+        p[:, 24:26] = np.asarray(shift_yx, dtype=np.float64).reshape(-1, 2)
+    return np.ascontiguousarray(p)
+
+
+class KeypointSet:
+    def __init__(self, S, cap, ctx=None):
+        self.ctx = ctx or L.default_context()
+        self.S, self.cap = S, cap
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.slam_kpset_create(self.ctx.h, S, cap, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.slam_kpset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host <-> device (initialisation, tests, host consumers) ----
+    def upload(self, s, yx, is_3d, xyz=None, ids=None, ctx=None):
+        c = ctx or self.ctx
+        yx = np.ascontiguousarray(yx, dtype=np.float64).reshape(-1, 2)
+        f = np.ascontiguousarray(np.asarray(is_3d).astype(np.uint8))
+        x = None if xyz is None else np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        i = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+        c.check(c.lib.slam_kpset_upload(c.h, self.h, s, L.ptr(yx), L.ptr(f, L.u8p), L.ptr(x) if x is not None else None,
+                                        L.ptr(i, L.i64p) if i is not None else None, len(yx)))
+
+    def download(self, s, ctx=None):
+        """dict(yx, is_3d, xyz, ids, stereo_yx, has_stereo) of stream s"""
+        c = ctx or self.ctx
+        cap = self.cap
+        yx = np.empty((cap, 2)); f = np.empty(cap, np.uint8); xyz = np.empty((cap, 3)); ids = np.empty(cap, np.int64)
+        syx = np.empty((cap, 2)); hs = np.empty(cap, np.uint8); n = C.c_int(0)
+        c.check(c.lib.slam_kpset_download(c.h, self.h, s, L.ptr(yx), L.ptr(f, L.u8p), L.ptr(xyz), L.ptr(ids, L.i64p), L.ptr(syx),
+                                          L.ptr(hs, L.u8p), cap, C.byref(n)))
+        k = n.value
+        return dict(yx=yx[:k].copy(), is_3d=f[:k].astype(bool), xyz=xyz[:k].copy(), ids=ids[:k].copy(), stereo_yx=syx[:k].copy(),
+                    has_stereo=hs[:k].astype(bool))
+
+    def counts(self, ctx=None):
+        """the S list lengths: the one small device -> host copy of a step (synchronises the context's stream)"""
+        c = ctx or self.ctx
+        out = np.zeros(self.S, dtype=np.int32)
+        c.check(c.lib.slam_kpset_counts(c.h, self.h, L.ptr(out, L.i32p)))
+        return out
+
+    # ---- enqueue-only calls ----
+    def flow_match(self, from_batch, to_batch, params, stream_params_=None, prior=0, pyramid_levels_3d=1, iterations=30, n_bound=0, ctx=None):
+        c = ctx or self.ctx
+        sp = None if stream_params_ is None else np.ascontiguousarray(stream_params_, dtype=np.float64)
+        rc = c.lib.slam_kpset_flow_match(c.h, self.h, from_batch.pyramids[0].h, to_batch.pyramids[0].h, L.ptr(sp) if sp is not None else None,
+                                         prior, params.pyramid_levels, pyramid_levels_3d, params.window_size, iterations, 1e-4, 1e-2,
+                                         float(params.max_ktl_distance), int(n_bound))
+        if rc == -3:
+            raise RuntimeError("Not enough layers in pyramids.")
+        c.check(rc)
+
+    def stereo_match(self, left_batch, right_batch, params, stream_params_=None, prior=0, pyramid_levels_3d=1, iterations=30,
+                     epipolar_error=2.0, n_bound=0, ctx=None):
+        c = ctx or self.ctx
+        sp = None if stream_params_ is None else np.ascontiguousarray(stream_params_, dtype=np.float64)
+        rc = c.lib.slam_kpset_stereo_match(c.h, self.h, left_batch.pyramids[0].h, right_batch.pyramids[0].h, L.ptr(sp) if sp is not None else None,
+                                           prior, params.pyramid_levels, pyramid_levels_3d, params.window_size, iterations, 1e-4, 1e-2,
+                                           float(params.max_ktl_distance), float(epipolar_error), int(n_bound))
+        if rc == -3:
+            raise RuntimeError("Not enough layers in pyramids.")
+        c.check(rc)
+
+    def remove(self, flags_dev_ptr, ctx=None):
+        """flags_dev_ptr: device pointer to S x cap bytes (1 = remove), e.g. torch_tensor.data_ptr()"""
+        c = ctx or self.ctx
+        c.check(c.lib.slam_kpset_remove(c.h, self.h, C.c_void_p(flags_dev_ptr)))
+
+    def detect(self, e, batch, sigma_mask=3.0, min_response=1e-4, ctx=None):
+        c = ctx or self.ctx
+        c.check(c.lib.slam_kpset_detect(c.h, self.h, batch.pyramids[0].h, e.max_points, e.radius, e.grid_resolution[0], e.grid_resolution[1],
+                                        e.cell_size, float(sigma_mask), float(min_response)))
+
+    def triangulate(self, cam1, cam2, T21, Twc, max_error, min_depth=0.1, n_bound=0, ctx=None):
+        from .triangulation import projection_matrices
+        c = ctx or self.ctx
+        P1, P2 = projection_matrices(cam1, cam2, T21)
+        P1 = np.asfortranarray(P1); P2 = np.asfortranarray(P2); T = np.asfortranarray(T21, dtype=np.float64)
+        c1 = np.ascontiguousarray(cam1, dtype=np.float64); c2 = np.ascontiguousarray(cam2, dtype=np.float64)
+        W = np.asarray(Twc, dtype=np.float64).reshape(-1, 4, 4)
+        W = np.ascontiguousarray(np.broadcast_to(W, (self.S, 4, 4)).transpose(0, 2, 1).reshape(self.S, 16))
+        c.check(c.lib.slam_kpset_triangulate(c.h, self.h, L.ptr(P1), L.ptr(P2), L.ptr(T), L.ptr(c1), L.ptr(c2), L.ptr(W),
+                                             float(max_error), float(min_depth), int(n_bound)))

@@ -1,0 +1,150 @@
+"""GPU: the device-resident keypoint set (slam_kpset_*) against the host protocol it replaces -- the same steps through the
+batch seams with numpy list surgery in between (slam_flow_match_batch_kept, numpy cull, slam_detect_batch + merge,
+slam_flow_match_batch for the stereo pair, slam_triangulate) -- element for element, and against the CPU oracle's
+optical_flow_matching! restatement."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(slam, texture, S, H, W, levels=3):
+    import torch
+    streams = [texture(H, W, seed=30 + s, step=(1.0 + 0.2 * s, -1.4), disparity=6.3) for s in range(S)]
+    a = slam.PyramidBatch((H, W), levels=levels, S=S); b = slam.PyramidBatch((H, W), levels=levels, S=S); r = slam.PyramidBatch((H, W), levels=levels, S=S)
+    dev = lambda k, f: [torch.from_numpy(np.ascontiguousarray(st[k][f].T)).cuda() for st in streams]
+    d0, d1, dr = dev(0, 0), dev(0, 1), dev(1, 1)
+    torch.cuda.synchronize()
+    a.update_([d.data_ptr() for d in d0]); b.update_([d.data_ptr() for d in d1]); r.update_([d.data_ptr() for d in dr])
+    return streams, a, b, r, (d0, d1, dr)
+
+
+def test_keyframe_step_equals_host_protocol(slam, orc, syn, texture):
+    import torch
+    S, H, W = 3, 120, 160
+    streams, a, b, r, keep = _setup(slam, texture, S, H, W)
+    params = slam.Params(stereo=True, max_nb_keypoints=150)
+    cam = slam.Camera(*syn.KITTI_CAM, height=H, width=W)
+    e = slam.Extractor.from_params(params, cam)
+    ncell = e.grid_resolution[0] * e.grid_resolution[1]
+    cap = params.max_nb_keypoints + ncell + 8
+    rng = np.random.default_rng(5)
+    # initial lists: detected keypoints of frame 0, some 3-D, some at hopeless places (borders), ragged counts
+    kps, is3, sid = [], [], []
+    for s in range(S):
+        k = orc.detect(streams[s][0][0], np.zeros((0, 2)), max_points=60 + 20 * s).astype(float)
+        k = np.concatenate([k, np.array([[1.0, 1.0], [H, W], [2.5, W - 1.5]])])
+        kps.append(k); is3.append(rng.random(len(k)) < 0.5); sid.append(np.full(len(k), s, np.int32))
+    ks = slam.KeypointSet(S, cap)
+    for s in range(S):
+        ks.upload(s, kps[s], is3[s])
+    shift = np.array([streams[s][2][1] for s in range(S)])                       # per-stream prior shift (the true flow)
+    sp = slam.stream_params(S, cam=syn.KITTI_CAM, shift_yx=shift)
+    # ---- temporal match ----
+    ks.flow_match(a, b, params, sp, prior=2)
+    P = np.concatenate(kps); T = np.concatenate(is3); I = np.concatenate(sid)
+    proj = P + shift[I]
+    inside = (proj[:, 0] >= 1) & (proj[:, 0] <= H) & (proj[:, 1] >= 1) & (proj[:, 1] <= W)
+    skip = T & ~inside                                                           # map_manager.jl:501-506: left as they are
+    hk, h3, hs, hsrc = slam.optical_flow_matching_batch_kept(a, b, I[~skip], P[~skip], T[~skip], proj[~skip], params)
+    # host list surgery: survivors + skipped ones, in input order
+    pos = np.full((len(P), 2), np.nan); alive = np.zeros(len(P), bool)
+    idx_ns = np.flatnonzero(~skip)
+    pos[idx_ns[hsrc]] = hk; alive[idx_ns[hsrc]] = True
+    pos[skip] = P[skip]; alive[skip] = True
+    cnt = ks.counts()
+    for s in range(S):
+        m = (I == s) & alive
+        got = ks.download(s)
+        assert cnt[s] == m.sum() == len(got["yx"]), s
+        assert np.array_equal(got["yx"], pos[m]) and np.array_equal(got["is_3d"], T[m]), s
+        # and against the CPU oracle's optical_flow_matching! restatement
+        ra, rb = orc.pyr_build(streams[s][0][0], 3, 1.0, 1), orc.pyr_build(streams[s][0][1], 3, 1.0, 1)
+        ref = orc.optical_flow_matching(ra, rb, kps[s], is3[s], kps[s] + shift[s], (H, W), sum_order=1)
+        keep_ref = ~ref["removed"]
+        assert np.array_equal(keep_ref, alive[I == s]), s
+        assert np.abs(got["yx"] - ref["new_pixels"][keep_ref]).max() <= 1e-9, s
+    P, T, I = pos[alive], T[alive], I[alive]
+    # ---- cull (flags in HBM) ----
+    flags = np.zeros((S, cap), np.uint8)
+    for s in range(S):
+        n = int(cnt[s]); flags[s, :n] = rng.random(n) < 0.2
+    fdev = torch.from_numpy(flags).cuda(); torch.cuda.synchronize()
+    ks.remove(fdev.data_ptr())
+    keepm = np.concatenate([flags[s, :int(cnt[s])] == 0 for s in range(S)])
+    P, T, I = P[keepm], T[keepm], I[keepm]
+    # ---- detect + merge ----
+    ks.detect(e, b)
+    fresh, fsid = slam.detect_batch(e, b, P, I)
+    cnt2 = ks.counts()
+    lists = []
+    for s in range(S):
+        cur = P[I == s]; new = fresh[fsid == s].astype(float)
+        lists.append((np.concatenate([cur, new]), np.concatenate([T[I == s], np.zeros(len(new), bool)])))
+        got = ks.download(s)
+        assert cnt2[s] == len(lists[s][0]), s
+        assert np.array_equal(got["yx"], lists[s][0]) and np.array_equal(got["is_3d"], lists[s][1]), s
+        assert len(np.unique(got["ids"])) == len(got["ids"])
+    assert sum(len(l[0]) for l in lists) > len(P)                                # something was detected
+    # ---- stereo match (left = b, right = r) + epipolar gate ----
+    sps = slam.stream_params(S, cam=syn.KITTI_CAM, shift_yx=np.tile([0.0, -6.3], (S, 1)))
+    ks.stereo_match(b, r, params, sps, prior=2)
+    for s in range(S):
+        kp, t3 = lists[s]
+        res = slam.optical_flow_matching_frame(b.pyramids[s], r.pyramids[s], kp, t3, kp + np.array([0.0, -6.3]), params, (H, W), stereo=True,
+                                               undistorted_left=kp, right_cam=syn.KITTI_CAM)
+        got = ks.download(s)
+        keep_s = ~res["removed"]
+        assert np.array_equal(got["yx"], kp[keep_s]), s                          # positions untouched, out-of-image 3-D observations removed
+        assert np.array_equal(got["has_stereo"], res["updated"][keep_s]), s
+        up = got["has_stereo"]
+        assert np.array_equal(got["stereo_yx"][up], res["new_pixels"][keep_s][up]), s
+        assert up.mean() > 0.3
+        lists[s] = (kp[keep_s], t3[keep_s], got["stereo_yx"], up)
+    # ---- triangulation of the 2-D keypoints with a stereo match ----
+    T21 = np.eye(4); T21[0, 3] = -0.54                                           # right camera 0.54 m to the right of the left one
+    Twc = np.eye(4); Twc[:3, 3] = [1.0, 2.0, 3.0]
+    ks.triangulate(syn.KITTI_CAM, syn.KITTI_CAM, T21, Twc, max_error=3.0)
+    for s in range(S):
+        kp, t3, syx, up = lists[s]
+        got = ks.download(s)
+        cand = up & ~t3
+        xyz, ok = slam.triangulate(syn.KITTI_CAM, syn.KITTI_CAM, T21, kp[cand], syx[cand], 3.0)
+        exp3 = t3.copy(); exp3[np.flatnonzero(cand)[ok]] = True
+        exps = up.copy(); exps[np.flatnonzero(cand)[~ok]] = False
+        assert np.array_equal(got["is_3d"], exp3) and np.array_equal(got["has_stereo"], exps), s
+        world = xyz[ok] + Twc[:3, 3]
+        assert np.abs(got["xyz"][np.flatnonzero(cand)[ok]] - world).max() <= 1e-9 * max(1.0, np.abs(world).max()), s
+        assert ok.any()
+
+
+def test_pose_prior_and_capacity(slam, syn, texture):
+    """prior = 1: the projection of the map point through Tcw and the lens model; full lists are not extended by detect."""
+    S, H, W = 2, 120, 160
+    streams, a, b, r, keep = _setup(slam, texture, S, H, W)
+    params = slam.Params(stereo=True, max_nb_keypoints=40)
+    cam = slam.Camera(*syn.KITTI_CAM, height=H, width=W)
+    e = slam.Extractor.from_params(params, cam)
+    cap = 40 + e.grid_resolution[0] * e.grid_resolution[1]
+    fx, fy, cx, cy = syn.KITTI_CAM
+    rng = np.random.default_rng(1)
+    ks = slam.KeypointSet(S, cap)
+    kp = np.stack([rng.uniform(25, H - 25, 45), rng.uniform(25, W - 25, 45)], 1)
+    z = rng.uniform(5, 30, 45)
+    flow = np.array(streams[0][2][1])
+    tgt = kp + flow                                                              # where the map point should project in the new frame
+    xyz = np.stack([(tgt[:, 1] - cx) / fx * z, (tgt[:, 0] - cy) / fy * z, z], 1)  # camera = world (Tcw = I)
+    for s in range(S):
+        ks.upload(s, kp, np.ones(45, bool), xyz=xyz)
+    sp = slam.stream_params(S, Tcw=np.eye(4), cam=syn.KITTI_CAM)
+    ks.flow_match(a, b, params, sp, prior=1)
+    got = ks.download(0)
+    new, st = slam.optical_flow_matching(a.pyramids[0], b.pyramids[0], kp, np.ones(45, bool), tgt, params)
+    assert st.sum() == len(got["yx"]) and np.abs(got["yx"] - new[st]).max() <= 1e-9    # the device projects xyz itself: the prior agrees to rounding
+    # stream 1 is at / above max_points after re-upload: detect must not append to it
+    ks.upload(0, kp[:10], np.zeros(10, bool)); ks.upload(1, kp[:41], np.zeros(41, bool))
+    ks.detect(e, b)
+    c = ks.counts()
+    assert c[1] == 41 and c[0] > 10
+    ref = slam.detect(e, b.pyramids[0], kp[:10])
+    assert np.array_equal(ks.download(0)["yx"][10:], ref.astype(float))
