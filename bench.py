@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the stereo front-end hot path (LK pyramid update,
-forward-backward LK, key-frame detect + stereo LK) on MI355X, plus local-BA
-ms/iteration, against the HBM roofline, with the CPU oracle timed beside it.
+forward-backward LK, key-frame detect + stereo LK + triangulation) on MI355X,
+plus local-BA ms/iteration, against the HBM roofline, with the CPU oracle timed
+beside it.
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (the driver launches N>1 through torch.distributed.run).
-A step = one frame of EACH of S lock-stepped, independent synthetic
-KITTI-05-shaped stereo streams (370 x 1226, 1000 keypoints, key-frame every
-5th frame) through the hot path -- one batch of S frames per pass, every launch
-shared by the S streams (slam_pyr_update_batch_dev / slam_flow_match_batch /
-slam_detect_batch), images already resident in HBM as Float64, all planes
-bit-exact.  value = frames/s over all streams and GPUs.  The single-stream
-(latency) numbers of the same workload are reported beside it.  N>1 = N
-independent replicas (the front-end does not shard: SURVEY 8e) -> weak scaling,
-no collective in the data path.  Rank 0 prints ONE JSON line.
+One process per GPU (a launcher's WORLD_SIZE / RANK are honoured; without one,
+`--gpus N` starts the N rank processes itself).  A step = one frame of EACH of S
+lock-stepped, independent synthetic KITTI-05-shaped stereo streams (370 x 1226,
+1000 keypoints, key-frame every 5th frame) through the hot path -- one batch of
+S frames per pass, every launch shared by the S streams, keypoint lists
+resident in HBM (slam_kpset_*).  The frames of a step START IN PINNED HOST
+MEMORY as the decoder's 8-bit images and are copied to the GPU inside the timed
+loop; all arithmetic is Float64 and every plane bit-exact.  value = frames/s
+over all streams and GPUs; the device-resident and host-Float64 ingest
+configurations and the single-stream (latency) numbers are reported beside it.
+N>1 = N independent replicas (the front-end does not shard: SURVEY 8e) -> weak
+scaling, no collective in the data path.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -317,6 +320,249 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
     return res
 
 
+def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, right, flows, disparity, params, extractor, world, dist, dev, ingest,
+                       hook=None, seed=1234):
+    """The headline configuration: S streams in lock-step, keypoints resident in HBM (slam_kpset_*), no host list work
+    between the calls of a step; the host sees the S list lengths once per step.
+
+    ingest: where a step's frames start --
+      "host_u8"  pinned host memory, 8-bit as the KITTI reader decodes them (example/kitty/kitty.jl:52-102): one H2D copy of
+                 the step's S frames on the pyramid stream, converted on the device (slam_pyr_update_batch_u8_dev);
+      "host_f64" pinned host memory as Matrix{Gray{Float64}} (what the Julia seam receives, SLAM.jl:250): 8x the bytes;
+      "dev_f64"  already in HBM as Float64 (round-1 headline).
+    Stream s plays the ping-pong sequence shifted by s frames, so a step's S frames are a contiguous window of the
+    periodic sequence: one copy per step."""
+    import ctypes as C
+    ctx, ctx_pyr, ctx_right, ctx_copy = slam.Context(local_rank), slam.Context(local_rank), slam.Context(local_rank), slam.Context(local_rank)
+    levels = params.pyramid_levels
+    AHEAD = 1
+    NLB = AHEAD + 3                                          # previous, current, AHEAD being built, one more being copied
+    lb = [slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx) for _ in range(NLB)]
+    rb = slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx)
+    built = [None] * NLB
+    copied = [None] * NLB; rcopied = [None]; rbuilt = [None]
+    ncell = extractor.grid_resolution[0] * extractor.grid_resolution[1]
+    cap = extractor.max_points + ncell + 8
+    ks = slam.KeypointSet(S, cap, ctx=ctx)
+    period = 2 * N_FRAMES - 2
+    seq = frame_sequence(period + S + 2)
+    u8 = ingest == "host_u8"
+    np_dtype, t_dtype, fbytes = (np.uint8, torch.uint8, H * W) if u8 else (np.float64, torch.float64, H * W * 8)
+    conv = (lambda im: np.round(im * 255).astype(np.uint8)) if u8 else (lambda im: im)
+    # the periodic frame sequence, contiguous (row-major (W, H) = Julia's column-major H x W)
+    def seq_tensor(frames):
+        a = np.stack([np.ascontiguousarray(conv(frames[seq[k]]).T) for k in range(period + S)])
+        return torch.from_numpy(a)
+    lseq, rseq = seq_tensor(left), seq_tensor(right)
+    host = ingest != "dev_f64"
+    if host:
+        lseq, rseq = lseq.pin_memory(), rseq.pin_memory()
+        lstage = [torch.empty((S, W, H), dtype=t_dtype, device=dev) for _ in range(NLB)]
+        rstage = torch.empty((S, W, H), dtype=t_dtype, device=dev)
+        st_copy = torch.cuda.ExternalStream(ctx_copy.stream, device=dev)         # H2D copies on their own stream, one step ahead of the builds
+    else:
+        lseq, rseq = lseq.to(dev), rseq.to(dev)
+    torch.cuda.synchronize()
+    flows_a = np.asarray(flows, dtype=np.float64); seq_a = np.asarray(seq)
+    rng = np.random.default_rng(seed)
+    st_main = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(seed + local_rank)
+    cull_u = torch.empty(S * cap, dtype=torch.float32, device=dev)      # allocated on torch's own stream: nothing is allocated inside the
+    cull_flags = torch.zeros(S * cap, dtype=torch.bool, device=dev)     # library-stream contexts below (the caching allocator would keep using that stream)
+    ev_pool = [(slam.Event(ctx_pyr, timed=True), slam.Event(ctx_pyr, timed=True)) for _ in range(48)]
+    ev_used = []
+
+    def ptrs(base_tensor):
+        b = base_tensor.data_ptr()
+        return [b + s * fbytes for s in range(S)]
+
+    def enqueue_copy(frame):
+        """the step's S left frames: pinned host -> staging slot, behind the last build that read the slot"""
+        slot = frame % NLB
+        if built[slot] is not None:
+            ctx_copy.wait_event(built[slot])
+        with torch.cuda.stream(st_copy):
+            lstage[slot].copy_(lseq[frame % period:frame % period + S], non_blocking=True)
+        copied[slot] = ctx_copy.record(copied[slot])
+
+    def enqueue_build(frame, timed=False):
+        slot = frame % NLB
+        o = frame % period
+        if host:
+            ctx_pyr.wait_event(copied[slot])
+            src = ptrs(lstage[slot])
+        else:
+            src = ptrs(lseq[o:o + S])
+        if timed:
+            pair = ev_pool[len(ev_used) % len(ev_pool)]
+            ctx_pyr.record(pair[0])
+        lb[slot].update_(src, sync=False, ctx=ctx_pyr, u8=u8)
+        if timed:
+            ctx_pyr.record(pair[1]); ev_used.append(pair)
+        built[slot] = ctx_pyr.record(built[slot])
+
+    def enqueue_right_copy(frame):
+        if rbuilt[0] is not None:
+            ctx_copy.wait_event(rbuilt[0])
+        with torch.cuda.stream(st_copy):
+            rstage.copy_(rseq[frame % period:frame % period + S], non_blocking=True)
+        rcopied[0] = ctx_copy.record(rcopied[0])
+
+    def enqueue_right(frame):
+        o = frame % period
+        if host:
+            ctx_right.wait_event(rcopied[0])
+            src = ptrs(rstage)
+        else:
+            src = ptrs(rseq[o:o + S])
+        rb.update_(src, sync=False, ctx=ctx_right, u8=u8)
+        rbuilt[0] = ctx_right.record(rbuilt[0])
+
+    nxt = [0]; nxc = [0]
+    def build_up_to(frame, timed=False):
+        if host:
+            while nxc[0] <= frame + 1:                       # copies run one frame ahead of the builds
+                enqueue_copy(nxc[0]); nxc[0] += 1
+        while nxt[0] <= frame:
+            enqueue_build(nxt[0], timed); nxt[0] += 1
+
+    from slam_jl_amd import synthetic as syn_
+    camt = tuple(syn_.KITTI_CAM)
+    baseline = disparity * 30.0 / camt[0]                    # a scene 30 m away: d = fx b / z
+    T21 = np.eye(4); T21[0, 3] = -baseline
+    Twc = np.eye(4)
+    sp_stereo = slam.stream_params(S, cam=camt, shift_yx=np.tile([0.0, -disparity], (S, 1)))
+    state = dict(n_bound=0, tracked=0, tracked_steps=0, timed=False)
+    if host:
+        enqueue_right_copy(1)                               # step 1 is a key-frame
+    build_up_to(AHEAD)
+    ctx_pyr.synchronize(); ctx_copy.synchronize()
+
+    def step(i):
+        kf = (i - 1) % KF_EVERY == 0
+        prevb, curb = lb[(i - 1) % NLB], lb[i % NLB]
+        if kf:
+            enqueue_right(i)
+        if host and i % KF_EVERY == 0:                      # the next step is a key-frame: its right frames start travelling now
+            enqueue_right_copy(i + 1)
+        ctx.wait_event(built[i % NLB])                      # tracking needs the build of frame i only
+        build_up_to(i + AHEAD, state["timed"])              # the next frame's copy + build overlap this step's tracking
+        if state["n_bound"] > 0:
+            # motion-model prior: the stream's image-plane shift, ~0.5 px off (project_world_to_image_distort of the map points
+            # under the predicted pose; the synthetic streams are image-plane translations)
+            shift = flows_a[seq_a[(i % period) + np.arange(S)]] - flows_a[seq_a[((i - 1) % period) + np.arange(S)]]
+            sp = slam.stream_params(S, cam=camt, shift_yx=shift + rng.normal(0, 0.5, (S, 2)))
+            ks.flow_match(prevb, curb, params, sp, prior=2, n_bound=state["n_bound"], ctx=ctx)
+        if kf:
+            # map culling between key-frames (outlier observations dropped by BA, failed triangulations): flags drawn in HBM
+            with torch.cuda.stream(st_main):
+                cull_u.uniform_(generator=gen)
+                torch.lt(cull_u, CULL_FRACTION, out=cull_flags)                 # bool = one byte per slot, 1 = remove
+            ks.remove(cull_flags.data_ptr(), ctx=ctx)
+            ks.detect(extractor, curb, ctx=ctx)
+            ctx.wait_for(ctx_right)
+            ks.stereo_match(curb, rb, params, sp_stereo, prior=2, ctx=ctx)
+            ks.triangulate(camt, camt, T21, Twc, max_error=3.0, ctx=ctx)
+        cnt = ks.counts(ctx=ctx)                            # the one device -> host copy of the step (synchronises)
+        tot = int(cnt.sum())
+        if not kf and state["n_bound"] > 0:
+            state["tracked"] += tot; state["tracked_steps"] += 1
+        state["n_bound"] = tot
+        if hook is not None:
+            hook()
+
+    def drain():
+        ctx_copy.synchronize(); ctx_pyr.synchronize(); ctx_right.synchronize(); ctx.synchronize(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    warm = max(warmup, 6)
+    for i in range(1, 1 + warm):
+        step(i)
+    state["tracked"] = 0; state["tracked_steps"] = 0
+    drain(); state["timed"] = True; t0 = time.perf_counter()
+    for i in range(1 + warm, 1 + warm + steps):
+        step(i)
+    drain(); dt = time.perf_counter() - t0
+    state["timed"] = False
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    builds = [a.elapsed_ms(b) for a, b in ev_used[-len(ev_pool):]]      # left builds of the timed region (graph replays on the pyramid stream)
+    res = {"ingest": ingest, "streams_per_gpu": S, "steps": steps, "value": world * S * steps / dt, "unit": "frames/sec", "seconds": dt,
+           "ms_per_step_of_S_frames": dt / steps * 1e3,
+           "tracked_kpts_per_frame": round(state["tracked"] / max(state["tracked_steps"], 1) / S, 1),
+           "pyramid_build_ms": {"mean": float(np.mean(builds)) if builds else None, "min": float(np.min(builds)) if builds else None,
+                                "n": len(builds), "what": "hipEvents around each left-batch build (ingest kernel + one hipGraph replay) on the pyramid "
+                                                          "stream inside the timed region, tracking running beside it"}}
+    for c in (ctx, ctx_pyr, ctx_right, ctx_copy):
+        c.synchronize()
+    torch.cuda.synchronize()
+    ks.close()
+    for e2 in ev_pool:
+        e2[0].close(); e2[1].close()
+    for m in built + copied + rcopied + rbuilt:
+        if m is not None:
+            m.close()
+    for b_ in lb + [rb]:
+        for p_ in b_.pyramids:
+            p_.close()
+    del lseq, rseq, cull_u, cull_flags
+    if host:
+        del lstage, rstage, st_copy
+    del st_main
+    for c in (ctx, ctx_pyr, ctx_right, ctx_copy):
+        c.close()
+    return res
+
+
+def kernel_spans(slam, torch, local_rank, S, H, W, left, params, dev):
+    """Per-kernel device time of the batched build with serial launches (hipEvent spans cannot look inside the graph)."""
+    ctx = slam.Context(local_rank)
+    pb = slam.PyramidBatch((H, W), levels=params.pyramid_levels, S=S, ctx=ctx)
+    seq = frame_sequence(S + 2)
+    t = torch.from_numpy(np.stack([np.ascontiguousarray(left[seq[k]].T) for k in range(S)])).to(dev)
+    torch.cuda.synchronize()
+    ptrs = [t.data_ptr() + s * H * W * 8 for s in range(S)]
+    pb.update_(ptrs, sync=True, ctx=ctx)
+    ea, eb = slam.Event(ctx, timed=True), slam.Event(ctx, timed=True)
+    ctx.record(ea)
+    for _ in range(20):                                      # the stage alone on the GPU: graph replays back to back
+        pb.update_(ptrs, sync=False, ctx=ctx)
+    ctx.record(eb)
+    isolated_us = ea.elapsed_ms(eb) / 20 * 1e3
+    ea.close(); eb.close()
+    ctx.prof_enable(True); ctx.prof_reset()
+    for _ in range(20):
+        pb.update_(ptrs, sync=False, ctx=ctx)
+    ctx.synchronize()
+    rows_ms, rows_n = ctx.prof_get("k_iir_rows"); pyr_ms, pyr_n = ctx.prof_get("pyr_update")
+    ctx.prof_enable(False)
+    ctx.close()
+    return rows_ms / max(rows_n, 1) * 1e3, pyr_ms / max(pyr_n, 1) * 1e3, isolated_us
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: N fresh processes, one per GPU (this process never initialises HIP)."""
+    import socket
+    import subprocess
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    procs = []
+    one_gpu = os.environ.get("SLAM_BENCH_ONE_GPU") is not None      # test hook: all ranks share GPU 0, collectives over gloo (scripts/two_rank_one_gpu.sh)
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if one_gpu else str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if one_gpu:
+            env["SLAM_BENCH_BACKEND"] = "gloo"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -328,13 +574,18 @@ def main():
     ap.add_argument("--no-tolerance", action="store_true", help="skip the tolerance-mode measurements")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU; it starts N fresh rank processes (one per GPU,
+        # the same environment the torch.distributed.run launcher gives them), forwards rank 0's line and exits with their status
+        raise SystemExit(spawn_ranks(args))
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -363,38 +614,74 @@ def main():
     S = args.streams
     levels = params.pyramid_levels
 
-    # ---- headline: S lock-stepped streams per GPU, bit-exact planes, every launch shared by the S streams ----
-    head = run_lockstep(slam, torch, local_rank, S, args.steps, args.warmup, H, W, left_dev, right_dev, flows, disparity,
-                        params, extractor, False, world, dist, dev)
+    def leg_done(tag):
+        """every leg leaves the device clean: an asynchronous HIP error is reported against the leg that caused it"""
+        try:
+            torch.cuda.synchronize()
+        except Exception as ex:
+            raise RuntimeError(f"bench leg '{tag}' left a HIP error: {ex}") from ex
+
+    # ---- headline: S lock-stepped streams per GPU, keypoints resident in HBM, bit-exact planes.  Three ingest configurations;
+    #      `value` is the one a deployment sees (frames arrive in host memory as the decoder's 8-bit images) ----
+    legs = {}
+    for ingest in ("host_u8", "dev_f64", "host_f64"):
+        n_steps = args.steps if ingest == "host_u8" else max(40, args.steps // 3)
+        legs[ingest] = run_lockstep_kpset(slam, torch, local_rank, S, n_steps, args.warmup if ingest == "host_u8" else min(args.warmup, 10), H, W,
+                                          left, right, flows, disparity, params, extractor, world, dist, dev, ingest)
+    leg_done("lockstep_kpset")
+    head = legs["host_u8"]
+    rows_us, serial_us, isolated_us = kernel_spans(slam, torch, local_rank, S, H, W, left, params, dev)
+    pb = S * pyramid_bytes(H, W, levels)
+    build_ms = head["pyramid_build_ms"]["mean"]
+    rb_bytes = S * iir_rows_bytes(H, W, levels) / (levels + 1)
     out = {
         "metric": "frames/sec KITTI-05 stereo @1k kpts; local-BA ms/iter for 50-KF window",
         "value": head["value"], "unit": "frames/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step_of_S_frames"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "KITTI-05-shaped stereo streams 370x1226 f64, 1000 kpts/frame, key-frame every 5th frame: "
+        "config": {"workload": "KITTI-05-shaped stereo streams 370x1226, 1000 kpts/frame, key-frame every 5th frame: "
                                "left pyramid update + FB-LK (3-D prior pass + 2-D pass) per frame; "
-                               "detect + right pyramid + stereo FB-LK per key-frame (BASELINE configs[1]); "
-                               f"one step = one frame of each of {S} independent streams",
+                               "detect + right pyramid + stereo FB-LK + stereo triangulation per key-frame (BASELINE configs[1]); "
+                               f"one step = one frame of each of {S} independent streams; frames START IN PINNED HOST MEMORY as the decoder's "
+                               "8-bit images and are copied to the GPU inside the timed loop (one H2D copy per step on the pyramid stream), "
+                               "converted to Float64 on the device; all arithmetic Float64",
+                   "frames_start": "pinned host memory, uint8 (example/kitty/kitty.jl:52-102 decode) -- copied H2D inside the timed region",
                    "streams_per_gpu": S, "frames_per_step": S, "parallelism": f"replicas x{world}",
                    "pyramid_mode": "bit-exact (slam_pyr_update mode 1 arithmetic; planes identical to the CPU oracle)",
                    "batching": "the S streams advance in lock-step and share every launch: pyramids live in slam_pyr_create_batch batches "
-                               "(grid.z = stream), all keypoints are tracked by one slam_flow_match_batch launch, key-frame detection is one "
-                               "slam_detect_batch launch; 3 HIP streams (tracking/detect; left pyramids; right pyramids), the next frame's "
-                               "pyramid build (one hipGraph replay) overlaps the current frame's tracking",
+                               "(grid.z = stream); the keypoint lists live in HBM (slam_kpset_*): tracking + removal of lost keypoints, culling, "
+                               "key-frame detection + merge, stereo matching and triangulation are enqueue-only calls, the host reads the S list "
+                               "lengths once per step; 3 HIP streams (tracking/detect; left pyramids; right pyramids), the next frame's copy + "
+                               "pyramid build (one hipGraph replay) overlap the current frame's tracking",
                    "tracked_kpts_per_frame": head["tracked_kpts_per_frame"],
                    "window_size": params.window_size, "pyramid_levels": levels,
                    "cull_fraction_per_keyframe": CULL_FRACTION},
-        "roofline": dict(head["roofline"], kernel="k_iir_rows (dim-2 IIR Gaussian pass of the LK pyramid, one launch for the S images of a step; "
-                                                  "the pyramid build is ~70 % of the device time of a step, this is its largest kernel)"),
-        "pyramid_batch_update_serial_us": head["pyramid_batch_update_serial_us"],
+        "ingest": {k: {"value": v["value"], "ms_per_step_of_S_frames": v["ms_per_step_of_S_frames"], "steps": v["steps"],
+                       "pyramid_build_ms_mean": v["pyramid_build_ms"]["mean"]} for k, v in legs.items()},
+        # the dominant stage (>= 60 % of the device time of a step): the LK pyramid update of the S images of a step.  algorithmic bytes =
+        # SURVEY 8(d): 7 planes x 8 B x sum_l H_l W_l per image; duration = hipEvents around the build on the stream it runs on, in the
+        # timed region (ingest kernel + hipGraph replay of the ~20 kernels of the build), tracking kernels running beside it
+        "roofline": {"bound": "hbm", "stage": f"LK pyramid update of {S} images (pyramid.jl:81-137 + lucas_kanade.jl:109-138): ingest + one hipGraph replay",
+                     "isolated_launch_us": isolated_us, "frac_isolated": pb / (isolated_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "achieved": pb / (build_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": pb / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "frac_of_achievable": pb / (build_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, "achievable_peak": HBM_ACHIEVABLE_GBS,
+                     "algorithmic_bytes_per_launch": pb, "avg_launch_us": build_ms * 1e3, "launches_timed": head["pyramid_build_ms"]["n"],
+                     "min_launch_us": head["pyramid_build_ms"]["min"] * 1e3, "serial_launches_us": serial_us,
+                     "traffic": None,
+                     "kernel": {"name": "k_iir_rows_ck (dim-2 IIR pass, largest kernel of the build; algorithmic = 1R + 1W of every plane it filters)",
+                                "avg_launch_us": rows_us, "algorithmic_bytes_per_launch": rb_bytes,
+                                "achieved": rb_bytes / (rows_us * 1e-6) / 1e9, "frac": rb_bytes / (rows_us * 1e-6) / 1e9 / HBM_PEAK_GBS}},
     }
-    pmc = os.path.join(ROOT, "profiles", "r01m_pmc_pyramid_batch.json")
-    if SHAPE == "kitti05" and os.path.exists(pmc):
-        j = json.load(open(pmc))
-        if j.get("streams") == S:
-            out["roofline"]["traffic"] = j["summary"]["k_iir_rows_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r01m_pmc_pyramid_batch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 corrected)"
+    for cand in ("r02b_pmc_pyramid_batch.json", "r02a_pmc_pyramid_batch.json"):
+        pmc = os.path.join(ROOT, "profiles", cand)
+        if SHAPE == "kitti05" and os.path.exists(pmc):
+            j = json.load(open(pmc))
+            if j.get("streams") == S:
+                out["roofline"]["traffic"] = j["summary"]["all_pyramid_kernels_bytes_per_batch_build"]
+                out["roofline"]["traffic_source"] = f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 corrected), all kernels of one {S}-image build"
+                break
 
     # ---- the same workload as ONE stream (latency view): 3 contexts, pipelined next-frame pyramid ----
     n1 = min(args.steps, 300)
@@ -463,14 +750,22 @@ def main():
             single["roofline"]["traffic"] = json.load(open(pmc1))["summary"]["k_iir_rows_bytes_per_launch"]
             single["roofline"]["traffic_source"] = "profiles/r01_pmc_pyramid.json"
     out["single_stream"] = single
+    leg_done("single_stream")
 
-    # ---- tolerance-mode pyramid (mode 3: parallel recurrences, planes within 1e-11 rel.): batched and single ----
+    # ---- the round-1 call protocol (keypoint lists on the host, numpy list surgery between the batch seams), frames resident in HBM:
+    #      what the device-resident keypoint sets replaced ----
+    hp = run_lockstep(slam, torch, local_rank, S, max(40, args.steps // 4), min(args.warmup, 10), H, W, left_dev, right_dev, flows, disparity,
+                      params, extractor, False, world, dist, dev)
+    out["host_protocol"] = {"value": hp["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": hp["ms_per_step_of_S_frames"],
+                            "what": "slam_flow_match_batch_kept / slam_detect_batch with host keypoint lists, frames resident in HBM as Float64 "
+                                    "(compare ingest.dev_f64)"}
+
+    leg_done("host_protocol")
+    # ---- tolerance-mode pyramid (mode 3: parallel recurrences, planes within 1e-11 rel.), single stream (batches of >= 4 images take
+    #      the bit-exact kernels in this mode too) ----
     if not args.no_tolerance:
-        tol = run_lockstep(slam, torch, local_rank, S, max(40, args.steps // 4), min(args.warmup, 10), H, W, left_dev, right_dev, flows, disparity,
-                           params, extractor, True, world, dist, dev)
-        out["tolerance_mode"] = dict(tol, pyramid="slam_pyr_update mode 3 (parallel recurrences; planes <= 1e-11 relative, tracked positions <= 1e-7 px vs "
-                                                  "the bit-exact mode: tests/test_gpu_pyramid.py::test_fast_mode_within_tolerance); the segmented kernels serve "
-                                                  "single-image latency - batches of >= 4 images take the bit-exact kernels in this mode too")
+        out["tolerance_mode"] = {"pyramid": "slam_pyr_update mode 3 (parallel recurrences; planes <= 1e-11 relative, tracked positions <= 1e-7 px vs "
+                                            "the bit-exact mode: tests/test_gpu_pyramid.py::test_fast_mode_within_tolerance)"}
         fctx = [slam.Context(local_rank) for _ in range(3)]
         fbe = GpuBackend(slam, fctx[0], fctx[1], fctx[2], H, W, left_dev, right_dev, params, extractor, fast=True)
         fs = Stream(fbe, flows, disparity, seed=rank)
@@ -491,6 +786,7 @@ def main():
         for c in fctx:
             c.close()
 
+    leg_done("tolerance_mode")
     # ---- BA: 50-KF window (BASELINE metric), single GPU; sharded over all ranks when N > 1 -------------
     if not args.no_ba:
         s = syn.ba_scene(P=50, M=10000, seed=7)
@@ -502,16 +798,26 @@ def main():
         out["ba"] = {"window_kf": 50, "observations": int(s["O"]), "points": int(s["M"]), "lm_iterations": iters,
                      "ms_per_iter": cache.stats["device_ms"] / max(iters, 1), "wall_ms_total": wall * 1e3,
                      "ssr_final": cache.stats["ssr_final"]}
-        if world > 1:
-            from slam_jl_amd import sharded_ba
-            s2 = syn.ba_scene(P=100, M=40000, seed=8)
+        leg_done("ba")
+        from slam_jl_amd import sharded_ba
+        try:
+            # the point-sharded driver (slam_ba_lm_* + RCCL through slam_comm_*): device-paced, one all-reduce + one all-gather per iteration
+            sP, sM = (100, 40000) if world > 1 else (50, 10000)
+            s2 = syn.ba_scene(P=sP, M=sM, seed=8 if world > 1 else 7)
             sharded_ba.sharded_bundle_adjustment(s2["cam"], s2["theta0"], s2["theta_const"], s2["pixels_yx"], s2["pose_ids"], s2["point_ids"])
             barrier(); t0 = time.perf_counter()
             _, _, st = sharded_ba.sharded_bundle_adjustment(s2["cam"], s2["theta0"], s2["theta_const"], s2["pixels_yx"], s2["pose_ids"], s2["point_ids"])
             barrier(); wall = time.perf_counter() - t0
-            out["ba_sharded"] = {"window_kf": 100, "observations": int(s2["O"]), "world_size": world,
-                                 "ms_per_iter_wall": wall * 1e3 / max(st["iters_pass1"] + st["iters_pass2"], 1),
-                                 "worth_sharding": bool(sharded_ba.worth_sharding(100, s2["O"], world)), "ssr_final": st["ssr_final"]}
+            out["ba_sharded"] = {"window_kf": sP, "observations": int(s2["O"]), "world_size": world,
+                                 "ms_per_iter_wall": (st["lm_wall_ms"] or wall * 1e3) / max(iters_fast_total := 15, 1),
+                                 "lm_iterations_enqueued": 15, "lm_iterations_effective": st["iters_pass1"] + st["iters_pass2"],
+                                 "whole_call_wall_ms": wall * 1e3,
+                                 "what": "wall clock of the two device-paced LM passes (enqueue of 5 + 10 iterations: build, RCCL all-reduce of the reduced system, "
+                                         "banded solve, all-gather of the trial costs, on-device decision; one host sync per pass) per iteration; the whole call "
+                                         "adds host partitioning, shard set-up and the RCCL communicator",
+                                 "worth_sharding": bool(sharded_ba.worth_sharding(sP, s2["O"], world)), "ssr_final": st["ssr_final"]}
+        except Exception as ex:                                   # never lose the line to the optional leg
+            out["ba_sharded"] = {"error": repr(ex)[:300], "world_size": world}
 
     # ---- compute_pose! arithmetic (front_end.jl:164-206): P3P RANSAC (256 triples, 1000 map points) + PnP refinement ----
     if not args.no_ba:
@@ -564,8 +870,8 @@ def main():
         if S == SB:
             # the tracked workload with the pose seams of all streams run after every step (pose inputs are independent
             # synthetic scenes of the same size: 1000 correspondences / map points per stream)
-            wp = run_lockstep(slam, torch, local_rank, S, max(20, args.steps // 4), min(args.warmup, 10), H, W, left_dev, right_dev, flows, disparity,
-                              params, extractor, False, world, dist, dev, hook=pose_batch_once)
+            wp = run_lockstep_kpset(slam, torch, local_rank, S, max(20, args.steps // 4), min(args.warmup, 10), H, W, left, right, flows, disparity,
+                                    params, extractor, world, dist, dev, "host_u8", hook=pose_batch_once)
             out["pose"]["frontend_with_pose"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": wp["ms_per_step_of_S_frames"],
                                                  "what": "headline workload + slam_five_point_ransac_batch + slam_p3p_ransac_batch + slam_pnp_ba_batch every step"}
 

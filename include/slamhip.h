@@ -62,6 +62,9 @@ int  slam_event_create(slam_ctx *ctx, slam_event **out);
 int  slam_event_record(slam_ctx *ctx, slam_event *e);
 int  slam_ctx_wait_event(slam_ctx *ctx, slam_event *e);
 int  slam_event_destroy(slam_event *e);
+/* the same with timing enabled: a pair brackets a stage on a context's stream; slam_event_elapsed_ms waits for `b` */
+int  slam_event_create_timed(slam_ctx *ctx, slam_event **out);
+int  slam_event_elapsed_ms(slam_event *a, slam_event *b, double *ms);
 /* the ctx's hipStream_t (as void*), for callers that record HIP events on it */
 void *slam_ctx_stream(slam_ctx *ctx);
 /* message of the last failing call on ctx (ctx == NULL: last ctx-less failure) */

@@ -7,7 +7,7 @@ The Julia `ccall` shim with the same surface is julia/SLAMHip.jl.
 
 There is no CPU fallback: every function here runs hand-written HIP kernels
 and raises if the library / a HIP device is unavailable."""
-from ._lib import Context, SlamHipError, default_context, load, LIB_PATH  # noqa: F401
+from ._lib import Context, Event, SlamHipError, default_context, load, LIB_PATH  # noqa: F401
 from .params import Camera, Params  # noqa: F401
 from .extractor import Extractor, detect, detect_batch, describe, brief_pattern  # noqa: F401
 from .optical_flow import (LKPyramid, LucasKanade, update_, copy_, deepcopy, has_gradients, fb_tracking_,  # noqa: F401

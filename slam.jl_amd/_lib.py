@@ -27,6 +27,8 @@ SIGNATURES = {
     "slam_event_record": (cint, [vp, vp]),
     "slam_ctx_wait_event": (cint, [vp, vp]),
     "slam_event_destroy": (cint, [vp]),
+    "slam_event_create_timed": (cint, [vp, C.POINTER(vp)]),
+    "slam_event_elapsed_ms": (cint, [vp, vp, C.POINTER(dbl)]),
     "slam_last_error": (C.c_char_p, [vp]),
     "slam_version": (C.c_char_p, []),
     "slam_prof_enable": (cint, [vp, cint]),
@@ -206,11 +208,19 @@ def default_context(device=0):
 class Event:
     """slam_event: a point in a context's stream that other contexts can wait on (Context.record / wait_event)."""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, timed=False):
         self.lib = ctx.lib
         h = C.c_void_p()
-        ctx.check(ctx.lib.slam_event_create(ctx.h, C.byref(h)))
+        ctx.check((ctx.lib.slam_event_create_timed if timed else ctx.lib.slam_event_create)(ctx.h, C.byref(h)))
         self.h = h
+
+    def elapsed_ms(self, later):
+        """milliseconds from this (timed) event to `later`, both recorded; waits for `later`"""
+        ms = C.c_double(0.0)
+        rc = self.lib.slam_event_elapsed_ms(self.h, later.h, C.byref(ms))
+        if rc != 0:
+            raise SlamHipError(f"slam_event_elapsed_ms failed ({rc}): {self.lib.slam_last_error(None).decode()}")
+        return ms.value
 
     def close(self):
         if getattr(self, "h", None):

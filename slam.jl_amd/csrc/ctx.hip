@@ -170,6 +170,29 @@ int slam_event_create(slam_ctx *ctx, slam_event **out)
     *out = e;
     return SLAM_OK;
 }
+// event with timing enabled: a pair of them brackets a stage on a context's stream (slam_event_elapsed_ms)
+int slam_event_create_timed(slam_ctx *ctx, slam_event **out)
+{
+    ARG_TRY(ctx, ctx != nullptr && out != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    slam_event *e = new slam_event();
+    e->device = ctx->device;
+    hipError_t rc = hipEventCreate(&e->ev);
+    if (rc != hipSuccess) { delete e; return slam_fail(ctx, SLAM_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(rc)); }
+    *out = e;
+    return SLAM_OK;
+}
+// milliseconds between two recorded timed events (waits for `b`)
+int slam_event_elapsed_ms(slam_event *a, slam_event *b, double *ms)
+{
+    if (!a || !b || !ms) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_event_elapsed_ms: NULL argument");
+    hipError_t rc = hipEventSynchronize(b->ev);
+    float f = 0.f;
+    if (rc == hipSuccess) rc = hipEventElapsedTime(&f, a->ev, b->ev);
+    if (rc != hipSuccess) return slam_fail(nullptr, SLAM_ERR_HIP, "slam_event_elapsed_ms: %s", hipGetErrorString(rc));
+    *ms = (double)f;
+    return SLAM_OK;
+}
 int slam_event_record(slam_ctx *ctx, slam_event *e)
 {
     ARG_TRY(ctx, ctx != nullptr && e != nullptr && e->device == ctx->device);

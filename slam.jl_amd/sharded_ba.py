@@ -108,6 +108,19 @@ class HipShard:
         ws = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         rank = dist.get_rank(group) if ws > 1 else 0
         idbuf = C.create_string_buffer(128)
+        # librccl prints a version banner on stdout when it initialises: keep the caller's stdout clean
+        import os
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            return self._make_comm(group, lib, ws, rank, idbuf, dist)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1); os.close(saved)
+
+    def _make_comm(self, group, lib, ws, rank, idbuf, dist):
         if rank == 0:
             self.ctx.check(lib.slam_comm_unique_id(idbuf))
         if ws > 1:
@@ -248,10 +261,14 @@ def sharded_bundle_adjustment(cam, theta, theta_const, pixels, pose_ids, point_i
         return ssr0, ssr, it
 
     device_paced = hasattr(shard, "lm_pass") and host_paced is not True
+    import time as _time
+    t_lm = 0.0
     if device_paced:
         # product path: RCCL through the C ABI on the library's own stream, LM decisions on the device
         shard.make_comm(group)
+        t0 = _time.perf_counter()
         _, ssr1, it1 = shard.lm_pass(0, iters_fast, True)
+        t_lm += _time.perf_counter() - t0
         st0 = np.zeros(8); shard.ctx.check(shard.ctx.lib.slam_ba_lm_state(shard.ctx.h, shard.h, L.ptr(st0)))
         ssr_init = st0[5]
     else:
@@ -259,7 +276,9 @@ def sharded_bundle_adjustment(cam, theta, theta_const, pixels, pose_ids, point_i
     n_out = torch.tensor([shard.flag_outliers(repr_eps)], dtype=torch.float64, device=shard.red.device if hasattr(shard, "red") else "cpu")
     _all_reduce(n_out, SUM, group)
     if device_paced:
+        t0 = _time.perf_counter()
         _, ssr2, it2 = shard.lm_pass(1, iterations, False)
+        t_lm += _time.perf_counter() - t0
     else:
         _, ssr2, it2 = run_pass(1, iterations)
     th_loc, ol_loc = shard.download()
@@ -276,7 +295,8 @@ def sharded_bundle_adjustment(cam, theta, theta_const, pixels, pose_ids, point_i
         theta_out[n + 3 * lo:n + 3 * hi] = th[n:]
         outl[s] = ol
     stats = dict(ssr_init=ssr_init, ssr_pass1=ssr1, ssr_final=ssr2, iters_pass1=it1, iters_pass2=it2,
-                 n_outliers=int(n_out[0]), world_size=ws, points_local=m_hi - m_lo, obs_local=len(sel))
+                 n_outliers=int(n_out[0]), world_size=ws, points_local=m_hi - m_lo, obs_local=len(sel),
+                 lm_wall_ms=t_lm * 1e3 if device_paced else None)
     if hasattr(shard, "close"):
         shard.close()
     return theta_out, outl, stats
