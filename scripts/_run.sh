@@ -1,14 +1,8 @@
-timeout 900 python -X faulthandler bench.py --steps 100 --warmup 10 --no-cpu > gpurun_out/r02n_bench.json 2> gpurun_out/r02n_bench.err
-echo rc=$?
-grep -v "^{" gpurun_out/r02n_bench.json | head -3; tail -6 gpurun_out/r02n_bench.err
-python - <<'PY'
-import json
-lines=[l for l in open('gpurun_out/r02n_bench.json').read().strip().splitlines() if l.startswith('{')]
-j=json.loads(lines[-1])
-print({k:(round(v,1) if isinstance(v,float) else v) for k,v in j.items() if k in ('value','ms_per_step')})
-print('ingest', {k:(round(v['value']), round(v['pyramid_build_ms_mean'],3)) for k,v in j['ingest'].items()})
-print('roofline frac', j['roofline']['frac'], 'build us', j['roofline']['avg_launch_us'], j['roofline']['min_launch_us'])
-print('host_protocol', j.get('host_protocol',{}).get('value'))
-print('single', j['single_stream']['value'], 'ba', j['ba']['ms_per_iter'])
-print('ba_sharded', j.get('ba_sharded'))
-PY
+python -m pytest tests/test_gpu_ba.py tests/test_gpu_edges.py tests/test_gpu_configs.py tests/test_golden.py -x -q 2>&1 | tail -3
+python scripts/prof_ba.py 50 10000 | tail -1
+python scripts/prof_ba.py 100 40000 | tail -1
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ba -o ba -- python3 $R/scripts/prof_ba.py 50 10000 > /dev/null 2>&1
+cd $R
+head -14 gpurun_out/prof_ba/ba_kernel_stats.csv | cut -c1-120
