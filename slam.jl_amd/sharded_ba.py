@@ -118,6 +118,7 @@ class HipShard:
             return self._make_comm(group, lib, ws, rank, idbuf, dist)
         finally:
             sys.stdout.flush()
+            C.CDLL(None).fflush(None)                        # the banner sits in C stdio's buffer: flush it while fd 1 still points at stderr
             os.dup2(saved, 1); os.close(saved)
 
     def _make_comm(self, group, lib, ws, rank, idbuf, dist):
