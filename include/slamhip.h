@@ -20,8 +20,14 @@
  *   - every call returns 0 on success, a negative slam_status on failure;
  *     slam_last_error(ctx) gives the message.  No C++ exception crosses the ABI;
  *   - one slam_ctx per calling task/thread (it owns a HIP stream and scratch);
- *     calls on one ctx are synchronous unless the name ends in `_async`;
- *     pyramid handles may be read by several contexts concurrently.
+ *     calls on one ctx are synchronous unless the name ends in `_async` or the
+ *     call has a `sync` argument / is documented as enqueue-only;
+ *     pyramid handles may be READ by several contexts concurrently.  A pyramid (or
+ *     a pyramid batch: its members share checkpoint scratch, the blur scratch
+ *     plane and the cached hipGraph of the build) is BUILT through one stream at a
+ *     time: enqueue its updates from one context, or order the contexts with
+ *     slam_ctx_wait_for / slam_event_* before switching -- concurrent builds of
+ *     one pyramid or of two members of one batch race on that scratch.
  */
 #ifndef SLAMHIP_H
 #define SLAMHIP_H

@@ -1427,7 +1427,8 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         // bandwidth-bound launches (many images x a large level) take the checkpointed IIR kernels; the column one squares
         // Iy / Ix itself, so the gradient kernel does not write (and the filter does not re-read) the Iyy / Ixx inputs
         const int np_ = has_next ? 4 : 3;
-        const bool ck_cols = !fast && p->ck != nullptr && mode != 0 && H >= 64 && (size_t)S * np_ * H * W * 8 >= ck_min_bytes() && getenv("SLAMHIP_NO_CK_COLS") == nullptr;
+        static const bool no_ck_cols = getenv("SLAMHIP_NO_CK_COLS") != nullptr;     // tuning toggles are read once per process: a cached graph never disagrees with them
+        const bool ck_cols = !fast && p->ck != nullptr && mode != 0 && H >= 64 && (size_t)S * np_ * H * W * 8 >= ck_min_bytes() && !no_ck_cols;
         static const bool no_sq = getenv("SLAMHIP_NO_SQ_FUSE") != nullptr;
         const bool fuse_sq = ck_cols && !no_sq;
         // ... and the fully fused dim-1 stage (Scharr + products + the four dim-1 recurrences straight from the layer)
@@ -1492,7 +1493,6 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         if (S >= 8 && !no_fused_cum && H <= CF_MAXW * 64) {                 // batches: one-pass integral image
             const int nw = (H + 63) / 64;
             const size_t lds = ((size_t)nw * CF_W * CF_LS + (size_t)nw * 2 * CF_W) * sizeof(double);
-            (void)hipFuncSetAttribute((const void *)k_cum_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             hipLaunchKernelGGL(k_cum_fused, dim3(1, 3, S), dim3(nw * 64), lds, aux, pc, H, W, P);
             continue;
         }
@@ -1582,6 +1582,8 @@ static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, 
     if (e == hipSuccess) e = slam_stream_wait(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(al->base); delete al; return slam_fail(ctx, SLAM_ERR_HIP, "slam_pyr_create: memset: %s", hipGetErrorString(e)); }
     al->refs = S;
+    // once per creation, outside any stream capture: k_cum_fused needs the > 64 KB dynamic-LDS opt-in
+    (void)hipFuncSetAttribute((const void *)k_cum_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     double *ckbuf = nullptr;
     if (S > 1) {   // checkpoint scratch of k_iir_rows_ck: (blocks x 3) doubles per line of the widest launch (level 0, 4 planes)
         const size_t lines = (size_t)S * 4 * (((size_t)Hs[0] + LINE_THREADS - 1) / LINE_THREADS) * LINE_THREADS;
