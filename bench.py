@@ -674,7 +674,7 @@ def main():
                                 "avg_launch_us": rows_us, "algorithmic_bytes_per_launch": rb_bytes,
                                 "achieved": rb_bytes / (rows_us * 1e-6) / 1e9, "frac": rb_bytes / (rows_us * 1e-6) / 1e9 / HBM_PEAK_GBS}},
     }
-    for cand in ("r02b_pmc_pyramid_batch.json", "r02a_pmc_pyramid_batch.json"):
+    for cand in ("r02c_pmc_pyramid_batch.json", "r02a_pmc_pyramid_batch.json"):
         pmc = os.path.join(ROOT, "profiles", cand)
         if SHAPE == "kitti05" and os.path.exists(pmc):
             j = json.load(open(pmc))

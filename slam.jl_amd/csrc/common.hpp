@@ -53,7 +53,7 @@ struct slam_pyr {
     int H[SLAM_MAX_LEVELS], W[SLAM_MAX_LEVELS];
     int P[SLAM_MAX_LEVELS];               // column pitch in doubles (H rounded up to 16)
     int64_t off[SLAM_MAX_LEVELS + 1];     // plane offsets in doubles (sum of P_l * W_l)
-    struct Alloc { double *base = nullptr; double *ck = nullptr; int refs = 0; };   // shared by the members of a batch
+    struct Alloc { double *base = nullptr; double *ck = nullptr; const void **srctab = nullptr; int refs = 0; };   // shared by the members of a batch; srctab: 64 source-image pointers (fused ingest)
     Alloc *alloc = nullptr;
     size_t zstride = 0;                   // doubles between consecutive images of a batch (7 * off[levels])
     int batch_index = 0, batch_size = 1;
@@ -63,7 +63,7 @@ struct slam_pyr {
     double *norm = nullptr;               // NA() normaliser per level (ctor mode), lazily built
     double norm_sigma = -1.0;
     // hipGraph replay of the build (captured lazily per (mode, sigma)); aux = forked stream
-    struct Graph { int mode; double sigma; int S; size_t ckmin; hipGraphExec_t exec; };
+    struct Graph { int mode; double sigma; int S; size_t ckmin; int src_kind; hipGraphExec_t exec; };
     std::vector<Graph> graphs;
     bool graph_failed = false;
     hipStream_t aux = nullptr;

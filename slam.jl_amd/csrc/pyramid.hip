@@ -661,6 +661,10 @@ struct ColsFusedArgs {
     double *T;                          // dim-1 blurred layer (scratch plane), nullptr at the last level
     double *Iy, *Ix, *Qyy, *Qxx, *Qyx;  // gradient planes; product planes (dim-1 filtered here, finished by the row pass)
     int H, W, P; size_t zs;
+    // level 0 with the ingest fused: the layer is read from the caller's dense column-major image of each stream (src_kind 1:
+    // Float64, 2: 8-bit, converted raw / 255 like k_gather_images_u8) through a device-side pointer table, and wave 0 writes the
+    // pitched layer plane on the way (src_kind 0: the layer plane itself, already ingested)
+    int src_kind; const void *const *srctab;
 };
 
 // x[0..N) holds the lane's layer samples of rows rb .. rb+N-1 on entry, the recurrence inputs of its role on exit
@@ -740,7 +744,7 @@ __device__ __forceinline__ void cf4_scharr8(const double *LB, double *IYB, doubl
 }
 
 template <int ROLE>
-__device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const IIRCoef &k, double *ck, double *LB, double *IYB, double *IXB, double *QB)
+__device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const IIRCoef &k, double *ck, double *LB, double *IYB, double *IXB, double *QB, const double *lut)
 {
     const int lane = threadIdx.x & 63, rp = lane & 7, cg = lane >> 3;
     const int H = A.H, W = A.W, P = A.P, n = H;
@@ -763,10 +767,40 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     const size_t lineid = (((size_t)blockIdx.z * nroles + (ROLE - (4 - nroles))) * gridDim.x + blockIdx.x) * LINE_THREADS + lane;
     const double a1 = k.a1, a2 = k.a2, a3 = k.a3, scale = k.scale;
     const int w = ROLE;                                           // wave index inside the workgroup
+    // the layer: the pitched plane, or (level 0, fused ingest) the stream's dense source image
+    const int skind = A.src_kind;
+    const void *simg = skind ? A.srctab[blockIdx.z] : nullptr;
+    auto src_at = [&](int row, int colx) -> double {              // dense source sample, indices in range; 8-bit: lut[v] = (double)v / 255.0 (k_gather_images_u8's conversion, tabulated)
+        return skind == 1 ? ((const double *)simg)[(size_t)row + (size_t)colx * H] : lut[((const unsigned char *)simg)[(size_t)row + (size_t)colx * H]];
+    };
+    auto ld_layer = [&](int row) -> double { return skind ? src_at(row, io.xown()) : io.ld_src(row); };
+    auto tile_layer = [&](int rb, double *t) {                    // rows rb + 2 rp, + 1 of columns x0 + 8 r + cg (the global tile layout)
+        if (!skind) { io.tile_load(io.src, rb, t); return; }
+        const int r0 = rb + 2 * rp < H ? rb + 2 * rp : H - 1;
+        const bool pair = rb + 2 * rp + 1 < H;                    // both rows exist: one load of two vertically adjacent samples
+        if (skind == 2) {
+            unsigned short v[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                int cx = xl + 8 * r + cg; cx = cx < W ? cx : W - 1;
+                const unsigned char *q = (const unsigned char *)simg + (size_t)r0 + (size_t)cx * H;
+                v[r] = pair ? (unsigned short)(q[0] | (q[1] << 8)) : (unsigned short)(q[0] | (q[0] << 8));
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) { t[2 * r] = lut[v[r] & 255]; t[2 * r + 1] = lut[v[r] >> 8]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                int cx = xl + 8 * r + cg; cx = cx < W ? cx : W - 1;
+                const double *q = (const double *)simg + (size_t)r0 + (size_t)cx * H;
+                t[2 * r] = q[0]; t[2 * r + 1] = pair ? q[1] : q[0];
+            }
+        }
+    };
     // recurrence input of a single row (boundary rows of the filter): the same arithmetic on scalar loads
     auto in_row = [&](int y) {
-        double v[1] = {io.ld_src(y)};
-        if (ROLE != 0) { double gdummy[1]; cf4_inputs<ROLE, 1>(v, io.ld_src(y > 0 ? y - 1 : 0), io.ld_src(y + 1 < H ? y + 1 : H - 1), y, H, edgeL, edgeR, gdummy); }
+        double v[1] = {ld_layer(y)};
+        if (ROLE != 0) { double gdummy[1]; cf4_inputs<ROLE, 1>(v, ld_layer(y > 0 ? y - 1 : 0), ld_layer(y + 1 < H ? y + 1 : H - 1), y, H, edgeL, edgeR, gdummy); }
         return v[0];
     };
     const double x0 = in_row(0);
@@ -783,16 +817,16 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     // layer row above the block, wave 3 the row below it
     auto prefetch = [&](int b) {
         const int rb = b << 5;
-        if (ROLE == 0) io.tile_load(io.src, rb, pre);
+        if (ROLE == 0) tile_layer(rb, pre);
         else if (ROLE == 1) {
-            if (2 * b + 1 < ntile) io.tile_load(io.src, rb + 16, pre);
+            if (2 * b + 1 < ntile) tile_layer(rb + 16, pre);
             else {
 #pragma unroll
                 for (int e = 0; e < 16; e++) pre[e] = 0.0;
             }
         }
-        else if (ROLE == 2) pre[0] = io.ld_src(rb > 0 ? rb - 1 : 0);
-        else pre[0] = io.ld_src(rb + 32 < H ? rb + 32 : H - 1);
+        else if (ROLE == 2) pre[0] = ld_layer(rb > 0 ? rb - 1 : 0);
+        else pre[0] = ld_layer(rb + 32 < H ? rb + 32 : H - 1);
     };
     auto publish = [&]() {                                        // phase 1: operands -> shared layer block
         if (ROLE <= 1) {
@@ -864,6 +898,18 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
         cf4_scharr8(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
         __syncthreads();
         if (active) read_inputs();
+        if (ROLE == 0 && skind) {                                 // fused ingest: the block's layer rows -> the pitched layer plane
+            ColIO<2> iol = io; iol.dst = const_cast<double *>(A.L) + z;
+            const int ghi = H - 1;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                if (t == 0 || (two && rb + 16 <= ghi)) {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) { const double2 q = *(const double2 *)(LB + (8 * r + cg) * CF4_LS + 2 + 16 * t + 2 * rp); u[2 * r] = q.x; u[2 * r + 1] = q.y; }
+                    iol.tile_store(rb + 16 * t, u, rb + 16 * t, ghi, rb + 16 * t + 15 > ghi);
+                }
+            }
+        }
         if (ROLE == 1 || ROLE == 2) {                             // Iy / Ix of the block -> their planes
             const double *blk = ROLE == 1 ? IYB : IXB;
             const int ghi = H - 1;
@@ -908,12 +954,14 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
 __global__ __launch_bounds__(256, 2) void k_cols_fused(ColsFusedArgs A, IIRPair cf, double *ck)
 {
     __shared__ __attribute__((aligned(16))) double sh[CF4_LDS_DOUBLES];
+    __shared__ double lut[256];                                  // 8-bit ingest: (double)v / 255.0
     double *LB = sh, *IYB = sh + 64 * CF4_LS, *IXB = IYB + 64 * CF4_GS, *QB = IXB + 64 * CF4_GS;
+    if (A.src_kind == 2) { lut[threadIdx.x] = (double)threadIdx.x / 255.0; __syncthreads(); }
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (w == 0) cols_fused_wave<0>(A, cf.c[0], ck, LB, IYB, IXB, QB);
-    else if (w == 1) cols_fused_wave<1>(A, cf.c[1], ck, LB, IYB, IXB, QB);
-    else if (w == 2) cols_fused_wave<2>(A, cf.c[1], ck, LB, IYB, IXB, QB);
-    else cols_fused_wave<3>(A, cf.c[1], ck, LB, IYB, IXB, QB);
+    if (w == 0) cols_fused_wave<0>(A, cf.c[0], ck, LB, IYB, IXB, QB, lut);
+    else if (w == 1) cols_fused_wave<1>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
+    else if (w == 2) cols_fused_wave<2>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
+    else cols_fused_wave<3>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
 }
 
 // integral_image!, lucas_kanade.jl:131-138: cumsum along dim 1 ...
@@ -1411,7 +1459,7 @@ static void seg_pow(const IIRPair &cf, int n, int SL, SegPow &sp)
 // with level l+1 (fork after the row pass, one join at the end).  With
 // aux == st everything is serial on one stream (profiling / fallback path).
 // mode 3 ("fast") swaps the sequential line kernels for the segmented ones.
-static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf, hipStream_t st, hipStream_t aux, bool spans, int S = 1)
+static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf, hipStream_t st, hipStream_t aux, bool spans, int S = 1, int src_kind = 0)
 {
     const size_t zs = p->zstride;
     const bool forked = aux != st;
@@ -1468,6 +1516,7 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             ColsFusedArgs ca;
             ca.L = v.L; ca.T = has_next ? T : nullptr; ca.Iy = v.Iy; ca.Ix = v.Ix; ca.Qyy = v.Iyy; ca.Qxx = v.Ixx; ca.Qyx = v.Iyx;
             ca.H = H; ca.W = W; ca.P = P; ca.zs = zs;
+            ca.src_kind = l == 0 ? src_kind : 0; ca.srctab = (const void *const *)p->alloc->srctab;
             hipLaunchKernelGGL(k_cols_fused, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, st, ca, cf, p->ck);
         }
         else if (ck_cols) hipLaunchKernelGGL(k_iir_cols_ck, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf, p->ck);
@@ -1503,12 +1552,27 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
     if (forked) { (void)hipEventRecord(p->ev_join, aux); (void)hipStreamWaitEvent(st, p->ev_join, 0); }
 }
 
+// level 0 of an S-image build runs k_cols_fused (which can ingest the source images itself): launch_build's conditions
+static bool level0_fused(const slam_pyr *p, int mode, int S)
+{
+    static const bool off = getenv("SLAMHIP_NO_COLS_FUSED") != nullptr || getenv("SLAMHIP_NO_SQ_FUSE") != nullptr || getenv("SLAMHIP_NO_CK_COLS") != nullptr ||
+                            getenv("SLAMHIP_NO_FUSED_INGEST") != nullptr;
+    if (off || mode == 0 || p->ck == nullptr || p->alloc->srctab == nullptr || p->H[0] < 64) return false;
+    if (mode == 3 && S < 4 && !(seg_len(p->H[0], PAR_T / 8) > PAR_SLMAX || seg_len(p->W[0], PAR_T / 8) > PAR_SLMAX)) return false;   // the segmented kernels
+    const int np_ = p->levels > 1 ? 4 : 3;
+    return (size_t)S * np_ * p->H[0] * p->W[0] * 8 >= ck_min_bytes();
+}
+__global__ void k_set_ptrs(const void **tab, ImgPtrs src)
+{
+    if (threadIdx.x < BATCH_MAX) tab[threadIdx.x] = src.p[threadIdx.x];
+}
+
 // Enqueue the whole pyramid build on ctx->stream; layer 0 must already hold the image.
 // Normal path: one hipGraph replay (captured once per (mode, sigma): two-stream
 // fork/join DAG, ~25 kernel nodes) -> one host launch instead of ~25.  With
 // profiling spans enabled (or SLAMHIP_NO_GRAPH=1) the same kernels are launched
 // directly, serially, so that per-kernel hipEvent spans are meaningful.
-static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma, int S = 1)
+static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma, int S = 1, int src_kind = 0)
 {
     IIRPair cf; cf.c[0] = slam_iir_coef(sigma); cf.c[1] = slam_iir_coef(4.0);   // lucas_kanade.jl:112
     if (mode == 0) { int rc = build_norm(ctx, p, sigma); if (rc) return rc; }
@@ -1516,13 +1580,13 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma, int
     static const bool no_graph = getenv("SLAMHIP_NO_GRAPH") != nullptr;
     if (ctx->prof_on || no_graph) {
         ProfScope span_all(ctx, "pyr_update");
-        launch_build(ctx, p, mode, cf, st, st, ctx->prof_on, S);
+        launch_build(ctx, p, mode, cf, st, st, ctx->prof_on, S, src_kind);
         HIP_TRY(ctx, hipGetLastError());
         return SLAM_OK;
     }
     hipGraphExec_t exec = nullptr;
     const size_t ckmin = ck_min_bytes();
-    for (auto &g : p->graphs) if (g.mode == mode && g.sigma == sigma && g.S == S && g.ckmin == ckmin) exec = g.exec;
+    for (auto &g : p->graphs) if (g.mode == mode && g.sigma == sigma && g.S == S && g.ckmin == ckmin && g.src_kind == src_kind) exec = g.exec;
     if (!exec && !p->graph_failed) {
         if (!p->aux) {
             HIP_TRY(ctx, hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
@@ -1532,16 +1596,16 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma, int
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
-            launch_build(ctx, p, mode, cf, st, p->aux, false, S);
+            launch_build(ctx, p, mode, cf, st, p->aux, false, S, src_kind);
             e = hipStreamEndCapture(st, &graph);
         }
         if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (graph) (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { (void)hipGetLastError(); p->graph_failed = true; exec = nullptr; }
-        else { slam_pyr::Graph g; g.mode = mode; g.sigma = sigma; g.S = S; g.ckmin = ckmin; g.exec = exec; p->graphs.push_back(g); }
+        else { slam_pyr::Graph g; g.mode = mode; g.sigma = sigma; g.S = S; g.ckmin = ckmin; g.src_kind = src_kind; g.exec = exec; p->graphs.push_back(g); }
     }
     if (exec) HIP_TRY(ctx, hipGraphLaunch(exec, st));
-    else launch_build(ctx, p, mode, cf, st, st, false, S);
+    else launch_build(ctx, p, mode, cf, st, st, false, S, src_kind);
     HIP_TRY(ctx, hipGetLastError());
     return SLAM_OK;
 }
@@ -1582,6 +1646,7 @@ static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, 
     if (e == hipSuccess) e = slam_stream_wait(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(al->base); delete al; return slam_fail(ctx, SLAM_ERR_HIP, "slam_pyr_create: memset: %s", hipGetErrorString(e)); }
     al->refs = S;
+    if (S > 1 && hipMalloc((void **)&al->srctab, 64 * sizeof(void *)) != hipSuccess) { (void)hipGetLastError(); al->srctab = nullptr; }
     // once per creation, outside any stream capture: k_cum_fused needs the > 64 KB dynamic-LDS opt-in
     (void)hipFuncSetAttribute((const void *)k_cum_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     double *ckbuf = nullptr;
@@ -1630,8 +1695,10 @@ int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double
     ImgPtrs ip;
     for (int s = 0; s < BATCH_MAX; s++) ip.p[s] = s < S ? images_dev[s] : nullptr;
     const size_t n = (size_t)p0->H[0] * p0->W[0];
-    hipLaunchKernelGGL(k_gather_images, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
-    int rc = enqueue_build(ctx, p0, mode, sigma, S);
+    const bool fused_ingest = level0_fused(p0, mode, S);          // the level-0 kernel reads the source images itself and writes the layer
+    if (fused_ingest) hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(64), 0, ctx->stream, p0->alloc->srctab, ip);
+    else hipLaunchKernelGGL(k_gather_images, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
+    int rc = enqueue_build(ctx, p0, mode, sigma, S, fused_ingest ? 1 : 0);
     if (rc) return rc;
     if (sync) HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
@@ -1648,8 +1715,10 @@ int slam_pyr_update_batch_u8_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const uin
     ImgPtrsU8 ip;
     for (int s = 0; s < BATCH_MAX; s++) ip.p[s] = s < S ? images_u8_dev[s] : nullptr;
     const size_t n = (size_t)p0->H[0] * p0->W[0];
-    hipLaunchKernelGGL(k_gather_images_u8, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
-    int rc = enqueue_build(ctx, p0, mode, sigma, S);
+    const bool fused_ingest = level0_fused(p0, mode, S);
+    if (fused_ingest) { ImgPtrs iq; for (int s = 0; s < BATCH_MAX; s++) iq.p[s] = (const double *)ip.p[s]; hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(64), 0, ctx->stream, p0->alloc->srctab, iq); }
+    else hipLaunchKernelGGL(k_gather_images_u8, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
+    int rc = enqueue_build(ctx, p0, mode, sigma, S, fused_ingest ? 2 : 0);
     if (rc) return rc;
     if (sync) HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
@@ -1660,7 +1729,7 @@ int slam_pyr_destroy(slam_pyr *p)
     if (!p) return SLAM_OK;
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
-    if (p->alloc && --p->alloc->refs == 0) { (void)hipFree(p->alloc->base); if (p->alloc->ck) (void)hipFree(p->alloc->ck); delete p->alloc; }
+    if (p->alloc && --p->alloc->refs == 0) { (void)hipFree(p->alloc->base); if (p->alloc->ck) (void)hipFree(p->alloc->ck); if (p->alloc->srctab) (void)hipFree(p->alloc->srctab); delete p->alloc; }
     if (p->norm) (void)hipFree(p->norm);
     for (auto &g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->aux) {
