@@ -333,7 +333,26 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
     Stream s plays the ping-pong sequence shifted by s frames, so a step's S frames are a contiguous window of the
     periodic sequence: one copy per step."""
     import ctypes as C
-    ctx, ctx_pyr, ctx_right, ctx_copy = slam.Context(local_rank), slam.Context(local_rank), slam.Context(local_rank), slam.Context(local_rank)
+    # optional chip partition (SLAM_BENCH_CU_SPLIT = "<n_track>[:pattern]"): the tracking / detect stream keeps n_track compute units,
+    # the pyramid streams the rest
+    split = os.environ.get("SLAM_BENCH_CU_SPLIT")
+    if split:
+        ncu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        nt = int(split.split(":")[0]); pat = split.split(":")[1] if ":" in split else "interleave"
+        if pat == "contig":
+            tmask = [1 if i < nt else 0 for i in range(ncu)]
+        else:                                                # spread over the enumeration in groups of 8
+            per8 = nt * 8 // ncu
+            tmask = [1 if (i % 8) < per8 else 0 for i in range(ncu)]
+        pmask = [1 - b for b in tmask]
+        ctx, ctx_pyr, ctx_right = slam.Context(local_rank, cu_mask=tmask), slam.Context(local_rank, cu_mask=pmask), slam.Context(local_rank, cu_mask=pmask)
+        ctx_copy = slam.Context(local_rank)
+    else:
+        # the tracking context's stream is in the high-priority class: a hardware queue of its own.  With four default-class streams
+        # the runtime placed the pyramid graph's small-level branch on the tracking stream's queue and every step's match sat behind
+        # it until the build was over (kernel trace, DESIGN 4); SLAM_BENCH_TRACK_PRIO=0 restores that for comparison.
+        prio = int(os.environ.get("SLAM_BENCH_TRACK_PRIO", "1"))
+        ctx, ctx_pyr, ctx_right, ctx_copy = slam.Context(local_rank, priority=prio), slam.Context(local_rank), slam.Context(local_rank), slam.Context(local_rank)
     levels = params.pyramid_levels
     AHEAD = 1
     NLB = AHEAD + 3                                          # previous, current, AHEAD being built, one more being copied
@@ -432,7 +451,7 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
     T21 = np.eye(4); T21[0, 3] = -baseline
     Twc = np.eye(4)
     sp_stereo = slam.stream_params(S, cam=camt, shift_yx=np.tile([0.0, -disparity], (S, 1)))
-    state = dict(n_bound=0, tracked=0, tracked_steps=0, timed=False)
+    state = dict(n_bound=0, tracked=0, tracked_steps=0, timed=False, wait_s=0.0)
     if host:
         enqueue_right_copy(1)                               # step 1 is a key-frame
     build_up_to(AHEAD)
@@ -463,7 +482,9 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
             ctx.wait_for(ctx_right)
             ks.stereo_match(curb, rb, params, sp_stereo, prior=2, ctx=ctx)
             ks.triangulate(camt, camt, T21, Twc, max_error=3.0, ctx=ctx)
+        t_enq = time.perf_counter()
         cnt = ks.counts(ctx=ctx)                            # the one device -> host copy of the step (synchronises)
+        state["wait_s"] += time.perf_counter() - t_enq      # host time spent waiting for the GPU (the rest of the step is enqueue work)
         tot = int(cnt.sum())
         if not kf and state["n_bound"] > 0:
             state["tracked"] += tot; state["tracked_steps"] += 1
@@ -480,7 +501,7 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
     for i in range(1, 1 + warm):
         step(i)
     state["tracked"] = 0; state["tracked_steps"] = 0
-    drain(); state["timed"] = True; t0 = time.perf_counter()
+    drain(); state["timed"] = True; state["wait_s"] = 0.0; t0 = time.perf_counter()
     for i in range(1 + warm, 1 + warm + steps):
         step(i)
     drain(); dt = time.perf_counter() - t0
@@ -492,6 +513,7 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
     builds = [a.elapsed_ms(b) for a, b in ev_used[-len(ev_pool):]]      # left builds of the timed region (graph replays on the pyramid stream)
     res = {"ingest": ingest, "streams_per_gpu": S, "steps": steps, "value": world * S * steps / dt, "unit": "frames/sec", "seconds": dt,
            "ms_per_step_of_S_frames": dt / steps * 1e3,
+           "host_wait_ms_per_step": state["wait_s"] / steps * 1e3,
            "tracked_kpts_per_frame": round(state["tracked"] / max(state["tracked_steps"], 1) / S, 1),
            "pyramid_build_ms": {"mean": float(np.mean(builds)) if builds else None, "min": float(np.min(builds)) if builds else None,
                                 "n": len(builds), "what": "hipEvents around each left-batch build (ingest kernel + one hipGraph replay) on the pyramid "

@@ -52,6 +52,12 @@ enum slam_status {
 
 /* ---- context --------------------------------------------------------------- */
 int  slam_ctx_create(int device, slam_ctx **out);
+/* the same, with the context's stream restricted to the compute units set in cu_mask (bit i of word i / 32 = CU i):
+ * partitions the chip between stages that run concurrently on different contexts */
+int  slam_ctx_create_cumask(int device, const uint32_t *cu_mask, int n_words, slam_ctx **out);
+/* the same, with the stream in its own scheduling class (priority > 0 high, < 0 low): its own hardware queue, which a
+ * replayed hipGraph's branches never share -- for the latency-critical stage of a multi-context pipeline */
+int  slam_ctx_create_priority(int device, int priority, slam_ctx **out);
 int  slam_ctx_destroy(slam_ctx *ctx);
 int  slam_ctx_synchronize(slam_ctx *ctx);
 /* Device-side ordering between two contexts of one device: work enqueued on `ctx`

@@ -19,6 +19,8 @@ dbl, cint = C.c_double, C.c_int
 # name -> (restype, argtypes); kept in sync with include/slamhip.h (tests/test_abi.py checks it)
 SIGNATURES = {
     "slam_ctx_create": (cint, [cint, C.POINTER(vp)]),
+    "slam_ctx_create_cumask": (cint, [cint, C.POINTER(C.c_uint32), cint, C.POINTER(vp)]),
+    "slam_ctx_create_priority": (cint, [cint, cint, C.POINTER(vp)]),
     "slam_ctx_destroy": (cint, [vp]),
     "slam_ctx_synchronize": (cint, [vp]),
     "slam_ctx_stream": (vp, [vp]),
@@ -138,10 +140,23 @@ def ptr(a, t=f64p):
 class Context:
     """One per calling task (SURVEY 8b threading): owns a HIP stream + scratch."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, cu_mask=None, priority=0):
+        """cu_mask: optional iterable of 0/1 per compute unit (slam_ctx_create_cumask); priority: > 0 puts the stream in the
+        high-priority scheduling class with a hardware queue of its own (slam_ctx_create_priority)"""
         self.lib = load()
         h = vp()
-        rc = self.lib.slam_ctx_create(device, C.byref(h))
+        if cu_mask is not None:
+            bits = list(cu_mask)
+            nw = (len(bits) + 31) // 32
+            words = (C.c_uint32 * nw)()
+            for i, b in enumerate(bits):
+                if b:
+                    words[i // 32] |= 1 << (i % 32)
+            rc = self.lib.slam_ctx_create_cumask(device, words, nw, C.byref(h))
+        elif priority:
+            rc = self.lib.slam_ctx_create_priority(device, int(priority), C.byref(h))
+        else:
+            rc = self.lib.slam_ctx_create(device, C.byref(h))
         if rc != 0:
             raise SlamHipError(f"slam_ctx_create failed ({rc}): {self.lib.slam_last_error(None).decode()}")
         self.h = h

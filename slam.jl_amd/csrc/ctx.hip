@@ -121,6 +121,49 @@ int slam_ctx_create(int device, slam_ctx **out)
     return SLAM_OK;
 }
 
+// A context whose stream may only use the compute units set in `cu_mask` (bit i of word i / 32: CU i of the device's
+// enumeration): lets two concurrently running stages -- the bandwidth-bound pyramid builds and the latency-bound tracking
+// kernels -- each keep a partition of the chip instead of evicting one another from the CUs (LDS and wave slots).
+int slam_ctx_create_cumask(int device, const uint32_t *cu_mask, int n_words, slam_ctx **out)
+{
+    if (!out || !cu_mask || n_words <= 0) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_ctx_create_cumask: bad argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create_cumask: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_ctx_create_cumask: device %d out of range [0,%d)", device, n);
+    slam_ctx *c = new slam_ctx();
+    c->device = device;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)n_words, cu_mask);
+    if (e != hipSuccess) { delete c; return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create_cumask: %s", hipGetErrorString(e)); }
+    *out = c;
+    return SLAM_OK;
+}
+
+// A context on a stream of its own scheduling class: priority > 0 high, < 0 low, 0 the default class.  The runtime maps
+// streams of one class onto a small shared set of hardware queues, and the branches of a replayed hipGraph are placed on that
+// same set: work enqueued behind a graph branch that is waiting for its predecessors waits with it (measured: the tracking
+// kernels of a step sat behind the pyramid graph's small-level branch for the whole build).  A stream of another class has
+// its own hardware queue, and the dispatcher prefers it -- what the latency-critical tracking stream of a pipeline wants.
+int slam_ctx_create_priority(int device, int priority, slam_ctx **out)
+{
+    if (!out) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_ctx_create_priority: out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create_priority: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_ctx_create_priority: device %d out of range [0,%d)", device, n);
+    slam_ctx *c = new slam_ctx();
+    c->device = device;
+    e = hipSetDevice(device);
+    int least = 0, greatest = 0;                      // numerically: greatest priority <= 0 <= least priority
+    if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    int p = priority > 0 ? greatest : priority < 0 ? least : 0;
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, p);
+    if (e != hipSuccess) { delete c; return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create_priority: %s", hipGetErrorString(e)); }
+    *out = c;
+    return SLAM_OK;
+}
+
 int slam_ctx_destroy(slam_ctx *ctx)
 {
     if (!ctx) return SLAM_OK;
