@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslamhip.so")
+LIB_PATH = os.environ.get("SLAMHIP_LIB") or os.path.join(_HERE, "libslamhip.so")     # SLAMHIP_LIB: another build of the same library (A/B timing)
 
 f64p = C.POINTER(C.c_double)
 u8p = C.POINTER(C.c_uint8)

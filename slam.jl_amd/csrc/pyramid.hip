@@ -164,6 +164,7 @@ struct RowIO {
 // the kernel under 256 VGPRs so that two waves share a SIMD).  Rows of the first / last tile
 // that lie outside the swept range are carried through untouched and not stored.
 #define COL_LS 18                       // LDS column stride in doubles: 16 + 2 keeps ds_*_b128 aligned and conflict-free
+typedef double v2d __attribute__((ext_vector_type(2)));
 template <int COL_NB> struct ColIO {
     const double *src; double *dst;     // plane bases
     int H, W, P, x0;                    // rows, columns, column pitch, first column of this wave
@@ -202,7 +203,7 @@ template <int COL_NB> struct ColIO {
             const int col = x0 + 8 * r + cg;
             if (col >= slo && col <= shi) {
                 double *q = dst + ((size_t)(x0 + 8 * r) * P + rb) + voff;
-                if (!partial) *(double2 *)q = make_double2(t[2 * r], t[2 * r + 1]);
+                if (!partial) { const v2d v = {t[2 * r], t[2 * r + 1]}; __builtin_nontemporal_store(v, (v2d *)q); }   // one 16-byte store (a plain one is split and merged with the partial path below: 8-byte stores)
                 else {
                     if (row >= lo && row <= hi) q[0] = t[2 * r];
                     if (row + 1 >= lo && row + 1 <= hi) q[1] = t[2 * r + 1];
@@ -708,6 +709,24 @@ __device__ __forceinline__ void cf4_inputs(double *x, double top, double bot, in
 // (ds_*_b128) is conflict-free: LB = layer rows rb-2 .. rb+35 of the 64 columns (row rb at index 2), IYB / IXB = Iy / Ix
 // of rows rb .. rb+31, QB = output staging of wave 3.  After the inputs have been consumed LB / IYB / IXB are the output
 // staging of waves 0 / 1 / 2.
+// workgroup barrier that orders the LDS traffic only.  __syncthreads() also waits for every outstanding global load and store
+// of the wave (s_waitcnt vmcnt(0)): the next block's prefetch and the previous block's stores would be drained at each of the
+// three or four barriers of a block, a full memory round trip each time.  Global memory is never shared between the waves here.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#ifdef CF4_EXP          /* scripts/ubench/rows_ck_bench.hip: parts of k_cols_fused switched off at run time to see what each costs */
+__device__ int cf4_exp;
+#define CFX(bit) ((cf4_exp >> (bit)) & 1)
+#else
+#define CFX(bit) false
+#endif
+#ifndef CF4_DEFER_U8
+#define CF4_DEFER_U8 1
+#endif
 #define CF4_LS 38
 #define CF4_GS 34
 #define CF4_LDS_DOUBLES (64 * CF4_LS + 3 * 64 * CF4_GS)
@@ -769,38 +788,65 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     const int w = ROLE;                                           // wave index inside the workgroup
     // the layer: the pitched plane, or (level 0, fused ingest) the stream's dense source image
     const int skind = A.src_kind;
+    // (the pointers are given their address spaces explicitly: a pointer loaded from the table, or the LDS table behind a
+    //  parameter, is generic to the compiler, and FLAT loads make every s_waitcnt of the kernel a full vmcnt(0) drain)
+    typedef const __attribute__((address_space(1))) double *gsrc_f64;
+    typedef const __attribute__((address_space(1))) unsigned char *gsrc_u8;
+    typedef const __attribute__((address_space(3))) double *lds_f64;
     const void *simg = skind ? A.srctab[blockIdx.z] : nullptr;
+    const gsrc_f64 simg_d = (gsrc_f64)simg; const gsrc_u8 simg_b = (gsrc_u8)simg; const lds_f64 lutl = (lds_f64)lut;
     auto src_at = [&](int row, int colx) -> double {              // dense source sample, indices in range; 8-bit: lut[v] = (double)v / 255.0 (k_gather_images_u8's conversion, tabulated)
-        return skind == 1 ? ((const double *)simg)[(size_t)row + (size_t)colx * H] : lut[((const unsigned char *)simg)[(size_t)row + (size_t)colx * H]];
+        return skind == 1 ? simg_d[(size_t)row + (size_t)colx * H] : lutl[simg_b[(size_t)row + (size_t)colx * H]];
     };
     auto ld_layer = [&](int row) -> double { return skind ? src_at(row, io.xown()) : io.ld_src(row); };
     auto tile_layer = [&](int rb, double *t) {                    // rows rb + 2 rp, + 1 of columns x0 + 8 r + cg (the global tile layout)
         if (!skind) { io.tile_load(io.src, rb, t); return; }
         const int r0 = rb + 2 * rp < H ? rb + 2 * rp : H - 1;
         const bool pair = rb + 2 * rp + 1 < H;                    // both rows exist: one load of two vertically adjacent samples
-        if (skind == 2) {
-            unsigned short v[8];
-#pragma unroll
+        if (skind == 2) {                                        // 8-bit: the raw bytes travel in t[r] (two per register pair, nothing waits for them here);
+#pragma unroll                                                    // publish() turns them into samples where the tile is consumed
             for (int r = 0; r < 8; r++) {
                 int cx = xl + 8 * r + cg; cx = cx < W ? cx : W - 1;
-                const unsigned char *q = (const unsigned char *)simg + (size_t)r0 + (size_t)cx * H;
-                v[r] = pair ? (unsigned short)(q[0] | (q[1] << 8)) : (unsigned short)(q[0] | (q[0] << 8));
+                const gsrc_u8 q = simg_b + (size_t)r0 + (size_t)cx * H;
+                const int b0 = q[0], b1 = q[pair ? 1 : 0];
+                t[r] = __hiloint2double(b1, b0);
             }
+            if (!CF4_DEFER_U8) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) { t[2 * r] = lut[v[r] & 255]; t[2 * r + 1] = lut[v[r] >> 8]; }
+                for (int r = 7; r >= 0; r--) { const int lo = __double2loint(t[r]), hi = __double2hiint(t[r]); t[2 * r] = lutl[lo]; t[2 * r + 1] = lutl[hi]; }
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 int cx = xl + 8 * r + cg; cx = cx < W ? cx : W - 1;
-                const double *q = (const double *)simg + (size_t)r0 + (size_t)cx * H;
+                const gsrc_f64 q = simg_d + (size_t)r0 + (size_t)cx * H;
                 t[2 * r] = q[0]; t[2 * r + 1] = pair ? q[1] : q[0];
             }
         }
     };
     // recurrence input of a single row (boundary rows of the filter): the same arithmetic on scalar loads
+    // the six layer rows the boundary inputs need (0 .. 3, n-2, n-1), requested together: one memory round trip instead of one per use
+    double brow[6];
+    {
+        const int rr[6] = {0, 1, 2, n > 3 ? 3 : n - 1, n - 2, n - 1};
+        if (!skind) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) brow[q] = io.ld_src(rr[q]);
+        } else if (skind == 1) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) brow[q] = simg_d[(size_t)rr[q] + (size_t)io.xown() * H];
+        } else {
+            unsigned char bb[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) bb[q] = simg_b[(size_t)rr[q] + (size_t)io.xown() * H];
+#pragma unroll
+            for (int q = 0; q < 6; q++) brow[q] = lutl[bb[q]];
+        }
+    }
+    auto brow_at = [&](int y) { return y <= 3 ? (y == 0 ? brow[0] : y == 1 ? brow[1] : y == 2 ? brow[2] : brow[3]) : (y == n - 2 ? brow[4] : brow[5]); };
     auto in_row = [&](int y) {
-        double v[1] = {ld_layer(y)};
-        if (ROLE != 0) { double gdummy[1]; cf4_inputs<ROLE, 1>(v, ld_layer(y > 0 ? y - 1 : 0), ld_layer(y + 1 < H ? y + 1 : H - 1), y, H, edgeL, edgeR, gdummy); }
+        double v[1] = {brow_at(y)};
+        if (ROLE != 0) { double gdummy[1]; cf4_inputs<ROLE, 1>(v, brow_at(y > 0 ? y - 1 : 0), brow_at(y + 1 < H ? y + 1 : H - 1), y, H, edgeL, edgeR, gdummy); }
         return v[0];
     };
     const double x0 = in_row(0);
@@ -817,6 +863,7 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     // layer row above the block, wave 3 the row below it
     auto prefetch = [&](int b) {
         const int rb = b << 5;
+        if (CFX(4)) { for (int e = 0; e < 16; e++) pre[e] = 0.5; return; }
         if (ROLE == 0) tile_layer(rb, pre);
         else if (ROLE == 1) {
             if (2 * b + 1 < ntile) tile_layer(rb + 16, pre);
@@ -825,14 +872,24 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
                 for (int e = 0; e < 16; e++) pre[e] = 0.0;
             }
         }
-        else if (ROLE == 2) pre[0] = ld_layer(rb > 0 ? rb - 1 : 0);
-        else pre[0] = ld_layer(rb + 32 < H ? rb + 32 : H - 1);
+        else {                                                    // halo row above (wave 2) / below (wave 3) the block
+            const int hrow = ROLE == 2 ? (rb > 0 ? rb - 1 : 0) : (rb + 32 < H ? rb + 32 : H - 1);
+            if (skind == 2 && CF4_DEFER_U8) pre[0] = __hiloint2double(0, (int)simg_b[(size_t)hrow + (size_t)io.xown() * H]);      // raw byte, converted in publish()
+            else pre[0] = ld_layer(hrow);
+        }
     };
     auto publish = [&]() {                                        // phase 1: operands -> shared layer block
+        if (ROLE <= 1 && skind == 2 && CF4_DEFER_U8) {            // 8-bit tile: bytes -> samples (table of v / 255.0)
+#pragma unroll
+            for (int r = 7; r >= 0; r--) {                        // in place, top down: pre[2r], pre[2r+1] <- the two bytes in pre[r]
+                const int lo = __double2loint(pre[r]), hi = __double2hiint(pre[r]);
+                pre[2 * r] = lutl[lo]; pre[2 * r + 1] = lutl[hi];
+            }
+        }
         if (ROLE <= 1) {
 #pragma unroll
             for (int r = 0; r < 8; r++) *(double2 *)(LB + (8 * r + cg) * CF4_LS + 2 + 16 * ROLE + 2 * rp) = make_double2(pre[2 * r], pre[2 * r + 1]);
-        } else LB[lane * CF4_LS + (ROLE == 2 ? 1 : 34)] = pre[0];
+        } else LB[lane * CF4_LS + (ROLE == 2 ? 1 : 34)] = skind == 2 && CF4_DEFER_U8 ? (double)lutl[__double2loint(pre[0]) & 255] : pre[0];
     };
     auto read_inputs = [&]() {                                    // phase 3: the lane's 32 recurrence inputs
         if (ROLE == 0) {
@@ -857,16 +914,17 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     prefetch(0);
     for (int b = 0; b < NBk; b++) {
         const int rb = b << 5;
-        __syncthreads();                                          // the previous block's shared data has been consumed
+        lds_barrier();                                            // the previous block's shared data has been consumed
         publish();
-        __syncthreads();
+        lds_barrier();  
         if (b + 1 < NBk) prefetch(b + 1);
-        cf4_scharr8(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
-        __syncthreads();
+        if (!CFX(2)) cf4_scharr8(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
+        lds_barrier();  
         if (!active) continue;
         read_inputs();
-        if (b >= 1) { double *c = ck + ((size_t)b * 3) * nlines + lineid; c[0] = w1; c[nlines] = w2; c[2 * nlines] = w3; }
-        if (rb >= 3 && rb + 31 <= n - 1) {
+        if (b >= 1 && !CFX(0)) { double *c = ck + ((size_t)b * 3) * nlines + lineid; c[0] = w1; c[nlines] = w2; c[2 * nlines] = w3; }
+        if (CFX(1)) { w1 += x[0] + x[31]; }
+        else if (rb >= 3 && rb + 31 <= n - 1) {
 #pragma unroll
             for (int e = 0; e < 32; e++) { const double tt = ((x[e] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; }
         } else {
@@ -887,16 +945,25 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     io.fence();
     // ---- pass B: blocks bottom to top.  Every block is visited (the gradient planes need all rows); rows [3, n-4] carry the
     //      recurrence, n-3 .. n-1 and 2 .. 0 are direct ----
+    // the forward state at the top of a block (its checkpoint) is requested a block ahead, like the layer operands: loaded where
+    // it is used, its s_waitcnt would also wait for every store issued before it (vmcnt counts in order) -- the block's gradient
+    // lines and the previous block's results -- and the stores would never overlap the recurrences
+    double f1n = o2, f2n = o1, f3n = o0;
+    auto load_ck = [&](int b) {
+        if (b > 0 && !CFX(3)) { const double *c = ck + ((size_t)b * 3) * nlines + lineid; f1n = c[0]; f2n = c[nlines]; f3n = c[2 * nlines]; }
+        else { f1n = o2; f2n = o1; f3n = o0; }
+    };
     prefetch(NBk - 1);
+    if (active) load_ck(NBk - 1);
     if (active) { io.st(n - 1, vA * scale); io.st(n - 2, vB * scale); io.st(n - 3, vC * scale); }
     for (int b = NBk - 1; b >= 0; b--) {
         const int rb = b << 5, lo = rb > 3 ? rb : 3, hi = rb + 31 < n - 4 ? rb + 31 : n - 4;     // recurrence rows of the block (may be empty: lo > hi)
         const bool two = 2 * b + 1 < ntile;
-        __syncthreads();
+        lds_barrier();  
         publish();
-        __syncthreads();
-        cf4_scharr8(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
-        __syncthreads();
+        lds_barrier();  
+        if (!CFX(2)) cf4_scharr8(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
+        lds_barrier();  
         if (active) read_inputs();
         if (ROLE == 0 && skind) {                                 // fused ingest: the block's layer rows -> the pitched layer plane
             ColIO<2> iol = io; iol.dst = const_cast<double *>(A.L) + z;
@@ -906,23 +973,22 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
                 if (t == 0 || (two && rb + 16 <= ghi)) {
 #pragma unroll
                     for (int r = 0; r < 8; r++) { const double2 q = *(const double2 *)(LB + (8 * r + cg) * CF4_LS + 2 + 16 * t + 2 * rp); u[2 * r] = q.x; u[2 * r + 1] = q.y; }
-                    iol.tile_store(rb + 16 * t, u, rb + 16 * t, ghi, rb + 16 * t + 15 > ghi);
+                    if (!CFX(0)) iol.tile_store(rb + 16 * t, u, rb + 16 * t, ghi, rb + 16 * t + 15 > ghi);
                 }
             }
         }
         if (ROLE == 1 || ROLE == 2) {                             // Iy / Ix of the block -> their planes
             const double *blk = ROLE == 1 ? IYB : IXB;
             const int ghi = H - 1;
-            get_tile(blk, 0, u); iog.tile_store(rb, u, rb, ghi, rb + 15 > ghi);
-            if (two && rb + 16 <= ghi) { get_tile(blk, 1, u); iog.tile_store(rb + 16, u, rb + 16, ghi, rb + 31 > ghi); }
+            get_tile(blk, 0, u); if (!CFX(0)) iog.tile_store(rb, u, rb, ghi, rb + 15 > ghi);
+            if (two && rb + 16 <= ghi) { get_tile(blk, 1, u); if (!CFX(0)) iog.tile_store(rb + 16, u, rb + 16, ghi, rb + 31 > ghi); }
         }
-        __syncthreads();                                          // inputs consumed: the shared blocks become output staging
-        if (b > 0) prefetch(b - 1);
+        lds_barrier();                                            // inputs consumed: the shared blocks become output staging
+        double f1 = f1n, f2 = f2n, f3 = f3n;
+        if (b > 0) { prefetch(b - 1); if (active) load_ck(b - 1); }
         if (!active || lo > hi) continue;                         // (a trailing block may hold rows n-3 .. n-1 only)
-        double f1, f2, f3;
-        if (b > 0) { const double *c = ck + ((size_t)b * 3) * nlines + lineid; f1 = c[0]; f2 = c[nlines]; f3 = c[2 * nlines]; }
-        else { f1 = o2; f2 = o1; f3 = o0; }
-        if (lo == rb && hi == rb + 31) {
+        if (CFX(1)) { v1 += f1 + x[0]; }
+        else if (lo == rb && hi == rb + 31) {
 #pragma unroll
             for (int e = 0; e < 32; e++) { const double tt = ((x[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = tt; x[e] = tt; }
 #pragma unroll
@@ -939,8 +1005,8 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
             for (int j = 0; j < 16; j++) *(double2 *)(q + 2 * j) = make_double2(x[2 * j], x[2 * j + 1]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
             get_tile(stage, 0, u);
-            io.tile_store(rb, u, lo, hi, !(lo <= rb && hi >= rb + 15));
-            if (two && hi >= rb + 16) { get_tile(stage, 1, u); io.tile_store(rb + 16, u, lo, hi, !(lo <= rb + 16 && hi >= rb + 31)); }
+            if (!CFX(0)) io.tile_store(rb, u, lo, hi, !(lo <= rb && hi >= rb + 15));
+            if (two && hi >= rb + 16) { get_tile(stage, 1, u); if (!CFX(0)) io.tile_store(rb + 16, u, lo, hi, !(lo <= rb + 16 && hi >= rb + 31)); }
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -1013,14 +1079,21 @@ __device__ __forceinline__ void cf_load_block(const double *plane, int P, int x0
 __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, int W, int P)
 {
     extern __shared__ __attribute__((aligned(16))) double cf_lds[];          // [nw][CF_W * CF_LS] blocks, then [nw][2][CF_W] column carries
-    __shared__ volatile int s_ready[CF_MAXW], s_done[CF_MAXW];
+    __shared__ int s_ready[CF_MAXW], s_done[CF_MAXW];            // read and written with relaxed workgroup-scope atomics: plain ds_read / ds_write (as `volatile` they were
+                                                                  // FLAT accesses with a vmcnt(0) in front of every poll: the block prefetch was drained once per block)
     const int pl = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int rp = lane & 7, cg = lane >> 3;
     double *plane = ps_plane(ps, pl);
-    double *Cb = cf_lds + (size_t)w * CF_W * CF_LS;
-    double *carry_out = cf_lds + (size_t)nw * CF_W * CF_LS + (size_t)w * 2 * CF_W;      // published by this wave
-    const double *carry_in = carry_out - 2 * CF_W;                                        // published by wave w - 1
-    if (lane == 0) { s_ready[w] = 0; s_done[w] = 0; }
+    // LDS pointers carry their address space: as generic pointers they became FLAT accesses, which turn every s_waitcnt of the
+    // kernel into a vmcnt(0) drain of the block prefetch and the stores; the hand-off fences order LDS only, for the same reason
+    typedef __attribute__((address_space(3))) double ldsd;
+    typedef __attribute__((address_space(3))) v2d ldsv2;
+    ldsd *Cb = (ldsd *)cf_lds + (size_t)w * CF_W * CF_LS;
+    ldsd *carry_out = (ldsd *)cf_lds + (size_t)nw * CF_W * CF_LS + (size_t)w * 2 * CF_W;  // published by this wave
+    const ldsd *carry_in = carry_out - 2 * CF_W;                                           // published by wave w - 1
+    auto flag_ld = [](int *f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto flag_st = [](int *f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    if (lane == 0) { flag_st(&s_ready[w], 0); flag_st(&s_done[w], 0); }
     __syncthreads();
     const int r0 = w * 64, hr = H - r0 < 64 ? H - r0 : 64;       // rows of this band that exist (>= 1 by the launch)
     const int ncb = (W + CF_W - 1) / CF_W;
@@ -1034,46 +1107,46 @@ __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, 
 #pragma unroll
         for (int sub = 0; sub < 4; sub++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) *(double2 *)(Cb + (8 * r + cg) * CF_LS + sub * 16 + 2 * rp) = make_double2(raw[sub][2 * r], raw[sub][2 * r + 1]);
+            for (int r = 0; r < 4; r++) { const v2d t2 = {raw[sub][2 * r], raw[sub][2 * r + 1]}; *(ldsv2 *)(Cb + (8 * r + cg) * CF_LS + sub * 16 + 2 * rp) = t2; }
         cf_load_block(plane, P, cb + 1 < ncb ? x0 + CF_W : x0, r0, voff, raw);       // next block (the last iteration re-reads, unused)
         // column sums of the band above
         double acc = 0.0;
         if (w > 0) {
-            while (s_ready[w - 1] <= cb) __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            while (flag_ld(&s_ready[w - 1]) <= cb) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             if (lane < CF_W) acc = carry_in[(cb & 1) * CF_W + lane];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) s_done[w] = cb + 1;                    // slot cb & 1 may be overwritten with block cb + 2
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if (lane == 0) flag_st(&s_done[w], cb + 1);                   // slot cb & 1 may be overwritten with block cb + 2
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         // (b) column sums, lane = column
         if (lane < CF_W) {
-            double *c = Cb + lane * CF_LS;
+            ldsd *c = Cb + lane * CF_LS;
             if (hr == 64 && w > 0) {
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     double v[32];
 #pragma unroll
-                    for (int j = 0; j < 16; j++) { const double2 q = *(const double2 *)(c + 32 * half + 2 * j); v[2 * j] = q.x; v[2 * j + 1] = q.y; }
+                    for (int j = 0; j < 16; j++) { const v2d q = *(const ldsv2 *)(c + 32 * half + 2 * j); v[2 * j] = q.x; v[2 * j + 1] = q.y; }
 #pragma unroll
                     for (int e = 0; e < 32; e++) { acc = acc + v[e]; v[e] = acc; }
 #pragma unroll
-                    for (int j = 0; j < 16; j++) *(double2 *)(c + 32 * half + 2 * j) = make_double2(v[2 * j], v[2 * j + 1]);
+                    for (int j = 0; j < 16; j++) { const v2d t2 = {v[2 * j], v[2 * j + 1]}; *(ldsv2 *)(c + 32 * half + 2 * j) = t2; }
                 }
             } else {
                 for (int e = 0; e < hr; e++) { acc = (r0 + e == 0) ? c[e] : acc + c[e]; c[e] = acc; }
             }
         }
         if (w + 1 < nw) {                                         // publish the bottom row's sums to the band below
-            while (s_done[w + 1] + 2 <= cb) __builtin_amdgcn_s_sleep(1);
+            while (flag_ld(&s_done[w + 1]) + 2 <= cb) __builtin_amdgcn_s_sleep(1);
             if (lane < CF_W) carry_out[(cb & 1) * CF_W + lane] = acc;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) s_ready[w] = cb + 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if (lane == 0) flag_st(&s_ready[w], cb + 1);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         // (c) row sums across the block's columns, lane = row
         if (lane < hr) {
-            double *c = Cb + lane;
+            ldsd *c = Cb + lane;
             if (wc == CF_W && cb > 0) {
                 double v[CF_W];
 #pragma unroll
@@ -1095,10 +1168,10 @@ __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, 
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int col = x0 + 8 * r + cg, row = rb + 2 * rp;
-                    const double2 q = *(const double2 *)(Cb + (8 * r + cg) * CF_LS + sub * 16 + 2 * rp);
+                    const v2d q = *(const ldsv2 *)(Cb + (8 * r + cg) * CF_LS + sub * 16 + 2 * rp);
                     double *g = plane + ((size_t)(x0 + 8 * r) * P + rb) + voff;
                     if (col < W) {
-                        if (row + 1 < H) *(double2 *)g = q;
+                        if (row + 1 < H) __builtin_nontemporal_store(q, (v2d *)g);
                         else if (row < H) g[0] = q.x;
                     }
                 }
