@@ -668,6 +668,24 @@ struct ColsFusedArgs {
     int src_kind; const void *const *srctab;
 };
 
+// neighbour lanes of the whole wave through DPP (wave_shr:1 / wave_shl:1 of the GFX9 family): lane i receives lane i-1 / i+1,
+// lane 0 / 63 keeps its own value -- __shfl_up / __shfl_down by one lane without the LDS crossbar (ds_bpermute_b32: two per
+// double, ~64 per 8-row Scharr step, queued behind the tile traffic of all eight waves of the CU)
+__device__ __forceinline__ double wave_prev(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_next(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 // x[0..N) holds the lane's layer samples of rows rb .. rb+N-1 on entry, the recurrence inputs of its role on exit
 // (ROLE 1: Iy^2, 2: Ix^2, 3: Iy Ix); g receives Iy (ROLE 1) / Ix (ROLE 2).  top / bot: the layer at rows rb-1 / rb+N.
 template <int ROLE, int N>
@@ -685,13 +703,13 @@ __device__ __forceinline__ void cf4_inputs(double *x, double top, double bot, in
         double iy = 0.0, ix = 0.0;
         if (ROLE == 1 || ROLE == 3) {
             double d = 0.0; d += aa * dk[0]; d += b * dk[1]; d += c * dk[2];
-            double dl = __shfl_up(d, 1), dr = __shfl_down(d, 1);
+            double dl = wave_prev(d), dr = wave_next(d);
             dl = edgeL ? d : dl; dr = edgeR ? d : dr;
             iy += dl * sk[0]; iy += d * sk[1]; iy += dr * sk[2];
         }
         if (ROLE == 2 || ROLE == 3) {
             double s = 0.0; s += aa * sk[0]; s += b * sk[1]; s += c * sk[2];
-            double sl = __shfl_up(s, 1), sr = __shfl_down(s, 1);
+            double sl = wave_prev(s), sr = wave_next(s);
             sl = edgeL ? s : sl; sr = edgeR ? s : sr;
             ix += sl * dk[0]; ix += s * dk[1]; ix += sr * dk[2];
         }
@@ -749,7 +767,7 @@ __device__ __forceinline__ void cf4_scharr8(const double *LB, double *IYB, doubl
         const double c = row == H - 1 ? b : v[3 + e];
         double d = 0.0; d += a * dk[0]; d += b * dk[1]; d += c * dk[2];
         double s = 0.0; s += a * sk[0]; s += b * sk[1]; s += c * sk[2];
-        double dl = __shfl_up(d, 1), dr = __shfl_down(d, 1), sl = __shfl_up(s, 1), sr = __shfl_down(s, 1);
+        double dl = wave_prev(d), dr = wave_next(d), sl = wave_prev(s), sr = wave_next(s);
         dl = edgeL ? d : dl; dr = edgeR ? d : dr; sl = edgeL ? s : sl; sr = edgeR ? s : sr;
         double iy = 0.0, ix = 0.0;
         iy += dl * sk[0]; iy += d * sk[1]; iy += dr * sk[2];
