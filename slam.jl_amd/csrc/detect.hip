@@ -84,15 +84,20 @@ __device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned 
 __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
 {
     extern __shared__ double lds[];
+    // per-stream view of the arguments in locals: writing to the argument struct (or indexing its tap array with a lane
+    // index) makes the compiler copy all 472 bytes of it to scratch and read every field back from there
+    const double *a_img = A.img, *a_cur = A.cur;
+    int a_ncur = A.n_cur, a_k = A.k;
+    int64_t *a_cell_out = A.cell_out; int *a_cell_cnt = A.cell_cnt;
     if (A.cur_cnt) {
         const int z = blockIdx.y, nc = A.grid_rows * A.grid_cols, ncur = A.cur_cnt[z];
-        A.img += (size_t)z * A.zs; A.cur += 2 * (size_t)z * A.cur_stride; A.n_cur = ncur;
-        A.k = ncur >= A.max_points ? 0 : (A.max_points - ncur + nc - 1) / nc;                 // extractor.jl:64-66, 74-76
-        A.cell_out += (size_t)z * nc * A.kmax * 2; A.cell_cnt += (size_t)z * nc;
+        a_img += (size_t)z * A.zs; a_cur += 2 * (size_t)z * A.cur_stride; a_ncur = ncur;
+        a_k = ncur >= A.max_points ? 0 : (A.max_points - ncur + nc - 1) / nc;                 // extractor.jl:64-66, 74-76
+        a_cell_out += (size_t)z * nc * A.kmax * 2; a_cell_cnt += (size_t)z * nc;
     } else if (A.cur_off) {
         const int z = blockIdx.y, o = A.cur_off[z], nc = A.grid_rows * A.grid_cols;
-        A.img += (size_t)z * A.zs; A.cur += 2 * (size_t)o; A.n_cur = A.cur_off[z + 1] - o; A.k = A.k_s[z];
-        A.cell_out += (size_t)z * nc * A.kmax * 2; A.cell_cnt += (size_t)z * nc;
+        a_img += (size_t)z * A.zs; a_cur += 2 * (size_t)o; a_ncur = A.cur_off[z + 1] - o; a_k = A.k_s[z];
+        a_cell_out += (size_t)z * nc * A.kmax * 2; a_cell_cnt += (size_t)z * nc;
     }
     const int cs = A.cs, H = A.H, W = A.W;
     const int cell = blockIdx.x;
@@ -110,16 +115,16 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     __shared__ int s_lim[DET_MAXR + 1];
     __shared__ double s_taps[DET_MAXTAPS];
 
-    if (h <= 0 || w <= 0 || A.k <= 0) { if (tid == 0) A.cell_cnt[cell] = 0; return; }
+    if (h <= 0 || w <= 0 || a_k <= 0) { if (tid == 0) a_cell_cnt[cell] = 0; return; }
 
     // ---- image tile -> bA ---------------------------------------------------
     for (int i = tid; i < h * w; i += DET_THREADS) {
         int y = i % h, x = i / h;
-        bA[i] = A.img[(size_t)(y0 + y) + (size_t)(x0 + x) * A.pitch];
+        bA[i] = a_img[(size_t)(y0 + y) + (size_t)(x0 + x) * A.pitch];
     }
 
     // ---- avoidance mask (get_mask + imfilter(mask, Kernel.gaussian) + .*) ---
-    if (A.n_cur > 0) {
+    if (a_ncur > 0) {
         const int hw = A.ntaps >> 1;
         const int mh = h + 2 * hw, mw = w + 2 * hw;
         const int r = A.radius;
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         // candidate keypoints: disk (+halo) touches the clamped tile region
         const int ylo = clampi(y0 - hw, 0, H - 1) + 1, yhi = clampi(y0 + h - 1 + hw, 0, H - 1) + 1; // 1-based
         const int xlo = clampi(x0 - hw, 0, W - 1) + 1, xhi = clampi(x0 + w - 1 + hw, 0, W - 1) + 1;
-        for (int k = tid; k < A.n_cur; k += DET_THREADS) {
-            long py = (long)rint(A.cur[2 * k]), px = (long)rint(A.cur[2 * k + 1]);
+        for (int k = tid; k < a_ncur; k += DET_THREADS) {
+            long py = (long)rint(a_cur[2 * k]), px = (long)rint(a_cur[2 * k + 1]);
             if (py + r >= ylo && py - r <= yhi && px + r >= xlo && px - r <= xhi) {
                 int slot = atomicAdd(&s_ncand, 1);
                 if (slot < DET_MAXCAND) { s_cand[2 * slot] = (int)py; s_cand[2 * slot + 1] = (int)px; }
@@ -179,8 +184,8 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
             for (int i = tid; i < mh * mw; i += DET_THREADS) {
                 const int yy = clampi(y0 + i % mh - hw, 0, H - 1) + 1, xx = clampi(x0 + i / mh - hw, 0, W - 1) + 1; // 1-based
                 unsigned char m = 1;
-                for (int c = 0; c < A.n_cur; c++) {
-                    long py = (long)rint(A.cur[2 * c]), px = (long)rint(A.cur[2 * c + 1]);
+                for (int c = 0; c < a_ncur; c++) {
+                    long py = (long)rint(a_cur[2 * c]), px = (long)rint(a_cur[2 * c + 1]);
                     const long dy = labs(yy - py), dx = labs(xx - px);
                     if (dy <= r && dx <= s_lim[dy]) { m = 0; break; }
                 }
@@ -190,7 +195,8 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         __syncthreads();
         if (A.ntaps > 0) {
             // taps -> LDS once (indexing the kernel argument inside the tap loops costs a scalar load per tap)
-            if (tid < A.ntaps) s_taps[tid] = A.taps[tid];
+#pragma unroll
+            for (int j = 0; j < DET_MAXTAPS; j++) if (tid == j && j < A.ntaps) s_taps[j] = A.taps[j];   // static indices: scalar loads of the argument
             __syncthreads();
             double *T = bB;                                   // h*mw doubles: bB, bC and the part of bD below the byte mask (checked on host)
             if (A.ntaps == 13) blur_mask<13>(bA, T, m0, s_taps, h, w, mh, mw, tid);      // sigma_mask = 3 (the default): unrolled
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
 
     // ---- top-k by response (stable: ties keep column-major order) ------------
     int *sel = (int *)bC;                                     // selected linear indices
-    for (int round = 0; round < A.k; round++) {
+    for (int round = 0; round < a_k; round++) {
         double bv = -INFINITY; int bi = 0x7fffffff;
         for (int i = tid; i < h * w; i += DET_THREADS)
             if (flag[i] == 1) {
@@ -279,12 +285,12 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     if (tid == 0) {
         int cnt = s_cnt;
         for (int i = 1; i < cnt; i++) { int v = sel[i], j = i - 1; while (j >= 0 && sel[j] > v) { sel[j + 1] = sel[j]; j--; } sel[j + 1] = v; }
-        int64_t *o = A.cell_out + (size_t)cell * A.k * 2;
+        int64_t *o = a_cell_out + (size_t)cell * a_k * 2;
         for (int i = 0; i < cnt; i++) {
             int y = sel[i] % h, x = sel[i] / h;
             o[2 * i] = y + 1 + y0; o[2 * i + 1] = x + 1 + x0;
         }
-        A.cell_cnt[cell] = cnt;
+        a_cell_cnt[cell] = cnt;
     }
 }
 

@@ -459,20 +459,23 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows_ck(PlaneSet ps, int H
         }
     };
     const int nfull = (n - 3) / CK_B;                           // blocks of pass A that are complete
-    if (nfull > 0) load_x(0, cur);
+    const int rem = (n - 3) - nfull * CK_B;                     // samples of the trailing partial block (block nfull), prefetched like the others
+    load_x(0, cur);
     for (int j = 0; j < nfull; j++) {
-        if (j + 1 < nfull) load_x(j + 1, nxt);
+        load_x(j + 1, nxt);                                     // (block nfull: clamped reads, the missing samples are zeros)
         if (j > 0 && j < nb) { double *c = ck + ((size_t)j * 3) * nlines + lineid; c[0] = w1; c[nlines] = w2; c[2 * nlines] = w3; }
 #pragma unroll
         for (int e = 0; e < CK_B; e++) { const double t = ((cur[e] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = t; }
 #pragma unroll
         for (int e = 0; e < CK_B; e++) cur[e] = nxt[e];
     }
-    {   // remainder (< CK_B samples): its start may still be a checkpoint
-        const int a = 3 + nfull * CK_B;
+    {   // remainder (< CK_B samples, in `cur`): its start may still be a checkpoint
         if (nfull > 0 && nfull < nb) { double *c = ck + ((size_t)nfull * 3) * nlines + lineid; c[0] = w1; c[nlines] = w2; c[2 * nlines] = w3; }
-        for (int i = a; i < n; i++) { const double t = ((p[(long)i * s] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = t; }
+#pragma unroll
+        for (int e = 0; e < CK_B; e++)
+            if (e < rem) { const double t = ((cur[e] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = t; }
     }
+    const bool have_last = nfull == nb - 1;                     // `cur` already holds the inputs of pass B's first block
     // ---- Triggs-Sdika right boundary (as iir_line) ----
     const double uplus = iplus / k.inv1masum, vplus = uplus / k.inv1mbsum;
     const double d0 = w1 - uplus, d1 = w2 - uplus, d2 = w3 - uplus;
@@ -495,7 +498,8 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows_ck(PlaneSet ps, int H
     if (nb > 0) {
         // rightmost block: possibly partial (1 .. CK_B samples), predicated
         const int j = nb - 1, a = 3 + j * CK_B, len = m - j * CK_B;
-        load_x(j, cur); load_ck(j, f1, f2, f3);
+        if (!have_last) load_x(j, cur);
+        load_ck(j, f1, f2, f3);
         if (j > 0) { load_x(j - 1, nxt); load_ck(j - 1, f1n, f2n, f3n); }
 #pragma unroll
         for (int e = 0; e < CK_B; e++)
