@@ -348,11 +348,14 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
         ctx, ctx_pyr, ctx_right = slam.Context(local_rank, cu_mask=tmask), slam.Context(local_rank, cu_mask=pmask), slam.Context(local_rank, cu_mask=pmask)
         ctx_copy = slam.Context(local_rank)
     else:
-        # the tracking context's stream is in the high-priority class: a hardware queue of its own.  With four default-class streams
-        # the runtime placed the pyramid graph's small-level branch on the tracking stream's queue and every step's match sat behind
-        # it until the build was over (kernel trace); SLAM_BENCH_TRACK_PRIO=0 restores that for comparison.
-        prio = int(os.environ.get("SLAM_BENCH_TRACK_PRIO", "1"))
-        ctx, ctx_pyr, ctx_right, ctx_copy = slam.Context(local_rank, priority=prio), slam.Context(local_rank), slam.Context(local_rank), slam.Context(local_rank)
+        # the tracking context's stream is in a scheduling class of its own (the low-priority one): a hardware queue that the branches
+        # of the pyramid graph never land on.  With four default-class streams the runtime placed the graph's small-level branch on
+        # the tracking stream's queue and every step's match sat behind it until the build was over (kernel trace).
+        # Measured at S = 32, host_u8: default class 14.7k frames/s, high 16.2k, low 16.5k (the builds are the longer chain of a
+        # step and are better left undisturbed).  SLAM_BENCH_TRACK_PRIO=0 restores the shared class for comparison.
+        prio = int(os.environ.get("SLAM_BENCH_TRACK_PRIO", "-1"))
+        pprio = int(os.environ.get("SLAM_BENCH_PYR_PRIO", "0"))
+        ctx, ctx_pyr, ctx_right, ctx_copy = slam.Context(local_rank, priority=prio), slam.Context(local_rank, priority=pprio), slam.Context(local_rank, priority=pprio), slam.Context(local_rank)
     levels = params.pyramid_levels
     AHEAD = 1
     NLB = AHEAD + 3                                          # previous, current, AHEAD being built, one more being copied
