@@ -271,6 +271,19 @@ int slam_kpset_detect(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *pyr0, int m
 int slam_kpset_triangulate(slam_ctx *ctx, slam_kpset *ks, const double *P1, const double *P2, const double *T21,
                            const double *cam1, const double *cam2, const double *Twc, double max_error, double min_depth, int n_bound);
 
+/* compute_pose! (front_end.jl:132-219) for every stream, on the set: the is_3d keypoints in list order (:139-160; undistorted
+ * pixel and normalised bearing from params[s][16..23] = fx fy cx cy k1 k2 p1 p2) -> P3P RANSAC (threshold = max_reprojection_error,
+ * `iters` triples per stream from a counter-based generator seeded with `seed`: three distinct indices,
+ * splitmix64(seed ^ s << 48 ^ iteration << 16 ^ attempt) mod n, restated in keypoint_set.py) -> its outliers leave the list
+ * (:187-189) -> pnp_bundle_adjustment of the inliers from the P3P pose (:203-206) -> its outliers leave the list (:213-215).
+ * status[s] = 1: poses_cw[16 s ..] is the refined world -> camera transform (column-major 4 x 4); 0: one of the reference's
+ * reset exits (fewer than 5 3-D keypoints :133, fewer than 5 P3P inliers :179, refinement left fewer than 5 inliers or a larger
+ * error :207; in the last case the P3P outliers are already gone, as in the reference), pose = identity.  n_inliers (P3P) and
+ * counts (list lengths after the removals) may be NULL.  Synchronous: the call is the step's one device -> host copy. */
+int slam_kpset_compute_pose(slam_ctx *ctx, slam_kpset *ks, const double *params, double threshold, int iters, uint64_t seed,
+                            int pnp_iters_fast, int pnp_iterations, double depth_eps, double repr_eps,
+                            double *poses_cw, int32_t *status, int32_t *n_inliers, int32_t *counts);
+
 /* ---- bundle adjustment ------------------------------------------------------ */
 /* Array-level body of triangulate_stereo! (parallax == NULL: every gate applies, src/mapper.jl:142-183) and
  * triangulate_temporal! (a gate removes the observation only when parallax[i] > min_parallax, :185-262), for n

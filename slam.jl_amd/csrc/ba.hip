@@ -42,7 +42,6 @@ struct LMState {
     int converged, accept, iters, n_outliers, chol_fail, iters_pass1, iters_pass2, pad;
 };
 
-struct Cam { double fx, fy, cx, cy; };
 
 struct BADev {
     Cam cam;
@@ -1646,11 +1645,6 @@ int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy, int
 // whole two-pass LM (dense 6x6 normal equations, exact Cholesky step) runs inside
 // ONE kernel / one workgroup: per iteration two block reductions and a
 // single-thread 6x6 solve; no host round trips.
-struct PnPArgs {
-    Cam cam; const double *px; const double *pts; int n;
-    double X0[6]; int iters_fast, iterations; double depth_eps, repr_eps;
-    uint8_t *outl; double *result;   // [X(6), err_init, err_final, n_outliers, identity, iters1, iters2]
-};
 
 #define PNP_T 256
 __device__ void pnp_reduce(double *v, int cnt, double *sh /* 4*cnt */, double *outv)
@@ -1817,6 +1811,14 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_batch(const PnPArgs *args)
     if (threadIdx.x == 0) A = args[blockIdx.x];
     __syncthreads();
     pnp_body(A);
+}
+
+int pnp_launch_device(slam_ctx *ctx, int S, const PnPArgs *args_dev)
+{
+    ProfScope span(ctx, "pnp_ba");
+    hipLaunchKernelGGL(k_pnp_batch, dim3(S), dim3(PNP_T), 0, ctx->stream, args_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLAM_OK;
 }
 
 // RotZYX(pose[1:3,1:3]) -> angles (Rotations.jl), pose column-major: R[i][j] = pose[i + 4j]

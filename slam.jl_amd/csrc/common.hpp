@@ -128,6 +128,16 @@ struct IIRCoef {
 IIRCoef slam_iir_coef(double sigma);
 int slam_gaussian_taps(double sigma, double *w);   // Kernel.gaussian 1-D factor
 
+// pinhole intrinsics; the argument block of one single-pose refinement (k_pnp / k_pnp_batch in ba.hip; filled on the device by
+// the keypoint-set pose seam in pose.hip)
+struct Cam { double fx, fy, cx, cy; };
+struct PnPArgs {
+    Cam cam; const double *px; const double *pts; int n;
+    double X0[6]; int iters_fast, iterations; double depth_eps, repr_eps;
+    uint8_t *outl; double *result;   // [X(6), err_init, err_final, n_outliers, identity, iters1, iters2]
+};
+int pnp_launch_device(slam_ctx *ctx, int S, const PnPArgs *args_dev);     // S problems, argument blocks already in device memory
+
 // kpset plumbing shared by kpset.hip / lk.hip / detect.hip
 int kpset_build_worklist(slam_ctx *ctx, slam_kpset *ks);
 int kpset_compact(slam_ctx *ctx, slam_kpset *ks, int mode, const uint8_t *flags_dev);

@@ -16,6 +16,7 @@ struct P3PArgs {                    // S independent problems (S = 1: slam_p3p_r
     const double *pts, *px, *pdn;   // concatenated: n x 3, n x 2 (x, y), n x 3
     const int32_t *samples;         // S x iters x 3, 0-based, local to the problem
     const int *off;                 // S + 1
+    const int *cnt; int stride;     // keypoint-set layout instead (cnt != nullptr): problem z owns [z * stride, z * stride + cnt[z])
     const double *Ks;               // S x 9, column-major 3x3
     int iters;
     double thr;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void k_p3p_score(P3PArgs T)
 {
     // four waves per triple: each runs the (wave-uniform) solver, wave s then scores pose s with its 64 lanes
     const int it = blockIdx.x, z = blockIdx.y, lane = threadIdx.x & 63, s = threadIdx.x >> 6;
-    const int base = T.off[z], n = T.off[z + 1] - base;
+    const int base = T.cnt ? z * T.stride : T.off[z], n = T.cnt ? T.cnt[z] : T.off[z + 1] - base;
     const double *pts = T.pts + 3 * (size_t)base, *px = T.px + 2 * (size_t)base, *pdn = T.pdn + 3 * (size_t)base;
     const int32_t *sm = T.samples + 3 * ((size_t)z * T.iters + it);
     const int i0 = sm[0], i1 = sm[1], i2 = sm[2];
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void k_p3p_select(P3PArgs T)
     __shared__ double s_P[12], s_K[9];
     __shared__ double s_err[P3P_ERR_LDS];
     const int tid = threadIdx.x, z = blockIdx.x, ne = 4 * T.iters;
-    const int base = T.off[z], n = T.off[z + 1] - base;
+    const int base = T.cnt ? z * T.stride : T.off[z], n = T.cnt ? T.cnt[z] : T.off[z + 1] - base;
     const double *pts = T.pts + 3 * (size_t)base, *px = T.px + 2 * (size_t)base;
     const int *counts = T.counts + (size_t)z * ne;
     const double *poses = T.poses + (size_t)z * ne * 12;
@@ -316,7 +317,7 @@ static int p3p_run(slam_ctx *ctx, int S, const int32_t *off, const double *pts3d
     P3PArgs T;
     T.pts = (const double *)(d + o_pts); T.px = (const double *)(d + o_px); T.pdn = (const double *)(d + o_pdn);
     T.samples = (const int32_t *)(d + o_smp); T.off = (const int *)(d + o_off); T.Ks = (const double *)(d + o_K);
-    T.iters = iters; T.thr = threshold;
+    T.iters = iters; T.thr = threshold; T.cnt = nullptr; T.stride = 0;
     T.counts = (int *)scr; T.poses = (double *)(scr + s_cnt); T.errs = (double *)(scr + s_cnt + s_pose);
     T.out = (double *)(d + o_out); T.inliers = (uint8_t *)(d + o_inl);
     { ProfScope span(ctx, "p3p_ransac");
@@ -378,4 +379,260 @@ extern "C" int slam_p3p_ransac_batch(slam_ctx *ctx, int S, const int32_t *offset
         return SLAM_OK;
     }
     return p3p_run(ctx, S, offsets, pts3d, px_xy, pdn, K, threshold, samples, iters, KP, Rt, inliers, n_inliers, error, best_iter);
+}
+
+// =====================================================================================================================
+// compute_pose! on the device-resident keypoint set (src/front_end.jl:132-219): for every stream, the 3-D keypoints of the
+// set -> P3P RANSAC (k_p3p_score / k_p3p_select above) -> removal of its outliers -> PnP refinement of the inliers
+// (k_pnp_batch, ba.hip) -> removal of its outliers, acceptance tests of :136, :179-183, :207-211.  Nothing but the S poses,
+// the S status words and the S list lengths travels to the host; the gather of :139-160 (ordered, is_3d keypoints only),
+// the inlier compaction of :190-201 and the observation removals are kernels on the set's arrays.
+// The reference draws its triples from Julia's global RNG inside RecoverPose; here they come from a counter-based generator
+// (splitmix64 of seed, stream, iteration, attempt; three distinct indices) that keypoint_set.py restates, so that the same
+// triples can be handed to the host seam (slam_p3p_ransac_batch) in the parity test.
+// =====================================================================================================================
+struct KPoseArgs {
+    const double *yx, *xyz; const uint8_t *is3d; const int *count; int cap;   // the set
+    const double *par;                 // S x 32: [16..19] fx fy cx cy, [20..23] k1 k2 p1 p2
+    double *pts, *px, *pdn; int *slot; int *n3;                                // gathered 3-D keypoints, stride cap per stream
+    int32_t *samples; int iters; unsigned long long seed;
+    double *p3p_out; uint8_t *inl;     // k_p3p_select's outputs (S x 32 doubles; stride cap)
+    double *bpx, *bpts; int *bslot; uint8_t *outl; PnPArgs *pnp; double *res;   // refinement inputs / outputs
+    int iters_fast, iterations; double depth_eps, repr_eps;
+    uint8_t *flags;                    // S x cap: observations to remove
+    double *poses; int *status, *ninl; // S x 16 (column-major Tcw), S, S
+};
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// ordered compaction of a stream's flagged elements: returns this thread's output position (or -1), advances *base
+__device__ __forceinline__ int ordered_slot(bool take, int *s_w, int *s_base)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned long long m = __ballot(take);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_w[wv] = __popcll(m);
+    __syncthreads();
+    int off = *s_base;
+    for (int w = 0; w < wv; w++) off += s_w[w];
+    const int pos = take ? off + before : -1;
+    __syncthreads();
+    if (tid == 0) *s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    return pos;
+}
+
+__global__ __launch_bounds__(256) void k_kpose_gather(KPoseArgs A)
+{
+    __shared__ int s_w[4], s_base;
+    const int z = blockIdx.x, tid = threadIdx.x, n = A.count[z];
+    const size_t b = (size_t)z * A.cap;
+    const double fx = A.par[32 * z + 16], fy = A.par[32 * z + 17], cx = A.par[32 * z + 18], cy = A.par[32 * z + 19];
+    const double k1 = A.par[32 * z + 20], k2 = A.par[32 * z + 21], p1 = A.par[32 * z + 22], p2 = A.par[32 * z + 23];
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int j = c0 + tid;
+        const bool take = j < n && A.is3d[b + j] != 0;
+        const int pos = ordered_slot(take, s_w, &s_base);
+        if (take) {
+            const size_t q = b + j, o = b + pos;
+            // undistort_point (camera.jl:98-125) -> undistorted_pixel (y, x); backproject (:138-140) -> position; normalize
+            const double ny = (A.yx[2 * q] - cy) / fy, nx = (A.yx[2 * q + 1] - cx) / fx;
+            const double s0 = ny * ny, s1 = nx * nx, r2 = s0 + s1;
+            const double rd = (1.0 + k1 * r2) + k2 * (r2 * r2);
+            const double pp = ny * nx;
+            const double dtx = 2 * p1 * pp + p2 * (r2 + 2 * s0), dty = p1 * (r2 + 2 * s1) + 2 * p2 * pp;
+            const double uy = (rd * ny + dty) * fy + cy, ux = (rd * nx + dtx) * fx + cx;
+            const double bx = (ux - cx) / fx, by = (uy - cy) / fy;
+            const double inv = 1.0 / sqrt((bx * bx + by * by) + 1.0);
+            A.px[2 * o] = ux; A.px[2 * o + 1] = uy;                                   // (x, y), front_end.jl:151
+            A.pdn[3 * o] = inv * bx; A.pdn[3 * o + 1] = inv * by; A.pdn[3 * o + 2] = inv * 1.0;
+            A.pts[3 * o] = A.xyz[3 * q]; A.pts[3 * o + 1] = A.xyz[3 * q + 1]; A.pts[3 * o + 2] = A.xyz[3 * q + 2];
+            A.slot[o] = j;
+        }
+    }
+    if (tid == 0) A.n3[z] = s_base;
+}
+
+__global__ __launch_bounds__(256) void k_kpose_samples(KPoseArgs A)
+{
+    const int z = blockIdx.y, it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= A.iters) return;
+    const int n = A.n3[z];
+    int32_t *sm = A.samples + 3 * ((size_t)z * A.iters + it);
+    if (n < 5) { sm[0] = sm[1] = sm[2] = -1; return; }              // front_end.jl:133-136: fewer than 5 3-D keypoints -> no P3P
+    int idx[3]; unsigned att = 0;
+    for (int k = 0; k < 3; k++) {
+        for (;;) {
+            const unsigned long long h = splitmix64(A.seed ^ ((unsigned long long)z << 48) ^ ((unsigned long long)it << 16) ^ (unsigned long long)att);
+            att++;
+            const int c = (int)(h % (unsigned long long)n);
+            bool dup = false;
+            for (int m = 0; m < k; m++) dup = dup || idx[m] == c;
+            if (!dup) { idx[k] = c; break; }
+        }
+    }
+    sm[0] = idx[0]; sm[1] = idx[1]; sm[2] = idx[2];
+}
+
+// RotZYX(R).theta1..3 (Rotations.jl; get_cw_ba, frame.jl:432-437) of a column-major 3 x 4 [R | t]
+__device__ __forceinline__ void rt_to_x(const double *Rt, double *X)
+{
+    const double R11 = Rt[0], R21 = Rt[1], R31 = Rt[2], R12 = Rt[3], R22 = Rt[4], R13 = Rt[6], R23 = Rt[7];
+    const double t1 = atan2(R21, R11), s1 = sin(t1), c1 = cos(t1);
+    X[0] = t1; X[1] = atan2(-R31, sqrt(R11 * R11 + R21 * R21)); X[2] = atan2(R13 * s1 - R23 * c1, R22 * c1 - R12 * s1);
+    X[3] = Rt[9]; X[4] = Rt[10]; X[5] = Rt[11];
+}
+
+__global__ __launch_bounds__(256) void k_kpose_prep(KPoseArgs A)
+{
+    __shared__ int s_w[4], s_base;
+    const int z = blockIdx.x, tid = threadIdx.x, n = A.n3[z];
+    const size_t b = (size_t)z * A.cap;
+    const double *out = A.p3p_out + 32 * (size_t)z;
+    const int best = ((const int *)(out + 25))[0];
+    const bool ok = n >= 5 && best >= 5;                                     // :133, :179
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    if (ok) {
+        for (int c0 = 0; c0 < n; c0 += 256) {
+            const int i = c0 + tid;
+            const bool in = i < n && A.inl[b + i] != 0;
+            if (i < n && !in) A.flags[b + A.slot[b + i]] = 1;                // :187-189 remove_obs_from_current_frame!
+            const int pos = ordered_slot(in, s_w, &s_base);
+            if (in) {
+                const size_t o = b + pos, q = b + i;
+                A.bpx[2 * o] = A.px[2 * q + 1]; A.bpx[2 * o + 1] = A.px[2 * q];      // back to (y, x), :195-199
+                A.bpts[3 * o] = A.pts[3 * q]; A.bpts[3 * o + 1] = A.pts[3 * q + 1]; A.bpts[3 * o + 2] = A.pts[3 * q + 2];
+                A.bslot[o] = A.slot[q];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        PnPArgs P;
+        P.cam = {A.par[32 * z + 16], A.par[32 * z + 17], A.par[32 * z + 18], A.par[32 * z + 19]};
+        P.px = A.bpx + 2 * b; P.pts = A.bpts + 3 * b; P.n = ok ? s_base : 0;
+        P.iters_fast = A.iters_fast; P.iterations = A.iterations; P.depth_eps = A.depth_eps; P.repr_eps = A.repr_eps;
+        P.outl = A.outl + b; P.result = A.res + 16 * (size_t)z;
+        if (ok) rt_to_x(out + 12, P.X0);                                     // set_cw!(frame, iK * KP) = [R | t] (:184)
+        else for (int a = 0; a < 6; a++) P.X0[a] = 0.0;
+        A.pnp[z] = P;
+        A.status[z] = ok ? 1 : 0; A.ninl[z] = ok ? best : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_kpose_finish(KPoseArgs A)
+{
+    const int z = blockIdx.x, tid = threadIdx.x;
+    const size_t b = (size_t)z * A.cap;
+    const double *r = A.res + 16 * (size_t)z;
+    const int n = A.pnp[z].n, no = (int)r[8];
+    const bool p3p_ok = A.status[z] != 0;
+    // :207-211: too few inliers after the refinement, or the refinement made the error worse -> reset (pose not applied, its
+    // outliers not removed); r[9] = pnp_bundle_adjustment's own < 5 inliers exit
+    const bool accept = p3p_ok && !(n - no < 5 || r[7] > r[6]) && r[9] == 0.0;
+    if (accept)
+        for (int i = tid; i < n; i += 256)
+            if (A.outl[b + i]) A.flags[b + A.bslot[b + i]] = 1;              // :213-215
+    if (tid == 0) {
+        double *T = A.poses + 16 * (size_t)z;
+        for (int k = 0; k < 16; k++) T[k] = (k % 5 == 0) ? 1.0 : 0.0;
+        if (accept) {
+            const double s1 = sin(r[0]), c1 = cos(r[0]), s2 = sin(r[1]), c2 = cos(r[1]), s3 = sin(r[2]), c3 = cos(r[2]);
+            const double R[9] = {c1 * c2, c1 * s2 * s3 - s1 * c3, c1 * s2 * c3 + s1 * s3, s1 * c2, s1 * s2 * s3 + c1 * c3, s1 * s2 * c3 - c1 * s3, -s2, c2 * s3, c2 * c3};
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[i + 4 * j] = R[3 * i + j];
+            T[12] = r[3]; T[13] = r[4]; T[14] = r[5];
+        }
+        A.status[z] = accept ? 1 : 0;
+    }
+}
+
+extern "C" int slam_kpset_compute_pose(slam_ctx *ctx, slam_kpset *ks, const double *params, double threshold, int iters, uint64_t seed,
+                                       int pnp_iters_fast, int pnp_iterations, double depth_eps, double repr_eps,
+                                       double *poses_cw, int32_t *status, int32_t *n_inliers, int32_t *counts)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && params != nullptr && iters > 0 && poses_cw && status);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int S = ks->S, cap = ks->cap;
+    const size_t nc = (size_t)S * cap;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    // scratch layout
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += up(bytes); return at; };
+    const size_t o_pts = take(nc * 24), o_px = take(nc * 16), o_pdn = take(nc * 24), o_slot = take(nc * 4), o_n3 = take((size_t)S * 4);
+    const size_t o_smp = take((size_t)S * iters * 12), o_cnt = take((size_t)S * iters * 16), o_pose = take((size_t)S * iters * 4 * 96);
+    const size_t o_err = take(nc * 8), o_out = take((size_t)S * 256), o_inl = take(nc);
+    const size_t o_bpx = take(nc * 16), o_bpts = take(nc * 24), o_bslot = take(nc * 4), o_outl = take(nc), o_pnp = take((size_t)S * sizeof(PnPArgs));
+    const size_t o_res = take((size_t)S * 128), o_flags = take(nc), o_T = take((size_t)S * 128), o_st = take((size_t)S * 4), o_ni = take((size_t)S * 4);
+    char *scr;
+    int rc = slam_scratch2(ctx, o, (void **)&scr);
+    if (rc) return rc;
+    const double *par_dev;
+    rc = kpset_stage_params(ctx, ks, params, (size_t)S * 32, &par_dev);
+    if (rc) return rc;
+    KPoseArgs A;
+    A.yx = ks->yx; A.xyz = ks->xyz; A.is3d = ks->is3d; A.count = ks->count; A.cap = cap; A.par = par_dev;
+    A.pts = (double *)(scr + o_pts); A.px = (double *)(scr + o_px); A.pdn = (double *)(scr + o_pdn); A.slot = (int *)(scr + o_slot); A.n3 = (int *)(scr + o_n3);
+    A.samples = (int32_t *)(scr + o_smp); A.iters = iters; A.seed = seed;
+    A.p3p_out = (double *)(scr + o_out); A.inl = (uint8_t *)(scr + o_inl);
+    A.bpx = (double *)(scr + o_bpx); A.bpts = (double *)(scr + o_bpts); A.bslot = (int *)(scr + o_bslot); A.outl = (uint8_t *)(scr + o_outl);
+    A.pnp = (PnPArgs *)(scr + o_pnp); A.res = (double *)(scr + o_res);
+    A.iters_fast = pnp_iters_fast; A.iterations = pnp_iterations; A.depth_eps = depth_eps; A.repr_eps = repr_eps;
+    A.flags = (uint8_t *)(scr + o_flags); A.poses = (double *)(scr + o_T); A.status = (int *)(scr + o_st); A.ninl = (int *)(scr + o_ni);
+    P3PArgs T;
+    T.pts = A.pts; T.px = A.px; T.pdn = A.pdn; T.samples = A.samples; T.off = nullptr; T.cnt = A.n3; T.stride = cap;
+    T.Ks = nullptr; T.iters = iters; T.thr = threshold;
+    T.counts = (int *)(scr + o_cnt); T.poses = (double *)(scr + o_pose); T.errs = (double *)(scr + o_err);
+    T.out = A.p3p_out; T.inliers = A.inl;
+    // K per stream (column-major 3 x 3) goes with the parameters: built on the host, staged like them
+    {
+        double *Kh; void *hv;
+        rc = slam_pinned(ctx, up((size_t)S * 72) + up((size_t)S * 128) + 3 * up((size_t)S * 4), &hv);
+        if (rc) return rc;
+        Kh = (double *)hv;
+        for (int z = 0; z < S; z++) {
+            double *K = Kh + 9 * z;
+            for (int j = 0; j < 9; j++) K[j] = 0.0;
+            K[0] = params[32 * z + 16]; K[4] = params[32 * z + 17]; K[6] = params[32 * z + 18]; K[7] = params[32 * z + 19]; K[8] = 1.0;
+        }
+        double *Kd;
+        HIP_TRY(ctx, hipHostGetDevicePointer((void **)&Kd, Kh, 0));
+        T.Ks = Kd;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(A.flags, 0, nc, ctx->stream));
+    { ProfScope span(ctx, "kpset_compute_pose");
+      hipLaunchKernelGGL(k_kpose_gather, dim3(S), dim3(256), 0, ctx->stream, A);
+      hipLaunchKernelGGL(k_kpose_samples, dim3((iters + 255) / 256, S), dim3(256), 0, ctx->stream, A);
+      hipLaunchKernelGGL(k_p3p_score, dim3(iters, S), dim3(256), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_p3p_select, dim3(S), dim3(256), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_kpose_prep, dim3(S), dim3(256), 0, ctx->stream, A);
+      rc = pnp_launch_device(ctx, S, A.pnp);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_kpose_finish, dim3(S), dim3(256), 0, ctx->stream, A); }
+    HIP_TRY(ctx, hipGetLastError());
+    rc = kpset_compact(ctx, ks, 1, A.flags);
+    if (rc) return rc;
+    // results: poses, status, inlier counts, list lengths -- one wait
+    void *hv;
+    rc = slam_pinned(ctx, up((size_t)S * 72) + up((size_t)S * 128) + 3 * up((size_t)S * 4), &hv);     // same block as above (K first)
+    if (rc) return rc;
+    char *h = (char *)hv + up((size_t)S * 72);
+    HIP_TRY(ctx, hipMemcpyAsync(h, A.poses, (size_t)S * 128, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + up((size_t)S * 128), A.status, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + up((size_t)S * 128) + up((size_t)S * 4), A.ninl, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + up((size_t)S * 128) + 2 * up((size_t)S * 4), ks->count, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    memcpy(poses_cw, h, (size_t)S * 128);
+    memcpy(status, h + up((size_t)S * 128), (size_t)S * 4);
+    if (n_inliers) memcpy(n_inliers, h + up((size_t)S * 128) + up((size_t)S * 4), (size_t)S * 4);
+    if (counts) memcpy(counts, h + up((size_t)S * 128) + 2 * up((size_t)S * 4), (size_t)S * 4);
+    return SLAM_OK;
 }

@@ -115,3 +115,63 @@ class KeypointSet:
         W = np.ascontiguousarray(np.broadcast_to(W, (self.S, 4, 4)).transpose(0, 2, 1).reshape(self.S, 16))
         c.check(c.lib.slam_kpset_triangulate(c.h, self.h, L.ptr(P1), L.ptr(P2), L.ptr(T), L.ptr(c1), L.ptr(c2), L.ptr(W),
                                              float(max_error), float(min_depth), int(n_bound)))
+
+    def compute_pose(self, sp, threshold=3.0, iters=256, seed=0, pnp_iters_fast=5, pnp_iterations=10, depth_eps=1e-6, repr_eps=None, ctx=None):
+        """compute_pose! (front_end.jl:132-219) for every stream on the device-resident lists (slam_kpset_compute_pose): returns
+        (poses (S, 4, 4) world -> camera, status (S,), P3P inlier counts (S,), list lengths after the outlier removals (S,)).
+        sp: stream_params(...) with the camera / distortion entries filled; repr_eps defaults to `threshold`
+        (max_reprojection_error on both, front_end.jl:166,206)."""
+        c = ctx or self.ctx
+        sp = np.ascontiguousarray(sp, dtype=np.float64).reshape(self.S, 32)
+        poses = np.zeros((self.S, 16)); status = np.zeros(self.S, dtype=np.int32); ninl = np.zeros(self.S, dtype=np.int32)
+        counts = np.zeros(self.S, dtype=np.int32)
+        c.check(c.lib.slam_kpset_compute_pose(c.h, self.h, L.ptr(sp), float(threshold), int(iters), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                              int(pnp_iters_fast), int(pnp_iterations), float(depth_eps),
+                                              float(threshold if repr_eps is None else repr_eps),
+                                              L.ptr(poses), L.ptr(status, L.i32p), L.ptr(ninl, L.i32p), L.ptr(counts, L.i32p)))
+        return poses.reshape(self.S, 4, 4).transpose(0, 2, 1).copy(), status, ninl, counts
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
+
+
+def pose_samples(seed, stream, n, iters):
+    """The triples slam_kpset_compute_pose draws for stream `stream` with `n` 3-D keypoints (csrc/pose.hip, k_kpose_samples):
+    three distinct indices per iteration, splitmix64(seed ^ stream << 48 ^ iteration << 16 ^ attempt) mod n; -1 when n < 5."""
+    out = np.full((iters, 3), -1, dtype=np.int32)
+    if n < 5:
+        return out
+    for it in range(iters):
+        att = 0
+        idx = []
+        while len(idx) < 3:
+            h = _splitmix64((int(seed) ^ (int(stream) << 48) ^ (it << 16) ^ att) & 0xFFFFFFFFFFFFFFFF)
+            att += 1
+            c = int(h % n)
+            if c not in idx:
+                idx.append(c)
+        out[it] = idx
+    return out
+
+
+def pose_inputs(cam, dist, yx, xyz):
+    """front_end.jl:139-160 for one stream's 3-D keypoints: (pts3d, px_xy, pdn) as p3p_ransac takes them -- undistort_point
+    (camera.jl:98-125), backproject (:138-140), normalize; the arithmetic of k_kpose_gather term by term."""
+    fx, fy, cx, cy = cam
+    k1, k2, p1, p2 = dist
+    yx = np.asarray(yx, dtype=np.float64).reshape(-1, 2)
+    ny = (yx[:, 0] - cy) / fy; nx = (yx[:, 1] - cx) / fx
+    s0 = ny * ny; s1 = nx * nx; r2 = s0 + s1
+    rd = (1.0 + k1 * r2) + k2 * (r2 * r2)
+    pp = ny * nx
+    dtx = 2 * p1 * pp + p2 * (r2 + 2 * s0); dty = p1 * (r2 + 2 * s1) + 2 * p2 * pp
+    uy = (rd * ny + dty) * fy + cy; ux = (rd * nx + dtx) * fx + cx
+    bx = (ux - cx) / fx; by = (uy - cy) / fy
+    inv = 1.0 / np.sqrt((bx * bx + by * by) + 1.0)
+    px_xy = np.stack([ux, uy], axis=1)
+    pdn = np.stack([inv * bx, inv * by, inv * 1.0], axis=1)
+    return np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3), px_xy, pdn

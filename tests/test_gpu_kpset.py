@@ -148,3 +148,75 @@ def test_pose_prior_and_capacity(slam, syn, texture):
     assert c[1] == 41 and c[0] > 10
     ref = slam.detect(e, b.pyramids[0], kp[:10])
     assert np.array_equal(ks.download(0)["yx"][10:], ref.astype(float))
+
+
+def test_compute_pose_on_the_set_equals_the_host_seams(slam, syn):
+    """slam_kpset_compute_pose (front_end.jl:132-219 on the device-resident lists) against the host route it replaces: download
+    the lists, build the P3P inputs with numpy, the SAME triples (pose_samples), slam_p3p_ransac_batch, numpy inlier surgery,
+    slam_pnp_ba_batch, numpy removal -- poses, status words and the surviving lists."""
+    S, cap = 4, 700
+    ks = slam.KeypointSet(S, cap)
+    cam = syn.KITTI_CAM
+    rng = np.random.default_rng(11)
+    host = []
+    for s in range(S):
+        n3 = [400, 3, 250, 60][s]                               # stream 1: fewer than five 3-D keypoints -> status 0, nothing removed
+        sc = syn.p3p_scene(n=n3, seed=20 + s, noise_px=0.3, outlier_frac=[0.25, 0.0, 0.1, 0.9][s], iters=4)   # stream 3: hardly any inliers
+        n2 = 50 + 10 * s                                         # 2-D keypoints interleaved with the 3-D ones
+        n = n3 + n2
+        order = rng.permutation(n)
+        yx = np.zeros((n, 2)); is3 = np.zeros(n, bool); xyz = np.zeros((n, 3))
+        yx[order[:n3]] = sc["px_xy"][:, ::-1]; is3[order[:n3]] = True; xyz[order[:n3]] = sc["pts3d"]
+        yx[order[n3:]] = rng.uniform(5, 300, (n2, 2))
+        ks.upload(s, yx, is3, xyz)
+        host.append((yx, is3, xyz, sc))
+    dist = (0.0, 0.0, 0.0, 0.0)
+    sp = slam.stream_params(S, cam=cam, dist=dist)
+    before = [ks.download(s) for s in range(S)]
+    iters, seed, thr = 128, 77, 3.0
+    poses, status, ninl, counts = ks.compute_pose(sp, threshold=thr, iters=iters, seed=seed)
+    after = [ks.download(s) for s in range(S)]
+    # ---- the host route ----
+    K = np.array([[cam[0], 0, cam[2]], [0, cam[1], cam[3]], [0, 0, 1.0]])
+    P, X, B, SM, idx3 = [], [], [], [], []
+    for s in range(S):
+        d = before[s]
+        m = d["is_3d"].astype(bool)
+        pts, px, pdn = slam.pose_inputs(cam, dist, d["yx"][m], d["xyz"][m])
+        P.append(px); X.append(pts); B.append(pdn); idx3.append(np.flatnonzero(m))
+        SM.append(slam.pose_samples(seed, s, int(m.sum()), iters))
+    r3 = slam.p3p_ransac_batch(X, P, B, K, threshold=thr, samples=SM)
+    ok = [r is not None and len(X[s]) >= 5 and r[0] >= 5 for s, r in enumerate(r3)]
+    T0, bp, bx = [], [], []
+    for s in range(S):
+        if ok[s]:
+            inl = r3[s][1][1]
+            T = np.eye(4); T[:3] = r3[s][1][3]
+            T0.append(T); bp.append(P[s][inl][:, ::-1]); bx.append(X[s][inl])
+        else:
+            T0.append(np.eye(4)); bp.append(np.zeros((0, 2))); bx.append(np.zeros((0, 3)))
+    rb = slam.pnp_bundle_adjustment_batch(cam, T0, bp, bx, repr_eps=thr)
+    assert ok == [True, False, True, False] or ok == [True, False, True, True]
+    for s in range(S):
+        keep = np.ones(len(before[s]["yx"]), bool)
+        accept = False
+        if ok[s]:
+            inl = r3[s][1][1]
+            keep[idx3[s][~inl]] = False                                          # P3P outliers leave the list
+            newT, e0, e1, outl, no = rb[s]
+            accept = not (int(inl.sum()) - no < 5 or e1 > e0) and not np.array_equal(newT, np.eye(4))
+            if accept:
+                keep[idx3[s][inl][outl]] = False
+                assert np.allclose(poses[s], newT, rtol=0, atol=1e-9), (s, np.abs(poses[s] - newT).max())
+                assert ninl[s] == int(inl.sum())
+        assert status[s] == (1 if accept else 0), s
+        if not accept:
+            assert np.array_equal(poses[s], np.eye(4))
+        assert counts[s] == keep.sum() == len(after[s]["yx"]), (s, counts[s], keep.sum())
+        assert np.array_equal(after[s]["yx"], before[s]["yx"][keep]) and np.array_equal(after[s]["ids"], before[s]["ids"][keep]), s
+        assert np.array_equal(after[s]["is_3d"], before[s]["is_3d"][keep])
+    # the accepted poses are the scene's pose
+    for s in (0, 2):
+        assert status[s] == 1
+        Rt = host[s][3]["Rt_gt"]
+        assert np.abs(poses[s][:3] - Rt).max() < 5e-3, np.abs(poses[s][:3] - Rt).max()
