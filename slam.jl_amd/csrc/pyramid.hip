@@ -170,6 +170,8 @@ template <int COL_NB> struct ColIO {
     int H, W, P, x0;                    // rows, columns, column pitch, first column of this wave
     int slo, shi;                       // columns this wave may store: [slo, shi] (whole image: 0, W - 1; the fused column kernel: its 62 own columns)
     double *lds;                        // 64 x COL_LS doubles
+    bool nt = false;                    // full tiles leave as nontemporal 16-byte stores: the bandwidth-bound batch kernels only (streams far larger than the
+                                        // caches; for a single image the next kernel finds the plane in L2 / MALL and nontemporal stores cost 39 % of the frame rate)
     __device__ __forceinline__ int xown() const { int x = x0 + (int)(threadIdx.x & 63); return x < W ? x : W - 1; }
     __device__ __forceinline__ bool valid() const { const int c = x0 + (int)(threadIdx.x & 63); return c >= slo && c <= shi; }
     __device__ __forceinline__ double ld_src(int i) const { return src[(size_t)i + (size_t)xown() * P]; }
@@ -203,7 +205,8 @@ template <int COL_NB> struct ColIO {
             const int col = x0 + 8 * r + cg;
             if (col >= slo && col <= shi) {
                 double *q = dst + ((size_t)(x0 + 8 * r) * P + rb) + voff;
-                if (!partial) { const v2d v = {t[2 * r], t[2 * r + 1]}; __builtin_nontemporal_store(v, (v2d *)q); }   // one 16-byte store (a plain one is split and merged with the partial path below: 8-byte stores)
+                if (!partial && nt) { const v2d v = {t[2 * r], t[2 * r + 1]}; __builtin_nontemporal_store(v, (v2d *)q); }   // one 16-byte store (a plain one is split and merged with the partial path below: 8-byte stores)
+                else if (!partial) *(double2 *)q = make_double2(t[2 * r], t[2 * r + 1]);
                 else {
                     if (row >= lo && row <= hi) q[0] = t[2 * r];
                     if (row + 1 >= lo && row + 1 <= hi) q[1] = t[2 * r + 1];
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_cols_ck(PlaneSet ps, const
     const double *sqsrc = ps_sq(ps, pl);                       // squared input (Iy -> Iyy, Ix -> Ixx), or nullptr
     const bool sq = sqsrc != nullptr;
     io.dst = ps_plane(ps, pl); io.src = sq ? sqsrc : ((pl == 0 && src0) ? src0 : io.dst);
-    io.H = H; io.W = W; io.P = P; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile; io.slo = 0; io.shi = W - 1;
+    io.H = H; io.W = W; io.P = P; io.x0 = blockIdx.x * LINE_THREADS; io.lds = tile; io.slo = 0; io.shi = W - 1; io.nt = true;
     const size_t nlines = (size_t)gridDim.z * gridDim.y * gridDim.x * LINE_THREADS;
     const size_t lineid = (((size_t)blockIdx.z * gridDim.y + pl) * gridDim.x + blockIdx.x) * LINE_THREADS + lane;
     const int n = H;
@@ -799,7 +802,7 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     io.src = A.L + z;
     io.dst = (ROLE == 0 ? A.T : ROLE == 1 ? A.Qyy : ROLE == 2 ? A.Qxx : A.Qyx) + z;
     io.H = H; io.W = W; io.P = P; io.x0 = xl; io.lds = stage;
-    io.slo = own0; io.shi = own0 + CF4_COLS - 1 < W - 1 ? own0 + CF4_COLS - 1 : W - 1;
+    io.slo = own0; io.shi = own0 + CF4_COLS - 1 < W - 1 ? own0 + CF4_COLS - 1 : W - 1; io.nt = true;
     ColIO<2> iog = io;                                            // gradient plane written on the way (ROLE 1: Iy, ROLE 2: Ix)
     iog.dst = (ROLE == 1 ? A.Iy : A.Ix) + z;
     const int col = xl + lane;
