@@ -1647,8 +1647,14 @@ int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy, int
 // single-thread 6x6 solve; no host round trips.
 
 #define PNP_T 256
-__device__ void pnp_reduce(double *v, int cnt, double *sh /* 4*cnt */, double *outv)
+// (templates + forced inlining keep the partial sums in registers and the LDS / global pointers in their address spaces: the
+//  generic version ran with 188 bytes of scratch per lane and FLAT accesses throughout)
+typedef const __attribute__((address_space(1))) double *pnp_gcd;
+typedef __attribute__((address_space(1))) uint8_t *pnp_gu8;
+template <int cnt>
+__device__ __forceinline__ void pnp_reduce(double *v, double *sh /* 4*cnt */, double *outv)
 {
+#pragma unroll
     for (int k = 0; k < cnt; k++) {
         double t = v[k];
 #pragma unroll
@@ -1656,13 +1662,16 @@ __device__ void pnp_reduce(double *v, int cnt, double *sh /* 4*cnt */, double *o
         v[k] = t;
     }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) for (int k = 0; k < cnt; k++) sh[(threadIdx.x >> 6) * cnt + k] = v[k];
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < cnt; k++) sh[(threadIdx.x >> 6) * cnt + k] = v[k];
+    }
     __syncthreads();
     if (threadIdx.x == 0) for (int k = 0; k < cnt; k++) { double t = 0.0; for (int w = 0; w < PNP_T / 64; w++) t += sh[w * cnt + k]; outv[k] = t; }
     __syncthreads();
 }
 
-__device__ int pnp_lm(const PnPArgs &A, double *X /*shared 6*/, int ignore, int iterations, double *sh, double *red /*shared 40*/,
+__device__ __forceinline__ int pnp_lm(const PnPArgs &A, pnp_gcd gpx, pnp_gcd gpts, pnp_gu8 goutl, double *X /*shared 6*/, int ignore, int iterations, double *sh, double *red /*shared 40*/,
                       double *Xt /*shared 6*/, double *dxs /*shared 6*/, int *flags /*shared 4*/, double *ssr_out)
 {
     const int tid = threadIdx.x, n = A.n;
@@ -1670,23 +1679,24 @@ __device__ int pnp_lm(const PnPArgs &A, double *X /*shared 6*/, int ignore, int 
     // ssr at X
     v[0] = 0.0;
     for (int i = tid; i < n; i += PNP_T) {
-        if (ignore && A.outl[i]) continue;
+        if (ignore && goutl[i]) continue;
         double r[2];
-        obs_eval(X, A.pts + 3 * i, A.px[2 * i], A.px[2 * i + 1], A.cam, r, nullptr, nullptr, nullptr);
+        obs_eval(X, (const double *)(gpts + 3 * i), gpx[2 * i], gpx[2 * i + 1], A.cam, r, nullptr, nullptr, nullptr);
         v[0] += r[0] * r[0] + r[1] * r[1];
     }
-    pnp_reduce(v, 1, sh, red);
+    pnp_reduce<1>(v, sh, red);
     double ssr = red[0], delta = LM_DELTA0, decrease = 2.0;
     __shared__ double Hs[36], gs[6];
     int need_jac = 1, converged = 0, iter = 0;
     while (!converged && iter < iterations) {
         iter++;
         if (need_jac) {
+#pragma unroll
             for (int k = 0; k < 27; k++) v[k] = 0.0;
             for (int i = tid; i < n; i += PNP_T) {
-                if (ignore && A.outl[i]) continue;
+                if (ignore && goutl[i]) continue;
                 double r[2], Jp[12], Jl[6];
-                obs_eval(X, A.pts + 3 * i, A.px[2 * i], A.px[2 * i + 1], A.cam, r, Jp, Jl, nullptr);
+                obs_eval(X, (const double *)(gpts + 3 * i), gpx[2 * i], gpx[2 * i + 1], A.cam, r, Jp, Jl, nullptr);
                 int c = 0;
 #pragma unroll
                 for (int a = 0; a < 6; a++)
@@ -1695,31 +1705,61 @@ __device__ int pnp_lm(const PnPArgs &A, double *X /*shared 6*/, int ignore, int 
 #pragma unroll
                 for (int a = 0; a < 6; a++) v[21 + a] += Jp[a] * r[0] + Jp[6 + a] * r[1];
             }
-            pnp_reduce(v, 27, sh, red);
+            pnp_reduce<27>(v, sh, red);
             if (tid == 0) {
                 int c = 0;
-                for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { Hs[a + 6 * b] = red[c]; Hs[b + 6 * a] = red[c]; c++; }
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = a; b < 6; b++) { Hs[a + 6 * b] = red[c]; Hs[b + 6 * a] = red[c]; c++; }
+#pragma unroll
                 for (int a = 0; a < 6; a++) gs[a] = red[21 + a];
             }
             need_jac = 0;
             __syncthreads();
         }
         if (tid == 0) {
+            // 6 x 6 damped normal equations, Cholesky + two triangular solves on one lane; every loop has constant bounds and is
+            // unrolled, so H and x live in registers (with run-time bounds they sat in scratch: ~100 dependent scratch round trips
+            // per LM iteration)
             double H[36], x[6];
+#pragma unroll
             for (int k = 0; k < 36; k++) H[k] = Hs[k];
+#pragma unroll
             for (int a = 0; a < 6; a++) { H[a + 6 * a] += fmin(fmax(Hs[a + 6 * a], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * (1 / delta); x[a] = gs[a]; }
             int fail = 0;
+#pragma unroll
             for (int j = 0; j < 6; j++) {
                 double dj = H[j + 6 * j];
+#pragma unroll
                 for (int k = 0; k < j; k++) dj -= H[j + 6 * k] * H[j + 6 * k];
-                if (!(dj > 0)) { fail = 1; break; }
-                dj = sqrt(dj); H[j + 6 * j] = dj;
-                for (int i = j + 1; i < 6; i++) { double s = H[i + 6 * j]; for (int k = 0; k < j; k++) s -= H[i + 6 * k] * H[j + 6 * k]; H[i + 6 * j] = s / dj; }
+                if (!(dj > 0)) fail = 1;
+                dj = fail ? 1.0 : sqrt(dj); H[j + 6 * j] = dj;           // (after a failure the remaining values are not used)
+#pragma unroll
+                for (int i = j + 1; i < 6; i++) {
+                    double sv = H[i + 6 * j];
+#pragma unroll
+                    for (int k = 0; k < j; k++) sv -= H[i + 6 * k] * H[j + 6 * k];
+                    H[i + 6 * j] = sv / dj;
+                }
             }
             if (!fail) {
-                for (int i = 0; i < 6; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= H[i + 6 * k] * x[k]; x[i] = s / H[i + 6 * i]; }
-                for (int i = 5; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < 6; k++) s -= H[k + 6 * i] * x[k]; x[i] = s / H[i + 6 * i]; }
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    double sv = x[i];
+#pragma unroll
+                    for (int k = 0; k < i; k++) sv -= H[i + 6 * k] * x[k];
+                    x[i] = sv / H[i + 6 * i];
+                }
+#pragma unroll
+                for (int i = 5; i >= 0; i--) {
+                    double sv = x[i];
+#pragma unroll
+                    for (int k = i + 1; k < 6; k++) sv -= H[k + 6 * i] * x[k];
+                    x[i] = sv / H[i + 6 * i];
+                }
             }
+#pragma unroll
             for (int a = 0; a < 6; a++) { dxs[a] = fail ? 0.0 : x[a]; Xt[a] = X[a] - dxs[a]; }
             flags[0] = fail;
         }
@@ -1727,10 +1767,10 @@ __device__ int pnp_lm(const PnPArgs &A, double *X /*shared 6*/, int ignore, int 
         if (flags[0]) break;
         v[0] = 0.0; v[1] = 0.0;
         for (int i = tid; i < n; i += PNP_T) {
-            if (ignore && A.outl[i]) continue;   // zero residual and zero Jacobian row: contributes 0 to both sums
+            if (ignore && goutl[i]) continue;   // zero residual and zero Jacobian row: contributes 0 to both sums
             double r[2], rt[2], Jp[12], Jl[6];
-            obs_eval(Xt, A.pts + 3 * i, A.px[2 * i], A.px[2 * i + 1], A.cam, rt, nullptr, nullptr, nullptr);
-            obs_eval(X, A.pts + 3 * i, A.px[2 * i], A.px[2 * i + 1], A.cam, r, Jp, Jl, nullptr);
+            obs_eval(Xt, (const double *)(gpts + 3 * i), gpx[2 * i], gpx[2 * i + 1], A.cam, rt, nullptr, nullptr, nullptr);
+            obs_eval(X, (const double *)(gpts + 3 * i), gpx[2 * i], gpx[2 * i + 1], A.cam, r, Jp, Jl, nullptr);
             double a = 0.0, b = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; k++) { a += Jp[k] * dxs[k]; b += Jp[6 + k] * dxs[k]; }
@@ -1738,7 +1778,7 @@ __device__ int pnp_lm(const PnPArgs &A, double *X /*shared 6*/, int ignore, int 
             v[0] += rt[0] * rt[0] + rt[1] * rt[1];
             v[1] += a * a + b * b;
         }
-        pnp_reduce(v, 2, sh, red);
+        pnp_reduce<2>(v, sh, red);
         const double trial = red[0], pred = red[1];
         double mx = 0.0;
         for (int a = 0; a < 6; a++) mx = fmax(mx, fabs(dxs[a]));
@@ -1764,38 +1804,39 @@ __device__ int pnp_lm(const PnPArgs &A, double *X /*shared 6*/, int ignore, int 
     return iter;
 }
 
-__device__ void pnp_body(const PnPArgs &A)
+__device__ __forceinline__ void pnp_body(const PnPArgs &A)
 {
+    const pnp_gcd gpx = (pnp_gcd)A.px, gpts = (pnp_gcd)A.pts; const pnp_gu8 goutl = (pnp_gu8)A.outl;
     __shared__ double X[6], Xt[6], dxs[6], sh[4 * 28], red[40];
     __shared__ int flags[4];
     const int tid = threadIdx.x, n = A.n;
     if (tid < 6) X[tid] = A.X0[tid];
-    for (int i = tid; i < n; i += PNP_T) A.outl[i] = 0;
+    for (int i = tid; i < n; i += PNP_T) goutl[i] = 0;
     __syncthreads();
     double v[1] = {0.0};
     for (int i = tid; i < n; i += PNP_T) {
         double r[2];
-        obs_eval(X, A.pts + 3 * i, A.px[2 * i], A.px[2 * i + 1], A.cam, r, nullptr, nullptr, nullptr);
+        obs_eval(X, (const double *)(gpts + 3 * i), gpx[2 * i], gpx[2 * i + 1], A.cam, r, nullptr, nullptr, nullptr);
         v[0] += r[0] * r[0] + r[1] * r[1];
     }
-    pnp_reduce(v, 1, sh, red);
+    pnp_reduce<1>(v, sh, red);
     const double err_init = red[0];
     double ssr1 = 0.0, ssr2 = 0.0;
-    const int it1 = pnp_lm(A, X, 0, A.iters_fast, sh, red, Xt, dxs, flags, &ssr1);
+    const int it1 = pnp_lm(A, gpx, gpts, goutl, X, 0, A.iters_fast, sh, red, Xt, dxs, flags, &ssr1);
     v[0] = 0.0;
     for (int i = tid; i < n; i += PNP_T) {
         double r[2], z;
-        obs_eval(X, A.pts + 3 * i, A.px[2 * i], A.px[2 * i + 1], A.cam, r, nullptr, nullptr, &z);
+        obs_eval(X, (const double *)(gpts + 3 * i), gpx[2 * i], gpx[2 * i + 1], A.cam, r, nullptr, nullptr, &z);
         const bool o = z < A.depth_eps || (r[0] * r[0] + r[1] * r[1]) > A.repr_eps;
-        A.outl[i] = o ? 1 : 0;
+        goutl[i] = o ? 1 : 0;
         v[0] += o ? 1.0 : 0.0;
     }
     __threadfence_block();
-    pnp_reduce(v, 1, sh, red);
+    pnp_reduce<1>(v, sh, red);
     const int no = (int)red[0];
     int identity = 0, it2 = 0;
     if (n - no < 5) { identity = 1; ssr2 = ssr1; }
-    else it2 = pnp_lm(A, X, 1, A.iterations, sh, red, Xt, dxs, flags, &ssr2);
+    else it2 = pnp_lm(A, gpx, gpts, goutl, X, 1, A.iterations, sh, red, Xt, dxs, flags, &ssr2);
     __syncthreads();
     if (tid == 0) {
         for (int a = 0; a < 6; a++) A.result[a] = X[a];
@@ -1807,10 +1848,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp(PnPArgs A) { pnp_body(A); }
 // S independent problems, one workgroup each (slam_pnp_ba_batch); the argument blocks live in mapped host memory
 __global__ __launch_bounds__(PNP_T) void k_pnp_batch(const PnPArgs *args)
 {
-    __shared__ PnPArgs A;
-    if (threadIdx.x == 0) A = args[blockIdx.x];
-    __syncthreads();
-    pnp_body(A);
+    pnp_body(args[blockIdx.x]);                                  // read in place (wave-uniform scalar loads): no LDS copy behind a generic reference
 }
 
 int pnp_launch_device(slam_ctx *ctx, int S, const PnPArgs *args_dev)
