@@ -47,7 +47,7 @@ __device__ static double cubic_root_nonneg(double B, double C, double D)
     return x;
 }
 
-__device__ static int quartic_real_roots(const double *A, double *roots)
+__device__ __forceinline__ int quartic_real_roots(const double *A, double *roots)
 {
     if (!(fabs(A[4]) > 0.0)) return 0;
     const double a = A[3] / A[4], b = A[2] / A[4], c = A[1] / A[4], d = A[0] / A[4];
@@ -57,34 +57,40 @@ __device__ static int quartic_real_roots(const double *A, double *roots)
     const double q = (c - 0.5 * a * b) + 0.125 * a2 * a;
     const double r = ((d - 0.25 * a * c) + 0.0625 * a2 * b) - 0.01171875 * a2 * a2;
     const double sh = 0.25 * a;
-    double y[4];
-    int n = 0;
+    // candidate roots in fixed slots with validity flags (a run-time counter would index the arrays dynamically and move them,
+    // and everything derived from them, to scratch: 400 bytes per lane in k_p3p_score); the order of the valid ones is the
+    // reference order y[n++]
+    double y[4] = {0.0, 0.0, 0.0, 0.0};
+    bool yv[4] = {false, false, false, false};
     const double z = cubic_root_nonneg(2.0 * p, p * p - 4.0 * r, -(q * q));
     if (z > 0.0) {
         const double s = sqrt(z), h = 0.5 * (p + z), g = q / (2.0 * s);
         const double d1 = z - 4.0 * (h - g), d2 = z - 4.0 * (h + g);
-        if (d1 >= 0.0) { const double w = sqrt(d1); y[n++] = 0.5 * (-s + w); y[n++] = 0.5 * (-s - w); }
-        if (d2 >= 0.0) { const double w = sqrt(d2); y[n++] = 0.5 * (s + w); y[n++] = 0.5 * (s - w); }
+        if (d1 >= 0.0) { const double w = sqrt(d1); y[0] = 0.5 * (-s + w); y[1] = 0.5 * (-s - w); yv[0] = yv[1] = true; }
+        if (d2 >= 0.0) { const double w = sqrt(d2); y[2] = 0.5 * (s + w); y[3] = 0.5 * (s - w); yv[2] = yv[3] = true; }
     } else {
         const double disc = p * p - 4.0 * r;
         if (disc >= 0.0) {
             const double w = sqrt(disc), t1 = 0.5 * (-p + w), t2 = 0.5 * (-p - w);
-            if (t1 >= 0.0) { const double e = sqrt(t1); y[n++] = e; y[n++] = -e; }
-            if (t2 >= 0.0) { const double e = sqrt(t2); y[n++] = e; y[n++] = -e; }
+            if (t1 >= 0.0) { const double e = sqrt(t1); y[0] = e; y[1] = -e; yv[0] = yv[1] = true; }
+            if (t2 >= 0.0) { const double e = sqrt(t2); y[2] = e; y[3] = -e; yv[2] = yv[3] = true; }
         }
     }
-    int m = 0;
-    for (int i = 0; i < n; i++) {
+    int mask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
         double x = y[i] - sh;
+#pragma unroll
         for (int k = 0; k < 4; k++) {
             const double f = (((A[4] * x + A[3]) * x + A[2]) * x + A[1]) * x + A[0];
             const double df = ((4.0 * A[4] * x + 3.0 * A[3]) * x + 2.0 * A[2]) * x + A[1];
             const double xn = x - f / df;
             if (isfinite(xn)) x = xn;
         }
-        if (isfinite(x)) roots[m++] = x;
+        roots[i] = x;
+        if (yv[i] && isfinite(x)) mask |= 1 << i;
     }
-    return m;
+    return mask;                                                  // bit i: roots[i] is a real root (slots in reference order)
 }
 
 __device__ static inline void v3_sub(const double *a, const double *b, double *o) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
@@ -112,8 +118,9 @@ __device__ static bool tri_frame(const double *p1, const double *p2, const doubl
     return true;
 }
 
-// X, F: 3 rows of 3; Rt: up to 4 poses x 12 (column-major 3x4) in LDS
-__device__ static int p3p_solve(const double *X, const double *F, double *Rt)
+// X, F: 3 rows of 3.  Returns the number of poses; Pout receives pose number `want` (column-major 3 x 4) of the reference
+// enumeration when it exists.  The candidate slots are visited with static indices (see quartic_real_roots).
+__device__ __forceinline__ int p3p_solve(const double *X, const double *F, int want, double *Pout)
 {
     double f1[3], f2[3], f3[3];
     if (!v3_unit(F, f1) || !v3_unit(F + 3, f2) || !v3_unit(F + 6, f3)) return 0;
@@ -139,11 +146,13 @@ __device__ static int p3p_solve(const double *X, const double *F, double *Rt)
     Q[3] = ((0.0 + NN3) - 2.0 * cg * ND3) - m * WD3;
     Q[4] = ((0.0 + NN4) - 2.0 * cg * 0.0) - m * WD4;
     double vr[4];
-    const int nr = quartic_real_roots(Q, vr);
+    const int rmask = quartic_real_roots(Q, vr);
     double Ew[9];
     if (!tri_frame(X, X + 3, X + 6, Ew)) return 0;
     int ns = 0;
-    for (int i = 0; i < nr; i++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (!((rmask >> i) & 1)) continue;
         const double v = vr[i];
         if (!(v > 0.0)) continue;
         const double den = D1 * v + D0;
@@ -167,7 +176,10 @@ __device__ static int p3p_solve(const double *X, const double *F, double *Rt)
         bool fin = true;
         for (int j = 0; j < 12; j++) fin = fin && isfinite(P[j]);
         if (!fin) continue;
-        for (int j = 0; j < 12; j++) Rt[12 * ns + j] = P[j];
+        if (ns == want) {
+#pragma unroll
+            for (int j = 0; j < 12; j++) Pout[j] = P[j];
+        }
         ns++;
     }
     return ns;
@@ -203,11 +215,7 @@ __global__ __launch_bounds__(256) void k_p3p_score(P3PArgs T)
             X[j] = pts[3 * i0 + j]; X[3 + j] = pts[3 * i1 + j]; X[6 + j] = pts[3 * i2 + j];
             F[j] = pdn[3 * i0 + j]; F[3 + j] = pdn[3 * i1 + j]; F[6 + j] = pdn[3 * i2 + j];
         }
-        double Rt[48];
-        ns = p3p_solve(X, F, Rt);
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (k == s) for (int j = 0; j < 12; j++) P[j] = Rt[12 * k + j];
+        ns = p3p_solve(X, F, s, P);
     }
     int cnt = 0;
     if (s < ns) {
