@@ -120,7 +120,9 @@ __device__ static bool tri_frame(const double *p1, const double *p2, const doubl
 
 // X, F: 3 rows of 3.  Returns the number of poses; Pout receives pose number `want` (column-major 3 x 4) of the reference
 // enumeration when it exists.  The candidate slots are visited with static indices (see quartic_real_roots).
-__device__ __forceinline__ int p3p_solve(const double *X, const double *F, int want, double *Pout)
+typedef __attribute__((address_space(3))) double p3p_lds;
+template <bool ALL>
+__device__ __forceinline__ int p3p_solve(const double *X, const double *F, int want, double *Pout, p3p_lds *all)
 {
     double f1[3], f2[3], f3[3];
     if (!v3_unit(F, f1) || !v3_unit(F + 3, f2) || !v3_unit(F + 6, f3)) return 0;
@@ -180,6 +182,11 @@ __device__ __forceinline__ int p3p_solve(const double *X, const double *F, int w
 #pragma unroll
             for (int j = 0; j < 12; j++) Pout[j] = P[j];
         }
+        if (ALL) {                                                // every pose, in enumeration order (an LDS array may be indexed at run time; LDS offset 0 is
+                                                                  // a valid address, so the choice is a template flag, not a null test)
+#pragma unroll
+            for (int j = 0; j < 12; j++) all[12 * ns + j] = P[j];
+        }
         ns++;
     }
     return ns;
@@ -196,10 +203,13 @@ __device__ static inline double p3p_reproj(const double *P, const double *K, con
     return sqrt(dx * dx + dy * dy);
 }
 
-__global__ __launch_bounds__(256) void k_p3p_score(P3PArgs T)
+__global__ __launch_bounds__(64) void k_p3p_score(P3PArgs T)
 {
-    // four waves per triple: each runs the (wave-uniform) solver, wave s then scores pose s with its 64 lanes
-    const int it = blockIdx.x, z = blockIdx.y, lane = threadIdx.x & 63, s = threadIdx.x >> 6;
+    // one wave per triple: the (wave-uniform, latency-bound: ~20 k cycles of dependent f64 divisions and square roots) minimal
+    // solver runs ONCE, its up to four poses go to LDS, then the 64 lanes stride over the map points and score every pose on
+    // each point they load.  (Four waves per triple, each repeating the solver for "its" pose, took 190 us per 32-stream call.)
+    __shared__ double s_P[48];
+    const int it = blockIdx.x, z = blockIdx.y, lane = threadIdx.x;
     const int base = T.cnt ? z * T.stride : T.off[z], n = T.cnt ? T.cnt[z] : T.off[z + 1] - base;
     const double *pts = T.pts + 3 * (size_t)base, *px = T.px + 2 * (size_t)base, *pdn = T.pdn + 3 * (size_t)base;
     const int32_t *sm = T.samples + 3 * ((size_t)z * T.iters + it);
@@ -207,31 +217,43 @@ __global__ __launch_bounds__(256) void k_p3p_score(P3PArgs T)
     double K[9];
     for (int j = 0; j < 9; j++) K[j] = T.Ks[9 * z + j];
     int ns = 0;
-    double P[12];
     const bool valid = !(i0 < 0 || i1 < 0 || i2 < 0 || i0 >= n || i1 >= n || i2 >= n || i0 == i1 || i0 == i2 || i1 == i2);
     if (valid) {
-        double X[9], F[9];
+        double X[9], F[9], Pd[12];
         for (int j = 0; j < 3; j++) {
             X[j] = pts[3 * i0 + j]; X[3 + j] = pts[3 * i1 + j]; X[6 + j] = pts[3 * i2 + j];
             F[j] = pdn[3 * i0 + j]; F[3 + j] = pdn[3 * i1 + j]; F[6 + j] = pdn[3 * i2 + j];
         }
-        ns = p3p_solve(X, F, s, P);
+        ns = p3p_solve<true>(X, F, -1, Pd, (p3p_lds *)s_P);             // all lanes hold the same values: the LDS stores coincide
     }
-    int cnt = 0;
-    if (s < ns) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    int cnt[4] = {0, 0, 0, 0};
+    if (ns > 0) {
+        double P[4][12];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int j = 0; j < 12; j++) P[k][j] = k < ns ? s_P[12 * k + j] : 0.0;
         for (int i = lane; i < n; i += 64) {
             const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
             const double q[2] = {px[2 * i], px[2 * i + 1]};
-            const double e = p3p_reproj(P, K, X, q);
-            cnt += (e >= 0.0 && e < T.thr) ? 1 : 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k < ns) {
+                    const double e = p3p_reproj(P[k], K, X, q);
+                    cnt[k] += (e >= 0.0 && e < T.thr) ? 1 : 0;
+                }
         }
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            for (int o = 32; o > 0; o >>= 1) cnt[k] += __shfl_xor(cnt[k], o, 64);
     }
-    if (lane == 0) {
-        const size_t e = ((size_t)z * T.iters + it) * 4 + s;
-        T.counts[e] = cnt;
-        if (s < ns)
-            for (int j = 0; j < 12; j++) T.poses[e * 12 + j] = P[j];
+    if (lane < 4) {
+        const int k = lane;
+        const size_t e = ((size_t)z * T.iters + it) * 4 + k;
+        T.counts[e] = k == 0 ? cnt[0] : k == 1 ? cnt[1] : k == 2 ? cnt[2] : cnt[3];
+        if (k < ns)
+            for (int j = 0; j < 12; j++) T.poses[e * 12 + j] = s_P[12 * k + j];
     }
 }
 
@@ -329,7 +351,7 @@ static int p3p_run(slam_ctx *ctx, int S, const int32_t *off, const double *pts3d
     T.counts = (int *)scr; T.poses = (double *)(scr + s_cnt); T.errs = (double *)(scr + s_cnt + s_pose);
     T.out = (double *)(d + o_out); T.inliers = (uint8_t *)(d + o_inl);
     { ProfScope span(ctx, "p3p_ransac");
-      hipLaunchKernelGGL(k_p3p_score, dim3(iters, S), dim3(256), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_p3p_score, dim3(iters, S), dim3(64), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_p3p_select, dim3(S), dim3(256), 0, ctx->stream, T); }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, slam_stream_wait(ctx->stream));
@@ -619,7 +641,7 @@ extern "C" int slam_kpset_compute_pose(slam_ctx *ctx, slam_kpset *ks, const doub
     { ProfScope span(ctx, "kpset_compute_pose");
       hipLaunchKernelGGL(k_kpose_gather, dim3(S), dim3(256), 0, ctx->stream, A);
       hipLaunchKernelGGL(k_kpose_samples, dim3((iters + 255) / 256, S), dim3(256), 0, ctx->stream, A);
-      hipLaunchKernelGGL(k_p3p_score, dim3(iters, S), dim3(256), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_p3p_score, dim3(iters, S), dim3(64), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_p3p_select, dim3(S), dim3(256), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_kpose_prep, dim3(S), dim3(256), 0, ctx->stream, A);
       rc = pnp_launch_device(ctx, S, A.pnp);
