@@ -907,11 +907,30 @@ def main():
         kspose = slam.KeypointSet(SB, 1024, ctx=ctx)
         for z, q in enumerate(pss):
             kspose.upload(z, q["px_xy"][:, ::-1], np.ones(len(q["pts3d"]), bool), q["pts3d"])
-        sp_pose = slam.stream_params(SB, cam=camp)
+            # the previous key-frame sits at the world origin: its observation of every map point (compute_pose_5pt! pairs it with
+            # the current pixel; the scene's camera pose is the key-frame -> frame motion)
+            Xw = q["pts3d"]
+            kf_px = np.stack([camp[1] * Xw[:, 1] / Xw[:, 2] + camp[3], camp[0] * Xw[:, 0] / Xw[:, 2] + camp[2]], axis=1)      # (y, x)
+            kspose.upload_keyframe(z, kf_px, Xw[:, 2] > 0.1)
+        sp_pose = slam.stream_params(SB, Tcw=np.eye(4), cam=camp)                 # R_compensation = I (no motion-model rotation)
         pose_seed = [0]
+        def pose5_kpset_once():
+            pose_seed[0] += 1
+            return kspose.compute_pose_5pt(sp_pose, min_parallax=5.0, max_repr_error=3.0, iters=128, seed=1000 + pose_seed[0], ctx=ctx)
         def pose_kpset_once():
             pose_seed[0] += 1
             return kspose.compute_pose(sp_pose, threshold=3.0, iters=256, seed=pose_seed[0], ctx=ctx)
+        def pose_frontend_once():                                 # front_end.jl:103-113: the epipolar filter, then compute_pose!
+            pose5_kpset_once()
+            return pose_kpset_once()
+        _, s50, n50, par0, c50 = pose5_kpset_once()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            _, s51, n51, par1, c51 = pose5_kpset_once()
+        out["pose"]["kpset_5pt"] = {"streams": SB, "ms_per_step": (time.perf_counter() - t0) / 10 * 1e3, "accepted": int(s51.sum()),
+                                    "pairs_per_stream": float(c51.mean()), "inliers_first_call": float(n50.mean()), "avg_parallax_px": float(par1.mean()),
+                                    "what": "slam_kpset_compute_pose_5pt: pairs with the key-frame observation, parallax, five-point RANSAC (128 tuples), "
+                                            "outlier removal for 32 streams on device-resident lists"}
         _, st0, ni0, cn0 = pose_kpset_once()
         t0 = time.perf_counter()
         for _ in range(10):
@@ -924,9 +943,10 @@ def main():
             # the tracked workload with compute_pose! of all streams run after every step (pose inputs are the independent
             # synthetic scenes above: the image-plane motion of the tracked streams is not a rigid 3-D motion)
             wp = run_lockstep_kpset(slam, torch, local_rank, S, max(20, args.steps // 4), min(args.warmup, 10), H, W, left, right, flows, disparity,
-                                    params, extractor, world, dist, dev, "host_u8", hook=pose_kpset_once)
+                                    params, extractor, world, dist, dev, "host_u8", hook=pose_frontend_once)
             out["pose"]["frontend_with_pose"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": wp["ms_per_step_of_S_frames"],
-                                                 "what": "headline workload + slam_kpset_compute_pose (P3P RANSAC + PnP refinement, 32 streams) every step"}
+                                                 "what": "headline workload + slam_kpset_compute_pose_5pt (five-point RANSAC) + slam_kpset_compute_pose (P3P "
+                                                         "RANSAC + PnP refinement) of the 32 streams every step: front_end.jl:103-113 on device-resident lists"}
             wp = run_lockstep_kpset(slam, torch, local_rank, S, max(20, args.steps // 4), min(args.warmup, 10), H, W, left, right, flows, disparity,
                                     params, extractor, world, dist, dev, "host_u8", hook=pose_batch_once)
             out["pose"]["frontend_with_host_pose_seams"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": wp["ms_per_step_of_S_frames"],

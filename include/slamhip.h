@@ -284,6 +284,25 @@ int slam_kpset_compute_pose(slam_ctx *ctx, slam_kpset *ks, const double *params,
                             int pnp_iters_fast, int pnp_iterations, double depth_eps, double repr_eps,
                             double *poses_cw, int32_t *status, int32_t *n_inliers, int32_t *counts);
 
+/* create_keyframe! (map_manager.jl:60-96) for the lists: the current frame becomes the previous key-frame of every keypoint it
+ * holds (call it after slam_kpset_detect: the key-frame contains the new keypoints).  The observation travels with the keypoint
+ * through every compaction; keypoints detected later have none until the next call. */
+int slam_kpset_keyframe(slam_ctx *ctx, slam_kpset *ks);
+/* the key-frame observations of stream s's list, host <-> device (restoring state, tests): kyx n x 2 (y, x), has_kf n flags */
+int slam_kpset_upload_keyframe(slam_ctx *ctx, slam_kpset *ks, int s, const double *kyx, const uint8_t *has_kf, int n);
+int slam_kpset_download_keyframe(slam_ctx *ctx, slam_kpset *ks, int s, double *kyx, uint8_t *has_kf, int cap_out, int *n_out);
+/* compute_pose_5pt! (front_end.jl:242-332, run every frame at :105) for every stream, on the set: the keypoints the previous
+ * key-frame also observes -> undistorted pixels and normalised coordinates of both views (:263-272), the rotation-compensated
+ * average parallax (:277-281; params[s][0..8] = R_compensation, column-major; [16..23] camera and distortion) -> five-point
+ * RANSAC (`iters` 5-tuples per stream from the generator of slam_kpset_compute_pose) -> its outliers leave the list (:310-318).
+ * status[s] = 1: P[12 s ..] is [R | t] (column-major 3 x 4, key-frame -> frame, |t| = 1) of the best essential matrix; 0: one
+ * of the `nothing` exits (fewer than 8 keypoints :243 / in the key-frame :283, parallax below min_parallax :290, fewer than 5
+ * inliers :305), nothing removed.  The composition with the motion-model scale (:320-330) is the caller's.  n_inliers, parallax
+ * (the average) and counts (list lengths after the removals) may be NULL.  Synchronous. */
+int slam_kpset_compute_pose_5pt(slam_ctx *ctx, slam_kpset *ks, const double *params, double min_parallax, double max_repr_error,
+                                int iters, uint64_t seed, double *P, int32_t *status, int32_t *n_inliers, double *parallax,
+                                int32_t *counts);
+
 /* ---- bundle adjustment ------------------------------------------------------ */
 /* Array-level body of triangulate_stereo! (parallax == NULL: every gate applies, src/mapper.jl:142-183) and
  * triangulate_temporal! (a gate removes the observation only when parallax[i] > min_parallax, :185-262), for n

@@ -81,6 +81,8 @@ struct slam_kpset {
     double *oyx = nullptr;       // [S cap][2] positions returned by the last temporal match (scratch)
     double *syx = nullptr;       // [S cap][2] stereo pixel (right image), valid where stereo != 0
     double *xyz = nullptr;       // [S cap][3] map point, valid where is3d != 0
+    double *kyx = nullptr;       // [S cap][2] pixel (y, x) in the previous key-frame, valid where haskf != 0 (slam_kpset_keyframe)
+    uint8_t *haskf = nullptr;    // [S cap] the keypoint is observed by the previous key-frame
     int64_t *id = nullptr;       // [S cap] keypoint id (per stream, ascending in creation order)
     uint8_t *is3d = nullptr, *stereo = nullptr, *st = nullptr;   // flags; st: status of the last match (0 lost, 1 tracked, 2 skipped)
     int *count = nullptr;        // [S]

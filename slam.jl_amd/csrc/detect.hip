@@ -504,7 +504,7 @@ extern "C" int slam_detect_batch(slam_ctx *ctx, const slam_pyr *pyr0, int S, con
 // pixels with is_3d = 0 and fresh ids -- extract_keypoints! + add_keypoints_to_frame! (map_manager.jl:98-113) on arrays.
 // One 1024-thread workgroup per stream: wave-level inclusive scans + one LDS hop (as detect_compact).
 __global__ __launch_bounds__(1024) void detect_append(const int64_t *cell_out, const int *cell_cnt, int n_cells, int kmax, int max_points,
-                                                       double *yx, double *syx, double *xyz, int64_t *id, uint8_t *is3d, uint8_t *stereo,
+                                                       double *yx, double *syx, double *xyz, int64_t *id, uint8_t *is3d, uint8_t *stereo, uint8_t *haskf,
                                                        int *count, int64_t *next_id, int cap)
 {
     const int z = blockIdx.x;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(1024) void detect_append(const int64_t *cell_out, c
                 const size_t q = b + j;
                 yx[2 * q] = (double)cell_out[((size_t)c * kz + i) * 2]; yx[2 * q + 1] = (double)cell_out[((size_t)c * kz + i) * 2 + 1];
                 syx[2 * q] = 0.0; syx[2 * q + 1] = 0.0; xyz[3 * q] = 0.0; xyz[3 * q + 1] = 0.0; xyz[3 * q + 2] = 0.0;
-                id[q] = id0 + start + i; is3d[q] = 0; stereo[q] = 0;
+                id[q] = id0 + start + i; is3d[q] = 0; stereo[q] = 0; haskf[q] = 0;
             }
         }
         __syncthreads();
@@ -586,7 +586,7 @@ extern "C" int slam_kpset_detect(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *
     { ProfScope span(ctx, "detect");
       hipLaunchKernelGGL(detect_cells, dim3(n_cells, S), dim3(DET_THREADS), lds_bytes, ctx->stream, A);
       hipLaunchKernelGGL(detect_append, dim3(S), dim3(1024), 0, ctx->stream, (const int64_t *)A.cell_out, (const int *)A.cell_cnt, n_cells, kmax, max_points,
-                         ks->yx, ks->syx, ks->xyz, ks->id, ks->is3d, ks->stereo, ks->count, ks->next_id, ks->cap); }
+                         ks->yx, ks->syx, ks->xyz, ks->id, ks->is3d, ks->stereo, ks->haskf, ks->count, ks->next_id, ks->cap); }
     HIP_TRY(ctx, hipGetLastError());
     return SLAM_OK;
 }

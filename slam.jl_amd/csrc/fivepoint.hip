@@ -31,6 +31,7 @@ struct FPArgs {                            // S independent problems (S = 1: sla
     const double *px1, *px2, *pd1, *pd2;   // concatenated, n x 2 each, (x, y)
     const int32_t *samples;                // S x iters x 5, 0-based, local to the problem
     const int *off;                        // S + 1
+    const int *cnt; int stride;            // keypoint-set layout instead (cnt != nullptr): problem z owns [z * stride, z * stride + cnt[z])
     const double *ks;                      // S x 8: fx, fy, cx, cy of camera 1 then of camera 2
     int iters;
     double thr;
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(FP_TPB * FP_TEAM) void k_5pt_solve(FPArgs T)
     extern __shared__ double s_fp[];
     const int team = threadIdx.x / FP_TEAM, l = threadIdx.x % FP_TEAM, z = blockIdx.y;
     const int it = blockIdx.x * FP_TPB + team;
-    const int base = T.off[z], n = T.off[z + 1] - base;
+    const int base = T.cnt ? z * T.stride : T.off[z], n = T.cnt ? T.cnt[z] : T.off[z + 1] - base;
     const double *pd1 = T.pd1 + 2 * (size_t)base, *pd2 = T.pd2 + 2 * (size_t)base;
     const Col L{s_fp + team};
     bool ok = it < T.iters;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(FP_SCORE_T) void k_5pt_score(FPArgs T)
         if (tid == 0) T.counts[slot * FP_MAXE + e] = 0;
         return;
     }
-    const int base = T.off[z], n = T.off[z + 1] - base;
+    const int base = T.cnt ? z * T.stride : T.off[z], n = T.cnt ? T.cnt[z] : T.off[z + 1] - base;
     const double *px1 = T.px1 + 2 * (size_t)base, *px2 = T.px2 + 2 * (size_t)base;
     double k1[4], k2[4];
     for (int j = 0; j < 4; j++) { k1[j] = T.ks[8 * z + j]; k2[j] = T.ks[8 * z + 4 + j]; }
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(FP_SEL_T) void k_5pt_select(FPArgs T)
     __shared__ double s_P[12], s_k[8];
     __shared__ double s_err[FP_ERR_LDS];
     const int tid = threadIdx.x, z = blockIdx.x, ne = FP_MAXE * T.iters;
-    const int base = T.off[z], n = T.off[z + 1] - base;
+    const int base = T.cnt ? z * T.stride : T.off[z], n = T.cnt ? T.cnt[z] : T.off[z + 1] - base;
     const double *px1 = T.px1 + 2 * (size_t)base, *px2 = T.px2 + 2 * (size_t)base;
     const int *counts = T.counts + (size_t)z * ne;
     const double *poses = T.poses + (size_t)z * ne * 12, *Es = T.Es + (size_t)z * ne * 9;
@@ -688,7 +689,7 @@ static int fp_run(slam_ctx *ctx, int S, const int32_t *off, const double *px1_xy
     FPArgs T;
     T.px1 = (const double *)d; T.px2 = (const double *)(d + pb); T.pd1 = (const double *)(d + 2 * pb); T.pd2 = (const double *)(d + 3 * pb);
     T.samples = (const int32_t *)(d + o_smp); T.off = (const int *)(d + o_off); T.ks = (const double *)(d + o_k);
-    T.iters = iters; T.thr = max_repr_error;
+    T.iters = iters; T.thr = max_repr_error; T.cnt = nullptr; T.stride = 0;
     T.ne = (int *)scr; T.Es = (double *)(scr + s_ne); T.poses = (double *)(scr + s_ne + s_es);
     T.counts = (int *)(scr + s_ne + s_es + s_po); T.errs = (double *)(scr + s_ne + s_es + s_po + s_cn);
     T.out = (double *)(d + o_out); T.inliers = (uint8_t *)(d + o_inl);
@@ -758,4 +759,199 @@ extern "C" int slam_five_point_ransac_batch(slam_ctx *ctx, int S, const int32_t 
         return SLAM_OK;
     }
     return fp_run(ctx, S, offsets, px1_xy, px2_xy, pd1_xy, pd2_xy, K1, K2, max_repr_error, samples, iters, E, P, inliers, n_inliers, error, best_iter);
+}
+
+
+// =====================================================================================================================
+// compute_pose_5pt! on the device-resident keypoint set (src/front_end.jl:242-332; called every frame at :105): the keypoints the
+// previous key-frame also observes (slam_kpset_keyframe keeps that observation beside every keypoint) -> undistorted pixels and
+// normalised coordinates of both views, the rotation-compensated average parallax (:277-281) -> five-point RANSAC (the kernels
+// above, tuples from the counter-based generator of pose.hip) -> its outliers leave the list (:314-318).  The pose composition
+// with the motion-model scale (:320-330) needs the key-frame's and the frame's poses: that stays with the caller
+// (keypoint_set.pose_5pt_compose), which receives [R | t] of the essential-matrix decomposition.
+// =====================================================================================================================
+struct KFiveArgs {
+    const double *yx, *kyx; const uint8_t *haskf; const int *count; int cap;
+    const double *par;                 // S x 32: [0..8] R_compensation (column-major 3 x 3), [16..19] fx fy cx cy, [20..23] k1 k2 p1 p2
+    double *px1, *px2, *pd1, *pd2; int *slot; int *n5; double *psum; double *ks;      // gathered pairs, stride cap; S x 8 intrinsics
+    int32_t *samples; int iters; unsigned long long seed; double min_parallax;
+    const double *fp_out; const uint8_t *inl;                                          // k_5pt_select's outputs
+    uint8_t *flags; double *P; int *status, *ninl; double *parallax;                   // results
+};
+
+__device__ __forceinline__ unsigned long long fp_splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ void fp_undistort(double y, double x, double fx, double fy, double cx, double cy, double k1, double k2, double p1, double p2,
+                                             double &uy, double &ux)
+{   // undistort_point, camera.jl:98-125 (the arithmetic of k_kpose_gather)
+    const double ny = (y - cy) / fy, nx = (x - cx) / fx;
+    const double s0 = ny * ny, s1 = nx * nx, r2 = s0 + s1;
+    const double rd = (1.0 + k1 * r2) + k2 * (r2 * r2);
+    const double pp = ny * nx;
+    const double dtx = 2 * p1 * pp + p2 * (r2 + 2 * s0), dty = p1 * (r2 + 2 * s1) + 2 * p2 * pp;
+    uy = (rd * ny + dty) * fy + cy; ux = (rd * nx + dtx) * fx + cx;
+}
+
+__global__ __launch_bounds__(256) void k_kfive_gather(KFiveArgs A)
+{
+    __shared__ int s_w[4], s_base;
+    __shared__ double s_par[4];
+    const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = A.count[z];
+    const size_t b = (size_t)z * A.cap;
+    const double *par = A.par + 32 * (size_t)z;
+    const double fx = par[16], fy = par[17], cx = par[18], cy = par[19], k1 = par[20], k2 = par[21], p1 = par[22], p2 = par[23];
+    if (tid == 0) s_base = 0;
+    if (tid < 8) A.ks[8 * z + tid] = par[16 + (tid & 3)];        // both views through the same camera
+    __syncthreads();
+    double psum = 0.0;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int j = c0 + tid;
+        const bool take = j < n && A.haskf[b + j] != 0;
+        const unsigned long long m = __ballot(take);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_w[wv] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wv; w++) off += s_w[w];
+        if (take) {
+            const size_t q = b + j, o = b + off + before;
+            double uy, ux, vy, vx;
+            fp_undistort(A.yx[2 * q], A.yx[2 * q + 1], fx, fy, cx, cy, k1, k2, p1, p2, uy, ux);
+            fp_undistort(A.kyx[2 * q], A.kyx[2 * q + 1], fx, fy, cx, cy, k1, k2, p1, p2, vy, vx);
+            const double bx = (ux - cx) / fx, by = (uy - cy) / fy, ax = (vx - cx) / fx, ay = (vy - cy) / fy;
+            A.px1[2 * o] = vx; A.px1[2 * o + 1] = vy; A.px2[2 * o] = ux; A.px2[2 * o + 1] = uy;      // (x, y), :266-267
+            A.pd1[2 * o] = ax; A.pd1[2 * o + 1] = ay; A.pd2[2 * o] = bx; A.pd2[2 * o + 1] = by;      // position[[1, 2]], :268-269
+            A.slot[o] = j;
+            // rotation-compensated parallax, :277-279: project(camera, R_compensation * position) - previous undistorted pixel
+            const double rx = (par[0] * bx + par[3] * by) + par[6] * 1.0, ry = (par[1] * bx + par[4] * by) + par[7] * 1.0,
+                         rz = (par[2] * bx + par[5] * by) + par[8] * 1.0;
+            const double qy = fy * ry / rz + cy, qx = fx * rx / rz + cx;
+            const double dy = qy - vy, dx = qx - vx;
+            psum += sqrt(dy * dy + dx * dx);
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    // the reference adds the terms in Dict iteration order (unspecified); here: per lane, then a fixed butterfly, then the four waves
+    for (int o = 32; o > 0; o >>= 1) psum += __shfl_xor(psum, o, 64);
+    if (lane == 0) s_par[wv] = psum;
+    __syncthreads();
+    if (tid == 0) { A.n5[z] = s_base; A.psum[z] = (s_par[0] + s_par[1]) + (s_par[2] + s_par[3]); }
+}
+
+__global__ __launch_bounds__(256) void k_kfive_samples(KFiveArgs A)
+{
+    const int z = blockIdx.y, it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= A.iters) return;
+    const int n = A.n5[z];
+    int32_t *sm = A.samples + 5 * ((size_t)z * A.iters + it);
+    // :243 fewer than 8 keypoints in the frame, :283 fewer than 8 in the key-frame, :290 not enough parallax -> no RANSAC
+    const bool run = A.count[z] >= 8 && n >= 8 && !(A.psum[z] / (double)n < A.min_parallax);
+    if (!run) { for (int k = 0; k < 5; k++) sm[k] = -1; return; }
+    int idx[5]; unsigned att = 0;
+    for (int k = 0; k < 5; k++) {
+        for (;;) {
+            const unsigned long long h = fp_splitmix64(A.seed ^ ((unsigned long long)z << 48) ^ ((unsigned long long)it << 16) ^ (unsigned long long)att);
+            att++;
+            const int c = (int)(h % (unsigned long long)n);
+            bool dup = false;
+            for (int m = 0; m < k; m++) dup = dup || idx[m] == c;
+            if (!dup) { idx[k] = c; break; }
+        }
+    }
+    for (int k = 0; k < 5; k++) sm[k] = idx[k];
+}
+
+__global__ __launch_bounds__(256) void k_kfive_finish(KFiveArgs A)
+{
+    const int z = blockIdx.x, tid = threadIdx.x, n = A.n5[z];
+    const size_t b = (size_t)z * A.cap;
+    const double *out = A.fp_out + 32 * (size_t)z;
+    const int best = ((const int *)(out + 22))[0];
+    const bool ran = A.count[z] >= 8 && n >= 8 && !(A.psum[z] / (double)n < A.min_parallax);
+    const bool ok = ran && best >= 5;                                        // :305
+    if (ok && best != n)                                                     // :310-318
+        for (int i = tid; i < n; i += 256)
+            if (!A.inl[b + i]) A.flags[b + A.slot[b + i]] = 1;
+    if (tid == 0) {
+        for (int j = 0; j < 12; j++) A.P[12 * z + j] = ok ? out[j] : 0.0;
+        A.status[z] = ok ? 1 : 0; A.ninl[z] = ran ? best : 0;
+        A.parallax[z] = n > 0 ? A.psum[z] / (double)n : 0.0;
+    }
+}
+
+int kpset_compact(slam_ctx *ctx, slam_kpset *ks, int mode, const uint8_t *flags_dev);
+
+extern "C" int slam_kpset_compute_pose_5pt(slam_ctx *ctx, slam_kpset *ks, const double *params, double min_parallax, double max_repr_error,
+                                           int iters, uint64_t seed, double *P, int32_t *status, int32_t *n_inliers, double *parallax,
+                                           int32_t *counts)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && params != nullptr && iters > 0 && P && status);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int S = ks->S, cap = ks->cap;
+    const size_t nc = (size_t)S * cap, slots = (size_t)S * iters;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += up(bytes); return at; };
+    const size_t o_px1 = take(nc * 16), o_px2 = take(nc * 16), o_pd1 = take(nc * 16), o_pd2 = take(nc * 16), o_slot = take(nc * 4);
+    const size_t o_n5 = take((size_t)S * 4), o_ps = take((size_t)S * 8), o_ks = take((size_t)S * 64), o_smp = take(slots * 20);
+    const size_t o_ne = take(slots * 4), o_es = take(slots * FP_MAXE * 72), o_po = take(slots * FP_MAXE * 96), o_cn = take(slots * FP_MAXE * 4);
+    const size_t o_er = take(nc * 8), o_out = take((size_t)S * 256), o_inl = take(nc), o_fl = take(nc);
+    const size_t o_P = take((size_t)S * 96), o_st = take((size_t)S * 4), o_ni = take((size_t)S * 4), o_pa = take((size_t)S * 8);
+    char *scr;
+    int rc = slam_scratch2(ctx, o, (void **)&scr);
+    if (rc) return rc;
+    const double *par_dev;
+    rc = kpset_stage_params(ctx, ks, params, (size_t)S * 32, &par_dev);
+    if (rc) return rc;
+    KFiveArgs A;
+    A.yx = ks->yx; A.kyx = ks->kyx; A.haskf = ks->haskf; A.count = ks->count; A.cap = cap; A.par = par_dev;
+    A.px1 = (double *)(scr + o_px1); A.px2 = (double *)(scr + o_px2); A.pd1 = (double *)(scr + o_pd1); A.pd2 = (double *)(scr + o_pd2);
+    A.slot = (int *)(scr + o_slot); A.n5 = (int *)(scr + o_n5); A.psum = (double *)(scr + o_ps); A.ks = (double *)(scr + o_ks);
+    A.samples = (int32_t *)(scr + o_smp); A.iters = iters; A.seed = seed; A.min_parallax = min_parallax;
+    A.fp_out = (const double *)(scr + o_out); A.inl = (const uint8_t *)(scr + o_inl);
+    A.flags = (uint8_t *)(scr + o_fl); A.P = (double *)(scr + o_P); A.status = (int *)(scr + o_st); A.ninl = (int *)(scr + o_ni);
+    A.parallax = (double *)(scr + o_pa);
+    FPArgs T;
+    T.px1 = A.px1; T.px2 = A.px2; T.pd1 = A.pd1; T.pd2 = A.pd2; T.samples = A.samples; T.off = nullptr; T.cnt = A.n5; T.stride = cap;
+    T.ks = A.ks; T.iters = iters; T.thr = max_repr_error;
+    T.ne = (int *)(scr + o_ne); T.Es = (double *)(scr + o_es); T.poses = (double *)(scr + o_po); T.counts = (int *)(scr + o_cn);
+    T.errs = (double *)(scr + o_er); T.out = (double *)(scr + o_out); T.inliers = (uint8_t *)(scr + o_inl);
+    const size_t lds = (size_t)FP_LDS_PER_THREAD * FP_TPB * sizeof(double);
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_5pt_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(ctx, hipMemsetAsync(A.flags, 0, nc, ctx->stream));
+    { ProfScope span(ctx, "kpset_compute_pose_5pt");
+      hipLaunchKernelGGL(k_kfive_gather, dim3(S), dim3(256), 0, ctx->stream, A);
+      hipLaunchKernelGGL(k_kfive_samples, dim3((iters + 255) / 256, S), dim3(256), 0, ctx->stream, A);
+      hipLaunchKernelGGL(k_5pt_solve, dim3((iters + FP_TPB - 1) / FP_TPB, S), dim3(FP_TPB * FP_TEAM), lds, ctx->stream, T);
+      hipLaunchKernelGGL(k_5pt_score, dim3(iters, FP_MAXE, S), dim3(FP_SCORE_T), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_5pt_select, dim3(S), dim3(FP_SEL_T), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_kfive_finish, dim3(S), dim3(256), 0, ctx->stream, A); }
+    HIP_TRY(ctx, hipGetLastError());
+    rc = kpset_compact(ctx, ks, 1, A.flags);
+    if (rc) return rc;
+    void *hv;
+    rc = slam_pinned(ctx, up((size_t)S * 96) + 4 * up((size_t)S * 8), &hv);
+    if (rc) return rc;
+    char *h = (char *)hv;
+    const size_t h_st = up((size_t)S * 96), h_ni = h_st + up((size_t)S * 8), h_pa = h_ni + up((size_t)S * 8), h_cn = h_pa + up((size_t)S * 8);
+    HIP_TRY(ctx, hipMemcpyAsync(h, A.P, (size_t)S * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + h_st, A.status, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + h_ni, A.ninl, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + h_pa, A.parallax, (size_t)S * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + h_cn, ks->count, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    memcpy(P, h, (size_t)S * 96);
+    memcpy(status, h + h_st, (size_t)S * 4);
+    if (n_inliers) memcpy(n_inliers, h + h_ni, (size_t)S * 4);
+    if (parallax) memcpy(parallax, h + h_pa, (size_t)S * 8);
+    if (counts) memcpy(counts, h + h_cn, (size_t)S * 4);
+    return SLAM_OK;
 }

@@ -39,7 +39,7 @@ int kpset_build_worklist(slam_ctx *ctx, slam_kpset *ks)
 // Chunks of 256 slots are read (all fields into registers), ranked with a wave ballot + the popcount of the lower lanes,
 // and written back after a barrier: destinations never lie to the right of their sources, so in place is safe.
 struct KpsetView {
-    double *yx, *oyx, *syx, *xyz; int64_t *id; uint8_t *is3d, *stereo, *st; int *count; int cap;
+    double *yx, *oyx, *syx, *xyz, *kyx; int64_t *id; uint8_t *is3d, *stereo, *st, *haskf; int *count; int cap;
 };
 __global__ __launch_bounds__(256) void k_kpset_compact(KpsetView K, int mode, const uint8_t *flags)
 {
@@ -52,12 +52,13 @@ __global__ __launch_bounds__(256) void k_kpset_compact(KpsetView K, int mode, co
     for (int c0 = 0; c0 < n; c0 += 256) {
         const int j = c0 + tid;
         bool keep = false;
-        double y = 0, x = 0, sy = 0, sx = 0, X0 = 0, X1 = 0, X2 = 0; int64_t id = 0; uint8_t f3 = 0, fs = 0;
+        double y = 0, x = 0, sy = 0, sx = 0, X0 = 0, X1 = 0, X2 = 0, ky = 0, kx = 0; int64_t id = 0; uint8_t f3 = 0, fs = 0, fk = 0;
         if (j < n) {
             const size_t q = b + j;
             if (mode == 0) { const uint8_t t = K.st[q]; keep = t != 0; if (t == 1) { y = K.oyx[2 * q]; x = K.oyx[2 * q + 1]; } else { y = K.yx[2 * q]; x = K.yx[2 * q + 1]; } }
             else { keep = flags[q] == 0; y = K.yx[2 * q]; x = K.yx[2 * q + 1]; }
-            if (keep) { sy = K.syx[2 * q]; sx = K.syx[2 * q + 1]; X0 = K.xyz[3 * q]; X1 = K.xyz[3 * q + 1]; X2 = K.xyz[3 * q + 2]; id = K.id[q]; f3 = K.is3d[q]; fs = K.stereo[q]; }
+            if (keep) { sy = K.syx[2 * q]; sx = K.syx[2 * q + 1]; X0 = K.xyz[3 * q]; X1 = K.xyz[3 * q + 1]; X2 = K.xyz[3 * q + 2]; id = K.id[q]; f3 = K.is3d[q]; fs = K.stereo[q];
+                        ky = K.kyx[2 * q]; kx = K.kyx[2 * q + 1]; fk = K.haskf[q]; }
         }
         const unsigned long long m = __ballot(keep);
         const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256) void k_kpset_compact(KpsetView K, int mode, co
             const size_t q = b + s_base + wbase + rank;
             K.yx[2 * q] = y; K.yx[2 * q + 1] = x; K.syx[2 * q] = sy; K.syx[2 * q + 1] = sx;
             K.xyz[3 * q] = X0; K.xyz[3 * q + 1] = X1; K.xyz[3 * q + 2] = X2; K.id[q] = id; K.is3d[q] = f3; K.stereo[q] = fs;
+            K.kyx[2 * q] = ky; K.kyx[2 * q + 1] = kx; K.haskf[q] = fk;
         }
         __syncthreads();
         if (tid == 0) s_base += total;
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(256) void k_kpset_compact(KpsetView K, int mode, co
 
 static KpsetView view_of(slam_kpset *ks)
 {
-    KpsetView K; K.yx = ks->yx; K.oyx = ks->oyx; K.syx = ks->syx; K.xyz = ks->xyz; K.id = ks->id; K.is3d = ks->is3d; K.stereo = ks->stereo;
+    KpsetView K; K.yx = ks->yx; K.oyx = ks->oyx; K.syx = ks->syx; K.xyz = ks->xyz; K.kyx = ks->kyx; K.id = ks->id; K.is3d = ks->is3d; K.stereo = ks->stereo;
+    K.haskf = ks->haskf;
     K.st = ks->st; K.count = ks->count; K.cap = ks->cap;
     return K;
 }
@@ -174,7 +177,7 @@ int slam_kpset_create(slam_ctx *ctx, int S, int cap, slam_kpset **out)
     auto take = [&](size_t b) { size_t o = off; off += al256(b); return o; };
     const size_t o_yx = take(n * 16), o_oyx = take(n * 16), o_syx = take(n * 16), o_xyz = take(n * 24), o_id = take(n * 8);
     const size_t o_3d = take(n), o_st = take(n), o_ss = take(n), o_cnt = take((size_t)S * 4), o_work = take(n * 4), o_nt = take(64);
-    const size_t o_nid = take((size_t)S * 8), o_par = take((size_t)8 * S * 32 * 8);
+    const size_t o_nid = take((size_t)S * 8), o_par = take((size_t)8 * S * 32 * 8), o_kyx = take(n * 16), o_hk = take(n);
     slam_kpset *ks = new slam_kpset();
     ks->device = ctx->device; ks->S = S; ks->cap = cap;
     hipError_t e = hipMalloc((void **)&ks->base, off);
@@ -185,7 +188,7 @@ int slam_kpset_create(slam_ctx *ctx, int S, int cap, slam_kpset **out)
     ks->yx = (double *)(B + o_yx); ks->oyx = (double *)(B + o_oyx); ks->syx = (double *)(B + o_syx); ks->xyz = (double *)(B + o_xyz);
     ks->id = (int64_t *)(B + o_id); ks->is3d = (uint8_t *)(B + o_3d); ks->stereo = (uint8_t *)(B + o_st); ks->st = (uint8_t *)(B + o_ss);
     ks->count = (int *)(B + o_cnt); ks->work = (int *)(B + o_work); ks->ntot = (int *)(B + o_nt); ks->next_id = (int64_t *)(B + o_nid);
-    ks->par = (double *)(B + o_par);
+    ks->par = (double *)(B + o_par); ks->kyx = (double *)(B + o_kyx); ks->haskf = (uint8_t *)(B + o_hk);
     e = hipHostMalloc((void **)&ks->par_host, (size_t)8 * S * 32 * 8);
     for (int i = 0; i < 8 && e == hipSuccess; i++) { e = hipEventCreateWithFlags(&ks->par_ev[i], hipEventDisableTiming); if (e == hipSuccess) e = hipEventRecord(ks->par_ev[i], ctx->stream); }
     if (e != hipSuccess) { slam_kpset_destroy(ks); return slam_fail(ctx, SLAM_ERR_HIP, "slam_kpset_create: %s", hipGetErrorString(e)); }
@@ -225,6 +228,7 @@ int slam_kpset_upload(slam_ctx *ctx, slam_kpset *ks, int s, const double *yx, co
         else HIP_TRY(ctx, hipMemsetAsync(ks->xyz + 3 * b, 0, (size_t)n * 24, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ks->id + b, idv.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ks->stereo + b, 0, (size_t)n, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ks->haskf + b, 0, (size_t)n, ctx->stream));
     }
     HIP_TRY(ctx, hipMemcpyAsync(ks->count + s, &n, 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ks->next_id + s, &next, 8, hipMemcpyHostToDevice, ctx->stream));
@@ -251,6 +255,54 @@ int slam_kpset_download(slam_ctx *ctx, slam_kpset *ks, int s, double *yx, uint8_
         if (ids) HIP_TRY(ctx, hipMemcpyAsync(ids, ks->id + b, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (stereo_yx) HIP_TRY(ctx, hipMemcpyAsync(stereo_yx, ks->syx + 2 * b, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
         if (has_stereo) HIP_TRY(ctx, hipMemcpyAsync(has_stereo, ks->stereo + b, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    }
+    return SLAM_OK;
+}
+
+// create_keyframe! (map_manager.jl:60-96) as far as the lists are concerned: the current frame becomes the previous key-frame
+// of every keypoint it holds (frames_map[kfid] is a copy of the frame, new keypoints included: call it after slam_kpset_detect)
+__global__ __launch_bounds__(256) void k_kpset_keyframe(KpsetView K)
+{
+    const int s = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= K.count[s]) return;
+    const size_t q = (size_t)s * K.cap + j;
+    K.kyx[2 * q] = K.yx[2 * q]; K.kyx[2 * q + 1] = K.yx[2 * q + 1]; K.haskf[q] = 1;
+}
+int slam_kpset_keyframe(slam_ctx *ctx, slam_kpset *ks)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_kpset_keyframe, dim3((ks->cap + 255) / 256, ks->S), dim3(256), 0, ctx->stream, view_of(ks));
+    HIP_TRY(ctx, hipGetLastError());
+    return SLAM_OK;
+}
+// the key-frame observations of stream s's list, host <-> device (restoring state, tests): kyx n x 2 (y, x), has_kf n flags
+int slam_kpset_upload_keyframe(slam_ctx *ctx, slam_kpset *ks, int s, const double *kyx, const uint8_t *has_kf, int n)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && s >= 0 && s < ks->S && n >= 0 && n <= ks->cap && (n == 0 || (kyx != nullptr && has_kf != nullptr)));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t b = (size_t)s * ks->cap;
+    if (n > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(ks->kyx + 2 * b, kyx, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ks->haskf + b, has_kf, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    }
+    return SLAM_OK;
+}
+int slam_kpset_download_keyframe(slam_ctx *ctx, slam_kpset *ks, int s, double *kyx, uint8_t *has_kf, int cap_out, int *n_out)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && s >= 0 && s < ks->S && n_out != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int n = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n, ks->count + s, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    *n_out = n;
+    if (n > cap_out) return slam_fail(ctx, SLAM_ERR_CAPACITY, "slam_kpset_download_keyframe: %d keypoints but cap = %d", n, cap_out);
+    const size_t b = (size_t)s * ks->cap;
+    if (n > 0) {
+        if (kyx) HIP_TRY(ctx, hipMemcpyAsync(kyx, ks->kyx + 2 * b, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (has_kf) HIP_TRY(ctx, hipMemcpyAsync(has_kf, ks->haskf + b, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     }
     return SLAM_OK;

@@ -116,6 +116,40 @@ class KeypointSet:
         c.check(c.lib.slam_kpset_triangulate(c.h, self.h, L.ptr(P1), L.ptr(P2), L.ptr(T), L.ptr(c1), L.ptr(c2), L.ptr(W),
                                              float(max_error), float(min_depth), int(n_bound)))
 
+    def keyframe(self, ctx=None):
+        """create_keyframe! for the lists: the current positions become the previous key-frame's observations (slam_kpset_keyframe)"""
+        c = ctx or self.ctx
+        c.check(c.lib.slam_kpset_keyframe(c.h, self.h))
+
+    def upload_keyframe(self, s, kyx, has_kf, ctx=None):
+        c = ctx or self.ctx
+        k = np.ascontiguousarray(kyx, dtype=np.float64).reshape(-1, 2)
+        f = np.ascontiguousarray(np.asarray(has_kf).astype(np.uint8))
+        c.check(c.lib.slam_kpset_upload_keyframe(c.h, self.h, s, L.ptr(k), L.ptr(f, L.u8p), len(k)))
+
+    def download_keyframe(self, s, ctx=None):
+        c = ctx or self.ctx
+        k = np.zeros((self.cap, 2)); f = np.zeros(self.cap, dtype=np.uint8); n = C.c_int(0)
+        c.check(c.lib.slam_kpset_download_keyframe(c.h, self.h, s, L.ptr(k), L.ptr(f, L.u8p), self.cap, C.byref(n)))
+        return k[:n.value].copy(), f[:n.value].astype(bool)
+
+    def compute_pose_5pt(self, sp, min_parallax=5.0, max_repr_error=3.0, iters=128, seed=0, ctx=None):
+        """compute_pose_5pt! (front_end.jl:242-332) for every stream on the device-resident lists (slam_kpset_compute_pose_5pt):
+        returns (Rt (S, 3, 4) key-frame -> frame with |t| = 1, status (S,), inlier counts (S,), average parallax (S,), list lengths
+        after the removals (S,)).  sp: stream_params(...) with R_compensation in the rotation part of the Tcw slot (rows / columns
+        0..2) and the camera / distortion entries filled."""
+        c = ctx or self.ctx
+        sp = np.ascontiguousarray(sp, dtype=np.float64).reshape(self.S, 32).copy()
+        # the seam reads R_compensation as a dense column-major 3 x 3 at [0..8]: repack from the 4 x 4 slot (column-major, stride 4)
+        T = sp[:, :16].reshape(self.S, 4, 4)                                       # [col][row]
+        sp[:, :9] = T[:, :3, :3].reshape(self.S, 9)
+        P = np.zeros((self.S, 12)); status = np.zeros(self.S, dtype=np.int32); ninl = np.zeros(self.S, dtype=np.int32)
+        par = np.zeros(self.S); counts = np.zeros(self.S, dtype=np.int32)
+        c.check(c.lib.slam_kpset_compute_pose_5pt(c.h, self.h, L.ptr(sp), float(min_parallax), float(max_repr_error), int(iters),
+                                                  int(seed) & 0xFFFFFFFFFFFFFFFF, L.ptr(P), L.ptr(status, L.i32p), L.ptr(ninl, L.i32p),
+                                                  L.ptr(par), L.ptr(counts, L.i32p)))
+        return P.reshape(self.S, 4, 3).transpose(0, 2, 1).copy(), status, ninl, par, counts
+
     def compute_pose(self, sp, threshold=3.0, iters=256, seed=0, pnp_iters_fast=5, pnp_iterations=10, depth_eps=1e-6, repr_eps=None, ctx=None):
         """compute_pose! (front_end.jl:132-219) for every stream on the device-resident lists (slam_kpset_compute_pose): returns
         (poses (S, 4, 4) world -> camera, status (S,), P3P inlier counts (S,), list lengths after the outlier removals (S,)).
@@ -156,6 +190,42 @@ def pose_samples(seed, stream, n, iters):
                 idx.append(c)
         out[it] = idx
     return out
+
+
+def pose_samples5(seed, stream, n, iters):
+    """The 5-tuples slam_kpset_compute_pose_5pt draws (csrc/fivepoint.hip, k_kfive_samples): as pose_samples, five distinct indices."""
+    out = np.full((iters, 5), -1, dtype=np.int32)
+    for it in range(iters):
+        att = 0
+        idx = []
+        while len(idx) < 5:
+            h = _splitmix64((int(seed) ^ (int(stream) << 48) ^ (it << 16) ^ att) & 0xFFFFFFFFFFFFFFFF)
+            att += 1
+            c = int(h % n)
+            if c not in idx:
+                idx.append(c)
+        out[it] = idx
+    return out
+
+
+def pose_5pt_inputs(cam, dist, yx, kyx):
+    """front_end.jl:263-272 for the keypoints both frames observe: (px1, px2, pd1, pd2), (x, y) order -- undistorted pixels and
+    normalised coordinates of the key-frame (1) and the frame (2); the arithmetic of k_kfive_gather."""
+    fx, fy, cx, cy = cam
+    z = np.zeros((len(np.atleast_2d(yx)), 3))
+    _, p2, _ = pose_inputs(cam, dist, yx, z)
+    _, p1, _ = pose_inputs(cam, dist, kyx, z)
+    pd = lambda p: np.stack([(p[:, 0] - cx) / fx, (p[:, 1] - cy) / fy], axis=1)
+    return p1, p2, pd(p1), pd(p2)
+
+
+def pose_5pt_compose(Rt, prev_cw, cur_wc):
+    """front_end.jl:320-330: translation scaled to the motion model's key-frame -> frame distance, composed with the key-frame pose."""
+    scale = np.linalg.norm((prev_cw @ cur_wc)[:3, 3])
+    R, t = Rt[:, :3], Rt[:, 3]
+    t = scale * (t / np.linalg.norm(t))
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    return T @ prev_cw
 
 
 def pose_inputs(cam, dist, yx, xyz):

@@ -220,3 +220,68 @@ def test_compute_pose_on_the_set_equals_the_host_seams(slam, syn):
         assert status[s] == 1
         Rt = host[s][3]["Rt_gt"]
         assert np.abs(poses[s][:3] - Rt).max() < 5e-3, np.abs(poses[s][:3] - Rt).max()
+
+
+def test_compute_pose_5pt_on_the_set_equals_the_host_seam(slam, syn):
+    """slam_kpset_compute_pose_5pt (front_end.jl:242-332 on the device-resident lists + the key-frame observation every keypoint
+    carries) against the host route: download, numpy gather of the pairs the key-frame observes, the SAME 5-tuples
+    (pose_samples5), slam_five_point_ransac_batch, numpy removal -- [R | t], status words, parallax and the surviving lists."""
+    S, cap = 4, 600
+    ks = slam.KeypointSet(S, cap)
+    cam = syn.KITTI_CAM
+    dist = (0.0, 0.0, 0.0, 0.0)
+    rng = np.random.default_rng(3)
+    for s in range(S):
+        n5 = [300, 6, 200, 120][s]                              # stream 1: fewer than 8 pairs -> status 0
+        fs = syn.five_point_scene(n=n5, seed=60 + s, noise_px=0.3, outlier_frac=[0.2, 0.0, 0.1, 0.3][s], iters=4)
+        extra = 15 + 5 * s                                       # keypoints the key-frame does not observe, interleaved
+        n = n5 + extra
+        order = rng.permutation(n)
+        yx = rng.uniform(5, 300, (n, 2)); kyx = np.zeros((n, 2)); hk = np.zeros(n, bool)
+        yx[order[:n5]] = fs["px2"][:, ::-1]; kyx[order[:n5]] = fs["px1"][:, ::-1]; hk[order[:n5]] = True
+        if s == 3:
+            kyx[hk] = yx[hk] + 0.25                              # no parallax: below min_parallax -> status 0
+        ks.upload(s, yx, np.zeros(n, bool))
+        ks.upload_keyframe(s, kyx, hk)
+    Rc = np.eye(4)
+    sp = slam.stream_params(S, Tcw=Rc, cam=cam, dist=dist)
+    before = [ks.download(s) for s in range(S)]
+    kf = [ks.download_keyframe(s) for s in range(S)]
+    iters, seed, thr = 96, 5, 3.0
+    Rt, status, ninl, par, counts = ks.compute_pose_5pt(sp, min_parallax=5.0, max_repr_error=thr, iters=iters, seed=seed)
+    after = [ks.download(s) for s in range(S)]
+    K = np.array([[cam[0], 0, cam[2]], [0, cam[1], cam[3]], [0, 0, 1.0]])
+    A1, A2, D1, D2, SM, idx, avg = [], [], [], [], [], [], []
+    for s in range(S):
+        m = kf[s][1]
+        p1, p2, d1, d2 = slam.pose_5pt_inputs(cam, dist, before[s]["yx"][m], kf[s][0][m])
+        A1.append(p1); A2.append(p2); D1.append(d1); D2.append(d2); idx.append(np.flatnonzero(m))
+        # identity compensation, no distortion: project(position) is the undistorted pixel itself (up to rounding)
+        avg.append(np.linalg.norm(p2 - p1, axis=1).mean() if m.sum() else 0.0)
+        run = len(before[s]["yx"]) >= 8 and m.sum() >= 8 and not (avg[-1] < 5.0)
+        SM.append(slam.pose_samples5(seed, s, int(m.sum()), iters) if run else np.full((iters, 5), -1, np.int32))
+    r5 = slam.five_point_ransac_batch(A1, A2, D1, D2, K, K, max_repr_error=thr, samples=SM)
+    expect_ok = []
+    for s in range(S):
+        keep = np.ones(len(before[s]["yx"]), bool)
+        n_in = r5[s][0]
+        ok = (SM[s][0, 0] >= 0) and n_in >= 5
+        expect_ok.append(bool(ok))
+        assert status[s] == (1 if ok else 0), (s, status[s], n_in)
+        assert abs(par[s] - avg[s]) <= 1e-9 * max(1.0, avg[s]), (s, par[s], avg[s])
+        if ok:
+            inl = r5[s][1][2]
+            if n_in != len(inl):
+                keep[idx[s][~inl]] = False
+            assert ninl[s] == n_in
+            assert np.array_equal(Rt[s], r5[s][1][1]), (s, np.abs(Rt[s] - r5[s][1][1]).max())
+        assert counts[s] == keep.sum() == len(after[s]["yx"]), (s, counts[s], keep.sum())
+        assert np.array_equal(after[s]["ids"], before[s]["ids"][keep]) and np.array_equal(after[s]["yx"], before[s]["yx"][keep]), s
+        k2, h2 = ks.download_keyframe(s)
+        assert np.array_equal(h2, kf[s][1][keep]) and np.array_equal(k2[h2], kf[s][0][keep][h2]), s      # the observation travels with the keypoint
+    assert expect_ok == [True, False, True, False]
+    # key-frame snapshot: every live keypoint gets its current position
+    ks.keyframe()
+    for s in range(S):
+        k2, h2 = ks.download_keyframe(s)
+        assert h2.all() and np.array_equal(k2, after[s]["yx"])
