@@ -565,32 +565,36 @@ __global__ __launch_bounds__(FP_TPB * FP_TEAM) void k_5pt_solve(FPArgs T)
 
 __global__ __launch_bounds__(FP_SCORE_T) void k_5pt_score(FPArgs T)
 {
-    __shared__ int s_part[FP_SCORE_T / 64];
-    const int it = blockIdx.x, e = blockIdx.y, z = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // one workgroup per 5-tuple scores ALL its poses (a grid of iters x FP_MAXE x S workgroups, most of them for poses that do not
+    // exist, each with its own reduction, took 385 us per 32-stream call): pose by pose (wave-uniform: the 12 numbers arrive by
+    // scalar loads), the threads stride over the correspondences, which stay in L1 / L2 between the poses
+    __shared__ int s_part[FP_SCORE_T / 64][FP_MAXE];
+    const int it = blockIdx.x, z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t slot = (size_t)z * T.iters + it;
-    if (e >= T.ne[slot]) {                                // workgroup-uniform
-        if (tid == 0) T.counts[slot * FP_MAXE + e] = 0;
-        return;
+    const int ne = T.ne[slot];                                  // workgroup-uniform
+    if (ne > 0) {
+        const int base = T.cnt ? z * T.stride : T.off[z], n = T.cnt ? T.cnt[z] : T.off[z + 1] - base;
+        const double *px1 = T.px1 + 2 * (size_t)base, *px2 = T.px2 + 2 * (size_t)base;
+        double k1[4], k2[4];
+        for (int j = 0; j < 4; j++) { k1[j] = T.ks[8 * z + j]; k2[j] = T.ks[8 * z + 4 + j]; }
+        for (int e = 0; e < ne; e++) {
+            double Rt[12];
+            for (int j = 0; j < 12; j++) Rt[j] = T.poses[(slot * FP_MAXE + e) * 12 + j];
+            int cnt = 0;
+            for (int i = tid; i < n; i += FP_SCORE_T) {
+                const double a[2] = {px1[2 * i], px1[2 * i + 1]}, b[2] = {px2[2 * i], px2[2 * i + 1]};
+                double e1, e2;
+                if (two_view_errors(k1, k2, Rt, a, b, &e1, &e2)) cnt += (e1 < T.thr && e2 < T.thr) ? 1 : 0;
+            }
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            if (lane == 0) s_part[wave][e] = cnt;
+        }
     }
-    const int base = T.cnt ? z * T.stride : T.off[z], n = T.cnt ? T.cnt[z] : T.off[z + 1] - base;
-    const double *px1 = T.px1 + 2 * (size_t)base, *px2 = T.px2 + 2 * (size_t)base;
-    double k1[4], k2[4];
-    for (int j = 0; j < 4; j++) { k1[j] = T.ks[8 * z + j]; k2[j] = T.ks[8 * z + 4 + j]; }
-    int cnt = 0;
-    double Rt[12];
-    for (int j = 0; j < 12; j++) Rt[j] = T.poses[(slot * FP_MAXE + e) * 12 + j];
-    for (int i = tid; i < n; i += FP_SCORE_T) {
-        const double a[2] = {px1[2 * i], px1[2 * i + 1]}, b[2] = {px2[2 * i], px2[2 * i + 1]};
-        double e1, e2;
-        if (two_view_errors(k1, k2, Rt, a, b, &e1, &e2)) cnt += (e1 < T.thr && e2 < T.thr) ? 1 : 0;
-    }
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if (lane == 0) s_part[wave] = cnt;
     __syncthreads();
-    if (tid == 0) {
+    if (tid < FP_MAXE) {
         int c = 0;
-        for (int w = 0; w < FP_SCORE_T / 64; w++) c += s_part[w];
-        T.counts[slot * FP_MAXE + e] = c;
+        if (tid < ne) for (int w = 0; w < FP_SCORE_T / 64; w++) c += s_part[w][tid];
+        T.counts[slot * FP_MAXE + tid] = c;
     }
 }
 
@@ -697,7 +701,7 @@ static int fp_run(slam_ctx *ctx, int S, const int32_t *off, const double *px1_xy
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_5pt_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     { ProfScope span(ctx, "five_point_ransac");
       hipLaunchKernelGGL(k_5pt_solve, dim3((iters + FP_TPB - 1) / FP_TPB, S), dim3(FP_TPB * FP_TEAM), lds, ctx->stream, T);
-      hipLaunchKernelGGL(k_5pt_score, dim3(iters, FP_MAXE, S), dim3(FP_SCORE_T), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_5pt_score, dim3(iters, S), dim3(FP_SCORE_T), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_5pt_select, dim3(S), dim3(FP_SEL_T), 0, ctx->stream, T); }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, slam_stream_wait(ctx->stream));
@@ -931,7 +935,7 @@ extern "C" int slam_kpset_compute_pose_5pt(slam_ctx *ctx, slam_kpset *ks, const 
       hipLaunchKernelGGL(k_kfive_gather, dim3(S), dim3(256), 0, ctx->stream, A);
       hipLaunchKernelGGL(k_kfive_samples, dim3((iters + 255) / 256, S), dim3(256), 0, ctx->stream, A);
       hipLaunchKernelGGL(k_5pt_solve, dim3((iters + FP_TPB - 1) / FP_TPB, S), dim3(FP_TPB * FP_TEAM), lds, ctx->stream, T);
-      hipLaunchKernelGGL(k_5pt_score, dim3(iters, FP_MAXE, S), dim3(FP_SCORE_T), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_5pt_score, dim3(iters, S), dim3(FP_SCORE_T), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_5pt_select, dim3(S), dim3(FP_SEL_T), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_kfive_finish, dim3(S), dim3(256), 0, ctx->stream, A); }
     HIP_TRY(ctx, hipGetLastError());
