@@ -45,9 +45,12 @@ struct FPArgs {                            // S independent problems (S = 1: sla
 };
 
 // per-thread array in LDS: element i of thread t at base[i * FP_TPB + t]
+// (the pointer carries the LDS address space: as a generic pointer every access was a FLAT instruction -- slower than ds_read /
+//  ds_write and, worse, a full vmcnt(0) + lgkmcnt(0) wait each)
+typedef __attribute__((address_space(3))) double fp_lds;
 struct Col {
-    double *b;
-    __device__ double &operator[](int i) const { return b[i * FP_TPB]; }
+    fp_lds *b;
+    __device__ fp_lds &operator[](int i) const { return b[i * FP_TPB]; }
     __device__ Col at(int off) const { return Col{b + off * FP_TPB}; }
 };
 
@@ -270,15 +273,15 @@ __device__ static bool nullspace_5x9(Col A, Col N)
 }
 
 // LDS per 5-tuple (doubles): M 200 | N 36 | Ep 36 | W 144 (A 45, then EEt 90 + tr 10, then D 121 + crit 11 + spare 11 + degree 1)
-#define FP_LDS_PER_THREAD (200 + 36 + 36 + 144)
+#define FP_LDS_PER_THREAD (200 + 36 + 36 + 144 + 9 * FP_MAXE)   /* + the essential matrices of the tuple (indexed by a run-time root count: LDS, not scratch) */
 
 // Called by all threads of the workgroup (it synchronises).  Lane l == 0 of each team owns the short sequential
 // phases; the cubic constraints, the Gauss-Jordan elimination and the root search are shared by the team's lanes --
 // one output polynomial / one matrix row / one bracketing interval per lane, each computed with exactly the
 // operations of the sequential statement.  Returns (to the owner) the number of essential matrices written to Es.
-__device__ static int five_point_solve(const double *q1, const double *q2, double *Es, Col L, int l, int team, bool valid)
+__device__ static int five_point_solve(const double *q1, const double *q2, Col L, int l, int team, bool valid)
 {
-    Col M = L, N = L.at(200), Ep = L.at(236), W = L.at(272);
+    Col M = L, N = L.at(200), Ep = L.at(236), W = L.at(272), Es = L.at(416);
     const bool owner = l == 0;
     // W[142]: 1.0 while the tuple is alive; W[143]: degree for the root search
     if (owner) {
@@ -405,11 +408,11 @@ __device__ static int five_point_solve(const double *q1, const double *q2, doubl
             }
         if (!(best > 0.0)) continue;
         const double x = nx / nz, y = ny / nz;
-        double *E = Es + 9 * ne;
         bool fin = true;
         for (int e = 0; e < 9; e++) {
-            E[e] = ((x * N[e] + y * N[9 + e]) + z * N[18 + e]) + N[27 + e];
-            fin = fin && isfinite(E[e]);
+            const double ev = ((x * N[e] + y * N[9 + e]) + z * N[18 + e]) + N[27 + e];
+            Es[9 * ne + e] = ev;
+            fin = fin && isfinite(ev);
         }
         if (fin) ne++;
     }
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(FP_TPB * FP_TEAM) void k_5pt_solve(FPArgs T)
     const int it = blockIdx.x * FP_TPB + team;
     const int base = T.cnt ? z * T.stride : T.off[z], n = T.cnt ? T.cnt[z] : T.off[z + 1] - base;
     const double *pd1 = T.pd1 + 2 * (size_t)base, *pd2 = T.pd2 + 2 * (size_t)base;
-    const Col L{s_fp + team};
+    const Col L{(fp_lds *)s_fp + team};
     bool ok = it < T.iters;
     int ids[5] = {0, 0, 0, 0, 0};
     if (ok) {
@@ -527,19 +530,21 @@ __global__ __launch_bounds__(FP_TPB * FP_TEAM) void k_5pt_solve(FPArgs T)
             for (int b = 0; b < a; b++) if (ids[a] == ids[b]) ok = false;
         }
     }
-    double q1[10], q2[10], Es[9 * FP_MAXE];
+    double q1[10], q2[10];
+    const Col Es = L.at(416);
     for (int a = 0; a < 5; a++) {
         const int id = ok ? ids[a] : 0;
         q1[2 * a] = ok ? pd1[2 * id] : 0.0; q1[2 * a + 1] = ok ? pd1[2 * id + 1] : 0.0;
         q2[2 * a] = ok ? pd2[2 * id] : 0.0; q2[2 * a + 1] = ok ? pd2[2 * id + 1] : 0.0;
     }
-    const int ne = five_point_solve(q1, q2, Es, L, l, team, ok);      // all threads: it synchronises
+    const int ne = five_point_solve(q1, q2, L, l, team, ok);          // all threads: it synchronises
     if (l != 0 || it >= T.iters) return;
     const size_t slot = (size_t)z * T.iters + it;
     int np = 0;
     for (int e = 0; e < ne; e++) {
-        double C[48];
-        if (!essential_poses(Es + 9 * e, C)) continue;
+        double C[48], Ee[9];
+        for (int j = 0; j < 9; j++) Ee[j] = Es[9 * e + j];
+        if (!essential_poses(Ee, C)) continue;
         int best = -1, bk = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(FP_TPB * FP_TEAM) void k_5pt_solve(FPArgs T)
             if (k == bk) for (int j = 0; j < 12; j++) Rb[j] = C[12 * k + j];
         double *po = T.poses + (slot * FP_MAXE + np) * 12, *eo = T.Es + (slot * FP_MAXE + np) * 9;
         for (int j = 0; j < 12; j++) po[j] = Rb[j];
-        for (int j = 0; j < 9; j++) eo[j] = Es[9 * e + j];
+        for (int j = 0; j < 9; j++) eo[j] = Ee[j];
         np++;
     }
     T.ne[slot] = np;
