@@ -322,7 +322,7 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
 
 
 def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, right, flows, disparity, params, extractor, world, dist, dev, ingest,
-                       hook=None, seed=1234):
+                       hook=None, seed=1234, pose=False):
     """The headline configuration: S streams in lock-step, keypoints resident in HBM (slam_kpset_*), no host list work
     between the calls of a step; the host sees the S list lengths once per step.
 
@@ -456,6 +456,14 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
     Twc = np.eye(4)
     sp_stereo = slam.stream_params(S, cam=camt, shift_yx=np.tile([0.0, -disparity], (S, 1)))
     state = dict(n_bound=0, tracked=0, tracked_steps=0, timed=False, wait_s=0.0)
+    # pose = True: the full per-frame front-end of front_end.jl:60-113 on the tracked lists themselves -- the streams are a rigid
+    # scene (a fronto-parallel plane 30 m away, cameras translating parallel to it), so the map points of the stereo
+    # triangulation, the pose priors of the tracking, the five-point filter against the previous key-frame and P3P + PnP are all
+    # consistent; the recovered camera translation is checked against the image offsets of the frames.
+    Z_PLANE = 30.0
+    pst = dict(Tcw=np.tile(np.eye(4), (S, 1, 1)), Tprev=np.tile(np.eye(4), (S, 1, 1)), Tkf=np.tile(np.eye(4), (S, 1, 1)), ref=None,
+               accepted=0, asked=0, err_max=0.0, acc5=0)
+    sp_cam = slam.stream_params(S, cam=camt)
     if host:
         enqueue_right_copy(1)                               # step 1 is a key-frame
     build_up_to(AHEAD)
@@ -470,7 +478,28 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
             enqueue_right_copy(i + 1)
         ctx.wait_event(built[i % NLB])                      # tracking needs the build of frame i only
         build_up_to(i + AHEAD, state["timed"])              # the next frame's copy + build overlap this step's tracking
-        if state["n_bound"] > 0:
+        cnt = None
+        if state["n_bound"] > 0 and pose:
+            # klt_tracking! with the motion model's prediction (constant velocity on the translation), then the epipolar filter and
+            # compute_pose!; the pose call is this step's device -> host copy
+            Tpred = pst["Tcw"].copy(); Tpred[:, :3, 3] += pst["Tcw"][:, :3, 3] - pst["Tprev"][:, :3, 3]
+            ks.flow_match(prevb, curb, params, slam.stream_params(S, Tcw=Tpred, cam=camt), prior=1, n_bound=state["n_bound"], ctx=ctx)
+            Rc = np.tile(np.eye(4), (S, 1, 1)); Rc[:, :3, :3] = pst["Tkf"][:, :3, :3] @ np.transpose(Tpred[:, :3, :3], (0, 2, 1))
+            _, st5, _, _, _ = ks.compute_pose_5pt(slam.stream_params(S, Tcw=Rc, cam=camt), min_parallax=5.0, max_repr_error=3.0, iters=128,
+                                                  seed=seed + 2 * i, ctx=ctx)
+            t_enq = time.perf_counter()
+            poses, stp, _, cnt = ks.compute_pose(sp_cam, threshold=3.0, iters=256, seed=seed + 2 * i + 1, ctx=ctx)
+            state["wait_s"] += time.perf_counter() - t_enq
+            pst["Tprev"] = pst["Tcw"].copy()
+            ok = stp.astype(bool)
+            pst["Tcw"][ok] = poses[ok]
+            if pst["ref"] is not None:
+                off = flows_a[seq_a[(i % period) + np.arange(S)]] - pst["ref"]
+                want = np.stack([off[:, 1] * Z_PLANE / camt[0], off[:, 0] * Z_PLANE / camt[1], np.zeros(S)], axis=1)
+                pst["asked"] += S; pst["accepted"] += int(ok.sum()); pst["acc5"] += int(np.asarray(st5).sum())
+                if ok.any():
+                    pst["err_max"] = max(pst["err_max"], float(np.abs(pst["Tcw"][ok, :3, 3] - want[ok]).max()))
+        elif state["n_bound"] > 0:
             # motion-model prior: the stream's image-plane shift, ~0.5 px off (project_world_to_image_distort of the map points
             # under the predicted pose; the synthetic streams are image-plane translations)
             shift = flows_a[seq_a[(i % period) + np.arange(S)]] - flows_a[seq_a[((i - 1) % period) + np.arange(S)]]
@@ -483,12 +512,19 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
                 torch.lt(cull_u, CULL_FRACTION, out=cull_flags)                 # bool = one byte per slot, 1 = remove
             ks.remove(cull_flags.data_ptr(), ctx=ctx)
             ks.detect(extractor, curb, ctx=ctx)
+            if pose:
+                ks.keyframe(ctx=ctx)                        # the frame becomes the previous key-frame of its keypoints
+                pst["Tkf"] = pst["Tcw"].copy()
+                if pst["ref"] is None:                      # world frame = the first key-frame's camera
+                    pst["ref"] = flows_a[seq_a[(i % period) + np.arange(S)]].copy()
             ctx.wait_for(ctx_right)
             ks.stereo_match(curb, rb, params, sp_stereo, prior=2, ctx=ctx)
-            ks.triangulate(camt, camt, T21, Twc, max_error=3.0, ctx=ctx)
-        t_enq = time.perf_counter()
-        cnt = ks.counts(ctx=ctx)                            # the one device -> host copy of the step (synchronises)
-        state["wait_s"] += time.perf_counter() - t_enq      # host time spent waiting for the GPU (the rest of the step is enqueue work)
+            ks.triangulate(camt, camt, T21, np.linalg.inv(pst["Tcw"]) if pose else Twc, max_error=3.0, ctx=ctx)
+            cnt = None
+        if cnt is None:
+            t_enq = time.perf_counter()
+            cnt = ks.counts(ctx=ctx)                        # the one device -> host copy of the step (synchronises)
+            state["wait_s"] += time.perf_counter() - t_enq  # host time spent waiting for the GPU (the rest of the step is enqueue work)
         tot = int(cnt.sum())
         if not kf and state["n_bound"] > 0:
             state["tracked"] += tot; state["tracked_steps"] += 1
@@ -519,6 +555,8 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
            "ms_per_step_of_S_frames": dt / steps * 1e3,
            "host_wait_ms_per_step": state["wait_s"] / steps * 1e3,
            "tracked_kpts_per_frame": round(state["tracked"] / max(state["tracked_steps"], 1) / S, 1),
+           "pose": None if not pose else {"accepted_fraction": pst["accepted"] / max(pst["asked"], 1), "five_point_accepted_fraction": pst["acc5"] / max(pst["asked"], 1),
+                                          "max_translation_error_m": pst["err_max"], "plane_depth_m": Z_PLANE},
            "pyramid_build_ms": {"mean": float(np.mean(builds)) if builds else None, "min": float(np.min(builds)) if builds else None,
                                 "n": len(builds), "what": "hipEvents around each left-batch build (ingest kernel + one hipGraph replay) on the pyramid "
                                                           "stream inside the timed region, tracking running beside it"}}
@@ -942,11 +980,18 @@ def main():
         if S == SB:
             # the tracked workload with compute_pose! of all streams run after every step (pose inputs are the independent
             # synthetic scenes above: the image-plane motion of the tracked streams is not a rigid 3-D motion)
+            wp = run_lockstep_kpset(slam, torch, local_rank, S, max(40, args.steps // 3), min(args.warmup, 10), H, W, left, right, flows, disparity,
+                                    params, extractor, world, dist, dev, "host_u8", pose=True)
+            out["pose"]["frontend_with_pose"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": wp["ms_per_step_of_S_frames"],
+                                                 "tracked_kpts_per_frame": wp["tracked_kpts_per_frame"], **wp["pose"],
+                                                 "what": "the headline workload as the reference's full per-frame front-end on the tracked lists themselves "
+                                                         "(front_end.jl:60-113): tracking with the priors of the predicted pose, slam_kpset_compute_pose_5pt, "
+                                                         "slam_kpset_compute_pose every step, key-frames with slam_kpset_keyframe and triangulation under the "
+                                                         "estimated pose; the streams are a rigid scene, the recovered translation is checked against the frames' offsets"}
             wp = run_lockstep_kpset(slam, torch, local_rank, S, max(20, args.steps // 4), min(args.warmup, 10), H, W, left, right, flows, disparity,
                                     params, extractor, world, dist, dev, "host_u8", hook=pose_frontend_once)
-            out["pose"]["frontend_with_pose"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": wp["ms_per_step_of_S_frames"],
-                                                 "what": "headline workload + slam_kpset_compute_pose_5pt (five-point RANSAC) + slam_kpset_compute_pose (P3P "
-                                                         "RANSAC + PnP refinement) of the 32 streams every step: front_end.jl:103-113 on device-resident lists"}
+            out["pose"]["frontend_with_scene_pose_seams"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": wp["ms_per_step_of_S_frames"],
+                                                             "what": "headline workload + both device-resident pose seams on 32 independent synthetic scenes every step"}
             wp = run_lockstep_kpset(slam, torch, local_rank, S, max(20, args.steps // 4), min(args.warmup, 10), H, W, left, right, flows, disparity,
                                     params, extractor, world, dist, dev, "host_u8", hook=pose_batch_once)
             out["pose"]["frontend_with_host_pose_seams"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": wp["ms_per_step_of_S_frames"],
