@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 KF_EVERY = 5
 N_KPTS = 1000
+RIGHT_TARGET_ONLY = os.environ.get("SLAM_BENCH_RIGHT_FULL") is None     # right frames are only matched INTO (mapper.jl:51-66): layers only above level 0 (SLAM_PYR_TARGET_ONLY)
 CULL_FRACTION = 0.15              # share of tracked keypoints the map drops per key-frame
 SHAPE = "kitti05"
 N_FRAMES = 8                      # distinct rendered frames, played ping-pong
@@ -116,7 +117,8 @@ class GpuBackend:
         if self.next_built != f_cur or not self.pipelined:
             self.slam.update_(self.cur, None, device_ptr=self.left[f_cur].data_ptr(), sync=False, ctx=self.ctx_pyr, fast=self.fast)
         if kf:                                            # right image of a key-frame, on its own stream (mapper task, mapper.jl:52)
-            self.slam.update_(self.rpyr, None, device_ptr=self.right[f_cur].data_ptr(), sync=False, ctx=self.ctx_right, fast=self.fast)
+            self.slam.update_(self.rpyr, None, device_ptr=self.right[f_cur].data_ptr(), sync=False, ctx=self.ctx_right, fast=self.fast,
+                              target_only=RIGHT_TARGET_ONLY)
         self.ctx.wait_for(self.ctx_pyr)                   # tracking below needs the left builds enqueued so far
         if self.pipelined and f_next is not None:
             self.slam.update_(self.pyr[(self.i + 1) % 3], None, device_ptr=self.left[f_next].data_ptr(), sync=False, ctx=self.ctx_pyr, fast=self.fast)
@@ -236,7 +238,7 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
         if not pipelined:                                   # span pass: build this step's pyramids now, serially
             enqueue_build(i); nxt[0] = max(nxt[0], i + 1)
         if kf:
-            rb.update_(rptr(i), sync=False, fast=fast, ctx=ctx_right)
+            rb.update_(rptr(i), sync=False, fast=fast, ctx=ctx_right, target_only=RIGHT_TARGET_ONLY)
         ctx.wait_event(built[i % NLB])                      # tracking needs the build of frame i only (i+1.. stay in flight)
         if pipelined:
             build_up_to(i + AHEAD)                          # overwrites the slot of a frame nothing reads any more
@@ -438,7 +440,7 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
             src = ptrs(rstage)
         else:
             src = ptrs(rseq[o:o + S])
-        rb.update_(src, sync=False, ctx=ctx_right, u8=u8)
+        rb.update_(src, sync=False, ctx=ctx_right, u8=u8, target_only=RIGHT_TARGET_ONLY)
         rbuilt[0] = ctx_right.record(rbuilt[0])
 
     nxt = [0]; nxc = [0]

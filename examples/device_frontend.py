@@ -74,7 +74,7 @@ def run(lefts, rights, cam, baseline, kf_every=4, max_keypoints=300, seed=0, ctx
             Tkf = Tcw.copy()
             rframes = [dev(rights[s][i]) for s in range(S)]
             torch.cuda.synchronize()
-            rpyr.update_([f.data_ptr() for f in rframes], sigma=params.pyramid_sigma, ctx=ctx)
+            rpyr.update_([f.data_ptr() for f in rframes], sigma=params.pyramid_sigma, ctx=ctx, target_only=True)   # only matched INTO
             ks.stereo_match(cur, rpyr, params, sp_right, prior=2, ctx=ctx)
             Twc = np.stack([np.linalg.inv(Tcw[s]) for s in range(S)])
             ks.triangulate(cam, cam, T21, Twc, max_error=params.max_reprojection_error, ctx=ctx)

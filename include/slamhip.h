@@ -141,6 +141,12 @@ int slam_describe(slam_ctx *ctx, const double *image, int H, int W,
  * pyramid_levels = levels above the base (Params.pyramid_levels = 3 -> 4 layers). */
 int slam_pyr_create(slam_ctx *ctx, int H, int W, int pyramid_levels, slam_pyr **out);
 int slam_pyr_destroy(slam_pyr *pyr);
+/* Update mode flag (OR it into `mode` = 1 or 3): the pyramid will only be the TARGET of matches -- the mapper's right pyramid
+ * (mapper.jl:51-56, optical_flow_matching!(..., left, right, true)).  optflow! samples a target's layers at every level and
+ * fb_tracking!'s backward pass (pyramid_levels = 0, tracker.jl:51-57) uses it as template at level 1 only, so the gradient,
+ * product and integral planes of the coarser levels are never read: level 0 is built in full, the other levels get their layers
+ * only (about a quarter of the build).  Passing such a pyramid as the SOURCE of a match is an error (SLAM_ERR_ARG). */
+#define SLAM_PYR_TARGET_ONLY 16
 /* mode 0: constructor semantics (pyramid.jl:40-79: NA() blur, Fill(0) Scharr);
  * mode 1: update! semantics (pyramid.jl:81-137: replicate borders);
  * mode 3: update! semantics with SEGMENTED recurrences: each IIR / cumulative-sum

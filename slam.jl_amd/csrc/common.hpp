@@ -57,6 +57,7 @@ struct slam_pyr {
     Alloc *alloc = nullptr;
     size_t zstride = 0;                   // doubles between consecutive images of a batch (7 * off[levels])
     int batch_index = 0, batch_size = 1;
+    bool target_only = false;             // last update built the gradient / integral planes of level 0 only (SLAM_PYR_TARGET_ONLY): usable as the `to` pyramid of a match
     double *planes = nullptr;             // 6 planes x off[levels] doubles (inside alloc)
     double *tmp = nullptr;                // blur scratch, off[levels] doubles
     double *ck = nullptr;                 // batches: checkpoint scratch of the bandwidth-bound row kernel (owned by alloc)
@@ -124,6 +125,7 @@ int slam_pinned(slam_ctx *ctx, size_t bytes, void **out);
     } while (0)
 
 // KernelFactors.IIRGaussian coefficients (host side; passed to kernels by value)
+#define SLAM_PYR_TARGET_ONLY 16          /* update mode flag, see include/slamhip.h */
 struct IIRCoef {
     double a1, a2, a3, scale, M[9], inv1masum /* 1-asum */, inv1mbsum /* 1-bsum */;
 };

@@ -495,6 +495,7 @@ static int kpset_match(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *from0, con
     const int need = pyramid_levels > levels3d ? pyramid_levels : levels3d;
     if (!(from0->levels > need && to0->levels > need)) return slam_fail(ctx, SLAM_ERR_LAYERS, "Not enough layers in pyramids.");
     ARG_TRY(ctx, from0->H[0] == to0->H[0] && from0->W[0] == to0->W[0]);
+    if (from0->target_only) return slam_fail(ctx, SLAM_ERR_ARG, "the source pyramid of a match was updated with SLAM_PYR_TARGET_ONLY: its gradient planes exist at level 0 only");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     KpMatchArgs M;
     M.from = from0->view; M.to = to0->view; M.zs_from = from0->zstride; M.zs_to = to0->zstride;
@@ -610,6 +611,7 @@ extern "C" int slam_fb_track(slam_ctx *ctx, const slam_pyr *prev, const slam_pyr
     if (!(prev->levels > pyramid_levels && cur->levels > pyramid_levels))
         return slam_fail(ctx, SLAM_ERR_LAYERS, "Not enough layers in pyramids.");   // lucas_kanade.jl:12-15
     ARG_TRY(ctx, prev->H[0] == cur->H[0] && prev->W[0] == cur->W[0]);
+    if (prev->target_only) return slam_fail(ctx, SLAM_ERR_ARG, "the source pyramid of a match was updated with SLAM_PYR_TARGET_ONLY: its gradient planes exist at level 0 only");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return run_tracking(ctx, prev, cur, pts_yx, disp0_yx, nullptr, n, pyramid_levels, 0, window, iterations, eig_thr, eps,
                         max_distance, out_yx, status, false);
@@ -629,6 +631,7 @@ extern "C" int slam_flow_match(slam_ctx *ctx, const slam_pyr *from, const slam_p
     if (!(from->levels > need && to->levels > need))
         return slam_fail(ctx, SLAM_ERR_LAYERS, "Not enough layers in pyramids.");
     ARG_TRY(ctx, from->H[0] == to->H[0] && from->W[0] == to->W[0]);
+    if (from->target_only) return slam_fail(ctx, SLAM_ERR_ARG, "the source pyramid of a match was updated with SLAM_PYR_TARGET_ONLY: its gradient planes exist at level 0 only");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return run_tracking(ctx, from, to, pts_yx, proj_yx, is_3d, n, pyramid_levels, pyramid_levels_3d, window, iterations, eig_thr, eps,
                         max_distance, out_yx, status, true);
@@ -652,6 +655,7 @@ extern "C" int slam_flow_match_batch(slam_ctx *ctx, const slam_pyr *from0, const
     if (!(from0->levels > need && to0->levels > need))
         return slam_fail(ctx, SLAM_ERR_LAYERS, "Not enough layers in pyramids.");
     ARG_TRY(ctx, from0->H[0] == to0->H[0] && from0->W[0] == to0->W[0]);
+    if (from0->target_only) return slam_fail(ctx, SLAM_ERR_ARG, "the source pyramid of a match was updated with SLAM_PYR_TARGET_ONLY: its gradient planes exist at level 0 only");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return run_tracking(ctx, from0, to0, pts_yx, proj_yx, is_3d, n, pyramid_levels, pyramid_levels_3d, window, iterations, eig_thr, eps,
                         max_distance, out_yx, status, true, img_index);

@@ -1557,7 +1557,7 @@ static void seg_pow(const IIRPair &cf, int n, int SL, SegPow &sp)
 // with level l+1 (fork after the row pass, one join at the end).  With
 // aux == st everything is serial on one stream (profiling / fallback path).
 // mode 3 ("fast") swaps the sequential line kernels for the segmented ones.
-static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf, hipStream_t st, hipStream_t aux, bool spans, int S = 1, int src_kind = 0)
+static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf, hipStream_t st, hipStream_t aux, bool spans, int S = 1, int src_kind = 0, bool target = false)
 {
     const size_t zs = p->zstride;
     const bool forked = aux != st;
@@ -1570,6 +1570,23 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         const LevelView &v = p->view.lv[l];
         const bool has_next = l + 1 < p->levels;
         double *T = p->tmp + p->off[l];
+        if (target && l >= 1) {                                   // the layer chain only: blur (dim 1, dim 2) -> resize
+            if (!has_next) continue;
+            PlaneSet pt = {}; pt.p[0] = T; pt.coef[0] = 0; pt.fill0[0] = (mode == 0); pt.nrm[0] = nullptr; pt.n = 1; pt.zs = zs;
+            const bool ckr = mode != 3 && p->ck != nullptr && mode != 0 && W >= 64 && H >= 64 && (size_t)S * 4 * H * W * 8 >= ck_min_bytes();
+            if (ckr) hipLaunchKernelGGL(k_iir_cols_ck, lines_grid(W, 1, S), dim3(LINE_THREADS), 0, st, pt, (const double *)v.L, H, W, P, cf, p->ck);
+            else hipLaunchKernelGGL(k_iir_cols<2>, lines_grid(W, 1, S), dim3(LINE_THREADS), 0, st, pt, (const double *)v.L, H, W, P, cf);
+            static const bool no_rr = getenv("SLAMHIP_NO_ROWS_RESIZE") != nullptr;
+            const bool rr = ckr && (H & 1) == 0 && !no_rr;
+            RowResize rzt = {};
+            if (rr) { rzt.dst = p->view.lv[l + 1].L; rzt.Hd = p->H[l + 1]; rzt.Wd = p->W[l + 1]; rzt.Pd = p->P[l + 1]; }
+            if (ckr) hipLaunchKernelGGL(k_iir_rows_ck, lines_grid(H, 1, S), dim3(LINE_THREADS), 0, st, pt, H, W, P, cf, p->ck, rzt);
+            else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, 1, S), dim3(LINE_THREADS), 0, st, pt, H, W, P, cf);
+            if (!rr)
+                hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, st,
+                                   p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
+            continue;
+        }
         // bandwidth-bound launches (many images x a large level) take the checkpointed IIR kernels; the column one squares
         // Iy / Ix itself, so the gradient kernel does not write (and the filter does not re-read) the Iyy / Ixx inputs
         const int np_ = has_next ? 4 : 3;
@@ -1670,15 +1687,23 @@ __global__ void k_set_ptrs(const void **tab, ImgPtrs src)
 // fork/join DAG, ~25 kernel nodes) -> one host launch instead of ~25.  With
 // profiling spans enabled (or SLAMHIP_NO_GRAPH=1) the same kernels are launched
 // directly, serially, so that per-kernel hipEvent spans are meaningful.
-static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma, int S = 1, int src_kind = 0)
+static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode_flags, double sigma, int S = 1, int src_kind = 0)
 {
+    // SLAM_PYR_TARGET_ONLY: the pyramid will only be the TARGET of matches (the mapper's right pyramid, mapper.jl:51-56): optflow!
+    // samples a target's layers at every level, and fb_tracking!'s backward pass (pyramid_levels = 0, tracker.jl:51-57) takes it as
+    // template at level 1 only -- the gradient, product and integral planes of the coarser levels are never read.  Level 0 is
+    // built in full, levels >= 1 get their blurred / resized layers and nothing else.
+    const bool target = (mode_flags & SLAM_PYR_TARGET_ONLY) != 0;
+    const int mode = mode_flags & ~SLAM_PYR_TARGET_ONLY;
+    p->target_only = target;                                      // (the other members of a batch are marked by the batch entry points)
+    if (target) src_kind |= 16;                                   // part of the graph key
     IIRPair cf; cf.c[0] = slam_iir_coef(sigma); cf.c[1] = slam_iir_coef(4.0);   // lucas_kanade.jl:112
     if (mode == 0) { int rc = build_norm(ctx, p, sigma); if (rc) return rc; }
     hipStream_t st = ctx->stream;
     static const bool no_graph = getenv("SLAMHIP_NO_GRAPH") != nullptr;
     if (ctx->prof_on || no_graph) {
         ProfScope span_all(ctx, "pyr_update");
-        launch_build(ctx, p, mode, cf, st, st, ctx->prof_on, S, src_kind);
+        launch_build(ctx, p, mode, cf, st, st, ctx->prof_on, S, src_kind & 15, target);
         HIP_TRY(ctx, hipGetLastError());
         return SLAM_OK;
     }
@@ -1694,7 +1719,7 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma, int
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
-            launch_build(ctx, p, mode, cf, st, p->aux, false, S, src_kind);
+            launch_build(ctx, p, mode, cf, st, p->aux, false, S, src_kind & 15, target);
             e = hipStreamEndCapture(st, &graph);
         }
         if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -1703,7 +1728,7 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode, double sigma, int
         else { slam_pyr::Graph g; g.mode = mode; g.sigma = sigma; g.S = S; g.ckmin = ckmin; g.src_kind = src_kind; g.exec = exec; p->graphs.push_back(g); }
     }
     if (exec) HIP_TRY(ctx, hipGraphLaunch(exec, st));
-    else launch_build(ctx, p, mode, cf, st, st, false, S, src_kind);
+    else launch_build(ctx, p, mode, cf, st, st, false, S, src_kind & 15, target);
     HIP_TRY(ctx, hipGetLastError());
     return SLAM_OK;
 }
@@ -1785,7 +1810,7 @@ int slam_pyr_create_batch(slam_ctx *ctx, int H, int W, int pyramid_levels, int S
 // pyrs[0..S) must be the members of one slam_pyr_create_batch call, in order
 int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double *const *images_dev, int S, int mode, double sigma, int sync)
 {
-    ARG_TRY(ctx, ctx != nullptr && pyrs != nullptr && images_dev != nullptr && S >= 1 && S <= BATCH_MAX && (mode == 1 || mode == 3) && sigma > 0);
+    ARG_TRY(ctx, ctx != nullptr && pyrs != nullptr && images_dev != nullptr && S >= 1 && S <= BATCH_MAX && ((mode & ~SLAM_PYR_TARGET_ONLY) == 1 || (mode & ~SLAM_PYR_TARGET_ONLY) == 3) && sigma > 0);
     slam_pyr *p0 = pyrs[0];
     ARG_TRY(ctx, p0 != nullptr && p0->batch_index == 0 && p0->batch_size == S);
     for (int s = 0; s < S; s++) ARG_TRY(ctx, pyrs[s] != nullptr && pyrs[s]->alloc == p0->alloc && pyrs[s]->batch_index == s && images_dev[s] != nullptr);
@@ -1793,10 +1818,11 @@ int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double
     ImgPtrs ip;
     for (int s = 0; s < BATCH_MAX; s++) ip.p[s] = s < S ? images_dev[s] : nullptr;
     const size_t n = (size_t)p0->H[0] * p0->W[0];
-    const bool fused_ingest = level0_fused(p0, mode, S);          // the level-0 kernel reads the source images itself and writes the layer
+    const bool fused_ingest = level0_fused(p0, mode & ~SLAM_PYR_TARGET_ONLY, S);          // the level-0 kernel reads the source images itself and writes the layer
     if (fused_ingest) hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(64), 0, ctx->stream, p0->alloc->srctab, ip);
     else hipLaunchKernelGGL(k_gather_images, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
     int rc = enqueue_build(ctx, p0, mode, sigma, S, fused_ingest ? 1 : 0);
+    for (int s = 0; s < S; s++) pyrs[s]->target_only = (mode & SLAM_PYR_TARGET_ONLY) != 0;
     if (rc) return rc;
     if (sync) HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
@@ -1805,7 +1831,7 @@ int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double
 // 8-bit frames already in HBM (column-major H x W bytes, as the KITTI reader decodes them): converted on the device
 int slam_pyr_update_batch_u8_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const uint8_t *const *images_u8_dev, int S, int mode, double sigma, int sync)
 {
-    ARG_TRY(ctx, ctx != nullptr && pyrs != nullptr && images_u8_dev != nullptr && S >= 1 && S <= BATCH_MAX && (mode == 1 || mode == 3) && sigma > 0);
+    ARG_TRY(ctx, ctx != nullptr && pyrs != nullptr && images_u8_dev != nullptr && S >= 1 && S <= BATCH_MAX && ((mode & ~SLAM_PYR_TARGET_ONLY) == 1 || (mode & ~SLAM_PYR_TARGET_ONLY) == 3) && sigma > 0);
     slam_pyr *p0 = pyrs[0];
     ARG_TRY(ctx, p0 != nullptr && p0->batch_index == 0 && p0->batch_size == S);
     for (int s = 0; s < S; s++) ARG_TRY(ctx, pyrs[s] != nullptr && pyrs[s]->alloc == p0->alloc && pyrs[s]->batch_index == s && images_u8_dev[s] != nullptr);
@@ -1813,10 +1839,11 @@ int slam_pyr_update_batch_u8_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const uin
     ImgPtrsU8 ip;
     for (int s = 0; s < BATCH_MAX; s++) ip.p[s] = s < S ? images_u8_dev[s] : nullptr;
     const size_t n = (size_t)p0->H[0] * p0->W[0];
-    const bool fused_ingest = level0_fused(p0, mode, S);
+    const bool fused_ingest = level0_fused(p0, mode & ~SLAM_PYR_TARGET_ONLY, S);
     if (fused_ingest) { ImgPtrs iq; for (int s = 0; s < BATCH_MAX; s++) iq.p[s] = (const double *)ip.p[s]; hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(64), 0, ctx->stream, p0->alloc->srctab, iq); }
     else hipLaunchKernelGGL(k_gather_images_u8, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
     int rc = enqueue_build(ctx, p0, mode, sigma, S, fused_ingest ? 2 : 0);
+    for (int s = 0; s < S; s++) pyrs[s]->target_only = (mode & SLAM_PYR_TARGET_ONLY) != 0;
     if (rc) return rc;
     if (sync) HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
@@ -1841,7 +1868,7 @@ int slam_pyr_destroy(slam_pyr *p)
 
 int slam_pyr_update_dev(slam_ctx *ctx, slam_pyr *p, const double *image_dev, int mode, double sigma, int sync)
 {
-    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_dev != nullptr && (mode == 0 || mode == 1 || mode == 3) && sigma > 0);
+    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_dev != nullptr && (mode == 0 || (mode & ~SLAM_PYR_TARGET_ONLY) == 1 || (mode & ~SLAM_PYR_TARGET_ONLY) == 3) && sigma > 0);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ingest_dense(ctx, p, image_dev);
     int rc = enqueue_build(ctx, p, mode, sigma);
@@ -1852,7 +1879,7 @@ int slam_pyr_update_dev(slam_ctx *ctx, slam_pyr *p, const double *image_dev, int
 
 int slam_pyr_update(slam_ctx *ctx, slam_pyr *p, const double *image, int mode, double sigma)
 {
-    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image != nullptr && (mode == 0 || mode == 1 || mode == 3) && sigma > 0);
+    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image != nullptr && (mode == 0 || (mode & ~SLAM_PYR_TARGET_ONLY) == 1 || (mode & ~SLAM_PYR_TARGET_ONLY) == 3) && sigma > 0);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     void *stage;
     int rc = slam_scratch2(ctx, (size_t)p->H[0] * p->W[0] * 8, &stage);
@@ -1867,7 +1894,7 @@ int slam_pyr_update(slam_ctx *ctx, slam_pyr *p, const double *image, int mode, d
 
 int slam_pyr_update_u8(slam_ctx *ctx, slam_pyr *p, const uint8_t *image_u8, int mode, double sigma)
 {
-    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_u8 != nullptr && (mode == 0 || mode == 1 || mode == 3) && sigma > 0);
+    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_u8 != nullptr && (mode == 0 || (mode & ~SLAM_PYR_TARGET_ONLY) == 1 || (mode & ~SLAM_PYR_TARGET_ONLY) == 3) && sigma > 0);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)p->H[0] * p->W[0];
     void *d8;

@@ -176,9 +176,12 @@ function hip_pyramid(image, levels; σ = 1.0, reusable = true)
     lk
 end
 
-function hip_update!(lk::LKPyramid, img; σ = 1.0)
+# target_only = true (SLAM_PYR_TARGET_ONLY): for a pyramid that is only ever matched INTO -- mapper.right_pyramid, whose one use is
+# optical_flow_matching!(…, kf.left_pyramid, mapper.right_pyramid, true) (mapper.jl:51-66): levels above the finest get their layers
+# only.  The generic update! method below cannot know the caller; mapper.jl:52 may call hip_update!(…; target_only = true) itself.
+function hip_update!(lk::LKPyramid, img; σ = 1.0, target_only::Bool = false)
     GC.@preserve img check(ccall((:slam_pyr_update, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Cint, Cdouble),
-        ctx(), handle(lk), rawptr(img), 1, Float64(σ)))
+        ctx(), handle(lk), rawptr(img), target_only ? (1 | 16) : 1, Float64(σ)))
     lk
 end
 

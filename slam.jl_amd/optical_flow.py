@@ -72,12 +72,12 @@ def has_gradients(lk):
     return True
 
 
-def update_(lk, img, sigma=1.0, device_ptr=None, sync=True, ctx=None, fast=False):
+def update_(lk, img, sigma=1.0, device_ptr=None, sync=True, ctx=None, fast=False, target_only=False):
     """update!(lk, img; σ) pyramid.jl:81-96.  `device_ptr`: image already in HBM;
     `ctx`: enqueue on another context's stream (default: the pyramid's own);
     `fast`: segmented recurrences (mode 3) -- planes agree with the sequential,
     bit-exact mode to ~1e-13 relative instead of bit for bit."""
-    mode = 3 if fast else 1
+    mode = (3 if fast else 1) | (16 if target_only else 0)       # SLAM_PYR_TARGET_ONLY: only ever matched INTO (the mapper's right pyramid)
     if device_ptr is not None:
         c = ctx or lk.ctx
         c.check(c.lib.slam_pyr_update_dev(c.h, lk.h, C.c_void_p(device_ptr), mode, float(sigma), 1 if sync else 0))
@@ -240,13 +240,15 @@ class PyramidBatch:
         self.pyramids = [LKPyramid(ctx=self.ctx, _handle=C.c_void_p(hs[s])) for s in range(S)]
         self._handles = (C.c_void_p * S)(*[p.h for p in self.pyramids])
 
-    def update_(self, device_ptrs, sigma=1.0, sync=True, fast=False, ctx=None, u8=False):
+    def update_(self, device_ptrs, sigma=1.0, sync=True, fast=False, ctx=None, u8=False, target_only=False):
         """update!() of all S pyramids from S device-resident images (list of device pointers to column-major
         H x W Float64 images, or to 8-bit frames when u8=True: converted raw / 255 on the device)."""
         c = ctx or self.ctx
         imgs = (C.c_void_p * self.S)(*[C.c_void_p(p) for p in device_ptrs])
         fn = c.lib.slam_pyr_update_batch_u8_dev if u8 else c.lib.slam_pyr_update_batch_dev
-        c.check(fn(c.h, self._handles, imgs, self.S, 3 if fast else 1, float(sigma), 1 if sync else 0))
+        # target_only (SLAM_PYR_TARGET_ONLY): the batch will only be matched INTO (the right frames of a stereo match): the coarser
+        # levels get their layers only
+        c.check(fn(c.h, self._handles, imgs, self.S, (3 if fast else 1) | (16 if target_only else 0), float(sigma), 1 if sync else 0))
         return self
 
 

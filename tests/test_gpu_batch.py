@@ -114,6 +114,16 @@ def test_batch_at_kitti_size_uses_checkpointed_kernels_and_stays_exact(slam, syn
             for name in PLANES:
                 assert np.array_equal(batch.pyramids[s].plane(name, l), single.plane(name, l)), (s, name, l)
                 assert np.array_equal(batch.pyramids[s].plane(name, l), ref.plane(name, l)), ("oracle", s, name, l)
+    # the same frames as a tracking-target-only batch (SLAM_PYR_TARGET_ONLY, fused / checkpointed kernels at this size): every layer
+    # and the finest level's gradient / integral planes are the full build's, bit for bit
+    tgt = slam.PyramidBatch((H, W), levels=3, S=S)
+    tgt.update_([d.data_ptr() for d in dev], target_only=True)
+    tgt.update_([d.data_ptr() for d in dev], target_only=True)       # (graph replay)
+    for s in (0, S - 1):
+        for l in range(4):
+            assert np.array_equal(tgt.pyramids[s].plane("layers", l), batch.pyramids[s].plane("layers", l)), (s, l)
+        for name in PLANES:
+            assert np.array_equal(tgt.pyramids[s].plane(name, 0), batch.pyramids[s].plane(name, 0)), (s, name)
 
 
 @pytest.mark.parametrize("shape", [(70, 71), (33, 102), (130, 135), (64, 64), (65, 129), (16, 200), (200, 17)])

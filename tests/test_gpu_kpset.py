@@ -285,3 +285,40 @@ def test_compute_pose_5pt_on_the_set_equals_the_host_seam(slam, syn):
     for s in range(S):
         k2, h2 = ks.download_keyframe(s)
         assert h2.all() and np.array_equal(k2, after[s]["yx"])
+
+
+def test_target_only_right_pyramids_give_the_same_stereo_matches(slam, syn, texture):
+    """SLAM_PYR_TARGET_ONLY: the right batch of a stereo match built with layers only above level 0 -- the matches, the removals and
+    every plane a target is ever read from are identical to the full build; using such a batch as the source is refused."""
+    S, H, W = 3, 160, 240
+    streams, a, b, r, keep = _setup(slam, texture, S, H, W)
+    import torch
+    r2 = slam.PyramidBatch((H, W), levels=3, S=S)
+    r2.update_([d.data_ptr() for d in keep[2]], target_only=True)
+    torch.cuda.synchronize()
+    for s in range(S):
+        for lvl in range(4):                                                   # 0-based: every layer
+            assert np.array_equal(r2.pyramids[s].plane("layers", lvl), r.pyramids[s].plane("layers", lvl)), (s, lvl)
+        for name in ("Iy", "Ix", "Iyy", "Ixx", "Iyx"):                             # the finest level's gradient / integral planes
+            assert np.array_equal(r2.pyramids[s].plane(name, 0), r.pyramids[s].plane(name, 0)), (s, name)
+    params = slam.Params(stereo=True, max_nb_keypoints=150)
+    cam = slam.Camera(*syn.KITTI_CAM, height=H, width=W)
+    e = slam.Extractor.from_params(params, cam)
+    cap = params.max_nb_keypoints + e.grid_resolution[0] * e.grid_resolution[1] + 8
+    sp = slam.stream_params(S, cam=syn.KITTI_CAM, shift_yx=np.tile([0.0, -6.3], (S, 1)))
+    res = []
+    for right in (r, r2):
+        ks = slam.KeypointSet(S, cap)
+        ks.detect(e, b)
+        ks.stereo_match(b, right, params, sp, prior=2)
+        res.append([ks.download(s) for s in range(S)])
+        ks.close()
+    for s in range(S):
+        for k in ("yx", "ids", "stereo_yx", "has_stereo"):
+            assert np.array_equal(res[0][s][k], res[1][s][k]), (s, k)
+        assert res[0][s]["has_stereo"].sum() > 20
+    ks = slam.KeypointSet(S, cap)
+    ks.detect(e, b)
+    with pytest.raises(Exception, match="TARGET_ONLY"):
+        ks.flow_match(r2, b, params, sp, prior=2)
+    ks.close()
