@@ -464,7 +464,7 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
     # consistent; the recovered camera translation is checked against the image offsets of the frames.
     Z_PLANE = 30.0
     pst = dict(Tcw=np.tile(np.eye(4), (S, 1, 1)), Tprev=np.tile(np.eye(4), (S, 1, 1)), Tkf=np.tile(np.eye(4), (S, 1, 1)), ref=None,
-               accepted=0, asked=0, err_max=0.0, acc5=0)
+               accepted=0, asked=0, err_max=0.0, acc5=0, asked5=0)
     sp_cam = slam.stream_params(S, cam=camt)
     if host:
         enqueue_right_copy(1)                               # step 1 is a key-frame
@@ -487,8 +487,9 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
             Tpred = pst["Tcw"].copy(); Tpred[:, :3, 3] += pst["Tcw"][:, :3, 3] - pst["Tprev"][:, :3, 3]
             ks.flow_match(prevb, curb, params, slam.stream_params(S, Tcw=Tpred, cam=camt), prior=1, n_bound=state["n_bound"], ctx=ctx)
             Rc = np.tile(np.eye(4), (S, 1, 1)); Rc[:, :3, :3] = pst["Tkf"][:, :3, :3] @ np.transpose(Tpred[:, :3, :3], (0, 2, 1))
-            _, st5, _, _, _ = ks.compute_pose_5pt(slam.stream_params(S, Tcw=Rc, cam=camt), min_parallax=5.0, max_repr_error=3.0, iters=128,
-                                                  seed=seed + 2 * i, ctx=ctx)
+            r5 = ks.compute_pose_5pt(slam.stream_params(S, Tcw=Rc, cam=camt), min_parallax=5.0, max_repr_error=3.0, iters=128,
+                                     seed=seed + 2 * i, ctx=ctx, fetch=(i % 4 == 0))      # enqueue-only on most steps: its effect is on the lists
+            st5 = r5[1] if r5 is not None else None
             t_enq = time.perf_counter()
             poses, stp, _, cnt = ks.compute_pose(sp_cam, threshold=3.0, iters=256, seed=seed + 2 * i + 1, ctx=ctx)
             state["wait_s"] += time.perf_counter() - t_enq
@@ -498,7 +499,9 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
             if pst["ref"] is not None:
                 off = flows_a[seq_a[(i % period) + np.arange(S)]] - pst["ref"]
                 want = np.stack([off[:, 1] * Z_PLANE / camt[0], off[:, 0] * Z_PLANE / camt[1], np.zeros(S)], axis=1)
-                pst["asked"] += S; pst["accepted"] += int(ok.sum()); pst["acc5"] += int(np.asarray(st5).sum())
+                pst["asked"] += S; pst["accepted"] += int(ok.sum())
+                if st5 is not None:
+                    pst["asked5"] += S; pst["acc5"] += int(np.asarray(st5).sum())
                 if ok.any():
                     pst["err_max"] = max(pst["err_max"], float(np.abs(pst["Tcw"][ok, :3, 3] - want[ok]).max()))
         elif state["n_bound"] > 0:
@@ -557,7 +560,7 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
            "ms_per_step_of_S_frames": dt / steps * 1e3,
            "host_wait_ms_per_step": state["wait_s"] / steps * 1e3,
            "tracked_kpts_per_frame": round(state["tracked"] / max(state["tracked_steps"], 1) / S, 1),
-           "pose": None if not pose else {"accepted_fraction": pst["accepted"] / max(pst["asked"], 1), "five_point_accepted_fraction": pst["acc5"] / max(pst["asked"], 1),
+           "pose": None if not pose else {"accepted_fraction": pst["accepted"] / max(pst["asked"], 1), "five_point_accepted_fraction": pst["acc5"] / max(pst["asked5"], 1),
                                           "max_translation_error_m": pst["err_max"], "plane_depth_m": Z_PLANE},
            "pyramid_build_ms": {"mean": float(np.mean(builds)) if builds else None, "min": float(np.min(builds)) if builds else None,
                                 "n": len(builds), "what": "hipEvents around each left-batch build (ingest kernel + one hipGraph replay) on the pyramid "

@@ -304,7 +304,8 @@ int slam_kpset_download_keyframe(slam_ctx *ctx, slam_kpset *ks, int s, double *k
  * status[s] = 1: P[12 s ..] is [R | t] (column-major 3 x 4, key-frame -> frame, |t| = 1) of the best essential matrix; 0: one
  * of the `nothing` exits (fewer than 8 keypoints :243 / in the key-frame :283, parallax below min_parallax :290, fewer than 5
  * inliers :305), nothing removed.  The composition with the motion-model scale (:320-330) is the caller's.  n_inliers, parallax
- * (the average) and counts (list lengths after the removals) may be NULL.  Synchronous. */
+ * (the average) and counts (list lengths after the removals) may be NULL.  Synchronous -- unless P and status are both NULL:
+ * then the call only enqueues (the epipolar filter acts on the lists; compute_pose! right behind it brings the step's copy). */
 int slam_kpset_compute_pose_5pt(slam_ctx *ctx, slam_kpset *ks, const double *params, double min_parallax, double max_repr_error,
                                 int iters, uint64_t seed, double *P, int32_t *status, int32_t *n_inliers, double *parallax,
                                 int32_t *counts);

@@ -902,7 +902,8 @@ extern "C" int slam_kpset_compute_pose_5pt(slam_ctx *ctx, slam_kpset *ks, const 
                                            int iters, uint64_t seed, double *P, int32_t *status, int32_t *n_inliers, double *parallax,
                                            int32_t *counts)
 {
-    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && params != nullptr && iters > 0 && P && status);
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && params != nullptr && iters > 0 && ((P != nullptr) == (status != nullptr)));
+    const bool fetch = P != nullptr;                             // P == status == NULL: enqueue only (the filter's effect is on the lists)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int S = ks->S, cap = ks->cap;
     const size_t nc = (size_t)S * cap, slots = (size_t)S * iters;
@@ -946,6 +947,7 @@ extern "C" int slam_kpset_compute_pose_5pt(slam_ctx *ctx, slam_kpset *ks, const 
     HIP_TRY(ctx, hipGetLastError());
     rc = kpset_compact(ctx, ks, 1, A.flags);
     if (rc) return rc;
+    if (!fetch) return SLAM_OK;
     void *hv;
     rc = slam_pinned(ctx, up((size_t)S * 96) + 4 * up((size_t)S * 8), &hv);
     if (rc) return rc;

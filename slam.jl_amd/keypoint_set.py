@@ -133,7 +133,7 @@ class KeypointSet:
         c.check(c.lib.slam_kpset_download_keyframe(c.h, self.h, s, L.ptr(k), L.ptr(f, L.u8p), self.cap, C.byref(n)))
         return k[:n.value].copy(), f[:n.value].astype(bool)
 
-    def compute_pose_5pt(self, sp, min_parallax=5.0, max_repr_error=3.0, iters=128, seed=0, ctx=None):
+    def compute_pose_5pt(self, sp, min_parallax=5.0, max_repr_error=3.0, iters=128, seed=0, ctx=None, fetch=True):
         """compute_pose_5pt! (front_end.jl:242-332) for every stream on the device-resident lists (slam_kpset_compute_pose_5pt):
         returns (Rt (S, 3, 4) key-frame -> frame with |t| = 1, status (S,), inlier counts (S,), average parallax (S,), list lengths
         after the removals (S,)).  sp: stream_params(...) with R_compensation in the rotation part of the Tcw slot (rows / columns
@@ -143,6 +143,10 @@ class KeypointSet:
         # the seam reads R_compensation as a dense column-major 3 x 3 at [0..8]: repack from the 4 x 4 slot (column-major, stride 4)
         T = sp[:, :16].reshape(self.S, 4, 4)                                       # [col][row]
         sp[:, :9] = T[:, :3, :3].reshape(self.S, 9)
+        if not fetch:                                            # enqueue only: the filter acts on the lists, nothing comes back
+            c.check(c.lib.slam_kpset_compute_pose_5pt(c.h, self.h, L.ptr(sp), float(min_parallax), float(max_repr_error), int(iters),
+                                                      int(seed) & 0xFFFFFFFFFFFFFFFF, None, None, None, None, None))
+            return None
         P = np.zeros((self.S, 12)); status = np.zeros(self.S, dtype=np.int32); ninl = np.zeros(self.S, dtype=np.int32)
         par = np.zeros(self.S); counts = np.zeros(self.S, dtype=np.int32)
         c.check(c.lib.slam_kpset_compute_pose_5pt(c.h, self.h, L.ptr(sp), float(min_parallax), float(max_repr_error), int(iters),

@@ -322,3 +322,23 @@ def test_target_only_right_pyramids_give_the_same_stereo_matches(slam, syn, text
     with pytest.raises(Exception, match="TARGET_ONLY"):
         ks.flow_match(r2, b, params, sp, prior=2)
     ks.close()
+
+
+def test_compute_pose_5pt_enqueue_only_filters_the_same_way(slam, syn):
+    """P = status = NULL: the five-point seam only enqueues; the lists end up exactly as after the fetching call."""
+    S, cap = 2, 400
+    cam = syn.KITTI_CAM
+    res = []
+    for fetch in (True, False):
+        ks = slam.KeypointSet(S, cap)
+        for s in range(S):
+            fs = syn.five_point_scene(n=250, seed=80 + s, noise_px=0.3, outlier_frac=0.25, iters=4)
+            ks.upload(s, fs["px2"][:, ::-1], np.zeros(250, bool))
+            ks.upload_keyframe(s, fs["px1"][:, ::-1], np.ones(250, bool))
+        sp = slam.stream_params(S, Tcw=np.eye(4), cam=cam)
+        r = ks.compute_pose_5pt(sp, iters=64, seed=3, fetch=fetch)
+        assert (r is None) == (not fetch)
+        res.append([ks.download(s)["ids"] for s in range(S)])
+        ks.close()
+    for s in range(S):
+        assert np.array_equal(res[0][s], res[1][s]) and 150 < len(res[0][s]) < 250
