@@ -838,6 +838,9 @@ def main():
                      "algorithmic_bytes_per_launch": pb, "avg_launch_us": build_ms * 1e3, "launches_timed": head["pyramid_build_ms"]["n"],
                      "min_launch_us": head["pyramid_build_ms"]["min"] * 1e3, "serial_launches_us": serial_us,
                      "traffic": None,
+                     "note": "frac / avg_launch_us: hipEvents around every build of the timed region on the pyramid stream -- the tracking kernels of the "
+                             "previous frame run beside the build for its whole duration (own hardware queue), so the duration contains their share of the "
+                             "GPU; frac_isolated / isolated_launch_us: the same ingest + graph replay alone on the GPU, back to back",
                      "kernel": {"name": "k_iir_rows_ck (dim-2 IIR pass, largest kernel of the build; algorithmic = 1R + 1W of every plane it filters)",
                                 "avg_launch_us": rows_us, "algorithmic_bytes_per_launch": rb_bytes,
                                 "achieved": rb_bytes / (rows_us * 1e-6) / 1e9, "frac": rb_bytes / (rows_us * 1e-6) / 1e9 / HBM_PEAK_GBS}},
