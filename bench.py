@@ -641,6 +641,7 @@ def main():
     ap.add_argument("--no-ba", action="store_true", help="skip the BA measurements")
     ap.add_argument("--streams", type=int, default=32, help="S: independent stereo streams per GPU advancing in lock-step (one batch of S frames per step)")
     ap.add_argument("--no-tolerance", action="store_true", help="skip the tolerance-mode measurements")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the S = 48 / 64 streams-per-GPU legs")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -854,6 +855,15 @@ def main():
                 out["roofline"]["traffic_source"] = f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 corrected), all kernels of one {S}-image build"
                 break
 
+    # more streams per GPU share every launch better (the build's per-frame cost falls until the big kernels run whole rounds of
+    # workgroups): the same loop at S = 48 and 64, short
+    if not args.no_sweep and S == 32:
+        out["streams_sweep"] = {}
+        for S2 in (48, 64):
+            r2 = run_lockstep_kpset(slam, torch, local_rank, S2, max(40, args.steps // 4), min(args.warmup, 10), H, W, left, right, flows, disparity,
+                                    params, extractor, world, dist, dev, "host_u8")
+            out["streams_sweep"][str(S2)] = {"value": r2["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": r2["ms_per_step_of_S_frames"]}
+        leg_done("streams_sweep")
     out["single_stream"] = single_result
     if tol_result is not None:
         out["tolerance_mode"] = tol_result
