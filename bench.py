@@ -639,7 +639,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ba", action="store_true", help="skip the BA measurements")
-    ap.add_argument("--streams", type=int, default=32, help="S: independent stereo streams per GPU advancing in lock-step (one batch of S frames per step)")
+    ap.add_argument("--streams", type=int, default=64, help="S: independent stereo streams per GPU advancing in lock-step (one batch of S frames per step); "
+                    "64 = the library's batch limit: the big pyramid kernels then run whole rounds of workgroups (S = 32, the round-1 value: -8 %%)")
     ap.add_argument("--no-tolerance", action="store_true", help="skip the tolerance-mode measurements")
     ap.add_argument("--no-sweep", action="store_true", help="skip the S = 48 / 64 streams-per-GPU legs")
     args = ap.parse_args()
@@ -846,7 +847,7 @@ def main():
                                 "avg_launch_us": rows_us, "algorithmic_bytes_per_launch": rb_bytes,
                                 "achieved": rb_bytes / (rows_us * 1e-6) / 1e9, "frac": rb_bytes / (rows_us * 1e-6) / 1e9 / HBM_PEAK_GBS}},
     }
-    for cand in ("r02d_pmc_pyramid_batch.json", "r02c_pmc_pyramid_batch.json", "r02a_pmc_pyramid_batch.json"):
+    for cand in ("r02g_pmc_pyramid_batch_s64.json", "r02d_pmc_pyramid_batch.json", "r02c_pmc_pyramid_batch.json", "r02a_pmc_pyramid_batch.json"):
         pmc = os.path.join(ROOT, "profiles", cand)
         if SHAPE == "kitti05" and os.path.exists(pmc):
             j = json.load(open(pmc))
@@ -856,10 +857,10 @@ def main():
                 break
 
     # more streams per GPU share every launch better (the build's per-frame cost falls until the big kernels run whole rounds of
-    # workgroups): the same loop at S = 48 and 64, short
-    if not args.no_sweep and S == 32:
+    # workgroups): the same loop at the other batch sizes, short
+    if not args.no_sweep and S in (32, 64):
         out["streams_sweep"] = {}
-        for S2 in (48, 64):
+        for S2 in ((48, 64) if S == 32 else (32, 48)):
             r2 = run_lockstep_kpset(slam, torch, local_rank, S2, max(40, args.steps // 4), min(args.warmup, 10), H, W, left, right, flows, disparity,
                                     params, extractor, world, dist, dev, "host_u8")
             out["streams_sweep"][str(S2)] = {"value": r2["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": r2["ms_per_step_of_S_frames"]}
@@ -937,7 +938,7 @@ def main():
         out["pose"]["five_point"] = {"points": 1000, "ransac_tuples": 128, "inliers": int(cnt5),
                                      "ms_per_call": (time.perf_counter() - t0) / 10 * 1e3}
         # the same three seams for 32 lock-stepped streams: one launch set each (slam_*_batch)
-        SB = 32
+        SB = S
         pss = [syn.p3p_scene(n=1000, seed=40 + z, noise_px=0.4, outlier_frac=0.25, iters=256) for z in range(SB)]
         fss = [syn.five_point_scene(n=1000, seed=40 + z, noise_px=0.4, outlier_frac=0.25, iters=128) for z in range(SB)]
         def pose_batch_once():
@@ -956,7 +957,7 @@ def main():
         for _ in range(5):
             pose_batch_once()
         out["pose"]["batch"] = {"streams": SB, "ms_per_step": (time.perf_counter() - t0) / 5 * 1e3,
-                                "what": "five-point RANSAC + P3P RANSAC + PnP refinement for 32 streams (3 launch sets), host lists in and out"}
+                                "what": "five-point RANSAC + P3P RANSAC + PnP refinement for the S streams (3 launch sets), host lists in and out"}
         # compute_pose! on device-resident lists (slam_kpset_compute_pose): the 3-D keypoints never visit the host.  A second set
         # holds the 32 synthetic scenes (1000 map points each, 25 % gross outliers: they leave the lists in the first call, as
         # in the reference; the timed calls see the 750 consistent points per stream)
@@ -986,14 +987,14 @@ def main():
         out["pose"]["kpset_5pt"] = {"streams": SB, "ms_per_step": (time.perf_counter() - t0) / 10 * 1e3, "accepted": int(s51.sum()),
                                     "pairs_per_stream": float(c51.mean()), "inliers_first_call": float(n50.mean()), "avg_parallax_px": float(par1.mean()),
                                     "what": "slam_kpset_compute_pose_5pt: pairs with the key-frame observation, parallax, five-point RANSAC (128 tuples), "
-                                            "outlier removal for 32 streams on device-resident lists"}
+                                            "outlier removal for the S streams on device-resident lists"}
         _, st0, ni0, cn0 = pose_kpset_once()
         t0 = time.perf_counter()
         for _ in range(10):
             _, st1, ni1, cn1 = pose_kpset_once()
         out["pose"]["kpset"] = {"streams": SB, "ms_per_step": (time.perf_counter() - t0) / 10 * 1e3, "accepted": int(st1.sum()),
                                 "points_per_stream": float(cn1.mean()), "inliers_first_call": float(ni0.mean()),
-                                "what": "slam_kpset_compute_pose: P3P RANSAC (256 triples) + PnP refinement + outlier removal for 32 streams on "
+                                "what": "slam_kpset_compute_pose: P3P RANSAC (256 triples) + PnP refinement + outlier removal for the S streams on "
                                         "device-resident lists; one device -> host copy (poses, status, list lengths)"}
         if S == SB:
             # the tracked workload with compute_pose! of all streams run after every step (pose inputs are the independent
