@@ -1,4 +1,5 @@
-timeout 1500 python bench.py > gpurun_out/r02g_bench.json 2> gpurun_out/r02g_bench.err; echo rc $?
-cd /tmp; export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r02g -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu > $GRAFT_REPO_ROOT/gpurun_out/r02g_bench_profiled.json 2> $GRAFT_REPO_ROOT/gpurun_out/r02g_prof.err; echo rc $?
-cd $GRAFT_REPO_ROOT; find gpurun_out/prof_r02g -name "*kernel_stats.csv" -exec cp {} gpurun_out/r02g_bench_kernel_stats.csv \; ; rm -rf gpurun_out/prof_r02g
+for i in 1 2; do
+SLAMHIP_LIB=$PWD/scripts/ubench/libslamhip_base.so timeout 200 python scripts/prof_pose_5pt.py 2>&1 | tail -2 | sed 's/^/base /'
+timeout 200 python scripts/prof_pose_5pt.py 2>&1 | tail -2 | sed 's/^/new  /'
+done
+timeout 600 python -m pytest tests/test_gpu_kpset.py tests/test_gpu_pose_batch.py tests/test_gpu_5pt.py tests/test_gpu_pose_fuzz.py -x -q 2>&1 | tail -1

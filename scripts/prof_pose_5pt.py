@@ -19,3 +19,7 @@ t0 = time.perf_counter()
 for i in range(20):
     r = ks.compute_pose_5pt(sp, iters=128, seed=2 + i, ctx=ctx)
 print("kpset compute_pose_5pt ms", (time.perf_counter() - t0) / 20 * 1e3, "accepted", int(r[1].sum()), "pairs", r[4].mean())
+t0 = time.perf_counter()
+for i in range(20):
+    rg = ks.compute_pose_5pt(sp, min_parallax=1e9, iters=128, seed=2 + i, ctx=ctx)
+print("gated (no parallax) ms", (time.perf_counter() - t0) / 20 * 1e3, "accepted", int(rg[1].sum()))

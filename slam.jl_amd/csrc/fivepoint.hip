@@ -530,6 +530,10 @@ __global__ __launch_bounds__(FP_TPB * FP_TEAM) void k_5pt_solve(FPArgs T)
             for (int b = 0; b < a; b++) if (ids[a] == ids[b]) ok = false;
         }
     }
+    if (__ballot(ok) == 0) {                                      // no valid tuple in this workgroup (one wave): e.g. the whole stream is gated off
+        if (l == 0 && it < T.iters) T.ne[(size_t)z * T.iters + it] = 0;
+        return;
+    }
     double q1[10], q2[10];
     const Col Es = L.at(416);
     for (int a = 0; a < 5; a++) {
