@@ -1,5 +1,3 @@
-for i in 1 2; do
-SLAMHIP_LIB=$PWD/scripts/ubench/libslamhip_base.so timeout 200 python scripts/prof_pose_5pt.py 2>&1 | tail -2 | sed 's/^/base /'
-timeout 200 python scripts/prof_pose_5pt.py 2>&1 | tail -2 | sed 's/^/new  /'
-done
-timeout 600 python -m pytest tests/test_gpu_kpset.py tests/test_gpu_pose_batch.py tests/test_gpu_5pt.py tests/test_gpu_pose_fuzz.py -x -q 2>&1 | tail -1
+# scratch: the command file handed to gpurun during development (overwritten freely)
+timeout 1400 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+timeout 1500 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; echo rc $?
