@@ -939,12 +939,12 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     prefetch(0);
     for (int b = 0; b < NBk; b++) {
         const int rb = b << 5;
-        lds_barrier();                                            // the previous block's shared data has been consumed
+        if (!CFX(5)) lds_barrier();                                            // the previous block's shared data has been consumed
         publish();
-        lds_barrier();  
+        if (!CFX(5)) lds_barrier();  
         if (b + 1 < NBk) prefetch(b + 1);
         if (!CFX(2)) cf4_scharr8(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
-        lds_barrier();  
+        if (!CFX(5)) lds_barrier();  
         if (!active) continue;
         read_inputs();
         if (b >= 1 && !CFX(0)) { double *c = ck + ((size_t)b * 3) * nlines + lineid; c[0] = w1; c[nlines] = w2; c[2 * nlines] = w3; }
@@ -984,11 +984,11 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     for (int b = NBk - 1; b >= 0; b--) {
         const int rb = b << 5, lo = rb > 3 ? rb : 3, hi = rb + 31 < n - 4 ? rb + 31 : n - 4;     // recurrence rows of the block (may be empty: lo > hi)
         const bool two = 2 * b + 1 < ntile;
-        lds_barrier();  
+        if (!CFX(5)) lds_barrier();  
         publish();
-        lds_barrier();  
+        if (!CFX(5)) lds_barrier();  
         if (!CFX(2)) cf4_scharr8(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
-        lds_barrier();  
+        if (!CFX(5)) lds_barrier();  
         if (active) read_inputs();
         if (ROLE == 0 && skind) {                                 // fused ingest: the block's layer rows -> the pitched layer plane
             ColIO<2> iol = io; iol.dst = const_cast<double *>(A.L) + z;
@@ -1008,7 +1008,7 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
             get_tile(blk, 0, u); if (!CFX(0)) iog.tile_store(rb, u, rb, ghi, rb + 15 > ghi);
             if (two && rb + 16 <= ghi) { get_tile(blk, 1, u); if (!CFX(0)) iog.tile_store(rb + 16, u, rb + 16, ghi, rb + 31 > ghi); }
         }
-        lds_barrier();                                            // inputs consumed: the shared blocks become output staging
+        if (!CFX(5)) lds_barrier();                                            // inputs consumed: the shared blocks become output staging
         double f1 = f1n, f2 = f2n, f3 = f3n;
         if (b > 0) { prefetch(b - 1); if (active) load_ck(b - 1); }
         if (!active || lo > hi) continue;                         // (a trailing block may hold rows n-3 .. n-1 only)
