@@ -464,7 +464,7 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
     # consistent; the recovered camera translation is checked against the image offsets of the frames.
     Z_PLANE = 30.0
     pst = dict(Tcw=np.tile(np.eye(4), (S, 1, 1)), Tprev=np.tile(np.eye(4), (S, 1, 1)), Tkf=np.tile(np.eye(4), (S, 1, 1)), ref=None,
-               accepted=0, asked=0, err_max=0.0, acc5=0, asked5=0)
+               accepted=0, asked=0, err_max=0.0, acc5=0, asked5=0, n_kf=0, kf_cw=np.tile(np.eye(4), (S, 8, 1, 1)))
     sp_cam = slam.stream_params(S, cam=camt)
     if host:
         enqueue_right_copy(1)                               # step 1 is a key-frame
@@ -524,7 +524,12 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
                     pst["ref"] = flows_a[seq_a[(i % period) + np.arange(S)]].copy()
             ctx.wait_for(ctx_right)
             ks.stereo_match(curb, rb, params, sp_stereo, prior=2, ctx=ctx)
-            ks.triangulate(camt, camt, T21, np.linalg.inv(pst["Tcw"]) if pose else Twc, max_error=3.0, ctx=ctx)
+            Twc_now = np.linalg.inv(pst["Tcw"]) if pose else Twc
+            ks.triangulate(camt, camt, T21, Twc_now, max_error=3.0, ctx=ctx)
+            if pose:                                        # mapper.jl:86: what stereo left 2-D, against its first observing key-frame
+                kfid = pst["n_kf"]; pst["kf_cw"][:, kfid % 8] = pst["Tcw"]; pst["n_kf"] += 1
+                if kfid > 0:
+                    ks.triangulate_temporal(sp_cam, pst["kf_cw"], Twc_now, kfid, max_error=3.0, ctx=ctx)
             cnt = None
         if cnt is None:
             t_enq = time.perf_counter()
@@ -911,7 +916,9 @@ def main():
             out["ba_sharded"] = {"error": repr(ex)[:300], "world_size": world}
 
     # ---- compute_pose! arithmetic (front_end.jl:164-206): P3P RANSAC (256 triples, 1000 map points) + PnP refinement ----
-    if not args.no_ba:
+    # (optional legs behind the headline: an exception in one of them -- a rare capture-state error of the HIP runtime has been
+    #  seen once after the RCCL leg -- is recorded in the line instead of losing it)
+    def pose_legs():
         ps = syn.p3p_scene(n=1000, seed=3, noise_px=0.4, outlier_frac=0.25, iters=256)
         Kc = ps["K"]; camp = (Kc[0, 0], Kc[1, 1], Kc[0, 2], Kc[1, 2])
         def pose_once():
@@ -1017,6 +1024,15 @@ def main():
                                                             "what": "headline workload + slam_five_point_ransac_batch + slam_p3p_ransac_batch + slam_pnp_ba_batch "
                                                                     "every step (host lists in and out: the round-1 configuration of this figure)"}
         kspose.close()
+    if not args.no_ba:
+        try:
+            pose_legs()
+        except Exception as ex:
+            out.setdefault("pose", {})["error"] = repr(ex)[:300]
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----------
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -1061,12 +1077,12 @@ def main():
             T0 = np.eye(4); T0[:3] = Rt
             Kc = ps["K"]
             orc.pnp_ba((Kc[0, 0], Kc[1, 1], Kc[0, 2], Kc[1, 2]), T0, ps["px_xy"][inl][:, ::-1], ps["pts3d"][inl], repr_eps=3.0)
-            out["pose"]["cpu_ms_per_call"] = (time.perf_counter() - t0) * 1e3
+            out.setdefault("pose", {})["cpu_ms_per_call"] = (time.perf_counter() - t0) * 1e3
             out["pose"]["cpu_cores"] = 1
             fs = syn.five_point_scene(n=1000, seed=3, noise_px=0.4, outlier_frac=0.25, iters=128)
             t0 = time.perf_counter()
             orc.five_point_ransac(fs["px1"], fs["px2"], fs["pd1"], fs["pd2"], fs["K"], fs["K"], 3.0, fs["samples"])
-            out["pose"]["five_point"]["cpu_ms_per_call"] = (time.perf_counter() - t0) * 1e3
+            out["pose"].setdefault("five_point", {})["cpu_ms_per_call"] = (time.perf_counter() - t0) * 1e3
 
     if rank == 0:
         print(json.dumps(out))

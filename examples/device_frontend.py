@@ -6,7 +6,7 @@ lock-stepped stereo streams with every keypoint list resident in HBM -- the call
     KeypointSet.flow_match      prior = projection of the map points under the predicted pose   (klt_tracking!)
     KeypointSet.compute_pose_5pt   epipolar outlier filter against the previous key-frame       (compute_pose_5pt!)
     KeypointSet.compute_pose       P3P RANSAC + PnP refinement -> the frame's pose              (compute_pose!)
-    key-frames: detect -> keyframe -> right frames -> stereo_match -> triangulate               (create_keyframe!, mapper)
+    key-frames: detect -> keyframe -> right frames -> stereo_match -> triangulate -> triangulate_temporal   (create_keyframe!, mapper)
 
 No host keypoint arrays anywhere; per frame the host receives S poses, S status words and S list lengths.  It is an
 array-level driver, not SLAM (no map maintenance, no bundle adjustment, no relocalisation): what it shows is that the seams
@@ -45,6 +45,7 @@ def run(lefts, rights, cam, baseline, kf_every=4, max_keypoints=300, seed=0, ctx
     dev = lambda im: torch.from_numpy(np.ascontiguousarray(im.T)).cuda()          # Julia layout: column-major H x W
     T21 = np.eye(4); T21[0, 3] = -baseline                                          # left camera -> right camera
     Tcw = np.tile(np.eye(4), (S, 1, 1)); Tkf = Tcw.copy()
+    NKF = 8; kf_cw = np.tile(np.eye(4), (S, NKF, 1, 1)); n_kf = 0          # poses of the last key-frames (triangulate_temporal!'s observers)
     sp_right = slam.stream_params(S, cam=cam, shift_yx=np.zeros((S, 2)))
     out = []
     for i in range(n_frames):
@@ -72,12 +73,15 @@ def run(lefts, rights, cam, baseline, kf_every=4, max_keypoints=300, seed=0, ctx
             ks.detect(ex, cur, ctx=ctx)
             ks.keyframe(ctx=ctx)
             Tkf = Tcw.copy()
+            kfid = n_kf; kf_cw[:, kfid % NKF] = Tcw; n_kf += 1
             rframes = [dev(rights[s][i]) for s in range(S)]
             torch.cuda.synchronize()
             rpyr.update_([f.data_ptr() for f in rframes], sigma=params.pyramid_sigma, ctx=ctx, target_only=True)   # only matched INTO
             ks.stereo_match(cur, rpyr, params, sp_right, prior=2, ctx=ctx)
             Twc = np.stack([np.linalg.inv(Tcw[s]) for s in range(S)])
             ks.triangulate(cam, cam, T21, Twc, max_error=params.max_reprojection_error, ctx=ctx)
+            if kfid > 0:                                                    # mapper.jl:86: 2-D keypoints left over, against their first observers
+                ks.triangulate_temporal(slam.stream_params(S, cam=cam), kf_cw, Twc, kfid, max_error=params.max_reprojection_error, ctx=ctx)
         cnt = ks.counts(ctx=ctx)
         row = dict(frame=i, keyframe=i % kf_every == 0, poses=Tcw.copy(), status=status.copy(), status_5pt=np.asarray(st5).copy(),
                    counts=cnt.copy(), ms=(time.perf_counter() - t0) * 1e3)

@@ -294,6 +294,19 @@ int slam_kpset_compute_pose(slam_ctx *ctx, slam_kpset *ks, const double *params,
  * holds (call it after slam_kpset_detect: the key-frame contains the new keypoints).  The observation travels with the keypoint
  * through every compaction; keypoints detected later have none until the next call. */
 int slam_kpset_keyframe(slam_ctx *ctx, slam_kpset *ks);
+/* triangulate_temporal! (mapper.jl:185-262) for every 2-D keypoint whose first observer -- the key-frame that detected it; the set
+ * keeps that observation and the key-frame's id (a per-stream counter advanced by slam_kpset_keyframe) beside the keypoint -- is an
+ * earlier key-frame than the frame's (kf_cur[s]) and still in the table (>= kf_lo[s]).  tab: S x nkf x 64 doubles, entry
+ * [s][kf % nkf] = { P2 = K * rel_pose_inv, rel_pose_inv, rel_pose = observer.cw * frame.wc, observer.wc }, column-major 4 x 4 each
+ * (what mapper.jl:226-231 computes once per observer).  Success: map point = observer.wc * X, is_3d = 1; a gate fails with the
+ * rotation-compensated parallax above min_parallax: the observation is removed (:244-258); otherwise the point is accepted. */
+int slam_kpset_triangulate_temporal(slam_ctx *ctx, slam_kpset *ks, const double *params, const double *tab, int nkf,
+                                    const int32_t *kf_cur, const int32_t *kf_lo, double max_error, double min_depth, double min_parallax,
+                                    int n_bound);
+/* the first observations of stream s's list, host <-> device (restoring state, tests): first_yx n x 2, first_kf n ids, and the
+ * stream's key-frame counter */
+int slam_kpset_upload_first(slam_ctx *ctx, slam_kpset *ks, int s, const double *first_yx, const int32_t *first_kf, int n, int kf_count);
+int slam_kpset_download_first(slam_ctx *ctx, slam_kpset *ks, int s, double *first_yx, int32_t *first_kf, int cap_out, int *n_out, int *kf_count);
 /* the key-frame observations of stream s's list, host <-> device (restoring state, tests): kyx n x 2 (y, x), has_kf n flags */
 int slam_kpset_upload_keyframe(slam_ctx *ctx, slam_kpset *ks, int s, const double *kyx, const uint8_t *has_kf, int n);
 int slam_kpset_download_keyframe(slam_ctx *ctx, slam_kpset *ks, int s, double *kyx, uint8_t *has_kf, int cap_out, int *n_out);

@@ -1,2 +1,3 @@
-# scratch: the command file handed to gpurun during development (overwritten freely)
-timeout 1400 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+timeout 500 python bench.py --no-cpu --steps 100 --warmup 10 --no-sweep > gpurun_out/b1.json 2> gpurun_out/b1.err; echo "nosweep rc $?"; grep -c "capturing" gpurun_out/b1.err
+timeout 500 python bench.py --no-cpu --steps 100 --warmup 10 > gpurun_out/b2.json 2> gpurun_out/b2.err; echo "sweep rc $?"; grep -c "capturing" gpurun_out/b2.err
+timeout 500 python bench.py --no-cpu --steps 100 --warmup 10 --no-sweep --no-ba > gpurun_out/b3.json 2> gpurun_out/b3.err; echo "nosweep noba rc $?"; grep -c "capturing" gpurun_out/b3.err

@@ -76,6 +76,9 @@ SIGNATURES = {
     "slam_kpset_detect": (cint, [vp, vp, vp, cint, cint, cint, cint, cint, dbl, dbl]),
     "slam_kpset_triangulate": (cint, [vp, vp, f64p, f64p, f64p, f64p, f64p, f64p, dbl, dbl, cint]),
     "slam_kpset_keyframe": (cint, [vp, vp]),
+    "slam_kpset_triangulate_temporal": (cint, [vp, vp, f64p, f64p, cint, i32p, i32p, dbl, dbl, dbl, cint]),
+    "slam_kpset_upload_first": (cint, [vp, vp, cint, f64p, i32p, cint, cint]),
+    "slam_kpset_download_first": (cint, [vp, vp, cint, f64p, i32p, cint, C.POINTER(cint), C.POINTER(cint)]),
     "slam_kpset_upload_keyframe": (cint, [vp, vp, cint, f64p, u8p, cint]),
     "slam_kpset_download_keyframe": (cint, [vp, vp, cint, f64p, u8p, cint, C.POINTER(cint)]),
     "slam_kpset_compute_pose_5pt": (cint, [vp, vp, f64p, dbl, dbl, cint, C.c_uint64, f64p, i32p, i32p, f64p, i32p]),

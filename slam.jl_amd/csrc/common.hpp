@@ -84,6 +84,9 @@ struct slam_kpset {
     double *xyz = nullptr;       // [S cap][3] map point, valid where is3d != 0
     double *kyx = nullptr;       // [S cap][2] pixel (y, x) in the previous key-frame, valid where haskf != 0 (slam_kpset_keyframe)
     uint8_t *haskf = nullptr;    // [S cap] the keypoint is observed by the previous key-frame
+    double *fyx = nullptr;       // [S cap][2] pixel (y, x) in the FIRST key-frame that observed the keypoint (the one that detected it)
+    int *fkf = nullptr;          // [S cap] that key-frame's id (per-stream counter), valid where haskf != 0
+    int *kfcount = nullptr;      // [S] number of key-frames created so far = id of the next one
     int64_t *id = nullptr;       // [S cap] keypoint id (per stream, ascending in creation order)
     uint8_t *is3d = nullptr, *stereo = nullptr, *st = nullptr;   // flags; st: status of the last match (0 lost, 1 tracked, 2 skipped)
     int *count = nullptr;        // [S]

@@ -39,7 +39,7 @@ int kpset_build_worklist(slam_ctx *ctx, slam_kpset *ks)
 // Chunks of 256 slots are read (all fields into registers), ranked with a wave ballot + the popcount of the lower lanes,
 // and written back after a barrier: destinations never lie to the right of their sources, so in place is safe.
 struct KpsetView {
-    double *yx, *oyx, *syx, *xyz, *kyx; int64_t *id; uint8_t *is3d, *stereo, *st, *haskf; int *count; int cap;
+    double *yx, *oyx, *syx, *xyz, *kyx, *fyx; int64_t *id; uint8_t *is3d, *stereo, *st, *haskf; int *fkf, *kfcount; int *count; int cap;
 };
 __global__ __launch_bounds__(256) void k_kpset_compact(KpsetView K, int mode, const uint8_t *flags)
 {
@@ -52,13 +52,13 @@ __global__ __launch_bounds__(256) void k_kpset_compact(KpsetView K, int mode, co
     for (int c0 = 0; c0 < n; c0 += 256) {
         const int j = c0 + tid;
         bool keep = false;
-        double y = 0, x = 0, sy = 0, sx = 0, X0 = 0, X1 = 0, X2 = 0, ky = 0, kx = 0; int64_t id = 0; uint8_t f3 = 0, fs = 0, fk = 0;
+        double y = 0, x = 0, sy = 0, sx = 0, X0 = 0, X1 = 0, X2 = 0, ky = 0, kx = 0, fy0 = 0, fx0 = 0; int64_t id = 0; uint8_t f3 = 0, fs = 0, fk = 0; int fkid = 0;
         if (j < n) {
             const size_t q = b + j;
             if (mode == 0) { const uint8_t t = K.st[q]; keep = t != 0; if (t == 1) { y = K.oyx[2 * q]; x = K.oyx[2 * q + 1]; } else { y = K.yx[2 * q]; x = K.yx[2 * q + 1]; } }
             else { keep = flags[q] == 0; y = K.yx[2 * q]; x = K.yx[2 * q + 1]; }
             if (keep) { sy = K.syx[2 * q]; sx = K.syx[2 * q + 1]; X0 = K.xyz[3 * q]; X1 = K.xyz[3 * q + 1]; X2 = K.xyz[3 * q + 2]; id = K.id[q]; f3 = K.is3d[q]; fs = K.stereo[q];
-                        ky = K.kyx[2 * q]; kx = K.kyx[2 * q + 1]; fk = K.haskf[q]; }
+                        ky = K.kyx[2 * q]; kx = K.kyx[2 * q + 1]; fk = K.haskf[q]; fy0 = K.fyx[2 * q]; fx0 = K.fyx[2 * q + 1]; fkid = K.fkf[q]; }
         }
         const unsigned long long m = __ballot(keep);
         const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_kpset_compact(KpsetView K, int mode, co
             const size_t q = b + s_base + wbase + rank;
             K.yx[2 * q] = y; K.yx[2 * q + 1] = x; K.syx[2 * q] = sy; K.syx[2 * q + 1] = sx;
             K.xyz[3 * q] = X0; K.xyz[3 * q + 1] = X1; K.xyz[3 * q + 2] = X2; K.id[q] = id; K.is3d[q] = f3; K.stereo[q] = fs;
-            K.kyx[2 * q] = ky; K.kyx[2 * q + 1] = kx; K.haskf[q] = fk;
+            K.kyx[2 * q] = ky; K.kyx[2 * q + 1] = kx; K.haskf[q] = fk; K.fyx[2 * q] = fy0; K.fyx[2 * q + 1] = fx0; K.fkf[q] = fkid;
         }
         __syncthreads();
         if (tid == 0) s_base += total;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_kpset_compact(KpsetView K, int mode, co
 static KpsetView view_of(slam_kpset *ks)
 {
     KpsetView K; K.yx = ks->yx; K.oyx = ks->oyx; K.syx = ks->syx; K.xyz = ks->xyz; K.kyx = ks->kyx; K.id = ks->id; K.is3d = ks->is3d; K.stereo = ks->stereo;
-    K.haskf = ks->haskf;
+    K.haskf = ks->haskf; K.fyx = ks->fyx; K.fkf = ks->fkf; K.kfcount = ks->kfcount;
     K.st = ks->st; K.count = ks->count; K.cap = ks->cap;
     return K;
 }
@@ -164,6 +164,91 @@ __global__ __launch_bounds__(64) void k_kpset_triangulate(KpsetView K, KTriArgs 
     } else K.stereo[q] = 0;
 }
 
+// Array-level body of triangulate_temporal! (src/mapper.jl:185-262) on the set: every 2-D keypoint whose first observer (the
+// key-frame that detected it, observers[1] of its map point) is an earlier key-frame is triangulated from that observation and the
+// current one.  The caller supplies, per stream and observer key-frame (slot kf % nkf of `tab`, 64 doubles), what mapper.jl:226-231
+// computes once per observer: P2 = K * rel_pose_inv, rel_pose_inv, rel_pose = observer.cw * frame.wc, and observer.wc -- all
+// column-major 4 x 4 -- so their arithmetic stays the host's (Manifolds' inv(SE3, .)).  Gates as slam_triangulate's temporal mode:
+// a failed gate removes the observation only when the rotation-compensated parallax exceeds min_parallax (20 px), otherwise the
+// point is accepted as it is (:244-258).
+struct KTempArgs {
+    const double *par;        // S x 32: [16..19] fx fy cx cy, [20..23] k1 k2 p1 p2
+    const double *tab;        // S x nkf x 64
+    const int *kf_cur, *kf_lo; int nkf;
+    double max_error, min_depth, min_parallax;
+    uint8_t *flags;
+};
+__device__ __forceinline__ void kp_undistort(const double *par, double y, double x, double &uy, double &ux)
+{
+    const double fx = par[16], fy = par[17], cx = par[18], cy = par[19], k1 = par[20], k2 = par[21], p1 = par[22], p2 = par[23];
+    const double ny = (y - cy) / fy, nx = (x - cx) / fx;
+    const double s0 = ny * ny, s1 = nx * nx, r2 = s0 + s1;
+    const double rd = (1.0 + k1 * r2) + k2 * (r2 * r2);
+    const double pp = ny * nx;
+    const double dtx = 2 * p1 * pp + p2 * (r2 + 2 * s0), dty = p1 * (r2 + 2 * s1) + 2 * p2 * pp;
+    uy = (rd * ny + dty) * fy + cy; ux = (rd * nx + dtx) * fx + cx;
+}
+__global__ __launch_bounds__(64) void k_kpset_tri_temporal(KpsetView K, KTempArgs T, const int *work, const int *ntot)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= ntot[0]) return;
+    const size_t q = (size_t)work[i];
+    if (K.is3d[q] || !K.haskf[q]) return;                        // get_2d_keypoints; keypoints no key-frame has observed yet
+    const int s = (int)(q / K.cap), kf = K.fkf[q];
+    if (kf == T.kf_cur[s] || kf < T.kf_lo[s]) return;            // :216 the frame itself is the first observer; observer no longer in the table
+    const double *par = T.par + 32 * (size_t)s;
+    const double *E = T.tab + ((size_t)s * T.nkf + (kf % T.nkf)) * 64;
+    const double *P2 = E, *T21 = E + 16, *REL = E + 32, *WOB = E + 48;
+    const double fx = par[16], fy = par[17], cx = par[18], cy = par[19];
+    double y1, x1, y2, x2;
+    kp_undistort(par, K.fyx[2 * q], K.fyx[2 * q + 1], y1, x1);  // obup
+    kp_undistort(par, K.yx[2 * q], K.yx[2 * q + 1], y2, x2);    // kpup
+    // parallax = |obup - project(camera, R(rel_pose) * kp.position)|, :236-237
+    const double bx = (x2 - cx) / fx, by = (y2 - cy) / fy;
+    const double rx = (REL[0] * bx + REL[4] * by) + REL[8] * 1.0, ry = (REL[1] * bx + REL[5] * by) + REL[9] * 1.0, rz = (REL[2] * bx + REL[6] * by) + REL[10] * 1.0;
+    const double qy = fy * ry / rz + cy, qx = fx * rx / rz + cx;
+    const double pdy = y1 - qy, pdx = x1 - qx;
+    const bool gated = sqrt(pdy * pdy + pdx * pdx) > T.min_parallax;
+    // P1 = K * I
+    const double P1[16] = {fx, 0, 0, 0, 0, fy, 0, 0, cx, cy, 1, 0, 0, 0, 0, 1};
+    double A[16], S[16], v[4];
+    for (int j = 0; j < 4; j++) {
+        A[0 + j] = x1 * P1[2 + 4 * j] - P1[0 + 4 * j];
+        A[4 + j] = y1 * P1[2 + 4 * j] - P1[1 + 4 * j];
+        A[8 + j] = x2 * P2[2 + 4 * j] - P2[0 + 4 * j];
+        A[12 + j] = y2 * P2[2 + 4 * j] - P2[1 + 4 * j];
+    }
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; k++) acc += A[4 * k + r] * A[4 * k + c];
+            S[4 * r + c] = acc;
+        }
+    sym4_min_eigvec(S, v);
+    const double iw = 1.0 / v[3];
+    const double L0 = v[0] * iw, L1 = v[1] * iw, L2 = v[2] * iw, L3 = v[3] * iw;
+    bool ok = !(L2 < T.min_depth && gated);
+    double R[3];
+    for (int r = 0; r < 3; r++) R[r] = ((T21[r] * L0 + T21[r + 4] * L1) + T21[r + 8] * L2) + T21[r + 12] * L3;
+    if (ok && R[2] < T.min_depth && gated) ok = false;
+    if (ok) {
+        const double iz = 1.0 / L2;
+        const double py = fy * L1 * iz + cy, px = fx * L0 * iz + cx;
+        const double dy = y1 - py, dx = x1 - px;
+        if (sqrt(dy * dy + dx * dx) > T.max_error && gated) ok = false;
+    }
+    if (ok) {
+        const double iz = 1.0 / R[2];
+        const double py = fy * R[1] * iz + cy, px = fx * R[0] * iz + cx;
+        const double dy = y2 - py, dx = x2 - px;
+        if (sqrt(dy * dy + dx * dx) > T.max_error && gated) ok = false;
+    }
+    if (ok) {
+        for (int r = 0; r < 3; r++) K.xyz[3 * q + r] = ((WOB[r] * L0 + WOB[r + 4] * L1) + WOB[r + 8] * L2) + WOB[r + 12] * L3;   // project_camera_to_world(observer_kf, .)
+        K.is3d[q] = 1;
+    } else T.flags[q] = 1;                                        // remove_mappoint_obs!(map_manager, id, frame.kfid)
+}
+
 extern "C" {
 
 int slam_kpset_destroy(slam_kpset *ks);
@@ -177,7 +262,7 @@ int slam_kpset_create(slam_ctx *ctx, int S, int cap, slam_kpset **out)
     auto take = [&](size_t b) { size_t o = off; off += al256(b); return o; };
     const size_t o_yx = take(n * 16), o_oyx = take(n * 16), o_syx = take(n * 16), o_xyz = take(n * 24), o_id = take(n * 8);
     const size_t o_3d = take(n), o_st = take(n), o_ss = take(n), o_cnt = take((size_t)S * 4), o_work = take(n * 4), o_nt = take(64);
-    const size_t o_nid = take((size_t)S * 8), o_par = take((size_t)8 * S * 32 * 8), o_kyx = take(n * 16), o_hk = take(n);
+    const size_t o_nid = take((size_t)S * 8), o_par = take((size_t)8 * S * 32 * 8), o_kyx = take(n * 16), o_hk = take(n), o_fyx = take(n * 16), o_fkf = take(n * 4), o_kfc = take((size_t)S * 4);
     slam_kpset *ks = new slam_kpset();
     ks->device = ctx->device; ks->S = S; ks->cap = cap;
     hipError_t e = hipMalloc((void **)&ks->base, off);
@@ -189,6 +274,7 @@ int slam_kpset_create(slam_ctx *ctx, int S, int cap, slam_kpset **out)
     ks->id = (int64_t *)(B + o_id); ks->is3d = (uint8_t *)(B + o_3d); ks->stereo = (uint8_t *)(B + o_st); ks->st = (uint8_t *)(B + o_ss);
     ks->count = (int *)(B + o_cnt); ks->work = (int *)(B + o_work); ks->ntot = (int *)(B + o_nt); ks->next_id = (int64_t *)(B + o_nid);
     ks->par = (double *)(B + o_par); ks->kyx = (double *)(B + o_kyx); ks->haskf = (uint8_t *)(B + o_hk);
+    ks->fyx = (double *)(B + o_fyx); ks->fkf = (int *)(B + o_fkf); ks->kfcount = (int *)(B + o_kfc);
     e = hipHostMalloc((void **)&ks->par_host, (size_t)8 * S * 32 * 8);
     for (int i = 0; i < 8 && e == hipSuccess; i++) { e = hipEventCreateWithFlags(&ks->par_ev[i], hipEventDisableTiming); if (e == hipSuccess) e = hipEventRecord(ks->par_ev[i], ctx->stream); }
     if (e != hipSuccess) { slam_kpset_destroy(ks); return slam_fail(ctx, SLAM_ERR_HIP, "slam_kpset_create: %s", hipGetErrorString(e)); }
@@ -267,17 +353,52 @@ __global__ __launch_bounds__(256) void k_kpset_keyframe(KpsetView K)
     const int s = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     if (j >= K.count[s]) return;
     const size_t q = (size_t)s * K.cap + j;
-    K.kyx[2 * q] = K.yx[2 * q]; K.kyx[2 * q + 1] = K.yx[2 * q + 1]; K.haskf[q] = 1;
+    const double y = K.yx[2 * q], x = K.yx[2 * q + 1];
+    if (!K.haskf[q]) { K.fyx[2 * q] = y; K.fyx[2 * q + 1] = x; K.fkf[q] = K.kfcount[s]; }     // detected by this key-frame: its first observer
+    K.kyx[2 * q] = y; K.kyx[2 * q + 1] = x; K.haskf[q] = 1;
 }
+__global__ void k_kpset_kf_advance(int *kfcount, int S) { if ((int)threadIdx.x < S) kfcount[threadIdx.x] += 1; }
 int slam_kpset_keyframe(slam_ctx *ctx, slam_kpset *ks)
 {
     ARG_TRY(ctx, ctx != nullptr && ks != nullptr);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_kpset_keyframe, dim3((ks->cap + 255) / 256, ks->S), dim3(256), 0, ctx->stream, view_of(ks));
+    hipLaunchKernelGGL(k_kpset_kf_advance, dim3(1), dim3(64), 0, ctx->stream, ks->kfcount, ks->S);
     HIP_TRY(ctx, hipGetLastError());
     return SLAM_OK;
 }
 // the key-frame observations of stream s's list, host <-> device (restoring state, tests): kyx n x 2 (y, x), has_kf n flags
+int slam_kpset_upload_first(slam_ctx *ctx, slam_kpset *ks, int s, const double *first_yx, const int32_t *first_kf, int n, int kf_count)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && s >= 0 && s < ks->S && n >= 0 && n <= ks->cap && (n == 0 || (first_yx != nullptr && first_kf != nullptr)));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t b = (size_t)s * ks->cap;
+    if (n > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(ks->fyx + 2 * b, first_yx, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ks->fkf + b, first_kf, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ks->kfcount + s, &kf_count, 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    return SLAM_OK;
+}
+int slam_kpset_download_first(slam_ctx *ctx, slam_kpset *ks, int s, double *first_yx, int32_t *first_kf, int cap_out, int *n_out, int *kf_count)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && s >= 0 && s < ks->S && n_out != nullptr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int n = 0, kc = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n, ks->count + s, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&kc, ks->kfcount + s, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    *n_out = n; if (kf_count) *kf_count = kc;
+    if (n > cap_out) return slam_fail(ctx, SLAM_ERR_CAPACITY, "slam_kpset_download_first: %d keypoints but cap = %d", n, cap_out);
+    const size_t b = (size_t)s * ks->cap;
+    if (n > 0) {
+        if (first_yx) HIP_TRY(ctx, hipMemcpyAsync(first_yx, ks->fyx + 2 * b, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (first_kf) HIP_TRY(ctx, hipMemcpyAsync(first_kf, ks->fkf + b, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    }
+    return SLAM_OK;
+}
 int slam_kpset_upload_keyframe(slam_ctx *ctx, slam_kpset *ks, int s, const double *kyx, const uint8_t *has_kf, int n)
 {
     ARG_TRY(ctx, ctx != nullptr && ks != nullptr && s >= 0 && s < ks->S && n >= 0 && n <= ks->cap && (n == 0 || (kyx != nullptr && has_kf != nullptr)));
@@ -347,6 +468,42 @@ int slam_kpset_triangulate(slam_ctx *ctx, slam_kpset *ks, const double *P1, cons
     const int nb = n_bound > 0 && n_bound < ks->S * ks->cap ? n_bound : ks->S * ks->cap;
     hipLaunchKernelGGL(k_kpset_triangulate, dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, view_of(ks), T, (const int *)ks->work, (const int *)ks->ntot);
     HIP_TRY(ctx, hipGetLastError());
+    return SLAM_OK;
+}
+
+int slam_kpset_triangulate_temporal(slam_ctx *ctx, slam_kpset *ks, const double *params, const double *tab, int nkf,
+                                    const int32_t *kf_cur, const int32_t *kf_lo, double max_error, double min_depth, double min_parallax,
+                                    int n_bound)
+{
+    ARG_TRY(ctx, ctx != nullptr && ks != nullptr && params && tab && kf_cur && kf_lo && nkf >= 1);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int S = ks->S;
+    const size_t nc = (size_t)S * ks->cap, tb = al256((size_t)S * nkf * 64 * 8), ib = al256((size_t)S * 4);
+    char *scr;
+    int rc = slam_scratch2(ctx, tb + 2 * ib + al256(nc), (void **)&scr);
+    if (rc) return rc;
+    void *hv;
+    rc = slam_pinned(ctx, tb + 2 * ib, &hv);
+    if (rc) return rc;
+    char *h = (char *)hv;
+    memcpy(h, tab, (size_t)S * nkf * 64 * 8); memcpy(h + tb, kf_cur, (size_t)S * 4); memcpy(h + tb + ib, kf_lo, (size_t)S * 4);
+    HIP_TRY(ctx, hipMemcpyAsync(scr, h, tb + 2 * ib, hipMemcpyHostToDevice, ctx->stream));
+    KTempArgs T;
+    rc = kpset_stage_params(ctx, ks, params, (size_t)S * 32, &T.par);
+    if (rc) return rc;
+    T.tab = (const double *)scr; T.kf_cur = (const int *)(scr + tb); T.kf_lo = (const int *)(scr + tb + ib); T.nkf = nkf;
+    T.max_error = max_error; T.min_depth = min_depth; T.min_parallax = min_parallax;
+    T.flags = (uint8_t *)(scr + tb + 2 * ib);
+    HIP_TRY(ctx, hipMemsetAsync(T.flags, 0, nc, ctx->stream));
+    rc = kpset_build_worklist(ctx, ks);
+    if (rc) return rc;
+    const int nb = n_bound > 0 && n_bound < S * ks->cap ? n_bound : S * ks->cap;
+    hipLaunchKernelGGL(k_kpset_tri_temporal, dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, view_of(ks), T, (const int *)ks->work, (const int *)ks->ntot);
+    HIP_TRY(ctx, hipGetLastError());
+    rc = kpset_compact(ctx, ks, 1, T.flags);
+    if (rc) return rc;
+    // the pinned table is read by the copy above: it must be gone from the host block before the next call reuses it
+    HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
 }
 

@@ -133,6 +133,44 @@ class KeypointSet:
         c.check(c.lib.slam_kpset_download_keyframe(c.h, self.h, s, L.ptr(k), L.ptr(f, L.u8p), self.cap, C.byref(n)))
         return k[:n.value].copy(), f[:n.value].astype(bool)
 
+    def upload_first(self, s, first_yx, first_kf, kf_count, ctx=None):
+        c = ctx or self.ctx
+        f = np.ascontiguousarray(first_yx, dtype=np.float64).reshape(-1, 2)
+        k = np.ascontiguousarray(first_kf, dtype=np.int32)
+        c.check(c.lib.slam_kpset_upload_first(c.h, self.h, s, L.ptr(f), L.ptr(k, L.i32p), len(f), int(kf_count)))
+
+    def download_first(self, s, ctx=None):
+        """(first_yx, first_kf, key-frame counter) of stream s: where and by which key-frame each keypoint was first observed"""
+        c = ctx or self.ctx
+        f = np.zeros((self.cap, 2)); k = np.zeros(self.cap, dtype=np.int32); n = C.c_int(0); kc = C.c_int(0)
+        c.check(c.lib.slam_kpset_download_first(c.h, self.h, s, L.ptr(f), L.ptr(k, L.i32p), self.cap, C.byref(n), C.byref(kc)))
+        return f[:n.value].copy(), k[:n.value].copy(), kc.value
+
+    def triangulate_temporal(self, sp, kf_cw, Twc, kf_cur, kf_lo=None, max_error=3.0, min_depth=0.1, min_parallax=20.0, n_bound=0, ctx=None):
+        """triangulate_temporal! (mapper.jl:185-262) on the lists (slam_kpset_triangulate_temporal).  kf_cw: (S, nkf, 4, 4) world ->
+        camera poses of the key-frames, key-frame id k of stream s at [s, k % nkf]; Twc: (S, 4, 4) camera -> world of the frame;
+        kf_cur: (S,) the frame's key-frame id; kf_lo: (S,) oldest id still in the table (default kf_cur - nkf + 1).  The per-observer
+        matrices of mapper.jl:226-231 are formed here (numpy), as the Julia caller would form them."""
+        c = ctx or self.ctx
+        sp = np.ascontiguousarray(sp, dtype=np.float64).reshape(self.S, 32)
+        kf_cw = np.asarray(kf_cw, dtype=np.float64).reshape(self.S, -1, 4, 4)
+        nkf = kf_cw.shape[1]
+        Twc = np.broadcast_to(np.asarray(Twc, dtype=np.float64).reshape(-1, 4, 4), (self.S, 4, 4))
+        kf_cur = np.ascontiguousarray(np.broadcast_to(np.asarray(kf_cur, dtype=np.int32), (self.S,)))
+        kf_lo = np.ascontiguousarray(np.maximum(kf_cur - nkf + 1, 0) if kf_lo is None else np.broadcast_to(np.asarray(kf_lo, dtype=np.int32), (self.S,)), dtype=np.int32)
+        tab = np.zeros((self.S, nkf, 4, 16))
+        for s in range(self.S):
+            fx, fy, cx, cy = sp[s, 16:20]
+            K4 = np.array([[fx, 0, cx, 0], [0, fy, cy, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+            for k in range(nkf):
+                rel = kf_cw[s, k] @ Twc[s]                                # observer_kf.cw * frame.wc
+                rel_inv = np.linalg.inv(rel)
+                for j, M in enumerate((K4 @ rel_inv, rel_inv, rel, np.linalg.inv(kf_cw[s, k]))):
+                    tab[s, k, j] = M.T.reshape(16)                        # column-major
+        tab = np.ascontiguousarray(tab.reshape(self.S, nkf, 64))
+        c.check(c.lib.slam_kpset_triangulate_temporal(c.h, self.h, L.ptr(sp), L.ptr(tab), int(nkf), L.ptr(kf_cur, L.i32p), L.ptr(kf_lo, L.i32p),
+                                                      float(max_error), float(min_depth), float(min_parallax), int(n_bound)))
+
     def compute_pose_5pt(self, sp, min_parallax=5.0, max_repr_error=3.0, iters=128, seed=0, ctx=None, fetch=True):
         """compute_pose_5pt! (front_end.jl:242-332) for every stream on the device-resident lists (slam_kpset_compute_pose_5pt):
         returns (Rt (S, 3, 4) key-frame -> frame with |t| = 1, status (S,), inlier counts (S,), average parallax (S,), list lengths

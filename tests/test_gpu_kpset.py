@@ -342,3 +342,85 @@ def test_compute_pose_5pt_enqueue_only_filters_the_same_way(slam, syn):
         ks.close()
     for s in range(S):
         assert np.array_equal(res[0][s], res[1][s]) and 150 < len(res[0][s]) < 250
+
+
+def test_temporal_triangulation_on_the_set_equals_the_host_seam(slam, syn):
+    """slam_kpset_triangulate_temporal (mapper.jl:185-262 on the device-resident lists: first observation + its key-frame id beside
+    every keypoint) against slam_triangulate's temporal mode fed with numpy-gathered arrays, per observer key-frame: map points,
+    is_3d flags and removals."""
+    S, cap, nkf = 2, 500, 4
+    cam = syn.KITTI_CAM
+    dist = (0.0, 0.0, 0.0, 0.0)
+    fx, fy, cx, cy = cam
+    rng = np.random.default_rng(8)
+    ks = slam.KeypointSet(S, cap)
+    # key-frame poses (world -> camera): a camera moving sideways and forward, a little yaw
+    def pose(k, s):
+        th = 0.01 * k
+        R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = [-0.6 * k - 0.1 * s, 0.02 * k, -0.3 * k]
+        return T
+    kf_cw = np.stack([np.stack([pose(k, s) for k in range(nkf)]) for s in range(S)])
+    kf_cur = np.array([3, 3], np.int32)
+    Tcw_cur = np.stack([pose(3.4, s) for s in range(S)])             # the frame: a little past key-frame 3 (it IS key-frame 3 being created)
+    Twc_cur = np.stack([np.linalg.inv(T) for T in Tcw_cur])
+    proj = lambda T, X: (lambda Xc: np.stack([fy * Xc[:, 1] / Xc[:, 2] + cy, fx * Xc[:, 0] / Xc[:, 2] + cx], 1))((X @ T[:3, :3].T) + T[:3, 3])
+    host = []
+    for s in range(S):
+        n = 300
+        X = np.stack([rng.uniform(-15, 15, n), rng.uniform(-4, 4, n), rng.uniform(6, 60, n)], 1)
+        fk = rng.integers(0, 4, n).astype(np.int32)                  # first observer 0..3 (3 = the frame itself: skipped)
+        yx = proj(Tcw_cur[s], X) + rng.normal(0, 0.2, (n, 2))
+        fyx = np.stack([proj(kf_cw[s, k], X[i:i + 1])[0] for i, k in enumerate(fk)]) + rng.normal(0, 0.2, (n, 2))
+        bad = rng.random(n) < 0.15
+        fyx[bad] += rng.uniform(25, 60, (int(bad.sum()), 2)) * rng.choice([-1, 1], (int(bad.sum()), 2))     # gross mismatches: gates + parallax
+        is3 = rng.random(n) < 0.3
+        haskf = rng.random(n) < 0.95
+        ks.upload(s, yx, is3, np.where(is3[:, None], X, 0.0))
+        ks.upload_keyframe(s, fyx, haskf)                             # (kyx is not used here; has_kf marks observed keypoints)
+        ks.upload_first(s, fyx, fk, kf_count=4)
+        host.append((yx, fyx, fk, is3, haskf))
+    sp = slam.stream_params(S, cam=cam, dist=dist)
+    before = [ks.download(s) for s in range(S)]
+    ks.triangulate_temporal(sp, kf_cw, Twc_cur, kf_cur, kf_lo=np.array([1, 0], np.int32), max_error=3.0)
+    after = [ks.download(s) for s in range(S)]
+    cnt = ks.counts()
+    n_new = 0
+    for s in range(S):
+        yx, fyx, fk, is3, haskf = host[s]
+        keep = np.ones(len(yx), bool); new3 = is3.copy(); xyz = before[s]["xyz"].copy()
+        lo = [1, 0][s]
+        for k in range(nkf):
+            m = ~is3 & haskf & (fk == k) & (fk != kf_cur[s]) & (fk >= lo)
+            if not m.any():
+                continue
+            rel = kf_cw[s, k] @ Twc_cur[s]; rel_inv = np.linalg.inv(rel)
+            _, p2, _ = slam.pose_inputs(cam, dist, yx[m], np.zeros((int(m.sum()), 3)))          # undistorted (x, y)
+            _, p1, _ = slam.pose_inputs(cam, dist, fyx[m], np.zeros((int(m.sum()), 3)))
+            b = np.stack([(p2[:, 0] - cx) / fx, (p2[:, 1] - cy) / fy, np.ones(len(p2))], 1) @ rel[:3, :3].T
+            par = np.linalg.norm(p1[:, ::-1] - np.stack([fy * b[:, 1] / b[:, 2] + cy, fx * b[:, 0] / b[:, 2] + cx], 1), axis=1)
+            Xc, ok = slam.triangulate(cam, cam, rel_inv, p1[:, ::-1], p2[:, ::-1], 3.0, parallax=par, min_parallax=20.0)
+            idx = np.flatnonzero(m)
+            keep[idx[~ok]] = False
+            new3[idx[ok]] = True
+            Wob = np.linalg.inv(kf_cw[s, k])
+            xyz[idx[ok]] = Xc[ok] @ Wob[:3, :3].T + Wob[:3, 3]
+            n_new += int(ok.sum())
+        assert cnt[s] == keep.sum() == len(after[s]["yx"]), (s, cnt[s], keep.sum())
+        assert np.array_equal(after[s]["ids"], before[s]["ids"][keep]), s
+        assert np.array_equal(after[s]["is_3d"].astype(bool), new3[keep]), s
+        got = after[s]["xyz"][new3[keep]]; want = xyz[keep][new3[keep]]
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-9), (s, np.abs(got - want).max())
+    assert n_new > 150                                                 # the call did triangulate, and removed some
+    assert sum(len(b["yx"]) for b in before) - int(cnt.sum()) > 10
+    # slam_kpset_keyframe: fresh keypoints get their first observation and the running key-frame id; old ones keep theirs
+    f0, k0, c0 = ks.download_first(0)
+    ks.keyframe()
+    f1, k1, c1 = ks.download_first(0)
+    assert c1 == c0 + 1 == 5
+    hk = ks.download_keyframe(0)[1]
+    assert hk.all()
+    was = after[0]
+    old = np.isin(was["ids"], before[0]["ids"][host[0][4]])           # had a key-frame observation before the call
+    assert np.array_equal(k1[old], k0[old]) and np.array_equal(f1[old], f0[old])
+    assert (k1[~old] == 4).all() and np.array_equal(f1[~old], was["yx"][~old])
