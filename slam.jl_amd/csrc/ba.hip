@@ -56,6 +56,11 @@ struct BADev {
     double *Vinv, *bl;           // SoA 6 x M, 3 x M
     double *T, *Wm;              // AoS O x 18 each
     const int2 *pairs; const int *blk_start; const int2 *blk_pq; int nblk;
+    // pt_start / pt_id: observations are sorted by map point, the map points by (first free observing pose, id); opk = the
+    // sorted position of an observation's point.  grp / fgrp / wpart: the point groups of k_schur_groups (below).
+    const int *pt_id, *opk;
+    const int4 *grp; const int *fgrp; int ngrp, whb, wstride;
+    double *wpart;
     double *S, *g, *udiag;       // reduce buffer views
     double *Swork, *dp, *dl;
     double *part;                // reduction partials
@@ -71,6 +76,8 @@ struct slam_ba {
     double *linv = nullptr;      // inverses of the factored diagonal tiles, nbc x 32 x 32
     double *lfac = nullptr;      // finished factor tiles + forward-substituted rhs row, (n+1) x n
     int hb = 0;                  // block half-bandwidth of the reduced system: S_pq = 0 for |p - q| > hb
+    bool grouped = false;        // the reduced system is built by k_schur_groups / k_schur_reduce (else: pair lists, k_blocks)
+    int nparts = 0;              // partial sums k_control folds after a linearisation inside a build
     double *band = nullptr;      // factor store of k_band_solve, P x ((hb + 1) x 36 + 8)
     std::vector<int> perm;       // sorted position -> original observation index
     int nblocks_obs = 0, nblocks_pts = 0;
@@ -211,11 +218,12 @@ __device__ __forceinline__ void inv3_sym(const double V[6], double I[6])
 __global__ __launch_bounds__(256) void k_points(BADev d, double inv_delta_host, int use_state)
 {
     if (use_state && d.st->converged) return;
-    const int j = blockIdx.x * 256 + threadIdx.x, M = d.M;
-    if (j >= M) return;
+    const int k = blockIdx.x * 256 + threadIdx.x, M = d.M;
+    if (k >= M) return;
+    const int j = d.pt_id[k];
     const double inv_delta = use_state ? 1.0 / d.st->delta : inv_delta_host;
     double V[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-    const int t0 = d.pt_start[j], t1 = d.pt_start[j + 1];
+    const int t0 = d.pt_start[k], t1 = d.pt_start[k + 1];
     for (int i = t0; i < t1; i++) {
         double jl[6], ff[2];
         ld_rec<6>(d.Jl + (size_t)i * 6, jl); ld_rec<2>(d.f + 2 * (size_t)i, ff);
@@ -339,6 +347,272 @@ __global__ __launch_bounds__(256) void k_blocks(BADev d, int use_state)
         d.g[6 * pq.x + a] = ((s_red[0][36 + a] + s_red[1][36 + a]) + s_red[2][36 + a]) + s_red[3][36 + a];
         d.udiag[6 * pq.x + a] = ((s_red[0][42 + a] + s_red[1][42 + a]) + s_red[2][42 + a]) + s_red[3][42 + a];
     }
+}
+
+// ---- the reduced camera system of a windowed problem, built point group by point group ---------------------------------
+// A map point seen by free poses f .. f + hb only touches the (hb + 1) x (hb + 1) window of 6 x 6 blocks that starts at its first
+// free observer f.  The map points are sorted by f; one 512-thread workgroup takes a group of <= SG_SB points with the same f
+// (<= SG_OB observations, contiguous) and does, without leaving LDS, what k_linearize + k_points + k_obs_factors + k_blocks do
+// through HBM (T / W records: 29 MB written, 160 MB gathered per iteration at O = 1e5):
+//   phase 0  thread = observation: residual + Jacobians (stored for k_backsub / k_trial), Jl'Jl and Jl'f into LDS
+//   phase 1  thread = point: V = sum Jl'Jl + D, V^-1, bl (fixed order)
+//   phase 2  thread = observation: W = Jp'Jl, Jp, Jp'f - W V^-1 bl into LDS
+//   phase 3  thread = (window block (a, b), row r): sum over the group's points of -(W_a V^-1) W_b' (+ Jp'Jp on the diagonal);
+//            thread = (window slot a, r): gradient and diagonal of U
+// and writes the window as a partial (wstride doubles per group).  k_schur_reduce adds the partials of every band block in a
+// fixed order (f ascending, groups ascending): deterministic, no atomics.  Inactive observations (ignored outliers, constant
+// poses) have no window slot and contribute nothing, as in the pair lists.
+#define SG_T 512
+#define SG_OB 448
+#define SG_SB 56
+static size_t sg_lds_bytes(int whb)
+{
+    const int hbw = whb + 1, nwin = hbw * (hbw + 1) / 2;
+    return (((size_t)SG_OB * 36 + (size_t)SG_SB * 10 + 8) * 8 + (size_t)SG_SB * hbw * 2 + (size_t)nwin * 2 + 15) & ~(size_t)15;
+}
+
+// sum over NS adjacent lanes (NS a power of two, uniform): DPP moves up to 16 lanes -- a ds_bpermute butterfly of the 36 block
+// entries costs more LDS issue slots than the block products themselves
+template <int CTRL> __device__ __forceinline__ double sg_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sg_fold(double v, int NS)
+{
+    if (NS >= 2) v = v + sg_dpp<0xB1>(v);       // quad_perm [1,0,3,2]
+    if (NS >= 4) v = v + sg_dpp<0x4E>(v);       // quad_perm [2,3,0,1]
+    if (NS >= 8) v = v + sg_dpp<0x141>(v);      // row_half_mirror (quads are uniform by now)
+    if (NS >= 16) v = v + sg_dpp<0x140>(v);     // row_mirror (octets are uniform)
+    if (NS >= 32) v = v + __shfl_xor(v, 16);
+    if (NS >= 64) v = v + __shfl_xor(v, 32);
+    return v;
+}
+
+#ifdef SG_TRACE
+#define SG_CLK_DECL long long sg_clk[8]; const long long sg_t0 = clock64()
+#define SG_CLK(k) sg_clk[k] = clock64() - sg_t0
+#define SG_DUMP() do { if (threadIdx.x == 0 && blockIdx.x == 100 && d.st->iters == 3) printf("schur group: npts %d nobs %d | init %lld ph0 %lld bar %lld ph1 %lld ph2 %lld ph3 %lld tail %lld cycles\n", npts, nobs, sg_clk[0], sg_clk[1] - sg_clk[0], sg_clk[2] - sg_clk[1], sg_clk[3] - sg_clk[2], sg_clk[4] - sg_clk[3], sg_clk[5] - sg_clk[4], sg_clk[6] - sg_clk[5]); } while (0)
+#else
+#define SG_CLK_DECL
+#define SG_CLK(k)
+#define SG_DUMP()
+#endif
+__global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta_host, int ignore_outliers, int use_state)
+{
+    extern __shared__ __attribute__((aligned(16))) double sg_lds[];
+    SG_CLK_DECL;
+    if (use_state && d.st->converged) return;
+    const int tid = threadIdx.x, M = d.M, O = d.O;
+    const int4 G = d.grp[blockIdx.x];                       // first point, first observation, f | points << 16, observations
+    const int k0 = G.x, o0 = G.y, f = G.z & 0xffff, npts = G.z >> 16, nobs = G.w;
+    const int hbw = d.whb + 1, nwin = hbw * (hbw + 1) / 2;
+    double *s_W = sg_lds;                          // [SG_OB][18]   (phases 0-1: [t][9] = Jl'Jl (6), Jl'f (3))
+    double *s_Jp = s_W + SG_OB * 18;               // [SG_OB][12]
+    double *s_g = s_Jp + SG_OB * 12;               // [SG_OB][6]
+    double *s_pt = s_g + SG_OB * 6;                // [SG_SB][10]   V^-1 (6), bl (3), pad
+    double *s_red = s_pt + SG_SB * 10;             // [8]
+    short *s_slot = (short *)(s_red + 8);          // [SG_SB][hbw]  observation (index in the group) of point x in window slot y, or -1
+    unsigned char *s_ab = (unsigned char *)(s_slot + SG_SB * hbw);   // [nwin][2]
+    for (int x = tid; x < npts * hbw; x += SG_T) s_slot[x] = -1;
+    for (int w = tid; w < nwin; w += SG_T) {
+        int a = 0, r = w;
+        while (r >= hbw - a) { r -= hbw - a; a++; }
+        s_ab[2 * w] = (unsigned char)a; s_ab[2 * w + 1] = (unsigned char)(a + r);
+    }
+    __syncthreads();
+    SG_CLK(0);
+    // ---- phase 0
+    double r2[2] = {0.0, 0.0}, Jp[12], Jl[6];
+#pragma unroll
+    for (int k = 0; k < 12; k++) Jp[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) Jl[k] = 0.0;
+    int pl = 0;
+    if (tid < nobs) {
+        const int i = o0 + tid;
+        const int p = d.opose[i], j = d.opoint[i];
+        pl = d.opk[i] - k0;
+        const bool active = !(ignore_outliers && d.outl[i]);
+        const bool hp = active && !d.pconst[p];
+        if (active) {
+            const double X[3] = {d.pts[3 * j], d.pts[3 * j + 1], d.pts[3 * j + 2]};
+            double pose[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) pose[k] = d.pose[6 * p + k];
+            obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r2, Jp, Jl, nullptr);
+            if (!hp) {
+#pragma unroll
+                for (int k = 0; k < 12; k++) Jp[k] = 0.0;
+            }
+        }
+        d.hasp[i] = hp ? 1 : 0;
+        st_rec<2>(d.f + 2 * (size_t)i, r2);
+        st_rec<12>(d.Jp + (size_t)i * 12, Jp);
+        st_rec<6>(d.Jl + (size_t)i * 6, Jl);
+        if (hp) s_slot[pl * hbw + (p - f)] = (short)tid;
+        double *v = s_W + tid * 18;
+        v[0] = Jl[0] * Jl[0] + Jl[3] * Jl[3]; v[1] = Jl[0] * Jl[1] + Jl[3] * Jl[4]; v[2] = Jl[0] * Jl[2] + Jl[3] * Jl[5];
+        v[3] = Jl[1] * Jl[1] + Jl[4] * Jl[4]; v[4] = Jl[1] * Jl[2] + Jl[4] * Jl[5]; v[5] = Jl[2] * Jl[2] + Jl[5] * Jl[5];
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[6 + k] = Jl[k] * r2[0] + Jl[3 + k] * r2[1];
+    }
+    SG_CLK(1);
+    __syncthreads();
+    SG_CLK(2);
+    // ---- phase 1
+    if (tid < npts) {
+        const int k = k0 + tid, j = d.pt_id[k];
+        const double inv_delta = use_state ? 1.0 / d.st->delta : inv_delta_host;
+        double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const int t0 = d.pt_start[k] - o0, t1 = d.pt_start[k + 1] - o0;
+        for (int t = t0; t < t1; t++) {
+#pragma unroll
+            for (int c = 0; c < 9; c++) V[c] += s_W[t * 18 + c];
+        }
+        V[0] += fmin(fmax(V[0], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+        V[3] += fmin(fmax(V[3], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+        V[5] += fmin(fmax(V[5], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+        double Vi[6];
+        inv3_sym(V, Vi);
+#pragma unroll
+        for (int c = 0; c < 6; c++) { d.Vinv[(size_t)c * M + j] = Vi[c]; s_pt[tid * 10 + c] = Vi[c]; }
+#pragma unroll
+        for (int c = 0; c < 3; c++) { d.bl[(size_t)c * M + j] = V[6 + c]; s_pt[tid * 10 + 6 + c] = V[6 + c]; }
+    }
+    __syncthreads();
+    SG_CLK(3);
+    // ---- phase 2
+    if (tid < nobs) {
+        double Vi[6], bl[3];
+#pragma unroll
+        for (int c = 0; c < 6; c++) Vi[c] = s_pt[pl * 10 + c];
+#pragma unroll
+        for (int c = 0; c < 3; c++) bl[c] = s_pt[pl * 10 + 6 + c];
+        const double vb0 = Vi[0] * bl[0] + Vi[1] * bl[1] + Vi[2] * bl[2];
+        const double vb1 = Vi[1] * bl[0] + Vi[3] * bl[1] + Vi[4] * bl[2];
+        const double vb2 = Vi[2] * bl[0] + Vi[4] * bl[1] + Vi[5] * bl[2];
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            const double w0 = Jp[a] * Jl[0] + Jp[6 + a] * Jl[3];
+            const double w1 = Jp[a] * Jl[1] + Jp[6 + a] * Jl[4];
+            const double w2 = Jp[a] * Jl[2] + Jp[6 + a] * Jl[5];
+            s_W[tid * 18 + 3 * a] = w0; s_W[tid * 18 + 3 * a + 1] = w1; s_W[tid * 18 + 3 * a + 2] = w2;
+            s_g[tid * 6 + a] = (Jp[a] * r2[0] + Jp[6 + a] * r2[1]) - (w0 * vb0 + w1 * vb1 + w2 * vb2);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) s_Jp[tid * 12 + k] = Jp[k];
+    }
+    __syncthreads();
+    SG_CLK(4);
+    double *out = d.wpart + (size_t)blockIdx.x * d.wstride;
+    // ---- phase 3: thread = (window block w, point subset s): NS adjacent lanes share a block and take every NS-th point; the
+    //      whole 6 x 6 block stays in registers (42 LDS doubles per 162 fused multiply-adds), the subsets are folded by a
+    //      butterfly (fixed order).  The diagonal blocks also carry Jp'Jp, the gradient and diag(U) of their slot.
+    {
+        int NS = 1, ls = 0;
+        while (NS < 64 && nwin * NS * 2 <= SG_T) { NS *= 2; ls++; }
+        const int w = tid >> ls, sub = tid & (NS - 1);
+        const bool live = w < nwin;
+        const int a = s_ab[live ? 2 * w : 0], b = s_ab[live ? 2 * w + 1 : 1];
+        double acc[36], gg[6], ud[6];
+#pragma unroll
+        for (int k = 0; k < 36; k++) acc[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) { gg[k] = 0.0; ud[k] = 0.0; }
+        for (int x = sub; x < npts; x += NS) {
+            const int ta = s_slot[x * hbw + a], tb = s_slot[x * hbw + b];
+            if (ta < 0 || tb < 0) continue;
+            double Vi[6], Wa[18], Wb[18], T[18];
+            ld_rec<6>(s_pt + x * 10, Vi); ld_rec<18>(s_W + ta * 18, Wa); ld_rec<18>(s_W + tb * 18, Wb);
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                T[3 * r] = fma(Wa[3 * r + 2], Vi[2], fma(Wa[3 * r + 1], Vi[1], Wa[3 * r] * Vi[0]));
+                T[3 * r + 1] = fma(Wa[3 * r + 2], Vi[4], fma(Wa[3 * r + 1], Vi[3], Wa[3 * r] * Vi[1]));
+                T[3 * r + 2] = fma(Wa[3 * r + 2], Vi[5], fma(Wa[3 * r + 1], Vi[4], Wa[3 * r] * Vi[2]));
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+                    acc[6 * r + c] = fma(-T[3 * r + 2], Wb[3 * c + 2], fma(-T[3 * r + 1], Wb[3 * c + 1], fma(-T[3 * r], Wb[3 * c], acc[6 * r + c])));
+            if (a == b) {
+                double J[12], gv[6];
+                ld_rec<12>(s_Jp + ta * 12, J); ld_rec<6>(s_g + ta * 6, gv);
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) acc[6 * r + c] = fma(J[6 + r], J[6 + c], fma(J[r], J[c], acc[6 * r + c]));
+                    gg[r] += gv[r];
+                    ud[r] = fma(J[6 + r], J[6 + r], fma(J[r], J[r], ud[r]));
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 36; k++) acc[k] = sg_fold(acc[k], NS);
+        if (a == b) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) { gg[k] = sg_fold(gg[k], NS); ud[k] = sg_fold(ud[k], NS); }
+        }
+        if (live && sub == 0) {
+            st_rec<36>(out + w * 36, acc);
+            if (a == b) { st_rec<6>(out + nwin * 36 + a * 12, gg); st_rec<6>(out + nwin * 36 + a * 12 + 6, ud); }
+        }
+    }
+    SG_CLK(5);
+    const double t = block_sum(r2[0] * r2[0] + r2[1] * r2[1], s_red);
+    if (tid == 0) d.part[blockIdx.x] = t;
+    SG_CLK(6);
+    SG_DUMP();
+}
+
+// S, g, diag(U) from the window partials: thread = (band block (p, p + dq), entry) / (pose, gradient or diagonal entry)
+__global__ __launch_bounds__(256) void k_schur_reduce(BADev d, int use_state)
+{
+    if (use_state && d.st->converged) return;
+    const int idx = blockIdx.x * 256 + threadIdx.x, P = d.P, n = d.n;
+    const int hbw = d.whb + 1, nwin = hbw * (hbw + 1) / 2;
+    const int nS = P * hbw * 36;
+    if (idx < nS) {
+        const int bb = idx / 36, e = idx - 36 * bb, p = bb / hbw, q = p + (bb - p * hbw);
+        if (q >= P) return;
+        // the contributing groups are one contiguous run (groups are sorted by f); eight loads in flight, summed in order
+        double sum = 0.0;
+        const int g1 = d.fgrp[p + 1];
+        for (int g0 = d.fgrp[max(0, q - d.whb)]; g0 < g1; g0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int gi = min(g0 + u, g1 - 1);
+                const int f = d.grp[gi].z & 0xffff, a = p - f, b = q - f, w = a * hbw - a * (a - 1) / 2 + (b - a);
+                v[u] = d.wpart[(size_t)gi * d.wstride + w * 36 + e];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) sum += g0 + u < g1 ? v[u] : 0.0;
+        }
+        const int r = e / 6, c = e - 6 * r;
+        d.S[(size_t)(6 * p + r) + (size_t)(6 * q + c) * n] = sum;
+        if (p != q) d.S[(size_t)(6 * q + c) + (size_t)(6 * p + r) * n] = sum;
+        return;
+    }
+    const int v = idx - nS;
+    if (v >= P * 12) return;
+    const int p = v / 12, r = v - 12 * p;
+    double sum = 0.0;
+    const int g1 = d.fgrp[p + 1];
+    for (int g0 = d.fgrp[max(0, p - d.whb)]; g0 < g1; g0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int gi = min(g0 + u, g1 - 1);
+            v[u] = d.wpart[(size_t)gi * d.wstride + nwin * 36 + (p - (d.grp[gi].z & 0xffff)) * 12 + r];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) sum += g0 + u < g1 ? v[u] : 0.0;
+    }
+    if (r < 6) d.g[6 * p + r] = sum; else d.udiag[6 * p + r - 6] = sum;
 }
 
 // ---- damped solve of the reduced camera system ----------------------------------
@@ -636,7 +910,7 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(BADev d, CholArgs C, con
 // Back-substitution L' dp = y then walks the block columns right to left with the stored L_ik and L_kk^-1.
 // Systems whose half-bandwidth exceeds BS_MAXHB blocks (dense windows of > 21 poses) keep the tiled path.
 #define BS_MAXHB 20
-struct BandArgs { const double *S, *g, *ud; double *Lg; int nb, hb; double inv_delta_host; int *fail; long long *trace; };
+struct BandArgs { const double *S, *g, *ud; double *Lg; int nb, hb; double inv_delta_host; int *fail; long long *trace; int lds_bytes; };
 #define BS_PF 6      // prefetch registers per prefetch thread: ceil(((BS_MAXHB + 1) * 36 + 6) / BS_PT)
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains the outstanding global loads / stores (the
@@ -656,15 +930,18 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     extern __shared__ __attribute__((aligned(16))) double bs_sm[];
     __shared__ int s_bad;
     const int hb = B.hb, hb1 = hb + 1, nb = B.nb, n = d.n, tid = threadIdx.x;
-    double *Wn = bs_sm;                                  // [hb1][hb1][36] window ring, blocks row-major 6x6
+    double *x = bs_sm;                                   // [n]: y, then dp
+    double *damp = x + n;                                // [n]: LM damping of the diagonal (k_chol_prepare)
+    double *chat = damp + n;                             // [n]: L_kk^-T y_k (narrow bands)
+    double *LiAll = chat + n;                            // [nb][36]: L_kk^-1 of every block column (the back-substitution reads them again)
+    double *Wn = LiAll + (size_t)nb * 36;                // [hb1][hb1][36] window ring, blocks row-major 6x6
     double *rhs = Wn + (size_t)hb1 * hb1 * 36;           // [hb1][6]
     double *Lp = rhs + hb1 * 6;                          // [hb1][36]: Lp[0] = L_kk^-1, Lp[di] = L_{k+di,k}
     double *yk = Lp + hb1 * 36;                          // [8]
     double *part = yk + 8;                               // [hb1][6] partial sums of the back-substitution
-    double *x = part + hb1 * 6;                          // [n]: y, then dp
-    double *damp = x + n;                                // [n]: LM damping of the diagonal (k_chol_prepare)
-    double *LiS = damp + n;                              // [2][36]: L_kk^-1 of the current / next block column (from the factor wave)
-    double *Dn = LiS + 72;                               // [36]: the next diagonal block, updated
+    double *Dn = part + hb1 * 6;                         // [36]: the next diagonal block, updated
+    double *Gs = Wn;                                     // narrow bands, after the factorisation: the staged G blocks (see the back-substitution)
+    const bool narrow = hb * 6 <= 58;                    // hb <= 9: the back-substitution is a one-wave recurrence
     unsigned char *ptab = (unsigned char *)(Dn + 36);    // [hb (hb+1) / 2][2] pair table (di, dj), dj <= di, ordered by di
     const double inv_delta = use_state ? 1.0 / d.st->delta : B.inv_delta_host;
     const size_t lgs = (size_t)hb1 * 36 + 8;             // doubles per block column in the global factor store
@@ -755,7 +1032,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     // Factor wave.  Every lane holds L_kk^-1 (Li) of the block column being eliminated.  Step k, before the first barrier:
     // lane (r, c) forms rows r and c of L_{k+1,k} = A_{k+1,k} L_kk^-T itself and its entry of D_{k+1} = A_{k+1,k+1} - L L';
     // between the barriers (while the update waves work on the window) it factors D_{k+1} and publishes L_{k+1,k+1}^-1 in the
-    // other LiS slot.  The critical path of a step never leaves this wave's registers.
+    // next LiAll slot.  The critical path of a step never leaves this wave's registers.
     double Li[6][6];
     auto factor = [&](const double *D, double *LiOut) {
         double L[6][6], rd[6];
@@ -794,11 +1071,11 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                 for (int c = 0; c < 6; c++) LiOut[i * 6 + c] = c <= i ? Li[i][c] : 0.0;
         }
     };
-    if (fwave) factor(Wn, LiS);                                  // D_0 = block (0, 0), ring slot [0][0]
+    if (fwave) factor(Wn, LiAll);                                // D_0 = block (0, 0), ring slot [0][0]
     bs_barrier();
     for (int k = 0; k < nb; k++) {
         const int kk = k % hb1, np = nb - 1 - k < hb ? nb - 1 - k : hb;      // blocks below the diagonal in this column
-        const double *LiK = LiS + 36 * (k & 1);                 // L_kk^-1 (the factor wave writes the other slot during this step)
+        const double *LiK = LiAll + 36 * k;                     // L_kk^-1 (the factor wave writes the next column's during this step)
         // ---- P1: the panel rows L_ik = A_ik L_kk^-T and the right-hand side ----
         double *Lgk = B.Lg + (size_t)k * lgs;
         if (tid < np * 6 + 1) {
@@ -916,7 +1193,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
             if (B.trace) trA += clock64() - t0_;
         } else if (k + 1 < nb) {
             const long long t0_ = B.trace ? clock64() : 0;
-            factor(Dn, LiS + 36 * ((k + 1) & 1));
+            factor(Dn, LiAll + 36 * (k + 1));
             if (B.trace) trA += clock64() - t0_;
         }
         BS_TR(trD)
@@ -945,67 +1222,122 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
         }
     };
     double *tv = yk;                                         // [6] t of the current step
-    if (hb * 6 <= 58) {
-        // narrow bands: one wave runs the whole back-substitution (lanes 0 .. 6 np - 1 = (di, c), lanes 58 .. 63 = the six columns
-        // of L_kk^-1); its LDS traffic is ordered by program order, so the three phases need no workgroup barrier
-        if (tid < 64) {
-            const int lane = tid;
-            auto fetch_back1 = [&](int k, double (&lr)[6], double (&lc)[6]) {
-                if (k < 0) return;
-                const int np = nb - 1 - k < hb ? nb - 1 - k : hb;
-                const double *Lgk = B.Lg + (size_t)k * lgs;
-                if (lane < np * 6) {
-                    const int di = lane / 6 + 1, c = lane - 6 * (di - 1);
+    if (narrow) {
+        // narrow bands (hb <= 9): dp_k = chat_k - sum_j G_{k,j} dp_{k+j} with G_{k,j} = L_kk^-T L_{k+j,k}^T, chat_k = L_kk^-T y_k
+        // -- nothing in the recurrence but the products with the newest dp.  One wave, lane = (slot s = k' mod (hb+1),
+        // row c), holds the running sum of the hb + 1 columns in flight.  Step k: the six lanes of slot k mod (hb+1) add chat_k and
+        // hold dp_k; it is broadcast with v_readlane, every other slot does base -= G_{k',k-k'}[c][:] . dp_k (six multiply-adds),
+        // the slot of k restarts at zero for column k - hb - 1.  ~150 cycles per step instead of three LDS round trips and a 21-deep chain (1 600).
+        // G and chat do not depend on dp: all threads form them first -- thread (k', j, r) one column of G_{k',j}
+        // (G[c][r] = sum_{m >= c} L_{k'+j,k'}[r][m] L_k'k'^-1[m][c]) from the factor store, into LDS by the step k = k' + j that uses it.
+        const int per_step = hb * 36, cap = (B.lds_bytes - (3 * n + 36 * nb) * 8) / (per_step * 8);
+        const int lane = tid, s_ = lane / 6, c_ = lane - 6 * s_;
+        const bool act = tid < hb1 * 6;
+        auto linv_times = [&](const double *Li, const double (&o)[6], double (&gq)[6]) {       // gq[c] = sum_{m >= c} o[m] L^-1[m][c]
+            double li[21];
+            {
+                int q = 0;
 #pragma unroll
-                    for (int r = 0; r < 6; r++) lr[r] = Lgk[di * 36 + r * 6 + c];
-                }
-                if (lane >= 58) {
-                    const int c = lane - 58;
+                for (int m = 0; m < 6; m++)
 #pragma unroll
-                    for (int m = 0; m < 6; m++) lc[m] = Lgk[m * 6 + c];
-                }
-            };
-            auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
-            // the factor blocks of a step are requested three steps ahead (a step is shorter than an L2 round trip)
-            double lrA[6], lrB[6], lrC[6], lcA[6], lcB[6], lcC[6];
-            auto step = [&](int k, double (&lr)[6], double (&lc)[6]) {
-                if (k < 0) return;
-                const int np = nb - 1 - k < hb ? nb - 1 - k : hb;
-                if (lane < np * 6) {
-                    const int di = lane / 6 + 1;
-                    double t = 0.0;
+                    for (int c = 0; c <= m; c++) li[q++] = Li[m * 6 + c];
+            }
 #pragma unroll
-                    for (int r = 0; r < 6; r++) t += lr[r] * x[6 * (k + di) + r];
-                    part[lane] = t;
-                }
-                double li[6];
+            for (int c = 0; c < 6; c++) {
+                double t = 0.0;
 #pragma unroll
-                for (int m = 0; m < 6; m++) li[m] = lc[m];
-                fetch_back1(k - 3, lr, lc);
-                wave_sync();
-                if (lane >= 58) {
-                    const int c = lane - 58;
-                    double a = x[6 * k + c], pv[9];
+                for (int m = c; m < 6; m++) t += o[m] * li[m * (m + 1) / 2 + c];
+                gq[c] = t;
+            }
+        };
+        long long trb0 = B.trace ? clock64() : 0;
+        for (int k = tid; k < nb; k += BS_T) {
+            double o[6], gq[6];
 #pragma unroll
-                    for (int di = 0; di < 9; di++) pv[di] = di < np ? part[di * 6 + c] : 0.0;
+            for (int m = 0; m < 6; m++) o[m] = x[6 * k + m];
+            linv_times(LiAll + 36 * k, o, gq);
 #pragma unroll
-                    for (int di = 0; di < 9; di++) if (di < np) a -= pv[di];
-                    tv[c] = a;
-                }
-                wave_sync();
-                if (lane >= 58) {
-                    const int c = lane - 58;
-                    double a = 0.0;
-#pragma unroll
-                    for (int m = 0; m < 6; m++) a += (m >= c ? li[m] : 0.0) * tv[m];
-                    x[6 * k + c] = a;
-                }
-                wave_sync();
-            };
-            fetch_back1(nb - 1, lrA, lcA); fetch_back1(nb - 2, lrB, lcB); fetch_back1(nb - 3, lrC, lcC);
-            for (int k = nb - 1; k >= 0; k -= 3) { step(k, lrA, lcA); step(k - 1, lrB, lcB); step(k - 2, lrC, lcC); }
+            for (int c = 0; c < 6; c++) chat[6 * k + c] = gq[c];
         }
-        bs_barrier();
+        __syncthreads();
+        if (B.trace && tid == 0) { const long long t_ = clock64(); B.trace[10] = t_ - trb0; trb0 = t_; }
+        double base = 0.0;                                     // - sum_j G_{k',j} dp_{k'+j} so far, of the column in this lane's slot
+        for (int kb = nb; kb > 0; ) {
+            const int ka = kb > cap ? kb - cap : 0;               // steps ka .. kb - 1 (step 0 has nothing to update: its G rows are never read)
+            const int tot = (kb - ka) * hb * 6;
+            for (int e0 = tid; e0 < tot; e0 += 3 * BS_T) {      // three items per thread in flight: the rows of L are L2 round trips
+                double o[3][6];
+                int ob[3], kq[3];
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    const int e = e0 + b * BS_T;
+                    const int blk = e / 6, r = e - 6 * blk, st = blk / hb, j = blk - st * hb + 1, kp = ka + st - j;
+                    const bool ok = e < tot && kp >= 0;
+                    ob[b] = ok ? blk * 36 + r : -1; kq[b] = ok ? kp : 0;
+                    ld_rec<6>(B.Lg + (size_t)kq[b] * lgs + (ok ? j * 36 + r * 6 : 0), o[b]);
+                }
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    if (ob[b] < 0) continue;
+                    double gq[6];
+                    linv_times(LiAll + 36 * kq[b], o[b], gq);
+#pragma unroll
+                    for (int c = 0; c < 6; c++) Gs[ob[b] + c * 6] = gq[c];
+                }
+            }
+            __syncthreads();
+            if (B.trace && tid == 0) { const long long t_ = clock64(); B.trace[11] = t_ - trb0; trb0 = t_; }
+            if (tid < 64) {
+                // two steps per trip with the roles of the two register sets swapped: the rows / chat entries of the next step are
+                // requested before this step's chain and nothing waits for them until they are used
+                auto load_next = [&](int k, int ksl, double (&gg)[6], double &cc, bool &on) {   // for step k: row c_ of G_{k', k - k'}, chat_k
+                    int j = ksl - s_; if (j < 0) j += hb1;
+                    on = act && j > 0 && k - j >= 0;
+                    const double *gp = Gs + ((size_t)(on ? k - ka : 0) * hb + (on ? j - 1 : 0)) * 36 + (act ? c_ : 0) * 6;
+                    ld_rec<6>(gp, gg);
+                    cc = chat[6 * k + (act ? c_ : 0)];
+                };
+                auto step = [&](int k, int ksl, const double (&gg)[6], double cc, bool on) {
+                    const bool own = act && s_ == ksl;
+                    const double v = own ? base + cc : base;          // dp_k on the lanes of its slot
+                    double dv[6];
+#pragma unroll
+                    for (int m = 0; m < 6; m++) {
+                        const int lo = __builtin_amdgcn_readlane(__double2loint(v), ksl * 6 + m);
+                        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), ksl * 6 + m);
+                        dv[m] = __hiloint2double(hi, lo);
+                    }
+                    const double t = fma(gg[2], dv[2], fma(gg[1], dv[1], gg[0] * dv[0])) + fma(gg[5], dv[5], fma(gg[4], dv[4], gg[3] * dv[3]));
+                    if (own) x[6 * k + c_] = v;
+                    base = own ? 0.0 : (on ? base - t : base);
+                };
+                // three register sets in rotation: the rows / chat entry of step k - 2 are requested at the start of step k
+                auto dec = [&](int q) { return q == 0 ? hb : q - 1; };
+                int ks = (kb - 1) % hb1;
+                double gA[6], gB[6], gC[6], cA = 0.0, cB = 0.0, cC = 0.0; bool onA = false, onB = false, onC = false;
+#pragma unroll
+                for (int m = 0; m < 6; m++) { gA[m] = 0.0; gB[m] = 0.0; gC[m] = 0.0; }
+                load_next(kb - 1, ks, gA, cA, onA);
+                if (kb - 2 >= ka) load_next(kb - 2, dec(ks), gB, cB, onB);
+                for (int k = kb - 1; k >= ka; k -= 3) {
+                    const int ks1 = dec(ks), ks2 = dec(ks1), ks3 = dec(ks2), ks4 = dec(ks3);
+                    if (k - 2 >= ka) load_next(k - 2, ks2, gC, cC, onC);
+                    step(k, ks, gA, cA, onA);
+                    if (k - 1 >= ka) {
+                        if (k - 3 >= ka) load_next(k - 3, ks3, gA, cA, onA);
+                        step(k - 1, ks1, gB, cB, onB);
+                    }
+                    if (k - 2 >= ka) {
+                        if (k - 4 >= ka) load_next(k - 4, ks4, gB, cB, onB);
+                        step(k - 2, ks2, gC, cC, onC);
+                    }
+                    ks = ks3;
+                }
+            }
+            if (B.trace && tid == 0) { const long long t_ = clock64(); B.trace[12] = t_ - trb0; trb0 = t_; }
+            __syncthreads();
+            kb = ka;
+        }
     } else {
     if (nb > 0) fetch_back(nb - 1);
     for (int k = nb - 1; k >= 0; k--) {
@@ -1053,11 +1385,12 @@ __global__ __launch_bounds__(256) void k_backsub(BADev d, int use_state)
 {
     __shared__ double sh[4];
     if (use_state && d.st->converged) return;
-    const int j = blockIdx.x * 256 + threadIdx.x, M = d.M;
+    const int kk = blockIdx.x * 256 + threadIdx.x, M = d.M;
     double mx = 0.0;
-    if (j < M) {
+    if (kk < M) {
+        const int j = d.pt_id[kk];
         double bl[3] = {d.bl[j], d.bl[(size_t)M + j], d.bl[(size_t)2 * M + j]};
-        for (int i = d.pt_start[j]; i < d.pt_start[j + 1]; i++) {
+        for (int i = d.pt_start[kk]; i < d.pt_start[kk + 1]; i++) {
             if (!d.hasp[i]) continue;
             const double *dp = d.dp + 6 * d.opose[i];
             double a = 0.0, b = 0.0;
@@ -1076,7 +1409,7 @@ __global__ __launch_bounds__(256) void k_backsub(BADev d, int use_state)
         d.pts_t[3 * j] = d.pts[3 * j] - l0; d.pts_t[3 * j + 1] = d.pts[3 * j + 1] - l1; d.pts_t[3 * j + 2] = d.pts[3 * j + 2] - l2;
         mx = fmax(fabs(l0), fmax(fabs(l1), fabs(l2)));
     }
-    if (j < d.n) { d.pose_t[j] = d.pose[j] - d.dp[j]; mx = fmax(mx, fabs(d.dp[j])); }
+    if (kk < d.n) { d.pose_t[kk] = d.pose[kk] - d.dp[kk]; mx = fmax(mx, fabs(d.dp[kk])); }
     const double t = block_max(mx, sh);
     if (threadIdx.x == 0) d.part[blockIdx.x] = t;
 }
@@ -1238,12 +1571,11 @@ __global__ __launch_bounds__(256) void k_outliers(BADev d, double repr_eps, doub
     const double t = block_sum(c, sh);
     if (threadIdx.x == 0) d.part[blockIdx.x] = t;
 }
-__global__ void k_outlier_count(BADev d, int nb_obs)
+__global__ __launch_bounds__(256) void k_outlier_count(BADev d, int nb_obs)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double t = 0.0;
-    for (int i = 0; i < nb_obs; i++) t += d.part[i];
-    d.st->n_outliers = (int)t;
+    __shared__ double sh[4];
+    const double t = ctl_sum(d.part, nb_obs, 1, sh);           // counts: exact in any order
+    if (threadIdx.x == 0) d.st->n_outliers = (int)t;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1263,61 +1595,104 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     slam_ba *ba = new slam_ba();
     ba->device = ctx->device;
     const int n = 6 * P;
-    // --- host-side structure: stable counting sort of observations by point
-    std::vector<int> start(M + 1, 0);
-    for (int i = 0; i < O; i++) start[point_ids[i]]++;
-    for (int j = 0; j < M; j++) start[j + 1] += start[j];
+    // --- host-side structure.  Map points sorted by (first free observing pose f, id); observations sorted by point in
+    //     that order (stable).  hb = widest span of free observers of one point = block half-bandwidth of S.
+    std::vector<int> cnt(M, 0), pfirst(M, P), plast(M, -1), pany(M, P);
+    for (int i = 0; i < O; i++) {
+        const int j = (int)point_ids[i] - 1, p = (int)pose_ids[i] - 1;
+        cnt[j]++; pany[j] = std::min(pany[j], p);
+        if (!theta_const[p]) { pfirst[j] = std::min(pfirst[j], p); plast[j] = std::max(plast[j], p); }
+    }
+    int hb = 0;
+    for (int j = 0; j < M; j++) {
+        if (plast[j] >= 0) hb = std::max(hb, plast[j] - pfirst[j]);
+        else pfirst[j] = pany[j] < P ? pany[j] : 0;          // no free observer: any window will do (it gets no slot)
+    }
+    ba->hb = hb;
+    std::vector<int> pt_id(M), rank(M), start(M + 1, 0);
+    { std::vector<int> fb(P + 1, 0);
+      for (int j = 0; j < M; j++) fb[pfirst[j] + 1]++;
+      for (int p = 0; p < P; p++) fb[p + 1] += fb[p];
+      for (int j = 0; j < M; j++) { const int k = fb[pfirst[j]]++; pt_id[k] = j; rank[j] = k; } }
+    for (int k = 0; k < M; k++) start[k + 1] = start[k] + cnt[pt_id[k]];
     ba->perm.assign(O, 0);
-    { std::vector<int> fill(start.begin(), start.end() - 1); for (int i = 0; i < O; i++) ba->perm[fill[point_ids[i] - 1]++] = i; }
-    std::vector<int> opose(O), opoint(O);
+    { std::vector<int> fill(start.begin(), start.end() - 1); for (int i = 0; i < O; i++) ba->perm[fill[rank[point_ids[i] - 1]]++] = i; }
+    std::vector<int> opose(O), opoint(O), opk(O);
     std::vector<double> pix(2 * (size_t)O);
     for (int s = 0; s < O; s++) {
         const int i = ba->perm[s];
-        opose[s] = (int)pose_ids[i] - 1; opoint[s] = (int)point_ids[i] - 1;
+        opose[s] = (int)pose_ids[i] - 1; opoint[s] = (int)point_ids[i] - 1; opk[s] = rank[opoint[s]];
         pix[s] = pixels_yx[2 * i]; pix[(size_t)O + s] = pixels_yx[2 * i + 1];
     }
-    // --- pair lists sorted by upper pose block (p <= q); both poses must be free
-    std::vector<int> bcount((size_t)P * P + 1, 0);
-    size_t npairs = 0;
-    for (int j = 0; j < M; j++)
-        for (int a = start[j]; a < start[j + 1]; a++) {
-            if (theta_const[opose[a]]) continue;
-            for (int b = start[j]; b < start[j + 1]; b++) {
-                if (theta_const[opose[b]]) continue;
-                const int p = opose[a], q = opose[b];
-                if (p > q || (p == q && a > b)) continue;   // upper blocks; within a diagonal block keep a <= b once
-                bcount[(size_t)p * P + q + 1]++; npairs++;
+    // a map point observed twice by one free pose has no place in a pose block (does not happen in the reference's feeder)
+    { std::vector<int> seen(P, -1);
+      for (int k = 0; k < M; k++)
+          for (int a = start[k]; a < start[k + 1]; a++) {
+              const int p = opose[a];
+              if (theta_const[p]) continue;
+              if (seen[p] == k) { delete ba; return slam_fail(ctx, SLAM_ERR_ARG, "slam_ba: map point %d is observed twice by pose %d", pt_id[k] + 1, p + 1); }
+              seen[p] = k;
+          } }
+    // --- point groups of k_schur_groups: same f, <= SG_SB points, <= SG_OB observations; evenly sized within one f
+    static const bool no_groups = getenv("SLAMHIP_NO_GROUPS") != nullptr;
+    bool grouped = !no_groups && hb <= BS_MAXHB && M > 0 && O > 0;
+    std::vector<int4> grp; std::vector<int> fgrp(P + 1, 0);
+    if (grouped) {
+        int k = 0;
+        for (int f = 0; f < P && grouped; f++) {
+            fgrp[f] = (int)grp.size();
+            int ke = k;
+            while (ke < M && pfirst[pt_id[ke]] == f) ke++;
+            const int nf = ke - k, ng = (nf + SG_SB - 1) / SG_SB, tgt = ng ? (nf + ng - 1) / ng : 0;
+            while (k < ke) {
+                int k1 = k, no = 0;
+                while (k1 < ke && k1 - k < tgt && no + cnt[pt_id[k1]] <= SG_OB) { no += cnt[pt_id[k1]]; k1++; }
+                if (k1 == k) { grouped = false; break; }          // one point with more than SG_OB observations: pair lists
+                grp.push_back(make_int4(k, start[k], f | ((k1 - k) << 16), no));
+                k = k1;
             }
         }
-    // a diagonal block needs both (a,b) and (b,a) when two observations of one
-    // point share a pose (does not happen in the reference's feeder); handled by
-    // keeping a <= b only and accepting the symmetric half: guard against it.
-    std::vector<int> boff((size_t)P * P + 1, 0);
-    for (size_t k = 0; k < (size_t)P * P; k++) boff[k + 1] = boff[k] + bcount[k + 1];
-    std::vector<int2> pairs(npairs);
-    { std::vector<int> fill(boff.begin(), boff.end() - 1);
-      for (int j = 0; j < M; j++)
-          for (int a = start[j]; a < start[j + 1]; a++) {
-              if (theta_const[opose[a]]) continue;
-              for (int b = start[j]; b < start[j + 1]; b++) {
-                  if (theta_const[opose[b]]) continue;
-                  const int p = opose[a], q = opose[b];
-                  if (p > q || (p == q && a > b)) continue;
-                  if (p == q && a != b) { delete ba; return slam_fail(ctx, SLAM_ERR_ARG, "slam_ba: map point %d is observed twice by pose %d", j + 1, p + 1); }
-                  pairs[fill[(size_t)p * P + q]++] = make_int2(a, b);
-              }
-          } }
-    std::vector<int> blk_start; std::vector<int2> blk_pq;
-    for (int p = 0; p < P; p++)
-        for (int q = p; q < P; q++) {
-            const size_t k = (size_t)p * P + q;
-            if (boff[k + 1] > boff[k]) { blk_start.push_back(boff[k]); blk_pq.push_back(make_int2(p, q)); }
-        }
+        fgrp[P] = (int)grp.size();
+    }
+    ba->grouped = grouped;
+    // --- pair lists sorted by upper pose block (p <= q), both poses free: only where the groups do not apply
+    std::vector<int2> pairs; std::vector<int> blk_start; std::vector<int2> blk_pq;
+    size_t npairs = 0;
+    if (!grouped) {
+        std::vector<int> bcount((size_t)P * P + 1, 0);
+        for (int j = 0; j < M; j++)
+            for (int a = start[j]; a < start[j + 1]; a++) {
+                if (theta_const[opose[a]]) continue;
+                for (int b = start[j]; b < start[j + 1]; b++) {
+                    if (theta_const[opose[b]]) continue;
+                    const int p = opose[a], q = opose[b];
+                    if (p > q || (p == q && a > b)) continue;   // upper blocks; within a diagonal block keep a <= b once
+                    bcount[(size_t)p * P + q + 1]++; npairs++;
+                }
+            }
+        std::vector<int> boff((size_t)P * P + 1, 0);
+        for (size_t k = 0; k < (size_t)P * P; k++) boff[k + 1] = boff[k] + bcount[k + 1];
+        pairs.resize(npairs);
+        { std::vector<int> fill(boff.begin(), boff.end() - 1);
+          for (int j = 0; j < M; j++)
+              for (int a = start[j]; a < start[j + 1]; a++) {
+                  if (theta_const[opose[a]]) continue;
+                  for (int b = start[j]; b < start[j + 1]; b++) {
+                      if (theta_const[opose[b]]) continue;
+                      const int p = opose[a], q = opose[b];
+                      if (p > q || (p == q && a > b)) continue;
+                      pairs[fill[(size_t)p * P + q]++] = make_int2(a, b);
+                  }
+              } }
+        for (int p = 0; p < P; p++)
+            for (int q = p; q < P; q++) {
+                const size_t k = (size_t)p * P + q;
+                if (boff[k + 1] > boff[k]) { blk_start.push_back(boff[k]); blk_pq.push_back(make_int2(p, q)); }
+            }
+    }
     blk_start.push_back((int)npairs);
     const int nblk = (int)blk_pq.size();
-    int hb = 0;
-    for (const int2 &pq : blk_pq) hb = std::max(hb, pq.y - pq.x);
-    ba->hb = hb;
+    const int ngrp = (int)grp.size(), hbw = hb + 1, wstride = grouped ? hbw * (hbw + 1) / 2 * 36 + hbw * 12 : 0;
 
     const int nbo = (O + 255) / 256, nbp = (std::max(M, n) + 255) / 256;
     ba->nblocks_obs = std::max(nbo, 1); ba->nblocks_pts = std::max(nbp, 1);
@@ -1334,8 +1709,10 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     const size_t o_pairs = take(npairs * 8 + 8), o_bs = take((size_t)(nblk + 1) * 4), o_bpq = take((size_t)nblk * 8 + 8);
     const size_t o_red = take(((size_t)n * n + 2 * n + 8) * 8), o_Sw = take((size_t)(n + 1) * n * 8), o_dp = take(n * 8), o_dl = take((size_t)3 * M * 8 + 8);
     const size_t o_cf = take(64), o_li = take((size_t)((n + CT - 1) / CT) * CT * CT * 8), o_lf = take((size_t)(n + 1) * n * 8);
-    const size_t o_part = take(((size_t)ba->nblocks_pts + 2 * ba->nblocks_obs + 8) * 8), o_st = take(sizeof(LMState));
+    const size_t o_part = take(((size_t)ba->nblocks_pts + 2 * (size_t)std::max(ba->nblocks_obs, ngrp) + 8) * 8), o_st = take(sizeof(LMState));
     const size_t o_band = take((size_t)P * ((size_t)(BS_MAXHB + 1) * 36 + 8) * 8);
+    const size_t o_ptid = take((size_t)M * 4 + 4), o_opk = take((size_t)O * 4 + 4), o_grp = take((size_t)ngrp * 16 + 16), o_fgrp = take((size_t)(P + 1) * 4);
+    const size_t o_wpart = take((size_t)ngrp * wstride * 8 + 8);
     char *A;
     hipError_t e = hipMalloc((void **)&A, off);
     if (e != hipSuccess) { delete ba; return slam_fail(ctx, SLAM_ERR_HIP, "slam_ba: hipMalloc(%zu): %s", off, hipGetErrorString(e)); }
@@ -1355,12 +1732,16 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     d.Swork = (double *)(A + o_Sw); d.dp = (double *)(A + o_dp); d.dl = (double *)(A + o_dl);
     d.part = (double *)(A + o_part); d.st = (LMState *)(A + o_st);
     ba->chol_flag = (int *)(A + o_cf); ba->linv = (double *)(A + o_li); ba->lfac = (double *)(A + o_lf); ba->band = (double *)(A + o_band);
+    d.pt_id = (const int *)(A + o_ptid); d.opk = (const int *)(A + o_opk); d.grp = (const int4 *)(A + o_grp); d.fgrp = (const int *)(A + o_fgrp);
+    d.ngrp = ngrp; d.whb = hb; d.wstride = wstride; d.wpart = (double *)(A + o_wpart);
+    ba->nparts = grouped ? ngrp : ba->nblocks_obs;
     hipStream_t st = ctx->stream;
 #define UP(dst, src, bytes) do { if ((bytes) > 0) HIP_TRY(ctx, hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
     UP(d.pose, theta, (size_t)n * 8); UP(d.pts, theta + n, (size_t)3 * M * 8);
     UP(d.pconst, theta_const, (size_t)P); UP(d.pix, pix.data(), (size_t)2 * O * 8);
     UP(d.opose, opose.data(), (size_t)O * 4); UP(d.opoint, opoint.data(), (size_t)O * 4); UP(d.pt_start, start.data(), (size_t)(M + 1) * 4);
     UP(d.pairs, pairs.data(), npairs * 8); UP(d.blk_start, blk_start.data(), (size_t)(nblk + 1) * 4); UP(d.blk_pq, blk_pq.data(), (size_t)nblk * 8);
+    UP(d.pt_id, pt_id.data(), (size_t)M * 4); UP(d.opk, opk.data(), (size_t)O * 4); UP(d.grp, grp.data(), (size_t)ngrp * 16); UP(d.fgrp, fgrp.data(), (size_t)(P + 1) * 4);
 #undef UP
     HIP_TRY(ctx, hipMemsetAsync(d.outl, 0, (size_t)O + 1, st));
     HIP_TRY(ctx, hipMemsetAsync(d.st, 0, sizeof(LMState), st));
@@ -1378,6 +1759,15 @@ static int ba_enqueue_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, dou
     d.S = red; d.g = red + (size_t)n * n; d.udiag = d.g + n;
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)n * n + 2 * n + 8) * 8, st));
+    if (ba->grouped) {
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_schur_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB)); attr_set = true; }
+        hipLaunchKernelGGL(k_schur_groups, dim3(d.ngrp), dim3(SG_T), sg_lds_bytes(d.whb), st, d, inv_delta, ignore_outliers, use_state);
+        if (!use_state) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 0, d.ngrp, ba->nblocks_pts, 0, red + (size_t)n * n + 2 * n);
+        const int nthr = d.P * (d.whb + 1) * 36 + d.P * 12;
+        hipLaunchKernelGGL(k_schur_reduce, dim3((nthr + 255) / 256), dim3(256), 0, st, d, use_state);
+        return SLAM_OK;
+    }
     hipLaunchKernelGGL(k_linearize, dim3(ba->nblocks_obs), dim3(256), 0, st, d, ignore_outliers, use_state);
     if (!use_state) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 0, ba->nblocks_obs, ba->nblocks_pts, 0, red + (size_t)n * n + 2 * n);
     if (d.M > 0) hipLaunchKernelGGL(k_points, dim3((d.M + 255) / 256), dim3(256), 0, st, d, inv_delta, use_state);
@@ -1394,15 +1784,20 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
     hipStream_t st = ctx->stream;
     static const bool no_band = getenv("SLAMHIP_NO_BAND") != nullptr;
     const int hb = std::min(std::max(ba->hb, 1), d.P - 1);      // >= 1: the factor wave reads block row k + 1 while row k + 1 + hb enters the ring
-    const size_t band_lds = ((size_t)(hb + 1) * (hb + 1) * 36 + (size_t)(hb + 1) * (6 + 36 + 6) + 8 + 108 + 2 * (size_t)n) * 8 + (size_t)hb * (hb + 1) + 16;
+    const size_t band_fixed = (3 * (size_t)n + 36 * (size_t)d.P) * 8;      // x, damp, chat, L_kk^-1 of every column
+    size_t band_lds = band_fixed + ((size_t)(hb + 1) * (hb + 1) * 36 + (size_t)(hb + 1) * (6 + 36 + 6) + 8 + 36) * 8 + (size_t)hb * (hb + 1) + 16;
+    if (hb * 6 <= 58) {      // narrow bands: room to stage the G blocks of (up to) all back-substitution steps, at least one
+        const size_t want = band_fixed + (size_t)d.P * hb * 36 * 8, least = band_fixed + (size_t)hb * 36 * 8;
+        band_lds = std::max(band_lds, std::max(std::min(want, (size_t)150 * 1024), least));
+    }
     if (!no_band && hb <= BS_MAXHB && band_lds <= 150 * 1024) {
         BandArgs B; B.S = red; B.g = red + (size_t)n * n; B.ud = red + (size_t)n * n + n; B.Lg = ba->band; B.nb = d.P; B.hb = hb;
-        B.inv_delta_host = inv_delta; B.fail = ba->chol_flag;
+        B.inv_delta_host = inv_delta; B.fail = ba->chol_flag; B.lds_bytes = (int)band_lds;
         static long long *trace_dev = nullptr; static int trace_n = 0;
         static const bool trace_on = getenv("SLAMHIP_BAND_TRACE") != nullptr;
         if (trace_on && !trace_dev) (void)hipHostMalloc((void **)&trace_dev, 128);
         B.trace = trace_dev;
-        if (trace_on && trace_n++ == 8) { (void)hipStreamSynchronize(st); fprintf(stderr, "band trace (cycles): P1 barrier wait %lld P2 barrier wait %lld backsub %lld | potrf+inv %lld panel %lld update %lld put/fetch %lld | factor wave %lld prefetch wave %lld\n", trace_dev[1], trace_dev[2], trace_dev[3], trace_dev[4], trace_dev[5], trace_dev[6], trace_dev[7], trace_dev[8], trace_dev[9]); }
+        if (trace_on && trace_n++ == 8) { (void)hipStreamSynchronize(st); fprintf(stderr, "band trace (cycles): P1 barrier wait %lld P2 barrier wait %lld backsub %lld | potrf+inv %lld panel %lld update %lld put/fetch %lld | factor wave %lld prefetch wave %lld | backsub: chat %lld G %lld recurrence %lld\n", trace_dev[1], trace_dev[2], trace_dev[3], trace_dev[4], trace_dev[5], trace_dev[6], trace_dev[7], trace_dev[8], trace_dev[9], trace_dev[10], trace_dev[11], trace_dev[12]); }
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
         hipLaunchKernelGGL(k_band_solve, dim3(1), dim3(BS_T), band_lds, st, d, B, use_state);
@@ -1558,7 +1953,7 @@ int slam_ba_flag_outliers(slam_ctx *ctx, slam_ba *ba, double repr_eps, double de
     ARG_TRY(ctx, ctx != nullptr && ba != nullptr);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_outliers, dim3(ba->nblocks_obs), dim3(256), 0, ctx->stream, ba->d, repr_eps, depth_eps);
-    hipLaunchKernelGGL(k_outlier_count, dim3(1), dim3(1), 0, ctx->stream, ba->d, ba->nblocks_obs);
+    hipLaunchKernelGGL(k_outlier_count, dim3(1), dim3(256), 0, ctx->stream, ba->d, ba->nblocks_obs);
     HIP_TRY(ctx, hipGetLastError());
     LMState h;
     HIP_TRY(ctx, hipMemcpyAsync(&h, ba->d.st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -1613,7 +2008,7 @@ int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy, int
     hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, st, d, 3);
     // flag outliers at theta_1 (bundle_adjustment.jl:45)
     hipLaunchKernelGGL(k_outliers, dim3(ba->nblocks_obs), dim3(256), 0, st, d, repr_eps, 1e-6);
-    hipLaunchKernelGGL(k_outlier_count, dim3(1), dim3(1), 0, st, d, ba->nblocks_obs);
+    hipLaunchKernelGGL(k_outlier_count, dim3(1), dim3(256), 0, st, d, ba->nblocks_obs);
     run_pass(1, iterations);
     hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, st, d, 2);
     (void)hipEventRecord(e1, st);
