@@ -78,6 +78,7 @@ struct slam_ba {
     int hb = 0;                  // block half-bandwidth of the reduced system: S_pq = 0 for |p - q| > hb
     bool grouped = false;        // the reduced system is built by k_schur_groups / k_schur_reduce (else: pair lists, k_blocks)
     int nparts = 0;              // partial sums k_control folds after a linearisation inside a build
+    const double *zeroed = nullptr;   // reduce buffer whose out-of-band part is known to be zero
     double *band = nullptr;      // factor store of k_band_solve, P x ((hb + 1) x 36 + 8)
     std::vector<int> perm;       // sorted position -> original observation index
     int nblocks_obs = 0, nblocks_pts = 0;
@@ -1446,6 +1447,84 @@ __global__ __launch_bounds__(256) void k_trial(BADev d, int ignore_outliers, int
     if (threadIdx.x == 0) { d.part[nb_pts + 2 * blockIdx.x] = t1; d.part[nb_pts + 2 * blockIdx.x + 1] = t2; }
 }
 
+// k_backsub + k_trial on the point groups of k_schur_groups (one workgroup per group, dp in LDS): thread = observation forms
+// Jl' (Jp dp), thread = point sums them in observation order, dl = V^-1 (bl - sum), trial point; thread = observation again: trial
+// and predicted residual.  Partials: part[g] = max |dx|, part[ngrp + 2 g] = trial cost, part[ngrp + 2 g + 1] = predicted cost.
+__global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outliers, int use_state)
+{
+    __shared__ double s_dp[SOLVE_MAX_N];
+    __shared__ double s_u[SG_OB * 3];
+    __shared__ double s_dl[SG_SB * 6];                      // dl (3), trial point (3)
+    __shared__ double s_red[8];
+    if (use_state && d.st->converged) return;
+    const int tid = threadIdx.x, M = d.M, O = d.O, n = d.n;
+    const int4 G = d.grp[blockIdx.x];
+    const int k0 = G.x, o0 = G.y, npts = G.z >> 16, nobs = G.w;
+    for (int a = tid; a < n; a += SG_T) s_dp[a] = d.dp[a];
+    __syncthreads();
+    double mx = 0.0;
+    if (blockIdx.x == 0)
+        for (int a = tid; a < n; a += SG_T) { const double v = s_dp[a]; d.pose_t[a] = d.pose[a] - v; mx = fmax(mx, fabs(v)); }
+    const int i = o0 + tid;
+    int p = 0, pl = 0;
+    double jp[12], jl[6], ff[2] = {0.0, 0.0}, a = 0.0, b = 0.0;
+    bool active = false;
+    if (tid < nobs) {
+        p = d.opose[i]; pl = d.opk[i] - k0;
+        active = !(ignore_outliers && d.outl[i]);
+        ld_rec<12>(d.Jp + (size_t)i * 12, jp); ld_rec<6>(d.Jl + (size_t)i * 6, jl); ld_rec<2>(d.f + 2 * (size_t)i, ff);
+#pragma unroll
+        for (int k = 0; k < 6; k++) { a += jp[k] * s_dp[6 * p + k]; b += jp[6 + k] * s_dp[6 * p + k]; }     // Jp = 0 unless the observation has a free pose
+#pragma unroll
+        for (int k = 0; k < 3; k++) s_u[tid * 3 + k] = jl[k] * a + jl[3 + k] * b;
+    }
+    __syncthreads();
+    if (tid < npts) {
+        const int kk = k0 + tid, j = d.pt_id[kk];
+        double bl[3] = {d.bl[j], d.bl[(size_t)M + j], d.bl[(size_t)2 * M + j]};
+        const int t0 = d.pt_start[kk] - o0, t1 = d.pt_start[kk + 1] - o0;
+        for (int t = t0; t < t1; t++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) bl[k] -= s_u[t * 3 + k];
+        }
+        double Vi[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) Vi[k] = d.Vinv[(size_t)k * M + j];
+        const double l0 = Vi[0] * bl[0] + Vi[1] * bl[1] + Vi[2] * bl[2];
+        const double l1 = Vi[1] * bl[0] + Vi[3] * bl[1] + Vi[4] * bl[2];
+        const double l2 = Vi[2] * bl[0] + Vi[4] * bl[1] + Vi[5] * bl[2];
+        const double X0 = d.pts[3 * j] - l0, X1 = d.pts[3 * j + 1] - l1, X2 = d.pts[3 * j + 2] - l2;
+        d.dl[3 * j] = l0; d.dl[3 * j + 1] = l1; d.dl[3 * j + 2] = l2;
+        d.pts_t[3 * j] = X0; d.pts_t[3 * j + 1] = X1; d.pts_t[3 * j + 2] = X2;
+        s_dl[tid * 6] = l0; s_dl[tid * 6 + 1] = l1; s_dl[tid * 6 + 2] = l2;
+        s_dl[tid * 6 + 3] = X0; s_dl[tid * 6 + 4] = X1; s_dl[tid * 6 + 5] = X2;
+        mx = fmax(mx, fmax(fabs(l0), fmax(fabs(l1), fabs(l2))));
+    }
+    __syncthreads();
+    double st = 0.0, sp = 0.0;
+    if (tid < nobs) {
+        double r[2] = {0.0, 0.0};
+        const double *dl = s_dl + pl * 6;
+        if (active) {
+            const double X[3] = {dl[3], dl[4], dl[5]};
+            double pose[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) pose[k] = d.pose[6 * p + k] - s_dp[6 * p + k];
+            obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, nullptr);
+        }
+        st_rec<2>(d.ft + 2 * (size_t)i, r);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { a += jl[k] * dl[k]; b += jl[3 + k] * dl[k]; }
+        a -= ff[0]; b -= ff[1];
+        st = r[0] * r[0] + r[1] * r[1];
+        sp = a * a + b * b;
+    }
+    const double t1 = block_sum(st, s_red);
+    const double t2 = block_sum(sp, s_red);
+    const double t3 = block_max(mx, s_red);
+    if (tid == 0) { d.part[blockIdx.x] = t3; d.part[d.ngrp + 2 * blockIdx.x] = t1; d.part[d.ngrp + 2 * blockIdx.x + 1] = t2; }
+}
+
 // Sums the partials (fixed order) and, in the single-GPU path, runs the
 // LeastSquaresOptim accept/reject logic.  mode 0: ssr of the current residuals
 // (after k_linearize); mode 1: trial/predicted/maxdx -> state (+ LM decision if lm).
@@ -1709,7 +1788,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     const size_t o_pairs = take(npairs * 8 + 8), o_bs = take((size_t)(nblk + 1) * 4), o_bpq = take((size_t)nblk * 8 + 8);
     const size_t o_red = take(((size_t)n * n + 2 * n + 8) * 8), o_Sw = take((size_t)(n + 1) * n * 8), o_dp = take(n * 8), o_dl = take((size_t)3 * M * 8 + 8);
     const size_t o_cf = take(64), o_li = take((size_t)((n + CT - 1) / CT) * CT * CT * 8), o_lf = take((size_t)(n + 1) * n * 8);
-    const size_t o_part = take(((size_t)ba->nblocks_pts + 2 * (size_t)std::max(ba->nblocks_obs, ngrp) + 8) * 8), o_st = take(sizeof(LMState));
+    const size_t o_part = take(((size_t)std::max(ba->nblocks_pts, ngrp) + 2 * (size_t)std::max(ba->nblocks_obs, ngrp) + 8) * 8), o_st = take(sizeof(LMState));
     const size_t o_band = take((size_t)P * ((size_t)(BS_MAXHB + 1) * 36 + 8) * 8);
     const size_t o_ptid = take((size_t)M * 4 + 4), o_opk = take((size_t)O * 4 + 4), o_grp = take((size_t)ngrp * 16 + 16), o_fgrp = take((size_t)(P + 1) * 4);
     const size_t o_wpart = take((size_t)ngrp * wstride * 8 + 8);
@@ -1758,7 +1837,8 @@ static int ba_enqueue_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, dou
     const int n = d.n;
     d.S = red; d.g = red + (size_t)n * n; d.udiag = d.g + n;
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)n * n + 2 * n + 8) * 8, st));
+    // the grouped build rewrites every in-band block, g and diag(U) each time: the rest of the buffer only needs zeroing once
+    if (!ba->grouped || ba->zeroed != red) { HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)n * n + 2 * n + 8) * 8, st)); ba->zeroed = red; }
     if (ba->grouped) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_schur_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB)); attr_set = true; }
@@ -1813,6 +1893,11 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
             if (tiles > 1) hipLaunchKernelGGL(k_chol_step, dim3(tiles), dim3(256), 0, st, d, C, ba->linv, k, nbr, use_state);
         }
         hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(256), 0, st, d, C, (const double *)ba->linv, use_state);
+    }
+    if (ba->grouped) {
+        hipLaunchKernelGGL(k_update_groups, dim3(d.ngrp), dim3(SG_T), 0, st, d, ignore_outliers, use_state);
+        hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 1, d.ngrp, d.ngrp, lm, out4);
+        return SLAM_OK;
     }
     hipLaunchKernelGGL(k_backsub, dim3(ba->nblocks_pts), dim3(256), 0, st, d, use_state);
     hipLaunchKernelGGL(k_trial, dim3(ba->nblocks_obs), dim3(256), 0, st, d, ignore_outliers, use_state, ba->nblocks_pts);
