@@ -11,17 +11,18 @@
 //
 // Per LM iteration (all on device, fixed launch sequence, no host sync; every
 // kernel early-outs once the device-side state says "converged"):
-//   k_linearize   per observation: residual, analytic 2x6 / 2x3 Jacobians
-//   k_points      per map point: V = Jl'Jl + D, V^-1, bl; per obs W = Jp'Jl, T = W V^-1
-//   k_blocks      one wave per non-zero (p,q) pose block: S_pq = U_pq - sum T W'
-//                 (pair lists sorted by block: deterministic, no atomics)
-//   k_solve       damped Cholesky of S (one workgroup), dp
-//   k_backsub     per point: dl = V^-1 (bl - W' dp); trial parameters
-//   k_trial       per observation: trial residual, predicted residual
-//   k_control     one thread: rho, accept/reject, radius update, convergence
-//   k_commit      accept: parameters/residuals <- trial
-// Observations are re-ordered by map point at upload so a point's observations
-// are contiguous; all per-observation arrays are SoA for coalesced access.
+//   k_schur_groups   one workgroup per group of map points with the same first free observer: residuals, analytic
+//                    2x6 / 2x3 Jacobians, V = Jl'Jl + D, V^-1, bl, W = Jp'Jl and the group's window of pose blocks
+//                    -(W V^-1) W' (+ Jp'Jp, gradient, diag U), all in LDS
+//   k_schur_reduce   S, g, diag(U) = fixed-order sums of the window partials (deterministic, no atomics)
+//   k_band_solve     damped banded Cholesky of S in one workgroup, dp (wide systems: the tiled k_chol_* chain)
+//   k_update_groups  per group: dl = V^-1 (bl - W' dp), trial parameters, trial and predicted residuals
+//   k_control        rho, accept/reject, radius update, convergence (LeastSquaresOptim's rules)
+//   k_commit         accept: parameters/residuals <- trial
+// Fallback for systems the groups do not cover (block half-bandwidth > 20, a point with > 448 observations):
+//   k_linearize, k_points, k_obs_factors, k_blocks (pair lists sorted by pose block), k_backsub, k_trial.
+// Observations are re-ordered by map point at upload (map points by first free observer) so a point's observations
+// and a group's points are contiguous.
 #include "common.hpp"
 #include <algorithm>
 #include <cmath>
