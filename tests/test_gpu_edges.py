@@ -33,6 +33,80 @@ def test_ba_large_window_tile_boundaries(slam, orc, syn):
         assert abs(cache.stats["ssr_final"] - st["ssr_final"]) <= 1e-8 * st["ssr_final"], P
 
 
+def _ba_vs_oracle(slam, orc, s, tag):
+    cache = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+    slam.bundle_adjustment_(cache, s["cam"])
+    th, ol, st = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], solver=1)
+    assert np.array_equal(cache.outliers, ol), tag
+    assert (cache.stats["iters_pass1"], cache.stats["iters_pass2"]) == (st["iters_pass1"], st["iters_pass2"]), tag
+    assert np.abs(cache.theta - th).max() <= 1e-6 * max(1.0, np.abs(th).max()), tag
+    assert abs(cache.stats["ssr_final"] - st["ssr_final"]) <= 1e-8 * st["ssr_final"], tag
+
+
+def test_ba_point_groups_with_shuffled_ids_scattered_constant_poses_and_orphan_points(slam, orc, syn):
+    """The grouped build sorts map points by their first FREE observer: shuffle point ids and the observation order, make poses in the
+    middle of the window constant (points whose first observer is constant, points seen by constant poses only), add points nobody
+    observes -- results must still equal the oracle's."""
+    s = syn.ba_scene(P=12, M=700, seed=5, obs_per_point=6, n_const=1)
+    rng = np.random.default_rng(3)
+    P, M = 12, 700
+    const = s["theta_const"].copy(); const[[4, 5, 9]] = 1                       # constant poses inside the window
+    perm_pts = rng.permutation(M)                                                # new id of point j = perm_pts[j] + 1
+    theta = s["theta0"].copy()
+    pts = theta[6 * P:].reshape(M, 3).copy()
+    new_pts = np.zeros((M + 3, 3)); new_pts[perm_pts] = pts
+    new_pts[M:] = [[1.0, 2.0, 30.0], [-3.0, 0.5, 12.0], [0.0, 0.0, 50.0]]        # three map points without observations
+    order = rng.permutation(len(s["pose_ids"]))
+    keep = np.ones(len(order), bool)
+    # points 0..19 keep only their observations by constant poses (if they have any)
+    pid0 = s["point_ids"] - 1
+    only_const = (pid0 < 20) & (const[s["pose_ids"] - 1] == 0)
+    has_const = np.zeros(M, bool); np.logical_or.at(has_const, pid0, const[s["pose_ids"] - 1] == 1)
+    keep &= ~(only_const & has_const[pid0])
+    order = order[keep[order]]
+    s2 = dict(s)
+    s2["theta0"] = np.concatenate([theta[:6 * P], new_pts.ravel()])
+    s2["theta_const"] = const
+    s2["pose_ids"] = s["pose_ids"][order]; s2["point_ids"] = (perm_pts[pid0[order]] + 1).astype(np.int64)
+    s2["pixels_yx"] = s["pixels_yx"][order]
+    _ba_vs_oracle(slam, orc, s2, "shuffled")
+
+
+def test_ba_wide_windows_fall_back_to_pair_lists_and_the_tiled_solve(slam, orc, syn):
+    """Every point seen by 24 consecutive key-frames: block half-bandwidth 23 > 20, so the point groups / banded solve do not apply and
+    the pair-list build + tiled Cholesky + per-point back-substitution run instead."""
+    s = syn.ba_scene(P=26, M=500, seed=11, obs_per_point=24, n_const=1)
+    _ba_vs_oracle(slam, orc, s, "wide")
+    # a single map point with more observations than a group holds (> 448, almost all from constant poses) also takes that path
+    s = syn.ba_scene(P=6, M=200, seed=12, obs_per_point=4, n_const=1)
+    rng = np.random.default_rng(1)
+    n_extra = 240                                                                 # old key-frames, each observing the point twice
+    j = 7                                                                         # the point that every "old key-frame" also sees
+    P = 6
+    # extra constant poses observing point j (twice each: only free poses must not repeat), appended as poses P+1 .. P+240
+    th = s["theta0"]; M = 200
+    base_pose = th[:6].copy()
+    extra = np.tile(base_pose, (n_extra, 1)) + rng.normal(0, [1e-3] * 3 + [5e-2] * 3, (n_extra, 6))
+    Xj = th[6 * P + 3 * j: 6 * P + 3 * j + 3]
+    import numpy as _np
+    def proj(pose, X):
+        t1, t2, t3 = pose[:3]
+        Rz = _np.array([[_np.cos(t1), -_np.sin(t1), 0], [_np.sin(t1), _np.cos(t1), 0], [0, 0, 1]])
+        Ry = _np.array([[_np.cos(t2), 0, _np.sin(t2)], [0, 1, 0], [-_np.sin(t2), 0, _np.cos(t2)]])
+        Rx = _np.array([[1, 0, 0], [0, _np.cos(t3), -_np.sin(t3)], [0, _np.sin(t3), _np.cos(t3)]])
+        Xc = Rz @ Ry @ Rx @ X + pose[3:]
+        fx, fy, cx, cy = s["cam"]
+        return _np.array([fy * Xc[1] / Xc[2] + cy, fx * Xc[0] / Xc[2] + cx])
+    px = _np.stack([proj(e, Xj) for e in extra] * 2) + rng.normal(0, 0.5, (2 * n_extra, 2))
+    s3 = dict(s)
+    s3["theta0"] = np.concatenate([th[:6 * P], extra.ravel(), th[6 * P:]])
+    s3["theta_const"] = np.concatenate([s["theta_const"], np.ones(n_extra, np.uint8)])
+    s3["pose_ids"] = np.concatenate([s["pose_ids"], np.tile(np.arange(P + 1, P + n_extra + 1), 2)]).astype(np.int64)
+    s3["point_ids"] = np.concatenate([s["point_ids"], np.full(2 * n_extra, j + 1)]).astype(np.int64)
+    s3["pixels_yx"] = np.concatenate([s["pixels_yx"], px])
+    _ba_vs_oracle(slam, orc, s3, "many observers")
+
+
 def test_error_paths(slam, texture):
     ctx = slam.default_context(0)
     with pytest.raises(slam.SlamHipError):
