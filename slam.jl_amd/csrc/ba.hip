@@ -81,6 +81,8 @@ struct slam_ba {
     int nparts = 0;              // partial sums k_control folds after a linearisation inside a build
     const double *zeroed = nullptr;   // reduce buffer whose out-of-band part is known to be zero
     double *band = nullptr;      // factor store of k_band_solve, P x ((hb + 1) x 36 + 8)
+    double *xchg = nullptr;      // twisted factorisation: the trailing window one side hands to the other
+    int epoch = 0;               // launch counter of k_band_solve (value of its hand-over flags)
     std::vector<int> perm;       // sorted position -> original observation index
     int nblocks_obs = 0, nblocks_pts = 0;
 };
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(BADev d, CholArgs C, con
 // Back-substitution L' dp = y then walks the block columns right to left with the stored L_ik and L_kk^-1.
 // Systems whose half-bandwidth exceeds BS_MAXHB blocks (dense windows of > 21 poses) keep the tiled path.
 #define BS_MAXHB 20
-struct BandArgs { const double *S, *g, *ud; double *Lg; int nb, hb; double inv_delta_host; int *fail; long long *trace; int lds_bytes; };
+struct BandArgs { const double *S, *g, *ud; double *Lg; int nb, hb; double inv_delta_host; int *fail; long long *trace; int lds_bytes; double *xchg; int epoch; };
 #define BS_PF 6      // prefetch registers per prefetch thread: ceil(((BS_MAXHB + 1) * 36 + 6) / BS_PT)
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains the outstanding global loads / stores (the
@@ -931,7 +933,19 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     if (use_state && d.st->converged) return;
     extern __shared__ __attribute__((aligned(16))) double bs_sm[];
     __shared__ int s_bad;
-    const int hb = B.hb, hb1 = hb + 1, nb = B.nb, n = d.n, tid = threadIdx.x;
+    // Twisted factorisation (grid of two workgroups): side 0 eliminates the poses 0 .. own - 1 top-down, side 1 the poses P - 1 ..
+    // P - own' bottom-up (the same algorithm on the block-reversed matrix: pose pi(i) = P - 1 - i) -- at the same time, on two CUs.
+    // The hb poses in the middle receive the Schur updates of both: side 1 hands its trailing window over through global memory
+    // (B.xchg, flag = launch epoch), side 0 adds it to its own (M = ringA + ringB - S), factors the middle and back-substitutes it,
+    // publishes dp of the middle poses, and both sides run their back-substitution outwards.  Sequential block columns: P / 2 + hb / 2
+    // instead of P, both ways.  A single workgroup (grid 1) runs the plain factorisation.
+    const int hb = B.hb, hb1 = hb + 1, nbT = B.nb, n = d.n, tid = threadIdx.x;
+    const bool tw = gridDim.x == 2;
+    const int side = tw ? (int)blockIdx.x : 0;
+    const int ownA = (nbT - hb) / 2, ownB = nbT - hb - ownA;
+    const int own = tw ? (side ? ownB : ownA) : nbT;      // block columns this side eliminates
+    const int nb = tw ? own + hb : nbT;                   // its local system: own columns, then the middle
+    auto gi = [&](int i) { return side ? nbT - 1 - i : i; };          // local block index -> pose
     double *x = bs_sm;                                   // [n]: y, then dp
     double *damp = x + n;                                // [n]: LM damping of the diagonal (k_chol_prepare)
     double *chat = damp + n;                             // [n]: L_kk^-T y_k (narrow bands)
@@ -947,6 +961,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     unsigned char *ptab = (unsigned char *)(Dn + 36);    // [hb (hb+1) / 2][2] pair table (di, dj), dj <= di, ordered by di
     const double inv_delta = use_state ? 1.0 / d.st->delta : B.inv_delta_host;
     const size_t lgs = (size_t)hb1 * 36 + 8;             // doubles per block column in the global factor store
+    double *const Lg = B.Lg + (size_t)side * nbT * lgs;
     if (tid == 0) {
         s_bad = 0;
         int q = 0;
@@ -958,9 +973,9 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     // writes both halves, so the entry is read as S[6 j + c, 6 i + r]: consecutive e are consecutive addresses
     auto fetch1 = [&](int i, int e) -> double {
         const int nj = (i < hb ? i : hb) + 1, nbk = nj * 36, j0 = i - (nj - 1);
-        if (e >= nbk) return B.g[6 * i + (e - nbk)];
-        const int r = e / (6 * nj), t = e - r * 6 * nj;
-        return B.S[(size_t)(6 * j0 + t) + (size_t)(6 * i + r) * n];
+        if (e >= nbk) return B.g[6 * gi(i) + (e - nbk)];
+        const int r = e / (6 * nj), t = e - r * 6 * nj, jb = t / 6, c = t - 6 * jb;
+        return B.S[(size_t)(6 * gi(j0 + jb) + c) + (size_t)(6 * gi(i) + r) * n];
     };
     auto put1 = [&](int i, int e, double v) {
         const int nj = (i < hb ? i : hb) + 1, nbk = nj * 36, j0 = i - (nj - 1);
@@ -970,7 +985,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
         if (jb == nj - 1 && r == c) v += damp[6 * i + r];      // the diagonal block's diagonal
         Wn[((size_t)ri * hb1 + ((j0 + jb) % hb1)) * 36 + r * 6 + c] = v;
     };
-    for (int a = tid; a < n; a += BS_T) damp[a] = fmin(fmax(B.ud[a], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+    for (int a = tid; a < 6 * nb; a += BS_T) damp[a] = fmin(fmax(B.ud[6 * gi(a / 6) + a % 6], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
     __syncthreads();
     // initial window: block rows 0 .. min(hb, nb - 1)
     for (int i = 0; i <= hb && i < nb; i++) {
@@ -992,12 +1007,14 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
         }
     }
     auto fetch_row = [&](int i) {                             // i > hb
-        const double *Srow = B.S + (size_t)6 * (i - hb) + (size_t)(6 * i) * n;
+        const int pi = gi(i);
 #pragma unroll
         for (int q = 0; q < BS_PF; q++) {
             pf[q] = 0.0;
-            if (el_w[q] >= 0) pf[q] = Srow[(size_t)el_t[q] + (size_t)el_r[q] * n];
-            else if (el_w[q] > -1000) pf[q] = B.g[6 * i - 1 - el_w[q]];
+            if (el_w[q] >= 0) {
+                const int jb = el_w[q] >> 6, c = (el_w[q] & 63) - 6 * el_r[q];
+                pf[q] = B.S[(size_t)(6 * gi(i - hb + jb) + c) + (size_t)(6 * pi + el_r[q]) * n];
+            } else if (el_w[q] > -1000) pf[q] = B.g[6 * pi - 1 - el_w[q]];
         }
     };
     auto put_row = [&](int i, int ri) {                       // i > hb, ri = i mod (hb + 1)
@@ -1020,7 +1037,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
         const int per_row = 6 * 6 * hb1;
         for (int e = tid; e < (nb - hb - 2) * per_row; e += BS_T) {
             const int i = hb + 2 + e / per_row, q = e - (e / per_row) * per_row, r = q / (6 * hb1), t = q - r * 6 * hb1;
-            acc += B.S[(size_t)(6 * (i - hb) + t) + (size_t)(6 * i + r) * n];
+            acc += B.S[(size_t)(6 * gi(i - hb + t / 6) + t % 6) + (size_t)(6 * gi(i) + r) * n];
         }
         if (acc == 1.2345e-300) d.dp[0] = acc;                 // keeps the loads alive; never true in practice and harmless if it were (dp is rewritten below)
     }
@@ -1075,11 +1092,13 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     };
     if (fwave) factor(Wn, LiAll);                                // D_0 = block (0, 0), ring slot [0][0]
     bs_barrier();
-    for (int k = 0; k < nb; k++) {
+    int kbeg = 0, kend = own;
+    for (int phase = 0; ; phase++) {
+    for (int k = kbeg; k < kend; k++) {
         const int kk = k % hb1, np = nb - 1 - k < hb ? nb - 1 - k : hb;      // blocks below the diagonal in this column
         const double *LiK = LiAll + 36 * k;                     // L_kk^-1 (the factor wave writes the next column's during this step)
         // ---- P1: the panel rows L_ik = A_ik L_kk^-T and the right-hand side ----
-        double *Lgk = B.Lg + (size_t)k * lgs;
+        double *Lgk = Lg + (size_t)k * lgs;
         if (tid < np * 6 + 1) {
             const bool is_rhs = tid == np * 6;
             const int di = tid / 6 + 1, r = tid - 6 * (di - 1);
@@ -1202,6 +1221,58 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
         bs_barrier();
         if (B.trace) { const long long t = clock64(); trP2 += t - trT; trT = t; }
     }
+    if (!tw || phase == 1) break;
+    // ---- the middle: rows own .. own + hb - 1 of the ring hold S - (this side's updates); the diagonal block (own, own) is in Dn
+    //      (the factor wave keeps the next diagonal block to itself).  Lower blocks (i >= j), row-major hb x hb triangle + rhs.
+    const int ntri = hb * (hb + 1) / 2;
+    if (side == 1) {
+        for (int e = tid; e < ntri * 36 + hb * 6; e += BS_T) {
+            double v;
+            if (e < ntri * 36) {
+                const int bq = e / 36, rc = e - 36 * bq;
+                int i = 0, q = bq; while (q > i) { q -= i + 1; i++; }            // bq = i (i + 1) / 2 + j
+                const int li = own + i, lj = own + q;
+                v = (i == 0) ? Dn[rc] : Wn[((size_t)(li % hb1) * hb1 + (lj % hb1)) * 36 + rc];
+            } else {
+                const int i = (e - ntri * 36) / 6, r = e - ntri * 36 - 6 * i;
+                v = rhs[((own + i) % hb1) * 6 + r];
+            }
+            B.xchg[e] = v;
+        }
+        if (bad) s_bad = 1;
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(B.fail + 1, B.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+    }
+    if (tid == 0) while (__hip_atomic_load(B.fail + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != B.epoch) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+    __threadfence();
+    for (int e = tid; e < ntri * 36 + hb * 6; e += BS_T) {
+        if (e < ntri * 36) {
+            const int bq = e / 36, rc = e - 36 * bq, r = rc / 6, c = rc - 6 * r;
+            int i = 0, q = bq; while (q > i) { q -= i + 1; i++; }                // middle block (own + i, own + q), i >= q
+            // the other side numbers the middle backwards and holds the transposed block: its (hb - 1 - q, hb - 1 - i), entry (c, r)
+            const int oi = hb - 1 - q, oj = hb - 1 - i;
+            const double vb = __builtin_nontemporal_load(B.xchg + (size_t)(oi * (oi + 1) / 2 + oj) * 36 + c * 6 + r);
+            const int I = own + i, J = own + q;
+            double sd = B.S[(size_t)(6 * I + r) + (size_t)(6 * J + c) * n];
+            if (i == q && r == c) sd += damp[6 * I + r];
+            double *w = Wn + ((size_t)(I % hb1) * hb1 + (J % hb1)) * 36 + rc;
+            const double va = (bq == 0) ? Dn[rc] : *w;
+            *w = (va + vb) - sd;
+        } else {
+            const int i = (e - ntri * 36) / 6, r = e - ntri * 36 - 6 * i;
+            const double vb = __builtin_nontemporal_load(B.xchg + (size_t)ntri * 36 + (hb - 1 - i) * 6 + r);
+            double *w = rhs + ((own + i) % hb1) * 6 + r;
+            *w = (*w + vb) - B.g[6 * (own + i) + r];
+        }
+    }
+    __syncthreads();
+    if (fwave) factor(Wn + ((size_t)(own % hb1) * hb1 + (own % hb1)) * 36, LiAll + 36 * own);
+    bs_barrier();
+    kbeg = own; kend = nb;
+    }
     if (bad) s_bad = 1;
     __threadfence();                                         // the factor store is re-read below by other threads
     __syncthreads();
@@ -1224,6 +1295,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
         }
     };
     double *tv = yk;                                         // [6] t of the current step
+    const int kfac2 = (tw && side) ? own : nb;
     if (narrow) {
         // narrow bands (hb <= 9): dp_k = chat_k - sum_j G_{k,j} dp_{k+j} with G_{k,j} = L_kk^-T L_{k+j,k}^T, chat_k = L_kk^-T y_k
         // -- nothing in the recurrence but the products with the newest dp.  One wave, lane = (slot s = k' mod (hb+1),
@@ -1233,6 +1305,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
         // G and chat do not depend on dp: all threads form them first -- thread (k', j, r) one column of G_{k',j}
         // (G[c][r] = sum_{m >= c} L_{k'+j,k'}[r][m] L_k'k'^-1[m][c]) from the factor store, into LDS by the step k = k' + j that uses it.
         const int per_step = hb * 36, cap = (B.lds_bytes - (3 * n + 36 * nb) * 8) / (per_step * 8);
+        const int kfac = (tw && side) ? own : nb;              // columns this side has factored (side 1: not the middle)
         const int lane = tid, s_ = lane / 6, c_ = lane - 6 * s_;
         const bool act = tid < hb1 * 6;
         auto linv_times = [&](const double *Li, const double (&o)[6], double (&gq)[6]) {       // gq[c] = sum_{m >= c} o[m] L^-1[m][c]
@@ -1253,7 +1326,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
             }
         };
         long long trb0 = B.trace ? clock64() : 0;
-        for (int k = tid; k < nb; k += BS_T) {
+        for (int k = tid; k < kfac; k += BS_T) {
             double o[6], gq[6];
 #pragma unroll
             for (int m = 0; m < 6; m++) o[m] = x[6 * k + m];
@@ -1274,9 +1347,9 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                 for (int b = 0; b < 3; b++) {
                     const int e = e0 + b * BS_T;
                     const int blk = e / 6, r = e - 6 * blk, st = blk / hb, j = blk - st * hb + 1, kp = ka + st - j;
-                    const bool ok = e < tot && kp >= 0;
+                    const bool ok = e < tot && kp >= 0 && kp < kfac;
                     ob[b] = ok ? blk * 36 + r : -1; kq[b] = ok ? kp : 0;
-                    ld_rec<6>(B.Lg + (size_t)kq[b] * lgs + (ok ? j * 36 + r * 6 : 0), o[b]);
+                    ld_rec<6>(Lg + (size_t)kq[b] * lgs + (ok ? j * 36 + r * 6 : 0), o[b]);
                 }
 #pragma unroll
                 for (int b = 0; b < 3; b++) {
@@ -1288,20 +1361,29 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                 }
             }
             __syncthreads();
+            if (tw && side && kb == nb) {
+                // the middle poses are the other side's: wait for their dp, enter it where this side's recurrence expects chat (their
+                // running sums stay zero: `on` below never selects a middle column)
+                if (tid == 0) while (__hip_atomic_load(B.fail + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != B.epoch) __builtin_amdgcn_s_sleep(8);
+                __syncthreads();
+                __threadfence();
+                for (int e = tid; e < hb * 6; e += BS_T) chat[6 * own + e] = __builtin_nontemporal_load(d.dp + 6 * gi(own + e / 6) + e % 6);
+                __syncthreads();
+            }
             if (B.trace && tid == 0) { const long long t_ = clock64(); B.trace[11] = t_ - trb0; trb0 = t_; }
             if (tid < 64) {
                 // two steps per trip with the roles of the two register sets swapped: the rows / chat entries of the next step are
                 // requested before this step's chain and nothing waits for them until they are used
                 auto load_next = [&](int k, int ksl, double (&gg)[6], double &cc, bool &on) {   // for step k: row c_ of G_{k', k - k'}, chat_k
                     int j = ksl - s_; if (j < 0) j += hb1;
-                    on = act && j > 0 && k - j >= 0;
+                    on = act && j > 0 && k - j >= 0 && k - j < kfac;
                     const double *gp = Gs + ((size_t)(on ? k - ka : 0) * hb + (on ? j - 1 : 0)) * 36 + (act ? c_ : 0) * 6;
                     ld_rec<6>(gp, gg);
                     cc = chat[6 * k + (act ? c_ : 0)];
                 };
                 auto step = [&](int k, int ksl, const double (&gg)[6], double cc, bool on) {
-                    const bool own = act && s_ == ksl;
-                    const double v = own ? base + cc : base;          // dp_k on the lanes of its slot
+                    const bool mine = act && s_ == ksl;
+                    const double v = mine ? base + cc : base;         // dp_k on the lanes of its slot
                     double dv[6];
 #pragma unroll
                     for (int m = 0; m < 6; m++) {
@@ -1310,8 +1392,15 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                         dv[m] = __hiloint2double(hi, lo);
                     }
                     const double t = fma(gg[2], dv[2], fma(gg[1], dv[1], gg[0] * dv[0])) + fma(gg[5], dv[5], fma(gg[4], dv[4], gg[3] * dv[3]));
-                    if (own) x[6 * k + c_] = v;
-                    base = own ? 0.0 : (on ? base - t : base);
+                    if (mine) x[6 * k + c_] = v;
+                    base = mine ? 0.0 : (on ? base - t : base);
+                    if (tw && side == 0 && k >= own) {               // the middle: the other side waits for these
+                        if (mine) d.dp[6 * k + c_] = v;
+                        if (k == own) {
+                            __threadfence();
+                            if (lane == 0) __hip_atomic_store(B.fail + 2, B.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
                 };
                 // three register sets in rotation: the rows / chat entry of step k - 2 are requested at the start of step k
                 auto dec = [&](int q) { return q == 0 ? hb : q - 1; };
@@ -1376,8 +1465,8 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
         bs_barrier();
     }
     }
-    for (int a = tid; a < n; a += BS_T) d.dp[a] = x[a];
-    if (tid == 0) { *B.fail = s_bad; if (s_bad) d.st->chol_fail = 1; }
+    for (int a = tid; a < 6 * kfac2; a += BS_T) d.dp[6 * gi(a / 6) + a % 6] = x[a];
+    if (tid == 0) { if (!tw || side == 0) *B.fail = s_bad; if (s_bad) d.st->chol_fail = 1; }
     if (B.trace && tid == BS_UT) B.trace[8] = trA;
     if (B.trace && tid == BS_UT + 64) B.trace[9] = trA;
     if (B.trace && tid == 0) { B.trace[0] = tr0; B.trace[1] = trP1; B.trace[2] = trP2; B.trace[3] = clock64() - trT; B.trace[4] = trA; B.trace[5] = trB; B.trace[6] = trC; B.trace[7] = trD; }
@@ -1793,6 +1882,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     const size_t o_band = take((size_t)P * ((size_t)(BS_MAXHB + 1) * 36 + 8) * 8);
     const size_t o_ptid = take((size_t)M * 4 + 4), o_opk = take((size_t)O * 4 + 4), o_grp = take((size_t)ngrp * 16 + 16), o_fgrp = take((size_t)(P + 1) * 4);
     const size_t o_wpart = take((size_t)ngrp * wstride * 8 + 8);
+    const size_t o_xchg = take(2048 * 8);
     char *A;
     hipError_t e = hipMalloc((void **)&A, off);
     if (e != hipSuccess) { delete ba; return slam_fail(ctx, SLAM_ERR_HIP, "slam_ba: hipMalloc(%zu): %s", off, hipGetErrorString(e)); }
@@ -1815,6 +1905,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     d.pt_id = (const int *)(A + o_ptid); d.opk = (const int *)(A + o_opk); d.grp = (const int4 *)(A + o_grp); d.fgrp = (const int *)(A + o_fgrp);
     d.ngrp = ngrp; d.whb = hb; d.wstride = wstride; d.wpart = (double *)(A + o_wpart);
     ba->nparts = grouped ? ngrp : ba->nblocks_obs;
+    ba->xchg = (double *)(A + o_xchg);
     hipStream_t st = ctx->stream;
 #define UP(dst, src, bytes) do { if ((bytes) > 0) HIP_TRY(ctx, hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
     UP(d.pose, theta, (size_t)n * 8); UP(d.pts, theta + n, (size_t)3 * M * 8);
@@ -1825,6 +1916,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
 #undef UP
     HIP_TRY(ctx, hipMemsetAsync(d.outl, 0, (size_t)O + 1, st));
     HIP_TRY(ctx, hipMemsetAsync(d.st, 0, sizeof(LMState), st));
+    HIP_TRY(ctx, hipMemsetAsync(ba->chol_flag, 0, 64, st));
     HIP_TRY(ctx, slam_stream_wait(st));   // host vectors go out of scope
     guard.b = nullptr;
     *out = ba;
@@ -1874,6 +1966,9 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
     if (!no_band && hb <= BS_MAXHB && band_lds <= 150 * 1024) {
         BandArgs B; B.S = red; B.g = red + (size_t)n * n; B.ud = red + (size_t)n * n + n; B.Lg = ba->band; B.nb = d.P; B.hb = hb;
         B.inv_delta_host = inv_delta; B.fail = ba->chol_flag; B.lds_bytes = (int)band_lds;
+        B.xchg = ba->xchg; B.epoch = ++ba->epoch;
+        static const bool no_twist = getenv("SLAMHIP_NO_TWIST") != nullptr;
+        const bool twist = !no_twist && hb * 6 <= 58 && d.P >= 3 * (hb + 1);
         static long long *trace_dev = nullptr; static int trace_n = 0;
         static const bool trace_on = getenv("SLAMHIP_BAND_TRACE") != nullptr;
         if (trace_on && !trace_dev) (void)hipHostMalloc((void **)&trace_dev, 128);
@@ -1881,7 +1976,7 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
         if (trace_on && trace_n++ == 8) { (void)hipStreamSynchronize(st); fprintf(stderr, "band trace (cycles): P1 barrier wait %lld P2 barrier wait %lld backsub %lld | potrf+inv %lld panel %lld update %lld put/fetch %lld | factor wave %lld prefetch wave %lld | backsub: chat %lld G %lld recurrence %lld\n", trace_dev[1], trace_dev[2], trace_dev[3], trace_dev[4], trace_dev[5], trace_dev[6], trace_dev[7], trace_dev[8], trace_dev[9], trace_dev[10], trace_dev[11], trace_dev[12]); }
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-        hipLaunchKernelGGL(k_band_solve, dim3(1), dim3(BS_T), band_lds, st, d, B, use_state);
+        hipLaunchKernelGGL(k_band_solve, dim3(twist ? 2 : 1), dim3(BS_T), band_lds, st, d, B, use_state);
     } else {
         CholArgs C; C.A = d.Swork; C.Lf = ba->lfac; C.n = n; C.ld = n + 1; C.fail = ba->chol_flag;
         const size_t tot = (size_t)(n + 1) * n;
