@@ -107,6 +107,14 @@ def test_ba_wide_windows_fall_back_to_pair_lists_and_the_tiled_solve(slam, orc, 
     _ba_vs_oracle(slam, orc, s3, "many observers")
 
 
+def test_ba_twisted_factorisation_split_sizes(slam, orc, syn):
+    """Windows of >= 3 (hb + 1) poses are factored from both ends (two workgroups, hb middle poses merged): the smallest such window,
+    odd / even splits, and a narrower band (6 observers: hb = 5, twisted from 18 poses on)."""
+    for P, opp in ((30, 10), (31, 10), (33, 10), (18, 6), (23, 6)):
+        s = syn.ba_scene(P=P, M=40 * P, seed=100 + P, obs_per_point=opp)
+        _ba_vs_oracle(slam, orc, s, (P, opp))
+
+
 def test_error_paths(slam, texture):
     ctx = slam.default_context(0)
     with pytest.raises(slam.SlamHipError):
