@@ -1037,6 +1037,7 @@ def main():
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----------
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import oracle as orc
+        cpu_flags = orc.use_native() or "-O2 -ffp-contract=off"       # -O3 -march=native, compiled on this host
         threads = max(1, min(4, os.cpu_count() or 1))                 # the reference recommends -t4 (docs/src/index.md:60-64)
         cbe = CpuBackend(orc, left, right, params, extractor, threads)
         cs = Stream(cbe, flows, disparity, seed=0)
@@ -1048,7 +1049,7 @@ def main():
         cdt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": n_cpu / cdt, "unit": "frames/sec", "cores": threads, "kind": "port",
                                "sample": f"first {n_cpu} frames of the same stream (incl. {1 + (n_cpu - 1) // KF_EVERY} key-frames) through the C oracle "
-                                         f"(-O2 -ffp-contract=off; LK loop OpenMP x{threads}, pyramid/detect single-threaded like the reference); "
+                                         f"({cpu_flags}; LK loop OpenMP x{threads}, pyramid/detect single-threaded like the reference); "
                                          f"host has {os.cpu_count()} cores"}
         if not args.no_ba:
             s = syn.ba_scene(P=50, M=10000, seed=7)

@@ -33,6 +33,24 @@ def build(force=False):
     return so
 
 
+def use_native():
+    """Switch this process to an -O3 -march=native build of the same sources, compiled here into a temporary directory (bench.py's
+    cpu_baseline leg; a host-specific binary must not travel with the tree).  Returns the flags used, or None if it did not build."""
+    global _LIB
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), f"libslam_oracle_native_{os.getuid()}.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native", f"NATIVE_OUT={out}"])
+        l = C.CDLL(out)
+    except (subprocess.CalledProcessError, OSError):
+        return None
+    l.orc_bilinear.restype = C.c_double
+    l.orc_bilinear.argtypes = [f64p, C.c_int, C.c_int, C.c_double, C.c_double]
+    l.orc_pyr_layout.restype = C.c_int64
+    _LIB = l
+    return "-O3 -march=native -ffp-contract=off -fno-fast-math"
+
+
 def lib():
     global _LIB
     if _LIB is None:
