@@ -135,6 +135,7 @@ int slam_ctx_create_cumask(int device, const uint32_t *cu_mask, int n_words, sla
     c->device = device;
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)n_words, cu_mask);
+    for (int w = 0; w < n_words; w++) c->cus += __builtin_popcount(cu_mask[w]);
     if (e != hipSuccess) { delete c; return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create_cumask: %s", hipGetErrorString(e)); }
     *out = c;
     return SLAM_OK;
