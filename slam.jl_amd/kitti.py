@@ -5,8 +5,8 @@ bytes/255 conversion happens on the GPU instead, bit-identical).
 
 `KittyDataset(base_dir, sequence, stereo=True)` keeps the reference's fields (K, Ti0, poses, timestamps, frame
 directories) and indexing (`dataset[i]` -> (left, right); 0-based here, 1-based in Julia).  `write_poses` emits the
-KITTI pose text format (12 numbers per line), the dataset's own interchange format; the reference's ReplaySaver BSON
-(src/io/saver.jl) is a visualiser dump, not reproduced."""
+KITTI pose text format (12 numbers per line), the dataset's own interchange format; the reference's ReplaySaver
+(src/io/saver.jl) is mirrored in saver.py."""
 import os
 import struct
 import zlib

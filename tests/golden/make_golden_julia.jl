@@ -107,6 +107,13 @@ for (i, b) in enumerate(desc), k in 0:(d.size - 1)
 end
 out["brief_pattern"] = pat; out["brief_bits"] = bits; out["brief_rc"] = to_mat(kept)
 
+# ---- ReplaySaver (src/io/saver.jl): three frames, one of them set twice; slam.jl_amd/saver.py mirrors it (BSON lowering unpinned)
+saver = SLAM.ReplaySaver()
+wc(t) = SMatrix{4, 4, Float64, 16}([1.0 0 0 t[1]; 0 1 0 t[2]; 0 0 1 t[3]; 0 0 0 1])
+SLAM.set_frame_wc!(saver, 7, wc((1.0, 2.0, 3.0))); SLAM.set_frame_wc!(saver, 9, wc((-4.0, 0.5, 6.0)))
+SLAM.set_frame_wc!(saver, 7, wc((1.5, 2.5, 3.5))); SLAM.set_frame_wc!(saver, 12, wc((0.0, 0.0, 10.0)))
+SLAM.save(saver, joinpath(dir, "julia_replay"))
+
 out["versions"] = [string(VERSION)]
 npzwrite(joinpath(dir, "julia_v1.npz"), Dict(k => (v isa Vector{String} ? codeunits(join(v, ";")) |> collect : v) for (k, v) in out))
 println("wrote ", joinpath(dir, "julia_v1.npz"), ": ", size(out["kp_nomask"], 1), " keypoints, ", sum(status), " tracked")

@@ -1,0 +1,60 @@
+"""CPU: ReplaySaver mirror (slam.jl_amd/saver.py <-> src/io/saver.jl): the set_frame_wc! rules, a save / load round trip, the error
+exits of load!, the BSON container, and -- when a maintainer has run tests/golden/make_golden_julia.jl -- the files BSON.jl wrote."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+
+def _wc(t):
+    T = np.eye(4); T[:3, 3] = t
+    return T
+
+
+def _fill(s):
+    s.set_frame_wc(7, _wc((1.0, 2.0, 3.0))); s.set_frame_wc(9, _wc((-4.0, 0.5, 6.0)))
+    s.set_frame_wc(7, _wc((1.5, 2.5, 3.5))); s.set_frame_wc(12, _wc((0.0, 0.0, 10.0)))
+
+
+def test_set_frame_wc_rules(slam_host):
+    s = slam_host.ReplaySaver()
+    _fill(s)
+    assert s.ids == {7: 1, 9: 2, 12: 3}                                   # 1-based position ids, first-seen order (saver.jl:47-53)
+    P = np.asarray(s.positions)
+    assert P.dtype == np.float32 and P.shape == (3, 3)
+    assert np.array_equal(P, np.array([[1.5, 3.5, 2.5], [-4.0, 6.0, 0.5], [0.0, 10.0, 0.0]], np.float32))     # (x, z, y), frame 7 overwritten
+    R = np.array([[0.0, -1, 0], [1, 0, 0], [0, 0, 1]]); T = np.eye(4); T[:3, :3] = R; T[:3, 3] = (3.0, 4.0, 5.0)
+    s.set_frame_wc(1, T)                                                   # only the translation column matters: wc * [0 0 0 1]
+    assert np.array_equal(s.positions[-1], np.array([3.0, 5.0, 4.0], np.float32))
+
+
+def test_save_load_round_trip_and_errors(slam_host, tmp_path):
+    s = slam_host.ReplaySaver(); _fill(s)
+    d = str(tmp_path / "replay")
+    s.save(d)
+    assert sorted(os.listdir(d)) == ["ids.bson", "positions.bson"]
+    t = slam_host.ReplaySaver().load(d)
+    assert t.ids == s.ids and np.array_equal(np.asarray(t.positions), np.asarray(s.positions))
+    # the container: a BSON document is <int32 total size> ... <0x00>, and the float payload is the raw little-endian array
+    raw = open(os.path.join(d, "positions.bson"), "rb").read()
+    assert struct.unpack("<i", raw[:4])[0] == len(raw) and raw[-1] == 0
+    assert np.asarray(s.positions, "<f4").tobytes() in raw
+    with pytest.raises(FileNotFoundError):
+        slam_host.ReplaySaver().load(str(tmp_path / "nowhere"))
+    os.remove(os.path.join(d, "ids.bson"))
+    with pytest.raises(FileNotFoundError):
+        slam_host.ReplaySaver().load(d)
+    # an empty saver round-trips too
+    e = str(tmp_path / "empty"); slam_host.ReplaySaver().save(e)
+    z = slam_host.ReplaySaver().load(e)
+    assert z.ids == {} and len(z.positions) == 0
+
+
+def test_files_written_by_julia_when_present(slam_host):
+    d = os.path.join(os.path.dirname(__file__), "golden", "julia_replay")
+    if not os.path.isdir(d):
+        pytest.skip("tests/golden/julia_replay absent: run tests/golden/make_golden_julia.jl with Julia + SLAM.jl to pin the BSON lowering")
+    t = slam_host.ReplaySaver().load(d)
+    s = slam_host.ReplaySaver(); _fill(s)
+    assert t.ids == s.ids and np.array_equal(np.asarray(t.positions), np.asarray(s.positions))
