@@ -1,5 +1,4 @@
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-timeout 900 python bench.py > gpurun_out/bench_plain.json 2> gpurun_out/bench_plain.err; echo plain rc $?
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o bench -- python3 bench.py --no-cpu > gpurun_out/bench_profiled.json 2> gpurun_out/bench_profiled.err; echo prof rc $?
-ls gpurun_out/prof_bench | head
+SLAMHIP_LIB=$GRAFT_REPO_ROOT/slam.jl_amd/libslamhip_sgt.so timeout 120 python scripts/prof_ba.py 2>&1 | tail -2
+timeout 60 python scripts/prof_ba.py 2>&1 | tail -2
+timeout 60 python scripts/prof_ba.py 100 40000 | tail -1
+timeout 900 python -m pytest $(grep -ln "local_ba\|bundle_adjustment\|ShardedBA\|slam_ba" tests/test_gpu*.py) -x -q 2>&1 | tail -8

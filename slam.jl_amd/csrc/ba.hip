@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void k_blocks(BADev d, int use_state)
 static size_t sg_lds_bytes(int whb)
 {
     const int hbw = whb + 1, nwin = hbw * (hbw + 1) / 2;
-    return (((size_t)SG_OB * 36 + (size_t)SG_SB * 10 + 8) * 8 + (size_t)SG_SB * hbw * 2 + (size_t)nwin * 2 + 15) & ~(size_t)15;
+    return ((((size_t)SG_OB * 36 + (size_t)SG_SB * 10 + 8) * 8 + (size_t)SG_SB * hbw * 2 + (size_t)nwin * 2 + 15) & ~(size_t)15) + (size_t)hbw * 36 * 8 + 16;
 }
 
 // sum over NS adjacent lanes (NS a power of two, uniform): DPP moves up to 16 lanes -- a ds_bpermute butterfly of the 36 block
@@ -396,14 +396,22 @@ __device__ __forceinline__ double sg_fold(double v, int NS)
 }
 
 #ifdef SG_TRACE
-#define SG_CLK_DECL long long sg_clk[8]; const long long sg_t0 = clock64()
+#define SG_CLK_DECL long long sg_clk[12]; const long long sg_t0 = clock64()
 #define SG_CLK(k) sg_clk[k] = clock64() - sg_t0
-#define SG_DUMP() do { if (threadIdx.x == 0 && blockIdx.x == 100 && d.st->iters == 3) printf("schur group: npts %d nobs %d | init %lld ph0 %lld bar %lld ph1 %lld ph2 %lld ph3 %lld tail %lld cycles\n", npts, nobs, sg_clk[0], sg_clk[1] - sg_clk[0], sg_clk[2] - sg_clk[1], sg_clk[3] - sg_clk[2], sg_clk[4] - sg_clk[3], sg_clk[5] - sg_clk[4], sg_clk[6] - sg_clk[5]); } while (0)
+#define SG_DUMP() do { if (threadIdx.x == 0 && blockIdx.x == 100 && d.st->iters == 3) printf("schur group: npts %d nobs %d | init %lld ph0 %lld bar %lld ph1 %lld ph2 %lld ph3 %lld bar %lld fold %lld tail %lld cycles\n", npts, nobs, sg_clk[0], sg_clk[1] - sg_clk[0], sg_clk[2] - sg_clk[1], sg_clk[3] - sg_clk[2], sg_clk[4] - sg_clk[3], sg_clk[8] - sg_clk[4], sg_clk[9] - sg_clk[8], sg_clk[5] - sg_clk[9], sg_clk[6] - sg_clk[5]); } while (0)
 #else
 #define SG_CLK_DECL
 #define SG_CLK(k)
 #define SG_DUMP()
 #endif
+// the fold buffers of phase 3 (the partial blocks and slot rows of the subsets 1 .. NS - 1) overlay everything below s_dg
+static bool sg_fold_fits(int whb)
+{
+    const int hbw = whb + 1, nwin = hbw * (hbw + 1) / 2, LPS = (nwin + 63) & ~63, NS = SG_T / LPS;
+    const size_t dg_off = (((size_t)SG_OB * 36 + (size_t)SG_SB * 10 + 8) * 8 + (size_t)SG_SB * hbw * 2 + (size_t)nwin * 2 + 15) & ~(size_t)15;
+    return NS >= 1 && ((size_t)(NS - 1) * nwin * 36 + (size_t)(NS - 1) * hbw * 6 * 7) * 8 <= dg_off;
+}
+
 __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta_host, int ignore_outliers, int use_state)
 {
     extern __shared__ __attribute__((aligned(16))) double sg_lds[];
@@ -420,6 +428,7 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
     double *s_red = s_pt + SG_SB * 10;             // [8]
     short *s_slot = (short *)(s_red + 8);          // [SG_SB][hbw]  observation (index in the group) of point x in window slot y, or -1
     unsigned char *s_ab = (unsigned char *)(s_slot + SG_SB * hbw);   // [nwin][2]
+    double *s_dg = sg_lds + (((((size_t)SG_OB * 36 + (size_t)SG_SB * 10 + 8) * 8 + (size_t)SG_SB * hbw * 2 + (size_t)nwin * 2 + 15) & ~(size_t)15) >> 3);   // [hbw][36] Jp'Jp per window slot
     for (int x = tid; x < npts * hbw; x += SG_T) s_slot[x] = -1;
     for (int w = tid; w < nwin; w += SG_T) {
         int a = 0, r = w;
@@ -512,57 +521,90 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
     __syncthreads();
     SG_CLK(4);
     double *out = d.wpart + (size_t)blockIdx.x * d.wstride;
-    // ---- phase 3: thread = (window block w, point subset s): NS adjacent lanes share a block and take every NS-th point; the
-    //      whole 6 x 6 block stays in registers (42 LDS doubles per 162 fused multiply-adds), the subsets are folded by a
-    //      butterfly (fixed order).  The diagonal blocks also carry Jp'Jp, the gradient and diag(U) of their slot.
+    // ---- phase 3: the window blocks.  A wave (a run of LPS lanes) is one point subset: its lanes are the blocks, all on the same
+    //      point at the same time -- V^-1 and the slot row are broadcast reads, the W_a rows are shared by up to hb + 1 lanes, the
+    //      W_b rows of neighbouring lanes are neighbouring records (conflict-free b128 reads).  The whole 6 x 6 block stays in
+    //      registers (42 LDS doubles per 162 fused multiply-adds).  The first 6 (hb + 1) lanes of a subset then take one row of
+    //      Jp'Jp and one gradient entry of a window slot each.  The subsets are folded through LDS in subset order by subset 0.
     {
-        int NS = 1, ls = 0;
-        while (NS < 64 && nwin * NS * 2 <= SG_T) { NS *= 2; ls++; }
-        const int w = tid >> ls, sub = tid & (NS - 1);
-        const bool live = w < nwin;
+        const int LPS = (nwin + 63) & ~63, NS = SG_T / LPS;                        // 8 subsets for hb <= 9, 4 up to 14, 2 up to 20
+        const int sub = tid / LPS, w = tid - sub * LPS;
+        const bool live = w < nwin, xl = w < hbw * 6;
         const int a = s_ab[live ? 2 * w : 0], b = s_ab[live ? 2 * w + 1 : 1];
-        double acc[36], gg[6], ud[6];
+        const int a2 = xl ? w / 6 : 0, r2 = w - 6 * (w / 6);
+        double acc[36], ex[7];
 #pragma unroll
         for (int k = 0; k < 36; k++) acc[k] = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; k++) { gg[k] = 0.0; ud[k] = 0.0; }
-        for (int x = sub; x < npts; x += NS) {
-            const int ta = s_slot[x * hbw + a], tb = s_slot[x * hbw + b];
-            if (ta < 0 || tb < 0) continue;
-            double Vi[6], Wa[18], Wb[18], T[18];
-            ld_rec<6>(s_pt + x * 10, Vi); ld_rec<18>(s_W + ta * 18, Wa); ld_rec<18>(s_W + tb * 18, Wb);
-#pragma unroll
-            for (int r = 0; r < 6; r++) {
-                T[3 * r] = fma(Wa[3 * r + 2], Vi[2], fma(Wa[3 * r + 1], Vi[1], Wa[3 * r] * Vi[0]));
-                T[3 * r + 1] = fma(Wa[3 * r + 2], Vi[4], fma(Wa[3 * r + 1], Vi[3], Wa[3 * r] * Vi[1]));
-                T[3 * r + 2] = fma(Wa[3 * r + 2], Vi[5], fma(Wa[3 * r + 1], Vi[4], Wa[3 * r] * Vi[2]));
-            }
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-                for (int c = 0; c < 6; c++)
-                    acc[6 * r + c] = fma(-T[3 * r + 2], Wb[3 * c + 2], fma(-T[3 * r + 1], Wb[3 * c + 1], fma(-T[3 * r], Wb[3 * c], acc[6 * r + c])));
-            if (a == b) {
-                double J[12], gv[6];
-                ld_rec<12>(s_Jp + ta * 12, J); ld_rec<6>(s_g + ta * 6, gv);
+        for (int k = 0; k < 7; k++) ex[k] = 0.0;
+        if (live)
+            for (int x = sub; x < npts; x += NS) {
+                const int ta = s_slot[x * hbw + a], tb = s_slot[x * hbw + b];
+                if (ta < 0 || tb < 0) continue;
+                double Vi[6], Wa[18], Wb[18], T[18];
+                ld_rec<6>(s_pt + x * 10, Vi); ld_rec<18>(s_W + ta * 18, Wa); ld_rec<18>(s_W + tb * 18, Wb);
 #pragma unroll
                 for (int r = 0; r < 6; r++) {
-#pragma unroll
-                    for (int c = 0; c < 6; c++) acc[6 * r + c] = fma(J[6 + r], J[6 + c], fma(J[r], J[c], acc[6 * r + c]));
-                    gg[r] += gv[r];
-                    ud[r] = fma(J[6 + r], J[6 + r], fma(J[r], J[r], ud[r]));
+                    T[3 * r] = fma(Wa[3 * r + 2], Vi[2], fma(Wa[3 * r + 1], Vi[1], Wa[3 * r] * Vi[0]));
+                    T[3 * r + 1] = fma(Wa[3 * r + 2], Vi[4], fma(Wa[3 * r + 1], Vi[3], Wa[3 * r] * Vi[1]));
+                    T[3 * r + 2] = fma(Wa[3 * r + 2], Vi[5], fma(Wa[3 * r + 1], Vi[4], Wa[3 * r] * Vi[2]));
                 }
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++)
+                        acc[6 * r + c] = fma(-T[3 * r + 2], Wb[3 * c + 2], fma(-T[3 * r + 1], Wb[3 * c + 1], fma(-T[3 * r], Wb[3 * c], acc[6 * r + c])));
+            }
+        if (xl)
+            for (int x = sub; x < npts; x += NS) {
+                const int ta = s_slot[x * hbw + a2];
+                if (ta < 0) continue;
+                double J[12];
+                ld_rec<12>(s_Jp + ta * 12, J);
+                const double j0 = r2 == 0 ? J[0] : r2 == 1 ? J[1] : r2 == 2 ? J[2] : r2 == 3 ? J[3] : r2 == 4 ? J[4] : J[5];
+                const double j1 = r2 == 0 ? J[6] : r2 == 1 ? J[7] : r2 == 2 ? J[8] : r2 == 3 ? J[9] : r2 == 4 ? J[10] : J[11];
+#pragma unroll
+                for (int c = 0; c < 6; c++) ex[c] = fma(j1, J[6 + c], fma(j0, J[c], ex[c]));
+                ex[6] += s_g[ta * 6 + r2];
+            }
+        SG_CLK(8);
+        __syncthreads();                                           // every read of W / Jp / g / V^-1 / the slots is done: the region becomes the fold buffer
+        SG_CLK(9);
+        double *fold = sg_lds, *efold = sg_lds + (size_t)(NS - 1) * nwin * 36;
+        if (sub >= 1) {
+            if (live) st_rec<36>(fold + ((size_t)(sub - 1) * nwin + w) * 36, acc);
+            if (xl) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) efold[((size_t)(sub - 1) * hbw * 6 + w) * 7 + k] = ex[k];
             }
         }
+        __syncthreads();
+        if (sub == 0) {
+            if (live)
+                for (int q = 0; q < NS - 1; q++) {
+                    double o[36];
+                    ld_rec<36>(fold + ((size_t)q * nwin + w) * 36, o);
 #pragma unroll
-        for (int k = 0; k < 36; k++) acc[k] = sg_fold(acc[k], NS);
-        if (a == b) {
+                    for (int k = 0; k < 36; k++) acc[k] += o[k];
+                }
+            if (xl) {
+                for (int q = 0; q < NS - 1; q++) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) { gg[k] = sg_fold(gg[k], NS); ud[k] = sg_fold(ud[k], NS); }
+                    for (int k = 0; k < 7; k++) ex[k] += efold[((size_t)q * hbw * 6 + w) * 7 + k];
+                }
+#pragma unroll
+                for (int c = 0; c < 6; c++) s_dg[a2 * 36 + r2 * 6 + c] = ex[c];
+                const double ud = r2 == 0 ? ex[0] : r2 == 1 ? ex[1] : r2 == 2 ? ex[2] : r2 == 3 ? ex[3] : r2 == 4 ? ex[4] : ex[5];
+                out[nwin * 36 + a2 * 12 + r2] = ex[6]; out[nwin * 36 + a2 * 12 + 6 + r2] = ud;
+            }
         }
+        __syncthreads();
         if (live && sub == 0) {
+            if (a == b) {
+#pragma unroll
+                for (int k = 0; k < 36; k++) acc[k] += s_dg[a * 36 + k];
+            }
             st_rec<36>(out + w * 36, acc);
-            if (a == b) { st_rec<6>(out + nwin * 36 + a * 12, gg); st_rec<6>(out + nwin * 36 + a * 12 + 6, ud); }
         }
     }
     SG_CLK(5);
@@ -1804,7 +1846,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
           } }
     // --- point groups of k_schur_groups: same f, <= SG_SB points, <= SG_OB observations; evenly sized within one f
     static const bool no_groups = getenv("SLAMHIP_NO_GROUPS") != nullptr;
-    bool grouped = !no_groups && hb <= BS_MAXHB && M > 0 && O > 0;
+    bool grouped = !no_groups && hb <= BS_MAXHB && M > 0 && O > 0 && sg_fold_fits(hb);
     std::vector<int4> grp; std::vector<int> fgrp(P + 1, 0);
     if (grouped) {
         int k = 0;
