@@ -115,6 +115,19 @@ def test_ba_twisted_factorisation_split_sizes(slam, orc, syn):
         _ba_vs_oracle(slam, orc, s, (P, opp))
 
 
+def test_ba_two_workgroup_solve_is_deterministic(slam, syn):
+    """The two sides of the twisted factorisation hand data over through global memory (release / acquire flags carrying the launch
+    epoch): the same window solved repeatedly must give bit-identical parameters, outliers and cost (scripts/ba_repeat.py runs more)."""
+    s = syn.ba_scene(P=40, M=3000, seed=3)
+    ref = None
+    for _ in range(40):
+        cache = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+        slam.bundle_adjustment_(cache, s["cam"])
+        key = (cache.theta.tobytes(), cache.outliers.tobytes(), cache.stats["ssr_final"])
+        ref = ref or key
+        assert key == ref
+
+
 def test_error_paths(slam, texture):
     ctx = slam.default_context(0)
     with pytest.raises(slam.SlamHipError):
