@@ -19,7 +19,8 @@
 #     ...
 #
 # NOTE: like SLAMHip.jl, written against the Julia manual and include/slamhip.h, never executed (no Julia in the build
-# container).  Every ccall below names its C prototype's line in slamhip.h so that a maintainer can check it by inspection.
+# container).  Every ccall mirrors the prototype of the same name in include/slamhip.h, argument for argument, so that a maintainer
+# can check it by inspection.
 module SLAMHipStreams
 
 import ..SLAMHip: LIB, ctx, check
