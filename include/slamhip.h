@@ -424,7 +424,9 @@ int    slam_ba_create(slam_ctx *ctx, double fx, double fy, double cx, double cy,
                       const int64_t *pose_ids, const int64_t *point_ids_local, slam_ba **out);
 int    slam_ba_destroy(slam_ba *ba);
 int64_t slam_ba_reduce_len(int P);
-/* linearise at the current theta and write the local contribution */
+/* linearise at the current theta and write the local contribution.  A shard keeps ONE reduce buffer for its lifetime: from the second
+ * build on only the blocks inside the band of the reduced system (and rhs / diag / ssr) are rewritten -- the rest of the buffer was
+ * zeroed by the first build and must not be written by anyone else (an in-place all-reduce keeps zeros zero). */
 int    slam_ba_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, double inv_delta, double *reduce_dev);
 /* solve the (all-reduced) system, back-substitute local points, evaluate the
  * trial step: writes [trial_ssr_local, predicted_ssr_local, max|dx| local, 0]
