@@ -81,9 +81,18 @@ __device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned 
     }
 }
 
+#ifdef DET_TRACE
+#define DT(k) do { __syncthreads(); dt_clk[k] = clock64() - dt_t0; } while (0)
+#else
+#define DT(k)
+#endif
 __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
 {
     extern __shared__ double lds[];
+#ifdef DET_TRACE
+    long long dt_clk[12]; const long long dt_t0 = clock64();
+    for (int q = 0; q < 12; q++) dt_clk[q] = 0;
+#endif
     // per-stream view of the arguments in locals: writing to the argument struct (or indexing its tap array with a lane
     // index) makes the compiler copy all 472 bytes of it to scratch and read every field back from there
     const double *a_img = A.img, *a_cur = A.cur;
@@ -123,6 +132,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         bA[i] = a_img[(size_t)(y0 + y) + (size_t)(x0 + x) * A.pitch];
     }
 
+    DT(0);
     // ---- avoidance mask (get_mask + imfilter(mask, Kernel.gaussian) + .*) ---
     if (a_ncur > 0) {
         const int hw = A.ntaps >> 1;
@@ -142,14 +152,23 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         // candidate keypoints: disk (+halo) touches the clamped tile region
         const int ylo = clampi(y0 - hw, 0, H - 1) + 1, yhi = clampi(y0 + h - 1 + hw, 0, H - 1) + 1; // 1-based
         const int xlo = clampi(x0 - hw, 0, W - 1) + 1, xhi = clampi(x0 + w - 1 + hw, 0, W - 1) + 1;
-        for (int k = tid; k < a_ncur; k += DET_THREADS) {
-            long py = (long)rint(a_cur[2 * k]), px = (long)rint(a_cur[2 * k + 1]);
-            if (py + r >= ylo && py - r <= yhi && px + r >= xlo && px - r <= xhi) {
-                int slot = atomicAdd(&s_ncand, 1);
-                if (slot < DET_MAXCAND) { s_cand[2 * slot] = (int)py; s_cand[2 * slot + 1] = (int)px; }
+        // (four keypoints per thread requested at once: one L2 round trip per 1024 keypoints instead of one per 256)
+        for (int k0 = tid; k0 < a_ncur; k0 += 4 * DET_THREADS) {
+            double2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int k = k0 + u * DET_THREADS; v[u] = ((const double2 *)a_cur)[k < a_ncur ? k : k0]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (k0 + u * DET_THREADS >= a_ncur) continue;
+                long py = (long)rint(v[u].x), px = (long)rint(v[u].y);
+                if (py + r >= ylo && py - r <= yhi && px + r >= xlo && px - r <= xhi) {
+                    int slot = atomicAdd(&s_ncand, 1);
+                    if (slot < DET_MAXCAND) { s_cand[2 * slot] = (int)py; s_cand[2 * slot + 1] = (int)px; }
+                }
             }
         }
         __syncthreads();
+        DT(1);
         const int ncand = s_ncand;
         const bool overflow = ncand > DET_MAXCAND;
         // raw mask over the halo'd tile (replicate = clamped coordinates) -> bB (as 0/1 doubles)
@@ -192,6 +211,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
                 m0[i] = m;
             }
         }
+        DT(2);
         __syncthreads();
         if (A.ntaps > 0) {
             // taps -> LDS once (indexing the kernel argument inside the tap loops costs a scalar load per tap)
@@ -210,6 +230,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     }
     __syncthreads();
 
+    DT(3);
     // ---- Images.shi_tomasi on the cell view (replicate border at cell edges) -
     // imgradients(cell, KernelFactors.sobel): g1 = (d/dy along dim 1, then (1,2,1)/4 along dim 2),
     // g2 = ((1,2,1)/4 along dim 1, then d/dx along dim 2); products -> bB, bC, bD
@@ -220,6 +241,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         bB[i] = g1 * g1; bC[i] = g1 * g2; bD[i] = g2 * g2;
     }
     __syncthreads();
+    DT(4);
     // 3x3 box mean of the products (1/3 x 1/3, two-pass arithmetic) and the min-eigenvalue response -> bA
     double *resp = bA;
     for (int i = tid; i < h * w; i += DET_THREADS) {
@@ -232,6 +254,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     }
     __syncthreads();
 
+    DT(5);
     // ---- findlocalmaxima: strict, 8-neighbourhood, edges included ------------
     unsigned char *flag = (unsigned char *)bB;                // 0: no, 1: maximum (candidate), 2: taken
     for (int i = tid; i < h * w; i += DET_THREADS) {
@@ -250,6 +273,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     if (tid == 0) s_cnt = 0;
     __syncthreads();
 
+    DT(6);
     // ---- top-k by response (stable: ties keep column-major order) ------------
     int *sel = (int *)bC;                                     // selected linear indices
     for (int round = 0; round < a_k; round++) {
@@ -281,6 +305,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         if (s_best == 0x7fffffff) break;
     }
 
+    DT(7);
     // ---- emit in column-major order (Keypoints(::Matrix{Bool}) = findall) ----
     if (tid == 0) {
         int cnt = s_cnt;
@@ -292,6 +317,10 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         }
         a_cell_cnt[cell] = cnt;
     }
+#ifdef DET_TRACE
+    DT(8);
+    if (tid == 0 && cell == 200 && blockIdx.y == 3) printf("detect cell: ncur %d k %d | tile %lld scan %lld raster %lld blur %lld grad %lld resp %lld lmax %lld topk %lld emit %lld cycles\n", a_ncur, a_k, dt_clk[0], dt_clk[1] - dt_clk[0], dt_clk[2] - dt_clk[1], dt_clk[3] - dt_clk[2], dt_clk[4] - dt_clk[3], dt_clk[5] - dt_clk[4], dt_clk[6] - dt_clk[5], dt_clk[7] - dt_clk[6], dt_clk[8] - dt_clk[7]);
+#endif
 }
 
 // Ordered compaction of the per-cell lists (cells row-major: extractor.jl:81):
