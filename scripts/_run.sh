@@ -1,2 +1,2 @@
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 900 python -m pytest $(grep -ln "local_ba\|bundle_adjustment\|ShardedBA\|slam_ba" tests/test_gpu*.py) -x -q 2>&1 | tail -3
+timeout 60 python scripts/prof_ba.py | tail -1

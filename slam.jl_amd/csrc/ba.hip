@@ -1916,7 +1916,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     const size_t o_f = take((size_t)2 * O * 8 + 8), o_ft = take((size_t)2 * O * 8 + 8);
     const size_t o_Jp = take((size_t)12 * O * 8 + 8), o_Jl = take((size_t)6 * O * 8 + 8);
     const size_t o_Vinv = take((size_t)6 * M * 8 + 8), o_bl = take((size_t)3 * M * 8 + 8);
-    const size_t o_T = take((size_t)18 * O * 8 + 8), o_W = take((size_t)18 * O * 8 + 8);
+    const size_t o_T = take(grouped ? 8 : (size_t)18 * O * 8 + 8), o_W = take(grouped ? 8 : (size_t)18 * O * 8 + 8);   // T / W records: pair-list path only
     const size_t o_pairs = take(npairs * 8 + 8), o_bs = take((size_t)(nblk + 1) * 4), o_bpq = take((size_t)nblk * 8 + 8);
     const size_t o_red = take(((size_t)n * n + 2 * n + 8) * 8), o_Sw = take((size_t)(n + 1) * n * 8), o_dp = take(n * 8), o_dl = take((size_t)3 * M * 8 + 8);
     const size_t o_cf = take(64), o_li = take((size_t)((n + CT - 1) / CT) * CT * CT * 8), o_lf = take((size_t)(n + 1) * n * 8);
