@@ -25,6 +25,7 @@
 // and a group's points are contiguous.
 #include "common.hpp"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 #define LM_MAX_DELTA 1e16
@@ -72,6 +73,7 @@ struct slam_ba {
     int device = 0;
     BADev d;
     void *arena = nullptr;       // one device allocation
+    bool owns_arena = true;      // false: the arena is the calling context's scratch (slam_local_ba)
     double *reduce = nullptr;    // internal reduce buffer (single-GPU path)
     int *chol_flag = nullptr;    // device flag: a pivot was not positive
     double *linv = nullptr;      // inverses of the factored diagonal tiles, nbc x 32 x 32
@@ -1794,7 +1796,7 @@ static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 
 static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, int P, int M, int O,
                     const double *theta, const uint8_t *theta_const, const double *pixels_yx,
-                    const int64_t *pose_ids, const int64_t *point_ids, slam_ba **out)
+                    const int64_t *pose_ids, const int64_t *point_ids, slam_ba **out, bool ctx_mem = false)
 {
     ARG_TRY(ctx, P > 0 && 6 * P <= SOLVE_MAX_N && M >= 0 && O >= 0 && theta != nullptr && theta_const != nullptr);
     ARG_TRY(ctx, O == 0 || (pixels_yx != nullptr && pose_ids != nullptr && point_ids != nullptr));
@@ -1910,26 +1912,37 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     // --- one device arena
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
-    const size_t o_pose = take(n * 8), o_pose_t = take(n * 8), o_pts = take((size_t)3 * M * 8 + 8), o_pts_t = take((size_t)3 * M * 8 + 8);
-    const size_t o_const = take(P), o_pix = take((size_t)2 * O * 8 + 8), o_opose = take((size_t)O * 4 + 4), o_opoint = take((size_t)O * 4 + 4);
-    const size_t o_start = take((size_t)(M + 1) * 4), o_outl = take((size_t)O + 1), o_hasp = take((size_t)O + 1);
+    // uploaded arrays first (one contiguous block: a single copy from the pinned staging buffer when the arena is the context's
+    // scratch), then the zero-initialised ones (one memset), then the rest
+    const size_t o_pose = take(n * 8), o_pts = take((size_t)3 * M * 8 + 8), o_const = take(P), o_pix = take((size_t)2 * O * 8 + 8);
+    const size_t o_opose = take((size_t)O * 4 + 4), o_opoint = take((size_t)O * 4 + 4), o_start = take((size_t)(M + 1) * 4);
+    const size_t o_ptid = take((size_t)M * 4 + 4), o_opk = take((size_t)O * 4 + 4), o_grp = take((size_t)ngrp * 16 + 16), o_fgrp = take((size_t)(P + 1) * 4);
+    const size_t o_pairs = take(npairs * 8 + 8), o_bs = take((size_t)(nblk + 1) * 4), o_bpq = take((size_t)nblk * 8 + 8);
+    const size_t up_end = off;
+    const size_t o_st = take(sizeof(LMState)), o_cf = take(64), o_outl = take((size_t)O + 1);
+    const size_t zero_end = off;
+    const size_t o_pose_t = take(n * 8), o_pts_t = take((size_t)3 * M * 8 + 8), o_hasp = take((size_t)O + 1);
     const size_t o_f = take((size_t)2 * O * 8 + 8), o_ft = take((size_t)2 * O * 8 + 8);
     const size_t o_Jp = take((size_t)12 * O * 8 + 8), o_Jl = take((size_t)6 * O * 8 + 8);
     const size_t o_Vinv = take((size_t)6 * M * 8 + 8), o_bl = take((size_t)3 * M * 8 + 8);
     const size_t o_T = take(grouped ? 8 : (size_t)18 * O * 8 + 8), o_W = take(grouped ? 8 : (size_t)18 * O * 8 + 8);   // T / W records: pair-list path only
-    const size_t o_pairs = take(npairs * 8 + 8), o_bs = take((size_t)(nblk + 1) * 4), o_bpq = take((size_t)nblk * 8 + 8);
     const size_t o_red = take(((size_t)n * n + 2 * n + 8) * 8), o_Sw = take((size_t)(n + 1) * n * 8), o_dp = take(n * 8), o_dl = take((size_t)3 * M * 8 + 8);
-    const size_t o_cf = take(64), o_li = take((size_t)((n + CT - 1) / CT) * CT * CT * 8), o_lf = take((size_t)(n + 1) * n * 8);
-    const size_t o_part = take(((size_t)std::max(ba->nblocks_pts, ngrp) + 2 * (size_t)std::max(ba->nblocks_obs, ngrp) + 8) * 8), o_st = take(sizeof(LMState));
+    const size_t o_li = take((size_t)((n + CT - 1) / CT) * CT * CT * 8), o_lf = take((size_t)(n + 1) * n * 8);
+    const size_t o_part = take(((size_t)std::max(ba->nblocks_pts, ngrp) + 2 * (size_t)std::max(ba->nblocks_obs, ngrp) + 8) * 8);
     const size_t o_band = take((size_t)P * ((size_t)(BS_MAXHB + 1) * 36 + 8) * 8);
-    const size_t o_ptid = take((size_t)M * 4 + 4), o_opk = take((size_t)O * 4 + 4), o_grp = take((size_t)ngrp * 16 + 16), o_fgrp = take((size_t)(P + 1) * 4);
     const size_t o_wpart = take((size_t)ngrp * wstride * 8 + 8);
     const size_t o_xchg = take(2048 * 8);
-    char *A;
-    hipError_t e = hipMalloc((void **)&A, off);
-    if (e != hipSuccess) { delete ba; return slam_fail(ctx, SLAM_ERR_HIP, "slam_ba: hipMalloc(%zu): %s", off, hipGetErrorString(e)); }
+    char *A = nullptr;
+    if (ctx_mem) {                                             // slam_local_ba: the context's grow-only scratch, no hipMalloc / hipFree per call
+        const int rcs = slam_scratch(ctx, off, (void **)&A);
+        if (rcs) { delete ba; return rcs; }
+        ba->owns_arena = false;
+    } else {
+        hipError_t e = hipMalloc((void **)&A, off);
+        if (e != hipSuccess) { delete ba; return slam_fail(ctx, SLAM_ERR_HIP, "slam_ba: hipMalloc(%zu): %s", off, hipGetErrorString(e)); }
+    }
     ba->arena = A;
-    struct Guard { slam_ba *b; ~Guard() { if (b) { if (b->arena) (void)hipFree(b->arena); delete b; } } } guard{ba};   // a failing upload frees the arena
+    struct Guard { slam_ba *b; ~Guard() { if (b) { if (b->arena && b->owns_arena) (void)hipFree(b->arena); delete b; } } } guard{ba};   // a failing upload frees the arena
     BADev &d = ba->d;
     d.cam = {fx, fy, cx, cy}; d.P = P; d.M = M; d.O = O; d.n = n;
     d.pose = (double *)(A + o_pose); d.pose_t = (double *)(A + o_pose_t); d.pts = (double *)(A + o_pts); d.pts_t = (double *)(A + o_pts_t);
@@ -1949,17 +1962,18 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     ba->nparts = grouped ? ngrp : ba->nblocks_obs;
     ba->xchg = (double *)(A + o_xchg);
     hipStream_t st = ctx->stream;
-#define UP(dst, src, bytes) do { if ((bytes) > 0) HIP_TRY(ctx, hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
-    UP(d.pose, theta, (size_t)n * 8); UP(d.pts, theta + n, (size_t)3 * M * 8);
-    UP(d.pconst, theta_const, (size_t)P); UP(d.pix, pix.data(), (size_t)2 * O * 8);
-    UP(d.opose, opose.data(), (size_t)O * 4); UP(d.opoint, opoint.data(), (size_t)O * 4); UP(d.pt_start, start.data(), (size_t)(M + 1) * 4);
-    UP(d.pairs, pairs.data(), npairs * 8); UP(d.blk_start, blk_start.data(), (size_t)(nblk + 1) * 4); UP(d.blk_pq, blk_pq.data(), (size_t)nblk * 8);
-    UP(d.pt_id, pt_id.data(), (size_t)M * 4); UP(d.opk, opk.data(), (size_t)O * 4); UP(d.grp, grp.data(), (size_t)ngrp * 16); UP(d.fgrp, fgrp.data(), (size_t)(P + 1) * 4);
+    char *stage = nullptr;
+    if (ctx_mem) { const int rcs = slam_pinned(ctx, up_end, (void **)&stage); if (rcs) return rcs; }
+#define UP(o, src, bytes) do { if ((bytes) > 0) { if (stage) memcpy(stage + (o), (src), (bytes)); else HIP_TRY(ctx, hipMemcpyAsync((void *)(A + (o)), (src), (bytes), hipMemcpyHostToDevice, st)); } } while (0)
+    UP(o_pose, theta, (size_t)n * 8); UP(o_pts, theta + n, (size_t)3 * M * 8);
+    UP(o_const, theta_const, (size_t)P); UP(o_pix, pix.data(), (size_t)2 * O * 8);
+    UP(o_opose, opose.data(), (size_t)O * 4); UP(o_opoint, opoint.data(), (size_t)O * 4); UP(o_start, start.data(), (size_t)(M + 1) * 4);
+    UP(o_pairs, pairs.data(), npairs * 8); UP(o_bs, blk_start.data(), (size_t)(nblk + 1) * 4); UP(o_bpq, blk_pq.data(), (size_t)nblk * 8);
+    UP(o_ptid, pt_id.data(), (size_t)M * 4); UP(o_opk, opk.data(), (size_t)O * 4); UP(o_grp, grp.data(), (size_t)ngrp * 16); UP(o_fgrp, fgrp.data(), (size_t)(P + 1) * 4);
 #undef UP
-    HIP_TRY(ctx, hipMemsetAsync(d.outl, 0, (size_t)O + 1, st));
-    HIP_TRY(ctx, hipMemsetAsync(d.st, 0, sizeof(LMState), st));
-    HIP_TRY(ctx, hipMemsetAsync(ba->chol_flag, 0, 64, st));
-    HIP_TRY(ctx, slam_stream_wait(st));   // host vectors go out of scope
+    if (stage) HIP_TRY(ctx, hipMemcpyAsync(A, stage, up_end, hipMemcpyHostToDevice, st));      // pinned -> device: one DMA, nothing to wait for
+    HIP_TRY(ctx, hipMemsetAsync(A + up_end, 0, zero_end - up_end, st));                         // LM state, flags, outlier marks
+    if (!stage) HIP_TRY(ctx, slam_stream_wait(st));   // pageable host vectors go out of scope
     guard.b = nullptr;
     *out = ba;
     return SLAM_OK;
@@ -2057,9 +2071,11 @@ extern "C" {
 int slam_ba_destroy(slam_ba *ba)
 {
     if (!ba) return SLAM_OK;
-    (void)hipSetDevice(ba->device);
-    (void)hipDeviceSynchronize();
-    if (ba->arena) (void)hipFree(ba->arena);
+    if (ba->owns_arena) {
+        (void)hipSetDevice(ba->device);
+        (void)hipDeviceSynchronize();
+        if (ba->arena) (void)hipFree(ba->arena);
+    }
     delete ba;
     return SLAM_OK;
 }
@@ -2210,8 +2226,11 @@ int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy, int
     ARG_TRY(ctx, ctx != nullptr && outliers != nullptr && iters_fast >= 0 && iterations >= 0);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     slam_ba *ba = nullptr;
-    int rc = ba_setup(ctx, fx, fy, cx, cy, P, M, O, theta, theta_const, pixels_yx, pose_ids, point_ids, &ba);
+    static const bool host_times = getenv("SLAMHIP_BA_HOSTTIME") != nullptr;
+    const auto tw0 = std::chrono::steady_clock::now();
+    int rc = ba_setup(ctx, fx, fy, cx, cy, P, M, O, theta, theta_const, pixels_yx, pose_ids, point_ids, &ba, true);
     if (rc) return rc;
+    const auto tw1 = std::chrono::steady_clock::now();
     hipStream_t st = ctx->stream;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -2246,8 +2265,15 @@ int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy, int
     if (e != hipSuccess) { slam_ba_destroy(ba); return slam_fail(ctx, SLAM_ERR_HIP, "slam_local_ba: %s", hipGetErrorString(e)); }
     // A failed factorisation leaves the caller's theta and outliers untouched (the reference's LSMR step cannot fail and
     // never leaves cache.theta half-updated): the state is only copied back from a run that completed.
+    const auto tw2 = std::chrono::steady_clock::now();
     rc = h.chol_fail ? SLAM_OK : slam_ba_download(ctx, ba, theta, outliers);
+    const auto tw3 = std::chrono::steady_clock::now();
     slam_ba_destroy(ba);
+    if (host_times) {
+        const auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        fprintf(stderr, "slam_local_ba host: setup %ld us, enqueue + wait %ld us (device %.0f us), download %ld us, destroy %ld us\n",
+                us(tw0, tw1), us(tw1, tw2), ms * 1e3, us(tw2, tw3), us(tw3, std::chrono::steady_clock::now()));
+    }
     if (rc) return rc;
     if (stats) {
         stats[0] = h.ssr_init; stats[1] = h.ssr_pass1; stats[2] = h.ssr_final; stats[3] = h.iters_pass1; stats[4] = h.iters_pass2;
