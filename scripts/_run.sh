@@ -1,2 +1,1 @@
-SLAMHIP_BA_HOSTTIME=1 timeout 60 python scripts/prof_ba.py 2>&1 | grep "host:" | tail -2
-SLAMHIP_BA_HOSTTIME=1 timeout 60 python scripts/prof_ba.py 20 4000 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_edges.py tests/test_gpu_ba.py -x -q 2>&1 | tail -3

@@ -2025,7 +2025,8 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
         B.xchg = ba->xchg; B.epoch = ++ba->epoch;
         static const bool no_twist = getenv("SLAMHIP_NO_TWIST") != nullptr;
         // (the two workgroups wait for each other: both must be resident, which a stream confined to one compute unit cannot promise)
-        const bool twist = !no_twist && hb * 6 <= 58 && d.P >= 3 * (hb + 1) && (ctx->cus == 0 || ctx->cus >= 2);
+        static const int twist_min = [] { const char *v = getenv("SLAMHIP_TWIST_MIN"); return v ? atoi(v) : 0; }();    // (measurement knob)
+        const bool twist = !no_twist && hb * 6 <= 58 && d.P >= (twist_min > 0 ? std::max(twist_min, hb + 8) : 2 * (hb + 1) + 6)      /* measured break-even: 24 poses at hb = 9 */ && (ctx->cus == 0 || ctx->cus >= 2);
         static long long *trace_dev = nullptr; static int trace_n = 0;
         static const bool trace_on = getenv("SLAMHIP_BAND_TRACE") != nullptr;
         if (trace_on && !trace_dev) (void)hipHostMalloc((void **)&trace_dev, 128);
