@@ -11,6 +11,7 @@
 // order and the build uses -ffp-contract=off.
 #include "common.hpp"
 #include <cmath>
+#include <cstddef>
 
 #define DET_THREADS 256
 #define DET_MAXCAND 512
@@ -58,15 +59,64 @@ __device__ __forceinline__ double sep3(const double *src, int h, int w, int y, i
 
 // imfilter(mask, Kernel.gaussian(sigma)) as two separable passes over the halo'd byte mask, then image .* mask.
 // acc = 0; acc += v[j] * k[j], j ascending (ImageFiltering order) in both passes.  NT > 0: tap count known at compile time.
+// Strips: a thread produces DET_SL consecutive outputs along the filtered dimension from one run of DET_SL + NT - 1 inputs held in
+// registers (NT known at compile time) -- 3.4 instead of 13 LDS reads per output; every output is still acc = 0; acc += v[j] * k[j]
+// with j ascending.
+#define DET_SL 5
 template <int NT>
 __device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned char *m0, const double *taps, int h, int w, int mh, int mw, int tid, int ntaps = NT)
 {
     const int nt = NT > 0 ? NT : ntaps;
+    if (NT > 0) {
+        constexpr int NK = NT > 0 ? NT : 1;
+        double k[NK];
+#pragma unroll
+        for (int j = 0; j < NK; j++) k[j] = taps[j];
+        // dim-1 pass: T(y, tx) = sum_j m0(y+j, tx) * k[j]; thread = (column tx, strip of DET_SL rows)
+        const int ns = (h + DET_SL - 1) / DET_SL;
+#ifndef DET_SKIP1
+        for (int it = tid; it < mw * ns; it += DET_THREADS) {
+            const int tx = it / ns, ys = (it - tx * ns) * DET_SL;
+            double v[DET_SL + NK - 1];
+#pragma unroll
+            for (int i = 0; i < DET_SL + NK - 1; i++) { const int yy = ys + i < mh ? ys + i : mh - 1; v[i] = (double)m0[yy + tx * mh]; }
+#pragma unroll
+            for (int q = 0; q < DET_SL; q++) {
+                if (ys + q < h) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NK; j++) acc += v[q + j] * k[j];
+                    T[(ys + q) + tx * h] = acc;
+                }
+            }
+        }
+#endif
+        __syncthreads();
+        // dim-2 pass and image .* mask; thread = (row y, strip of DET_SL columns)
+        const int nsx = (w + DET_SL - 1) / DET_SL;
+#ifndef DET_SKIP2
+        for (int it = tid; it < h * nsx; it += DET_THREADS) {
+            const int sx = it / h, y = it - sx * h, xs = sx * DET_SL;
+            double v[DET_SL + NK - 1];
+#pragma unroll
+            for (int i = 0; i < DET_SL + NK - 1; i++) { const int xx = xs + i < mw ? xs + i : mw - 1; v[i] = T[y + xx * h]; }
+#pragma unroll
+            for (int q = 0; q < DET_SL; q++) {
+                if (xs + q < w) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NK; j++) acc += v[q + j] * k[j];
+                    bA[y + (xs + q) * h] = bA[y + (xs + q) * h] * acc;
+                }
+            }
+        }
+#endif
+        return;
+    }
     // dim-1 pass: T(y, tx) = sum_j m0(y+j, tx) * k[j]
     for (int i = tid; i < h * mw; i += DET_THREADS) {
         const int y = i % h, tx = i / h;
         double acc = 0.0;
-#pragma unroll
         for (int j = 0; j < nt; j++) acc += (double)m0[(y + j) + tx * mh] * taps[j];
         T[i] = acc;
     }
@@ -75,10 +125,36 @@ __device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned 
     for (int i = tid; i < h * w; i += DET_THREADS) {
         const int y = i % h, x = i / h;
         double acc = 0.0;
-#pragma unroll
         for (int j = 0; j < nt; j++) acc += T[y + (x + j) * h] * taps[j];
         bA[i] = bA[i] * acc;
     }
+}
+
+// A (DET_SL + 2) x 3 neighbourhood of a cell plane in registers: rows ys - 1 .. ys + DET_SL, columns x - 1 .. x + 1, replicate
+// border at the cell edge (clamped indices), for the DET_SL outputs (ys .. ys + DET_SL - 1, x).
+struct DetStrip { double v[3][DET_SL + 2]; };
+__device__ __forceinline__ void det_strip_load(DetStrip &S, const double *src, int h, int w, int ys, int x)
+{
+    const int xm = clampi(x - 1, 0, w - 1), xp = clampi(x + 1, 0, w - 1);
+#pragma unroll
+    for (int i = 0; i < DET_SL + 2; i++) {
+        const int yy = clampi(ys - 1 + i, 0, h - 1);
+        S.v[0][i] = src[yy + xm * h]; S.v[1][i] = src[yy + x * h]; S.v[2][i] = src[yy + xp * h];
+    }
+}
+// sep3 (above) for output q of the strip: the same operations on the same operands
+__device__ __forceinline__ double det_strip_sep3(const DetStrip &S, int q, double ky0, double ky1, double ky2, double kx0, double kx1, double kx2)
+{
+    double t[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double acc = 0.0;
+        acc += S.v[j][q] * ky0; acc += S.v[j][q + 1] * ky1; acc += S.v[j][q + 2] * ky2;
+        t[j] = acc;
+    }
+    double acc = 0.0;
+    acc += t[0] * kx0; acc += t[1] * kx1; acc += t[2] * kx2;
+    return acc;
 }
 
 #ifdef DET_TRACE
@@ -117,7 +193,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     const int n = cs * cs;
     double *bA = lds, *bB = lds + n, *bC = lds + 2 * n, *bD = lds + 3 * n;
     __shared__ int s_ncand, s_cnt;
-    __shared__ int s_cand[2 * DET_MAXCAND];
+    __shared__ __attribute__((aligned(16))) int s_cand[2 * DET_MAXCAND];
     __shared__ double s_rv[DET_THREADS / 64];
     __shared__ int s_ri[DET_THREADS / 64];
     __shared__ int s_best;
@@ -126,10 +202,23 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
 
     if (h <= 0 || w <= 0 || a_k <= 0) { if (tid == 0) a_cell_cnt[cell] = 0; return; }
 
+    // taps -> LDS once.  Indexing A.taps with a lane index makes the compiler copy the argument struct to scratch, and 41 statically
+    // indexed copies are 41 serialised scalar loads (6.5 k cycles): read the kernel-argument segment itself with one vector load per
+    // lane instead (detect_cells has a single argument: the struct starts at offset 0 of the segment).
+    if (a_ncur > 0 && A.ntaps > 0 && tid < A.ntaps) {
+        const double *kt = (const double *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(DetectArgs, taps));
+        s_taps[tid] = kt[tid];
+    }
     // ---- image tile -> bA ---------------------------------------------------
-    for (int i = tid; i < h * w; i += DET_THREADS) {
-        int y = i % h, x = i / h;
-        bA[i] = a_img[(size_t)(y0 + y) + (size_t)(x0 + x) * A.pitch];
+    for (int i0 = tid; i0 < h * w; i0 += 5 * DET_THREADS) {          // five loads per thread in flight (a 35 x 35 cell: one trip)
+        double v[5];
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int i = i0 + u * DET_THREADS, ic = i < h * w ? i : i0;
+            v[u] = a_img[(size_t)(y0 + ic % h) + (size_t)(x0 + ic / h) * A.pitch];
+        }
+#pragma unroll
+        for (int u = 0; u < 5; u++) { const int i = i0 + u * DET_THREADS; if (i < h * w) bA[i] = v[u]; }
     }
 
     DT(0);
@@ -142,10 +231,14 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         // ImageDraw's disk test ((dy/r)^2 + (dx/r)^2 < 1, f64) as a table: s_lim[|dy|] = largest |dx| inside the
         // disk (-1: none).  Same operations on the same operands as the per-pixel test, evaluated once per cell
         // instead of two f64 divisions per (pixel, keypoint) pair.
+        // (the r + 1 quotients d / r are formed once, one per thread, instead of r + 1 divisions in sequence by every table thread)
+        double *s_q = (double *)s_cand;                       // s_cand is filled after the table is complete
+        if (tid <= r) s_q[tid] = (double)tid / (double)r;
+        __syncthreads();
         if (tid <= r) {
-            const double a = (double)tid / (double)r;
+            const double a = s_q[tid];
             int lim = -1;
-            for (int dx = 0; dx <= r; dx++) { const double b = (double)dx / (double)r; if (a * a + b * b < 1) lim = dx; else break; }
+            for (int dx = 0; dx <= r; dx++) { const double b = s_q[dx]; if (a * a + b * b < 1) lim = dx; else break; }
             s_lim[tid] = lim;
         }
         __syncthreads();
@@ -214,10 +307,6 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         DT(2);
         __syncthreads();
         if (A.ntaps > 0) {
-            // taps -> LDS once (indexing the kernel argument inside the tap loops costs a scalar load per tap)
-#pragma unroll
-            for (int j = 0; j < DET_MAXTAPS; j++) if (tid == j && j < A.ntaps) s_taps[j] = A.taps[j];   // static indices: scalar loads of the argument
-            __syncthreads();
             double *T = bB;                                   // h*mw doubles: bB, bC and the part of bD below the byte mask (checked on host)
             if (A.ntaps == 13) blur_mask<13>(bA, T, m0, s_taps, h, w, mh, mw, tid);      // sigma_mask = 3 (the default): unrolled
             else blur_mask<0>(bA, T, m0, s_taps, h, w, mh, mw, tid, A.ntaps);
@@ -234,41 +323,71 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     // ---- Images.shi_tomasi on the cell view (replicate border at cell edges) -
     // imgradients(cell, KernelFactors.sobel): g1 = (d/dy along dim 1, then (1,2,1)/4 along dim 2),
     // g2 = ((1,2,1)/4 along dim 1, then d/dx along dim 2); products -> bB, bC, bD
-    for (int i = tid; i < h * w; i += DET_THREADS) {
-        const int y = i % h, x = i / h;
-        const double g1 = sep3(bA, h, w, y, x, -1.0 / 2, 0.0 / 2, 1.0 / 2, 1.0 / 4, 2.0 / 4, 1.0 / 4);
-        const double g2 = sep3(bA, h, w, y, x, 1.0 / 4, 2.0 / 4, 1.0 / 4, -1.0 / 2, 0.0 / 2, 1.0 / 2);
-        bB[i] = g1 * g1; bC[i] = g1 * g2; bD[i] = g2 * g2;
+    // thread = (column x, strip of DET_SL rows): 21 LDS reads per DET_SL pixels and plane instead of 9 per pixel
+    const int nstr = (h + DET_SL - 1) / DET_SL;
+    for (int it = tid; it < w * nstr; it += DET_THREADS) {
+        const int x = it / nstr, ys = (it - x * nstr) * DET_SL;
+        DetStrip S;
+        det_strip_load(S, bA, h, w, ys, x);
+#pragma unroll
+        for (int q = 0; q < DET_SL; q++) {
+            if (ys + q < h) {
+                const double g1 = det_strip_sep3(S, q, -1.0 / 2, 0.0 / 2, 1.0 / 2, 1.0 / 4, 2.0 / 4, 1.0 / 4);
+                const double g2 = det_strip_sep3(S, q, 1.0 / 4, 2.0 / 4, 1.0 / 4, -1.0 / 2, 0.0 / 2, 1.0 / 2);
+                const int i = (ys + q) + x * h;
+                bB[i] = g1 * g1; bC[i] = g1 * g2; bD[i] = g2 * g2;
+            }
+        }
     }
     __syncthreads();
     DT(4);
     // 3x3 box mean of the products (1/3 x 1/3, two-pass arithmetic) and the min-eigenvalue response -> bA
     double *resp = bA;
-    for (int i = tid; i < h * w; i += DET_THREADS) {
-        const int y = i % h, x = i / h;
-        const double xx = sep3(bB, h, w, y, x, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3);
-        const double xy = sep3(bC, h, w, y, x, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3);
-        const double yy = sep3(bD, h, w, y, x, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3);
-        const double dd = xx - yy;
-        resp[i] = ((xx + yy) - sqrt(dd * dd + 4 * (xy * xy))) / 2;
+    for (int it = tid; it < w * nstr; it += DET_THREADS) {
+        const int x = it / nstr, ys = (it - x * nstr) * DET_SL;
+        double xx[DET_SL], xy[DET_SL], yy[DET_SL];
+        DetStrip S;
+        det_strip_load(S, bB, h, w, ys, x);
+#pragma unroll
+        for (int q = 0; q < DET_SL; q++) xx[q] = det_strip_sep3(S, q, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3);
+        det_strip_load(S, bC, h, w, ys, x);
+#pragma unroll
+        for (int q = 0; q < DET_SL; q++) xy[q] = det_strip_sep3(S, q, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3);
+        det_strip_load(S, bD, h, w, ys, x);
+#pragma unroll
+        for (int q = 0; q < DET_SL; q++) yy[q] = det_strip_sep3(S, q, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 3);
+#pragma unroll
+        for (int q = 0; q < DET_SL; q++) {
+            if (ys + q < h) {
+                const double dd = xx[q] - yy[q];
+                resp[(ys + q) + x * h] = ((xx[q] + yy[q]) - sqrt(dd * dd + 4 * (xy[q] * xy[q]))) / 2;
+            }
+        }
     }
     __syncthreads();
-
     DT(5);
-    // ---- findlocalmaxima: strict, 8-neighbourhood, edges included ------------
+
+    // ---- findlocalmaxima: strict, 8-neighbourhood, edges included (neighbours outside the cell are not compared) ------------
     unsigned char *flag = (unsigned char *)bB;                // 0: no, 1: maximum (candidate), 2: taken
-    for (int i = tid; i < h * w; i += DET_THREADS) {
-        int y = i % h, x = i / h;
-        double c = resp[i];
-        bool ismax = true;
-        for (int dx = -1; dx <= 1 && ismax; dx++)
-            for (int dy = -1; dy <= 1; dy++) {
-                if (!dx && !dy) continue;
-                int yy = y + dy, xx = x + dx;
-                if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
-                if (!(resp[yy + xx * h] < c)) { ismax = false; break; }
+    for (int it = tid; it < w * nstr; it += DET_THREADS) {
+        const int x = it / nstr, ys = (it - x * nstr) * DET_SL;
+        DetStrip S;
+        det_strip_load(S, resp, h, w, ys, x);
+        const bool cl = x > 0, cr = x < w - 1;
+#pragma unroll
+        for (int q = 0; q < DET_SL; q++) {
+            const int y = ys + q;
+            if (y < h) {
+                const double c = S.v[1][q + 1];
+                const bool ru = y > 0, rd = y < h - 1;
+                bool ismax = true;
+                if (cl) { if (ru && !(S.v[0][q] < c)) ismax = false; if (!(S.v[0][q + 1] < c)) ismax = false; if (rd && !(S.v[0][q + 2] < c)) ismax = false; }
+                if (ru && !(S.v[1][q] < c)) ismax = false;
+                if (rd && !(S.v[1][q + 2] < c)) ismax = false;
+                if (cr) { if (ru && !(S.v[2][q] < c)) ismax = false; if (!(S.v[2][q + 1] < c)) ismax = false; if (rd && !(S.v[2][q + 2] < c)) ismax = false; }
+                flag[y + x * h] = ismax ? 1 : 0;
             }
-        flag[i] = ismax ? 1 : 0;
+        }
     }
     if (tid == 0) s_cnt = 0;
     __syncthreads();
