@@ -1,1 +1,1 @@
-timeout 600 python bench.py --no-cpu > gpurun_out/b.json 2> gpurun_out/b.err; echo rc $?
+timeout 600 python -m pytest tests/test_gpu_detect.py -q 2>&1 | grep -E "SlamHipError|Error:|FAILED|passed|failed" | head -12

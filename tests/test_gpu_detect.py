@@ -36,6 +36,21 @@ def test_detect_with_avoidance_mask_exact(slam, orc, texture, H, W, maxp, ncur):
         assert d.min() > 0
 
 
+@pytest.mark.parametrize("cell", [9, 12, 23, 40, 51])
+def test_detect_other_cell_sizes_exact(slam, orc, texture, cell):
+    """The stencil phases work on strips of five rows / columns: cell sizes that are not multiples of five, smaller than a strip run
+    and with ragged border cells (H, W not multiples of the cell), with and without the avoidance mask."""
+    H, W = 131, 203
+    img = texture(H, W)[0][0]
+    e = _extractor(slam, H, W, 400, cell)
+    rng = np.random.default_rng(cell)
+    cur = np.stack([rng.uniform(1, H, 40), rng.uniform(1, W, 40)], 1)
+    for c in (np.zeros((0, 2)), cur):
+        got = slam.detect(e, img, c)
+        ref = orc.detect(img, c, max_points=400, radius=e.radius, cell_size=cell)
+        assert len(ref) > 0 and np.array_equal(got, ref), (cell, len(c))
+
+
 def test_detect_sigma_zero_and_clustered_points(slam, orc, texture):
     H, W = 200, 300
     img = texture(H, W)[0][0]
