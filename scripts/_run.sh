@@ -1,1 +1,1 @@
-timeout 600 python -m pytest tests/test_gpu_detect.py -q 2>&1 | grep -E "E  |FAILED|passed|failed" | head -8
+timeout 300 python -m pytest tests/test_gpu_edges.py -x -q -k "failed_factorisation" 2>&1 | tail -12

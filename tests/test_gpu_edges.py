@@ -128,6 +128,26 @@ def test_ba_two_workgroup_solve_is_deterministic(slam, syn):
         assert key == ref
 
 
+def test_ba_failed_factorisation_leaves_the_cache_untouched(slam, syn):
+    """A reduced camera system that is not positive definite (here: a NaN map point poisons every block it touches) ends the call with
+    SLAM_ERR_NUMERIC and theta / outliers as they were (the reference's LSMR step cannot fail and never leaves cache.theta half
+    updated) -- on the single-workgroup solve, on the two-workgroup one (whose sides wait for each other: no hang), and on the tiled
+    path of wide windows."""
+    for P, opp in ((12, 10), (40, 10), (26, 24)):
+        s = syn.ba_scene(P=P, M=60 * P, seed=P, obs_per_point=opp)
+        th = s["theta0"].copy(); th[6 * P + 3 * (30 * P) + 1] = np.nan                 # y of a map point in the middle of the window
+        cache = slam.LocalBACache(th, s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+        before = cache.theta.copy()
+        with pytest.raises(slam.SlamHipError) as ei:
+            slam.bundle_adjustment_(cache, s["cam"])
+        assert "not positive definite" in str(ei.value), (P, str(ei.value))
+        assert np.array_equal(cache.theta, before, equal_nan=True), P
+        # the context is still usable: the same window without the NaN solves
+        good = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+        slam.bundle_adjustment_(good, s["cam"])
+        assert good.stats["ssr_final"] < good.stats["ssr_init"], P
+
+
 def test_error_paths(slam, texture):
     ctx = slam.default_context(0)
     with pytest.raises(slam.SlamHipError):
