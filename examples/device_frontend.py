@@ -109,6 +109,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--streams", type=int, default=2)
+    ap.add_argument("--replay-dir", default=None, help="write stream s's camera positions to DIR/stream_s as a ReplaySaver dump (src/io/saver.jl)")
     args = ap.parse_args()
     cam, baseline, disparity = syn.KITTI_CAM, 0.54, 8.0
     lefts, rights, offs = synthetic_scene(args.streams, args.frames, disparity=disparity)
@@ -119,6 +120,14 @@ def main():
         want = np.array([o[1] * Z / cam[0], o[0] * Z / cam[1], 0.0])
         got = out[-1]["poses"][s][:3, 3]
         print(f"stream {s}: translation {np.round(got, 3).tolist()} m, expected {np.round(want, 3).tolist()} m (plane at {Z:.1f} m), {n3[s]} map points")
+    if args.replay_dir:
+        import os
+        for s in range(args.streams):
+            saver = slam.ReplaySaver()                      # set_frame_wc!(saver, frame id, wc) as SlamManager does after every frame
+            for r in out:
+                saver.set_frame_wc(r["frame"], np.linalg.inv(r["poses"][s]))
+            saver.save(os.path.join(args.replay_dir, f"stream_{s}"))
+        print(f"wrote positions.bson / ids.bson for {args.streams} streams under {args.replay_dir}")
     ms = np.array([r["ms"] for r in out[1:]])
     print(f"median {np.median(ms):.2f} ms per step of {args.streams} frames (wall, incl. the host -> device frame copies)")
 
