@@ -1,3 +1,3 @@
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 900 python bench.py > gpurun_out/final.json 2> gpurun_out/final.err; echo bench rc $?
+timeout 60 python scripts/prof_ba.py 2>&1 | tail -2
+timeout 60 python scripts/prof_ba.py 100 40000 | tail -1
+timeout 900 python -m pytest $(grep -ln "local_ba\|bundle_adjustment\|ShardedBA\|slam_ba" tests/test_gpu*.py) -x -q 2>&1 | tail -3

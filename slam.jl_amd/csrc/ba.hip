@@ -626,19 +626,22 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BADev d, int use_state)
     if (idx < nS) {
         const int bb = idx / 36, e = idx - 36 * bb, p = bb / hbw, q = p + (bb - p * hbw);
         if (q >= P) return;
-        // the contributing groups are one contiguous run (groups are sorted by f); eight loads in flight, summed in order
+        // the contributing groups are one contiguous run (groups are sorted by f); sixteen loads in flight (their groups' f first),
+        // summed in order
         double sum = 0.0;
         const int g1 = d.fgrp[p + 1];
-        for (int g0 = d.fgrp[max(0, q - d.whb)]; g0 < g1; g0 += 8) {
-            double v[8];
+        for (int g0 = d.fgrp[max(0, q - d.whb)]; g0 < g1; g0 += 16) {
+            int fz[16]; double v[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 16; u++) fz[u] = d.grp[min(g0 + u, g1 - 1)].z;
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
                 const int gi = min(g0 + u, g1 - 1);
-                const int f = d.grp[gi].z & 0xffff, a = p - f, b = q - f, w = a * hbw - a * (a - 1) / 2 + (b - a);
+                const int f = fz[u] & 0xffff, a = p - f, b = q - f, w = a * hbw - a * (a - 1) / 2 + (b - a);
                 v[u] = d.wpart[(size_t)gi * d.wstride + w * 36 + e];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) sum += g0 + u < g1 ? v[u] : 0.0;
+            for (int u = 0; u < 16; u++) sum += g0 + u < g1 ? v[u] : 0.0;
         }
         const int r = e / 6, c = e - 6 * r;
         d.S[(size_t)(6 * p + r) + (size_t)(6 * q + c) * n] = sum;
@@ -1565,7 +1568,6 @@ __global__ __launch_bounds__(256) void k_trial(BADev d, int ignore_outliers, int
             for (int k = 0; k < 6; k++) pose[k] = d.pose_t[6 * p + k];
             obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, nullptr);
         }
-        d.ft[2 * (size_t)i] = r[0]; d.ft[2 * (size_t)i + 1] = r[1];
         double a = 0.0, b = 0.0;
         const double *dp = d.dp + 6 * p, *dl = d.dl + 3 * j;
 #pragma unroll
@@ -1646,7 +1648,6 @@ __global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outl
             for (int k = 0; k < 6; k++) pose[k] = d.pose[6 * p + k] - s_dp[6 * p + k];
             obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, nullptr);
         }
-        st_rec<2>(d.ft + 2 * (size_t)i, r);
 #pragma unroll
         for (int k = 0; k < 3; k++) { a += jl[k] * dl[k]; b += jl[3 + k] * dl[k]; }
         a -= ff[0]; b -= ff[1];
@@ -1751,7 +1752,7 @@ __global__ __launch_bounds__(256) void k_commit(BADev d, int accept_host, int us
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < d.n) d.pose[i] = d.pose_t[i];
     if (i < 3 * d.M) d.pts[i] = d.pts_t[i];
-    if (i < 2 * d.O) d.f[i] = d.ft[i];
+    // (the residuals are not copied: every build re-evaluates them at the committed parameters before anything reads d.f)
 }
 
 __global__ void k_lm_reset(BADev d, int pass)
@@ -1922,7 +1923,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     const size_t o_st = take(sizeof(LMState)), o_cf = take(64), o_outl = take((size_t)O + 1);
     const size_t zero_end = off;
     const size_t o_pose_t = take(n * 8), o_pts_t = take((size_t)3 * M * 8 + 8), o_hasp = take((size_t)O + 1);
-    const size_t o_f = take((size_t)2 * O * 8 + 8), o_ft = take((size_t)2 * O * 8 + 8);
+    const size_t o_f = take((size_t)2 * O * 8 + 8), o_ft = take(8);    // (trial residuals are not kept: every build re-evaluates d.f)
     const size_t o_Jp = take((size_t)12 * O * 8 + 8), o_Jl = take((size_t)6 * O * 8 + 8);
     const size_t o_Vinv = take((size_t)6 * M * 8 + 8), o_bl = take((size_t)3 * M * 8 + 8);
     const size_t o_T = take(grouped ? 8 : (size_t)18 * O * 8 + 8), o_W = take(grouped ? 8 : (size_t)18 * O * 8 + 8);   // T / W records: pair-list path only
@@ -2062,7 +2063,7 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
 static int ba_enqueue_commit(slam_ctx *ctx, slam_ba *ba, int accept, int use_state, int iter_tag)
 {
     BADev d = ba->d;
-    const int m = std::max(std::max(d.n, 3 * d.M), 2 * d.O);
+    const int m = std::max(d.n, 3 * d.M);
     hipLaunchKernelGGL(k_commit, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, d, accept, use_state, iter_tag);
     return SLAM_OK;
 }
