@@ -1,3 +1,6 @@
-timeout 60 python scripts/prof_ba.py 2>&1 | tail -2
-timeout 60 python scripts/prof_ba.py 100 40000 | tail -1
-timeout 900 python -m pytest $(grep -ln "local_ba\|bundle_adjustment\|ShardedBA\|slam_ba" tests/test_gpu*.py) -x -q 2>&1 | tail -3
+for rep in 1 2 3; do
+for L in libslamhip.so libslamhip_old.so; do
+  SLAMHIP_LIB=$GRAFT_REPO_ROOT/slam.jl_amd/$L timeout 300 python bench.py --no-cpu --no-ba --no-sweep --steps 100 --warmup 10 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('$L', round(d['value']))"
+done; done

@@ -14,21 +14,27 @@
 
 static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-// live slots of all streams back to back + their number
-__global__ __launch_bounds__(1024) void k_kpset_worklist(const int *count, int S, int cap, int *work, int *ntot)
+// live slots of all streams back to back + their number.  One small workgroup per stream (it sums the counts before its own: S <= 64
+// loads): a single 1024-thread workgroup had to wait for sixteen free wave slots on one CU while the pyramid kernels fill the chip
+// (58 us on average in the pipeline for 12 us of work).
+__global__ __launch_bounds__(256) void k_kpset_worklist(const int *count, int S, int cap, int *work, int *ntot)
 {
-    __shared__ int off[65];
-    if (threadIdx.x == 0) { int o = 0; for (int s = 0; s < S; s++) { off[s] = o; o += count[s]; } off[S] = o; ntot[0] = o; }
-    __syncthreads();
-    for (int s = 0; s < S; s++) {
-        const int n = off[s + 1] - off[s];
-        for (int j = threadIdx.x; j < n; j += 1024) work[off[s] + j] = s * cap + j;
+    __shared__ int s_off;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) {
+        int c = tid < s ? count[tid] : 0, t = tid < S ? count[tid] : 0;     // (S <= 64: one wave covers every stream)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { c += __shfl_xor(c, m); t += __shfl_xor(t, m); }
+        if (tid == 0) { s_off = c; if (s == 0) ntot[0] = t; }
     }
+    __syncthreads();
+    const int off = s_off, n = count[s];
+    for (int j = tid; j < n; j += 256) work[off + j] = s * cap + j;
 }
 
 int kpset_build_worklist(slam_ctx *ctx, slam_kpset *ks)
 {
-    hipLaunchKernelGGL(k_kpset_worklist, dim3(1), dim3(1024), 0, ctx->stream, (const int *)ks->count, ks->S, ks->cap, ks->work, ks->ntot);
+    hipLaunchKernelGGL(k_kpset_worklist, dim3(ks->S), dim3(256), 0, ctx->stream, (const int *)ks->count, ks->S, ks->cap, ks->work, ks->ntot);
     HIP_TRY(ctx, hipGetLastError());
     return SLAM_OK;
 }
