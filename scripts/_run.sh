@@ -1,6 +1,4 @@
-for rep in 1 2; do
-for L in libslamhip.so libslamhip_old.so; do
-  SLAMHIP_LIB=$GRAFT_REPO_ROOT/slam.jl_amd/$L timeout 400 python bench.py --no-cpu --no-sweep --steps 100 --warmup 10 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('$L', round(d['value']), round(d['pose']['frontend_with_pose']['value']), round(d['pose']['frontend_with_scene_pose_seams']['value']) if 'frontend_with_scene_pose_seams' in d['pose'] else '')"
-done; done
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+S_=64 timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_hl -o hl -- python3 scripts/prof_headline.py > gpurun_out/hl.txt 2>&1
+tail -2 gpurun_out/hl.txt
+python scripts/queue_gaps.py gpurun_out/prof_hl
