@@ -205,7 +205,7 @@ int slam_flow_match(slam_ctx *ctx, const slam_pyr *from, const slam_pyr *to,
  * be the S members of one batch, in order; images already in HBM); slam_flow_match_batch tracks the keypoints
  * of all S streams in one launch (img_index[i] = stream of point i; from0 / to0 = member 0 of two batches).
  * Batch updates: mode 1 or 3 as for slam_pyr_update; with S >= 4 both modes run the bit-exact kernels (the segmented
- * ones of mode 3 only pay for a single image); launches with >= 96 MB of plane data use the checkpointed IIR kernels
+ * ones of mode 3 only pay for a single image); launches with >= 40 MB of plane data use the checkpointed IIR kernels
  * (forward state every 32 samples, forward values recomputed: 2 reads + 1 write per sample instead of 2 + 2), still
  * bit-identical to mode 1 on a single pyramid. */
 int slam_pyr_create_batch(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, slam_pyr **out);

@@ -1,4 +1,3 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-S_=64 timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_hl -o hl -- python3 scripts/prof_headline.py > gpurun_out/hl.txt 2>&1
-tail -2 gpurun_out/hl.txt
-python scripts/queue_gaps.py gpurun_out/prof_hl
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+timeout 600 python bench.py --no-cpu > gpurun_out/b.json 2>/dev/null; python -c "
+import json; d=json.loads(open('gpurun_out/b.json').read().strip().split('\n')[-1]); print(round(d['value']), d['streams_sweep'], round(d['pose']['frontend_with_pose']['value']))"
