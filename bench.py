@@ -360,7 +360,7 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
         pprio = int(os.environ.get("SLAM_BENCH_PYR_PRIO", "0"))
         ctx, ctx_pyr, ctx_right, ctx_copy = slam.Context(local_rank, priority=prio), slam.Context(local_rank, priority=pprio), slam.Context(local_rank, priority=pprio), slam.Context(local_rank)
     levels = params.pyramid_levels
-    AHEAD = 1
+    AHEAD = max(1, int(os.environ.get("SLAM_BENCH_KP_AHEAD", "2")))   # builds enqueued ahead of the step being tracked (same-box A/B: 2 = +0.9 % over 1 -- the next graph is already queued when a build ends; 3 = -1.4 %)
     NLB = AHEAD + 3                                          # previous, current, AHEAD being built, one more being copied
     lb = [slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx) for _ in range(NLB)]
     rb = slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx)

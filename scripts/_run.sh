@@ -1,3 +1,6 @@
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-timeout 600 python bench.py --no-cpu > gpurun_out/b.json 2>/dev/null; python -c "
-import json; d=json.loads(open('gpurun_out/b.json').read().strip().split('\n')[-1]); print(round(d['value']), d['streams_sweep'], round(d['pose']['frontend_with_pose']['value']))"
+for rep in 1 2; do
+for A in 2 3; do
+  SLAM_BENCH_KP_AHEAD=$A timeout 300 python bench.py --no-cpu --no-ba --no-sweep --steps 100 --warmup 10 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('ahead $A', round(d['value']), d['roofline']['frac'])"
+done; done
