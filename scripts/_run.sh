@@ -1,3 +1,6 @@
-timeout 900 python bench.py > gpurun_out/final.json 2> gpurun_out/final.err; echo bench rc $?
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o bench -- python3 bench.py --no-cpu > gpurun_out/final_profiled.json 2> /dev/null; echo prof rc $?
+for rep in 1 2; do
+for PR in 0 1; do
+  SLAM_BENCH_PYR_PRIO=$PR timeout 300 python bench.py --no-cpu --no-ba --no-sweep --steps 100 --warmup 10 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('pyr prio $PR', round(d['value']), d['roofline']['frac'])"
+done; done
