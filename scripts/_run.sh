@@ -1,6 +1,3 @@
-for rep in 1 2; do
-for PR in 0 1; do
-  SLAM_BENCH_PYR_PRIO=$PR timeout 300 python bench.py --no-cpu --no-ba --no-sweep --steps 100 --warmup 10 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('pyr prio $PR', round(d['value']), d['roofline']['frac'])"
-done; done
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 3 > gpurun_out/drv.json 2> gpurun_out/drv.err; echo rc $?
+python -c "
+import json; d=json.loads(open('gpurun_out/drv.json').read().strip().split('\n')[-1]); print(d['metric'][:60], round(d['value']), d['steps'], d['warmup'], d['ms_per_step'], d['n_gpus'], d['scaling'], d['dtype'], d['config']['workload'][:80])"
