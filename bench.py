@@ -4,20 +4,25 @@ forward-backward LK, key-frame detect + stereo LK + triangulation) on MI355X,
 plus local-BA ms/iteration, against the HBM roofline, with the CPU oracle timed
 beside it.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--only leg[,leg...]]
 
 One process per GPU (a launcher's WORLD_SIZE / RANK are honoured; without one,
-`--gpus N` starts the N rank processes itself).  A step = one frame of EACH of S
-lock-stepped, independent synthetic KITTI-05-shaped stereo streams (370 x 1226,
-1000 keypoints, key-frame every 5th frame) through the hot path -- one batch of
-S frames per pass, every launch shared by the S streams, keypoint lists
-resident in HBM (slam_kpset_*).  The frames of a step START IN PINNED HOST
-MEMORY as the decoder's 8-bit images and are copied to the GPU inside the timed
-loop; all arithmetic is Float64 and every plane bit-exact.  value = frames/s
-over all streams and GPUs; the device-resident and host-Float64 ingest
-configurations and the single-stream (latency) numbers are reported beside it.
-N>1 = N independent replicas (the front-end does not shard: SURVEY 8e) -> weak
-scaling, no collective in the data path.  Rank 0 prints ONE JSON line.
+`--gpus N` starts the N rank processes itself).  A step = ONE KEY-FRAME PERIOD
+(KF_EVERY = 5 frames, the first of them a key-frame) of EACH of S lock-stepped,
+independent synthetic KITTI-05-shaped stereo streams (370 x 1226, 1000
+keypoints) through the hot path -- every timed step is the same work: 5 left
+pyramid builds + 5 temporal matches + 1 cull / detect / right build / stereo
+match / triangulation, every launch shared by the S streams, keypoint lists
+resident in HBM (slam_kpset_*).  The frames START IN PINNED HOST MEMORY as the
+decoder's 8-bit images and are copied to the GPU inside the timed loop; all
+arithmetic is Float64 and every plane bit-exact.  value = frames/s over all
+streams and GPUs = S * KF_EVERY * K / seconds.  N>1 = N independent replicas
+(the front-end does not shard: SURVEY 8e) -> weak scaling, no collective in the
+data path.  Rank 0 prints ONE JSON line.
+
+Legs (`--only`, for profiling one population of kernels at a time; default all):
+  single, tolerance, headline, ingest, sweep, host_protocol, configs, ba,
+  ba_sharded, pose, cpu
 """
 import argparse
 import json
@@ -32,10 +37,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 KF_EVERY = 5
-N_KPTS = 1000
 RIGHT_TARGET_ONLY = os.environ.get("SLAM_BENCH_RIGHT_FULL") is None     # right frames are only matched INTO (mapper.jl:51-66): layers only above level 0 (SLAM_PYR_TARGET_ONLY)
 CULL_FRACTION = 0.15              # share of tracked keypoints the map drops per key-frame
-SHAPE = "kitti05"
 N_FRAMES = 8                      # distinct rendered frames, played ping-pong
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0       # same guide: measured-achievable stream rate (SURVEY 8d's denominator, quoted beside the spec)
@@ -323,54 +326,82 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
     return res
 
 
-def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, right, flows, disparity, params, extractor, world, dist, dev, ingest,
-                       hook=None, seed=1234, pose=False):
-    """The headline configuration: S streams in lock-step, keypoints resident in HBM (slam_kpset_*), no host list work
-    between the calls of a step; the host sees the S list lengths once per step.
+WORKLOADS = {
+    # name: shape (slam_jl_amd.synthetic.SHAPES), keypoints per frame, stereo, streams per GPU, camera (fx, fy, cx, cy), image step per frame
+    "kitti05_1000": dict(shape="kitti05", kpts=1000, stereo=True, S=64, cam=None, step=(1.3, -2.1), n_frames=8,
+                         what="BASELINE configs[1]: KITTI 05 stereo 370x1226, 1000 kpts/frame (the headline)"),
+    "kitti00_2000": dict(shape="kitti00", kpts=2000, stereo=True, S=64, cam=None, step=(1.3, -2.1), n_frames=8,
+                         what="BASELINE configs[2]: KITTI 00 stereo 376x1241 (example/kitty/main.jl:21-22), 2000 kpts/frame; its 20-KF BA is ba.windows.P20"),
+    "euroc_mono": dict(shape="euroc", kpts=1000, stereo=False, S=64, cam=(458.654, 457.296, 367.215, 248.375), step=(2.6, -4.2), n_frames=8,
+                       what="BASELINE configs[3]: monocular 480x640, PnP-tracking path (front_end.jl:132-219: five-point filter + P3P RANSAC + PnP "
+                            "refinement every frame, no right image), new keypoints by triangulate_temporal!; its 50-KF BA is ba.windows.P50"),
+    "fhd_4000": dict(shape="fhd", kpts=4000, stereo=True, S=16, cam=(910.0, 910.0, 960.0, 540.0), step=(1.3, -2.1), n_frames=4,
+                     what="BASELINE configs[4] on one GPU: 1080x1920 stereo (example/uni/main.jl:11-13), 4000 kpts/frame; its 100-KF BA is ba.windows.P100"),
+}
 
-    ingest: where a step's frames start --
+
+def make_workload(slam, syn, name, seed=0, streams=None):
+    w = dict(WORKLOADS[name]); w["name"] = name
+    H, W = syn.SHAPES[w["shape"]]
+    camt = tuple(w["cam"] or syn.KITTI_CAM)
+    params = slam.Params(stereo=w["stereo"], max_nb_keypoints=w["kpts"])
+    cam = slam.Camera(*camt, height=H, width=W)
+    w.update(H=H, W=W, camt=camt, params=params, extractor=slam.Extractor.from_params(params, cam), disparity=12.4, levels=params.pyramid_levels)
+    if streams:
+        w["S"] = streams
+    w["left"], w["right"], w["flows"] = syn.stereo_stream(w["shape"], w["n_frames"], seed=seed, step=w["step"], disparity=w["disparity"])
+    if not w["stereo"]:
+        w["right"] = None
+    return w
+
+
+def frame_sequence_n(n_frames, n_steps):
+    fwd = list(range(n_frames)) + list(range(n_frames - 2, 0, -1))
+    return [fwd[i % len(fwd)] for i in range(n_steps + 1)]
+
+
+def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world, dist, dev, ingest,
+                       hook=None, seed=1234, pose=False, record=None, snapshot=None):
+    """The headline loop: S streams in lock-step, keypoints resident in HBM (slam_kpset_*), no host list work
+    between the calls of a frame; the host sees the S list lengths once per frame.  Timed: `periods` key-frame periods
+    (KF_EVERY frames of every stream each, the first a key-frame) after `warm_periods` untimed ones.
+
+    ingest: where a frame starts --
       "host_u8"  pinned host memory, 8-bit as the KITTI reader decodes them (example/kitty/kitty.jl:52-102): one H2D copy of
-                 the step's S frames on the pyramid stream, converted on the device (slam_pyr_update_batch_u8_dev);
+                 the S frames on the copy stream, converted on the device (slam_pyr_update_batch_u8_dev);
       "host_f64" pinned host memory as Matrix{Gray{Float64}} (what the Julia seam receives, SLAM.jl:250): 8x the bytes;
       "dev_f64"  already in HBM as Float64 (round-1 headline).
-    Stream s plays the ping-pong sequence shifted by s frames, so a step's S frames are a contiguous window of the
-    periodic sequence: one copy per step."""
+    Stream s plays the ping-pong sequence shifted by s frames, so the S frames of a step are a contiguous window of the
+    periodic sequence: one copy per step.
+
+    record (dict, optional): replay mode for the parity check -- runs record["frame_steps"] frames from the empty lists, no
+      warm-up, and appends per frame {"i", "kf", "shift" (S, 2), "cull" (S, cap) uint8 or None} to record["steps"].
+    snapshot (list of stream ids, optional): after the last frame, download those streams' keypoint lists and all planes of
+      their current left pyramids into the result (the cpu_baseline leg compares them with the oracle)."""
     import ctypes as C
-    # optional chip partition (SLAM_BENCH_CU_SPLIT = "<n_track>[:pattern]"): the tracking / detect stream keeps n_track compute units,
-    # the pyramid streams the rest
-    split = os.environ.get("SLAM_BENCH_CU_SPLIT")
-    if split:
-        ncu = torch.cuda.get_device_properties(local_rank).multi_processor_count
-        nt = int(split.split(":")[0]); pat = split.split(":")[1] if ":" in split else "interleave"
-        if pat == "contig":
-            tmask = [1 if i < nt else 0 for i in range(ncu)]
-        else:                                                # spread over the enumeration in groups of 8
-            per8 = nt * 8 // ncu
-            tmask = [1 if (i % 8) < per8 else 0 for i in range(ncu)]
-        pmask = [1 - b for b in tmask]
-        ctx, ctx_pyr, ctx_right = slam.Context(local_rank, cu_mask=tmask), slam.Context(local_rank, cu_mask=pmask), slam.Context(local_rank, cu_mask=pmask)
-        ctx_copy = slam.Context(local_rank)
-    else:
-        # the tracking context's stream is in a scheduling class of its own (the low-priority one): a hardware queue that the branches
-        # of the pyramid graph never land on.  With four default-class streams the runtime placed the graph's small-level branch on
-        # the tracking stream's queue and every step's match sat behind it until the build was over (kernel trace, DESIGN 4).
-        # Measured at S = 32, host_u8: default class 14.7k frames/s, high 16.2k, low 16.5k (the builds are the longer chain of a
-        # step and are better left undisturbed).  SLAM_BENCH_TRACK_PRIO=0 restores the shared class for comparison.
-        prio = int(os.environ.get("SLAM_BENCH_TRACK_PRIO", "-1"))
-        pprio = int(os.environ.get("SLAM_BENCH_PYR_PRIO", "0"))
-        ctx, ctx_pyr, ctx_right, ctx_copy = slam.Context(local_rank, priority=prio), slam.Context(local_rank, priority=pprio), slam.Context(local_rank, priority=pprio), slam.Context(local_rank)
+    S, H, W, params, extractor, camt, disparity = wl["S"], wl["H"], wl["W"], wl["params"], wl["extractor"], wl["camt"], wl["disparity"]
+    left, right, flows, stereo = wl["left"], wl["right"], wl["flows"], wl["stereo"]
+    # the tracking context's stream is in a scheduling class of its own (the low-priority one): a hardware queue that the branches
+    # of the pyramid graph never land on.  With four default-class streams the runtime placed the graph's small-level branch on
+    # the tracking stream's queue and every step's match sat behind it until the build was over (kernel trace, DESIGN 4).
+    # Measured at S = 32, host_u8: default class 14.7k frames/s, high 16.2k, low 16.5k (the builds are the longer chain of a
+    # step and are better left undisturbed).  SLAM_BENCH_TRACK_PRIO=0 restores the shared class for comparison.
+    prio = int(os.environ.get("SLAM_BENCH_TRACK_PRIO", "-1"))
+    pprio = int(os.environ.get("SLAM_BENCH_PYR_PRIO", "0"))
+    ctx, ctx_pyr, ctx_right, ctx_copy = slam.Context(local_rank, priority=prio), slam.Context(local_rank, priority=pprio), slam.Context(local_rank, priority=pprio), slam.Context(local_rank)
     levels = params.pyramid_levels
     AHEAD = max(1, int(os.environ.get("SLAM_BENCH_KP_AHEAD", "2")))   # builds enqueued ahead of the step being tracked (same-box A/B: 2 = +0.9 % over 1 -- the next graph is already queued when a build ends; 3 = -1.4 %)
     NLB = AHEAD + 3                                          # previous, current, AHEAD being built, one more being copied
     lb = [slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx) for _ in range(NLB)]
-    rb = slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx)
+    rb = slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx) if stereo else None
     built = [None] * NLB
     copied = [None] * NLB; rcopied = [None]; rbuilt = [None]
     ncell = extractor.grid_resolution[0] * extractor.grid_resolution[1]
     cap = extractor.max_points + ncell + 8
     ks = slam.KeypointSet(S, cap, ctx=ctx)
-    period = 2 * N_FRAMES - 2
-    seq = frame_sequence(period + S + 2)
+    n_frames = len(left)
+    period = 2 * n_frames - 2
+    seq = frame_sequence_n(n_frames, period + S + 2)
     u8 = ingest == "host_u8"
     np_dtype, t_dtype, fbytes = (np.uint8, torch.uint8, H * W) if u8 else (np.float64, torch.float64, H * W * 8)
     conv = (lambda im: np.round(im * 255).astype(np.uint8)) if u8 else (lambda im: im)
@@ -378,15 +409,17 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
     def seq_tensor(frames):
         a = np.stack([np.ascontiguousarray(conv(frames[seq[k]]).T) for k in range(period + S)])
         return torch.from_numpy(a)
-    lseq, rseq = seq_tensor(left), seq_tensor(right)
+    lseq = seq_tensor(left); rseq = seq_tensor(right) if stereo else None
     host = ingest != "dev_f64"
     if host:
-        lseq, rseq = lseq.pin_memory(), rseq.pin_memory()
+        lseq = lseq.pin_memory()
         lstage = [torch.empty((S, W, H), dtype=t_dtype, device=dev) for _ in range(NLB)]
-        rstage = torch.empty((S, W, H), dtype=t_dtype, device=dev)
+        if stereo:
+            rseq = rseq.pin_memory()
+            rstage = torch.empty((S, W, H), dtype=t_dtype, device=dev)
         st_copy = torch.cuda.ExternalStream(ctx_copy.stream, device=dev)         # H2D copies on their own stream, one step ahead of the builds
     else:
-        lseq, rseq = lseq.to(dev), rseq.to(dev)
+        lseq = lseq.to(dev); rseq = rseq.to(dev) if stereo else None
     torch.cuda.synchronize()
     flows_a = np.asarray(flows, dtype=np.float64); seq_a = np.asarray(seq)
     rng = np.random.default_rng(seed)
@@ -451,22 +484,20 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
         while nxt[0] <= frame:
             enqueue_build(nxt[0], timed); nxt[0] += 1
 
-    from slam_jl_amd import synthetic as syn_
-    camt = tuple(syn_.KITTI_CAM)
-    baseline = disparity * 30.0 / camt[0]                    # a scene 30 m away: d = fx b / z
+    Z_PLANE = 30.0
+    baseline = disparity * Z_PLANE / camt[0]                 # a scene 30 m away: d = fx b / z
     T21 = np.eye(4); T21[0, 3] = -baseline
     Twc = np.eye(4)
     sp_stereo = slam.stream_params(S, cam=camt, shift_yx=np.tile([0.0, -disparity], (S, 1)))
-    state = dict(n_bound=0, tracked=0, tracked_steps=0, timed=False, wait_s=0.0)
+    state = dict(n_bound=0, tracked=0, tracked_steps=0, timed=False, wait_s=0.0, booted=False)
     # pose = True: the full per-frame front-end of front_end.jl:60-113 on the tracked lists themselves -- the streams are a rigid
     # scene (a fronto-parallel plane 30 m away, cameras translating parallel to it), so the map points of the stereo
     # triangulation, the pose priors of the tracking, the five-point filter against the previous key-frame and P3P + PnP are all
     # consistent; the recovered camera translation is checked against the image offsets of the frames.
-    Z_PLANE = 30.0
     pst = dict(Tcw=np.tile(np.eye(4), (S, 1, 1)), Tprev=np.tile(np.eye(4), (S, 1, 1)), Tkf=np.tile(np.eye(4), (S, 1, 1)), ref=None,
-               accepted=0, asked=0, err_max=0.0, acc5=0, asked5=0, n_kf=0, kf_cw=np.tile(np.eye(4), (S, 8, 1, 1)))
+               accepted=0, asked=0, err_max=0.0, acc5=0, asked5=0, gated5=0, n_kf=0, kf_cw=np.tile(np.eye(4), (S, 8, 1, 1)))
     sp_cam = slam.stream_params(S, cam=camt)
-    if host:
+    if host and stereo:
         enqueue_right_copy(1)                               # step 1 is a key-frame
     build_up_to(AHEAD)
     ctx_pyr.synchronize(); ctx_copy.synchronize()
@@ -474,13 +505,16 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
     def step(i):
         kf = (i - 1) % KF_EVERY == 0
         prevb, curb = lb[(i - 1) % NLB], lb[i % NLB]
-        if kf:
+        if kf and stereo:
             enqueue_right(i)
-        if host and i % KF_EVERY == 0:                      # the next step is a key-frame: its right frames start travelling now
+        if host and stereo and i % KF_EVERY == 0:           # the next step is a key-frame: its right frames start travelling now
             enqueue_right_copy(i + 1)
         ctx.wait_event(built[i % NLB])                      # tracking needs the build of frame i only
         build_up_to(i + AHEAD, state["timed"])              # the next frame's copy + build overlap this step's tracking
         cnt = None
+        rec = None
+        if record is not None:
+            rec = {"i": i, "kf": kf, "shift": None, "cull": None}; record["steps"].append(rec)
         if state["n_bound"] > 0 and pose:
             # klt_tracking! with the motion model's prediction (constant velocity on the translation), then the epipolar filter and
             # compute_pose!; the pose call is this step's device -> host copy
@@ -489,7 +523,6 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
             Rc = np.tile(np.eye(4), (S, 1, 1)); Rc[:, :3, :3] = pst["Tkf"][:, :3, :3] @ np.transpose(Tpred[:, :3, :3], (0, 2, 1))
             r5 = ks.compute_pose_5pt(slam.stream_params(S, Tcw=Rc, cam=camt), min_parallax=5.0, max_repr_error=3.0, iters=128,
                                      seed=seed + 2 * i, ctx=ctx, fetch=(i % 4 == 0))      # enqueue-only on most steps: its effect is on the lists
-            st5 = r5[1] if r5 is not None else None
             t_enq = time.perf_counter()
             poses, stp, _, cnt = ks.compute_pose(sp_cam, threshold=3.0, iters=256, seed=seed + 2 * i + 1, ctx=ctx)
             state["wait_s"] += time.perf_counter() - t_enq
@@ -500,32 +533,49 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
                 off = flows_a[seq_a[(i % period) + np.arange(S)]] - pst["ref"]
                 want = np.stack([off[:, 1] * Z_PLANE / camt[0], off[:, 0] * Z_PLANE / camt[1], np.zeros(S)], axis=1)
                 pst["asked"] += S; pst["accepted"] += int(ok.sum())
-                if st5 is not None:
-                    pst["asked5"] += S; pst["acc5"] += int(np.asarray(st5).sum())
+                if r5 is not None:
+                    st5 = np.asarray(r5[1]).astype(bool); par5 = np.asarray(r5[3])
+                    pst["asked5"] += S; pst["acc5"] += int(st5.sum()); pst["gated5"] += int((~st5 & (par5 < 5.0)).sum())
                 if ok.any():
                     pst["err_max"] = max(pst["err_max"], float(np.abs(pst["Tcw"][ok, :3, 3] - want[ok]).max()))
         elif state["n_bound"] > 0:
             # motion-model prior: the stream's image-plane shift, ~0.5 px off (project_world_to_image_distort of the map points
             # under the predicted pose; the synthetic streams are image-plane translations)
             shift = flows_a[seq_a[(i % period) + np.arange(S)]] - flows_a[seq_a[((i - 1) % period) + np.arange(S)]]
-            sp = slam.stream_params(S, cam=camt, shift_yx=shift + rng.normal(0, 0.5, (S, 2)))
+            shift = shift + rng.normal(0, 0.5, (S, 2))
+            if rec is not None:
+                rec["shift"] = shift.copy()
+            sp = slam.stream_params(S, cam=camt, shift_yx=shift)
             ks.flow_match(prevb, curb, params, sp, prior=2, n_bound=state["n_bound"], ctx=ctx)
         if kf:
             # map culling between key-frames (outlier observations dropped by BA, failed triangulations): flags drawn in HBM
             with torch.cuda.stream(st_main):
                 cull_u.uniform_(generator=gen)
                 torch.lt(cull_u, CULL_FRACTION, out=cull_flags)                 # bool = one byte per slot, 1 = remove
+            if rec is not None:
+                ctx.synchronize()
+                rec["cull"] = cull_flags.cpu().numpy().astype(np.uint8).reshape(S, cap)
             ks.remove(cull_flags.data_ptr(), ctx=ctx)
             ks.detect(extractor, curb, ctx=ctx)
+            if pose and not stereo and not state["booted"]:
+                # monocular initialisation taken as given (front_end.jl:243-332 + mapper.jl:185-262 run once at start-up): the first
+                # key-frame's keypoints become map points on the scene plane; the loop measures the PnP-tracking steady state
+                for s_ in range(S):
+                    d_ = ks.download(s_, ctx=ctx)
+                    yx_ = d_["yx"]
+                    xyz_ = np.stack([(yx_[:, 1] - camt[2]) / camt[0] * Z_PLANE, (yx_[:, 0] - camt[3]) / camt[1] * Z_PLANE, np.full(len(yx_), Z_PLANE)], axis=1)
+                    ks.upload(s_, yx_, np.ones(len(yx_), bool), xyz_, ids=d_["ids"], ctx=ctx)
+                state["booted"] = True
             if pose:
                 ks.keyframe(ctx=ctx)                        # the frame becomes the previous key-frame of its keypoints
                 pst["Tkf"] = pst["Tcw"].copy()
                 if pst["ref"] is None:                      # world frame = the first key-frame's camera
                     pst["ref"] = flows_a[seq_a[(i % period) + np.arange(S)]].copy()
-            ctx.wait_for(ctx_right)
-            ks.stereo_match(curb, rb, params, sp_stereo, prior=2, ctx=ctx)
             Twc_now = np.linalg.inv(pst["Tcw"]) if pose else Twc
-            ks.triangulate(camt, camt, T21, Twc_now, max_error=3.0, ctx=ctx)
+            if stereo:
+                ctx.wait_for(ctx_right)
+                ks.stereo_match(curb, rb, params, sp_stereo, prior=2, ctx=ctx)
+                ks.triangulate(camt, camt, T21, Twc_now, max_error=3.0, ctx=ctx)
             if pose:                                        # mapper.jl:86: what stereo left 2-D, against its first observing key-frame
                 kfid = pst["n_kf"]; pst["kf_cw"][:, kfid % 8] = pst["Tcw"]; pst["n_kf"] += 1
                 if kfid > 0:
@@ -547,29 +597,46 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
         if world > 1:
             dist.barrier()
 
-    warm = max(warmup, 6)
+    if record is not None:
+        warm, nsteps = 0, int(record["frame_steps"])
+    else:
+        warm, nsteps = max(warm_periods, 2) * KF_EVERY, periods * KF_EVERY
     for i in range(1, 1 + warm):
         step(i)
     state["tracked"] = 0; state["tracked_steps"] = 0
     drain(); state["timed"] = True; state["wait_s"] = 0.0; t0 = time.perf_counter()
-    for i in range(1 + warm, 1 + warm + steps):
+    for i in range(1 + warm, 1 + warm + nsteps):
         step(i)
     drain(); dt = time.perf_counter() - t0
     state["timed"] = False
+    i_last = warm + nsteps
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
     builds = [a.elapsed_ms(b) for a, b in ev_used[-len(ev_pool):]]      # left builds of the timed region (graph replays on the pyramid stream)
-    res = {"ingest": ingest, "streams_per_gpu": S, "steps": steps, "value": world * S * steps / dt, "unit": "frames/sec", "seconds": dt,
-           "ms_per_step_of_S_frames": dt / steps * 1e3,
-           "host_wait_ms_per_step": state["wait_s"] / steps * 1e3,
+    res = {"ingest": ingest, "streams_per_gpu": S, "steps": periods, "frame_steps": nsteps, "value": world * S * nsteps / dt, "unit": "frames/sec", "seconds": dt,
+           "ms_per_step": dt / max(periods, 1) * 1e3, "ms_per_frame_of_S_streams": dt / nsteps * 1e3,
+           "host_wait_ms_per_frame": state["wait_s"] / nsteps * 1e3,
            "tracked_kpts_per_frame": round(state["tracked"] / max(state["tracked_steps"], 1) / S, 1),
-           "pose": None if not pose else {"accepted_fraction": pst["accepted"] / max(pst["asked"], 1), "five_point_accepted_fraction": pst["acc5"] / max(pst["asked5"], 1),
+           "pose": None if not pose else {"accepted_fraction": pst["accepted"] / max(pst["asked"], 1),
+                                          "five_point_accepted_fraction": pst["acc5"] / max(pst["asked5"], 1),
+                                          "five_point_rejected_by_parallax_gate_fraction": pst["gated5"] / max(pst["asked5"], 1),
+                                          "five_point_note": "compute_pose_5pt! returns nothing while the average parallax against the previous key-frame is below 5 px "
+                                                             "(front_end.jl:290): the first frames after each key-frame; every remaining call is accepted when the two fractions add up to 1",
                                           "max_translation_error_m": pst["err_max"], "plane_depth_m": Z_PLANE},
            "pyramid_build_ms": {"mean": float(np.mean(builds)) if builds else None, "min": float(np.min(builds)) if builds else None,
-                                "n": len(builds), "what": "hipEvents around each left-batch build (ingest kernel + one hipGraph replay) on the pyramid "
+                                "n": len(builds), "what": "hipEvents around each left-batch build (one hipGraph replay, u8 ingest fused) on the pyramid "
                                                           "stream inside the timed region, tracking running beside it"}}
+    if snapshot is not None:
+        snap = {}
+        curb = lb[i_last % NLB]
+        for s_ in snapshot:
+            snap[s_] = {"frame_id": int(seq[(i_last % period) + s_]), "list": ks.download(s_, ctx=ctx),
+                        "planes": {(nm, l): curb.pyramids[s_].plane(nm, l, ctx=ctx) for l in range(levels + 1)
+                                   for nm in ("layers", "Iy", "Ix", "Iyy", "Ixx", "Iyx")}}
+        res["snapshot"] = snap
+        res["seq"] = seq; res["period"] = period; res["cap"] = cap
     for c in (ctx, ctx_pyr, ctx_right, ctx_copy):
         c.synchronize()
     torch.cuda.synchronize()
@@ -579,46 +646,91 @@ def run_lockstep_kpset(slam, torch, local_rank, S, steps, warmup, H, W, left, ri
     for m in built + copied + rcopied + rbuilt:
         if m is not None:
             m.close()
-    for b_ in lb + [rb]:
+    for b_ in lb + ([rb] if rb is not None else []):
         for p_ in b_.pyramids:
             p_.close()
     del lseq, rseq, cull_u, cull_flags
     if host:
-        del lstage, rstage, st_copy
+        del lstage, st_copy
     del st_main
     for c in (ctx, ctx_pyr, ctx_right, ctx_copy):
         c.close()
     return res
 
 
-def kernel_spans(slam, torch, local_rank, S, H, W, left, params, dev):
-    """Per-kernel device time of the batched build with serial launches (hipEvent spans cannot look inside the graph)."""
+def replay_stream_on_oracle(orc, slam, wl, rec, res, s, threads):
+    """The oracle's replay of stream s of a recorded run_lockstep_kpset run (checker; cpu_baseline leg only): the same 8-bit
+    frames, prior shifts and cull flags through orc.pyr_build / optical_flow_matching / detect / triangulate
+    (pyramid.jl:81-137, map_manager.jl:451-564 + :579-590, extractor.jl:63-95, mapper.jl:142-183).  Returns (yx, is_3d)."""
+    from slam_jl_amd.triangulation import projection_matrices
+    H, W, e, camt, disparity = wl["H"], wl["W"], wl["extractor"], wl["camt"], wl["disparity"]
+    seq, period = res["seq"], res["period"]
+    u8f = lambda im: np.asfortranarray(np.round(im * 255).astype(np.uint8).astype(np.float64) / 255.0)
+    T21 = np.eye(4); T21[0, 3] = -(disparity * 30.0 / camt[0])
+    P1, P2 = projection_matrices(camt, camt, T21)
+    kp = np.zeros((0, 2)); is3 = np.zeros(0, bool)
+    prev = None
+    for r in rec["steps"]:
+        i = r["i"]
+        f = seq[(i % period) + s]
+        img = u8f(wl["left"][f])
+        cur = orc.pyr_build(img, wl["levels"], 1.0, 1)
+        if len(kp) and r["shift"] is not None:
+            ref = orc.optical_flow_matching(prev, cur, kp, is3, kp + r["shift"][s], (H, W), sum_order=1, threads=threads)
+            keep = ~ref["removed"]
+            kp, is3 = ref["new_pixels"][keep], is3[keep]
+        if r["kf"]:
+            keep = r["cull"][s, :len(kp)] == 0
+            kp, is3 = kp[keep], is3[keep]
+            fresh = orc.detect(img, kp, max_points=e.max_points, radius=e.radius, cell_size=e.cell_size).astype(np.float64)
+            kp = np.concatenate([kp, fresh]); is3 = np.concatenate([is3, np.zeros(len(fresh), bool)])
+            rp = orc.pyr_build(u8f(wl["right"][f]), wl["levels"], 1.0, 1)
+            ref = orc.optical_flow_matching(cur, rp, kp, is3, kp + np.array([0.0, -disparity]), (H, W), stereo=True, undistorted_left=kp,
+                                            right_cam=camt, sum_order=1, threads=threads)
+            keep = ~ref["removed"]
+            kp, is3 = kp[keep], is3[keep]
+            up, syx = ref["updated"][keep], ref["new_pixels"][keep]
+            cand = np.flatnonzero(up & ~is3)
+            if len(cand):
+                _, ok = orc.triangulate(P1, P2, T21, camt, camt, kp[cand], syx[cand], 3.0)
+                is3 = is3.copy(); is3[cand[ok]] = True
+        prev = cur
+    return kp, is3
+
+
+def kernel_spans(slam, torch, local_rank, wl, dev):
+    """Per-kernel device time of the batched build with serial launches (hipEvent spans cannot look inside the graph),
+    and the graph replay alone on the GPU."""
+    S, H, W, params, left = wl["S"], wl["H"], wl["W"], wl["params"], wl["left"]
     ctx = slam.Context(local_rank)
     pb = slam.PyramidBatch((H, W), levels=params.pyramid_levels, S=S, ctx=ctx)
-    seq = frame_sequence(S + 2)
-    t = torch.from_numpy(np.stack([np.ascontiguousarray(left[seq[k]].T) for k in range(S)])).to(dev)
+    seq = frame_sequence_n(len(left), S + 2)
+    t = torch.from_numpy(np.stack([np.ascontiguousarray(np.round(left[seq[k]] * 255).astype(np.uint8).T) for k in range(S)])).to(dev)
     torch.cuda.synchronize()
-    ptrs = [t.data_ptr() + s * H * W * 8 for s in range(S)]
-    pb.update_(ptrs, sync=True, ctx=ctx)
+    ptrs = [t.data_ptr() + s * H * W for s in range(S)]
+    pb.update_(ptrs, sync=True, ctx=ctx, u8=True)
     ea, eb = slam.Event(ctx, timed=True), slam.Event(ctx, timed=True)
     ctx.record(ea)
     for _ in range(20):                                      # the stage alone on the GPU: graph replays back to back
-        pb.update_(ptrs, sync=False, ctx=ctx)
+        pb.update_(ptrs, sync=False, ctx=ctx, u8=True)
     ctx.record(eb)
     isolated_us = ea.elapsed_ms(eb) / 20 * 1e3
     ea.close(); eb.close()
     ctx.prof_enable(True); ctx.prof_reset()
     for _ in range(20):
-        pb.update_(ptrs, sync=False, ctx=ctx)
+        pb.update_(ptrs, sync=False, ctx=ctx, u8=True)
     ctx.synchronize()
     rows_ms, rows_n = ctx.prof_get("k_iir_rows"); pyr_ms, pyr_n = ctx.prof_get("pyr_update")
     ctx.prof_enable(False)
+    for p_ in pb.pyramids:
+        p_.close()
     ctx.close()
     return rows_ms / max(rows_n, 1) * 1e3, pyr_ms / max(pyr_n, 1) * 1e3, isolated_us
 
 
 def spawn_ranks(args):
-    """`python bench.py --gpus N` without a launcher: N fresh processes, one per GPU (this process never initialises HIP)."""
+    """`python bench.py --gpus N` without a launcher: N fresh processes, one per GPU (this process never initialises HIP).
+    A rank that fails takes its siblings with it (they would wait in a collective for ever), and the whole job has a deadline."""
     import socket
     import subprocess
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
@@ -631,24 +743,72 @@ def spawn_ranks(args):
             env["SLAM_BENCH_BACKEND"] = "gloo"
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + float(os.environ.get("SLAM_BENCH_SPAWN_TIMEOUT_S", "3600"))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                rc = max(rc, abs(code))
+        if live and (rc != 0 or time.time() > deadline):
+            for p in live:                                   # exactly the processes started above
+                p.kill()
+            for p in live:
+                p.wait()
+            return rc or 124
+        time.sleep(0.2)
     return rc
+
+
+LEGS = ("single", "tolerance", "headline", "ingest", "sweep", "host_protocol", "configs", "ba", "ba_sharded", "pose", "cpu")
+
+
+def newest_pmc(S):
+    """the newest profiles/r*_pmc_pyramid_batch_s<S>.json (names sort by round + letter), or None"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_pyramid_batch_s{S}.json")))
+    return c[-1] if c else None
+
+
+def ba_windows(syn):
+    """The BA windows SURVEY 8d / BASELINE name.  P5: the reference's own shape -- at most 5 free key-frames and many
+    constant observers (estimator.jl:327-331, :163-229): 25 poses of which the 20 oldest are constant, O ~ 8 k.
+    P20 / P50 / P100: every point seen by 10 consecutive key-frames.  P50_loop: the 50-KF window with loop-closure observations
+    (1500 points of the first 5 key-frames re-observed by the last 5): half-bandwidth 49 -> the non-banded fallback path."""
+    w = {}
+    s = syn.ba_scene(P=25, M=800, seed=5, n_const=20); w["P5_free_20_const"] = s
+    w["P20"] = syn.ba_scene(P=20, M=4000, seed=6)
+    w["P50"] = syn.ba_scene(P=50, M=10000, seed=7)
+    w["P100"] = syn.ba_scene(P=100, M=40000, seed=8)
+    w["P50_loop"] = syn.ba_scene_loop(P=50, M=10000, seed=7, n_loop=1500)
+    return w
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-ba", action="store_true", help="skip the BA measurements")
-    ap.add_argument("--streams", type=int, default=64, help="S: independent stereo streams per GPU advancing in lock-step (one batch of S frames per step); "
+    ap.add_argument("--steps", type=int, default=60, help="timed steps; one step = one key-frame period (5 frames) of each of the S streams")
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--only", type=str, default="", help="comma-separated legs to run (default: all): " + ", ".join(LEGS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and the oracle parity checks that live in it)")
+    ap.add_argument("--no-ba", action="store_true", help="skip the BA and pose measurements")
+    ap.add_argument("--streams", type=int, default=64, help="S: independent stereo streams per GPU advancing in lock-step (one batch of S frames per frame step); "
                     "64 = the library's batch limit: the big pyramid kernels then run whole rounds of workgroups (S = 32, the round-1 value: -8 %%)")
     ap.add_argument("--no-tolerance", action="store_true", help="skip the tolerance-mode measurements")
-    ap.add_argument("--no-sweep", action="store_true", help="skip the S = 48 / 64 streams-per-GPU legs")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the S = 32 / 48 streams-per-GPU legs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE shapes (kitti00_2000, euroc_mono, fhd_4000)")
     args = ap.parse_args()
+    legs = set(x for x in args.only.split(",") if x) or set(LEGS)
+    unknown = legs - set(LEGS)
+    if unknown:
+        raise SystemExit(f"unknown leg(s) {sorted(unknown)}; known: {LEGS}")
+    if args.no_cpu: legs.discard("cpu")
+    if args.no_ba: legs -= {"ba", "ba_sharded", "pose"}
+    if args.no_tolerance: legs.discard("tolerance")
+    if args.no_sweep: legs.discard("sweep")
+    if args.no_configs: legs.discard("configs")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process has not touched the GPU; it starts N fresh rank processes (one per GPU,
@@ -676,19 +836,13 @@ def main():
     import slam_jl_amd as slam
     from slam_jl_amd import synthetic as syn
     ctx = slam.Context(local_rank)
-    H, W = syn.SHAPES[SHAPE]
-    params = slam.Params(stereo=True, max_nb_keypoints=N_KPTS)
-    cam = slam.Camera(*syn.KITTI_CAM, height=H, width=W)
-    extractor = slam.Extractor.from_params(params, cam)
-    disparity = 12.4
-    left, right, flows = syn.stereo_stream(SHAPE, N_FRAMES, seed=rank, disparity=disparity)
     dev = torch.device("cuda", local_rank)
-    # Julia layout: column-major H x W  ==  row-major (W, H) tensor
-    left_dev = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in left]
-    right_dev = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in right]
-    torch.cuda.synchronize()
     S = args.streams
-    levels = params.pyramid_levels
+    wl = make_workload(slam, syn, "kitti05_1000", seed=rank, streams=S)
+    H, W, params, extractor, levels = wl["H"], wl["W"], wl["params"], wl["extractor"], wl["levels"]
+    left, right, flows, disparity = wl["left"], wl["right"], wl["flows"], wl["disparity"]
+    frame_steps = args.steps * KF_EVERY
+    fails = []
 
     def leg_done(tag):
         """every leg leaves the device clean: an asynchronous HIP error is reported against the leg that caused it"""
@@ -697,23 +851,6 @@ def main():
         except Exception as ex:
             raise RuntimeError(f"bench leg '{tag}' left a HIP error: {ex}") from ex
 
-    # The single-stream legs (latency views) run FIRST: once a stream of another priority class exists in the process (the headline legs
-    # create one for their tracking context) the runtime schedules the default-class queues differently and these latency-bound legs
-    # lose ~40 % (measured: 2 260 -> 1 400 frames/s); a deployment picks one configuration or the other, the bench measures each in its own.
-    single_result = None; tol_result = None
-    # ---- the same workload as ONE stream (latency view): 3 contexts, pipelined next-frame pyramid ----
-    n1 = min(args.steps, 300)
-    ctx_pyr = slam.Context(local_rank); ctx_right = slam.Context(local_rank)
-    be = GpuBackend(slam, ctx, ctx_pyr, ctx_right, H, W, left_dev, right_dev, params, extractor)
-    stream = Stream(be, flows, disparity, seed=rank)
-    seq = frame_sequence(args.warmup + n1 + 202)   # the ping-pong sequence is periodic
-    be.prime(seq[0])
-
-    def barrier():
-        be.drain(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
     def max_over_ranks(dt):
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -721,196 +858,272 @@ def main():
             return float(tt[0])
         return dt
 
-    for i in range(args.warmup):
-        stream.step(seq[i], seq[i + 1], seq[i + 2])
-    kp_before = stream.n_tracked
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + n1):
-        stream.step(seq[i], seq[i + 1], seq[i + 2])
-    barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
-    n_tracked_timed = stream.n_tracked - kp_before
-    # per-kernel device time: a second pass over the same stream with hipEvent spans on
-    # the library stream.  Spans force the direct-launch path (the timed region above
-    # replays the pyramid build as one hipGraph, which events cannot look inside).
-    prof_steps = min(n1, 100)
-    be.pipelined = False
-    for c in (ctx, ctx_pyr, ctx_right):
-        c.prof_enable(True); c.prof_reset()
-    base = args.warmup + n1
-    for i in range(base, base + prof_steps):
-        stream.step(seq[i], seq[i + 1], seq[i + 2])
-    pyr_ms, pyr_n = [a + b for a, b in zip(ctx_pyr.prof_get("pyr_update"), ctx_right.prof_get("pyr_update"))]
-    rows_ms, rows_n = [a + b for a, b in zip(ctx_pyr.prof_get("k_iir_rows"), ctx_right.prof_get("k_iir_rows"))]
-    fb_ms, fb_n = ctx.prof_get("fb_track")
-    det_ms, det_n = ctx.prof_get("detect")
-    for c in (ctx, ctx_pyr, ctx_right):
-        c.prof_enable(False)
-    be.pipelined = True
-    single = {"value": world * n1 / dt, "unit": "frames/sec", "steps": n1, "ms_per_frame": dt / n1 * 1e3, "streams_per_gpu": 1,
-              "tracked_kpts_per_frame": round(n_tracked_timed / max(n1, 1), 1),
-              "note": "the same workload as one stream per GPU through the single-image entry points (frame latency view)"}
-    if pyr_n:
-        pyr_bytes = pyramid_bytes(H, W, levels)
-        rows_bytes = iir_rows_bytes(H, W, levels) / (levels + 1)   # per launch (4 launches / pyramid)
-        a = rows_bytes / (rows_ms / rows_n * 1e-3) / 1e9
-        single["roofline"] = {"bound": "hbm", "kernel": "k_iir_rows, one image per launch (bound by the dependent f64 chain of the recurrence, not by HBM)",
-                              "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None,
-                              "avg_launch_us": rows_ms / rows_n * 1e3, "algorithmic_bytes_per_launch": rows_bytes,
-                              "stage": {"name": "pyramid update (all kernels of one image)", "algorithmic_bytes": pyr_bytes,
-                                        "avg_us": pyr_ms / pyr_n * 1e3, "achieved": pyr_bytes / (pyr_ms / pyr_n * 1e-3) / 1e9,
-                                        "frac": pyr_bytes / (pyr_ms / pyr_n * 1e-3) / 1e9 / HBM_PEAK_GBS}}
-        single["device_ms_per_frame"] = {"pyr_update_serial_launches": pyr_ms / prof_steps, "fb_track": fb_ms / prof_steps, "detect": det_ms / prof_steps,
-                                         "spans_over_steps": prof_steps, "launches": {"pyr_update": pyr_n, "fb_track": fb_n, "detect": det_n}}
-        pmc1 = os.path.join(ROOT, "profiles", "r01_pmc_pyramid.json")
-        if SHAPE == "kitti05" and os.path.exists(pmc1):
-            single["roofline"]["traffic"] = json.load(open(pmc1))["summary"]["k_iir_rows_bytes_per_launch"]
-            single["roofline"]["traffic_source"] = "profiles/r01_pmc_pyramid.json"
-    single_result = single
-    leg_done("single_stream")
+    out = {
+        "metric": "frames/sec KITTI-05 stereo @1k kpts; local-BA ms/iter for 50-KF window",
+        "value": None, "unit": "frames/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic", "legs": sorted(legs),
+    }
+
+    # The single-stream legs (latency views) run FIRST: once a stream of another priority class exists in the process (the headline legs
+    # create one for their tracking context) the runtime schedules the default-class queues differently and these latency-bound legs
+    # lose ~40 % (measured: 2 260 -> 1 400 frames/s); a deployment picks one configuration or the other, the bench measures each in its own.
+    if legs & {"single", "tolerance"}:
+        # Julia layout: column-major H x W  ==  row-major (W, H) tensor
+        left_dev = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in left]
+        right_dev = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in right]
+        torch.cuda.synchronize()
+        n1 = min(frame_steps, 300)
+        seq = frame_sequence(args.warmup * KF_EVERY + n1 + 202)   # the ping-pong sequence is periodic
+        w1 = max(args.warmup, 2) * KF_EVERY
+
+        def one_stream(fast):
+            c3 = [slam.Context(local_rank) for _ in range(3)]
+            be = GpuBackend(slam, c3[0], c3[1], c3[2], H, W, left_dev, right_dev, params, extractor, fast=fast)
+            stream = Stream(be, flows, disparity, seed=rank)
+            be.prime(seq[0])
+            for i in range(w1):
+                stream.step(seq[i], seq[i + 1], seq[i + 2])
+            kp_before = stream.n_tracked
+            be.drain(); torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for i in range(w1, w1 + n1):
+                stream.step(seq[i], seq[i + 1], seq[i + 2])
+            be.drain(); torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt = max_over_ranks(time.perf_counter() - t0)
+            return be, stream, c3, dt, stream.n_tracked - kp_before
+
+    if "single" in legs:
+        # ---- the same workload as ONE stream (latency view): 3 contexts, pipelined next-frame pyramid ----
+        be, stream, c3, dt, n_tracked_timed = one_stream(False)
+        # per-kernel device time: a second pass over the same stream with hipEvent spans on
+        # the library stream.  Spans force the direct-launch path (the timed region above
+        # replays the pyramid build as one hipGraph, which events cannot look inside).
+        prof_steps = min(n1, 100)
+        be.pipelined = False
+        for c in c3:
+            c.prof_enable(True); c.prof_reset()
+        base = w1 + n1
+        for i in range(base, base + prof_steps):
+            stream.step(seq[i], seq[i + 1], seq[i + 2])
+        pyr_ms, pyr_n = [a + b for a, b in zip(c3[1].prof_get("pyr_update"), c3[2].prof_get("pyr_update"))]
+        rows_ms, rows_n = [a + b for a, b in zip(c3[1].prof_get("k_iir_rows"), c3[2].prof_get("k_iir_rows"))]
+        fb_ms, fb_n = c3[0].prof_get("fb_track")
+        det_ms, det_n = c3[0].prof_get("detect")
+        for c in c3:
+            c.prof_enable(False)
+        single = {"value": world * n1 / dt, "unit": "frames/sec", "steps": n1, "ms_per_frame": dt / n1 * 1e3, "streams_per_gpu": 1,
+                  "tracked_kpts_per_frame": round(n_tracked_timed / max(n1, 1), 1),
+                  "note": "the same workload as one stream per GPU through the single-image entry points (frame latency view)"}
+        if pyr_n:
+            pyr_bytes = pyramid_bytes(H, W, levels)
+            rows_bytes = iir_rows_bytes(H, W, levels) / (levels + 1)   # per launch (4 launches / pyramid)
+            a = rows_bytes / (rows_ms / rows_n * 1e-3) / 1e9
+            single["roofline"] = {"bound": "hbm", "kernel": "k_iir_rows, one image per launch (bound by the dependent f64 chain of the recurrence, not by HBM)",
+                                  "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None,
+                                  "avg_launch_us": rows_ms / rows_n * 1e3, "algorithmic_bytes_per_launch": rows_bytes,
+                                  "stage": {"name": "pyramid update (all kernels of one image)", "algorithmic_bytes": pyr_bytes,
+                                            "avg_us": pyr_ms / pyr_n * 1e3, "achieved": pyr_bytes / (pyr_ms / pyr_n * 1e-3) / 1e9,
+                                            "frac": pyr_bytes / (pyr_ms / pyr_n * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+            single["device_ms_per_frame"] = {"pyr_update_serial_launches": pyr_ms / prof_steps, "fb_track": fb_ms / prof_steps, "detect": det_ms / prof_steps,
+                                             "spans_over_steps": prof_steps, "launches": {"pyr_update": pyr_n, "fb_track": fb_n, "detect": det_n}}
+        out["single_stream"] = single
+        for c in c3:
+            c.close()
+        leg_done("single_stream")
 
     # ---- tolerance-mode pyramid (mode 3: parallel recurrences, planes within 1e-11 rel.), single stream (batches of >= 4 images take
     #      the bit-exact kernels in this mode too) ----
-    if not args.no_tolerance:
-        tol_result = {"pyramid": "slam_pyr_update mode 3 (parallel recurrences; planes <= 1e-11 relative, tracked positions <= 1e-7 px vs "
-                                            "the bit-exact mode: tests/test_gpu_pyramid.py::test_fast_mode_within_tolerance)"}
-        fctx = [slam.Context(local_rank) for _ in range(3)]
-        fbe = GpuBackend(slam, fctx[0], fctx[1], fctx[2], H, W, left_dev, right_dev, params, extractor, fast=True)
-        fs = Stream(fbe, flows, disparity, seed=rank)
-        fbe.prime(seq[0])
-        for i in range(args.warmup):
-            fs.step(seq[i], seq[i + 1], seq[i + 2])
-        fbe.drain(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for i in range(args.warmup, args.warmup + n1):
-            fs.step(seq[i], seq[i + 1], seq[i + 2])
-        fbe.drain(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dtf = max_over_ranks(time.perf_counter() - t0)
-        tol_result["single_stream"] = {"value": world * n1 / dtf, "unit": "frames/sec", "ms_per_frame": dtf / n1 * 1e3}
-        for c in fctx:
+    if "tolerance" in legs:
+        be, stream, c3, dtf, _ = one_stream(True)
+        out["tolerance_mode"] = {"pyramid": "slam_pyr_update mode 3 (parallel recurrences; planes <= 1e-11 relative, tracked positions <= 1e-7 px vs "
+                                            "the bit-exact mode: tests/test_gpu_pyramid.py::test_fast_mode_within_tolerance)",
+                                 "single_stream": {"value": world * n1 / dtf, "unit": "frames/sec", "ms_per_frame": dtf / n1 * 1e3}}
+        for c in c3:
             c.close()
+        leg_done("tolerance_mode")
 
-    leg_done("tolerance_mode")
-    # ---- headline: S lock-stepped streams per GPU, keypoints resident in HBM, bit-exact planes.  Three ingest configurations;
-    #      `value` is the one a deployment sees (frames arrive in host memory as the decoder's 8-bit images) ----
-    legs = {}
-    for ingest in ("host_u8", "dev_f64", "host_f64"):
-        n_steps = args.steps if ingest == "host_u8" else max(40, args.steps // 3)
-        legs[ingest] = run_lockstep_kpset(slam, torch, local_rank, S, n_steps, args.warmup if ingest == "host_u8" else min(args.warmup, 10), H, W,
-                                          left, right, flows, disparity, params, extractor, world, dist, dev, ingest)
-    leg_done("lockstep_kpset")
-    head = legs["host_u8"]
-    rows_us, serial_us, isolated_us = kernel_spans(slam, torch, local_rank, S, H, W, left, params, dev)
-    pb = S * pyramid_bytes(H, W, levels)
-    build_ms = head["pyramid_build_ms"]["mean"]
-    rb_bytes = S * iir_rows_bytes(H, W, levels) / (levels + 1)
-    out = {
-        "metric": "frames/sec KITTI-05 stereo @1k kpts; local-BA ms/iter for 50-KF window",
-        "value": head["value"], "unit": "frames/sec",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": head["ms_per_step_of_S_frames"], "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "KITTI-05-shaped stereo streams 370x1226, 1000 kpts/frame, key-frame every 5th frame: "
-                               "left pyramid update + FB-LK (3-D prior pass + 2-D pass) per frame; "
-                               "detect + right pyramid + stereo FB-LK + stereo triangulation per key-frame (BASELINE configs[1]); "
-                               f"one step = one frame of each of {S} independent streams; frames START IN PINNED HOST MEMORY as the decoder's "
-                               "8-bit images and are copied to the GPU inside the timed loop (one H2D copy per step on the pyramid stream), "
-                               "converted to Float64 on the device; all arithmetic Float64",
-                   "frames_start": "pinned host memory, uint8 (example/kitty/kitty.jl:52-102 decode) -- copied H2D inside the timed region",
-                   "streams_per_gpu": S, "frames_per_step": S, "parallelism": f"replicas x{world}",
-                   "pyramid_mode": "bit-exact (slam_pyr_update mode 1 arithmetic; planes identical to the CPU oracle)",
-                   "batching": "the S streams advance in lock-step and share every launch: pyramids live in slam_pyr_create_batch batches "
-                               "(grid.z = stream); the keypoint lists live in HBM (slam_kpset_*): tracking + removal of lost keypoints, culling, "
-                               "key-frame detection + merge, stereo matching and triangulation are enqueue-only calls, the host reads the S list "
-                               "lengths once per step; 3 HIP streams (tracking/detect; left pyramids; right pyramids), the next frame's copy + "
-                               "pyramid build (one hipGraph replay) overlap the current frame's tracking",
-                   "tracked_kpts_per_frame": head["tracked_kpts_per_frame"],
-                   "window_size": params.window_size, "pyramid_levels": levels,
-                   "cull_fraction_per_keyframe": CULL_FRACTION},
-        "ingest": {k: {"value": v["value"], "ms_per_step_of_S_frames": v["ms_per_step_of_S_frames"], "steps": v["steps"],
-                       "pyramid_build_ms_mean": v["pyramid_build_ms"]["mean"]} for k, v in legs.items()},
-        # the dominant stage (>= 60 % of the device time of a step): the LK pyramid update of the S images of a step.  algorithmic bytes =
-        # 7 planes x 8 B x sum_l H_l W_l per image; duration = hipEvents around the build on the stream it runs on, in the
-        # timed region (ingest kernel + hipGraph replay of the ~20 kernels of the build), tracking kernels running beside it
-        "roofline": {"bound": "hbm", "stage": f"LK pyramid update of {S} images (pyramid.jl:81-137 + lucas_kanade.jl:109-138): ingest + one hipGraph replay",
-                     "isolated_launch_us": isolated_us, "frac_isolated": pb / (isolated_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                     "achieved": pb / (build_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": pb / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "frac_of_achievable": pb / (build_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, "achievable_peak": HBM_ACHIEVABLE_GBS,
-                     "algorithmic_bytes_per_launch": pb, "avg_launch_us": build_ms * 1e3, "launches_timed": head["pyramid_build_ms"]["n"],
-                     "min_launch_us": head["pyramid_build_ms"]["min"] * 1e3, "serial_launches_us": serial_us,
-                     "traffic": None,
-                     "note": "frac / avg_launch_us: hipEvents around every build of the timed region on the pyramid stream -- the tracking kernels of the "
-                             "previous frame run beside the build for its whole duration (own hardware queue), so the duration contains their share of the "
-                             "GPU; frac_isolated / isolated_launch_us: the same ingest + graph replay alone on the GPU, back to back",
-                     "kernel": {"name": "k_iir_rows_ck (dim-2 IIR pass, largest kernel of the build; algorithmic = 1R + 1W of every plane it filters)",
-                                "avg_launch_us": rows_us, "algorithmic_bytes_per_launch": rb_bytes,
-                                "achieved": rb_bytes / (rows_us * 1e-6) / 1e9, "frac": rb_bytes / (rows_us * 1e-6) / 1e9 / HBM_PEAK_GBS}},
-    }
-    for cand in ("r02g_pmc_pyramid_batch_s64.json", "r02d_pmc_pyramid_batch.json", "r02c_pmc_pyramid_batch.json", "r02a_pmc_pyramid_batch.json"):
-        pmc = os.path.join(ROOT, "profiles", cand)
-        if SHAPE == "kitti05" and os.path.exists(pmc):
+    # ---- headline: S lock-stepped streams per GPU, keypoints resident in HBM, bit-exact planes; frames arrive in host memory as the
+    #      decoder's 8-bit images ----
+    head = None
+    if "headline" in legs:
+        head = run_lockstep_kpset(slam, torch, local_rank, wl, args.steps, args.warmup, world, dist, dev, "host_u8", snapshot=[0, S - 1])
+        leg_done("headline")
+        rows_us, serial_us, isolated_us = kernel_spans(slam, torch, local_rank, wl, dev)
+        pb = S * pyramid_bytes(H, W, levels)
+        build_ms = head["pyramid_build_ms"]["mean"]
+        rb_bytes = S * iir_rows_bytes(H, W, levels) / (levels + 1)
+        out.update({
+            "value": head["value"], "ms_per_step": head["ms_per_step"],
+            "config": {"workload": "KITTI-05-shaped stereo streams 370x1226, 1000 kpts/frame, key-frame every 5th frame: "
+                                   "left pyramid update + FB-LK (3-D prior pass + 2-D pass) per frame; "
+                                   "detect + right pyramid + stereo FB-LK + stereo triangulation per key-frame (BASELINE configs[1]); "
+                                   f"one step = one key-frame period = {KF_EVERY} consecutive frames (the first a key-frame) of each of {S} independent streams "
+                                   f"= {S * KF_EVERY} frames; frames START IN PINNED HOST MEMORY as the decoder's "
+                                   "8-bit images and are copied to the GPU inside the timed loop (one H2D copy per frame step on the copy stream), "
+                                   "converted to Float64 on the device; all arithmetic Float64",
+                       "frames_start": "pinned host memory, uint8 (example/kitty/kitty.jl:52-102 decode) -- copied H2D inside the timed region",
+                       "streams_per_gpu": S, "frames_per_step": S * KF_EVERY, "key_frames_per_step": S, "frame_steps_timed": head["frame_steps"],
+                       "ms_per_frame_of_S_streams": head["ms_per_frame_of_S_streams"], "parallelism": f"replicas x{world}",
+                       "pyramid_mode": "bit-exact (slam_pyr_update mode 1 arithmetic; planes identical to the CPU oracle)",
+                       "batching": "the S streams advance in lock-step and share every launch: pyramids live in slam_pyr_create_batch batches "
+                                   "(grid.z = stream); the keypoint lists live in HBM (slam_kpset_*): tracking + removal of lost keypoints, culling, "
+                                   "key-frame detection + merge, stereo matching and triangulation are enqueue-only calls, the host reads the S list "
+                                   "lengths once per frame; 4 HIP streams (tracking/detect; left pyramids; right pyramids; copies), the next frames' copy + "
+                                   "pyramid build (one hipGraph replay) overlap the current frame's tracking",
+                       "tracked_kpts_per_frame": head["tracked_kpts_per_frame"], "host_wait_ms_per_frame": head["host_wait_ms_per_frame"],
+                       "window_size": params.window_size, "pyramid_levels": levels,
+                       "cull_fraction_per_keyframe": CULL_FRACTION},
+            # the dominant stage (>= 60 % of the device time of a step): the LK pyramid update of the S images of a frame step.  algorithmic
+            # bytes = SURVEY 8(d): 7 planes x 8 B x sum_l H_l W_l per image; duration = hipEvents around the build on the stream it runs on, in
+            # the timed region (one hipGraph replay of the ~20 kernels of the build), tracking kernels running beside it
+            "roofline": {"bound": "hbm", "stage": f"LK pyramid update of {S} images (pyramid.jl:81-137 + lucas_kanade.jl:109-138): one hipGraph replay, u8 ingest fused",
+                         "isolated_launch_us": isolated_us, "frac_isolated": pb / (isolated_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "achieved": pb / (build_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": pb / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_of_achievable": pb / (build_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, "achievable_peak": HBM_ACHIEVABLE_GBS,
+                         "algorithmic_bytes_per_launch": pb, "avg_launch_us": build_ms * 1e3, "launches_timed": head["pyramid_build_ms"]["n"],
+                         "min_launch_us": head["pyramid_build_ms"]["min"] * 1e3, "serial_launches_us": serial_us,
+                         "traffic": None,
+                         "note": "frac / avg_launch_us: hipEvents around every build of the timed region on the pyramid stream -- the tracking kernels of the "
+                                 "previous frame run beside the build for its whole duration (own hardware queue), so the duration contains their share of the "
+                                 "GPU; frac_isolated / isolated_launch_us: the same graph replay alone on the GPU, back to back",
+                         "kernel_local": {"name": "k_iir_rows_ck (dim-2 IIR pass, largest kernel of the build); bytes = 1R + 1W of every plane it filters -- "
+                                                  "a kernel-local figure, NOT SURVEY 8d's stage bytes",
+                                          "avg_launch_us": rows_us, "bytes_per_launch": rb_bytes,
+                                          "achieved": rb_bytes / (rows_us * 1e-6) / 1e9, "frac": rb_bytes / (rows_us * 1e-6) / 1e9 / HBM_PEAK_GBS}},
+        })
+        pmc = newest_pmc(S)
+        if pmc is not None:
             j = json.load(open(pmc))
-            if j.get("streams") == S:
-                out["roofline"]["traffic"] = j["summary"]["all_pyramid_kernels_bytes_per_batch_build"]
-                out["roofline"]["traffic_source"] = f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 corrected), all kernels of one {S}-image build"
-                break
+            out["roofline"]["traffic"] = j["summary"]["all_pyramid_kernels_bytes_per_batch_build"]
+            out["roofline"]["traffic_over_algorithmic"] = j["summary"]["all_pyramid_kernels_bytes_per_batch_build"] / pb
+            out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per "
+                                                 f"MI355X_MICROARCH.md, WRITE exact), all kernels of one {S}-image build; collected at commit {j.get('commit', 'unrecorded')}")
+
+    # ---- the other ingest configurations of the same loop ----
+    if "ingest" in legs:
+        out["ingest"] = {}
+        if head is not None:
+            out["ingest"]["host_u8"] = {"value": head["value"], "ms_per_step": head["ms_per_step"], "steps": head["steps"], "pyramid_build_ms_mean": head["pyramid_build_ms"]["mean"]}
+        for ingest in ("dev_f64", "host_f64"):
+            v = run_lockstep_kpset(slam, torch, local_rank, wl, max(8, args.steps // 3), 2, world, dist, dev, ingest)
+            out["ingest"][ingest] = {"value": v["value"], "ms_per_step": v["ms_per_step"], "steps": v["steps"], "pyramid_build_ms_mean": v["pyramid_build_ms"]["mean"]}
+        leg_done("ingest")
 
     # more streams per GPU share every launch better (the build's per-frame cost falls until the big kernels run whole rounds of
     # workgroups): the same loop at the other batch sizes, short
-    if not args.no_sweep and S in (32, 64):
+    if "sweep" in legs and S in (32, 64):
         out["streams_sweep"] = {}
         for S2 in ((48, 64) if S == 32 else (32, 48)):
-            r2 = run_lockstep_kpset(slam, torch, local_rank, S2, max(40, args.steps // 4), min(args.warmup, 10), H, W, left, right, flows, disparity,
-                                    params, extractor, world, dist, dev, "host_u8")
-            out["streams_sweep"][str(S2)] = {"value": r2["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": r2["ms_per_step_of_S_frames"]}
+            w2 = dict(wl); w2["S"] = S2
+            r2 = run_lockstep_kpset(slam, torch, local_rank, w2, max(8, args.steps // 4), 2, world, dist, dev, "host_u8")
+            out["streams_sweep"][str(S2)] = {"value": r2["value"], "unit": "frames/sec", "ms_per_step": r2["ms_per_step"]}
         leg_done("streams_sweep")
-    out["single_stream"] = single_result
-    if tol_result is not None:
-        out["tolerance_mode"] = tol_result
 
     # ---- the round-1 call protocol (keypoint lists on the host, numpy list surgery between the batch seams), frames resident in HBM:
     #      what the device-resident keypoint sets replaced ----
-    hp = run_lockstep(slam, torch, local_rank, S, max(40, args.steps // 4), min(args.warmup, 10), H, W, left_dev, right_dev, flows, disparity,
-                      params, extractor, False, world, dist, dev)
-    out["host_protocol"] = {"value": hp["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": hp["ms_per_step_of_S_frames"],
-                            "what": "slam_flow_match_batch_kept / slam_detect_batch with host keypoint lists, frames resident in HBM as Float64 "
-                                    "(compare ingest.dev_f64)"}
+    if "host_protocol" in legs:
+        left_dev = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in left]
+        right_dev = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in right]
+        torch.cuda.synchronize()
+        hp = run_lockstep(slam, torch, local_rank, S, max(40, frame_steps // 4), 10, H, W, left_dev, right_dev, flows, disparity,
+                          params, extractor, False, world, dist, dev)
+        out["host_protocol"] = {"value": hp["value"], "unit": "frames/sec", "ms_per_frame_of_S_streams": hp["ms_per_step_of_S_frames"],
+                                "what": "slam_flow_match_batch_kept / slam_detect_batch with host keypoint lists, frames resident in HBM as Float64 "
+                                        "(compare ingest.dev_f64)"}
+        del left_dev, right_dev
+        leg_done("host_protocol")
 
-    leg_done("host_protocol")
-    # ---- BA: 50-KF window (BASELINE metric), single GPU; sharded over all ranks when N > 1 -------------
-    if not args.no_ba:
-        s = syn.ba_scene(P=50, M=10000, seed=7)
-        cache = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
-        slam.bundle_adjustment_(cache, s["cam"], ctx=ctx)            # warm-up
-        cache = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
-        t0 = time.perf_counter(); slam.bundle_adjustment_(cache, s["cam"], ctx=ctx); wall = time.perf_counter() - t0
-        iters = cache.stats["iters_pass1"] + cache.stats["iters_pass2"]
-        out["ba"] = {"window_kf": 50, "observations": int(s["O"]), "points": int(s["M"]), "lm_iterations": iters,
-                     "ms_per_iter": cache.stats["device_ms"] / max(iters, 1), "wall_ms_total": wall * 1e3,
-                     "ssr_final": cache.stats["ssr_final"]}
+    # ---- the other BASELINE shapes through the same loop (their own streams-per-GPU, their own stage roofline) ----
+    if "configs" in legs:
+        out["configs"] = {}
+        for name in ("kitti00_2000", "euroc_mono", "fhd_4000"):
+            try:
+                w2 = make_workload(slam, syn, name, seed=rank)
+                mono = not w2["stereo"]
+                r2 = run_lockstep_kpset(slam, torch, local_rank, w2, max(6, args.steps // 4), 2, world, dist, dev, "host_u8", pose=mono)
+                _, serial2, iso2 = kernel_spans(slam, torch, local_rank, w2, dev)
+                pb2 = w2["S"] * pyramid_bytes(w2["H"], w2["W"], w2["levels"])
+                bm = r2["pyramid_build_ms"]["mean"]
+                out["configs"][name] = {
+                    "what": w2["what"], "shape": [w2["H"], w2["W"]], "kpts": w2["kpts"], "stereo": w2["stereo"], "streams_per_gpu": w2["S"],
+                    "value": r2["value"], "unit": "frames/sec", "steps": r2["steps"], "ms_per_step": r2["ms_per_step"],
+                    "ms_per_frame_of_S_streams": r2["ms_per_frame_of_S_streams"], "tracked_kpts_per_frame": r2["tracked_kpts_per_frame"],
+                    "pose": r2["pose"],
+                    "roofline": {"bound": "hbm", "stage": f"LK pyramid update of {w2['S']} images", "algorithmic_bytes_per_launch": pb2,
+                                 "avg_launch_us": bm * 1e3, "achieved": pb2 / (bm * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": pb2 / (bm * 1e-3) / 1e9 / HBM_PEAK_GBS, "isolated_launch_us": iso2,
+                                 "frac_isolated": pb2 / (iso2 * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+                del w2
+            except Exception as ex:                                   # never lose the line to an optional leg
+                out["configs"][name] = {"error": repr(ex)[:300]}
+                try:
+                    torch.cuda.synchronize()
+                except Exception:
+                    pass
+        leg_done("configs")
+
+    # ---- BA: the windows BASELINE / SURVEY 8d name, single GPU ----
+    ba_scenes = None
+    if "ba" in legs:
+        ba_scenes = ba_windows(syn)
+        out["ba"] = {"windows": {}}
+        for name, s in ba_scenes.items():
+            cache = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+            slam.bundle_adjustment_(cache, s["cam"], ctx=ctx)            # warm-up
+            hbw = syn.ba_halfband(s)
+            best = None
+            for _ in range(3):
+                cache = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+                t0 = time.perf_counter(); slam.bundle_adjustment_(cache, s["cam"], ctx=ctx); wall = time.perf_counter() - t0
+                iters = cache.stats["iters_pass1"] + cache.stats["iters_pass2"]
+                r = {"poses": int(s["P"]), "free_poses": int((np.asarray(s["theta_const"]) == 0).sum()), "observations": int(s["O"]), "points": int(s["M"]),
+                     "lm_iterations": iters, "ms_per_iter": cache.stats["device_ms"] / max(iters, 1), "wall_ms_total": wall * 1e3,
+                     "ssr_final": cache.stats["ssr_final"], "half_bandwidth": hbw,
+                     "solver_path": "banded: k_schur_groups + k_band_solve" if hbw <= 20 else "general: pair lists (k_blocks) + tiled Cholesky"}
+                if best is None or r["ms_per_iter"] < best["ms_per_iter"]:
+                    best = r
+            bytes_iter = 33 * s["O"] + 96 * s["P"] + 48 * s["M"] + 8 * (6 * s["P"]) ** 2
+            best["roofline"] = {"bound": "hbm", "algorithmic_bytes_per_iter": int(bytes_iter), "achieved": bytes_iter / (best["ms_per_iter"] * 1e-3) / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_iter / (best["ms_per_iter"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "latency-bound: a chain of dependent launches and block columns, not bytes"}
+            out["ba"]["windows"][name] = best
+        p50 = out["ba"]["windows"]["P50"]
+        out["ba"].update({"window_kf": 50, "observations": p50["observations"], "points": p50["points"], "lm_iterations": p50["lm_iterations"],
+                          "ms_per_iter": p50["ms_per_iter"], "wall_ms_total": p50["wall_ms_total"], "ssr_final": p50["ssr_final"]})
         leg_done("ba")
+    if "ba_sharded" in legs:
         from slam_jl_amd import sharded_ba
         try:
             # the point-sharded driver (slam_ba_lm_* + RCCL through slam_comm_*): device-paced, one all-reduce + one all-gather per iteration
             sP, sM = (100, 40000) if world > 1 else (50, 10000)
             s2 = syn.ba_scene(P=sP, M=sM, seed=8 if world > 1 else 7)
             sharded_ba.sharded_bundle_adjustment(s2["cam"], s2["theta0"], s2["theta_const"], s2["pixels_yx"], s2["pose_ids"], s2["point_ids"])
-            barrier(); t0 = time.perf_counter()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
             _, _, st = sharded_ba.sharded_bundle_adjustment(s2["cam"], s2["theta0"], s2["theta_const"], s2["pixels_yx"], s2["pose_ids"], s2["point_ids"])
-            barrier(); wall = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            wall = time.perf_counter() - t0
+            _, _, st3 = sharded_ba.sharded_bundle_adjustment(s2["cam"], s2["theta0"], s2["theta_const"], s2["pixels_yx"], s2["pose_ids"], s2["point_ids"], timings={})
+            st["collectives_us"] = st3.get("collectives_us")
             out["ba_sharded"] = {"window_kf": sP, "observations": int(s2["O"]), "world_size": world,
-                                 "ms_per_iter_wall": (st["lm_wall_ms"] or wall * 1e3) / max(iters_fast_total := 15, 1),
+                                 "ms_per_iter_wall": (st["lm_wall_ms"] or wall * 1e3) / 15,
                                  "lm_iterations_enqueued": 15, "lm_iterations_effective": st["iters_pass1"] + st["iters_pass2"],
                                  "whole_call_wall_ms": wall * 1e3,
                                  "what": "wall clock of the two device-paced LM passes (enqueue of 5 + 10 iterations: build, RCCL all-reduce of the reduced system, "
                                          "banded solve, all-gather of the trial costs, on-device decision; one host sync per pass) per iteration; the whole call "
                                          "adds host partitioning, shard set-up and the RCCL communicator",
+                                 "collectives_us": st.get("collectives_us"),
                                  "worth_sharding": bool(sharded_ba.worth_sharding(sP, s2["O"], world)), "ssr_final": st["ssr_final"]}
         except Exception as ex:                                   # never lose the line to the optional leg
             out["ba_sharded"] = {"error": repr(ex)[:300], "world_size": world}
@@ -944,7 +1157,7 @@ def main():
             cnt5 = fp_once()
         out["pose"]["five_point"] = {"points": 1000, "ransac_tuples": 128, "inliers": int(cnt5),
                                      "ms_per_call": (time.perf_counter() - t0) / 10 * 1e3}
-        # the same three seams for 32 lock-stepped streams: one launch set each (slam_*_batch)
+        # the same three seams for S lock-stepped streams: one launch set each (slam_*_batch)
         SB = S
         pss = [syn.p3p_scene(n=1000, seed=40 + z, noise_px=0.4, outlier_frac=0.25, iters=256) for z in range(SB)]
         fss = [syn.five_point_scene(n=1000, seed=40 + z, noise_px=0.4, outlier_frac=0.25, iters=128) for z in range(SB)]
@@ -966,7 +1179,7 @@ def main():
         out["pose"]["batch"] = {"streams": SB, "ms_per_step": (time.perf_counter() - t0) / 5 * 1e3,
                                 "what": "five-point RANSAC + P3P RANSAC + PnP refinement for the S streams (3 launch sets), host lists in and out"}
         # compute_pose! on device-resident lists (slam_kpset_compute_pose): the 3-D keypoints never visit the host.  A second set
-        # holds the 32 synthetic scenes (1000 map points each, 25 % gross outliers: they leave the lists in the first call, as
+        # holds the S synthetic scenes (1000 map points each, 25 % gross outliers: they leave the lists in the first call, as
         # in the reference; the timed calls see the 750 consistent points per stream)
         kspose = slam.KeypointSet(SB, 1024, ctx=ctx)
         for z, q in enumerate(pss):
@@ -1003,28 +1216,20 @@ def main():
                                 "points_per_stream": float(cn1.mean()), "inliers_first_call": float(ni0.mean()),
                                 "what": "slam_kpset_compute_pose: P3P RANSAC (256 triples) + PnP refinement + outlier removal for the S streams on "
                                         "device-resident lists; one device -> host copy (poses, status, list lengths)"}
-        if S == SB:
-            # the tracked workload with compute_pose! of all streams run after every step (pose inputs are the independent
-            # synthetic scenes above: the image-plane motion of the tracked streams is not a rigid 3-D motion)
-            wp = run_lockstep_kpset(slam, torch, local_rank, S, max(40, args.steps // 3), min(args.warmup, 10), H, W, left, right, flows, disparity,
-                                    params, extractor, world, dist, dev, "host_u8", pose=True)
-            out["pose"]["frontend_with_pose"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": wp["ms_per_step_of_S_frames"],
-                                                 "tracked_kpts_per_frame": wp["tracked_kpts_per_frame"], **wp["pose"],
-                                                 "what": "the headline workload as the reference's full per-frame front-end on the tracked lists themselves "
-                                                         "(front_end.jl:60-113): tracking with the priors of the predicted pose, slam_kpset_compute_pose_5pt, "
-                                                         "slam_kpset_compute_pose every step, key-frames with slam_kpset_keyframe and triangulation under the "
-                                                         "estimated pose; the streams are a rigid scene, the recovered translation is checked against the frames' offsets"}
-            wp = run_lockstep_kpset(slam, torch, local_rank, S, max(20, args.steps // 4), min(args.warmup, 10), H, W, left, right, flows, disparity,
-                                    params, extractor, world, dist, dev, "host_u8", hook=pose_frontend_once)
-            out["pose"]["frontend_with_scene_pose_seams"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": wp["ms_per_step_of_S_frames"],
-                                                             "what": "headline workload + both device-resident pose seams on 32 independent synthetic scenes every step"}
-            wp = run_lockstep_kpset(slam, torch, local_rank, S, max(20, args.steps // 4), min(args.warmup, 10), H, W, left, right, flows, disparity,
-                                    params, extractor, world, dist, dev, "host_u8", hook=pose_batch_once)
-            out["pose"]["frontend_with_host_pose_seams"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step_of_S_frames": wp["ms_per_step_of_S_frames"],
-                                                            "what": "headline workload + slam_five_point_ransac_batch + slam_p3p_ransac_batch + slam_pnp_ba_batch "
-                                                                    "every step (host lists in and out: the round-1 configuration of this figure)"}
+        # the tracked workload as the reference's full per-frame front-end on the tracked lists themselves
+        wp = run_lockstep_kpset(slam, torch, local_rank, wl, max(8, args.steps // 3), 2, world, dist, dev, "host_u8", pose=True)
+        out["pose"]["frontend_with_pose"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step": wp["ms_per_step"],
+                                             "tracked_kpts_per_frame": wp["tracked_kpts_per_frame"], **wp["pose"],
+                                             "what": "the headline workload as the reference's full per-frame front-end on the tracked lists themselves "
+                                                     "(front_end.jl:60-113): tracking with the priors of the predicted pose, slam_kpset_compute_pose_5pt, "
+                                                     "slam_kpset_compute_pose every frame, key-frames with slam_kpset_keyframe and triangulation under the "
+                                                     "estimated pose; the streams are a rigid scene, the recovered translation is checked against the frames' offsets"}
+        wp = run_lockstep_kpset(slam, torch, local_rank, wl, max(4, args.steps // 4), 2, world, dist, dev, "host_u8", hook=pose_batch_once)
+        out["pose"]["frontend_with_host_pose_seams"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step": wp["ms_per_step"],
+                                                        "what": "headline workload + slam_five_point_ransac_batch + slam_p3p_ransac_batch + slam_pnp_ba_batch "
+                                                                "every frame (host lists in and out: the round-1 configuration of this figure)"}
         kspose.close()
-    if not args.no_ba:
+    if "pose" in legs:
         try:
             pose_legs()
         except Exception as ex:
@@ -1034,8 +1239,9 @@ def main():
             except Exception:
                 pass
 
-    # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----------
-    if rank == 0 and world == 1 and not args.no_cpu:
+    # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only); the oracle is also the CHECKER of
+    #      the measured GPU paths here: planes of the timed run, a replayed key-frame cycle, every BA window ----
+    if rank == 0 and world == 1 and "cpu" in legs:
         from oracle import oracle as orc
         cpu_flags = orc.use_native() or "-O2 -ffp-contract=off"       # -O3 -march=native, compiled on this host
         threads = max(1, min(4, os.cpu_count() or 1))                 # the reference recommends -t4 (docs/src/index.md:60-64)
@@ -1051,27 +1257,68 @@ def main():
                                "sample": f"first {n_cpu} frames of the same stream (incl. {1 + (n_cpu - 1) // KF_EVERY} key-frames) through the C oracle "
                                          f"({cpu_flags}; LK loop OpenMP x{threads}, pyramid/detect single-threaded like the reference); "
                                          f"host has {os.cpu_count()} cores"}
-        if not args.no_ba:
-            s = syn.ba_scene(P=50, M=10000, seed=7)
-            t0 = time.perf_counter()
-            _, _, st0 = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], 2, 3, 5.0, solver=0)
-            c0 = (time.perf_counter() - t0) * 1e3 / max(st0["iters_pass1"] + st0["iters_pass2"], 1)
-            t0 = time.perf_counter()
-            _, _, st1 = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], 2, 3, 5.0, solver=1)
-            c1 = (time.perf_counter() - t0) * 1e3 / max(st1["iters_pass1"] + st1["iters_pass2"], 1)
-            # the measured GPU solver against the oracle on the same 50-KF problem and iteration budget (parity, not timing)
-            chk = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
-            slam.bundle_adjustment_(chk, s["cam"], iterations=3, iters_fast=2, ctx=ctx)
-            rel = abs(chk.stats["ssr_final"] - st1["ssr_final"]) / st1["ssr_final"]
-            rel0 = abs(chk.stats["ssr_final"] - st0["ssr_final"]) / st0["ssr_final"]
-            assert rel <= 1e-8 and chk.stats["n_outliers"] == st1["n_outliers"], ("BA parity vs oracle Schur-LM", rel, chk.stats, st1)
-            assert rel0 <= 1e-2, ("BA cost vs reference-style LM+LSMR", rel0)
-            out["ba"]["parity_vs_oracle"] = {"iters": [2, 3], "ssr_final_gpu": chk.stats["ssr_final"], "ssr_final_oracle_schur": st1["ssr_final"],
-                                             "rel_diff_schur": rel, "ssr_final_oracle_lm_lsmr": st0["ssr_final"], "rel_diff_lm_lsmr": rel0,
-                                             "outliers_equal": True}
-            out["ba"]["cpu_ms_per_iter_reference_style_lm_lsmr"] = c0
-            out["ba"]["cpu_ms_per_iter_schur"] = c1
-            out["ba"]["cpu_cores"] = 1
+        # -- parity of the front-end the headline measured: (1) the planes the TIMED run left behind, (2) a replayed run of the same
+        #    loop (same S, same u8 ingest path, two key-frames) whose keypoint lists the oracle reproduces
+        if head is not None:
+            par = {"ok": True}
+            u8f = lambda im: np.asfortranarray(np.round(im * 255).astype(np.uint8).astype(np.float64) / 255.0)
+            n_eq = 0
+            for s_, sn in head["snapshot"].items():
+                ref = orc.pyr_build(u8f(left[sn["frame_id"]]), levels, 1.0, 1)
+                for (nm, l), a in sn["planes"].items():
+                    eq = bool(np.array_equal(a, ref.plane(nm, l))); n_eq += eq
+                    if not eq:
+                        par["ok"] = False; fails.append(f"headline planes: stream {s_} {nm} level {l} differ from the oracle")
+            par["planes_after_timed_run"] = {"streams": sorted(head["snapshot"]), "planes_compared": 6 * (levels + 1) * len(head["snapshot"]),
+                                             "bit_equal": n_eq, "what": "all planes of the last left pyramids of the timed run vs orc.pyr_build of the same 8-bit frame"}
+            rec = {"frame_steps": 7, "steps": []}
+            rr = run_lockstep_kpset(slam, torch, local_rank, wl, 0, 0, world, dist, dev, "host_u8", record=rec, snapshot=[0, S - 1])
+            worst = 0.0; lists_ok = True
+            for s_, sn in rr["snapshot"].items():
+                kp_ref, is3_ref = replay_stream_on_oracle(orc, slam, wl, rec, rr, s_, threads)
+                got = sn["list"]
+                same = len(got["yx"]) == len(kp_ref) and bool(np.array_equal(got["is_3d"], is3_ref))
+                if same and len(kp_ref):
+                    worst = max(worst, float(np.abs(got["yx"] - kp_ref).max()))
+                lists_ok &= same
+            lists_ok &= worst <= 1e-6
+            if not lists_ok:
+                par["ok"] = False; fails.append(f"replayed key-frame cycle: keypoint lists differ from the oracle (max |dpx| {worst})")
+            par["replayed_frames"] = {"frames": 7, "key_frames": 2, "streams_per_gpu": S, "streams_checked": sorted(rr["snapshot"]),
+                                      "list_lengths_and_3d_flags_equal": bool(lists_ok), "max_abs_position_diff_px": worst,
+                                      "keypoints_per_checked_stream": [int(len(sn["list"]["yx"])) for sn in rr["snapshot"].values()],
+                                      "what": "the headline loop from empty lists for 7 frames (detect, stereo match, triangulate, 5 temporal matches, cull, detect ...) "
+                                              "with recorded priors / cull flags, replayed per stream through orc.pyr_build / optical_flow_matching / detect / triangulate"}
+            out["parity_vs_oracle"] = par
+        if ba_scenes is not None:
+            # the measured GPU solver against the oracle on every timed window (parity, not timing: 2 + 3 iterations)
+            for name, s in ba_scenes.items():
+                t0 = time.perf_counter()
+                _, _, st1 = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], 2, 3, 5.0, solver=1)
+                c1 = (time.perf_counter() - t0) * 1e3 / max(st1["iters_pass1"] + st1["iters_pass2"], 1)
+                chk = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+                slam.bundle_adjustment_(chk, s["cam"], iterations=3, iters_fast=2, ctx=ctx)
+                rel = abs(chk.stats["ssr_final"] - st1["ssr_final"]) / st1["ssr_final"]
+                okw = bool(rel <= 1e-8 and chk.stats["n_outliers"] == st1["n_outliers"])
+                if not okw:
+                    fails.append(f"BA window {name}: GPU vs oracle Schur-LM rel {rel}, outliers {chk.stats['n_outliers']} vs {st1['n_outliers']}")
+                wv = out["ba"]["windows"][name]
+                wv["parity_vs_oracle"] = {"iters": [2, 3], "ssr_final_gpu": chk.stats["ssr_final"], "ssr_final_oracle_schur": st1["ssr_final"],
+                                          "rel_diff_schur": rel, "outliers_equal": bool(chk.stats["n_outliers"] == st1["n_outliers"]), "ok": okw}
+                wv["cpu_ms_per_iter_schur"] = c1
+                if name == "P50":
+                    t0 = time.perf_counter()
+                    _, _, st0 = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], 2, 3, 5.0, solver=0)
+                    c0 = (time.perf_counter() - t0) * 1e3 / max(st0["iters_pass1"] + st0["iters_pass2"], 1)
+                    rel0 = abs(chk.stats["ssr_final"] - st0["ssr_final"]) / st0["ssr_final"]
+                    if rel0 > 1e-2:
+                        fails.append(f"BA P50: cost vs reference-style LM+LSMR rel {rel0}")
+                    wv["parity_vs_oracle"].update({"ssr_final_oracle_lm_lsmr": st0["ssr_final"], "rel_diff_lm_lsmr": rel0})
+                    out["ba"]["parity_vs_oracle"] = wv["parity_vs_oracle"]
+                    out["ba"]["cpu_ms_per_iter_reference_style_lm_lsmr"] = c0
+                    out["ba"]["cpu_ms_per_iter_schur"] = c1
+                    out["ba"]["cpu_cores"] = 1
+        if "pose" in legs:
             ps = syn.p3p_scene(n=1000, seed=3, noise_px=0.4, outlier_frac=0.25, iters=256)
             t0 = time.perf_counter()
             cnt, KP, Rt, inl, err, bi = orc.p3p_ransac(ps["pts3d"], ps["px_xy"], ps["pdn"], ps["K"], 3.0, ps["samples"])
@@ -1085,10 +1332,17 @@ def main():
             orc.five_point_ransac(fs["px1"], fs["px2"], fs["pd1"], fs["pd2"], fs["K"], fs["K"], 3.0, fs["samples"])
             out["pose"].setdefault("five_point", {})["cpu_ms_per_call"] = (time.perf_counter() - t0) * 1e3
 
+    if head is not None:
+        head.pop("snapshot", None)
+    if fails:
+        out["parity_failures"] = fails
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if fails:                                                     # the line is out; the exit status says a checker disagreed
+        print("PARITY FAILURES:\n  " + "\n  ".join(fails), file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

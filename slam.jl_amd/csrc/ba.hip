@@ -1987,11 +1987,16 @@ static int ba_enqueue_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, dou
     const int n = d.n;
     d.S = red; d.g = red + (size_t)n * n; d.udiag = d.g + n;
     hipStream_t st = ctx->stream;
-    // the grouped build rewrites every in-band block, g and diag(U) each time: the rest of the buffer only needs zeroing once
-    if (!ba->grouped || ba->zeroed != red) { HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)n * n + 2 * n + 8) * 8, st)); ba->zeroed = red; }
+    // the grouped build rewrites every block inside THIS problem's band (d.whb), g and diag(U) each time: the rest of the buffer only
+    // needs zeroing once -- as long as nobody else writes to it.  A caller-owned buffer (the sharded path all-reduces it in place, and a
+    // peer's band may be wider than ours: those blocks would keep the previous iteration's SUM and be summed again) is zeroed every time.
+    const bool private_red = red == ba->reduce;
+    if (!ba->grouped || !private_red || ba->zeroed != red) { HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)n * n + 2 * n + 8) * 8, st)); ba->zeroed = private_red ? red : nullptr; }
     if (ba->grouped) {
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_schur_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB)); attr_set = true; }
+        // the attribute belongs to the function object of the CURRENT device: once per device, result checked
+        static bool attr_set[64] = {};
+        const int dv = ctx->device & 63;
+        if (!attr_set[dv]) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB))); attr_set[dv] = true; }
         hipLaunchKernelGGL(k_schur_groups, dim3(d.ngrp), dim3(SG_T), sg_lds_bytes(d.whb), st, d, inv_delta, ignore_outliers, use_state);
         if (!use_state) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 0, d.ngrp, ba->nblocks_pts, 0, red + (size_t)n * n + 2 * n);
         const int nthr = d.P * (d.whb + 1) * 36 + d.P * 12;
@@ -2033,8 +2038,9 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
         if (trace_on && !trace_dev) (void)hipHostMalloc((void **)&trace_dev, 128);
         B.trace = trace_dev;
         if (trace_on && trace_n++ == 8) { (void)hipStreamSynchronize(st); fprintf(stderr, "band trace (cycles): P1 barrier wait %lld P2 barrier wait %lld backsub %lld | potrf+inv %lld panel %lld update %lld put/fetch %lld | factor wave %lld prefetch wave %lld | backsub: chat %lld G %lld recurrence %lld\n", trace_dev[1], trace_dev[2], trace_dev[3], trace_dev[4], trace_dev[5], trace_dev[6], trace_dev[7], trace_dev[8], trace_dev[9], trace_dev[10], trace_dev[11], trace_dev[12]); }
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        static bool attr_set[64] = {};
+        const int dv = ctx->device & 63;
+        if (!attr_set[dv]) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set[dv] = true; }
         hipLaunchKernelGGL(k_band_solve, dim3(twist ? 2 : 1), dim3(BS_T), band_lds, st, d, B, use_state);
     } else {
         CholArgs C; C.A = d.Swork; C.Lf = ba->lfac; C.n = n; C.ld = n + 1; C.fail = ba->chol_flag;

@@ -133,12 +133,37 @@ class HipShard:
         self.comm, self.ws = h, ws
         self.gathered = self.torch.zeros(4 * ws, dtype=self.torch.float64, device=self.red.device)
         self.torch.cuda.synchronize(self.red.device)
-        # the all-reduced system is as wide as the widest shard's
-        hb = self.torch.tensor([lib.slam_ba_halfband(self.h)], dtype=self.torch.int32, device=self.red.device)
-        if ws > 1:
-            dist.all_reduce(hb, op=dist.ReduceOp.MAX, group=group)
-        self.ctx.check(lib.slam_ba_set_halfband(self.h, int(hb[0])))
         return self
+
+    def halfband(self):
+        """block half-bandwidth of THIS shard's contribution to the reduced camera system"""
+        return int(self.ctx.lib.slam_ba_halfband(self.h))
+
+    def set_halfband(self, hb):
+        """the all-reduced system is as wide as the widest shard's: every rank solves with the maximum over the ranks"""
+        self.ctx.check(self.ctx.lib.slam_ba_set_halfband(self.h, int(hb)))
+
+    def measure_collectives(self, reps=20):
+        """device time (us) of one all-reduce of the reduce buffer and of one all-gather of the trial costs on this shard's
+        communicator, hipEvents on the library stream (the constants of worth_sharding, measured where they run)"""
+        from ._lib import Event
+        lib, c = self.ctx.lib, self.ctx
+        scratch = self.torch.zeros_like(self.red); self.torch.cuda.synchronize(self.red.device)
+        red, n_red = C.c_void_p(scratch.data_ptr()), scratch.numel()
+        trial, gath = C.c_void_p(self.trial.data_ptr()), C.c_void_p(self.gathered.data_ptr())
+        out = {}
+        for name, call in (("allreduce", lambda: lib.slam_comm_allreduce_sum(c.h, self.comm, red, n_red)),
+                           ("allgather", lambda: lib.slam_comm_allgather(c.h, self.comm, trial, gath, 4))):
+            c.check(call())
+            a, b = Event(c, timed=True), Event(c, timed=True)
+            c.record(a)
+            for _ in range(reps):
+                c.check(call())
+            c.record(b)
+            out[name] = a.elapsed_ms(b) / reps * 1e3
+            a.close(); b.close()
+        out["allreduce_bytes"] = n_red * 8
+        return out
 
     def lm_pass(self, ignore, iters, first_pass):
         """One LM pass (bundle_adjustment.jl:35-54): returns (ssr at the start, ssr at the end, iterations)."""
@@ -224,8 +249,38 @@ def sharded_bundle_adjustment(cam, theta, theta_const, pixels, pose_ids, point_i
     m_lo, m_hi = parts[rank]
     sel = np.where((li - 1 >= m_lo) & (li - 1 < m_hi))[0]
     theta_local = np.concatenate([theta[:n], theta[n + 3 * m_lo:n + 3 * m_hi]])
-    shard = shard_factory(cam, P, theta_local, tc, px[sel], pi[sel], li[sel] - m_lo)
     SUM, MAX = dist.ReduceOp.SUM, dist.ReduceOp.MAX
+
+    def agree(err):
+        """every rank learns whether ANY rank failed (a rank that raised alone would leave its peers in the next collective for ever)"""
+        if ws > 1:
+            flag = torch.tensor([1.0 if err is not None else 0.0], dtype=torch.float64,
+                                device=torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=MAX, group=group)
+            if err is None and float(flag[0]) != 0.0:
+                raise L.SlamHipError("sharded BA: another rank failed to set up its shard")
+        if err is not None:
+            raise err
+
+    shard, err = None, None
+    try:
+        shard = shard_factory(cam, P, theta_local, tc, px[sel], pi[sel], li[sel] - m_lo)
+    except Exception as ex:                                  # noqa: BLE001 -- re-raised on every rank by agree()
+        err = ex
+    agree(err)
+    device_paced = hasattr(shard, "lm_pass") and host_paced is not True
+    if device_paced:
+        try:
+            shard.make_comm(group)                           # RCCL through the C ABI on the library's own stream
+        except Exception as ex:                              # noqa: BLE001
+            err = ex
+        agree(err)
+    if hasattr(shard, "halfband"):
+        # the all-reduced system has the widest shard's band: agreed BEFORE the first solve of either path (a shard solving the summed
+        # system with its own narrower band would ignore blocks its peers contributed)
+        hbt = torch.tensor([float(shard.halfband())], dtype=torch.float64, device=shard.red.device if hasattr(shard, "red") else "cpu")
+        _all_reduce(hbt, MAX, group)
+        shard.set_halfband(int(hbt[0]))
 
     def run_pass(ignore, iters):
         delta, decrease = LM_DELTA0, 2.0
@@ -261,12 +316,10 @@ def sharded_bundle_adjustment(cam, theta, theta_const, pixels, pose_ids, point_i
                 converged = maxdx <= LM_XTOL
         return ssr0, ssr, it
 
-    device_paced = hasattr(shard, "lm_pass") and host_paced is not True
     import time as _time
     t_lm = 0.0
     if device_paced:
-        # product path: RCCL through the C ABI on the library's own stream, LM decisions on the device
-        shard.make_comm(group)
+        # product path: LM decisions on the device, no host synchronisation inside a pass
         t0 = _time.perf_counter()
         _, ssr1, it1 = shard.lm_pass(0, iters_fast, True)
         t_lm += _time.perf_counter() - t0
@@ -297,7 +350,8 @@ def sharded_bundle_adjustment(cam, theta, theta_const, pixels, pose_ids, point_i
         outl[s] = ol
     stats = dict(ssr_init=ssr_init, ssr_pass1=ssr1, ssr_final=ssr2, iters_pass1=it1, iters_pass2=it2,
                  n_outliers=int(n_out[0]), world_size=ws, points_local=m_hi - m_lo, obs_local=len(sel),
-                 lm_wall_ms=t_lm * 1e3 if device_paced else None)
+                 lm_wall_ms=t_lm * 1e3 if device_paced else None,
+                 collectives_us=shard.measure_collectives() if (device_paced and timings is not None) else None)
     if hasattr(shard, "close"):
         shard.close()
     return theta_out, outl, stats

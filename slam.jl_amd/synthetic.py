@@ -124,6 +124,52 @@ def ba_scene(P=5, M=800, obs_per_point=10, seed=0, cam=KITTI_CAM, H=376, W=1241,
                 gross_outliers=np.sort(out_idx))
 
 
+def ba_scene_loop(P=50, M=10000, seed=0, n_loop=1500, k_loop=5, **kw):
+    """ba_scene plus `n_loop` loop-closure map points: far points ahead of the track that the first `k_loop` AND the last
+    `k_loop` key-frames observe (local_map_matching re-associating old map points, map_manager.jl:300-449).  The reduced camera
+    system is no longer block-banded (half-bandwidth P - 1 - n_const): the solver's general path."""
+    s = ba_scene(P=P, M=M, seed=seed, **kw)
+    rng = np.random.default_rng(0xC105E + seed)
+    fx, fy, cx, cy = s["cam"]
+    H, W = kw.get("H", 376), kw.get("W", 1241)
+    noise_px = kw.get("noise_px", 0.5)
+    gt = s["theta_gt"]
+    poses = gt[:6 * P].reshape(P, 6)
+    Rp = _rot_batch(poses[:, :3]); tp = poses[:, 3:]
+    cams = np.concatenate([np.arange(k_loop), np.arange(P - k_loop, P)])
+    pts, pix = [], []
+    while len(pts) < n_loop:
+        u = rng.uniform(200, W - 200); v = rng.uniform(80, H - 80); z = rng.uniform(15.0, 60.0)
+        Xc = np.array([(u - cx) / fx * z, (v - cy) / fy * z, z])
+        Xw = Rp[P - 1].T @ (Xc - tp[P - 1])
+        xc = np.einsum("kij,j->ki", Rp[cams], Xw) + tp[cams]
+        py = fy * xc[:, 1] / xc[:, 2] + cy; px = fx * xc[:, 0] / xc[:, 2] + cx
+        if (xc[:, 2] > 1.0).all() and (py >= 1).all() and (py <= H).all() and (px >= 1).all() and (px <= W).all():
+            pts.append(Xw); pix.append(np.stack([py, px], 1))
+    pts = np.array(pts); pix = np.concatenate(pix) + rng.normal(0, noise_px, (n_loop * len(cams), 2))
+    M0 = s["M"]
+    obs_point = np.repeat(np.arange(M0 + 1, M0 + n_loop + 1, dtype=np.int64), len(cams))
+    obs_pose = np.tile(cams + 1, n_loop).astype(np.int64)
+    s["theta_gt"] = np.concatenate([gt, pts.ravel()])
+    s["theta0"] = np.concatenate([s["theta0"], (pts + rng.normal(0, 5e-2, pts.shape)).ravel()])
+    s["pixels_yx"] = np.ascontiguousarray(np.concatenate([s["pixels_yx"], pix]))
+    s["pose_ids"] = np.concatenate([s["pose_ids"], obs_pose]); s["point_ids"] = np.concatenate([s["point_ids"], obs_point])
+    s["M"] = M0 + n_loop; s["O"] = len(s["pose_ids"])
+    return s
+
+
+def ba_halfband(s):
+    """block half-bandwidth of the reduced camera system of a scene: widest span of FREE observers of one map point"""
+    free = np.asarray(s["theta_const"])[s["pose_ids"] - 1] == 0
+    pid, pose = s["point_ids"][free], s["pose_ids"][free]
+    if len(pid) == 0:
+        return 0
+    lo = np.full(s["M"] + 1, 1 << 30); hi = np.full(s["M"] + 1, -1)
+    np.minimum.at(lo, pid, pose); np.maximum.at(hi, pid, pose)
+    seen = hi >= 0
+    return int((hi[seen] - lo[seen]).max())
+
+
 def pnp_scene(n=300, seed=0, cam=KITTI_CAM, H=376, W=1241, noise_px=0.5, outlier_frac=0.05):
     rng = np.random.default_rng(0x9A9 + seed)
     fx, fy, cx, cy = cam
