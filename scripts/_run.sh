@@ -1,3 +1,3 @@
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 3 > gpurun_out/drv.json 2> gpurun_out/drv.err; echo rc $?
-python -c "
-import json; d=json.loads(open('gpurun_out/drv.json').read().strip().split('\n')[-1]); print(d['metric'][:60], round(d['value']), d['steps'], d['warmup'], d['ms_per_step'], d['n_gpus'], d['scaling'], d['dtype'], d['config']['workload'][:80])"
+python -m pytest tests/test_gpu_lk.py tests/test_gpu_kpset.py tests/test_gpu_batch.py tests/test_gpu_headline.py tests/test_gpu_edges.py tests/test_gpu_device_frontend.py tests/test_gpu_kitti_example.py -x -q 2>&1 | tail -4
+python scripts/prof_flow.py 32 2>&1 | tail -6
+python scripts/prof_headline.py 2>&1 | tail -1

@@ -14,4 +14,4 @@ for its in (0, 1, 30):
     new, ok = slam.optical_flow_matching_batch(pb[0], pb[1], sid, kp, is3d, proj, params, iterations=its, ctx=ctx)
     lib.slam_debug_lk_ticks(buf)
     t = [b * 10.0 / n / 1e3 for b in buf]      # us per point (100 MHz ticks)
-    print(f"iterations={its}: per point us: total {t[0]:.2f} | spatial_gradient {t[1]:.2f} | template {t[2]:.2f} | iter loads+accumulate {t[3]:.2f} | reduce+solve {t[4]:.2f}")
+    print(f"iterations={its}: per point us: total {t[0]:.2f} | position + offsets {t[5]:.2f} | set-up loads (template, patch, corners) + gradient {t[1]:.2f} | eig test {t[2]:.2f} | LDS samples + accumulate {t[3]:.2f} | reduce + solve {t[4]:.2f}")

@@ -3,16 +3,15 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-import bench
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 its = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-H, W = syn.SHAPES[bench.SHAPE]
-params = slam.Params(stereo=True, max_nb_keypoints=bench.N_KPTS)
+H, W = syn.SHAPES['kitti05']
+params = slam.Params(stereo=True, max_nb_keypoints=1000)
 cam = slam.Camera(*syn.KITTI_CAM, height=H, width=W)
 ex = slam.Extractor.from_params(params, cam)
-left, right, flows = syn.stereo_stream(bench.SHAPE, 4, seed=0, disparity=12.4)
+left, right, flows = syn.stereo_stream('kitti05', 4, seed=0, disparity=12.4)
 dev = torch.device("cuda", 0)
 ld = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in left]
 torch.cuda.synchronize()

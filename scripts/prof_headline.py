@@ -8,11 +8,8 @@ import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn
 import bench
 dev = torch.device("cuda", 0)
-H, W = syn.SHAPES["kitti05"]
-params = slam.Params(stereo=True, max_nb_keypoints=1000)
-cam = slam.Camera(*syn.KITTI_CAM, height=H, width=W)
-ex = slam.Extractor.from_params(params, cam)
-left, right, flows = syn.stereo_stream("kitti05", 8, seed=0, disparity=12.4)
-S_ = int(os.environ.get("S_", "32"))
-r = bench.run_lockstep_kpset(slam, torch, 0, S_, 100, 10, H, W, left, right, flows, 12.4, params, ex, 1, None, dev, sys.argv[1] if len(sys.argv) > 1 else "host_u8")
-print("split", os.environ.get("SLAM_BENCH_CU_SPLIT"), "value", round(r["value"]), "ms/step", round(r["ms_per_step_of_S_frames"], 3), "build ms", round(r["pyramid_build_ms"]["mean"] or 0, 3), "host wait ms/step", round(r["host_wait_ms_per_step"], 3))
+S_ = int(os.environ.get("S_", "64"))
+wl = bench.make_workload(slam, syn, os.environ.get("WL_", "kitti05_1000"), seed=0, streams=S_)
+r = bench.run_lockstep_kpset(slam, torch, 0, wl, int(os.environ.get("PERIODS_", "20")), 2, 1, None, dev, sys.argv[1] if len(sys.argv) > 1 else "host_u8")
+print("lib", os.environ.get("SLAMHIP_LIB", "default"), "value", round(r["value"]), "ms/frame-step", round(r["ms_per_frame_of_S_streams"], 3), "build ms", round(r["pyramid_build_ms"]["mean"] or 0, 3),
+      "host wait ms/frame", round(r["host_wait_ms_per_frame"], 3), "tracked", r["tracked_kpts_per_frame"])

@@ -43,6 +43,13 @@ extern "C" int slam_debug_lk_ticks(unsigned long long *out)
 #define LKT(k)
 #endif
 
+// (register allocation left to the compiler: 133 / 167 / 207 VGPRs for the 3- / 6- / 9-slot instantiations = 3 / 3 / 2 waves per SIMD;
+//  LK_WAVES caps it for experiments)
+#ifdef LK_WAVES
+#define LK_OCC __attribute__((amdgpu_waves_per_eu(LK_WAVES, LK_WAVES)))
+#else
+#define LK_OCC
+#endif
 struct Offs { int up, down, left, right; };
 
 __device__ __forceinline__ Offs get_offsets(int p0, int p1, double n0, double n1, int window, int H, int W)
@@ -65,13 +72,62 @@ __device__ __forceinline__ double boxdiff(const double *I, int H, int y1, int y2
     return sum;
 }
 
+// Wave-wide sum in the fixed butterfly order a[l] += a[l ^ m], m = 1, 2, 4, 8, 16, 32 (restated in the CPU
+// oracle, sum_order = 1), without touching the LDS crossbar: the reduction sits on the critical path of every LK
+// iteration, and six dependent ds_bpermute round trips cost ~700 cycles.  m = 1, 2: DPP quad_perm; m = 4, 8:
+// row_half_mirror / row_mirror (the partner group already holds one uniform value, so mirroring == xor);
+// m = 16, 32: the four row sums are read with v_readlane and combined as (R0 + R1) + (R2 + R3) in every lane.
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v = v + dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]  : l ^ 1
+    v = v + dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]  : l ^ 2
+    v = v + dpp_f64<0x141>(v);     // row_half_mirror      : l ^ 4 (quads are uniform)
+    v = v + dpp_f64<0x140>(v);     // row_mirror           : l ^ 8 (octets are uniform)
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    const int row = (threadIdx.x & 63) >> 4;
+    const double a = (row & 1) ? r1 + r0 : r0 + r1, b = (row & 1) ? r3 + r2 : r2 + r3;   // own row first (commutative: same bits)
+    return (row & 2) ? b + a : a + b;
+}
+
 // compute_spatial_gradient + svd2x2 + pinv2x2 (utils.jl:5-45)
 __device__ __forceinline__ double spatial_gradient(const LevelView &v, int p0, int p1, Offs o, double Gi[4])
 {
     const int y1 = p0 - o.up, y2 = p0 + o.down, x1 = p1 - o.left, x2 = p1 + o.right;
-    const double syy = boxdiff(v.Iyy, v.P, y1, y2, x1, x2);
-    const double sxx = boxdiff(v.Ixx, v.P, y1, y2, x1, x2);
-    const double syx = boxdiff(v.Iyx, v.P, y1, y2, x1, x2);
+    // Images.boxdiff of the three integral images (lucas_kanade.jl:143-145): the 12 corners are ONE load -- lane l < 12 fetches
+    // corner l & 3 of plane l >> 2 (corners left of / above the image read as 0, as boxdiff's index-0 rule) -- and the four terms
+    // of each plane are combined in boxdiff's order from v_readlane broadcasts (12 loads held 24 registers through the set-up)
+    double syy, sxx, syx;
+    {
+        const int lane = threadIdx.x & 63;
+        const int pl = lane >> 2, cn = lane & 3;
+        // (Iyy, Ixx, Iyx are consecutive planes of one allocation, pyramid.hip: plane(3..5, l); a per-lane select among the struct's
+        //  pointer fields becomes an indexed read of the struct and moves it to scratch)
+        const double *I = v.Iyy + (ptrdiff_t)pl * (v.Ixx - v.Iyy);
+        const int yy = (cn & 2) ? y1 - 2 : y2 - 1, xx = (cn & 1) ? x1 - 2 : x2 - 1;
+        const bool okc = lane < 12 && yy >= 0 && xx >= 0;
+        const double val = okc ? I[(size_t)yy + (size_t)xx * v.P] : 0.0;
+        double sm[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double sum = readlane_f64(val, 4 * k);
+            sum -= readlane_f64(val, 4 * k + 1);
+            sum -= readlane_f64(val, 4 * k + 2);
+            sum += readlane_f64(val, 4 * k + 3);
+            sm[k] = sum;
+        }
+        syy = sm[0]; sxx = sm[1]; syx = sm[2];
+    }
     // M col-major: M11 = syy, M21 = syx, M12 = syx, M22 = sxx
     const double E = (syy + sxx) / 2, F = (syy - sxx) / 2, G = (syx + syx) / 2, Hh = (syx - syx) / 2;
     const double Q = sqrt(E * E + Hh * Hh), R = sqrt(F * F + G * G);
@@ -122,34 +178,6 @@ __device__ __forceinline__ bool lies_in(int H, int W, double a, double b)
     return 1.0 <= a && a <= (double)H && 1.0 <= b && b <= (double)W;
 }
 
-// Wave-wide sum in the fixed butterfly order a[l] += a[l ^ m], m = 1, 2, 4, 8, 16, 32 (restated in the CPU
-// oracle, sum_order = 1), without touching the LDS crossbar: the reduction sits on the critical path of every LK
-// iteration, and six dependent ds_bpermute round trips cost ~700 cycles.  m = 1, 2: DPP quad_perm; m = 4, 8:
-// row_half_mirror / row_mirror (the partner group already holds one uniform value, so mirroring == xor);
-// m = 16, 32: the four row sums are read with v_readlane and combined as (R0 + R1) + (R2 + R3) in every lane.
-template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-__device__ __forceinline__ double wave_sum(double v)
-{
-    v = v + dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]  : l ^ 1
-    v = v + dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]  : l ^ 2
-    v = v + dpp_f64<0x141>(v);     // row_half_mirror      : l ^ 4 (quads are uniform)
-    v = v + dpp_f64<0x140>(v);     // row_mirror           : l ^ 8 (octets are uniform)
-    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
-    const int row = (threadIdx.x & 63) >> 4;
-    const double a = (row & 1) ? r1 + r0 : r0 + r1, b = (row & 1) ? r3 + r2 : r2 + r3;   // own row first (commutative: same bits)
-    return (row & 2) ? b + a : a + b;
-}
-
 // The lane's share of the (2w+1)^2 template: element e = lane + 64*k of the reference's (q outer, p inner)
 // enumeration.  Template samples, gradients and the element's window offsets depend only on the window
 // geometry, so they are fetched once per geometry and stay in registers across the <= 30 iterations
@@ -163,8 +191,15 @@ __device__ __forceinline__ double wave_sum(double v)
 // which is also what the 9 KB of LDS per wave allow).  Measured (scripts/lk_trace.py, rocprofv3 --pmc): a point executes
 // ~5k wave instructions as one dependent stream (~18 cycles each), VALU 33 % busy; L1-miss latency averages 400
 // cycles with only 2-3 misses outstanding per wave, so the kernel is bound by that instruction stream, not by HBM or L1.
+// LK_TMPL_LDS: template samples in an LDS spill area ([plane][slot][lane], 9 KB for 6 slots; round 1 / 2 layout: 105 VGPRs,
+// 4 waves per SIMD, needed while every iteration waited for global loads); default since round 3: template in registers
+// (36 VGPRs for 6 slots) -- the iteration reads the target from an LDS patch, and the LDS port is what it is bound by.
 template <int LK_MAXE> struct Tmpl {
+#ifdef LK_TMPL_LDS
     double (*s)[LK_MAXE][64];      // LDS: s[0] = template samples, s[1] = Iy, s[2] = Ix
+#else
+    double t0[LK_MAXE], t1[LK_MAXE], t2[LK_MAXE];
+#endif
     int pq[LK_MAXE];               // window coordinates p | q << 16 of slot k (0 | 0 past the window)
     int ne, kmax;
 };
@@ -187,8 +222,51 @@ __device__ __forceinline__ void load_template(Tmpl<LK_MAXE> &T, const LevelView 
         pe += sp; qe += sq;
         if (pe >= P) { pe -= P; qe++; }
         const size_t a = (size_t)(p0 - o.up + p - 1) + (size_t)(p1 - o.left + q - 1) * pitch;
+#ifdef LK_TMPL_LDS
         T.s[0][k][lane] = in ? first.L[a] : 0.0; T.s[1][k][lane] = in ? first.Iy[a] : 0.0; T.s[2][k][lane] = in ? first.Ix[a] : 0.0;
+#else
+        T.t0[k] = in ? first.L[a] : 0.0; T.t1[k] = in ? first.Iy[a] : 0.0; T.t2[k] = in ? first.Ix[a] : 0.0;
+#endif
         T.pq[k] = p | (q << 16);
+    }
+}
+
+// ---- the target footprint lives in LDS (north_star: "per-keypoint patches in LDS") -------------------------------------------
+// An iteration samples the (2w + 2)^2 footprint of the target layer around the current estimate, and the estimate moves by a
+// fraction of a pixel per iteration: the wave stages a PS x PS patch of the target layer (footprint + >= LK_PM pixels of
+// margin on every side) ONCE per level visit -- 16-byte loads, consecutive lanes on consecutive row pairs of a column, issued
+// together with the template loads -- and every iteration reads its four bilinear samples per element from LDS
+// (ds_read2_b64 x 2) instead of waiting for two global round trips.  The patch is re-staged, centred on the current estimate,
+// only when the footprint leaves it.  Same samples, same operations, same order: results are bit-identical to the global path.
+#define LK_PM 4
+template <int LK_MAXE> struct PatchGeom {
+    static constexpr int WMAX = LK_MAXE == 3 ? 6 : LK_MAXE == 6 ? 9 : 11;        // largest window_size of the instantiation
+    static constexpr int PS = 2 * WMAX + 2 + 2 * LK_PM;                           // 22 / 28 / 32 (even)
+};
+// top-left (cy, cx) 0-based is clipped so that the patch lies inside the image where the image is large enough.  No bounds
+// guards on the loads: rows / columns past the image are only staged when the image is smaller than the patch, they lie
+// inside the pyramid allocation (the layer planes are followed by the gradient planes) and are never sampled -- the
+// caller samples footprints that lie inside the image.
+template <int PS>
+__device__ __forceinline__ void stage_patch(double *patch, const double *img, int H, int W, int pitch, int cy, int cx, int &pry, int &prx)
+{
+    const int lane = threadIdx.x & 63;
+    const int hy = H - PS, hx = W - PS;
+    pry = cy < 0 ? 0 : (cy > hy ? (hy > 0 ? hy : 0) : cy);
+    prx = cx < 0 ? 0 : (cx > hx ? (hx > 0 ? hx : 0) : cx);
+    // LDS-DMA (global_load_lds_dwordx4): one instruction moves CPI whole patch columns -- lane = (column c of the group, row pair ch)
+    // in column-major order, so lane j lands at byte 16 j of the group: the lane-linear destination of the instruction IS the
+    // patch's [column][row] layout; no staging registers, no ds_write pass; the per-lane source offset is the same for every group
+    constexpr int CPC = PS / 2;                  // 16-byte chunks (row pairs) per column
+    constexpr int CPI = 64 / CPC;                // columns per instruction
+    constexpr int NIT = (PS + CPI - 1) / CPI;
+    const int ch = lane % CPC, c = lane / CPC;
+    const double *src = img + (size_t)pry + (size_t)prx * pitch + (2 * ch + (size_t)c * pitch);
+#pragma unroll
+    for (int i = 0; i < NIT; i++) {
+        if (c < CPI && i * CPI + c < PS)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)(i * CPI) * pitch),
+                                             (__attribute__((address_space(3))) void *)(patch + i * CPI * PS), 16, 0, 0);
     }
 }
 
@@ -206,8 +284,15 @@ __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView
     const double pf0 = (double)p0, pf1 = (double)p1;
     LKT_BEGIN;
     const bool cached = (2 * window + 1) * (2 * window + 1) <= 64 * LK_MAXE;
+    Tmpl<LK_MAXE> T;
+#ifdef LK_TMPL_LDS
     __shared__ double lds_tmpl[3][LK_MAXE][64];
-    Tmpl<LK_MAXE> T; T.s = lds_tmpl;
+    T.s = lds_tmpl;
+#endif
+    constexpr int PS = PatchGeom<LK_MAXE>::PS;
+    __shared__ __attribute__((aligned(16))) double lds_patch[PS * PS];
+    int pry = 0, prx = 0;
+    const int pmarg = (PS - (2 * window + 2)) >> 1;          // margin on each side of a full footprint (>= LK_PM)
     Offs o = {0, 0, 0, 0};
     double Gi[4];
     double c0 = 0.0, c1 = 0.0;
@@ -222,30 +307,40 @@ __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView
             if (!lies_in(H, W, r0, r1)) return false;
         }
         const Offs no = get_offsets(p0, p1, r0, r1, window, H, W);
+        LKT(5);
+        // where this pass samples the target (it = -1: where the first iteration will): the patch is staged at the level's
+        // starting estimate -- requested BEFORE the template and the integral-image corners, one memory round trip for all three --
+        // and again only when a later footprint leaves it.  Footprint strictly inside the image (always, except when
+        // r0 + down == H or r1 + right == W exactly): element (p, q) reads rows iy0+dp-1, iy0+dp of columns ix0+dq-1, ix0+dq,
+        // i.e. a fixed offset from the wave-uniform window origin; floor(r0 + dp) == floor(r0) + dp (and where rounding makes the
+        // left side one larger, fy == 1 selects the same samples), so the results equal bilinear()'s bit for bit.
+        const double e0 = it < 0 ? pf0 + dy : r0, e1 = it < 0 ? pf1 + dx : r1;
+        const double fr0 = floor(e0), fr1 = floor(e1);
+        const int iy0 = (int)fr0, ix0 = (int)fr1;
+        const bool fast = cached && iy0 - no.up >= 1 && iy0 + no.down <= H - 1 && ix0 - no.left >= 1 && ix0 + no.right <= W - 1;
+        const int fy0 = iy0 - no.up - 1, fx0 = ix0 - no.left - 1;                    // 0-based top-left sample of the footprint
+        if (cached && (it < 0 || (fast && (fy0 < pry || iy0 + no.down > pry + PS - 1 || fx0 < prx || ix0 + no.right > prx + PS - 1))))
+            stage_patch<PS>(lds_patch, second.L, H, W, pitch, iy0 - window - 1 - pmarg, ix0 - window - 1 - pmarg, pry, prx);
         if (it < 0 || no.up != o.up || no.down != o.down || no.left != o.left || no.right != o.right) {
             o = no;
+            if (cached) load_template(T, first, p0, p1, o);
             const double min_eig = spatial_gradient(first, p0, p1, o, Gi);
             LKT(1);
             if (min_eig < eig_thr) return false;
-            if (cached) load_template(T, first, p0, p1, o);
             LKT(2);
         }
         if (it < 0) continue;
         // prepare_linear_system (lucas_kanade.jl:159-173), wave order
         double ay = 0.0, ax = 0.0;
-        // Footprint strictly inside the image (always, except when r0 + down == H or r1 + right == W exactly):
-        // element (p, q) reads rows iy0+dp-1, iy0+dp of columns ix0+dq-1, ix0+dq, i.e. a fixed offset from
-        // the wave-uniform window origin; floor(r0 + dp) == floor(r0) + dp (and where rounding makes the left side
-        // one larger, fy == 1 selects the same samples), so the results equal bilinear()'s bit for bit.
-        const double fr0 = floor(r0), fr1 = floor(r1);
-        const int iy0 = (int)fr0, ix0 = (int)fr1;
-        if (cached && iy0 - o.up >= 1 && iy0 + o.down <= H - 1 && ix0 - o.left >= 1 && ix0 + o.right <= W - 1) {
-            // Two phases so that every footprint load of the iteration is in flight before the first one is used
-            // (k < kmax is wave-uniform; slots past the window hold a zero template and re-read element (0, 0)).
-            // bilinear(): rows iy-1, iy of columns ix-1, ix -> two 16-byte loads.
-            // (in two halves of LK_MAXE / 2 slots: half the loads in flight, 24 fewer VGPRs -> 4 waves per SIMD)
+        if (fast) {
+            // hipcc does not order these LDS reads behind an LDS-DMA still in flight (the patch re-staged in this pass: no other
+            // load sits between the DMA and the reads; at the first iteration the wait for the integral-image corners has
+            // already retired it) -- the wait is free whenever nothing is outstanding
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const double *pb = lds_patch + (fy0 - pry) + (fx0 - prx) * PS;
+            // bilinear(): rows iy-1, iy of columns ix-1, ix -> two 16-byte LDS reads per element
+            // (in two halves of LK_MAXE / 2 slots: fewer registers in flight)
             constexpr int HS = (LK_MAXE + 1) / 2;
-            const char *wbase = (const char *)(second.L + ((size_t)(iy0 - o.up - 1) + (size_t)(ix0 - o.left - 1) * pitch));
 #pragma unroll
             for (int h0 = 0; h0 < LK_MAXE; h0 += HS) {
                 D2 c0v[HS], c1v[HS];
@@ -253,8 +348,8 @@ __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView
                 for (int j = 0; j < HS; j++) {
                     const int k = h0 + j;
                     if (k < LK_MAXE && k < T.kmax) {
-                        const char *ptr = wbase + (unsigned)((T.pq[k] & 0xffff) + (T.pq[k] >> 16) * pitch) * 8u;
-                        c0v[j] = *(const D2 *)ptr; c1v[j] = *(const D2 *)(ptr + (size_t)pitch * 8);
+                        const double *ptr = pb + ((T.pq[k] & 0xffff) + (T.pq[k] >> 16) * PS);
+                        c0v[j] = *(const D2 *)ptr; c1v[j] = *(const D2 *)(ptr + PS);
                     }
                 }
 #pragma unroll
@@ -265,9 +360,15 @@ __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView
                         const double fy = (r0 + dp) - (fr0 + dp), fx = (r1 + dq) - (fr1 + dq);
                         const double t0 = (1 - fx) * c0v[j].a + fx * c1v[j].a;
                         const double t1 = (1 - fx) * c0v[j].b + fx * c1v[j].b;
+#ifdef LK_TMPL_LDS
                         const double dI = T.s[0][k][lane] - ((1 - fy) * t0 + fy * t1);
                         ay += dI * T.s[1][k][lane];
                         ax += dI * T.s[2][k][lane];
+#else
+                        const double dI = T.t0[k] - ((1 - fy) * t0 + fy * t1);
+                        ay += dI * T.t1[k];
+                        ax += dI * T.t2[k];
+#endif
                     }
                 }
             }
@@ -344,7 +445,7 @@ __device__ __forceinline__ int xcd_point(int n)
 static inline unsigned lk_grid(int n) { return (unsigned)((n + LK_XCDS - 1) / LK_XCDS) * LK_XCDS; }
 
 template <int LK_MAXE>
-__global__ __launch_bounds__(64) void k_fb_track(LKArgs A)
+__global__ __launch_bounds__(64) LK_OCC void k_fb_track(LKArgs A)
 {
     const int i = xcd_point(A.n);
     if (i >= A.n) return;
@@ -372,7 +473,7 @@ struct FlowArgs {
     size_t zs_from, zs_to;     // batch strides (doubles) of the from / to pyramids
 };
 template <int LK_MAXE>
-__global__ __launch_bounds__(64) void k_flow_match(FlowArgs F)
+__global__ __launch_bounds__(64) LK_OCC void k_flow_match(FlowArgs F)
 {
     const LKArgs &A = F.lk;
     const int i = xcd_point(A.n);
@@ -430,7 +531,7 @@ __device__ __forceinline__ void pdn_to_pixel(const double *cam, const double *di
     oy = (rd * ny + dty) * cam[1] + cam[3]; ox = (rd * nx + dtx) * cam[0] + cam[2];
 }
 template <int LK_MAXE>
-__global__ __launch_bounds__(64) void k_kpset_match(KpMatchArgs M)
+__global__ __launch_bounds__(64) LK_OCC void k_kpset_match(KpMatchArgs M)
 {
     const int ntot = M.ntot[0], per = (ntot + LK_XCDS - 1) / LK_XCDS;
     const int slotx = (int)(blockIdx.x / LK_XCDS);
