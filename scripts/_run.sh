@@ -1,3 +1,4 @@
-python -m pytest tests/test_gpu_lk.py tests/test_gpu_kpset.py tests/test_gpu_batch.py tests/test_gpu_headline.py tests/test_gpu_edges.py tests/test_gpu_device_frontend.py tests/test_gpu_kitti_example.py -x -q 2>&1 | tail -4
-python scripts/prof_flow.py 32 2>&1 | tail -6
-python scripts/prof_headline.py 2>&1 | tail -1
+for v in c d1 d2 c d1 d2; do
+  echo "=== $v"
+  SLAMHIP_LIB=$PWD/slam.jl_amd/libslamhip_lk_$v.so python scripts/prof_flow.py 32 2>&1 | tail -5 | head -2
+done

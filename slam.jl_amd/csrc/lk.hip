@@ -221,11 +221,15 @@ __device__ __forceinline__ void load_template(Tmpl<LK_MAXE> &T, const LevelView 
         const int p = in ? pe : 0, q = in ? qe : 0;
         pe += sp; qe += sq;
         if (pe >= P) { pe -= P; qe++; }
+        // (exec-masked loads: letting the slots past the window load element (0, 0) unconditionally -- straight-line code, all loads
+        //  back to back -- was measured 13 % SLOWER: the texture-address path is what the set-up is short of)
         const size_t a = (size_t)(p0 - o.up + p - 1) + (size_t)(p1 - o.left + q - 1) * pitch;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+        if (in) { v0 = first.L[a]; v1 = first.Iy[a]; v2 = first.Ix[a]; }
 #ifdef LK_TMPL_LDS
-        T.s[0][k][lane] = in ? first.L[a] : 0.0; T.s[1][k][lane] = in ? first.Iy[a] : 0.0; T.s[2][k][lane] = in ? first.Ix[a] : 0.0;
+        T.s[0][k][lane] = in ? v0 : 0.0; T.s[1][k][lane] = in ? v1 : 0.0; T.s[2][k][lane] = in ? v2 : 0.0;
 #else
-        T.t0[k] = in ? first.L[a] : 0.0; T.t1[k] = in ? first.Iy[a] : 0.0; T.t2[k] = in ? first.Ix[a] : 0.0;
+        T.t0[k] = in ? v0 : 0.0; T.t1[k] = in ? v1 : 0.0; T.t2[k] = in ? v2 : 0.0;
 #endif
         T.pq[k] = p | (q << 16);
     }
@@ -279,8 +283,8 @@ __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView
 {
     const int lane = threadIdx.x & 63;
     const int H = first.H, W = first.W, pitch = first.P;
-    const double scale = (double)(1 << (level - 1));
-    const int p0 = (int)floor(pty / scale), p1 = (int)floor(ptx / scale);
+    const double iscale = __hiloint2double((1023 - (level - 1)) << 20, 0);      // 2^-(level-1), built from its exponent: x * iscale == x / scale bit for bit (lucas_kanade.jl:38), no division sequence
+    const int p0 = (int)floor(pty * iscale), p1 = (int)floor(ptx * iscale);
     const double pf0 = (double)p0, pf1 = (double)p1;
     LKT_BEGIN;
     const bool cached = (2 * window + 1) * (2 * window + 1) <= 64 * LK_MAXE;
