@@ -398,6 +398,15 @@ __device__ __forceinline__ double dpp_pair_next(double v)        // lanes 2k and
     hi = __builtin_amdgcn_update_dpp(0, hi, 0xF5, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+// every sample of this kernel is touched once per sweep by one wave, and the two sweeps of a line are ~2 GB of other lines' traffic
+// apart: nontemporal loads and stores (no line kept for a reuse that cannot happen) -- k_iir_rows_ck -10 % (same-box A/B, S = 64)
+#ifdef ROWS_PLAIN
+#define RCK_LD(ptr) (*(ptr))
+#define RCK_ST(ptr, v) (*(ptr) = (v))
+#else
+#define RCK_LD(ptr) __builtin_nontemporal_load(ptr)
+#define RCK_ST(ptr, v) __builtin_nontemporal_store(v, ptr)
+#endif
 __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows_ck(PlaneSet ps, int H, int W, int P, IIRPair cf, double *ck, RowResize rz)
 {
     const int y = blockIdx.x * LINE_THREADS + threadIdx.x, pl = blockIdx.y;
@@ -455,7 +464,7 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows_ck(PlaneSet ps, int H
         const int len = n - (3 + j * CK_B);                     // samples left in the line
         if (len >= CK_B) {
 #pragma unroll
-            for (int e = 0; e < CK_B; e++) buf[e] = q[(long)e * s];
+            for (int e = 0; e < CK_B; e++) buf[e] = RCK_LD(q + (long)e * s);
         } else {
 #pragma unroll
             for (int e = 0; e < CK_B; e++) buf[e] = e < len ? q[(long)e * s] : 0.0;
@@ -513,7 +522,7 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows_ck(PlaneSet ps, int H
         double *q = p + (long)a * s;
         if (!resize) {
 #pragma unroll
-            for (int e = 0; e < CK_B; e++) if (e < len) q[(long)e * s] = cur[e];
+            for (int e = 0; e < CK_B; e++) if (e < len) RCK_ST(q + (long)e * s, cur[e]);
         }
 #pragma unroll
         for (int e = 0; e < CK_B; e++) cur[e] = nxt[e];
@@ -528,7 +537,7 @@ __global__ __launch_bounds__(LINE_THREADS) void k_iir_rows_ck(PlaneSet ps, int H
         double *q = p + (long)(3 + j * CK_B) * s;
         if (!resize) {
 #pragma unroll
-            for (int e = 0; e < CK_B; e++) q[(long)e * s] = cur[e];
+            for (int e = 0; e < CK_B; e++) RCK_ST(q + (long)e * s, cur[e]);
         }
 #pragma unroll
         for (int e = 0; e < CK_B; e++) cur[e] = nxt[e];
