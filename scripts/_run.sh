@@ -1,3 +1,2 @@
-for v in rbase rnt rbase rnt; do
-SLAMHIP_LIB=$PWD/slam.jl_amd/libslamhip_$v.so python scripts/prof_pyr_batch.py 64 30 u8 2>&1 | tail -1
-done
+python -m pytest tests/test_gpu_kpset.py tests/test_gpu_headline.py tests/test_gpu_device_frontend.py tests/test_gpu_lk.py -x -q 2>&1 | tail -4
+python scripts/prof_headline.py 2>&1 | tail -1

@@ -123,10 +123,8 @@ struct KTriArgs {
     const double *Twc;                 // [S][16] column-major camera-1 -> world, device
     double max_error, min_depth;
 };
-__global__ __launch_bounds__(64) void k_kpset_triangulate(KpsetView K, KTriArgs T, const int *work, const int *ntot)
+__device__ __forceinline__ void k_kpset_triangulate_slot(const KpsetView &K, const KTriArgs &T, const int *work, int i)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= ntot[0]) return;
     const size_t q = (size_t)work[i];
     if (!K.stereo[q] || K.is3d[q]) return;
     const int s = (int)(q / K.cap);
@@ -169,6 +167,12 @@ __global__ __launch_bounds__(64) void k_kpset_triangulate(KpsetView K, KTriArgs 
         K.is3d[q] = 1;
     } else K.stereo[q] = 0;
 }
+// (the grid is sized from the host's bound of the list lengths, which is only a hint: the loop covers every live slot whatever it was)
+__global__ __launch_bounds__(64) void k_kpset_triangulate(KpsetView K, KTriArgs T, const int *work, const int *ntot)
+{
+    const int n = ntot[0];
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) k_kpset_triangulate_slot(K, T, work, i);
+}
 
 // Array-level body of triangulate_temporal! (src/mapper.jl:185-262) on the set: every 2-D keypoint whose first observer (the
 // key-frame that detected it, observers[1] of its map point) is an earlier key-frame is triangulated from that observation and the
@@ -194,10 +198,8 @@ __device__ __forceinline__ void kp_undistort(const double *par, double y, double
     const double dtx = 2 * p1 * pp + p2 * (r2 + 2 * s0), dty = p1 * (r2 + 2 * s1) + 2 * p2 * pp;
     uy = (rd * ny + dty) * fy + cy; ux = (rd * nx + dtx) * fx + cx;
 }
-__global__ __launch_bounds__(64) void k_kpset_tri_temporal(KpsetView K, KTempArgs T, const int *work, const int *ntot)
+__device__ __forceinline__ void k_kpset_tri_temporal_slot(const KpsetView &K, const KTempArgs &T, const int *work, int i)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= ntot[0]) return;
     const size_t q = (size_t)work[i];
     if (K.is3d[q] || !K.haskf[q]) return;                        // get_2d_keypoints; keypoints no key-frame has observed yet
     const int s = (int)(q / K.cap), kf = K.fkf[q];
@@ -253,6 +255,12 @@ __global__ __launch_bounds__(64) void k_kpset_tri_temporal(KpsetView K, KTempArg
         for (int r = 0; r < 3; r++) K.xyz[3 * q + r] = ((WOB[r] * L0 + WOB[r + 4] * L1) + WOB[r + 8] * L2) + WOB[r + 12] * L3;   // project_camera_to_world(observer_kf, .)
         K.is3d[q] = 1;
     } else T.flags[q] = 1;                                        // remove_mappoint_obs!(map_manager, id, frame.kfid)
+}
+// (the grid is sized from the host's bound of the list lengths, which is only a hint: the loop covers every live slot whatever it was)
+__global__ __launch_bounds__(64) void k_kpset_tri_temporal(KpsetView K, KTempArgs T, const int *work, const int *ntot)
+{
+    const int n = ntot[0];
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) k_kpset_tri_temporal_slot(K, T, work, i);
 }
 
 extern "C" {

@@ -538,9 +538,12 @@ template <int LK_MAXE>
 __global__ __launch_bounds__(64) LK_OCC void k_kpset_match(KpMatchArgs M)
 {
     const int ntot = M.ntot[0], per = (ntot + LK_XCDS - 1) / LK_XCDS;
-    const int slotx = (int)(blockIdx.x / LK_XCDS);
-    const int idx = (int)(blockIdx.x % LK_XCDS) * per + slotx;     // each XCD a contiguous eighth of the (spatially ordered) list
-    if (slotx >= per || idx >= ntot) return;
+    // each XCD a contiguous eighth of the (spatially ordered) list.  The grid is sized from the host's bound of the list lengths,
+    // which is only a hint: a launch smaller than the lists walks them in several rounds (a keypoint that no wave visited would keep
+    // the previous call's status and be compacted away or kept from stale data)
+    for (int slotx = (int)(blockIdx.x / LK_XCDS); slotx < per; slotx += (int)(gridDim.x / LK_XCDS)) {
+    const int idx = (int)(blockIdx.x % LK_XCDS) * per + slotx;
+    if (idx >= ntot) break;
     const size_t q = (size_t)M.work[idx];
     const int s = (int)(q / M.cap);
     const double *P = M.par + 32 * (size_t)s;
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(64) LK_OCC void k_kpset_match(KpMatchArgs M)
     const bool lane0 = (threadIdx.x & 63) == 0;
     if (is3 && !inside) {
         if (lane0) { M.st[q] = M.stereo_mode ? 0 : 2; if (M.stereo_mode) M.stereo[q] = 0; }
-        return;
+        continue;
     }
     const size_t offF = (size_t)s * M.zs_from, offT = (size_t)s * M.zs_to;
     double ny = nan(""), nx = nan("");
@@ -574,11 +577,10 @@ __global__ __launch_bounds__(64) LK_OCC void k_kpset_match(KpMatchArgs M)
         ok = fb_point<LK_MAXE>(M.from, M.to, py, px, dy, dx, att == 0 ? M.levels3d : M.pyramid_levels, M.window, M.iterations, M.eig_thr, M.eps,
                                M.max_distance, ny, nx, offF, offT);
     }
-    if (!lane0) return;
-    if (!M.stereo_mode) {
+    if (lane0 && !M.stereo_mode) {
         M.oyx[2 * q] = ok ? ny : nan(""); M.oyx[2 * q + 1] = ok ? nx : nan("");
         M.st[q] = ok ? 1 : 0;
-    } else {
+    } else if (lane0) {
         if (ok) {                                                                                    // maybe_stereo_update!
             double uy, ux;
             pdn_to_pixel(P + 16, P + 20, (ny - P[19]) / P[17], (nx - P[18]) / P[16], uy, ux);      // undistort_point (camera.jl:98-103)
@@ -587,6 +589,7 @@ __global__ __launch_bounds__(64) LK_OCC void k_kpset_match(KpMatchArgs M)
         if (ok) { M.syx[2 * q] = py; M.syx[2 * q + 1] = nx; }
         M.stereo[q] = ok ? 1 : 0;
         M.st[q] = 2;
+    }
     }
 }
 

@@ -424,3 +424,30 @@ def test_temporal_triangulation_on_the_set_equals_the_host_seam(slam, syn):
     old = np.isin(was["ids"], before[0]["ids"][host[0][4]])           # had a key-frame observation before the call
     assert np.array_equal(k1[old], k0[old]) and np.array_equal(f1[old], f0[old])
     assert (k1[~old] == 4).all() and np.array_equal(f1[~old], was["yx"][~old])
+
+
+def test_a_small_n_bound_is_only_a_hint(slam, orc, syn, texture):
+    """n_bound sizes the launches from a host-side estimate; an estimate below the live count must not leave keypoints
+    with a stale status -- the kernels walk the work list in rounds.  Same lists with n_bound = 64 as with the default bound."""
+    S, H, W = 3, 120, 160
+    streams, a, b, r, keep = _setup(slam, texture, S, H, W)
+    params = slam.Params(stereo=True, max_nb_keypoints=150)
+    rng = np.random.default_rng(9)
+    out = []
+    for bound in (0, 64):
+        ks = slam.KeypointSet(S, 200)
+        for s in range(S):
+            k = orc.detect(streams[s][0][0], np.zeros((0, 2)), max_points=150).astype(float)
+            ks.upload(s, k, np.arange(len(k)) % 3 == 0)
+        shift = np.array([streams[s][2][1] for s in range(S)])
+        ks.flow_match(a, b, params, slam.stream_params(S, cam=syn.KITTI_CAM, shift_yx=shift), prior=2, n_bound=bound)
+        ks.stereo_match(b, r, params, slam.stream_params(S, cam=syn.KITTI_CAM, shift_yx=np.tile([0.0, -6.3], (S, 1))), prior=2, n_bound=bound)
+        T21 = np.eye(4); T21[0, 3] = -0.54
+        ks.triangulate(syn.KITTI_CAM, syn.KITTI_CAM, T21, np.eye(4), max_error=3.0, n_bound=bound)
+        out.append([ks.download(s) for s in range(S)])
+        assert ks.counts().sum() > 3 * 64
+        ks.close()
+    for s in range(S):
+        for key in ("yx", "is_3d", "xyz", "stereo_yx", "has_stereo"):
+            m = out[0][s]["is_3d"] if key == "xyz" else (out[0][s]["has_stereo"] if key == "stereo_yx" else slice(None))
+            assert np.array_equal(out[0][s][key][m], out[1][s][key][m]), (s, key)
