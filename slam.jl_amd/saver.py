@@ -11,11 +11,17 @@ int32 / int64 / double / string elements, bsonspec.org 1.1) is exact, the loweri
 package's published scheme (BSON.jl src/extensions.jl):
   positions :: Vector{Point3f0}   {tag: "array", type: {tag: "datatype", name: ["GeometryBasics", "Point"], params: [3, <Float32>]},
                                    size: [n], data: <binary, n x 3 little-endian float32>}      (an array of an isbits element type)
-  ids :: Dict{Int64,Int64}        written here as {tag: "dict", type: <Dict{Int64,Int64}>, keys: [int64 ...], vals: [int64 ...]} -- this
-                                   module's own layout, not a claim about BSON.jl's (it routes such a Dict through its struct path).
-`load` reads its own files, and for files written by Julia accepts the tagged array above or a plain BSON array of 3-vectors for the
-positions, and `data: [[keys ...], [vals ...]]` for the ids; tests/golden/make_golden_julia.jl saves a ReplaySaver from Julia into
-tests/golden/julia_replay/ so that a maintainer can pin (or correct) this against the real package."""
+  ids :: Dict{Int64,Int64}        BSON.jl has no dictionary tag for non-String / Symbol keys: such a Dict goes through its generic struct
+                                   path, `lower(x) = {tag: "struct", type: <typeof(x)>, data: structdata(x)}` with
+                                   `structdata(d::Dict) = Any[collect(keys(d)), collect(values(d))]`, and each Vector{Int64} is again a
+                                   tagged array: {tag: "struct", type: {tag: "datatype", name: ["Base", "Dict"], params: [<Int64>, <Int64>]},
+                                   data: [{tag: "array", type: <Int64>, size: [n], data: <binary, n little-endian int64>}, {... values}]}
+                                   -- what the reference's `@load ids_file ids` (saver.jl:92) rebuilds a Dict{Int64,Int64} from.
+`load` reads that layout (binary or plain-array keys / values), the positions as the tagged array above or as a plain BSON array of
+3-vectors, and the `{tag: "dict", keys, vals}` files this module wrote before round 3.  tests/golden/make_golden_julia.jl saves a
+ReplaySaver from Julia into tests/golden/julia_replay/ so that a maintainer can pin (or correct) this byte for byte against the real package
+(tests/test_saver.py compares the bytes when the directory exists).
+"""
 import os
 import struct
 
@@ -123,9 +129,11 @@ class ReplaySaver:
         f32 = _datatype(["Core", "Float32"])
         pos_doc = {"positions": {"tag": "array", "type": _datatype(["GeometryBasics", "Point"], [3, f32]),
                                  "size": [_I64(len(P))], "data": P.tobytes()}}
-        keys = sorted(self.ids)
-        ids_doc = {"ids": {"tag": "dict", "type": _datatype(["Base", "Dict"], [_datatype(["Core", "Int64"]), _datatype(["Core", "Int64"])]),
-                           "keys": [_I64(k) for k in keys], "vals": [_I64(self.ids[k]) for k in keys]}}
+        keys = list(self.ids)                                    # insertion order = first-seen order of the frame ids
+        i64 = _datatype(["Core", "Int64"])
+        vec = lambda a: {"tag": "array", "type": i64, "size": [_I64(len(a))], "data": np.asarray(a, dtype="<i8").tobytes()}
+        ids_doc = {"ids": {"tag": "struct", "type": _datatype(["Base", "Dict"], [i64, i64]),
+                           "data": [vec(keys), vec([self.ids[k] for k in keys])]}}
         with open(os.path.join(save_dir, "positions.bson"), "wb") as f:
             f.write(_enc_doc(pos_doc))
         with open(os.path.join(save_dir, "ids.bson"), "wb") as f:
@@ -146,10 +154,14 @@ class ReplaySaver:
         else:                                                   # a plain BSON array of 3-element arrays
             P = np.asarray(pos, dtype=np.float32).reshape(-1, 3)
         ids = _dec_doc(open(idf, "rb").read())["ids"]
-        if "keys" in ids and "vals" in ids:
+        def ints(a):                                             # a tagged Vector{Int64} (binary payload) or a plain BSON array
+            if isinstance(a, dict) and a.get("tag") == "array":
+                return np.frombuffer(a["data"], dtype="<i8").tolist() if isinstance(a["data"], (bytes, bytearray)) else list(a["data"])
+            return list(a)
+        if "keys" in ids and "vals" in ids:                      # this module's own layout before round 3
             k, v = ids["keys"], ids["vals"]
-        elif "data" in ids and isinstance(ids["data"], list) and len(ids["data"]) == 2:      # [[keys...], [vals...]]
-            k, v = ids["data"]
+        elif "data" in ids and isinstance(ids["data"], list) and len(ids["data"]) == 2:      # BSON.jl: structdata(d) = [keys, values]
+            k, v = ints(ids["data"][0]), ints(ids["data"][1])
         else:
             raise ValueError("ids.bson: unknown dictionary layout")
         self.ids = {int(a): int(b) for a, b in zip(k, v)}

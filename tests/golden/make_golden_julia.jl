@@ -6,9 +6,13 @@
 # tests/golden/julia_v1.npz under the same key names.  tests/test_golden_julia.py picks the file up when it exists and
 # compares the oracle (CPU) and the HIP path (GPU) against it -- that is what pins the oracle.
 #
-#     cd /path/to/SLAM.jl
-#     julia --project=. -e 'using Pkg; Pkg.add("NPZ")'
+#     cd /path/to/SLAM.jl                                    # at the commit this repository was built against (Project.toml: Images 0.24,
+#     julia --project=. -e 'using Pkg; Pkg.instantiate()'    #  ImageFiltering 0.6/0.7, ImageDraw 0.2, ImageFeatures 0.4, Interpolations 0.13,
+#     julia --project=. -e 'using Pkg; Pkg.add(name="NPZ", version="0.4")'   #  LeastSquaresOptim 0.8, SparseDiffTools 1, Rotations 1, BSON 0.3, RecoverPose 0.1)
 #     julia --project=. /path/to/repo/tests/golden/make_golden_julia.jl /path/to/repo/tests/golden
+#
+# One command writes every fixture the skipped tests wait for: julia_v1.npz (part 1), julia_frontend_v1.npz (part 2) and the
+# directory julia_replay/ (ReplaySaver BSON files).  `Pkg.status()` of the run is stored in julia_v1.npz["versions"].
 #
 # Besides the seam outputs it records the upstream-package primitives the oracle restates from their published
 # semantics (SURVEY Appendix A) on the same image -- shi_tomasi of one cell, the IIR Gaussian, imresize, the avoidance
@@ -114,6 +118,113 @@ SLAM.set_frame_wc!(saver, 7, wc((1.0, 2.0, 3.0))); SLAM.set_frame_wc!(saver, 9, 
 SLAM.set_frame_wc!(saver, 7, wc((1.5, 2.5, 3.5))); SLAM.set_frame_wc!(saver, 12, wc((0.0, 0.0, 10.0)))
 SLAM.save(saver, joinpath(dir, "julia_replay"))
 
-out["versions"] = [string(VERSION)]
+import Pkg
+out["versions"] = [string(VERSION); ["$(p.name)=$(p.version)" for p in values(Pkg.dependencies()) if p.is_direct_dep]]
 npzwrite(joinpath(dir, "julia_v1.npz"), Dict(k => (v isa Vector{String} ? codeunits(join(v, ";")) |> collect : v) for (k, v) in out))
 println("wrote ", joinpath(dir, "julia_v1.npz"), ": ", size(out["kp_nomask"], 1), " keypoints, ", sum(status), " tracked")
+
+# =====================================================================================================================
+# Part 2 (round 3): the rows SURVEY 8f added -- optical_flow_matching! (src/map_manager.jl:451-564, temporal and stereo with
+# maybe_stereo_update! :579-590), triangulate_stereo! (src/mapper.jl:142-183), RecoverPose's triangulate / p3p_ransac /
+# five_point_ransac as compute_pose! (src/front_end.jl:164-167) and compute_pose_5pt! (:305-308) call them.  Inputs:
+# tests/golden/frontend_v1.npz and tests/golden/pose_v1.npz; output: tests/golden/julia_frontend_v1.npz.
+# =====================================================================================================================
+using RecoverPose
+F = npzread(joinpath(dir, "frontend_v1.npz"))
+fo = Dict{String, Any}()
+l0, l1, r1 = gray(F["l0_u8"]), gray(F["l1_u8"]), gray(F["r1_u8"])
+FH, FW = size(l0)
+fcam = F["cam"]; baseline = F["baseline"][1]
+Ti0 = SMatrix{4, 4, Float64, 16}([1.0 0 0 -baseline; 0 1 0 0; 0 0 1 0; 0 0 0 1])      # right camera: x_right = x_left - baseline
+cam_l = SLAM.Camera(; fx = fcam[1], fy = fcam[2], cx = fcam[3], cy = fcam[4], height = FH, width = FW)
+cam_r = SLAM.Camera(; fx = fcam[1], fy = fcam[2], cx = fcam[3], cy = fcam[4], height = FH, width = FW, Ti0)
+fparams = SLAM.Params(; stereo = true, pyramid_levels = 3, window_size = 9, max_ktl_distance = 1.0)
+fex = SLAM.Extractor(80, 17, (cld(FH, 35), cld(FW, 35)), 35)
+q0 = SLAM.LKPyramid(l0, 3; σ = 1.0, reusable = true); SLAM.update!(q0, l0)
+q1 = SLAM.LKPyramid(l1, 3; σ = 1.0, reusable = true); SLAM.update!(q1, l1)
+qr = SLAM.LKPyramid(r1, 3; σ = 1.0, reusable = true); SLAM.update!(qr, r1)
+
+# a Frame + MapManager carrying exactly the fixture's keypoints: keypoint i has id i; a 3-D keypoint's map point sits where the
+# frame (cw = I) projects it onto the fixture's prior `proj[i]` (depth 10), so project_world_to_image_distort returns proj[i]
+function build_frame(kp, is3d, proj; depth = 10.0, right = false)
+    frame = SLAM.Frame(; camera = cam_l, right_camera = cam_r, cell_size = 35, id = 1, kfid = 1)
+    mm = SLAM.MapManager(fparams, frame, fex)
+    for i in 1:size(kp, 1)
+        SLAM.add_keypoint!(frame, SLAM.Point2f(kp[i, 1], kp[i, 2]), i; is_3d = Bool(is3d[i]))
+        mp = SLAM.MapPoint(i, 1, BitVector(), true)
+        if Bool(is3d[i])
+            # right image: x_right = x_left - baseline  ->  the left-camera point whose RIGHT projection is proj[i]
+            xs = (proj[i, 2] - fcam[3]) / fcam[1] * depth + (right ? baseline : 0.0)
+            ys = (proj[i, 1] - fcam[4]) / fcam[2] * depth
+            SLAM.set_position!(mp, SLAM.Point3f(xs, ys, depth))
+        end
+        mm.map_points[i] = mp
+    end
+    frame, mm
+end
+function dump_frame(frame, n)
+    pix = fill(NaN, n, 2); present = zeros(UInt8, n); stereo = zeros(UInt8, n); rpix = fill(NaN, n, 2); is3 = zeros(UInt8, n)
+    for (id, k) in frame.keypoints
+        pix[id, :] .= k.pixel; present[id] = 1; is3[id] = k.is_3d
+        if k.is_stereo
+            stereo[id] = 1; rpix[id, :] .= k.right_pixel
+        end
+    end
+    pix, present, stereo, rpix, is3
+end
+
+# ---- temporal: optical_flow_matching!(map_manager, frame, from, to, false)
+kp, is3d, proj = F["kp"], F["is3d"], F["proj"]
+n = size(kp, 1)
+frame, mm = build_frame(kp, is3d, proj)
+SLAM.optical_flow_matching!(mm, frame, q0, q1, false)
+pix, present, _, _, _ = dump_frame(frame, n)
+fo["t_new"] = pix; fo["t_present"] = present                       # present = 0: observation removed (:559)
+
+# ---- stereo: the surviving keypoints at their tracked positions, matched into the right image; then triangulate_stereo!
+keepi = findall(present .== 1)
+kp1 = pix[keepi, :]; is3d1 = is3d[keepi]
+sproj = F["s_proj"]
+@assert size(sproj, 1) == length(keepi) "the oracle kept $(size(sproj, 1)) keypoints, Julia kept $(length(keepi)): the temporal match already differs"
+frame2, mm2 = build_frame(kp1, is3d1, sproj; right = true)
+SLAM.optical_flow_matching!(mm2, frame2, q1, qr, true)
+pix2, present2, stereo2, rpix2, _ = dump_frame(frame2, length(keepi))
+fo["s_present"] = present2; fo["s_stereo"] = stereo2; fo["s_right"] = rpix2
+SLAM.triangulate_stereo!(mm2, frame2, 3.0, RecoverPose.GEEV4x4Cache())
+tri3 = zeros(UInt8, length(keepi)); trixyz = fill(NaN, length(keepi), 3); tristereo = zeros(UInt8, length(keepi))
+for (id, k) in frame2.keypoints
+    tristereo[id] = k.is_stereo
+    mp = get(mm2.map_points, id, nothing)
+    if mp !== nothing && mp.is_3d
+        tri3[id] = 1; trixyz[id, :] .= SLAM.get_position(mp)
+    end
+end
+fo["tri_is3d"] = tri3; fo["tri_xyz"] = trixyz; fo["tri_stereo_after"] = tristereo
+
+# ---- RecoverPose primitives on the inputs of pose_v1.npz
+Pz = npzread(joinpath(dir, "pose_v1.npz"))
+tc = Pz["tri_cam"]; T21 = SMatrix{4, 4, Float64, 16}(Pz["tri_T21"])
+K4(c) = SMatrix{4, 4, Float64, 16}([c[1] 0 c[3] 0; 0 c[2] c[4] 0; 0 0 1 0; 0 0 0 1])
+P1 = K4(tc) * SMatrix{4, 4, Float64, 16}(I); P2 = K4(tc) * T21
+cache = RecoverPose.GEEV4x4Cache()
+ntri = size(Pz["tri_px1"], 1)
+tri = zeros(Float64, ntri, 4)
+for i in 1:ntri                                                        # mapper.jl:162-165: (x, y) pixels
+    tri[i, :] .= RecoverPose.triangulate(SLAM.Point2f(Pz["tri_px1"][i, 2], Pz["tri_px1"][i, 1]), SLAM.Point2f(Pz["tri_px2"][i, 2], Pz["tri_px2"][i, 1]), P1, P2, cache)
+end
+fo["rp_triangulate_h"] = tri                                          # homogeneous, before the division by [4]
+K3(m) = SMatrix{3, 3, Float64, 9}(m)
+p3pts = [SLAM.Point3f(Pz["p3p_pts"][i, :]...) for i in 1:size(Pz["p3p_pts"], 1)]
+p3px = [SLAM.Point2f(Pz["p3p_px"][i, :]...) for i in 1:size(Pz["p3p_px"], 1)]
+p3pdn = [SLAM.Point3f(Pz["p3p_pdn"][i, :]...) for i in 1:size(Pz["p3p_pdn"], 1)]
+res = RecoverPose.p3p_ransac(p3pts, p3px, p3pdn, K3(Pz["p3p_K"]); threshold = 3.0)           # front_end.jl:164-167
+if res !== nothing
+    n_inl, (KP, inl, err) = res
+    fo["p3p_n"] = [n_inl]; fo["p3p_KP"] = Matrix{Float64}(KP); fo["p3p_inliers"] = UInt8.(inl); fo["p3p_error"] = [Float64(err)]
+end
+fp1 = [SLAM.Point2f(Pz["fp_px1"][i, :]...) for i in 1:size(Pz["fp_px1"], 1)]; fp2 = [SLAM.Point2f(Pz["fp_px2"][i, :]...) for i in 1:size(Pz["fp_px2"], 1)]
+fd1 = [SLAM.Point2f(Pz["fp_pd1"][i, :]...) for i in 1:size(Pz["fp_pd1"], 1)]; fd2 = [SLAM.Point2f(Pz["fp_pd2"][i, :]...) for i in 1:size(Pz["fp_pd2"], 1)]
+n5, (E5, P5, inl5, err5) = RecoverPose.five_point_ransac(fp1, fp2, fd1, fd2, K3(Pz["fp_K"]), K3(Pz["fp_K"]), cache; max_repr_error = 3.0)   # front_end.jl:305-308
+fo["fp_n"] = [n5]; fo["fp_E"] = Matrix{Float64}(E5); fo["fp_P"] = Matrix{Float64}(P5); fo["fp_inliers"] = UInt8.(inl5)
+npzwrite(joinpath(dir, "julia_frontend_v1.npz"), fo)
+println("wrote ", joinpath(dir, "julia_frontend_v1.npz"), ": ", sum(present), " of ", n, " keypoints kept, ", sum(stereo2), " stereo matches, ", sum(tri3), " map points")

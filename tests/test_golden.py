@@ -76,3 +76,27 @@ def test_hip_reproduces_pose_golden(slam):
                                                         max_repr_error=3.0, samples=GP["fp_samples"], return_extra=True)
     assert cnt == GP["fp_n"] and bi == GP["fp_best"] and err == GP["fp_error"]
     assert np.array_equal(inl, GP["fp_inliers"]) and np.array_equal(P, GP["fp_P"]) and np.array_equal(E, GP["fp_E"])
+
+
+def test_frontend_fixture_is_what_the_oracle_computes(orc):
+    """tests/golden/frontend_v1.npz (inputs of the Julia pin route for optical_flow_matching! + triangulate_stereo!) still equals the oracle."""
+    from slam_jl_amd.triangulation import projection_matrices
+    F = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frontend_v1.npz"))
+    f = lambda u8: np.asfortranarray(u8.astype(np.float64) / 255.0)
+    H, W = F["l0_u8"].shape
+    cam = tuple(F["cam"])
+    p0, p1, pr = (orc.pyr_build(f(F[k]), 3, 1.0, 1) for k in ("l0_u8", "l1_u8", "r1_u8"))
+    t = orc.optical_flow_matching(p0, p1, F["kp"], F["is3d"], F["proj"], (H, W), sum_order=0)
+    assert np.array_equal(t["updated"], F["t_updated"]) and np.array_equal(t["removed"], F["t_removed"]) and np.array_equal(t["new_pixels"], F["t_new"])
+    keep = ~t["removed"]
+    kp1, is3d1 = t["new_pixels"][keep], F["is3d"][keep]
+    s = orc.optical_flow_matching(p1, pr, kp1, is3d1, F["s_proj"], (H, W), stereo=True, undistorted_left=kp1, right_cam=cam, sum_order=0)
+    assert np.array_equal(s["updated"], F["s_updated"]) and np.array_equal(s["removed"], F["s_removed"]) and np.array_equal(s["new_pixels"], F["s_new"])
+    sk = ~s["removed"]
+    T21 = np.eye(4); T21[0, 3] = -float(F["baseline"][0])
+    P1, P2 = projection_matrices(cam, cam, T21)
+    kp2, up, syx, i3 = kp1[sk], s["updated"][sk], s["new_pixels"][sk], is3d1[sk]
+    cand = np.flatnonzero(up & ~i3)
+    assert np.array_equal(cand, F["tri_cand"])
+    xyz, ok = orc.triangulate(P1, P2, T21, cam, cam, kp2[cand], syx[cand], 3.0)
+    assert np.array_equal(ok, F["tri_ok"]) and np.array_equal(xyz, F["tri_xyz"])

@@ -74,3 +74,61 @@ def test_hip_matches_julia(slam):
     assert abs(cache.stats["ssr_final"] - J["ba_ssr_final"][0]) <= BA_COST_RTOL * J["ba_ssr_final"][0]
     bits, rc = slam.describe(e, img0, J["kp_nomask"], pattern=J["brief_pattern"])
     assert np.array_equal(rc, J["brief_rc"]) and np.array_equal(bits, J["brief_bits"])
+
+
+# ---- part 2: the rows SURVEY 8f added (tests/golden/julia_frontend_v1.npz, written by the same Julia script) -------------------------
+JF = os.path.join(HERE, "golden", "julia_frontend_v1.npz")
+needs_frontend = pytest.mark.skipif(not os.path.exists(JF), reason="tests/golden/julia_frontend_v1.npz not generated (needs Julia + SLAM.jl: tests/golden/make_golden_julia.jl)")
+
+
+@needs_frontend
+def test_oracle_flow_matching_and_triangulation_match_julia(orc):
+    """optical_flow_matching! (temporal + stereo) and triangulate_stereo! of the real SLAM.jl on the inputs of frontend_v1.npz."""
+    from slam_jl_amd.triangulation import projection_matrices
+    F = np.load(os.path.join(HERE, "golden", "frontend_v1.npz")); J = np.load(JF)
+    f = lambda u8: np.asfortranarray(u8.astype(np.float64) / 255.0)
+    H, W = F["l0_u8"].shape
+    cam = tuple(F["cam"])
+    p0, p1, pr = (orc.pyr_build(f(F[k]), 3, 1.0, 1) for k in ("l0_u8", "l1_u8", "r1_u8"))
+    t = orc.optical_flow_matching(p0, p1, F["kp"], F["is3d"], F["proj"], (H, W), sum_order=0)
+    keep = ~t["removed"]
+    assert np.array_equal(keep, J["t_present"].astype(bool))
+    assert np.abs(t["new_pixels"][keep] - J["t_new"][keep]).max() <= LK_TOL
+    kp1, is3d1 = t["new_pixels"][keep], F["is3d"][keep]
+    s = orc.optical_flow_matching(p1, pr, kp1, is3d1, F["s_proj"], (H, W), stereo=True, undistorted_left=kp1, right_cam=cam, sum_order=0)
+    assert np.array_equal(~s["removed"], J["s_present"].astype(bool))
+    up = s["updated"]
+    assert np.array_equal(up, J["s_stereo"].astype(bool))
+    assert np.abs(s["new_pixels"][up] - J["s_right"][up]).max() <= LK_TOL
+    T21 = np.eye(4); T21[0, 3] = -float(F["baseline"][0])
+    P1, P2 = projection_matrices(cam, cam, T21)
+    sk = ~s["removed"]
+    cand = np.flatnonzero(up & ~is3d1 & sk)
+    xyz, ok = orc.triangulate(P1, P2, T21, cam, cam, kp1[cand], s["new_pixels"][cand], 3.0)
+    assert np.array_equal(ok, J["tri_is3d"].astype(bool)[cand])
+    assert np.abs(xyz[ok] - J["tri_xyz"][cand][ok]).max() <= 1e-6 * max(1.0, np.abs(xyz[ok]).max())      # frame.wc = I: world = camera
+
+
+@needs_frontend
+def test_oracle_pose_primitives_match_recoverpose(orc):
+    """RecoverPose.triangulate / p3p_ransac / five_point_ransac on the inputs of pose_v1.npz.  The RANSACs draw their own samples in
+    Julia, so poses are compared up to the scenes' noise and inlier sets by overlap; triangulate is deterministic."""
+    from slam_jl_amd.triangulation import projection_matrices
+    G = np.load(os.path.join(HERE, "golden", "pose_v1.npz")); J = np.load(JF)
+    cam = tuple(G["tri_cam"])
+    P1, P2 = projection_matrices(cam, cam, G["tri_T21"])
+    xyz, st = orc.triangulate(P1, P2, G["tri_T21"], cam, cam, G["tri_px1"], G["tri_px2"], 1e9, min_depth=-1e9)     # no gates: the raw DLT points
+    h = J["rp_triangulate_h"]
+    ref = h[:, :3] / h[:, 3:4]
+    assert np.abs(xyz - ref).max() <= 1e-6 * np.abs(ref).max()
+    if "p3p_KP" in J.files:
+        cnt, KP, Rt, inl, err, bi = orc.p3p_ransac(G["p3p_pts"], G["p3p_px"], G["p3p_pdn"], G["p3p_K"], 3.0, G["p3p_samples"])
+        jin = J["p3p_inliers"].astype(bool)
+        assert (inl & jin).sum() >= 0.95 * max(inl.sum(), jin.sum())
+        a, b = KP / np.linalg.norm(KP[:, :3]), J["p3p_KP"] / np.linalg.norm(J["p3p_KP"][:, :3])
+        assert np.abs(a - b).max() <= 2e-2
+    cnt, E, P, inl, err, bi = orc.five_point_ransac(G["fp_px1"], G["fp_px2"], G["fp_pd1"], G["fp_pd2"], G["fp_K"], G["fp_K"], 3.0, G["fp_samples"])
+    jin = J["fp_inliers"].astype(bool)
+    assert (inl & jin).sum() >= 0.9 * max(inl.sum(), jin.sum())
+    Rj, tj = J["fp_P"][:, :3], J["fp_P"][:, 3]
+    assert np.abs(P[:, :3] - Rj).max() <= 2e-2 and abs(abs(P[:, 3] @ tj) / (np.linalg.norm(P[:, 3]) * np.linalg.norm(tj)) - 1.0) <= 2e-2
