@@ -273,7 +273,10 @@ int slam_kpset_remove(slam_ctx *ctx, slam_kpset *ks, const uint8_t *flags_dev);
 int slam_kpset_detect(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *pyr0, int max_points, int radius, int grid_rows, int grid_cols,
                       int cell_size, double sigma_mask, double min_response);
 /* triangulate_stereo! (mapper.jl:142-183) for every 2-D keypoint with a stereo match: success -> map point Twc[s] X and
- * is_3d = 1, failure -> the stereo observation is dropped.  P1, P2, T21, cam1, cam2 as slam_triangulate; Twc: S x 16. */
+ * is_3d = 1, failure -> the stereo observation is dropped.  P1, P2, T21, cam1, cam2 as slam_triangulate; Twc: S x 16.
+ * The left and right pixels are used as stored: the set's stereo path is for RECTIFIED, zero-distortion pairs (KITTI, the reference's
+ * stereo example), where kp.undistorted_pixel == kp.pixel (mapper.jl:162-163); for cameras with lens distortion undistort on the
+ * host and use slam_triangulate, or leave the stereo seams on the host lists. */
 int slam_kpset_triangulate(slam_ctx *ctx, slam_kpset *ks, const double *P1, const double *P2, const double *T21,
                            const double *cam1, const double *cam2, const double *Twc, double max_error, double min_depth, int n_bound);
 
