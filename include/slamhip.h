@@ -147,6 +147,11 @@ int slam_pyr_destroy(slam_pyr *pyr);
  * product and integral planes of the coarser levels are never read: level 0 is built in full, the other levels get their layers
  * only (about a quarter of the build).  Passing such a pyramid as the SOURCE of a match is an error (SLAM_ERR_ARG). */
 #define SLAM_PYR_TARGET_ONLY 16
+/* Update mode flag: replay the build as ONE chain on the calling context's stream (no forked integral-image branch).  One build
+ * alone takes ~15 % longer (441 vs 376 us for a 370 x 1226 image), but it occupies one hardware queue instead of two and costs the
+ * host a third per call (31 vs 84 us): the choice for a host that keeps the builds of several consecutive frames in flight on several
+ * contexts (preprocess! of frames t+1 .. t+3 while frame t is tracked: 170 us per build with three in flight). */
+#define SLAM_PYR_CHAIN 32
 /* mode 0: constructor semantics (pyramid.jl:40-79: NA() blur, Fill(0) Scharr);
  * mode 1: update! semantics (pyramid.jl:81-137: replicate borders);
  * mode 3: update! semantics with SEGMENTED recurrences: each IIR / cumulative-sum

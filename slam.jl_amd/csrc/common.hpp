@@ -129,7 +129,9 @@ int slam_pinned(slam_ctx *ctx, size_t bytes, void **out);
     } while (0)
 
 // KernelFactors.IIRGaussian coefficients (host side; passed to kernels by value)
-#define SLAM_PYR_TARGET_ONLY 16          /* update mode flag, see include/slamhip.h */
+#define SLAM_PYR_TARGET_ONLY 16          /* update mode flags, see include/slamhip.h */
+#define SLAM_PYR_CHAIN 32
+#define SLAM_PYR_FLAGS (SLAM_PYR_TARGET_ONLY | SLAM_PYR_CHAIN)
 struct IIRCoef {
     double a1, a2, a3, scale, M[9], inv1masum /* 1-asum */, inv1mbsum /* 1-bsum */;
 };

@@ -1703,9 +1703,15 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode_flags, double sigm
     // template at level 1 only -- the gradient, product and integral planes of the coarser levels are never read.  Level 0 is
     // built in full, levels >= 1 get their blurred / resized layers and nothing else.
     const bool target = (mode_flags & SLAM_PYR_TARGET_ONLY) != 0;
-    const int mode = mode_flags & ~SLAM_PYR_TARGET_ONLY;
+    // SLAM_PYR_CHAIN: the build as ONE chain on the calling context's stream (no forked integral-image branch).  A single build takes
+    // ~15 % longer, but it occupies one hardware queue instead of two and its replay costs the host a third (31 vs 84 us): the
+    // choice when several builds of consecutive frames are kept in flight on several contexts (3 in flight: 170 us per build, 376 forked)
+    static const bool linear_env = getenv("SLAMHIP_LINEAR_GRAPH") != nullptr;
+    const bool chain = (mode_flags & SLAM_PYR_CHAIN) != 0 || linear_env;
+    const int mode = mode_flags & ~SLAM_PYR_FLAGS;
     p->target_only = target;                                      // (the other members of a batch are marked by the batch entry points)
     if (target) src_kind |= 16;                                   // part of the graph key
+    if (chain) src_kind |= 32;
     IIRPair cf; cf.c[0] = slam_iir_coef(sigma); cf.c[1] = slam_iir_coef(4.0);   // lucas_kanade.jl:112
     if (mode == 0) { int rc = build_norm(ctx, p, sigma); if (rc) return rc; }
     hipStream_t st = ctx->stream;
@@ -1728,7 +1734,7 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode_flags, double sigm
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
-            launch_build(ctx, p, mode, cf, st, p->aux, false, S, src_kind & 15, target);
+            launch_build(ctx, p, mode, cf, st, chain ? st : p->aux, false, S, src_kind & 15, target);
             e = hipStreamEndCapture(st, &graph);
         }
         if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -1819,7 +1825,7 @@ int slam_pyr_create_batch(slam_ctx *ctx, int H, int W, int pyramid_levels, int S
 // pyrs[0..S) must be the members of one slam_pyr_create_batch call, in order
 int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double *const *images_dev, int S, int mode, double sigma, int sync)
 {
-    ARG_TRY(ctx, ctx != nullptr && pyrs != nullptr && images_dev != nullptr && S >= 1 && S <= BATCH_MAX && ((mode & ~SLAM_PYR_TARGET_ONLY) == 1 || (mode & ~SLAM_PYR_TARGET_ONLY) == 3) && sigma > 0);
+    ARG_TRY(ctx, ctx != nullptr && pyrs != nullptr && images_dev != nullptr && S >= 1 && S <= BATCH_MAX && ((mode & ~SLAM_PYR_FLAGS) == 1 || (mode & ~SLAM_PYR_FLAGS) == 3) && sigma > 0);
     slam_pyr *p0 = pyrs[0];
     ARG_TRY(ctx, p0 != nullptr && p0->batch_index == 0 && p0->batch_size == S);
     for (int s = 0; s < S; s++) ARG_TRY(ctx, pyrs[s] != nullptr && pyrs[s]->alloc == p0->alloc && pyrs[s]->batch_index == s && images_dev[s] != nullptr);
@@ -1827,7 +1833,7 @@ int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double
     ImgPtrs ip;
     for (int s = 0; s < BATCH_MAX; s++) ip.p[s] = s < S ? images_dev[s] : nullptr;
     const size_t n = (size_t)p0->H[0] * p0->W[0];
-    const bool fused_ingest = level0_fused(p0, mode & ~SLAM_PYR_TARGET_ONLY, S);          // the level-0 kernel reads the source images itself and writes the layer
+    const bool fused_ingest = level0_fused(p0, mode & ~SLAM_PYR_FLAGS, S);          // the level-0 kernel reads the source images itself and writes the layer
     if (fused_ingest) hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(64), 0, ctx->stream, p0->alloc->srctab, ip);
     else hipLaunchKernelGGL(k_gather_images, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
     int rc = enqueue_build(ctx, p0, mode, sigma, S, fused_ingest ? 1 : 0);
@@ -1840,7 +1846,7 @@ int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double
 // 8-bit frames already in HBM (column-major H x W bytes, as the KITTI reader decodes them): converted on the device
 int slam_pyr_update_batch_u8_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const uint8_t *const *images_u8_dev, int S, int mode, double sigma, int sync)
 {
-    ARG_TRY(ctx, ctx != nullptr && pyrs != nullptr && images_u8_dev != nullptr && S >= 1 && S <= BATCH_MAX && ((mode & ~SLAM_PYR_TARGET_ONLY) == 1 || (mode & ~SLAM_PYR_TARGET_ONLY) == 3) && sigma > 0);
+    ARG_TRY(ctx, ctx != nullptr && pyrs != nullptr && images_u8_dev != nullptr && S >= 1 && S <= BATCH_MAX && ((mode & ~SLAM_PYR_FLAGS) == 1 || (mode & ~SLAM_PYR_FLAGS) == 3) && sigma > 0);
     slam_pyr *p0 = pyrs[0];
     ARG_TRY(ctx, p0 != nullptr && p0->batch_index == 0 && p0->batch_size == S);
     for (int s = 0; s < S; s++) ARG_TRY(ctx, pyrs[s] != nullptr && pyrs[s]->alloc == p0->alloc && pyrs[s]->batch_index == s && images_u8_dev[s] != nullptr);
@@ -1848,7 +1854,7 @@ int slam_pyr_update_batch_u8_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const uin
     ImgPtrsU8 ip;
     for (int s = 0; s < BATCH_MAX; s++) ip.p[s] = s < S ? images_u8_dev[s] : nullptr;
     const size_t n = (size_t)p0->H[0] * p0->W[0];
-    const bool fused_ingest = level0_fused(p0, mode & ~SLAM_PYR_TARGET_ONLY, S);
+    const bool fused_ingest = level0_fused(p0, mode & ~SLAM_PYR_FLAGS, S);
     if (fused_ingest) { ImgPtrs iq; for (int s = 0; s < BATCH_MAX; s++) iq.p[s] = (const double *)ip.p[s]; hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(64), 0, ctx->stream, p0->alloc->srctab, iq); }
     else hipLaunchKernelGGL(k_gather_images_u8, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
     int rc = enqueue_build(ctx, p0, mode, sigma, S, fused_ingest ? 2 : 0);
@@ -1877,7 +1883,7 @@ int slam_pyr_destroy(slam_pyr *p)
 
 int slam_pyr_update_dev(slam_ctx *ctx, slam_pyr *p, const double *image_dev, int mode, double sigma, int sync)
 {
-    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_dev != nullptr && (mode == 0 || (mode & ~SLAM_PYR_TARGET_ONLY) == 1 || (mode & ~SLAM_PYR_TARGET_ONLY) == 3) && sigma > 0);
+    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_dev != nullptr && (mode == 0 || (mode & ~SLAM_PYR_FLAGS) == 1 || (mode & ~SLAM_PYR_FLAGS) == 3) && sigma > 0);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ingest_dense(ctx, p, image_dev);
     int rc = enqueue_build(ctx, p, mode, sigma);
@@ -1888,7 +1894,7 @@ int slam_pyr_update_dev(slam_ctx *ctx, slam_pyr *p, const double *image_dev, int
 
 int slam_pyr_update(slam_ctx *ctx, slam_pyr *p, const double *image, int mode, double sigma)
 {
-    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image != nullptr && (mode == 0 || (mode & ~SLAM_PYR_TARGET_ONLY) == 1 || (mode & ~SLAM_PYR_TARGET_ONLY) == 3) && sigma > 0);
+    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image != nullptr && (mode == 0 || (mode & ~SLAM_PYR_FLAGS) == 1 || (mode & ~SLAM_PYR_FLAGS) == 3) && sigma > 0);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     void *stage;
     int rc = slam_scratch2(ctx, (size_t)p->H[0] * p->W[0] * 8, &stage);
@@ -1903,7 +1909,7 @@ int slam_pyr_update(slam_ctx *ctx, slam_pyr *p, const double *image, int mode, d
 
 int slam_pyr_update_u8(slam_ctx *ctx, slam_pyr *p, const uint8_t *image_u8, int mode, double sigma)
 {
-    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_u8 != nullptr && (mode == 0 || (mode & ~SLAM_PYR_TARGET_ONLY) == 1 || (mode & ~SLAM_PYR_TARGET_ONLY) == 3) && sigma > 0);
+    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_u8 != nullptr && (mode == 0 || (mode & ~SLAM_PYR_FLAGS) == 1 || (mode & ~SLAM_PYR_FLAGS) == 3) && sigma > 0);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)p->H[0] * p->W[0];
     void *d8;

@@ -72,12 +72,12 @@ def has_gradients(lk):
     return True
 
 
-def update_(lk, img, sigma=1.0, device_ptr=None, sync=True, ctx=None, fast=False, target_only=False):
+def update_(lk, img, sigma=1.0, device_ptr=None, sync=True, ctx=None, fast=False, target_only=False, chain=False):
     """update!(lk, img; σ) pyramid.jl:81-96.  `device_ptr`: image already in HBM;
     `ctx`: enqueue on another context's stream (default: the pyramid's own);
     `fast`: segmented recurrences (mode 3) -- planes agree with the sequential,
     bit-exact mode to ~1e-13 relative instead of bit for bit."""
-    mode = (3 if fast else 1) | (16 if target_only else 0)       # SLAM_PYR_TARGET_ONLY: only ever matched INTO (the mapper's right pyramid)
+    mode = (3 if fast else 1) | (16 if target_only else 0) | (32 if chain else 0)      # SLAM_PYR_TARGET_ONLY: only ever matched INTO (the mapper's right pyramid); SLAM_PYR_CHAIN: unforked replay
     if device_ptr is not None:
         c = ctx or lk.ctx
         c.check(c.lib.slam_pyr_update_dev(c.h, lk.h, C.c_void_p(device_ptr), mode, float(sigma), 1 if sync else 0))

@@ -99,3 +99,27 @@ def test_u8_ingest_bit_exact(slam, orc, texture):
     for name in PLANES:
         for l in range(3):
             assert np.array_equal(lk.plane(name, l), ref.plane(name, l)), (name, l)
+
+
+def test_chain_replay_is_bit_identical(slam, orc, texture):
+    """SLAM_PYR_CHAIN (the build replayed as one chain, no forked integral-image branch) changes the schedule, not one bit of a plane;
+    three such builds kept in flight on three contexts (what a host does for frames t+1 .. t+3) equal the oracle as well."""
+    import torch
+    H, W = 370, 1226
+    L, R, flows = texture(H, W, n=3)
+    dev = [torch.from_numpy(np.ascontiguousarray(im.T)).cuda() for im in L]
+    torch.cuda.synchronize()
+    ctxs = [slam.Context(0) for _ in range(3)]
+    pyr = [slam.LKPyramid(shape=(H, W), levels=3, ctx=ctxs[k]) for k in range(3)]
+    for rep in range(2):                                                     # capture, then replay
+        for k in range(3):
+            slam.update_(pyr[k], None, device_ptr=dev[k].data_ptr(), sync=False, ctx=ctxs[k], chain=True)
+    for c in ctxs:
+        c.synchronize()
+    for k in range(3):
+        ref = orc.pyr_build(L[k], 3, 1.0, 1)
+        for l in range(4):
+            for name in ("layers", "Iy", "Ix", "Iyy", "Ixx", "Iyx"):
+                assert np.array_equal(pyr[k].plane(name, l), ref.plane(name, l)), (k, name, l)
+    for c in ctxs:
+        c.close()
