@@ -222,7 +222,10 @@ __device__ __forceinline__ void load_template(Tmpl<LK_MAXE> &T, const LevelView 
         pe += sp; qe += sq;
         if (pe >= P) { pe -= P; qe++; }
         // (exec-masked loads: letting the slots past the window load element (0, 0) unconditionally -- straight-line code, all loads
-        //  back to back -- was measured 13 % SLOWER: the texture-address path is what the set-up is short of)
+        //  back to back -- was measured 13 % SLOWER.  Also measured and dropped: staging the window + 1 of the LAYER by LDS-DMA and
+        //  evaluating the Scharr gradients in the kernel with the build's own operations (bit-identical, all tests green; 5 DMA
+        //  instructions instead of 18 loads): 255 vs 183 us for 18 480 points -- the 54 LDS reads + ~350 f64 operations per level
+        //  visit cost more than the loads they replace)
         const size_t a = (size_t)(p0 - o.up + p - 1) + (size_t)(p1 - o.left + q - 1) * pitch;
         double v0 = 0.0, v1 = 0.0, v2 = 0.0;
         if (in) { v0 = first.L[a]; v1 = first.Iy[a]; v2 = first.Ix[a]; }

@@ -1930,6 +1930,7 @@ int slam_pyr_copy(slam_ctx *ctx, slam_pyr *dst, const slam_pyr *src)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(dst->planes, src->planes, (size_t)src->off[src->levels] * 6 * 8, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    dst->target_only = src->target_only;       // what the planes are travels with them
     return SLAM_OK;
 }
 
