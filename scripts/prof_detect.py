@@ -2,15 +2,15 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-import bench
+
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-H, W = syn.SHAPES[bench.SHAPE]
-params = slam.Params(stereo=True, max_nb_keypoints=bench.N_KPTS)
+H, W = syn.SHAPES["kitti05"]
+params = slam.Params(stereo=True, max_nb_keypoints=1000)
 cam = slam.Camera(*syn.KITTI_CAM, height=H, width=W)
 ex = slam.Extractor.from_params(params, cam)
-left, right, flows = syn.stereo_stream(bench.SHAPE, 2, seed=0, disparity=12.4)
+left, right, flows = syn.stereo_stream("kitti05", 2, seed=0, disparity=12.4)
 dev = torch.device("cuda", 0)
 ld = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in left]
 torch.cuda.synchronize()
@@ -20,9 +20,13 @@ pb.update_([ld[s % 2].data_ptr() for s in range(S)], sync=True, ctx=ctx)
 kp0, sid0 = slam.detect_batch(ex, pb, np.zeros((0, 2)), np.zeros(0, dtype=np.int32), ctx=ctx)
 kp0 = kp0.astype(np.float64)
 def t(fn, n=10):
-    fn(); ctx.synchronize(); t0 = time.perf_counter()
+    """device time of the call's kernels (hipEvent span "detect" of the library), us"""
+    fn(); ctx.synchronize()
+    ctx.prof_enable(True); ctx.prof_reset()
     for _ in range(n): fn()
-    ctx.synchronize(); return (time.perf_counter() - t0) / n * 1e6
+    ctx.synchronize()
+    ms, cnt = ctx.prof_get("detect"); ctx.prof_enable(False)
+    return ms / max(cnt, 1) * 1e3
 print("S", S, "keypoints", len(kp0))
 print("no current points (no mask): us", round(t(lambda: slam.detect_batch(ex, pb, np.zeros((0, 2)), np.zeros(0, dtype=np.int32), ctx=ctx))))
 keep = np.arange(len(kp0)) % 100 < 85

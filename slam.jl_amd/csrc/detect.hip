@@ -194,9 +194,6 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     double *bA = lds, *bB = lds + n, *bC = lds + 2 * n, *bD = lds + 3 * n;
     __shared__ int s_ncand, s_cnt;
     __shared__ __attribute__((aligned(16))) int s_cand[2 * DET_MAXCAND];
-    __shared__ double s_rv[DET_THREADS / 64];
-    __shared__ int s_ri[DET_THREADS / 64];
-    __shared__ int s_best;
     __shared__ int s_lim[DET_MAXR + 1];
     __shared__ double s_taps[DET_MAXTAPS];
 
@@ -250,13 +247,20 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
             double2 v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) { const int k = k0 + u * DET_THREADS; v[u] = ((const double2 *)a_cur)[k < a_ncur ? k : k0]; }
+            // compaction by wave ballot: a hit's slot is the wave's base (one LDS atomic per wave and pass) + the number of hits in
+            // the lower lanes (popcount of the ballot below the lane) -- no per-hit atomics
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (k0 + u * DET_THREADS >= a_ncur) continue;
-                long py = (long)rint(v[u].x), px = (long)rint(v[u].y);
-                if (py + r >= ylo && py - r <= yhi && px + r >= xlo && px - r <= xhi) {
-                    int slot = atomicAdd(&s_ncand, 1);
-                    if (slot < DET_MAXCAND) { s_cand[2 * slot] = (int)py; s_cand[2 * slot + 1] = (int)px; }
+                const bool live = k0 + u * DET_THREADS < a_ncur;
+                const long py = (long)rint(v[u].x), px = (long)rint(v[u].y);
+                const bool hit = live && py + r >= ylo && py - r <= yhi && px + r >= xlo && px - r <= xhi;
+                const unsigned long long bal = __ballot(hit);
+                if (bal) {                                                        // wave-uniform
+                    int base = 0;
+                    if ((tid & 63) == 0) base = atomicAdd(&s_ncand, __popcll(bal));
+                    base = __shfl(base, 0);
+                    const int slot = base + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+                    if (hit && slot < DET_MAXCAND) { s_cand[2 * slot] = (int)py; s_cand[2 * slot + 1] = (int)px; }
                 }
             }
         }
@@ -368,61 +372,72 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     DT(5);
 
     // ---- findlocalmaxima: strict, 8-neighbourhood, edges included (neighbours outside the cell are not compared) ------------
-    unsigned char *flag = (unsigned char *)bB;                // 0: no, 1: maximum (candidate), 2: taken
-    for (int it = tid; it < w * nstr; it += DET_THREADS) {
-        const int x = it / nstr, ys = (it - x * nstr) * DET_SL;
+    // The strict maxima (typically 20-40 of a 35 x 35 cell) are compacted as they are found -- wave ballot + popcount of the lower lanes,
+    // one LDS atomic per wave and strip pass -- into a list of (pixel index, response); the top-k selection then runs on ONE wave
+    // over that list: k rounds of a wave arg-max on the key (response descending, pixel index ascending = Julia's stable sortperm over
+    // the column-major maxima, extractor.jl:27-40), no workgroup barrier and no merge thread per round.
+    int *mx_idx = (int *)bC;                                  // compacted maxima: pixel index (column-major) ...
+    double *mx_val = bD;                                      // ... and response
+    if (tid == 0) { s_cnt = 0; s_ncand = 0; }
+    __syncthreads();
+    for (int it0 = 0; it0 < w * nstr; it0 += DET_THREADS) {   // (whole waves enter every pass: the ballots need them)
+        const int it = it0 + tid;
+        const bool act = it < w * nstr;
+        const int x = act ? it / nstr : 0, ys = act ? (it - x * nstr) * DET_SL : 0;
         DetStrip S;
         det_strip_load(S, resp, h, w, ys, x);
         const bool cl = x > 0, cr = x < w - 1;
 #pragma unroll
         for (int q = 0; q < DET_SL; q++) {
             const int y = ys + q;
-            if (y < h) {
-                const double c = S.v[1][q + 1];
-                const bool ru = y > 0, rd = y < h - 1;
-                bool ismax = true;
-                if (cl) { if (ru && !(S.v[0][q] < c)) ismax = false; if (!(S.v[0][q + 1] < c)) ismax = false; if (rd && !(S.v[0][q + 2] < c)) ismax = false; }
-                if (ru && !(S.v[1][q] < c)) ismax = false;
-                if (rd && !(S.v[1][q + 2] < c)) ismax = false;
-                if (cr) { if (ru && !(S.v[2][q] < c)) ismax = false; if (!(S.v[2][q + 1] < c)) ismax = false; if (rd && !(S.v[2][q + 2] < c)) ismax = false; }
-                flag[y + x * h] = ismax ? 1 : 0;
+            const double c = S.v[1][q + 1];
+            bool ismax = act && y < h;
+            const bool ru = y > 0, rd = y < h - 1;
+            if (cl) { if (ru && !(S.v[0][q] < c)) ismax = false; if (!(S.v[0][q + 1] < c)) ismax = false; if (rd && !(S.v[0][q + 2] < c)) ismax = false; }
+            if (ru && !(S.v[1][q] < c)) ismax = false;
+            if (rd && !(S.v[1][q + 2] < c)) ismax = false;
+            if (cr) { if (ru && !(S.v[2][q] < c)) ismax = false; if (!(S.v[2][q + 1] < c)) ismax = false; if (rd && !(S.v[2][q + 2] < c)) ismax = false; }
+            const unsigned long long bal = __ballot(ismax);
+            if (bal) {
+                int base = 0;
+                if ((tid & 63) == 0) base = atomicAdd(&s_ncand, __popcll(bal));
+                base = __shfl(base, 0);
+                const int slot = base + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+                if (ismax) { mx_idx[slot] = y + x * h; mx_val[slot] = c; }      // (at most h w / 4 strict maxima: the planes have room)
             }
         }
     }
-    if (tid == 0) s_cnt = 0;
     __syncthreads();
 
     DT(6);
-    // ---- top-k by response (stable: ties keep column-major order) ------------
-    int *sel = (int *)bC;                                     // selected linear indices
-    for (int round = 0; round < a_k; round++) {
-        double bv = -INFINITY; int bi = 0x7fffffff;
-        for (int i = tid; i < h * w; i += DET_THREADS)
-            if (flag[i] == 1) {
-                double v = resp[i];
-                if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    // ---- top-k by response (stable: ties keep column-major order), wave 0 only ------------
+    int *sel = (int *)bB;                                     // selected pixel indices
+    if (tid < 64) {
+        const int nmx = s_ncand;
+        int cnt = 0;
+        for (int round = 0; round < a_k; round++) {
+            double bv = -INFINITY; int bi = 0x7fffffff, bs = -1;
+            for (int j = tid; j < nmx; j += 64) {
+                const int i = mx_idx[j];
+                if (i >= 0) {                                                     // (taken entries are marked -1)
+                    const double v = mx_val[j];
+                    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; bs = j; }
+                }
             }
-        for (int off = 32; off >= 1; off >>= 1) {
-            double ov = __shfl_down(bv, off); int oi = __shfl_down(bi, off);
-            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ov = __shfl_xor(bv, off); const int oi = __shfl_xor(bi, off), os = __shfl_xor(bs, off);
+                if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; bs = os; }
+            }
+            if (bi == 0x7fffffff) break;                                          // wave-uniform after the butterfly
+            if (tid == 0) {
+                mx_idx[bs] = -1;
+                if (!(bv < A.min_response)) sel[cnt] = bi;                       // `responses[mx] < min_response && continue`
+            }
+            if (!(bv < A.min_response)) cnt++;
         }
-        if ((tid & 63) == 0) { s_rv[tid >> 6] = bv; s_ri[tid >> 6] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            double v = s_rv[0]; int ix = s_ri[0];
-            for (int wv = 1; wv < DET_THREADS / 64; wv++) {
-                double ov = s_rv[wv]; int oi = s_ri[wv];
-                if (oi != 0x7fffffff && (ix == 0x7fffffff || ov > v || (ov == v && oi < ix))) { v = ov; ix = oi; }
-            }
-            s_best = ix;
-            if (ix != 0x7fffffff) {
-                flag[ix] = 2;
-                if (!(resp[ix] < A.min_response)) sel[s_cnt++] = ix;   // `responses[mx] < min_response && continue`
-            }
-        }
-        __syncthreads();
-        if (s_best == 0x7fffffff) break;
+        if (tid == 0) s_cnt = cnt;
     }
+    __syncthreads();
 
     DT(7);
     // ---- emit in column-major order (Keypoints(::Matrix{Bool}) = findall) ----
