@@ -138,3 +138,26 @@ def test_kpset_keyframe_cycle_at_kitti_size_vs_oracle(slam, syn, orc, texture):
         assert np.abs(got["stereo_yx"][up] - ref["new_pixels"][keep][up]).max() <= 1e-9, s
         assert up.mean() > 0.8
     ks.close()
+
+
+@pytest.mark.parametrize("shape,S", [((376, 1241), 64), ((480, 640), 64), ((1080, 1920), 16)])
+def test_config_shapes_u8_batches_vs_oracle(slam, syn, orc, shape, S):
+    """The other BASELINE shapes at the batch sizes bench.py's `configs` legs run them with (kitti00_2000 S = 64, euroc_mono S = 64,
+    fhd_4000 S = 16; 8-bit ingest): first and last stream against the oracle, all planes and levels.  (1080 rows: above the 512-row
+    limit of the one-pass integral kernel -> k_cum_cols + k_cum_rows; odd 1241 -> 621 columns: general bilinear resize.)"""
+    import torch
+    Hc, Wc = shape
+    rng = np.random.default_rng(Hc)
+    base = syn.texture_canvas(Hc, Wc, seed=3, margin=0)
+    u8 = [np.asfortranarray(np.round(np.clip(base + 0.03 * rng.standard_normal((Hc, Wc)), 0, 1) * 255).astype(np.uint8)) for _ in range(2)]
+    frames = [u8[s % 2] if s not in (0, S - 1) else np.asfortranarray(np.roll(u8[s % 2], s + 1, axis=1)) for s in range(S)]
+    dev = torch.from_numpy(np.stack([np.ascontiguousarray(im.T) for im in frames])).cuda()
+    torch.cuda.synchronize()
+    b = slam.PyramidBatch((Hc, Wc), levels=3, S=S)
+    ptrs = [dev.data_ptr() + s * Hc * Wc for s in range(S)]
+    b.update_(ptrs, u8=True); b.update_(ptrs, u8=True)
+    for s in (0, S - 1):
+        ref = orc.pyr_build(np.asfortranarray(frames[s].astype(np.float64) / 255.0), 3, 1.0, 1)
+        for l in range(4):
+            for name in PLANES:
+                assert np.array_equal(b.pyramids[s].plane(name, l), ref.plane(name, l)), (shape, s, name, l)
