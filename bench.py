@@ -66,6 +66,7 @@ class Stream:
     def step(self, f_prev, f_cur, upcoming=()):
         be = self.be
         kf = self.t % KF_EVERY == 0
+        be.kf_next = (self.t + 1) % KF_EVERY == 0            # the workload's key-frame cadence is fixed: a backend may request the next key-frame's right pyramid early
         be.begin_frame(f_cur, upcoming, kf)
         if len(self.kp):
             flow = np.array(self.flows[f_cur]) - np.array(self.flows[f_prev])
@@ -105,7 +106,11 @@ class GpuBackend:
         self.ahead = max(1, ahead)
         self.npyr = self.ahead + 2
         self.pyr = [slam.LKPyramid(shape=(H, W), levels=params.pyramid_levels, ctx=ctx) for _ in range(self.npyr)]
-        self.rpyr = slam.LKPyramid(shape=(H, W), levels=params.pyramid_levels, ctx=ctx)
+        self.rpyrs = [slam.LKPyramid(shape=(H, W), levels=params.pyramid_levels, ctx=ctx) for _ in range(2)]
+        self.rpyr = self.rpyrs[0]
+        self.rheld = [None, None]                # frame number whose right image each right pyramid holds / is being built with
+        self.rbuilt = [None, None]               # marker: that build is complete
+        self.kf_next = False
         self.built = [None] * self.npyr          # marker: "the build into this slot is complete"
         self.holds = [None] * self.npyr          # (frame number, image id) the slot holds or is being built with
         self.i = 0                 # frame number of the current frame; slot = i % npyr
@@ -125,6 +130,16 @@ class GpuBackend:
         self.built[slot] = c.record(self.built[slot])
         self.holds[slot] = (t, f)
 
+    def _build_right(self, t, f):
+        # with several build streams the right build goes FIRST onto the stream whose left build the tracking has just waited for (its
+        # queue is empty; the next left build of that stream is enqueued behind it): one more stream would be one more than the GPU has
+        # hardware queues, and the right build would sit behind whatever it aliased with
+        c = self.build_ctx[self.i % len(self.build_ctx)] if self.ahead > 1 else self.ctx_right
+        self.slam.update_(self.rpyrs[t % 2], None, device_ptr=self.right[f].data_ptr(), sync=False, ctx=c, fast=self.fast,
+                          target_only=RIGHT_TARGET_ONLY, chain=self.ahead > 1)
+        self.rbuilt[t % 2] = c.record(self.rbuilt[t % 2])
+        self.rheld[t % 2] = t
+
     def prime(self, f):
         self._build(self.i, f, sync=True)
 
@@ -133,9 +148,14 @@ class GpuBackend:
         if self.holds[self.i % self.npyr] != (self.i, f_cur) or not self.pipelined:
             self._build(self.i, f_cur)
         if kf:                                            # right image of a key-frame, on its own stream (mapper task, mapper.jl:52)
-            self.slam.update_(self.rpyr, None, device_ptr=self.right[f_cur].data_ptr(), sync=False, ctx=self.ctx_right, fast=self.fast,
-                              target_only=RIGHT_TARGET_ONLY, chain=self.ahead > 1)
+            self.rpyr = self.rpyrs[self.i % 2]
+            if self.rheld[self.i % 2] != self.i:
+                self._build_right(self.i, f_cur)
         self.ctx.wait_event(self.built[self.i % self.npyr])        # tracking below needs the build of THIS frame only
+        if self.pipelined and self.ahead > 1 and self.kf_next and len(upcoming):
+            # the next frame is a key-frame (fixed cadence of the workload): its right pyramid is requested now, so that the stereo
+            # match does not sit behind a 400-700 us build (the reference's mapper thread builds it beside the front-end, mapper.jl:52)
+            self._build_right(self.i + 1, list(upcoming)[0])
         if self.pipelined:
             for k, f in enumerate(list(upcoming)[:self.ahead], 1):
                 if self.holds[(self.i + k) % self.npyr] != (self.i + k, f):
@@ -144,7 +164,7 @@ class GpuBackend:
     def match(self, stereo, kp, is3d, proj):
         a, b = (self.cur, self.rpyr) if stereo else (self.prev, self.cur)
         if stereo:
-            self.ctx.wait_for(self.ctx_right)
+            self.ctx.wait_event(self.rbuilt[self.i % 2])
         return self.slam.optical_flow_matching(a, b, kp, is3d, proj, self.params, ctx=self.ctx)
 
     def detect(self, cur):
@@ -156,10 +176,10 @@ class GpuBackend:
         self.ctx_right.synchronize(); self.ctx.synchronize()
 
     def close(self):
-        for m in self.built:
+        for m in self.built + self.rbuilt:
             if m is not None:
                 m.close()
-        for p_ in self.pyr + [self.rpyr]:
+        for p_ in self.pyr + self.rpyrs:
             p_.close()
 
 
@@ -901,7 +921,7 @@ def main():
         seq = frame_sequence(args.warmup * KF_EVERY + n1 + 202)   # the ping-pong sequence is periodic
         w1 = max(args.warmup, 2) * KF_EVERY
 
-        AH = 4                                                  # frames of lookahead the sequence provides to the build pipeline
+        AH = 6                                                  # frames of lookahead the sequence provides to the build pipeline
 
         def one_stream(fast, ahead=1):
             sp = int(os.environ.get("SLAM_BENCH_SINGLE_PRIO", "0"))          # scheduling class of the tracking context (experiment)
@@ -926,9 +946,10 @@ def main():
 
     if "single" in legs:
         # ---- the same workload as ONE stream (latency view): 3 contexts, pipelined next-frame pyramid ----
-        # builds in flight ahead of the tracking: 1 = the next frame only (rounds 1-2), 2 / 3 = two / three builds on as many streams
+        # builds in flight ahead of the tracking: 1 = the next frame only (rounds 1-2), 3 .. 5 = that many unforked builds (SLAM_PYR_CHAIN) on as
+        # many streams, the key-frame's right pyramid requested one frame early on the stream that has just gone idle
         deep = {}
-        for ah in (2, 3):
+        for ah in (4, 5, 6):                                    # (which depth wins depends on how the runtime maps the streams onto its four hardware queues)
             be_, _, c3_, dt_, _ = one_stream(False, ahead=ah)
             deep[ah] = world * n1 / dt_
             be_.close()
