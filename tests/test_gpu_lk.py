@@ -180,3 +180,22 @@ def test_ill_conditioned_windows_with_zero_eigenvalue_threshold(slam, orc):
     assert np.abs(out[st] - o1[st]).max() <= 1e-7
     assert np.abs((out - pts)[st][:, 1].mean() - 0.6) < 0.05       # the shift along x is recovered, nothing along y
     assert np.abs((out - pts)[st][:, 0]).max() < 1e-6
+
+
+@pytest.mark.parametrize("window", [5, 9, 11])
+def test_priors_far_off_restage_the_lds_patch(slam, orc, texture, window):
+    """Round 3: an iteration samples the target from an LDS patch staged around the level's starting estimate (footprint + >= 4 px of
+    margin).  Priors that are 3-7 px off in every direction make the estimate walk out of the patch inside a level: the re-staging
+    path (and its explicit wait for the LDS-DMA) must give the oracle's result, point for point, for all three kernel instantiations."""
+    H, W = 240, 320
+    L, R, flows = texture(H, W, step=(2.2, -3.1))
+    g, r = _pyrs(slam, orc, L)
+    kp = orc.detect(L[0], np.zeros((0, 2)), max_points=400).astype(float)
+    rng = np.random.default_rng(window)
+    ang = rng.uniform(0, 2 * np.pi, len(kp)); mag = rng.uniform(3.0, 7.0, len(kp))
+    prior = np.array(flows[1]) + np.stack([mag * np.sin(ang), mag * np.cos(ang)], 1)          # displacement at level 1 (pyramid_levels = 0)
+    for levels in (0, 1):
+        out, st = _check(slam, orc, g, r, kp, disp=prior / 2 ** levels, levels=levels, window=window)
+        assert 0.2 < st.mean()                                                                  # many still converge: they crossed the margin
+    # and far beyond the margin (most of these fail, none may differ)
+    _check(slam, orc, g, r, kp, disp=(np.array(flows[1]) + 3.0 * (prior - np.array(flows[1]))), levels=0, window=window)
