@@ -858,6 +858,24 @@ def main():
         # the same environment the torch.distributed.run launcher gives them), forwards rank 0's line and exits with their status
         raise SystemExit(spawn_ranks(args))
 
+    # The single-stream legs (latency views) and the lock-stepped legs want different process states: once a stream of another priority
+    # class exists (the headline's tracking context) the default-class single-stream legs lose ~40 %, and the dozen contexts the
+    # single-stream legs create and destroy shift the runtime's stream -> hardware-queue placement of the headline's four streams
+    # (-2.5 % on `value`, same-box A/B).  So this process -- before it touches the GPU -- runs them in a CHILD process of their own
+    # (a fresh process per GPU; at N > 1 every rank does so for its GPU and the slowest rank counts) and merges their part of the line.
+    child_part = None
+    if legs & {"single", "tolerance"} and os.environ.get("SLAM_BENCH_CHILD") is None and legs - {"single", "tolerance"}:
+        import subprocess
+        sub = sorted(legs & {"single", "tolerance"})
+        env = dict(os.environ, SLAM_BENCH_CHILD="1", WORLD_SIZE="1", RANK="0")
+        cmd = [sys.executable, os.path.abspath(__file__), "--only", ",".join(sub), "--steps", str(args.steps), "--warmup", str(args.warmup), "--streams", str(args.streams)]
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900)
+            child_part = json.loads(r.stdout.strip().split("\n")[-1])
+        except Exception as ex:                                   # the optional legs never cost the line
+            child_part = {"single_stream": {"error": repr(ex)[:200]}}
+        legs -= {"single", "tolerance"}
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -878,7 +896,8 @@ def main():
 
     import slam_jl_amd as slam
     from slam_jl_amd import synthetic as syn
-    ctx = slam.Context(local_rank)
+    ctx = None                                               # the context of the BA / pose legs: created when they start -- an idle stream created up
+                                                             # front shifts the runtime's stream -> hardware-queue placement of the headline's four (-4 %, same-box A/B)
     dev = torch.device("cuda", local_rank)
     S = args.streams
     wl = make_workload(slam, syn, "kitti05_1000", seed=rank, streams=S)
@@ -909,6 +928,19 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic", "legs": sorted(legs),
     }
 
+    if child_part is not None:
+        for key in ("single_stream", "tolerance_mode"):
+            if key in child_part:
+                out[key] = child_part[key]
+        if world > 1:                                            # one stream per GPU: the slowest GPU counts, times the number of GPUs
+            for key, sub_ in (("single_stream", None), ("tolerance_mode", "single_stream")):
+                node = out.get(key, {}) if sub_ is None else out.get(key, {}).get(sub_, {})
+                if "value" in node:
+                    tt = torch.tensor([float(node["value"])], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+                    node["value"] = float(tt[0]) * world
+        out["legs"] = sorted(set(out["legs"]) | ({"single"} if "single_stream" in child_part else set()) | ({"tolerance"} if "tolerance_mode" in child_part else set()))
+        out["single_stream_legs_in_child_process"] = True
     # The single-stream legs (latency views) run FIRST: once a stream of another priority class exists in the process (the headline legs
     # create one for their tracking context) the runtime schedules the default-class queues differently and these latency-bound legs
     # lose ~40 % (measured: 2 260 -> 1 400 frames/s); a deployment picks one configuration or the other, the bench measures each in its own.
@@ -1002,10 +1034,10 @@ def main():
     # ---- tolerance-mode pyramid (mode 3: parallel recurrences, planes within 1e-11 rel.), single stream (batches of >= 4 images take
     #      the bit-exact kernels in this mode too) ----
     if "tolerance" in legs:
-        be, stream, c3, dtf, _ = one_stream(True)
+        be, stream, c3, dtf, _ = one_stream(True, ahead=5)
         out["tolerance_mode"] = {"pyramid": "slam_pyr_update mode 3 (parallel recurrences; planes <= 1e-11 relative, tracked positions <= 1e-7 px vs "
                                             "the bit-exact mode: tests/test_gpu_pyramid.py::test_fast_mode_within_tolerance)",
-                                 "single_stream": {"value": world * n1 / dtf, "unit": "frames/sec", "ms_per_frame": dtf / n1 * 1e3}}
+                                 "single_stream": {"value": world * n1 / dtf, "unit": "frames/sec", "ms_per_frame": dtf / n1 * 1e3, "builds_in_flight": 5}}
         be.close()
         for c in c3:
             c.close()
@@ -1132,6 +1164,8 @@ def main():
                     pass
         leg_done("configs")
 
+    if legs & {"ba", "pose", "cpu"}:
+        ctx = slam.Context(local_rank)
     # ---- BA: the windows BASELINE / SURVEY 8d name, single GPU ----
     ba_scenes = None
     if "ba" in legs:
