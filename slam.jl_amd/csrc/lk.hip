@@ -43,12 +43,13 @@ extern "C" int slam_debug_lk_ticks(unsigned long long *out)
 #define LKT(k)
 #endif
 
-// (register allocation left to the compiler: 133 / 167 / 207 VGPRs for the 3- / 6- / 9-slot instantiations = 3 / 3 / 2 waves per SIMD;
-//  LK_WAVES caps it for experiments)
+// occupancy target of the tracking kernels: 3 waves per SIMD (<= 168 VGPRs) for the 3- / 6-slot instantiations, 2 for the 9-slot one.
+// Left to itself the register allocator lands on 167 or on 183 registers for the 6-slot kernel depending on unrelated details of the
+// source (a wave per SIMD and 15 % of the kernel's speed); the bound makes it 168.  LK_WAVES overrides it for experiments.
 #ifdef LK_WAVES
 #define LK_OCC __attribute__((amdgpu_waves_per_eu(LK_WAVES, LK_WAVES)))
 #else
-#define LK_OCC
+#define LK_OCC __attribute__((amdgpu_waves_per_eu(LK_MAXE == 9 ? 2 : 3, LK_MAXE == 9 ? 2 : 3)))
 #endif
 struct Offs { int up, down, left, right; };
 
@@ -130,7 +131,11 @@ __device__ __forceinline__ double spatial_gradient(const LevelView &v, int p0, i
     }
     // M col-major: M11 = syy, M21 = syx, M12 = syx, M22 = sxx
     const double E = (syy + sxx) / 2, F = (syy - sxx) / 2, G = (syx + syx) / 2, Hh = (syx - syx) / 2;
-    const double Q = sqrt(E * E + Hh * Hh), R = sqrt(F * F + G * G);
+    // M is symmetric: Hh = (syx - syx) / 2 = 0 and Q = sqrt(E * E + 0) = |E| exactly (sqrt(fl(x * x)) == |x| in binary floating point
+    // unless x * x over- or underflows); the square-root sequence only runs outside that range
+    double Q = fabs(E);
+    if (!(Q > 1e-150 && Q < 1e150)) Q = sqrt(E * E + Hh * Hh);
+    const double R = sqrt(F * F + G * G);
     const double sx = Q + R, sy = Q - R;
     const double S0 = sx, S1 = fabs(sy);
     const double tol = 1.4901161193847656e-08;
@@ -211,9 +216,14 @@ __device__ __forceinline__ void load_template(Tmpl<LK_MAXE> &T, const LevelView 
     const int lane = threadIdx.x & 63, pitch = first.P;
     const int P = o.up + o.down + 1, Q = o.left + o.right + 1, NE = P * Q;
     T.ne = NE; T.kmax = (NE + 63) >> 6;
-    // element e = lane + 64 k -> (p, q) = (e % P, e / P), advanced incrementally (one division per template)
-    int pe = lane % P, qe = lane / P;
-    const int sp = 64 % P, sq = 64 / P;
+    // element e = lane + 64 k -> (p, q) = (e % P, e / P), advanced incrementally (one division per template; for the unclipped
+    // windows of the usual sizes -- 2 w + 1 = 19 (window_size 9), 13, 23 -- by a constant: a multiply-shift, not the ~40-instruction
+    // run-time division sequence every level visit used to start with)
+    int pe, qe, sp, sq;
+    if (P == 19) { pe = lane % 19; qe = lane / 19; sp = 64 % 19; sq = 64 / 19; }
+    else if (P == 13) { pe = lane % 13; qe = lane / 13; sp = 64 % 13; sq = 64 / 13; }
+    else if (P == 23) { pe = lane % 23; qe = lane / 23; sp = 64 % 23; sq = 64 / 23; }
+    else { pe = lane % P; qe = lane / P; sp = 64 % P; sq = 64 / P; }
 #pragma unroll
     for (int k = 0; k < LK_MAXE; k++) {
         const int e = lane + 64 * k;
