@@ -8,7 +8,8 @@
 // independent, so the reference's valid_ids bookkeeping (tracker.jl:30-48)
 // reduces to per-point control flow.
 //
-// Mapping: a 64-lane wave owns a point; the (2w+1)^2 window is dealt to lanes
+// Mapping: a 64-lane wave owns a point (a level visit stages its target footprint once into an LDS patch by LDS-DMA and iterates
+// there: see stage_rect / lk_level); the (2w+1)^2 window is dealt to lanes
 // in the reference's iteration order (q outer, p inner; element e -> lane
 // e % 64, sequential per lane) and the two sums of prepare_linear_system are
 // folded with a 6-step xor butterfly.  That summation order is restated in the
@@ -190,12 +191,9 @@ __device__ __forceinline__ bool lies_in(int H, int W, double a, double b)
 // LK_MAXE slots per lane: the kernels are instantiated for 3 (window_size <= 6), 6 (<= 9, the default 19 x 19
 // window) and 9 (<= 11) slots so that the register footprint follows the window; larger windows take the
 // uncached path.
-// The template samples live in LDS (a private [plane][slot][lane] spill area of the single-wave workgroup, 9 KB
-// for 6 slots, no barriers); only the packed window coordinates stay in registers.  With the footprint loads issued in two
-// halves and pinv2x2's fallback in closed form the default-window kernel needs 115 VGPRs -> 4 waves per SIMD (16 per CU,
-// which is also what the 9 KB of LDS per wave allow).  Measured (scripts/lk_trace.py, rocprofv3 --pmc): a point executes
-// ~5k wave instructions as one dependent stream (~18 cycles each), VALU 33 % busy; L1-miss latency averages 400
-// cycles with only 2-3 misses outstanding per wave, so the kernel is bound by that instruction stream, not by HBM or L1.
+// (Rounds 1-2 kept the template samples in an LDS spill area -- 115 VGPRs, 4 waves per SIMD -- because every iteration waited for
+// its footprint loads from global memory; since round 3 the iteration samples an LDS-resident target patch instead (below), the
+// template lives in registers, and the kernel is VALU-bound: ~3 300 VALU instructions per point in the bench's launches, ~90 % busy.)
 // LK_TMPL_LDS: template samples in an LDS spill area ([plane][slot][lane], 9 KB for 6 slots; round 1 / 2 layout: 105 VGPRs,
 // 4 waves per SIMD, needed while every iteration waited for global loads); default since round 3: template in registers
 // (36 VGPRs for 6 slots) -- the iteration reads the target from an LDS patch, and the LDS port is what it is bound by.
