@@ -1195,7 +1195,22 @@ def main():
         out["ba"].update({"window_kf": 50, "observations": p50["observations"], "points": p50["points"], "lm_iterations": p50["lm_iterations"],
                           "ms_per_iter": p50["ms_per_iter"], "wall_ms_total": p50["wall_ms_total"], "ssr_final": p50["ssr_final"]})
         leg_done("ba")
-    if "ba_sharded" in legs:
+    if "ba_sharded" in legs and world > 1 and os.environ.get("SLAM_BENCH_CHILD") is None:
+        # N > 1: the library's own RCCL communicator (slam_comm_*) has never run on real multi-GPU hardware in the build environment.  A
+        # collective that does not return cannot be caught as an exception, so every rank runs this leg in a CHILD process (its own
+        # process group on another port) under a deadline: a hang costs this object, not the line.
+        import subprocess
+        env = dict(os.environ, SLAM_BENCH_CHILD="1", MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
+        cmd = [sys.executable, os.path.abspath(__file__), "--only", "ba_sharded", "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=float(os.environ.get("SLAM_BENCH_SHARDED_TIMEOUT_S", "300")))
+            if rank == 0:
+                out["ba_sharded"] = json.loads(r.stdout.strip().split("\n")[-1]).get("ba_sharded", {"error": "the child printed no ba_sharded object", "world_size": world})
+        except subprocess.TimeoutExpired:
+            out["ba_sharded"] = {"error": "deadline passed: the sharded BA leg did not return (child processes killed)", "world_size": world}
+        except Exception as ex:
+            out["ba_sharded"] = {"error": repr(ex)[:300], "world_size": world}
+    elif "ba_sharded" in legs:
         from slam_jl_amd import sharded_ba
         try:
             # the point-sharded driver (slam_ba_lm_* + RCCL through slam_comm_*): device-paced, one all-reduce + one all-gather per iteration
