@@ -10,11 +10,11 @@ from slam_jl_amd import synthetic as syn
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 fast = len(sys.argv) > 2 and sys.argv[2] == "fast"
-H, W = syn.SHAPES[bench.SHAPE]
-params = slam.Params(stereo=True, max_nb_keypoints=bench.N_KPTS)
+H, W = syn.SHAPES["kitti05"]
+params = slam.Params(stereo=True, max_nb_keypoints=1000)
 cam = slam.Camera(*syn.KITTI_CAM, height=H, width=W)
 ex = slam.Extractor.from_params(params, cam)
-left, right, flows = syn.stereo_stream(bench.SHAPE, bench.N_FRAMES, seed=0, disparity=12.4)
+left, right, flows = syn.stereo_stream("kitti05", 8, seed=0, disparity=12.4)
 dev = torch.device("cuda", 0)
 ld = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in left]
 rd = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in right]

@@ -9,8 +9,8 @@ from slam_jl_amd import synthetic as syn
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 parts = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 reps = 30
-H, W = syn.SHAPES[bench.SHAPE]
-left, right, flows = syn.stereo_stream(bench.SHAPE, bench.N_FRAMES, seed=0, disparity=12.4)
+H, W = syn.SHAPES["kitti05"]
+left, right, flows = syn.stereo_stream("kitti05", 8, seed=0, disparity=12.4)
 dev = torch.device("cuda", 0)
 ld = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in left]
 torch.cuda.synchronize()
