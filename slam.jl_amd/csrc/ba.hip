@@ -961,8 +961,10 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(BADev d, CholArgs C, con
 // Back-substitution L' dp = y then walks the block columns right to left with the stored L_ik and L_kk^-1.
 // Systems whose half-bandwidth exceeds BS_MAXHB blocks (dense windows of > 21 poses) keep the tiled path.
 #define BS_MAXHB 20
-struct BandArgs { const double *S, *g, *ud; double *Lg; int nb, hb; double inv_delta_host; int *fail; long long *trace; int lds_bytes; double *xchg; int epoch; };
+struct BandArgs { const double *S, *g, *ud; double *Lg; int nb, hb; double inv_delta_host; int *fail; long long *trace; int lds_bytes; double *xchg; int epoch; int shift; };
 #define BS_PF 6      // prefetch registers per prefetch thread: ceil(((BS_MAXHB + 1) * 36 + 6) / BS_PT)
+#define BS_WS 38     // doubles per 6 x 6 block in the window ring and the panel: 36 + 2, so that the blocks the lanes of a wave read at the
+                     // same time start 12 banks apart (a stride of 36 doubles = 8 banks puts every fourth block on the same ones)
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains the outstanding global loads / stores (the
 // prefetch of the next block row, the factor store), which put a full memory round trip into every step
@@ -972,14 +974,14 @@ __device__ __forceinline__ void bs_barrier()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-#define BS_T 512      /* waves 0-4: panel / trailing update, wave 5: factors the next diagonal block one step ahead, waves 6-7: ring prefetch (8 waves = 2 per SIMD: 256 registers each, no spills) */
-#define BS_PT 128     /* threads of the prefetch waves */
-#define BS_UT 320     /* threads of the update waves */
+#define BS_T 512      /* eight waves, two per SIMD (256 registers each, no spills); roles in the column loop: see there */
+#define BS_PT 128     /* threads of the prefetch waves (3 and 7) */
+#define BS_UT 128     /* threads of the update waves (1-2) */
 __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int use_state)
 {
     if (use_state && d.st->converged) return;
     extern __shared__ __attribute__((aligned(16))) double bs_sm[];
-    __shared__ int s_bad;
+    __shared__ int s_bad, s_step;
     // Twisted factorisation (grid of two workgroups): side 0 eliminates the poses 0 .. own - 1 top-down, side 1 the poses P - 1 ..
     // P - own' bottom-up (the same algorithm on the block-reversed matrix: pose pi(i) = P - 1 - i) -- at the same time, on two CUs.
     // The hb poses in the middle receive the Schur updates of both: side 1 hands its trailing window over through global memory
@@ -987,9 +989,15 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     // publishes dp of the middle poses, and both sides run their back-substitution outwards.  Sequential block columns: P / 2 + hb / 2
     // instead of P, both ways.  A single workgroup (grid 1) runs the plain factorisation.
     const int hb = B.hb, hb1 = hb + 1, nbT = B.nb, n = d.n, tid = threadIdx.x;
-    const bool tw = gridDim.x == 2;
-    const int side = tw ? (int)blockIdx.x : 0;
-    const int ownA = (nbT - hb) / 2, ownB = nbT - hb - ownA;
+    // The twisted launch has NINE workgroups: the two sides are workgroups 0 and 8 -- workgroups go to the eight XCDs round-robin, so
+    // these two share an L2 and their two hand-overs (the trailing window, the middle dp) are L2 round trips instead of trips through
+    // the fabric; workgroups 1-7 leave at once.
+    const bool tw = gridDim.x > 1;
+    if (tw && (blockIdx.x & 7) != 0) { if (B.trace && threadIdx.x == 0) B.trace[80 + blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 20); return; }
+    const int side = tw ? (int)(blockIdx.x >> 3) : 0;
+    // side 0 also eliminates the middle, after side 1's window has arrived: side 1 gets fewer columns so that it is there in time
+    int ownA = (nbT - hb) / 2 + B.shift; if (ownA > nbT - hb - 4) ownA = nbT - hb - 4;
+    const int ownB = nbT - hb - ownA;
     const int own = tw ? (side ? ownB : ownA) : nbT;      // block columns this side eliminates
     const int nb = tw ? own + hb : nbT;                   // its local system: own columns, then the middle
     auto gi = [&](int i) { return side ? nbT - 1 - i : i; };          // local block index -> pose
@@ -997,10 +1005,10 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     double *damp = x + n;                                // [n]: LM damping of the diagonal (k_chol_prepare)
     double *chat = damp + n;                             // [n]: L_kk^-T y_k (narrow bands)
     double *LiAll = chat + n;                            // [nb][36]: L_kk^-1 of every block column (the back-substitution reads them again)
-    double *Wn = LiAll + (size_t)nb * 36;                // [hb1][hb1][36] window ring, blocks row-major 6x6
-    double *rhs = Wn + (size_t)hb1 * hb1 * 36;           // [hb1][6]
-    double *Lp = rhs + hb1 * 6;                          // [hb1][36]: Lp[0] = L_kk^-1, Lp[di] = L_{k+di,k}
-    double *yk = Lp + hb1 * 36;                          // [8]
+    double *Wn = LiAll + (size_t)nb * 36;                // [hb1][hb1][BS_WS] window ring, blocks row-major 6x6
+    double *rhs = Wn + (size_t)hb1 * hb1 * BS_WS;        // [hb1][6]
+    double *Lp = rhs + hb1 * 6;                          // [hb1][BS_WS]: Lp[di] = L_{k+di,k}
+    double *yk = Lp + hb1 * BS_WS;                       // [8]
     double *part = yk + 8;                               // [hb1][6] partial sums of the back-substitution
     double *Dn = part + hb1 * 6;                         // [36]: the next diagonal block, updated
     double *Gs = Wn;                                     // narrow bands, after the factorisation: the staged G blocks (see the back-substitution)
@@ -1009,8 +1017,17 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     const double inv_delta = use_state ? 1.0 / d.st->delta : B.inv_delta_host;
     const size_t lgs = (size_t)hb1 * 36 + 8;             // doubles per block column in the global factor store
     double *const Lg = B.Lg + (size_t)side * nbT * lgs;
+    // The two sides of a twisted solve hand data to each other through global memory.  On the same XCD (the normal case, see above) the
+    // L2 is common: the producer's stores only have to have arrived there (s_waitcnt vmcnt(0)) and the consumer reads with sc1 loads, past
+    // its own L1 -- no agent-scope fence, whose L2 write-back / invalidate costs microseconds.  Each side publishes its XCC_ID (tagged
+    // with the launch epoch) at the start and compares the other's with its own at its hand-over; a side that does not see a matching
+    // id takes the agent-scope fence.
+    const int myxcc = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15);
+    const int xcc_tag = B.epoch * 32 + 16;
+    if (tw && tid == 0) __hip_atomic_store(B.fail + 3 + side, xcc_tag + myxcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto same_xcd = [&]() { return __hip_atomic_load(B.fail + 3 + (1 - side), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xcc_tag + myxcc; };
     if (tid == 0) {
-        s_bad = 0;
+        s_bad = 0; s_step = 0;
         int q = 0;
         for (int di = 1; di <= hb; di++) for (int dj = 1; dj <= di; dj++) { ptab[2 * q] = (unsigned char)di; ptab[2 * q + 1] = (unsigned char)dj; q++; }
     }
@@ -1030,7 +1047,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
         if (e >= nbk) { rhs[ri * 6 + (e - nbk)] = v; return; }
         const int r = e / (6 * nj), t = e - r * 6 * nj, jb = t / 6, c = t - 6 * jb;
         if (jb == nj - 1 && r == c) v += damp[6 * i + r];      // the diagonal block's diagonal
-        Wn[((size_t)ri * hb1 + ((j0 + jb) % hb1)) * 36 + r * 6 + c] = v;
+        Wn[((size_t)ri * hb1 + ((j0 + jb) % hb1)) * BS_WS + r * 6 + c] = v;
     };
     for (int a = tid; a < 6 * nb; a += BS_T) damp[a] = fmin(fmax(B.ud[6 * gi(a / 6) + a % 6], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
     __syncthreads();
@@ -1039,44 +1056,58 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
         const int cnt = row_count(i);
         for (int e = tid; e < cnt; e += BS_T) put1(i, e, fetch1(i, e));
     }
-    // Rows i > hb all have hb + 1 blocks: the element -> (row r, band column t, block jb, column c) maps of this thread's
-    // elements are computed once (run-time integer divisions cost ~50 instructions each), per row only the ring slot moves.
+    // Rows i > hb all have hb + 1 blocks.  The prefetch lanes (waves 3 and 7) own fixed elements of such a row; the global index of an
+    // element is linear in the row number on either side (pose = i or P - 1 - i), so a lane keeps its elements' indices for row hb + 1
+    // and per row only adds a stride; the ring slot moves with the row.
     double pf[BS_PF];
-    int el_r[BS_PF], el_t[BS_PF], el_w[BS_PF];               // el_w: jb * 36 + r * 6 + c, or -(1 + c) for a right-hand-side entry, INT_MIN: none
+    int2 *etab = (int2 *)(Dn + 36 + 56);                      // [BS_PF][BS_PT], behind the pair table's <= 420 bytes (in LDS: registers are what the update waves are short of)
+    // .x: jb * 64 + r * 6 + c (+ 4096 on the diagonal block's diagonal), or -(1 + c) for a right-hand-side entry, -1000: none;  .y: index in S / g for row hb + 1
+    int strideS = 0, strideG = 0;
+    const bool pl = (tid >> 6) == 3 || (tid >> 6) == 7;
+    const int pidx = ((tid >> 6) == 7 ? 64 : 0) + (tid & 63);
     {
-        const int cnt = hb1 * 36 + 6;
-#pragma unroll
-        for (int q = 0; q < BS_PF; q++) {
-            const int e = tid >= BS_UT + 64 ? (tid - BS_UT - 64) + BS_PT * q : 1 << 30;
-            el_r[q] = 0; el_t[q] = 0; el_w[q] = -1000;
-            if (e < hb1 * 36) { const int r = e / (6 * hb1), t = e - r * 6 * hb1, jb = t / 6, c = t - 6 * jb; el_r[q] = r; el_t[q] = t; el_w[q] = jb * 64 + r * 6 + c; }
-            else if (e < cnt) el_w[q] = -(1 + (e - hb1 * 36));
-        }
+        const int cnt = hb1 * 36 + 6, i0 = hb + 1;
+        auto idxS = [&](int i, int jb, int r, int c) { return (6 * gi(i - hb + jb) + c) + (6 * gi(i) + r) * n; };
+        strideS = idxS(i0 + 1, 0, 0, 0) - idxS(i0, 0, 0, 0); strideG = 6 * (gi(i0 + 1) - gi(i0));
+        if (pl)
+            for (int q = 0; q < BS_PF; q++) {
+                const int e = pidx + BS_PT * q;
+                int2 v = make_int2(-1000, 0);
+                if (e < hb1 * 36) {
+                    const int r = e / (6 * hb1), t = e - r * 6 * hb1, jb = t / 6, c = t - 6 * jb;
+                    v = make_int2(jb * 64 + r * 6 + c + ((jb == hb && r == c) ? 4096 : 0), idxS(i0, jb, r, c));
+                } else if (e < cnt) v = make_int2(-(1 + (e - hb1 * 36)), 6 * gi(i0) + (e - hb1 * 36));
+                etab[q * BS_PT + pidx] = v;
+            }
     }
-    auto fetch_row = [&](int i) {                             // i > hb
-        const int pi = gi(i);
+    // (the table is read in one go -- BS_PF independent LDS reads, one wait -- and the entries' work is branch-free where it can be: a
+    //  read, a wait and a branch per entry made this the longest wave of a step)
+    auto load_tab = [&](int2 (&e)[BS_PF]) {
+#pragma unroll
+        for (int q = 0; q < BS_PF; q++) e[q] = etab[q * BS_PT + pidx];
+    };
+    auto fetch_row = [&](int i, const int2 (&e)[BS_PF]) {    // i > hb; prefetch lanes only
+        const int di = i - (hb + 1);
 #pragma unroll
         for (int q = 0; q < BS_PF; q++) {
+            const double *src = e[q].x >= 0 ? B.S + (e[q].y + di * strideS) : B.g + (e[q].y + di * strideG);
             pf[q] = 0.0;
-            if (el_w[q] >= 0) {
-                const int jb = el_w[q] >> 6, c = (el_w[q] & 63) - 6 * el_r[q];
-                pf[q] = B.S[(size_t)(6 * gi(i - hb + jb) + c) + (size_t)(6 * pi + el_r[q]) * n];
-            } else if (el_w[q] > -1000) pf[q] = B.g[6 * pi - 1 - el_w[q]];
+            if (e[q].x > -1000) pf[q] = *src;
         }
     };
-    auto put_row = [&](int i, int ri) {                       // i > hb, ri = i mod (hb + 1)
+    auto put_row = [&](int i, int ri, const int2 (&e)[BS_PF], const double (&v)[BS_PF], bool blocks, bool rhs_rows) {      // i > hb, ri = i mod (hb + 1)
 #pragma unroll
         for (int q = 0; q < BS_PF; q++) {
-            if (el_w[q] >= 0) {
-                const int jb = el_w[q] >> 6, rc = el_w[q] & 63;
+            const int ew = e[q].x;
+            if (ew >= 0) {
+                const int jb = (ew >> 6) & 63, rc = ew & 63;
                 int sl = ri + 1 + jb; if (sl >= hb1) sl -= hb1;            // (i - hb + jb) mod (hb + 1)
-                double v = pf[q];
-                if (jb == hb && el_r[q] * 7 == rc) v += damp[6 * i + el_r[q]];
-                Wn[((size_t)ri * hb1 + sl) * 36 + rc] = v;
-            } else if (el_w[q] > -1000) rhs[ri * 6 - 1 - el_w[q]] = pf[q];
+                if (blocks) Wn[(ri * hb1 + sl) * BS_WS + rc] = ew >= 4096 ? v[q] + damp[6 * i + rc / 7] : v[q];
+            } else if (rhs_rows && ew > -1000) rhs[ri * 6 - 1 - ew] = v[q];
         }
     };
-    if (hb + 1 < nb) fetch_row(hb + 1);
+    __syncthreads();                                          // (the table: its lanes only read their own entries, but ptab above is everybody's)
+    if (pl && hb + 1 < nb) { int2 e[BS_PF]; load_tab(e); fetch_row(hb + 1, e); }
     {   // Pull the rest of the band into this XCD's L2 now.  k_blocks wrote S from all eight XCDs, so the first touch of a line
         // is an HBM round trip (~2.5 us, longer than a factorisation step): with the lines resident, the one-step-ahead request
         // of the prefetch wave is an L2 hit.
@@ -1090,184 +1121,257 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     }
     __syncthreads();
     bool bad = false;
-    long long tr0 = B.trace ? clock64() : 0, trP1 = 0, trP2 = 0, trT = tr0, trA = 0, trB = 0, trC = 0, trD = 0;
+    long long tr0 = B.trace ? clock64() : 0, trT = tr0, trA = 0, trB = 0, trC = 0, trD = 0, trW = 0;
+#ifdef BS_TRACE_ACC      /* per-phase sums: every clock read costs the wave ~200 cycles, so only on request; the step-10 stamps below are always there */
 #define BS_TR(acc) if (B.trace) { const long long t_ = clock64(); acc += t_ - trT; trT = t_; }
-    const bool fwave = tid >= BS_UT && tid < BS_UT + 64;         // the factor wave
-    const bool pwave = tid >= BS_UT + 64;                        // the prefetch wave
-    const int flane = tid - BS_UT;
-    // Factor wave.  Every lane holds L_kk^-1 (Li) of the block column being eliminated.  Step k, before the first barrier:
-    // lane (r, c) forms rows r and c of L_{k+1,k} = A_{k+1,k} L_kk^-T itself and its entry of D_{k+1} = A_{k+1,k+1} - L L';
-    // between the barriers (while the update waves work on the window) it factors D_{k+1} and publishes L_{k+1,k+1}^-1 in the
-    // next LiAll slot.  The critical path of a step never leaves this wave's registers.
+#else
+#define BS_TR(acc)
+#endif
+    // Roles in the column loop -- one busy wave per SIMD (the waves w and w + 4 of a workgroup share a SIMD, and the second of two busy
+    // waves only gets the issue slots the first one leaves), and as few LDS instructions as possible (the LDS takes a fixed number of
+    // cycles per wave instruction however many lanes are active; the trailing update's loads are what a step's other LDS traffic queues behind):
+    //   wave 0  the factor wave;   waves 1-2  trailing update;   wave 3 (+ wave 7, a few instructions)  ring prefetch;
+    //   wave 4  copies L_kk^-1 to the factor store;   waves 5-6  idle.
+    const bool fwave = tid < 64;
+    const bool uwave = tid >= 64 && tid < 64 + BS_UT;
+    const bool pwave = (tid >> 6) == 3 || (tid >> 6) == 7;
+    const int flane = tid;
+    // Factor wave.  Every lane holds L_kk^-1 (Li) of the block column being eliminated.  Step k: lane t forms row t of the panel
+    // L_ik = A_ik L_kk^-T (the right-hand side rides along as one more row) straight from those registers, lane (r, c) rows r and c of
+    // L_{k+1,k} once more and its entry of D_{k+1} = A_{k+1,k+1} - L L'; the panel is published with an LDS flag (the update and prefetch
+    // waves poll it: no workgroup barrier) and the wave goes on: D_{k+1} reaches every lane through v_readlane (no LDS round trip behind
+    // the update waves' loads), is factored and inverted there.  One barrier per step, at its end: the critical path of a step never
+    // leaves this wave's registers.
     double Li[6][6];
-    auto factor = [&](const double *D, double *LiOut) {
-        double L[6][6], rd[6];
+    // The factorisation is the serial part of a step, and a dependent f64 operation costs ~14 cycles on a lone wave: the textbook
+    // loop has ~11 of them per pivot (update, rsqrt + two Newton steps, scale, square).  Here the elimination runs DIVISION-FREE on scaled
+    // entries -- m_ik <- (m_ik p_j - m_ij m_kj) 2^-e_j with p_j the scaled pivot and e_j its exponent (an exact rescaling that keeps the
+    // magnitudes where they are): a multiply, a fused multiply-add and a v_ldexp per pivot on the critical path.  If s_j is the scale the
+    // entries carry at step j (s_0 = 1, s_{j+1} = s_j mant(p_j)), the true pivot is p_j / s_j and the Cholesky column is
+    // L_ij = m_ij rsqrt(p_j s_j): the six rsqrt are independent of each other and overlap.
+    auto factor = [&](const double (&dd)[21], double *LiOut) {       // dd: lower triangle, row-major
+#pragma clang fp contract(fast)
+        double M[21], L[6][6], rd[6], invd[6], ps[6];
+#pragma unroll
+        for (int q = 0; q < 21; q++) M[q] = dd[q];
+        double sc = 1.0;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            double sd = D[j * 6 + j];
-#pragma unroll
-            for (int m = 0; m < j; m++) sd -= L[j][m] * L[j][m];
-            bad = bad || !(sd > 0);
-            sd = sd > 0 ? sd : 1.0;
-            rd[j] = rsqrt(sd);
-            L[j][j] = sd * rd[j];
+            double pj = M[j * (j + 1) / 2 + j];
+            bad = bad || !(pj > 0);
+            pj = pj > 0 ? pj : 1.0;
+            ps[j] = pj * sc;                                  // p_j s_j
+            invd[j] = sc;
+            const int e = -__builtin_amdgcn_frexp_exp(pj);
+            sc *= __builtin_amdgcn_frexp_mant(pj);
 #pragma unroll
             for (int i = j + 1; i < 6; i++) {
-                double a = D[i * 6 + j];
+                L[i][j] = M[i * (i + 1) / 2 + j];             // (unscaled column: times rd[j] below)
 #pragma unroll
-                for (int m = 0; m < j; m++) a -= L[i][m] * L[j][m];
-                L[i][j] = a * rd[j];
+                for (int k2 = j + 1; k2 <= i; k2++) {
+                    const double t = M[i * (i + 1) / 2 + k2] * pj - M[i * (i + 1) / 2 + j] * M[k2 * (k2 + 1) / 2 + j];
+                    M[i * (i + 1) / 2 + k2] = __builtin_amdgcn_ldexp(t, e);
+                }
             }
+            L[j][j] = pj;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) rd[j] = rsqrt(ps[j]);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            invd[j] *= rd[j];                                 // 1 / L_jj = s_j rsqrt(p_j s_j)
+#pragma unroll
+            for (int i = j; i < 6; i++) L[i][j] *= rd[j];
         }
 #pragma unroll
         for (int c = 0; c < 6; c++) {                        // column c of L^-1 by forward substitution
-            Li[c][c] = rd[c];
+            Li[c][c] = invd[c];
 #pragma unroll
             for (int i = c + 1; i < 6; i++) {
                 double a = 0.0;
 #pragma unroll
                 for (int m = c; m < i; m++) a += L[i][m] * Li[m][c];
-                Li[i][c] = -a * rd[i];
+                Li[i][c] = -a * invd[i];
             }
         }
         if (flane == 0) {
+            double lo[36];
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
-                for (int c = 0; c < 6; c++) LiOut[i * 6 + c] = c <= i ? Li[i][c] : 0.0;
+                for (int c = 0; c < 6; c++) lo[i * 6 + c] = c <= i ? Li[i][c] : 0.0;
+            st_rec<36>(LiOut, lo);
         }
     };
-    if (fwave) factor(Wn, LiAll);                                // D_0 = block (0, 0), ring slot [0][0]
+    auto factor_lds = [&](const double *D, double *LiOut) {
+        double dd[21];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) dd[i * (i + 1) / 2 + j] = D[i * 6 + j];
+        factor(dd, LiOut);
+    };
+    const int u_di = ptab[2 * (tid & 63) < hb * hb1 ? 2 * (tid & 63) : 0], u_dj = ptab[2 * (tid & 63) + 1 < hb * hb1 ? 2 * (tid & 63) + 1 : 0];    // an update lane's pair (first 64 pairs)
+    bool has_rhs_el = false;                                     // a prefetch lane that carries right-hand-side entries of the incoming row
+    if (pl) for (int q = 0; q < BS_PF; q++) { const int ew = etab[q * BS_PT + pidx].x; has_rhs_el = has_rhs_el || (ew < 0 && ew > -1000); }
+    if (fwave) factor_lds(Wn, LiAll);                            // D_0 = block (0, 0), ring slot [0][0]
     bs_barrier();
-    int kbeg = 0, kend = own;
+    if (B.trace && side == 0 && tid == 0) B.trace[16] = clock64() - tr0;
+    if (B.trace && tid == 0) B.trace[20 + side] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    int kbeg = 0, kend = own, kk = 0;                            // kk = k mod (hb + 1), kept by hand (a run-time division costs ~40 scalar instructions)
     for (int phase = 0; ; phase++) {
-    for (int k = kbeg; k < kend; k++) {
-        const int kk = k % hb1, np = nb - 1 - k < hb ? nb - 1 - k : hb;      // blocks below the diagonal in this column
-        const double *LiK = LiAll + 36 * k;                     // L_kk^-1 (the factor wave writes the next column's during this step)
-        // ---- P1: the panel rows L_ik = A_ik L_kk^-T and the right-hand side ----
+    for (int k = kbeg; k < kend; k++, kk = kk + 1 == hb1 ? 0 : kk + 1) {
+        const int np = nb - 1 - k < hb ? nb - 1 - k : hb;        // blocks below the diagonal in this column
         double *Lgk = Lg + (size_t)k * lgs;
-        if (tid < np * 6 + 1) {
-            const bool is_rhs = tid == np * 6;
-            const int di = tid / 6 + 1, r = tid - 6 * (di - 1);
-            int ri = kk + di; if (ri >= hb1) ri -= hb1;
-            const double *Arow = is_rhs ? rhs + kk * 6 : Wn + ((size_t)ri * hb1 + kk) * 36 + r * 6;
-            double a[6], o[6], li[21];
-#pragma unroll
-            for (int m = 0; m < 6; m++) a[m] = Arow[m];
-            {
-                int q = 0;
-#pragma unroll
-                for (int c = 0; c < 6; c++)
-#pragma unroll
-                    for (int m = 0; m <= c; m++) li[q++] = LiK[c * 6 + m];
-            }
-            {
-                int q = 0;
-#pragma unroll
-                for (int c = 0; c < 6; c++) {                    // X = A L^-T: X[r][c] = sum_{m <= c} A[r][m] Linv[c][m]
-                    double t = 0.0;
-#pragma unroll
-                    for (int m = 0; m <= c; m++) t += a[m] * li[q++];
-                    o[c] = t;
-                }
-            }
-            if (is_rhs) {
-#pragma unroll
-                for (int c = 0; c < 6; c++) { yk[c] = o[c]; x[6 * k + c] = o[c]; }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 6; c++) { Lp[di * 36 + r * 6 + c] = o[c]; Lgk[di * 36 + r * 6 + c] = o[c]; }
-            }
-        } else if (tid >= 128 && tid < 164) Lgk[tid - 128] = LiK[tid - 128];
-        else if (fwave && k + 1 < nb) {
+        const bool stamp = B.trace && side == 0 && k == 10 && (tid & 63) == 0;
+        if (stamp) B.trace[32 + (tid >> 6)] = clock64();
+        if (fwave) {
+#pragma clang fp contract(fast)
+            // ---- the panel rows L_ik = A_ik L_kk^-T and the right-hand side (lane t: row t), D_{k+1} (lane (r, c) < 36) ----
+            const int nrow = np * 6 + 1;
             int r1 = kk + 1; if (r1 >= hb1) r1 -= hb1;
-            if (flane < 36) {
-                const int r = flane / 6, c = flane - 6 * r;
-                const double *Ar = Wn + ((size_t)r1 * hb1 + kk) * 36 + r * 6, *Ac = Wn + ((size_t)r1 * hb1 + kk) * 36 + c * 6;
-                double ar[6], ac[6], xr[6], xc[6];
+            double a[6], ar[6], ac[6], o[6], xr[6], xc[6];
+            const bool prow = flane < nrow, is_rhs = flane == np * 6;
+            const int pdi = flane / 6 + 1, pr = flane - 6 * (pdi - 1);
+            {
+                int ri = kk + pdi; if (ri >= hb1) ri -= hb1;
+                const double *Arow = is_rhs ? rhs + kk * 6 : Wn + (prow ? (ri * hb1 + kk) * BS_WS + pr * 6 : 0);
+                const int fl = flane < 36 ? flane : 0, r = fl / 6, c = fl - 6 * r;
+                const double *Ar = Wn + (r1 * hb1 + kk) * BS_WS + r * 6, *Ac = Wn + (r1 * hb1 + kk) * BS_WS + c * 6;
+                ld_rec<6>(Arow, a); ld_rec<6>(Ar, ar); ld_rec<6>(Ac, ac);
+                const double dv = Wn[(r1 * hb1 + r1) * BS_WS + fl];
 #pragma unroll
-                for (int m = 0; m < 6; m++) { ar[m] = Ar[m]; ac[m] = Ac[m]; }
-                const double dv = Wn[((size_t)r1 * hb1 + r1) * 36 + flane];
+                for (int q = 0; q < 6; q++) {                    // X = A L^-T: X[r][q] = sum_{m <= q} A[r][m] Linv[q][m]
+                    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
 #pragma unroll
-                for (int q = 0; q < 6; q++) {                    // rows r and c of L_{k+1,k} (the same sums the panel threads form)
-                    double tr = 0.0, tc = 0.0;
-#pragma unroll
-                    for (int m = 0; m <= q; m++) { tr += ar[m] * Li[q][m]; tc += ac[m] * Li[q][m]; }
-                    xr[q] = tr; xc[q] = tc;
+                    for (int m = 0; m <= q; m++) { t0 += a[m] * Li[q][m]; t1 += ar[m] * Li[q][m]; t2 += ac[m] * Li[q][m]; }
+                    o[q] = t0; xr[q] = t1; xc[q] = t2;
                 }
-                double t = 0.0;
+                double tt = 0.0;
 #pragma unroll
-                for (int m = 0; m < 6; m++) t += xr[m] * xc[m];
-                Dn[flane] = dv - t;
+                for (int m = 0; m < 6; m++) tt += xr[m] * xc[m];
+                xr[0] = dv - tt;                                  // this lane's entry of D_{k+1}
             }
-        }
-        BS_TR(trB)
-        bs_barrier();
-        if (B.trace) { const long long t = clock64(); trP1 += t - trT; trT = t; }
-        // ---- P2: trailing update of the window (update waves); the next block row enters (prefetch wave); D_{k+1} is factored ----
-        if (tid < BS_UT) {
-            const int npair = np * (np + 1) / 2, nwork = npair * 6 + np;
-            for (int wk = tid + 6; wk < nwork; wk += BS_UT) {    // work items 0 .. 5 = pair (1, 1) = the next diagonal block: the factor wave's
-                if (wk < npair * 6) {
-                    const int pr = wk / 6, r = wk - 6 * pr;
-                    const int di = ptab[2 * pr], dj = ptab[2 * pr + 1];
-                    int ri = kk + di; if (ri >= hb1) ri -= hb1;
-                    int rj = kk + dj; if (rj >= hb1) rj -= hb1;
-                    double a[6], lj[36], wb[6];                   // all operands into registers first: one LDS wait per work item
+            if (prow) {
+                if (is_rhs) { st_rec<6>(yk, o); st_rec<6>(x + 6 * k, o); }
+                else { st_rec<6>(Lp + pdi * BS_WS + pr * 6, o); st_rec<6>(Lgk + pdi * 36 + pr * 6, o); }
+            }
+            for (int t = flane + 64; t < nrow; t += 64) {        // wide bands (hb > 10): the rows beyond the first 64
+                const bool rh = t == np * 6;
+                const int di = t / 6 + 1, r = t - 6 * (di - 1);
+                int ri = kk + di; if (ri >= hb1) ri -= hb1;
+                const double *Arow = rh ? rhs + kk * 6 : Wn + (ri * hb1 + kk) * BS_WS + r * 6;
+                ld_rec<6>(Arow, a);
 #pragma unroll
-                    for (int m = 0; m < 6; m++) a[m] = Lp[di * 36 + r * 6 + m];
-                    double *Wb = Wn + ((size_t)ri * hb1 + rj) * 36 + r * 6;
-                    const double *Lj = Lp + dj * 36;
+                for (int q = 0; q < 6; q++) {
+                    double t0 = 0.0;
 #pragma unroll
-                    for (int q = 0; q < 36; q++) lj[q] = Lj[q];
-#pragma unroll
-                    for (int c = 0; c < 6; c++) wb[c] = Wb[c];
-#pragma unroll
-                    for (int c = 0; c < 6; c++) {
-                        double t = 0.0;
-#pragma unroll
-                        for (int m = 0; m < 6; m++) t += a[m] * lj[c * 6 + m];
-                        wb[c] -= t;
-                    }
-#pragma unroll
-                    for (int c = 0; c < 6; c++) Wb[c] = wb[c];
-                } else {
-                    const int dj = wk - npair * 6 + 1;
-                    int rj = kk + dj; if (rj >= hb1) rj -= hb1;
-                    const double *Lj = Lp + dj * 36;
-                    double a[6], lj[36], wb[6];
-#pragma unroll
-                    for (int m = 0; m < 6; m++) a[m] = yk[m];
-#pragma unroll
-                    for (int q = 0; q < 36; q++) lj[q] = Lj[q];
-#pragma unroll
-                    for (int c = 0; c < 6; c++) wb[c] = rhs[rj * 6 + c];
-#pragma unroll
-                    for (int c = 0; c < 6; c++) {
-                        double t = 0.0;
-#pragma unroll
-                        for (int m = 0; m < 6; m++) t += a[m] * lj[c * 6 + m];
-                        wb[c] -= t;
-                    }
-#pragma unroll
-                    for (int c = 0; c < 6; c++) rhs[rj * 6 + c] = wb[c];
+                    for (int m = 0; m <= q; m++) t0 += a[m] * Li[q][m];
+                    o[q] = t0;
                 }
+                if (rh) { st_rec<6>(yk, o); st_rec<6>(x + 6 * k, o); }
+                else { st_rec<6>(Lp + di * BS_WS + r * 6, o); st_rec<6>(Lgk + di * 36 + r * 6, o); }
+            }
+            if (flane < 36) Dn[flane] = xr[0];                   // (the hand-over to / from the other side reads it after the loop)
+            asm volatile("" ::: "memory");                       // the LDS executes a wave's instructions in order: the flag lands after the panel
+            if (flane == 0) __hip_atomic_store(&s_step, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            BS_TR(trB)
+            if (stamp) B.trace[40] = clock64();
+            if (k + 1 < nb) {
+                double dd[21];
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j <= i; j++) {
+                        const int lo = __builtin_amdgcn_readlane(__double2loint(xr[0]), i * 6 + j), hi = __builtin_amdgcn_readlane(__double2hiint(xr[0]), i * 6 + j);
+                        dd[i * (i + 1) / 2 + j] = __hiloint2double(hi, lo);
+                    }
+                factor(dd, LiAll + 36 * (k + 1));
+            }
+            BS_TR(trA)
+        } else if (uwave) {
+#pragma clang fp contract(fast)
+            // ---- trailing update of the window: lane = block pair (di, dj), dj <= di; wave 1 takes rows 0-2 of the block, wave 2 rows 3-5 ----
+            while (__hip_atomic_load(&s_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            BS_TR(trW)
+            const int npair = np * (np + 1) / 2, h = (tid >> 6) - 1;
+            for (int pr = tid & 63; pr < npair; pr += 64) {
+                if (pr == 0) continue;                           // pair (1, 1) = the next diagonal block: the factor wave's
+                const int di = pr < 64 ? u_di : ptab[2 * pr], dj = pr < 64 ? u_dj : ptab[2 * pr + 1];
+                int ri = kk + di; if (ri >= hb1) ri -= hb1;
+                int rj = kk + dj; if (rj >= hb1) rj -= hb1;
+                const double *Ai = Lp + di * BS_WS + h * 18, *Lj = Lp + dj * BS_WS;
+                double *Wb = Wn + (ri * hb1 + rj) * BS_WS + h * 18;
+                double a[18], wb[18];
+                ld_rec<18>(Ai, a);                                // 16-byte LDS accesses (ds_read_b128: 256 B per clock; ds_read2_b64: half that)
+                ld_rec<18>(Wb, wb);
+#pragma unroll
+                for (int hc = 0; hc < 2; hc++) {                 // L_dj in two halves (the registers: 256 per lane with two waves per SIMD)
+                    double lj[18];
+                    ld_rec<18>(Lj + hc * 18, lj);
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            double tt = 0.0;
+#pragma unroll
+                            for (int m = 0; m < 6; m++) tt += a[r * 6 + m] * lj[c * 6 + m];
+                            wb[r * 6 + hc * 3 + c] -= tt;
+                        }
+                }
+                st_rec<18>(Wb, wb);
             }
             BS_TR(trC)
+        } else if ((tid >> 6) == 5) {
+#pragma clang fp contract(fast)
+            // ---- the right-hand side rows of the window: lane = dj ----
+            while (__hip_atomic_load(&s_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            for (int dj = (tid & 63) + 1; dj <= np; dj += 64) {
+                int rj = kk + dj; if (rj >= hb1) rj -= hb1;
+                const double *Lj = Lp + dj * BS_WS;
+                double a[6], lj[36], wb[6];
+                ld_rec<6>(yk, a);
+                ld_rec<36>(Lj, lj);
+                ld_rec<6>(rhs + rj * 6, wb);
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double tt = 0.0;
+#pragma unroll
+                    for (int m = 0; m < 6; m++) tt += a[m] * lj[c * 6 + m];
+                    wb[c] -= tt;
+                }
+                st_rec<6>(rhs + rj * 6, wb);
+            }
         } else if (pwave) {
-            const long long t0_ = B.trace ? clock64() : 0;
-            if (k + 1 + hb < nb) put_row(k + 1 + hb, kk);    // into the ring row that block row k vacated: (k + 1 + hb) mod (hb + 1) = k mod (hb + 1)
-            if (k + 2 + hb < nb) fetch_row(k + 2 + hb);
-            if (B.trace) trA += clock64() - t0_;
-        } else if (k + 1 < nb) {
-            const long long t0_ = B.trace ? clock64() : 0;
-            factor(Dn, LiAll + 36 * (k + 1));
-            if (B.trace) trA += clock64() - t0_;
-        }
-        BS_TR(trD)
+            // ---- the next block row enters the ring row that block row k vacated ((k + 1 + hb) mod (hb + 1) = k mod (hb + 1)): nobody reads
+            //      that row's blocks in this step, so they go in right away, while the LDS is idle (the update waves' bursts start at the
+            //      flag), and the row after it is requested; the row's right-hand side waits for the flag -- the factor wave reads the old
+            //      one for the panel ----
+            double pg[BS_PF];
+            int2 e[BS_PF];
+            load_tab(e);
+#pragma unroll
+            for (int q = 0; q < BS_PF; q++) pg[q] = pf[q];
+            if (stamp && tid == 192) B.trace[72] = clock64();
+            if (k + 1 + hb < nb) put_row(k + 1 + hb, kk, e, pg, true, false);
+            if (stamp && tid == 192) B.trace[73] = clock64();
+            if (k + 2 + hb < nb) fetch_row(k + 2 + hb, e);
+            if (stamp && tid == 192) B.trace[74] = clock64();
+            if (has_rhs_el) {
+                while (__hip_atomic_load(&s_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                if (k + 1 + hb < nb) put_row(k + 1 + hb, kk, e, pg, false, true);
+            }
+            BS_TR(trC)
+        } else if (tid - 256 < 36) Lgk[tid - 256] = LiAll[36 * k + tid - 256];       // L_kk^-1 (the factor wave writes the next column's during this step)
+        if (stamp) B.trace[48 + (tid >> 6)] = clock64();
         bs_barrier();
-        if (B.trace) { const long long t = clock64(); trP2 += t - trT; trT = t; }
+        BS_TR(trD)
+        if (stamp) { B.trace[56 + (tid >> 6)] = clock64(); B.trace[64 + (tid >> 6)] = __builtin_amdgcn_s_getreg(63492); }
     }
+    if (B.trace && side == 0 && tid == 0) B.trace[17 + 2 * phase] = clock64() - tr0;
     if (!tw || phase == 1) break;
     // ---- the middle: rows own .. own + hb - 1 of the ring hold S - (this side's updates); the diagonal block (own, own) is in Dn
     //      (the factor wave keeps the next diagonal block to itself).  Lower blocks (i >= j), row-major hb x hb triangle + rhs.
@@ -1279,7 +1383,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                 const int bq = e / 36, rc = e - 36 * bq;
                 int i = 0, q = bq; while (q > i) { q -= i + 1; i++; }            // bq = i (i + 1) / 2 + j
                 const int li = own + i, lj = own + q;
-                v = (i == 0) ? Dn[rc] : Wn[((size_t)(li % hb1) * hb1 + (lj % hb1)) * 36 + rc];
+                v = (i == 0) ? Dn[rc] : Wn[((size_t)(li % hb1) * hb1 + (lj % hb1)) * BS_WS + rc];
             } else {
                 const int i = (e - ntri * 36) / 6, r = e - ntri * 36 - 6 * i;
                 v = rhs[((own + i) % hb1) * 6 + r];
@@ -1287,41 +1391,72 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
             B.xchg[e] = v;
         }
         if (bad) s_bad = 1;
-        __threadfence();
+        if (same_xcd()) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); else __threadfence();
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(B.fail + 1, B.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(B.fail + 1, B.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
     }
-    if (tid == 0) while (__hip_atomic_load(B.fail + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != B.epoch) __builtin_amdgcn_s_sleep(8);
-    __syncthreads();
-    __threadfence();
-    for (int e = tid; e < ntri * 36 + hb * 6; e += BS_T) {
-        if (e < ntri * 36) {
-            const int bq = e / 36, rc = e - 36 * bq, r = rc / 6, c = rc - 6 * r;
-            int i = 0, q = bq; while (q > i) { q -= i + 1; i++; }                // middle block (own + i, own + q), i >= q
-            // the other side numbers the middle backwards and holds the transposed block: its (hb - 1 - q, hb - 1 - i), entry (c, r)
-            const int oi = hb - 1 - q, oj = hb - 1 - i;
-            const double vb = __builtin_nontemporal_load(B.xchg + (size_t)(oi * (oi + 1) / 2 + oj) * 36 + c * 6 + r);
-            const int I = own + i, J = own + q;
-            double sd = B.S[(size_t)(6 * I + r) + (size_t)(6 * J + c) * n];
-            if (i == q && r == c) sd += damp[6 * I + r];
-            double *w = Wn + ((size_t)(I % hb1) * hb1 + (J % hb1)) * 36 + rc;
-            const double va = (bq == 0) ? Dn[rc] : *w;
-            *w = (va + vb) - sd;
-        } else {
-            const int i = (e - ntri * 36) / 6, r = e - ntri * 36 - 6 * i;
-            const double vb = __builtin_nontemporal_load(B.xchg + (size_t)ntri * 36 + (hb - 1 - i) * 6 + r);
-            double *w = rhs + ((own + i) % hb1) * 6 + r;
-            *w = (*w + vb) - B.g[6 * (own + i) + r];
+    // M = ringA + ringB' - S for the middle.  What does not depend on the other side is done BEFORE the wait: each thread's (<= 4) entries --
+    // where they come from and go to -- and their S / g values (requested now, in flight during the wait); after the flag the other side's
+    // values are requested together: one L2 round trip, not one per entry.
+    // (a thread keeps one position (r, c) inside the blocks and takes block t / 36 + 14 qq in pass qq; the blocks' (i, q) come from the
+    //  pair table; the 6 hb right-hand-side entries ride in the last pass's spare slots: no run-time division, no search)
+    constexpr int ME = 4;                                          // 14 blocks per pass: 56 >= 45 (twisted solves have hb <= 9) + the right-hand side
+    int m_x[ME], m_w[ME], m_s[ME]; double m_sd[ME];               // index in xchg; LDS word (of bs_sm) written / read; S (+ damping) or g value
+    {
+        const int rc = tid % 36, r = rc / 6, c = rc - 6 * r, b0 = tid / 36, ob = own % hb1;
+#pragma unroll
+        for (int qq = 0; qq < ME; qq++) {
+            const int bq = b0 + 14 * qq;
+            m_x[qq] = -1; m_w[qq] = 0; m_s[qq] = 0; m_sd[qq] = 0.0;
+            if (tid >= 504) continue;
+            if (bq < ntri) {
+                const int i = ptab[2 * bq] - 1, q = ptab[2 * bq + 1] - 1;          // middle block (own + i, own + q), i >= q
+                // the other side numbers the middle backwards and holds the transposed block: its (hb - 1 - q, hb - 1 - i), entry (c, r)
+                const int oi = hb - 1 - q, oj = hb - 1 - i;
+                m_x[qq] = (oi * (oi + 1) / 2 + oj) * 36 + c * 6 + r;
+                const int I = own + i, J = own + q;
+                double sd = B.S[(6 * J + c) + (6 * I + r) * n];                     // (S is symmetric, both halves written: this is the half the start of the kernel pulled into the L2)
+                if (i == q && r == c) sd += damp[6 * I + r];
+                m_sd[qq] = sd;
+                int si = ob + i; if (si >= hb1) si -= hb1;
+                int sj = ob + q; if (sj >= hb1) sj -= hb1;
+                m_w[qq] = (int)(Wn - bs_sm) + (si * hb1 + sj) * BS_WS + rc;
+                m_s[qq] = bq == 0 ? (int)(Dn - bs_sm) + rc : m_w[qq];                // (the factor wave keeps the next diagonal block in Dn)
+            } else {
+                const int er = (bq - ntri) * 36 + rc;
+                if (er < hb * 6) {
+                    const int i = er / 6, rr = er - 6 * i;
+                    m_x[qq] = ntri * 36 + (hb - 1 - i) * 6 + rr;
+                    int si = ob + i; if (si >= hb1) si -= hb1;
+                    m_w[qq] = m_s[qq] = (int)(rhs - bs_sm) + si * 6 + rr;
+                    m_sd[qq] = B.g[6 * (own + i) + rr];
+                }
+            }
         }
     }
+    if (B.trace && side == 0 && tid == 0) B.trace[22] = clock64() - tr0;
+    if (tid == 0) while (__hip_atomic_load(B.fail + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != B.epoch) __builtin_amdgcn_s_sleep(2);
+    if (B.trace && side == 0 && tid == 0) B.trace[23] = clock64() - tr0;
     __syncthreads();
-    if (fwave) factor(Wn + ((size_t)(own % hb1) * hb1 + (own % hb1)) * 36, LiAll + 36 * own);
+    if (same_xcd()) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); else __threadfence();
+    if (B.trace && side == 0 && tid == 0) B.trace[24] = clock64() - tr0;
+    {
+        double vb[ME];
+#pragma unroll
+        for (int qq = 0; qq < ME; qq++) vb[qq] = __hip_atomic_load(B.xchg + (m_x[qq] >= 0 ? m_x[qq] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (sc1: from the L2)
+#pragma unroll
+        for (int qq = 0; qq < ME; qq++) if (m_x[qq] >= 0) bs_sm[m_w[qq]] = (bs_sm[m_s[qq]] + vb[qq]) - m_sd[qq];
+    }
+    __syncthreads();
+    if (B.trace && side == 0 && tid == 0) B.trace[25] = clock64() - tr0;
+    if (fwave) factor_lds(Wn + ((size_t)(own % hb1) * hb1 + (own % hb1)) * BS_WS, LiAll + 36 * own);
     bs_barrier();
+    if (B.trace && side == 0 && tid == 0) B.trace[18] = clock64() - tr0;
     kbeg = own; kend = nb;
     }
     if (bad) s_bad = 1;
-    __threadfence();                                         // the factor store is re-read below by other threads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the factor store is re-read below by other threads (of this workgroup)
     __syncthreads();
     // ---- back-substitution L' dp = y, block columns right to left ----
     // step k: (A) thread (di, c): sum_r L_{k+di,k}[r][c] x_{k+di}[r]; (B) thread c: t_c = y_k[c] - the partial sums, in fixed order;
@@ -1382,7 +1517,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
             for (int c = 0; c < 6; c++) chat[6 * k + c] = gq[c];
         }
         __syncthreads();
-        if (B.trace && tid == 0) { const long long t_ = clock64(); B.trace[10] = t_ - trb0; trb0 = t_; }
+        if (B.trace && side == 0 && tid == 0) { const long long t_ = clock64(); B.trace[10] = t_ - trb0; trb0 = t_; }
         double base = 0.0;                                     // - sum_j G_{k',j} dp_{k'+j} so far, of the column in this lane's slot
         for (int kb = nb; kb > 0; ) {
             const int ka = kb > cap ? kb - cap : 0;               // steps ka .. kb - 1 (step 0 has nothing to update: its G rows are never read)
@@ -1411,13 +1546,13 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
             if (tw && side && kb == nb) {
                 // the middle poses are the other side's: wait for their dp, enter it where this side's recurrence expects chat (their
                 // running sums stay zero: `on` below never selects a middle column)
-                if (tid == 0) while (__hip_atomic_load(B.fail + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != B.epoch) __builtin_amdgcn_s_sleep(8);
+                if (tid == 0) while (__hip_atomic_load(B.fail + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != B.epoch) __builtin_amdgcn_s_sleep(2);
                 __syncthreads();
-                __threadfence();
-                for (int e = tid; e < hb * 6; e += BS_T) chat[6 * own + e] = __builtin_nontemporal_load(d.dp + 6 * gi(own + e / 6) + e % 6);
+                if (same_xcd()) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); else __threadfence();
+                for (int e = tid; e < hb * 6; e += BS_T) chat[6 * own + e] = __hip_atomic_load(d.dp + 6 * gi(own + e / 6) + e % 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __syncthreads();
             }
-            if (B.trace && tid == 0) { const long long t_ = clock64(); B.trace[11] = t_ - trb0; trb0 = t_; }
+            if (B.trace && side == 0 && tid == 0) { const long long t_ = clock64(); B.trace[11] = t_ - trb0; trb0 = t_; }
             if (tid < 64) {
                 // two steps per trip with the roles of the two register sets swapped: the rows / chat entries of the next step are
                 // requested before this step's chain and nothing waits for them until they are used
@@ -1428,6 +1563,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                     ld_rec<6>(gp, gg);
                     cc = chat[6 * k + (act ? c_ : 0)];
                 };
+                const bool same0 = tw && side == 0 && same_xcd();
                 auto step = [&](int k, int ksl, const double (&gg)[6], double cc, bool on) {
                     const bool mine = act && s_ == ksl;
                     const double v = mine ? base + cc : base;         // dp_k on the lanes of its slot
@@ -1444,8 +1580,8 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                     if (tw && side == 0 && k >= own) {               // the middle: the other side waits for these
                         if (mine) d.dp[6 * k + c_] = v;
                         if (k == own) {
-                            __threadfence();
-                            if (lane == 0) __hip_atomic_store(B.fail + 2, B.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                            if (same0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); else __threadfence();
+                            if (lane == 0) __hip_atomic_store(B.fail + 2, B.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
                 };
@@ -1472,7 +1608,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                     ks = ks3;
                 }
             }
-            if (B.trace && tid == 0) { const long long t_ = clock64(); B.trace[12] = t_ - trb0; trb0 = t_; }
+            if (B.trace && side == 0 && tid == 0) { const long long t_ = clock64(); B.trace[12] = t_ - trb0; trb0 = t_; }
             __syncthreads();
             kb = ka;
         }
@@ -1514,9 +1650,11 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     }
     for (int a = tid; a < 6 * kfac2; a += BS_T) d.dp[6 * gi(a / 6) + a % 6] = x[a];
     if (tid == 0) { if (!tw || side == 0) *B.fail = s_bad; if (s_bad) d.st->chol_fail = 1; }
-    if (B.trace && tid == BS_UT) B.trace[8] = trA;
-    if (B.trace && tid == BS_UT + 64) B.trace[9] = trA;
-    if (B.trace && tid == 0) { B.trace[0] = tr0; B.trace[1] = trP1; B.trace[2] = trP2; B.trace[3] = clock64() - trT; B.trace[4] = trA; B.trace[5] = trB; B.trace[6] = trC; B.trace[7] = trD; }
+    if (B.trace && side == 0) {
+        if (tid == 0) { B.trace[0] = tr0; B.trace[1] = trD; B.trace[3] = clock64() - trT; B.trace[4] = trA; B.trace[5] = trB; }
+        if (tid == 64) { B.trace[2] = trW; B.trace[6] = trC; B.trace[7] = trD; }
+        if (tid == 192) { B.trace[8] = trW; B.trace[9] = trC; }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_backsub(BADev d, int use_state)
@@ -2020,7 +2158,7 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
     static const bool no_band = getenv("SLAMHIP_NO_BAND") != nullptr;
     const int hb = std::min(std::max(ba->hb, 1), d.P - 1);      // >= 1: the factor wave reads block row k + 1 while row k + 1 + hb enters the ring
     const size_t band_fixed = (3 * (size_t)n + 36 * (size_t)d.P) * 8;      // x, damp, chat, L_kk^-1 of every column
-    size_t band_lds = band_fixed + ((size_t)(hb + 1) * (hb + 1) * 36 + (size_t)(hb + 1) * (6 + 36 + 6) + 8 + 36) * 8 + (size_t)hb * (hb + 1) + 16;
+    size_t band_lds = band_fixed + ((size_t)(hb + 1) * (hb + 1) * BS_WS + (size_t)(hb + 1) * (6 + BS_WS + 6) + 8 + 36 + 56) * 8 + (size_t)BS_PF * BS_PT * 8;
     if (hb * 6 <= 58) {      // narrow bands: room to stage the G blocks of (up to) all back-substitution steps, at least one
         const size_t want = band_fixed + (size_t)d.P * hb * 36 * 8, least = band_fixed + (size_t)hb * 36 * 8;
         band_lds = std::max(band_lds, std::max(std::min(want, (size_t)150 * 1024), least));
@@ -2029,19 +2167,34 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
         BandArgs B; B.S = red; B.g = red + (size_t)n * n; B.ud = red + (size_t)n * n + n; B.Lg = ba->band; B.nb = d.P; B.hb = hb;
         B.inv_delta_host = inv_delta; B.fail = ba->chol_flag; B.lds_bytes = (int)band_lds;
         B.xchg = ba->xchg; B.epoch = ++ba->epoch;
+        static const int twist_shift = [] { const char *v = getenv("SLAMHIP_TWIST_SHIFT"); return v ? atoi(v) : 1; }();    // (measurement knob; +1: side 0 takes two columns more than side 1, measured best at P = 50)
+        B.shift = twist_shift;
         static const bool no_twist = getenv("SLAMHIP_NO_TWIST") != nullptr;
         // (the two workgroups wait for each other: both must be resident, which a stream confined to one compute unit cannot promise)
         static const int twist_min = [] { const char *v = getenv("SLAMHIP_TWIST_MIN"); return v ? atoi(v) : 0; }();    // (measurement knob)
         const bool twist = !no_twist && hb * 6 <= 58 && d.P >= (twist_min > 0 ? std::max(twist_min, hb + 8) : 2 * (hb + 1) + 6)      /* measured break-even: 24 poses at hb = 9 */ && (ctx->cus == 0 || ctx->cus >= 2);
         static long long *trace_dev = nullptr; static int trace_n = 0;
         static const bool trace_on = getenv("SLAMHIP_BAND_TRACE") != nullptr;
-        if (trace_on && !trace_dev) (void)hipHostMalloc((void **)&trace_dev, 128);
+        if (trace_on && !trace_dev) (void)hipHostMalloc((void **)&trace_dev, 1024);
         B.trace = trace_dev;
-        if (trace_on && trace_n++ == 8) { (void)hipStreamSynchronize(st); fprintf(stderr, "band trace (cycles): P1 barrier wait %lld P2 barrier wait %lld backsub %lld | potrf+inv %lld panel %lld update %lld put/fetch %lld | factor wave %lld prefetch wave %lld | backsub: chat %lld G %lld recurrence %lld\n", trace_dev[1], trace_dev[2], trace_dev[3], trace_dev[4], trace_dev[5], trace_dev[6], trace_dev[7], trace_dev[8], trace_dev[9], trace_dev[10], trace_dev[11], trace_dev[12]); }
+        if (trace_on && trace_n++ == 8) {      // side 0 of the ninth launch, shader cycles
+            (void)hipStreamSynchronize(st);
+            fprintf(stderr, "band trace (cycles): factor wave: panel %lld factor %lld barrier %lld, then middle + back-substitution %lld | update wave 1: flag %lld update %lld barrier %lld | prefetch wave: flag %lld put/fetch %lld | backsub: chat %lld G %lld recurrence %lld\n",
+                    trace_dev[5], trace_dev[4], trace_dev[1], trace_dev[3], trace_dev[2], trace_dev[6], trace_dev[7], trace_dev[8], trace_dev[9], trace_dev[10], trace_dev[11], trace_dev[12]);
+            fprintf(stderr, "  side 0 timeline (cycles since kernel start): column loop starts %lld, own columns done %lld, middle assembled + factored %lld, forward done %lld\n", trace_dev[16], trace_dev[17], trace_dev[18], trace_dev[19]);
+            fprintf(stderr, "  middle: entries prepared %lld, flag seen %lld, fence done %lld, assembled %lld\n", trace_dev[22], trace_dev[23], trace_dev[24], trace_dev[25]);
+            fprintf(stderr, "  XCC_ID of side 0 / side 1: %lld / %lld; of the idle workgroups 1-7:", trace_dev[20] & 15, trace_dev[21] & 15);
+            for (int w = 1; w < 8; w++) fprintf(stderr, " %lld", trace_dev[80 + w] & 15);
+            fprintf(stderr, "\n");
+            const long long t0 = trace_dev[32];      // step 10 per wave, relative to wave 0's start of the step: start, (wave 0: flag published), arrival at the barrier, release
+            fprintf(stderr, "  wave 3: registers copied %lld, blocks in the ring %lld, next row requested %lld\n", trace_dev[72] - t0, trace_dev[73] - t0, trace_dev[74] - t0);
+            for (int w = 0; w < 8; w++) fprintf(stderr, "  wave %d (simd %lld): start %lld%s arrive %lld release %lld\n", w, (trace_dev[64 + w] >> 4) & 3, trace_dev[32 + w] - t0,
+                                                w == 0 ? (" flag " + std::to_string(trace_dev[40] - t0)).c_str() : "", trace_dev[48 + w] - t0, trace_dev[56 + w] - t0);
+        }
         static bool attr_set[64] = {};
         const int dv = ctx->device & 63;
         if (!attr_set[dv]) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set[dv] = true; }
-        hipLaunchKernelGGL(k_band_solve, dim3(twist ? 2 : 1), dim3(BS_T), band_lds, st, d, B, use_state);
+        hipLaunchKernelGGL(k_band_solve, dim3(twist ? 9 : 1), dim3(BS_T), band_lds, st, d, B, use_state);
     } else {
         CholArgs C; C.A = d.Swork; C.Lf = ba->lfac; C.n = n; C.ld = n + 1; C.fail = ba->chol_flag;
         const size_t tot = (size_t)(n + 1) * n;
