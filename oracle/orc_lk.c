@@ -119,7 +119,9 @@ static void flow_vector(const orc_pyr *first, const orc_pyr *second, int lv, con
                 ay[e & 63] += dI * Iy[a];
                 ax[e & 63] += dI * Ix[a];
             }
-        for (int m = 1; m <= 32; m <<= 1) {
+        static const int order[6] = {32, 16, 1, 2, 4, 8};     /* the butterfly order of the device kernel's wave sum (csrc/lk.hip: wave_sum2) */
+        for (int mi = 0; mi < 6; mi++) {
+            const int m = order[mi];
             double ty[64], tx[64];
             for (int l = 0; l < 64; l++) { ty[l] = ay[l] + ay[l ^ m]; tx[l] = ax[l] + ax[l ^ m]; }
             memcpy(ay, ty, sizeof ay); memcpy(ax, tx, sizeof ax);

@@ -95,7 +95,7 @@ void orc_pinv2x2(const double M[4], double Ginv[4], double S[2]);
  * initialised to all-true inside (trues(n)).  sum_order: 0 = reference order
  * (q outer, p inner, one accumulator; lucas_kanade.jl:163-170); 1 = "wave
  * order": element e = q*P + p goes to accumulator e % 64, accumulators are
- * folded with a 6-step butterfly (xor 1,2,4,8,16,32), the order the HIP kernel
+ * folded with a 6-step butterfly (xor 32,16,1,2,4,8), the order the HIP kernel
  * uses.  Returns n_good (counted from status; the reference's racy counter,
  * SURVEY F9, is not reproduced).  Returns -1 when "Not enough layers". */
 int  orc_optflow(double *disp_yx, const orc_pyr *first, const orc_pyr *second,

@@ -12,7 +12,7 @@
 // there: see stage_rect / lk_level); the (2w+1)^2 window is dealt to lanes
 // in the reference's iteration order (q outer, p inner; element e -> lane
 // e % 64, sequential per lane) and the two sums of prepare_linear_system are
-// folded with a 6-step xor butterfly.  That summation order is restated in the
+// folded with a 6-step xor butterfly (wave_sum2: m = 32, 16, 1, 2, 4, 8).  That summation order is restated in the
 // CPU oracle (sum_order = 1) and is bit-reproducible; it differs from the
 // reference's single-accumulator order only in rounding (<= 1e-12 px observed).
 #include "common.hpp"
@@ -74,11 +74,14 @@ __device__ __forceinline__ double boxdiff(const double *I, int H, int y1, int y2
     return sum;
 }
 
-// Wave-wide sum in the fixed butterfly order a[l] += a[l ^ m], m = 1, 2, 4, 8, 16, 32 (restated in the CPU
-// oracle, sum_order = 1), without touching the LDS crossbar: the reduction sits on the critical path of every LK
-// iteration, and six dependent ds_bpermute round trips cost ~700 cycles.  m = 1, 2: DPP quad_perm; m = 4, 8:
-// row_half_mirror / row_mirror (the partner group already holds one uniform value, so mirroring == xor);
-// m = 16, 32: the four row sums are read with v_readlane and combined as (R0 + R1) + (R2 + R3) in every lane.
+// Wave-wide sums of the iteration's TWO right-hand-side terms in the fixed butterfly order a[l] += a[l ^ m], m = 32, 16, 1, 2, 4, 8
+// (restated in the CPU oracle, sum_order = 1), without touching the LDS crossbar: the reduction sits on the critical path of every LK
+// iteration, and six dependent ds_bpermute round trips cost ~700 cycles.  m = 32: v_permlane32_swap (gfx950) exchanges the upper half
+// of ay with the lower half of ax, so ONE add leaves ay(l) + ay(l + 32) in the lanes below 32 and ax(l - 32) + ax(l) in the lanes above
+// -- from here on the two sums share every instruction; m = 16: v_permlane16_swap of the value with itself gives the rows {0, 0, 2, 2}
+// and {1, 1, 3, 3}; m = 1, 2: DPP quad_perm; m = 4, 8: row_half_mirror / row_mirror (the partner group already holds one uniform value,
+// so mirroring == xor).  Every lane of a half ends with the same bits (a + b == b + a); lanes 0 and 32 are read.  24 instructions for
+// both sums (two separate butterflies with v_readlane row sums: 46).
 template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -90,16 +93,19 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
-__device__ __forceinline__ double wave_sum(double v)
+__device__ __forceinline__ void wave_sum2(double &ay, double &ax)
 {
+    const auto l32 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(ay), (unsigned)__double2loint(ax), false, false);
+    const auto h32 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(ay), (unsigned)__double2hiint(ax), false, false);
+    double v = __hiloint2double((int)h32[0], (int)l32[0]) + __hiloint2double((int)h32[1], (int)l32[1]);      // l ^ 32
+    const auto l16 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto h16 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    v = __hiloint2double((int)h16[0], (int)l16[0]) + __hiloint2double((int)h16[1], (int)l16[1]);             // l ^ 16
     v = v + dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]  : l ^ 1
     v = v + dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]  : l ^ 2
     v = v + dpp_f64<0x141>(v);     // row_half_mirror      : l ^ 4 (quads are uniform)
     v = v + dpp_f64<0x140>(v);     // row_mirror           : l ^ 8 (octets are uniform)
-    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
-    const int row = (threadIdx.x & 63) >> 4;
-    const double a = (row & 1) ? r1 + r0 : r0 + r1, b = (row & 1) ? r3 + r2 : r2 + r3;   // own row first (commutative: same bits)
-    return (row & 2) ? b + a : a + b;
+    ay = readlane_f64(v, 0); ax = readlane_f64(v, 32);
 }
 
 // compute_spatial_gradient + svd2x2 + pinv2x2 (utils.jl:5-45)
@@ -399,7 +405,7 @@ __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView
             }
         }
         LKT(3);
-        ay = wave_sum(ay); ax = wave_sum(ax);
+        wave_sum2(ay, ax);
         const double fl0 = Gi[0] * ay + Gi[2] * ax, fl1 = Gi[1] * ay + Gi[3] * ax;
         if (fabs(fl0) < eps && fabs(fl1) < eps) break;
         c0 += fl0; c1 += fl1;
