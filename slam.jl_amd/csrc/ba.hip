@@ -992,9 +992,11 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     // The twisted launch has NINE workgroups: the two sides are workgroups 0 and 8 -- workgroups go to the eight XCDs round-robin, so
     // these two share an L2 and their two hand-overs (the trailing window, the middle dp) are L2 round trips instead of trips through
     // the fabric; workgroups 1-7 leave at once.
+    // (a launch of TWO workgroups -- SLAMHIP_TWIST_SPREAD=1, a test knob -- puts the sides on neighbouring XCDs: the hand-overs then take
+    //  the agent-scope path below)
     const bool tw = gridDim.x > 1;
-    if (tw && (blockIdx.x & 7) != 0) { if (B.trace && threadIdx.x == 0) B.trace[80 + blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 20); return; }
-    const int side = tw ? (int)(blockIdx.x >> 3) : 0;
+    if (gridDim.x == 9 && (blockIdx.x & 7) != 0) { if (B.trace && threadIdx.x == 0) B.trace[80 + blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 20); return; }
+    const int side = gridDim.x == 9 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     // side 0 also eliminates the middle, after side 1's window has arrived: side 1 gets fewer columns so that it is there in time
     int ownA = (nbT - hb) / 2 + B.shift; if (ownA > nbT - hb - 4) ownA = nbT - hb - 4;
     const int ownB = nbT - hb - ownA;
@@ -2250,7 +2252,8 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
         static bool attr_set[64] = {};
         const int dv = ctx->device & 63;
         if (!attr_set[dv]) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set[dv] = true; }
-        hipLaunchKernelGGL(k_band_solve, dim3(twist ? 9 : 1), dim3(BS_T), band_lds, st, d, B, use_state);
+        static const bool twist_spread = getenv("SLAMHIP_TWIST_SPREAD") != nullptr;     // (test knob: the two sides on different XCDs)
+        hipLaunchKernelGGL(k_band_solve, dim3(twist ? (twist_spread ? 2 : 9) : 1), dim3(BS_T), band_lds, st, d, B, use_state);
     } else {
         CholArgs C; C.A = d.Swork; C.Lf = ba->lfac; C.n = n; C.ld = n + 1; C.fail = ba->chol_flag;
         const size_t tot = (size_t)(n + 1) * n;

@@ -120,3 +120,37 @@ def test_local_ba_vs_reference_style_lsmr_20kf(slam, orc, syn):
     assert (cache.outliers != ol0).mean() < 0.01
     assert np.abs(cache.theta[:120] - th0[:120]).max() < 1e-3
     _check_recall(cache.outliers, s)
+
+
+def test_twisted_solve_with_the_sides_on_different_xcds():
+    """The banded solve's two workgroups normally share an XCD (launch of nine, sides = workgroups 0 and 8) and hand data to each
+    other through the common L2 without agent-scope fences; each side checks the other's XCC_ID and falls back to the agent-scope
+    path otherwise.  SLAMHIP_TWIST_SPREAD=1 launches the two sides as neighbouring workgroups (different XCDs): the fallback must give
+    bit-identical parameters (the env is read once per process: a child process each)."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, hashlib, numpy as np
+        sys.path.insert(0, %r)
+        import slam_jl_amd as slam
+        from slam_jl_amd import synthetic as syn
+        out = []
+        for P, M in ((50, 10000), (31, 1500)):
+            s = syn.ba_scene(P=P, M=M, seed=3)
+            for _ in range(3):
+                c = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+                slam.bundle_adjustment_(c, s["cam"])
+                out.append(hashlib.sha256(c.theta.tobytes() + c.outliers.tobytes()).hexdigest() + repr(c.stats["ssr_final"]))
+        print("RESULT", *out)
+    """ % root)
+    res = {}
+    for spread in (False, True):
+        env = dict(os.environ)
+        env.pop("SLAMHIP_TWIST_SPREAD", None)
+        if spread: env["SLAMHIP_TWIST_SPREAD"] = "1"
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[spread] = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0]
+    assert res[False] == res[True]
+    toks = res[False].split()[1:]
+    assert toks[0] == toks[1] == toks[2] and toks[3] == toks[4] == toks[5]      # and each repeat gives the same bits
