@@ -135,6 +135,37 @@ __device__ __forceinline__ void obs_eval(const double *pose, const double *X, do
 }
 
 // deterministic block reduction (256 threads): wave butterfly, then wave order
+// workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the outstanding global loads / stores: after a store
+// that is a full memory round trip (k_schur_groups: its "barrier" phases were mostly the Jacobian / partial stores being acknowledged).
+// For barriers that only hand LDS data (or nothing) between the threads of a workgroup.
+__device__ __forceinline__ void lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ double block_sum_lds(double v, double *sh)       // block_sum with LDS-only barriers
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    lds_sync();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    lds_sync();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += sh[w];
+    return t;
+}
+__device__ __forceinline__ double block_max_lds(double v, double *sh)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+    lds_sync();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    lds_sync();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) t = fmax(t, sh[w]);
+    return t;
+}
 __device__ __forceinline__ double block_sum(double v, double *sh)
 {
 #pragma unroll
@@ -437,7 +468,7 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
         while (r >= hbw - a) { r -= hbw - a; a++; }
         s_ab[2 * w] = (unsigned char)a; s_ab[2 * w + 1] = (unsigned char)(a + r);
     }
-    __syncthreads();
+    lds_sync();
     SG_CLK(0);
     // ---- phase 0
     double r2[2] = {0.0, 0.0}, Jp[12], Jl[6];
@@ -475,7 +506,7 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
         for (int k = 0; k < 3; k++) v[6 + k] = Jl[k] * r2[0] + Jl[3 + k] * r2[1];
     }
     SG_CLK(1);
-    __syncthreads();
+    lds_sync();
     SG_CLK(2);
     // ---- phase 1
     if (tid < npts) {
@@ -497,7 +528,7 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
 #pragma unroll
         for (int c = 0; c < 3; c++) { d.bl[(size_t)c * M + j] = V[6 + c]; s_pt[tid * 10 + 6 + c] = V[6 + c]; }
     }
-    __syncthreads();
+    lds_sync();
     SG_CLK(3);
     // ---- phase 2
     if (tid < nobs) {
@@ -520,7 +551,7 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
 #pragma unroll
         for (int k = 0; k < 12; k++) s_Jp[tid * 12 + k] = Jp[k];
     }
-    __syncthreads();
+    lds_sync();
     SG_CLK(4);
     double *out = d.wpart + (size_t)blockIdx.x * d.wstride;
     // ---- phase 3: the window blocks.  A wave (a run of LPS lanes) is one point subset: its lanes are the blocks, all on the same
@@ -570,7 +601,7 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
                 ex[6] += s_g[ta * 6 + r2];
             }
         SG_CLK(8);
-        __syncthreads();                                           // every read of W / Jp / g / V^-1 / the slots is done: the region becomes the fold buffer
+        lds_sync();                                           // every read of W / Jp / g / V^-1 / the slots is done: the region becomes the fold buffer
         SG_CLK(9);
         double *fold = sg_lds, *efold = sg_lds + (size_t)(NS - 1) * nwin * 36;
         if (sub >= 1) {
@@ -580,7 +611,7 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
                 for (int k = 0; k < 7; k++) efold[((size_t)(sub - 1) * hbw * 6 + w) * 7 + k] = ex[k];
             }
         }
-        __syncthreads();
+        lds_sync();
         if (sub == 0) {
             if (live)
                 for (int q = 0; q < NS - 1; q++) {
@@ -600,7 +631,7 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
                 out[nwin * 36 + a2 * 12 + r2] = ex[6]; out[nwin * 36 + a2 * 12 + 6 + r2] = ud;
             }
         }
-        __syncthreads();
+        lds_sync();
         if (live && sub == 0) {
             if (a == b) {
 #pragma unroll
@@ -610,7 +641,7 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
         }
     }
     SG_CLK(5);
-    const double t = block_sum(r2[0] * r2[0] + r2[1] * r2[1], s_red);
+    const double t = block_sum_lds(r2[0] * r2[0] + r2[1] * r2[1], s_red);
     if (tid == 0) d.part[blockIdx.x] = t;
     SG_CLK(6);
     SG_DUMP();
@@ -1790,7 +1821,7 @@ __global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outl
     const int4 G = d.grp[blockIdx.x];
     const int k0 = G.x, o0 = G.y, npts = G.z >> 16, nobs = G.w;
     for (int a = tid; a < n; a += SG_T) s_dp[a] = d.dp[a];
-    __syncthreads();
+    lds_sync();
     double mx = 0.0;
     if (blockIdx.x == 0)
         for (int a = tid; a < n; a += SG_T) { const double v = s_dp[a]; d.pose_t[a] = d.pose[a] - v; mx = fmax(mx, fabs(v)); }
@@ -1807,7 +1838,7 @@ __global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outl
 #pragma unroll
         for (int k = 0; k < 3; k++) s_u[tid * 3 + k] = jl[k] * a + jl[3 + k] * b;
     }
-    __syncthreads();
+    lds_sync();
     if (tid < npts) {
         const int kk = k0 + tid, j = d.pt_id[kk];
         double bl[3] = {d.bl[j], d.bl[(size_t)M + j], d.bl[(size_t)2 * M + j]};
@@ -1829,7 +1860,7 @@ __global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outl
         s_dl[tid * 6 + 3] = X0; s_dl[tid * 6 + 4] = X1; s_dl[tid * 6 + 5] = X2;
         mx = fmax(mx, fmax(fabs(l0), fmax(fabs(l1), fabs(l2))));
     }
-    __syncthreads();
+    lds_sync();
     double st = 0.0, sp = 0.0;
     if (tid < nobs) {
         double r[2] = {0.0, 0.0};
@@ -1847,9 +1878,9 @@ __global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outl
         st = r[0] * r[0] + r[1] * r[1];
         sp = a * a + b * b;
     }
-    const double t1 = block_sum(st, s_red);
-    const double t2 = block_sum(sp, s_red);
-    const double t3 = block_max(mx, s_red);
+    const double t1 = block_sum_lds(st, s_red);
+    const double t2 = block_sum_lds(sp, s_red);
+    const double t3 = block_max_lds(mx, s_red);
     if (tid == 0) { d.part[blockIdx.x] = t3; d.part[d.ngrp + 2 * blockIdx.x] = t1; d.part[d.ngrp + 2 * blockIdx.x + 1] = t2; }
 }
 
