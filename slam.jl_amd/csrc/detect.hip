@@ -32,7 +32,25 @@ struct DetectArgs {
     // keypoint-set launch (slam_kpset_detect): stream z's current keypoints are cur[2 * z * cur_stride ..], cur_cnt[z] of them
     // (device-side count), k follows from it
     const int *cur_cnt; int cur_stride, max_points;
+    // ImageDraw's disk test ((dy/r)^2 + (dx/r)^2 < 1, f64) as a table: lim[|dy|] = largest |dx| inside the disk (-1: none), formed once
+    // on the host with the per-pixel test's operations (det_disk_table; every cell used to rebuild it: ~3 k of a cell's 39 k cycles)
+    signed char lim[DET_MAXR + 1];
 };
+static void det_disk_table(DetectArgs &A)
+{
+    const int r = A.radius;
+    for (int dy = 0; dy <= DET_MAXR; dy++) A.lim[dy] = -1;
+    for (int dy = 0; dy <= r && dy <= DET_MAXR; dy++) {
+        const volatile double a = (double)dy / (double)r;
+        int lim = -1;
+        for (int dx = 0; dx <= r; dx++) {
+            const volatile double b = (double)dx / (double)r;
+            const volatile double aa = a * a, bb = b * b;       // (separately rounded products: no contraction)
+            if (aa + bb < 1) lim = dx; else break;
+        }
+        A.lim[dy] = (signed char)lim;
+    }
+}
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -229,15 +247,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         // disk (-1: none).  Same operations on the same operands as the per-pixel test, evaluated once per cell
         // instead of two f64 divisions per (pixel, keypoint) pair.
         // (the r + 1 quotients d / r are formed once, one per thread, instead of r + 1 divisions in sequence by every table thread)
-        double *s_q = (double *)s_cand;                       // s_cand is filled after the table is complete
-        if (tid <= r) s_q[tid] = (double)tid / (double)r;
-        __syncthreads();
-        if (tid <= r) {
-            const double a = s_q[tid];
-            int lim = -1;
-            for (int dx = 0; dx <= r; dx++) { const double b = s_q[dx]; if (a * a + b * b < 1) lim = dx; else break; }
-            s_lim[tid] = lim;
-        }
+        if (tid <= r) s_lim[tid] = ((const signed char *)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(DetectArgs, lim) + tid];      // (a lane-indexed read of the by-value struct would copy all of it to scratch)
         __syncthreads();
         // candidate keypoints: disk (+halo) touches the clamped tile region
         const int ylo = clampi(y0 - hw, 0, H - 1) + 1, yhi = clampi(y0 + h - 1 + hw, 0, H - 1) + 1; // 1-based
@@ -509,7 +519,7 @@ int slam_detect_device(slam_ctx *ctx, const double *img_dev, int H, int W, int p
     const int n_detect = max_points - n_cur;
     const int k = (n_detect + n_cells - 1) / n_cells;             // ceil(Int, n_detect / n_cells)
     DetectArgs A;
-    A.img = img_dev; A.H = H; A.W = W; A.pitch = pitch; A.n_cur = n_cur; A.radius = radius;
+    A.img = img_dev; A.H = H; A.W = W; A.pitch = pitch; A.n_cur = n_cur; A.radius = radius; det_disk_table(A);
     A.grid_rows = grid_rows; A.grid_cols = grid_cols; A.cs = cell_size; A.k = k; A.min_response = min_response;
     A.ntaps = 0; A.cur_off = nullptr; A.k_s = nullptr; A.zs = 0; A.kmax = k; A.cur_cnt = nullptr; A.cur_stride = 0; A.max_points = max_points;
     if (n_cur > 0 && sigma_mask != 0) {
@@ -608,7 +618,7 @@ extern "C" int slam_detect_batch(slam_ctx *ctx, const slam_pyr *pyr0, int S, con
     if (kmax == 0) return SLAM_OK;
     DetectArgs A;
     A.img = pyr0->plane(0, 0); A.H = pyr0->H[0]; A.W = pyr0->W[0]; A.pitch = pyr0->P[0]; A.zs = pyr0->zstride;
-    A.n_cur = 0; A.radius = radius; A.grid_rows = grid_rows; A.grid_cols = grid_cols; A.cs = cell_size; A.k = 0; A.kmax = kmax;
+    A.n_cur = 0; A.radius = radius; det_disk_table(A); A.grid_rows = grid_rows; A.grid_cols = grid_cols; A.cs = cell_size; A.k = 0; A.kmax = kmax;
     A.min_response = min_response; A.ntaps = 0; A.cur_cnt = nullptr; A.cur_stride = 0; A.max_points = max_points;
     if (sigma_mask != 0) {
         ARG_TRY(ctx, 4 * (int)std::ceil(sigma_mask) + 1 <= DET_MAXTAPS);
@@ -723,7 +733,7 @@ extern "C" int slam_kpset_detect(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *
     ARG_TRY(ctx, ks->cap >= max_points + n_cells);                  // a stream below max_points may receive up to n_cells * k > max_points - n_cur keypoints
     DetectArgs A;
     A.img = pyr0->plane(0, 0); A.H = pyr0->H[0]; A.W = pyr0->W[0]; A.pitch = pyr0->P[0]; A.zs = pyr0->zstride;
-    A.n_cur = 0; A.radius = radius; A.grid_rows = grid_rows; A.grid_cols = grid_cols; A.cs = cell_size; A.k = 0; A.kmax = kmax;
+    A.n_cur = 0; A.radius = radius; det_disk_table(A); A.grid_rows = grid_rows; A.grid_cols = grid_cols; A.cs = cell_size; A.k = 0; A.kmax = kmax;
     A.min_response = min_response; A.ntaps = 0; A.cur_off = nullptr; A.k_s = nullptr;
     A.cur = ks->yx; A.cur_cnt = ks->count; A.cur_stride = ks->cap; A.max_points = max_points;
     if (sigma_mask != 0) {
