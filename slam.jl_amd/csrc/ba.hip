@@ -18,7 +18,8 @@
 //   k_band_solve     damped banded Cholesky of S in one workgroup, dp (wide systems: the tiled k_chol_* chain)
 //   k_update_groups  per group: dl = V^-1 (bl - W' dp), trial parameters, trial and predicted residuals
 //   k_control        rho, accept/reject, radius update, convergence (LeastSquaresOptim's rules)
-//   k_commit         accept: parameters/residuals <- trial
+//   (commit)         accept: the committed and the trial parameter buffers swap roles (LMState::cur, flipped by lm_decide); k_commit is
+//                    the host-paced protocol's flip
 // Fallback for systems the groups do not cover (block half-bandwidth > 20, a point with > 448 observations):
 //   k_linearize, k_points, k_obs_factors, k_blocks (pair lists sorted by pose block), k_backsub, k_trial.
 // Observations are re-ordered by map point at upload (map points by first free observer) so a point's observations
@@ -41,7 +42,9 @@
 struct LMState {
     double delta, decrease_factor, ssr, trial_ssr, pred_ssr, maxdx;
     double ssr_init, ssr_pass1, ssr_final;
-    int converged, accept, iters, n_outliers, chol_fail, iters_pass1, iters_pass2, pad;
+    int converged, accept, iters, n_outliers, chol_fail, iters_pass1, iters_pass2;
+    int cur;                     // which of the two parameter buffers is the committed one: an accepted step SWAPS them (lm_decide) -- no copy
+                                 // kernel per iteration (k_commit cost the iteration a launch: ~5 us of its 127)
 };
 
 
@@ -68,6 +71,14 @@ struct BADev {
     double *part;                // reduction partials
     LMState *st;
 };
+// the committed parameters and the trial ones: d.pose / d.pts hold the committed set while st->cur == 0, d.pose_t / d.pts_t while it is 1
+struct ParamBufs { double *pose, *pts, *pose_t, *pts_t; };
+__device__ __forceinline__ ParamBufs param_bufs(const BADev &d)
+{
+    const bool sw = d.st->cur != 0;
+    return ParamBufs{sw ? d.pose_t : d.pose, sw ? d.pts_t : d.pts, sw ? d.pose : d.pose_t, sw ? d.pts : d.pts_t};
+}
+
 
 struct slam_ba {
     int device = 0;
@@ -209,6 +220,7 @@ template <int N> __device__ __forceinline__ void st_rec(double *p, const double 
 
 __global__ __launch_bounds__(256) void k_linearize(BADev d, int ignore_outliers, int respect_done)
 {
+    const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
     __shared__ double sh[4];
     if (respect_done && d.st->converged) return;
     const int i = blockIdx.x * 256 + threadIdx.x, O = d.O;
@@ -223,10 +235,10 @@ __global__ __launch_bounds__(256) void k_linearize(BADev d, int ignore_outliers,
 #pragma unroll
         for (int k = 0; k < 6; k++) Jl[k] = 0.0;
         if (active) {
-            const double X[3] = {d.pts[3 * j], d.pts[3 * j + 1], d.pts[3 * j + 2]};
+            const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
             double pose[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) pose[k] = d.pose[6 * p + k];
+            for (int k = 0; k < 6; k++) pose[k] = pb.pose[6 * p + k];
             obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r, Jp, Jl, nullptr);
             if (!hp) {
 #pragma unroll
@@ -447,6 +459,7 @@ static bool sg_fold_fits(int whb)
 
 __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta_host, int ignore_outliers, int use_state)
 {
+    const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
     extern __shared__ __attribute__((aligned(16))) double sg_lds[];
     SG_CLK_DECL;
     if (use_state && d.st->converged) return;
@@ -484,10 +497,10 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
         const bool active = !(ignore_outliers && d.outl[i]);
         const bool hp = active && !d.pconst[p];
         if (active) {
-            const double X[3] = {d.pts[3 * j], d.pts[3 * j + 1], d.pts[3 * j + 2]};
+            const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
             double pose[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) pose[k] = d.pose[6 * p + k];
+            for (int k = 0; k < 6; k++) pose[k] = pb.pose[6 * p + k];
             obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r2, Jp, Jl, nullptr);
             if (!hp) {
 #pragma unroll
@@ -1745,6 +1758,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
 
 __global__ __launch_bounds__(256) void k_backsub(BADev d, int use_state)
 {
+    const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
     __shared__ double sh[4];
     if (use_state && d.st->converged) return;
     const int kk = blockIdx.x * 256 + threadIdx.x, M = d.M;
@@ -1768,16 +1782,17 @@ __global__ __launch_bounds__(256) void k_backsub(BADev d, int use_state)
         const double l1 = Vi[1] * bl[0] + Vi[3] * bl[1] + Vi[4] * bl[2];
         const double l2 = Vi[2] * bl[0] + Vi[4] * bl[1] + Vi[5] * bl[2];
         d.dl[3 * j] = l0; d.dl[3 * j + 1] = l1; d.dl[3 * j + 2] = l2;
-        d.pts_t[3 * j] = d.pts[3 * j] - l0; d.pts_t[3 * j + 1] = d.pts[3 * j + 1] - l1; d.pts_t[3 * j + 2] = d.pts[3 * j + 2] - l2;
+        pb.pts_t[3 * j] = pb.pts[3 * j] - l0; pb.pts_t[3 * j + 1] = pb.pts[3 * j + 1] - l1; pb.pts_t[3 * j + 2] = pb.pts[3 * j + 2] - l2;
         mx = fmax(fabs(l0), fmax(fabs(l1), fabs(l2)));
     }
-    if (kk < d.n) { d.pose_t[kk] = d.pose[kk] - d.dp[kk]; mx = fmax(mx, fabs(d.dp[kk])); }
+    if (kk < d.n) { pb.pose_t[kk] = pb.pose[kk] - d.dp[kk]; mx = fmax(mx, fabs(d.dp[kk])); }
     const double t = block_max(mx, sh);
     if (threadIdx.x == 0) d.part[blockIdx.x] = t;
 }
 
 __global__ __launch_bounds__(256) void k_trial(BADev d, int ignore_outliers, int use_state, int nb_pts)
 {
+    const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
     __shared__ double sh[4];
     if (use_state && d.st->converged) return;
     const int i = blockIdx.x * 256 + threadIdx.x, O = d.O;
@@ -1786,10 +1801,10 @@ __global__ __launch_bounds__(256) void k_trial(BADev d, int ignore_outliers, int
         const int p = d.opose[i], j = d.opoint[i];
         double r[2] = {0.0, 0.0};
         if (!(ignore_outliers && d.outl[i])) {
-            const double X[3] = {d.pts_t[3 * j], d.pts_t[3 * j + 1], d.pts_t[3 * j + 2]};
+            const double X[3] = {pb.pts_t[3 * j], pb.pts_t[3 * j + 1], pb.pts_t[3 * j + 2]};
             double pose[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) pose[k] = d.pose_t[6 * p + k];
+            for (int k = 0; k < 6; k++) pose[k] = pb.pose_t[6 * p + k];
             obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, nullptr);
         }
         double a = 0.0, b = 0.0;
@@ -1812,6 +1827,7 @@ __global__ __launch_bounds__(256) void k_trial(BADev d, int ignore_outliers, int
 // and predicted residual.  Partials: part[g] = max |dx|, part[ngrp + 2 g] = trial cost, part[ngrp + 2 g + 1] = predicted cost.
 __global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outliers, int use_state)
 {
+    const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
     __shared__ double s_dp[SOLVE_MAX_N];
     __shared__ double s_u[SG_OB * 3];
     __shared__ double s_dl[SG_SB * 6];                      // dl (3), trial point (3)
@@ -1824,7 +1840,7 @@ __global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outl
     lds_sync();
     double mx = 0.0;
     if (blockIdx.x == 0)
-        for (int a = tid; a < n; a += SG_T) { const double v = s_dp[a]; d.pose_t[a] = d.pose[a] - v; mx = fmax(mx, fabs(v)); }
+        for (int a = tid; a < n; a += SG_T) { const double v = s_dp[a]; pb.pose_t[a] = pb.pose[a] - v; mx = fmax(mx, fabs(v)); }
     const int i = o0 + tid;
     int p = 0, pl = 0;
     double jp[12], jl[6], ff[2] = {0.0, 0.0}, a = 0.0, b = 0.0;
@@ -1853,9 +1869,9 @@ __global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outl
         const double l0 = Vi[0] * bl[0] + Vi[1] * bl[1] + Vi[2] * bl[2];
         const double l1 = Vi[1] * bl[0] + Vi[3] * bl[1] + Vi[4] * bl[2];
         const double l2 = Vi[2] * bl[0] + Vi[4] * bl[1] + Vi[5] * bl[2];
-        const double X0 = d.pts[3 * j] - l0, X1 = d.pts[3 * j + 1] - l1, X2 = d.pts[3 * j + 2] - l2;
+        const double X0 = pb.pts[3 * j] - l0, X1 = pb.pts[3 * j + 1] - l1, X2 = pb.pts[3 * j + 2] - l2;
         d.dl[3 * j] = l0; d.dl[3 * j + 1] = l1; d.dl[3 * j + 2] = l2;
-        d.pts_t[3 * j] = X0; d.pts_t[3 * j + 1] = X1; d.pts_t[3 * j + 2] = X2;
+        pb.pts_t[3 * j] = X0; pb.pts_t[3 * j + 1] = X1; pb.pts_t[3 * j + 2] = X2;
         s_dl[tid * 6] = l0; s_dl[tid * 6 + 1] = l1; s_dl[tid * 6 + 2] = l2;
         s_dl[tid * 6 + 3] = X0; s_dl[tid * 6 + 4] = X1; s_dl[tid * 6 + 5] = X2;
         mx = fmax(mx, fmax(fabs(l0), fmax(fabs(l1), fabs(l2))));
@@ -1869,7 +1885,7 @@ __global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outl
             const double X[3] = {dl[3], dl[4], dl[5]};
             double pose[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) pose[k] = d.pose[6 * p + k] - s_dp[6 * p + k];
+            for (int k = 0; k < 6; k++) pose[k] = pb.pose[6 * p + k] - s_dp[6 * p + k];
             obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, nullptr);
         }
 #pragma unroll
@@ -1916,6 +1932,7 @@ __device__ __forceinline__ void lm_decide(LMState *s, double t, double p, double
         s->delta = fmin(s->delta / fmax(1.0 / 3.0, 1.0 - u * u * u), LM_MAX_DELTA);
         s->decrease_factor = 2.0;
         s->accept = 1;
+        s->cur ^= 1;                                         // the trial parameters become the committed ones
         s->converged = x_conv || f_conv;
     } else {
         s->delta = fmax(s->delta / s->decrease_factor, LM_MIN_DELTA);
@@ -1967,16 +1984,11 @@ __global__ void k_lm_start(BADev d, const double *ssr_slot, int first_pass)
     s->delta = LM_DELTA0; s->decrease_factor = 2.0; s->converged = 0; s->accept = 0; s->iters = 0;
 }
 
-// note: must run even when `converged` was set by THIS iteration's k_control
-__global__ __launch_bounds__(256) void k_commit(BADev d, int accept_host, int use_state, int iter_tag)
+// host-paced protocol (slam_ba_commit): the host has decided -- an accepted step swaps the two parameter buffers.  (The device-paced
+// paths swap inside lm_decide: no launch at all.)
+__global__ void k_commit(BADev d, int accept_host)
 {
-    const int accept = use_state ? d.st->accept : accept_host;
-    if (use_state && d.st->iters != iter_tag) return;     // this iteration was skipped (already converged)
-    if (!accept) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < d.n) d.pose[i] = d.pose_t[i];
-    if (i < 3 * d.M) d.pts[i] = d.pts_t[i];
-    // (the residuals are not copied: every build re-evaluates them at the committed parameters before anything reads d.f)
+    if (threadIdx.x == 0 && blockIdx.x == 0 && accept_host) d.st->cur ^= 1;
 }
 
 __global__ void k_lm_reset(BADev d, int pass)
@@ -1992,15 +2004,16 @@ __global__ void k_lm_reset(BADev d, int pass)
 // _ba_detect_outliers!, bundle_adjustment.jl:90-111
 __global__ __launch_bounds__(256) void k_outliers(BADev d, double repr_eps, double depth_eps)
 {
+    const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
     __shared__ double sh[4];
     const int i = blockIdx.x * 256 + threadIdx.x, O = d.O;
     double c = 0.0;
     if (i < O) {
         const int p = d.opose[i], j = d.opoint[i];
-        const double X[3] = {d.pts[3 * j], d.pts[3 * j + 1], d.pts[3 * j + 2]};
+        const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
         double pose[6], r[2], z;
 #pragma unroll
-        for (int k = 0; k < 6; k++) pose[k] = d.pose[6 * p + k];
+        for (int k = 0; k < 6; k++) pose[k] = pb.pose[6 * p + k];
         obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, &z);
         const bool out = z < depth_eps || (r[0] * r[0] + r[1] * r[1]) > repr_eps;
         d.outl[i] = out ? 1 : 0;
@@ -2311,9 +2324,9 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
 
 static int ba_enqueue_commit(slam_ctx *ctx, slam_ba *ba, int accept, int use_state, int iter_tag)
 {
-    BADev d = ba->d;
-    const int m = std::max(d.n, 3 * d.M);
-    hipLaunchKernelGGL(k_commit, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, d, accept, use_state, iter_tag);
+    (void)iter_tag;
+    if (use_state) return SLAM_OK;                           // device-paced: lm_decide has swapped the buffers already
+    hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, ctx->stream, ba->d, accept);
     return SLAM_OK;
 }
 
@@ -2459,8 +2472,11 @@ int slam_ba_download(slam_ctx *ctx, slam_ba *ba, double *theta, uint8_t *outlier
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const BADev &d = ba->d;
     if (theta) {
-        HIP_TRY(ctx, hipMemcpyAsync(theta, d.pose, (size_t)d.n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (d.M > 0) HIP_TRY(ctx, hipMemcpyAsync(theta + d.n, d.pts, (size_t)3 * d.M * 8, hipMemcpyDeviceToHost, ctx->stream));
+        int cur = 0;                                         // which buffer pair holds the committed parameters (LMState::cur)
+        HIP_TRY(ctx, hipMemcpyAsync(&cur, &d.st->cur, sizeof cur, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(theta, cur ? d.pose_t : d.pose, (size_t)d.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (d.M > 0) HIP_TRY(ctx, hipMemcpyAsync(theta + d.n, cur ? d.pts_t : d.pts, (size_t)3 * d.M * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     std::vector<uint8_t> tmp;
     if (outliers && d.O > 0) { tmp.resize(d.O); HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), d.outl, (size_t)d.O, hipMemcpyDeviceToHost, ctx->stream)); }
