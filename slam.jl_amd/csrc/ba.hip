@@ -26,6 +26,7 @@
 // and a group's points are contiguous.
 #include "common.hpp"
 #include <algorithm>
+#include <type_traits>
 #include <chrono>
 #include <cmath>
 
@@ -1108,11 +1109,14 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                 s_kind[q] = 2; s_i0[q] = 0; s_g[q] = 6 * gi(0) + c; s_st[q] = 6 * (gi(1) - gi(0));
                 s_l[q] = (int)(rhs - bs_sm) + c; s_ls[q] = 6;
             }
+            auto request = [&](auto R) {                          // rows 0 .. R - 1 (straight-line: every load goes out before anything waits)
 #pragma unroll
-            for (int i = 0; i <= BS_MAXHB; i++) {
-                wv[q][i] = 0.0;
-                if (i >= s_i0[q] && i < nrow0) wv[q][i] = (s_kind[q] == 1 ? B.S : B.g)[s_g[q] + i * s_st[q]];
-            }
+                for (int i = 0; i < decltype(R)::value; i++) {
+                    wv[q][i] = 0.0;
+                    if (i >= s_i0[q] && i < nrow0) wv[q][i] = (s_kind[q] == 1 ? B.S : B.g)[s_g[q] + i * s_st[q]];
+                }
+            };
+            if (hb1 <= 10) request(std::integral_constant<int, 10>()); else request(std::integral_constant<int, BS_MAXHB + 1>());
         }
     if (B.trace && side == 0 && tid == 0) B.trace[104] = clock64() - tr_in;
     // Rows i > hb all have hb + 1 blocks.  The prefetch lanes (waves 3 and 7) own fixed elements of such a row; the global index of an
@@ -1191,10 +1195,14 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
         __syncthreads();
         if (B.trace && side == 0 && tid == 0) B.trace[107] = clock64() - tr_in;
 #pragma unroll
-        for (int q = 0; q < NS; q++)
+        for (int q = 0; q < NS; q++) {
+            auto place = [&](auto R) {                             // ring row i, ring column i - hb + jb (no wrap inside the first window)
 #pragma unroll
-            for (int i = 0; i <= BS_MAXHB; i++)                    // ring row i, ring column i - hb + jb (no wrap inside the first window)
-                if (i >= s_i0[q] && i < nrow0) bs_sm[s_l[q] + i * s_ls[q]] = s_dm[q] >= 0 ? wv[q][i] + damp[6 * i + s_dm[q]] : wv[q][i];
+                for (int i = 0; i < decltype(R)::value; i++)
+                    if (i >= s_i0[q] && i < nrow0) bs_sm[s_l[q] + i * s_ls[q]] = s_dm[q] >= 0 ? wv[q][i] + damp[6 * i + s_dm[q]] : wv[q][i];
+            };
+            if (hb1 <= 10) place(std::integral_constant<int, 10>()); else place(std::integral_constant<int, BS_MAXHB + 1>());
+        }
     __syncthreads();
     bool bad = false;
     long long tr0 = B.trace ? clock64() : 0, trT = tr0, trA = 0, trB = 0, trC = 0, trD = 0, trW = 0;
