@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     if (use_state && d.st->converged) return;
     extern __shared__ __attribute__((aligned(16))) double bs_sm[];
     __shared__ int s_bad, s_step;
-    // Twisted factorisation (grid of two workgroups): side 0 eliminates the poses 0 .. own - 1 top-down, side 1 the poses P - 1 ..
+    // Twisted factorisation (two workgroups at work): side 0 eliminates the poses 0 .. own - 1 top-down, side 1 the poses P - 1 ..
     // P - own' bottom-up (the same algorithm on the block-reversed matrix: pose pi(i) = P - 1 - i) -- at the same time, on two CUs.
     // The hb poses in the middle receive the Schur updates of both: side 1 hands its trailing window over through global memory
     // (B.xchg, flag = launch epoch), side 0 adds it to its own (M = ringA + ringB - S), factors the middle and back-substitutes it,
@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     double *x = bs_sm;                                   // [n]: y, then dp
     double *damp = x + n;                                // [n]: LM damping of the diagonal (k_chol_prepare)
     double *chat = damp + n;                             // [n]: L_kk^-T y_k (narrow bands)
-    double *LiAll = chat + n;                            // [nb][36]: L_kk^-1 of every block column (the back-substitution reads them again)
+    double *LiAll = chat + n;                            // [nb][36]: L_kk of every block column (the factor wave's; 1 / L_jj in the upper triangle), turned into L_kk^-1 for the back-substitution
     double *Wn = LiAll + (size_t)nb * 36;                // [hb1][hb1][BS_WS] window ring, blocks row-major 6x6
     double *rhs = Wn + (size_t)hb1 * hb1 * BS_WS;        // [hb1][6]
     double *Lp = rhs + hb1 * 6;                          // [hb1][BS_WS]: Lp[di] = L_{k+di,k}
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     // id takes the agent-scope fence.
     const long long tr_in = B.trace ? clock64() : 0;
     const int myxcc = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15);
-    const int xcc_tag = B.epoch * 32 + 16;
+    const int xcc_tag = (int)(((unsigned)B.epoch << 5) + 16u);       // (unsigned: the epoch counts launches for the life of the solver object)
     if (tw && tid == 0) __hip_atomic_store(B.fail + 3 + side, xcc_tag + myxcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     auto same_xcd = [&]() { return __hip_atomic_load(B.fail + 3 + (1 - side), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xcc_tag + myxcc; };
     if (tid == 0) { s_bad = 0; s_step = 0; }
