@@ -1662,25 +1662,32 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
             if (tid < 64) {
                 // two steps per trip with the roles of the two register sets swapped: the rows / chat entries of the next step are
                 // requested before this step's chain and nothing waits for them until they are used
-                auto load_next = [&](int k, int ksl, double (&gg)[6], double &cc, bool &on) {   // for step k: row c_ of G_{k', k - k'}, chat_k
-                    int j = ksl - s_; if (j < 0) j += hb1;
-                    on = act && j > 0 && k - j >= 0 && k - j < kfac;
-                    const double *gp = Gs + ((size_t)(on ? k - ka : 0) * hb + (on ? j - 1 : 0)) * 36 + (act ? c_ : 0) * 6;
-                    ld_rec<6>(gp, gg);
-                    cc = chat[6 * k + (act ? c_ : 0)];
+                // Per lane (slot s_, row c_) the state moves by one step per request: jn = distance of the lane's slot from the step's slot
+                // (0: the lane holds dp of that step), gp = row c_ of G_{k - jn, jn} in the staged blocks -- (k, jn) -> (k - 1, jn - 1) is
+                // hb + 1 blocks back, and when the slot wraps (jn: 0 -> hb) the address stays --, cp = the step's chat entry.
+                const int k_first = kb - 1;
+                int jn = k_first % hb1 - s_; if (jn < 0) jn += hb1;
+                int go = ((k_first - ka) * hb + jn - 1) * 36 + (act ? c_ : 0) * 6;      // offset in Gs (jn = 0: one block before the step's first; never read)
+                int co = 6 * k_first + (act ? c_ : 0);                                   // offset in chat  (offsets, not pointers: loop-carried pointers lose their address space)
+                auto load_next = [&](int k, double (&gg)[6], double &cc, bool &on, bool &mine) {   // for step k: row c_ of G_{k - jn, jn}, chat_k
+                    mine = act && jn == 0;
+                    on = act && jn > 0 && k - jn >= 0 && k - jn < kfac;
+                    ld_rec<6>(Gs + (on ? go : 0), gg);
+                    cc = chat[co];
+                    go -= jn != 0 ? hb1 * 36 : 0; co -= 6;
+                    jn = jn == 0 ? hb : jn - 1;
                 };
                 const bool same0 = tw && side == 0 && same_xcd();
-                auto step = [&](int k, int ksl, const double (&gg)[6], double cc, bool on) {
-                    const bool mine = act && s_ == ksl;
+                auto step = [&](int k, int ksl6, const double (&gg)[6], double cc, bool on, bool mine) {
                     const double v = mine ? base + cc : base;         // dp_k on the lanes of its slot
                     double dv[6];
 #pragma unroll
                     for (int m = 0; m < 6; m++) {
-                        const int lo = __builtin_amdgcn_readlane(__double2loint(v), ksl * 6 + m);
-                        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), ksl * 6 + m);
+                        const int lo = __builtin_amdgcn_readlane(__double2loint(v), ksl6 + m);
+                        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), ksl6 + m);
                         dv[m] = __hiloint2double(hi, lo);
                     }
-                    const double t = fma(gg[2], dv[2], fma(gg[1], dv[1], gg[0] * dv[0])) + fma(gg[5], dv[5], fma(gg[4], dv[4], gg[3] * dv[3]));
+                    const double t = (fma(gg[1], dv[1], gg[0] * dv[0]) + fma(gg[3], dv[3], gg[2] * dv[2])) + fma(gg[5], dv[5], gg[4] * dv[4]);
                     if (mine) x[6 * k + c_] = v;
                     base = mine ? 0.0 : (on ? base - t : base);
                     if (tw && side == 0 && k >= own) {               // the middle: the other side waits for these
@@ -1692,26 +1699,26 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                     }
                 };
                 // three register sets in rotation: the rows / chat entry of step k - 2 are requested at the start of step k
-                auto dec = [&](int q) { return q == 0 ? hb : q - 1; };
-                int ks = (kb - 1) % hb1;
-                double gA[6], gB[6], gC[6], cA = 0.0, cB = 0.0, cC = 0.0; bool onA = false, onB = false, onC = false;
+                int ks6 = (k_first % hb1) * 6;                       // first lane of the step's slot
+                auto dec6 = [&](int q) { return q == 0 ? hb * 6 : q - 6; };
+                double gA[6], gB[6], gC[6], cA = 0.0, cB = 0.0, cC = 0.0; bool onA = false, onB = false, onC = false, mA = false, mB = false, mC = false;
 #pragma unroll
                 for (int m = 0; m < 6; m++) { gA[m] = 0.0; gB[m] = 0.0; gC[m] = 0.0; }
-                load_next(kb - 1, ks, gA, cA, onA);
-                if (kb - 2 >= ka) load_next(kb - 2, dec(ks), gB, cB, onB);
+                load_next(kb - 1, gA, cA, onA, mA);
+                if (kb - 2 >= ka) load_next(kb - 2, gB, cB, onB, mB);
                 for (int k = kb - 1; k >= ka; k -= 3) {
-                    const int ks1 = dec(ks), ks2 = dec(ks1), ks3 = dec(ks2), ks4 = dec(ks3);
-                    if (k - 2 >= ka) load_next(k - 2, ks2, gC, cC, onC);
-                    step(k, ks, gA, cA, onA);
+                    const int ks1 = dec6(ks6), ks2 = dec6(ks1);
+                    if (k - 2 >= ka) load_next(k - 2, gC, cC, onC, mC);
+                    step(k, ks6, gA, cA, onA, mA);
                     if (k - 1 >= ka) {
-                        if (k - 3 >= ka) load_next(k - 3, ks3, gA, cA, onA);
-                        step(k - 1, ks1, gB, cB, onB);
+                        if (k - 3 >= ka) load_next(k - 3, gA, cA, onA, mA);
+                        step(k - 1, ks1, gB, cB, onB, mB);
                     }
                     if (k - 2 >= ka) {
-                        if (k - 4 >= ka) load_next(k - 4, ks4, gB, cB, onB);
-                        step(k - 2, ks2, gC, cC, onC);
+                        if (k - 4 >= ka) load_next(k - 4, gB, cB, onB, mB);
+                        step(k - 2, ks2, gC, cC, onC, mC);
                     }
-                    ks = ks3;
+                    ks6 = dec6(ks2);
                 }
             }
             if (B.trace && side == 0 && tid == 0) { const long long t_ = clock64(); B.trace[12] = t_ - trb0; trb0 = t_; }
