@@ -755,7 +755,8 @@ __global__ __launch_bounds__(256) void k_chol_prepare(BADev d, const double *Sin
 __device__ __forceinline__ void tile_potrf_inv(double (*t)[CT + 1], double (*inv)[CT + 1], int h, int w, int *fail)
 {
     __shared__ double s_rdiag[CT];
-    __shared__ volatile int s_prog;
+    __shared__ int s_prog;                                 // (relaxed workgroup-scope atomics = ds_read / ds_write_b32; a volatile LDS int is a FLAT access
+                                                           //  with sc0 sc1 and a vmcnt(0) + lgkmcnt(0) drain in front of every poll)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane < CT ? lane : CT - 1;
     if (threadIdx.x == 0) s_prog = 0;
     __syncthreads();
@@ -786,7 +787,7 @@ __device__ __forceinline__ void tile_potrf_inv(double (*t)[CT + 1], double (*inv
             if (active && lane >= j && lane < CT) t[lane][j] = l;
             if (lane == 0) s_rdiag[j] = rd;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            if (lane == 0) s_prog = j + 1;
+            if (lane == 0) __hip_atomic_store(&s_prog, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (bad && lane == 0) *fail = 1;
     } else if (wv == 1) {
@@ -794,7 +795,7 @@ __device__ __forceinline__ void tile_potrf_inv(double (*t)[CT + 1], double (*inv
         double x[CT];
 #pragma unroll
         for (int i = 0; i < CT; i++) {
-            while (s_prog <= i) __builtin_amdgcn_s_sleep(1);
+            while (__hip_atomic_load(&s_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= i) __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             double ps[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
