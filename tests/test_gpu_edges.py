@@ -180,3 +180,13 @@ def test_identical_frames_track_to_zero_motion(slam, texture, orc):
     ro, rs = orc.fb_tracking(ref, ref, kp, sum_order=1)
     assert np.array_equal(st, rs) and st.mean() > 0.8               # the eigenvalue gate may reject a few at coarse levels
     assert np.abs(out[st] - kp[st]).max() < 1e-9
+
+
+def test_ba_wide_bands_take_the_banded_solver_too(slam, orc, syn):
+    """Half-bandwidths 10 .. 20 stay on the one-launch banded solve, on its other paths: a panel of more than 64 rows (second trip of the
+    factor wave), two window slots per set-up thread (hb >= 14), six prefetch entries per lane, the three-phase back-substitution
+    with L_kk^-1 read back from the factor store, no twisted split.  11, 15 and 20 observers per point (hb = 10, 14, 19), and the last
+    width the grouped build accepts."""
+    for P, opp in ((24, 11), (30, 15), (26, 20), (40, 21)):
+        s = syn.ba_scene(P=P, M=50 * P, seed=200 + opp, obs_per_point=opp)
+        _ba_vs_oracle(slam, orc, s, (P, opp))
