@@ -108,9 +108,10 @@ def test_ba_wide_windows_fall_back_to_pair_lists_and_the_tiled_solve(slam, orc, 
 
 
 def test_ba_twisted_factorisation_split_sizes(slam, orc, syn):
-    """Windows of >= 2 (hb + 1) + 6 poses are factored from both ends (two workgroups, hb middle poses merged): the smallest such windows
+    """Windows of >= max(2 (hb + 1), hb + 8) poses are factored from both ends (two workgroups, hb middle poses merged): the smallest such windows
     for three band widths (10, 6 and 2 observers per point), odd / even splits, windows on both sides of the threshold."""
-    for P, opp in ((30, 10), (31, 10), (33, 10), (25, 10), (26, 10), (27, 10), (17, 6), (18, 6), (19, 6), (23, 6), (9, 2), (10, 2), (11, 2)):
+    for P, opp in ((30, 10), (31, 10), (33, 10), (25, 10), (26, 10), (27, 10), (19, 10), (20, 10), (21, 10), (17, 6), (18, 6), (19, 6), (23, 6),
+                   (12, 6), (13, 6), (14, 6), (8, 2), (9, 2), (10, 2), (11, 2)):
         s = syn.ba_scene(P=P, M=40 * P, seed=100 + P, obs_per_point=opp)
         _ba_vs_oracle(slam, orc, s, (P, opp))
 
