@@ -91,6 +91,9 @@ struct slam_ba {
     double *linv = nullptr;      // inverses of the factored diagonal tiles, nbc x 32 x 32
     double *lfac = nullptr;      // finished factor tiles + forward-substituted rhs row, (n+1) x n
     int hb = 0;                  // block half-bandwidth of the reduced system: S_pq = 0 for |p - q| > hb
+    int p0 = 0, pspan = 0;       // the banded solve runs on the poses p0 .. p0 + pspan - 1 = first .. last FREE pose: the constant poses outside
+                                 // that span (the reference's window: <= 5 free key-frames + their constant observers, estimator.jl:327-331) have
+                                 // identity blocks and dp = 0 -- each of them used to be a block column of the factorisation all the same
     bool grouped = false;        // the reduced system is built by k_schur_groups / k_schur_reduce (else: pair lists, k_blocks)
     int nparts = 0;              // partial sums k_control folds after a linearisation inside a build
     const double *zeroed = nullptr;   // reduce buffer whose out-of-band part is known to be zero
@@ -1007,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(BADev d, CholArgs C, con
 // Back-substitution L' dp = y then walks the block columns right to left with the stored L_ik and L_kk^-1.
 // Systems whose half-bandwidth exceeds BS_MAXHB blocks (dense windows of > 21 poses) keep the tiled path.
 #define BS_MAXHB 20
-struct BandArgs { const double *S, *g, *ud; double *Lg; int nb, hb; double inv_delta_host; int *fail; long long *trace; int lds_bytes; double *xchg; int epoch; int shift; };
+struct BandArgs { const double *S, *g, *ud; double *Lg; int nb, hb; double inv_delta_host; int *fail; long long *trace; int lds_bytes; double *xchg; int epoch; int shift; int p0; };
 #define BS_PF 6      // prefetch registers per prefetch thread: ceil(((BS_MAXHB + 1) * 36 + 6) / BS_PT)
 #define BS_WS 38     // doubles per 6 x 6 block in the window ring and the panel: 36 + 2, so that the blocks the lanes of a wave read at the
                      // same time start 12 banks apart (a stride of 36 doubles = 8 banks puts every fourth block on the same ones)
@@ -1065,6 +1068,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     const double inv_delta = use_state ? 1.0 / d.st->delta : B.inv_delta_host;
     const size_t lgs = (size_t)hb1 * 36 + 8;             // doubles per block column in the global factor store
     double *const Lg = B.Lg + (size_t)side * nbT * lgs;
+    double *const dpo = d.dp + 6 * B.p0;                   // dp of the solve's first pose (the span of the free poses)
     // The two sides of a twisted solve hand data to each other through global memory.  On the same XCD (the normal case, see above) the
     // L2 is common: the producer's stores only have to have arrived there (s_waitcnt vmcnt(0)) and the consumer reads with sc1 loads, past
     // its own L1 -- no agent-scope fence, whose L2 write-back / invalidate costs microseconds.  Each side publishes its XCC_ID (tagged
@@ -1656,7 +1660,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                 if (tid == 0) while (__hip_atomic_load(B.fail + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != B.epoch) __builtin_amdgcn_s_sleep(2);
                 __syncthreads();
                 if (same_xcd()) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); else __threadfence();
-                for (int e = tid; e < hb * 6; e += BS_T) chat[6 * own + e] = __hip_atomic_load(d.dp + 6 * gi(own + e / 6) + e % 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int e = tid; e < hb * 6; e += BS_T) chat[6 * own + e] = __hip_atomic_load(dpo + 6 * gi(own + e / 6) + e % 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __syncthreads();
             }
             if (B.trace && side == 0 && tid == 0) { const long long t_ = clock64(); B.trace[11] = t_ - trb0; trb0 = t_; }
@@ -1692,7 +1696,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                     if (mine) x[6 * k + c_] = v;
                     base = mine ? 0.0 : (on ? base - t : base);
                     if (tw && side == 0 && k >= own) {               // the middle: the other side waits for these
-                        if (mine) d.dp[6 * k + c_] = v;
+                        if (mine) dpo[6 * k + c_] = v;
                         if (k == own) {
                             if (same0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); else __threadfence();
                             if (lane == 0) __hip_atomic_store(B.fail + 2, B.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1763,7 +1767,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     }
     }
     if (warm_acc == 1.2345e-300) x[0] = warm_acc;             // keeps the warm-up loads alive; never true in practice
-    for (int a = tid; a < 6 * kfac2; a += BS_T) d.dp[6 * gi(a / 6) + a % 6] = x[a];
+    for (int a = tid; a < 6 * kfac2; a += BS_T) dpo[6 * gi(a / 6) + a % 6] = x[a];
     if (tid == 0) { if (!tw || side == 0) *B.fail = s_bad; if (s_bad) d.st->chol_fail = 1; }
     if (B.trace && side == 0) {
         if (tid == 0) { B.trace[0] = tr0; B.trace[1] = trD; B.trace[3] = clock64() - trT; B.trace[4] = trA; B.trace[5] = trB; }
@@ -2076,6 +2080,9 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
         else pfirst[j] = pany[j] < P ? pany[j] : 0;          // no free observer: any window will do (it gets no slot)
     }
     ba->hb = hb;
+    {   int f0 = P, f1 = -1;
+        for (int p = 0; p < P; p++) if (!theta_const[p]) { f0 = std::min(f0, p); f1 = std::max(f1, p); }
+        if (f1 - f0 + 1 >= 2) { ba->p0 = f0; ba->pspan = f1 - f0 + 1; } else { ba->p0 = 0; ba->pspan = P; } }
     std::vector<int> pt_id(M), rank(M), start(M + 1, 0);
     { std::vector<int> fb(P + 1, 0);
       for (int j = 0; j < M; j++) fb[pfirst[j] + 1]++;
@@ -2227,6 +2234,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
 #undef UP
     if (stage) HIP_TRY(ctx, hipMemcpyAsync(A, stage, up_end, hipMemcpyHostToDevice, st));      // pinned -> device: one DMA, nothing to wait for
     HIP_TRY(ctx, hipMemsetAsync(A + up_end, 0, zero_end - up_end, st));                         // LM state, flags, outlier marks
+    if (ba->pspan < P) HIP_TRY(ctx, hipMemsetAsync(d.dp, 0, (size_t)n * 8, st));                 // dp of the constant poses outside the solve's span stays zero
     if (!stage) HIP_TRY(ctx, slam_stream_wait(st));   // pageable host vectors go out of scope
     guard.b = nullptr;
     *out = ba;
@@ -2271,15 +2279,16 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
     const int n = d.n;
     hipStream_t st = ctx->stream;
     static const bool no_band = getenv("SLAMHIP_NO_BAND") != nullptr;
-    const int hb = std::min(std::max(ba->hb, 1), d.P - 1);      // >= 1: the factor wave reads block row k + 1 while row k + 1 + hb enters the ring
-    const size_t band_fixed = (3 * (size_t)n + 36 * (size_t)d.P) * 8;      // x, damp, chat, L_kk^-1 of every column
+    const int Ps = ba->pspan > 0 ? ba->pspan : d.P, p0 = ba->pspan > 0 ? ba->p0 : 0;       // the poses the banded solve covers: first .. last free pose
+    const int hb = std::min(std::max(ba->hb, 1), Ps - 1);      // >= 1: the factor wave reads block row k + 1 while row k + 1 + hb enters the ring
+    const size_t band_fixed = (3 * (size_t)n + 36 * (size_t)Ps) * 8;      // x, damp, chat, L_kk^-1 of every column
     size_t band_lds = band_fixed + ((size_t)(hb + 1) * (hb + 1) * BS_WS + (size_t)(hb + 1) * (6 + BS_WS + 6) + 8 + 36 + 56) * 8 + (size_t)BS_PF * BS_PT * 8;
     if (hb * 6 <= 58) {      // narrow bands: room to stage the G blocks of (up to) all back-substitution steps, at least one
-        const size_t want = band_fixed + (size_t)d.P * hb * 36 * 8, least = band_fixed + (size_t)hb * 36 * 8;
+        const size_t want = band_fixed + (size_t)Ps * hb * 36 * 8, least = band_fixed + (size_t)hb * 36 * 8;
         band_lds = std::max(band_lds, std::max(std::min(want, (size_t)150 * 1024), least));
     }
     if (!no_band && hb <= BS_MAXHB && band_lds <= 150 * 1024) {
-        BandArgs B; B.S = red; B.g = red + (size_t)n * n; B.ud = red + (size_t)n * n + n; B.Lg = ba->band; B.nb = d.P; B.hb = hb;
+        BandArgs B; B.S = red + (size_t)6 * p0 * (n + 1); B.g = red + (size_t)n * n + 6 * p0; B.ud = red + (size_t)n * n + n + 6 * p0; B.Lg = ba->band; B.nb = Ps; B.hb = hb; B.p0 = p0;
         B.inv_delta_host = inv_delta; B.fail = ba->chol_flag; B.lds_bytes = (int)band_lds;
         B.xchg = ba->xchg; B.epoch = ++ba->epoch;
         static const int twist_shift = [] { const char *v = getenv("SLAMHIP_TWIST_SHIFT"); return v ? atoi(v) : 1; }();    // (measurement knob; +1: side 0 takes two columns more than side 1, measured best at P = 50)
@@ -2287,7 +2296,7 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
         static const bool no_twist = getenv("SLAMHIP_NO_TWIST") != nullptr;
         // (the two workgroups wait for each other: both must be resident, which a stream confined to one compute unit cannot promise)
         static const int twist_min = [] { const char *v = getenv("SLAMHIP_TWIST_MIN"); return v ? atoi(v) : 0; }();    // (measurement knob)
-        const bool twist = !no_twist && hb * 6 <= 58 && d.P >= (twist_min > 0 ? std::max(twist_min, hb + 8) : std::max(2 * (hb + 1), hb + 8))      /* measured: pays from 20 poses at hb = 9 since the hand-overs stay in one L2 (24 before) */ && (ctx->cus == 0 || ctx->cus >= 2);
+        const bool twist = !no_twist && hb * 6 <= 58 && Ps >= (twist_min > 0 ? std::max(twist_min, hb + 8) : std::max(2 * (hb + 1), hb + 8))      /* measured: pays from 20 poses at hb = 9 since the hand-overs stay in one L2 (24 before) */ && (ctx->cus == 0 || ctx->cus >= 2);
         static long long *trace_dev = nullptr; static int trace_n = 0;
         static const bool trace_on = getenv("SLAMHIP_BAND_TRACE") != nullptr;
         if (trace_on && !trace_dev) (void)hipHostMalloc((void **)&trace_dev, 1024);
