@@ -2491,15 +2491,18 @@ int slam_ba_flag_outliers(slam_ctx *ctx, slam_ba *ba, double repr_eps, double de
     return SLAM_OK;
 }
 
-int slam_ba_download(slam_ctx *ctx, slam_ba *ba, double *theta, uint8_t *outliers)
+// cur_known: LMState::cur if the caller has the state on the host already, -1: ask the device (one more synchronisation)
+static int ba_download(slam_ctx *ctx, slam_ba *ba, double *theta, uint8_t *outliers, int cur_known)
 {
     ARG_TRY(ctx, ctx != nullptr && ba != nullptr);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const BADev &d = ba->d;
     if (theta) {
-        int cur = 0;                                         // which buffer pair holds the committed parameters (LMState::cur)
-        HIP_TRY(ctx, hipMemcpyAsync(&cur, &d.st->cur, sizeof cur, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+        int cur = cur_known;                                 // which buffer pair holds the committed parameters (LMState::cur)
+        if (cur < 0) {
+            HIP_TRY(ctx, hipMemcpyAsync(&cur, &d.st->cur, sizeof cur, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+        }
         HIP_TRY(ctx, hipMemcpyAsync(theta, cur ? d.pose_t : d.pose, (size_t)d.n * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (d.M > 0) HIP_TRY(ctx, hipMemcpyAsync(theta + d.n, cur ? d.pts_t : d.pts, (size_t)3 * d.M * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
@@ -2509,6 +2512,7 @@ int slam_ba_download(slam_ctx *ctx, slam_ba *ba, double *theta, uint8_t *outlier
     if (outliers) for (int s = 0; s < d.O; s++) outliers[ba->perm[s]] = tmp[s];
     return SLAM_OK;
 }
+int slam_ba_download(slam_ctx *ctx, slam_ba *ba, double *theta, uint8_t *outliers) { return ba_download(ctx, ba, theta, outliers, -1); }
 
 int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy, int P, int M, int O,
                   double *theta, const uint8_t *theta_const, const double *pixels_yx,
@@ -2558,7 +2562,7 @@ int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy, int
     // A failed factorisation leaves the caller's theta and outliers untouched (the reference's LSMR step cannot fail and
     // never leaves cache.theta half-updated): the state is only copied back from a run that completed.
     const auto tw2 = std::chrono::steady_clock::now();
-    rc = h.chol_fail ? SLAM_OK : slam_ba_download(ctx, ba, theta, outliers);
+    rc = h.chol_fail ? SLAM_OK : ba_download(ctx, ba, theta, outliers, h.cur);
     const auto tw3 = std::chrono::steady_clock::now();
     slam_ba_destroy(ba);
     if (host_times) {
