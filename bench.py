@@ -261,7 +261,7 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
     rb = slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx)
     seq = frame_sequence(steps + warmup + 60 + S)
     rng = np.random.default_rng(1234)
-    noise_pool = rng.normal(0, 0.5, (1 << 17, 2))          # prior noise, drawn once (synthetic-input generation, not SLAM work)
+    noise_pool = rng.normal(0, 0.5, (max(1 << 17, 4096 * S), 2))          # prior noise, drawn once (synthetic-input generation, not SLAM work)
     seq_a = np.asarray(seq); flows_a = np.asarray(flows, dtype=np.float64)
     lp = [t.data_ptr() for t in left_dev]; rp = [t.data_ptr() for t in right_dev]
     lptr = lambda i: [lp[f] for f in seq[i:i + S]]
@@ -846,10 +846,10 @@ def main():
     ap.add_argument("--only", type=str, default="", help="comma-separated legs to run (default: all): " + ", ".join(LEGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and the oracle parity checks that live in it)")
     ap.add_argument("--no-ba", action="store_true", help="skip the BA and pose measurements")
-    ap.add_argument("--streams", type=int, default=64, help="S: independent stereo streams per GPU advancing in lock-step (one batch of S frames per frame step); "
+    ap.add_argument("--streams", type=int, default=128, help="S: independent stereo streams per GPU advancing in lock-step (one batch of S frames per frame step); "
                     "64 = the library's batch limit: the big pyramid kernels then run whole rounds of workgroups (S = 32, the round-1 value: -8 %%)")
     ap.add_argument("--no-tolerance", action="store_true", help="skip the tolerance-mode measurements")
-    ap.add_argument("--no-sweep", action="store_true", help="skip the S = 32 / 48 streams-per-GPU legs")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the streams-per-GPU sweep legs (S = 32 / 64 / 96 at the default 128)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE shapes (kitti00_2000, euroc_mono, fhd_4000)")
     args = ap.parse_args()
     legs = set(x for x in args.only.split(",") if x) or set(LEGS)
@@ -1122,9 +1122,9 @@ def main():
 
     # more streams per GPU share every launch better (the build's per-frame cost falls until the big kernels run whole rounds of
     # workgroups): the same loop at the other batch sizes, short
-    if "sweep" in legs and S in (32, 64):
+    if "sweep" in legs and S in (32, 64, 128):
         out["streams_sweep"] = {}
-        for S2 in ((48, 64) if S == 32 else (32, 48)):
+        for S2 in {32: (48, 64), 64: (32, 48), 128: (32, 64, 96)}[S]:
             w2 = dict(wl); w2["S"] = S2
             r2 = run_lockstep_kpset(slam, torch, local_rank, w2, max(8, args.steps // 4), 2, world, dist, dev, "host_u8")
             out["streams_sweep"][str(S2)] = {"value": r2["value"], "unit": "frames/sec", "ms_per_step": r2["ms_per_step"]}

@@ -205,7 +205,7 @@ int slam_flow_match(slam_ctx *ctx, const slam_pyr *from, const slam_pyr *to,
 /* ---- lock-stepped batches of streams --------------------------------------- */
 /* The recurrences of the pyramid build are latency-bound for one image; S independent images
  * (left + right of a key-frame, or S camera streams) share every launch when their pyramids live in one batch.
- * slam_pyr_create_batch fills out[0..S) (1 <= S <= 64) with ordinary pyramid handles backed by one allocation; each can be used
+ * slam_pyr_create_batch fills out[0..S) (1 <= S <= 128) with ordinary pyramid handles backed by one allocation; each can be used
  * with every single-pyramid call above.  slam_pyr_update_batch_dev rebuilds all S in one launch set (pyrs must
  * be the S members of one batch, in order; images already in HBM); slam_flow_match_batch tracks the keypoints
  * of all S streams in one launch (img_index[i] = stream of point i; from0 / to0 = member 0 of two batches).

@@ -601,13 +601,13 @@ extern "C" int slam_detect_batch(slam_ctx *ctx, const slam_pyr *pyr0, int S, con
                                  int max_points, int radius, int grid_rows, int grid_cols, int cell_size,
                                  double sigma_mask, double min_response, int64_t *out_rc, int cap, int32_t *out_off)
 {
-    ARG_TRY(ctx, ctx != nullptr && pyr0 != nullptr && S >= 1 && S <= 64 && cur_off != nullptr && out_off != nullptr);
+    ARG_TRY(ctx, ctx != nullptr && pyr0 != nullptr && S >= 1 && S <= 128 && cur_off != nullptr && out_off != nullptr);
     ARG_TRY(ctx, pyr0->batch_index == 0 && pyr0->batch_size == S);
     ARG_TRY(ctx, grid_rows > 0 && grid_cols > 0 && cell_size >= 8 && radius > 0 && radius <= DET_MAXR && cap >= 0 && (cap == 0 || out_rc != nullptr));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int n_cells = grid_rows * grid_cols, n_tot = cur_off[S];
     ARG_TRY(ctx, cur_off[0] == 0 && n_tot >= 0 && (n_tot == 0 || cur_yx != nullptr));
-    int ks[64], kmax = 0;
+    int ks[128], kmax = 0;
     for (int s = 0; s < S; s++) {
         const int nc = cur_off[s + 1] - cur_off[s];
         ARG_TRY(ctx, nc >= 0);
@@ -634,8 +634,8 @@ extern "C" int slam_detect_batch(slam_ctx *ctx, const slam_pyr *pyr0, int S, con
     const size_t lds_bytes = 4 * n * sizeof(double);
     ARG_TRY(ctx, lds_bytes <= 150 * 1024);
 
-    // host -> device in one copy: [cur_off (S+1 ints) at 0] [k_s (S ints) at 512] [cur (2 * n_tot doubles) at 1024]
-    const size_t hdr_b = 1024, cur_b = ((size_t)n_tot * 16 + 255) & ~(size_t)255;
+    // host -> device in one copy: [cur_off (S+1 ints) at 0] [k_s (S ints) at 1024] [cur (2 * n_tot doubles) at 2048]
+    const size_t hdr_b = 2048, cur_b = ((size_t)n_tot * 16 + 255) & ~(size_t)255;
     const size_t cnt_b = ((size_t)S * n_cells * 4 + 255) & ~(size_t)255;
     const size_t cout_b = ((size_t)S * n_cells * kmax * 16 + 255) & ~(size_t)255;
     const size_t pairs = (size_t)n_cells * kmax, out_b = (size_t)S * (8 + pairs * 16);
@@ -644,10 +644,10 @@ extern "C" int slam_detect_batch(slam_ctx *ctx, const slam_pyr *pyr0, int S, con
     if (rc) return rc;
     rc = slam_pinned(ctx, hdr_b + cur_b + out_b, (void **)&h);
     if (rc) return rc;
-    memcpy(h, cur_off, (size_t)(S + 1) * 4); memcpy(h + 512, ks, (size_t)S * 4);
+    memcpy(h, cur_off, (size_t)(S + 1) * 4); memcpy(h + 1024, ks, (size_t)S * 4);
     if (n_tot > 0) memcpy(h + hdr_b, cur_yx, (size_t)n_tot * 16);
     HIP_TRY(ctx, hipMemcpyAsync(d, h, hdr_b + (size_t)n_tot * 16, hipMemcpyHostToDevice, ctx->stream));
-    A.cur_off = (const int *)d; A.k_s = (const int *)(d + 512); A.cur = (const double *)(d + hdr_b);
+    A.cur_off = (const int *)d; A.k_s = (const int *)(d + 1024); A.cur = (const double *)(d + hdr_b);
     A.cell_cnt = (int *)(d + hdr_b + cur_b); A.cell_out = (int64_t *)(d + hdr_b + cur_b + cnt_b);
     int64_t *d_out = (int64_t *)(d + hdr_b + cur_b + cnt_b + cout_b);
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)detect_cells, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

@@ -14,7 +14,7 @@
 
 static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-// live slots of all streams back to back + their number.  One small workgroup per stream (it sums the counts before its own: S <= 64
+// live slots of all streams back to back + their number.  One small workgroup per stream (it sums the counts before its own: S
 // loads): a single 1024-thread workgroup had to wait for sixteen free wave slots on one CU while the pyramid kernels fill the chip
 // (58 us on average in the pipeline for 12 us of work).
 __global__ __launch_bounds__(256) void k_kpset_worklist(const int *count, int S, int cap, int *work, int *ntot)
@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void k_kpset_worklist(const int *count, int S,
     __shared__ int s_off;
     const int s = blockIdx.x, tid = threadIdx.x;
     if (tid < 64) {
-        int c = tid < s ? count[tid] : 0, t = tid < S ? count[tid] : 0;     // (S <= 64: one wave covers every stream)
+        int c = 0, t = 0;
+        for (int i = tid; i < S; i += 64) { const int v = count[i]; t += v; c += i < s ? v : 0; }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { c += __shfl_xor(c, m); t += __shfl_xor(t, m); }
         if (tid == 0) { s_off = c; if (s == 0) ntot[0] = t; }
@@ -269,7 +270,7 @@ int slam_kpset_destroy(slam_kpset *ks);
 
 int slam_kpset_create(slam_ctx *ctx, int S, int cap, slam_kpset **out)
 {
-    ARG_TRY(ctx, ctx != nullptr && out != nullptr && S >= 1 && S <= 64 && cap >= 1 && (size_t)S * cap < (1u << 30));
+    ARG_TRY(ctx, ctx != nullptr && out != nullptr && S >= 1 && S <= 128 && cap >= 1 && (size_t)S * cap < (1u << 30));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)S * cap;
     size_t off = 0;

@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__(256) void k_u8_to_f64(double *dst, const unsigned c
 }
 
 // ingest: the dense H x W image z (its own device pointer) is copied into the pitched layer 0 of pyramid z
-#define BATCH_MAX 64
+#define BATCH_MAX 128
 struct ImgPtrs { const double *p[BATCH_MAX]; };
 __global__ __launch_bounds__(256) void k_gather_images(ImgPtrs src, double *dst, int H, int W, int P, size_t zs)
 {
@@ -1791,7 +1791,7 @@ static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, 
     if (e == hipSuccess) e = slam_stream_wait(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(al->base); delete al; return slam_fail(ctx, SLAM_ERR_HIP, "slam_pyr_create: memset: %s", hipGetErrorString(e)); }
     al->refs = S;
-    if (S > 1 && hipMalloc((void **)&al->srctab, 64 * sizeof(void *)) != hipSuccess) { (void)hipGetLastError(); al->srctab = nullptr; }
+    if (S > 1 && hipMalloc((void **)&al->srctab, BATCH_MAX * sizeof(void *)) != hipSuccess) { (void)hipGetLastError(); al->srctab = nullptr; }
     // once per creation, outside any stream capture: k_cum_fused needs the > 64 KB dynamic-LDS opt-in
     (void)hipFuncSetAttribute((const void *)k_cum_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     double *ckbuf = nullptr;
@@ -1841,7 +1841,7 @@ int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double
     for (int s = 0; s < BATCH_MAX; s++) ip.p[s] = s < S ? images_dev[s] : nullptr;
     const size_t n = (size_t)p0->H[0] * p0->W[0];
     const bool fused_ingest = level0_fused(p0, mode & ~SLAM_PYR_FLAGS, S);          // the level-0 kernel reads the source images itself and writes the layer
-    if (fused_ingest) hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(64), 0, ctx->stream, p0->alloc->srctab, ip);
+    if (fused_ingest) hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(BATCH_MAX), 0, ctx->stream, p0->alloc->srctab, ip);
     else hipLaunchKernelGGL(k_gather_images, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
     int rc = enqueue_build(ctx, p0, mode, sigma, S, fused_ingest ? 1 : 0);
     for (int s = 0; s < S; s++) pyrs[s]->target_only = (mode & SLAM_PYR_TARGET_ONLY) != 0;
@@ -1862,7 +1862,7 @@ int slam_pyr_update_batch_u8_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const uin
     for (int s = 0; s < BATCH_MAX; s++) ip.p[s] = s < S ? images_u8_dev[s] : nullptr;
     const size_t n = (size_t)p0->H[0] * p0->W[0];
     const bool fused_ingest = level0_fused(p0, mode & ~SLAM_PYR_FLAGS, S);
-    if (fused_ingest) { ImgPtrs iq; for (int s = 0; s < BATCH_MAX; s++) iq.p[s] = (const double *)ip.p[s]; hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(64), 0, ctx->stream, p0->alloc->srctab, iq); }
+    if (fused_ingest) { ImgPtrs iq; for (int s = 0; s < BATCH_MAX; s++) iq.p[s] = (const double *)ip.p[s]; hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(BATCH_MAX), 0, ctx->stream, p0->alloc->srctab, iq); }
     else hipLaunchKernelGGL(k_gather_images_u8, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
     int rc = enqueue_build(ctx, p0, mode, sigma, S, fused_ingest ? 2 : 0);
     for (int s = 0; s < S; s++) pyrs[s]->target_only = (mode & SLAM_PYR_TARGET_ONLY) != 0;

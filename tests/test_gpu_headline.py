@@ -47,6 +47,29 @@ def test_batch_u8_s64_kitti_vs_oracle(slam, syn, orc):
             assert np.array_equal(tgt.pyramids[s].plane(name, 0), ref.plane(name, 0)), ("target_only", s, name)
 
 
+def test_batch_u8_s128_kitti_vs_oracle(slam, syn, orc):
+    """128 u8 frames of 370 x 1226 per build -- bench.py's default batch since the end of round 3 (the largest a batch can be:
+    slam_pyr_create_batch's limit): full and target-only builds, streams 0, 64 and 127 against the oracle, all planes and levels."""
+    import torch
+    S = 128
+    u8 = _u8_frames(syn, S, seed=13)
+    dev = torch.from_numpy(np.stack([np.ascontiguousarray(im.T) for im in u8])).cuda()
+    torch.cuda.synchronize()
+    ptrs = [dev.data_ptr() + s * H * W for s in range(S)]
+    full = slam.PyramidBatch((H, W), levels=3, S=S)
+    full.update_(ptrs, u8=True); full.update_(ptrs, u8=True)
+    tgt = slam.PyramidBatch((H, W), levels=3, S=S)
+    tgt.update_(ptrs, u8=True, target_only=True); tgt.update_(ptrs, u8=True, target_only=True)
+    for s in (0, 64, 127):
+        ref = orc.pyr_build(np.asfortranarray(u8[s].astype(np.float64) / 255.0), 3, 1.0, 1)
+        for l in range(4):
+            for name in PLANES:
+                assert np.array_equal(full.pyramids[s].plane(name, l), ref.plane(name, l)), ("full", s, name, l)
+            assert np.array_equal(tgt.pyramids[s].plane("layers", l), ref.plane("layers", l)), ("target_only", s, l)
+        for name in PLANES:
+            assert np.array_equal(tgt.pyramids[s].plane(name, 0), ref.plane(name, 0)), ("target_only", s, name)
+
+
 def test_batch_f64_s48_kitti_vs_oracle(slam, syn, orc):
     """S = 48 Float64 frames (the streams_sweep leg; levels 1 and 2 cross the 40 MB kernel-selection threshold between S = 16 and
     S = 48): streams 0 and 47 against the oracle."""

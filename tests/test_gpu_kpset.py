@@ -451,3 +451,43 @@ def test_a_small_n_bound_is_only_a_hint(slam, orc, syn, texture):
         for key in ("yx", "is_3d", "xyz", "stereo_yx", "has_stereo"):
             m = out[0][s]["is_3d"] if key == "xyz" else (out[0][s]["has_stereo"] if key == "stereo_yx" else slice(None))
             assert np.array_equal(out[0][s][key][m], out[1][s][key][m]), (s, key)
+
+
+def test_more_than_64_streams(slam, orc, syn, texture):
+    """Up to 128 streams share a keypoint set and its launches (bench.py's default since the end of round 3: 128): the work list's
+    offsets are sums over MORE than one wave's worth of stream counts.  70 small streams with ragged lists: temporal match + detect +
+    stereo match on the set; streams 0, 63, 64 and 69 are replayed through the oracle."""
+    S, H, W = 70, 96, 128
+    streams, a, b, r, keep = _setup(slam, texture, S, H, W)
+    params = slam.Params(stereo=True, max_nb_keypoints=80)
+    cam = slam.Camera(*syn.KITTI_CAM, height=H, width=W)
+    e = slam.Extractor.from_params(params, cam)
+    ncell = e.grid_resolution[0] * e.grid_resolution[1]
+    ks = slam.KeypointSet(S, params.max_nb_keypoints + ncell + 8)
+    kps, is3 = [], []
+    for s in range(S):
+        k = orc.detect(streams[s][0][0], np.zeros((0, 2)), max_points=30 + (s * 7) % 40).astype(float)
+        kps.append(k); is3.append(np.arange(len(k)) % 2 == 0)
+        ks.upload(s, k, is3[s])
+    shift = np.array([streams[s][2][1] for s in range(S)])
+    ks.flow_match(a, b, params, slam.stream_params(S, cam=syn.KITTI_CAM, shift_yx=shift), prior=2)
+    cnt = ks.counts()
+    check = (0, 63, 64, 69)
+    lists = {}
+    f = lambda im: np.asfortranarray(im)
+    for s in check:
+        ra, rb = orc.pyr_build(f(streams[s][0][0]), 3, 1.0, 1), orc.pyr_build(f(streams[s][0][1]), 3, 1.0, 1)
+        ref = orc.optical_flow_matching(ra, rb, kps[s], is3[s], kps[s] + shift[s], (H, W), sum_order=1)
+        keep_ = ~ref["removed"]
+        got = ks.download(s)
+        assert cnt[s] == keep_.sum() == len(got["yx"]), s
+        assert np.abs(got["yx"] - ref["new_pixels"][keep_]).max() <= 1e-9, s
+        lists[s] = got["yx"]
+    ks.detect(e, b)
+    cnt2 = ks.counts()
+    for s in check:
+        fresh = orc.detect(f(streams[s][0][1]), lists[s], max_points=params.max_nb_keypoints).astype(float)
+        got = ks.download(s)
+        assert cnt2[s] == len(lists[s]) + len(fresh), s
+        assert np.array_equal(got["yx"][len(lists[s]):], fresh), s
+    ks.close()
