@@ -380,14 +380,14 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
 
 WORKLOADS = {
     # name: shape (slam_jl_amd.synthetic.SHAPES), keypoints per frame, stereo, streams per GPU, camera (fx, fy, cx, cy), image step per frame
-    "kitti05_1000": dict(shape="kitti05", kpts=1000, stereo=True, S=64, cam=None, step=(1.3, -2.1), n_frames=8,
+    "kitti05_1000": dict(shape="kitti05", kpts=1000, stereo=True, S=128, cam=None, step=(1.3, -2.1), n_frames=8,
                          what="BASELINE configs[1]: KITTI 05 stereo 370x1226, 1000 kpts/frame (the headline)"),
-    "kitti00_2000": dict(shape="kitti00", kpts=2000, stereo=True, S=64, cam=None, step=(1.3, -2.1), n_frames=8,
+    "kitti00_2000": dict(shape="kitti00", kpts=2000, stereo=True, S=128, cam=None, step=(1.3, -2.1), n_frames=8,
                          what="BASELINE configs[2]: KITTI 00 stereo 376x1241 (example/kitty/main.jl:21-22), 2000 kpts/frame; its 20-KF BA is ba.windows.P20"),
-    "euroc_mono": dict(shape="euroc", kpts=1000, stereo=False, S=64, cam=(458.654, 457.296, 367.215, 248.375), step=(2.6, -4.2), n_frames=8,
+    "euroc_mono": dict(shape="euroc", kpts=1000, stereo=False, S=128, cam=(458.654, 457.296, 367.215, 248.375), step=(2.6, -4.2), n_frames=8,
                        what="BASELINE configs[3]: monocular 480x640, PnP-tracking path (front_end.jl:132-219: five-point filter + P3P RANSAC + PnP "
                             "refinement every frame, no right image), new keypoints by triangulate_temporal!; its 50-KF BA is ba.windows.P50"),
-    "fhd_4000": dict(shape="fhd", kpts=4000, stereo=True, S=16, cam=(910.0, 910.0, 960.0, 540.0), step=(1.3, -2.1), n_frames=4,
+    "fhd_4000": dict(shape="fhd", kpts=4000, stereo=True, S=32, cam=(910.0, 910.0, 960.0, 540.0), step=(1.3, -2.1), n_frames=4,
                      what="BASELINE configs[4] on one GPU: 1080x1920 stereo (example/uni/main.jl:11-13), 4000 kpts/frame; its 100-KF BA is ba.windows.P100"),
 }
 

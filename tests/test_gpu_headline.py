@@ -163,10 +163,10 @@ def test_kpset_keyframe_cycle_at_kitti_size_vs_oracle(slam, syn, orc, texture):
     ks.close()
 
 
-@pytest.mark.parametrize("shape,S", [((376, 1241), 64), ((480, 640), 64), ((1080, 1920), 16)])
+@pytest.mark.parametrize("shape,S", [((376, 1241), 64), ((480, 640), 64), ((1080, 1920), 16), ((376, 1241), 128), ((480, 640), 128), ((1080, 1920), 32)])
 def test_config_shapes_u8_batches_vs_oracle(slam, syn, orc, shape, S):
-    """The other BASELINE shapes at the batch sizes bench.py's `configs` legs run them with (kitti00_2000 S = 64, euroc_mono S = 64,
-    fhd_4000 S = 16; 8-bit ingest): first and last stream against the oracle, all planes and levels.  (1080 rows: above the 512-row
+    """The other BASELINE shapes at the batch sizes bench.py's `configs` legs run them with (kitti00_2000 S = 128, euroc_mono S = 128,
+    fhd_4000 S = 32; until the last day of round 3: 64 / 64 / 16; 8-bit ingest): first and last stream against the oracle, all planes and levels.  (1080 rows: above the 512-row
     limit of the one-pass integral kernel -> k_cum_cols + k_cum_rows; odd 1241 -> 621 columns: general bilinear resize.)"""
     import torch
     Hc, Wc = shape
