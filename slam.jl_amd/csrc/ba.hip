@@ -2291,7 +2291,7 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
         BandArgs B; B.S = red + (size_t)6 * p0 * (n + 1); B.g = red + (size_t)n * n + 6 * p0; B.ud = red + (size_t)n * n + n + 6 * p0; B.Lg = ba->band; B.nb = Ps; B.hb = hb; B.p0 = p0;
         B.inv_delta_host = inv_delta; B.fail = ba->chol_flag; B.lds_bytes = (int)band_lds;
         B.xchg = ba->xchg; B.epoch = ++ba->epoch;
-        static const int twist_shift = [] { const char *v = getenv("SLAMHIP_TWIST_SHIFT"); return v ? atoi(v) : 1; }();    // (measurement knob; +1: side 0 takes two columns more than side 1, measured best at P = 50)
+        static const int twist_shift = [] { const char *v = getenv("SLAMHIP_TWIST_SHIFT"); return v ? atoi(v) : 0; }();    // (measurement knob: side 0 takes 2 x shift columns more than side 1; +1 paid while the hand-over cost 13 k cycles, with 7 k an even split is 1 % ahead)
         B.shift = twist_shift;
         static const bool no_twist = getenv("SLAMHIP_NO_TWIST") != nullptr;
         // (the two workgroups wait for each other: both must be resident, which a stream confined to one compute unit cannot promise)
