@@ -55,3 +55,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".jl")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "slam_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_bench_batch_sizes_fit_the_library_limit():
+    """bench.py's streams-per-GPU (default and per workload) must not exceed what a batch / keypoint set takes (include/slamhip.h:
+    slam_pyr_create_batch's 1 <= S <= 128; csrc/pyramid.hip BATCH_MAX)."""
+    import importlib.util, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "slamhip.h")).read()
+    m = re.search(r"1 <= S <= (\d+)", hdr)
+    assert m, "the header documents the batch limit"
+    limit = int(m.group(1))
+    src = open(os.path.join(root, "slam.jl_amd", "csrc", "pyramid.hip")).read()
+    assert int(re.search(r"#define BATCH_MAX (\d+)", src).group(1)) == limit
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    assert all(w["S"] <= limit for w in b.WORKLOADS.values())
+    assert int(re.search(r'"--streams", type=int, default=(\d+)', open(os.path.join(root, "bench.py")).read()).group(1)) <= limit
