@@ -667,7 +667,12 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
     builds = [a.elapsed_ms(b) for a, b in ev_used[-len(ev_pool):]]      # left builds of the timed region (graph replays on the pyramid stream)
-    res = {"ingest": ingest, "streams_per_gpu": S, "steps": periods, "frame_steps": nsteps, "value": world * S * nsteps / dt, "unit": "frames/sec", "seconds": dt,
+    try:
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        hbm_gb = (total_b - free_b) / 1e9                                # everything this process (and anyone else on the device) holds while the loop's buffers are alive
+    except Exception:
+        hbm_gb = None
+    res = {"ingest": ingest, "streams_per_gpu": S, "hbm_in_use_gb": hbm_gb, "steps": periods, "frame_steps": nsteps, "value": world * S * nsteps / dt, "unit": "frames/sec", "seconds": dt,
            "ms_per_step": dt / max(periods, 1) * 1e3, "ms_per_frame_of_S_streams": dt / nsteps * 1e3,
            "host_wait_ms_per_frame": state["wait_s"] / nsteps * 1e3,
            "tracked_kpts_per_frame": round(state["tracked"] / max(state["tracked_steps"], 1) / S, 1),
@@ -1074,6 +1079,7 @@ def main():
                        "frames_start": "pinned host memory, uint8 (example/kitty/kitty.jl:52-102 decode) -- copied H2D inside the timed region",
                        "streams_per_gpu": S, "frames_per_step": S * KF_EVERY, "key_frames_per_step": S, "frame_steps_timed": head["frame_steps"],
                        "ms_per_frame_of_S_streams": head["ms_per_frame_of_S_streams"], "parallelism": f"replicas x{world}",
+                       "hbm_in_use_gb": head.get("hbm_in_use_gb"),
                        "pyramid_mode": "bit-exact (slam_pyr_update mode 1 arithmetic; planes identical to the CPU oracle)",
                        "batching": "the S streams advance in lock-step and share every launch: pyramids live in slam_pyr_create_batch batches "
                                    "(grid.z = stream); the keypoint lists live in HBM (slam_kpset_*): tracking + removal of lost keypoints, culling, "
