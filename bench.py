@@ -833,13 +833,16 @@ def ba_windows(syn):
     """The BA windows SURVEY 8d / BASELINE name.  P5: the reference's own shape -- at most 5 free key-frames and many
     constant observers (estimator.jl:327-331, :163-229): 25 poses of which the 20 oldest are constant, O ~ 8 k.
     P20 / P50 / P100: every point seen by 10 consecutive key-frames.  P50_loop: the 50-KF window with loop-closure observations
-    (1500 points of the first 5 key-frames re-observed by the last 5): half-bandwidth 49 -> the non-banded fallback path."""
+    (1500 points of the first 5 key-frames re-observed by the last 5): half-bandwidth 48 in key-frame order (a ring), 18 in the
+    folded order slam_local_ba solves it in.  P26_dense: every point seen by 24 consecutive key-frames -- half-bandwidth 23 in any
+    order: the non-banded general path (pair lists + tiled Cholesky)."""
     w = {}
     s = syn.ba_scene(P=25, M=800, seed=5, n_const=20); w["P5_free_20_const"] = s
     w["P20"] = syn.ba_scene(P=20, M=4000, seed=6)
     w["P50"] = syn.ba_scene(P=50, M=10000, seed=7)
     w["P100"] = syn.ba_scene(P=100, M=40000, seed=8)
     w["P50_loop"] = syn.ba_scene_loop(P=50, M=10000, seed=7, n_loop=1500)
+    w["P26_dense"] = syn.ba_scene(P=26, M=5200, seed=9, obs_per_point=24)
     return w
 
 
@@ -1189,7 +1192,8 @@ def main():
         for name, s in ba_scenes.items():
             cache = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
             slam.bundle_adjustment_(cache, s["cam"], ctx=ctx)            # warm-up
-            hbw = syn.ba_halfband(s)
+            hbw0 = syn.ba_halfband(s)                            # in the caller's pose order
+            _, hbw, reordered = slam.ba_plan_order(cache)        # in the order slam_local_ba solves in (loop closures: folded ring)
             best = None
             for _ in range(3):
                 cache = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
@@ -1197,8 +1201,9 @@ def main():
                 iters = cache.stats["iters_pass1"] + cache.stats["iters_pass2"]
                 r = {"poses": int(s["P"]), "free_poses": int((np.asarray(s["theta_const"]) == 0).sum()), "observations": int(s["O"]), "points": int(s["M"]),
                      "lm_iterations": iters, "ms_per_iter": cache.stats["device_ms"] / max(iters, 1), "wall_ms_total": wall * 1e3,
-                     "ssr_final": cache.stats["ssr_final"], "half_bandwidth": hbw,
-                     "solver_path": "banded: k_schur_groups + k_band_solve" if hbw <= 20 else "general: pair lists (k_blocks) + tiled Cholesky"}
+                     "ssr_final": cache.stats["ssr_final"], "half_bandwidth": hbw, "half_bandwidth_in_key_frame_order": hbw0, "poses_reordered": reordered,
+                     "solver_path": ("banded: k_schur_groups + k_band_solve" + (" on relabelled poses (folded ring, slam_ba_plan_order)" if reordered else ""))
+                                    if hbw <= 20 else "general: pair lists (k_blocks) + tiled Cholesky"}
                 if best is None or r["ms_per_iter"] < best["ms_per_iter"]:
                     best = r
             bytes_iter = 33 * s["O"] + 96 * s["P"] + 48 * s["M"] + 8 * (6 * s["P"]) ** 2

@@ -446,6 +446,16 @@ int    slam_ba_commit(slam_ctx *ctx, slam_ba *ba, int accept);
 int    slam_ba_flag_outliers(slam_ctx *ctx, slam_ba *ba, double repr_eps, double depth_eps, int *n_out);
 /* read back theta (6P + 3 M_local) and the outlier flags (O_local) */
 int    slam_ba_download(slam_ctx *ctx, slam_ba *ba, double *theta, uint8_t *outliers);
+/* The pose order slam_local_ba solves in (host work only, no device call; ctx-free).  The reduced camera system of a window of
+ * consecutive key-frames is block-banded in the caller's order (S_pq = 0 for |p - q| > hb) and takes the single-launch banded
+ * solver when hb <= 20.  A window that is not -- loop closures: the first and the last key-frames share map points
+ * (src/map_manager.jl:300-449 re-associates old map points), so the covisibility chain is a ring -- is solved on relabelled poses when
+ * a fold of the ring or a Cuthill-McKee order of the free poses' covisibility graph brings hb <= 20 (constant poses first); theta
+ * comes back in the caller's order.  order_out (P entries, may be NULL): the caller's 0-based pose at the solver's position k;
+ * hb_out (may be NULL): the half-bandwidth in that order.  Returns 1 if the window is reordered, 0 if the caller's order is kept,
+ * < 0 on bad arguments.  (SLAMHIP_BA_NO_REORDER=1 in the environment keeps the caller's order: measurement knob.) */
+int    slam_ba_plan_order(int P, int M, int O, const uint8_t *theta_const, const int64_t *pose_ids, const int64_t *point_ids,
+                          int32_t *order_out, int *hb_out);
 /* Block half-bandwidth of the shard's reduced system (S_pq = 0 for |p - q| > hb).  The all-reduced system has the maximum
  * over the ranks: the driver sets that on every rank before the first solve (single-launch banded solver). */
 int    slam_ba_halfband(const slam_ba *ba);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "slam_ba_commit": (cint, [vp, vp, cint]),
     "slam_ba_flag_outliers": (cint, [vp, vp, dbl, dbl, C.POINTER(cint)]),
     "slam_ba_download": (cint, [vp, vp, f64p, u8p]),
+    "slam_ba_plan_order": (cint, [cint, cint, cint, u8p, i64p, i64p, i32p, C.POINTER(cint)]),
     "slam_ba_halfband": (cint, [vp]),
     "slam_ba_set_halfband": (cint, [vp, cint]),
     "slam_ba_lm_begin": (cint, [vp, vp, cint, vp]),

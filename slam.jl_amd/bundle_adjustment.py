@@ -52,6 +52,23 @@ def bundle_adjustment_(cache, camera, iterations=10, repr_eps=5.0, iters_fast=5,
     return cache
 
 
+def ba_plan_order(cache):
+    """-> (order, half_bandwidth, reordered): the pose order bundle_adjustment_ solves `cache` in (order[k] = the cache's 0-based pose
+    at the solver's position k) and the block half-bandwidth of the reduced camera system in it -- `slam_ba_plan_order`, host work only.
+    A window with loop closures (map_manager.jl:300-449) is not banded in key-frame order; folded, it is."""
+    lib = L.load()
+    tc = np.ascontiguousarray(cache.theta_const, dtype=np.uint8)
+    pi = np.ascontiguousarray(cache.poses_ids, dtype=np.int64)
+    li = np.ascontiguousarray(cache.points_ids, dtype=np.int64)
+    P, O = len(tc), len(pi)
+    M = (len(cache.theta) - 6 * P) // 3
+    order = np.zeros(P, dtype=np.int32); hb = C.c_int(0)
+    rc = lib.slam_ba_plan_order(P, M, O, L.ptr(tc, L.u8p), L.ptr(pi, L.i64p), L.ptr(li, L.i64p), L.ptr(order, L.i32p), C.byref(hb))
+    if rc < 0:
+        raise L.SlamHipError(f"slam_ba_plan_order: bad arguments ({rc})")
+    return order, int(hb.value), bool(rc)
+
+
 def pnp_bundle_adjustment(camera, pose, pixels, points, iterations=10, depth_eps=1e-6, repr_eps=5.0, iters_fast=5, ctx=None):
     """-> (new_pose 4x4, initial_error, final_error, outliers, n_outliers) -- bundle_adjustment.jl:113-171"""
     ctx = ctx or L.default_context()

@@ -101,6 +101,7 @@ struct slam_ba {
     double *xchg = nullptr;      // twisted factorisation: the trailing window one side hands to the other
     int epoch = 0;               // launch counter of k_band_solve (value of its hand-over flags)
     std::vector<int> perm;       // sorted position -> original observation index
+    std::vector<int> pose_order; // solver's pose k = the caller's pose pose_order[k]; empty: the caller's order (see ba_pose_order)
     int nblocks_obs = 0, nblocks_pts = 0;
 };
 
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
     {
         const int LPS = (nwin + 63) & ~63, NS = SG_T / LPS;                        // 8 subsets for hb <= 9, 4 up to 14, 2 up to 20
         const int sub = tid / LPS, w = tid - sub * LPS;
-        const bool live = w < nwin, xl = w < hbw * 6;
+        const bool live = sub < NS && w < nwin, xl = sub < NS && w < hbw * 6;      // (LPS = 192 leaves 128 threads over: they are no subset)
         const int a = s_ab[live ? 2 * w : 0], b = s_ab[live ? 2 * w + 1 : 1];
         const int a2 = xl ? w / 6 : 0, r2 = w - 6 * (w / 6);
         double acc[36], ex[7];
@@ -1091,7 +1092,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     //      entry -- of the generic band row [hb + 1 blocks | 6] and loads it for all hb + 1 rows (block column i - hb + jb: the rows of the
     //      first window lack their leading blocks).  The values are consumed further down, after the other requests of the set-up (the next
     //      row, the L2 warm-up) have gone out too ----
-        const double udv = tid < 6 * nb ? B.ud[6 * gi(tid / 6) + tid % 6] : 0.0;          // (6 nb <= BS_T for every banded window: nb <= 85)
+        const double udv = tid < 6 * nb ? B.ud[6 * gi(tid / 6) + tid % 6] : 0.0;          // (6 nb <= BS_T up to nb = 85; the entries beyond follow below)
         constexpr int NS = ((BS_MAXHB + 1) * 36 + 6 + BS_T - 1) / BS_T;                    // slots per thread (2)
         double wv[NS][BS_MAXHB + 1];
         // per slot: global index of row 0 and its stride per row (linear in the row number on either side), first valid row, LDS word
@@ -2052,10 +2053,88 @@ __global__ __launch_bounds__(256) void k_outlier_count(BADev d, int nb_obs)
 // ---------------------------------------------------------------------------------
 static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 
-static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, int P, int M, int O,
-                    const double *theta, const uint8_t *theta_const, const double *pixels_yx,
-                    const int64_t *pose_ids, const int64_t *point_ids, slam_ba **out, bool ctx_mem = false)
+// dynamic LDS of k_band_solve for Ps block columns of half-bandwidth hb (n = 6 P: the damping / solution vectors span every pose)
+static size_t band_lds_bytes(int n, int Ps, int hb)
 {
+    const size_t band_fixed = (3 * (size_t)n + 36 * (size_t)Ps) * 8;      // x, damp, chat, L_kk^-1 of every column
+    size_t band_lds = band_fixed + ((size_t)(hb + 1) * (hb + 1) * BS_WS + (size_t)(hb + 1) * (6 + BS_WS + 6) + 8 + 36 + 56) * 8 + (size_t)BS_PF * BS_PT * 8;
+    if (hb * 6 <= 58) {      // narrow bands: room to stage the G blocks of (up to) all back-substitution steps, at least one
+        const size_t want = band_fixed + (size_t)Ps * hb * 36 * 8, least = band_fixed + (size_t)hb * 36 * 8;
+        band_lds = std::max(band_lds, std::max(std::min(want, (size_t)150 * 1024), least));
+    }
+    return band_lds;
+}
+
+// A pose order in which the reduced camera system is block-banded, for windows that are not in the caller's order: a loop closure
+// (the first and the last key-frames of the window share map points, map_manager.jl:300-449) turns the covisibility chain into a ring, and
+// a ring of half-bandwidth h is a band of half-bandwidth ~2 h once it is folded (c, c - 1, c + 1, c - 2, ...).  Candidates, judged by the
+// half-bandwidth of the FREE poses' covisibility graph (the constant poses go first: they have no block in the system and only widen the
+// span between free ones): the caller's order, every fold of it, Cuthill-McKee from a pose of lowest degree and its reverse.  Returns
+// false if none fits the banded solver.  Host work: O(observations) + O(poses x edges); only windows headed for the general path get here.
+static bool ba_pose_order(int P, int M, int O, const uint8_t *theta_const, const int64_t *pose_ids, const int64_t *point_ids, std::vector<int> &order)
+{
+    std::vector<int> fidx(P, -1), fr;
+    for (int p = 0; p < P; p++) if (!theta_const[p]) { fidx[p] = (int)fr.size(); fr.push_back(p); }
+    const int F = (int)fr.size();
+    if (F < 3) return false;
+    // the free observers of every point (counting sort by point), then the graph: an edge per pair of free poses that share a point
+    std::vector<int> st(M + 1, 0);
+    for (int i = 0; i < O; i++) if (fidx[pose_ids[i] - 1] >= 0) st[point_ids[i]]++;
+    for (int j = 0; j < M; j++) st[j + 1] += st[j];
+    std::vector<int> lst(st[M]), fill(st.begin(), st.end() - 1);
+    for (int i = 0; i < O; i++) { const int f = fidx[pose_ids[i] - 1]; if (f >= 0) lst[fill[point_ids[i] - 1]++] = f; }
+    std::vector<uint8_t> adj((size_t)F * F, 0);
+    for (int j = 0; j < M; j++) {
+        const int a0 = st[j], a1 = st[j + 1], k = a1 - a0;
+        if (j > 0 && st[j] - st[j - 1] == k && std::equal(lst.begin() + a0, lst.begin() + a1, lst.begin() + st[j - 1])) continue;   // same observers as the point before
+        for (int a = a0; a < a1; a++)
+            for (int b = a0; b < a1; b++) adj[(size_t)lst[a] * F + lst[b]] = 1;
+    }
+    std::vector<int2> edges; std::vector<int> deg(F, 0);
+    for (int a = 0; a < F; a++)
+        for (int b = a + 1; b < F; b++) if (adj[(size_t)a * F + b]) { edges.push_back(make_int2(a, b)); deg[a]++; deg[b]++; }
+    std::vector<int> pos(F), cand(F), best;
+    int best_bw = 1 << 30;
+    auto judge = [&]() {                                       // cand[k] = free pose at position k
+        for (int k = 0; k < F; k++) pos[cand[k]] = k;
+        int bw = 0;
+        for (const int2 &e : edges) bw = std::max(bw, std::abs(pos[e.x] - pos[e.y]));
+        if (bw < best_bw) { best_bw = bw; best = cand; }
+    };
+    for (int k = 0; k < F; k++) cand[k] = k;
+    judge();
+    for (int c = 0; c < F; c++) {                              // folds: c, c - 1, c + 1, c - 2, ... around the ring
+        for (int k = 0; k < F; k++) cand[k] = ((k & 1 ? c - (k + 1) / 2 : c + k / 2) % F + F) % F;
+        judge();
+    }
+    {   // Cuthill-McKee (neighbours by ascending degree), every component from its pose of lowest degree; then reversed
+        std::vector<uint8_t> seen(F, 0); std::vector<int> q; q.reserve(F);
+        while ((int)q.size() < F) {
+            int s0 = -1;
+            for (int a = 0; a < F; a++) if (!seen[a] && (s0 < 0 || deg[a] < deg[s0])) s0 = a;
+            seen[s0] = 1; size_t head = q.size(); q.push_back(s0);
+            while (head < q.size()) {
+                const int u = q[head++]; const size_t n0 = q.size();
+                for (int v = 0; v < F; v++) if (!seen[v] && adj[(size_t)u * F + v]) { seen[v] = 1; q.push_back(v); }
+                std::stable_sort(q.begin() + n0, q.end(), [&](int x, int y) { return deg[x] < deg[y]; });
+            }
+        }
+        cand = q; judge();
+        std::reverse(cand.begin(), cand.end()); judge();
+    }
+    const int hbq = std::min(std::max(best_bw, 1), F - 1);
+    if (best_bw > BS_MAXHB || !sg_fold_fits(best_bw) || band_lds_bytes(6 * P, F, hbq) > 150 * 1024) return false;
+    order.clear();
+    for (int p = 0; p < P; p++) if (theta_const[p]) order.push_back(p);
+    for (int k = 0; k < F; k++) order.push_back(fr[best[k]]);
+    return true;
+}
+
+static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, int P, int M, int O,
+                    const double *theta, const uint8_t *theta_const_in, const double *pixels_yx,
+                    const int64_t *pose_ids, const int64_t *point_ids, slam_ba **out, bool ctx_mem = false, bool may_reorder = false)
+{
+    const uint8_t *theta_const = theta_const_in;
     ARG_TRY(ctx, P > 0 && 6 * P <= SOLVE_MAX_N && M >= 0 && O >= 0 && theta != nullptr && theta_const != nullptr);
     ARG_TRY(ctx, O == 0 || (pixels_yx != nullptr && pose_ids != nullptr && point_ids != nullptr));
     for (int i = 0; i < O; i++) {
@@ -2068,16 +2147,31 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     const int n = 6 * P;
     // --- host-side structure.  Map points sorted by (first free observing pose f, id); observations sorted by point in
     //     that order (stable).  hb = widest span of free observers of one point = block half-bandwidth of S.
-    std::vector<int> cnt(M, 0), pfirst(M, P), plast(M, -1), pany(M, P);
-    for (int i = 0; i < O; i++) {
-        const int j = (int)point_ids[i] - 1, p = (int)pose_ids[i] - 1;
-        cnt[j]++; pany[j] = std::min(pany[j], p);
-        if (!theta_const[p]) { pfirst[j] = std::min(pfirst[j], p); plast[j] = std::max(plast[j], p); }
-    }
+    std::vector<int> cnt(M), pfirst(M), plast(M), pany(M), new_of;      // new_of: the caller's pose -> the solver's (empty: the same)
+    std::vector<uint8_t> const_perm;
+    auto lab = [&](int64_t id) { return new_of.empty() ? (int)id - 1 : new_of[id - 1]; };
     int hb = 0;
-    for (int j = 0; j < M; j++) {
-        if (plast[j] >= 0) hb = std::max(hb, plast[j] - pfirst[j]);
-        else pfirst[j] = pany[j] < P ? pany[j] : 0;          // no free observer: any window will do (it gets no slot)
+    auto spans = [&]() {
+        std::fill(cnt.begin(), cnt.end(), 0); std::fill(pfirst.begin(), pfirst.end(), P); std::fill(plast.begin(), plast.end(), -1); std::fill(pany.begin(), pany.end(), P);
+        for (int i = 0; i < O; i++) {
+            const int j = (int)point_ids[i] - 1, p = lab(pose_ids[i]);
+            cnt[j]++; pany[j] = std::min(pany[j], p);
+            if (!theta_const[p]) { pfirst[j] = std::min(pfirst[j], p); plast[j] = std::max(plast[j], p); }
+        }
+        hb = 0;
+        for (int j = 0; j < M; j++) {
+            if (plast[j] >= 0) hb = std::max(hb, plast[j] - pfirst[j]);
+            else pfirst[j] = pany[j] < P ? pany[j] : 0;          // no free observer: any window will do (it gets no slot)
+        }
+    };
+    spans();
+    static const bool no_reorder = getenv("SLAMHIP_BA_NO_REORDER") != nullptr;      // (measurement knob)
+    if (may_reorder && !no_reorder && M > 0 && O > 0 && (hb > BS_MAXHB || !sg_fold_fits(hb)) && ba_pose_order(P, M, O, theta_const_in, pose_ids, point_ids, ba->pose_order)) {
+        // not banded in the caller's pose order, banded in another one: the solver works on relabelled poses, ba_download restores the order
+        new_of.resize(P); const_perm.resize(P);
+        for (int k = 0; k < P; k++) { new_of[ba->pose_order[k]] = k; const_perm[k] = theta_const_in[ba->pose_order[k]]; }
+        theta_const = const_perm.data();
+        spans();
     }
     ba->hb = hb;
     {   int f0 = P, f1 = -1;
@@ -2095,7 +2189,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     std::vector<double> pix(2 * (size_t)O);
     for (int s = 0; s < O; s++) {
         const int i = ba->perm[s];
-        opose[s] = (int)pose_ids[i] - 1; opoint[s] = (int)point_ids[i] - 1; opk[s] = rank[opoint[s]];
+        opose[s] = lab(pose_ids[i]); opoint[s] = (int)point_ids[i] - 1; opk[s] = rank[opoint[s]];
         pix[s] = pixels_yx[2 * i]; pix[(size_t)O + s] = pixels_yx[2 * i + 1];
     }
     // a map point observed twice by one free pose has no place in a pose block (does not happen in the reference's feeder)
@@ -2104,7 +2198,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
           for (int a = start[k]; a < start[k + 1]; a++) {
               const int p = opose[a];
               if (theta_const[p]) continue;
-              if (seen[p] == k) { delete ba; return slam_fail(ctx, SLAM_ERR_ARG, "slam_ba: map point %d is observed twice by pose %d", pt_id[k] + 1, p + 1); }
+              if (seen[p] == k) { delete ba; return slam_fail(ctx, SLAM_ERR_ARG, "slam_ba: map point %d is observed twice by pose %d", pt_id[k] + 1, (new_of.empty() ? p : ba->pose_order[p]) + 1); }
               seen[p] = k;
           } }
     // --- point groups of k_schur_groups: same f, <= SG_SB points, <= SG_OB observations; evenly sized within one f
@@ -2226,7 +2320,9 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     char *stage = nullptr;
     if (ctx_mem) { const int rcs = slam_pinned(ctx, up_end, (void **)&stage); if (rcs) return rcs; }
 #define UP(o, src, bytes) do { if ((bytes) > 0) { if (stage) memcpy(stage + (o), (src), (bytes)); else HIP_TRY(ctx, hipMemcpyAsync((void *)(A + (o)), (src), (bytes), hipMemcpyHostToDevice, st)); } } while (0)
-    UP(o_pose, theta, (size_t)n * 8); UP(o_pts, theta + n, (size_t)3 * M * 8);
+    std::vector<double> pose_perm;
+    if (!new_of.empty()) { pose_perm.resize(n); for (int k = 0; k < P; k++) memcpy(&pose_perm[6 * k], theta + 6 * ba->pose_order[k], 48); }
+    UP(o_pose, new_of.empty() ? theta : pose_perm.data(), (size_t)n * 8); UP(o_pts, theta + n, (size_t)3 * M * 8);
     UP(o_const, theta_const, (size_t)P); UP(o_pix, pix.data(), (size_t)2 * O * 8);
     UP(o_opose, opose.data(), (size_t)O * 4); UP(o_opoint, opoint.data(), (size_t)O * 4); UP(o_start, start.data(), (size_t)(M + 1) * 4);
     UP(o_pairs, pairs.data(), npairs * 8); UP(o_bs, blk_start.data(), (size_t)(nblk + 1) * 4); UP(o_bpq, blk_pq.data(), (size_t)nblk * 8);
@@ -2281,12 +2377,7 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
     static const bool no_band = getenv("SLAMHIP_NO_BAND") != nullptr;
     const int Ps = ba->pspan > 0 ? ba->pspan : d.P, p0 = ba->pspan > 0 ? ba->p0 : 0;       // the poses the banded solve covers: first .. last free pose
     const int hb = std::min(std::max(ba->hb, 1), Ps - 1);      // >= 1: the factor wave reads block row k + 1 while row k + 1 + hb enters the ring
-    const size_t band_fixed = (3 * (size_t)n + 36 * (size_t)Ps) * 8;      // x, damp, chat, L_kk^-1 of every column
-    size_t band_lds = band_fixed + ((size_t)(hb + 1) * (hb + 1) * BS_WS + (size_t)(hb + 1) * (6 + BS_WS + 6) + 8 + 36 + 56) * 8 + (size_t)BS_PF * BS_PT * 8;
-    if (hb * 6 <= 58) {      // narrow bands: room to stage the G blocks of (up to) all back-substitution steps, at least one
-        const size_t want = band_fixed + (size_t)Ps * hb * 36 * 8, least = band_fixed + (size_t)hb * 36 * 8;
-        band_lds = std::max(band_lds, std::max(std::min(want, (size_t)150 * 1024), least));
-    }
+    const size_t band_lds = band_lds_bytes(n, Ps, hb);
     if (!no_band && hb <= BS_MAXHB && band_lds <= 150 * 1024) {
         BandArgs B; B.S = red + (size_t)6 * p0 * (n + 1); B.g = red + (size_t)n * n + 6 * p0; B.ud = red + (size_t)n * n + n + 6 * p0; B.Lg = ba->band; B.nb = Ps; B.hb = hb; B.p0 = p0;
         B.inv_delta_host = inv_delta; B.fail = ba->chol_flag; B.lds_bytes = (int)band_lds;
@@ -2474,6 +2565,37 @@ int slam_ba_lm_state(slam_ctx *ctx, slam_ba *ba, double *out8)
 }
 // block half-bandwidth of this shard's reduced system (S_pq = 0 for |p - q| > hb); the all-reduced system has the maximum over
 // the ranks, which the driver sets on every rank before the first solve
+// host only: the pose order slam_local_ba solves in, and the block half-bandwidth of the reduced camera system in that order
+int slam_ba_plan_order(int P, int M, int O, const uint8_t *theta_const, const int64_t *pose_ids, const int64_t *point_ids, int32_t *order_out, int *hb_out)
+{
+    if (P <= 0 || M < 0 || O < 0 || !theta_const || (O > 0 && (!pose_ids || !point_ids))) return SLAM_ERR_ARG;
+    for (int i = 0; i < O; i++) if (pose_ids[i] < 1 || pose_ids[i] > P || point_ids[i] < 1 || point_ids[i] > M) return SLAM_ERR_ARG;
+    std::vector<int> new_of(P), order(P);
+    for (int p = 0; p < P; p++) new_of[p] = order[p] = p;
+    auto halfband = [&]() {
+        std::vector<int> lo(M, P), hi(M, -1);
+        for (int i = 0; i < O; i++) {
+            if (theta_const[pose_ids[i] - 1]) continue;
+            const int j = (int)point_ids[i] - 1, q = new_of[pose_ids[i] - 1];
+            lo[j] = std::min(lo[j], q); hi[j] = std::max(hi[j], q);
+        }
+        int hb = 0;
+        for (int j = 0; j < M; j++) if (hi[j] >= 0) hb = std::max(hb, hi[j] - lo[j]);
+        return hb;
+    };
+    int hb = halfband(), reordered = 0;
+    static const bool no_reorder = getenv("SLAMHIP_BA_NO_REORDER") != nullptr;
+    std::vector<int> cand;
+    if (!no_reorder && M > 0 && O > 0 && (hb > BS_MAXHB || !sg_fold_fits(hb)) && ba_pose_order(P, M, O, theta_const, pose_ids, point_ids, cand)) {
+        order = cand;
+        for (int k = 0; k < P; k++) new_of[order[k]] = k;
+        hb = halfband(); reordered = 1;
+    }
+    if (order_out) for (int k = 0; k < P; k++) order_out[k] = order[k];
+    if (hb_out) *hb_out = hb;
+    return reordered;
+}
+
 int slam_ba_halfband(const slam_ba *ba) { return ba ? ba->hb : SLAM_ERR_ARG; }
 int slam_ba_set_halfband(slam_ba *ba, int hb) { if (!ba || hb < 0) return SLAM_ERR_ARG; ba->hb = hb; return SLAM_OK; }
 
@@ -2503,7 +2625,13 @@ static int ba_download(slam_ctx *ctx, slam_ba *ba, double *theta, uint8_t *outli
             HIP_TRY(ctx, hipMemcpyAsync(&cur, &d.st->cur, sizeof cur, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, slam_stream_wait(ctx->stream));
         }
-        HIP_TRY(ctx, hipMemcpyAsync(theta, cur ? d.pose_t : d.pose, (size_t)d.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (ba->pose_order.empty()) HIP_TRY(ctx, hipMemcpyAsync(theta, cur ? d.pose_t : d.pose, (size_t)d.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        else {                                               // the solver's pose order -> the caller's
+            std::vector<double> tmp(d.n);
+            HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), cur ? d.pose_t : d.pose, (size_t)d.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+            for (int k = 0; k < d.P; k++) memcpy(theta + 6 * ba->pose_order[k], &tmp[6 * k], 48);
+        }
         if (d.M > 0) HIP_TRY(ctx, hipMemcpyAsync(theta + d.n, cur ? d.pts_t : d.pts, (size_t)3 * d.M * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     std::vector<uint8_t> tmp;
@@ -2524,7 +2652,7 @@ int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy, int
     slam_ba *ba = nullptr;
     static const bool host_times = getenv("SLAMHIP_BA_HOSTTIME") != nullptr;
     const auto tw0 = std::chrono::steady_clock::now();
-    int rc = ba_setup(ctx, fx, fy, cx, cy, P, M, O, theta, theta_const, pixels_yx, pose_ids, point_ids, &ba, true);
+    int rc = ba_setup(ctx, fx, fy, cx, cy, P, M, O, theta, theta_const, pixels_yx, pose_ids, point_ids, &ba, true, true);
     if (rc) return rc;
     const auto tw1 = std::chrono::steady_clock::now();
     hipStream_t st = ctx->stream;

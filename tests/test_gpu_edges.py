@@ -107,6 +107,26 @@ def test_ba_wide_windows_fall_back_to_pair_lists_and_the_tiled_solve(slam, orc, 
     _ba_vs_oracle(slam, orc, s3, "many observers")
 
 
+def test_ba_loop_closure_windows_are_solved_in_a_folded_pose_order(slam, orc, syn):
+    """A window whose first and last key-frames share map points is a ring, not a band: slam_local_ba relabels the poses (fold /
+    Cuthill-McKee, constant poses first: tests/test_ba_plan_order.py), solves on the banded path and hands theta back in the caller's
+    order.  Against the oracle, which solves in the caller's order: same outliers, iterations, cost, parameters."""
+    for P, k_loop, n_const in ((30, 5, 1), (40, 3, 2), (24, 5, 1), (50, 5, 1)):
+        s = syn.ba_scene_loop(P=P, M=30 * P, seed=400 + P, n_loop=120, k_loop=k_loop, n_const=n_const)
+        cache = slam.LocalBACache(s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+        _, hb, reordered = slam.ba_plan_order(cache)
+        assert reordered and hb <= 20, (P, hb)
+        _ba_vs_oracle(slam, orc, s, ("loop", P))
+    # constant poses between the free ones: span 21 in the caller's order, 7 among the free poses
+    P = 45
+    s = syn.ba_scene(P=P, M=900, seed=44, obs_per_point=22)
+    const = np.ones(P, dtype=np.uint8); const[::3] = 0
+    s["theta_const"] = const
+    cache = slam.LocalBACache(s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+    assert slam.ba_plan_order(cache)[1:] == (7, True)
+    _ba_vs_oracle(slam, orc, s, "interleaved constants")
+
+
 def test_ba_twisted_factorisation_split_sizes(slam, orc, syn):
     """Windows of >= max(2 (hb + 1), hb + 8) poses are factored from both ends (two workgroups, hb middle poses merged): the smallest such windows
     for three band widths (10, 6 and 2 observers per point), odd / even splits, windows on both sides of the threshold."""
@@ -191,3 +211,14 @@ def test_ba_wide_bands_take_the_banded_solver_too(slam, orc, syn):
     for P, opp in ((24, 11), (30, 15), (26, 20), (40, 21)):
         s = syn.ba_scene(P=P, M=50 * P, seed=200 + opp, obs_per_point=opp)
         _ba_vs_oracle(slam, orc, s, (P, opp))
+
+
+def test_ba_every_band_width_of_the_grouped_build(slam, orc, syn):
+    """Every half-bandwidth 9 .. 20 (the grouped build folds 8 / 4 / 2 point subsets; at hb = 15 .. 18 a subset is 192 lanes and a
+    quarter of the workgroup belongs to no subset -- those widths failed until round 3), and a single workgroup on more than 85 poses
+    (damping entries beyond the workgroup's 512 threads)."""
+    for opp in range(10, 22):
+        s = syn.ba_scene(P=24, M=600, seed=300 + opp, obs_per_point=opp)
+        _ba_vs_oracle(slam, orc, s, (24, opp))
+    s = syn.ba_scene(P=96, M=2400, seed=333, obs_per_point=12)
+    _ba_vs_oracle(slam, orc, s, (96, 12))
