@@ -158,6 +158,41 @@ def ba_scene_loop(P=50, M=10000, seed=0, n_loop=1500, k_loop=5, **kw):
     return s
 
 
+def ba_scene_ragged(seed):
+    """A random window for fuzzing the solver's paths: 2-40 poses, 2-24 observers per point of which 0 / 15 / 40 % are dropped at
+    random (ragged tracks: gaps, points with two observations), constant poses at the front, anywhere, or most of the window (the
+    reference's shape), sometimes loop-closure points, sometimes a shuffled observation order."""
+    rng = np.random.default_rng(seed)
+    P = int(rng.integers(2, 41)); k = int(rng.integers(2, min(P, 24) + 1)); M = int(rng.integers(20, 40 * P))
+    loop = P >= 16 and rng.random() < 0.3
+    if loop:
+        s = ba_scene_loop(P=P, M=M, seed=seed, n_loop=int(rng.integers(5, 80)), k_loop=int(rng.integers(2, 6)), obs_per_point=k)
+    else:
+        s = ba_scene(P=P, M=M, seed=seed, obs_per_point=k)
+    M = s["M"]
+    const = np.zeros(P, dtype=np.uint8)
+    mode = rng.integers(0, 4)
+    if mode == 0: const[0] = 1
+    elif mode == 1: const[rng.random(P) < 0.3] = 1
+    elif mode == 2: const[: int(rng.integers(1, P))] = 1
+    else: const[rng.random(P) < 0.7] = 1
+    if const.all(): const[int(rng.integers(0, P))] = 0
+    # gauge: at least one constant pose unless the window is tiny
+    if not const.any(): const[0] = 1
+    s["theta_const"] = const
+    # the perturbation of ba_scene moved only its own free poses: fine either way
+    keep = rng.random(s["O"]) >= rng.choice([0.0, 0.15, 0.4])
+    # every point keeps at least two observations
+    cnt = np.bincount(s["point_ids"][keep], minlength=M + 1)
+    short = np.isin(s["point_ids"], np.where(cnt < 2)[0])
+    keep |= short
+    order = np.where(keep)[0]
+    if rng.random() < 0.5: order = rng.permutation(order)
+    for key in ("pose_ids", "point_ids"): s[key] = s[key][order]
+    s["pixels_yx"] = np.ascontiguousarray(s["pixels_yx"][order]); s["O"] = len(order)
+    return s
+
+
 def ba_halfband(s):
     """block half-bandwidth of the reduced camera system of a scene: widest span of FREE observers of one map point"""
     free = np.asarray(s["theta_const"])[s["pose_ids"] - 1] == 0

@@ -127,6 +127,15 @@ def test_ba_loop_closure_windows_are_solved_in_a_folded_pose_order(slam, orc, sy
     _ba_vs_oracle(slam, orc, s, "interleaved constants")
 
 
+def test_ba_ragged_windows_fuzz(slam, orc, syn):
+    """Sixty random windows (syn.ba_scene_ragged: dropped observations, constant poses anywhere, loop closures, shuffled order) against
+    the oracle -- every solver path the dispatch can take (twisted / single-workgroup / wide band, relabelled poses, pair lists).
+    scripts/ba_fuzz.py runs more of them."""
+    for seed in range(60):
+        s = syn.ba_scene_ragged(seed)
+        _ba_vs_oracle(slam, orc, s, ("ragged", seed))
+
+
 def test_ba_twisted_factorisation_split_sizes(slam, orc, syn):
     """Windows of >= max(2 (hb + 1), hb + 8) poses are factored from both ends (two workgroups, hb middle poses merged): the smallest such windows
     for three band widths (10, 6 and 2 observers per point), odd / even splits, windows on both sides of the threshold."""
