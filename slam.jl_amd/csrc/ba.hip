@@ -2137,11 +2137,6 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     const uint8_t *theta_const = theta_const_in;
     ARG_TRY(ctx, P > 0 && 6 * P <= SOLVE_MAX_N && M >= 0 && O >= 0 && theta != nullptr && theta_const != nullptr);
     ARG_TRY(ctx, O == 0 || (pixels_yx != nullptr && pose_ids != nullptr && point_ids != nullptr));
-    for (int i = 0; i < O; i++) {
-        if (pose_ids[i] < 1 || pose_ids[i] > P || point_ids[i] < 1 || point_ids[i] > M)
-            return slam_fail(ctx, SLAM_ERR_ARG, "slam_ba: observation %d has pose id %lld / point id %lld out of range", i,
-                             (long long)pose_ids[i], (long long)point_ids[i]);
-    }
     slam_ba *ba = new slam_ba();
     ba->device = ctx->device;
     const int n = 6 * P;
@@ -2150,10 +2145,11 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     std::vector<int> cnt(M), pfirst(M), plast(M), pany(M), new_of;      // new_of: the caller's pose -> the solver's (empty: the same)
     std::vector<uint8_t> const_perm;
     auto lab = [&](int64_t id) { return new_of.empty() ? (int)id - 1 : new_of[id - 1]; };
-    int hb = 0;
-    auto spans = [&]() {
+    int hb = 0, bad_obs = -1;
+    auto spans = [&]() {                                     // (the first pass also checks the ids: one walk over the observations, not two)
         std::fill(cnt.begin(), cnt.end(), 0); std::fill(pfirst.begin(), pfirst.end(), P); std::fill(plast.begin(), plast.end(), -1); std::fill(pany.begin(), pany.end(), P);
         for (int i = 0; i < O; i++) {
+            if (pose_ids[i] < 1 || pose_ids[i] > P || point_ids[i] < 1 || point_ids[i] > M) { bad_obs = i; return; }
             const int j = (int)point_ids[i] - 1, p = lab(pose_ids[i]);
             cnt[j]++; pany[j] = std::min(pany[j], p);
             if (!theta_const[p]) { pfirst[j] = std::min(pfirst[j], p); plast[j] = std::max(plast[j], p); }
@@ -2165,6 +2161,11 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
         }
     };
     spans();
+    if (bad_obs >= 0) {
+        const long long bp = pose_ids[bad_obs], bl = point_ids[bad_obs];
+        delete ba;
+        return slam_fail(ctx, SLAM_ERR_ARG, "slam_ba: observation %d has pose id %lld / point id %lld out of range", bad_obs, bp, bl);
+    }
     static const bool no_reorder = getenv("SLAMHIP_BA_NO_REORDER") != nullptr;      // (measurement knob)
     if (may_reorder && !no_reorder && M > 0 && O > 0 && (hb > BS_MAXHB || !sg_fold_fits(hb)) && ba_pose_order(P, M, O, theta_const_in, pose_ids, point_ids, ba->pose_order)) {
         // not banded in the caller's pose order, banded in another one: the solver works on relabelled poses, ba_download restores the order
@@ -2183,24 +2184,33 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
       for (int p = 0; p < P; p++) fb[p + 1] += fb[p];
       for (int j = 0; j < M; j++) { const int k = fb[pfirst[j]]++; pt_id[k] = j; rank[j] = k; } }
     for (int k = 0; k < M; k++) start[k + 1] = start[k] + cnt[pt_id[k]];
+    // The per-observation arrays (sorted by point): ONE walk over the caller's observations -- the sorted position of observation i is the
+    // next free one of its point -- writing straight into the pinned upload block when that exists by then (slam_local_ba on the grouped
+    // path: the arena's layout does not depend on these arrays), into host vectors otherwise (the pair lists are built from them).
+    // The walk also finds a map point observed twice by one free pose: it has no place in a pose block (does not happen in the
+    // reference's feeder).  At O = 4e5 the set-up took 3.4 ms of an 8 ms call: a pass for the ids, one for the permutation, one gathering
+    // through it, one for the check, and a copy of everything into the pinned block.
     ba->perm.assign(O, 0);
-    { std::vector<int> fill(start.begin(), start.end() - 1); for (int i = 0; i < O; i++) ba->perm[fill[rank[point_ids[i] - 1]]++] = i; }
-    std::vector<int> opose(O), opoint(O), opk(O);
-    std::vector<double> pix(2 * (size_t)O);
-    for (int s = 0; s < O; s++) {
-        const int i = ba->perm[s];
-        opose[s] = lab(pose_ids[i]); opoint[s] = (int)point_ids[i] - 1; opk[s] = rank[opoint[s]];
-        pix[s] = pixels_yx[2 * i]; pix[(size_t)O + s] = pixels_yx[2 * i + 1];
-    }
-    // a map point observed twice by one free pose has no place in a pose block (does not happen in the reference's feeder)
-    { std::vector<int> seen(P, -1);
-      for (int k = 0; k < M; k++)
-          for (int a = start[k]; a < start[k + 1]; a++) {
-              const int p = opose[a];
-              if (theta_const[p]) continue;
-              if (seen[p] == k) { delete ba; return slam_fail(ctx, SLAM_ERR_ARG, "slam_ba: map point %d is observed twice by pose %d", pt_id[k] + 1, (new_of.empty() ? p : ba->pose_order[p]) + 1); }
-              seen[p] = k;
-          } }
+    int twice_pt = -1, twice_pose = -1;
+    auto fill_obs = [&](int *opose, int *opoint, int *opk, double *pix) {
+        std::vector<int> fill(start.begin(), start.end() - 1), seen((size_t)P, -1);     // seen[p]: the last point (sorted position) free pose p observed
+        for (int i = 0; i < O; i++) {
+            const int j = (int)point_ids[i] - 1, k = rank[j], s = fill[k]++;
+            ba->perm[s] = i;
+            opose[s] = lab(pose_ids[i]); opoint[s] = j; opk[s] = k;
+            pix[s] = pixels_yx[2 * i]; pix[(size_t)O + s] = pixels_yx[2 * i + 1];
+        }
+        for (int k = 0; k < M && twice_pt < 0; k++)
+            for (int a = start[k]; a < start[k + 1]; a++) {
+                const int p = opose[a];
+                if (theta_const[p]) continue;
+                if (seen[p] == k) { twice_pt = pt_id[k]; twice_pose = new_of.empty() ? p : ba->pose_order[p]; break; }
+                seen[p] = k;
+            }
+    };
+    auto twice_error = [&]() { return slam_fail(ctx, SLAM_ERR_ARG, "slam_ba: map point %d is observed twice by pose %d", twice_pt + 1, twice_pose + 1); };
+    std::vector<int> v_opose, v_opoint, v_opk;
+    std::vector<double> v_pix;
     // --- point groups of k_schur_groups: same f, <= SG_SB points, <= SG_OB observations; evenly sized within one f
     static const bool no_groups = getenv("SLAMHIP_NO_GROUPS") != nullptr;
     bool grouped = !no_groups && hb <= BS_MAXHB && M > 0 && O > 0 && sg_fold_fits(hb);
@@ -2223,6 +2233,15 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
         fgrp[P] = (int)grp.size();
     }
     ba->grouped = grouped;
+    const int *opose = nullptr;                              // sorted observation -> pose, host copy (needed by the pair lists)
+    bool filled = false;
+    if (!grouped || !ctx_mem) {
+        v_opose.resize(O); v_opoint.resize(O); v_opk.resize(O); v_pix.resize(2 * (size_t)O);
+        fill_obs(v_opose.data(), v_opoint.data(), v_opk.data(), v_pix.data());
+        filled = true;
+        if (twice_pt >= 0) { delete ba; return twice_error(); }
+        opose = v_opose.data();
+    }
     // --- pair lists sorted by upper pose block (p <= q), both poses free: only where the groups do not apply
     std::vector<int2> pairs; std::vector<int> blk_start; std::vector<int2> blk_pq;
     size_t npairs = 0;
@@ -2323,10 +2342,14 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     std::vector<double> pose_perm;
     if (!new_of.empty()) { pose_perm.resize(n); for (int k = 0; k < P; k++) memcpy(&pose_perm[6 * k], theta + 6 * ba->pose_order[k], 48); }
     UP(o_pose, new_of.empty() ? theta : pose_perm.data(), (size_t)n * 8); UP(o_pts, theta + n, (size_t)3 * M * 8);
-    UP(o_const, theta_const, (size_t)P); UP(o_pix, pix.data(), (size_t)2 * O * 8);
-    UP(o_opose, opose.data(), (size_t)O * 4); UP(o_opoint, opoint.data(), (size_t)O * 4); UP(o_start, start.data(), (size_t)(M + 1) * 4);
+    UP(o_const, theta_const, (size_t)P); UP(o_start, start.data(), (size_t)(M + 1) * 4);
+    if (filled) { UP(o_pix, v_pix.data(), (size_t)2 * O * 8); UP(o_opose, v_opose.data(), (size_t)O * 4); UP(o_opoint, v_opoint.data(), (size_t)O * 4); UP(o_opk, v_opk.data(), (size_t)O * 4); }
+    else {                                                   // (grouped && ctx_mem: the pinned block exists) written in place
+        fill_obs((int *)(stage + o_opose), (int *)(stage + o_opoint), (int *)(stage + o_opk), (double *)(stage + o_pix));
+        if (twice_pt >= 0) return twice_error();             // (the guard releases the solver object)
+    }
     UP(o_pairs, pairs.data(), npairs * 8); UP(o_bs, blk_start.data(), (size_t)(nblk + 1) * 4); UP(o_bpq, blk_pq.data(), (size_t)nblk * 8);
-    UP(o_ptid, pt_id.data(), (size_t)M * 4); UP(o_opk, opk.data(), (size_t)O * 4); UP(o_grp, grp.data(), (size_t)ngrp * 16); UP(o_fgrp, fgrp.data(), (size_t)(P + 1) * 4);
+    UP(o_ptid, pt_id.data(), (size_t)M * 4); UP(o_grp, grp.data(), (size_t)ngrp * 16); UP(o_fgrp, fgrp.data(), (size_t)(P + 1) * 4);
 #undef UP
     if (stage) HIP_TRY(ctx, hipMemcpyAsync(A, stage, up_end, hipMemcpyHostToDevice, st));      // pinned -> device: one DMA, nothing to wait for
     HIP_TRY(ctx, hipMemsetAsync(A + up_end, 0, zero_end - up_end, st));                         // LM state, flags, outlier marks

@@ -136,6 +136,26 @@ def test_ba_ragged_windows_fuzz(slam, orc, syn):
         _ba_vs_oracle(slam, orc, s, ("ragged", seed))
 
 
+def test_ba_refuses_bad_ids_and_repeated_observers(slam, syn):
+    """an id out of range, or a map point observed twice by one FREE pose (no place in a pose block), is an argument error on both set-up
+    paths (the arrays written in place into the pinned block: banded windows; host vectors: the general path); theta stays untouched"""
+    import pytest
+    for opp in (6, 24):                                                           # banded / general path
+        s = syn.ba_scene(P=26, M=300, seed=21, obs_per_point=opp)
+        for what in ("pose id", "point id", "twice"):
+            pose_ids, point_ids = s["pose_ids"].copy(), s["point_ids"].copy()
+            if what == "pose id": pose_ids[17] = 27
+            elif what == "point id": point_ids[40] = 0
+            else:
+                i = int(np.where(s["theta_const"][pose_ids - 1] == 0)[0][5]); j = i + 1 if point_ids[i + 1] == point_ids[i] else i - 1
+                pose_ids[j] = pose_ids[i]                                         # same point, same free pose twice
+            cache = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], pose_ids, point_ids)
+            with pytest.raises(slam.SlamHipError, match="out of range" if what != "twice" else "observed twice"):
+                slam.bundle_adjustment_(cache, s["cam"])
+            assert np.array_equal(cache.theta, s["theta0"])
+    # twice by a CONSTANT pose is allowed (tests above: "many observers")
+
+
 def test_ba_twisted_factorisation_split_sizes(slam, orc, syn):
     """Windows of >= max(2 (hb + 1), hb + 8) poses are factored from both ends (two workgroups, hb middle poses merged): the smallest such windows
     for three band widths (10, 6 and 2 observers per point), odd / even splits, windows on both sides of the threshold."""
