@@ -1971,7 +1971,9 @@ __global__ __launch_bounds__(256) void k_control(BADev d, int mode, int nb_obs, 
         if (threadIdx.x == 0) { s->ssr = t; if (out4) out4[0] = t; }
         return;
     }
-    if (lm && s->converged) return;
+    const int paced = lm >> 1;                               // bit 1: the LM state lives on the device (device-paced paths): nothing runs after convergence
+    lm &= 1;
+    if ((lm || paced) && s->converged) return;               // (the sharded path used to overwrite trial_ssr / maxdx with this shard's stale LOCAL sums here)
     const double mx = ctl_max(d.part, nb_pts, sh);
     const double t = ctl_sum(d.part + nb_pts, nb_obs, 2, sh);
     const double p = ctl_sum(d.part + nb_pts + 1, nb_obs, 2, sh);
@@ -2452,12 +2454,12 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
     }
     if (ba->grouped) {
         hipLaunchKernelGGL(k_update_groups, dim3(d.ngrp), dim3(SG_T), 0, st, d, ignore_outliers, use_state);
-        hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 1, d.ngrp, d.ngrp, lm, out4);
+        hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 1, d.ngrp, d.ngrp, lm | (use_state ? 2 : 0), out4);
         return SLAM_OK;
     }
     hipLaunchKernelGGL(k_backsub, dim3(ba->nblocks_pts), dim3(256), 0, st, d, use_state);
     hipLaunchKernelGGL(k_trial, dim3(ba->nblocks_obs), dim3(256), 0, st, d, ignore_outliers, use_state, ba->nblocks_pts);
-    hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 1, ba->nblocks_obs, ba->nblocks_pts, lm, out4);
+    hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 1, ba->nblocks_obs, ba->nblocks_pts, lm | (use_state ? 2 : 0), out4);
     return SLAM_OK;
 }
 

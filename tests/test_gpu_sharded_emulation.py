@@ -136,6 +136,26 @@ def test_two_shards_with_different_half_bandwidths(slam, syn):
     # ADVICE r2 (medium) -- it used to solve with each shard's local band
 
 
+def test_two_shards_on_ragged_windows(slam, syn):
+    """Ragged windows (syn.ba_scene_ragged: dropped observations, constant poses anywhere, loop closures) cut into two shards at an
+    arbitrary point: the shards' local bands and solver paths differ from each other's and from the single solve's (which may reorder
+    the poses), early convergence leaves iterations that do nothing -- decisions, outliers, cost and parameters must still agree.
+    (Seeds 76 ... 145 converge early: the converged state used to pick up each shard's stale LOCAL trial cost.)
+    scripts/ba_shard_fuzz.py runs more."""
+    from slam_jl_amd import sharded_ba
+    for seed in (3, 59, 76, 98, 110, 125, 133, 138, 145):
+        s = syn.ba_scene_ragged(seed)
+        rng = np.random.default_rng(seed)
+        cut = int(rng.integers(1, s["M"] - 1)) if rng.random() < 0.5 else None
+        bounds = [(0, cut), (cut, s["M"])] if cut else sharded_ba.partition_points(s["point_ids"], s["M"], 2)
+        theta, outl, st = _two_shard_ba(slam, s, bounds)
+        ref = _single(slam, s)
+        assert (st["iters_pass1"], st["iters_pass2"]) == (ref.stats["iters_pass1"], ref.stats["iters_pass2"]), seed
+        assert np.array_equal(outl, ref.outliers), seed
+        assert abs(st["ssr_final"] - ref.stats["ssr_final"]) <= 1e-8 * ref.stats["ssr_final"], seed
+        assert np.abs(theta - ref.theta).max() <= 1e-6 * max(1.0, np.abs(ref.theta).max()), seed
+
+
 def test_one_rank_collectives_are_timed(slam, syn):
     """ba_sharded's `collectives_us` (the measured half of worth_sharding's constants): one-rank RCCL all-reduce of the reduce
     buffer + all-gather of the trial costs on the library stream."""
