@@ -15,3 +15,11 @@ def test_frontend_fuzz_short_run():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_frontend.py"), "25", "5000"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "parts ['pyr', 'batch', 'lk', 'detect']: 0 failures" in r.stdout, r.stdout[-3000:]
+
+
+def test_keypoint_set_fuzz_short_run():
+    """scripts/kpset_fuzz.py: key-frame steps on the device-resident lists with random stream counts, shapes and list sizes (empty
+    streams, full lists, a stream with everything culled) against the host protocol and the oracle (560 steps at the end of round 3)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "kpset_fuzz.py"), "15", "7000"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "15 key-frame steps, 0 failures" in r.stdout, r.stdout[-3000:]
