@@ -2,8 +2,9 @@
   pyr     single-image pyramids, random H x W (4 .. 300), levels, sigma, both ctor modes
   batch   batched pyramids with the bandwidth-bound kernel set FORCED on small shapes (SLAMHIP_CK_MIN_MB=0: k_cols_fused, k_iir_rows_ck
           with the fused resize, k_cum_fused), f64 / u8 ingest, target-only builds, S = 1 .. 6
-  lk      fb_tracking with random window sizes (2 .. 11), levels, priors, points on and near the borders
+  lk      fb_tracking with random window sizes (2 .. 14: the three cached instantiations and the uncached path), levels, priors, points on and near the borders
   detect  random shapes, cell sizes, current keypoints (none / few / many / clustered), mask sigma
+  brief   describe with random shapes and keypoints on / next to the borders (dropped ones included)
 python scripts/fuzz_frontend.py [n per part] [seed0] [parts]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +15,7 @@ from oracle import oracle as orc
 PLANES = ("layers", "Iy", "Ix", "Iyy", "Ixx", "Iyx")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-parts = sys.argv[3].split(",") if len(sys.argv) > 3 else ["pyr", "batch", "lk", "detect"]
+parts = sys.argv[3].split(",") if len(sys.argv) > 3 else ["pyr", "batch", "lk", "detect", "brief"]
 fails = 0
 
 
@@ -91,7 +92,7 @@ if "lk" in parts:
     for t in range(n):
         rng = np.random.default_rng(20000 + seed0 + t)
         H, W = int(rng.integers(40, 260)), int(rng.integers(40, 320))
-        levels = int(rng.integers(0, max_levels(H, W) + 1)); window = int(rng.integers(2, 12)); maxd = float(rng.choice([0.5, 1.0, 3.0]))
+        levels = int(rng.integers(0, max_levels(H, W) + 1)); window = int(rng.integers(2, 15)); maxd = float(rng.choice([0.5, 1.0, 3.0]))
         step = (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)))
         L, R, flows = syn.stereo_stream((H, W), 2, int(rng.integers(0, 50)), step, 5.0)
         npts = int(rng.integers(1, 400))
@@ -135,4 +136,24 @@ if "detect" in parts:
         except Exception as ex:
             fail(f"{tag}: {repr(ex)[:200]}")
     print("detect done", flush=True)
+if "brief" in parts:
+    pat = slam.brief_pattern()
+    for t in range(n):
+        rng = np.random.default_rng(40000 + seed0 + t)
+        H, W = int(rng.integers(30, 300)), int(rng.integers(30, 400))
+        img = rand_image(rng, H, W)
+        nk = int(rng.integers(0, 400))
+        kp = np.stack([rng.integers(1, H + 1, nk), rng.integers(1, W + 1, nk)], 1).astype(np.int64)
+        edge = rng.random(nk) < 0.3
+        kp[edge, 0] = rng.choice([1, 2, 15, 16, 17, H - 17, H - 16, H - 15, H - 1, H], edge.sum())
+        edge = rng.random(nk) < 0.3
+        kp[edge, 1] = rng.choice([1, 2, 15, 16, 17, W - 17, W - 16, W - 15, W - 1, W], edge.sum())
+        tag = f"brief seed {40000 + seed0 + t} {H}x{W} keypoints {nk}"
+        try:
+            bits, rc = slam.describe(slam.Extractor(1000, 17, (-(-H // 35), -(-W // 35)), 35), img, kp, pattern=pat)
+            rbits, rrc = orc.describe(img, kp, pat)
+            if not (np.array_equal(rc, rrc) and np.array_equal(bits, rbits)): fail(f"{tag}: {len(rc)} vs {len(rrc)} described")
+        except Exception as ex:
+            fail(f"{tag}: {repr(ex)[:200]}")
+    print("brief done", flush=True)
 print(f"{n} trials per part, parts {parts}: {fails} failures")
