@@ -2218,12 +2218,18 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     bool grouped = !no_groups && hb <= BS_MAXHB && M > 0 && O > 0 && sg_fold_fits(hb);
     std::vector<int4> grp; std::vector<int> fgrp(P + 1, 0);
     if (grouped) {
+        static const int sg_points = [] { const char *v = getenv("SLAMHIP_SG_POINTS"); return v ? atoi(v) : 0; }();      // (measurement knob)
+        // points per group: a small window in full groups occupies a few compute units and each workgroup walks 7 points per subset; with
+        // 16-point groups the reference-shaped window (800 points: 18 -> 50 groups) builds in 0.75 instead of 0.83 ms per 15 iterations,
+        // while anything that already fills the chip gets slower with more, smaller groups (more partials for k_schur_reduce, more than one
+        // round of workgroups: P = 50 +12 % at 40 points per group) -- so: M / 96, between 16 and SG_SB
+        const int sb_eff = sg_points > 0 ? std::min(sg_points, SG_SB) : std::min(std::max((M + 95) / 96, 16), SG_SB);
         int k = 0;
         for (int f = 0; f < P && grouped; f++) {
             fgrp[f] = (int)grp.size();
             int ke = k;
             while (ke < M && pfirst[pt_id[ke]] == f) ke++;
-            const int nf = ke - k, ng = (nf + SG_SB - 1) / SG_SB, tgt = ng ? (nf + ng - 1) / ng : 0;
+            const int nf = ke - k, ng = (nf + sb_eff - 1) / sb_eff, tgt = ng ? (nf + ng - 1) / ng : 0;
             while (k < ke) {
                 int k1 = k, no = 0;
                 while (k1 < ke && k1 - k < tgt && no + cnt[pt_id[k1]] <= SG_OB) { no += cnt[pt_id[k1]]; k1++; }
