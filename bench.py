@@ -192,6 +192,72 @@ class GpuBackend:
             p_.close()
 
 
+class GpuPeriodBackend:
+    """One stereo stream whose next KEY-FRAME PERIOD is built in one batched launch set: a recorded sequence has its next frames at hand,
+    and the library builds S images per launch with the bit-exact kernels (slam_pyr_update_batch_dev) -- the chain-bound single-image
+    kernels of five independent builds in flight leave the GPU mostly idle, one batch of the period's five left frames + the key-frame's
+    right frame costs little more than one image.  Tracking, detection and stereo matching go through the single-image entry points on the
+    batch's member pyramids, every call synchronous, exactly as in GpuBackend; period k + 1 is requested on the build context when
+    period k's first frame is reached (three batches rotate: the last member of period k - 1 is still `prev` then)."""
+
+    def __init__(self, slam, ctx, ctx_build, H, W, left_dev, right_dev, params, extractor, period):
+        self.slam, self.ctx, self.cb, self.params, self.e = slam, ctx, ctx_build, params, extractor
+        self.left, self.right, self.B = left_dev, right_dev, period
+        self.batches = [slam.PyramidBatch((H, W), levels=params.pyramid_levels, S=period + 1, ctx=ctx_build) for _ in range(3)]
+        self.built = [None, None, None]              # marker: the build into that batch is complete
+        self.first = slam.LKPyramid(shape=(H, W), levels=params.pyramid_levels, ctx=ctx)
+        self.i = 0; self.requested = -1
+        self.cur = self.prev = self.rpyr = None
+        self.kf_next = False
+
+    def prime(self, f):
+        self.slam.update_(self.first, None, device_ptr=self.left[f].data_ptr(), sync=True, ctx=self.ctx)
+        self.cur = self.first
+
+    def _request(self, k, frames):
+        """period k: its B left frames + the right frame of its first (key-)frame, one batched build"""
+        b = self.batches[k % 3]
+        ptrs = [self.left[f].data_ptr() for f in frames] + [self.right[frames[0]].data_ptr()]
+        b.update_(ptrs, sigma=self.params.pyramid_sigma, sync=False, ctx=self.cb)
+        self.built[k % 3] = self.cb.record(self.built[k % 3])
+        self.requested = k
+
+    def begin_frame(self, f_cur, upcoming, kf):
+        self.i += 1
+        k, m = divmod(self.i - 1, self.B)
+        up = list(upcoming)
+        if m == 0:
+            assert kf, "the period of the batches is the key-frame cadence"
+            if self.requested < k:                                            # the very first period
+                self._request(k, [f_cur] + up[:self.B - 1])
+            self.ctx.wait_event(self.built[k % 3])
+            if len(up) >= 2 * self.B - 1:
+                self._request(k + 1, up[self.B - 1:2 * self.B - 1])
+        b = self.batches[k % 3]
+        self.prev, self.cur = self.cur, b.pyramids[m]
+        if kf:
+            self.rpyr = b.pyramids[self.B]
+
+    def match(self, stereo, kp, is3d, proj):
+        a, b = (self.cur, self.rpyr) if stereo else (self.prev, self.cur)
+        return self.slam.optical_flow_matching(a, b, kp, is3d, proj, self.params, ctx=self.ctx)
+
+    def detect(self, cur):
+        return self.slam.detect(self.e, self.cur, cur, ctx=self.ctx)
+
+    def drain(self):
+        self.cb.synchronize(); self.ctx.synchronize()
+
+    def close(self):
+        for m in self.built:
+            if m is not None:
+                m.close()
+        self.first.close()
+        for b in self.batches:
+            for p_ in b.pyramids:
+                p_.close()
+
+
 class CpuBackend:
     """The CPU oracle on the same protocol (cpu_baseline leg only)."""
 
@@ -970,12 +1036,15 @@ def main():
         seq = frame_sequence(args.warmup * KF_EVERY + n1 + 202)   # the ping-pong sequence is periodic
         w1 = max(args.warmup, 2) * KF_EVERY
 
-        AH = 6                                                  # frames of lookahead the sequence provides to the build pipeline
+        AH = 2 * KF_EVERY                                        # frames of lookahead the sequence provides to the build pipeline
 
-        def one_stream(fast, ahead=1):
+        def one_stream(fast, ahead=1, period=False):
             sp = int(os.environ.get("SLAM_BENCH_SINGLE_PRIO", "0"))          # scheduling class of the tracking context (experiment)
             c3 = [slam.Context(local_rank, priority=sp)] + [slam.Context(local_rank) for _ in range(2 + max(ahead - 1, 0))]
-            be = GpuBackend(slam, c3[0], c3[1], c3[2], H, W, left_dev, right_dev, params, extractor, fast=fast, ahead=ahead, extra_build_ctx=c3[3:])
+            if period:
+                be = GpuPeriodBackend(slam, c3[0], c3[1], H, W, left_dev, right_dev, params, extractor, KF_EVERY)
+            else:
+                be = GpuBackend(slam, c3[0], c3[1], c3[2], H, W, left_dev, right_dev, params, extractor, fast=fast, ahead=ahead, extra_build_ctx=c3[3:])
             stream = Stream(be, flows, disparity, seed=rank)
             be.prime(seq[0])
             for i in range(w1):
@@ -1004,7 +1073,17 @@ def main():
             be_.close()
             for c in c3_:
                 c.close()
+        # the next key-frame period (5 left frames + the key-frame's right frame) as ONE batched build: GpuPeriodBackend
+        be_, st_, c3_, dt_, ntr_ = one_stream(False, period=True)
+        period_rate, period_tracked = world * n1 / dt_, ntr_ / max(n1, 1)
+        period_kp = (st_.kp.copy(), st_.is3d.copy())              # the list after the timed frames: compared with the single-image builds' below
+        be_.close()
+        for c in c3_:
+            c.close()
         be, stream, c3, dt, n_tracked_timed = one_stream(False)
+        period_same = bool(np.array_equal(period_kp[0], stream.kp) and np.array_equal(period_kp[1], stream.is3d))
+        if not period_same:
+            fails.append("single stream: the keypoint list after the timed frames differs between the batched-period builds and the single-image builds")
         # per-kernel device time: a second pass over the same stream with hipEvent spans on
         # the library stream.  Spans force the direct-launch path (the timed region above
         # replays the pyramid build as one hipGraph, which events cannot look inside).
@@ -1022,13 +1101,17 @@ def main():
         for c in c3:
             c.prof_enable(False)
         best_ah = max(deep, key=deep.get)
-        single = {"value": max(deep[best_ah], world * n1 / dt), "unit": "frames/sec", "steps": n1, "ms_per_frame": 1e3 * world / max(deep[best_ah], world * n1 / dt), "streams_per_gpu": 1,
-                  "builds_in_flight": best_ah if deep[best_ah] > world * n1 / dt else 1,
-                  "by_builds_in_flight": {"1": world * n1 / dt, **{str(k): v for k, v in deep.items()}},
-                  "tracked_kpts_per_frame": round(n_tracked_timed / max(n1, 1), 1),
+        best_rate = max(deep[best_ah], world * n1 / dt, period_rate)
+        single = {"value": best_rate, "unit": "frames/sec", "steps": n1, "ms_per_frame": 1e3 * world / best_rate, "streams_per_gpu": 1,
+                  "builds_in_flight": "key-frame period as one batch" if period_rate >= best_rate else (best_ah if deep[best_ah] > world * n1 / dt else 1),
+                  "by_builds_in_flight": {"1": world * n1 / dt, **{str(k): v for k, v in deep.items()}, "period_batch": period_rate},
+                  "tracked_kpts_per_frame": round(n_tracked_timed / max(n1, 1), 1), "tracked_kpts_per_frame_period_batch": round(period_tracked, 1),
+                  "period_batch_keypoint_list_identical_to_single_image_builds": period_same,
                   "note": "the same workload as ONE stream per GPU through the single-image entry points, host keypoint lists, every call synchronous as in "
                           "the reference's front-end task; `value` = throughput of one recorded sequence with the left pyramids of the next frames built "
-                          "ahead on their own streams (builds_in_flight; by_builds_in_flight[\"1\"] = next frame only, the rounds 1-2 figure); "
+                          "ahead on their own streams (builds_in_flight; by_builds_in_flight[\"1\"] = next frame only, the rounds 1-2 figure; "
+                          "\"period_batch\" = the next key-frame period's five left frames + its right frame built by ONE batched launch set, "
+                          "slam_pyr_update_batch_dev: same planes bit for bit, the chain-bound single-image kernels stop leaving the GPU idle); "
                           "a frame's own latency is build + track, see device_ms_per_frame"}
         if pyr_n:
             pyr_bytes = pyramid_bytes(H, W, levels)
