@@ -1147,9 +1147,24 @@ def main():
     #      decoder's 8-bit images ----
     head = None
     if "headline" in legs:
-        head = run_lockstep_kpset(slam, torch, local_rank, wl, args.steps, args.warmup, world, dist, dev, "host_u8", snapshot=[0, S - 1])
+        def retried(what, fn):
+            """A HIP "operation not permitted when stream is capturing" error surfaced once in ~10 full runs of round 3 in a torch call of a
+            lock-stepped leg (never reproduced in isolation): one retry after a device synchronisation, the first error goes on the line.
+            (Single process only: a retry on one rank alone would leave the others at their barrier.)"""
+            try:
+                return fn()
+            except Exception as ex:
+                if world > 1:
+                    raise
+                out.setdefault("retried", []).append({"leg": what, "error": repr(ex)[:300]})
+                try:
+                    torch.cuda.synchronize()
+                except Exception:
+                    pass
+                return fn()
+        head = retried("headline", lambda: run_lockstep_kpset(slam, torch, local_rank, wl, args.steps, args.warmup, world, dist, dev, "host_u8", snapshot=[0, S - 1]))
         leg_done("headline")
-        rows_us, serial_us, isolated_us = kernel_spans(slam, torch, local_rank, wl, dev)
+        rows_us, serial_us, isolated_us = retried("headline kernel spans", lambda: kernel_spans(slam, torch, local_rank, wl, dev))
         pb = S * pyramid_bytes(H, W, levels)
         build_ms = head["pyramid_build_ms"]["mean"]
         rb_bytes = S * iir_rows_bytes(H, W, levels) / (levels + 1)
@@ -1239,7 +1254,11 @@ def main():
     # ---- the other BASELINE shapes through the same loop (their own streams-per-GPU, their own stage roofline) ----
     if "configs" in legs:
         out["configs"] = {}
-        for name in ("kitti00_2000", "euroc_mono", "fhd_4000"):
+        import traceback
+        for name, attempt in [(n_, a_) for n_ in ("kitti00_2000", "euroc_mono", "fhd_4000") for a_ in (0, 1)]:
+            if attempt == 1 and "error" not in out["configs"].get(name, {"error": 1}):
+                continue                                              # the first attempt succeeded
+            first_error = out["configs"].get(name, {}).get("error")
             try:
                 w2 = make_workload(slam, syn, name, seed=rank)
                 mono = not w2["stereo"]
@@ -1256,9 +1275,13 @@ def main():
                                  "avg_launch_us": bm * 1e3, "achieved": pb2 / (bm * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": pb2 / (bm * 1e-3) / 1e9 / HBM_PEAK_GBS, "isolated_launch_us": iso2,
                                  "frac_isolated": pb2 / (iso2 * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+                if first_error:                                       # (seen once in ~10 full runs of round 3: a HIP "stream is capturing" error surfacing in a torch call of this leg; not reproduced in isolation)
+                    out["configs"][name]["first_attempt_error"] = first_error
                 del w2
-            except Exception as ex:                                   # never lose the line to an optional leg
-                out["configs"][name] = {"error": repr(ex)[:300]}
+            except Exception as ex:                                   # never lose the line to an optional leg; one retry, the first error stays on the record
+                out["configs"][name] = {"error": repr(ex)[:300] + " | " + " <- ".join(l.strip() for l in traceback.format_exc().splitlines()[-8:-1:2])[:500]}
+                if first_error:
+                    out["configs"][name]["first_attempt_error"] = first_error
                 try:
                     torch.cuda.synchronize()
                 except Exception:
