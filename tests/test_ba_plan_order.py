@@ -62,3 +62,41 @@ def test_bad_ids_are_refused():
     s["pose_ids"] = s["pose_ids"].copy(); s["pose_ids"][3] = 7
     with pytest.raises(slam.SlamHipError):
         slam.ba_plan_order(_cache(s))
+
+
+def test_random_covisibility_graphs_property():
+    """slam_ba_plan_order on random observation structures (no geometry needed: it only reads the ids and the constant flags) -- chains cut
+    into pieces, rings, stars, random sparse graphs, isolated poses: the order is a permutation with the constant poses first, the
+    half-bandwidth it reports is the one of that order, and a window is only reordered when that brings it into the banded solver's range."""
+    rng = np.random.default_rng(0)
+    n_reordered = 0
+    for trial in range(300):
+        P = int(rng.integers(3, 120)); M = int(rng.integers(1, 400))
+        const = (rng.random(P) < rng.choice([0.0, 0.1, 0.5])).astype(np.uint8)
+        kind = trial % 5
+        pose_ids, point_ids = [], []
+        for j in range(M):
+            if kind == 0:   obs = (int(rng.integers(0, P)) + np.arange(int(rng.integers(2, 12)))) % P                  # ring
+            elif kind == 1: a = int(rng.integers(0, P)); obs = np.arange(a, min(P, a + int(rng.integers(2, 12))))       # chain
+            elif kind == 2: obs = np.unique(np.concatenate([[0], rng.integers(0, P, 2)]))                              # star around pose 0
+            elif kind == 3: obs = np.unique(rng.integers(0, P, int(rng.integers(2, 6))))                               # random sparse
+            else:                                                                                                      # two interleaved chains
+                a = int(rng.integers(0, P // 2 + 1)); obs = 2 * np.arange(a, min(P // 2, a + 6)) + int(rng.integers(0, 2)); obs = obs[obs < P]
+            if len(obs) == 0: obs = np.array([0])
+            pose_ids += [int(o) + 1 for o in obs]; point_ids += [j + 1] * len(obs)
+        s = dict(P=P, M=M, theta_const=const, pose_ids=np.asarray(pose_ids, np.int64), point_ids=np.asarray(point_ids, np.int64))
+        cache = slam.LocalBACache(np.zeros(6 * P + 3 * M), const, np.zeros((len(pose_ids), 2)), s["pose_ids"], s["point_ids"])
+        order, hb, reordered = slam.ba_plan_order(cache)
+        assert sorted(order.tolist()) == list(range(P)), trial
+        free = const[s["pose_ids"] - 1] == 0
+        hb_id = syn.ba_halfband(s) if free.any() else 0
+        hb_new = _halfband_in(s, order) if free.any() else 0
+        assert hb == hb_new, (trial, hb, hb_new)
+        if reordered:
+            n_reordered += 1
+            assert hb_id > 20 and hb <= 20, (trial, hb_id, hb)
+            nc = int(const.sum())
+            assert const[order[:nc]].all(), trial
+        else:
+            assert np.array_equal(order, np.arange(P)) and hb == hb_id, trial
+    assert n_reordered > 20
