@@ -190,6 +190,33 @@ def ba_scene_ragged(seed):
     if rng.random() < 0.5: order = rng.permutation(order)
     for key in ("pose_ids", "point_ids"): s[key] = s[key][order]
     s["pixels_yx"] = np.ascontiguousarray(s["pixels_yx"][order]); s["O"] = len(order)
+    if P >= 6 and rng.random() < 0.4:
+        # far map points seen by a random handful of poses ANYWHERE in the window (re-observed old map points, map_manager.jl:300-449):
+        # the covisibility graph stops being a chain or a ring -- stars, chords -- and the pose order the solver picks is Cuthill-McKee's
+        fx, fy, cx, cy = s["cam"]
+        gt = s["theta_gt"][:6 * P].reshape(P, 6)
+        Rp = _rot_batch(gt[:, :3]); tp = gt[:, 3:]
+        n_far = int(rng.integers(1, 40)); H, W = 376, 1241
+        new_pts, new_pose, new_pix = [], [], []
+        for _ in range(n_far):
+            a = int(rng.integers(0, P))
+            u = rng.uniform(300, W - 300); v = rng.uniform(100, H - 100); z = rng.uniform(60.0, 120.0)
+            Xw = Rp[a].T @ (np.array([(u - cx) / fx * z, (v - cy) / fy * z, z]) - tp[a])
+            xc = np.einsum("kij,j->ki", Rp, Xw) + tp
+            py = fy * xc[:, 1] / xc[:, 2] + cy; px = fx * xc[:, 0] / xc[:, 2] + cx
+            vis = np.flatnonzero((xc[:, 2] > 5.0) & (py >= 1) & (py <= H) & (px >= 1) & (px <= W))
+            if len(vis) < 2: continue
+            cams = np.sort(rng.choice(vis, size=min(len(vis), int(rng.integers(2, 7))), replace=False))
+            new_pts.append(Xw); new_pose.append(cams)
+            new_pix.append(np.stack([py[cams], px[cams]], 1) + rng.normal(0, 0.5, (len(cams), 2)))
+        if new_pts:
+            M0 = s["M"]; k = len(new_pts)
+            s["theta_gt"] = np.concatenate([s["theta_gt"], np.ravel(new_pts)])
+            s["theta0"] = np.concatenate([s["theta0"], (np.array(new_pts) + rng.normal(0, 5e-2, (k, 3))).ravel()])
+            s["pose_ids"] = np.concatenate([s["pose_ids"], np.concatenate(new_pose) + 1]).astype(np.int64)
+            s["point_ids"] = np.concatenate([s["point_ids"], np.concatenate([np.full(len(c), M0 + j + 1) for j, c in enumerate(new_pose)])]).astype(np.int64)
+            s["pixels_yx"] = np.ascontiguousarray(np.concatenate([s["pixels_yx"], np.concatenate(new_pix)]))
+            s["M"] = M0 + k; s["O"] = len(s["pose_ids"])
     return s
 
 
