@@ -2418,7 +2418,7 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
         static const bool no_twist = getenv("SLAMHIP_NO_TWIST") != nullptr;
         // (the two workgroups wait for each other: both must be resident, which a stream confined to one compute unit cannot promise)
         static const int twist_min = [] { const char *v = getenv("SLAMHIP_TWIST_MIN"); return v ? atoi(v) : 0; }();    // (measurement knob)
-        const bool twist = !no_twist && hb * 6 <= 58 && Ps >= (twist_min > 0 ? std::max(twist_min, hb + 8) : std::max(2 * (hb + 1), hb + 8))      /* measured: pays from 20 poses at hb = 9 since the hand-overs stay in one L2 (24 before) */ && (ctx->cus == 0 || ctx->cus >= 2);
+        const bool twist = !no_twist && hb * 6 <= 58 && Ps >= (twist_min > 0 ? std::max(twist_min, hb + 8) : std::max(2 * (hb + 1) - 1, hb + 8))      /* measured: pays from 19 free poses at hb = 9 (19: 92.1 -> 89.3 us per iteration, 18: equal) since the hand-overs stay in one L2 (24 before) */ && (ctx->cus == 0 || ctx->cus >= 2);
         static long long *trace_dev = nullptr; static int trace_n = 0;
         static const bool trace_on = getenv("SLAMHIP_BAND_TRACE") != nullptr;
         if (trace_on && !trace_dev) (void)hipHostMalloc((void **)&trace_dev, 1024);

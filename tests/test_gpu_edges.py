@@ -157,7 +157,7 @@ def test_ba_refuses_bad_ids_and_repeated_observers(slam, syn):
 
 
 def test_ba_twisted_factorisation_split_sizes(slam, orc, syn):
-    """Windows of >= max(2 (hb + 1), hb + 8) poses are factored from both ends (two workgroups, hb middle poses merged): the smallest such windows
+    """Windows of >= max(2 (hb + 1) - 1, hb + 8) free poses are factored from both ends (two workgroups, hb middle poses merged): the smallest such windows
     for three band widths (10, 6 and 2 observers per point), odd / even splits, windows on both sides of the threshold."""
     for P, opp in ((30, 10), (31, 10), (33, 10), (25, 10), (26, 10), (27, 10), (19, 10), (20, 10), (21, 10), (17, 6), (18, 6), (19, 6), (23, 6),
                    (12, 6), (13, 6), (14, 6), (8, 2), (9, 2), (10, 2), (11, 2)):
