@@ -517,6 +517,7 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     ncell = extractor.grid_resolution[0] * extractor.grid_resolution[1]
     cap = extractor.max_points + ncell + 8
     ks = slam.KeypointSet(S, cap, ctx=ctx)
+    peek("run_lockstep_kpset: start")
     n_frames = len(left)
     period = 2 * n_frames - 2
     seq = frame_sequence_n(n_frames, period + S + 2)
@@ -760,24 +761,31 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
                                    for nm in ("layers", "Iy", "Ix", "Iyy", "Ixx", "Iyx")}}
         res["snapshot"] = snap
         res["seq"] = seq; res["period"] = period; res["cap"] = cap
+    peek("run_lockstep_kpset: after the loop")
     for c in (ctx, ctx_pyr, ctx_right, ctx_copy):
         c.synchronize()
     torch.cuda.synchronize()
+    peek("run_lockstep_kpset: after the synchronisation")
     ks.close()
+    peek("run_lockstep_kpset: after ks.close")
     for e2 in ev_pool:
         e2[0].close(); e2[1].close()
     for m in built + copied + rcopied + rbuilt:
         if m is not None:
             m.close()
+    peek("run_lockstep_kpset: after closing events / markers")
     for b_ in lb + ([rb] if rb is not None else []):
         for p_ in b_.pyramids:
             p_.close()
+    peek("run_lockstep_kpset: after destroying the pyramids")
     del lseq, rseq, cull_u, cull_flags
     if host:
         del lstage, st_copy
     del st_main
+    peek("run_lockstep_kpset: after freeing the torch buffers")
     for c in (ctx, ctx_pyr, ctx_right, ctx_copy):
         c.close()
+    peek("run_lockstep_kpset: after destroying the contexts")
     return res
 
 
@@ -821,6 +829,25 @@ def replay_stream_on_oracle(orc, slam, wl, rec, res, s, threads):
     return kp, is3
 
 
+_HIP = None
+
+
+def peek(label):
+    """SLAM_BENCH_PEEK=1: report the calling thread's pending HIP error (hipPeekAtLastError of the runtime torch and the library share)
+    -- to find the call that leaves hipErrorStreamCaptureUnsupported behind for a later torch call to trip over"""
+    global _HIP
+    if os.environ.get("SLAM_BENCH_PEEK") is None:
+        return
+    import ctypes, sys as _s
+    if _HIP is None:
+        import torch as _t
+        libdir = os.path.join(os.path.dirname(_t.__file__), "lib")
+        _HIP = ctypes.CDLL(os.path.join(libdir, "libamdhip64.so"))
+    e = _HIP.hipPeekAtLastError()
+    if e != 0:
+        print(f"[peek] pending HIP error {e} at {label}", file=_s.stderr, flush=True)
+
+
 def kernel_spans(slam, torch, local_rank, wl, dev):
     """Per-kernel device time of the batched build with serial launches (hipEvent spans cannot look inside the graph),
     and the graph replay alone on the GPU."""
@@ -831,13 +858,16 @@ def kernel_spans(slam, torch, local_rank, wl, dev):
     t = torch.from_numpy(np.stack([np.ascontiguousarray(np.round(left[seq[k]] * 255).astype(np.uint8).T) for k in range(S)])).to(dev)
     torch.cuda.synchronize()
     ptrs = [t.data_ptr() + s * H * W for s in range(S)]
+    peek("kernel_spans: before the first build")
     pb.update_(ptrs, sync=True, ctx=ctx, u8=True)
+    peek("kernel_spans: after the first build (capture)")
     ea, eb = slam.Event(ctx, timed=True), slam.Event(ctx, timed=True)
     ctx.record(ea)
     for _ in range(20):                                      # the stage alone on the GPU: graph replays back to back
         pb.update_(ptrs, sync=False, ctx=ctx, u8=True)
     ctx.record(eb)
     isolated_us = ea.elapsed_ms(eb) / 20 * 1e3
+    peek("kernel_spans: after the replays")
     ea.close(); eb.close()
     ctx.prof_enable(True); ctx.prof_reset()
     for _ in range(20):
@@ -845,9 +875,12 @@ def kernel_spans(slam, torch, local_rank, wl, dev):
     ctx.synchronize()
     rows_ms, rows_n = ctx.prof_get("k_iir_rows"); pyr_ms, pyr_n = ctx.prof_get("pyr_update")
     ctx.prof_enable(False)
+    peek("kernel_spans: after the profiled builds")
     for p_ in pb.pyramids:
         p_.close()
+    peek("kernel_spans: after destroying the pyramids")
     ctx.close()
+    peek("kernel_spans: after destroying the context")
     return rows_ms / max(rows_n, 1) * 1e3, pyr_ms / max(pyr_n, 1) * 1e3, isolated_us
 
 
@@ -1146,7 +1179,7 @@ def main():
     # ---- headline: S lock-stepped streams per GPU, keypoints resident in HBM, bit-exact planes; frames arrive in host memory as the
     #      decoder's 8-bit images ----
     head = None
-    if "headline" in legs:
+    if True:
         def retried(what, fn):
             """A HIP "operation not permitted when stream is capturing" error surfaced once in ~10 full runs of round 3 in a torch call of a
             lock-stepped leg (never reproduced in isolation): one retry after a device synchronisation, the first error goes on the line.
@@ -1162,6 +1195,7 @@ def main():
                 except Exception:
                     pass
                 return fn()
+    if "headline" in legs:
         head = retried("headline", lambda: run_lockstep_kpset(slam, torch, local_rank, wl, args.steps, args.warmup, world, dist, dev, "host_u8", snapshot=[0, S - 1]))
         leg_done("headline")
         rows_us, serial_us, isolated_us = retried("headline kernel spans", lambda: kernel_spans(slam, torch, local_rank, wl, dev))
@@ -1223,7 +1257,7 @@ def main():
         if head is not None:
             out["ingest"]["host_u8"] = {"value": head["value"], "ms_per_step": head["ms_per_step"], "steps": head["steps"], "pyramid_build_ms_mean": head["pyramid_build_ms"]["mean"]}
         for ingest in ("dev_f64", "host_f64"):
-            v = run_lockstep_kpset(slam, torch, local_rank, wl, max(8, args.steps // 3), 2, world, dist, dev, ingest)
+            v = retried("ingest " + ingest, lambda: run_lockstep_kpset(slam, torch, local_rank, wl, max(8, args.steps // 3), 2, world, dist, dev, ingest))
             out["ingest"][ingest] = {"value": v["value"], "ms_per_step": v["ms_per_step"], "steps": v["steps"], "pyramid_build_ms_mean": v["pyramid_build_ms"]["mean"]}
         leg_done("ingest")
 
@@ -1233,7 +1267,7 @@ def main():
         out["streams_sweep"] = {}
         for S2 in {32: (48, 64), 64: (32, 48), 128: (32, 64, 96)}[S]:
             w2 = dict(wl); w2["S"] = S2
-            r2 = run_lockstep_kpset(slam, torch, local_rank, w2, max(8, args.steps // 4), 2, world, dist, dev, "host_u8")
+            r2 = retried("streams sweep", lambda: run_lockstep_kpset(slam, torch, local_rank, w2, max(8, args.steps // 4), 2, world, dist, dev, "host_u8"))
             out["streams_sweep"][str(S2)] = {"value": r2["value"], "unit": "frames/sec", "ms_per_step": r2["ms_per_step"]}
         leg_done("streams_sweep")
 
@@ -1243,8 +1277,8 @@ def main():
         left_dev = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in left]
         right_dev = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in right]
         torch.cuda.synchronize()
-        hp = run_lockstep(slam, torch, local_rank, S, max(40, frame_steps // 4), 10, H, W, left_dev, right_dev, flows, disparity,
-                          params, extractor, False, world, dist, dev)
+        hp = retried("host protocol", lambda: run_lockstep(slam, torch, local_rank, S, max(40, frame_steps // 4), 10, H, W, left_dev, right_dev, flows, disparity,
+                                                           params, extractor, False, world, dist, dev))
         out["host_protocol"] = {"value": hp["value"], "unit": "frames/sec", "ms_per_frame_of_S_streams": hp["ms_per_step_of_S_frames"],
                                 "what": "slam_flow_match_batch_kept / slam_detect_batch with host keypoint lists, frames resident in HBM as Float64 "
                                         "(compare ingest.dev_f64)"}
@@ -1455,14 +1489,14 @@ def main():
                                 "what": "slam_kpset_compute_pose: P3P RANSAC (256 triples) + PnP refinement + outlier removal for the S streams on "
                                         "device-resident lists; one device -> host copy (poses, status, list lengths)"}
         # the tracked workload as the reference's full per-frame front-end on the tracked lists themselves
-        wp = run_lockstep_kpset(slam, torch, local_rank, wl, max(8, args.steps // 3), 2, world, dist, dev, "host_u8", pose=True)
+        wp = retried("front-end with poses", lambda: run_lockstep_kpset(slam, torch, local_rank, wl, max(8, args.steps // 3), 2, world, dist, dev, "host_u8", pose=True))
         out["pose"]["frontend_with_pose"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step": wp["ms_per_step"],
                                              "tracked_kpts_per_frame": wp["tracked_kpts_per_frame"], **wp["pose"],
                                              "what": "the headline workload as the reference's full per-frame front-end on the tracked lists themselves "
                                                      "(front_end.jl:60-113): tracking with the priors of the predicted pose, slam_kpset_compute_pose_5pt, "
                                                      "slam_kpset_compute_pose every frame, key-frames with slam_kpset_keyframe and triangulation under the "
                                                      "estimated pose; the streams are a rigid scene, the recovered translation is checked against the frames' offsets"}
-        wp = run_lockstep_kpset(slam, torch, local_rank, wl, max(4, args.steps // 4), 2, world, dist, dev, "host_u8", hook=pose_batch_once)
+        wp = retried("front-end with host pose seams", lambda: run_lockstep_kpset(slam, torch, local_rank, wl, max(4, args.steps // 4), 2, world, dist, dev, "host_u8", hook=pose_batch_once))
         out["pose"]["frontend_with_host_pose_seams"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step": wp["ms_per_step"],
                                                         "what": "headline workload + slam_five_point_ransac_batch + slam_p3p_ransac_batch + slam_pnp_ba_batch "
                                                                 "every frame (host lists in and out: the round-1 configuration of this figure)"}
@@ -1510,7 +1544,7 @@ def main():
             par["planes_after_timed_run"] = {"streams": sorted(head["snapshot"]), "planes_compared": 6 * (levels + 1) * len(head["snapshot"]),
                                              "bit_equal": n_eq, "what": "all planes of the last left pyramids of the timed run vs orc.pyr_build of the same 8-bit frame"}
             rec = {"frame_steps": 7, "steps": []}
-            rr = run_lockstep_kpset(slam, torch, local_rank, wl, 0, 0, world, dist, dev, "host_u8", record=rec, snapshot=[0, S - 1])
+            rr = retried("replayed key-frame cycle", lambda: run_lockstep_kpset(slam, torch, local_rank, wl, 0, 0, world, dist, dev, "host_u8", record=rec, snapshot=[0, S - 1]))
             worst = 0.0; lists_ok = True
             for s_, sn in rr["snapshot"].items():
                 kp_ref, is3_ref = replay_stream_on_oracle(orc, slam, wl, rec, rr, s_, threads)
