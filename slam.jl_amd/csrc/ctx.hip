@@ -176,8 +176,7 @@ int slam_ctx_destroy(slam_ctx *ctx)
     if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
     for (auto &sp : ctx->prof_pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
-    static const bool leak_streams = getenv("SLAMHIP_LEAK_STREAMS") != nullptr;      // (experiment)
-    if (!leak_streams) (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SLAM_OK;
 }

@@ -21,7 +21,6 @@
 #include "common.hpp"
 #include <cmath>
 #include <cstdlib>
-#include <mutex>
 
 #define LINE_THREADS 64
 
@@ -1685,35 +1684,6 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
 }
 
 // level 0 of an S-image build runs k_cols_fused (which can ingest the source images itself): launch_build's conditions
-// The side stream and the fork / join events of a pyramid's build graph are recorded INSIDE stream captures.  They are never destroyed:
-// a pyramid that goes away parks them (per device) for the next one.  With hipStreamDestroy / hipEventDestroy at slam_pyr_destroy, a later
-// torch call of the same process (pin_memory: hipHostMalloc, hipEventQuery on the allocator's own events) failed about once in five full
-// bench runs with hipErrorStreamCaptureUnsupported or hipErrorCapturedEvent -- no capture was in progress anywhere; whichever
-// mode the capture ran in (thread-local, relaxed).  Captured objects the runtime recycles seem to keep their capture state.
-struct ForkSet { int device; hipStream_t aux; hipEvent_t ev_fork[SLAM_MAX_LEVELS], ev_join; };
-static std::mutex g_fork_mu;
-static std::vector<ForkSet> g_fork_sets;
-static bool fork_set_take(slam_pyr *p)
-{
-    std::lock_guard<std::mutex> lock(g_fork_mu);
-    for (size_t k = 0; k < g_fork_sets.size(); k++)
-        if (g_fork_sets[k].device == p->device) {
-            p->aux = g_fork_sets[k].aux; p->ev_join = g_fork_sets[k].ev_join;
-            for (int l = 0; l < SLAM_MAX_LEVELS; l++) p->ev_fork[l] = g_fork_sets[k].ev_fork[l];
-            g_fork_sets.erase(g_fork_sets.begin() + (long)k);
-            return true;
-        }
-    return false;
-}
-static void fork_set_give(slam_pyr *p)
-{
-    ForkSet f; f.device = p->device; f.aux = p->aux; f.ev_join = p->ev_join;
-    for (int l = 0; l < SLAM_MAX_LEVELS; l++) f.ev_fork[l] = p->ev_fork[l];
-    std::lock_guard<std::mutex> lock(g_fork_mu);
-    g_fork_sets.push_back(f);
-    p->aux = nullptr;
-}
-
 static bool level0_fused(const slam_pyr *p, int mode, int S)
 {
     static const bool off = getenv("SLAMHIP_NO_COLS_FUSED") != nullptr || getenv("SLAMHIP_NO_SQ_FUSE") != nullptr || getenv("SLAMHIP_NO_CK_COLS") != nullptr ||
@@ -1763,18 +1733,13 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode_flags, double sigm
     const size_t ckmin = ck_min_bytes();
     for (auto &g : p->graphs) if (g.mode == mode && g.sigma == sigma && g.S == S && g.ckmin == ckmin && g.src_kind == src_kind) exec = g.exec;
     if (!exec && !p->graph_failed) {
-        if (!p->aux && !fork_set_take(p)) {
+        if (!p->aux) {
             HIP_TRY(ctx, hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
-            for (int l = 0; l < SLAM_MAX_LEVELS; l++) HIP_TRY(ctx, hipEventCreateWithFlags(&p->ev_fork[l], hipEventDisableTiming));
+            for (int l = 0; l < p->levels; l++) HIP_TRY(ctx, hipEventCreateWithFlags(&p->ev_fork[l], hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
         }
         hipGraph_t graph = nullptr;
-        // Relaxed mode: the capture window below contains this library's launches and event edges only -- nothing in it is "potentially
-        // unsafe" -- and the stricter modes make the RUNTIME police the calling thread's later calls through a per-thread list of capturing
-        // streams.  With hipStreamCaptureModeThreadLocal a torch call of the same thread (pin_memory -> hipHostMalloc) failed with
-        // hipErrorStreamCaptureUnsupported once in ~5 full bench runs, long after every capture had ended (a stale entry of that list,
-        // gone again once the previous leg's pyramids -- and their streams -- were destroyed).
-        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
             launch_build(ctx, p, mode, cf, st, chain ? st : p->aux, false, S, src_kind & 15, target);
             e = hipStreamEndCapture(st, &graph);
@@ -1914,7 +1879,11 @@ int slam_pyr_destroy(slam_pyr *p)
     if (p->alloc && --p->alloc->refs == 0) { (void)hipFree(p->alloc->base); if (p->alloc->ck) (void)hipFree(p->alloc->ck); if (p->alloc->srctab) (void)hipFree(p->alloc->srctab); delete p->alloc; }
     if (p->norm) (void)hipFree(p->norm);
     for (auto &g : p->graphs) (void)hipGraphExecDestroy(g.exec);
-    if (p->aux) fork_set_give(p);                            // (kept for the next pyramid of this device: see fork_set_take)
+    if (p->aux) {
+        (void)hipStreamDestroy(p->aux);
+        for (int l = 0; l < p->levels; l++) (void)hipEventDestroy(p->ev_fork[l]);
+        (void)hipEventDestroy(p->ev_join);
+    }
     delete p;
     return SLAM_OK;
 }
