@@ -1,7 +1,7 @@
 """Random ragged BA windows (observers dropped at random, constant poses anywhere, loop-closure points, shuffled observation order) against
-the oracle: python scripts/ba_fuzz.py [n] [seed0]"""
+the oracle: python tests/fuzz/ba_fuzz.py [n] [seed0]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 

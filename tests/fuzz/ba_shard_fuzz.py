@@ -1,7 +1,7 @@
 """Random ragged windows through the two-shard emulation of the device-paced sharded LM pass (tests/test_gpu_sharded_emulation.py)
-against slam_local_ba on the whole window: python scripts/ba_shard_fuzz.py [n] [seed0]"""
+against slam_local_ba on the whole window: python tests/fuzz/ba_shard_fuzz.py [n] [seed0]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import slam_jl_amd as slam

@@ -5,9 +5,9 @@
   lk      fb_tracking with random window sizes (2 .. 14: the three cached instantiations and the uncached path), levels, priors, points on and near the borders
   detect  random shapes, cell sizes, current keypoints (none / few / many / clustered), mask sigma
   brief   describe with random shapes and keypoints on / next to the borders (dropped ones included)
-python scripts/fuzz_frontend.py [n per part] [seed0] [parts]"""
+python tests/fuzz/fuzz_frontend.py [n per part] [seed0] [parts]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

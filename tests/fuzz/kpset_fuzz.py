@@ -1,8 +1,8 @@
 """Random key-frame steps on the device-resident keypoint lists (slam_kpset_*: temporal match, cull, detect + merge, stereo match,
 triangulate) against the host protocol on the batch seams and the oracle's optical_flow_matching! -- tests/test_gpu_kpset.py's step
-with random stream counts, shapes, list sizes (empty streams, full lists, everything culled): python scripts/kpset_fuzz.py [n] [seed0]"""
+with random stream counts, shapes, list sizes (empty streams, full lists, everything culled): python tests/fuzz/kpset_fuzz.py [n] [seed0]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

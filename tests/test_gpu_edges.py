@@ -130,7 +130,7 @@ def test_ba_loop_closure_windows_are_solved_in_a_folded_pose_order(slam, orc, sy
 def test_ba_ragged_windows_fuzz(slam, orc, syn):
     """Sixty random windows (syn.ba_scene_ragged: dropped observations, constant poses anywhere, loop closures, shuffled order) against
     the oracle -- every solver path the dispatch can take (twisted / single-workgroup / wide band, relabelled poses, pair lists).
-    scripts/ba_fuzz.py runs more of them."""
+    tests/fuzz/ba_fuzz.py runs more of them."""
     for seed in range(60):
         s = syn.ba_scene_ragged(seed)
         _ba_vs_oracle(slam, orc, s, ("ragged", seed))

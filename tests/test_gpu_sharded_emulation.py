@@ -141,7 +141,7 @@ def test_two_shards_on_ragged_windows(slam, syn):
     arbitrary point: the shards' local bands and solver paths differ from each other's and from the single solve's (which may reorder
     the poses), early convergence leaves iterations that do nothing -- decisions, outliers, cost and parameters must still agree.
     (Seeds 76 ... 145 converge early: the converged state used to pick up each shard's stale LOCAL trial cost.)
-    scripts/ba_shard_fuzz.py runs more."""
+    tests/fuzz/ba_shard_fuzz.py runs more."""
     from slam_jl_amd import sharded_ba
     for seed in (3, 59, 76, 98, 110, 125, 133, 138, 145):
         s = syn.ba_scene_ragged(seed)
