@@ -18,7 +18,8 @@ decoder's 8-bit images and are copied to the GPU inside the timed loop; all
 arithmetic is Float64 and every plane bit-exact.  value = frames/s over all
 streams and GPUs = S * KF_EVERY * K / seconds.  N>1 = N independent replicas
 (the front-end does not shard: SURVEY 8e) -> weak scaling, no collective in the
-data path.  Rank 0 prints ONE JSON line.
+data path.  Rank 0 prints ONE compact JSON line (< 4 KB) as its LAST stdout line;
+the full record goes to bench_detail.json and stderr.
 
 Legs (`--only`, for profiling one population of kernels at a time; default all):
   single, tolerance, headline, ingest, sweep, host_protocol, configs, ba,
@@ -548,6 +549,9 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     cull_flags = torch.zeros(S * cap, dtype=torch.bool, device=dev)     # library-stream contexts below (the caching allocator would keep using that stream)
     ev_pool = [(slam.Event(ctx_pyr, timed=True), slam.Event(ctx_pyr, timed=True)) for _ in range(48)]
     ev_used = []
+    # hipEvents around the temporal match (k_kpset_match + the compaction behind it) on the TRACKING stream, timed region only
+    lk_pool = [(slam.Event(ctx, timed=True), slam.Event(ctx, timed=True)) for _ in range(48)]
+    lk_used = []                                             # (event pair, keypoints that entered the match)
 
     def ptrs(base_tensor):
         b = base_tensor.data_ptr()
@@ -665,7 +669,12 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
             if rec is not None:
                 rec["shift"] = shift.copy()
             sp = slam.stream_params(S, cam=camt, shift_yx=shift)
+            lkp = None
+            if state["timed"]:
+                lkp = lk_pool[len(lk_used) % len(lk_pool)]; ctx.record(lkp[0])
             ks.flow_match(prevb, curb, params, sp, prior=2, n_bound=state["n_bound"], ctx=ctx)
+            if lkp is not None:
+                ctx.record(lkp[1]); lk_used.append((lkp, state["n_bound"]))
         if kf:
             # map culling between key-frames (outlier observations dropped by BA, failed triangulations): flags drawn in HBM
             with torch.cuda.stream(st_main):
@@ -734,6 +743,7 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
     builds = [a.elapsed_ms(b) for a, b in ev_used[-len(ev_pool):]]      # left builds of the timed region (graph replays on the pyramid stream)
+    lk_spans = [(a.elapsed_ms(b), n) for (a, b), n in lk_used[-len(lk_pool):]]
     try:
         free_b, total_b = torch.cuda.mem_get_info(dev)
         hbm_gb = (total_b - free_b) / 1e9                                # everything this process (and anyone else on the device) holds while the loop's buffers are alive
@@ -749,6 +759,8 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
                                           "five_point_note": "compute_pose_5pt! returns nothing while the average parallax against the previous key-frame is below 5 px "
                                                              "(front_end.jl:290): the first frames after each key-frame; every remaining call is accepted when the two fractions add up to 1",
                                           "max_translation_error_m": pst["err_max"], "plane_depth_m": Z_PLANE},
+           "lk_match": None if not lk_spans else {"mean_ms": float(np.mean([m for m, _ in lk_spans])), "points_per_launch": float(np.mean([n for _, n in lk_spans])),
+                                                  "n": len(lk_spans), "what": "hipEvents around slam_kpset_flow_match (k_kpset_match + compaction) on the tracking stream, timed region"},
            "pyramid_build_ms": {"mean": float(np.mean(builds)) if builds else None, "min": float(np.min(builds)) if builds else None,
                                 "n": len(builds), "what": "hipEvents around each left-batch build (one hipGraph replay, u8 ingest fused) on the pyramid "
                                                           "stream inside the timed region, tracking running beside it"}}
@@ -768,7 +780,7 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     peek("run_lockstep_kpset: after the synchronisation")
     ks.close()
     peek("run_lockstep_kpset: after ks.close")
-    for e2 in ev_pool:
+    for e2 in ev_pool + lk_pool:
         e2[0].close(); e2[1].close()
     for m in built + copied + rcopied + rbuilt:
         if m is not None:
@@ -936,6 +948,122 @@ def newest_pmc(S):
     return c[-1] if c else None
 
 
+LK_VISIT_BYTES = lambda w: 3 * (2 * w + 1) ** 2 * 8 + (2 * w + 2) ** 2 * 8 + 12 * 8 + 33     # template + target footprint + 12 corners + point record
+
+
+def frame_and_lk_rooflines(wl, head, frac3d):
+    """SURVEY 8d's whole-step and LK bytes for the headline loop (per stream and key-frame period: KF_EVERY left builds + KF_EVERY temporal
+    matches + 1 detect + 1 right build + 1 stereo match), against the measured step / match span.  Level visits per keypoint follow
+    map_manager.jl:451-564 + tracker.jl:30-66: a 2-D keypoint = 4 forward + 1 backward visit, a 3-D keypoint with a prior = 2 + 1
+    (pyramid_levels_3d = 1); failed 3-D attempts that fall back to the 2-D pass are not counted (a lower bound on the bytes)."""
+    S, H, W, levels, params = wl["S"], wl["H"], wl["W"], wl["levels"], wl["params"]
+    pb = pyramid_bytes(H, W, levels)
+    vb = LK_VISIT_BYTES(params.window_size)
+    kpts = head["tracked_kpts_per_frame"]
+    visits = frac3d * 3 + (1 - frac3d) * 5
+    lk_point = vb * visits
+    K = wl["kpts"]
+    detect_b = 8 * H * W + 16 * K + 16 * K * CULL_FRACTION
+    stereo_b = vb * 5 * K                                     # stereo match: every keypoint as a 2-D keypoint (shift prior, all levels)
+    per_period = KF_EVERY * pb + KF_EVERY * kpts * lk_point + detect_b + (pb if wl["stereo"] else 0) + (stereo_b if wl["stereo"] else 0)
+    step_bytes = S * per_period
+    sec = head["ms_per_step"] * 1e-3
+    fr = {"algorithmic_bytes_per_step": int(step_bytes), "achieved": step_bytes / sec / 1e9, "frac": step_bytes / sec / 1e9 / HBM_PEAK_GBS,
+          "bound_fps_at_peak": S * KF_EVERY / (step_bytes / (HBM_PEAK_GBS * 1e9)), "visits_per_kpt": round(visits, 2), "frac_3d": round(frac3d, 3)}
+    lk = None
+    if head.get("lk_match"):
+        m = head["lk_match"]
+        b = m["points_per_launch"] * lk_point
+        lk = {"kernel": "k_kpset_match", "algorithmic_bytes_per_launch": int(b), "avg_launch_us": m["mean_ms"] * 1e3, "points_per_launch": int(m["points_per_launch"]),
+              "ns_per_point": m["mean_ms"] * 1e6 / max(m["points_per_launch"], 1), "achieved": b / (m["mean_ms"] * 1e-3) / 1e9,
+              "frac": b / (m["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "VALU-issue bound, not HBM (DESIGN 3.3)"}
+    return fr, lk
+
+
+def _r(x, n=4):
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if abs(x) < 1 else round(x, 3)
+    return x
+
+
+def compact_line(out):
+    """The ONE stdout line the driver parses: numbers only, < 4 KB (hard limit 8 KB).  Everything else lives in bench_detail.json."""
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = out.get("config") or {}
+    c["config"] = {"workload": "KITTI-05-shaped stereo 370x1226 @1000 kpts, KF every 5th frame (BASELINE configs[1]); step = 1 key-frame period of each stream; "
+                               "u8 frames from pinned host memory inside the timed loop; f64 bit-exact",
+                   "streams_per_gpu": cfg.get("streams_per_gpu"), "frames_per_step": cfg.get("frames_per_step"), "parallelism": cfg.get("parallelism"),
+                   "pyramid_mode": out.get("pyramid_mode", "bit-exact")}
+    rf = out.get("roofline")
+    if rf:
+        c["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_isolated", "algorithmic_bytes_per_launch", "avg_launch_us",
+                                                     "isolated_launch_us", "traffic", "traffic_over_algorithmic")}
+        c["roofline"]["stage"] = f"LK pyramid update of {cfg.get('streams_per_gpu')} images, one graph launch"
+        if rf.get("traffic_source"):
+            c["roofline"]["traffic_source"] = rf["traffic_source"].split(" ")[0]
+        for k in ("frame", "lk"):
+            if rf.get(k):
+                c["roofline"][k] = {a: _r(b) for a, b in rf[k].items() if a not in ("note", "kernel")}
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:120]}
+        if out.get("value"):
+            c["cpu_baseline"]["gpu_over_cpu"] = _r(out["value"] / cb["value"])
+    ba = out.get("ba")
+    if ba:
+        c["ba"] = {"ms_per_iter": _r(ba.get("ms_per_iter")), "window_kf": 50, "observations": ba.get("observations"),
+                   "windows_ms_per_iter": {k: _r(v["ms_per_iter"]) for k, v in ba.get("windows", {}).items()},
+                   "roofline_frac_P50": _r(ba.get("windows", {}).get("P50", {}).get("roofline", {}).get("frac")),
+                   "cpu_ms_per_iter_schur": _r(ba.get("cpu_ms_per_iter_schur")), "cpu_ms_per_iter_lm_lsmr": _r(ba.get("cpu_ms_per_iter_reference_style_lm_lsmr"))}
+    bs = out.get("ba_sharded")
+    if bs:
+        c["ba_sharded"] = {k: _r(bs.get(k)) for k in ("world_size", "window_kf", "ms_per_iter_wall", "worth_sharding", "error") if bs.get(k) is not None}
+    ss = out.get("single_stream")
+    if ss and "by_builds_in_flight" in ss:
+        c["single_stream"] = {"live": _r(ss["by_builds_in_flight"].get("1")), "lookahead": _r(ss.get("value")), "unit": "frames/sec"}
+        if ss.get("live_graph") is not None:
+            c["single_stream"]["live_graph"] = _r(ss["live_graph"])
+    elif ss:
+        c["single_stream"] = {"error": str(ss.get("error"))[:120]}
+    tm = out.get("tolerance_mode")
+    if tm:
+        c["tolerance_mode"] = {k: _r(v) for k, v in tm.items() if isinstance(v, (int, float, bool))}
+        if isinstance(tm.get("single_stream"), dict):
+            c["tolerance_mode"]["single_stream"] = _r(tm["single_stream"].get("value"))
+    if out.get("configs"):
+        c["configs"] = {k: (_r(v.get("value")) if "value" in v else "error") for k, v in out["configs"].items()}
+    if out.get("pose", {}).get("frontend_with_pose"):
+        c["frontend_with_pose"] = _r(out["pose"]["frontend_with_pose"]["value"])
+    pv = out.get("parity_vs_oracle")
+    if pv:
+        c["parity_vs_oracle"] = {"ok": pv["ok"] and not out.get("parity_failures")}
+    if out.get("parity_failures"):
+        c["parity_failures"] = len(out["parity_failures"])
+    if out.get("retried"):
+        c["retried"] = len(out["retried"])
+    c["detail"] = "bench_detail.json"
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) > 8000:                                          # never lose the line to its own size: drop the optional objects, largest first
+        for k in ("configs", "ba_sharded", "tolerance_mode", "single_stream"):
+            c.pop(k, None)
+        line = json.dumps(c, separators=(",", ":"))
+    assert len(line) <= 8000, len(line)
+    return line
+
+
+def write_detail(out):
+    """the full record (notes, sweeps, per-window objects): next to bench.py, under gpurun_out/ when that exists, and on stderr"""
+    txt = json.dumps(out)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(txt + "\n")
+            except OSError:
+                pass
+    print(txt, file=sys.stderr, flush=True)
+
+
 def ba_windows(syn):
     """The BA windows SURVEY 8d / BASELINE name.  P5: the reference's own shape -- at most 5 free key-frames and many
     constant observers (estimator.jl:327-331, :163-229): 25 poses of which the 20 oldest are constant, O ~ 8 k.
@@ -962,7 +1090,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and the oracle parity checks that live in it)")
     ap.add_argument("--no-ba", action="store_true", help="skip the BA and pose measurements")
     ap.add_argument("--streams", type=int, default=128, help="S: independent stereo streams per GPU advancing in lock-step (one batch of S frames per frame step); "
-                    "64 = the library's batch limit: the big pyramid kernels then run whole rounds of workgroups (S = 32, the round-1 value: -8 %%)")
+                    "128 = the library's batch limit (SLAM_MAX_BATCH): every launch is shared by more frames (same-box sweep 32 / 64 / 96 / 128: 18.6 / 20.8 / 21.5 / 22.1 k frames/s)")
     ap.add_argument("--no-tolerance", action="store_true", help="skip the tolerance-mode measurements")
     ap.add_argument("--no-sweep", action="store_true", help="skip the streams-per-GPU sweep legs (S = 32 / 64 / 96 at the default 128)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE shapes (kitti00_2000, euroc_mono, fhd_4000)")
@@ -1251,6 +1379,9 @@ def main():
                                           "avg_launch_us": rows_us, "bytes_per_launch": rb_bytes,
                                           "achieved": rb_bytes / (rows_us * 1e-6) / 1e9, "frac": rb_bytes / (rows_us * 1e-6) / 1e9 / HBM_PEAK_GBS}},
         })
+        lists = [sn["list"]["is_3d"] for sn in head.get("snapshot", {}).values()]
+        frac3d = float(np.mean(np.concatenate(lists))) if lists and sum(len(x) for x in lists) else 0.8
+        out["roofline"]["frame"], out["roofline"]["lk"] = frame_and_lk_rooflines(wl, head, frac3d)
         pmc = newest_pmc(S)
         if pmc is not None:
             j = json.load(open(pmc))
@@ -1616,8 +1747,12 @@ def main():
         head.pop("snapshot", None)
     if fails:
         out["parity_failures"] = fails
-    if rank == 0:
-        print(json.dumps(out))
+    if rank == 0 and os.environ.get("SLAM_BENCH_CHILD") is not None:
+        print(json.dumps(out), flush=True)                        # a child leg's part of the record, parsed by the parent process
+    elif rank == 0:
+        write_detail(out)
+        sys.stdout.flush()
+        print(compact_line(out), flush=True)                      # the LAST stdout line, the one the driver parses
     if world > 1:
         dist.destroy_process_group()
     if fails:                                                     # the line is out; the exit status says a checker disagreed
