@@ -1090,7 +1090,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and the oracle parity checks that live in it)")
     ap.add_argument("--no-ba", action="store_true", help="skip the BA and pose measurements")
     ap.add_argument("--streams", type=int, default=128, help="S: independent stereo streams per GPU advancing in lock-step (one batch of S frames per frame step); "
-                    "128 = the library's batch limit (SLAM_MAX_BATCH): every launch is shared by more frames (same-box sweep 32 / 64 / 96 / 128: 18.6 / 20.8 / 21.5 / 22.1 k frames/s)")
+                    "128 = the library's batch limit: every launch is shared by more frames (same-box sweep 32 / 64 / 96 / 128: 18.6 / 20.8 / 21.5 / 22.1 k frames/s)")
     ap.add_argument("--no-tolerance", action="store_true", help="skip the tolerance-mode measurements")
     ap.add_argument("--no-sweep", action="store_true", help="skip the streams-per-GPU sweep legs (S = 32 / 64 / 96 at the default 128)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE shapes (kitti00_2000, euroc_mono, fhd_4000)")
