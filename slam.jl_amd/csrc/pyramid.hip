@@ -685,6 +685,10 @@ struct ColsFusedArgs {
     // Float64, 2: 8-bit, converted raw / 255 like k_gather_images_u8) through a device-side pointer table, and wave 0 writes the
     // pitched layer plane on the way (src_kind 0: the layer plane itself, already ingested)
     int src_kind; const void *const *srctab;
+    // tolerance build (TOL): the product planes leave this kernel as EXCLUSIVE SUFFIX SUMS along y of their dim-1-filtered values,
+    // E[y] = sum_{i > y} v[i] (formed bottom-up, the order the backward sweep emits the rows), and the column totals go to
+    // tot[(z * 3 + role - 1) * tot_stride + x]; the row kernel k_rows_tol takes C1[y] = tot - E[y] = cumsum along dim 1
+    double *tot; int tot_stride;
 };
 
 // neighbour lanes of the whole wave through DPP (wave_shr:1 / wave_shl:1 of the GFX9 family): lane i receives lane i-1 / i+1,
@@ -799,7 +803,7 @@ __device__ __forceinline__ void cf4_scharr8(const double *LB, double *IYB, doubl
     for (int j = 0; j < 4; j++) { *(double2 *)(py + 2 * j) = make_double2(iy8[2 * j], iy8[2 * j + 1]); *(double2 *)(px + 2 * j) = make_double2(ix8[2 * j], ix8[2 * j + 1]); }
 }
 
-template <int ROLE>
+template <int ROLE, bool TOL>
 __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const IIRCoef &k, double *ck, double *LB, double *IYB, double *IXB, double *QB, const double *lut)
 {
     const int lane = threadIdx.x & 63, rp = lane & 7, cg = lane >> 3;
@@ -992,7 +996,10 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     };
     prefetch(NBk - 1);
     if (active) load_ck(NBk - 1);
-    if (active) { io.st(n - 1, vA * scale); io.st(n - 2, vB * scale); io.st(n - 3, vC * scale); }
+    constexpr bool SFX = TOL && ROLE != 0;                        // this wave's outputs leave as exclusive suffix sums (see ColsFusedArgs::tot)
+    double sfx = 0.0;
+    if (active && !SFX) { io.st(n - 1, vA * scale); io.st(n - 2, vB * scale); io.st(n - 3, vC * scale); }
+    if (active && SFX) { io.st(n - 1, sfx); sfx = sfx + vA * scale; io.st(n - 2, sfx); sfx = sfx + vB * scale; io.st(n - 3, sfx); sfx = sfx + vC * scale; }
     for (int b = NBk - 1; b >= 0; b--) {
         const int rb = b << 5, lo = rb > 3 ? rb : 3, hi = rb + 31 < n - 4 ? rb + 31 : n - 4;     // recurrence rows of the block (may be empty: lo > hi)
         const bool two = 2 * b + 1 < ntile;
@@ -1029,12 +1036,14 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
 #pragma unroll
             for (int e = 0; e < 32; e++) { const double tt = ((x[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = tt; x[e] = tt; }
 #pragma unroll
-            for (int e = 31; e >= 0; e--) { const double tt = ((x[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; x[e] = tt * scale; }
+            for (int e = 31; e >= 0; e--) { const double tt = ((x[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt;
+                                            if (SFX) { x[e] = sfx; sfx = sfx + tt * scale; } else x[e] = tt * scale; }
         } else {
 #pragma unroll
             for (int e = 0; e < 32; e++) { const int row = rb + e; if (row >= lo && row <= hi) { const double tt = ((x[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = tt; x[e] = tt; } }
 #pragma unroll
-            for (int e = 31; e >= 0; e--) { const int row = rb + e; if (row >= lo && row <= hi) { const double tt = ((x[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; x[e] = tt * scale; } }
+            for (int e = 31; e >= 0; e--) { const int row = rb + e; if (row >= lo && row <= hi) { const double tt = ((x[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt;
+                                                                                             if (SFX) { x[e] = sfx; sfx = sfx + tt * scale; } else x[e] = tt * scale; } }
         }
         {   // outputs -> own staging block (lane = column), back in tile layout, stored as aligned lines
             double *q = stage + lane * CF4_GS;
@@ -1047,13 +1056,20 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (active) {   // rows 2, 1, 0: forward values o2, o1, o0
+    if (active && !SFX) {   // rows 2, 1, 0: forward values o2, o1, o0
         double tt = ((o2 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(2, tt * scale);
         tt = ((o1 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(1, tt * scale);
         tt = ((o0 + a1 * v1) + a2 * v2) + a3 * v3; io.st(0, tt * scale);
     }
+    if (active && SFX) {
+        double tt = ((o2 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(2, sfx); sfx = sfx + tt * scale;
+        tt = ((o1 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(1, sfx); sfx = sfx + tt * scale;
+        tt = ((o0 + a1 * v1) + a2 * v2) + a3 * v3; io.st(0, sfx); sfx = sfx + tt * scale;
+        if (io.valid()) A.tot[((size_t)blockIdx.z * 3 + (ROLE - 1)) * A.tot_stride + io.xown()] = sfx;
+    }
 }
 
+template <bool TOL>
 __global__ __launch_bounds__(256, 2) void k_cols_fused(ColsFusedArgs A, IIRPair cf, double *ck)
 {
     __shared__ __attribute__((aligned(16))) double sh[CF4_LDS_DOUBLES];
@@ -1061,10 +1077,10 @@ __global__ __launch_bounds__(256, 2) void k_cols_fused(ColsFusedArgs A, IIRPair 
     double *LB = sh, *IYB = sh + 64 * CF4_LS, *IXB = IYB + 64 * CF4_GS, *QB = IXB + 64 * CF4_GS;
     if (A.src_kind == 2) { lut[threadIdx.x] = (double)threadIdx.x / 255.0; __syncthreads(); }
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (w == 0) cols_fused_wave<0>(A, cf.c[0], ck, LB, IYB, IXB, QB, lut);
-    else if (w == 1) cols_fused_wave<1>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
-    else if (w == 2) cols_fused_wave<2>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
-    else cols_fused_wave<3>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
+    if (w == 0) cols_fused_wave<0, TOL>(A, cf.c[0], ck, LB, IYB, IXB, QB, lut);
+    else if (w == 1) cols_fused_wave<1, TOL>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
+    else if (w == 2) cols_fused_wave<2, TOL>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
+    else cols_fused_wave<3, TOL>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
 }
 
 // integral_image!, lucas_kanade.jl:131-138: cumsum along dim 1 ...
@@ -1396,6 +1412,173 @@ __global__ __launch_bounds__(PAR_T) void k_cum_seg(PlaneSet ps, int H, int W, in
     }
 }
 
+// ---- tolerance build (mode 3, batches): the whole dim-2 stage of a level in ONE kernel, 1 R + 1 W per plane ----------------------------
+// k_iir_rows_ck + k_cum_fused move 8 R + 3.25 W + 3 R + 3 W plane passes per level because a bit-identical recurrence needs a line's
+// samples twice, a line apart.  Here a 1024-thread workgroup owns 16 ROWS of one plane (16 consecutive y = one aligned
+// 128-byte line per column) and cuts them into 64 column segments of SL <= SLMAX samples, one per thread: the thread loads its samples
+// ONCE into registers, runs the forward recurrence from a zero state, the true entry states follow from a two-level fold of the affine
+// maps s -> M^SL s + z through LDS (k_iir_seg's scheme), the thread re-runs the recurrence from its true entry state, the same right to
+// left for the backward recurrence on the register-resident forward values; then, still in registers,
+//   * product planes: the running sum along x (local prefix, segment totals folded through LDS) -- the finished integral image.  Their
+//     input is k_cols_fused<TOL>'s output: exclusive suffix sums E along y of the dim-1-filtered products + the column totals, i.e. the
+//     dim-1 running sum C1[y] = tot - E[y] (a running sum along y and a filter along x commute: different dimensions, both linear);
+//   * the blurred layer: imresize! into the next level's layer (k_resize's arithmetic: horizontal interpolation per lane, row pairs
+//     averaged through DPP; even heights), or a plain store (odd heights: k_resize follows).
+// Inside a segment the arithmetic is the sequential one; the entry states, the order of the two running sums and the suffix-sum form
+// of the dim-1 sum round differently: planes within 1e-11 of the exact mode relative to the plane's magnitude (tests/test_gpu_tol_batch.py).
+#define RT_R 16
+struct RowsTolArgs {
+    double *p[4];           // [blurred layer (dim 1 done)], Qyy, Qxx, Qyx (image 0 of the batch)
+    int coef[4];            // IIRCoef index
+    int kind[4];            // 0: blurred layer, 1: product plane
+    int n, nq0;             // planes; index of the first product plane
+    size_t zs;
+    const double *tot; int tot_stride;
+    RowResize rz;           // kind 0: next level's layer if rz.dst
+};
+template <int SLMAX>
+__global__ __launch_bounds__(PAR_T) void k_rows_tol(RowsTolArgs A, int H, int W, int P, IIRPair cf, SegPow sp, int SL)
+{
+    constexpr int LPW = RT_R, NSEG = PAR_T / LPW;
+    __shared__ double Z[3][NSEG][LPW];
+    __shared__ double GT[3][NSEG / PAR_G + 1][LPW];
+    __shared__ double Fin[3][LPW];
+    const int t = threadIdx.x, l = t % LPW, g = t / LPW, pl = blockIdx.y;
+    const int n = W;
+    const int y = blockIdx.x * LPW + l;
+    const bool valid = y < H;
+    const int yc = valid ? y : H - 1;                      // idle lanes shadow the last row (reads only)
+    double *plane = PS_PICK(A, p, pl) + (size_t)blockIdx.z * A.zs;
+    const int kind = PS_PICK(A, kind, pl), cs = PS_PICK(A, coef, pl);
+    const IIRCoef &k = cf.c[cs];
+    const double a1 = k.a1, a2 = k.a2, a3 = k.a3, scale = k.scale;
+    const int nseg = (n + SL - 1) / SL;
+    const bool has = g < nseg;
+    const int b = g * SL, len = has ? min(n, b + SL) - b : 0;
+    const bool lastseg = has && g == nseg - 1;
+    const double *srcp = plane + yc;
+    double x[SLMAX];
+#pragma unroll
+    for (int j = 0; j < SLMAX; j++) x[j] = (j < len) ? __builtin_nontemporal_load(srcp + (size_t)(b + j) * P) : 0.0;
+    double x0 = srcp[0], xlast = srcp[(size_t)(n - 1) * P];
+    if (kind == 1) {
+        const double *tp = A.tot + ((size_t)blockIdx.z * 3 + (pl - A.nq0)) * A.tot_stride;
+#pragma unroll
+        for (int j = 0; j < SLMAX; j++) if (j < len) x[j] = tp[b + j] - x[j];
+        x0 = tp[0] - x0; xlast = tp[n - 1] - xlast;
+    }
+    const double uminus = x0 / k.inv1masum;
+    // ---------------- forward: zero-state pass, fold, true pass ----------------
+    {
+        double w1 = 0.0, w2 = 0.0, w3 = 0.0;
+#pragma unroll
+        for (int j = 0; j < SLMAX; j++) if (j < len) { const double tt = ((x[j] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; }
+        if (has) { Z[0][g][l] = w1; Z[1][g][l] = w2; Z[2][g][l] = w3; }
+    }
+    __syncthreads();
+    {
+        double w1, w2, w3;
+        fold_entry<LPW>(sp, cs, Z, GT, l, g, has, [](int kk) { return kk; }, uminus, uminus, uminus, w1, w2, w3);
+#pragma unroll
+        for (int j = 0; j < SLMAX; j++) if (j < len) { const double tt = ((x[j] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; x[j] = tt; }
+        if (lastseg) { Fin[0][l] = w1; Fin[1][l] = w2; Fin[2][l] = w3; }
+    }
+    __syncthreads();
+    // ---------------- Triggs-Sdika right boundary ----------------
+    const double f1 = Fin[0][l], f2 = Fin[1][l], f3 = Fin[2][l];
+    const double uplus = xlast / k.inv1masum, vplus = uplus / k.inv1mbsum;
+    const double d0 = f1 - uplus, d1 = f2 - uplus, d2 = f3 - uplus;
+    const double vr0 = ((k.M[0] * d0 + k.M[1] * d1) + k.M[2] * d2) + vplus;
+    const double vr1 = ((k.M[3] * d0 + k.M[4] * d1) + k.M[5] * d2) + vplus;
+    const double vr2 = ((k.M[6] * d0 + k.M[7] * d1) + k.M[8] * d2) + vplus;
+    // ---------------- backward (sample n-1 is not part of the recurrence: v[n-1] = vr0) ----------------
+    const int blen = lastseg ? len - 1 : len;
+    {
+        double v1 = 0.0, v2 = 0.0, v3 = 0.0;
+#pragma unroll
+        for (int j = SLMAX - 1; j >= 0; j--) if (j < blen) { const double tt = ((x[j] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; }
+        if (has) { Z[0][g][l] = v1; Z[1][g][l] = v2; Z[2][g][l] = v3; }
+    }
+    __syncthreads();
+    {
+        double s0a = vr0, s0b = vr1, s0c = vr2;
+        mv3(sp.Plast[cs], s0a, s0b, s0c, Z[0][nseg - 1][l], Z[1][nseg - 1][l], Z[2][nseg - 1][l]);
+        double v1, v2, v3;
+        const int kq = nseg - 2 - g;
+        const bool hasq = has && !lastseg;
+        fold_entry<LPW>(sp, cs, Z, GT, l, hasq ? kq : 0, hasq, [nseg](int kk) { return nseg - 2 - kk; }, s0a, s0b, s0c, v1, v2, v3);
+        if (lastseg) { v1 = vr0; v2 = vr1; v3 = vr2; }
+#pragma unroll
+        for (int j = SLMAX - 1; j >= 0; j--) if (j < blen) { const double tt = ((x[j] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; x[j] = tt * scale; }
+#pragma unroll
+        for (int j = 0; j < SLMAX; j++) if (lastseg && j == len - 1) x[j] = vr0 * scale;
+    }
+    __syncthreads();                                       // every thread is done with Z / GT: they are reused below
+    double (*Zs)[LPW] = Z[0];                              // [NSEG][LPW]
+    double (*Gs)[LPW] = GT[0];                             // [NSEG / PAR_G + 1][LPW]
+    if (kind == 1) {
+        // ---------------- running sum along x (k_cum_seg's scheme on the register-resident values) ----------------
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < SLMAX; j++) if (j < len) acc = acc + x[j];
+        if (has) Zs[g][l] = acc;
+        __syncthreads();
+        const int q = g % PAR_G, grp = g / PAR_G;
+        double pre = 0.0;
+        if (has) for (int i = 0; i < q; i++) pre = pre + Zs[grp * PAR_G + i][l];
+        if (has && q == PAR_G - 1) Gs[grp][l] = pre + Zs[g][l];
+        __syncthreads();
+        double base = 0.0;
+        if (has) for (int h = 0; h < grp; h++) base = base + Gs[h][l];
+        acc = base + pre;
+        double *dstp = plane + yc;
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < SLMAX; j++) if (j < len) { acc = acc + x[j]; __builtin_nontemporal_store(acc, dstp + (size_t)(b + j) * P); }
+        }
+        return;
+    }
+    if (A.rz.dst == nullptr) {                             // blurred layer, plain store (k_resize follows)
+        double *dstp = plane + yc;
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < SLMAX; j++) if (j < len) dstp[(size_t)(b + j) * P] = x[j];
+        }
+        return;
+    }
+    // ---------------- imresize! of the blurred layer into the next level's layer (k_resize's arithmetic, exact 2:1 row ratio) ----------------
+    if (has) Zs[g][l] = x[0];
+    __syncthreads();
+    const double nxt = (has && g + 1 < nseg) ? Zs[g + 1][l] : 0.0;
+    const int Wd = A.rz.Wd, Hd = A.rz.Hd;
+    const double sx = (double)W / (double)Wd, ox = 1 - 0.5 - sx * (1 - 0.5);
+    // first output column (1-based) whose left source sample (1-based floor(c)) is >= b + 1
+    int xo = (int)ceil(((double)(b + 1) - ox) / sx);
+    if (xo < 1) xo = 1;
+    while (xo > 1 && (int)floor(sx * (xo - 1) + ox) >= b + 1) xo--;
+    while (xo <= Wd && (int)floor(sx * xo + ox) < b + 1) xo++;
+    double *dbase = A.rz.dst + (size_t)blockIdx.z * A.zs + (size_t)(y >> 1);
+    const bool writer = valid && (l & 1) == 0 && (y >> 1) < Hd;
+#pragma unroll
+    for (int j = 0; j < SLMAX; j++) {
+        if (j < len) {                                     // (uniform over the 16 rows of a segment: the DPP pairs stay together)
+            const double c = sx * xo + ox;
+            int ixx = (int)floor(c);
+            if (ixx > W - 1) ixx = W - 1;
+            if (ixx < 1) ixx = 1;
+            if (xo <= Wd && ixx == b + j + 1) {
+                const double fx = c - ixx;
+                const double bb = (j + 1 < SLMAX && j + 1 < len) ? x[j + 1 < SLMAX ? j + 1 : j] : nxt;
+                const double h = (1 - fx) * x[j] + fx * bb;
+                const double hn = dpp_pair_next(h);        // lanes 2k, 2k+1 <- lane 2k+1
+                const double fy = 0.5;                      // r = 2 y' - 0.5: exact
+                if (writer) dbase[(size_t)(xo - 1) * A.rz.Pd] = (1 - fy) * h + fy * hn;
+                xo++;
+            }
+        }
+    }
+}
+
 // imgradients (KernelFactors.scharr, separable: derivative (-1,0,1)/2, smoothing
 // (3,10,3)/16; first factor along dim 1 first) + the three gradient products.
 // border 0: replicate (update!, pyramid.jl:98-103); 1: Fill(0) (ctor, pyramid.jl:51,59).
@@ -1643,12 +1826,45 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             hipLaunchKernelGGL(k_cum_seg<false>, gr3, dim3(PAR_T), 0, aux, pc, H, W, P, slr);
             continue;
         }
+        // tolerance build of a batch (mode 3, S >= 4): the dim-1 stage leaves the product planes as suffix sums along y, ONE row kernel
+        // finishes the level (dim-2 filter + running sum along x + imresize!): 1 R + 1 W per plane instead of 11 R + 6.25 W
+        static const bool no_tol_batch = getenv("SLAMHIP_NO_TOL_BATCH") != nullptr;
+        const int slr_t = seg_len(W, PAR_T / RT_R);
+        const bool tolb = mode == 3 && S >= 4 && cols_fused && p->alloc->tot != nullptr && slr_t <= 32 && !no_tol_batch;
         if (cols_fused) {
             ColsFusedArgs ca;
             ca.L = v.L; ca.T = has_next ? T : nullptr; ca.Iy = v.Iy; ca.Ix = v.Ix; ca.Qyy = v.Iyy; ca.Qxx = v.Ixx; ca.Qyx = v.Iyx;
             ca.H = H; ca.W = W; ca.P = P; ca.zs = zs;
             ca.src_kind = l == 0 ? src_kind : 0; ca.srctab = (const void *const *)p->alloc->srctab;
-            hipLaunchKernelGGL(k_cols_fused, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, st, ca, cf, p->ck);
+            size_t toff = 0;
+            for (int q = 0; q < l; q++) toff += (size_t)3 * S * p->W[q];
+            ca.tot = tolb ? p->alloc->tot + toff : nullptr; ca.tot_stride = W;
+            if (tolb) hipLaunchKernelGGL(k_cols_fused<true>, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, st, ca, cf, p->ck);
+            else hipLaunchKernelGGL(k_cols_fused<false>, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, st, ca, cf, p->ck);
+            if (tolb) {
+                RowsTolArgs ra = {};
+                int nr = 0;
+                if (has_next) { ra.p[nr] = T; ra.coef[nr] = 0; ra.kind[nr] = 0; nr++; }
+                ra.nq0 = nr;
+                ra.p[nr] = v.Iyy; ra.coef[nr] = 1; ra.kind[nr] = 1; nr++;
+                ra.p[nr] = v.Ixx; ra.coef[nr] = 1; ra.kind[nr] = 1; nr++;
+                ra.p[nr] = v.Iyx; ra.coef[nr] = 1; ra.kind[nr] = 1; nr++;
+                ra.n = nr; ra.zs = zs; ra.tot = ca.tot; ra.tot_stride = W;
+                const bool rzf = has_next && (H & 1) == 0;
+                if (rzf) { ra.rz.dst = p->view.lv[l + 1].L; ra.rz.Hd = p->H[l + 1]; ra.rz.Wd = p->W[l + 1]; ra.rz.Pd = p->P[l + 1]; }
+                SegPow spr; seg_pow(cf, W, slr_t, spr);
+                const dim3 gr((H + RT_R - 1) / RT_R, nr, S);
+                auto go = [&]() {
+                    if (slr_t <= 16) hipLaunchKernelGGL(k_rows_tol<16>, gr, dim3(PAR_T), 0, st, ra, H, W, P, cf, spr, slr_t);
+                    else if (slr_t <= 24) hipLaunchKernelGGL(k_rows_tol<24>, gr, dim3(PAR_T), 0, st, ra, H, W, P, cf, spr, slr_t);
+                    else hipLaunchKernelGGL(k_rows_tol<32>, gr, dim3(PAR_T), 0, st, ra, H, W, P, cf, spr, slr_t);
+                };
+                if (spans) { ProfScope span(ctx, "k_iir_rows"); go(); } else go();
+                if (has_next && !rzf)
+                    hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, st,
+                                       p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
+                continue;
+            }
         }
         else if (ck_cols) hipLaunchKernelGGL(k_iir_cols_ck, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf, p->ck);
         else if (S == 1) hipLaunchKernelGGL(k_iir_cols<3>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
@@ -1803,6 +2019,9 @@ static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, 
         const size_t need = lines * nbk > lines_c * nbk_c ? lines * nbk : lines_c * nbk_c;
         if (hipMalloc((void **)&ckbuf, need * 3 * 8) != hipSuccess) { (void)hipGetLastError(); ckbuf = nullptr; }
         al->ck = ckbuf;
+        // column totals of the tolerance build's suffix-sum planes: 3 planes x S images x W_l doubles per level
+        size_t wsum = 0; for (int l = 0; l < levels; l++) wsum += (size_t)Ws[l];
+        if (hipMalloc((void **)&al->tot, (size_t)3 * S * wsum * 8) != hipSuccess) { (void)hipGetLastError(); al->tot = nullptr; }
     }
     for (int s = 0; s < S; s++) {
         slam_pyr *p = new slam_pyr();
@@ -1876,7 +2095,7 @@ int slam_pyr_destroy(slam_pyr *p)
     if (!p) return SLAM_OK;
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
-    if (p->alloc && --p->alloc->refs == 0) { (void)hipFree(p->alloc->base); if (p->alloc->ck) (void)hipFree(p->alloc->ck); if (p->alloc->srctab) (void)hipFree(p->alloc->srctab); delete p->alloc; }
+    if (p->alloc && --p->alloc->refs == 0) { (void)hipFree(p->alloc->base); if (p->alloc->ck) (void)hipFree(p->alloc->ck); if (p->alloc->tot) (void)hipFree(p->alloc->tot); if (p->alloc->srctab) (void)hipFree(p->alloc->srctab); delete p->alloc; }
     if (p->norm) (void)hipFree(p->norm);
     for (auto &g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->aux) {
