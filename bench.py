@@ -22,8 +22,8 @@ data path.  Rank 0 prints ONE compact JSON line (< 4 KB) as its LAST stdout line
 the full record goes to bench_detail.json and stderr.
 
 Legs (`--only`, for profiling one population of kernels at a time; default all):
-  single, tolerance, headline, ingest, sweep, host_protocol, configs, ba,
-  ba_sharded, pose, cpu
+  single, tolerance, headline, tolbatch, ingest, sweep, host_protocol, configs,
+  ba, ba_sharded, pose, cpu
 """
 import argparse
 import json
@@ -499,6 +499,7 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     import ctypes as C
     S, H, W, params, extractor, camt, disparity = wl["S"], wl["H"], wl["W"], wl["params"], wl["extractor"], wl["camt"], wl["disparity"]
     left, right, flows, stereo = wl["left"], wl["right"], wl["flows"], wl["stereo"]
+    fastpyr = bool(wl.get("tolerance"))                       # slam_pyr_update_batch mode 3: the tolerance-mode batch kernels (planes <= 1e-11 relative)
     # the tracking context's stream is in a scheduling class of its own (the low-priority one): a hardware queue that the branches
     # of the pyramid graph never land on.  With four default-class streams the runtime placed the graph's small-level branch on
     # the tracking stream's queue and every step's match sat behind it until the build was over (kernel trace).
@@ -577,7 +578,7 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
         if timed:
             pair = ev_pool[len(ev_used) % len(ev_pool)]
             ctx_pyr.record(pair[0])
-        lb[slot].update_(src, sync=False, ctx=ctx_pyr, u8=u8)
+        lb[slot].update_(src, sync=False, ctx=ctx_pyr, u8=u8, fast=fastpyr)
         if timed:
             ctx_pyr.record(pair[1]); ev_used.append(pair)
         built[slot] = ctx_pyr.record(built[slot])
@@ -596,7 +597,7 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
             src = ptrs(rstage)
         else:
             src = ptrs(rseq[o:o + S])
-        rb.update_(src, sync=False, ctx=ctx_right, u8=u8, target_only=RIGHT_TARGET_ONLY)
+        rb.update_(src, sync=False, ctx=ctx_right, u8=u8, target_only=RIGHT_TARGET_ONLY, fast=fastpyr)
         rbuilt[0] = ctx_right.record(rbuilt[0])
 
     nxt = [0]; nxc = [0]
@@ -871,6 +872,7 @@ def peek(label):
 
 
 def kernel_spans(slam, torch, local_rank, wl, dev):
+    fast = bool(wl.get("tolerance"))
     """Per-kernel device time of the batched build with serial launches (hipEvent spans cannot look inside the graph),
     and the graph replay alone on the GPU."""
     S, H, W, params, left = wl["S"], wl["H"], wl["W"], wl["params"], wl["left"]
@@ -881,19 +883,19 @@ def kernel_spans(slam, torch, local_rank, wl, dev):
     torch.cuda.synchronize()
     ptrs = [t.data_ptr() + s * H * W for s in range(S)]
     peek("kernel_spans: before the first build")
-    pb.update_(ptrs, sync=True, ctx=ctx, u8=True)
+    pb.update_(ptrs, sync=True, ctx=ctx, u8=True, fast=fast)
     peek("kernel_spans: after the first build (capture)")
     ea, eb = slam.Event(ctx, timed=True), slam.Event(ctx, timed=True)
     ctx.record(ea)
     for _ in range(20):                                      # the stage alone on the GPU: graph replays back to back
-        pb.update_(ptrs, sync=False, ctx=ctx, u8=True)
+        pb.update_(ptrs, sync=False, ctx=ctx, u8=True, fast=fast)
     ctx.record(eb)
     isolated_us = ea.elapsed_ms(eb) / 20 * 1e3
     peek("kernel_spans: after the replays")
     ea.close(); eb.close()
     ctx.prof_enable(True); ctx.prof_reset()
     for _ in range(20):
-        pb.update_(ptrs, sync=False, ctx=ctx, u8=True)
+        pb.update_(ptrs, sync=False, ctx=ctx, u8=True, fast=fast)
     ctx.synchronize()
     rows_ms, rows_n = ctx.prof_get("k_iir_rows"); pyr_ms, pyr_n = ctx.prof_get("pyr_update")
     ctx.prof_enable(False)
@@ -938,7 +940,7 @@ def spawn_ranks(args):
     return rc
 
 
-LEGS = ("single", "tolerance", "headline", "ingest", "sweep", "host_protocol", "configs", "ba", "ba_sharded", "pose", "cpu")
+LEGS = ("single", "tolerance", "headline", "tolbatch", "ingest", "sweep", "host_protocol", "configs", "ba", "ba_sharded", "pose", "cpu")
 
 
 def newest_pmc(S):
@@ -1030,6 +1032,10 @@ def compact_line(out):
         c["tolerance_mode"] = {k: _r(v) for k, v in tm.items() if isinstance(v, (int, float, bool))}
         if isinstance(tm.get("single_stream"), dict):
             c["tolerance_mode"]["single_stream"] = _r(tm["single_stream"].get("value"))
+        if isinstance(tm.get("batch"), dict):
+            b = tm["batch"]
+            c["tolerance_mode"].update({"value": _r(b.get("value")), "ms_per_step": _r(b.get("ms_per_step")), "planes_rel_tol": 1e-11})
+            c["tolerance_mode"]["roofline"] = {k: _r(b["roofline"].get(k)) for k in ("frac", "frac_isolated", "avg_launch_us", "isolated_launch_us", "traffic", "traffic_over_algorithmic")}
     if out.get("configs"):
         c["configs"] = {k: (_r(v.get("value")) if "value" in v else "error") for k, v in out["configs"].items()}
     if out.get("pose", {}).get("frontend_with_pose"):
@@ -1183,7 +1189,7 @@ def main():
     if child_part is not None:
         for key in ("single_stream", "tolerance_mode"):
             if key in child_part:
-                out[key] = child_part[key]
+                out[key] = dict(child_part[key])
         if world > 1:                                            # one stream per GPU: the slowest GPU counts, times the number of GPUs
             for key, sub_ in (("single_stream", None), ("tolerance_mode", "single_stream")):
                 node = out.get(key, {}) if sub_ is None else out.get(key, {}).get(sub_, {})
@@ -1389,6 +1395,31 @@ def main():
             out["roofline"]["traffic_over_algorithmic"] = j["summary"]["all_pyramid_kernels_bytes_per_batch_build"] / pb
             out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per "
                                                  f"MI355X_MICROARCH.md, WRITE exact), all kernels of one {S}-image build; collected at commit {j.get('commit', 'unrecorded')}")
+
+    # ---- the headline loop on TOLERANCE-MODE pyramids (slam_pyr_update_batch mode 3: k_cols_fused<TOL> + k_rows_tol, planes <= 1e-11 relative
+    #      to the exact build, tracked positions <= 1e-6 px: tests/test_gpu_tol_batch.py); keypoint indices still come from detect on the raw frame ----
+    if "tolbatch" in legs:
+        wt = dict(wl); wt["tolerance"] = True
+        tb = retried("tolerance batch", lambda: run_lockstep_kpset(slam, torch, local_rank, wt, max(8, args.steps // 2), 2, world, dist, dev, "host_u8"))
+        leg_done("tolbatch")
+        _, tserial_us, tiso_us = retried("tolerance batch kernel spans", lambda: kernel_spans(slam, torch, local_rank, wt, dev))
+        pbt = S * pyramid_bytes(H, W, levels)
+        tbm = tb["pyramid_build_ms"]["mean"]
+        tnode = out.setdefault("tolerance_mode", {})
+        tnode["batch"] = {"value": tb["value"], "unit": "frames/sec", "streams_per_gpu": S, "steps": tb["steps"], "ms_per_step": tb["ms_per_step"],
+                          "tracked_kpts_per_frame": tb["tracked_kpts_per_frame"],
+                          "pyramid": "slam_pyr_update_batch_u8_dev mode 3: dim-1 stage k_cols_fused<TOL> (product planes leave as suffix sums along y), dim-2 stage + running sum "
+                                     "along x + imresize! in ONE kernel k_rows_tol (1 R + 1 W per plane); planes <= 1e-11 relative, positions <= 1e-6 px",
+                          "roofline": {"bound": "hbm", "stage": f"LK pyramid update of {S} images, tolerance mode", "algorithmic_bytes_per_launch": pbt,
+                                       "avg_launch_us": tbm * 1e3, "achieved": pbt / (tbm * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": pbt / (tbm * 1e-3) / 1e9 / HBM_PEAK_GBS, "isolated_launch_us": tiso_us,
+                                       "frac_isolated": pbt / (tiso_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "serial_launches_us": tserial_us, "traffic": None}}
+        import glob as _g
+        c = sorted(_g.glob(os.path.join(ROOT, "profiles", f"r*_pmc_pyramid_tol_batch_s{S}.json")))
+        if c:
+            j = json.load(open(c[-1]))
+            tr = j["summary"]["all_pyramid_kernels_bytes_per_batch_build"]
+            tnode["batch"]["roofline"].update({"traffic": tr, "traffic_over_algorithmic": tr / pbt, "traffic_source": f"profiles/{os.path.basename(c[-1])}"})
 
     # ---- the other ingest configurations of the same loop ----
     if "ingest" in legs:

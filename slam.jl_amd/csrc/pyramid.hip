@@ -1427,6 +1427,7 @@ __global__ __launch_bounds__(PAR_T) void k_cum_seg(PlaneSet ps, int H, int W, in
 // Inside a segment the arithmetic is the sequential one; the entry states, the order of the two running sums and the suffix-sum form
 // of the dim-1 sum round differently: planes within 1e-11 of the exact mode relative to the plane's magnitude (tests/test_gpu_tol_batch.py).
 #define RT_R 16
+#define RT_NS 32
 struct RowsTolArgs {
     double *p[4];           // [blurred layer (dim 1 done)], Qyy, Qxx, Qyx (image 0 of the batch)
     int coef[4];            // IIRCoef index
@@ -1435,52 +1436,133 @@ struct RowsTolArgs {
     size_t zs;
     const double *tot; int tot_stride;
     RowResize rz;           // kind 0: next level's layer if rz.dst
+    int dbg;                // SLAMHIP_RT_DBG (timing experiments only): 1 = loads + stores without the arithmetic (invalid planes)
 };
-template <int SLMAX>
-__global__ __launch_bounds__(PAR_T) void k_rows_tol(RowsTolArgs A, int H, int W, int P, IIRPair cf, SegPow sp, int SL)
+// (this kernel is tolerance mode by definition: its multiply-adds are fused -- half the f64 instructions of the -ffp-contract=off form)
+__device__ __forceinline__ double rt_step(double x, double a1, double a2, double a3, double w1, double w2, double w3)
 {
-    constexpr int LPW = RT_R, NSEG = PAR_T / LPW;
-    __shared__ double Z[3][NSEG][LPW];
-    __shared__ double GT[3][NSEG / PAR_G + 1][LPW];
+    return __builtin_fma(a3, w3, __builtin_fma(a2, w2, __builtin_fma(a1, w1, x)));
+}
+__device__ __forceinline__ void mv3f(const double *P, double &a, double &b, double &c, double za, double zb, double zc)
+{
+    const double n1 = __builtin_fma(P[0], a, __builtin_fma(P[1], b, __builtin_fma(P[2], c, za)));
+    const double n2 = __builtin_fma(P[3], a, __builtin_fma(P[4], b, __builtin_fma(P[5], c, zb)));
+    const double n3 = __builtin_fma(P[6], a, __builtin_fma(P[7], b, __builtin_fma(P[8], c, zc)));
+    a = n1; b = n2; c = n3;
+}
+// entry state of segment `k` (0-based in fold order) of row l: two-level fold over groups of PAR_G segments (fold_entry's scheme).
+// Z: zero-state end states [3][NS][RT_R] indexed through slot(fold index); GT: group totals [3][NS / PAR_G + 1][RT_R]
+template <int NS, int R, class Slot>
+__device__ __forceinline__ void rt_fold(const double *PW, double (*Z)[NS][R], double (*GT)[NS / PAR_G + 1][R], int l, int k, bool has, Slot slot,
+                                        double s0a, double s0b, double s0c, double &ea, double &eb, double &ec)
+{
+    const int q = k % PAR_G, grp = k / PAR_G;
+    const double *P1 = PW, *P8 = PW + 9 * (PAR_G - 1);      // PW: M^(SL q), q = 1 .. PAR_G, 9 doubles each (LDS)
+    double a = 0.0, b = 0.0, c = 0.0;
+    if (has) {
+#pragma unroll 1
+        for (int i = 0; i < q; i++) { const int s = slot(grp * PAR_G + i); mv3f(P1, a, b, c, Z[0][s][l], Z[1][s][l], Z[2][s][l]); }
+    }
+    if (has && q == PAR_G - 1) {
+        double ta = a, tb = b, tc = c; const int s = slot(k);
+        mv3f(P1, ta, tb, tc, Z[0][s][l], Z[1][s][l], Z[2][s][l]);
+        GT[0][grp][l] = ta; GT[1][grp][l] = tb; GT[2][grp][l] = tc;
+    }
+    __syncthreads();
+    double Sa = s0a, Sb = s0b, Sc = s0c;
+    if (has) {
+#pragma unroll 1
+        for (int h = 0; h < grp; h++) mv3f(P8, Sa, Sb, Sc, GT[0][h][l], GT[1][h][l], GT[2][h][l]);
+        if (q > 0) mv3f(PW + 9 * (q - 1), Sa, Sb, Sc, 0.0, 0.0, 0.0);
+    }
+    ea = Sa + a; eb = Sb + b; ec = Sc + c;
+}
+// Every segment has exactly SL samples (no per-sample predicates in the recurrences): the line is padded on the LEFT with
+// pad = nseg SL - n virtual samples equal to x[0] -- under the replicate border the forward state before sample 0 is the steady
+// state of a constant input x[0], which those samples leave unchanged; their outputs are never stored and count as zeros in the
+// running sum.
+template <int SL, int NS, int R>
+__global__ __launch_bounds__(R * NS, (R * NS >= 1024 ? 4 : 4)) void k_rows_tol(RowsTolArgs A, int H, int W, int P, IIRPair cf, SegPow sp)
+{
+    constexpr int LPW = R;
+    __shared__ double Z[3][NS][LPW];
+    __shared__ double GT[3][NS / PAR_G + 1][LPW];
     __shared__ double Fin[3][LPW];
+    __shared__ double PW[9 * (PAR_G + 1)];                 // M^(SL q), q = 1 .. PAR_G; M^(SL - 1)
+    __shared__ double TOT[SL * NS];                        // product planes: the column totals of this plane's image (tot - E = running sum along y)
+    // XCD-aware placement: workgroups go to the 8 XCDs round-robin by linear id; with R = 8 a 128-byte line (16 rows of a column) is shared
+    // by two workgroups, which are given linear ids 8 apart -- the same XCD, so the second finds the line in that L2
+    int bx = blockIdx.x;
+    if (R == 8) {
+        const int xcd = bx & 7, slot = bx >> 3;
+        const int unit = (slot >> 1) * 8 + xcd;
+        bx = unit * 2 + (slot & 1);
+        if (bx * R >= H) return;                                   // (the grid is rounded up to whole pairs of 8)
+    }
     const int t = threadIdx.x, l = t % LPW, g = t / LPW, pl = blockIdx.y;
     const int n = W;
-    const int y = blockIdx.x * LPW + l;
+    const int y = bx * LPW + l;
     const bool valid = y < H;
     const int yc = valid ? y : H - 1;                      // idle lanes shadow the last row (reads only)
     double *plane = PS_PICK(A, p, pl) + (size_t)blockIdx.z * A.zs;
     const int kind = PS_PICK(A, kind, pl), cs = PS_PICK(A, coef, pl);
     const IIRCoef &k = cf.c[cs];
     const double a1 = k.a1, a2 = k.a2, a3 = k.a3, scale = k.scale;
-    const int nseg = (n + SL - 1) / SL;
+    const int nseg = (n + SL - 1) / SL, pad = nseg * SL - n;
     const bool has = g < nseg;
-    const int b = g * SL, len = has ? min(n, b + SL) - b : 0;
-    const bool lastseg = has && g == nseg - 1;
-    const double *srcp = plane + yc;
-    double x[SLMAX];
+    const int b = g * SL - pad;                            // column of the segment's first sample (negative inside the padding)
+    const bool lastseg = g == nseg - 1;
+    if (t < 9 * PAR_G) PW[t] = sp.P[cs][t / 9][t % 9];
+    else if (t < 9 * PAR_G + 9) PW[t] = sp.Plast[cs][t - 9 * PAR_G];
+    // addressing: uniform plane / column base (SGPRs) + one 32-bit byte offset per lane -- no per-load 64-bit address arithmetic in VGPRs
+    const char *pb = (const char *)plane;
+    const int bl = b < n - SL ? b : n - SL;               // idle segments (g >= nseg) shadow the last one (reads only)
+    double x[SL];
+    const double x0r = *(const double *)(pb + (unsigned)yc * 8u), xlr = *(const double *)(pb + ((size_t)(n - 1) * P) * 8 + (unsigned)yc * 8u);
+    {
 #pragma unroll
-    for (int j = 0; j < SLMAX; j++) x[j] = (j < len) ? __builtin_nontemporal_load(srcp + (size_t)(b + j) * P) : 0.0;
-    double x0 = srcp[0], xlast = srcp[(size_t)(n - 1) * P];
+        for (int j = 0; j < SL; j++) {
+            const int col = bl + j > 0 ? bl + j : 0;       // the padding of segment 0 shadows column 0 (replaced by x0 below)
+            x[j] = __builtin_nontemporal_load((const double *)(pb + (unsigned)(((unsigned)col * (unsigned)P + (unsigned)yc) * 8u)));
+        }
+    }
+    double x0 = x0r, xlast = xlr;
     if (kind == 1) {
         const double *tp = A.tot + ((size_t)blockIdx.z * 3 + (pl - A.nq0)) * A.tot_stride;
+        for (int i = t; i < n; i += R * NS) TOT[i] = tp[i];
+        __syncthreads();
+        if (has) {
 #pragma unroll
-        for (int j = 0; j < SLMAX; j++) if (j < len) x[j] = tp[b + j] - x[j];
-        x0 = tp[0] - x0; xlast = tp[n - 1] - xlast;
+            for (int j = 0; j < SL; j++) x[j] = TOT[b + j >= 0 ? b + j : 0] - x[j];
+        }
+        x0 = TOT[0] - x0; xlast = TOT[n - 1] - xlast;
+    } else __syncthreads();                                // PW
+    if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < SL; j++) if (j < pad) x[j] = x0;
+    }
+    if (A.dbg & 1) {
+        char *wb = (char *)plane;
+        if (valid && has && kind == 1) {
+#pragma unroll
+            for (int j = 0; j < SL; j++) if (j >= pad || g != 0) __builtin_nontemporal_store(x[j], (double *)(wb + (unsigned)(((unsigned)(b + j) * (unsigned)P + (unsigned)yc) * 8u)));
+        }
+        return;
     }
     const double uminus = x0 / k.inv1masum;
     // ---------------- forward: zero-state pass, fold, true pass ----------------
     {
         double w1 = 0.0, w2 = 0.0, w3 = 0.0;
 #pragma unroll
-        for (int j = 0; j < SLMAX; j++) if (j < len) { const double tt = ((x[j] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; }
+        for (int j = 0; j < SL; j++) { const double tt = rt_step(x[j], a1, a2, a3, w1, w2, w3); w3 = w2; w2 = w1; w1 = tt; }
         if (has) { Z[0][g][l] = w1; Z[1][g][l] = w2; Z[2][g][l] = w3; }
     }
     __syncthreads();
     {
         double w1, w2, w3;
-        fold_entry<LPW>(sp, cs, Z, GT, l, g, has, [](int kk) { return kk; }, uminus, uminus, uminus, w1, w2, w3);
+        rt_fold<NS, R>(PW, Z, GT, l, g, has, [](int kk) { return kk; }, uminus, uminus, uminus, w1, w2, w3);
 #pragma unroll
-        for (int j = 0; j < SLMAX; j++) if (j < len) { const double tt = ((x[j] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; x[j] = tt; }
+        for (int j = 0; j < SL; j++) { const double tt = rt_step(x[j], a1, a2, a3, w1, w2, w3); w3 = w2; w2 = w1; w1 = tt; x[j] = tt; }
         if (lastseg) { Fin[0][l] = w1; Fin[1][l] = w2; Fin[2][l] = w3; }
     }
     __syncthreads();
@@ -1491,36 +1573,39 @@ __global__ __launch_bounds__(PAR_T) void k_rows_tol(RowsTolArgs A, int H, int W,
     const double vr0 = ((k.M[0] * d0 + k.M[1] * d1) + k.M[2] * d2) + vplus;
     const double vr1 = ((k.M[3] * d0 + k.M[4] * d1) + k.M[5] * d2) + vplus;
     const double vr2 = ((k.M[6] * d0 + k.M[7] * d1) + k.M[8] * d2) + vplus;
-    // ---------------- backward (sample n-1 is not part of the recurrence: v[n-1] = vr0) ----------------
-    const int blen = lastseg ? len - 1 : len;
+    // ---------------- backward (sample n-1, the last segment's last, is not part of the recurrence: v[n-1] = vr0) ----------------
     {
         double v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        if (!lastseg) { const double tt = rt_step(x[SL - 1], a1, a2, a3, v1, v2, v3); v3 = v2; v2 = v1; v1 = tt; }
 #pragma unroll
-        for (int j = SLMAX - 1; j >= 0; j--) if (j < blen) { const double tt = ((x[j] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; }
+        for (int j = SL - 2; j >= 0; j--) { const double tt = rt_step(x[j], a1, a2, a3, v1, v2, v3); v3 = v2; v2 = v1; v1 = tt; }
         if (has) { Z[0][g][l] = v1; Z[1][g][l] = v2; Z[2][g][l] = v3; }
     }
     __syncthreads();
     {
         double s0a = vr0, s0b = vr1, s0c = vr2;
-        mv3(sp.Plast[cs], s0a, s0b, s0c, Z[0][nseg - 1][l], Z[1][nseg - 1][l], Z[2][nseg - 1][l]);
+        mv3f(PW + 9 * PAR_G, s0a, s0b, s0c, Z[0][nseg - 1][l], Z[1][nseg - 1][l], Z[2][nseg - 1][l]);
         double v1, v2, v3;
         const int kq = nseg - 2 - g;
         const bool hasq = has && !lastseg;
-        fold_entry<LPW>(sp, cs, Z, GT, l, hasq ? kq : 0, hasq, [nseg](int kk) { return nseg - 2 - kk; }, s0a, s0b, s0c, v1, v2, v3);
-        if (lastseg) { v1 = vr0; v2 = vr1; v3 = vr2; }
+        rt_fold<NS, R>(PW, Z, GT, l, hasq ? kq : 0, hasq, [nseg](int kk) { return nseg - 2 - kk; }, s0a, s0b, s0c, v1, v2, v3);
+        if (lastseg) { v1 = vr0; v2 = vr1; v3 = vr2; x[SL - 1] = vr0 * scale; }
+        else { const double tt = rt_step(x[SL - 1], a1, a2, a3, v1, v2, v3); v3 = v2; v2 = v1; v1 = tt; x[SL - 1] = tt * scale; }
 #pragma unroll
-        for (int j = SLMAX - 1; j >= 0; j--) if (j < blen) { const double tt = ((x[j] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; x[j] = tt * scale; }
-#pragma unroll
-        for (int j = 0; j < SLMAX; j++) if (lastseg && j == len - 1) x[j] = vr0 * scale;
+        for (int j = SL - 2; j >= 0; j--) { const double tt = rt_step(x[j], a1, a2, a3, v1, v2, v3); v3 = v2; v2 = v1; v1 = tt; x[j] = tt * scale; }
     }
     __syncthreads();                                       // every thread is done with Z / GT: they are reused below
-    double (*Zs)[LPW] = Z[0];                              // [NSEG][LPW]
-    double (*Gs)[LPW] = GT[0];                             // [NSEG / PAR_G + 1][LPW]
+    double (*Zs)[LPW] = Z[0];                              // [NS][LPW]
+    double (*Gs)[LPW] = GT[0];                             // [NS / PAR_G + 1][LPW]
     if (kind == 1) {
         // ---------------- running sum along x (k_cum_seg's scheme on the register-resident values) ----------------
+        if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < SL; j++) if (j < pad) x[j] = 0.0;
+        }
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < SLMAX; j++) if (j < len) acc = acc + x[j];
+        for (int j = 0; j < SL; j++) acc = acc + x[j];
         if (has) Zs[g][l] = acc;
         __syncthreads();
         const int q = g % PAR_G, grp = g / PAR_G;
@@ -1531,50 +1616,53 @@ __global__ __launch_bounds__(PAR_T) void k_rows_tol(RowsTolArgs A, int H, int W,
         double base = 0.0;
         if (has) for (int h = 0; h < grp; h++) base = base + Gs[h][l];
         acc = base + pre;
-        double *dstp = plane + yc;
-        if (valid) {
+        char *wb = (char *)plane;
+        if (valid && has && g != 0) {
 #pragma unroll
-            for (int j = 0; j < SLMAX; j++) if (j < len) { acc = acc + x[j]; __builtin_nontemporal_store(acc, dstp + (size_t)(b + j) * P); }
+            for (int j = 0; j < SL; j++) { acc = acc + x[j]; __builtin_nontemporal_store(acc, (double *)(wb + (unsigned)(((unsigned)(b + j) * (unsigned)P + (unsigned)yc) * 8u))); }
+        } else if (valid && has) {
+#pragma unroll
+            for (int j = 0; j < SL; j++) { acc = acc + x[j]; if (j >= pad) __builtin_nontemporal_store(acc, (double *)(wb + (unsigned)(((unsigned)(b + j) * (unsigned)P + (unsigned)yc) * 8u))); }
         }
         return;
     }
     if (A.rz.dst == nullptr) {                             // blurred layer, plain store (k_resize follows)
-        double *dstp = plane + yc;
-        if (valid) {
+        char *wb = (char *)plane;
+        if (valid && has) {
 #pragma unroll
-            for (int j = 0; j < SLMAX; j++) if (j < len) dstp[(size_t)(b + j) * P] = x[j];
+            for (int j = 0; j < SL; j++) if (j >= pad || g != 0) *(double *)(wb + (unsigned)(((unsigned)(b + j) * (unsigned)P + (unsigned)yc) * 8u)) = x[j];
         }
         return;
     }
     // ---------------- imresize! of the blurred layer into the next level's layer (k_resize's arithmetic, exact 2:1 row ratio) ----------------
     if (has) Zs[g][l] = x[0];
     __syncthreads();
-    const double nxt = (has && g + 1 < nseg) ? Zs[g + 1][l] : 0.0;
+    if (!has) return;
+    const double nxt = g + 1 < nseg ? Zs[g + 1][l] : 0.0;
     const int Wd = A.rz.Wd, Hd = A.rz.Hd;
     const double sx = (double)W / (double)Wd, ox = 1 - 0.5 - sx * (1 - 0.5);
-    // first output column (1-based) whose left source sample (1-based floor(c)) is >= b + 1
-    int xo = (int)ceil(((double)(b + 1) - ox) / sx);
+    // first output column (1-based) whose left source sample (1-based: floor(c)) is >= max(b, 0) + 1
+    const int b0 = b > 0 ? b : 0;
+    int xo = (int)ceil(((double)(b0 + 1) - ox) / sx);
     if (xo < 1) xo = 1;
-    while (xo > 1 && (int)floor(sx * (xo - 1) + ox) >= b + 1) xo--;
-    while (xo <= Wd && (int)floor(sx * xo + ox) < b + 1) xo++;
+    while (xo > 1 && (int)floor(sx * (xo - 1) + ox) >= b0 + 1) xo--;
+    while (xo <= Wd && (int)floor(sx * xo + ox) < b0 + 1) xo++;
     double *dbase = A.rz.dst + (size_t)blockIdx.z * A.zs + (size_t)(y >> 1);
     const bool writer = valid && (l & 1) == 0 && (y >> 1) < Hd;
 #pragma unroll
-    for (int j = 0; j < SLMAX; j++) {
-        if (j < len) {                                     // (uniform over the 16 rows of a segment: the DPP pairs stay together)
-            const double c = sx * xo + ox;
-            int ixx = (int)floor(c);
-            if (ixx > W - 1) ixx = W - 1;
-            if (ixx < 1) ixx = 1;
-            if (xo <= Wd && ixx == b + j + 1) {
-                const double fx = c - ixx;
-                const double bb = (j + 1 < SLMAX && j + 1 < len) ? x[j + 1 < SLMAX ? j + 1 : j] : nxt;
-                const double h = (1 - fx) * x[j] + fx * bb;
-                const double hn = dpp_pair_next(h);        // lanes 2k, 2k+1 <- lane 2k+1
-                const double fy = 0.5;                      // r = 2 y' - 0.5: exact
-                if (writer) dbase[(size_t)(xo - 1) * A.rz.Pd] = (1 - fy) * h + fy * hn;
-                xo++;
-            }
+    for (int j = 0; j < SL; j++) {                         // (the conditions are uniform over the 16 rows of a segment: the DPP pairs stay together)
+        const double c = sx * xo + ox;
+        int ixx = (int)floor(c);
+        if (ixx > W - 1) ixx = W - 1;
+        if (ixx < 1) ixx = 1;
+        if (xo <= Wd && ixx == b + j + 1) {
+            const double fx = c - ixx;
+            const double bb = j + 1 < SL ? x[j + 1 < SL ? j + 1 : j] : nxt;
+            const double h = (1 - fx) * x[j] + fx * bb;
+            const double hn = dpp_pair_next(h);            // lanes 2k, 2k+1 <- lane 2k+1
+            const double fy = 0.5;                          // r = 2 y' - 0.5: exact
+            if (writer) dbase[(size_t)(xo - 1) * A.rz.Pd] = (1 - fy) * h + fy * hn;
+            xo++;
         }
     }
 }
@@ -1750,6 +1838,20 @@ static void seg_pow(const IIRPair &cf, int n, int SL, SegPow &sp)
     }
 }
 
+// k_rows_tol: samples per segment from a fixed menu (one instantiation each), the smallest that covers a row with RT_NS segments; 0: none
+static int rt_seg_len(int n)
+{
+    static const int menu[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 40};
+    for (int m : menu) if ((n + m - 1) / m <= RT_NS && n >= 2 * m) return m;
+    return 0;
+}
+static void rt_seg_pow(const IIRPair &cf, int SL, SegPow &sp)     // M^(SL q), q = 1 .. PAR_G; M^(SL - 1): all segments are full (left padding)
+{
+    for (int c = 0; c < 2; c++) {
+        for (int q = 1; q <= PAR_G; q++) mat3_pow(cf.c[c], SL * q, sp.P[c][q - 1]);
+        mat3_pow(cf.c[c], SL - 1, sp.Plast[c]);
+    }
+}
 // Launch every kernel of one pyramid build.  `st` carries the dependent chain
 // (gradients -> IIR dim 1 -> IIR dim 2 -> resize -> next level); the integral-image
 // passes of level l only feed the LK kernel, so they run on `aux`, concurrently
@@ -1829,8 +1931,8 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         // tolerance build of a batch (mode 3, S >= 4): the dim-1 stage leaves the product planes as suffix sums along y, ONE row kernel
         // finishes the level (dim-2 filter + running sum along x + imresize!): 1 R + 1 W per plane instead of 11 R + 6.25 W
         static const bool no_tol_batch = getenv("SLAMHIP_NO_TOL_BATCH") != nullptr;
-        const int slr_t = seg_len(W, PAR_T / RT_R);
-        const bool tolb = mode == 3 && S >= 4 && cols_fused && p->alloc->tot != nullptr && slr_t <= 32 && !no_tol_batch;
+        const int slr_t = rt_seg_len(W);
+        const bool tolb = mode == 3 && S >= 4 && cols_fused && p->alloc->tot != nullptr && slr_t > 0 && !no_tol_batch;
         if (cols_fused) {
             ColsFusedArgs ca;
             ca.L = v.L; ca.T = has_next ? T : nullptr; ca.Iy = v.Iy; ca.Ix = v.Ix; ca.Qyy = v.Iyy; ca.Qxx = v.Ixx; ca.Qyx = v.Iyx;
@@ -1852,12 +1954,14 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
                 ra.n = nr; ra.zs = zs; ra.tot = ca.tot; ra.tot_stride = W;
                 const bool rzf = has_next && (H & 1) == 0;
                 if (rzf) { ra.rz.dst = p->view.lv[l + 1].L; ra.rz.Hd = p->H[l + 1]; ra.rz.Wd = p->W[l + 1]; ra.rz.Pd = p->P[l + 1]; }
-                SegPow spr; seg_pow(cf, W, slr_t, spr);
-                const dim3 gr((H + RT_R - 1) / RT_R, nr, S);
+                SegPow spr; rt_seg_pow(cf, slr_t, spr);
+                static const int rt_dbg = getenv("SLAMHIP_RT_DBG") ? atoi(getenv("SLAMHIP_RT_DBG")) : 0; ra.dbg = rt_dbg;
+                const dim3 gr(RT_R == 8 ? (((H + 15) / 16 + 7) / 8) * 16 : (H + RT_R - 1) / RT_R, nr, S), bd(RT_R * RT_NS);
                 auto go = [&]() {
-                    if (slr_t <= 16) hipLaunchKernelGGL(k_rows_tol<16>, gr, dim3(PAR_T), 0, st, ra, H, W, P, cf, spr, slr_t);
-                    else if (slr_t <= 24) hipLaunchKernelGGL(k_rows_tol<24>, gr, dim3(PAR_T), 0, st, ra, H, W, P, cf, spr, slr_t);
-                    else hipLaunchKernelGGL(k_rows_tol<32>, gr, dim3(PAR_T), 0, st, ra, H, W, P, cf, spr, slr_t);
+#define RT_GO(SLV) hipLaunchKernelGGL((k_rows_tol<SLV, RT_NS, RT_R>), gr, bd, 0, st, ra, H, W, P, cf, spr)
+                    switch (slr_t) { case 4: RT_GO(4); break; case 6: RT_GO(6); break; case 8: RT_GO(8); break; case 10: RT_GO(10); break; case 12: RT_GO(12); break;
+                                     case 16: RT_GO(16); break; case 20: RT_GO(20); break; case 24: RT_GO(24); break; case 32: RT_GO(32); break; default: RT_GO(40); break; }
+#undef RT_GO
                 };
                 if (spans) { ProfScope span(ctx, "k_iir_rows"); go(); } else go();
                 if (has_next && !rzf)
