@@ -108,6 +108,10 @@ static void flow_vector(const orc_pyr *first, const orc_pyr *second, int lv, con
                 bx += dI * Ix[a];
             }
     } else {
+        /* sum_order 1: the element e of the (q outer, p inner) enumeration goes to lane e % 64, a lane adds its elements in order, the
+         * 64 partial sums are folded by the xor butterfly m = 32, 16, 1, 2, 4, 8 (rounds 1-3 of the device kernel: one wave per keypoint);
+         * sum_order 2: lane e % 32 and the butterfly m = 16, 1, 2, 4, 8 (round 4: one 32-lane half-wave per keypoint, csrc/lk.hip: half_sum2) */
+        const int NL = sum_order == 2 ? 32 : 64;
         double ay[64], ax[64];
         for (int l = 0; l < 64; l++) ay[l] = ax[l] = 0.0;
         int e = 0;
@@ -116,15 +120,16 @@ static void flow_vector(const orc_pyr *first, const orc_pyr *second, int lv, con
                 double r = corr[0] + (double)(p - o.up), c = corr[1] + (double)(q - o.left);
                 size_t a = IDX(point[0] - o.up + p - 1, point[1] - o.left + q - 1, H);
                 double dI = A[a] - orc_bilinear(B, H, W, r, c);
-                ay[e & 63] += dI * Iy[a];
-                ax[e & 63] += dI * Ix[a];
+                ay[e % NL] += dI * Iy[a];
+                ax[e % NL] += dI * Ix[a];
             }
-        static const int order[6] = {32, 16, 1, 2, 4, 8};     /* the butterfly order of the device kernel's wave sum (csrc/lk.hip: wave_sum2) */
-        for (int mi = 0; mi < 6; mi++) {
+        static const int order1[6] = {32, 16, 1, 2, 4, 8}, order2[5] = {16, 1, 2, 4, 8};
+        const int *order = sum_order == 2 ? order2 : order1, nsteps = sum_order == 2 ? 5 : 6;
+        for (int mi = 0; mi < nsteps; mi++) {
             const int m = order[mi];
             double ty[64], tx[64];
-            for (int l = 0; l < 64; l++) { ty[l] = ay[l] + ay[l ^ m]; tx[l] = ax[l] + ax[l ^ m]; }
-            memcpy(ay, ty, sizeof ay); memcpy(ax, tx, sizeof ax);
+            for (int l = 0; l < NL; l++) { ty[l] = ay[l] + ay[l ^ m]; tx[l] = ax[l] + ax[l ^ m]; }
+            memcpy(ay, ty, sizeof(double) * NL); memcpy(ax, tx, sizeof(double) * NL);
         }
         by = ay[0]; bx = ax[0];
     }
