@@ -264,10 +264,9 @@ template <int LK_MAXE> struct PatchGeom {
     static constexpr int WMAX = LK_MAXE == 3 ? 6 : LK_MAXE == 6 ? 9 : 11;        // largest window_size of the instantiation
     static constexpr int PS = 2 * WMAX + 2 + 2 * LK_PM;                           // 22 / 28 / 32 (even)
 };
-// top-left (cy, cx) 0-based is clipped so that the patch lies inside the image where the image is large enough.  No bounds
-// guards on the loads: rows / columns past the image are only staged when the image is smaller than the patch, they lie
-// inside the pyramid allocation (the layer planes are followed by the gradient planes) and are never sampled -- the
-// caller samples footprints that lie inside the image.
+// top-left (cy, cx) 0-based is clipped so that the patch lies inside the image where the image is large enough; rows / columns
+// past the image exist only when the image is smaller than the patch and are never sampled -- the caller samples footprints that
+// lie inside the image.
 template <int PS>
 __device__ __forceinline__ void stage_patch(double *patch, const double *img, int H, int W, int pitch, int cy, int cx, int &pry, int &prx)
 {
@@ -283,9 +282,13 @@ __device__ __forceinline__ void stage_patch(double *patch, const double *img, in
     constexpr int NIT = (PS + CPI - 1) / CPI;
     const int ch = lane % CPC, c = lane / CPC;
     const double *src = img + (size_t)pry + (size_t)prx * pitch + (2 * ch + (size_t)c * pitch);
+    // images smaller than the patch (H < PS or W < PS: the coarsest levels, degenerate narrow frames): the chunks / columns past the
+    // image are not requested, so the loads stay inside the layer plane (for odd H the chunk of row H - 1 also takes the pitch padding
+    // row behind it); those patch cells are never sampled
+    const bool rows_ok = pry + 2 * ch < H;
 #pragma unroll
     for (int i = 0; i < NIT; i++) {
-        if (c < CPI && i * CPI + c < PS)
+        if (c < CPI && i * CPI + c < PS && rows_ok && prx + i * CPI + c < W)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)(i * CPI) * pitch),
                                              (__attribute__((address_space(3))) void *)(patch + i * CPI * PS), 16, 0, 0);
     }

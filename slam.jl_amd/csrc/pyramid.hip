@@ -1453,11 +1453,13 @@ __device__ __forceinline__ void mv3f(const double *P, double &a, double &b, doub
 // entry state of segment `k` (0-based in fold order) of row l: two-level fold over groups of PAR_G segments (fold_entry's scheme).
 // Z: zero-state end states [3][NS][RT_R] indexed through slot(fold index); GT: group totals [3][NS / PAR_G + 1][RT_R]
 template <int NS, int R, class Slot>
-__device__ __forceinline__ void rt_fold(const double *PW, double (*Z)[NS][R], double (*GT)[NS / PAR_G + 1][R], int l, int k, bool has, Slot slot,
+__device__ __forceinline__ void rt_fold(const SegPow &sp, int cs, const double *PW, double (*Z)[NS][R], double (*GT)[NS / PAR_G + 1][R], int l, int k, bool has, Slot slot,
                                         double s0a, double s0b, double s0c, double &ea, double &eb, double &ec)
 {
     const int q = k % PAR_G, grp = k / PAR_G;
-    const double *P1 = PW, *P8 = PW + 9 * (PAR_G - 1);      // PW: M^(SL q), q = 1 .. PAR_G, 9 doubles each (LDS)
+    // M^SL and M^(8 SL) are the same for every lane: read from the kernel-argument segment (cs is wave-uniform -> scalar loads, SGPR
+    // operands of the multiply-adds, no vector registers); only the per-lane power M^(SL q) comes from the LDS copy PW
+    const double *P1 = sp.P[cs][0], *P8 = sp.P[cs][PAR_G - 1];
     double a = 0.0, b = 0.0, c = 0.0;
     if (has) {
 #pragma unroll 1
@@ -1560,7 +1562,7 @@ __global__ __launch_bounds__(R * NS, (R * NS >= 1024 ? 4 : 4)) void k_rows_tol(R
     __syncthreads();
     {
         double w1, w2, w3;
-        rt_fold<NS, R>(PW, Z, GT, l, g, has, [](int kk) { return kk; }, uminus, uminus, uminus, w1, w2, w3);
+        rt_fold<NS, R>(sp, cs, PW, Z, GT, l, g, has, [](int kk) { return kk; }, uminus, uminus, uminus, w1, w2, w3);
 #pragma unroll
         for (int j = 0; j < SL; j++) { const double tt = rt_step(x[j], a1, a2, a3, w1, w2, w3); w3 = w2; w2 = w1; w1 = tt; x[j] = tt; }
         if (lastseg) { Fin[0][l] = w1; Fin[1][l] = w2; Fin[2][l] = w3; }
@@ -1584,11 +1586,11 @@ __global__ __launch_bounds__(R * NS, (R * NS >= 1024 ? 4 : 4)) void k_rows_tol(R
     __syncthreads();
     {
         double s0a = vr0, s0b = vr1, s0c = vr2;
-        mv3f(PW + 9 * PAR_G, s0a, s0b, s0c, Z[0][nseg - 1][l], Z[1][nseg - 1][l], Z[2][nseg - 1][l]);
+        mv3f(sp.Plast[cs], s0a, s0b, s0c, Z[0][nseg - 1][l], Z[1][nseg - 1][l], Z[2][nseg - 1][l]);
         double v1, v2, v3;
         const int kq = nseg - 2 - g;
         const bool hasq = has && !lastseg;
-        rt_fold<NS, R>(PW, Z, GT, l, hasq ? kq : 0, hasq, [nseg](int kk) { return nseg - 2 - kk; }, s0a, s0b, s0c, v1, v2, v3);
+        rt_fold<NS, R>(sp, cs, PW, Z, GT, l, hasq ? kq : 0, hasq, [nseg](int kk) { return nseg - 2 - kk; }, s0a, s0b, s0c, v1, v2, v3);
         if (lastseg) { v1 = vr0; v2 = vr1; v3 = vr2; x[SL - 1] = vr0 * scale; }
         else { const double tt = rt_step(x[SL - 1], a1, a2, a3, v1, v2, v3); v3 = v2; v2 = v1; v1 = tt; x[SL - 1] = tt * scale; }
 #pragma unroll
