@@ -319,8 +319,8 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
     """S streams in lock-step through the batch entry points.  Stream s plays the same ping-pong sequence shifted
     by s frames (so the S images of a step differ); key-frames fall on the same step for all streams."""
     # tracking stream in a scheduling class of its own, as in run_lockstep_kpset (hardware-queue aliasing with the pyramid graph's branches)
-    ctx, ctx_pyr, ctx_right = (shared_ctx(slam, local_rank, "track", int(os.environ.get("SLAM_BENCH_TRACK_PRIO", "-1"))), shared_ctx(slam, local_rank, "pyr"),
-                               shared_ctx(slam, local_rank, "right"))
+    ctx, ctx_pyr, ctx_right = (leg_ctx(slam, local_rank, int(os.environ.get("SLAM_BENCH_TRACK_PRIO", "-1"))), leg_ctx(slam, local_rank),
+                               leg_ctx(slam, local_rank))
     levels = params.pyramid_levels
     AHEAD = max(1, int(os.environ.get("SLAM_BENCH_AHEAD", "1")))   # pyramid builds kept in flight ahead of the step being tracked (2 measured 5 % slower: two builds + LK contend for the HBM)
     NLB = AHEAD + 2                                         # rotating left batches: previous, current, AHEAD in flight
@@ -441,7 +441,9 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
                                 "frac": pb / (pyr_ms / max(pyr_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "note": "algorithmic = read the layer + write the 6 planes of every level once (SURVEY 8d); the separable filters and the "
                                         "two-dimensional recurrences need ~40 plane passes per level, which is what the kernels are bound by"}
-    return res                                                 # (shared_ctx's contexts stay)
+    for c_ in (ctx, ctx_pyr, ctx_right):
+        c_.close()
+    return res
 
 
 WORKLOADS = {
@@ -507,8 +509,8 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     # step and are better left undisturbed).  SLAM_BENCH_TRACK_PRIO=0 restores the shared class for comparison.
     prio = int(os.environ.get("SLAM_BENCH_TRACK_PRIO", "-1"))
     pprio = int(os.environ.get("SLAM_BENCH_PYR_PRIO", "0"))
-    ctx, ctx_pyr, ctx_right, ctx_copy = (shared_ctx(slam, local_rank, "track", prio), shared_ctx(slam, local_rank, "pyr", pprio),
-                                         shared_ctx(slam, local_rank, "right", pprio), shared_ctx(slam, local_rank, "copy"))
+    ctx, ctx_pyr, ctx_right, ctx_copy = (leg_ctx(slam, local_rank, prio), leg_ctx(slam, local_rank, pprio),
+                                         leg_ctx(slam, local_rank, pprio), leg_ctx(slam, local_rank))
     levels = params.pyramid_levels
     AHEAD = max(1, int(os.environ.get("SLAM_BENCH_KP_AHEAD", "2")))   # builds enqueued ahead of the step being tracked (same-box A/B: 2 = +0.9 % over 1 -- the next graph is already queued when a build ends; 3 = -1.4 %)
     NLB = AHEAD + 3                                          # previous, current, AHEAD being built, one more being copied
@@ -796,7 +798,9 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
         del lstage, st_copy
     del st_main
     peek("run_lockstep_kpset: after freeing the torch buffers")
-    return res                                                 # (the contexts are shared_ctx's: they stay)
+    for c_ in (ctx, ctx_pyr, ctx_right, ctx_copy):
+        c_.close()
+    return res
 
 
 def replay_stream_on_oracle(orc, slam, wl, rec, res, s, threads):
@@ -839,17 +843,11 @@ def replay_stream_on_oracle(orc, slam, wl, rec, res, s, threads):
     return kp, is3
 
 
-_CTX = {}
-
-
-def shared_ctx(slam, local_rank, tag, priority=0):
-    """The contexts (HIP streams) of the lock-stepped legs live as long as the process: a leg that destroyed its streams and the next one
-    that created new ones tripped, about once in six full runs, over a HIP runtime state that outlives a destroyed capture-origin stream
-    (torch's pin_memory() then fails with a stream-capture error).  Same creation order as before for the first leg."""
-    key = (local_rank, tag, priority)
-    if key not in _CTX:
-        _CTX[key] = slam.Context(local_rank, priority=priority) if priority else slam.Context(local_rank)
-    return _CTX[key]
+def leg_ctx(slam, local_rank, priority=0):
+    """a context (HIP stream, scratch, pinned block) for one leg; the leg closes it.  (Round 3 kept the lock-stepped legs' contexts for the
+    life of the process because a destroyed capture-origin stream left runtime state behind; the build graphs are now
+    constructed node by node -- no stream capture -- and contexts come and go with the legs.)"""
+    return slam.Context(local_rank, priority=priority) if priority else slam.Context(local_rank)
 
 
 _HIP = None
@@ -876,7 +874,7 @@ def kernel_spans(slam, torch, local_rank, wl, dev):
     """Per-kernel device time of the batched build with serial launches (hipEvent spans cannot look inside the graph),
     and the graph replay alone on the GPU."""
     S, H, W, params, left = wl["S"], wl["H"], wl["W"], wl["params"], wl["left"]
-    ctx = shared_ctx(slam, local_rank, "spans")
+    ctx = leg_ctx(slam, local_rank)
     pb = slam.PyramidBatch((H, W), levels=params.pyramid_levels, S=S, ctx=ctx)
     seq = frame_sequence_n(len(left), S + 2)
     t = torch.from_numpy(np.stack([np.ascontiguousarray(np.round(left[seq[k]] * 255).astype(np.uint8).T) for k in range(S)])).to(dev)
@@ -903,6 +901,7 @@ def kernel_spans(slam, torch, local_rank, wl, dev):
     for p_ in pb.pyramids:
         p_.close()
     peek("kernel_spans: after destroying the pyramids")
+    ctx.close()
     return rows_ms / max(rows_n, 1) * 1e3, pyr_ms / max(pyr_n, 1) * 1e3, isolated_us
 
 
@@ -1045,8 +1044,6 @@ def compact_line(out):
         c["parity_vs_oracle"] = {"ok": pv["ok"] and not out.get("parity_failures")}
     if out.get("parity_failures"):
         c["parity_failures"] = len(out["parity_failures"])
-    if out.get("retried"):
-        c["retried"] = len(out["retried"])
     c["detail"] = "bench_detail.json"
     line = json.dumps(c, separators=(",", ":"))
     if len(line) > 8000:                                          # never lose the line to its own size: drop the optional objects, largest first
@@ -1321,26 +1318,10 @@ def main():
     # ---- headline: S lock-stepped streams per GPU, keypoints resident in HBM, bit-exact planes; frames arrive in host memory as the
     #      decoder's 8-bit images ----
     head = None
-    if True:
-        def retried(what, fn):
-            """A HIP "operation not permitted when stream is capturing" error surfaced once in ~10 full runs of round 3 in a torch call of a
-            lock-stepped leg (never reproduced in isolation): one retry after a device synchronisation, the first error goes on the line.
-            (Single process only: a retry on one rank alone would leave the others at their barrier.)"""
-            try:
-                return fn()
-            except Exception as ex:
-                if world > 1:
-                    raise
-                out.setdefault("retried", []).append({"leg": what, "error": repr(ex)[:300]})
-                try:
-                    torch.cuda.synchronize()
-                except Exception:
-                    pass
-                return fn()
     if "headline" in legs:
-        head = retried("headline", lambda: run_lockstep_kpset(slam, torch, local_rank, wl, args.steps, args.warmup, world, dist, dev, "host_u8", snapshot=[0, S - 1]))
+        head = run_lockstep_kpset(slam, torch, local_rank, wl, args.steps, args.warmup, world, dist, dev, "host_u8", snapshot=[0, S - 1])
         leg_done("headline")
-        rows_us, serial_us, isolated_us = retried("headline kernel spans", lambda: kernel_spans(slam, torch, local_rank, wl, dev))
+        rows_us, serial_us, isolated_us = kernel_spans(slam, torch, local_rank, wl, dev)
         pb = S * pyramid_bytes(H, W, levels)
         build_ms = head["pyramid_build_ms"]["mean"]
         rb_bytes = S * iir_rows_bytes(H, W, levels) / (levels + 1)
@@ -1400,9 +1381,9 @@ def main():
     #      to the exact build, tracked positions <= 1e-6 px: tests/test_gpu_tol_batch.py); keypoint indices still come from detect on the raw frame ----
     if "tolbatch" in legs:
         wt = dict(wl); wt["tolerance"] = True
-        tb = retried("tolerance batch", lambda: run_lockstep_kpset(slam, torch, local_rank, wt, max(8, args.steps // 2), 2, world, dist, dev, "host_u8"))
+        tb = run_lockstep_kpset(slam, torch, local_rank, wt, max(8, args.steps // 2), 2, world, dist, dev, "host_u8")
         leg_done("tolbatch")
-        _, tserial_us, tiso_us = retried("tolerance batch kernel spans", lambda: kernel_spans(slam, torch, local_rank, wt, dev))
+        _, tserial_us, tiso_us = kernel_spans(slam, torch, local_rank, wt, dev)
         pbt = S * pyramid_bytes(H, W, levels)
         tbm = tb["pyramid_build_ms"]["mean"]
         tnode = out.setdefault("tolerance_mode", {})
@@ -1427,7 +1408,7 @@ def main():
         if head is not None:
             out["ingest"]["host_u8"] = {"value": head["value"], "ms_per_step": head["ms_per_step"], "steps": head["steps"], "pyramid_build_ms_mean": head["pyramid_build_ms"]["mean"]}
         for ingest in ("dev_f64", "host_f64"):
-            v = retried("ingest " + ingest, lambda: run_lockstep_kpset(slam, torch, local_rank, wl, max(8, args.steps // 3), 2, world, dist, dev, ingest))
+            v = run_lockstep_kpset(slam, torch, local_rank, wl, max(8, args.steps // 3), 2, world, dist, dev, ingest)
             out["ingest"][ingest] = {"value": v["value"], "ms_per_step": v["ms_per_step"], "steps": v["steps"], "pyramid_build_ms_mean": v["pyramid_build_ms"]["mean"]}
         leg_done("ingest")
 
@@ -1437,7 +1418,7 @@ def main():
         out["streams_sweep"] = {}
         for S2 in {32: (48, 64), 64: (32, 48), 128: (32, 64, 96)}[S]:
             w2 = dict(wl); w2["S"] = S2
-            r2 = retried("streams sweep", lambda: run_lockstep_kpset(slam, torch, local_rank, w2, max(8, args.steps // 4), 2, world, dist, dev, "host_u8"))
+            r2 = run_lockstep_kpset(slam, torch, local_rank, w2, max(8, args.steps // 4), 2, world, dist, dev, "host_u8")
             out["streams_sweep"][str(S2)] = {"value": r2["value"], "unit": "frames/sec", "ms_per_step": r2["ms_per_step"]}
         leg_done("streams_sweep")
 
@@ -1447,8 +1428,8 @@ def main():
         left_dev = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in left]
         right_dev = [torch.from_numpy(np.ascontiguousarray(im.T)).to(dev) for im in right]
         torch.cuda.synchronize()
-        hp = retried("host protocol", lambda: run_lockstep(slam, torch, local_rank, S, max(40, frame_steps // 4), 10, H, W, left_dev, right_dev, flows, disparity,
-                                                           params, extractor, False, world, dist, dev))
+        hp = run_lockstep(slam, torch, local_rank, S, max(40, frame_steps // 4), 10, H, W, left_dev, right_dev, flows, disparity,
+                                                           params, extractor, False, world, dist, dev)
         out["host_protocol"] = {"value": hp["value"], "unit": "frames/sec", "ms_per_frame_of_S_streams": hp["ms_per_step_of_S_frames"],
                                 "what": "slam_flow_match_batch_kept / slam_detect_batch with host keypoint lists, frames resident in HBM as Float64 "
                                         "(compare ingest.dev_f64)"}
@@ -1459,10 +1440,7 @@ def main():
     if "configs" in legs:
         out["configs"] = {}
         import traceback
-        for name, attempt in [(n_, a_) for n_ in ("kitti00_2000", "euroc_mono", "fhd_4000") for a_ in (0, 1)]:
-            if attempt == 1 and "error" not in out["configs"].get(name, {"error": 1}):
-                continue                                              # the first attempt succeeded
-            first_error = out["configs"].get(name, {}).get("error")
+        for name in ("kitti00_2000", "euroc_mono", "fhd_4000"):
             try:
                 w2 = make_workload(slam, syn, name, seed=rank)
                 mono = not w2["stereo"]
@@ -1479,13 +1457,9 @@ def main():
                                  "avg_launch_us": bm * 1e3, "achieved": pb2 / (bm * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": pb2 / (bm * 1e-3) / 1e9 / HBM_PEAK_GBS, "isolated_launch_us": iso2,
                                  "frac_isolated": pb2 / (iso2 * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
-                if first_error:                                       # (seen once in ~10 full runs of round 3: a HIP "stream is capturing" error surfacing in a torch call of this leg; not reproduced in isolation)
-                    out["configs"][name]["first_attempt_error"] = first_error
                 del w2
-            except Exception as ex:                                   # never lose the line to an optional leg; one retry, the first error stays on the record
+            except Exception as ex:                                   # an optional leg never costs the line: the error goes on the record
                 out["configs"][name] = {"error": repr(ex)[:300] + " | " + " <- ".join(l.strip() for l in traceback.format_exc().splitlines()[-8:-1:2])[:500]}
-                if first_error:
-                    out["configs"][name]["first_attempt_error"] = first_error
                 try:
                     torch.cuda.synchronize()
                 except Exception:
@@ -1659,14 +1633,14 @@ def main():
                                 "what": "slam_kpset_compute_pose: P3P RANSAC (256 triples) + PnP refinement + outlier removal for the S streams on "
                                         "device-resident lists; one device -> host copy (poses, status, list lengths)"}
         # the tracked workload as the reference's full per-frame front-end on the tracked lists themselves
-        wp = retried("front-end with poses", lambda: run_lockstep_kpset(slam, torch, local_rank, wl, max(8, args.steps // 3), 2, world, dist, dev, "host_u8", pose=True))
+        wp = run_lockstep_kpset(slam, torch, local_rank, wl, max(8, args.steps // 3), 2, world, dist, dev, "host_u8", pose=True)
         out["pose"]["frontend_with_pose"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step": wp["ms_per_step"],
                                              "tracked_kpts_per_frame": wp["tracked_kpts_per_frame"], **wp["pose"],
                                              "what": "the headline workload as the reference's full per-frame front-end on the tracked lists themselves "
                                                      "(front_end.jl:60-113): tracking with the priors of the predicted pose, slam_kpset_compute_pose_5pt, "
                                                      "slam_kpset_compute_pose every frame, key-frames with slam_kpset_keyframe and triangulation under the "
                                                      "estimated pose; the streams are a rigid scene, the recovered translation is checked against the frames' offsets"}
-        wp = retried("front-end with host pose seams", lambda: run_lockstep_kpset(slam, torch, local_rank, wl, max(4, args.steps // 4), 2, world, dist, dev, "host_u8", hook=pose_batch_once))
+        wp = run_lockstep_kpset(slam, torch, local_rank, wl, max(4, args.steps // 4), 2, world, dist, dev, "host_u8", hook=pose_batch_once)
         out["pose"]["frontend_with_host_pose_seams"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step": wp["ms_per_step"],
                                                         "what": "headline workload + slam_five_point_ransac_batch + slam_p3p_ransac_batch + slam_pnp_ba_batch "
                                                                 "every frame (host lists in and out: the round-1 configuration of this figure)"}
@@ -1714,7 +1688,7 @@ def main():
             par["planes_after_timed_run"] = {"streams": sorted(head["snapshot"]), "planes_compared": 6 * (levels + 1) * len(head["snapshot"]),
                                              "bit_equal": n_eq, "what": "all planes of the last left pyramids of the timed run vs orc.pyr_build of the same 8-bit frame"}
             rec = {"frame_steps": 7, "steps": []}
-            rr = retried("replayed key-frame cycle", lambda: run_lockstep_kpset(slam, torch, local_rank, wl, 0, 0, world, dist, dev, "host_u8", record=rec, snapshot=[0, S - 1]))
+            rr = run_lockstep_kpset(slam, torch, local_rank, wl, 0, 0, world, dist, dev, "host_u8", record=rec, snapshot=[0, S - 1])
             worst = 0.0; lists_ok = True
             for s_, sn in rr["snapshot"].items():
                 kp_ref, is3_ref = replay_stream_on_oracle(orc, slam, wl, rec, rr, s_, threads)

@@ -25,6 +25,7 @@
 // Observations are re-ordered by map point at upload (map points by first free observer) so a point's observations
 // and a group's points are contiguous.
 #include "common.hpp"
+#include <atomic>
 #include <algorithm>
 #include <type_traits>
 #include <chrono>
@@ -2382,9 +2383,10 @@ static int ba_enqueue_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, dou
     if (!ba->grouped || !private_red || ba->zeroed != red) { HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)n * n + 2 * n + 8) * 8, st)); ba->zeroed = private_red ? red : nullptr; }
     if (ba->grouped) {
         // the attribute belongs to the function object of the CURRENT device: once per device, result checked
-        static bool attr_set[64] = {};
+        // (the reference's three tasks call the library concurrently, SLAM.jl:166: the flag is atomic; setting the attribute twice is harmless)
+        static std::atomic<bool> attr_set[64];
         const int dv = ctx->device & 63;
-        if (!attr_set[dv]) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB))); attr_set[dv] = true; }
+        if (!attr_set[dv].load(std::memory_order_acquire)) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB))); attr_set[dv].store(true, std::memory_order_release); }
         hipLaunchKernelGGL(k_schur_groups, dim3(d.ngrp), dim3(SG_T), sg_lds_bytes(d.whb), st, d, inv_delta, ignore_outliers, use_state);
         if (!use_state) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 0, d.ngrp, ba->nblocks_pts, 0, red + (size_t)n * n + 2 * n);
         const int nthr = d.P * (d.whb + 1) * 36 + d.P * 12;
@@ -2440,9 +2442,9 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
             for (int w = 0; w < 8; w++) fprintf(stderr, "  wave %d (simd %lld): start %lld%s arrive %lld release %lld\n", w, (trace_dev[64 + w] >> 4) & 3, trace_dev[32 + w] - t0,
                                                 w == 0 ? (" flag " + std::to_string(trace_dev[40] - t0)).c_str() : "", trace_dev[48 + w] - t0, trace_dev[56 + w] - t0);
         }
-        static bool attr_set[64] = {};
+        static std::atomic<bool> attr_set[64];
         const int dv = ctx->device & 63;
-        if (!attr_set[dv]) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set[dv] = true; }
+        if (!attr_set[dv].load(std::memory_order_acquire)) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set[dv].store(true, std::memory_order_release); }
         static const bool twist_spread = getenv("SLAMHIP_TWIST_SPREAD") != nullptr;     // (test knob: the two sides on different XCDs)
         hipLaunchKernelGGL(k_band_solve, dim3(twist ? (twist_spread ? 2 : 9) : 1), dim3(BS_T), band_lds, st, d, B, use_state);
     } else {

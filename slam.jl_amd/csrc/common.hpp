@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <mutex>
 #include "../../include/slamhip.h"
 
 #define SLAM_MAX_LEVELS 8
@@ -54,7 +55,7 @@ struct slam_pyr {
     int H[SLAM_MAX_LEVELS], W[SLAM_MAX_LEVELS];
     int P[SLAM_MAX_LEVELS];               // column pitch in doubles (H rounded up to 16)
     int64_t off[SLAM_MAX_LEVELS + 1];     // plane offsets in doubles (sum of P_l * W_l)
-    struct Alloc { double *base = nullptr; double *ck = nullptr; double *tot = nullptr; const void **srctab = nullptr; int refs = 0; };   // shared by the members of a batch; srctab: 64 source-image pointers (fused ingest)
+    struct Alloc { double *base = nullptr; double *ck = nullptr; double *tot = nullptr; const void **srctab = nullptr; int refs = 0; std::mutex graph_mu; };   // shared by the members of a batch; srctab: 64 source-image pointers (fused ingest)
     Alloc *alloc = nullptr;
     size_t zstride = 0;                   // doubles between consecutive images of a batch (7 * off[levels])
     int batch_index = 0, batch_size = 1;
@@ -64,12 +65,10 @@ struct slam_pyr {
     double *ck = nullptr;                 // batches: checkpoint scratch of the bandwidth-bound row kernel (owned by alloc)
     double *norm = nullptr;               // NA() normaliser per level (ctor mode), lazily built
     double norm_sigma = -1.0;
-    // hipGraph replay of the build (captured lazily per (mode, sigma)); aux = forked stream
+    // hipGraph replay of the build (constructed lazily per (mode, sigma, S, source kind): explicit kernel nodes, no stream capture)
     struct Graph { int mode; double sigma; int S; size_t ckmin; int src_kind; hipGraphExec_t exec; };
     std::vector<Graph> graphs;
     bool graph_failed = false;
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork[SLAM_MAX_LEVELS] = {}, ev_join = nullptr;
     PyrView view;
     double *plane(int p, int l) const { return planes + (int64_t)p * off[levels] + off[l]; }
 };

@@ -21,6 +21,9 @@
 #include "common.hpp"
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
+#include <tuple>
+#include <utility>
 
 #define LINE_THREADS 64
 
@@ -1860,10 +1863,47 @@ static void rt_seg_pow(const IIRPair &cf, int SL, SegPow &sp)     // M^(SL q), q
 // with level l+1 (fork after the row pass, one join at the end).  With
 // aux == st everything is serial on one stream (profiling / fallback path).
 // mode 3 ("fast") swaps the sequential line kernels for the segmented ones.
-static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf, hipStream_t st, hipStream_t aux, bool spans, int S = 1, int src_kind = 0, bool target = false)
+// Where the kernels of one build go: straight onto a stream (profiling spans, SLAMHIP_NO_GRAPH), or into an EXPLICITLY constructed
+// hipGraph -- hipGraphAddKernelNode with the dependencies of a two-lane DAG (lane 0: the dependent chain gradients -> dim 1 -> dim 2
+// -> resize -> next level; lane 1: the integral-image passes of level l, which only feed the tracking kernels and run beside level
+// l + 1).  Rounds 1-3 recorded the DAG with hipStreamBeginCapture on the caller's stream + a forked side stream: a capture is
+// process-visible runtime state (another thread's or library's event queries and pinned allocations fail with
+// hipErrorStreamCaptureUnsupported / hipErrorCapturedEvent while one is open, and a stream that was a capture origin left state
+// behind when destroyed: DESIGN 6.6).  Building the graph node by node touches no stream at all.
+enum { LN_MAIN = 0, LN_AUX = 1 };
+struct BuildSink {
+    hipStream_t st = nullptr;                          // direct mode: every kernel on this stream, in program order
+    hipGraph_t graph = nullptr;                        // graph mode
+    bool forked = false;                               // graph mode: lane 1 is a branch of its own (else one chain)
+    hipGraphNode_t last[2] = {nullptr, nullptr}, fork_dep = nullptr;
+    hipError_t err = hipSuccess;
+    template <typename Tup, size_t... I> static void addr_of(Tup &t, void **out, std::index_sequence<I...>) { ((out[I] = (void *)&std::get<I>(t)), ...); }
+    template <typename... KA, typename... A>
+    void launch(void (*kern)(KA...), dim3 grid, dim3 block, size_t lds, int lane, A &&...a)
+    {
+        if (!graph) { hipLaunchKernelGGL(kern, grid, block, lds, st, std::forward<A>(a)...); return; }
+        std::tuple<KA...> args(std::forward<A>(a)...);  // the kernel's own parameter types (the node copies them)
+        void *ptrs[sizeof...(KA)];
+        addr_of(args, ptrs, std::index_sequence_for<KA...>{});
+        hipKernelNodeParams np = {};
+        np.func = (void *)kern; np.gridDim = grid; np.blockDim = block; np.sharedMemBytes = (unsigned)lds; np.kernelParams = ptrs; np.extra = nullptr;
+        const int ln = forked ? lane : LN_MAIN;
+        hipGraphNode_t deps[2]; int nd = 0;
+        if (last[ln]) deps[nd++] = last[ln];
+        if (ln == LN_AUX && fork_dep && fork_dep != last[ln]) deps[nd++] = fork_dep;
+        hipGraphNode_t node = nullptr;
+        const hipError_t e = hipGraphAddKernelNode(&node, graph, nd ? deps : nullptr, (size_t)nd, &np);
+        if (e != hipSuccess) { if (err == hipSuccess) err = e; return; }
+        last[ln] = node;
+        if (ln == LN_AUX) fork_dep = nullptr;
+    }
+    // lane 1's next kernel also waits for everything lane 0 has issued so far
+    void fork() { if (graph && forked) fork_dep = last[LN_MAIN]; }
+};
+
+static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf, BuildSink &B, bool spans, int S = 1, int src_kind = 0, bool target = false)
 {
     const size_t zs = p->zstride;
-    const bool forked = aux != st;
     bool fast = mode == 3;
     if (fast && (seg_len(p->H[0], PAR_T / 8) > PAR_SLMAX || seg_len(p->W[0], PAR_T / 8) > PAR_SLMAX)) fast = false;   // lines > 2048 samples: exact kernels
     if (fast && S >= 4) fast = false;   // the segmented kernels buy latency for ONE image; with several images per launch the exact kernels are faster (and trivially within the tolerance)
@@ -1877,16 +1917,16 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             if (!has_next) continue;
             PlaneSet pt = {}; pt.p[0] = T; pt.coef[0] = 0; pt.fill0[0] = (mode == 0); pt.nrm[0] = nullptr; pt.n = 1; pt.zs = zs;
             const bool ckr = mode != 3 && p->ck != nullptr && mode != 0 && W >= 64 && H >= 64 && (size_t)S * 4 * H * W * 8 >= ck_min_bytes();
-            if (ckr) hipLaunchKernelGGL(k_iir_cols_ck, lines_grid(W, 1, S), dim3(LINE_THREADS), 0, st, pt, (const double *)v.L, H, W, P, cf, p->ck);
-            else hipLaunchKernelGGL(k_iir_cols<2>, lines_grid(W, 1, S), dim3(LINE_THREADS), 0, st, pt, (const double *)v.L, H, W, P, cf);
+            if (ckr) B.launch(k_iir_cols_ck, lines_grid(W, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, pt, (const double *)v.L, H, W, P, cf, p->ck);
+            else B.launch(k_iir_cols<2>, lines_grid(W, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, pt, (const double *)v.L, H, W, P, cf);
             static const bool no_rr = getenv("SLAMHIP_NO_ROWS_RESIZE") != nullptr;
             const bool rr = ckr && (H & 1) == 0 && !no_rr;
             RowResize rzt = {};
             if (rr) { rzt.dst = p->view.lv[l + 1].L; rzt.Hd = p->H[l + 1]; rzt.Wd = p->W[l + 1]; rzt.Pd = p->P[l + 1]; }
-            if (ckr) hipLaunchKernelGGL(k_iir_rows_ck, lines_grid(H, 1, S), dim3(LINE_THREADS), 0, st, pt, H, W, P, cf, p->ck, rzt);
-            else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, 1, S), dim3(LINE_THREADS), 0, st, pt, H, W, P, cf);
+            if (ckr) B.launch(k_iir_rows_ck, lines_grid(H, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, pt, H, W, P, cf, p->ck, rzt);
+            else B.launch(k_iir_rows, lines_grid(H, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, pt, H, W, P, cf);
             if (!rr)
-                hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, st,
+                B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
                                    p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
             continue;
         }
@@ -1901,7 +1941,7 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         static const bool no_cols_fused = getenv("SLAMHIP_NO_COLS_FUSED") != nullptr;
         const bool cols_fused = fuse_sq && !no_cols_fused;
         if (!cols_fused)
-            hipLaunchKernelGGL(k_scharr_products, dim3((H + 63) / 64, (W + SCH_XC - 1) / SCH_XC, S), dim3(64), 0, st, v, border_mode, zs, fuse_sq ? 0 : 1);
+            B.launch(k_scharr_products, dim3((H + 63) / 64, (W + SCH_XC - 1) / SCH_XC, S), dim3(64), 0, LN_MAIN, v, border_mode, zs, fuse_sq ? 0 : 1);
         // dim-1 IIR: [blur: L -> T], Iyy, Ixx, Iyx in place
         PlaneSet ps = {};
         int np = 0;
@@ -1918,16 +1958,16 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             SegPow spc, spr;
             seg_pow(cf, H, slc, spc); seg_pow(cf, W, slr, spr);
             const dim3 gc((W + 7) / 8, np, S), gr((H + 7) / 8, np, S), gc3((W + 7) / 8, 3, S), gr3((H + 7) / 8, 3, S);
-            hipLaunchKernelGGL(k_iir_seg<true>, gc, dim3(PAR_T), 0, st, ps, src0, H, W, P, cf, spc, slc);
+            B.launch(k_iir_seg<true>, gc, dim3(PAR_T), 0, LN_MAIN, ps, src0, H, W, P, cf, spc, slc);
             if (spans) { ProfScope span(ctx, "k_iir_rows");
-                hipLaunchKernelGGL(k_iir_seg<false>, gr, dim3(PAR_T), 0, st, ps, (const double *)nullptr, H, W, P, cf, spr, slr); }
-            else hipLaunchKernelGGL(k_iir_seg<false>, gr, dim3(PAR_T), 0, st, ps, (const double *)nullptr, H, W, P, cf, spr, slr);
-            if (forked) { (void)hipEventRecord(p->ev_fork[l], st); (void)hipStreamWaitEvent(aux, p->ev_fork[l], 0); }
+                B.launch(k_iir_seg<false>, gr, dim3(PAR_T), 0, LN_MAIN, ps, (const double *)nullptr, H, W, P, cf, spr, slr); }
+            else B.launch(k_iir_seg<false>, gr, dim3(PAR_T), 0, LN_MAIN, ps, (const double *)nullptr, H, W, P, cf, spr, slr);
+            B.fork();
             if (has_next)
-                hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, st,
+                B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
                                    p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
-            hipLaunchKernelGGL(k_cum_seg<true>, gc3, dim3(PAR_T), 0, aux, pc, H, W, P, slc);
-            hipLaunchKernelGGL(k_cum_seg<false>, gr3, dim3(PAR_T), 0, aux, pc, H, W, P, slr);
+            B.launch(k_cum_seg<true>, gc3, dim3(PAR_T), 0, LN_AUX, pc, H, W, P, slc);
+            B.launch(k_cum_seg<false>, gr3, dim3(PAR_T), 0, LN_AUX, pc, H, W, P, slr);
             continue;
         }
         // tolerance build of a batch (mode 3, S >= 4): the dim-1 stage leaves the product planes as suffix sums along y, ONE row kernel
@@ -1943,8 +1983,8 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             size_t toff = 0;
             for (int q = 0; q < l; q++) toff += (size_t)3 * S * p->W[q];
             ca.tot = tolb ? p->alloc->tot + toff : nullptr; ca.tot_stride = W;
-            if (tolb) hipLaunchKernelGGL(k_cols_fused<true>, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, st, ca, cf, p->ck);
-            else hipLaunchKernelGGL(k_cols_fused<false>, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, st, ca, cf, p->ck);
+            if (tolb) B.launch(k_cols_fused<true>, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, LN_MAIN, ca, cf, p->ck);
+            else B.launch(k_cols_fused<false>, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, LN_MAIN, ca, cf, p->ck);
             if (tolb) {
                 RowsTolArgs ra = {};
                 int nr = 0;
@@ -1960,21 +2000,21 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
                 static const int rt_dbg = getenv("SLAMHIP_RT_DBG") ? atoi(getenv("SLAMHIP_RT_DBG")) : 0; ra.dbg = rt_dbg;
                 const dim3 gr(RT_R == 8 ? (((H + 15) / 16 + 7) / 8) * 16 : (H + RT_R - 1) / RT_R, nr, S), bd(RT_R * RT_NS);
                 auto go = [&]() {
-#define RT_GO(SLV) hipLaunchKernelGGL((k_rows_tol<SLV, RT_NS, RT_R>), gr, bd, 0, st, ra, H, W, P, cf, spr)
+#define RT_GO(SLV) B.launch((k_rows_tol<SLV, RT_NS, RT_R>), gr, bd, 0, LN_MAIN, ra, H, W, P, cf, spr)
                     switch (slr_t) { case 4: RT_GO(4); break; case 6: RT_GO(6); break; case 8: RT_GO(8); break; case 10: RT_GO(10); break; case 12: RT_GO(12); break;
                                      case 16: RT_GO(16); break; case 20: RT_GO(20); break; case 24: RT_GO(24); break; case 32: RT_GO(32); break; default: RT_GO(40); break; }
 #undef RT_GO
                 };
                 if (spans) { ProfScope span(ctx, "k_iir_rows"); go(); } else go();
                 if (has_next && !rzf)
-                    hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, st,
+                    B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
                                        p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
                 continue;
             }
         }
-        else if (ck_cols) hipLaunchKernelGGL(k_iir_cols_ck, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf, p->ck);
-        else if (S == 1) hipLaunchKernelGGL(k_iir_cols<3>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
-        else hipLaunchKernelGGL(k_iir_cols<2>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, st, ps, src0, H, W, P, cf);
+        else if (ck_cols) B.launch(k_iir_cols_ck, lines_grid(W, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, src0, H, W, P, cf, p->ck);
+        else if (S == 1) B.launch(k_iir_cols<3>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, src0, H, W, P, cf);
+        else B.launch(k_iir_cols<2>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, src0, H, W, P, cf);
         // bandwidth-bound launches (many images x a large level) take the checkpointed row kernel (2R+1W instead of 2R+2W)
         const bool ck_rows = p->ck != nullptr && mode != 0 && W >= 64 && (size_t)S * np * H * W * 8 >= ck_min_bytes();
         // ... with the imresize! into the next level fused into the blurred layer's backward sweep when the row ratio is exactly 2:1
@@ -1983,26 +2023,25 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         RowResize rz = {};
         if (rows_resize) { rz.dst = p->view.lv[l + 1].L; rz.Hd = p->H[l + 1]; rz.Wd = p->W[l + 1]; rz.Pd = p->P[l + 1]; }
         if (spans) { ProfScope span(ctx, "k_iir_rows");
-            if (ck_rows) hipLaunchKernelGGL(k_iir_rows_ck, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf, p->ck, rz);
-            else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf); }
-        else if (ck_rows) hipLaunchKernelGGL(k_iir_rows_ck, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf, p->ck, rz);
-        else hipLaunchKernelGGL(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, st, ps, H, W, P, cf);
-        if (forked) { (void)hipEventRecord(p->ev_fork[l], st); (void)hipStreamWaitEvent(aux, p->ev_fork[l], 0); }
+            if (ck_rows) B.launch(k_iir_rows_ck, lines_grid(H, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, H, W, P, cf, p->ck, rz);
+            else B.launch(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, H, W, P, cf); }
+        else if (ck_rows) B.launch(k_iir_rows_ck, lines_grid(H, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, H, W, P, cf, p->ck, rz);
+        else B.launch(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, H, W, P, cf);
+        B.fork();
         if (has_next && !rows_resize)
-            hipLaunchKernelGGL(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, st,
+            B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
                                p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
         static const bool no_fused_cum = getenv("SLAMHIP_NO_FUSED_CUM") != nullptr;
         if (S >= 8 && !no_fused_cum && H <= CF_MAXW * 64) {                 // batches: one-pass integral image
             const int nw = (H + 63) / 64;
             const size_t lds = ((size_t)nw * CF_W * CF_LS + (size_t)nw * 2 * CF_W) * sizeof(double);
-            hipLaunchKernelGGL(k_cum_fused, dim3(1, 3, S), dim3(nw * 64), lds, aux, pc, H, W, P);
+            B.launch(k_cum_fused, dim3(1, 3, S), dim3(nw * 64), lds, LN_AUX, pc, H, W, P);
             continue;
         }
-        if (S == 1) hipLaunchKernelGGL(k_cum_cols<3>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, aux, pc, H, W, P);
-        else hipLaunchKernelGGL(k_cum_cols<2>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, aux, pc, H, W, P);
-        hipLaunchKernelGGL(k_cum_rows, lines_grid(H, 3, S), dim3(LINE_THREADS), 0, aux, pc, H, W, P);
+        if (S == 1) B.launch(k_cum_cols<3>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, LN_AUX, pc, H, W, P);
+        else B.launch(k_cum_cols<2>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, LN_AUX, pc, H, W, P);
+        B.launch(k_cum_rows, lines_grid(H, 3, S), dim3(LINE_THREADS), 0, LN_AUX, pc, H, W, P);
     }
-    if (forked) { (void)hipEventRecord(p->ev_join, aux); (void)hipStreamWaitEvent(st, p->ev_join, 0); }
 }
 
 // level 0 of an S-image build runs k_cols_fused (which can ingest the source images itself): launch_build's conditions
@@ -2047,32 +2086,33 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode_flags, double sigm
     static const bool no_graph = getenv("SLAMHIP_NO_GRAPH") != nullptr;
     if (ctx->prof_on || no_graph) {
         ProfScope span_all(ctx, "pyr_update");
-        launch_build(ctx, p, mode, cf, st, st, ctx->prof_on, S, src_kind & 15, target);
+        BuildSink B; B.st = st;
+        launch_build(ctx, p, mode, cf, B, ctx->prof_on, S, src_kind & 15, target);
         HIP_TRY(ctx, hipGetLastError());
         return SLAM_OK;
     }
     hipGraphExec_t exec = nullptr;
     const size_t ckmin = ck_min_bytes();
-    for (auto &g : p->graphs) if (g.mode == mode && g.sigma == sigma && g.S == S && g.ckmin == ckmin && g.src_kind == src_kind) exec = g.exec;
-    if (!exec && !p->graph_failed) {
-        if (!p->aux) {
-            HIP_TRY(ctx, hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
-            for (int l = 0; l < p->levels; l++) HIP_TRY(ctx, hipEventCreateWithFlags(&p->ev_fork[l], hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    {
+        std::lock_guard<std::mutex> lk(p->alloc->graph_mu);       // two contexts (threads) may request the first build of one pyramid at once
+        for (auto &g : p->graphs) if (g.mode == mode && g.sigma == sigma && g.S == S && g.ckmin == ckmin && g.src_kind == src_kind) exec = g.exec;
+        if (!exec && !p->graph_failed) {
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipGraphCreate(&graph, 0);
+            if (e == hipSuccess) {
+                BuildSink B; B.graph = graph; B.forked = !chain;
+                launch_build(ctx, p, mode, cf, B, false, S, src_kind & 15, target);
+                e = B.err;
+            }
+            if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) { (void)hipGetLastError(); p->graph_failed = true; exec = nullptr; }
+            else { slam_pyr::Graph g; g.mode = mode; g.sigma = sigma; g.S = S; g.ckmin = ckmin; g.src_kind = src_kind; g.exec = exec; p->graphs.push_back(g); }
         }
-        hipGraph_t graph = nullptr;
-        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-        if (e == hipSuccess) {
-            launch_build(ctx, p, mode, cf, st, chain ? st : p->aux, false, S, src_kind & 15, target);
-            e = hipStreamEndCapture(st, &graph);
-        }
-        if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        if (graph) (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) { (void)hipGetLastError(); p->graph_failed = true; exec = nullptr; }
-        else { slam_pyr::Graph g; g.mode = mode; g.sigma = sigma; g.S = S; g.ckmin = ckmin; g.src_kind = src_kind; g.exec = exec; p->graphs.push_back(g); }
+        // (launched under the lock: one executable graph is not launched from two threads at the same moment)
+        if (exec) HIP_TRY(ctx, hipGraphLaunch(exec, st));
     }
-    if (exec) HIP_TRY(ctx, hipGraphLaunch(exec, st));
-    else launch_build(ctx, p, mode, cf, st, st, false, S, src_kind & 15, target);
+    if (!exec) { BuildSink B; B.st = st; launch_build(ctx, p, mode, cf, B, false, S, src_kind & 15, target); }
     HIP_TRY(ctx, hipGetLastError());
     return SLAM_OK;
 }
@@ -2115,7 +2155,10 @@ static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, 
     al->refs = S;
     if (S > 1 && hipMalloc((void **)&al->srctab, BATCH_MAX * sizeof(void *)) != hipSuccess) { (void)hipGetLastError(); al->srctab = nullptr; }
     // once per creation, outside any stream capture: k_cum_fused needs the > 64 KB dynamic-LDS opt-in
-    (void)hipFuncSetAttribute((const void *)k_cum_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    {
+        const hipError_t ea = hipFuncSetAttribute((const void *)k_cum_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (ea != hipSuccess) { (void)hipFree(al->base); delete al; return slam_fail(ctx, SLAM_ERR_HIP, "slam_pyr_create: hipFuncSetAttribute(k_cum_fused): %s", hipGetErrorString(ea)); }
+    }
     double *ckbuf = nullptr;
     if (S > 1) {   // checkpoint scratch of k_iir_rows_ck: (blocks x 3) doubles per line of the widest launch (level 0, 4 planes)
         const size_t lines = (size_t)S * 4 * (((size_t)Hs[0] + LINE_THREADS - 1) / LINE_THREADS) * LINE_THREADS;
@@ -2204,11 +2247,6 @@ int slam_pyr_destroy(slam_pyr *p)
     if (p->alloc && --p->alloc->refs == 0) { (void)hipFree(p->alloc->base); if (p->alloc->ck) (void)hipFree(p->alloc->ck); if (p->alloc->tot) (void)hipFree(p->alloc->tot); if (p->alloc->srctab) (void)hipFree(p->alloc->srctab); delete p->alloc; }
     if (p->norm) (void)hipFree(p->norm);
     for (auto &g : p->graphs) (void)hipGraphExecDestroy(g.exec);
-    if (p->aux) {
-        (void)hipStreamDestroy(p->aux);
-        for (int l = 0; l < p->levels; l++) (void)hipEventDestroy(p->ev_fork[l]);
-        (void)hipEventDestroy(p->ev_join);
-    }
     delete p;
     return SLAM_OK;
 }
