@@ -1723,13 +1723,14 @@ def main():
                                           "rel_diff_schur": rel, "outliers_equal": bool(chk.stats["n_outliers"] == st1["n_outliers"]), "ok": okw}
                 wv["cpu_ms_per_iter_schur"] = c1
                 if name == "P50":
+                    # the timed run's result (the reference's 5 + 10 iterations) against the reference-style solver with the same iteration counts
                     t0 = time.perf_counter()
-                    _, _, st0 = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], 2, 3, 5.0, solver=0)
+                    _, _, st0 = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], 5, 10, 5.0, solver=0)
                     c0 = (time.perf_counter() - t0) * 1e3 / max(st0["iters_pass1"] + st0["iters_pass2"], 1)
-                    rel0 = abs(chk.stats["ssr_final"] - st0["ssr_final"]) / st0["ssr_final"]
-                    if rel0 > 1e-2:
+                    rel0 = abs(wv["ssr_final"] - st0["ssr_final"]) / st0["ssr_final"]
+                    if rel0 > 1e-3:                                 # the tests' cross-algorithm bar (tests/test_gpu_ba.py)
                         fails.append(f"BA P50: cost vs reference-style LM+LSMR rel {rel0}")
-                    wv["parity_vs_oracle"].update({"ssr_final_oracle_lm_lsmr": st0["ssr_final"], "rel_diff_lm_lsmr": rel0})
+                    wv["parity_vs_oracle"].update({"ssr_final_oracle_lm_lsmr_5_10": st0["ssr_final"], "ssr_final_gpu_5_10": wv["ssr_final"], "rel_diff_lm_lsmr": rel0})
                     out["ba"]["parity_vs_oracle"] = wv["parity_vs_oracle"]
                     out["ba"]["cpu_ms_per_iter_reference_style_lm_lsmr"] = c0
                     out["ba"]["cpu_ms_per_iter_schur"] = c1

@@ -1470,10 +1470,13 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                 const int i = (e - ntri * 36) / 6, r = e - ntri * 36 - 6 * i;
                 v = rhs[((own + i) % hb1) * 6 + r];
             }
-            B.xchg[e] = v;
+            __hip_atomic_store(B.xchg + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (an agent-scope store: no data race with the other workgroup's atomic loads)
         }
         if (bad) s_bad = 1;
-        if (same_xcd()) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); else __threadfence();
+        // hand-over on a common L2, made explicit (it does not lean on how the compiler lowers a workgroup-scope fence): every store
+        // of this wave has ARRIVED at the L2 (the L1 is write-through; vmcnt counts stores until they are acknowledged) before the
+        // barrier, the flag store follows the barrier, and the consumer reads flag and data with agent-scope (sc1) loads, past its L1
+        if (same_xcd()) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else __threadfence();
         __syncthreads();
         if (tid == 0) __hip_atomic_store(B.fail + 1, B.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
@@ -1521,7 +1524,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
     if (tid == 0) while (__hip_atomic_load(B.fail + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != B.epoch) __builtin_amdgcn_s_sleep(2);
     if (B.trace && side == 0 && tid == 0) B.trace[23] = clock64() - tr0;
     __syncthreads();
-    if (same_xcd()) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); else __threadfence();
+    if (same_xcd()) asm volatile("" ::: "memory"); else __threadfence();           // (same L2: the loads below are agent-scope atomics, served by the L2)
     if (B.trace && side == 0 && tid == 0) B.trace[24] = clock64() - tr0;
     {
         double vb[ME];
@@ -1661,7 +1664,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                 // running sums stay zero: `on` below never selects a middle column)
                 if (tid == 0) while (__hip_atomic_load(B.fail + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != B.epoch) __builtin_amdgcn_s_sleep(2);
                 __syncthreads();
-                if (same_xcd()) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); else __threadfence();
+                if (same_xcd()) asm volatile("" ::: "memory"); else __threadfence();
                 for (int e = tid; e < hb * 6; e += BS_T) chat[6 * own + e] = __hip_atomic_load(dpo + 6 * gi(own + e / 6) + e % 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __syncthreads();
             }
@@ -1698,9 +1701,9 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
                     if (mine) x[6 * k + c_] = v;
                     base = mine ? 0.0 : (on ? base - t : base);
                     if (tw && side == 0 && k >= own) {               // the middle: the other side waits for these
-                        if (mine) dpo[6 * k + c_] = v;
+                        if (mine) __hip_atomic_store(dpo + 6 * k + c_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (k == own) {
-                            if (same0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); else __threadfence();
+                            if (same0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else __threadfence();
                             if (lane == 0) __hip_atomic_store(B.fail + 2, B.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }

@@ -122,6 +122,22 @@ def test_local_ba_vs_reference_style_lsmr_20kf(slam, orc, syn):
     _check_recall(cache.outliers, s)
 
 
+@pytest.mark.parametrize("P,M", [(50, 10000), (100, 40000)])
+def test_local_ba_vs_reference_style_lsmr_at_the_baseline_windows(slam, orc, syn, P, M):
+    """The metric's 50-KF window and configs[4]'s 100-KF window against the reference-style solver -- LM + LSMR on the full Jacobian with
+    the reference's 5 + 10 iterations (bundle_adjustment.jl:35-54) -- at the cross-algorithm bar of the small windows: final cost within
+    1e-3 relative (the Schur-LM takes exact steps, LSMR with btol = 0.5 inexact ones), outlier sets within 1 %."""
+    s = syn.ba_scene(P=P, M=M, seed=P)
+    cache = slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+    slam.bundle_adjustment_(cache, s["cam"], iterations=10, iters_fast=5)
+    th0, ol0, st0 = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], 5, 10, 5.0, solver=0)
+    rel = abs(cache.stats["ssr_final"] - st0["ssr_final"]) / st0["ssr_final"]
+    assert rel <= 1e-3, rel
+    assert cache.stats["ssr_final"] <= st0["ssr_final"] * (1 + 1e-3)
+    assert (cache.outliers != ol0).mean() < 0.01
+    _check_recall(cache.outliers, s)
+
+
 def test_twisted_solve_with_the_sides_on_different_xcds():
     """The banded solve's two workgroups normally share an XCD (launch of nine, sides = workgroups 0 and 8) and hand data to each
     other through the common L2 without agent-scope fences; each side checks the other's XCC_ID and falls back to the agent-scope
