@@ -215,6 +215,15 @@ class HipShard:
 def _all_reduce(t, op, group):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if t.is_cuda and dist.get_backend(group) != "nccl":
+            # a host-side backend (gloo: two processes sharing one GPU, where RCCL refuses a second rank per device): staged through
+            # the host; .cpu() waits for the library's stream only if the caller synchronised it (slam_ba_build / _solve do)
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=op, group=group)
+            t.copy_(h)
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
+            return t
         dist.all_reduce(t, op=op, group=group)
         if t.is_cuda:
             # RCCL runs on torch's streams, libslamhip on its own non-blocking stream: the
