@@ -37,872 +37,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-KF_EVERY = 5
-RIGHT_TARGET_ONLY = os.environ.get("SLAM_BENCH_RIGHT_FULL") is None     # right frames are only matched INTO (mapper.jl:51-66): layers only above level 0 (SLAM_PYR_TARGET_ONLY)
-CULL_FRACTION = 0.15              # share of tracked keypoints the map drops per key-frame
-N_FRAMES = 8                      # distinct rendered frames, played ping-pong
-HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-HBM_ACHIEVABLE_GBS = 6290.0       # same guide: measured-achievable stream rate (SURVEY 8d's denominator, quoted beside the spec)
-
-
-def frame_sequence(n_steps):
-    fwd = list(range(N_FRAMES)) + list(range(N_FRAMES - 2, 0, -1))
-    return [fwd[i % len(fwd)] for i in range(n_steps + 1)]
-
-
-class Stream:
-    """The reference's per-frame call protocol on arrays: preprocess! (pyramid
-    swap + update!, front_end.jl:454-470), optical_flow_matching! for tracked
-    keypoints (map_manager.jl:451-564), and at key-frames extract_keypoints!
-    (map_manager.jl:98-113) + right pyramid update! + stereo matching
-    (mapper.jl:51-66).  `be` supplies the five seams (GPU product or CPU oracle)."""
-
-    def __init__(self, be, flows, disparity, seed=0):
-        self.be, self.flows, self.disparity = be, flows, disparity
-        self.kp = np.zeros((0, 2)); self.is3d = np.zeros(0, dtype=bool)
-        self.rng = np.random.default_rng(seed)
-        self.t = 0
-        self.n_tracked = 0
-        # the prior's noise is INPUT (a stand-in for the motion model's error): drawn once, before any timed region, and read in turn --
-        # drawing 2 x n normals per frame inside the loop cost the single-stream loop ~15 us of numpy per 290-us frame
-        self.noise = self.rng.normal(0, 0.5, (1 << 17, 2)); self.noise_at = 0
-        self.dflow = {}
-
-    def step(self, f_prev, f_cur, upcoming=()):
-        be = self.be
-        kf = self.t % KF_EVERY == 0
-        be.kf_next = (self.t + 1) % KF_EVERY == 0            # the workload's key-frame cadence is fixed: a backend may request the next key-frame's right pyramid early
-        be.begin_frame(f_cur, upcoming, kf)
-        if len(self.kp):
-            flow = self.dflow.get((f_prev, f_cur))
-            if flow is None:
-                flow = self.dflow[(f_prev, f_cur)] = np.array(self.flows[f_cur]) - np.array(self.flows[f_prev])
-            n = len(self.kp)
-            if self.noise_at + n > len(self.noise): self.noise_at = 0
-            proj = self.kp + flow + self.noise[self.noise_at:self.noise_at + n]       # motion-model prior, ~0.5 px off
-            self.noise_at += n
-            new, st = be.match(False, self.kp, self.is3d, proj)
-            self.kp, self.is3d = new[st], self.is3d[st]
-            self.n_tracked += int(st.sum())
-        if kf:
-            # map culling between key-frames (outlier observations dropped by BA, estimator.jl:283-292;
-            # failed triangulations, mapper.jl:142-263): the synthetic scene never loses tracks by itself
-            if len(self.kp):
-                keep = self.rng.random(len(self.kp)) >= CULL_FRACTION
-                self.kp, self.is3d = self.kp[keep], self.is3d[keep]
-            fresh = be.detect(self.kp)
-            if len(fresh):
-                self.kp = np.concatenate([self.kp, fresh.astype(np.float64)])
-                self.is3d = np.concatenate([self.is3d, np.zeros(len(fresh), dtype=bool)])
-            proj = self.kp + np.array([0.0, -self.disparity])
-            _, st = be.match(True, self.kp, self.is3d, proj)
-            self.is3d = self.is3d | st                                            # stereo-matched -> triangulated
-        self.t += 1
-
-
-class GpuBackend:
-    """One stereo stream through the single-image entry points (latency view).  Contexts (HIP streams) mirror the reference's tasks:
-    `ctx` tracks / detects (front-end), `ctx_right` builds the right pyramid of a key-frame (mapper, mapper.jl:52), and the left
-    pyramids are built AHEAD of the tracking on `ahead` build contexts in turn: the pyramid of frame t+k does not depend on the
-    tracking result of frame t, a recorded sequence (example/kitty/main.jl reads its frames from disk) has the next frames at hand,
-    and a single-image build leaves most of the chip idle -- so `ahead` builds are in flight while frame t is tracked
-    (ahead = 1: the next frame only, the configuration of rounds 1-2).  ahead + 2 pyramids rotate so that a build never overwrites
-    planes still being read; markers (slam_event) order the tracking behind the one build it needs."""
-
-    def __init__(self, slam, ctx, ctx_pyr, ctx_right, H, W, left_dev, right_dev, params, extractor, pipelined=True, fast=False, ahead=1, extra_build_ctx=()):
-        self.slam, self.ctx, self.ctx_right, self.params, self.e = slam, ctx, ctx_right, params, extractor
-        self.build_ctx = [ctx_pyr] + list(extra_build_ctx)[:max(ahead - 1, 0)]
-        self.left, self.right, self.pipelined, self.fast = left_dev, right_dev, pipelined, fast
-        self.ahead = max(1, ahead)
-        self.npyr = self.ahead + 2
-        self.pyr = [slam.LKPyramid(shape=(H, W), levels=params.pyramid_levels, ctx=ctx) for _ in range(self.npyr)]
-        self.rpyrs = [slam.LKPyramid(shape=(H, W), levels=params.pyramid_levels, ctx=ctx) for _ in range(2)]
-        self.rpyr = self.rpyrs[0]
-        self.rheld = [None, None]                # frame number whose right image each right pyramid holds / is being built with
-        self.rbuilt = [None, None]               # marker: that build is complete
-        self.kf_next = False
-        self.built = [None] * self.npyr          # marker: "the build into this slot is complete"
-        self.holds = [None] * self.npyr          # (frame number, image id) the slot holds or is being built with
-        self.i = 0                 # frame number of the current frame; slot = i % npyr
-
-    @property
-    def cur(self):
-        return self.pyr[self.i % self.npyr]
-
-    @property
-    def prev(self):
-        return self.pyr[(self.i - 1) % self.npyr]
-
-    def _build(self, t, f, sync=False):
-        slot = t % self.npyr
-        c = self.build_ctx[t % len(self.build_ctx)]
-        self.slam.update_(self.pyr[slot], None, device_ptr=self.left[f].data_ptr(), sync=sync, ctx=c, fast=self.fast, chain=self.ahead > 1)
-        self.built[slot] = c.record(self.built[slot])
-        self.holds[slot] = (t, f)
-
-    def _build_right(self, t, f):
-        # with several build streams the right build goes FIRST onto the stream whose left build the tracking has just waited for (its
-        # queue is empty; the next left build of that stream is enqueued behind it): one more stream would be one more than the GPU has
-        # hardware queues, and the right build would sit behind whatever it aliased with
-        c = self.build_ctx[self.i % len(self.build_ctx)] if self.ahead > 1 else self.ctx_right
-        self.slam.update_(self.rpyrs[t % 2], None, device_ptr=self.right[f].data_ptr(), sync=False, ctx=c, fast=self.fast,
-                          target_only=RIGHT_TARGET_ONLY, chain=self.ahead > 1)
-        self.rbuilt[t % 2] = c.record(self.rbuilt[t % 2])
-        self.rheld[t % 2] = t
-
-    def prime(self, f):
-        self._build(self.i, f, sync=True)
-
-    def begin_frame(self, f_cur, upcoming, kf):
-        self.i += 1                                       # copy!(prev, cur) as a handle rotation (pyramid.jl:28)
-        if self.holds[self.i % self.npyr] != (self.i, f_cur) or not self.pipelined:
-            self._build(self.i, f_cur)
-        if kf:                                            # right image of a key-frame, on its own stream (mapper task, mapper.jl:52)
-            self.rpyr = self.rpyrs[self.i % 2]
-            if self.rheld[self.i % 2] != self.i:
-                self._build_right(self.i, f_cur)
-        self.ctx.wait_event(self.built[self.i % self.npyr])        # tracking below needs the build of THIS frame only
-        if self.pipelined and self.ahead > 1 and self.kf_next and len(upcoming):
-            # the next frame is a key-frame (fixed cadence of the workload): its right pyramid is requested now, so that the stereo
-            # match does not sit behind a 400-700 us build (the reference's mapper thread builds it beside the front-end, mapper.jl:52)
-            self._build_right(self.i + 1, list(upcoming)[0])
-        if self.pipelined:
-            for k, f in enumerate(list(upcoming)[:self.ahead], 1):
-                if self.holds[(self.i + k) % self.npyr] != (self.i + k, f):
-                    self._build(self.i + k, f)
-
-    def match(self, stereo, kp, is3d, proj):
-        a, b = (self.cur, self.rpyr) if stereo else (self.prev, self.cur)
-        if stereo:
-            self.ctx.wait_event(self.rbuilt[self.i % 2])
-        return self.slam.optical_flow_matching(a, b, kp, is3d, proj, self.params, ctx=self.ctx)
-
-    def detect(self, cur):
-        return self.slam.detect(self.e, self.cur, cur, ctx=self.ctx)
-
-    def drain(self):
-        for c in self.build_ctx:
-            c.synchronize()
-        self.ctx_right.synchronize(); self.ctx.synchronize()
-
-    def close(self):
-        for m in self.built + self.rbuilt:
-            if m is not None:
-                m.close()
-        for p_ in self.pyr + self.rpyrs:
-            p_.close()
-
-
-class GpuPeriodBackend:
-    """One stereo stream whose next KEY-FRAME PERIOD is built in one batched launch set: a recorded sequence has its next frames at hand,
-    and the library builds S images per launch with the bit-exact kernels (slam_pyr_update_batch_dev) -- the chain-bound single-image
-    kernels of five independent builds in flight leave the GPU mostly idle, one batch of the period's five left frames + the key-frame's
-    right frame costs little more than one image.  Tracking, detection and stereo matching go through the single-image entry points on the
-    batch's member pyramids, every call synchronous, exactly as in GpuBackend; period k + 1 is requested on the build context when
-    period k's first frame is reached (three batches rotate: the last member of period k - 1 is still `prev` then)."""
-
-    def __init__(self, slam, ctx, ctx_build, H, W, left_dev, right_dev, params, extractor, period):
-        self.slam, self.ctx, self.cb, self.params, self.e = slam, ctx, ctx_build, params, extractor
-        self.left, self.right, self.B = left_dev, right_dev, period
-        self.batches = [slam.PyramidBatch((H, W), levels=params.pyramid_levels, S=period + 1, ctx=ctx_build) for _ in range(3)]
-        self.built = [None, None, None]              # marker: the build into that batch is complete
-        self.first = slam.LKPyramid(shape=(H, W), levels=params.pyramid_levels, ctx=ctx)
-        self.i = 0; self.requested = -1
-        self.cur = self.prev = self.rpyr = None
-        self.kf_next = False
-
-    def prime(self, f):
-        self.slam.update_(self.first, None, device_ptr=self.left[f].data_ptr(), sync=True, ctx=self.ctx)
-        self.cur = self.first
-
-    def _request(self, k, frames):
-        """period k: its B left frames + the right frame of its first (key-)frame, one batched build"""
-        b = self.batches[k % 3]
-        ptrs = [self.left[f].data_ptr() for f in frames] + [self.right[frames[0]].data_ptr()]
-        b.update_(ptrs, sigma=self.params.pyramid_sigma, sync=False, ctx=self.cb)
-        self.built[k % 3] = self.cb.record(self.built[k % 3])
-        self.requested = k
-
-    def begin_frame(self, f_cur, upcoming, kf):
-        self.i += 1
-        k, m = divmod(self.i - 1, self.B)
-        up = list(upcoming)
-        if m == 0:
-            assert kf, "the period of the batches is the key-frame cadence"
-            if self.requested < k:                                            # the very first period
-                self._request(k, [f_cur] + up[:self.B - 1])
-            self.ctx.wait_event(self.built[k % 3])
-            if len(up) >= 2 * self.B - 1:
-                self._request(k + 1, up[self.B - 1:2 * self.B - 1])
-        b = self.batches[k % 3]
-        self.prev, self.cur = self.cur, b.pyramids[m]
-        if kf:
-            self.rpyr = b.pyramids[self.B]
-
-    def match(self, stereo, kp, is3d, proj):
-        a, b = (self.cur, self.rpyr) if stereo else (self.prev, self.cur)
-        return self.slam.optical_flow_matching(a, b, kp, is3d, proj, self.params, ctx=self.ctx)
-
-    def detect(self, cur):
-        return self.slam.detect(self.e, self.cur, cur, ctx=self.ctx)
-
-    def drain(self):
-        self.cb.synchronize(); self.ctx.synchronize()
-
-    def close(self):
-        for m in self.built:
-            if m is not None:
-                m.close()
-        self.first.close()
-        for b in self.batches:
-            for p_ in b.pyramids:
-                p_.close()
-
-
-class CpuBackend:
-    """The CPU oracle on the same protocol (cpu_baseline leg only)."""
-
-    def __init__(self, orc, left, right, params, extractor, threads):
-        self.orc, self.left, self.right, self.params, self.e, self.threads = orc, left, right, params, extractor, threads
-        self.prev = self.cur = self.rpyr = None
-        self.img = None
-
-    def prime(self, f):
-        self.cur = self.orc.pyr_build(self.left[f], self.params.pyramid_levels, self.params.pyramid_sigma, 1)
-
-    def begin_frame(self, f_cur, upcoming, kf):
-        self.prev = self.cur
-        self.img = self.left[f_cur]
-        self.cur = self.orc.pyr_build(self.img, self.params.pyramid_levels, self.params.pyramid_sigma, 1)
-        if kf:
-            self.rpyr = self.orc.pyr_build(self.right[f_cur], self.params.pyramid_levels, self.params.pyramid_sigma, 1)
-
-    def _fb(self, a, b, pts, disp, levels):
-        return self.orc.fb_tracking(a, b, pts, disp, 30, self.params.window_size, levels, 1e-4, 1e-2,
-                                    self.params.max_ktl_distance, sum_order=0, threads=self.threads)
-
-    def match(self, stereo, kp, is3d, proj):
-        a, b = (self.cur, self.rpyr) if stereo else (self.prev, self.cur)
-        n = len(kp); new = kp.copy(); status = np.zeros(n, dtype=bool)
-        ids3 = np.where(is3d)[0]; ids2 = list(np.where(~is3d)[0])
-        if len(ids3):
-            nk, st = self._fb(a, b, kp[ids3], 0.5 * (proj[ids3] - kp[ids3]), 1)
-            new[ids3[st]] = nk[st]; status[ids3[st]] = True; ids2 += list(ids3[~st])
-        if len(ids2):
-            ids2 = np.asarray(ids2)
-            nk, st = self._fb(a, b, kp[ids2], None, self.params.pyramid_levels)
-            new[ids2[st]] = nk[st]; status[ids2[st]] = True
-        return new, status
-
-    def detect(self, cur):
-        return self.orc.detect(self.img, cur, max_points=self.e.max_points, radius=self.e.radius, cell_size=self.e.cell_size)
-
-
-def pyramid_bytes(H, W, levels):
-    """per level read the layer + write layer, Iy, Ix, Iyy, Ixx, Iyx = 7 * 8 * sum(H_l W_l)."""
-    tot = 0
-    for _ in range(levels + 1):
-        tot += H * W; H = (H + 1) // 2; W = (W + 1) // 2
-    return 7 * 8 * tot
-
-
-def iir_rows_bytes(H, W, levels):
-    """k_iir_rows algorithmic bytes per pyramid: every element of each plane it filters read once + written once."""
-    tot = 0
-    for l in range(levels + 1):
-        planes = 4 if l < levels else 3
-        tot += planes * H * W * 16; H = (H + 1) // 2; W = (W + 1) // 2
-    return tot
-
-
-def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, right_dev, flows, disparity, params, extractor, fast, world, dist, dev, hook=None):
-    """S streams in lock-step through the batch entry points.  Stream s plays the same ping-pong sequence shifted
-    by s frames (so the S images of a step differ); key-frames fall on the same step for all streams."""
-    # tracking stream in a scheduling class of its own, as in run_lockstep_kpset (hardware-queue aliasing with the pyramid graph's branches)
-    ctx, ctx_pyr, ctx_right = (leg_ctx(slam, local_rank, int(os.environ.get("SLAM_BENCH_TRACK_PRIO", "-1"))), leg_ctx(slam, local_rank),
-                               leg_ctx(slam, local_rank))
-    levels = params.pyramid_levels
-    AHEAD = max(1, int(os.environ.get("SLAM_BENCH_AHEAD", "1")))   # pyramid builds kept in flight ahead of the step being tracked (2 measured 5 % slower: two builds + LK contend for the HBM)
-    NLB = AHEAD + 2                                         # rotating left batches: previous, current, AHEAD in flight
-    lb = [slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx) for _ in range(NLB)]
-    built = [None] * NLB       # marker on the pyramid stream: "the build into this slot is complete"
-    rb = slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx)
-    seq = frame_sequence(steps + warmup + 60 + S)
-    rng = np.random.default_rng(1234)
-    noise_pool = rng.normal(0, 0.5, (max(1 << 17, 4096 * S), 2))          # prior noise, drawn once (synthetic-input generation, not SLAM work)
-    seq_a = np.asarray(seq); flows_a = np.asarray(flows, dtype=np.float64)
-    lp = [t.data_ptr() for t in left_dev]; rp = [t.data_ptr() for t in right_dev]
-    lptr = lambda i: [lp[f] for f in seq[i:i + S]]
-    rptr = lambda i: [rp[f] for f in seq[i:i + S]]
-    flow_at = lambda i: flows_a[seq_a[i:i + S]] - flows_a[seq_a[i - 1:i - 1 + S]]
-    kp = np.zeros((0, 2)); is3d = np.zeros(0, dtype=bool); sid = np.zeros(0, dtype=np.int32)
-    cur = 0
-
-    nxt = [0]                  # next frame whose left build has not been enqueued yet
-
-    def enqueue_build(frame):
-        slot = frame % NLB
-        lb[slot].update_(lptr(frame), sync=False, fast=fast, ctx=ctx_pyr)
-        built[slot] = ctx_pyr.record(built[slot])
-
-    def build_up_to(frame):
-        while nxt[0] <= frame:
-            enqueue_build(nxt[0]); nxt[0] += 1
-
-    build_up_to(AHEAD)
-    ctx_pyr.synchronize()
-    kf_tail = os.environ.get("SLAM_BENCH_KF_TAIL", "0") != "0"     # measured 5 % slower when on
-    state = dict(kp=kp, is3d=is3d, sid=sid, cur=cur, tracked=0)
-
-    def step(i, pipelined=True):
-        kf = (i - 1) % KF_EVERY == 0
-        st_ = state
-        prevb, curb = lb[(i - 1) % NLB], lb[i % NLB]
-        if not pipelined:                                   # span pass: build this step's pyramids now, serially
-            enqueue_build(i); nxt[0] = max(nxt[0], i + 1)
-        if kf:
-            rb.update_(rptr(i), sync=False, fast=fast, ctx=ctx_right, target_only=RIGHT_TARGET_ONLY)
-        ctx.wait_event(built[i % NLB])                      # tracking needs the build of frame i only (i+1.. stay in flight)
-        if pipelined:
-            build_up_to(i + AHEAD)                          # overwrites the slot of a frame nothing reads any more
-        kp, is3d, sid = st_["kp"], st_["is3d"], st_["sid"]
-        if len(kp):
-            o = (i * 7919) % (len(noise_pool) - len(kp))
-            proj = flow_at(i).take(sid, axis=0); proj += kp; proj += noise_pool[o:o + len(kp)]
-            # track + drop the keypoints whose tracking failed (map_manager.jl:523-560) in one call
-            kp, is3d, sid, _ = slam.optical_flow_matching_batch_kept(prevb, curb, sid, kp, is3d, proj, params, ctx=ctx)
-            st_["tracked"] += len(kp)
-        if kf:
-            if len(kp):
-                keep = np.flatnonzero(rng.random(len(kp)) >= CULL_FRACTION)
-                kp, is3d, sid = kp.take(keep, axis=0), is3d.take(keep), sid.take(keep)
-            fresh, fsid = slam.detect_batch(extractor, curb, kp, sid, ctx=ctx)       # kp is kept grouped by stream
-            if len(fresh):
-                a = np.searchsorted(sid, np.arange(S + 1)); b = np.searchsorted(fsid, np.arange(S + 1))
-                fresh = fresh.astype(np.float64)
-                kp = np.concatenate([x for s_ in range(S) for x in (kp[a[s_]:a[s_ + 1]], fresh[b[s_]:b[s_ + 1]])])
-                is3d = np.concatenate([x for s_ in range(S) for x in (is3d[a[s_]:a[s_ + 1]], np.zeros(b[s_ + 1] - b[s_], dtype=bool))])
-                sid = np.concatenate([x for s_ in range(S) for x in (sid[a[s_]:a[s_ + 1]], fsid[b[s_]:b[s_ + 1]])])
-            if pipelined and kf_tail:
-                # the stereo match below is the tail of a key-frame step: the left / right builds are (nearly) done and the
-                # match alone does not fill the GPU, so the build of frame i+AHEAD+1 starts now (its slot held frame i-1,
-                # which the temporal match above was the last to read)
-                build_up_to(i + AHEAD + 1)
-            ctx.wait_for(ctx_right)
-            proj = kp + np.array([0.0, -disparity])
-            _, ok = slam.optical_flow_matching_batch(curb, rb, sid, kp, is3d, proj, params, ctx=ctx, status_only=True)
-            is3d = is3d | ok
-        st_["kp"], st_["is3d"], st_["sid"] = kp, is3d, sid
-        if hook is not None and pipelined:
-            hook()                                          # e.g. the pose seams of the step (synchronous, own context)
-
-    def drain():
-        ctx_pyr.synchronize(); ctx_right.synchronize(); ctx.synchronize(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    warm = max(warmup, 6)
-    for i in range(1, 1 + warm):
-        step(i)
-    state["tracked"] = 0
-    drain(); t0 = time.perf_counter()
-    for i in range(1 + warm, 1 + warm + steps):
-        step(i)
-    drain(); dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
-    tracked = state["tracked"] / max(steps, 1) / S
-    # per-kernel spans (serial launches, no pipelining) for the roofline of the batched launches
-    for c in (ctx_pyr, ctx_right):
-        c.prof_enable(True); c.prof_reset()
-    base = 1 + warm + steps
-    nprof = 20
-    ctx_pyr.synchronize()
-    for i in range(base, base + nprof):
-        step(i, pipelined=False)
-    drain()
-    rows_ms, rows_n = [a + b for a, b in zip(ctx_pyr.prof_get("k_iir_rows"), ctx_right.prof_get("k_iir_rows"))]
-    pyr_ms, pyr_n = [a + b for a, b in zip(ctx_pyr.prof_get("pyr_update"), ctx_right.prof_get("pyr_update"))]
-    for c in (ctx_pyr, ctx_right):
-        c.prof_enable(False)
-    rb_bytes = S * iir_rows_bytes(H, W, levels) / (levels + 1)
-    res = {"streams_per_gpu": S, "steps": steps, "value": world * S * steps / dt, "unit": "frames/sec", "seconds": dt,
-           "ms_per_step_of_S_frames": dt / steps * 1e3, "tracked_kpts_per_frame": round(tracked, 1),
-           "roofline": {"bound": "hbm", "kernel": "k_iir_seg<rows>" if (fast and S < 4) else "k_iir_rows (bit-exact kernels: batches of >= 4 images take them in mode 3 too)" if fast else "k_iir_rows", "achieved": rb_bytes / (rows_ms / max(rows_n, 1) * 1e-3) / 1e9,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rb_bytes / (rows_ms / max(rows_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "frac_of_achievable": rb_bytes / (rows_ms / max(rows_n, 1) * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, "achievable_peak": HBM_ACHIEVABLE_GBS,
-                        "avg_launch_us": rows_ms / max(rows_n, 1) * 1e3, "algorithmic_bytes_per_launch": rb_bytes, "traffic": None},
-           "pyramid_batch_update_serial_us": pyr_ms / max(pyr_n, 1) * 1e3}
-    pb = S * pyramid_bytes(H, W, levels)
-    res["roofline"]["stage"] = {"name": f"pyramid update of {S} images (all kernels, serial launches)", "algorithmic_bytes": pb,
-                                "avg_us": pyr_ms / max(pyr_n, 1) * 1e3, "achieved": pb / (pyr_ms / max(pyr_n, 1) * 1e-3) / 1e9,
-                                "frac": pb / (pyr_ms / max(pyr_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "note": "algorithmic = read the layer + write the 6 planes of every level once (SURVEY 8d); the separable filters and the "
-                                        "two-dimensional recurrences need ~40 plane passes per level, which is what the kernels are bound by"}
-    for c_ in (ctx, ctx_pyr, ctx_right):
-        c_.close()
-    return res
-
-
-WORKLOADS = {
-    # name: shape (slam_jl_amd.synthetic.SHAPES), keypoints per frame, stereo, streams per GPU, camera (fx, fy, cx, cy), image step per frame
-    "kitti05_1000": dict(shape="kitti05", kpts=1000, stereo=True, S=128, cam=None, step=(1.3, -2.1), n_frames=8,
-                         what="BASELINE configs[1]: KITTI 05 stereo 370x1226, 1000 kpts/frame (the headline)"),
-    "kitti00_2000": dict(shape="kitti00", kpts=2000, stereo=True, S=128, cam=None, step=(1.3, -2.1), n_frames=8,
-                         what="BASELINE configs[2]: KITTI 00 stereo 376x1241 (example/kitty/main.jl:21-22), 2000 kpts/frame; its 20-KF BA is ba.windows.P20"),
-    "euroc_mono": dict(shape="euroc", kpts=1000, stereo=False, S=128, cam=(458.654, 457.296, 367.215, 248.375), step=(2.6, -4.2), n_frames=8,
-                       what="BASELINE configs[3]: monocular 480x640, PnP-tracking path (front_end.jl:132-219: five-point filter + P3P RANSAC + PnP "
-                            "refinement every frame, no right image), new keypoints by triangulate_temporal!; its 50-KF BA is ba.windows.P50"),
-    "fhd_4000": dict(shape="fhd", kpts=4000, stereo=True, S=32, cam=(910.0, 910.0, 960.0, 540.0), step=(1.3, -2.1), n_frames=4,
-                     what="BASELINE configs[4] on one GPU: 1080x1920 stereo (example/uni/main.jl:11-13), 4000 kpts/frame; its 100-KF BA is ba.windows.P100"),
-}
-
-
-def make_workload(slam, syn, name, seed=0, streams=None):
-    w = dict(WORKLOADS[name]); w["name"] = name
-    H, W = syn.SHAPES[w["shape"]]
-    camt = tuple(w["cam"] or syn.KITTI_CAM)
-    params = slam.Params(stereo=w["stereo"], max_nb_keypoints=w["kpts"])
-    cam = slam.Camera(*camt, height=H, width=W)
-    w.update(H=H, W=W, camt=camt, params=params, extractor=slam.Extractor.from_params(params, cam), disparity=12.4, levels=params.pyramid_levels)
-    if streams:
-        w["S"] = streams
-    w["left"], w["right"], w["flows"] = syn.stereo_stream(w["shape"], w["n_frames"], seed=seed, step=w["step"], disparity=w["disparity"])
-    if not w["stereo"]:
-        w["right"] = None
-    return w
-
-
-def frame_sequence_n(n_frames, n_steps):
-    fwd = list(range(n_frames)) + list(range(n_frames - 2, 0, -1))
-    return [fwd[i % len(fwd)] for i in range(n_steps + 1)]
-
-
-def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world, dist, dev, ingest,
-                       hook=None, seed=1234, pose=False, record=None, snapshot=None):
-    """The headline loop: S streams in lock-step, keypoints resident in HBM (slam_kpset_*), no host list work
-    between the calls of a frame; the host sees the S list lengths once per frame.  Timed: `periods` key-frame periods
-    (KF_EVERY frames of every stream each, the first a key-frame) after `warm_periods` untimed ones.
-
-    ingest: where a frame starts --
-      "host_u8"  pinned host memory, 8-bit as the KITTI reader decodes them (example/kitty/kitty.jl:52-102): one H2D copy of
-                 the S frames on the copy stream, converted on the device (slam_pyr_update_batch_u8_dev);
-      "host_f64" pinned host memory as Matrix{Gray{Float64}} (what the Julia seam receives, SLAM.jl:250): 8x the bytes;
-      "dev_f64"  already in HBM as Float64 (round-1 headline).
-    Stream s plays the ping-pong sequence shifted by s frames, so the S frames of a step are a contiguous window of the
-    periodic sequence: one copy per step.
-
-    record (dict, optional): replay mode for the parity check -- runs record["frame_steps"] frames from the empty lists, no
-      warm-up, and appends per frame {"i", "kf", "shift" (S, 2), "cull" (S, cap) uint8 or None} to record["steps"].
-    snapshot (list of stream ids, optional): after the last frame, download those streams' keypoint lists and all planes of
-      their current left pyramids into the result (the cpu_baseline leg compares them with the oracle)."""
-    import ctypes as C
-    S, H, W, params, extractor, camt, disparity = wl["S"], wl["H"], wl["W"], wl["params"], wl["extractor"], wl["camt"], wl["disparity"]
-    left, right, flows, stereo = wl["left"], wl["right"], wl["flows"], wl["stereo"]
-    fastpyr = bool(wl.get("tolerance"))                       # slam_pyr_update_batch mode 3: the tolerance-mode batch kernels (planes <= 1e-11 relative)
-    # the tracking context's stream is in a scheduling class of its own (the low-priority one): a hardware queue that the branches
-    # of the pyramid graph never land on.  With four default-class streams the runtime placed the graph's small-level branch on
-    # the tracking stream's queue and every step's match sat behind it until the build was over (kernel trace, DESIGN 4).
-    # Measured at S = 32, host_u8: default class 14.7k frames/s, high 16.2k, low 16.5k (the builds are the longer chain of a
-    # step and are better left undisturbed).  SLAM_BENCH_TRACK_PRIO=0 restores the shared class for comparison.
-    prio = int(os.environ.get("SLAM_BENCH_TRACK_PRIO", "-1"))
-    pprio = int(os.environ.get("SLAM_BENCH_PYR_PRIO", "0"))
-    ctx, ctx_pyr, ctx_right, ctx_copy = (leg_ctx(slam, local_rank, prio), leg_ctx(slam, local_rank, pprio),
-                                         leg_ctx(slam, local_rank, pprio), leg_ctx(slam, local_rank))
-    levels = params.pyramid_levels
-    AHEAD = max(1, int(os.environ.get("SLAM_BENCH_KP_AHEAD", "2")))   # builds enqueued ahead of the step being tracked (same-box A/B: 2 = +0.9 % over 1 -- the next graph is already queued when a build ends; 3 = -1.4 %)
-    NLB = AHEAD + 3                                          # previous, current, AHEAD being built, one more being copied
-    lb = [slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx) for _ in range(NLB)]
-    rb = slam.PyramidBatch((H, W), levels=levels, S=S, ctx=ctx) if stereo else None
-    built = [None] * NLB
-    copied = [None] * NLB; rcopied = [None]; rbuilt = [None]
-    ncell = extractor.grid_resolution[0] * extractor.grid_resolution[1]
-    cap = extractor.max_points + ncell + 8
-    ks = slam.KeypointSet(S, cap, ctx=ctx)
-    peek("run_lockstep_kpset: start")
-    n_frames = len(left)
-    period = 2 * n_frames - 2
-    seq = frame_sequence_n(n_frames, period + S + 2)
-    u8 = ingest == "host_u8"
-    np_dtype, t_dtype, fbytes = (np.uint8, torch.uint8, H * W) if u8 else (np.float64, torch.float64, H * W * 8)
-    conv = (lambda im: np.round(im * 255).astype(np.uint8)) if u8 else (lambda im: im)
-    # the periodic frame sequence, contiguous (row-major (W, H) = Julia's column-major H x W)
-    def seq_tensor(frames):
-        a = np.stack([np.ascontiguousarray(conv(frames[seq[k]]).T) for k in range(period + S)])
-        return torch.from_numpy(a)
-    lseq = seq_tensor(left); rseq = seq_tensor(right) if stereo else None
-    host = ingest != "dev_f64"
-    if host:
-        lseq = lseq.pin_memory()
-        lstage = [torch.empty((S, W, H), dtype=t_dtype, device=dev) for _ in range(NLB)]
-        if stereo:
-            rseq = rseq.pin_memory()
-            rstage = torch.empty((S, W, H), dtype=t_dtype, device=dev)
-        st_copy = torch.cuda.ExternalStream(ctx_copy.stream, device=dev)         # H2D copies on their own stream, one step ahead of the builds
-    else:
-        lseq = lseq.to(dev); rseq = rseq.to(dev) if stereo else None
-    torch.cuda.synchronize()
-    flows_a = np.asarray(flows, dtype=np.float64); seq_a = np.asarray(seq)
-    rng = np.random.default_rng(seed)
-    st_main = torch.cuda.ExternalStream(ctx.stream, device=dev)
-    gen = torch.Generator(device=dev); gen.manual_seed(seed + local_rank)
-    cull_u = torch.empty(S * cap, dtype=torch.float32, device=dev)      # allocated on torch's own stream: nothing is allocated inside the
-    cull_flags = torch.zeros(S * cap, dtype=torch.bool, device=dev)     # library-stream contexts below (the caching allocator would keep using that stream)
-    ev_pool = [(slam.Event(ctx_pyr, timed=True), slam.Event(ctx_pyr, timed=True)) for _ in range(48)]
-    ev_used = []
-    # hipEvents around the temporal match (k_kpset_match + the compaction behind it) on the TRACKING stream, timed region only
-    lk_pool = [(slam.Event(ctx, timed=True), slam.Event(ctx, timed=True)) for _ in range(48)]
-    lk_used = []                                             # (event pair, keypoints that entered the match)
-
-    def ptrs(base_tensor):
-        b = base_tensor.data_ptr()
-        return [b + s * fbytes for s in range(S)]
-
-    def enqueue_copy(frame):
-        """the step's S left frames: pinned host -> staging slot, behind the last build that read the slot"""
-        slot = frame % NLB
-        if built[slot] is not None:
-            ctx_copy.wait_event(built[slot])
-        with torch.cuda.stream(st_copy):
-            lstage[slot].copy_(lseq[frame % period:frame % period + S], non_blocking=True)
-        copied[slot] = ctx_copy.record(copied[slot])
-
-    def enqueue_build(frame, timed=False):
-        slot = frame % NLB
-        o = frame % period
-        if host:
-            ctx_pyr.wait_event(copied[slot])
-            src = ptrs(lstage[slot])
-        else:
-            src = ptrs(lseq[o:o + S])
-        if timed:
-            pair = ev_pool[len(ev_used) % len(ev_pool)]
-            ctx_pyr.record(pair[0])
-        lb[slot].update_(src, sync=False, ctx=ctx_pyr, u8=u8, fast=fastpyr)
-        if timed:
-            ctx_pyr.record(pair[1]); ev_used.append(pair)
-        built[slot] = ctx_pyr.record(built[slot])
-
-    def enqueue_right_copy(frame):
-        if rbuilt[0] is not None:
-            ctx_copy.wait_event(rbuilt[0])
-        with torch.cuda.stream(st_copy):
-            rstage.copy_(rseq[frame % period:frame % period + S], non_blocking=True)
-        rcopied[0] = ctx_copy.record(rcopied[0])
-
-    def enqueue_right(frame):
-        o = frame % period
-        if host:
-            ctx_right.wait_event(rcopied[0])
-            src = ptrs(rstage)
-        else:
-            src = ptrs(rseq[o:o + S])
-        rb.update_(src, sync=False, ctx=ctx_right, u8=u8, target_only=RIGHT_TARGET_ONLY, fast=fastpyr)
-        rbuilt[0] = ctx_right.record(rbuilt[0])
-
-    nxt = [0]; nxc = [0]
-    def build_up_to(frame, timed=False):
-        if host:
-            while nxc[0] <= frame + 1:                       # copies run one frame ahead of the builds
-                enqueue_copy(nxc[0]); nxc[0] += 1
-        while nxt[0] <= frame:
-            enqueue_build(nxt[0], timed); nxt[0] += 1
-
-    Z_PLANE = 30.0
-    baseline = disparity * Z_PLANE / camt[0]                 # a scene 30 m away: d = fx b / z
-    T21 = np.eye(4); T21[0, 3] = -baseline
-    Twc = np.eye(4)
-    sp_stereo = slam.stream_params(S, cam=camt, shift_yx=np.tile([0.0, -disparity], (S, 1)))
-    state = dict(n_bound=0, tracked=0, tracked_steps=0, timed=False, wait_s=0.0, booted=False)
-    # pose = True: the full per-frame front-end of front_end.jl:60-113 on the tracked lists themselves -- the streams are a rigid
-    # scene (a fronto-parallel plane 30 m away, cameras translating parallel to it), so the map points of the stereo
-    # triangulation, the pose priors of the tracking, the five-point filter against the previous key-frame and P3P + PnP are all
-    # consistent; the recovered camera translation is checked against the image offsets of the frames.
-    pst = dict(Tcw=np.tile(np.eye(4), (S, 1, 1)), Tprev=np.tile(np.eye(4), (S, 1, 1)), Tkf=np.tile(np.eye(4), (S, 1, 1)), ref=None,
-               accepted=0, asked=0, err_max=0.0, acc5=0, asked5=0, gated5=0, n_kf=0, kf_cw=np.tile(np.eye(4), (S, 8, 1, 1)))
-    sp_cam = slam.stream_params(S, cam=camt)
-    if host and stereo:
-        enqueue_right_copy(1)                               # step 1 is a key-frame
-    build_up_to(AHEAD)
-    ctx_pyr.synchronize(); ctx_copy.synchronize()
-
-    def step(i):
-        kf = (i - 1) % KF_EVERY == 0
-        prevb, curb = lb[(i - 1) % NLB], lb[i % NLB]
-        if kf and stereo:
-            enqueue_right(i)
-        if host and stereo and i % KF_EVERY == 0:           # the next step is a key-frame: its right frames start travelling now
-            enqueue_right_copy(i + 1)
-        ctx.wait_event(built[i % NLB])                      # tracking needs the build of frame i only
-        build_up_to(i + AHEAD, state["timed"])              # the next frame's copy + build overlap this step's tracking
-        cnt = None
-        rec = None
-        if record is not None:
-            rec = {"i": i, "kf": kf, "shift": None, "cull": None}; record["steps"].append(rec)
-        if state["n_bound"] > 0 and pose:
-            # klt_tracking! with the motion model's prediction (constant velocity on the translation), then the epipolar filter and
-            # compute_pose!; the pose call is this step's device -> host copy
-            Tpred = pst["Tcw"].copy(); Tpred[:, :3, 3] += pst["Tcw"][:, :3, 3] - pst["Tprev"][:, :3, 3]
-            ks.flow_match(prevb, curb, params, slam.stream_params(S, Tcw=Tpred, cam=camt), prior=1, n_bound=state["n_bound"], ctx=ctx)
-            Rc = np.tile(np.eye(4), (S, 1, 1)); Rc[:, :3, :3] = pst["Tkf"][:, :3, :3] @ np.transpose(Tpred[:, :3, :3], (0, 2, 1))
-            r5 = ks.compute_pose_5pt(slam.stream_params(S, Tcw=Rc, cam=camt), min_parallax=5.0, max_repr_error=3.0, iters=128,
-                                     seed=seed + 2 * i, ctx=ctx, fetch=(i % 4 == 0))      # enqueue-only on most steps: its effect is on the lists
-            t_enq = time.perf_counter()
-            poses, stp, _, cnt = ks.compute_pose(sp_cam, threshold=3.0, iters=256, seed=seed + 2 * i + 1, ctx=ctx)
-            state["wait_s"] += time.perf_counter() - t_enq
-            pst["Tprev"] = pst["Tcw"].copy()
-            ok = stp.astype(bool)
-            pst["Tcw"][ok] = poses[ok]
-            if pst["ref"] is not None:
-                off = flows_a[seq_a[(i % period) + np.arange(S)]] - pst["ref"]
-                want = np.stack([off[:, 1] * Z_PLANE / camt[0], off[:, 0] * Z_PLANE / camt[1], np.zeros(S)], axis=1)
-                pst["asked"] += S; pst["accepted"] += int(ok.sum())
-                if r5 is not None:
-                    st5 = np.asarray(r5[1]).astype(bool); par5 = np.asarray(r5[3])
-                    pst["asked5"] += S; pst["acc5"] += int(st5.sum()); pst["gated5"] += int((~st5 & (par5 < 5.0)).sum())
-                if ok.any():
-                    pst["err_max"] = max(pst["err_max"], float(np.abs(pst["Tcw"][ok, :3, 3] - want[ok]).max()))
-        elif state["n_bound"] > 0:
-            # motion-model prior: the stream's image-plane shift, ~0.5 px off (project_world_to_image_distort of the map points
-            # under the predicted pose; the synthetic streams are image-plane translations)
-            shift = flows_a[seq_a[(i % period) + np.arange(S)]] - flows_a[seq_a[((i - 1) % period) + np.arange(S)]]
-            shift = shift + rng.normal(0, 0.5, (S, 2))
-            if rec is not None:
-                rec["shift"] = shift.copy()
-            sp = slam.stream_params(S, cam=camt, shift_yx=shift)
-            lkp = None
-            if state["timed"]:
-                lkp = lk_pool[len(lk_used) % len(lk_pool)]; ctx.record(lkp[0])
-            ks.flow_match(prevb, curb, params, sp, prior=2, n_bound=state["n_bound"], ctx=ctx)
-            if lkp is not None:
-                ctx.record(lkp[1]); lk_used.append((lkp, state["n_bound"]))
-        if kf:
-            # map culling between key-frames (outlier observations dropped by BA, failed triangulations): flags drawn in HBM
-            with torch.cuda.stream(st_main):
-                cull_u.uniform_(generator=gen)
-                torch.lt(cull_u, CULL_FRACTION, out=cull_flags)                 # bool = one byte per slot, 1 = remove
-            if rec is not None:
-                ctx.synchronize()
-                rec["cull"] = cull_flags.cpu().numpy().astype(np.uint8).reshape(S, cap)
-            ks.remove(cull_flags.data_ptr(), ctx=ctx)
-            ks.detect(extractor, curb, ctx=ctx)
-            if pose and not stereo and not state["booted"]:
-                # monocular initialisation taken as given (front_end.jl:243-332 + mapper.jl:185-262 run once at start-up): the first
-                # key-frame's keypoints become map points on the scene plane; the loop measures the PnP-tracking steady state
-                for s_ in range(S):
-                    d_ = ks.download(s_, ctx=ctx)
-                    yx_ = d_["yx"]
-                    xyz_ = np.stack([(yx_[:, 1] - camt[2]) / camt[0] * Z_PLANE, (yx_[:, 0] - camt[3]) / camt[1] * Z_PLANE, np.full(len(yx_), Z_PLANE)], axis=1)
-                    ks.upload(s_, yx_, np.ones(len(yx_), bool), xyz_, ids=d_["ids"], ctx=ctx)
-                state["booted"] = True
-            if pose:
-                ks.keyframe(ctx=ctx)                        # the frame becomes the previous key-frame of its keypoints
-                pst["Tkf"] = pst["Tcw"].copy()
-                if pst["ref"] is None:                      # world frame = the first key-frame's camera
-                    pst["ref"] = flows_a[seq_a[(i % period) + np.arange(S)]].copy()
-            Twc_now = np.linalg.inv(pst["Tcw"]) if pose else Twc
-            if stereo:
-                ctx.wait_for(ctx_right)
-                ks.stereo_match(curb, rb, params, sp_stereo, prior=2, ctx=ctx)
-                ks.triangulate(camt, camt, T21, Twc_now, max_error=3.0, ctx=ctx)
-            if pose:                                        # mapper.jl:86: what stereo left 2-D, against its first observing key-frame
-                kfid = pst["n_kf"]; pst["kf_cw"][:, kfid % 8] = pst["Tcw"]; pst["n_kf"] += 1
-                if kfid > 0:
-                    ks.triangulate_temporal(sp_cam, pst["kf_cw"], Twc_now, kfid, max_error=3.0, ctx=ctx)
-            cnt = None
-        if cnt is None:
-            t_enq = time.perf_counter()
-            cnt = ks.counts(ctx=ctx)                        # the one device -> host copy of the step (synchronises)
-            state["wait_s"] += time.perf_counter() - t_enq  # host time spent waiting for the GPU (the rest of the step is enqueue work)
-        tot = int(cnt.sum())
-        if not kf and state["n_bound"] > 0:
-            state["tracked"] += tot; state["tracked_steps"] += 1
-        state["n_bound"] = tot
-        if hook is not None:
-            hook()
-
-    def drain():
-        ctx_copy.synchronize(); ctx_pyr.synchronize(); ctx_right.synchronize(); ctx.synchronize(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    if record is not None:
-        warm, nsteps = 0, int(record["frame_steps"])
-    else:
-        warm, nsteps = max(warm_periods, 2) * KF_EVERY, periods * KF_EVERY
-    for i in range(1, 1 + warm):
-        step(i)
-    state["tracked"] = 0; state["tracked_steps"] = 0
-    drain(); state["timed"] = True; state["wait_s"] = 0.0; t0 = time.perf_counter()
-    for i in range(1 + warm, 1 + warm + nsteps):
-        step(i)
-    drain(); dt = time.perf_counter() - t0
-    state["timed"] = False
-    i_last = warm + nsteps
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
-    builds = [a.elapsed_ms(b) for a, b in ev_used[-len(ev_pool):]]      # left builds of the timed region (graph replays on the pyramid stream)
-    lk_spans = [(a.elapsed_ms(b), n) for (a, b), n in lk_used[-len(lk_pool):]]
-    try:
-        free_b, total_b = torch.cuda.mem_get_info(dev)
-        hbm_gb = (total_b - free_b) / 1e9                                # everything this process (and anyone else on the device) holds while the loop's buffers are alive
-    except Exception:
-        hbm_gb = None
-    res = {"ingest": ingest, "streams_per_gpu": S, "hbm_in_use_gb": hbm_gb, "steps": periods, "frame_steps": nsteps, "value": world * S * nsteps / dt, "unit": "frames/sec", "seconds": dt,
-           "ms_per_step": dt / max(periods, 1) * 1e3, "ms_per_frame_of_S_streams": dt / nsteps * 1e3,
-           "host_wait_ms_per_frame": state["wait_s"] / nsteps * 1e3,
-           "tracked_kpts_per_frame": round(state["tracked"] / max(state["tracked_steps"], 1) / S, 1),
-           "pose": None if not pose else {"accepted_fraction": pst["accepted"] / max(pst["asked"], 1),
-                                          "five_point_accepted_fraction": pst["acc5"] / max(pst["asked5"], 1),
-                                          "five_point_rejected_by_parallax_gate_fraction": pst["gated5"] / max(pst["asked5"], 1),
-                                          "five_point_note": "compute_pose_5pt! returns nothing while the average parallax against the previous key-frame is below 5 px "
-                                                             "(front_end.jl:290): the first frames after each key-frame; every remaining call is accepted when the two fractions add up to 1",
-                                          "max_translation_error_m": pst["err_max"], "plane_depth_m": Z_PLANE},
-           "lk_match": None if not lk_spans else {"mean_ms": float(np.mean([m for m, _ in lk_spans])), "points_per_launch": float(np.mean([n for _, n in lk_spans])),
-                                                  "n": len(lk_spans), "what": "hipEvents around slam_kpset_flow_match (k_kpset_match + compaction) on the tracking stream, timed region"},
-           "pyramid_build_ms": {"mean": float(np.mean(builds)) if builds else None, "min": float(np.min(builds)) if builds else None,
-                                "n": len(builds), "what": "hipEvents around each left-batch build (one hipGraph replay, u8 ingest fused) on the pyramid "
-                                                          "stream inside the timed region, tracking running beside it"}}
-    if snapshot is not None:
-        snap = {}
-        curb = lb[i_last % NLB]
-        for s_ in snapshot:
-            snap[s_] = {"frame_id": int(seq[(i_last % period) + s_]), "list": ks.download(s_, ctx=ctx),
-                        "planes": {(nm, l): curb.pyramids[s_].plane(nm, l, ctx=ctx) for l in range(levels + 1)
-                                   for nm in ("layers", "Iy", "Ix", "Iyy", "Ixx", "Iyx")}}
-        res["snapshot"] = snap
-        res["seq"] = seq; res["period"] = period; res["cap"] = cap
-    peek("run_lockstep_kpset: after the loop")
-    for c in (ctx, ctx_pyr, ctx_right, ctx_copy):
-        c.synchronize()
-    torch.cuda.synchronize()
-    peek("run_lockstep_kpset: after the synchronisation")
-    ks.close()
-    peek("run_lockstep_kpset: after ks.close")
-    for e2 in ev_pool + lk_pool:
-        e2[0].close(); e2[1].close()
-    for m in built + copied + rcopied + rbuilt:
-        if m is not None:
-            m.close()
-    peek("run_lockstep_kpset: after closing events / markers")
-    for b_ in lb + ([rb] if rb is not None else []):
-        for p_ in b_.pyramids:
-            p_.close()
-    peek("run_lockstep_kpset: after destroying the pyramids")
-    del lseq, rseq, cull_u, cull_flags
-    if host:
-        del lstage, st_copy
-    del st_main
-    peek("run_lockstep_kpset: after freeing the torch buffers")
-    for c_ in (ctx, ctx_pyr, ctx_right, ctx_copy):
-        c_.close()
-    return res
-
-
-def replay_stream_on_oracle(orc, slam, wl, rec, res, s, threads):
-    """The oracle's replay of stream s of a recorded run_lockstep_kpset run (checker; cpu_baseline leg only): the same 8-bit
-    frames, prior shifts and cull flags through orc.pyr_build / optical_flow_matching / detect / triangulate
-    (pyramid.jl:81-137, map_manager.jl:451-564 + :579-590, extractor.jl:63-95, mapper.jl:142-183).  Returns (yx, is_3d)."""
-    from slam_jl_amd.triangulation import projection_matrices
-    H, W, e, camt, disparity = wl["H"], wl["W"], wl["extractor"], wl["camt"], wl["disparity"]
-    seq, period = res["seq"], res["period"]
-    u8f = lambda im: np.asfortranarray(np.round(im * 255).astype(np.uint8).astype(np.float64) / 255.0)
-    T21 = np.eye(4); T21[0, 3] = -(disparity * 30.0 / camt[0])
-    P1, P2 = projection_matrices(camt, camt, T21)
-    kp = np.zeros((0, 2)); is3 = np.zeros(0, bool)
-    prev = None
-    for r in rec["steps"]:
-        i = r["i"]
-        f = seq[(i % period) + s]
-        img = u8f(wl["left"][f])
-        cur = orc.pyr_build(img, wl["levels"], 1.0, 1)
-        if len(kp) and r["shift"] is not None:
-            ref = orc.optical_flow_matching(prev, cur, kp, is3, kp + r["shift"][s], (H, W), sum_order=1, threads=threads)
-            keep = ~ref["removed"]
-            kp, is3 = ref["new_pixels"][keep], is3[keep]
-        if r["kf"]:
-            keep = r["cull"][s, :len(kp)] == 0
-            kp, is3 = kp[keep], is3[keep]
-            fresh = orc.detect(img, kp, max_points=e.max_points, radius=e.radius, cell_size=e.cell_size).astype(np.float64)
-            kp = np.concatenate([kp, fresh]); is3 = np.concatenate([is3, np.zeros(len(fresh), bool)])
-            rp = orc.pyr_build(u8f(wl["right"][f]), wl["levels"], 1.0, 1)
-            ref = orc.optical_flow_matching(cur, rp, kp, is3, kp + np.array([0.0, -disparity]), (H, W), stereo=True, undistorted_left=kp,
-                                            right_cam=camt, sum_order=1, threads=threads)
-            keep = ~ref["removed"]
-            kp, is3 = kp[keep], is3[keep]
-            up, syx = ref["updated"][keep], ref["new_pixels"][keep]
-            cand = np.flatnonzero(up & ~is3)
-            if len(cand):
-                _, ok = orc.triangulate(P1, P2, T21, camt, camt, kp[cand], syx[cand], 3.0)
-                is3 = is3.copy(); is3[cand[ok]] = True
-        prev = cur
-    return kp, is3
-
-
-def leg_ctx(slam, local_rank, priority=0):
-    """a context (HIP stream, scratch, pinned block) for one leg; the leg closes it.  (Round 3 kept the lock-stepped legs' contexts for the
-    life of the process because a destroyed capture-origin stream left runtime state behind; the build graphs are now
-    constructed node by node -- no stream capture -- and contexts come and go with the legs.)"""
-    return slam.Context(local_rank, priority=priority) if priority else slam.Context(local_rank)
-
-
-_HIP = None
-
-
-def peek(label):
-    """SLAM_BENCH_PEEK=1: report the calling thread's pending HIP error (hipPeekAtLastError of the runtime torch and the library share)
-    -- to find the call that leaves hipErrorStreamCaptureUnsupported behind for a later torch call to trip over"""
-    global _HIP
-    if os.environ.get("SLAM_BENCH_PEEK") is None:
-        return
-    import ctypes, sys as _s
-    if _HIP is None:
-        import torch as _t
-        libdir = os.path.join(os.path.dirname(_t.__file__), "lib")
-        _HIP = ctypes.CDLL(os.path.join(libdir, "libamdhip64.so"))
-    e = _HIP.hipPeekAtLastError()
-    if e != 0:
-        print(f"[peek] pending HIP error {e} at {label}", file=_s.stderr, flush=True)
-
-
-def kernel_spans(slam, torch, local_rank, wl, dev):
-    fast = bool(wl.get("tolerance"))
-    """Per-kernel device time of the batched build with serial launches (hipEvent spans cannot look inside the graph),
-    and the graph replay alone on the GPU."""
-    S, H, W, params, left = wl["S"], wl["H"], wl["W"], wl["params"], wl["left"]
-    ctx = leg_ctx(slam, local_rank)
-    pb = slam.PyramidBatch((H, W), levels=params.pyramid_levels, S=S, ctx=ctx)
-    seq = frame_sequence_n(len(left), S + 2)
-    t = torch.from_numpy(np.stack([np.ascontiguousarray(np.round(left[seq[k]] * 255).astype(np.uint8).T) for k in range(S)])).to(dev)
-    torch.cuda.synchronize()
-    ptrs = [t.data_ptr() + s * H * W for s in range(S)]
-    peek("kernel_spans: before the first build")
-    pb.update_(ptrs, sync=True, ctx=ctx, u8=True, fast=fast)
-    peek("kernel_spans: after the first build (capture)")
-    ea, eb = slam.Event(ctx, timed=True), slam.Event(ctx, timed=True)
-    ctx.record(ea)
-    for _ in range(20):                                      # the stage alone on the GPU: graph replays back to back
-        pb.update_(ptrs, sync=False, ctx=ctx, u8=True, fast=fast)
-    ctx.record(eb)
-    isolated_us = ea.elapsed_ms(eb) / 20 * 1e3
-    peek("kernel_spans: after the replays")
-    ea.close(); eb.close()
-    ctx.prof_enable(True); ctx.prof_reset()
-    for _ in range(20):
-        pb.update_(ptrs, sync=False, ctx=ctx, u8=True, fast=fast)
-    ctx.synchronize()
-    rows_ms, rows_n = ctx.prof_get("k_iir_rows"); pyr_ms, pyr_n = ctx.prof_get("pyr_update")
-    ctx.prof_enable(False)
-    peek("kernel_spans: after the profiled builds")
-    for p_ in pb.pyramids:
-        p_.close()
-    peek("kernel_spans: after destroying the pyramids")
-    ctx.close()
-    return rows_ms / max(rows_n, 1) * 1e3, pyr_ms / max(pyr_n, 1) * 1e3, isolated_us
+from benchlib.common import (KF_EVERY, RIGHT_TARGET_ONLY, CULL_FRACTION, N_FRAMES, HBM_PEAK_GBS, HBM_ACHIEVABLE_GBS,      # noqa: E402,F401
+                             frame_sequence, frame_sequence_n, pyramid_bytes, iir_rows_bytes)
+from benchlib.backends import Stream, GpuBackend, GpuPeriodBackend, CpuBackend                                           # noqa: E402,F401
+from benchlib.lockstep import run_lockstep, run_lockstep_kpset, kernel_spans, make_workload, WORKLOADS, leg_ctx, peek   # noqa: E402,F401
+from benchlib.checkers import replay_stream_on_oracle                                                                    # noqa: E402
+from benchlib.report import compact_line, write_detail, frame_and_lk_rooflines, newest_pmc                               # noqa: E402
 
 
 def spawn_ranks(args):
@@ -941,130 +81,6 @@ def spawn_ranks(args):
 
 LEGS = ("single", "tolerance", "headline", "tolbatch", "ingest", "sweep", "host_protocol", "configs", "ba", "ba_sharded", "pose", "cpu")
 
-
-def newest_pmc(S):
-    """the newest profiles/r*_pmc_pyramid_batch_s<S>.json (names sort by round + letter), or None"""
-    import glob
-    c = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_pyramid_batch_s{S}.json")))
-    return c[-1] if c else None
-
-
-LK_VISIT_BYTES = lambda w: 3 * (2 * w + 1) ** 2 * 8 + (2 * w + 2) ** 2 * 8 + 12 * 8 + 33     # SURVEY 8d: template + target footprint + 12 corners + point record
-
-
-def frame_and_lk_rooflines(wl, head, frac3d):
-    """SURVEY 8d's whole-step and LK bytes for the headline loop (per stream and key-frame period: KF_EVERY left builds + KF_EVERY temporal
-    matches + 1 detect + 1 right build + 1 stereo match), against the measured step / match span.  Level visits per keypoint follow
-    map_manager.jl:451-564 + tracker.jl:30-66: a 2-D keypoint = 4 forward + 1 backward visit, a 3-D keypoint with a prior = 2 + 1
-    (pyramid_levels_3d = 1); failed 3-D attempts that fall back to the 2-D pass are not counted (a lower bound on the bytes)."""
-    S, H, W, levels, params = wl["S"], wl["H"], wl["W"], wl["levels"], wl["params"]
-    pb = pyramid_bytes(H, W, levels)
-    vb = LK_VISIT_BYTES(params.window_size)
-    kpts = head["tracked_kpts_per_frame"]
-    visits = frac3d * 3 + (1 - frac3d) * 5
-    lk_point = vb * visits
-    K = wl["kpts"]
-    detect_b = 8 * H * W + 16 * K + 16 * K * CULL_FRACTION
-    stereo_b = vb * 5 * K                                     # stereo match: every keypoint as a 2-D keypoint (shift prior, all levels)
-    per_period = KF_EVERY * pb + KF_EVERY * kpts * lk_point + detect_b + (pb if wl["stereo"] else 0) + (stereo_b if wl["stereo"] else 0)
-    step_bytes = S * per_period
-    sec = head["ms_per_step"] * 1e-3
-    fr = {"algorithmic_bytes_per_step": int(step_bytes), "achieved": step_bytes / sec / 1e9, "frac": step_bytes / sec / 1e9 / HBM_PEAK_GBS,
-          "bound_fps_at_peak": S * KF_EVERY / (step_bytes / (HBM_PEAK_GBS * 1e9)), "visits_per_kpt": round(visits, 2), "frac_3d": round(frac3d, 3)}
-    lk = None
-    if head.get("lk_match"):
-        m = head["lk_match"]
-        b = m["points_per_launch"] * lk_point
-        lk = {"kernel": "k_kpset_match", "algorithmic_bytes_per_launch": int(b), "avg_launch_us": m["mean_ms"] * 1e3, "points_per_launch": int(m["points_per_launch"]),
-              "ns_per_point": m["mean_ms"] * 1e6 / max(m["points_per_launch"], 1), "achieved": b / (m["mean_ms"] * 1e-3) / 1e9,
-              "frac": b / (m["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "VALU-issue bound, not HBM (DESIGN 3.3)"}
-    return fr, lk
-
-
-def _r(x, n=4):
-    if isinstance(x, float):
-        return float(f"{x:.{n}g}") if abs(x) < 1 else round(x, 3)
-    return x
-
-
-def compact_line(out):
-    """The ONE stdout line the driver parses: numbers only, < 4 KB (hard limit 8 KB).  Everything else lives in bench_detail.json."""
-    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
-    cfg = out.get("config") or {}
-    c["config"] = {"workload": "KITTI-05-shaped stereo 370x1226 @1000 kpts, KF every 5th frame (BASELINE configs[1]); step = 1 key-frame period of each stream; "
-                               "u8 frames from pinned host memory inside the timed loop; f64 bit-exact",
-                   "streams_per_gpu": cfg.get("streams_per_gpu"), "frames_per_step": cfg.get("frames_per_step"), "parallelism": cfg.get("parallelism"),
-                   "pyramid_mode": out.get("pyramid_mode", "bit-exact")}
-    rf = out.get("roofline")
-    if rf:
-        c["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_isolated", "algorithmic_bytes_per_launch", "avg_launch_us",
-                                                     "isolated_launch_us", "traffic", "traffic_over_algorithmic")}
-        c["roofline"]["stage"] = f"LK pyramid update of {cfg.get('streams_per_gpu')} images, one graph launch"
-        if rf.get("traffic_source"):
-            c["roofline"]["traffic_source"] = rf["traffic_source"].split(" ")[0]
-        for k in ("frame", "lk"):
-            if rf.get(k):
-                c["roofline"][k] = {a: _r(b) for a, b in rf[k].items() if a not in ("note", "kernel")}
-    cb = out.get("cpu_baseline")
-    if cb:
-        c["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:120]}
-        if out.get("value"):
-            c["cpu_baseline"]["gpu_over_cpu"] = _r(out["value"] / cb["value"])
-    ba = out.get("ba")
-    if ba:
-        c["ba"] = {"ms_per_iter": _r(ba.get("ms_per_iter")), "window_kf": 50, "observations": ba.get("observations"),
-                   "windows_ms_per_iter": {k: _r(v["ms_per_iter"]) for k, v in ba.get("windows", {}).items()},
-                   "roofline_frac_P50": _r(ba.get("windows", {}).get("P50", {}).get("roofline", {}).get("frac")),
-                   "cpu_ms_per_iter_schur": _r(ba.get("cpu_ms_per_iter_schur")), "cpu_ms_per_iter_lm_lsmr": _r(ba.get("cpu_ms_per_iter_reference_style_lm_lsmr"))}
-    bs = out.get("ba_sharded")
-    if bs:
-        c["ba_sharded"] = {k: _r(bs.get(k)) for k in ("world_size", "window_kf", "ms_per_iter_wall", "worth_sharding", "error") if bs.get(k) is not None}
-    ss = out.get("single_stream")
-    if ss and "by_builds_in_flight" in ss:
-        c["single_stream"] = {"live": _r(ss["by_builds_in_flight"].get("1")), "lookahead": _r(ss.get("value")), "unit": "frames/sec"}
-        if ss.get("live_graph") is not None:
-            c["single_stream"]["live_graph"] = _r(ss["live_graph"])
-    elif ss:
-        c["single_stream"] = {"error": str(ss.get("error"))[:120]}
-    tm = out.get("tolerance_mode")
-    if tm:
-        c["tolerance_mode"] = {k: _r(v) for k, v in tm.items() if isinstance(v, (int, float, bool))}
-        if isinstance(tm.get("single_stream"), dict):
-            c["tolerance_mode"]["single_stream"] = _r(tm["single_stream"].get("value"))
-        if isinstance(tm.get("batch"), dict):
-            b = tm["batch"]
-            c["tolerance_mode"].update({"value": _r(b.get("value")), "ms_per_step": _r(b.get("ms_per_step")), "planes_rel_tol": 1e-11})
-            c["tolerance_mode"]["roofline"] = {k: _r(b["roofline"].get(k)) for k in ("frac", "frac_isolated", "avg_launch_us", "isolated_launch_us", "traffic", "traffic_over_algorithmic")}
-    if out.get("configs"):
-        c["configs"] = {k: (_r(v.get("value")) if "value" in v else "error") for k, v in out["configs"].items()}
-    if out.get("pose", {}).get("frontend_with_pose"):
-        c["frontend_with_pose"] = _r(out["pose"]["frontend_with_pose"]["value"])
-    pv = out.get("parity_vs_oracle")
-    if pv:
-        c["parity_vs_oracle"] = {"ok": pv["ok"] and not out.get("parity_failures")}
-    if out.get("parity_failures"):
-        c["parity_failures"] = len(out["parity_failures"])
-    c["detail"] = "bench_detail.json"
-    line = json.dumps(c, separators=(",", ":"))
-    if len(line) > 8000:                                          # never lose the line to its own size: drop the optional objects, largest first
-        for k in ("configs", "ba_sharded", "tolerance_mode", "single_stream"):
-            c.pop(k, None)
-        line = json.dumps(c, separators=(",", ":"))
-    assert len(line) <= 8000, len(line)
-    return line
-
-
-def write_detail(out):
-    """the full record (notes, sweeps, per-window objects): next to bench.py, under gpurun_out/ when that exists, and on stderr"""
-    txt = json.dumps(out)
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
-        if os.path.isdir(d):
-            try:
-                with open(os.path.join(d, "bench_detail.json"), "w") as f:
-                    f.write(txt + "\n")
-            except OSError:
-                pass
-    print(txt, file=sys.stderr, flush=True)
 
 
 def ba_windows(syn):
@@ -1768,3 +784,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+

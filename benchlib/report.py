@@ -1,0 +1,135 @@
+"""What bench.py prints: the compact line the driver parses (< 4 KB), the full record beside it, and the SURVEY 8d whole-step / LK rooflines."""
+import json
+import os
+import sys
+
+import numpy as np
+
+from .common import ROOT, KF_EVERY, CULL_FRACTION, HBM_PEAK_GBS, pyramid_bytes
+
+
+def newest_pmc(S):
+    """the newest profiles/r*_pmc_pyramid_batch_s<S>.json (names sort by round + letter), or None"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_pyramid_batch_s{S}.json")))
+    return c[-1] if c else None
+
+
+LK_VISIT_BYTES = lambda w: 3 * (2 * w + 1) ** 2 * 8 + (2 * w + 2) ** 2 * 8 + 12 * 8 + 33     # template + target footprint + 12 corners + point record
+
+
+def frame_and_lk_rooflines(wl, head, frac3d):
+    """SURVEY 8d's whole-step and LK bytes for the headline loop (per stream and key-frame period: KF_EVERY left builds + KF_EVERY temporal
+    matches + 1 detect + 1 right build + 1 stereo match), against the measured step / match span.  Level visits per keypoint follow
+    map_manager.jl:451-564 + tracker.jl:30-66: a 2-D keypoint = 4 forward + 1 backward visit, a 3-D keypoint with a prior = 2 + 1
+    (pyramid_levels_3d = 1); failed 3-D attempts that fall back to the 2-D pass are not counted (a lower bound on the bytes)."""
+    S, H, W, levels, params = wl["S"], wl["H"], wl["W"], wl["levels"], wl["params"]
+    pb = pyramid_bytes(H, W, levels)
+    vb = LK_VISIT_BYTES(params.window_size)
+    kpts = head["tracked_kpts_per_frame"]
+    visits = frac3d * 3 + (1 - frac3d) * 5
+    lk_point = vb * visits
+    K = wl["kpts"]
+    detect_b = 8 * H * W + 16 * K + 16 * K * CULL_FRACTION
+    stereo_b = vb * 5 * K                                     # stereo match: every keypoint as a 2-D keypoint (shift prior, all levels)
+    per_period = KF_EVERY * pb + KF_EVERY * kpts * lk_point + detect_b + (pb if wl["stereo"] else 0) + (stereo_b if wl["stereo"] else 0)
+    step_bytes = S * per_period
+    sec = head["ms_per_step"] * 1e-3
+    fr = {"algorithmic_bytes_per_step": int(step_bytes), "achieved": step_bytes / sec / 1e9, "frac": step_bytes / sec / 1e9 / HBM_PEAK_GBS,
+          "bound_fps_at_peak": S * KF_EVERY / (step_bytes / (HBM_PEAK_GBS * 1e9)), "visits_per_kpt": round(visits, 2), "frac_3d": round(frac3d, 3)}
+    lk = None
+    if head.get("lk_match"):
+        m = head["lk_match"]
+        b = m["points_per_launch"] * lk_point
+        lk = {"kernel": "k_kpset_match", "algorithmic_bytes_per_launch": int(b), "avg_launch_us": m["mean_ms"] * 1e3, "points_per_launch": int(m["points_per_launch"]),
+              "ns_per_point": m["mean_ms"] * 1e6 / max(m["points_per_launch"], 1), "achieved": b / (m["mean_ms"] * 1e-3) / 1e9,
+              "frac": b / (m["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "VALU-issue bound, not HBM (DESIGN 3.3)"}
+    return fr, lk
+
+
+def _r(x, n=4):
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if abs(x) < 1 else round(x, 3)
+    return x
+
+
+def compact_line(out):
+    """The ONE stdout line the driver parses: numbers only, < 4 KB (hard limit 8 KB).  Everything else lives in bench_detail.json."""
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = out.get("config") or {}
+    c["config"] = {"workload": "KITTI-05-shaped stereo 370x1226 @1000 kpts, KF every 5th frame (BASELINE configs[1]); step = 1 key-frame period of each stream; "
+                               "u8 frames from pinned host memory inside the timed loop; f64 bit-exact",
+                   "streams_per_gpu": cfg.get("streams_per_gpu"), "frames_per_step": cfg.get("frames_per_step"), "parallelism": cfg.get("parallelism"),
+                   "pyramid_mode": out.get("pyramid_mode", "bit-exact")}
+    rf = out.get("roofline")
+    if rf:
+        c["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_isolated", "algorithmic_bytes_per_launch", "avg_launch_us",
+                                                     "isolated_launch_us", "traffic", "traffic_over_algorithmic")}
+        c["roofline"]["stage"] = f"LK pyramid update of {cfg.get('streams_per_gpu')} images, one graph launch"
+        if rf.get("traffic_source"):
+            c["roofline"]["traffic_source"] = rf["traffic_source"].split(" ")[0]
+        for k in ("frame", "lk"):
+            if rf.get(k):
+                c["roofline"][k] = {a: _r(b) for a, b in rf[k].items() if a not in ("note", "kernel")}
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:120]}
+        if out.get("value"):
+            c["cpu_baseline"]["gpu_over_cpu"] = _r(out["value"] / cb["value"])
+    ba = out.get("ba")
+    if ba:
+        c["ba"] = {"ms_per_iter": _r(ba.get("ms_per_iter")), "window_kf": 50, "observations": ba.get("observations"),
+                   "windows_ms_per_iter": {k: _r(v["ms_per_iter"]) for k, v in ba.get("windows", {}).items()},
+                   "roofline_frac_P50": _r(ba.get("windows", {}).get("P50", {}).get("roofline", {}).get("frac")),
+                   "cpu_ms_per_iter_schur": _r(ba.get("cpu_ms_per_iter_schur")), "cpu_ms_per_iter_lm_lsmr": _r(ba.get("cpu_ms_per_iter_reference_style_lm_lsmr"))}
+    bs = out.get("ba_sharded")
+    if bs:
+        c["ba_sharded"] = {k: _r(bs.get(k)) for k in ("world_size", "window_kf", "ms_per_iter_wall", "worth_sharding", "error") if bs.get(k) is not None}
+    ss = out.get("single_stream")
+    if ss and "by_builds_in_flight" in ss:
+        c["single_stream"] = {"live": _r(ss["by_builds_in_flight"].get("1")), "lookahead": _r(ss.get("value")), "unit": "frames/sec"}
+        if ss.get("live_graph") is not None:
+            c["single_stream"]["live_graph"] = _r(ss["live_graph"])
+    elif ss:
+        c["single_stream"] = {"error": str(ss.get("error"))[:120]}
+    tm = out.get("tolerance_mode")
+    if tm:
+        c["tolerance_mode"] = {k: _r(v) for k, v in tm.items() if isinstance(v, (int, float, bool))}
+        if isinstance(tm.get("single_stream"), dict):
+            c["tolerance_mode"]["single_stream"] = _r(tm["single_stream"].get("value"))
+        if isinstance(tm.get("batch"), dict):
+            b = tm["batch"]
+            c["tolerance_mode"].update({"value": _r(b.get("value")), "ms_per_step": _r(b.get("ms_per_step")), "planes_rel_tol": 1e-11})
+            c["tolerance_mode"]["roofline"] = {k: _r(b["roofline"].get(k)) for k in ("frac", "frac_isolated", "avg_launch_us", "isolated_launch_us", "traffic", "traffic_over_algorithmic")}
+    if out.get("configs"):
+        c["configs"] = {k: (_r(v.get("value")) if "value" in v else "error") for k, v in out["configs"].items()}
+    if out.get("pose", {}).get("frontend_with_pose"):
+        c["frontend_with_pose"] = _r(out["pose"]["frontend_with_pose"]["value"])
+    pv = out.get("parity_vs_oracle")
+    if pv:
+        c["parity_vs_oracle"] = {"ok": pv["ok"] and not out.get("parity_failures")}
+    if out.get("parity_failures"):
+        c["parity_failures"] = len(out["parity_failures"])
+    c["detail"] = "bench_detail.json"
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) > 8000:                                          # never lose the line to its own size: drop the optional objects, largest first
+        for k in ("configs", "ba_sharded", "tolerance_mode", "single_stream"):
+            c.pop(k, None)
+        line = json.dumps(c, separators=(",", ":"))
+    assert len(line) <= 8000, len(line)
+    return line
+
+
+def write_detail(out):
+    """the full record (notes, sweeps, per-window objects): next to bench.py, under gpurun_out/ when that exists, and on stderr"""
+    txt = json.dumps(out)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(txt + "\n")
+            except OSError:
+                pass
+    print(txt, file=sys.stderr, flush=True)
+
+

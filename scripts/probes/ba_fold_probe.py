@@ -1,7 +1,7 @@
 """Does relabelling the poses of a loop-closure window (fold ordering 0, P-1, 1, P-2, ...) bring it into the banded solver's range, and what
 does an LM iteration cost then?  python scripts/ba_fold_probe.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

@@ -1,6 +1,6 @@
 """Host / device split of slam_local_ba per window: SLAMHIP_BA_HOSTTIME=1 python scripts/ba_hosttime.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

@@ -1,5 +1,5 @@
 """Determinism / hand-over stress of the twisted banded solve: the same window solved N times must give bit-identical parameters."""
-import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

@@ -1,6 +1,6 @@
 """Phase breakdown of the batched LK kernel (needs slam.jl_amd/libslamhip_trace.so built with -DLK_TRACE)."""
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import slam_jl_amd._lib as L
 L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libslamhip_trace.so")
 sys.argv = [sys.argv[0]] + sys.argv[1:]

@@ -1,5 +1,5 @@
 """The general solver path alone (26 poses, 24 observers per point: no banded order; for rocprofv3 --kernel-trace --stats)"""
-import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

@@ -1,5 +1,5 @@
 """The reference-shaped window alone (25 poses, 20 constant; for rocprofv3 --kernel-trace --stats): python scripts/prof_ba_p5.py"""
-import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

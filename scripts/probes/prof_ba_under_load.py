@@ -1,7 +1,7 @@
 """Local BA (50-KF window) alone vs while the lock-stepped front-end loop runs on the same GPU (the estimator thread beside the front-end,
 estimator.jl:308-355): python scripts/prof_ba_under_load.py"""
 import os, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

@@ -1,5 +1,5 @@
 import sys, time
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

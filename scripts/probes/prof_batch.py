@@ -1,7 +1,7 @@
 """Breakdown of the lock-step batched step: python scripts/prof_batch.py [S] [fast]
 (run under rocprofv3 --kernel-trace --stats for per-kernel numbers)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import bench

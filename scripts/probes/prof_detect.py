@@ -1,6 +1,6 @@
 """Batched detect alone: python scripts/prof_detect.py [S]  (with / without current keypoints = with / without the avoidance mask)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 
 import slam_jl_amd as slam

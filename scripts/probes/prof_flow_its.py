@@ -1,7 +1,7 @@
 """Batched LK with a fixed iteration cap only (for rocprofv3 --pmc: instruction counts of set-up vs iterations):
 python3 scripts/prof_flow_its.py S its [noise_px]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

@@ -1,6 +1,6 @@
 """P3P / five-point RANSAC entry points only (for rocprofv3 --kernel-trace): python3 scripts/prof_pose.py [n] [tuples]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

@@ -1,7 +1,7 @@
 """slam_kpset_compute_pose_5pt (five-point RANSAC on device-resident lists with key-frame observations, 32 scenes), wall clock:
 python scripts/prof_pose_5pt.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

@@ -1,7 +1,7 @@
 """slam_kpset_compute_pose (P3P RANSAC + PnP refinement on device-resident lists, 32 scenes) and the single-stream seams, wall clock:
 python scripts/prof_pose_kpset.py   (A/B another build with SLAMHIP_LIB=...; under rocprofv3 --kernel-trace --stats for the kernel table)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

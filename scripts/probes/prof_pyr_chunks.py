@@ -1,7 +1,7 @@
 """Does chunking the 64-image build help (intermediates of a chunk re-read while still in the 256 MB Infinity Cache)?
 python scripts/prof_pyr_chunks.py : one S=64 batch vs C chunks of 64/C images on K contexts, 8-bit frames, graph replays."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

@@ -1,6 +1,6 @@
 """Two half batches on two streams vs one batch: python scripts/prof_pyr_split.py [S] [parts]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import bench

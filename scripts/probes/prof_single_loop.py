@@ -1,6 +1,6 @@
 """Where a single-stream frame's wall time goes (bench.GpuBackend / Stream, builds_in_flight = 3): python scripts/prof_single_loop.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

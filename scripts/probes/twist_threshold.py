@@ -1,6 +1,6 @@
 """ms per LM iteration around the twisted solve's threshold (hb = 9): python scripts/twist_threshold.py   [SLAMHIP_TWIST_MIN=17 for the lower one]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import slam_jl_amd as slam
 from slam_jl_amd import synthetic as syn

@@ -28,7 +28,7 @@ struct LKArgs {
     uint8_t *status;
 };
 
-// -DLK_TRACE: per-phase tick totals (100 MHz wall clock, summed over waves) for scripts/lk_trace.py; off in the product build
+// -DLK_TRACE: per-phase tick totals (100 MHz wall clock, summed over waves) for scripts/probes/lk_trace.py; off in the product build
 #ifdef LK_TRACE
 __device__ unsigned long long g_lk_ticks[8];
 #define LKT_BEGIN unsigned long long _t0 = wall_clock64()

@@ -167,7 +167,7 @@ def test_ba_twisted_factorisation_split_sizes(slam, orc, syn):
 
 def test_ba_two_workgroup_solve_is_deterministic(slam, syn):
     """The two sides of the twisted factorisation hand data over through global memory (release / acquire flags carrying the launch
-    epoch): the same window solved repeatedly must give bit-identical parameters, outliers and cost (scripts/ba_repeat.py runs more)."""
+    epoch): the same window solved repeatedly must give bit-identical parameters, outliers and cost (scripts/probes/ba_repeat.py runs more)."""
     s = syn.ba_scene(P=40, M=3000, seed=3)
     ref = None
     for _ in range(40):
