@@ -129,7 +129,10 @@ class ReplaySaver:
         f32 = _datatype(["Core", "Float32"])
         pos_doc = {"positions": {"tag": "array", "type": _datatype(["GeometryBasics", "Point"], [3, f32]),
                                  "size": [_I64(len(P))], "data": P.tobytes()}}
-        keys = list(self.ids)                                    # insertion order = first-seen order of the frame ids
+        # insertion order = first-seen order of the frame ids.  Julia's Dict is serialised in HASH-SLOT order (BSON.jl lowers the struct's
+        # keys / vals arrays as they sit in the table), so a Julia-written ids.bson holds the same (key, value) pairs in another order:
+        # parity of ids.bson is SEMANTIC (load! rebuilds the Dict either way), not byte-level; positions.bson is byte-level.
+        keys = list(self.ids)
         i64 = _datatype(["Core", "Int64"])
         vec = lambda a: {"tag": "array", "type": i64, "size": [_I64(len(a))], "data": np.asarray(a, dtype="<i8").tobytes()}
         ids_doc = {"ids": {"tag": "struct", "type": _datatype(["Base", "Dict"], [i64, i64]),

@@ -62,6 +62,25 @@ out["prim_iir_sigma1_NA"] = raw(imfilter(img0, (kern1, kern1), NA()))
 out["prim_imresize_half"] = raw(imresize(img0, (cld(H, 2), cld(W, 2))))
 gy, gx = imgradients(img0, KernelFactors.scharr, "replicate")
 out["prim_scharr_y"] = raw(gy); out["prim_scharr_x"] = raw(gx)
+# (round 4) the primitives a first run needs to LOCALISE an Appendix-A error -- each is one upstream call on a small input:
+#  * the constructor's gradient border (pyramid.jl:51,59: Fill(0)) beside update!'s replicate border above
+gy0, gx0 = imgradients(img0, KernelFactors.scharr, Fill(zero(eltype(img0))))
+out["prim_scharr_fill0_y"] = raw(gy0); out["prim_scharr_fill0_x"] = raw(gx0)
+#  * shi_tomasi's 3 x 3 box mean ALONE (Images 0.24 corner.jl: imfilter(cxx, centered(ones(3, 3) ./ 9)) -- dense, or SVD-factored into two
+#    passes by ImageFiltering: the oracle applies 1/3 (x) 1/3 separably; a 1-ulp difference here flips strict maxima and keypoint indices)
+cell11 = @view(img0[1:cell, 1:cell])
+sgx, sgy = imgradients(cell11, KernelFactors.sobel, "replicate")
+out["prim_sobel_y_cell11"] = raw(sgy); out["prim_sobel_x_cell11"] = raw(sgx)
+out["prim_box3_of_gy2_cell11"] = raw(imfilter(sgy .* sgy, centered(ones(3, 3) ./ 9)))
+#  * findlocalmaxima of the cell response (strict 8-neighbour maxima, edges included, column-major order) and the stable descending order
+resp11 = shi_tomasi(cell11)
+mx = findlocalmaxima(resp11)
+out["prim_localmaxima_cell11"] = isempty(mx) ? zeros(Int64, 0, 2) : permutedims(hcat([[k[1], k[2]] for k in mx]...))
+ord = sortperm([resp11[k] for k in mx]; lt = (x, y) -> x > y)
+out["prim_localmaxima_order_cell11"] = Int64.(ord)
+#  * Images.boxdiff on an integral image (lucas_kanade.jl:143-145), windows touching the first row / column (the index-0 rule) and interior
+ii = integral_image(raw(img0))
+out["prim_boxdiff"] = Float64[boxdiff(ii, 1:5, 1:7), boxdiff(ii, 3:21, 1:19), boxdiff(ii, 1:19, 4:22), boxdiff(ii, 10:28, 15:33), boxdiff(ii, (H - 18):H, (W - 18):W)]
 
 # ---- fb_tracking! (src/tracker.jl:70-82) with the arguments optical_flow_matching! passes (map_manager.jl:549-552)
 kps = [SLAM.Point2f(Float64(out["kp_nomask"][i, 1]), Float64(out["kp_nomask"][i, 2])) for i in 1:size(out["kp_nomask"], 1)]

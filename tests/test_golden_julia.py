@@ -34,6 +34,28 @@ def test_oracle_matches_julia(orc):
     assert np.allclose(orc.iir_gaussian(img0, 1.0, border=0), J["prim_iir_sigma1_replicate"], rtol=0, atol=1e-14)
     assert np.allclose(orc.iir_gaussian(img0, 4.0, border=0), J["prim_iir_sigma4_replicate"], rtol=0, atol=1e-14)
     assert np.allclose(orc.imresize(img0, -(-H // 2), -(-W // 2)), J["prim_imresize_half"], rtol=0, atol=1e-15)
+    if "prim_box3_of_gy2_cell11" in J.files:                       # round-4 generator: the pieces behind shi_tomasi / findlocalmaxima / boxdiff
+        c11 = img0[:35, :35]
+        sob_d, sob_s = np.array([-1.0, 0.0, 1.0]) / 2, np.array([1.0, 2.0, 1.0]) / 4
+        gy = orc.imfilter_sep(c11, sob_d, sob_s)                   # derivative along dim 1, smoothing along dim 2
+        assert np.allclose(gy, J["prim_sobel_y_cell11"], rtol=0, atol=1e-15)
+        assert np.allclose(orc.imfilter_sep(c11, sob_s, sob_d), J["prim_sobel_x_cell11"], rtol=0, atol=1e-15)
+        third = np.full(3, 1.0 / 3)
+        assert np.array_equal(orc.imfilter_sep(gy * gy, third, third), J["prim_box3_of_gy2_cell11"]), "the 3 x 3 box mean is not the separable 1/3 (x) 1/3: keypoint indices can differ"
+        resp = orc.shi_tomasi(c11)
+        pad = np.pad(resp, 1, constant_values=-np.inf)
+        nb = np.stack([pad[1 + dy:36 + dy, 1 + dx:36 + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dy, dx) != (0, 0)])
+        mx = np.argwhere((resp[None] > nb).all(0).T)[:, ::-1] + 1    # column-major order, 1-based (row, col)
+        assert np.array_equal(mx, J["prim_localmaxima_cell11"])
+        vals = resp[mx[:, 0] - 1, mx[:, 1] - 1]
+        assert np.array_equal(np.argsort(-vals, kind="stable") + 1, J["prim_localmaxima_order_cell11"])
+        sch_d, sch_s = np.array([-1.0, 0.0, 1.0]) / 2, np.array([3.0, 10.0, 3.0]) / 16
+        assert np.allclose(orc.imfilter_sep(img0, sch_d, sch_s, border=1), J["prim_scharr_fill0_y"], rtol=0, atol=1e-15)
+        assert np.allclose(orc.imfilter_sep(img0, sch_s, sch_d, border=1), J["prim_scharr_fill0_x"], rtol=0, atol=1e-15)
+        ii = np.cumsum(np.cumsum(img0, axis=0), axis=1)
+        bd = lambda y1, y2, x1, x2: ii[y2 - 1, x2 - 1] - (ii[y2 - 1, x1 - 2] if x1 > 1 else 0.0) - (ii[y1 - 2, x2 - 1] if y1 > 1 else 0.0) + (ii[y1 - 2, x1 - 2] if (y1 > 1 and x1 > 1) else 0.0)
+        want = [bd(1, 5, 1, 7), bd(3, 21, 1, 19), bd(1, 19, 4, 22), bd(10, 28, 15, 33), bd(H - 18, H, W - 18, W)]
+        assert np.allclose(want, J["prim_boxdiff"], rtol=1e-13, atol=0)
     # seams
     assert np.array_equal(orc.detect(img0, np.zeros((0, 2)), max_points=60), J["kp_nomask"])
     assert np.array_equal(orc.detect(img0, G["cur"], max_points=60), J["kp_mask"])

@@ -83,3 +83,33 @@ def test_files_written_by_julia_when_present(slam_host):
         if sv._dec_doc(open(os.path.join(d, "ids.bson"), "rb").read())["ids"]["data"][0].get("data") == sv._dec_doc(open(os.path.join(tmp, "ids.bson"), "rb").read())["ids"]["data"][0]["data"]:
             assert open(os.path.join(tmp, "ids.bson"), "rb").read() == open(os.path.join(d, "ids.bson"), "rb").read()
         assert open(os.path.join(tmp, "positions.bson"), "rb").read() == open(os.path.join(d, "positions.bson"), "rb").read()
+
+
+def test_container_level_against_an_independent_bson_implementation(slam_host, tmp_path):
+    """The BSON CONTAINER saver.py writes (document sizes, element type bytes, cstring keys, int32 / int64 / binary / array encodings) is
+    decoded by the `bson` package of the image (pymongo's codec, written independently of this repository) and gives back the same
+    values our own decoder reads; a document encoded by that package loads through our decoder.  What stays unpinned is BSON.jl's
+    LOWERING of the two Julia values (the "tag" / "type" / "size" conventions), not the byte format."""
+    bson = pytest.importorskip("bson")
+    from slam_jl_amd import saver as sv
+    s = slam_host.ReplaySaver(); _fill(s)
+    d = str(tmp_path / "replay"); s.save(d)
+    for name in ("positions.bson", "ids.bson"):
+        raw = open(os.path.join(d, name), "rb").read()
+        theirs = bson.decode(raw) if hasattr(bson, "decode") else bson.BSON(raw).decode()
+        ours = sv._dec_doc(raw)
+
+        def same(a, b):
+            if isinstance(a, dict):
+                return isinstance(b, dict) and list(a) == list(b) and all(same(a[k], b[k]) for k in a)
+            if isinstance(a, (list, tuple)):
+                return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+            if isinstance(a, (bytes, bytearray)) or isinstance(b, (bytes, bytearray)):
+                return bytes(a) == bytes(b)
+            return int(a) == int(b) if isinstance(a, (int, np.integer)) or hasattr(a, "__int__") and not isinstance(a, float) else a == b
+        assert same(ours, theirs), name
+    # and the other way round: a document their encoder writes, read by ours
+    enc = bson.encode if hasattr(bson, "encode") else bson.BSON.encode
+    doc = {"k": {"tag": "array", "size": [bson.Int64(2)], "data": bson.Binary(np.arange(2, dtype="<i8").tobytes())}, "n": 5}
+    back = sv._dec_doc(bytes(enc(doc)))
+    assert back["n"] == 5 and back["k"]["tag"] == "array" and int(back["k"]["size"][0]) == 2 and bytes(back["k"]["data"]) == np.arange(2, dtype="<i8").tobytes()
