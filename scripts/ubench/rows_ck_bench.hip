@@ -45,7 +45,7 @@ int main(int argc, char **argv)
             float best = 1e9;
             for (int rep = 0; rep < 4; rep++) {
                 hipEventRecord(a);
-                hipLaunchKernelGGL(k_cols_fused<false>, dim3(ntx, 1, Sv), dim3(256), 0, 0, A, cf, ck2);
+                hipLaunchKernelGGL((k_cols_fused<false, false>), dim3(ntx, 1, Sv), dim3(256), 0, 0, A, cf, ck2);
                 hipEventRecord(b); hipEventSynchronize(b);
                 float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
             }

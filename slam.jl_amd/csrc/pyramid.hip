@@ -692,6 +692,9 @@ struct ColsFusedArgs {
     // E[y] = sum_{i > y} v[i] (formed bottom-up, the order the backward sweep emits the rows), and the column totals go to
     // tot[(z * 3 + role - 1) * tot_stride + x]; the row kernel k_rows_tol takes C1[y] = tot - E[y] = cumsum along dim 1
     double *tot; int tot_stride;
+    // tolerance build, even H with P % 32 == 0: the dim-1-blurred layer leaves HALVED along y -- Th[k] = (v[2k] + v[2k+1]) / 2, column pitch
+    // P / 2 -- the dim-1 half of imresize! (a blur along x and an average along y commute); the row kernel finishes it
+    int dec;
 };
 
 // neighbour lanes of the whole wave through DPP (wave_shr:1 / wave_shl:1 of the GFX9 family): lane i receives lane i-1 / i+1,
@@ -773,7 +776,7 @@ __device__ int cf4_exp;
 #endif
 #define CF4_LS 38
 #define CF4_GS 34
-#define CF4_LDS_DOUBLES (64 * CF4_LS + 3 * 64 * CF4_GS)
+#define CF4_LDS_DOUBLES (64 * CF4_LS + 3 * 64 * CF4_GS + 3 * 64)      // + the blur wave's three trailing rows (tolerance build, halved layer)
 
 // phase 2: wave w forms Iy, Ix of rows rb + 8w .. rb + 8w + 7 for the 64 columns (lane = column) from the shared layer block
 __device__ __forceinline__ void cf4_scharr8(const double *LB, double *IYB, double *IXB, int w, int rb, int H, bool edgeL, bool edgeR)
@@ -806,7 +809,7 @@ __device__ __forceinline__ void cf4_scharr8(const double *LB, double *IYB, doubl
     for (int j = 0; j < 4; j++) { *(double2 *)(py + 2 * j) = make_double2(iy8[2 * j], iy8[2 * j + 1]); *(double2 *)(px + 2 * j) = make_double2(ix8[2 * j], ix8[2 * j + 1]); }
 }
 
-template <int ROLE, bool TOL>
+template <int ROLE, bool TOL, bool DEC>
 __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const IIRCoef &k, double *ck, double *LB, double *IYB, double *IXB, double *QB, const double *lut)
 {
     const int lane = threadIdx.x & 63, rp = lane & 7, cg = lane >> 3;
@@ -1000,8 +1003,11 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     prefetch(NBk - 1);
     if (active) load_ck(NBk - 1);
     constexpr bool SFX = TOL && ROLE != 0;                        // this wave's outputs leave as exclusive suffix sums (see ColsFusedArgs::tot)
+    constexpr bool dec = TOL && DEC && ROLE == 0;                 // the blurred layer leaves halved along y (ColsFusedArgs::dec; a compile-time variant: the plain store path is not in this instantiation)
     double sfx = 0.0;
-    if (active && !SFX) { io.st(n - 1, vA * scale); io.st(n - 2, vB * scale); io.st(n - 3, vC * scale); }
+    if (active && !SFX && !dec) { io.st(n - 1, vA * scale); io.st(n - 2, vB * scale); io.st(n - 3, vC * scale); }
+    double *tailv = QB + 64 * CF4_GS + 3 * lane;                  // (dec) rows n-1, n-2, n-3 wait here for their block: not in registers across the loop
+    if (active && dec) { tailv[0] = vA * scale; tailv[1] = vB * scale; tailv[2] = vC * scale; }
     if (active && SFX) { io.st(n - 1, sfx); sfx = sfx + vA * scale; io.st(n - 2, sfx); sfx = sfx + vB * scale; io.st(n - 3, sfx); sfx = sfx + vC * scale; }
     for (int b = NBk - 1; b >= 0; b--) {
         const int rb = b << 5, lo = rb > 3 ? rb : 3, hi = rb + 31 < n - 4 ? rb + 31 : n - 4;     // recurrence rows of the block (may be empty: lo > hi)
@@ -1033,8 +1039,9 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
         if (!CFX(5)) lds_barrier();                                            // inputs consumed: the shared blocks become output staging
         double f1 = f1n, f2 = f2n, f3 = f3n;
         if (b > 0) { prefetch(b - 1); if (active) load_ck(b - 1); }
-        if (!active || lo > hi) continue;                         // (a trailing block may hold rows n-3 .. n-1 only)
+        if (!active || (lo > hi && !dec)) continue;               // (a trailing block may hold rows n-3 .. n-1 only)
         if (CFX(1)) { v1 += f1 + x[0]; }
+        else if (lo > hi) {}
         else if (lo == rb && hi == rb + 31) {
 #pragma unroll
             for (int e = 0; e < 32; e++) { const double tt = ((x[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = tt; x[e] = tt; }
@@ -1048,6 +1055,36 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
             for (int e = 31; e >= 0; e--) { const int row = rb + e; if (row >= lo && row <= hi) { const double tt = ((x[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt;
                                                                                              if (SFX) { x[e] = sfx; sfx = sfx + tt * scale; } else x[e] = tt * scale; } }
         }
+        if (dec) {
+            // the block's 32 rows go to the staging block as in the plain path; the three rows below the recurrence and (block 0) the three
+            // above it -- which the plain path stores one by one -- are patched in there (LDS takes a run-time index, registers do not);
+            // then row pairs are averaged in place and the 16 half-height rows leave as one tile
+            double *q = stage + lane * CF4_GS;
+#pragma unroll
+            for (int j = 0; j < 16; j++) *(double2 *)(q + 2 * j) = make_double2(x[2 * j], x[2 * j + 1]);
+            if (rb + 31 >= n - 3) {
+                if (n - 1 >= rb) q[n - 1 - rb] = tailv[0];
+                if (n - 2 >= rb) q[n - 2 - rb] = tailv[1];
+                if (n - 3 >= rb) q[n - 3 - rb] = tailv[2];
+            }
+            if (b == 0) {
+                double tt = ((o2 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; q[2] = tt * scale;
+                tt = ((o1 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; q[1] = tt * scale;
+                tt = ((o0 + a1 * v1) + a2 * v2) + a3 * v3; q[0] = tt * scale;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {                         // in place: pair j writes q[2j], q[2j+1] < the next pair's reads q[4j+4 ..]
+                const double2 a = *(const double2 *)(q + 4 * j), c = *(const double2 *)(q + 4 * j + 2);
+                *(double2 *)(q + 2 * j) = make_double2(0.5 * a.x + 0.5 * a.y, 0.5 * c.x + 0.5 * c.y);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            get_tile(stage, 0, u);
+            const int rbh = rb >> 1, hih = (H >> 1) - 1;
+            ColIO<2> iod = io; iod.P = P >> 1; iod.H = H >> 1;    // the half-height plane Th (same memory as T)
+            if (!CFX(0)) iod.tile_store(rbh, u, rbh, hih, rbh + 15 > hih);
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         {   // outputs -> own staging block (lane = column), back in tile layout, stored as aligned lines
             double *q = stage + lane * CF4_GS;
 #pragma unroll
@@ -1059,7 +1096,7 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (active && !SFX) {   // rows 2, 1, 0: forward values o2, o1, o0
+    if (active && !SFX && !dec) {   // rows 2, 1, 0: forward values o2, o1, o0
         double tt = ((o2 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(2, tt * scale);
         tt = ((o1 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(1, tt * scale);
         tt = ((o0 + a1 * v1) + a2 * v2) + a3 * v3; io.st(0, tt * scale);
@@ -1072,7 +1109,7 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     }
 }
 
-template <bool TOL>
+template <bool TOL, bool DEC = false>
 __global__ __launch_bounds__(256, 2) void k_cols_fused(ColsFusedArgs A, IIRPair cf, double *ck)
 {
     __shared__ __attribute__((aligned(16))) double sh[CF4_LDS_DOUBLES];
@@ -1080,10 +1117,10 @@ __global__ __launch_bounds__(256, 2) void k_cols_fused(ColsFusedArgs A, IIRPair 
     double *LB = sh, *IYB = sh + 64 * CF4_LS, *IXB = IYB + 64 * CF4_GS, *QB = IXB + 64 * CF4_GS;
     if (A.src_kind == 2) { lut[threadIdx.x] = (double)threadIdx.x / 255.0; __syncthreads(); }
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (w == 0) cols_fused_wave<0, TOL>(A, cf.c[0], ck, LB, IYB, IXB, QB, lut);
-    else if (w == 1) cols_fused_wave<1, TOL>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
-    else if (w == 2) cols_fused_wave<2, TOL>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
-    else cols_fused_wave<3, TOL>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
+    if (w == 0) cols_fused_wave<0, TOL, DEC>(A, cf.c[0], ck, LB, IYB, IXB, QB, lut);
+    else if (w == 1) cols_fused_wave<1, TOL, DEC>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
+    else if (w == 2) cols_fused_wave<2, TOL, DEC>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
+    else cols_fused_wave<3, TOL, DEC>(A, cf.c[1], ck, LB, IYB, IXB, QB, lut);
 }
 
 // integral_image!, lucas_kanade.jl:131-138: cumsum along dim 1 ...
@@ -1439,6 +1476,7 @@ struct RowsTolArgs {
     size_t zs;
     const double *tot; int tot_stride;
     RowResize rz;           // kind 0: next level's layer if rz.dst
+    int dec;                // kind 0: the plane is the half-height Th of k_cols_fused<TOL> (H / 2 rows, pitch P / 2): no row pairing left to do
     int dbg;                // SLAMHIP_RT_DBG (timing experiments only): 1 = loads + stores without the arithmetic (invalid planes)
 };
 // (this kernel is tolerance mode by definition: its multiply-adds are fused -- half the f64 instructions of the -ffp-contract=off form)
@@ -1506,11 +1544,14 @@ __global__ __launch_bounds__(R * NS, (R * NS >= 1024 ? 4 : 4)) void k_rows_tol(R
     }
     const int t = threadIdx.x, l = t % LPW, g = t / LPW, pl = blockIdx.y;
     const int n = W;
+    const int kind = PS_PICK(A, kind, pl), cs = PS_PICK(A, coef, pl);
+    const bool hd = kind == 0 && A.dec != 0;               // the half-height blurred layer
+    if (hd) { H >>= 1; P >>= 1; }
+    if (bx * LPW >= H) return;                             // (the grid covers the full-height planes)
     const int y = bx * LPW + l;
     const bool valid = y < H;
     const int yc = valid ? y : H - 1;                      // idle lanes shadow the last row (reads only)
     double *plane = PS_PICK(A, p, pl) + (size_t)blockIdx.z * A.zs;
-    const int kind = PS_PICK(A, kind, pl), cs = PS_PICK(A, coef, pl);
     const IIRCoef &k = cf.c[cs];
     const double a1 = k.a1, a2 = k.a2, a3 = k.a3, scale = k.scale;
     const int nseg = (n + SL - 1) / SL, pad = nseg * SL - n;
@@ -1652,8 +1693,8 @@ __global__ __launch_bounds__(R * NS, (R * NS >= 1024 ? 4 : 4)) void k_rows_tol(R
     if (xo < 1) xo = 1;
     while (xo > 1 && (int)floor(sx * (xo - 1) + ox) >= b0 + 1) xo--;
     while (xo <= Wd && (int)floor(sx * xo + ox) < b0 + 1) xo++;
-    double *dbase = A.rz.dst + (size_t)blockIdx.z * A.zs + (size_t)(y >> 1);
-    const bool writer = valid && (l & 1) == 0 && (y >> 1) < Hd;
+    double *dbase = A.rz.dst + (size_t)blockIdx.z * A.zs + (size_t)(hd ? y : y >> 1);
+    const bool writer = hd ? (valid && y < Hd) : (valid && (l & 1) == 0 && (y >> 1) < Hd);
 #pragma unroll
     for (int j = 0; j < SL; j++) {                         // (the conditions are uniform over the 16 rows of a segment: the DPP pairs stay together)
         const double c = sx * xo + ox;
@@ -1666,7 +1707,7 @@ __global__ __launch_bounds__(R * NS, (R * NS >= 1024 ? 4 : 4)) void k_rows_tol(R
             const double h = (1 - fx) * x[j] + fx * bb;
             const double hn = dpp_pair_next(h);            // lanes 2k, 2k+1 <- lane 2k+1
             const double fy = 0.5;                          // r = 2 y' - 0.5: exact
-            if (writer) dbase[(size_t)(xo - 1) * A.rz.Pd] = (1 - fy) * h + fy * hn;
+            if (writer) dbase[(size_t)(xo - 1) * A.rz.Pd] = hd ? h : (1 - fy) * h + fy * hn;
             xo++;
         }
     }
@@ -1983,8 +2024,11 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             size_t toff = 0;
             for (int q = 0; q < l; q++) toff += (size_t)3 * S * p->W[q];
             ca.tot = tolb ? p->alloc->tot + toff : nullptr; ca.tot_stride = W;
-            if (tolb) B.launch(k_cols_fused<true>, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, LN_MAIN, ca, cf, p->ck);
-            else B.launch(k_cols_fused<false>, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, LN_MAIN, ca, cf, p->ck);
+            static const bool no_dec = getenv("SLAMHIP_NO_TOL_DEC") != nullptr;
+            ca.dec = (tolb && has_next && (H & 1) == 0 && (P & 31) == 0 && !no_dec) ? 1 : 0;
+            if (tolb && ca.dec) B.launch(k_cols_fused<true, true>, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, LN_MAIN, ca, cf, p->ck);
+            else if (tolb) B.launch(k_cols_fused<true, false>, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, LN_MAIN, ca, cf, p->ck);
+            else B.launch(k_cols_fused<false, false>, dim3((W + CF4_COLS - 1) / CF4_COLS, 1, S), dim3(256), 0, LN_MAIN, ca, cf, p->ck);
             if (tolb) {
                 RowsTolArgs ra = {};
                 int nr = 0;
@@ -1995,6 +2039,7 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
                 ra.p[nr] = v.Iyx; ra.coef[nr] = 1; ra.kind[nr] = 1; nr++;
                 ra.n = nr; ra.zs = zs; ra.tot = ca.tot; ra.tot_stride = W;
                 const bool rzf = has_next && (H & 1) == 0;
+                ra.dec = ca.dec;
                 if (rzf) { ra.rz.dst = p->view.lv[l + 1].L; ra.rz.Hd = p->H[l + 1]; ra.rz.Wd = p->W[l + 1]; ra.rz.Pd = p->P[l + 1]; }
                 SegPow spr; rt_seg_pow(cf, slr_t, spr);
                 static const int rt_dbg = getenv("SLAMHIP_RT_DBG") ? atoi(getenv("SLAMHIP_RT_DBG")) : 0; ra.dbg = rt_dbg;
