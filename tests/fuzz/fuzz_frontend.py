@@ -2,6 +2,7 @@
   pyr     single-image pyramids, random H x W (4 .. 300), levels, sigma, both ctor modes
   batch   batched pyramids with the bandwidth-bound kernel set FORCED on small shapes (SLAMHIP_CK_MIN_MB=0: k_cols_fused, k_iir_rows_ck
           with the fused resize, k_cum_fused), f64 / u8 ingest, target-only builds, S = 1 .. 6
+  tolbatch the tolerance-mode batch build (mode 3, S = 4 .. 10) forced onto small random shapes: planes <= 1e-11 relative to the oracle's exact build
   lk      fb_tracking with random window sizes (2 .. 14: the three cached instantiations and the uncached path), levels, priors, points on and near the borders
   detect  random shapes, cell sizes, current keypoints (none / few / many / clustered), mask sigma
   brief   describe with random shapes and keypoints on / next to the borders (dropped ones included)
@@ -15,7 +16,7 @@ from oracle import oracle as orc
 PLANES = ("layers", "Iy", "Ix", "Iyy", "Ixx", "Iyx")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-parts = sys.argv[3].split(",") if len(sys.argv) > 3 else ["pyr", "batch", "lk", "detect", "brief"]
+parts = sys.argv[3].split(",") if len(sys.argv) > 3 else ["pyr", "batch", "tolbatch", "lk", "detect", "brief"]
 fails = 0
 
 
@@ -87,6 +88,41 @@ if "batch" in parts:
             os.environ.pop("SLAMHIP_CK_MIN_MB", None)
             fail(f"{tag}: {repr(ex)[:200]}")
     print("batch done", flush=True)
+
+if "tolbatch" in parts:
+    # the tolerance-mode batch build (mode 3, S >= 4: k_cols_fused<TOL[, DEC]> + k_rows_tol) forced onto small random shapes: every plane within
+    # 1e-11 of the oracle's exact build relative to the plane's magnitude (heights >= 64 reach the fused kernels; odd / even heights and pitches
+    # select the halved or the full blur plane; widths select the samples per thread of the row kernel)
+    for t in range(n):
+        rng = np.random.default_rng(50000 + seed0 + t)
+        H, W = int(rng.integers(64, 330)), int(rng.integers(12, 520))
+        levels = int(rng.integers(0, max_levels(H, W) + 1)); S = int(rng.integers(4, 11)); u8 = bool(rng.integers(0, 2)); tgt = bool(rng.integers(0, 3) == 0)
+        imgs = [rand_image(rng, H, W) for _ in range(S)]
+        if u8:
+            raw = [np.round(im * 255).astype(np.uint8) for im in imgs]
+            imgs = [np.asfortranarray(r.astype(np.float64) / 255.0) for r in raw]
+            dev = [torch.from_numpy(np.ascontiguousarray(r.T)).cuda() for r in raw]
+        else:
+            dev = [torch.from_numpy(np.ascontiguousarray(im.T)).cuda() for im in imgs]
+        torch.cuda.synchronize()
+        tag = f"tolbatch seed {50000 + seed0 + t} {H}x{W} levels {levels} S {S} u8 {u8} target_only {tgt}"
+        try:
+            os.environ["SLAMHIP_CK_MIN_MB"] = "0"
+            b = slam.PyramidBatch((H, W), levels=levels, S=S)
+            b.update_([d.data_ptr() for d in dev], u8=u8, target_only=tgt, fast=True)
+            b.update_([d.data_ptr() for d in dev], u8=u8, target_only=tgt, fast=True)          # graph replay
+            os.environ.pop("SLAMHIP_CK_MIN_MB", None)
+            for s_ in {0, S - 1}:
+                ref = orc.pyr_build(imgs[s_], levels, 1.0, 1)
+                for l in range(levels + 1):
+                    for name in (PLANES if (l == 0 or not tgt) else ("layers",)):
+                        g, r = b.pyramids[s_].plane(name, l), ref.plane(name, l)
+                        err = np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)
+                        if not (err <= 1e-11): fail(f"{tag}: stream {s_} {name} level {l} rel {err:.2e}"); break
+        except Exception as ex:
+            os.environ.pop("SLAMHIP_CK_MIN_MB", None)
+            fail(f"{tag}: {repr(ex)[:200]}")
+    print("tolbatch done", flush=True)
 
 if "lk" in parts:
     for t in range(n):
