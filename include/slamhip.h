@@ -209,10 +209,16 @@ int slam_flow_match(slam_ctx *ctx, const slam_pyr *from, const slam_pyr *to,
  * with every single-pyramid call above.  slam_pyr_update_batch_dev rebuilds all S in one launch set (pyrs must
  * be the S members of one batch, in order; images already in HBM); slam_flow_match_batch tracks the keypoints
  * of all S streams in one launch (img_index[i] = stream of point i; from0 / to0 = member 0 of two batches).
- * Batch updates: mode 1 or 3 as for slam_pyr_update; with S >= 4 both modes run the bit-exact kernels (the segmented
- * ones of mode 3 only pay for a single image); launches with >= 40 MB of plane data use the checkpointed IIR kernels
- * (forward state every 32 samples, forward values recomputed: 2 reads + 1 write per sample instead of 2 + 2), still
- * bit-identical to mode 1 on a single pyramid. */
+ * Batch updates: mode 1 or 3 as for slam_pyr_update.
+ *   mode 1 -- every plane bit-identical to mode 1 on a single pyramid (the parity reference and the default); launches with >= 40 MB
+ *     of plane data use the checkpointed IIR kernels (forward state every 32 samples, forward values recomputed: 2 reads + 1 write
+ *     per sample instead of 2 + 2) and the fused dim-1 stage, still bit-identical.
+ *   mode 3 with S >= 4 (round 4) -- the TOLERANCE-mode batch build: per level one dim-1 kernel that leaves the product planes as
+ *     suffix sums along y and one dim-2 kernel that finishes filter, running sum and imresize! with one read and one write per plane
+ *     (2.2x instead of 3.9x the algorithmic bytes).  Every plane within 1e-11 of the mode-1 plane relative to the
+ *     plane's largest magnitude; tracked positions within 1e-6 px.  Keypoint INDICES are not affected: slam_detect* work on the raw
+ *     frame / the base layer, which is the same bytes in both modes.  Levels too small for those kernels (and S < 4: the segmented
+ *     single-image kernels of slam_pyr_update's mode 3) fall back per level; a batch may be updated in either mode at any time. */
 int slam_pyr_create_batch(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, slam_pyr **out);
 int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double *const *images_dev, int S,
                               int mode, double sigma, int sync);
