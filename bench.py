@@ -329,6 +329,11 @@ def main():
         be.close()
         for c in c3:
             c.close()
+        be, stream, c3, dtl, _ = one_stream(True)                 # live: the next frame only
+        out["tolerance_mode"]["single_stream_live"] = {"value": world * n1 / dtl, "unit": "frames/sec", "ms_per_frame": dtl / n1 * 1e3, "builds_in_flight": 1}
+        be.close()
+        for c in c3:
+            c.close()
         leg_done("tolerance_mode")
 
     # ---- headline: S lock-stepped streams per GPU, keypoints resident in HBM, bit-exact planes; frames arrive in host memory as the

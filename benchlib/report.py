@@ -97,6 +97,8 @@ def compact_line(out):
         c["tolerance_mode"] = {k: _r(v) for k, v in tm.items() if isinstance(v, (int, float, bool))}
         if isinstance(tm.get("single_stream"), dict):
             c["tolerance_mode"]["single_stream"] = _r(tm["single_stream"].get("value"))
+        if isinstance(tm.get("single_stream_live"), dict):
+            c["tolerance_mode"]["single_stream_live"] = _r(tm["single_stream_live"].get("value"))
         if isinstance(tm.get("batch"), dict):
             b = tm["batch"]
             c["tolerance_mode"].update({"value": _r(b.get("value")), "ms_per_step": _r(b.get("ms_per_step")), "planes_rel_tol": 1e-11})
