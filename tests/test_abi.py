@@ -51,13 +51,16 @@ def test_no_cpu_fallback_without_device():
 def test_product_never_imports_the_oracle():
     """the package, the examples and the measurement scripts: the oracle is the checker of tests/, smoke() and bench.py's cpu_baseline leg
     only (the randomised parity runs that use it live under tests/fuzz/)"""
-    for sub in ("slam.jl_amd", "scripts", "examples"):
+    for sub in ("slam.jl_amd", "scripts", "examples", "benchlib"):        # benchlib: bench.py's parts take the oracle module as an ARGUMENT from the cpu_baseline leg
         pkg = os.path.join(ROOT, sub)
         for dirpath, _, files in os.walk(pkg):
             for f in files:
                 if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".jl", ".sh")):
                     txt = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "slam_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(sub, f)
+    # bench.py itself: exactly one import site, inside the cpu_baseline leg (rank 0, N = 1)
+    txt = open(os.path.join(ROOT, "bench.py")).read()
+    assert txt.count("from oracle import") == 1 and txt.index("from oracle import") > txt.index('"cpu" in legs:')
 
 
 def test_bench_batch_sizes_fit_the_library_limit():
