@@ -74,12 +74,15 @@ function upload!(f::FrameRing, frames::AbstractVector{<:AbstractMatrix{UInt8}})
 end
 
 "update! of all S pyramids from the uint8 frames (raw / 255 on the device; slamhip.h: slam_pyr_update_batch_u8_dev).  target_only:
-the batch is only ever matched INTO (right pyramids, mapper.jl:51-66) -- SLAM_PYR_TARGET_ONLY = 16."
-function update!(b::PyramidBatch, f::FrameRing; σ = 1.0, target_only::Bool = false, sync::Bool = false)
+the batch is only ever matched INTO (right pyramids, mapper.jl:51-66) -- SLAM_PYR_TARGET_ONLY = 16.  tolerance = true selects mode 3:
+with S >= 4 the tolerance-mode batch build (every plane within 1e-11 of the bit-exact one relative to the plane's magnitude, 2.2x instead
+of 3.9x the algorithmic bytes; keypoint indices unaffected -- detect! works on the base layer); the default is the bit-exact mode 1."
+function update!(b::PyramidBatch, f::FrameRing; σ = 1.0, target_only::Bool = false, tolerance::Bool = false, sync::Bool = false)
     hs = b.handles; ps = f.ptrs
+    mode = (tolerance ? 3 : 1) | (target_only ? 16 : 0)
     GC.@preserve hs ps check(ccall((:slam_pyr_update_batch_u8_dev, LIB[]), Cint,
         (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{UInt8}}, Cint, Cint, Cdouble, Cint),
-        ctx(), hs, ps, length(hs), target_only ? (1 | 16) : 1, Float64(σ), sync ? 1 : 0))
+        ctx(), hs, ps, length(hs), mode, Float64(σ), sync ? 1 : 0))
     b
 end
 
