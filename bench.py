@@ -478,6 +478,12 @@ def main():
                                  "avg_launch_us": bm * 1e3, "achieved": pb2 / (bm * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": pb2 / (bm * 1e-3) / 1e9 / HBM_PEAK_GBS, "isolated_launch_us": iso2,
                                  "frac_isolated": pb2 / (iso2 * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+                if "tolbatch" in legs:                                # the same shape on tolerance-mode pyramids (planes <= 1e-11 relative)
+                    w2t = dict(w2); w2t["tolerance"] = True
+                    r2t = run_lockstep_kpset(slam, torch, local_rank, w2t, max(5, args.steps // 5), 2, world, dist, dev, "host_u8", pose=mono)
+                    out["configs"][name]["tolerance_value"] = r2t["value"]
+                    out["configs"][name]["tolerance_pyramid_build_ms"] = r2t["pyramid_build_ms"]["mean"]
+                    del w2t
                 del w2
             except Exception as ex:                                   # an optional leg never costs the line: the error goes on the record
                 out["configs"][name] = {"error": repr(ex)[:300] + " | " + " <- ".join(l.strip() for l in traceback.format_exc().splitlines()[-8:-1:2])[:500]}

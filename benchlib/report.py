@@ -105,6 +105,8 @@ def compact_line(out):
             c["tolerance_mode"]["roofline"] = {k: _r(b["roofline"].get(k)) for k in ("frac", "frac_isolated", "avg_launch_us", "isolated_launch_us", "traffic", "traffic_over_algorithmic")}
     if out.get("configs"):
         c["configs"] = {k: (_r(v.get("value")) if "value" in v else "error") for k, v in out["configs"].items()}
+        if any("tolerance_value" in v for v in out["configs"].values()):
+            c["configs_tolerance_mode"] = {k: _r(v.get("tolerance_value")) for k, v in out["configs"].items() if "tolerance_value" in v}
     if out.get("pose", {}).get("frontend_with_pose"):
         c["frontend_with_pose"] = _r(out["pose"]["frontend_with_pose"]["value"])
     pv = out.get("parity_vs_oracle")

@@ -1884,11 +1884,16 @@ static void seg_pow(const IIRPair &cf, int n, int SL, SegPow &sp)
     }
 }
 
-// k_rows_tol: samples per segment from a fixed menu (one instantiation each), the smallest that covers a row with RT_NS segments; 0: none
-static int rt_seg_len(int n)
+// k_rows_tol: samples per segment from a fixed menu (one instantiation each), the smallest that covers a row with RT_NS = 32 segments
+// (512 threads: two workgroups per CU); rows wider than 40 x 32 samples (the 1920-wide level 0 of configs[4]) take 64 segments of 24 / 32
+// samples (1024 threads, one workgroup per CU: 40+ samples per thread would spill at 128 registers).  Returns 0 when no variant fits.
+static int rt_seg_len(int n, int *ns)
 {
     static const int menu[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 40};
+    *ns = RT_NS;
     for (int m : menu) if ((n + m - 1) / m <= RT_NS && n >= 2 * m) return m;
+    *ns = 2 * RT_NS;
+    for (int m : {24, 32}) if ((n + m - 1) / m <= 2 * RT_NS && n >= 2 * m) return m;
     return 0;
 }
 static void rt_seg_pow(const IIRPair &cf, int SL, SegPow &sp)     // M^(SL q), q = 1 .. PAR_G; M^(SL - 1): all segments are full (left padding)
@@ -2014,7 +2019,8 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         // tolerance build of a batch (mode 3, S >= 4): the dim-1 stage leaves the product planes as suffix sums along y, ONE row kernel
         // finishes the level (dim-2 filter + running sum along x + imresize!): 1 R + 1 W per plane instead of 11 R + 6.25 W
         static const bool no_tol_batch = getenv("SLAMHIP_NO_TOL_BATCH") != nullptr;
-        const int slr_t = rt_seg_len(W);
+        int rt_ns = RT_NS;
+        const int slr_t = rt_seg_len(W, &rt_ns);
         const bool tolb = mode == 3 && S >= 4 && cols_fused && p->alloc->tot != nullptr && slr_t > 0 && !no_tol_batch;
         if (cols_fused) {
             ColsFusedArgs ca;
@@ -2043,8 +2049,13 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
                 if (rzf) { ra.rz.dst = p->view.lv[l + 1].L; ra.rz.Hd = p->H[l + 1]; ra.rz.Wd = p->W[l + 1]; ra.rz.Pd = p->P[l + 1]; }
                 SegPow spr; rt_seg_pow(cf, slr_t, spr);
                 static const int rt_dbg = getenv("SLAMHIP_RT_DBG") ? atoi(getenv("SLAMHIP_RT_DBG")) : 0; ra.dbg = rt_dbg;
-                const dim3 gr(RT_R == 8 ? (((H + 15) / 16 + 7) / 8) * 16 : (H + RT_R - 1) / RT_R, nr, S), bd(RT_R * RT_NS);
+                const dim3 gr(RT_R == 8 ? (((H + 15) / 16 + 7) / 8) * 16 : (H + RT_R - 1) / RT_R, nr, S), bd(RT_R * rt_ns);
                 auto go = [&]() {
+                    if (rt_ns != RT_NS) {                          // wide rows: 64 segments
+                        if (slr_t == 24) B.launch((k_rows_tol<24, 2 * RT_NS, RT_R>), gr, bd, 0, LN_MAIN, ra, H, W, P, cf, spr);
+                        else B.launch((k_rows_tol<32, 2 * RT_NS, RT_R>), gr, bd, 0, LN_MAIN, ra, H, W, P, cf, spr);
+                        return;
+                    }
 #define RT_GO(SLV) B.launch((k_rows_tol<SLV, RT_NS, RT_R>), gr, bd, 0, LN_MAIN, ra, H, W, P, cf, spr)
                     switch (slr_t) { case 4: RT_GO(4); break; case 6: RT_GO(6); break; case 8: RT_GO(8); break; case 10: RT_GO(10); break; case 12: RT_GO(12); break;
                                      case 16: RT_GO(16); break; case 20: RT_GO(20); break; case 24: RT_GO(24); break; case 32: RT_GO(32); break; default: RT_GO(40); break; }
