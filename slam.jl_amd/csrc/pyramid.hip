@@ -1454,20 +1454,24 @@ __global__ __launch_bounds__(PAR_T) void k_cum_seg(PlaneSet ps, int H, int W, in
 
 // ---- tolerance build (mode 3, batches): the whole dim-2 stage of a level in ONE kernel, 1 R + 1 W per plane ----------------------------
 // k_iir_rows_ck + k_cum_fused move 8 R + 3.25 W + 3 R + 3 W plane passes per level because a bit-identical recurrence needs a line's
-// samples twice, a line apart.  Here a 1024-thread workgroup owns 16 ROWS of one plane (16 consecutive y = one aligned
-// 128-byte line per column) and cuts them into 64 column segments of SL <= SLMAX samples, one per thread: the thread loads its samples
+// samples twice, a line apart.  Here a workgroup owns 16 ROWS of one plane (16 consecutive y = one aligned 128-byte line per
+// column) and cuts them into NS column segments of exactly SL samples, one per thread (NS = 32: 512 threads, two workgroups per CU --
+// their load / compute / store phases overlap; NS = 64 for rows wider than 1280 samples): the thread loads its samples
 // ONCE into registers, runs the forward recurrence from a zero state, the true entry states follow from a two-level fold of the affine
 // maps s -> M^SL s + z through LDS (k_iir_seg's scheme), the thread re-runs the recurrence from its true entry state, the same right to
 // left for the backward recurrence on the register-resident forward values; then, still in registers,
 //   * product planes: the running sum along x (local prefix, segment totals folded through LDS) -- the finished integral image.  Their
 //     input is k_cols_fused<TOL>'s output: exclusive suffix sums E along y of the dim-1-filtered products + the column totals, i.e. the
 //     dim-1 running sum C1[y] = tot - E[y] (a running sum along y and a filter along x commute: different dimensions, both linear);
-//   * the blurred layer: imresize! into the next level's layer (k_resize's arithmetic: horizontal interpolation per lane, row pairs
-//     averaged through DPP; even heights), or a plain store (odd heights: k_resize follows).
+//   * the blurred layer: imresize! into the next level's layer (k_resize's arithmetic: horizontal interpolation per lane; the row pairs
+//     were already averaged by k_cols_fused<TOL, DEC> -- the plane arrives at half height -- or are averaged here through DPP; even
+//     heights), or a plain store (odd heights: k_resize follows).
+// The fold's uniform power matrices are SGPR operands read from the kernel-argument segment (as LDS copies they cost 36+ vector registers
+// and the 40-sample variant spilled); only the per-lane power M^(SL q) comes from LDS.
 // Inside a segment the arithmetic is the sequential one; the entry states, the order of the two running sums and the suffix-sum form
 // of the dim-1 sum round differently: planes within 1e-11 of the exact mode relative to the plane's magnitude (tests/test_gpu_tol_batch.py).
-#define RT_R 16
-#define RT_NS 32
+#define RT_R 16                         // rows per workgroup
+#define RT_NS 32                        // column segments per row (the default variant)
 struct RowsTolArgs {
     double *p[4];           // [blurred layer (dim 1 done)], Qyy, Qxx, Qyx (image 0 of the batch)
     int coef[4];            // IIRCoef index
