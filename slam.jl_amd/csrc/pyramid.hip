@@ -1537,15 +1537,8 @@ __global__ __launch_bounds__(R * NS, (R * NS >= 1024 ? 4 : 4)) void k_rows_tol(R
     __shared__ double Fin[3][LPW];
     __shared__ double PW[9 * (PAR_G + 1)];                 // M^(SL q), q = 1 .. PAR_G; M^(SL - 1)
     __shared__ double TOT[SL * NS];                        // product planes: the column totals of this plane's image (tot - E = running sum along y)
-    // XCD-aware placement: workgroups go to the 8 XCDs round-robin by linear id; with R = 8 a 128-byte line (16 rows of a column) is shared
-    // by two workgroups, which are given linear ids 8 apart -- the same XCD, so the second finds the line in that L2
-    int bx = blockIdx.x;
-    if (R == 8) {
-        const int xcd = bx & 7, slot = bx >> 3;
-        const int unit = (slot >> 1) * 8 + xcd;
-        bx = unit * 2 + (slot & 1);
-        if (bx * R >= H) return;                                   // (the grid is rounded up to whole pairs of 8)
-    }
+    // (8 rows per workgroup -- 64-byte half lines, the two halves of a line placed on one XCD -- was measured: 984 us against 650 with 16 rows)
+    const int bx = blockIdx.x;
     const int t = threadIdx.x, l = t % LPW, g = t / LPW, pl = blockIdx.y;
     const int n = W;
     const int kind = PS_PICK(A, kind, pl), cs = PS_PICK(A, coef, pl);
@@ -2053,7 +2046,7 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
                 if (rzf) { ra.rz.dst = p->view.lv[l + 1].L; ra.rz.Hd = p->H[l + 1]; ra.rz.Wd = p->W[l + 1]; ra.rz.Pd = p->P[l + 1]; }
                 SegPow spr; rt_seg_pow(cf, slr_t, spr);
                 static const int rt_dbg = getenv("SLAMHIP_RT_DBG") ? atoi(getenv("SLAMHIP_RT_DBG")) : 0; ra.dbg = rt_dbg;
-                const dim3 gr(RT_R == 8 ? (((H + 15) / 16 + 7) / 8) * 16 : (H + RT_R - 1) / RT_R, nr, S), bd(RT_R * rt_ns);
+                const dim3 gr((H + RT_R - 1) / RT_R, nr, S), bd(RT_R * rt_ns);
                 auto go = [&]() {
                     if (rt_ns != RT_NS) {                          // wide rows: 64 segments
                         if (slr_t == 24) B.launch((k_rows_tol<24, 2 * RT_NS, RT_R>), gr, bd, 0, LN_MAIN, ra, H, W, P, cf, spr);
