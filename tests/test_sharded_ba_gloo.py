@@ -79,3 +79,27 @@ def test_two_rank_gloo_matches_oracle(orc, syn):
     assert np.array_equal(o0, ro)
     assert abs(s0["ssr_final"] - rs["ssr_final"]) < 1e-7 * rs["ssr_final"]
     assert np.abs(t0 - rt).max() < 1e-6
+
+
+@pytest.mark.timeout(400)
+def test_four_rank_gloo_matches_oracle(orc, syn):
+    """the same with four ranks (the driver's scaling runs go to 8): four point ranges, the all-reduce over four contributions, every rank the same result"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(4)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    s = syn.ba_scene(P=6, M=90, seed=11, obs_per_point=4)
+    rt, ro, rs = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], solver=1)
+    for r in res[1:]:
+        assert np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
+    assert res[0][3]["world_size"] == 4 and sum(r[3]["points_local"] for r in res) == 90
+    assert np.array_equal(res[0][2], ro)
+    assert abs(res[0][3]["ssr_final"] - rs["ssr_final"]) < 1e-7 * rs["ssr_final"]
+    assert np.abs(res[0][1] - rt).max() < 1e-6
