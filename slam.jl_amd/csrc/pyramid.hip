@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__(PAR_T) void k_cum_seg(PlaneSet ps, int H, int W, in
 struct RowsTolArgs {
     double *p[4];           // [blurred layer (dim 1 done)], Qyy, Qxx, Qyx (image 0 of the batch)
     int coef[4];            // IIRCoef index
-    int kind[4];            // 0: blurred layer, 1: product plane
+    int kind[4];            // 0: blurred layer, 1: product plane as suffix sums E + totals (from k_cols_fused<TOL>), 2: product plane holding its dim-1 running sum already (single images: k_iir_seg + k_cum_seg along y)
     int n, nq0;             // planes; index of the first product plane
     size_t zs;
     const double *tot; int tot_stride;
@@ -1640,7 +1640,7 @@ __global__ __launch_bounds__(R * NS, (R * NS >= 1024 ? 4 : 4)) void k_rows_tol(R
     __syncthreads();                                       // every thread is done with Z / GT: they are reused below
     double (*Zs)[LPW] = Z[0];                              // [NS][LPW]
     double (*Gs)[LPW] = GT[0];                             // [NS / PAR_G + 1][LPW]
-    if (kind == 1) {
+    if (kind >= 1) {
         // ---------------- running sum along x (k_cum_seg's scheme on the register-resident values) ----------------
         if (g == 0) {
 #pragma unroll
@@ -2002,6 +2002,41 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             seg_pow(cf, H, slc, spc); seg_pow(cf, W, slr, spr);
             const dim3 gc((W + 7) / 8, np, S), gr((H + 7) / 8, np, S), gc3((W + 7) / 8, 3, S), gr3((H + 7) / 8, 3, S);
             B.launch(k_iir_seg<true>, gc, dim3(PAR_T), 0, LN_MAIN, ps, src0, H, W, P, cf, spc, slc);
+            // round 4: the dim-2 stage of a single image through k_rows_tol as well -- the blurred layer (filter along x + imresize!, one launch on
+            // the main chain instead of k_iir_seg + k_resize) and, on the branch, the product planes (running sum along y first: the two
+            // directions commute; then filter + running sum along x in one launch instead of k_iir_seg + k_cum_seg): 5 launches per level, 3 of
+            // them on the chain the next level waits for (6 / 4 before)
+            int rns = RT_NS;
+            const int slt = rt_seg_len(W, &rns);
+            static const bool no_rt1 = getenv("SLAMHIP_NO_ROWS_TOL_SINGLE") != nullptr;
+            if (slt > 0 && rns == RT_NS && !no_rt1) {
+                SegPow spt; rt_seg_pow(cf, slt, spt);
+                auto rows_tol = [&](RowsTolArgs &ra, int nplanes, int lane_) {
+                    const dim3 g2((H + RT_R - 1) / RT_R, nplanes, S), b2(RT_R * RT_NS);
+#define RT_GO1(SLV) B.launch((k_rows_tol<SLV, RT_NS, RT_R>), g2, b2, 0, lane_, ra, H, W, P, cf, spt)
+                    switch (slt) { case 4: RT_GO1(4); break; case 6: RT_GO1(6); break; case 8: RT_GO1(8); break; case 10: RT_GO1(10); break; case 12: RT_GO1(12); break;
+                                   case 16: RT_GO1(16); break; case 20: RT_GO1(20); break; case 24: RT_GO1(24); break; case 32: RT_GO1(32); break; default: RT_GO1(40); break; }
+#undef RT_GO1
+                };
+                B.fork();
+                if (has_next) {
+                    RowsTolArgs rt = {};
+                    rt.p[0] = T; rt.coef[0] = 0; rt.kind[0] = 0; rt.n = 1; rt.nq0 = 1; rt.zs = zs;
+                    const bool rzf = (H & 1) == 0;
+                    if (rzf) { rt.rz.dst = p->view.lv[l + 1].L; rt.rz.Hd = p->H[l + 1]; rt.rz.Wd = p->W[l + 1]; rt.rz.Pd = p->P[l + 1]; }
+                    if (spans) { ProfScope span(ctx, "k_iir_rows"); rows_tol(rt, 1, LN_MAIN); } else rows_tol(rt, 1, LN_MAIN);
+                    if (!rzf)
+                        B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
+                                           p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
+                }
+                B.launch(k_cum_seg<true>, gc3, dim3(PAR_T), 0, LN_AUX, pc, H, W, P, slc);
+                RowsTolArgs rq = {};
+                rq.p[0] = v.Iyy; rq.p[1] = v.Ixx; rq.p[2] = v.Iyx;
+                for (int q = 0; q < 3; q++) { rq.coef[q] = 1; rq.kind[q] = 2; }
+                rq.n = 3; rq.nq0 = 0; rq.zs = zs;
+                rows_tol(rq, 3, LN_AUX);
+                continue;
+            }
             if (spans) { ProfScope span(ctx, "k_iir_rows");
                 B.launch(k_iir_seg<false>, gr, dim3(PAR_T), 0, LN_MAIN, ps, (const double *)nullptr, H, W, P, cf, spr, slr); }
             else B.launch(k_iir_seg<false>, gr, dim3(PAR_T), 0, LN_MAIN, ps, (const double *)nullptr, H, W, P, cf, spr, slr);

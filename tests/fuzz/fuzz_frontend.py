@@ -2,6 +2,7 @@
   pyr     single-image pyramids, random H x W (4 .. 300), levels, sigma, both ctor modes
   batch   batched pyramids with the bandwidth-bound kernel set FORCED on small shapes (SLAMHIP_CK_MIN_MB=0: k_cols_fused, k_iir_rows_ck
           with the fused resize, k_cum_fused), f64 / u8 ingest, target-only builds, S = 1 .. 6
+  tolpyr  single-image tolerance mode (mode 3) on random shapes up to 400 x 1400: planes <= 1e-11 relative to the oracle's exact build
   tolbatch the tolerance-mode batch build (mode 3, S = 4 .. 10) forced onto small random shapes: planes <= 1e-11 relative to the oracle's exact build
   lk      fb_tracking with random window sizes (2 .. 14: the three cached instantiations and the uncached path), levels, priors, points on and near the borders
   detect  random shapes, cell sizes, current keypoints (none / few / many / clustered), mask sigma
@@ -16,7 +17,7 @@ from oracle import oracle as orc
 PLANES = ("layers", "Iy", "Ix", "Iyy", "Ixx", "Iyx")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-parts = sys.argv[3].split(",") if len(sys.argv) > 3 else ["pyr", "batch", "tolbatch", "lk", "detect", "brief"]
+parts = sys.argv[3].split(",") if len(sys.argv) > 3 else ["pyr", "batch", "tolpyr", "tolbatch", "lk", "detect", "brief"]
 fails = 0
 
 
@@ -88,6 +89,28 @@ if "batch" in parts:
             os.environ.pop("SLAMHIP_CK_MIN_MB", None)
             fail(f"{tag}: {repr(ex)[:200]}")
     print("batch done", flush=True)
+
+if "tolpyr" in parts:
+    # single-image tolerance mode (slam_pyr_update mode 3: k_iir_seg / k_cum_seg along y, k_rows_tol along x where the row is long enough)
+    for t in range(n):
+        rng = np.random.default_rng(60000 + seed0 + t)
+        H, W = int(rng.integers(4, 400)), int(rng.integers(4, 1400))
+        levels = int(rng.integers(0, max_levels(H, W) + 1))
+        img = rand_image(rng, H, W)
+        tag = f"tolpyr seed {60000 + seed0 + t} {H}x{W} levels {levels}"
+        try:
+            lk = slam.LKPyramid(shape=(H, W), levels=levels)
+            slam.update_(lk, img, fast=True)
+            slam.update_(lk, img, fast=True)                       # graph replay
+            ref = orc.pyr_build(img, levels, 1.0, 1)
+            for l in range(levels + 1):
+                for name in PLANES:
+                    g, r = lk.plane(name, l), ref.plane(name, l)
+                    err = np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)
+                    if not (err <= 1e-11): fail(f"{tag}: {name} level {l} rel {err:.2e}"); break
+        except Exception as ex:
+            fail(f"{tag}: {repr(ex)[:200]}")
+    print("tolpyr done", flush=True)
 
 if "tolbatch" in parts:
     # the tolerance-mode batch build (mode 3, S >= 4: k_cols_fused<TOL[, DEC]> + k_rows_tol) forced onto small random shapes: every plane within

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_frontend_fuzz_short_run():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_frontend.py"), "25", "5000"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert "parts ['pyr', 'batch', 'tolbatch', 'lk', 'detect', 'brief']: 0 failures" in r.stdout, r.stdout[-3000:]
+    assert "parts ['pyr', 'batch', 'tolpyr', 'tolbatch', 'lk', 'detect', 'brief']: 0 failures" in r.stdout, r.stdout[-3000:]
 
 
 def test_keypoint_set_fuzz_short_run():
