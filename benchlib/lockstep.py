@@ -200,7 +200,7 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     prio = int(os.environ.get("SLAM_BENCH_TRACK_PRIO", "-1"))
     pprio = int(os.environ.get("SLAM_BENCH_PYR_PRIO", "0"))
     ctx, ctx_pyr, ctx_right, ctx_copy = (leg_ctx(slam, local_rank, prio), leg_ctx(slam, local_rank, pprio),
-                                         leg_ctx(slam, local_rank, pprio), leg_ctx(slam, local_rank))
+                                         leg_ctx(slam, local_rank, pprio), copy_ctx(slam, local_rank))
     levels = params.pyramid_levels
     AHEAD = max(1, int(os.environ.get("SLAM_BENCH_KP_AHEAD", "2")))   # builds enqueued ahead of the step being tracked (same-box A/B: 2 = +0.9 % over 1 -- the next graph is already queued when a build ends; 3 = -1.4 %)
     NLB = AHEAD + 3                                          # previous, current, AHEAD being built, one more being copied
@@ -487,17 +487,39 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     if host:
         del lstage, st_copy
     del st_main
+    retire_torch_host_events(torch)
     peek("run_lockstep_kpset: after freeing the torch buffers")
-    for c_ in (ctx, ctx_pyr, ctx_right, ctx_copy):
+    for c_ in (ctx, ctx_pyr, ctx_right):                         # (the copy context lives as long as the process: copy_ctx)
         c_.close()
     return res
 
 
 def leg_ctx(slam, local_rank, priority=0):
-    """a context (HIP stream, scratch, pinned block) for one leg; the leg closes it.  (Round 3 kept the lock-stepped legs' contexts for the
-    life of the process because a destroyed capture-origin stream left runtime state behind; the build graphs are now
-    constructed node by node -- no stream capture -- and contexts come and go with the legs.)"""
+    """a context (HIP stream, scratch, pinned block) for one leg; the leg closes it"""
     return slam.Context(local_rank, priority=priority) if priority else slam.Context(local_rank)
+
+
+_COPY_CTX = {}
+
+
+def copy_ctx(slam, local_rank):
+    """The context whose stream PyTorch copies pinned host frames on (torch.cuda.ExternalStream) lives as long as the process.  PyTorch's
+    pinned-memory allocator records an event on that stream for every non-blocking copy and queries those events on LATER allocations;
+    once in ~17 full runs a later pin_memory() failed with hipErrorCapturedEvent ("event last recorded in a capturing stream") after the
+    stream had been destroyed with its leg -- although nothing in the process captures a stream any more: the runtime's
+    answer to querying an event whose stream is gone.  Keeping this ONE stream (and retiring the allocator's events before the other
+    contexts of a leg are closed, retire_torch_host_events) removes the situation; the library's own contexts need no such care."""
+    if local_rank not in _COPY_CTX:
+        _COPY_CTX[local_rank] = slam.Context(local_rank)
+    return _COPY_CTX[local_rank]
+
+
+def retire_torch_host_events(torch):
+    """after the leg's pinned tensors are gone and the device is idle: one small pinned allocation makes PyTorch's host allocator walk its
+    pending events (all complete by now) while the streams they were recorded on still exist"""
+    torch.cuda.synchronize()
+    torch.empty(64, dtype=torch.uint8).pin_memory()
+    torch.cuda.synchronize()
 
 
 _HIP = None
