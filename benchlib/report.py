@@ -114,6 +114,8 @@ def compact_line(out):
         c["parity_vs_oracle"] = {"ok": pv["ok"] and not out.get("parity_failures")}
     if out.get("parity_failures"):
         c["parity_failures"] = len(out["parity_failures"])
+    if out.get("leg_error"):
+        c["leg_error"] = {"after_leg": out["leg_error"].get("after_leg"), "error": str(out["leg_error"].get("error"))[:160]}
     c["detail"] = "bench_detail.json"
     line = json.dumps(c, separators=(",", ":"))
     if len(line) > 8000:                                          # never lose the line to its own size: drop the optional objects, largest first
