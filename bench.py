@@ -176,6 +176,7 @@ def main():
     left, right, flows, disparity = wl["left"], wl["right"], wl["flows"], wl["disparity"]
     frame_steps = args.steps * KF_EVERY
     fails = []
+    pose_fails = []                                          # a loop whose recovered poses are wrong measured a different workload: leg_error
 
     progress = {"last_done": "start"}
 
@@ -344,6 +345,7 @@ def main():
     # ---- headline: S lock-stepped streams per GPU, keypoints resident in HBM, bit-exact planes; frames arrive in host memory as the
     #      decoder's 8-bit images ----
     head = None
+    tol_snapshot = None
     if "headline" in legs:
         head = run_lockstep_kpset(slam, torch, local_rank, wl, args.steps, args.warmup, world, dist, dev, "host_u8", snapshot=[0, S - 1])
         leg_done("headline")
@@ -411,8 +413,10 @@ def main():
         #      to the exact build, tracked positions <= 1e-6 px: tests/test_gpu_tol_batch.py); keypoint indices still come from detect on the raw frame ----
         if "tolbatch" in legs:
             wt = dict(wl); wt["tolerance"] = True
-            tb = run_lockstep_kpset(slam, torch, local_rank, wt, max(8, args.steps // 2), 2, world, dist, dev, "host_u8")
+            tb = run_lockstep_kpset(slam, torch, local_rank, wt, max(8, args.steps // 2), 2, world, dist, dev, "host_u8",
+                                    snapshot=[0, S // 2, S - 1] if (rank == 0 and world == 1 and "cpu" in legs) else None)
             leg_done("tolbatch")
+            tol_snapshot = tb.pop("snapshot", None)                  # checked against the oracle in the cpu leg: tolerance_mode.parity_ok
             _, tserial_us, tiso_us = kernel_spans(slam, torch, local_rank, wt, dev)
             pbt = S * pyramid_bytes(H, W, levels)
             tbm = tb["pyramid_build_ms"]["mean"]
@@ -487,11 +491,17 @@ def main():
                                      "avg_launch_us": bm * 1e3, "achieved": pb2 / (bm * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": pb2 / (bm * 1e-3) / 1e9 / HBM_PEAK_GBS, "isolated_launch_us": iso2,
                                      "frac_isolated": pb2 / (iso2 * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+                    if r2["pose"] is not None and not r2["pose"]["pose_ok"]:
+                        pose_fails.append(f"configs.{name}: pose check failed ({r2['pose']['max_translation_error_m']:.3f} m, accepted {r2['pose']['accepted_fraction']:.3f})")
                     if "tolbatch" in legs:                                # the same shape on tolerance-mode pyramids (planes <= 1e-11 relative)
                         w2t = dict(w2); w2t["tolerance"] = True
                         r2t = run_lockstep_kpset(slam, torch, local_rank, w2t, max(5, args.steps // 5), 2, world, dist, dev, "host_u8", pose=mono)
                         out["configs"][name]["tolerance_value"] = r2t["value"]
                         out["configs"][name]["tolerance_pyramid_build_ms"] = r2t["pyramid_build_ms"]["mean"]
+                        if r2t["pose"] is not None:
+                            out["configs"][name]["tolerance_pose"] = r2t["pose"]
+                            if not r2t["pose"]["pose_ok"]:
+                                pose_fails.append(f"configs.{name} (tolerance mode): pose check failed ({r2t['pose']['max_translation_error_m']:.3f} m)")
                         del w2t
                     del w2
                 except Exception as ex:                                   # an optional leg never costs the line: the error goes on the record
@@ -670,6 +680,8 @@ def main():
                                             "device-resident lists; one device -> host copy (poses, status, list lengths)"}
             # the tracked workload as the reference's full per-frame front-end on the tracked lists themselves
             wp = run_lockstep_kpset(slam, torch, local_rank, wl, max(8, args.steps // 3), 2, world, dist, dev, "host_u8", pose=True)
+            if not wp["pose"]["pose_ok"]:
+                pose_fails.append(f"pose.frontend_with_pose: pose check failed ({wp['pose']['max_translation_error_m']:.3f} m, accepted {wp['pose']['accepted_fraction']:.3f})")
             out["pose"]["frontend_with_pose"] = {"value": wp["value"], "unit": "frames/sec", "ms_per_step": wp["ms_per_step"],
                                                  "tracked_kpts_per_frame": wp["tracked_kpts_per_frame"], **wp["pose"],
                                                  "what": "the headline workload as the reference's full per-frame front-end on the tracked lists themselves "
@@ -742,6 +754,22 @@ def main():
                                           "what": "the headline loop from empty lists for 7 frames (detect, stereo match, triangulate, 5 temporal matches, cull, detect ...) "
                                                   "with recorded priors / cull flags, replayed per stream through orc.pyr_build / optical_flow_matching / detect / triangulate"}
                 out["parity_vs_oracle"] = par
+            if tol_snapshot:
+                # the planes the TIMED tolerance-mode run left behind (S streams, default kernel-selection thresholds) against the oracle's exact build
+                u8f = lambda im: np.asfortranarray(np.round(im * 255).astype(np.uint8).astype(np.float64) / 255.0)
+                worst_t = 0.0
+                for s_, sn in tol_snapshot.items():
+                    ref = orc.pyr_build(u8f(left[sn["frame_id"]]), levels, 1.0, 1)
+                    for (nm, l), a in sn["planes"].items():
+                        r_ = ref.plane(nm, l)
+                        worst_t = max(worst_t, float(np.abs(a - r_).max() / max(np.abs(r_).max(), 1e-300)))
+                tnode = out.setdefault("tolerance_mode", {})
+                tnode["parity_ok"] = bool(worst_t <= 1e-11)
+                tnode["parity_vs_oracle"] = {"streams": sorted(tol_snapshot), "planes_compared": 6 * (levels + 1) * len(tol_snapshot), "max_rel_err": worst_t, "bar": 1e-11,
+                                             "what": "all planes of the last left pyramids of the timed tolerance-mode run vs orc.pyr_build of the same 8-bit frame, "
+                                                     "relative to each plane's largest magnitude"}
+                if worst_t > 1e-11:
+                    fails.append(f"tolerance-mode batch planes: max relative error {worst_t} > 1e-11")
             if ba_scenes is not None:
                 # the measured GPU solver against the oracle on every timed window (parity, not timing: 2 + 3 iterations)
                 for name, s in ba_scenes.items():
@@ -794,6 +822,8 @@ def main():
         except Exception:
             pass
 
+    if pose_fails and not out.get("leg_error"):
+        out["leg_error"] = {"after_leg": progress["last_done"], "error": "; ".join(pose_fails)[:300], "where": "pose check of a lock-stepped loop (benchlib/lockstep.py: pose_ok)"}
     if head is not None:
         head.pop("snapshot", None)
     if fails:

@@ -140,6 +140,9 @@ def run_lockstep(slam, torch, local_rank, S, steps, warmup, H, W, left_dev, righ
     return res
 
 
+POSE_TOL_M = 0.1            # recovered camera translation vs the frames' image offsets (plane 30 m away), metres
+
+
 WORKLOADS = {
     # name: shape (slam_jl_amd.synthetic.SHAPES), keypoints per frame, stereo, streams per GPU, camera (fx, fy, cx, cy), image step per frame
     "kitti05_1000": dict(shape="kitti05", kpts=1000, stereo=True, S=128, cam=None, step=(1.3, -2.1), n_frames=8,
@@ -171,7 +174,7 @@ def make_workload(slam, syn, name, seed=0, streams=None):
 
 
 def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world, dist, dev, ingest,
-                       hook=None, seed=1234, pose=False, record=None, snapshot=None):
+                       hook=None, seed=1234, pose=False, record=None, snapshot=None, diag=None):
     """The headline loop: S streams in lock-step, keypoints resident in HBM (slam_kpset_*), no host list work
     between the calls of a frame; the host sees the S list lengths once per frame.  Timed: `periods` key-frame periods
     (KF_EVERY frames of every stream each, the first a key-frame) after `warm_periods` untimed ones.
@@ -412,6 +415,8 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
         state["n_bound"] = tot
         if hook is not None:
             hook()
+        if diag is not None:                                    # probes / tests: look at the lists and poses after every frame step
+            diag(i, kf, pst, ks, ctx, flows_a[seq_a[(i % period) + np.arange(S)]])
 
     def drain():
         ctx_copy.synchronize(); ctx_pyr.synchronize(); ctx_right.synchronize(); ctx.synchronize(); torch.cuda.synchronize()
@@ -451,7 +456,11 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
                                           "five_point_rejected_by_parallax_gate_fraction": pst["gated5"] / max(pst["asked5"], 1),
                                           "five_point_note": "compute_pose_5pt! returns nothing while the average parallax against the previous key-frame is below 5 px "
                                                              "(front_end.jl:290): the first frames after each key-frame; every remaining call is accepted when the two fractions add up to 1",
-                                          "max_translation_error_m": pst["err_max"], "plane_depth_m": Z_PLANE},
+                                          "max_translation_error_m": pst["err_max"], "plane_depth_m": Z_PLANE,
+                                          # the loop's own check: every compute_pose! accepted and the recovered translation within POSE_TOL_M of the
+                                          # frames' offsets (a 30 m scene, translations of a few metres); bench.py turns a failure into leg_error
+                                          "pose_ok": bool(pst["asked"] > 0 and pst["accepted"] == pst["asked"] and pst["err_max"] < POSE_TOL_M),
+                                          "pose_tol_m": POSE_TOL_M},
            "lk_match": None if not lk_spans else {"mean_ms": float(np.mean([m for m, _ in lk_spans])), "points_per_launch": float(np.mean([n for _, n in lk_spans])),
                                                   "n": len(lk_spans), "what": "hipEvents around slam_kpset_flow_match (k_kpset_match + compaction) on the tracking stream, timed region"},
            "pyramid_build_ms": {"mean": float(np.mean(builds)) if builds else None, "min": float(np.min(builds)) if builds else None,

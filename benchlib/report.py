@@ -109,6 +109,17 @@ def compact_line(out):
             c["configs_tolerance_mode"] = {k: _r(v.get("tolerance_value")) for k, v in out["configs"].items() if "tolerance_value" in v}
     if out.get("pose", {}).get("frontend_with_pose"):
         c["frontend_with_pose"] = _r(out["pose"]["frontend_with_pose"]["value"])
+    # the loops that recover poses check them against the scene (translation within pose_tol_m, every compute_pose! accepted)
+    pk = {}
+    if out.get("pose", {}).get("frontend_with_pose"):
+        f = out["pose"]["frontend_with_pose"]
+        pk["frontend_with_pose"] = {"ok": f.get("pose_ok"), "max_translation_error_m": _r(f.get("max_translation_error_m"))}
+    for k, v in (out.get("configs") or {}).items():
+        if isinstance(v.get("pose"), dict):
+            pk[k] = {"ok": v["pose"].get("pose_ok"), "max_translation_error_m": _r(v["pose"].get("max_translation_error_m"))}
+    if pk:
+        c["pose_ok"] = all(bool(v["ok"]) for v in pk.values())
+        c["pose_checks"] = pk
     pv = out.get("parity_vs_oracle")
     if pv:
         c["parity_vs_oracle"] = {"ok": pv["ok"] and not out.get("parity_failures")}

@@ -110,7 +110,9 @@ static void flow_vector(const orc_pyr *first, const orc_pyr *second, int lv, con
     } else {
         /* sum_order 1: the element e of the (q outer, p inner) enumeration goes to lane e % 64, a lane adds its elements in order, the
          * 64 partial sums are folded by the xor butterfly m = 32, 16, 1, 2, 4, 8 (rounds 1-3 of the device kernel: one wave per keypoint);
-         * sum_order 2: lane e % 32 and the butterfly m = 16, 1, 2, 4, 8 (round 4: one 32-lane half-wave per keypoint, csrc/lk.hip: half_sum2) */
+         * sum_order 2: lane e % 32 and the butterfly m = 16, 1, 2, 4, 8 -- the order of the PARKED half-wave experiment
+         * (scripts/ubench/lk_halfwave.hip.txt, measured 1.6x slower, never shipped): no product kernel sums in this order; the bit-exact GPU
+         * tests stay on sum_order 1 (csrc/lk.hip: wave_sum2) */
         const int NL = sum_order == 2 ? 32 : 64;
         double ay[64], ax[64];
         for (int l = 0; l < 64; l++) ay[l] = ax[l] = 0.0;

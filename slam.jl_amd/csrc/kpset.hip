@@ -372,13 +372,13 @@ __global__ __launch_bounds__(256) void k_kpset_keyframe(KpsetView K)
     if (!K.haskf[q]) { K.fyx[2 * q] = y; K.fyx[2 * q + 1] = x; K.fkf[q] = K.kfcount[s]; }     // detected by this key-frame: its first observer
     K.kyx[2 * q] = y; K.kyx[2 * q + 1] = x; K.haskf[q] = 1;
 }
-__global__ void k_kpset_kf_advance(int *kfcount, int S) { if ((int)threadIdx.x < S) kfcount[threadIdx.x] += 1; }
+__global__ void k_kpset_kf_advance(int *kfcount, int S) { const int s = blockIdx.x * 64 + threadIdx.x; if (s < S) kfcount[s] += 1; }   // (one 64-thread block until round 5: streams 64.. never advanced)
 int slam_kpset_keyframe(slam_ctx *ctx, slam_kpset *ks)
 {
     ARG_TRY(ctx, ctx != nullptr && ks != nullptr);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_kpset_keyframe, dim3((ks->cap + 255) / 256, ks->S), dim3(256), 0, ctx->stream, view_of(ks));
-    hipLaunchKernelGGL(k_kpset_kf_advance, dim3(1), dim3(64), 0, ctx->stream, ks->kfcount, ks->S);
+    hipLaunchKernelGGL(k_kpset_kf_advance, dim3((ks->S + 63) / 64), dim3(64), 0, ctx->stream, ks->kfcount, ks->S);
     HIP_TRY(ctx, hipGetLastError());
     return SLAM_OK;
 }

@@ -1959,7 +1959,7 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         if (target && l >= 1) {                                   // the layer chain only: blur (dim 1, dim 2) -> resize
             if (!has_next) continue;
             PlaneSet pt = {}; pt.p[0] = T; pt.coef[0] = 0; pt.fill0[0] = (mode == 0); pt.nrm[0] = nullptr; pt.n = 1; pt.zs = zs;
-            const bool ckr = mode != 3 && p->ck != nullptr && mode != 0 && W >= 64 && H >= 64 && (size_t)S * 4 * H * W * 8 >= ck_min_bytes();
+            const bool ckr = (mode != 3 || S >= 4) && p->ck != nullptr && mode != 0 && W >= 64 && H >= 64 && (size_t)S * 4 * H * W * 8 >= ck_min_bytes();
             if (ckr) B.launch(k_iir_cols_ck, lines_grid(W, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, pt, (const double *)v.L, H, W, P, cf, p->ck);
             else B.launch(k_iir_cols<2>, lines_grid(W, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, pt, (const double *)v.L, H, W, P, cf);
             static const bool no_rr = getenv("SLAMHIP_NO_ROWS_RESIZE") != nullptr;

@@ -215,9 +215,12 @@ class HipShard:
 def _all_reduce(t, op, group):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        if t.is_cuda and dist.get_backend(group) != "nccl":
-            # a host-side backend (gloo: two processes sharing one GPU, where RCCL refuses a second rank per device): staged through
-            # the host; .cpu() waits for the library's stream only if the caller synchronised it (slam_ba_build / _solve do)
+        backend = str(dist.get_backend(group)).lower()          # "nccl", "gloo", or a composite such as "cuda:nccl,cpu:gloo" (default init)
+        if t.is_cuda and "nccl" not in backend:
+            # a host-only backend (gloo: two processes sharing one GPU, where RCCL refuses a second rank per device): staged through
+            # the host.  ONLY the host-paced callers reach this branch (slam_ba_build / slam_ba_solve synchronise the library's
+            # non-blocking stream before returning, so .cpu() on torch's stream sees the finished buffer); the device-paced driver
+            # uses slam_comm_* and never comes here
             h = t.detach().cpu()
             dist.all_reduce(h, op=op, group=group)
             t.copy_(h)

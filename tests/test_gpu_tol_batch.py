@@ -79,3 +79,27 @@ def test_tolerance_batch_tracking_vs_oracle(slam, syn, orc, monkeypatch):
     both = st & rs
     assert both.sum() > len(kp) // 2
     assert np.abs(got[both] - ro[both]).max() <= 1e-6
+
+
+def test_tolerance_batch_s128_kitti_vs_oracle(slam, syn, orc):
+    """The configuration bench.py quotes `tolerance_mode.value` on: 128 u8 frames of 370 x 1226 per build, DEFAULT kernel-selection
+    thresholds (no SLAMHIP_CK_MIN_MB override), full and target-only builds; streams 0, 64 and 127 within 1e-11 of the oracle."""
+    import torch
+    H, W, S = 370, 1226, 128
+    fr = _frames(syn, H, W, S, seed=17)
+    dev = torch.from_numpy(np.stack([np.ascontiguousarray(im.T) for im in fr])).cuda()
+    torch.cuda.synchronize()
+    ptrs = [dev.data_ptr() + s * H * W for s in range(S)]
+    pb = slam.PyramidBatch((H, W), levels=3, S=S)
+    pb.update_(ptrs, u8=True, fast=True); pb.update_(ptrs, u8=True, fast=True)
+    tg = slam.PyramidBatch((H, W), levels=3, S=S)
+    tg.update_(ptrs, u8=True, fast=True, target_only=True); tg.update_(ptrs, u8=True, fast=True, target_only=True)
+    for s in (0, 64, 127):
+        ref = orc.pyr_build(np.asfortranarray(fr[s].astype(np.float64) / 255.0), 3, 1.0, 1)
+        _check_planes(pb.pyramids[s], ref, 3, ("full", s))
+        for l in range(4):                                           # what a tracking target needs: every layer + the finest level's planes
+            g, r = tg.pyramids[s].plane("layers", l), ref.plane("layers", l)
+            assert np.abs(g - r).max() / np.abs(r).max() <= TOL, ("target_only", s, l)
+        for name in PLANES:
+            g, r = tg.pyramids[s].plane(name, 0), ref.plane(name, 0)
+            assert np.abs(g - r).max() / max(np.abs(r).max(), 1e-300) <= TOL, ("target_only", s, name)

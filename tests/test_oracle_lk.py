@@ -47,7 +47,7 @@ def test_summation_orders_agree_and_prior(orc, texture):
     o0, s0 = orc.fb_tracking(p0, p1, kp, sum_order=0)
     o1, s1 = orc.fb_tracking(p0, p1, kp, sum_order=1)
     assert (s0 != s1).sum() <= 1 and np.abs(o0[s0 & s1] - o1[s0 & s1]).max() < 1e-9
-    oh, sh = orc.fb_tracking(p0, p1, kp, sum_order=2)                        # the device kernels' half-wave order (round 4)
+    oh, sh = orc.fb_tracking(p0, p1, kp, sum_order=2)                        # the parked half-wave experiment's order (scripts/ubench/lk_halfwave.hip.txt): matches no shipped kernel
     assert (s0 != sh).sum() <= 1 and np.abs(o0[s0 & sh] - oh[s0 & sh]).max() < 1e-9
     prior = np.tile(np.array(flows[1]) / 2, (len(kp), 1))
     o2, s2 = orc.fb_tracking(p0, p1, kp, disp0=prior, pyramid_levels=1)
