@@ -417,6 +417,22 @@ int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy,
                   const int64_t *pose_ids, const int64_t *point_ids, uint8_t *outliers,
                   int iters_fast, int iterations, double repr_eps, double *stats);
 
+/* bundle_adjustment! for S windows in one set of launches (no reference counterpart, like the other *_batch entry points): the
+ * caller is the estimator task of S lock-stepped SlamManagers -- every key-frame of every manager owes one local_bundle_adjustment!
+ * (src/estimator.jl:78-99, :317-347; src/bundle_adjustment.jl:35-54).  Window z has Pn[z] poses, Mn[z] points, On[z] observations and
+ * camera cams[4 z ..] = fx, fy, cx, cy; the arrays of the windows are stored back to back in window order: theta (6 Pn[z] + 3 Mn[z]
+ * doubles each, in / out), theta_const (Pn[z] bytes), pixels_yx (2 On[z] doubles), pose_ids / point_ids (On[z], 1-based, local to the
+ * window), outliers (On[z] bytes, out), stats (8 doubles per window as slam_local_ba's, may be NULL).  Each window runs its own
+ * device-side Levenberg-Marquardt state (a converged window idles) and its results equal slam_local_ba's on its arrays; windows the
+ * banded group kernels do not cover (no banded pose order, a point with > 448 observations, no observations) are solved one by one
+ * after the batch.  status (S ints, may be NULL): per-window code -- 0, SLAM_ERR_NUMERIC (reduced system not positive definite: that
+ * window's theta / outliers are left unchanged) or SLAM_ERR_ARG; with status the call returns SLAM_OK unless the batch itself failed,
+ * without it the first window error is returned.  Host set-up runs on up to 16 threads (SLAMHIP_BA_THREADS overrides). */
+int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t *Pn, const int32_t *Mn, const int32_t *On,
+                        double *theta, const uint8_t *theta_const, const double *pixels_yx,
+                        const int64_t *pose_ids, const int64_t *point_ids, uint8_t *outliers,
+                        int iters_fast, int iterations, double repr_eps, double *stats, int32_t *status);
+
 /* pnp_bundle_adjustment(camera, pose, pixels, points; iterations, depth_eps,
  * repr_eps) -- src/bundle_adjustment.jl:113-171.  pose_cw/out_pose: 4x4
  * column-major.  out_pose = identity when fewer than 5 inliers remain (:157-161). */

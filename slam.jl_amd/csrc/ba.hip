@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <type_traits>
 #include <chrono>
+#include <thread>
 #include <cmath>
 
 #define LM_MAX_DELTA 1e16
@@ -67,6 +68,8 @@ struct BADev {
     // sorted position of an observation's point.  grp / fgrp / wpart: the point groups of k_schur_groups (below).
     const int *pt_id, *opk;
     const int4 *grp; const int *fgrp; int ngrp, whb, wstride;
+    int sg_ob, sg_sb;            // k_schur_groups' LDS layout: room for sg_ob observations / sg_sb points per group (SG_OB / SG_SB; a batch of small
+                                 // windows sizes it to its largest group, so that several workgroups share a compute unit)
     double *wpart;
     double *S, *g, *udiag;       // reduce buffer views
     double *Swork, *dp, *dl;
@@ -109,11 +112,17 @@ struct slam_ba {
 // ---------------------------------------------------------------------------------
 // residual of one observation + analytic Jacobian (bundle_adjustment.jl:23-30;
 // RotZYX = Rz(t1) Ry(t2) Rx(t3)).  Jp: 2x6 row-major, Jl: 2x3 row-major.
-__device__ __forceinline__ void obs_eval(const double *pose, const double *X, double py, double px, const Cam &c,
-                                         double r[2], double *Jp, double *Jl, double *depth)
+// sc = (sin, cos) of the three angles, tr = the translation: the group kernels form sc ONCE per pose and workgroup (sincos in Float64 is a few
+// hundred instructions; an observation evaluated it three times) -- the same function of the same argument, so the same bits
+__device__ __forceinline__ void pose_sincos(const double *pose, double sc[6])
 {
-    double s1, c1, s2, c2, s3, c3;
-    sincos(pose[0], &s1, &c1); sincos(pose[1], &s2, &c2); sincos(pose[2], &s3, &c3);
+    sincos(pose[0], &sc[0], &sc[1]); sincos(pose[1], &sc[2], &sc[3]); sincos(pose[2], &sc[4], &sc[5]);
+}
+__device__ __forceinline__ void obs_eval_sc(const double *sc, const double *tr, const double *X, double py, double px, const Cam &c,
+                                            double r[2], double *Jp, double *Jl, double *depth)
+{
+    const double s1 = sc[0], c1 = sc[1], s2 = sc[2], c2 = sc[3], s3 = sc[4], c3 = sc[5];
+    const double pose[6] = {0.0, 0.0, 0.0, tr[0], tr[1], tr[2]};
     const double R[9] = {c1 * c2, c1 * s2 * s3 - s1 * c3, c1 * s2 * c3 + s1 * s3,
                          s1 * c2, s1 * s2 * s3 + c1 * c3, s1 * s2 * c3 - c1 * s3,
                          -s2, c2 * s3, c2 * c3};
@@ -149,6 +158,13 @@ __device__ __forceinline__ void obs_eval(const double *pose, const double *X, do
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) { Jp[3 + k] = dy[k]; Jp[9 + k] = dx[k]; }
+}
+__device__ __forceinline__ void obs_eval(const double *pose, const double *X, double py, double px, const Cam &c,
+                                         double r[2], double *Jp, double *Jl, double *depth)
+{
+    double sc[6];
+    pose_sincos(pose, sc);
+    obs_eval_sc(sc, pose + 3, X, py, px, c, r, Jp, Jl, depth);
 }
 
 // deterministic block reduction (256 threads): wave butterfly, then wave order
@@ -224,7 +240,7 @@ template <int N> __device__ __forceinline__ void st_rec(double *p, const double 
     for (int k = 0; k < N / 2; k++) q[k] = make_double2(v[2 * k], v[2 * k + 1]);
 }
 
-__global__ __launch_bounds__(256) void k_linearize(BADev d, int ignore_outliers, int respect_done)
+__device__ __forceinline__ void linearize_body(const BADev &d, int ignore_outliers, int respect_done)
 {
     const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
     __shared__ double sh[4];
@@ -260,6 +276,7 @@ __global__ __launch_bounds__(256) void k_linearize(BADev d, int ignore_outliers,
     const double t = block_sum(ss, sh);
     if (threadIdx.x == 0) d.part[blockIdx.x] = t;
 }
+__global__ __launch_bounds__(256) void k_linearize(BADev d, int ignore_outliers, int respect_done) { linearize_body(d, ignore_outliers, respect_done); }
 
 __device__ __forceinline__ void inv3_sym(const double V[6], double I[6])
 {
@@ -420,10 +437,17 @@ __global__ __launch_bounds__(256) void k_blocks(BADev d, int use_state)
 #define SG_T 512
 #define SG_OB 448
 #define SG_SB 56
-static size_t sg_lds_bytes(int whb)
+// byte offset of s_dg = end of the phase 0-2 arrays, or of the fold buffers of phase 3 that overlay them (whichever is larger)
+__host__ __device__ __forceinline__ size_t sg_dg_off(int whb, int ob, int sb, int nthreads)
 {
-    const int hbw = whb + 1, nwin = hbw * (hbw + 1) / 2;
-    return ((((size_t)SG_OB * 36 + (size_t)SG_SB * 10 + 8) * 8 + (size_t)SG_SB * hbw * 2 + (size_t)nwin * 2 + 15) & ~(size_t)15) + (size_t)hbw * 36 * 8 + 16;
+    const int hbw = whb + 1, nwin = hbw * (hbw + 1) / 2, LPS = (nwin + 63) & ~63, NS = nthreads / LPS;
+    const size_t lay = (((size_t)ob * 36 + (size_t)sb * 10 + 8) * 8 + (size_t)sb * hbw * 2 + (size_t)nwin * 2 + 15) & ~(size_t)15;
+    const size_t fold = NS >= 1 ? ((((size_t)(NS - 1) * nwin * 36 + (size_t)(NS - 1) * hbw * 6 * 7) * 8 + 15) & ~(size_t)15) : 0;
+    return lay > fold ? lay : fold;
+}
+static size_t sg_lds_bytes(int whb, int P, int ob = SG_OB, int sb = SG_SB, int nthreads = 512)
+{
+    return sg_dg_off(whb, ob, sb, nthreads) + (size_t)(whb + 1) * 36 * 8 + (size_t)P * 6 * 8 + 16;
 }
 
 // sum over NS adjacent lanes (NS a power of two, uniform): DPP moves up to 16 lanes -- a ds_bpermute butterfly of the 36 block
@@ -449,7 +473,7 @@ __device__ __forceinline__ double sg_fold(double v, int NS)
 #ifdef SG_TRACE
 #define SG_CLK_DECL long long sg_clk[12]; const long long sg_t0 = clock64()
 #define SG_CLK(k) sg_clk[k] = clock64() - sg_t0
-#define SG_DUMP() do { if (threadIdx.x == 0 && blockIdx.x == 100 && d.st->iters == 3) printf("schur group: npts %d nobs %d | init %lld ph0 %lld bar %lld ph1 %lld ph2 %lld ph3 %lld bar %lld fold %lld tail %lld cycles\n", npts, nobs, sg_clk[0], sg_clk[1] - sg_clk[0], sg_clk[2] - sg_clk[1], sg_clk[3] - sg_clk[2], sg_clk[4] - sg_clk[3], sg_clk[8] - sg_clk[4], sg_clk[9] - sg_clk[8], sg_clk[5] - sg_clk[9], sg_clk[6] - sg_clk[5]); } while (0)
+#define SG_DUMP() do { if (threadIdx.x == 0 && blockIdx.x == (gridDim.y > 1 ? 10 : 100) && blockIdx.y == (gridDim.y > 1 ? 5 : 0) && d.st->iters == 3) printf("schur group: npts %d nobs %d | init %lld ph0 %lld bar %lld ph1 %lld ph2 %lld ph3 %lld bar %lld fold %lld tail %lld cycles\n", npts, nobs, sg_clk[0], sg_clk[1] - sg_clk[0], sg_clk[2] - sg_clk[1], sg_clk[3] - sg_clk[2], sg_clk[4] - sg_clk[3], sg_clk[8] - sg_clk[4], sg_clk[9] - sg_clk[8], sg_clk[5] - sg_clk[9], sg_clk[6] - sg_clk[5]); } while (0)
 #else
 #define SG_CLK_DECL
 #define SG_CLK(k)
@@ -463,7 +487,8 @@ static bool sg_fold_fits(int whb)
     return NS >= 1 && ((size_t)(NS - 1) * nwin * 36 + (size_t)(NS - 1) * hbw * 6 * 7) * 8 <= dg_off;
 }
 
-__global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta_host, int ignore_outliers, int use_state)
+template <int TT>      // threads per workgroup: SG_T, or 256 for a batch of windows whose groups all have <= 256 observations (two to three workgroups per compute unit)
+__device__ __forceinline__ void schur_groups_body(const BADev &d, double inv_delta_host, int ignore_outliers, int use_state)
 {
     const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
     extern __shared__ __attribute__((aligned(16))) double sg_lds[];
@@ -473,16 +498,19 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
     const int4 G = d.grp[blockIdx.x];                       // first point, first observation, f | points << 16, observations
     const int k0 = G.x, o0 = G.y, f = G.z & 0xffff, npts = G.z >> 16, nobs = G.w;
     const int hbw = d.whb + 1, nwin = hbw * (hbw + 1) / 2;
-    double *s_W = sg_lds;                          // [SG_OB][18]   (phases 0-1: [t][9] = Jl'Jl (6), Jl'f (3))
-    double *s_Jp = s_W + SG_OB * 18;               // [SG_OB][12]
-    double *s_g = s_Jp + SG_OB * 12;               // [SG_OB][6]
-    double *s_pt = s_g + SG_OB * 6;                // [SG_SB][10]   V^-1 (6), bl (3), pad
-    double *s_red = s_pt + SG_SB * 10;             // [8]
-    short *s_slot = (short *)(s_red + 8);          // [SG_SB][hbw]  observation (index in the group) of point x in window slot y, or -1
-    unsigned char *s_ab = (unsigned char *)(s_slot + SG_SB * hbw);   // [nwin][2]
-    double *s_dg = sg_lds + (((((size_t)SG_OB * 36 + (size_t)SG_SB * 10 + 8) * 8 + (size_t)SG_SB * hbw * 2 + (size_t)nwin * 2 + 15) & ~(size_t)15) >> 3);   // [hbw][36] Jp'Jp per window slot
-    for (int x = tid; x < npts * hbw; x += SG_T) s_slot[x] = -1;
-    for (int w = tid; w < nwin; w += SG_T) {
+    const int OBc = d.sg_ob, SBc = d.sg_sb;        // layout capacities (SG_OB / SG_SB, or the largest group of a batch of small windows)
+    double *s_W = sg_lds;                          // [OBc][18]   (phases 0-1: [t][9] = Jl'Jl (6), Jl'f (3))
+    double *s_Jp = s_W + OBc * 18;                 // [OBc][12]
+    double *s_g = s_Jp + OBc * 12;                 // [OBc][6]
+    double *s_pt = s_g + OBc * 6;                  // [SBc][10]   V^-1 (6), bl (3), pad
+    double *s_red = s_pt + SBc * 10;               // [8]
+    short *s_slot = (short *)(s_red + 8);          // [SBc][hbw]  observation (index in the group) of point x in window slot y, or -1
+    unsigned char *s_ab = (unsigned char *)(s_slot + SBc * hbw);   // [nwin][2]
+    double *s_dg = sg_lds + (sg_dg_off(d.whb, OBc, SBc, TT) >> 3);     // [hbw][36] Jp'Jp per window slot
+    double *s_sc = s_dg + hbw * 36;                                    // [P][6] sin / cos of every pose's angles (pose_sincos)
+    for (int p = tid; p < d.P; p += TT) pose_sincos(pb.pose + 6 * p, s_sc + 6 * p);
+    for (int x = tid; x < npts * hbw; x += TT) s_slot[x] = -1;
+    for (int w = tid; w < nwin; w += TT) {
         int a = 0, r = w;
         while (r >= hbw - a) { r -= hbw - a; a++; }
         s_ab[2 * w] = (unsigned char)a; s_ab[2 * w + 1] = (unsigned char)(a + r);
@@ -504,10 +532,12 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
         const bool hp = active && !d.pconst[p];
         if (active) {
             const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
-            double pose[6];
+            double sc[6], tr[3];
 #pragma unroll
-            for (int k = 0; k < 6; k++) pose[k] = pb.pose[6 * p + k];
-            obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r2, Jp, Jl, nullptr);
+            for (int k = 0; k < 6; k++) sc[k] = s_sc[6 * p + k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) tr[k] = pb.pose[6 * p + 3 + k];
+            obs_eval_sc(sc, tr, X, d.pix[i], d.pix[O + i], d.cam, r2, Jp, Jl, nullptr);
             if (!hp) {
 #pragma unroll
                 for (int k = 0; k < 12; k++) Jp[k] = 0.0;
@@ -579,7 +609,7 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
     //      registers (42 LDS doubles per 162 fused multiply-adds).  The first 6 (hb + 1) lanes of a subset then take one row of
     //      Jp'Jp and one gradient entry of a window slot each.  The subsets are folded through LDS in subset order by subset 0.
     {
-        const int LPS = (nwin + 63) & ~63, NS = SG_T / LPS;                        // 8 subsets for hb <= 9, 4 up to 14, 2 up to 20
+        const int LPS = (nwin + 63) & ~63, NS = TT / LPS;                          // 8 subsets for hb <= 9, 4 up to 14, 2 up to 20
         const int sub = tid / LPS, w = tid - sub * LPS;
         const bool live = sub < NS && w < nwin, xl = sub < NS && w < hbw * 6;      // (LPS = 192 leaves 128 threads over: they are no subset)
         const int a = s_ab[live ? 2 * w : 0], b = s_ab[live ? 2 * w + 1 : 1];
@@ -665,9 +695,10 @@ __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta
     SG_CLK(6);
     SG_DUMP();
 }
+__global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta_host, int ignore_outliers, int use_state) { schur_groups_body<SG_T>(d, inv_delta_host, ignore_outliers, use_state); }
 
 // S, g, diag(U) from the window partials: thread = (band block (p, p + dq), entry) / (pose, gradient or diagonal entry)
-__global__ __launch_bounds__(256) void k_schur_reduce(BADev d, int use_state)
+__device__ __forceinline__ void schur_reduce_body(const BADev &d, int use_state)
 {
     if (use_state && d.st->converged) return;
     const int idx = blockIdx.x * 256 + threadIdx.x, P = d.P, n = d.n;
@@ -715,6 +746,7 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BADev d, int use_state)
     }
     if (r < 6) d.g[6 * p + r] = sum; else d.udiag[6 * p + r - 6] = sum;
 }
+__global__ __launch_bounds__(256) void k_schur_reduce(BADev d, int use_state) { schur_reduce_body(d, use_state); }
 
 // ---- damped solve of the reduced camera system ----------------------------------
 // Tiled right-looking Cholesky over 32x32 tiles, one launch per tile column, every
@@ -1028,7 +1060,7 @@ __device__ __forceinline__ void bs_barrier()
 #define BS_T 512      /* eight waves, two per SIMD (256 registers each, no spills); roles in the column loop: see there */
 #define BS_PT 128     /* threads of the prefetch waves (3 and 7) */
 #define BS_UT 128     /* threads of the update waves (1-2) */
-__global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int use_state)
+__device__ __forceinline__ void band_solve_body(const BADev &d, const BandArgs &B, int use_state)
 {
     if (use_state && d.st->converged) return;
     extern __shared__ __attribute__((aligned(16))) double bs_sm[];
@@ -1780,6 +1812,7 @@ __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int us
         if (tid == 192) { B.trace[8] = trW; B.trace[9] = trC; }
     }
 }
+__global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int use_state) { band_solve_body(d, B, use_state); }
 
 __global__ __launch_bounds__(256) void k_backsub(BADev d, int use_state)
 {
@@ -1850,7 +1883,8 @@ __global__ __launch_bounds__(256) void k_trial(BADev d, int ignore_outliers, int
 // k_backsub + k_trial on the point groups of k_schur_groups (one workgroup per group, dp in LDS): thread = observation forms
 // Jl' (Jp dp), thread = point sums them in observation order, dl = V^-1 (bl - sum), trial point; thread = observation again: trial
 // and predicted residual.  Partials: part[g] = max |dx|, part[ngrp + 2 g] = trial cost, part[ngrp + 2 g + 1] = predicted cost.
-__global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outliers, int use_state)
+template <int TT>
+__device__ __forceinline__ void update_groups_body(const BADev &d, int ignore_outliers, int use_state)
 {
     const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
     __shared__ double s_dp[SOLVE_MAX_N];
@@ -1861,11 +1895,16 @@ __global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outl
     const int tid = threadIdx.x, M = d.M, O = d.O, n = d.n;
     const int4 G = d.grp[blockIdx.x];
     const int k0 = G.x, o0 = G.y, npts = G.z >> 16, nobs = G.w;
-    for (int a = tid; a < n; a += SG_T) s_dp[a] = d.dp[a];
+    __shared__ double s_sct[SOLVE_MAX_N];                  // sin / cos of every TRIAL pose's angles
+    for (int a = tid; a < n; a += TT) s_dp[a] = d.dp[a];
     lds_sync();
+    for (int q = tid; q < d.P; q += TT) {
+        const double tp[3] = {pb.pose[6 * q] - s_dp[6 * q], pb.pose[6 * q + 1] - s_dp[6 * q + 1], pb.pose[6 * q + 2] - s_dp[6 * q + 2]};
+        pose_sincos(tp, s_sct + 6 * q);
+    }
     double mx = 0.0;
     if (blockIdx.x == 0)
-        for (int a = tid; a < n; a += SG_T) { const double v = s_dp[a]; pb.pose_t[a] = pb.pose[a] - v; mx = fmax(mx, fabs(v)); }
+        for (int a = tid; a < n; a += TT) { const double v = s_dp[a]; pb.pose_t[a] = pb.pose[a] - v; mx = fmax(mx, fabs(v)); }
     const int i = o0 + tid;
     int p = 0, pl = 0;
     double jp[12], jl[6], ff[2] = {0.0, 0.0}, a = 0.0, b = 0.0;
@@ -1908,10 +1947,12 @@ __global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outl
         const double *dl = s_dl + pl * 6;
         if (active) {
             const double X[3] = {dl[3], dl[4], dl[5]};
-            double pose[6];
+            double sc[6], tr[3];
 #pragma unroll
-            for (int k = 0; k < 6; k++) pose[k] = pb.pose[6 * p + k] - s_dp[6 * p + k];
-            obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, nullptr);
+            for (int k = 0; k < 6; k++) sc[k] = s_sct[6 * p + k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) tr[k] = pb.pose[6 * p + 3 + k] - s_dp[6 * p + 3 + k];
+            obs_eval_sc(sc, tr, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, nullptr);
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) { a += jl[k] * dl[k]; b += jl[3 + k] * dl[k]; }
@@ -1924,6 +1965,7 @@ __global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outl
     const double t3 = block_max_lds(mx, s_red);
     if (tid == 0) { d.part[blockIdx.x] = t3; d.part[d.ngrp + 2 * blockIdx.x] = t1; d.part[d.ngrp + 2 * blockIdx.x + 1] = t2; }
 }
+__global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outliers, int use_state) { update_groups_body<SG_T>(d, ignore_outliers, use_state); }
 
 // Sums the partials (fixed order) and, in the single-GPU path, runs the
 // LeastSquaresOptim accept/reject logic.  mode 0: ssr of the current residuals
@@ -1966,7 +2008,7 @@ __device__ __forceinline__ void lm_decide(LMState *s, double t, double p, double
         s->converged = mx <= LM_XTOL;
     }
 }
-__global__ __launch_bounds__(256) void k_control(BADev d, int mode, int nb_obs, int nb_pts, int lm, double *out4)
+__device__ __forceinline__ void control_body(const BADev &d, int mode, int nb_obs, int nb_pts, int lm, double *out4)
 {
     __shared__ double sh[4];
     LMState *s = d.st;
@@ -1987,6 +2029,7 @@ __global__ __launch_bounds__(256) void k_control(BADev d, int mode, int nb_obs, 
     if (!lm) return;
     lm_decide(s, t, p, mx);
 }
+__global__ __launch_bounds__(256) void k_control(BADev d, int mode, int nb_obs, int nb_pts, int lm, double *out4) { control_body(d, mode, nb_obs, nb_pts, lm, out4); }
 
 // The sharded path: every rank's [trial_ssr, pred_ssr, max|dx|, chol_fail] gathered into g (nranks x 4).  Sums / maxima in
 // rank order, then the same decision as the single-GPU path -- identical on every rank, taken on the device.
@@ -2029,7 +2072,7 @@ __global__ void k_lm_reset(BADev d, int pass)
 }
 
 // _ba_detect_outliers!, bundle_adjustment.jl:90-111
-__global__ __launch_bounds__(256) void k_outliers(BADev d, double repr_eps, double depth_eps)
+__device__ __forceinline__ void outliers_body(const BADev &d, double repr_eps, double depth_eps)
 {
     const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
     __shared__ double sh[4];
@@ -2049,11 +2092,114 @@ __global__ __launch_bounds__(256) void k_outliers(BADev d, double repr_eps, doub
     const double t = block_sum(c, sh);
     if (threadIdx.x == 0) d.part[blockIdx.x] = t;
 }
-__global__ __launch_bounds__(256) void k_outlier_count(BADev d, int nb_obs)
+__global__ __launch_bounds__(256) void k_outliers(BADev d, double repr_eps, double depth_eps) { outliers_body(d, repr_eps, depth_eps); }
+__device__ __forceinline__ void outlier_count_body(const BADev &d, int nb_obs)
 {
     __shared__ double sh[4];
     const double t = ctl_sum(d.part, nb_obs, 1, sh);           // counts: exact in any order
     if (threadIdx.x == 0) d.st->n_outliers = (int)t;
+}
+__global__ __launch_bounds__(256) void k_outlier_count(BADev d, int nb_obs) { outlier_count_body(d, nb_obs); }
+
+// ---- the same kernels for a BATCH of windows (slam_local_ba_batch): blockIdx.y = window.  A window's BADev / BandArgs sit in a device
+// table that is read through the constant address space with a wave-uniform index -- scalar loads into SGPRs, exactly where a by-value
+// kernel argument lives (a generic pointer into the table moved the plane pointers into VGPRs and reloaded them after every store) --
+// and the grid's x extent is the largest window's: workgroups beyond a window's own count leave at once.  Every window runs its own
+// device-side LM state; a converged window's workgroups early-out as in the single-window path.
+struct BAWin { BADev d; BandArgs B; int nb_obs, nb_pts, n_red, pad; };
+static_assert(sizeof(BAWin) % 8 == 0, "BAWin is copied as 64-bit words");
+__device__ __forceinline__ BAWin ba_win(const BAWin *tab)
+{
+    typedef const __attribute__((address_space(4))) unsigned long long *cq_t;
+    cq_t q = (cq_t)(const void *)(tab + blockIdx.y);
+    unsigned long long raw[sizeof(BAWin) / 8];
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(BAWin) / 8); k++) raw[k] = q[k];
+    BAWin w;
+    __builtin_memcpy(&w, raw, sizeof w);
+    return w;
+}
+__global__ __launch_bounds__(256) void k_linearize_b(const BAWin *tab, int ignore_outliers, int respect_done)
+{
+    const BAWin w = ba_win(tab);
+    if ((int)blockIdx.x >= w.nb_obs) return;
+    linearize_body(w.d, ignore_outliers, respect_done);
+}
+// start of a pass: ssr of the current residuals (k_control mode 0) + the reset of the LM state (k_lm_reset), one launch
+__global__ __launch_bounds__(256) void k_pass_start_b(const BAWin *tab, int pass)
+{
+    const BAWin w = ba_win(tab);
+    control_body(w.d, 0, w.nb_obs, w.nb_pts, 0, nullptr);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    LMState *s = w.d.st;
+    if (pass == 0) { s->ssr_init = s->ssr; s->chol_fail = 0; s->n_outliers = 0; }
+    s->delta = LM_DELTA0; s->decrease_factor = 2.0; s->converged = 0; s->accept = 0; s->iters = 0;
+}
+template <int TT> __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(3))) void k_schur_groups_b(const BAWin *tab, int ignore_outliers)
+{
+    const BAWin w = ba_win(tab);
+    if ((int)blockIdx.x >= w.d.ngrp) return;
+    schur_groups_body<TT>(w.d, 0.0, ignore_outliers, 1);
+}
+__global__ __launch_bounds__(256) void k_schur_reduce_b(const BAWin *tab)
+{
+    const BAWin w = ba_win(tab);
+    if ((int)blockIdx.x >= w.n_red) return;
+    schur_reduce_body(w.d, 1);
+}
+__global__ __launch_bounds__(BS_T) void k_band_solve_b(const BAWin *tab)
+{
+    const BAWin w = ba_win(tab);
+    band_solve_body(w.d, w.B, 1);
+}
+template <int TT> __global__ __launch_bounds__(TT) void k_update_groups_b(const BAWin *tab, int ignore_outliers)
+{
+    const BAWin w = ba_win(tab);
+    if ((int)blockIdx.x >= w.d.ngrp) return;
+    update_groups_body<TT>(w.d, ignore_outliers, 1);
+}
+__global__ __launch_bounds__(256) void k_control_b(const BAWin *tab)
+{
+    const BAWin w = ba_win(tab);
+    control_body(w.d, 1, w.d.ngrp, w.d.ngrp, 1 | 2, nullptr);
+}
+// end of pass 1: record it, flag the outliers at theta_1 (bundle_adjustment.jl:45); the count follows in k_outlier_count_b
+__global__ __launch_bounds__(256) void k_outliers_b(const BAWin *tab, double repr_eps, double depth_eps)
+{
+    const BAWin w = ba_win(tab);
+    if ((int)blockIdx.x >= w.nb_obs) return;
+    outliers_body(w.d, repr_eps, depth_eps);
+}
+__global__ __launch_bounds__(256) void k_outlier_count_b(const BAWin *tab)
+{
+    const BAWin w = ba_win(tab);
+    LMState *s = w.d.st;
+    if (threadIdx.x == 0) { s->ssr_pass1 = s->ssr; s->iters_pass1 = s->iters; }
+    outlier_count_body(w.d, w.nb_obs);
+}
+// end of pass 2: record it and pack every window's result -- committed parameters (solver's pose order), LM state, outlier flags (sorted
+// observation order) -- into one contiguous block for a single device -> host copy.  res: per window [LMState | theta 6P + 3M | outl O]
+struct BARes { size_t off_state, off_theta, off_outl; };
+__global__ __launch_bounds__(256) void k_results_b(const BAWin *tab, const BARes *rtab, char *res)
+{
+    const BAWin w = ba_win(tab);
+    const BADev &d = w.d;
+    LMState *s = d.st;
+    const BARes r = rtab[blockIdx.y];
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    const int cur = s->cur;
+    const double *pose = cur ? d.pose_t : d.pose, *pts = cur ? d.pts_t : d.pts;
+    double *th = (double *)(res + r.off_theta);
+    for (int i = tid; i < d.n; i += nth) th[i] = pose[i];
+    for (int i = tid; i < 3 * d.M; i += nth) th[d.n + i] = pts[i];
+    uint8_t *ol = (uint8_t *)(res + r.off_outl);
+    for (int i = tid; i < d.O; i += nth) ol[i] = d.outl[i];
+    if (tid == 0) {
+        LMState h = *s;
+        h.ssr_final = h.ssr; h.iters_pass2 = h.iters;
+        *(LMState *)(res + r.off_state) = h;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -2136,69 +2282,40 @@ static bool ba_pose_order(int P, int M, int O, const uint8_t *theta_const, const
     return true;
 }
 
-static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, int P, int M, int O,
-                    const double *theta, const uint8_t *theta_const_in, const double *pixels_yx,
-                    const int64_t *pose_ids, const int64_t *point_ids, slam_ba **out, bool ctx_mem = false, bool may_reorder = false)
-{
-    const uint8_t *theta_const = theta_const_in;
-    ARG_TRY(ctx, P > 0 && 6 * P <= SOLVE_MAX_N && M >= 0 && O >= 0 && theta != nullptr && theta_const != nullptr);
-    ARG_TRY(ctx, O == 0 || (pixels_yx != nullptr && pose_ids != nullptr && point_ids != nullptr));
-    slam_ba *ba = new slam_ba();
-    ba->device = ctx->device;
-    const int n = 6 * P;
-    // --- host-side structure.  Map points sorted by (first free observing pose f, id); observations sorted by point in
-    //     that order (stable).  hb = widest span of free observers of one point = block half-bandwidth of S.
-    std::vector<int> cnt(M), pfirst(M), plast(M), pany(M), new_of;      // new_of: the caller's pose -> the solver's (empty: the same)
+// ---- set-up of one window, in two host-only halves so that a batch of windows can be prepared by several threads:
+//   ba_plan   the structure of the problem (map points sorted by first free observer, observation order, point groups or pair lists,
+//             pose order) and the layout of its device memory in three regions -- uploaded arrays, zero-initialised state, work arrays;
+//   ba_emit   binds the device pointers to the three region bases and writes the uploaded region into a host staging block.
+// slam_ba_create / slam_local_ba give one window its own arena (the three regions back to back); slam_local_ba_batch lays the
+// regions of all windows out region-major (one H2D copy, one memset for the whole batch).  Neither half makes a HIP call.
+struct BAPlan {
+    // inputs
+    double fx = 0, fy = 0, cx = 0, cy = 0; int P = 0, M = 0, O = 0;
+    const double *theta = nullptr; const uint8_t *theta_const_in = nullptr; const double *pixels_yx = nullptr;
+    const int64_t *pose_ids = nullptr, *point_ids = nullptr;
+    bool may_reorder = false, small_groups = false;
+    // results
+    slam_ba *ba = nullptr;
+    int err = 0; char msg[160] = {0};
+    std::vector<int> cnt, pfirst, new_of, pt_id, rank, start, fgrp;
     std::vector<uint8_t> const_perm;
-    auto lab = [&](int64_t id) { return new_of.empty() ? (int)id - 1 : new_of[id - 1]; };
-    int hb = 0, bad_obs = -1;
-    auto spans = [&]() {                                     // (the first pass also checks the ids: one walk over the observations, not two)
-        std::fill(cnt.begin(), cnt.end(), 0); std::fill(pfirst.begin(), pfirst.end(), P); std::fill(plast.begin(), plast.end(), -1); std::fill(pany.begin(), pany.end(), P);
-        for (int i = 0; i < O; i++) {
-            if (pose_ids[i] < 1 || pose_ids[i] > P || point_ids[i] < 1 || point_ids[i] > M) { bad_obs = i; return; }
-            const int j = (int)point_ids[i] - 1, p = lab(pose_ids[i]);
-            cnt[j]++; pany[j] = std::min(pany[j], p);
-            if (!theta_const[p]) { pfirst[j] = std::min(pfirst[j], p); plast[j] = std::max(plast[j], p); }
-        }
-        hb = 0;
-        for (int j = 0; j < M; j++) {
-            if (plast[j] >= 0) hb = std::max(hb, plast[j] - pfirst[j]);
-            else pfirst[j] = pany[j] < P ? pany[j] : 0;          // no free observer: any window will do (it gets no slot)
-        }
-    };
-    spans();
-    if (bad_obs >= 0) {
-        const long long bp = pose_ids[bad_obs], bl = point_ids[bad_obs];
-        delete ba;
-        return slam_fail(ctx, SLAM_ERR_ARG, "slam_ba: observation %d has pose id %lld / point id %lld out of range", bad_obs, bp, bl);
-    }
-    static const bool no_reorder = getenv("SLAMHIP_BA_NO_REORDER") != nullptr;      // (measurement knob)
-    if (may_reorder && !no_reorder && M > 0 && O > 0 && (hb > BS_MAXHB || !sg_fold_fits(hb)) && ba_pose_order(P, M, O, theta_const_in, pose_ids, point_ids, ba->pose_order)) {
-        // not banded in the caller's pose order, banded in another one: the solver works on relabelled poses, ba_download restores the order
-        new_of.resize(P); const_perm.resize(P);
-        for (int k = 0; k < P; k++) { new_of[ba->pose_order[k]] = k; const_perm[k] = theta_const_in[ba->pose_order[k]]; }
-        theta_const = const_perm.data();
-        spans();
-    }
-    ba->hb = hb;
-    {   int f0 = P, f1 = -1;
-        for (int p = 0; p < P; p++) if (!theta_const[p]) { f0 = std::min(f0, p); f1 = std::max(f1, p); }
-        if (f1 - f0 + 1 >= 2) { ba->p0 = f0; ba->pspan = f1 - f0 + 1; } else { ba->p0 = 0; ba->pspan = P; } }
-    std::vector<int> pt_id(M), rank(M), start(M + 1, 0);
-    { std::vector<int> fb(P + 1, 0);
-      for (int j = 0; j < M; j++) fb[pfirst[j] + 1]++;
-      for (int p = 0; p < P; p++) fb[p + 1] += fb[p];
-      for (int j = 0; j < M; j++) { const int k = fb[pfirst[j]]++; pt_id[k] = j; rank[j] = k; } }
-    for (int k = 0; k < M; k++) start[k + 1] = start[k] + cnt[pt_id[k]];
-    // The per-observation arrays (sorted by point): ONE walk over the caller's observations -- the sorted position of observation i is the
-    // next free one of its point -- writing straight into the pinned upload block when that exists by then (slam_local_ba on the grouped
-    // path: the arena's layout does not depend on these arrays), into host vectors otherwise (the pair lists are built from them).
-    // The walk also finds a map point observed twice by one free pose: it has no place in a pose block (does not happen in the
-    // reference's feeder).  At O = 4e5 the set-up took 3.4 ms of an 8 ms call: a pass for the ids, one for the permutation, one gathering
-    // through it, one for the check, and a copy of everything into the pinned block.
-    ba->perm.assign(O, 0);
+    std::vector<int4> grp;
+    std::vector<int2> pairs, blk_pq; std::vector<int> blk_start;
+    std::vector<int> v_opose, v_opoint, v_opk; std::vector<double> v_pix; bool filled = false;
+    const uint8_t *theta_const = nullptr;
+    size_t npairs = 0; int nblk = 0, ngrp = 0, wstride = 0, hb = 0, sg_ob = SG_OB, sg_sb = SG_SB;
     int twice_pt = -1, twice_pose = -1;
-    auto fill_obs = [&](int *opose, int *opoint, int *opk, double *pix) {
+    // layout: offsets inside the three regions
+    size_t o_pose, o_pts, o_const, o_pix, o_opose, o_opoint, o_start, o_ptid, o_opk, o_grp, o_fgrp, o_pairs, o_bs, o_bpq, up_bytes = 0;
+    size_t o_st, o_cf, o_outl, zero_bytes = 0;
+    size_t o_pose_t, o_pts_t, o_hasp, o_f, o_ft, o_Jp, o_Jl, o_Vinv, o_bl, o_T, o_W, o_red, o_Sw, o_dp, o_dl, o_li, o_lf, o_part, o_band, o_wpart, o_xchg, work_bytes = 0;
+    ~BAPlan() { delete ba; }
+    int lab(int64_t id) const { return new_of.empty() ? (int)id - 1 : new_of[id - 1]; }
+    int fail(int code, const char *fmt, long long a = 0, long long b = 0, long long c = 0) { err = code; snprintf(msg, sizeof msg, fmt, a, b, c); return code; }
+    // the per-observation arrays (sorted by point): ONE walk over the caller's observations -- the sorted position of observation i is the
+    // next free one of its point.  The walk also finds a map point observed twice by one free pose: it has no place in a pose block.
+    void fill_obs(int *opose, int *opoint, int *opk, double *pix)
+    {
         std::vector<int> fill(start.begin(), start.end() - 1), seen((size_t)P, -1);     // seen[p]: the last point (sorted position) free pose p observed
         for (int i = 0; i < O; i++) {
             const int j = (int)point_ids[i] - 1, k = rank[j], s = fill[k]++;
@@ -2213,21 +2330,79 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
                 if (seen[p] == k) { twice_pt = pt_id[k]; twice_pose = new_of.empty() ? p : ba->pose_order[p]; break; }
                 seen[p] = k;
             }
+    }
+};
+
+static int ba_plan(BAPlan &pl)
+{
+    const int P = pl.P, M = pl.M, O = pl.O;
+    const int64_t *pose_ids = pl.pose_ids, *point_ids = pl.point_ids;
+    if (!(P > 0 && 6 * P <= SOLVE_MAX_N && M >= 0 && O >= 0 && pl.theta != nullptr && pl.theta_const_in != nullptr)) return pl.fail(SLAM_ERR_ARG, "slam_ba: bad arguments (P %lld, M %lld, O %lld)", P, M, O);
+    if (!(O == 0 || (pl.pixels_yx != nullptr && pose_ids != nullptr && point_ids != nullptr))) return pl.fail(SLAM_ERR_ARG, "slam_ba: observations without arrays");
+    pl.theta_const = pl.theta_const_in;
+    const uint8_t *&theta_const = pl.theta_const;
+    slam_ba *ba = pl.ba = new slam_ba();
+    const int n = 6 * P;
+    // --- host-side structure.  Map points sorted by (first free observing pose f, id); observations sorted by point in
+    //     that order (stable).  hb = widest span of free observers of one point = block half-bandwidth of S.
+    std::vector<int> &cnt = pl.cnt, &pfirst = pl.pfirst, plast(M), pany(M);
+    cnt.assign(M, 0); pfirst.assign(M, 0);
+    int hb = 0, bad_obs = -1;
+    auto spans = [&]() {                                     // (the first pass also checks the ids: one walk over the observations, not two)
+        std::fill(cnt.begin(), cnt.end(), 0); std::fill(pfirst.begin(), pfirst.end(), P); std::fill(plast.begin(), plast.end(), -1); std::fill(pany.begin(), pany.end(), P);
+        for (int i = 0; i < O; i++) {
+            if (pose_ids[i] < 1 || pose_ids[i] > P || point_ids[i] < 1 || point_ids[i] > M) { bad_obs = i; return; }
+            const int j = (int)point_ids[i] - 1, p = pl.lab(pose_ids[i]);
+            cnt[j]++; pany[j] = std::min(pany[j], p);
+            if (!theta_const[p]) { pfirst[j] = std::min(pfirst[j], p); plast[j] = std::max(plast[j], p); }
+        }
+        hb = 0;
+        for (int j = 0; j < M; j++) {
+            if (plast[j] >= 0) hb = std::max(hb, plast[j] - pfirst[j]);
+            else pfirst[j] = pany[j] < P ? pany[j] : 0;          // no free observer: any window will do (it gets no slot)
+        }
     };
-    auto twice_error = [&]() { return slam_fail(ctx, SLAM_ERR_ARG, "slam_ba: map point %d is observed twice by pose %d", twice_pt + 1, twice_pose + 1); };
-    std::vector<int> v_opose, v_opoint, v_opk;
-    std::vector<double> v_pix;
+    spans();
+    if (bad_obs >= 0) return pl.fail(SLAM_ERR_ARG, "slam_ba: observation %lld has pose id %lld / point id %lld out of range", bad_obs, pose_ids[bad_obs], point_ids[bad_obs]);
+    static const bool no_reorder = getenv("SLAMHIP_BA_NO_REORDER") != nullptr;      // (measurement knob)
+    if (pl.may_reorder && !no_reorder && M > 0 && O > 0 && (hb > BS_MAXHB || !sg_fold_fits(hb)) && ba_pose_order(P, M, O, pl.theta_const_in, pose_ids, point_ids, ba->pose_order)) {
+        // not banded in the caller's pose order, banded in another one: the solver works on relabelled poses, ba_download restores the order
+        pl.new_of.resize(P); pl.const_perm.resize(P);
+        for (int k = 0; k < P; k++) { pl.new_of[ba->pose_order[k]] = k; pl.const_perm[k] = pl.theta_const_in[ba->pose_order[k]]; }
+        theta_const = pl.const_perm.data();
+        spans();
+    }
+    ba->hb = hb; pl.hb = hb;
+    {   int f0 = P, f1 = -1;
+        for (int p = 0; p < P; p++) if (!theta_const[p]) { f0 = std::min(f0, p); f1 = std::max(f1, p); }
+        if (f1 - f0 + 1 >= 2) { ba->p0 = f0; ba->pspan = f1 - f0 + 1; } else { ba->p0 = 0; ba->pspan = P; } }
+    std::vector<int> &pt_id = pl.pt_id, &rank = pl.rank, &start = pl.start;
+    pt_id.assign(M, 0); rank.assign(M, 0); start.assign(M + 1, 0);
+    { std::vector<int> fb(P + 1, 0);
+      for (int j = 0; j < M; j++) fb[pfirst[j] + 1]++;
+      for (int p = 0; p < P; p++) fb[p + 1] += fb[p];
+      for (int j = 0; j < M; j++) { const int k = fb[pfirst[j]]++; pt_id[k] = j; rank[j] = k; } }
+    for (int k = 0; k < M; k++) start[k + 1] = start[k] + cnt[pt_id[k]];
+    ba->perm.assign(O, 0);
     // --- point groups of k_schur_groups: same f, <= SG_SB points, <= SG_OB observations; evenly sized within one f
     static const bool no_groups = getenv("SLAMHIP_NO_GROUPS") != nullptr;
     bool grouped = !no_groups && hb <= BS_MAXHB && M > 0 && O > 0 && sg_fold_fits(hb);
-    std::vector<int4> grp; std::vector<int> fgrp(P + 1, 0);
+    std::vector<int4> &grp = pl.grp; std::vector<int> &fgrp = pl.fgrp;
+    fgrp.assign(P + 1, 0);
+    int max_no = 0, max_np = 0;
     if (grouped) {
         static const int sg_points = [] { const char *v = getenv("SLAMHIP_SG_POINTS"); return v ? atoi(v) : 0; }();      // (measurement knob)
         // points per group: a small window in full groups occupies a few compute units and each workgroup walks 7 points per subset; with
         // 16-point groups the reference-shaped window (800 points: 18 -> 50 groups) builds in 0.75 instead of 0.83 ms per 15 iterations,
         // while anything that already fills the chip gets slower with more, smaller groups (more partials for k_schur_reduce, more than one
         // round of workgroups: P = 50 +12 % at 40 points per group) -- so: M / 96, between 16 and SG_SB
-        const int sb_eff = sg_points > 0 ? std::min(sg_points, SG_SB) : std::min(std::max((M + 95) / 96, 16), SG_SB);
+        // a batch of windows (small_groups) fills the chip whatever the group size: groups of <= 256 observations run as 256-thread
+        // workgroups, three to a compute unit (128 reference-shaped windows: 7.5 ms with the single-window sizes, 3.7 ms so)
+        int ob_cap = pl.small_groups ? 256 : SG_OB;
+        int sb_eff = sg_points > 0 ? std::min(sg_points, SG_SB)
+                   : pl.small_groups ? std::min(std::max(ob_cap / std::max(1, (O + M - 1) / M), 8), SG_SB)
+                   : std::min(std::max((M + 95) / 96, 16), SG_SB);
+        if (pl.small_groups) for (int j = 0; j < M; j++) if (cnt[j] > ob_cap) { ob_cap = SG_OB; sb_eff = std::min(sb_eff, SG_SB); break; }
         int k = 0;
         for (int f = 0; f < P && grouped; f++) {
             fgrp[f] = (int)grp.size();
@@ -2236,26 +2411,27 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
             const int nf = ke - k, ng = (nf + sb_eff - 1) / sb_eff, tgt = ng ? (nf + ng - 1) / ng : 0;
             while (k < ke) {
                 int k1 = k, no = 0;
-                while (k1 < ke && k1 - k < tgt && no + cnt[pt_id[k1]] <= SG_OB) { no += cnt[pt_id[k1]]; k1++; }
+                while (k1 < ke && k1 - k < tgt && no + cnt[pt_id[k1]] <= ob_cap) { no += cnt[pt_id[k1]]; k1++; }
                 if (k1 == k) { grouped = false; break; }          // one point with more than SG_OB observations: pair lists
                 grp.push_back(make_int4(k, start[k], f | ((k1 - k) << 16), no));
+                max_no = std::max(max_no, no); max_np = std::max(max_np, k1 - k);
                 k = k1;
             }
         }
         fgrp[P] = (int)grp.size();
     }
     ba->grouped = grouped;
+    if (grouped && pl.small_groups) { pl.sg_ob = std::max(64, (max_no + 7) & ~7); pl.sg_sb = std::max(8, (max_np + 1) & ~1); }
     const int *opose = nullptr;                              // sorted observation -> pose, host copy (needed by the pair lists)
-    bool filled = false;
-    if (!grouped || !ctx_mem) {
-        v_opose.resize(O); v_opoint.resize(O); v_opk.resize(O); v_pix.resize(2 * (size_t)O);
-        fill_obs(v_opose.data(), v_opoint.data(), v_opk.data(), v_pix.data());
-        filled = true;
-        if (twice_pt >= 0) { delete ba; return twice_error(); }
-        opose = v_opose.data();
+    if (!grouped) {
+        pl.v_opose.resize(O); pl.v_opoint.resize(O); pl.v_opk.resize(O); pl.v_pix.resize(2 * (size_t)O);
+        pl.fill_obs(pl.v_opose.data(), pl.v_opoint.data(), pl.v_opk.data(), pl.v_pix.data());
+        pl.filled = true;
+        if (pl.twice_pt >= 0) return pl.fail(SLAM_ERR_ARG, "slam_ba: map point %lld is observed twice by pose %lld", pl.twice_pt + 1, pl.twice_pose + 1);
+        opose = pl.v_opose.data();
     }
     // --- pair lists sorted by upper pose block (p <= q), both poses free: only where the groups do not apply
-    std::vector<int2> pairs; std::vector<int> blk_start; std::vector<int2> blk_pq;
+    std::vector<int2> &pairs = pl.pairs, &blk_pq = pl.blk_pq; std::vector<int> &blk_start = pl.blk_start;
     size_t npairs = 0;
     if (!grouped) {
         std::vector<int> bcount((size_t)P * P + 1, 0);
@@ -2290,87 +2466,118 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
             }
     }
     blk_start.push_back((int)npairs);
-    const int nblk = (int)blk_pq.size();
-    const int ngrp = (int)grp.size(), hbw = hb + 1, wstride = grouped ? hbw * (hbw + 1) / 2 * 36 + hbw * 12 : 0;
-
+    pl.npairs = npairs;
+    const int nblk = pl.nblk = (int)blk_pq.size();
+    const int ngrp = pl.ngrp = (int)grp.size(), hbw = hb + 1;
+    pl.wstride = grouped ? hbw * (hbw + 1) / 2 * 36 + hbw * 12 : 0;
     const int nbo = (O + 255) / 256, nbp = (std::max(M, n) + 255) / 256;
     ba->nblocks_obs = std::max(nbo, 1); ba->nblocks_pts = std::max(nbp, 1);
-    // --- one device arena
+    // --- layout: uploaded arrays (one contiguous block: a single copy from the staging buffer), the zero-initialised ones (one memset), the rest
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
-    // uploaded arrays first (one contiguous block: a single copy from the pinned staging buffer when the arena is the context's
-    // scratch), then the zero-initialised ones (one memset), then the rest
-    const size_t o_pose = take(n * 8), o_pts = take((size_t)3 * M * 8 + 8), o_const = take(P), o_pix = take((size_t)2 * O * 8 + 8);
-    const size_t o_opose = take((size_t)O * 4 + 4), o_opoint = take((size_t)O * 4 + 4), o_start = take((size_t)(M + 1) * 4);
-    const size_t o_ptid = take((size_t)M * 4 + 4), o_opk = take((size_t)O * 4 + 4), o_grp = take((size_t)ngrp * 16 + 16), o_fgrp = take((size_t)(P + 1) * 4);
-    const size_t o_pairs = take(npairs * 8 + 8), o_bs = take((size_t)(nblk + 1) * 4), o_bpq = take((size_t)nblk * 8 + 8);
-    const size_t up_end = off;
-    const size_t o_st = take(sizeof(LMState)), o_cf = take(64), o_outl = take((size_t)O + 1);
-    const size_t zero_end = off;
-    const size_t o_pose_t = take(n * 8), o_pts_t = take((size_t)3 * M * 8 + 8), o_hasp = take((size_t)O + 1);
-    const size_t o_f = take((size_t)2 * O * 8 + 8), o_ft = take(8);    // (trial residuals are not kept: every build re-evaluates d.f)
-    const size_t o_Jp = take((size_t)12 * O * 8 + 8), o_Jl = take((size_t)6 * O * 8 + 8);
-    const size_t o_Vinv = take((size_t)6 * M * 8 + 8), o_bl = take((size_t)3 * M * 8 + 8);
-    const size_t o_T = take(grouped ? 8 : (size_t)18 * O * 8 + 8), o_W = take(grouped ? 8 : (size_t)18 * O * 8 + 8);   // T / W records: pair-list path only
-    const size_t o_red = take(((size_t)n * n + 2 * n + 8) * 8), o_Sw = take((size_t)(n + 1) * n * 8), o_dp = take(n * 8), o_dl = take((size_t)3 * M * 8 + 8);
-    const size_t o_li = take((size_t)((n + CT - 1) / CT) * CT * CT * 8), o_lf = take((size_t)(n + 1) * n * 8);
-    const size_t o_part = take(((size_t)std::max(ba->nblocks_pts, ngrp) + 2 * (size_t)std::max(ba->nblocks_obs, ngrp) + 8) * 8);
-    const size_t o_band = take((size_t)P * ((size_t)(BS_MAXHB + 1) * 36 + 8) * 8);
-    const size_t o_wpart = take((size_t)ngrp * wstride * 8 + 8);
-    const size_t o_xchg = take(2048 * 8);
+    pl.o_pose = take(n * 8); pl.o_pts = take((size_t)3 * M * 8 + 8); pl.o_const = take(P); pl.o_pix = take((size_t)2 * O * 8 + 8);
+    pl.o_opose = take((size_t)O * 4 + 4); pl.o_opoint = take((size_t)O * 4 + 4); pl.o_start = take((size_t)(M + 1) * 4);
+    pl.o_ptid = take((size_t)M * 4 + 4); pl.o_opk = take((size_t)O * 4 + 4); pl.o_grp = take((size_t)ngrp * 16 + 16); pl.o_fgrp = take((size_t)(P + 1) * 4);
+    pl.o_pairs = take(npairs * 8 + 8); pl.o_bs = take((size_t)(nblk + 1) * 4); pl.o_bpq = take((size_t)nblk * 8 + 8);
+    pl.up_bytes = off; off = 0;
+    pl.o_st = take(sizeof(LMState)); pl.o_cf = take(64); pl.o_outl = take((size_t)O + 1);
+    pl.o_dp = take(n * 8);                                       // dp of the constant poses outside the solve's span stays zero
+    pl.o_red = take(((size_t)n * n + 2 * n + 8) * 8);            // the private reduce buffer: only its band is ever rewritten
+    pl.zero_bytes = off; off = 0;
+    pl.o_pose_t = take(n * 8); pl.o_pts_t = take((size_t)3 * M * 8 + 8); pl.o_hasp = take((size_t)O + 1);
+    pl.o_f = take((size_t)2 * O * 8 + 8); pl.o_ft = take(8);    // (trial residuals are not kept: every build re-evaluates d.f)
+    pl.o_Jp = take((size_t)12 * O * 8 + 8); pl.o_Jl = take((size_t)6 * O * 8 + 8);
+    pl.o_Vinv = take((size_t)6 * M * 8 + 8); pl.o_bl = take((size_t)3 * M * 8 + 8);
+    pl.o_T = take(grouped ? 8 : (size_t)18 * O * 8 + 8); pl.o_W = take(grouped ? 8 : (size_t)18 * O * 8 + 8);   // T / W records: pair-list path only
+    // (the tiled Cholesky's working matrices exist for every window: a window whose band does not fit k_band_solve's LDS takes that path)
+    pl.o_Sw = take((size_t)(n + 1) * n * 8); pl.o_dl = take((size_t)3 * M * 8 + 8);
+    pl.o_li = take((size_t)((n + CT - 1) / CT) * CT * CT * 8); pl.o_lf = take((size_t)(n + 1) * n * 8);
+    pl.o_part = take(((size_t)std::max(ba->nblocks_pts, ngrp) + 2 * (size_t)std::max(ba->nblocks_obs, ngrp) + 8) * 8);
+    pl.o_band = take((size_t)P * ((size_t)(BS_MAXHB + 1) * 36 + 8) * 8);
+    pl.o_wpart = take((size_t)ngrp * pl.wstride * 8 + 8);
+    pl.o_xchg = take(2048 * 8);
+    pl.work_bytes = off;
+    return SLAM_OK;
+}
+
+// bind the device pointers (region bases Aup / Azero / Awork) and write the uploaded region into `stage` (host memory, up_bytes)
+static int ba_emit(BAPlan &pl, char *Aup, char *Azero, char *Awork, char *stage)
+{
+    slam_ba *ba = pl.ba;
+    const int P = pl.P, M = pl.M, O = pl.O, n = 6 * P;
+    BADev &d = ba->d;
+    d.cam = {pl.fx, pl.fy, pl.cx, pl.cy}; d.P = P; d.M = M; d.O = O; d.n = n;
+    d.pose = (double *)(Aup + pl.o_pose); d.pose_t = (double *)(Awork + pl.o_pose_t); d.pts = (double *)(Aup + pl.o_pts); d.pts_t = (double *)(Awork + pl.o_pts_t);
+    d.pconst = (const uint8_t *)(Aup + pl.o_const); d.pix = (const double *)(Aup + pl.o_pix);
+    d.opose = (const int *)(Aup + pl.o_opose); d.opoint = (const int *)(Aup + pl.o_opoint); d.pt_start = (const int *)(Aup + pl.o_start);
+    d.outl = (uint8_t *)(Azero + pl.o_outl); d.hasp = (uint8_t *)(Awork + pl.o_hasp);
+    d.f = (double *)(Awork + pl.o_f); d.ft = (double *)(Awork + pl.o_ft); d.Jp = (double *)(Awork + pl.o_Jp); d.Jl = (double *)(Awork + pl.o_Jl);
+    d.Vinv = (double *)(Awork + pl.o_Vinv); d.bl = (double *)(Awork + pl.o_bl); d.T = (double *)(Awork + pl.o_T); d.Wm = (double *)(Awork + pl.o_W);
+    d.pairs = (const int2 *)(Aup + pl.o_pairs); d.blk_start = (const int *)(Aup + pl.o_bs); d.blk_pq = (const int2 *)(Aup + pl.o_bpq); d.nblk = pl.nblk;
+    ba->reduce = (double *)(Azero + pl.o_red);
+    ba->zeroed = ba->reduce;                                   // (the set-up's memset of the zero region covers it)
+    d.S = ba->reduce; d.g = ba->reduce + (size_t)n * n; d.udiag = d.g + n;
+    d.Swork = (double *)(Awork + pl.o_Sw); d.dp = (double *)(Azero + pl.o_dp); d.dl = (double *)(Awork + pl.o_dl);
+    d.part = (double *)(Awork + pl.o_part); d.st = (LMState *)(Azero + pl.o_st);
+    ba->chol_flag = (int *)(Azero + pl.o_cf); ba->linv = (double *)(Awork + pl.o_li); ba->lfac = (double *)(Awork + pl.o_lf); ba->band = (double *)(Awork + pl.o_band);
+    d.pt_id = (const int *)(Aup + pl.o_ptid); d.opk = (const int *)(Aup + pl.o_opk); d.grp = (const int4 *)(Aup + pl.o_grp); d.fgrp = (const int *)(Aup + pl.o_fgrp);
+    d.ngrp = pl.ngrp; d.whb = pl.hb; d.wstride = pl.wstride; d.wpart = (double *)(Awork + pl.o_wpart);
+    d.sg_ob = pl.sg_ob; d.sg_sb = pl.sg_sb;
+    ba->nparts = ba->grouped ? pl.ngrp : ba->nblocks_obs;
+    ba->xchg = (double *)(Awork + pl.o_xchg);
+#define UP(o, src, bytes) do { if ((bytes) > 0) memcpy(stage + (o), (src), (bytes)); } while (0)
+    if (!pl.new_of.empty()) { double *dst = (double *)(stage + pl.o_pose); for (int k = 0; k < P; k++) memcpy(dst + 6 * k, pl.theta + 6 * ba->pose_order[k], 48); }
+    else UP(pl.o_pose, pl.theta, (size_t)n * 8);
+    UP(pl.o_pts, pl.theta + n, (size_t)3 * M * 8);
+    UP(pl.o_const, pl.theta_const, (size_t)P); UP(pl.o_start, pl.start.data(), (size_t)(M + 1) * 4);
+    if (pl.filled) { UP(pl.o_pix, pl.v_pix.data(), (size_t)2 * O * 8); UP(pl.o_opose, pl.v_opose.data(), (size_t)O * 4); UP(pl.o_opoint, pl.v_opoint.data(), (size_t)O * 4); UP(pl.o_opk, pl.v_opk.data(), (size_t)O * 4); }
+    else {                                                   // (grouped: nothing on the host needs these arrays) written in place
+        pl.fill_obs((int *)(stage + pl.o_opose), (int *)(stage + pl.o_opoint), (int *)(stage + pl.o_opk), (double *)(stage + pl.o_pix));
+        if (pl.twice_pt >= 0) return pl.fail(SLAM_ERR_ARG, "slam_ba: map point %lld is observed twice by pose %lld", pl.twice_pt + 1, pl.twice_pose + 1);
+    }
+    UP(pl.o_pairs, pl.pairs.data(), pl.npairs * 8); UP(pl.o_bs, pl.blk_start.data(), (size_t)(pl.nblk + 1) * 4); UP(pl.o_bpq, pl.blk_pq.data(), (size_t)pl.nblk * 8);
+    UP(pl.o_ptid, pl.pt_id.data(), (size_t)M * 4); UP(pl.o_grp, pl.grp.data(), (size_t)pl.ngrp * 16); UP(pl.o_fgrp, pl.fgrp.data(), (size_t)(P + 1) * 4);
+#undef UP
+    return SLAM_OK;
+}
+
+static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, int P, int M, int O,
+                    const double *theta, const uint8_t *theta_const_in, const double *pixels_yx,
+                    const int64_t *pose_ids, const int64_t *point_ids, slam_ba **out, bool ctx_mem = false, bool may_reorder = false)
+{
+    BAPlan pl;
+    pl.fx = fx; pl.fy = fy; pl.cx = cx; pl.cy = cy; pl.P = P; pl.M = M; pl.O = O; pl.theta = theta; pl.theta_const_in = theta_const_in;
+    pl.pixels_yx = pixels_yx; pl.pose_ids = pose_ids; pl.point_ids = point_ids; pl.may_reorder = may_reorder;
+    if (ba_plan(pl)) return slam_fail(ctx, pl.err, "%s", pl.msg);
+    slam_ba *ba = pl.ba;
+    ba->device = ctx->device;
+    const size_t up_end = pl.up_bytes, zero_end = up_end + pl.zero_bytes, total = zero_end + pl.work_bytes;
     char *A = nullptr;
     if (ctx_mem) {                                             // slam_local_ba: the context's grow-only scratch, no hipMalloc / hipFree per call
-        const int rcs = slam_scratch(ctx, off, (void **)&A);
-        if (rcs) { delete ba; return rcs; }
+        const int rcs = slam_scratch(ctx, total, (void **)&A);
+        if (rcs) return rcs;
         ba->owns_arena = false;
     } else {
-        hipError_t e = hipMalloc((void **)&A, off);
-        if (e != hipSuccess) { delete ba; return slam_fail(ctx, SLAM_ERR_HIP, "slam_ba: hipMalloc(%zu): %s", off, hipGetErrorString(e)); }
+        hipError_t e = hipMalloc((void **)&A, total);
+        if (e != hipSuccess) return slam_fail(ctx, SLAM_ERR_HIP, "slam_ba: hipMalloc(%zu): %s", total, hipGetErrorString(e));
     }
     ba->arena = A;
-    struct Guard { slam_ba *b; ~Guard() { if (b) { if (b->arena && b->owns_arena) (void)hipFree(b->arena); delete b; } } } guard{ba};   // a failing upload frees the arena
-    BADev &d = ba->d;
-    d.cam = {fx, fy, cx, cy}; d.P = P; d.M = M; d.O = O; d.n = n;
-    d.pose = (double *)(A + o_pose); d.pose_t = (double *)(A + o_pose_t); d.pts = (double *)(A + o_pts); d.pts_t = (double *)(A + o_pts_t);
-    d.pconst = (const uint8_t *)(A + o_const); d.pix = (const double *)(A + o_pix);
-    d.opose = (const int *)(A + o_opose); d.opoint = (const int *)(A + o_opoint); d.pt_start = (const int *)(A + o_start);
-    d.outl = (uint8_t *)(A + o_outl); d.hasp = (uint8_t *)(A + o_hasp);
-    d.f = (double *)(A + o_f); d.ft = (double *)(A + o_ft); d.Jp = (double *)(A + o_Jp); d.Jl = (double *)(A + o_Jl);
-    d.Vinv = (double *)(A + o_Vinv); d.bl = (double *)(A + o_bl); d.T = (double *)(A + o_T); d.Wm = (double *)(A + o_W);
-    d.pairs = (const int2 *)(A + o_pairs); d.blk_start = (const int *)(A + o_bs); d.blk_pq = (const int2 *)(A + o_bpq); d.nblk = nblk;
-    ba->reduce = (double *)(A + o_red);
-    d.S = ba->reduce; d.g = ba->reduce + (size_t)n * n; d.udiag = d.g + n;
-    d.Swork = (double *)(A + o_Sw); d.dp = (double *)(A + o_dp); d.dl = (double *)(A + o_dl);
-    d.part = (double *)(A + o_part); d.st = (LMState *)(A + o_st);
-    ba->chol_flag = (int *)(A + o_cf); ba->linv = (double *)(A + o_li); ba->lfac = (double *)(A + o_lf); ba->band = (double *)(A + o_band);
-    d.pt_id = (const int *)(A + o_ptid); d.opk = (const int *)(A + o_opk); d.grp = (const int4 *)(A + o_grp); d.fgrp = (const int *)(A + o_fgrp);
-    d.ngrp = ngrp; d.whb = hb; d.wstride = wstride; d.wpart = (double *)(A + o_wpart);
-    ba->nparts = grouped ? ngrp : ba->nblocks_obs;
-    ba->xchg = (double *)(A + o_xchg);
+    struct Guard { slam_ba *b; ~Guard() { if (b && b->arena && b->owns_arena) (void)hipFree(b->arena); } } guard{ba};   // a failing upload frees the arena (the plan owns the object)
     hipStream_t st = ctx->stream;
     char *stage = nullptr;
+    std::vector<char> pageable;
     if (ctx_mem) { const int rcs = slam_pinned(ctx, up_end, (void **)&stage); if (rcs) return rcs; }
-#define UP(o, src, bytes) do { if ((bytes) > 0) { if (stage) memcpy(stage + (o), (src), (bytes)); else HIP_TRY(ctx, hipMemcpyAsync((void *)(A + (o)), (src), (bytes), hipMemcpyHostToDevice, st)); } } while (0)
-    std::vector<double> pose_perm;
-    if (!new_of.empty()) { pose_perm.resize(n); for (int k = 0; k < P; k++) memcpy(&pose_perm[6 * k], theta + 6 * ba->pose_order[k], 48); }
-    UP(o_pose, new_of.empty() ? theta : pose_perm.data(), (size_t)n * 8); UP(o_pts, theta + n, (size_t)3 * M * 8);
-    UP(o_const, theta_const, (size_t)P); UP(o_start, start.data(), (size_t)(M + 1) * 4);
-    if (filled) { UP(o_pix, v_pix.data(), (size_t)2 * O * 8); UP(o_opose, v_opose.data(), (size_t)O * 4); UP(o_opoint, v_opoint.data(), (size_t)O * 4); UP(o_opk, v_opk.data(), (size_t)O * 4); }
-    else {                                                   // (grouped && ctx_mem: the pinned block exists) written in place
-        fill_obs((int *)(stage + o_opose), (int *)(stage + o_opoint), (int *)(stage + o_opk), (double *)(stage + o_pix));
-        if (twice_pt >= 0) return twice_error();             // (the guard releases the solver object)
-    }
-    UP(o_pairs, pairs.data(), npairs * 8); UP(o_bs, blk_start.data(), (size_t)(nblk + 1) * 4); UP(o_bpq, blk_pq.data(), (size_t)nblk * 8);
-    UP(o_ptid, pt_id.data(), (size_t)M * 4); UP(o_grp, grp.data(), (size_t)ngrp * 16); UP(o_fgrp, fgrp.data(), (size_t)(P + 1) * 4);
-#undef UP
-    if (stage) HIP_TRY(ctx, hipMemcpyAsync(A, stage, up_end, hipMemcpyHostToDevice, st));      // pinned -> device: one DMA, nothing to wait for
-    HIP_TRY(ctx, hipMemsetAsync(A + up_end, 0, zero_end - up_end, st));                         // LM state, flags, outlier marks
-    if (ba->pspan < P) HIP_TRY(ctx, hipMemsetAsync(d.dp, 0, (size_t)n * 8, st));                 // dp of the constant poses outside the solve's span stays zero
-    if (!stage) HIP_TRY(ctx, slam_stream_wait(st));   // pageable host vectors go out of scope
+    else { pageable.resize(up_end); stage = pageable.data(); }
+    if (ba_emit(pl, A, A + up_end, A + zero_end, stage)) return slam_fail(ctx, pl.err, "%s", pl.msg);
+    HIP_TRY(ctx, hipMemcpyAsync(A, stage, up_end, hipMemcpyHostToDevice, st));                  // pinned -> device: one DMA, nothing to wait for
+    HIP_TRY(ctx, hipMemsetAsync(A + up_end, 0, zero_end - up_end, st));                         // LM state, flags, outlier marks, dp, the reduce buffer
+    if (!ctx_mem) HIP_TRY(ctx, slam_stream_wait(st));        // the pageable staging block goes out of scope
     guard.b = nullptr;
+    pl.ba = nullptr;                                           // ownership passes to the caller
     *out = ba;
     return SLAM_OK;
 }
+
 
 // linearise at the current parameters and build [S; g; udiag] into `red`
 static int ba_enqueue_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, double inv_delta, int use_state, double *red)
@@ -2389,8 +2596,8 @@ static int ba_enqueue_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, dou
         // (the reference's three tasks call the library concurrently, SLAM.jl:166: the flag is atomic; setting the attribute twice is harmless)
         static std::atomic<bool> attr_set[64];
         const int dv = ctx->device & 63;
-        if (!attr_set[dv].load(std::memory_order_acquire)) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB))); attr_set[dv].store(true, std::memory_order_release); }
-        hipLaunchKernelGGL(k_schur_groups, dim3(d.ngrp), dim3(SG_T), sg_lds_bytes(d.whb), st, d, inv_delta, ignore_outliers, use_state);
+        if (!attr_set[dv].load(std::memory_order_acquire)) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB, SOLVE_MAX_N / 6))); attr_set[dv].store(true, std::memory_order_release); }
+        hipLaunchKernelGGL(k_schur_groups, dim3(d.ngrp), dim3(SG_T), sg_lds_bytes(d.whb, d.P, d.sg_ob, d.sg_sb), st, d, inv_delta, ignore_outliers, use_state);
         if (!use_state) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 0, d.ngrp, ba->nblocks_pts, 0, red + (size_t)n * n + 2 * n);
         const int nthr = d.P * (d.whb + 1) * 36 + d.P * 12;
         hipLaunchKernelGGL(k_schur_reduce, dim3((nthr + 255) / 256), dim3(256), 0, st, d, use_state);
@@ -2741,6 +2948,202 @@ int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy, int
     }
     if (h.chol_fail) return slam_fail(ctx, SLAM_ERR_NUMERIC, "slam_local_ba: reduced camera system not positive definite (theta and outliers left unchanged)");
     return SLAM_OK;
+}
+
+
+// bundle_adjustment! for S windows at once (no reference counterpart, like the other *_batch entry points; the caller is the estimator
+// task of S lock-stepped SlamManagers, estimator.jl:78-99 / :317-347): every kernel of slam_local_ba with the window on blockIdx.y, each
+// window with its own device-side LM state; host set-up (structure analysis, staging) spread over threads; ONE host -> device copy, one
+// memset, 5 launches per LM iteration for the whole batch, one device -> host copy.  Window z's results equal slam_local_ba's on its
+// arrays.  Windows the banded group kernels do not cover (no banded pose order, a point with > 448 observations, no observations) are
+// solved one by one through slam_local_ba afterwards.
+int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t *Pn, const int32_t *Mn, const int32_t *On,
+                        double *theta, const uint8_t *theta_const, const double *pixels_yx,
+                        const int64_t *pose_ids, const int64_t *point_ids, uint8_t *outliers,
+                        int iters_fast, int iterations, double repr_eps, double *stats, int32_t *status)
+{
+    ARG_TRY(ctx, ctx != nullptr && S >= 1 && S <= 65535 && cams != nullptr && Pn != nullptr && Mn != nullptr && On != nullptr);
+    ARG_TRY(ctx, theta != nullptr && theta_const != nullptr && outliers != nullptr && iters_fast >= 0 && iterations >= 0);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    static const bool host_times = getenv("SLAMHIP_BA_HOSTTIME") != nullptr;
+    const auto tw0 = std::chrono::steady_clock::now();
+    std::vector<size_t> th_off(S + 1, 0), pc_off(S + 1, 0), ob_off(S + 1, 0);
+    for (int z = 0; z < S; z++) {
+        ARG_TRY(ctx, Pn[z] > 0 && Mn[z] >= 0 && On[z] >= 0);
+        th_off[z + 1] = th_off[z] + 6 * (size_t)Pn[z] + 3 * (size_t)Mn[z]; pc_off[z + 1] = pc_off[z] + Pn[z]; ob_off[z + 1] = ob_off[z] + On[z];
+    }
+    ARG_TRY(ctx, ob_off[S] == 0 || (pixels_yx != nullptr && pose_ids != nullptr && point_ids != nullptr));
+    std::vector<BAPlan> pl(S);
+    for (int z = 0; z < S; z++) {
+        BAPlan &q = pl[z];
+        q.fx = cams[4 * z]; q.fy = cams[4 * z + 1]; q.cx = cams[4 * z + 2]; q.cy = cams[4 * z + 3];
+        q.P = Pn[z]; q.M = Mn[z]; q.O = On[z]; q.theta = theta + th_off[z]; q.theta_const_in = theta_const + pc_off[z];
+        q.pixels_yx = pixels_yx ? pixels_yx + 2 * ob_off[z] : nullptr; q.pose_ids = pose_ids ? pose_ids + ob_off[z] : nullptr; q.point_ids = point_ids ? point_ids + ob_off[z] : nullptr;
+        q.may_reorder = true; q.small_groups = true;
+    }
+    static const int env_threads = [] { const char *v = getenv("SLAMHIP_BA_THREADS"); return v ? atoi(v) : 0; }();
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nthr = std::max(1, std::min(S, env_threads > 0 ? env_threads : std::min(hw > 0 ? hw : 4, 16)));
+    auto parallel = [&](auto fn) {                             // fn(z) for z = 0 .. S - 1, windows dealt round-robin
+        if (nthr == 1) { for (int z = 0; z < S; z++) fn(z); return; }
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthr; t++) th.emplace_back([&, t] { for (int z = t; z < S; z += nthr) fn(z); });
+        for (int z = 0; z < S; z += nthr) fn(z);
+        for (auto &x : th) x.join();
+    };
+    parallel([&](int z) { ba_plan(pl[z]); });
+    const auto tw1 = std::chrono::steady_clock::now();
+    std::vector<int> st_code(S, SLAM_OK);
+    std::vector<int> batch;                                    // windows the batch kernels take
+    std::vector<int> single;                                   // windows solved one by one afterwards
+    for (int z = 0; z < S; z++) {
+        BAPlan &q = pl[z];
+        if (q.err) { st_code[z] = q.err; if (!status) return slam_fail(ctx, q.err, "slam_local_ba_batch: window %d: %s", z, q.msg); continue; }
+        const slam_ba *b = q.ba;
+        const int Ps = b->pspan > 0 ? b->pspan : q.P, hbq = std::min(std::max(b->hb, 1), Ps - 1);
+        if (b->grouped && hbq >= 1 && hbq <= BS_MAXHB && band_lds_bytes(6 * q.P, Ps, hbq) <= 150 * 1024) batch.push_back(z); else single.push_back(z);
+    }
+    const int NB = (int)batch.size();
+    float dev_ms = 0;
+    if (NB > 0) {
+        // region-major arena: [window table | result table | uploads of every window][zero regions][work regions][results]
+        std::vector<size_t> up(NB + 1), ze(NB + 1), wk(NB + 1), rs(NB + 1);
+        const size_t tab_bytes = al((size_t)NB * sizeof(BAWin)), rtab_bytes = al((size_t)NB * sizeof(BARes));
+        up[0] = tab_bytes + rtab_bytes; ze[0] = 0; wk[0] = 0; rs[0] = 0;
+        for (int k = 0; k < NB; k++) {
+            const BAPlan &q = pl[batch[k]];
+            up[k + 1] = up[k] + q.up_bytes; ze[k + 1] = ze[k] + q.zero_bytes; wk[k + 1] = wk[k] + q.work_bytes;
+            rs[k + 1] = rs[k] + al(sizeof(LMState)) + al((6 * (size_t)q.P + 3 * (size_t)q.M) * 8 + 8) + al((size_t)q.O + 8);
+        }
+        const size_t up_total = up[NB], zero_base = up_total, work_base = zero_base + ze[NB], res_base = work_base + wk[NB], total = res_base + rs[NB];
+        char *A = nullptr, *stage = nullptr;
+        int rc = slam_scratch(ctx, total, (void **)&A);
+        if (rc) return rc;
+        rc = slam_pinned(ctx, up_total + rs[NB], (void **)&stage);
+        if (rc) return rc;
+        char *res_host = stage + up_total;
+        BAWin *tab_h = (BAWin *)stage; BARes *rtab_h = (BARes *)(stage + tab_bytes);
+        parallel([&](int zz) {
+            if (zz >= NB) return;
+            const int k = zz; BAPlan &q = pl[batch[k]];
+            if (ba_emit(q, A + up[k], A + zero_base + ze[k], A + work_base + wk[k], stage + up[k])) return;
+            slam_ba *b = q.ba; b->device = ctx->device; b->owns_arena = false; b->arena = A;
+            BAWin &w = tab_h[k];
+            memset(&w, 0, sizeof w);
+            w.d = b->d;
+            const int n = w.d.n, Ps = b->pspan > 0 ? b->pspan : q.P, p0 = b->pspan > 0 ? b->p0 : 0, hb = std::min(std::max(b->hb, 1), Ps - 1);
+            const double *red = b->reduce;
+            w.B.S = red + (size_t)6 * p0 * (n + 1); w.B.g = red + (size_t)n * n + 6 * p0; w.B.ud = red + (size_t)n * n + n + 6 * p0; w.B.Lg = b->band;
+            w.B.nb = Ps; w.B.hb = hb; w.B.p0 = p0; w.B.inv_delta_host = 0.0; w.B.fail = b->chol_flag; w.B.trace = nullptr;
+            w.B.lds_bytes = (int)band_lds_bytes(n, Ps, hb); w.B.xchg = b->xchg; w.B.epoch = 1; w.B.shift = 0;
+            w.nb_obs = b->nblocks_obs; w.nb_pts = b->nblocks_pts; w.n_red = (w.d.P * (w.d.whb + 1) * 36 + w.d.P * 12 + 255) / 256;
+            BARes &r = rtab_h[k];
+            r.off_state = res_base + rs[k]; r.off_theta = r.off_state + al(sizeof(LMState)); r.off_outl = r.off_theta + al((6 * (size_t)q.P + 3 * (size_t)q.M) * 8 + 8);
+        });
+        for (int k = 0; k < NB; k++) {
+            BAPlan &q = pl[batch[k]];
+            if (q.err) { st_code[batch[k]] = q.err; if (!status) return slam_fail(ctx, q.err, "slam_local_ba_batch: window %d: %s", batch[k], q.msg); }
+        }
+        // a window whose set-up failed in ba_emit (a point observed twice by one pose) stays in the table as an inert entry: no groups, no blocks
+        int gx_obs = 1, gx_grp = 1, gx_red = 1, max_ob = 0, max_hb = 0; size_t lds_sg = 0, lds_band = 0;
+        for (int k = 0; k < NB; k++) {
+            BAPlan &q = pl[batch[k]]; BAWin &w = tab_h[k];
+            if (q.err) { w.d.ngrp = 0; w.nb_obs = 0; w.n_red = 0; w.d.O = 0; w.d.M = 0; w.d.n = 0; w.B.nb = 0; continue; }
+            gx_obs = std::max(gx_obs, w.nb_obs); gx_grp = std::max(gx_grp, w.d.ngrp); gx_red = std::max(gx_red, w.n_red);
+            max_ob = std::max(max_ob, w.d.sg_ob); max_hb = std::max(max_hb, w.d.whb);
+            lds_band = std::max(lds_band, (size_t)w.B.lds_bytes);
+        }
+        // small groups everywhere (the reference's window shape: 16 points x 10 observers): 256-thread workgroups, two to three per compute unit
+        static const bool no_t256 = getenv("SLAMHIP_BA_BATCH_T512") != nullptr;
+        const int TT = (!no_t256 && max_ob <= 256 && (max_hb + 1) * (max_hb + 2) / 2 <= 256) ? 256 : SG_T;
+        for (int k = 0; k < NB; k++) if (!pl[batch[k]].err) lds_sg = std::max(lds_sg, sg_lds_bytes(tab_h[k].d.whb, tab_h[k].d.P, tab_h[k].d.sg_ob, tab_h[k].d.sg_sb, TT));
+        const auto tw2 = std::chrono::steady_clock::now();
+        hipStream_t st = ctx->stream;
+        static std::atomic<bool> attr_set[64];
+        const int dv = ctx->device & 63;
+        if (!attr_set[dv].load(std::memory_order_acquire)) {
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups_b<SG_T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB, SOLVE_MAX_N / 6)));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups_b<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB, SOLVE_MAX_N / 6)));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_band_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set[dv].store(true, std::memory_order_release);
+        }
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        hipError_t e = hipMemcpyAsync(A, stage, up_total, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemsetAsync(A + zero_base, 0, ze[NB], st);
+        (void)hipEventRecord(e0, st);
+        const BAWin *tab = (const BAWin *)A; const BARes *rtab = (const BARes *)(A + tab_bytes);
+        auto run_pass = [&](int ignore, int iters) {
+            hipLaunchKernelGGL(k_linearize_b, dim3(gx_obs, NB), dim3(256), 0, st, tab, ignore, 0);
+            hipLaunchKernelGGL(k_pass_start_b, dim3(1, NB), dim3(256), 0, st, tab, ignore ? 1 : 0);
+            for (int it = 1; it <= iters; it++) {
+                if (TT == 256) hipLaunchKernelGGL(k_schur_groups_b<256>, dim3(gx_grp, NB), dim3(256), lds_sg, st, tab, ignore);
+                else hipLaunchKernelGGL(k_schur_groups_b<SG_T>, dim3(gx_grp, NB), dim3(SG_T), lds_sg, st, tab, ignore);
+                hipLaunchKernelGGL(k_schur_reduce_b, dim3(gx_red, NB), dim3(256), 0, st, tab);
+                hipLaunchKernelGGL(k_band_solve_b, dim3(1, NB), dim3(BS_T), lds_band, st, tab);
+                if (TT == 256) hipLaunchKernelGGL(k_update_groups_b<256>, dim3(gx_grp, NB), dim3(256), 0, st, tab, ignore);
+                else hipLaunchKernelGGL(k_update_groups_b<SG_T>, dim3(gx_grp, NB), dim3(SG_T), 0, st, tab, ignore);
+                hipLaunchKernelGGL(k_control_b, dim3(1, NB), dim3(256), 0, st, tab);
+            }
+        };
+        if (e == hipSuccess) {
+            run_pass(0, iters_fast);
+            hipLaunchKernelGGL(k_outliers_b, dim3(gx_obs, NB), dim3(256), 0, st, tab, repr_eps, 1e-6);
+            hipLaunchKernelGGL(k_outlier_count_b, dim3(1, NB), dim3(256), 0, st, tab);
+            run_pass(1, iterations);
+            hipLaunchKernelGGL(k_results_b, dim3(8, NB), dim3(256), 0, st, tab, rtab, A);
+            e = hipGetLastError();
+        }
+        (void)hipEventRecord(e1, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(res_host, A + res_base, rs[NB], hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = slam_stream_wait(st);
+        if (e == hipSuccess) (void)hipEventElapsedTime(&dev_ms, e0, e1);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (e != hipSuccess) return slam_fail(ctx, SLAM_ERR_HIP, "slam_local_ba_batch: %s", hipGetErrorString(e));
+        const auto tw3 = std::chrono::steady_clock::now();
+        // results -> the caller's arrays (its pose order, its observation order); a failed factorisation leaves a window's arrays untouched
+        parallel([&](int zz) {
+            if (zz >= NB) return;
+            const int k = zz, z = batch[k]; BAPlan &q = pl[z];
+            if (q.err) return;
+            const BARes &r = rtab_h[k];
+            const LMState &h = *(const LMState *)(res_host + (r.off_state - res_base));
+            if (stats) {
+                double *sv = stats + 8 * (size_t)z;
+                sv[0] = h.ssr_init; sv[1] = h.ssr_pass1; sv[2] = h.ssr_final; sv[3] = h.iters_pass1; sv[4] = h.iters_pass2; sv[5] = h.n_outliers; sv[6] = dev_ms; sv[7] = h.chol_fail;
+            }
+            if (h.chol_fail) { st_code[z] = SLAM_ERR_NUMERIC; return; }
+            const double *th = (const double *)(res_host + (r.off_theta - res_base));
+            double *dst = theta + th_off[z];
+            const int n = 6 * q.P;
+            if (q.ba->pose_order.empty()) memcpy(dst, th, (size_t)n * 8);
+            else for (int p = 0; p < q.P; p++) memcpy(dst + 6 * q.ba->pose_order[p], th + 6 * p, 48);
+            memcpy(dst + n, th + n, (size_t)3 * q.M * 8);
+            const uint8_t *ol = (const uint8_t *)(res_host + (r.off_outl - res_base));
+            uint8_t *od = outliers + ob_off[z];
+            for (int s2 = 0; s2 < q.O; s2++) od[q.ba->perm[s2]] = ol[s2];
+        });
+        if (host_times) {
+            const auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+            fprintf(stderr, "slam_local_ba_batch host: %d windows (%d threads): plan %ld us, emit %ld us, enqueue + wait %ld us (device %.0f us), scatter %ld us; %zu B up, %zu B arena\n",
+                    NB, nthr, us(tw0, tw1), us(tw1, tw2), us(tw2, tw3), dev_ms * 1e3, us(tw3, std::chrono::steady_clock::now()), up_total, total);
+        }
+    }
+    for (int z : single) {
+        if (st_code[z]) continue;
+        const BAPlan &q = pl[z];
+        double sv[8] = {0};
+        const int rc1 = slam_local_ba(ctx, q.fx, q.fy, q.cx, q.cy, q.P, q.M, q.O, theta + th_off[z], theta_const + pc_off[z], q.pixels_yx, q.pose_ids, q.point_ids,
+                                      outliers + ob_off[z], iters_fast, iterations, repr_eps, sv);
+        if (stats) memcpy(stats + 8 * (size_t)z, sv, sizeof sv);
+        st_code[z] = rc1;
+        if (rc1 && rc1 != SLAM_ERR_NUMERIC && !status) return rc1;
+    }
+    int first = SLAM_OK;
+    for (int z = 0; z < S; z++) { if (status) status[z] = st_code[z]; if (st_code[z] && !first) first = st_code[z]; }
+    if (status) return SLAM_OK;                                // per-window codes are in status[]
+    if (first == SLAM_ERR_NUMERIC) return slam_fail(ctx, SLAM_ERR_NUMERIC, "slam_local_ba_batch: a reduced camera system was not positive definite (that window's theta and outliers are left unchanged)");
+    return first;
 }
 
 } // extern "C"

@@ -1,0 +1,94 @@
+"""GPU: slam_local_ba_batch -- bundle_adjustment! (src/bundle_adjustment.jl:1-111) for S windows in one set of launches, the estimator
+tasks of S lock-stepped SlamManagers (src/estimator.jl:78-99, :317-347).  Every window must come out as S separate slam_local_ba calls
+leave it (outlier sets array_equal, cost 1e-8, theta 1e-6 -- in fact bit-equal: same kernels, same order) and as the oracle's Schur-LM
+does, on ragged window sizes, with windows that converge early, windows the batch kernels do not cover and degenerate ones mixed in."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cache(slam, s):
+    return slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+
+
+def _scenes(syn):
+    sc = [syn.ba_scene(P=25, M=800, seed=5, n_const=20),            # the reference's shape: 5 free + 20 constant key-frames
+          syn.ba_scene(P=5, M=300, seed=0), syn.ba_scene(P=8, M=600, seed=1), syn.ba_scene(P=20, M=2000, seed=2),
+          syn.ba_scene(P=25, M=500, seed=11, n_const=21), syn.ba_scene(P=12, M=150, seed=12, n_const=3),
+          syn.ba_scene(P=6, M=40, seed=13), syn.ba_scene(P=30, M=1200, seed=14, n_const=24)]
+    return sc
+
+
+def test_batch_equals_single_calls_and_oracle_on_ragged_windows(slam, orc, syn):
+    sc = _scenes(syn)
+    single = []
+    for s in sc:
+        c = _cache(slam, s); slam.bundle_adjustment_(c, s["cam"]); single.append(c)
+    caches = [_cache(slam, s) for s in sc]
+    status = slam.bundle_adjustment_batch_(caches, [s["cam"] for s in sc])
+    assert not status.any(), status
+    for z, (s, c, ref) in enumerate(zip(sc, caches, single)):
+        assert np.array_equal(c.outliers, ref.outliers), z
+        assert c.stats["iters_pass1"] == ref.stats["iters_pass1"] and c.stats["iters_pass2"] == ref.stats["iters_pass2"], z
+        for k in ("ssr_init", "ssr_pass1", "ssr_final"):
+            assert abs(c.stats[k] - ref.stats[k]) <= 1e-8 * ref.stats[k], (z, k)
+        assert np.abs(c.theta - ref.theta).max() <= 1e-6 * max(1.0, np.abs(ref.theta).max()), z
+        th, ol, st = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], 5, 10, 5.0, solver=1)
+        assert np.array_equal(c.outliers, ol), z
+        assert abs(c.stats["ssr_final"] - st["ssr_final"]) <= 1e-8 * st["ssr_final"], z
+        assert np.abs(c.theta - th).max() <= 1e-6 * max(1.0, np.abs(th).max()), z
+        cst = s["theta_const"].astype(bool); P = len(cst)
+        assert np.array_equal(c.theta[:6 * P].reshape(P, 6)[cst], s["theta0"][:6 * P].reshape(P, 6)[cst]), z      # constant poses never move
+
+
+def test_batch_with_windows_outside_the_batch_kernels(slam, orc, syn):
+    """a dense window (half-bandwidth 23: the general path), a loop-closure window (solved on relabelled poses), an all-constant window,
+    an empty one and a regular one in the same call"""
+    sc = [syn.ba_scene(P=26, M=600, seed=9, obs_per_point=24), syn.ba_scene_loop(P=30, M=1500, seed=7, n_loop=200),
+          syn.ba_scene(P=4, M=100, seed=4, n_const=4), syn.ba_scene(P=5, M=200, seed=3)]
+    empty = dict(theta0=np.zeros(12), theta_const=np.array([1, 0], dtype=np.uint8), pixels_yx=np.zeros((0, 2)), pose_ids=np.zeros(0, np.int64),
+                 point_ids=np.zeros(0, np.int64), cam=sc[0]["cam"])
+    sc.insert(2, empty)
+    single = []
+    for s in sc:
+        c = _cache(slam, s); slam.bundle_adjustment_(c, s["cam"]); single.append(c)
+    caches = [_cache(slam, s) for s in sc]
+    status = slam.bundle_adjustment_batch_(caches, [s["cam"] for s in sc])
+    assert not status.any(), status
+    for z, (c, ref) in enumerate(zip(caches, single)):
+        assert np.array_equal(c.outliers, ref.outliers), z
+        assert np.abs(c.theta - ref.theta).max() <= 1e-6 * max(1.0, np.abs(ref.theta).max()), z
+        if ref.stats["ssr_final"] > 0:
+            assert abs(c.stats["ssr_final"] - ref.stats["ssr_final"]) <= 1e-8 * ref.stats["ssr_final"], z
+
+
+def test_batch_of_128_reference_shaped_windows(slam, orc, syn):
+    """the bench's batch: 128 windows of 5 free + 20 constant key-frames (estimator.jl:327-331), different data per window; windows 0, 64
+    and 127 against the oracle, all against each other's iteration counts being plausible"""
+    S = 128
+    sc = [syn.ba_scene(P=25, M=800, seed=100 + z, n_const=20) for z in range(S)]
+    caches = [_cache(slam, s) for s in sc]
+    status = slam.bundle_adjustment_batch_(caches, sc[0]["cam"])
+    assert not status.any()
+    for z in (0, 64, 127):
+        s, c = sc[z], caches[z]
+        th, ol, st = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], 5, 10, 5.0, solver=1)
+        assert np.array_equal(c.outliers, ol), z
+        assert abs(c.stats["ssr_final"] - st["ssr_final"]) <= 1e-8 * st["ssr_final"], z
+        assert np.abs(c.theta - th).max() <= 1e-6 * max(1.0, np.abs(th).max()), z
+    ref = _cache(slam, sc[77]); slam.bundle_adjustment_(ref, sc[77]["cam"])
+    # (256-thread workgroups sum a group's points in four subsets instead of eight: equal to rounding, not to the bit)
+    assert np.abs(caches[77].theta - ref.theta).max() <= 1e-9 and np.array_equal(caches[77].outliers, ref.outliers)
+
+
+def test_batch_reports_a_bad_window_and_solves_the_others(slam, syn):
+    good = syn.ba_scene(P=5, M=200, seed=3)
+    bad = syn.ba_scene(P=5, M=200, seed=4)
+    bad = dict(bad); bad["pose_ids"] = bad["pose_ids"].copy(); bad["pose_ids"][7] = 99            # pose id out of range
+    caches = [_cache(slam, good), _cache(slam, bad), _cache(slam, good)]
+    status = slam.bundle_adjustment_batch_(caches, good["cam"])
+    assert status[0] == 0 and status[2] == 0 and status[1] != 0
+    ref = _cache(slam, good); slam.bundle_adjustment_(ref, good["cam"])
+    assert np.abs(caches[0].theta - ref.theta).max() <= 1e-9 and np.array_equal(caches[2].theta, caches[0].theta)
+    assert np.array_equal(caches[1].theta, bad["theta0"])                                          # untouched
