@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 from benchlib.common import (KF_EVERY, RIGHT_TARGET_ONLY, CULL_FRACTION, N_FRAMES, HBM_PEAK_GBS, HBM_ACHIEVABLE_GBS,      # noqa: E402,F401
                              frame_sequence, frame_sequence_n, pyramid_bytes, iir_rows_bytes)
 from benchlib.backends import Stream, GpuBackend, GpuPeriodBackend, CpuBackend                                           # noqa: E402,F401
-from benchlib.lockstep import run_lockstep, run_lockstep_kpset, kernel_spans, make_workload, WORKLOADS, leg_ctx, peek   # noqa: E402,F401
+from benchlib.lockstep import run_lockstep, run_lockstep_kpset, kernel_spans, make_workload, WORKLOADS, leg_ctx, peek, BAWorker   # noqa: E402,F401
 from benchlib.checkers import replay_stream_on_oracle                                                                    # noqa: E402
 from benchlib.report import compact_line, write_detail, frame_and_lk_rooflines, newest_pmc                               # noqa: E402
 
@@ -541,10 +541,50 @@ def main():
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_iter / (best["ms_per_iter"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "note": "latency-bound: a chain of dependent launches and block columns, not bytes"}
                 out["ba"]["windows"][name] = best
+            # ---- S windows per call (slam_local_ba_batch): what S lock-stepped streams owe per key-frame period ----
+            out["ba"]["batch"] = {}
+            for bname, mk in (("P5_free_20_const", lambda z: syn.ba_scene(P=25, M=800, seed=100 + z, n_const=20)), ("P20", lambda z: syn.ba_scene(P=20, M=4000, seed=300 + z))):
+                base = [mk(z) for z in range(8)]
+                bb = slam.BABatch([slam.LocalBACache(base[z % 8]["theta0"].copy(), base[z % 8]["theta_const"], base[z % 8]["pixels_yx"], base[z % 8]["pose_ids"],
+                                                     base[z % 8]["point_ids"]) for z in range(S)], base[0]["cam"])
+                bb.solve(ctx=ctx, reset=True)
+                walls = []
+                for _ in range(5):
+                    bb.theta[:] = bb.theta0
+                    t0 = time.perf_counter(); bb.solve(ctx=ctx); walls.append(time.perf_counter() - t0)
+                one = slam.LocalBACache(base[0]["theta0"].copy(), base[0]["theta_const"], base[0]["pixels_yx"], base[0]["pose_ids"], base[0]["point_ids"])
+                slam.bundle_adjustment_(one, base[0]["cam"], ctx=ctx)
+                th0, ol0, st0 = bb.window(0)
+                same = bool(np.array_equal(ol0, one.outliers) and np.abs(th0 - one.theta).max() <= 1e-6 * max(1.0, np.abs(one.theta).max()))
+                if not same:
+                    fails.append(f"ba.batch {bname}: window 0 of the batch differs from slam_local_ba on the same arrays")
+                its = float(np.mean(bb.stats[:, 3] + bb.stats[:, 4]))
+                out["ba"]["batch"][bname] = {"windows": S, "observations_per_window": int(base[0]["O"]), "wall_ms_per_call": min(walls) * 1e3, "device_ms_per_call": float(bb.stats[0, 6]),
+                                             "windows_per_s": S / min(walls), "mean_lm_iterations": its, "device_ms_per_iter_of_S_windows": float(bb.stats[0, 6]) / max(its, 1),
+                                             "all_windows_ok": bool((bb.status == 0).all()), "window_0_equals_single_call": same,
+                                             "single_window_call_ms": None if bname not in out["ba"]["windows"] else out["ba"]["windows"][bname]["wall_ms_total"],
+                                             "what": "slam_local_ba_batch: host set-up of the S windows (threads), one H2D copy, 5 launches per LM iteration for all windows, one D2H copy; "
+                                                     "wall clock of the whole call, arrays already concatenated"}
             p50 = out["ba"]["windows"]["P50"]
             out["ba"].update({"window_kf": 50, "observations": p50["observations"], "points": p50["points"], "lm_iterations": p50["lm_iterations"],
                               "ms_per_iter": p50["ms_per_iter"], "wall_ms_total": p50["wall_ms_total"], "ssr_final": p50["ssr_final"]})
             leg_done("ba")
+            # ---- the headline loop with the local BA running inside it: every key-frame step hands the S streams' windows to the estimator
+            #      thread (third context), as SlamManager's task #3 does (estimator.jl:78-99) ----
+            if head is not None or "headline" not in legs:
+                try:
+                    worker = BAWorker(slam, syn, local_rank, S, prio=int(os.environ.get("SLAM_BENCH_BA_PRIO", "0")))
+                    wb = run_lockstep_kpset(slam, torch, local_rank, wl, max(8, args.steps // 2), 2, world, dist, dev, "host_u8", ba=worker)
+                    worker.close()
+                    out["frontend_with_ba"] = {"value": wb["value"], "unit": "frames/sec", "ms_per_step": wb["ms_per_step"], "steps": wb["steps"], "local_ba": wb["local_ba"],
+                                               "fraction_of_headline": None if head is None else wb["value"] / head["value"],
+                                               "what": "the headline loop (bit-exact pyramids) with slam_local_ba_batch of the S streams' windows once per key-frame period on a "
+                                                       "third context and host thread; a hand-over waits for the previous solve"}
+                    if not wb["local_ba"]["all_windows_ok"]:
+                        fails.append("frontend_with_ba: a window of the last batch did not solve")
+                except Exception as ex:                               # noqa: BLE001
+                    out["frontend_with_ba"] = {"error": repr(ex)[:300]}
+                leg_done("frontend_with_ba")
         if "ba_sharded" in legs and world > 1 and os.environ.get("SLAM_BENCH_CHILD") is None:
             # N > 1: the library's own RCCL communicator (slam_comm_*) has never run on real multi-GPU hardware in the build environment.  A
             # collective that does not return cannot be caught as an exception, so every rank runs this leg in a CHILD process (its own

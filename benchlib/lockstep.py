@@ -174,7 +174,7 @@ def make_workload(slam, syn, name, seed=0, streams=None):
 
 
 def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world, dist, dev, ingest,
-                       hook=None, seed=1234, pose=False, record=None, snapshot=None, diag=None):
+                       hook=None, seed=1234, pose=False, record=None, snapshot=None, diag=None, ba=None):
     """The headline loop: S streams in lock-step, keypoints resident in HBM (slam_kpset_*), no host list work
     between the calls of a frame; the host sees the S list lengths once per frame.  Timed: `periods` key-frame periods
     (KF_EVERY frames of every stream each, the first a key-frame) after `warm_periods` untimed ones.
@@ -405,6 +405,8 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
                 if kfid > 0:
                     ks.triangulate_temporal(sp_cam, pst["kf_cw"], Twc_now, kfid, max_error=3.0, ctx=ctx)
             cnt = None
+        if kf and ba is not None:
+            ba.submit()                                         # add_new_kf!(estimator, kf): this key-frame's local BA of every stream (task #3)
         if cnt is None:
             t_enq = time.perf_counter()
             cnt = ks.counts(ctx=ctx)                        # the one device -> host copy of the step (synchronises)
@@ -430,9 +432,13 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     for i in range(1, 1 + warm):
         step(i)
     state["tracked"] = 0; state["tracked_steps"] = 0
+    if ba is not None:
+        ba.reset_counters()
     drain(); state["timed"] = True; state["wait_s"] = 0.0; t0 = time.perf_counter()
     for i in range(1 + warm, 1 + warm + nsteps):
         step(i)
+    if ba is not None:
+        ba.join()                                               # the last key-frame's windows are part of the timed work
     drain(); dt = time.perf_counter() - t0
     state["timed"] = False
     i_last = warm + nsteps
@@ -450,6 +456,7 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     res = {"ingest": ingest, "streams_per_gpu": S, "hbm_in_use_gb": hbm_gb, "steps": periods, "frame_steps": nsteps, "value": world * S * nsteps / dt, "unit": "frames/sec", "seconds": dt,
            "ms_per_step": dt / max(periods, 1) * 1e3, "ms_per_frame_of_S_streams": dt / nsteps * 1e3,
            "host_wait_ms_per_frame": state["wait_s"] / nsteps * 1e3,
+           "local_ba": None if ba is None else ba.result(),
            "tracked_kpts_per_frame": round(state["tracked"] / max(state["tracked_steps"], 1) / S, 1),
            "pose": None if not pose else {"accepted_fraction": pst["accepted"] / max(pst["asked"], 1),
                                           "five_point_accepted_fraction": pst["acc5"] / max(pst["asked5"], 1),
@@ -501,6 +508,56 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     for c_ in (ctx, ctx_pyr, ctx_right):                         # (the copy context lives as long as the process: copy_ctx)
         c_.close()
     return res
+
+
+class BAWorker:
+    """The reference's estimator task (#3, estimator.jl:78-99) for S lock-stepped streams: every key-frame step hands the S windows of the
+    streams (reference-shaped: 5 free + 20 constant key-frames, estimator.jl:327-331) to slam_local_ba_batch on a context and a host thread
+    of their own; the front-end loop goes on.  A new hand-over first waits for the previous solve (the estimator takes key-frames in order),
+    so a solve slower than a key-frame period shows in the loop's frame rate.  The windows are synthetic (the array contract of
+    _get_ba_parameters, estimator.jl:143-266, filled by synthetic.ba_scene): map bookkeeping stays on the host in the reference."""
+
+    def __init__(self, slam, syn, local_rank, S, prio=0):
+        import threading
+        self.threading = threading
+        self.ctx = leg_ctx(slam, local_rank, prio)
+        base = [syn.ba_scene(P=25, M=800, seed=100 + z, n_const=20) for z in range(8)]
+        caches = [slam.LocalBACache(base[z % 8]["theta0"].copy(), base[z % 8]["theta_const"], base[z % 8]["pixels_yx"], base[z % 8]["pose_ids"],
+                                    base[z % 8]["point_ids"]) for z in range(S)]
+        self.batch = slam.BABatch(caches, base[0]["cam"])
+        self.S = S; self.th = None; self.calls = 0; self.wall = 0.0; self.wait = 0.0; self.err = None
+        self.batch.solve(ctx=self.ctx, reset=True)                  # warm-up: scratch, pinned block, function attributes
+
+    def _run(self):
+        try:
+            t0 = time.perf_counter()
+            self.batch.solve(ctx=self.ctx, reset=True)
+            self.wall += time.perf_counter() - t0; self.calls += 1
+        except Exception as ex:                                     # noqa: BLE001
+            self.err = ex
+
+    def join(self):
+        if self.th is not None:
+            t0 = time.perf_counter(); self.th.join(); self.wait += time.perf_counter() - t0; self.th = None
+        if self.err is not None:
+            raise self.err
+
+    def submit(self):
+        self.join()
+        self.th = self.threading.Thread(target=self._run); self.th.start()
+
+    def reset_counters(self):
+        self.join(); self.calls = 0; self.wall = 0.0; self.wait = 0.0
+
+    def result(self):
+        self.join()
+        ok = bool((self.batch.status == 0).all())
+        return {"windows_per_call": self.S, "calls": self.calls, "mean_call_ms": self.wall / max(self.calls, 1) * 1e3,
+                "front_end_waited_ms_per_call": self.wait / max(self.calls, 1) * 1e3, "all_windows_ok": ok,
+                "window": "5 free + 20 constant key-frames, 800 points, 8000 observations (estimator.jl:327-331), 5 + 10 LM iterations"}
+
+    def close(self):
+        self.join(); self.ctx.close()
 
 
 def leg_ctx(slam, local_rank, priority=0):

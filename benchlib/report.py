@@ -82,6 +82,13 @@ def compact_line(out):
                    "windows_ms_per_iter": {k: _r(v["ms_per_iter"]) for k, v in ba.get("windows", {}).items()},
                    "roofline_frac_P50": _r(ba.get("windows", {}).get("P50", {}).get("roofline", {}).get("frac")),
                    "cpu_ms_per_iter_schur": _r(ba.get("cpu_ms_per_iter_schur")), "cpu_ms_per_iter_lm_lsmr": _r(ba.get("cpu_ms_per_iter_reference_style_lm_lsmr"))}
+    if ba and ba.get("batch"):
+        c["ba"]["batch"] = {k: {"windows": v["windows"], "wall_ms": _r(v["wall_ms_per_call"]), "device_ms": _r(v["device_ms_per_call"]), "windows_per_s": _r(v["windows_per_s"])}
+                            for k, v in ba["batch"].items()}
+    fb = out.get("frontend_with_ba")
+    if fb:
+        c["frontend_with_ba"] = ({"value": _r(fb["value"]), "fraction_of_headline": _r(fb.get("fraction_of_headline")), "ba_call_ms": _r(fb["local_ba"]["mean_call_ms"]),
+                                  "windows_per_call": fb["local_ba"]["windows_per_call"]} if "value" in fb else {"error": fb.get("error", "")[:120]})
     bs = out.get("ba_sharded")
     if bs:
         c["ba_sharded"] = {k: _r(bs.get(k)) for k in ("world_size", "window_kf", "ms_per_iter_wall", "worth_sharding", "error") if bs.get(k) is not None}

@@ -13,7 +13,7 @@ from .extractor import Extractor, detect, detect_batch, describe, brief_pattern 
 from .optical_flow import (LKPyramid, LucasKanade, update_, copy_, deepcopy, has_gradients, fb_tracking_,  # noqa: F401
                            optical_flow_matching, optical_flow_matching_frame, PyramidBatch, optical_flow_matching_batch,
                            optical_flow_matching_batch_kept)
-from .bundle_adjustment import LocalBACache, bundle_adjustment_, bundle_adjustment_batch_, ba_plan_order, pnp_bundle_adjustment, pnp_bundle_adjustment_batch  # noqa: F401
+from .bundle_adjustment import LocalBACache, bundle_adjustment_, bundle_adjustment_batch_, BABatch, ba_plan_order, pnp_bundle_adjustment, pnp_bundle_adjustment_batch  # noqa: F401
 from .triangulation import triangulate, projection_matrices  # noqa: F401
 from .pose import p3p_ransac, five_point_ransac, draw_samples, p3p_ransac_batch, five_point_ransac_batch  # noqa: F401
 from .kitti import KittyDataset  # noqa: F401

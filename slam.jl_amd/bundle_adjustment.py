@@ -52,36 +52,57 @@ def bundle_adjustment_(cache, camera, iterations=10, repr_eps=5.0, iters_fast=5,
     return cache
 
 
+class BABatch:
+    """The arrays of S LocalBACaches stored back to back as `slam_local_ba_batch` takes them (packed once; `theta0` is kept so that the
+    same windows can be solved again: bench.py).  cameras: one (fx, fy, cx, cy) / Camera or one per cache."""
+
+    def __init__(self, caches, cameras):
+        S = self.S = len(caches)
+        one = hasattr(cameras, "intrinsics") or np.ndim(cameras) == 1
+        self.cams = np.asarray([(c.intrinsics if hasattr(c, "intrinsics") else c) for c in ([cameras] * S if one else cameras)], dtype=np.float64).reshape(S, 4)
+        th = [np.ascontiguousarray(c.theta, dtype=np.float64) for c in caches]
+        tc = [np.ascontiguousarray(c.theta_const, dtype=np.uint8) for c in caches]
+        px = [np.ascontiguousarray(c.pixels, dtype=np.float64).reshape(-1, 2) for c in caches]
+        pi = [np.ascontiguousarray(c.poses_ids, dtype=np.int64) for c in caches]
+        li = [np.ascontiguousarray(c.points_ids, dtype=np.int64) for c in caches]
+        self.Pn = np.array([len(t) for t in tc], dtype=np.int32); self.On = np.array([len(t) for t in pi], dtype=np.int32)
+        self.Mn = np.array([(len(t) - 6 * p) // 3 for t, p in zip(th, self.Pn)], dtype=np.int32)
+        cat = lambda xs, dt, shape=(0,): np.ascontiguousarray(np.concatenate(xs)) if sum(len(x) for x in xs) else np.zeros(shape, dtype=dt)
+        self.theta0 = cat(th, np.float64); self.theta = self.theta0.copy()
+        self.tc = cat(tc, np.uint8); self.px = cat(px, np.float64, (0, 2)); self.pi = cat(pi, np.int64); self.li = cat(li, np.int64)
+        self.outl = np.zeros(max(int(self.On.sum()), 1), dtype=np.uint8)
+        self.stats = np.zeros((S, 8)); self.status = np.zeros(S, dtype=np.int32)
+        self.th_off = np.concatenate([[0], np.cumsum(6 * self.Pn.astype(np.int64) + 3 * self.Mn)])
+        self.ob_off = np.concatenate([[0], np.cumsum(self.On.astype(np.int64))])
+
+    def solve(self, iterations=10, repr_eps=5.0, iters_fast=5, ctx=None, reset=False):
+        """one `slam_local_ba_batch` call on the packed arrays (theta in place; reset: start again from theta0)"""
+        ctx = ctx or L.default_context()
+        if reset:
+            self.theta[:] = self.theta0
+        ctx.check(ctx.lib.slam_local_ba_batch(ctx.h, self.S, L.ptr(self.cams), L.ptr(self.Pn, L.i32p), L.ptr(self.Mn, L.i32p), L.ptr(self.On, L.i32p),
+                                              L.ptr(self.theta), L.ptr(self.tc, L.u8p), L.ptr(self.px), L.ptr(self.pi, L.i64p), L.ptr(self.li, L.i64p),
+                                              L.ptr(self.outl, L.u8p), int(iters_fast), int(iterations), float(repr_eps), L.ptr(self.stats),
+                                              L.ptr(self.status, L.i32p)))
+        return self.status
+
+    def window(self, z):
+        """(theta, outliers, stats dict) of window z after solve()"""
+        st = self.stats[z]
+        return (self.theta[self.th_off[z]:self.th_off[z + 1]].copy(), self.outl[self.ob_off[z]:self.ob_off[z + 1]].astype(bool),
+                dict(ssr_init=st[0], ssr_pass1=st[1], ssr_final=st[2], iters_pass1=int(st[3]), iters_pass2=int(st[4]), n_outliers=int(st[5]),
+                     device_ms=st[6], status=int(self.status[z])))
+
+
 def bundle_adjustment_batch_(caches, cameras, iterations=10, repr_eps=5.0, iters_fast=5, ctx=None):
     """bundle_adjustment! for a list of LocalBACaches in one set of launches (`slam_local_ba_batch`): the estimator tasks of S
     lock-stepped SlamManagers (estimator.jl:78-99).  cameras: one (fx, fy, cx, cy) / Camera or one per cache.  Mutates every cache
     (theta, outliers, stats); returns the per-window status codes (0 = ok, SLAM_ERR_NUMERIC = that window left unchanged)."""
-    ctx = ctx or L.default_context()
-    S = len(caches)
-    one = hasattr(cameras, "intrinsics") or np.ndim(cameras) == 1
-    cams = np.asarray([(c.intrinsics if hasattr(c, "intrinsics") else c) for c in ([cameras] * S if one else cameras)], dtype=np.float64).reshape(S, 4)
-    th = [np.ascontiguousarray(c.theta, dtype=np.float64) for c in caches]
-    tc = [np.ascontiguousarray(c.theta_const, dtype=np.uint8) for c in caches]
-    px = [np.ascontiguousarray(c.pixels, dtype=np.float64).reshape(-1, 2) for c in caches]
-    pi = [np.ascontiguousarray(c.poses_ids, dtype=np.int64) for c in caches]
-    li = [np.ascontiguousarray(c.points_ids, dtype=np.int64) for c in caches]
-    Pn = np.array([len(t) for t in tc], dtype=np.int32); On = np.array([len(t) for t in pi], dtype=np.int32)
-    Mn = np.array([(len(t) - 6 * p) // 3 for t, p in zip(th, Pn)], dtype=np.int32)
-    theta = np.concatenate(th) if S else np.zeros(0)
-    cat = lambda xs, dt, shape=(0,): np.ascontiguousarray(np.concatenate(xs)) if sum(len(x) for x in xs) else np.zeros(shape, dtype=dt)
-    tca = cat(tc, np.uint8); pxa = cat(px, np.float64, (0, 2)); pia = cat(pi, np.int64); lia = cat(li, np.int64)
-    outl = np.zeros(max(int(On.sum()), 1), dtype=np.uint8)
-    st = np.zeros((S, 8)); status = np.zeros(S, dtype=np.int32)
-    ctx.check(ctx.lib.slam_local_ba_batch(ctx.h, S, L.ptr(cams), L.ptr(Pn, L.i32p), L.ptr(Mn, L.i32p), L.ptr(On, L.i32p), L.ptr(theta), L.ptr(tca, L.u8p),
-                                          L.ptr(pxa), L.ptr(pia, L.i64p), L.ptr(lia, L.i64p), L.ptr(outl, L.u8p), int(iters_fast), int(iterations),
-                                          float(repr_eps), L.ptr(st), L.ptr(status, L.i32p)))
-    to = np.concatenate([[0], np.cumsum(6 * Pn.astype(np.int64) + 3 * Mn)]); oo = np.concatenate([[0], np.cumsum(On.astype(np.int64))])
+    b = BABatch(caches, cameras)
+    status = b.solve(iterations=iterations, repr_eps=repr_eps, iters_fast=iters_fast, ctx=ctx)
     for z, c in enumerate(caches):
-        c.theta = theta[to[z]:to[z + 1]].copy()
-        c.outliers = outl[oo[z]:oo[z + 1]].astype(bool)
-        c.stats = dict(ssr_init=st[z, 0], ssr_pass1=st[z, 1], ssr_final=st[z, 2], iters_pass1=int(st[z, 3]), iters_pass2=int(st[z, 4]),
-                       n_outliers=int(st[z, 5]), device_ms=st[z, 6], status=int(status[z]))
-    return status
+        c.theta, c.outliers, c.stats = b.window(z)
+    return status.copy()
 
 
 def ba_plan_order(cache):

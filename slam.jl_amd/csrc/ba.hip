@@ -545,7 +545,7 @@ __device__ __forceinline__ void schur_groups_body(const BADev &d, double inv_del
         }
         d.hasp[i] = hp ? 1 : 0;
         st_rec<2>(d.f + 2 * (size_t)i, r2);
-        st_rec<12>(d.Jp + (size_t)i * 12, Jp);
+        if (hp) st_rec<12>(d.Jp + (size_t)i * 12, Jp);     // (k_update_groups takes zeros where hasp is clear: the reference's window is 80 % observations of constant poses)
         st_rec<6>(d.Jl + (size_t)i * 6, Jl);
         if (hp) s_slot[pl * hbw + (p - f)] = (short)tid;
         double *v = s_W + tid * 18;
@@ -1912,9 +1912,14 @@ __device__ __forceinline__ void update_groups_body(const BADev &d, int ignore_ou
     if (tid < nobs) {
         p = d.opose[i]; pl = d.opk[i] - k0;
         active = !(ignore_outliers && d.outl[i]);
-        ld_rec<12>(d.Jp + (size_t)i * 12, jp); ld_rec<6>(d.Jl + (size_t)i * 6, jl); ld_rec<2>(d.f + 2 * (size_t)i, ff);
+        if (d.hasp[i]) ld_rec<12>(d.Jp + (size_t)i * 12, jp);
+        else {
 #pragma unroll
-        for (int k = 0; k < 6; k++) { a += jp[k] * s_dp[6 * p + k]; b += jp[6 + k] * s_dp[6 * p + k]; }     // Jp = 0 unless the observation has a free pose
+            for (int k = 0; k < 12; k++) jp[k] = 0.0;                                                           // Jp = 0 unless the observation has a free pose (not stored then)
+        }
+        ld_rec<6>(d.Jl + (size_t)i * 6, jl); ld_rec<2>(d.f + 2 * (size_t)i, ff);
+#pragma unroll
+        for (int k = 0; k < 6; k++) { a += jp[k] * s_dp[6 * p + k]; b += jp[6 + k] * s_dp[6 * p + k]; }
 #pragma unroll
         for (int k = 0; k < 3; k++) s_u[tid * 3 + k] = jl[k] * a + jl[3 + k] * b;
     }
