@@ -423,6 +423,8 @@ def main():
             tnode = out.setdefault("tolerance_mode", {})
             tnode["batch"] = {"value": tb["value"], "unit": "frames/sec", "streams_per_gpu": S, "steps": tb["steps"], "ms_per_step": tb["ms_per_step"],
                               "tracked_kpts_per_frame": tb["tracked_kpts_per_frame"],
+                              "lk_match": None if not tb.get("lk_match") else dict(tb["lk_match"], ns_per_point=tb["lk_match"]["mean_ms"] * 1e6 / max(tb["lk_match"]["points_per_launch"], 1),
+                                                                                   kernel="k_kpset_match<6, TOL>: contracted arithmetic (positions <= 1e-6 px)"),
                               "pyramid": "slam_pyr_update_batch_u8_dev mode 3: dim-1 stage k_cols_fused<TOL> (product planes leave as suffix sums along y), dim-2 stage + running sum "
                                          "along x + imresize! in ONE kernel k_rows_tol (1 R + 1 W per plane); planes <= 1e-11 relative, positions <= 1e-6 px",
                               "roofline": {"bound": "hbm", "stage": f"LK pyramid update of {S} images, tolerance mode", "algorithmic_bytes_per_launch": pbt,

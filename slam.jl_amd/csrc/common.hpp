@@ -59,6 +59,7 @@ struct slam_pyr {
     Alloc *alloc = nullptr;
     size_t zstride = 0;                   // doubles between consecutive images of a batch (7 * off[levels])
     int batch_index = 0, batch_size = 1;
+    bool tol_planes = false;              // last update ran in tolerance mode (mode 3): matches between two such pyramids take the contracted-arithmetic tracking kernels
     bool target_only = false;             // last update built the gradient / integral planes of level 0 only (SLAM_PYR_TARGET_ONLY): usable as the `to` pyramid of a match
     double *planes = nullptr;             // 6 planes x off[levels] doubles (inside alloc)
     double *tmp = nullptr;                // blur scratch, off[levels] doubles

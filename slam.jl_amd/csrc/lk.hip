@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include <vector>
 #include <cmath>
+#include <cstdlib>
 
 struct LKArgs {
     PyrView prev, cur;
@@ -52,6 +53,7 @@ extern "C" int slam_debug_lk_ticks(unsigned long long *out)
 #else
 #define LK_OCC __attribute__((amdgpu_waves_per_eu(LK_MAXE == 9 ? 2 : 3, LK_MAXE == 9 ? 2 : 3)))
 #endif
+#define LK_PM 4
 struct Offs { int up, down, left, right; };
 
 __device__ __forceinline__ Offs get_offsets(int p0, int p1, double n0, double n1, int window, int H, int W)
@@ -214,7 +216,7 @@ template <int LK_MAXE> struct Tmpl {
 };
 struct __attribute__((packed, aligned(8))) D2 { double a, b; };   // two vertically adjacent samples, one 16-byte load
 
-template <int LK_MAXE>
+template <int LK_MAXE, bool TOL>
 __device__ __forceinline__ void load_template(Tmpl<LK_MAXE> &T, const LevelView &first, int p0, int p1, Offs o)
 {
     const int lane = threadIdx.x & 63, pitch = first.P;
@@ -248,7 +250,9 @@ __device__ __forceinline__ void load_template(Tmpl<LK_MAXE> &T, const LevelView 
 #else
         T.t0[k] = in ? v0 : 0.0; T.t1[k] = in ? v1 : 0.0; T.t2[k] = in ? v2 : 0.0;
 #endif
-        T.pq[k] = p | (q << 16);
+        // tolerance mode: the element's offset inside the LDS patch (its window coordinates are not needed: the bilinear weights are
+        // the estimate's own fractions there)
+        T.pq[k] = TOL ? p + q * (2 * (LK_MAXE == 3 ? 6 : LK_MAXE == 6 ? 9 : 11) + 2 + 2 * LK_PM) : (p | (q << 16));
     }
 }
 
@@ -259,7 +263,6 @@ __device__ __forceinline__ void load_template(Tmpl<LK_MAXE> &T, const LevelView 
 // together with the template loads -- and every iteration reads its four bilinear samples per element from LDS
 // (ds_read2_b64 x 2) instead of waiting for two global round trips.  The patch is re-staged, centred on the current estimate,
 // only when the footprint leaves it.  Same samples, same operations, same order: results are bit-identical to the global path.
-#define LK_PM 4
 template <int LK_MAXE> struct PatchGeom {
     static constexpr int WMAX = LK_MAXE == 3 ? 6 : LK_MAXE == 6 ? 9 : 11;        // largest window_size of the instantiation
     static constexpr int PS = 2 * WMAX + 2 + 2 * LK_PM;                           // 22 / 28 / 32 (even)
@@ -296,7 +299,12 @@ __device__ __forceinline__ void stage_patch(double *patch, const double *img, in
 
 // One pyramid level of optflow! for one point (lucas_kanade.jl:33-96).  All
 // control flow is wave-uniform.  Returns the point's status.
-template <int LK_MAXE>
+// TOL (tolerance mode, selected for pyramids built in mode 3): the iteration's arithmetic is contracted -- bilinear() as two-operation
+// lerps a + f (b - a) with the estimate's own fractions as weights (floor(r + dp) == floor(r) + dp, so the per-element fractions the
+// reference forms differ from them by rounding only), fused multiply-adds in the two accumulations and the 2 x 2 solve: 9 Float64
+// operations per window element instead of 26.  Positions agree with the sequential-order oracle to <= 1e-6 px (the summation order
+// already differs by rounding); keypoint INDICES never pass through here (detect works on the raw frame).
+template <int LK_MAXE, bool TOL>
 __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView &second, int level,
                          double pty, double ptx, double &dy, double &dx,
                          int window, int iterations, double eig_thr, double eps)
@@ -347,7 +355,7 @@ __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView
             stage_patch<PS>(lds_patch, second.L, H, W, pitch, iy0 - window - 1 - pmarg, ix0 - window - 1 - pmarg, pry, prx);
         if (it < 0 || no.up != o.up || no.down != o.down || no.left != o.left || no.right != o.right) {
             o = no;
-            if (cached) load_template(T, first, p0, p1, o);
+            if (cached) load_template<LK_MAXE, TOL>(T, first, p0, p1, o);
             const double min_eig = spatial_gradient(first, p0, p1, o, Gi);
             LKT(1);
             if (min_eig < eig_thr) return false;
@@ -365,6 +373,33 @@ __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView
             // bilinear(): rows iy-1, iy of columns ix-1, ix -> two 16-byte LDS reads per element
             // (in two halves of LK_MAXE / 2 slots: fewer registers in flight)
             constexpr int HS = (LK_MAXE + 1) / 2;
+            if (TOL) {
+                const double fy = r0 - fr0, fx = r1 - fr1;
+#pragma unroll
+                for (int h0 = 0; h0 < LK_MAXE; h0 += HS) {
+                    D2 c0v[HS], c1v[HS];
+#pragma unroll
+                    for (int j = 0; j < HS; j++) {
+                        const int k = h0 + j;
+                        if (k < LK_MAXE && k < T.kmax) { const double *ptr = pb + T.pq[k]; c0v[j] = *(const D2 *)ptr; c1v[j] = *(const D2 *)(ptr + PS); }
+                    }
+#pragma unroll
+                    for (int j = 0; j < HS; j++) {
+                        const int k = h0 + j;
+                        if (k < LK_MAXE && k < T.kmax) {
+                            const double t0 = __builtin_fma(fx, c1v[j].a - c0v[j].a, c0v[j].a);
+                            const double t1 = __builtin_fma(fx, c1v[j].b - c0v[j].b, c0v[j].b);
+#ifdef LK_TMPL_LDS
+                            const double dI = T.s[0][k][lane] - __builtin_fma(fy, t1 - t0, t0);
+                            ay = __builtin_fma(dI, T.s[1][k][lane], ay); ax = __builtin_fma(dI, T.s[2][k][lane], ax);
+#else
+                            const double dI = T.t0[k] - __builtin_fma(fy, t1 - t0, t0);
+                            ay = __builtin_fma(dI, T.t1[k], ay); ax = __builtin_fma(dI, T.t2[k], ax);
+#endif
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int h0 = 0; h0 < LK_MAXE; h0 += HS) {
                 D2 c0v[HS], c1v[HS];
@@ -409,7 +444,7 @@ __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView
         }
         LKT(3);
         wave_sum2(ay, ax);
-        const double fl0 = Gi[0] * ay + Gi[2] * ax, fl1 = Gi[1] * ay + Gi[3] * ax;
+        const double fl0 = TOL ? __builtin_fma(Gi[0], ay, Gi[2] * ax) : Gi[0] * ay + Gi[2] * ax, fl1 = TOL ? __builtin_fma(Gi[1], ay, Gi[3] * ax) : Gi[1] * ay + Gi[3] * ax;
         if (fabs(fl0) < eps && fabs(fl1) < eps) break;
         c0 += fl0; c1 += fl1;
         if (!lies_in(H, W, r0 + fl0, r1 + fl1)) return false;
@@ -432,7 +467,7 @@ __device__ __forceinline__ LevelView shifted(const LevelView &v, size_t off)
 // offP / offC: plane offset (doubles) of this point's image inside a pyramid batch (0 for single pyramids).
 // The forward levels and the backward pass run through ONE inlined copy of lk_level (a loop over passes with the
 // roles of the two pyramids swapped for the last one): the tracking kernels are a few KB instead of ~100 KB.
-template <int LK_MAXE>
+template <int LK_MAXE, bool TOL = false>
 __device__ __forceinline__ bool fb_point(const PyrView &prev, const PyrView &cur, double py, double px, double dy, double dx,
                                          int pyramid_levels, int window, int iterations, double eig_thr, double eps,
                                          double max_distance, double &ny, double &nx, size_t offP = 0, size_t offC = 0)
@@ -448,7 +483,7 @@ __device__ __forceinline__ bool fb_point(const PyrView &prev, const PyrView &cur
         }
         // backward: pyramid_levels = 0, default eps 1e-2 (tracker.jl:34,51-57)
         const PyrView *pf = back ? &cur : &prev, *ps = back ? &prev : &cur;
-        const bool ok = lk_level<LK_MAXE>(shifted(pf->lv[level - 1], back ? offC : offP), shifted(ps->lv[level - 1], back ? offP : offC),
+        const bool ok = lk_level<LK_MAXE, TOL>(shifted(pf->lv[level - 1], back ? offC : offP), shifted(ps->lv[level - 1], back ? offP : offC),
                                           level, qy, qx, cy, cx, window, iterations, eig_thr, back ? 1e-2 : eps);
         if (!ok) return false;
     }
@@ -554,7 +589,7 @@ __device__ __forceinline__ void pdn_to_pixel(const double *cam, const double *di
     const double dty = dist[2] * (r2 + 2 * s1) + 2 * dist[3] * p;
     oy = (rd * ny + dty) * cam[1] + cam[3]; ox = (rd * nx + dtx) * cam[0] + cam[2];
 }
-template <int LK_MAXE>
+template <int LK_MAXE, bool TOL>
 __global__ __launch_bounds__(64) LK_OCC void k_kpset_match(KpMatchArgs M)
 {
     const int ntot = M.ntot[0], per = (ntot + LK_XCDS - 1) / LK_XCDS;
@@ -594,7 +629,7 @@ __global__ __launch_bounds__(64) LK_OCC void k_kpset_match(KpMatchArgs M)
             const double scale = 1.0 / (double)(1 << M.levels3d);
             dy = scale * (pry - py); dx = scale * (prx - px);                                        // map_manager.jl:494,504
         }
-        ok = fb_point<LK_MAXE>(M.from, M.to, py, px, dy, dx, att == 0 ? M.levels3d : M.pyramid_levels, M.window, M.iterations, M.eig_thr, M.eps,
+        ok = fb_point<LK_MAXE, TOL>(M.from, M.to, py, px, dy, dx, att == 0 ? M.levels3d : M.pyramid_levels, M.window, M.iterations, M.eig_thr, M.eps,
                                M.max_distance, ny, nx, offF, offT);
     }
     if (lane0 && !M.stereo_mode) {
@@ -641,9 +676,17 @@ static int kpset_match(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *from0, con
     const int nb = n_bound > 0 && n_bound < nmax ? n_bound : nmax;
     { ProfScope span(ctx, "fb_track");
       const int ne = (2 * window + 1) * (2 * window + 1);
-      if (ne <= 192) hipLaunchKernelGGL(k_kpset_match<3>, dim3(lk_grid(nb)), dim3(64), 0, ctx->stream, M);
-      else if (ne <= 384) hipLaunchKernelGGL(k_kpset_match<6>, dim3(lk_grid(nb)), dim3(64), 0, ctx->stream, M);
-      else hipLaunchKernelGGL(k_kpset_match<9>, dim3(lk_grid(nb)), dim3(64), 0, ctx->stream, M); }
+      // both pyramids built in tolerance mode (slam_pyr_update* mode 3): the contracted-arithmetic instantiation (positions <= 1e-6 px)
+      static const bool no_tol_lk = getenv("SLAMHIP_NO_TOL_LK") != nullptr;
+      const bool tol = from0->tol_planes && to0->tol_planes && !no_tol_lk;
+      if (tol) {
+          if (ne <= 192) hipLaunchKernelGGL((k_kpset_match<3, true>), dim3(lk_grid(nb)), dim3(64), 0, ctx->stream, M);
+          else if (ne <= 384) hipLaunchKernelGGL((k_kpset_match<6, true>), dim3(lk_grid(nb)), dim3(64), 0, ctx->stream, M);
+          else hipLaunchKernelGGL((k_kpset_match<9, true>), dim3(lk_grid(nb)), dim3(64), 0, ctx->stream, M);
+      }
+      else if (ne <= 192) hipLaunchKernelGGL((k_kpset_match<3, false>), dim3(lk_grid(nb)), dim3(64), 0, ctx->stream, M);
+      else if (ne <= 384) hipLaunchKernelGGL((k_kpset_match<6, false>), dim3(lk_grid(nb)), dim3(64), 0, ctx->stream, M);
+      else hipLaunchKernelGGL((k_kpset_match<9, false>), dim3(lk_grid(nb)), dim3(64), 0, ctx->stream, M); }
     HIP_TRY(ctx, hipGetLastError());
     return kpset_compact(ctx, ks, 0, nullptr);                   // lost keypoints (st = 0) leave the lists; stable
 }

@@ -1944,40 +1944,41 @@ struct BuildSink {
     void fork() { if (graph && forked) fork_dep = last[LN_MAIN]; }
 };
 
-static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf, BuildSink &B, bool spans, int S = 1, int src_kind = 0, bool target = false)
+// One level of the build for the images [z0, z0 + S) of a batch of Sall (kernel selection follows Sall: a sub-batch runs the kernels the
+// whole batch would).
+static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf, BuildSink &B, bool spans, int S, int src_kind, bool target, int l, int z0, int Sall, bool fast)
 {
-    const size_t zs = p->zstride;
-    bool fast = mode == 3;
-    if (fast && (seg_len(p->H[0], PAR_T / 8) > PAR_SLMAX || seg_len(p->W[0], PAR_T / 8) > PAR_SLMAX)) fast = false;   // lines > 2048 samples: exact kernels
-    if (fast && S >= 4) fast = false;   // the segmented kernels buy latency for ONE image; with several images per launch the exact kernels are faster (and trivially within the tolerance)
+    const size_t zs = p->zstride, zo = (size_t)z0 * zs;
     const int border_mode = (mode == 0) ? 1 : 0;
-    for (int l = 0; l < p->levels; l++) {
+    {
         const int H = p->H[l], W = p->W[l], P = p->P[l];
-        const LevelView &v = p->view.lv[l];
+        LevelView v = p->view.lv[l];
+        v.L += zo; v.Iy += zo; v.Ix += zo; v.Iyy += zo; v.Ixx += zo; v.Iyx += zo;
         const bool has_next = l + 1 < p->levels;
-        double *T = p->tmp + p->off[l];
+        double *T = p->tmp + p->off[l] + zo;
+        double *nextL = has_next ? p->view.lv[l + 1].L + zo : nullptr;
         if (target && l >= 1) {                                   // the layer chain only: blur (dim 1, dim 2) -> resize
-            if (!has_next) continue;
+            if (!has_next) return;
             PlaneSet pt = {}; pt.p[0] = T; pt.coef[0] = 0; pt.fill0[0] = (mode == 0); pt.nrm[0] = nullptr; pt.n = 1; pt.zs = zs;
-            const bool ckr = (mode != 3 || S >= 4) && p->ck != nullptr && mode != 0 && W >= 64 && H >= 64 && (size_t)S * 4 * H * W * 8 >= ck_min_bytes();
+            const bool ckr = (mode != 3 || Sall >= 4) && p->ck != nullptr && mode != 0 && W >= 64 && H >= 64 && (size_t)Sall * 4 * H * W * 8 >= ck_min_bytes();
             if (ckr) B.launch(k_iir_cols_ck, lines_grid(W, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, pt, (const double *)v.L, H, W, P, cf, p->ck);
             else B.launch(k_iir_cols<2>, lines_grid(W, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, pt, (const double *)v.L, H, W, P, cf);
             static const bool no_rr = getenv("SLAMHIP_NO_ROWS_RESIZE") != nullptr;
             const bool rr = ckr && (H & 1) == 0 && !no_rr;
             RowResize rzt = {};
-            if (rr) { rzt.dst = p->view.lv[l + 1].L; rzt.Hd = p->H[l + 1]; rzt.Wd = p->W[l + 1]; rzt.Pd = p->P[l + 1]; }
+            if (rr) { rzt.dst = nextL; rzt.Hd = p->H[l + 1]; rzt.Wd = p->W[l + 1]; rzt.Pd = p->P[l + 1]; }
             if (ckr) B.launch(k_iir_rows_ck, lines_grid(H, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, pt, H, W, P, cf, p->ck, rzt);
             else B.launch(k_iir_rows, lines_grid(H, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, pt, H, W, P, cf);
             if (!rr)
                 B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
-                                   p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
-            continue;
+                                   nextL, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
+            return;
         }
         // bandwidth-bound launches (many images x a large level) take the checkpointed IIR kernels; the column one squares
         // Iy / Ix itself, so the gradient kernel does not write (and the filter does not re-read) the Iyy / Ixx inputs
         const int np_ = has_next ? 4 : 3;
         static const bool no_ck_cols = getenv("SLAMHIP_NO_CK_COLS") != nullptr;     // tuning toggles are read once per process: a cached graph never disagrees with them
-        const bool ck_cols = !fast && p->ck != nullptr && mode != 0 && H >= 64 && (size_t)S * np_ * H * W * 8 >= ck_min_bytes() && !no_ck_cols;
+        const bool ck_cols = !fast && p->ck != nullptr && mode != 0 && H >= 64 && (size_t)Sall * np_ * H * W * 8 >= ck_min_bytes() && !no_ck_cols;
         static const bool no_sq = getenv("SLAMHIP_NO_SQ_FUSE") != nullptr;
         const bool fuse_sq = ck_cols && !no_sq;
         // ... and the fully fused dim-1 stage (Scharr + products + the four dim-1 recurrences straight from the layer)
@@ -2023,11 +2024,11 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
                     RowsTolArgs rt = {};
                     rt.p[0] = T; rt.coef[0] = 0; rt.kind[0] = 0; rt.n = 1; rt.nq0 = 1; rt.zs = zs;
                     const bool rzf = (H & 1) == 0;
-                    if (rzf) { rt.rz.dst = p->view.lv[l + 1].L; rt.rz.Hd = p->H[l + 1]; rt.rz.Wd = p->W[l + 1]; rt.rz.Pd = p->P[l + 1]; }
+                    if (rzf) { rt.rz.dst = nextL; rt.rz.Hd = p->H[l + 1]; rt.rz.Wd = p->W[l + 1]; rt.rz.Pd = p->P[l + 1]; }
                     if (spans) { ProfScope span(ctx, "k_iir_rows"); rows_tol(rt, 1, LN_MAIN); } else rows_tol(rt, 1, LN_MAIN);
                     if (!rzf)
                         B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
-                                           p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
+                                           nextL, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
                 }
                 B.launch(k_cum_seg<true>, gc3, dim3(PAR_T), 0, LN_AUX, pc, H, W, P, slc);
                 RowsTolArgs rq = {};
@@ -2035,7 +2036,7 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
                 for (int q = 0; q < 3; q++) { rq.coef[q] = 1; rq.kind[q] = 2; }
                 rq.n = 3; rq.nq0 = 0; rq.zs = zs;
                 rows_tol(rq, 3, LN_AUX);
-                continue;
+                return;
             }
             if (spans) { ProfScope span(ctx, "k_iir_rows");
                 B.launch(k_iir_seg<false>, gr, dim3(PAR_T), 0, LN_MAIN, ps, (const double *)nullptr, H, W, P, cf, spr, slr); }
@@ -2043,24 +2044,25 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             B.fork();
             if (has_next)
                 B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
-                                   p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
+                                   nextL, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
             B.launch(k_cum_seg<true>, gc3, dim3(PAR_T), 0, LN_AUX, pc, H, W, P, slc);
             B.launch(k_cum_seg<false>, gr3, dim3(PAR_T), 0, LN_AUX, pc, H, W, P, slr);
-            continue;
+            return;
         }
         // tolerance build of a batch (mode 3, S >= 4): the dim-1 stage leaves the product planes as suffix sums along y, ONE row kernel
         // finishes the level (dim-2 filter + running sum along x + imresize!): 1 R + 1 W per plane instead of 11 R + 6.25 W
         static const bool no_tol_batch = getenv("SLAMHIP_NO_TOL_BATCH") != nullptr;
         int rt_ns = RT_NS;
         const int slr_t = rt_seg_len(W, &rt_ns);
-        const bool tolb = mode == 3 && S >= 4 && cols_fused && p->alloc->tot != nullptr && slr_t > 0 && !no_tol_batch;
+        const bool tolb = mode == 3 && Sall >= 4 && cols_fused && p->alloc->tot != nullptr && slr_t > 0 && !no_tol_batch;
         if (cols_fused) {
             ColsFusedArgs ca;
             ca.L = v.L; ca.T = has_next ? T : nullptr; ca.Iy = v.Iy; ca.Ix = v.Ix; ca.Qyy = v.Iyy; ca.Qxx = v.Ixx; ca.Qyx = v.Iyx;
             ca.H = H; ca.W = W; ca.P = P; ca.zs = zs;
-            ca.src_kind = l == 0 ? src_kind : 0; ca.srctab = (const void *const *)p->alloc->srctab;
+            ca.src_kind = l == 0 ? src_kind : 0; ca.srctab = (const void *const *)p->alloc->srctab + z0;
             size_t toff = 0;
-            for (int q = 0; q < l; q++) toff += (size_t)3 * S * p->W[q];
+            for (int q = 0; q < l; q++) toff += (size_t)3 * Sall * p->W[q];
+            toff += (size_t)3 * z0 * W;
             ca.tot = tolb ? p->alloc->tot + toff : nullptr; ca.tot_stride = W;
             static const bool no_dec = getenv("SLAMHIP_NO_TOL_DEC") != nullptr;
             ca.dec = (tolb && has_next && (H & 1) == 0 && (P & 31) == 0 && !no_dec) ? 1 : 0;
@@ -2078,7 +2080,7 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
                 ra.n = nr; ra.zs = zs; ra.tot = ca.tot; ra.tot_stride = W;
                 const bool rzf = has_next && (H & 1) == 0;
                 ra.dec = ca.dec;
-                if (rzf) { ra.rz.dst = p->view.lv[l + 1].L; ra.rz.Hd = p->H[l + 1]; ra.rz.Wd = p->W[l + 1]; ra.rz.Pd = p->P[l + 1]; }
+                if (rzf) { ra.rz.dst = nextL; ra.rz.Hd = p->H[l + 1]; ra.rz.Wd = p->W[l + 1]; ra.rz.Pd = p->P[l + 1]; }
                 SegPow spr; rt_seg_pow(cf, slr_t, spr);
                 static const int rt_dbg = getenv("SLAMHIP_RT_DBG") ? atoi(getenv("SLAMHIP_RT_DBG")) : 0; ra.dbg = rt_dbg;
                 const dim3 gr((H + RT_R - 1) / RT_R, nr, S), bd(RT_R * rt_ns);
@@ -2096,20 +2098,20 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
                 if (spans) { ProfScope span(ctx, "k_iir_rows"); go(); } else go();
                 if (has_next && !rzf)
                     B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
-                                       p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
-                continue;
+                                       nextL, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
+                return;
             }
         }
         else if (ck_cols) B.launch(k_iir_cols_ck, lines_grid(W, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, src0, H, W, P, cf, p->ck);
         else if (S == 1) B.launch(k_iir_cols<3>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, src0, H, W, P, cf);
         else B.launch(k_iir_cols<2>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, src0, H, W, P, cf);
         // bandwidth-bound launches (many images x a large level) take the checkpointed row kernel (2R+1W instead of 2R+2W)
-        const bool ck_rows = p->ck != nullptr && mode != 0 && W >= 64 && (size_t)S * np * H * W * 8 >= ck_min_bytes();
+        const bool ck_rows = p->ck != nullptr && mode != 0 && W >= 64 && (size_t)Sall * np * H * W * 8 >= ck_min_bytes();
         // ... with the imresize! into the next level fused into the blurred layer's backward sweep when the row ratio is exactly 2:1
         static const bool no_rows_resize = getenv("SLAMHIP_NO_ROWS_RESIZE") != nullptr;
         const bool rows_resize = ck_rows && has_next && (H & 1) == 0 && !no_rows_resize;
         RowResize rz = {};
-        if (rows_resize) { rz.dst = p->view.lv[l + 1].L; rz.Hd = p->H[l + 1]; rz.Wd = p->W[l + 1]; rz.Pd = p->P[l + 1]; }
+        if (rows_resize) { rz.dst = nextL; rz.Hd = p->H[l + 1]; rz.Wd = p->W[l + 1]; rz.Pd = p->P[l + 1]; }
         if (spans) { ProfScope span(ctx, "k_iir_rows");
             if (ck_rows) B.launch(k_iir_rows_ck, lines_grid(H, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, H, W, P, cf, p->ck, rz);
             else B.launch(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, H, W, P, cf); }
@@ -2118,17 +2120,38 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         B.fork();
         if (has_next && !rows_resize)
             B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
-                               p->view.lv[l + 1].L, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
+                               nextL, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
         static const bool no_fused_cum = getenv("SLAMHIP_NO_FUSED_CUM") != nullptr;
-        if (S >= 8 && !no_fused_cum && H <= CF_MAXW * 64) {                 // batches: one-pass integral image
+        if (Sall >= 8 && !no_fused_cum && H <= CF_MAXW * 64) {                 // batches: one-pass integral image
             const int nw = (H + 63) / 64;
             const size_t lds = ((size_t)nw * CF_W * CF_LS + (size_t)nw * 2 * CF_W) * sizeof(double);
             B.launch(k_cum_fused, dim3(1, 3, S), dim3(nw * 64), lds, LN_AUX, pc, H, W, P);
-            continue;
+            return;
         }
         if (S == 1) B.launch(k_cum_cols<3>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, LN_AUX, pc, H, W, P);
         else B.launch(k_cum_cols<2>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, LN_AUX, pc, H, W, P);
         B.launch(k_cum_rows, lines_grid(H, 3, S), dim3(LINE_THREADS), 0, LN_AUX, pc, H, W, P);
+    }
+}
+
+
+// Launch every kernel of one pyramid build (see BuildSink above for where they go).  A large batch is built in SUB-BATCHES of the big
+// levels: the 3.5 intermediate planes a level's dim-1 stage leaves behind (12.7 MB per 370 x 1226 image) are re-read by its dim-2 stage
+// while they still sit in the 256 MiB Infinity Cache, instead of after the whole batch's 1.6 GB have gone through it.
+static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf, BuildSink &B, bool spans, int S = 1, int src_kind = 0, bool target = false)
+{
+    bool fast = mode == 3;
+    if (fast && (seg_len(p->H[0], PAR_T / 8) > PAR_SLMAX || seg_len(p->W[0], PAR_T / 8) > PAR_SLMAX)) fast = false;   // lines > 2048 samples: exact kernels
+    if (fast && S >= 4) fast = false;   // the segmented kernels buy latency for ONE image; with several images per launch the exact kernels are faster (and trivially within the tolerance)
+    static const int chunk_mb = [] { const char *v = getenv("SLAMHIP_PYR_CHUNK_MB"); return v ? atoi(v) : 0; }();      // intermediate planes of a sub-batch, MB (0: no sub-batches)
+    for (int l = 0; l < p->levels; l++) {
+        int C = S;
+        if (chunk_mb > 0 && S >= 8 && mode != 0) {
+            const size_t per_image = (size_t)4 * p->P[l] * p->W[l] * 8;                  // blurred layer + three product planes between the two stages
+            const size_t want = (size_t)chunk_mb << 20;
+            if (per_image * S > 2 * want) { C = (int)std::max<size_t>(4, want / per_image); C = std::min(C, S); }
+        }
+        for (int z0 = 0; z0 < S; z0 += C) launch_level(ctx, p, mode, cf, B, spans, std::min(C, S - z0), src_kind, target, l, z0, S, fast);
     }
 }
 
@@ -2166,6 +2189,7 @@ static int enqueue_build(slam_ctx *ctx, slam_pyr *p, int mode_flags, double sigm
     const bool chain = (mode_flags & SLAM_PYR_CHAIN) != 0 || linear_env;
     const int mode = mode_flags & ~SLAM_PYR_FLAGS;
     p->target_only = target;                                      // (the other members of a batch are marked by the batch entry points)
+    p->tol_planes = mode == 3;
     if (target) src_kind |= 16;                                   // part of the graph key
     if (chain) src_kind |= 32;
     IIRPair cf; cf.c[0] = slam_iir_coef(sigma); cf.c[1] = slam_iir_coef(4.0);   // lucas_kanade.jl:112
@@ -2300,7 +2324,7 @@ int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double
     if (fused_ingest) hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(BATCH_MAX), 0, ctx->stream, p0->alloc->srctab, ip);
     else hipLaunchKernelGGL(k_gather_images, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
     int rc = enqueue_build(ctx, p0, mode, sigma, S, fused_ingest ? 1 : 0);
-    for (int s = 0; s < S; s++) pyrs[s]->target_only = (mode & SLAM_PYR_TARGET_ONLY) != 0;
+    for (int s = 0; s < S; s++) { pyrs[s]->target_only = (mode & SLAM_PYR_TARGET_ONLY) != 0; pyrs[s]->tol_planes = (mode & ~SLAM_PYR_FLAGS) == 3; }
     if (rc) return rc;
     if (sync) HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
@@ -2321,7 +2345,7 @@ int slam_pyr_update_batch_u8_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const uin
     if (fused_ingest) { ImgPtrs iq; for (int s = 0; s < BATCH_MAX; s++) iq.p[s] = (const double *)ip.p[s]; hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(BATCH_MAX), 0, ctx->stream, p0->alloc->srctab, iq); }
     else hipLaunchKernelGGL(k_gather_images_u8, dim3((n + 255) / 256, 1, S), dim3(256), 0, ctx->stream, ip, p0->plane(0, 0), p0->H[0], p0->W[0], p0->P[0], p0->zstride);
     int rc = enqueue_build(ctx, p0, mode, sigma, S, fused_ingest ? 2 : 0);
-    for (int s = 0; s < S; s++) pyrs[s]->target_only = (mode & SLAM_PYR_TARGET_ONLY) != 0;
+    for (int s = 0; s < S; s++) { pyrs[s]->target_only = (mode & SLAM_PYR_TARGET_ONLY) != 0; pyrs[s]->tol_planes = (mode & ~SLAM_PYR_FLAGS) == 3; }
     if (rc) return rc;
     if (sync) HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     return SLAM_OK;
@@ -2389,6 +2413,7 @@ int slam_pyr_copy(slam_ctx *ctx, slam_pyr *dst, const slam_pyr *src)
     HIP_TRY(ctx, hipMemcpyAsync(dst->planes, src->planes, (size_t)src->off[src->levels] * 6 * 8, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, slam_stream_wait(ctx->stream));
     dst->target_only = src->target_only;       // what the planes are travels with them
+    dst->tol_planes = src->tol_planes;
     return SLAM_OK;
 }
 

@@ -103,3 +103,46 @@ def test_tolerance_batch_s128_kitti_vs_oracle(slam, syn, orc):
         for name in PLANES:
             g, r = tg.pyramids[s].plane(name, 0), ref.plane(name, 0)
             assert np.abs(g - r).max() / max(np.abs(r).max(), 1e-300) <= TOL, ("target_only", s, name)
+
+
+def test_tolerance_kpset_match_vs_oracle(slam, syn, orc, monkeypatch):
+    """slam_kpset_flow_match between two TOLERANCE-mode batches takes the contracted-arithmetic tracking kernel (lk.hip, TOL): against
+    the oracle's optical_flow_matching! on its exact planes, sequential summation order -- positions <= 1e-6 px, at most 0.5 % of the
+    keypoints differ in fate; SLAMHIP_NO_TOL_LK=1 (the exact kernel on the same planes) must agree to the same bar."""
+    import torch
+    monkeypatch.setenv("SLAMHIP_CK_MIN_MB", "1")
+    H, W, S = 370, 1226, 4
+    streams = [syn.stereo_stream((H, W), 2, seed=40 + s, step=(1.0 + 0.2 * s, -1.4)) for s in range(S)]
+    u8 = lambda im: np.asfortranarray(np.round(im * 255).astype(np.uint8))
+    def batch(k):
+        fr = [u8(streams[s][0][k]) for s in range(S)]
+        dev = torch.from_numpy(np.stack([np.ascontiguousarray(f.T) for f in fr])).cuda(); torch.cuda.synchronize()
+        pb = slam.PyramidBatch((H, W), levels=3, S=S)
+        pb.update_([dev.data_ptr() + s * H * W for s in range(S)], u8=True, fast=True)
+        return pb, [np.asfortranarray(f.astype(np.float64) / 255.0) for f in fr]
+    a, fa = batch(0); b, fb = batch(1)
+    params = slam.Params(stereo=True, max_nb_keypoints=1000)
+    rng = np.random.default_rng(3)
+    kps = [orc.detect(fa[s], np.zeros((0, 2)), max_points=1000).astype(float) for s in range(S)]
+    is3 = [rng.random(len(k)) < 0.6 for k in kps]
+    shift = np.array([streams[s][2][1] for s in range(S)], dtype=np.float64) + rng.normal(0, 0.4, (S, 2))
+    sp = slam.stream_params(S, cam=syn.KITTI_CAM, shift_yx=shift)
+    ks = slam.KeypointSet(S, 1400)
+    for s in range(S):
+        ks.upload(s, kps[s], is3[s])
+    ks.flow_match(a, b, params, sp, prior=2)
+    n_diff = n_all = 0; worst = 0.0
+    for s in range(S):
+        got = ks.download(s)
+        ra, rb = orc.pyr_build(fa[s], 3, 1.0, 1), orc.pyr_build(fb[s], 3, 1.0, 1)
+        ref = orc.optical_flow_matching(ra, rb, kps[s], is3[s], kps[s] + shift[s], (H, W), sum_order=0)
+        keep_ref = ~ref["removed"]
+        n_all += len(kps[s])
+        if len(got["yx"]) == keep_ref.sum():
+            d = np.abs(got["yx"] - ref["new_pixels"][keep_ref]).max(axis=1)
+            n_diff += int((d > 1e-6).sum()); worst = max(worst, float(d[d <= 1e-6].max()))
+        else:
+            n_diff += abs(len(got["yx"]) - int(keep_ref.sum())) + 1
+    assert n_diff <= max(1, n_all // 200), (n_diff, n_all)
+    assert worst <= 1e-6
+    ks.close()
