@@ -61,6 +61,7 @@ def spawn_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     deadline = time.time() + float(os.environ.get("SLAM_BENCH_SPAWN_TIMEOUT_S", "3600"))
+    t_start = time.time() - 1.0
     rc = 0
     live = list(procs)
     while live:
@@ -74,6 +75,14 @@ def spawn_ranks(args):
                 p.kill()
             for p in live:
                 p.wait()
+            part = os.path.join(ROOT, "bench_headline_partial.json")
+            if os.path.exists(part) and os.path.getmtime(part) >= t_start:      # rank 0 had measured the headline before a rank was lost: one line, marked
+                try:
+                    j = json.load(open(part))
+                    j["leg_error"] = {"after_leg": "headline", "error": f"a rank process exited with status {rc or 124}: the remaining ranks were stopped; the line is rank 0's headline as measured before that"}
+                    print(json.dumps(j, separators=(",", ":")), flush=True)
+                except Exception:                              # noqa: BLE001
+                    pass
             return rc or 124
         time.sleep(0.2)
     return rc
@@ -165,6 +174,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if os.environ.get("SLAM_BENCH_KILL_RANK") == str(rank) and world > 1:      # test hook (tests/test_gpu_two_rank_bench.py): this rank dies before its first leg
+        os._exit(7)
     import slam_jl_amd as slam
     from slam_jl_amd import synthetic as syn
     ctx = None                                               # the context of the BA / pose legs: created when they start -- an idle stream created up
@@ -349,6 +360,22 @@ def main():
     if "headline" in legs:
         head = run_lockstep_kpset(slam, torch, local_rank, wl, args.steps, args.warmup, world, dist, dev, "host_u8", snapshot=[0, S - 1])
         leg_done("headline")
+        if world > 1:
+            # every rank's own frame rate over its own clock (`value` = all frames over the SLOWEST rank's time, as the contract asks)
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, float(head["value_this_rank"]))
+            out["per_rank_values"] = per_rank
+            out["sum_of_rank_values"] = float(sum(per_rank))
+            if rank == 0:
+                # a later leg that loses a rank takes this process with it before the line is printed: the measured headline is left
+                # behind for the launcher (spawn_ranks prints it, marked, and exits non-zero)
+                try:
+                    with open(os.path.join(ROOT, "bench_headline_partial.json"), "w") as f:
+                        json.dump({"metric": out["metric"], "value": head["value"], "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                   "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                                   "per_rank_values": per_rank, "config": {"workload": "KITTI-05-shaped stereo 370x1226 @1000 kpts (BASELINE configs[1])", "streams_per_gpu": S}}, f)
+                except OSError:
+                    pass
         rows_us, serial_us, isolated_us = kernel_spans(slam, torch, local_rank, wl, dev)
         pb = S * pyramid_bytes(H, W, levels)
         build_ms = head["pyramid_build_ms"]["mean"]
@@ -628,7 +655,10 @@ def main():
                                              "banded solve, all-gather of the trial costs, on-device decision; one host sync per pass) per iteration; the whole call "
                                              "adds host partitioning, shard set-up and the RCCL communicator",
                                      "collectives_us": st.get("collectives_us"),
-                                     "worth_sharding": bool(sharded_ba.worth_sharding(sP, s2["O"], world)), "ssr_final": st["ssr_final"]}
+                                     "worth_sharding": bool(sharded_ba.worth_sharding(sP, s2["O"], world)), "ssr_final": st["ssr_final"],
+                                     "rccl_ranks_seen": world if os.environ.get("SLAM_BENCH_BACKEND", "nccl") == "nccl" else 1,
+                                     "rccl_note": "the library's RCCL communicator (slam_comm_*) has only ever run with ONE rank in the build environment (1-GPU boxes); "
+                                                  "N > 1 ran over gloo with two processes on one GPU (tests/test_gpu_two_process_shards.py)" if world == 1 or os.environ.get("SLAM_BENCH_BACKEND") == "gloo" else None}
             except Exception as ex:                                   # never lose the line to the optional leg
                 out["ba_sharded"] = {"error": repr(ex)[:300], "world_size": world}
 

@@ -202,8 +202,25 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     # step and are better left undisturbed).  SLAM_BENCH_TRACK_PRIO=0 restores the shared class for comparison.
     prio = int(os.environ.get("SLAM_BENCH_TRACK_PRIO", "-1"))
     pprio = int(os.environ.get("SLAM_BENCH_PYR_PRIO", "0"))
-    ctx, ctx_pyr, ctx_right, ctx_copy = (leg_ctx(slam, local_rank, prio), leg_ctx(slam, local_rank, pprio),
-                                         leg_ctx(slam, local_rank, pprio), copy_ctx(slam, local_rank))
+    # co-runner policies (measurement knobs): SLAM_BENCH_CU_SPLIT="T[:stride]" confines the tracking / detect context to T compute
+    # units and the two pyramid contexts to the other 256 - T (contiguous CU numbers, or every k-th with ":stride");
+    # SLAM_BENCH_SERIAL=1 puts everything on ONE stream (no overlap at all)
+    split = os.environ.get("SLAM_BENCH_CU_SPLIT")
+    serial = os.environ.get("SLAM_BENCH_SERIAL") is not None
+    if split:
+        T = int(split.split(":")[0]); stride = ":" in split
+        ncu = 256
+        if stride:
+            k = max(1, round(ncu / max(T, 1))); tr = [1 if i % k == 0 else 0 for i in range(ncu)]
+        else:
+            tr = [1 if i >= ncu - T else 0 for i in range(ncu)]
+        py = [1 - b for b in tr]
+        ctx, ctx_pyr, ctx_right, ctx_copy = (slam.Context(local_rank, cu_mask=tr), slam.Context(local_rank, cu_mask=py), slam.Context(local_rank, cu_mask=py), copy_ctx(slam, local_rank))
+    elif serial:
+        ctx = leg_ctx(slam, local_rank); ctx_pyr = ctx_right = ctx; ctx_copy = copy_ctx(slam, local_rank)
+    else:
+        ctx, ctx_pyr, ctx_right, ctx_copy = (leg_ctx(slam, local_rank, prio), leg_ctx(slam, local_rank, pprio),
+                                             leg_ctx(slam, local_rank, pprio), copy_ctx(slam, local_rank))
     levels = params.pyramid_levels
     AHEAD = max(1, int(os.environ.get("SLAM_BENCH_KP_AHEAD", "2")))   # builds enqueued ahead of the step being tracked (same-box A/B: 2 = +0.9 % over 1 -- the next graph is already queued when a build ends; 3 = -1.4 %)
     NLB = AHEAD + 3                                          # previous, current, AHEAD being built, one more being copied
@@ -440,6 +457,7 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     if ba is not None:
         ba.join()                                               # the last key-frame's windows are part of the timed work
     drain(); dt = time.perf_counter() - t0
+    dt_own = dt
     state["timed"] = False
     i_last = warm + nsteps
     if world > 1:
@@ -454,6 +472,7 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     except Exception:
         hbm_gb = None
     res = {"ingest": ingest, "streams_per_gpu": S, "hbm_in_use_gb": hbm_gb, "steps": periods, "frame_steps": nsteps, "value": world * S * nsteps / dt, "unit": "frames/sec", "seconds": dt,
+           "value_this_rank": S * nsteps / dt_own, "seconds_this_rank": dt_own,
            "ms_per_step": dt / max(periods, 1) * 1e3, "ms_per_frame_of_S_streams": dt / nsteps * 1e3,
            "host_wait_ms_per_frame": state["wait_s"] / nsteps * 1e3,
            "local_ba": None if ba is None else ba.result(),
@@ -505,7 +524,7 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     del st_main
     retire_torch_host_events(torch)
     peek("run_lockstep_kpset: after freeing the torch buffers")
-    for c_ in (ctx, ctx_pyr, ctx_right):                         # (the copy context lives as long as the process: copy_ctx)
+    for c_ in ({id(c): c for c in (ctx, ctx_pyr, ctx_right)}).values():      # (the copy context lives as long as the process: copy_ctx)
         c_.close()
     return res
 

@@ -61,6 +61,8 @@ def compact_line(out):
                                "u8 frames from pinned host memory inside the timed loop; f64 bit-exact",
                    "streams_per_gpu": cfg.get("streams_per_gpu"), "frames_per_step": cfg.get("frames_per_step"), "parallelism": cfg.get("parallelism"),
                    "pyramid_mode": out.get("pyramid_mode", "bit-exact")}
+    if out.get("per_rank_values"):
+        c["per_rank_values"] = [_r(v) for v in out["per_rank_values"]]
     rf = out.get("roofline")
     if rf:
         c["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_isolated", "algorithmic_bytes_per_launch", "avg_launch_us",
@@ -91,7 +93,7 @@ def compact_line(out):
                                   "windows_per_call": fb["local_ba"]["windows_per_call"]} if "value" in fb else {"error": fb.get("error", "")[:120]})
     bs = out.get("ba_sharded")
     if bs:
-        c["ba_sharded"] = {k: _r(bs.get(k)) for k in ("world_size", "window_kf", "ms_per_iter_wall", "worth_sharding", "error") if bs.get(k) is not None}
+        c["ba_sharded"] = {k: _r(bs.get(k)) for k in ("world_size", "window_kf", "ms_per_iter_wall", "worth_sharding", "rccl_ranks_seen", "error") if bs.get(k) is not None}
     ss = out.get("single_stream")
     if ss and "by_builds_in_flight" in ss:
         c["single_stream"] = {"live": _r(ss["by_builds_in_flight"].get("1")), "lookahead": _r(ss.get("value")), "unit": "frames/sec"}
