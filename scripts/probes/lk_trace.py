@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import slam_jl_amd._lib as L
 L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libslamhip_trace.so")
 sys.argv = [sys.argv[0]] + sys.argv[1:]
-exec(open(os.path.join(os.path.dirname(__file__), "prof_flow.py")).read().split("import ctypes as C, time")[0])
+exec(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "prof_flow.py")).read().split("import ctypes as C, time")[0])
 lib = ctx.lib
 lib.slam_debug_lk_ticks.restype = C.c_int
 buf = (C.c_ulonglong * 8)()

@@ -68,6 +68,8 @@ struct BADev {
     // sorted position of an observation's point.  grp / fgrp / wpart: the point groups of k_schur_groups (below).
     const int *pt_id, *opk;
     const int4 *grp; const int *fgrp; int ngrp, whb, wstride;
+    const int *ohp; int sg_hp;   // ohp[i]: index of observation i among its group's observations of FREE poses (or -1): the phase 2-3 records (W, Jp, gradient:
+                                 // 36 doubles) exist for those only -- the reference's window is 80 % observations of constant poses; sg_hp: room for that many
     int sg_ob, sg_sb;            // k_schur_groups' LDS layout: room for sg_ob observations / sg_sb points per group (SG_OB / SG_SB; a batch of small
                                  // windows sizes it to its largest group, so that several workgroups share a compute unit)
     double *wpart;
@@ -438,16 +440,17 @@ __global__ __launch_bounds__(256) void k_blocks(BADev d, int use_state)
 #define SG_OB 448
 #define SG_SB 56
 // byte offset of s_dg = end of the phase 0-2 arrays, or of the fold buffers of phase 3 that overlay them (whichever is larger)
-__host__ __device__ __forceinline__ size_t sg_dg_off(int whb, int ob, int sb, int nthreads)
+__host__ __device__ __forceinline__ size_t sg_w_doubles(int ob, int hp) { const size_t a = (size_t)ob * 9, b = (size_t)hp * 18; return ((a > b ? a : b) + 1) & ~(size_t)1; }
+__host__ __device__ __forceinline__ size_t sg_dg_off(int whb, int ob, int sb, int nthreads, int hp)
 {
     const int hbw = whb + 1, nwin = hbw * (hbw + 1) / 2, LPS = (nwin + 63) & ~63, NS = nthreads / LPS;
-    const size_t lay = (((size_t)ob * 36 + (size_t)sb * 10 + 8) * 8 + (size_t)sb * hbw * 2 + (size_t)nwin * 2 + 15) & ~(size_t)15;
+    const size_t lay = ((sg_w_doubles(ob, hp) + (size_t)hp * 18 + (size_t)sb * 10 + 8) * 8 + (size_t)sb * hbw * 2 + (size_t)nwin * 2 + 15) & ~(size_t)15;
     const size_t fold = NS >= 1 ? ((((size_t)(NS - 1) * nwin * 36 + (size_t)(NS - 1) * hbw * 6 * 7) * 8 + 15) & ~(size_t)15) : 0;
     return lay > fold ? lay : fold;
 }
-static size_t sg_lds_bytes(int whb, int P, int ob = SG_OB, int sb = SG_SB, int nthreads = 512)
+static size_t sg_lds_bytes(int whb, int P, int ob = SG_OB, int sb = SG_SB, int nthreads = 512, int hp = SG_OB)
 {
-    return sg_dg_off(whb, ob, sb, nthreads) + (size_t)(whb + 1) * 36 * 8 + (size_t)P * 6 * 8 + 16;
+    return sg_dg_off(whb, ob, sb, nthreads, hp) + (size_t)(whb + 1) * 36 * 8 + (size_t)P * 6 * 8 + 16;
 }
 
 // sum over NS adjacent lanes (NS a power of two, uniform): DPP moves up to 16 lanes -- a ds_bpermute butterfly of the 36 block
@@ -499,14 +502,15 @@ __device__ __forceinline__ void schur_groups_body(const BADev &d, double inv_del
     const int k0 = G.x, o0 = G.y, f = G.z & 0xffff, npts = G.z >> 16, nobs = G.w;
     const int hbw = d.whb + 1, nwin = hbw * (hbw + 1) / 2;
     const int OBc = d.sg_ob, SBc = d.sg_sb;        // layout capacities (SG_OB / SG_SB, or the largest group of a batch of small windows)
-    double *s_W = sg_lds;                          // [OBc][18]   (phases 0-1: [t][9] = Jl'Jl (6), Jl'f (3))
-    double *s_Jp = s_W + OBc * 18;                 // [OBc][12]
-    double *s_g = s_Jp + OBc * 12;                 // [OBc][6]
-    double *s_pt = s_g + OBc * 6;                  // [SBc][10]   V^-1 (6), bl (3), pad
+    const int HPc = d.sg_hp;                       // room for that many observations of free poses (the only ones with W / Jp / gradient records)
+    double *s_W = sg_lds;                          // phases 0-1: [OBc][9] = Jl'Jl (6), Jl'f (3) of every observation; phases 2-3: [HPc][18] W = Jp'Jl
+    double *s_Jp = s_W + sg_w_doubles(OBc, HPc);   // [HPc][12]
+    double *s_g = s_Jp + HPc * 12;                 // [HPc][6]
+    double *s_pt = s_g + HPc * 6;                  // [SBc][10]   V^-1 (6), bl (3), pad
     double *s_red = s_pt + SBc * 10;               // [8]
     short *s_slot = (short *)(s_red + 8);          // [SBc][hbw]  observation (index in the group) of point x in window slot y, or -1
     unsigned char *s_ab = (unsigned char *)(s_slot + SBc * hbw);   // [nwin][2]
-    double *s_dg = sg_lds + (sg_dg_off(d.whb, OBc, SBc, TT) >> 3);     // [hbw][36] Jp'Jp per window slot
+    double *s_dg = sg_lds + (sg_dg_off(d.whb, OBc, SBc, TT, HPc) >> 3);     // [hbw][36] Jp'Jp per window slot
     double *s_sc = s_dg + hbw * 36;                                    // [P][6] sin / cos of every pose's angles (pose_sincos)
     for (int p = tid; p < d.P; p += TT) pose_sincos(pb.pose + 6 * p, s_sc + 6 * p);
     for (int x = tid; x < npts * hbw; x += TT) s_slot[x] = -1;
@@ -523,11 +527,12 @@ __device__ __forceinline__ void schur_groups_body(const BADev &d, double inv_del
     for (int k = 0; k < 12; k++) Jp[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; k++) Jl[k] = 0.0;
-    int pl = 0;
+    int pl = 0, hpi = -1;
     if (tid < nobs) {
         const int i = o0 + tid;
         const int p = d.opose[i], j = d.opoint[i];
         pl = d.opk[i] - k0;
+        hpi = d.ohp[i];
         const bool active = !(ignore_outliers && d.outl[i]);
         const bool hp = active && !d.pconst[p];
         if (active) {
@@ -547,8 +552,8 @@ __device__ __forceinline__ void schur_groups_body(const BADev &d, double inv_del
         st_rec<2>(d.f + 2 * (size_t)i, r2);
         if (hp) st_rec<12>(d.Jp + (size_t)i * 12, Jp);     // (k_update_groups takes zeros where hasp is clear: the reference's window is 80 % observations of constant poses)
         st_rec<6>(d.Jl + (size_t)i * 6, Jl);
-        if (hp) s_slot[pl * hbw + (p - f)] = (short)tid;
-        double *v = s_W + tid * 18;
+        if (hp) s_slot[pl * hbw + (p - f)] = (short)hpi; else hpi = -1;
+        double *v = s_W + tid * 9;
         v[0] = Jl[0] * Jl[0] + Jl[3] * Jl[3]; v[1] = Jl[0] * Jl[1] + Jl[3] * Jl[4]; v[2] = Jl[0] * Jl[2] + Jl[3] * Jl[5];
         v[3] = Jl[1] * Jl[1] + Jl[4] * Jl[4]; v[4] = Jl[1] * Jl[2] + Jl[4] * Jl[5]; v[5] = Jl[2] * Jl[2] + Jl[5] * Jl[5];
 #pragma unroll
@@ -565,7 +570,7 @@ __device__ __forceinline__ void schur_groups_body(const BADev &d, double inv_del
         const int t0 = d.pt_start[k] - o0, t1 = d.pt_start[k + 1] - o0;
         for (int t = t0; t < t1; t++) {
 #pragma unroll
-            for (int c = 0; c < 9; c++) V[c] += s_W[t * 18 + c];
+            for (int c = 0; c < 9; c++) V[c] += s_W[t * 9 + c];
         }
         V[0] += fmin(fmax(V[0], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
         V[3] += fmin(fmax(V[3], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
@@ -580,7 +585,7 @@ __device__ __forceinline__ void schur_groups_body(const BADev &d, double inv_del
     lds_sync();
     SG_CLK(3);
     // ---- phase 2
-    if (tid < nobs) {
+    if (hpi >= 0) {                                        // (observations of constant poses and ignored outliers have no records: nothing reads them)
         double Vi[6], bl[3];
 #pragma unroll
         for (int c = 0; c < 6; c++) Vi[c] = s_pt[pl * 10 + c];
@@ -594,11 +599,11 @@ __device__ __forceinline__ void schur_groups_body(const BADev &d, double inv_del
             const double w0 = Jp[a] * Jl[0] + Jp[6 + a] * Jl[3];
             const double w1 = Jp[a] * Jl[1] + Jp[6 + a] * Jl[4];
             const double w2 = Jp[a] * Jl[2] + Jp[6 + a] * Jl[5];
-            s_W[tid * 18 + 3 * a] = w0; s_W[tid * 18 + 3 * a + 1] = w1; s_W[tid * 18 + 3 * a + 2] = w2;
-            s_g[tid * 6 + a] = (Jp[a] * r2[0] + Jp[6 + a] * r2[1]) - (w0 * vb0 + w1 * vb1 + w2 * vb2);
+            s_W[hpi * 18 + 3 * a] = w0; s_W[hpi * 18 + 3 * a + 1] = w1; s_W[hpi * 18 + 3 * a + 2] = w2;
+            s_g[hpi * 6 + a] = (Jp[a] * r2[0] + Jp[6 + a] * r2[1]) - (w0 * vb0 + w1 * vb1 + w2 * vb2);
         }
 #pragma unroll
-        for (int k = 0; k < 12; k++) s_Jp[tid * 12 + k] = Jp[k];
+        for (int k = 0; k < 12; k++) s_Jp[hpi * 12 + k] = Jp[k];
     }
     lds_sync();
     SG_CLK(4);
@@ -2141,7 +2146,7 @@ __global__ __launch_bounds__(256) void k_pass_start_b(const BAWin *tab, int pass
     if (pass == 0) { s->ssr_init = s->ssr; s->chol_fail = 0; s->n_outliers = 0; }
     s->delta = LM_DELTA0; s->decrease_factor = 2.0; s->converged = 0; s->accept = 0; s->iters = 0;
 }
-template <int TT> __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(3))) void k_schur_groups_b(const BAWin *tab, int ignore_outliers)
+template <int TT> __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(4))) void k_schur_groups_b(const BAWin *tab, int ignore_outliers)
 {
     const BAWin w = ba_win(tab);
     if ((int)blockIdx.x >= w.d.ngrp) return;
@@ -2311,7 +2316,8 @@ struct BAPlan {
     size_t npairs = 0; int nblk = 0, ngrp = 0, wstride = 0, hb = 0, sg_ob = SG_OB, sg_sb = SG_SB;
     int twice_pt = -1, twice_pose = -1;
     // layout: offsets inside the three regions
-    size_t o_pose, o_pts, o_const, o_pix, o_opose, o_opoint, o_start, o_ptid, o_opk, o_grp, o_fgrp, o_pairs, o_bs, o_bpq, up_bytes = 0;
+    size_t o_pose, o_pts, o_const, o_pix, o_opose, o_opoint, o_start, o_ptid, o_opk, o_ohp, o_grp, o_fgrp, o_pairs, o_bs, o_bpq, up_bytes = 0;
+    int sg_hp = SG_OB;
     size_t o_st, o_cf, o_outl, zero_bytes = 0;
     size_t o_pose_t, o_pts_t, o_hasp, o_f, o_ft, o_Jp, o_Jl, o_Vinv, o_bl, o_T, o_W, o_red, o_Sw, o_dp, o_dl, o_li, o_lf, o_part, o_band, o_wpart, o_xchg, work_bytes = 0;
     ~BAPlan() { delete ba; }
@@ -2319,7 +2325,7 @@ struct BAPlan {
     int fail(int code, const char *fmt, long long a = 0, long long b = 0, long long c = 0) { err = code; snprintf(msg, sizeof msg, fmt, a, b, c); return code; }
     // the per-observation arrays (sorted by point): ONE walk over the caller's observations -- the sorted position of observation i is the
     // next free one of its point.  The walk also finds a map point observed twice by one free pose: it has no place in a pose block.
-    void fill_obs(int *opose, int *opoint, int *opk, double *pix)
+    void fill_obs(int *opose, int *opoint, int *opk, double *pix, int *ohp = nullptr)
     {
         std::vector<int> fill(start.begin(), start.end() - 1), seen((size_t)P, -1);     // seen[p]: the last point (sorted position) free pose p observed
         for (int i = 0; i < O; i++) {
@@ -2335,6 +2341,15 @@ struct BAPlan {
                 if (seen[p] == k) { twice_pt = pt_id[k]; twice_pose = new_of.empty() ? p : ba->pose_order[p]; break; }
                 seen[p] = k;
             }
+        if (ohp) {                                              // index of an observation among its group's observations of free poses
+            int mx = 0;
+            for (const int4 &G : grp) {
+                int c = 0;
+                for (int a = G.y; a < G.y + G.w; a++) ohp[a] = theta_const[opose[a]] ? -1 : c++;
+                mx = std::max(mx, c);
+            }
+            if (small_groups) sg_hp = std::max(8, (mx + 1) & ~1);
+        }
     }
 };
 
@@ -2482,7 +2497,7 @@ static int ba_plan(BAPlan &pl)
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     pl.o_pose = take(n * 8); pl.o_pts = take((size_t)3 * M * 8 + 8); pl.o_const = take(P); pl.o_pix = take((size_t)2 * O * 8 + 8);
     pl.o_opose = take((size_t)O * 4 + 4); pl.o_opoint = take((size_t)O * 4 + 4); pl.o_start = take((size_t)(M + 1) * 4);
-    pl.o_ptid = take((size_t)M * 4 + 4); pl.o_opk = take((size_t)O * 4 + 4); pl.o_grp = take((size_t)ngrp * 16 + 16); pl.o_fgrp = take((size_t)(P + 1) * 4);
+    pl.o_ptid = take((size_t)M * 4 + 4); pl.o_opk = take((size_t)O * 4 + 4); pl.o_ohp = take((size_t)O * 4 + 4); pl.o_grp = take((size_t)ngrp * 16 + 16); pl.o_fgrp = take((size_t)(P + 1) * 4);
     pl.o_pairs = take(npairs * 8 + 8); pl.o_bs = take((size_t)(nblk + 1) * 4); pl.o_bpq = take((size_t)nblk * 8 + 8);
     pl.up_bytes = off; off = 0;
     pl.o_st = take(sizeof(LMState)); pl.o_cf = take(64); pl.o_outl = take((size_t)O + 1);
@@ -2527,7 +2542,7 @@ static int ba_emit(BAPlan &pl, char *Aup, char *Azero, char *Awork, char *stage)
     ba->chol_flag = (int *)(Azero + pl.o_cf); ba->linv = (double *)(Awork + pl.o_li); ba->lfac = (double *)(Awork + pl.o_lf); ba->band = (double *)(Awork + pl.o_band);
     d.pt_id = (const int *)(Aup + pl.o_ptid); d.opk = (const int *)(Aup + pl.o_opk); d.grp = (const int4 *)(Aup + pl.o_grp); d.fgrp = (const int *)(Aup + pl.o_fgrp);
     d.ngrp = pl.ngrp; d.whb = pl.hb; d.wstride = pl.wstride; d.wpart = (double *)(Awork + pl.o_wpart);
-    d.sg_ob = pl.sg_ob; d.sg_sb = pl.sg_sb;
+    d.sg_ob = pl.sg_ob; d.sg_sb = pl.sg_sb; d.ohp = (const int *)(Aup + pl.o_ohp);
     ba->nparts = ba->grouped ? pl.ngrp : ba->nblocks_obs;
     ba->xchg = (double *)(Awork + pl.o_xchg);
 #define UP(o, src, bytes) do { if ((bytes) > 0) memcpy(stage + (o), (src), (bytes)); } while (0)
@@ -2537,12 +2552,13 @@ static int ba_emit(BAPlan &pl, char *Aup, char *Azero, char *Awork, char *stage)
     UP(pl.o_const, pl.theta_const, (size_t)P); UP(pl.o_start, pl.start.data(), (size_t)(M + 1) * 4);
     if (pl.filled) { UP(pl.o_pix, pl.v_pix.data(), (size_t)2 * O * 8); UP(pl.o_opose, pl.v_opose.data(), (size_t)O * 4); UP(pl.o_opoint, pl.v_opoint.data(), (size_t)O * 4); UP(pl.o_opk, pl.v_opk.data(), (size_t)O * 4); }
     else {                                                   // (grouped: nothing on the host needs these arrays) written in place
-        pl.fill_obs((int *)(stage + pl.o_opose), (int *)(stage + pl.o_opoint), (int *)(stage + pl.o_opk), (double *)(stage + pl.o_pix));
+        pl.fill_obs((int *)(stage + pl.o_opose), (int *)(stage + pl.o_opoint), (int *)(stage + pl.o_opk), (double *)(stage + pl.o_pix), (int *)(stage + pl.o_ohp));
         if (pl.twice_pt >= 0) return pl.fail(SLAM_ERR_ARG, "slam_ba: map point %lld is observed twice by pose %lld", pl.twice_pt + 1, pl.twice_pose + 1);
     }
     UP(pl.o_pairs, pl.pairs.data(), pl.npairs * 8); UP(pl.o_bs, pl.blk_start.data(), (size_t)(pl.nblk + 1) * 4); UP(pl.o_bpq, pl.blk_pq.data(), (size_t)pl.nblk * 8);
     UP(pl.o_ptid, pl.pt_id.data(), (size_t)M * 4); UP(pl.o_grp, pl.grp.data(), (size_t)pl.ngrp * 16); UP(pl.o_fgrp, pl.fgrp.data(), (size_t)(P + 1) * 4);
 #undef UP
+    d.sg_hp = pl.sg_hp;
     return SLAM_OK;
 }
 
@@ -2602,7 +2618,7 @@ static int ba_enqueue_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, dou
         static std::atomic<bool> attr_set[64];
         const int dv = ctx->device & 63;
         if (!attr_set[dv].load(std::memory_order_acquire)) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB, SOLVE_MAX_N / 6))); attr_set[dv].store(true, std::memory_order_release); }
-        hipLaunchKernelGGL(k_schur_groups, dim3(d.ngrp), dim3(SG_T), sg_lds_bytes(d.whb, d.P, d.sg_ob, d.sg_sb), st, d, inv_delta, ignore_outliers, use_state);
+        hipLaunchKernelGGL(k_schur_groups, dim3(d.ngrp), dim3(SG_T), sg_lds_bytes(d.whb, d.P, d.sg_ob, d.sg_sb, 512, d.sg_hp), st, d, inv_delta, ignore_outliers, use_state);
         if (!use_state) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 0, d.ngrp, ba->nblocks_pts, 0, red + (size_t)n * n + 2 * n);
         const int nthr = d.P * (d.whb + 1) * 36 + d.P * 12;
         hipLaunchKernelGGL(k_schur_reduce, dim3((nthr + 255) / 256), dim3(256), 0, st, d, use_state);
@@ -3061,7 +3077,7 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
         // small groups everywhere (the reference's window shape: 16 points x 10 observers): 256-thread workgroups, two to three per compute unit
         static const bool no_t256 = getenv("SLAMHIP_BA_BATCH_T512") != nullptr;
         const int TT = (!no_t256 && max_ob <= 256 && (max_hb + 1) * (max_hb + 2) / 2 <= 256) ? 256 : SG_T;
-        for (int k = 0; k < NB; k++) if (!pl[batch[k]].err) lds_sg = std::max(lds_sg, sg_lds_bytes(tab_h[k].d.whb, tab_h[k].d.P, tab_h[k].d.sg_ob, tab_h[k].d.sg_sb, TT));
+        for (int k = 0; k < NB; k++) if (!pl[batch[k]].err) lds_sg = std::max(lds_sg, sg_lds_bytes(tab_h[k].d.whb, tab_h[k].d.P, tab_h[k].d.sg_ob, tab_h[k].d.sg_sb, TT, tab_h[k].d.sg_hp));
         const auto tw2 = std::chrono::steady_clock::now();
         hipStream_t st = ctx->stream;
         static std::atomic<bool> attr_set[64];

@@ -673,7 +673,10 @@ static int kpset_match(slam_ctx *ctx, slam_kpset *ks, const slam_pyr *from0, con
     rc = kpset_build_worklist(ctx, ks);
     if (rc) return rc;
     const int nmax = ks->S * ks->cap;
-    const int nb = n_bound > 0 && n_bound < nmax ? n_bound : nmax;
+    int nb = n_bound > 0 && n_bound < nmax ? n_bound : nmax;
+    // (measurement knob) cap the launch: every wave then walks several keypoints (the kernel loops) instead of one wave being dispatched per keypoint
+    static const int grid_cap = [] { const char *v = getenv("SLAMHIP_LK_GRID"); return v ? atoi(v) : 0; }();
+    if (grid_cap > 0 && nb > grid_cap) nb = grid_cap;
     { ProfScope span(ctx, "fb_track");
       const int ne = (2 * window + 1) * (2 * window + 1);
       // both pyramids built in tolerance mode (slam_pyr_update* mode 3): the contracted-arithmetic instantiation (positions <= 1e-6 px)

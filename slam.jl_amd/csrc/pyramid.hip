@@ -1913,12 +1913,12 @@ static void rt_seg_pow(const IIRPair &cf, int SL, SegPow &sp)     // M^(SL q), q
 // process-visible runtime state (another thread's or library's event queries and pinned allocations fail with
 // hipErrorStreamCaptureUnsupported / hipErrorCapturedEvent while one is open, and a stream that was a capture origin left state
 // behind when destroyed: DESIGN 6.6).  Building the graph node by node touches no stream at all.
-enum { LN_MAIN = 0, LN_AUX = 1 };
+enum { LN_MAIN = 0, LN_AUX = 1, LN_SIDE0 = 2, LN_COUNT = 2 + SLAM_MAX_LEVELS };   // LN_SIDE0 + l: the side branch of level l (single-image latency topology)
 struct BuildSink {
     hipStream_t st = nullptr;                          // direct mode: every kernel on this stream, in program order
     hipGraph_t graph = nullptr;                        // graph mode
-    bool forked = false;                               // graph mode: lane 1 is a branch of its own (else one chain)
-    hipGraphNode_t last[2] = {nullptr, nullptr}, fork_dep = nullptr;
+    bool forked = false;                               // graph mode: lanes >= 1 are branches of their own (else one chain)
+    hipGraphNode_t last[LN_COUNT] = {}, fork_dep[LN_COUNT] = {};
     hipError_t err = hipSuccess;
     template <typename Tup, size_t... I> static void addr_of(Tup &t, void **out, std::index_sequence<I...>) { ((out[I] = (void *)&std::get<I>(t)), ...); }
     template <typename... KA, typename... A>
@@ -1933,15 +1933,16 @@ struct BuildSink {
         const int ln = forked ? lane : LN_MAIN;
         hipGraphNode_t deps[2]; int nd = 0;
         if (last[ln]) deps[nd++] = last[ln];
-        if (ln == LN_AUX && fork_dep && fork_dep != last[ln]) deps[nd++] = fork_dep;
+        if (ln != LN_MAIN && fork_dep[ln] && fork_dep[ln] != last[ln]) deps[nd++] = fork_dep[ln];
         hipGraphNode_t node = nullptr;
         const hipError_t e = hipGraphAddKernelNode(&node, graph, nd ? deps : nullptr, (size_t)nd, &np);
         if (e != hipSuccess) { if (err == hipSuccess) err = e; return; }
         last[ln] = node;
-        if (ln == LN_AUX) fork_dep = nullptr;
+        if (ln != LN_MAIN) fork_dep[ln] = nullptr;
     }
-    // lane 1's next kernel also waits for everything lane 0 has issued so far
-    void fork() { if (graph && forked) fork_dep = last[LN_MAIN]; }
+    // lane `ln`'s next kernel also waits for everything lane 0 has issued so far
+    void fork(int ln = LN_AUX) { if (graph && forked) fork_dep[ln] = last[LN_MAIN]; }
+    bool lanes() const { return graph && forked; }
 };
 
 // One level of the build for the images [z0, z0 + S) of a batch of Sall (kernel selection follows Sall: a sub-batch runs the kernels the
@@ -1984,8 +1985,21 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         // ... and the fully fused dim-1 stage (Scharr + products + the four dim-1 recurrences straight from the layer)
         static const bool no_cols_fused = getenv("SLAMHIP_NO_COLS_FUSED") != nullptr;
         const bool cols_fused = fuse_sq && !no_cols_fused;
+        // LATENCY TOPOLOGY of a single image (round 5): the only thing level l + 1 waits for is level l's blurred, resized layer.  The main
+        // chain carries exactly that -- the dim-1 filter of the layer alone, the dim-2 filter (+ imresize!): 2-3 one-plane kernels per level;
+        // the gradients, the three product planes and their integral images of level l are a side branch of their own (lane LN_SIDE0 + l),
+        // which starts as soon as layer l exists and runs beside the chain and beside the other levels' branches.  Same kernels, same
+        // arithmetic per plane (a launch over 4 planes and two launches over 1 + 3 planes do the same per-line work).
+        // MEASURED (round 5, one 370 x 1226 image, builds back to back): tolerance mode 243 us per build with the topology, 218 without; bit-exact
+        // 450 vs 369 -- the split launches and the extra graph branches cost more than the shorter chain saves (the runtime serialises
+        // branch nodes onto few hardware queues), as the round-1 experiment on the bit-exact kernels had found.  Off unless SLAMHIP_TOPOLOGY=1.
+        static const bool no_topo = getenv("SLAMHIP_TOPOLOGY") == nullptr;
+        const bool topo = S == 1 && Sall == 1 && has_next && !cols_fused && B.lanes() && !no_topo;
+        const int side = topo ? LN_SIDE0 + l : LN_MAIN;            // lane of the gradients / products (non-topology: the main chain)
+        const int side_cum = topo ? LN_SIDE0 + l : LN_AUX;         // lane of the integral images
+        if (topo) B.fork(side);
         if (!cols_fused)
-            B.launch(k_scharr_products, dim3((H + 63) / 64, (W + SCH_XC - 1) / SCH_XC, S), dim3(64), 0, LN_MAIN, v, border_mode, zs, fuse_sq ? 0 : 1);
+            B.launch(k_scharr_products, dim3((H + 63) / 64, (W + SCH_XC - 1) / SCH_XC, S), dim3(64), 0, side, v, border_mode, zs, fuse_sq ? 0 : 1);
         // dim-1 IIR: [blur: L -> T], Iyy, Ixx, Iyx in place
         PlaneSet ps = {};
         int np = 0;
@@ -1995,6 +2009,12 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         ps.p[np] = v.Iyx; ps.coef[np] = 1; np++;
         ps.n = np; ps.zs = zs;
         const double *src0 = has_next ? (const double *)v.L : (const double *)nullptr;
+        PlaneSet psT = {}, psQ = {};                                // topology: the blurred layer alone / the three product planes
+        if (topo) {
+            psT.p[0] = ps.p[0]; psT.coef[0] = ps.coef[0]; psT.fill0[0] = ps.fill0[0]; psT.nrm[0] = ps.nrm[0]; psT.n = 1; psT.zs = zs;
+            for (int q = 0; q < 3; q++) { psQ.p[q] = ps.p[q + 1]; psQ.coef[q] = ps.coef[q + 1]; psQ.fill0[q] = ps.fill0[q + 1]; psQ.nrm[q] = ps.nrm[q + 1]; psQ.sq[q] = ps.sq[q + 1]; }
+            psQ.n = 3; psQ.zs = zs;
+        }
         PlaneSet pc = {};
         pc.p[0] = v.Iyy; pc.p[1] = v.Ixx; pc.p[2] = v.Iyx; pc.n = 3; pc.zs = zs;
         if (fast) {
@@ -2002,7 +2022,11 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             SegPow spc, spr;
             seg_pow(cf, H, slc, spc); seg_pow(cf, W, slr, spr);
             const dim3 gc((W + 7) / 8, np, S), gr((H + 7) / 8, np, S), gc3((W + 7) / 8, 3, S), gr3((H + 7) / 8, 3, S);
-            B.launch(k_iir_seg<true>, gc, dim3(PAR_T), 0, LN_MAIN, ps, src0, H, W, P, cf, spc, slc);
+            if (topo) {
+                B.launch(k_iir_seg<true>, dim3((W + 7) / 8, 1, S), dim3(PAR_T), 0, LN_MAIN, psT, src0, H, W, P, cf, spc, slc);
+                B.launch(k_iir_seg<true>, gc3, dim3(PAR_T), 0, side, psQ, (const double *)nullptr, H, W, P, cf, spc, slc);
+            }
+            else B.launch(k_iir_seg<true>, gc, dim3(PAR_T), 0, LN_MAIN, ps, src0, H, W, P, cf, spc, slc);
             // round 4: the dim-2 stage of a single image through k_rows_tol as well -- the blurred layer (filter along x + imresize!, one launch on
             // the main chain instead of k_iir_seg + k_resize) and, on the branch, the product planes (running sum along y first: the two
             // directions commute; then filter + running sum along x in one launch instead of k_iir_seg + k_cum_seg): 5 launches per level, 3 of
@@ -2019,7 +2043,7 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
                                    case 16: RT_GO1(16); break; case 20: RT_GO1(20); break; case 24: RT_GO1(24); break; case 32: RT_GO1(32); break; default: RT_GO1(40); break; }
 #undef RT_GO1
                 };
-                B.fork();
+                if (!topo) B.fork();
                 if (has_next) {
                     RowsTolArgs rt = {};
                     rt.p[0] = T; rt.coef[0] = 0; rt.kind[0] = 0; rt.n = 1; rt.nq0 = 1; rt.zs = zs;
@@ -2030,23 +2054,27 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
                         B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
                                            nextL, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
                 }
-                B.launch(k_cum_seg<true>, gc3, dim3(PAR_T), 0, LN_AUX, pc, H, W, P, slc);
+                B.launch(k_cum_seg<true>, gc3, dim3(PAR_T), 0, side_cum, pc, H, W, P, slc);
                 RowsTolArgs rq = {};
                 rq.p[0] = v.Iyy; rq.p[1] = v.Ixx; rq.p[2] = v.Iyx;
                 for (int q = 0; q < 3; q++) { rq.coef[q] = 1; rq.kind[q] = 2; }
                 rq.n = 3; rq.nq0 = 0; rq.zs = zs;
-                rows_tol(rq, 3, LN_AUX);
+                rows_tol(rq, 3, side_cum);
                 return;
             }
-            if (spans) { ProfScope span(ctx, "k_iir_rows");
+            if (topo) {
+                B.launch(k_iir_seg<false>, dim3((H + 7) / 8, 1, S), dim3(PAR_T), 0, LN_MAIN, psT, (const double *)nullptr, H, W, P, cf, spr, slr);
+                B.launch(k_iir_seg<false>, gr3, dim3(PAR_T), 0, side, psQ, (const double *)nullptr, H, W, P, cf, spr, slr);
+            }
+            else if (spans) { ProfScope span(ctx, "k_iir_rows");
                 B.launch(k_iir_seg<false>, gr, dim3(PAR_T), 0, LN_MAIN, ps, (const double *)nullptr, H, W, P, cf, spr, slr); }
             else B.launch(k_iir_seg<false>, gr, dim3(PAR_T), 0, LN_MAIN, ps, (const double *)nullptr, H, W, P, cf, spr, slr);
-            B.fork();
+            if (!topo) B.fork();
             if (has_next)
                 B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
                                    nextL, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
-            B.launch(k_cum_seg<true>, gc3, dim3(PAR_T), 0, LN_AUX, pc, H, W, P, slc);
-            B.launch(k_cum_seg<false>, gr3, dim3(PAR_T), 0, LN_AUX, pc, H, W, P, slr);
+            B.launch(k_cum_seg<true>, gc3, dim3(PAR_T), 0, side_cum, pc, H, W, P, slc);
+            B.launch(k_cum_seg<false>, gr3, dim3(PAR_T), 0, side_cum, pc, H, W, P, slr);
             return;
         }
         // tolerance build of a batch (mode 3, S >= 4): the dim-1 stage leaves the product planes as suffix sums along y, ONE row kernel
@@ -2103,6 +2131,10 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             }
         }
         else if (ck_cols) B.launch(k_iir_cols_ck, lines_grid(W, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, src0, H, W, P, cf, p->ck);
+        else if (topo) {
+            B.launch(k_iir_cols<3>, lines_grid(W, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, psT, src0, H, W, P, cf);
+            B.launch(k_iir_cols<3>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, side, psQ, (const double *)nullptr, H, W, P, cf);
+        }
         else if (S == 1) B.launch(k_iir_cols<3>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, src0, H, W, P, cf);
         else B.launch(k_iir_cols<2>, lines_grid(W, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, src0, H, W, P, cf);
         // bandwidth-bound launches (many images x a large level) take the checkpointed row kernel (2R+1W instead of 2R+2W)
@@ -2112,12 +2144,16 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         const bool rows_resize = ck_rows && has_next && (H & 1) == 0 && !no_rows_resize;
         RowResize rz = {};
         if (rows_resize) { rz.dst = nextL; rz.Hd = p->H[l + 1]; rz.Wd = p->W[l + 1]; rz.Pd = p->P[l + 1]; }
-        if (spans) { ProfScope span(ctx, "k_iir_rows");
+        if (topo) {
+            B.launch(k_iir_rows, lines_grid(H, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, psT, H, W, P, cf);
+            B.launch(k_iir_rows, lines_grid(H, 3, S), dim3(LINE_THREADS), 0, side, psQ, H, W, P, cf);
+        }
+        else if (spans) { ProfScope span(ctx, "k_iir_rows");
             if (ck_rows) B.launch(k_iir_rows_ck, lines_grid(H, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, H, W, P, cf, p->ck, rz);
             else B.launch(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, H, W, P, cf); }
         else if (ck_rows) B.launch(k_iir_rows_ck, lines_grid(H, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, H, W, P, cf, p->ck, rz);
         else B.launch(k_iir_rows, lines_grid(H, np, S), dim3(LINE_THREADS), 0, LN_MAIN, ps, H, W, P, cf);
-        B.fork();
+        if (!topo) B.fork();
         if (has_next && !rows_resize)
             B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
                                nextL, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
@@ -2128,9 +2164,9 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             B.launch(k_cum_fused, dim3(1, 3, S), dim3(nw * 64), lds, LN_AUX, pc, H, W, P);
             return;
         }
-        if (S == 1) B.launch(k_cum_cols<3>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, LN_AUX, pc, H, W, P);
+        if (S == 1) B.launch(k_cum_cols<3>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, side_cum, pc, H, W, P);
         else B.launch(k_cum_cols<2>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, LN_AUX, pc, H, W, P);
-        B.launch(k_cum_rows, lines_grid(H, 3, S), dim3(LINE_THREADS), 0, LN_AUX, pc, H, W, P);
+        B.launch(k_cum_rows, lines_grid(H, 3, S), dim3(LINE_THREADS), 0, S == 1 ? side_cum : LN_AUX, pc, H, W, P);
     }
 }
 
