@@ -58,6 +58,9 @@ int  slam_ctx_create_cumask(int device, const uint32_t *cu_mask, int n_words, sl
 /* the same, with the stream in its own scheduling class (priority > 0 high, < 0 low): its own hardware queue, which a
  * replayed hipGraph's branches never share -- for the latency-critical stage of a multi-context pipeline */
 int  slam_ctx_create_priority(int device, int priority, slam_ctx **out);
+/* waits for the context's stream, frees its scratch; the STREAM itself is parked for the next context of the same device and scheduling
+ * class instead of being destroyed -- events another library recorded on it (PyTorch's pinned-memory allocator does, for copies issued on
+ * the stream) stay valid for the life of the process */
 int  slam_ctx_destroy(slam_ctx *ctx);
 int  slam_ctx_synchronize(slam_ctx *ctx);
 /* Device-side ordering between two contexts of one device: work enqueued on `ctx`
@@ -218,7 +221,12 @@ int slam_flow_match(slam_ctx *ctx, const slam_pyr *from, const slam_pyr *to,
  *     (2.2x instead of 3.9x the algorithmic bytes).  Every plane within 1e-11 of the mode-1 plane relative to the
  *     plane's largest magnitude; tracked positions within 1e-6 px.  Keypoint INDICES are not affected: slam_detect* work on the raw
  *     frame / the base layer, which is the same bytes in both modes.  Levels too small for those kernels (and S < 4: the segmented
- *     single-image kernels of slam_pyr_update's mode 3) fall back per level; a batch may be updated in either mode at any time. */
+ *     single-image kernels of slam_pyr_update's mode 3) fall back per level; a batch may be updated in either mode at any time.
+ *     NOTE: in this mode the ARITHMETIC is no longer the reference's operation sequence -- the dim-2 kernel contracts its multiply-adds
+ *     into FMAs and evaluates the recurrences through affine maps of row segments, the dim-1 kernel leaves suffix sums instead of
+ *     filtered values -- only the RESULT is held to the reference's (1e-11 relative).  Matches between two pyramids last built in
+ *     mode 3 (slam_kpset_flow_match / _stereo_match) likewise take a tracking kernel with contracted arithmetic (two-operation
+ *     lerps, FMA accumulation; positions within 1e-6 px of the sequential-order oracle, csrc/lk.hip TOL). */
 int slam_pyr_create_batch(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, slam_pyr **out);
 int slam_pyr_update_batch_dev(slam_ctx *ctx, slam_pyr *const *pyrs, const double *const *images_dev, int S,
                               int mode, double sigma, int sync);

@@ -15,6 +15,7 @@ struct slam_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int cus = 0;                          // compute units the stream may use (0: all of the device)
+    int pool_class = 99;                  // scheduling class the stream is parked under when the context goes (ctx.hip); 99: not pooled (CU-masked)
     std::string err;
     // grow-only device scratch and pinned host staging
     void *scratch = nullptr; size_t scratch_bytes = 0;

@@ -1,5 +1,7 @@
 // ctx.hip -- context, scratch management, error reporting, filter coefficients.
 #include "common.hpp"
+#include <mutex>
+#include <cstdlib>
 #include <chrono>
 #include <cstdlib>
 #include <cmath>
@@ -104,6 +106,28 @@ int slam_prof_get(slam_ctx *ctx, const char *name, double *total_ms, int64_t *co
     return SLAM_OK;
 }
 
+// Streams are PARKED, not destroyed, when their context goes (and handed to the next context of the same device and scheduling
+// class): another library sharing the process may still hold events it recorded on a context's stream -- PyTorch's pinned-memory
+// allocator does, for every non-blocking copy issued on a torch.cuda.ExternalStream of ours, and queries them on LATER allocations; a
+// query of an event whose stream had been destroyed failed once in ~17 full bench runs with hipErrorCapturedEvent.  Until
+// round 5 the rule "retire foreign events before slam_ctx_destroy" lived in INTEGRATION prose; now no stream a caller has seen ever
+// dies before the process does.  (CU-masked streams are not pooled: their mask is part of their identity.)  SLAMHIP_NO_STREAM_POOL=1
+// restores destroy-on-close.
+namespace {
+struct ParkedStream { int device, prio; hipStream_t st; };
+std::mutex g_park_mu;
+std::vector<ParkedStream> g_parked;
+bool stream_pool_on() { static const bool on = getenv("SLAMHIP_NO_STREAM_POOL") == nullptr; return on; }
+hipStream_t take_parked(int device, int prio)
+{
+    if (!stream_pool_on()) return nullptr;
+    std::lock_guard<std::mutex> lk(g_park_mu);
+    for (size_t i = 0; i < g_parked.size(); i++)
+        if (g_parked[i].device == device && g_parked[i].prio == prio) { hipStream_t s = g_parked[i].st; g_parked.erase(g_parked.begin() + (long)i); return s; }
+    return nullptr;
+}
+}  // namespace
+
 int slam_ctx_create(int device, slam_ctx **out)
 {
     if (!out) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_ctx_create: out is NULL");
@@ -115,7 +139,8 @@ int slam_ctx_create(int device, slam_ctx **out)
     slam_ctx *c = new slam_ctx();
     c->device = device;
     e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    c->pool_class = 0;
+    if (e == hipSuccess && (c->stream = take_parked(device, 0)) == nullptr) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create: %s", hipGetErrorString(e)); }
     *out = c;
     return SLAM_OK;
@@ -159,7 +184,8 @@ int slam_ctx_create_priority(int device, int priority, slam_ctx **out)
     int least = 0, greatest = 0;                      // numerically: greatest priority <= 0 <= least priority
     if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&least, &greatest);
     int p = priority > 0 ? greatest : priority < 0 ? least : 0;
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, p);
+    c->pool_class = priority > 0 ? 1 : priority < 0 ? -1 : 0;
+    if (e == hipSuccess && (c->stream = take_parked(device, c->pool_class)) == nullptr) e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, p);
     if (e != hipSuccess) { delete c; return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create_priority: %s", hipGetErrorString(e)); }
     *out = c;
     return SLAM_OK;
@@ -176,7 +202,8 @@ int slam_ctx_destroy(slam_ctx *ctx)
     if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
     for (auto &sp : ctx->prof_pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(ctx->stream);
+    if (stream_pool_on() && ctx->pool_class != 99) { std::lock_guard<std::mutex> lk(g_park_mu); g_parked.push_back({ctx->device, ctx->pool_class, ctx->stream}); }
+    else (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SLAM_OK;
 }

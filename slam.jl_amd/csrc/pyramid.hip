@@ -1733,13 +1733,14 @@ __device__ __forceinline__ ColTerm scharr_col(const double *L, int H, int W, int
     t.s += a * sk[0]; t.s += b * sk[1]; t.s += c * sk[2];
     return t;
 }
+template <int XC>      // columns per thread: 16 for batches (each layer sample fetched 1.1 times), 4 for a single image (four times the waves: the kernel is latency-bound there)
 __global__ __launch_bounds__(64) void k_scharr_products(LevelView v, int border, size_t zs, int squares)
 {
     { const size_t z = (size_t)blockIdx.z * zs; v.L += z; v.Iy += z; v.Ix += z; v.Iyy += z; v.Ixx += z; v.Iyx += z; }
     const int H = v.H, W = v.W, P = v.P;
     const int y = blockIdx.x * 64 + threadIdx.x;
     if (y >= H) return;
-    const int xs = blockIdx.y * SCH_XC, xe = min(W, xs + SCH_XC);
+    const int xs = blockIdx.y * XC, xe = min(W, xs + XC);
     const double dk[3] = {-1.0 / 2, 0.0 / 2, 1.0 / 2}, sk[3] = {3.0 / 16, 10.0 / 16, 3.0 / 16};
     ColTerm t0 = scharr_col(v.L, H, W, P, y, xs - 1, border), t1 = scharr_col(v.L, H, W, P, y, xs, border);
     for (int x = xs; x < xe; x++) {
@@ -1998,8 +1999,14 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         const int side = topo ? LN_SIDE0 + l : LN_MAIN;            // lane of the gradients / products (non-topology: the main chain)
         const int side_cum = topo ? LN_SIDE0 + l : LN_AUX;         // lane of the integral images
         if (topo) B.fork(side);
-        if (!cols_fused)
-            B.launch(k_scharr_products, dim3((H + 63) / 64, (W + SCH_XC - 1) / SCH_XC, S), dim3(64), 0, side, v, border_mode, zs, fuse_sq ? 0 : 1);
+        {
+            static const int sch1 = [] { const char *e = getenv("SLAMHIP_SCHARR_XC1"); return e ? atoi(e) : 2; }();      // (measurement knob) columns per thread for a single image: 16 / 8 / 4 / 2 / 1 -> 216 / 200 / 192 / 189 / 189 us per tolerance-mode build
+            if (!cols_fused && S == 1 && sch1 == 4) B.launch(k_scharr_products<4>, dim3((H + 63) / 64, (W + 3) / 4, S), dim3(64), 0, side, v, border_mode, zs, fuse_sq ? 0 : 1);
+            else if (!cols_fused && S == 1 && sch1 == 2) B.launch(k_scharr_products<2>, dim3((H + 63) / 64, (W + 1) / 2, S), dim3(64), 0, side, v, border_mode, zs, fuse_sq ? 0 : 1);
+            else if (!cols_fused && S == 1 && sch1 == 1) B.launch(k_scharr_products<1>, dim3((H + 63) / 64, W, S), dim3(64), 0, side, v, border_mode, zs, fuse_sq ? 0 : 1);
+            else if (!cols_fused && S == 1 && sch1 == 8) B.launch(k_scharr_products<8>, dim3((H + 63) / 64, (W + 7) / 8, S), dim3(64), 0, side, v, border_mode, zs, fuse_sq ? 0 : 1);
+            else if (!cols_fused) B.launch(k_scharr_products<SCH_XC>, dim3((H + 63) / 64, (W + SCH_XC - 1) / SCH_XC, S), dim3(64), 0, side, v, border_mode, zs, fuse_sq ? 0 : 1);
+        }
         // dim-1 IIR: [blur: L -> T], Iyy, Ixx, Iyx in place
         PlaneSet ps = {};
         int np = 0;

@@ -223,4 +223,32 @@ function compute_pose!(k::KeypointSet, params::Matrix{Float64}; threshold = 3.0,
     (Tcw = [reshape(poses[:, s], 4, 4) for s in 1:k.S], status = status, n_inliers = ninl, counts = cnt)
 end
 
+# bundle_adjustment! (bundle_adjustment.jl:1-111) for the LocalBACaches of S lock-stepped SlamManagers in one set of launches
+# (slam_local_ba_batch): what the S estimator tasks (estimator.jl:78-99, local_bundle_adjustment! :317-347) would each call once per
+# key-frame.  caches: any objects with the LocalBACache fields (θ, θconst, pixels, poses_ids, points_ids, outliers, poses_remap,
+# points_remap, observations -- estimator.jl:16-40); cameras: one Camera per cache.  Mutates every cache.θ / cache.outliers like
+# S bundle_adjustment! calls; returns the per-window status codes (0 = solved; a window whose reduced system was not positive definite
+# is left unchanged and reports -5).
+function bundle_adjustment_batch!(caches::AbstractVector, cameras::AbstractVector; iterations::Int = 10, repr_ϵ::Real = 5.0)
+    S = length(caches)
+    Pn = Int32[length(c.poses_remap) for c in caches]; Mn = Int32[length(c.points_remap) for c in caches]; On = Int32[length(c.observations) for c in caches]
+    cams = Float64[]; for cam in cameras; append!(cams, (cam.fx, cam.fy, cam.cx, cam.cy)); end
+    θ = reduce(vcat, [Vector{Float64}(c.θ) for c in caches]); tc = reduce(vcat, [Vector{UInt8}(c.θconst) for c in caches])
+    px = reduce(vcat, [vec(Matrix{Float64}(c.pixels)) for c in caches])                  # 2 x O column-major = (y, x) pairs back to back
+    pid = reduce(vcat, [Vector{Int64}(c.poses_ids) for c in caches]); lid = reduce(vcat, [Vector{Int64}(c.points_ids) for c in caches])
+    outl = zeros(UInt8, max(sum(On), 1)); status = zeros(Int32, S)
+    GC.@preserve cams Pn Mn On θ tc px pid lid outl status check(ccall((:slam_local_ba_batch, LIB[]), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{UInt8},
+         Cint, Cint, Cdouble, Ptr{Float64}, Ptr{Int32}),
+        ctx(), S, cams, Pn, Mn, On, θ, tc, px, pid, lid, outl, 5, iterations, Float64(repr_ϵ), C_NULL, status))
+    to = 0; oo = 0
+    for (z, c) in enumerate(caches)
+        n = 6 * Pn[z] + 3 * Mn[z]
+        copyto!(c.θ, 1, θ, to + 1, n); to += n
+        for i in 1:On[z]; c.outliers[i] = outl[oo + i] != 0; end
+        oo += On[z]
+    end
+    status
+end
+
 end # module

@@ -23,3 +23,9 @@ def test_keypoint_set_fuzz_short_run():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "kpset_fuzz.py"), "15", "7000"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "15 key-frame steps, 0 failures" in r.stdout, r.stdout[-3000:]
+
+
+def test_ba_batch_fuzz_short_run():
+    """tests/fuzz/ba_fuzz.py in batch mode: 48 random ragged windows through slam_local_ba_batch, 12 per call, against the oracle"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "ba_fuzz.py"), "48", "11000", "12"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and " 0 failures" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
