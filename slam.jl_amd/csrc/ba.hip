@@ -30,6 +30,9 @@
 #include <type_traits>
 #include <chrono>
 #include <thread>
+#include <functional>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 
 #define LM_MAX_DELTA 1e16
@@ -68,6 +71,8 @@ struct BADev {
     // sorted position of an observation's point.  grp / fgrp / wpart: the point groups of k_schur_groups (below).
     const int *pt_id, *opk;
     const int4 *grp; const int *fgrp; int ngrp, whb, wstride;
+    const int *fobs;             // the observations of free poses, grouped by map point in sorted order (pfs[M] entries)
+    const int *pfs;              // pfs[k]: observations of free poses of the map points (sorted order) before point k, M + 1 entries (k_ba_window's chunks)
     const int *ohp; int sg_hp;   // ohp[i]: index of observation i among its group's observations of FREE poses (or -1): the phase 2-3 records (W, Jp, gradient:
                                  // 36 doubles) exist for those only -- the reference's window is 80 % observations of constant poses; sg_hp: room for that many
     int sg_ob, sg_sb;            // k_schur_groups' LDS layout: room for sg_ob observations / sg_sb points per group (SG_OB / SG_SB; a batch of small
@@ -2116,7 +2121,7 @@ __global__ __launch_bounds__(256) void k_outlier_count(BADev d, int nb_obs) { ou
 // kernel argument lives (a generic pointer into the table moved the plane pointers into VGPRs and reloaded them after every store) --
 // and the grid's x extent is the largest window's: workgroups beyond a window's own count leave at once.  Every window runs its own
 // device-side LM state; a converged window's workgroups early-out as in the single-window path.
-struct BAWin { BADev d; BandArgs B; int nb_obs, nb_pts, n_red, pad; };
+struct BAWin { BADev d; BandArgs B; int nb_obs, nb_pts, n_red, pad; };      // pad = 1: the window runs in k_ba_window (one workgroup, all iterations)
 static_assert(sizeof(BAWin) % 8 == 0, "BAWin is copied as 64-bit words");
 __device__ __forceinline__ BAWin ba_win(const BAWin *tab)
 {
@@ -2132,6 +2137,7 @@ __device__ __forceinline__ BAWin ba_win(const BAWin *tab)
 __global__ __launch_bounds__(256) void k_linearize_b(const BAWin *tab, int ignore_outliers, int respect_done)
 {
     const BAWin w = ba_win(tab);
+    if (w.pad) return;                                       // the window is k_ba_window's
     if ((int)blockIdx.x >= w.nb_obs) return;
     linearize_body(w.d, ignore_outliers, respect_done);
 }
@@ -2139,6 +2145,7 @@ __global__ __launch_bounds__(256) void k_linearize_b(const BAWin *tab, int ignor
 __global__ __launch_bounds__(256) void k_pass_start_b(const BAWin *tab, int pass)
 {
     const BAWin w = ba_win(tab);
+    if (w.pad) return;                                       // the window is k_ba_window's
     control_body(w.d, 0, w.nb_obs, w.nb_pts, 0, nullptr);
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -2149,41 +2156,48 @@ __global__ __launch_bounds__(256) void k_pass_start_b(const BAWin *tab, int pass
 template <int TT> __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(4))) void k_schur_groups_b(const BAWin *tab, int ignore_outliers)
 {
     const BAWin w = ba_win(tab);
+    if (w.pad) return;                                       // the window is k_ba_window's
     if ((int)blockIdx.x >= w.d.ngrp) return;
     schur_groups_body<TT>(w.d, 0.0, ignore_outliers, 1);
 }
 __global__ __launch_bounds__(256) void k_schur_reduce_b(const BAWin *tab)
 {
     const BAWin w = ba_win(tab);
+    if (w.pad) return;                                       // the window is k_ba_window's
     if ((int)blockIdx.x >= w.n_red) return;
     schur_reduce_body(w.d, 1);
 }
 __global__ __launch_bounds__(BS_T) void k_band_solve_b(const BAWin *tab)
 {
     const BAWin w = ba_win(tab);
+    if (w.pad) return;                                       // the window is k_ba_window's
     band_solve_body(w.d, w.B, 1);
 }
 template <int TT> __global__ __launch_bounds__(TT) void k_update_groups_b(const BAWin *tab, int ignore_outliers)
 {
     const BAWin w = ba_win(tab);
+    if (w.pad) return;                                       // the window is k_ba_window's
     if ((int)blockIdx.x >= w.d.ngrp) return;
     update_groups_body<TT>(w.d, ignore_outliers, 1);
 }
 __global__ __launch_bounds__(256) void k_control_b(const BAWin *tab)
 {
     const BAWin w = ba_win(tab);
+    if (w.pad) return;                                       // the window is k_ba_window's
     control_body(w.d, 1, w.d.ngrp, w.d.ngrp, 1 | 2, nullptr);
 }
 // end of pass 1: record it, flag the outliers at theta_1 (bundle_adjustment.jl:45); the count follows in k_outlier_count_b
 __global__ __launch_bounds__(256) void k_outliers_b(const BAWin *tab, double repr_eps, double depth_eps)
 {
     const BAWin w = ba_win(tab);
+    if (w.pad) return;                                       // the window is k_ba_window's
     if ((int)blockIdx.x >= w.nb_obs) return;
     outliers_body(w.d, repr_eps, depth_eps);
 }
 __global__ __launch_bounds__(256) void k_outlier_count_b(const BAWin *tab)
 {
     const BAWin w = ba_win(tab);
+    if (w.pad) return;                                       // the window is k_ba_window's
     LMState *s = w.d.st;
     if (threadIdx.x == 0) { s->ssr_pass1 = s->ssr; s->iters_pass1 = s->iters; }
     outlier_count_body(w.d, w.nb_obs);
@@ -2209,6 +2223,473 @@ __global__ __launch_bounds__(256) void k_results_b(const BAWin *tab, const BARes
         LMState h = *s;
         h.ssr_final = h.ssr; h.iters_pass2 = h.iters;
         *(LMState *)(res + r.off_state) = h;
+    }
+}
+
+
+// ---- small windows: the WHOLE two-pass Levenberg-Marquardt of one window in ONE workgroup, one launch for the batch -------------------
+// The reference's window is at most 5 free key-frames and their constant observers (estimator.jl:327-331): the reduced camera system is
+// 30 x 30, a few hundred map points see a free pose at all, and the rest only move themselves.  Spread over the chip kernel by kernel
+// (above) such a window costs 5 launches per iteration whose workgroups are mostly latency; here a 1024-thread workgroup keeps the
+// window to itself for all 5 + 10 iterations -- no launch boundaries, the LM state never leaves the compute unit:
+//   A1 thread = observation (coalesced loads, pose data from LDS): residual + Jacobians, stored for the later phases
+//   A2 thread = map point: V = sum Jl'Jl + D, V^-1, bl over its (contiguous) observations -- loads only, no evaluation
+//   B  the observations of free poses (a host-built list), in chunks that fit LDS: thread = record -> W = Jp'Jl, gradient term;
+//      then lane = block pair (a, b) of the 6 x 6 blocks, 32 subsets of 32 lanes walk the chunk's points; fixed-order fold
+//      (deterministic, no atomics): S, g, diag U
+//   S  dense damped Cholesky of the <= 30 x 30 system by ONE wave (wave-synchronous LDS, no workgroup barriers), L y = g, L' dp = y
+//   C1 thread = map point: dl = V^-1 (bl - W' dp), trial point;  C2 thread = observation: trial and predicted residuals
+//   D  LeastSquaresOptim's accept / reject (lm_decide), on the device as everywhere
+// then the outlier flags between the passes.  128 such windows occupy 128 compute units at once.  Windows with more free poses, free
+// poses that are not consecutive, > 128 poses or > BW_OMAX observations take the batch kernels above.
+// (First version, thread = map point with a serial loop over its observations at 512 threads: 235 us per iteration -- two waves per
+//  SIMD cannot hide the dependent loads and the Float64 latency of ten evaluations in a row; slower than the kernels it replaces.)
+#ifdef BW_TRACE
+#define BW_CLK(k) do { if (tid == 0) bw_clk[k] = clock64(); } while (0)
+#else
+#define BW_CLK(k)
+#endif
+#define BW_T 512
+#define BW_FMAX 5
+#define BW_PMAX 128
+#define BW_OMAX 40000
+#define BW_HC 336                   // free-pose observation records (W 18, Jp 12, gradient 6 doubles) per chunk
+#define BW_PC 256                   // points per chunk
+#define BW_FIXED_DBL(P) ((size_t)15 * (P) + 31 * 30 + 32 + 32 + 32 + 2 + (size_t)BW_PC * 10)
+static size_t bw_lds_bytes(int P)
+{
+    size_t b = BW_FIXED_DBL(P) * 8 + (size_t)BW_PC * BW_FMAX * 2 + (size_t)P;
+    b = (b + 15) & ~(size_t)15;
+    return b + (size_t)BW_HC * 36 * 8 + 16;
+}
+__device__ __forceinline__ double bw_sum(double v, double *sh)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < BW_T / 64; w++) t += sh[w];
+    return t;
+}
+__device__ __forceinline__ double bw_max(double v, double *sh)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < BW_T / 64; w++) t = fmax(t, sh[w]);
+    return t;
+}
+__device__ __forceinline__ void bw_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+__global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int *list, int iters_fast, int iterations, double repr_eps, double depth_eps)
+{
+    BAWin w;
+    {   typedef const __attribute__((address_space(4))) unsigned long long *cq_t;
+        cq_t q = (cq_t)(const void *)(tab + list[blockIdx.x]);
+        unsigned long long raw[sizeof(BAWin) / 8];
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(BAWin) / 8); k++) raw[k] = q[k];
+        __builtin_memcpy(&w, raw, sizeof w); }
+    const BADev &d = w.d;
+    extern __shared__ __attribute__((aligned(16))) double bw_sm[];
+    const int tid = threadIdx.x;
+    const int P = d.P, M = d.M, O = d.O, p0 = w.B.p0, F = w.B.nb, n = 6 * F, nwin = F * (F + 1) / 2, NF = d.pfs[M];
+    LMState *s = d.st;
+    double *s_sc = bw_sm;                              // [P][6] sin / cos of the committed poses' angles
+    double *s_sct = s_sc + 6 * P;                      // [P][6] of the trial poses
+    double *s_tr = s_sct + 6 * P;                      // [P][3] committed translations
+    double *s_A = s_tr + 3 * P;                        // [n + 1][n]: damped S (full, row-major), row n = right-hand side
+    double *s_dp = s_A + 31 * 30;                      // [32]
+    double *s_ud = s_dp + 32;                          // [32] diag U (damping)
+    double *s_red = s_ud + 32;                         // [32]
+    int *s_flag = (int *)(s_red + 32);                 // [4]
+    double *s_pt = s_red + 34;                         // [BW_PC][10] V^-1 (6), bl (3)
+    short *s_slot = (short *)(s_pt + BW_PC * 10);      // [BW_PC][BW_FMAX] record of point x for free pose a, or -1
+    unsigned char *s_const = (unsigned char *)(s_slot + BW_PC * BW_FMAX);   // [P]
+    double *s_W = bw_sm + (((BW_FIXED_DBL(P) * 8 + (size_t)BW_PC * BW_FMAX * 2 + (size_t)P + 15) & ~(size_t)15) >> 3);   // [BW_HC][18]
+    double *s_Jp = s_W + BW_HC * 18;                   // [BW_HC][12]
+    double *s_gr = s_Jp + BW_HC * 12;                  // [BW_HC][6]
+    double *s_fold = s_W;                              // after the last chunk: [15][32 * 18 + n * 7] partials of the waves 1 .. 15
+    // phase B: 32 subsets of 32 lanes; lane = (block pair (a <= b), upper / lower three rows of its 6 x 6 block) and / or (slot a2, row r2):
+    // half a block per lane keeps the accumulators + one W record under the 128 registers of a 1024-thread workgroup
+    const int sub = tid >> 5, wl = tid & 31, w2 = wl >> 1, rh = 3 * (wl & 1);
+    int ba_ = 0, bb_ = 0;
+    { int r = w2; while (ba_ < F && r >= F - ba_) { r -= F - ba_; ba_++; } bb_ = ba_ + r; }
+    const bool live = w2 < nwin, xl = wl < n;
+    const int a2 = xl ? wl / 6 : 0, r2 = wl - 6 * (wl / 6);
+    for (int p = tid; p < P; p += BW_T) s_const[p] = d.pconst[p];
+#ifdef BW_TRACE
+    long long bw_clk[12];
+#endif
+    // committed pose data -> LDS (sin / cos of the angles, translation)
+    auto stage_poses = [&](const ParamBufs &pb) {
+        for (int p = tid; p < P; p += BW_T) {
+            pose_sincos(pb.pose + 6 * p, s_sc + 6 * p);
+            s_tr[3 * p] = pb.pose[6 * p + 3]; s_tr[3 * p + 1] = pb.pose[6 * p + 4]; s_tr[3 * p + 2] = pb.pose[6 * p + 5];
+        }
+    };
+
+    for (int pass = 0; pass < 2; pass++) {
+        const int ignore = pass, iters = pass ? iterations : iters_fast;
+        // ---- cost at the committed parameters (LeastSquaresOptim evaluates f!(fcur, x) first)
+        {
+            const ParamBufs pb = param_bufs(d);
+            __syncthreads();
+            stage_poses(pb);
+            __syncthreads();
+            double ss = 0.0;
+            for (int i = tid; i < O; i += BW_T) {
+                if (ignore && d.outl[i]) continue;
+                const int p = d.opose[i], j = d.opoint[i];
+                const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
+                double r[2];
+                obs_eval_sc(s_sc + 6 * p, s_tr + 3 * p, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, nullptr);
+                ss += r[0] * r[0] + r[1] * r[1];
+            }
+            const double t = bw_sum(ss, s_red);
+            if (tid == 0) {
+                s->ssr = t;
+                if (pass == 0) { s->ssr_init = t; s->chol_fail = 0; s->n_outliers = 0; }
+                s->delta = LM_DELTA0; s->decrease_factor = 2.0; s->converged = 0; s->accept = 0; s->iters = 0;
+            }
+            __syncthreads();
+        }
+        for (int it = 1; it <= iters; it++) {
+            if (s->converged) break;                           // (uniform: every thread reads the flag after a barrier)
+            const ParamBufs pb = param_bufs(d);
+            const double inv_delta = 1.0 / s->delta;
+            BW_CLK(0);
+            stage_poses(pb);
+            __syncthreads();
+            BW_CLK(1);
+            // ---- A1: thread = observation
+            for (int i = tid; i < O; i += BW_T) {
+                const int p = d.opose[i], j = d.opoint[i];
+                const bool active = !(ignore && d.outl[i]);
+                const bool hp = active && !s_const[p];
+                double r[2] = {0.0, 0.0}, Jp[12], Jl[6] = {0, 0, 0, 0, 0, 0};
+                if (active) {
+                    const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
+                    obs_eval_sc(s_sc + 6 * p, s_tr + 3 * p, X, d.pix[i], d.pix[O + i], d.cam, r, hp ? Jp : nullptr, Jl, nullptr);
+                }
+                d.hasp[i] = hp ? 1 : 0;
+                st_rec<2>(d.f + 2 * (size_t)i, r);
+                st_rec<6>(d.Jl + (size_t)i * 6, Jl);
+                if (hp) st_rec<12>(d.Jp + (size_t)i * 12, Jp);
+            }
+            __syncthreads();
+            // ---- A2: thread = map point (sorted order k): V, V^-1, bl from the stored Jl / f of its observations
+            for (int k = tid; k < M; k += BW_T) {
+                const int j = d.pt_id[k];
+                double V[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+                const int t0 = d.pt_start[k], t1 = d.pt_start[k + 1];
+                for (int i = t0; i < t1; i++) {
+                    double Jl[6], r[2];
+                    ld_rec<6>(d.Jl + (size_t)i * 6, Jl); ld_rec<2>(d.f + 2 * (size_t)i, r);
+                    V[0] += Jl[0] * Jl[0] + Jl[3] * Jl[3]; V[1] += Jl[0] * Jl[1] + Jl[3] * Jl[4]; V[2] += Jl[0] * Jl[2] + Jl[3] * Jl[5];
+                    V[3] += Jl[1] * Jl[1] + Jl[4] * Jl[4]; V[4] += Jl[1] * Jl[2] + Jl[4] * Jl[5]; V[5] += Jl[2] * Jl[2] + Jl[5] * Jl[5];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) bl[c] += Jl[c] * r[0] + Jl[3 + c] * r[1];
+                }
+                V[0] += fmin(fmax(V[0], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+                V[3] += fmin(fmax(V[3], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+                V[5] += fmin(fmax(V[5], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+                double Vi[6];
+                inv3_sym(V, Vi);
+#pragma unroll
+                for (int c = 0; c < 6; c++) d.Vinv[(size_t)c * M + j] = Vi[c];
+#pragma unroll
+                for (int c = 0; c < 3; c++) d.bl[(size_t)c * M + j] = bl[c];
+            }
+            __syncthreads();
+            BW_CLK(2);
+            // ---- B: the reduced camera system from the observations of free poses (records fobs[0 .. NF)), chunk by chunk
+            double acc[18], ex[7];
+#pragma unroll
+            for (int k = 0; k < 18; k++) acc[k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) ex[k] = 0.0;
+            for (int k0 = 0; k0 < M;) {
+                // the chunk [k0, k1): <= BW_PC points, <= BW_HC records (pfs = running count of free-pose observations by sorted point)
+                const int base = d.pfs[k0];
+                int lo = k0 + 1, hi = min(M, k0 + BW_PC);
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (d.pfs[mid] - base <= BW_HC) lo = mid; else hi = mid - 1; }
+                const int k1 = lo, npc = k1 - k0, nrec = d.pfs[k1] - base;
+                if (nrec == 0) { k0 = k1; continue; }                    // no point of the chunk sees a free pose
+                for (int x = tid; x < npc; x += BW_T) {
+                    const int j = d.pt_id[k0 + x];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) s_pt[x * 10 + c] = d.Vinv[(size_t)c * M + j];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) s_pt[x * 10 + 6 + c] = d.bl[(size_t)c * M + j];
+#pragma unroll
+                    for (int a = 0; a < BW_FMAX; a++) s_slot[x * BW_FMAX + a] = -1;
+                }
+                __syncthreads();
+                for (int rec = tid; rec < nrec; rec += BW_T) {           // thread = record
+                    const int i = d.fobs[base + rec];
+                    if (!d.hasp[i]) continue;                            // an ignored outlier: no slot
+                    const int x = d.opk[i] - k0, p = d.opose[i];
+                    double jp[12], jl[6], ff[2], Vi[6], bl[3];
+                    ld_rec<12>(d.Jp + (size_t)i * 12, jp); ld_rec<6>(d.Jl + (size_t)i * 6, jl); ld_rec<2>(d.f + 2 * (size_t)i, ff);
+#pragma unroll
+                    for (int c = 0; c < 6; c++) Vi[c] = s_pt[x * 10 + c];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) bl[c] = s_pt[x * 10 + 6 + c];
+                    const double vb0 = Vi[0] * bl[0] + Vi[1] * bl[1] + Vi[2] * bl[2];
+                    const double vb1 = Vi[1] * bl[0] + Vi[3] * bl[1] + Vi[4] * bl[2];
+                    const double vb2 = Vi[2] * bl[0] + Vi[4] * bl[1] + Vi[5] * bl[2];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+                        const double w0 = jp[a] * jl[0] + jp[6 + a] * jl[3];
+                        const double w1 = jp[a] * jl[1] + jp[6 + a] * jl[4];
+                        const double w2 = jp[a] * jl[2] + jp[6 + a] * jl[5];
+                        s_W[rec * 18 + 3 * a] = w0; s_W[rec * 18 + 3 * a + 1] = w1; s_W[rec * 18 + 3 * a + 2] = w2;
+                        s_gr[rec * 6 + a] = (jp[a] * ff[0] + jp[6 + a] * ff[1]) - (w0 * vb0 + w1 * vb1 + w2 * vb2);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 12; c++) s_Jp[rec * 12 + c] = jp[c];
+                    s_slot[x * BW_FMAX + (p - p0)] = (short)rec;
+                }
+                __syncthreads();
+                if (live)
+                    for (int x = sub; x < npc; x += BW_T / 32) {
+                        const int ta = s_slot[x * BW_FMAX + ba_], tb = s_slot[x * BW_FMAX + bb_];
+                        if (ta < 0 || tb < 0) continue;
+                        double Vi[6], Wb[18];
+                        ld_rec<6>(s_pt + x * 10, Vi); ld_rec<18>(s_W + tb * 18, Wb);
+#pragma unroll
+                        for (int rr = 0; rr < 3; rr++) {
+                            const double *wa = s_W + ta * 18 + 3 * (rh + rr);
+                            const double a0 = wa[0], a1 = wa[1], a2v = wa[2];
+                            const double T0 = fma(a2v, Vi[2], fma(a1, Vi[1], a0 * Vi[0]));
+                            const double T1 = fma(a2v, Vi[4], fma(a1, Vi[3], a0 * Vi[1]));
+                            const double T2 = fma(a2v, Vi[5], fma(a1, Vi[4], a0 * Vi[2]));
+#pragma unroll
+                            for (int c = 0; c < 6; c++)
+                                acc[6 * rr + c] = fma(-T2, Wb[3 * c + 2], fma(-T1, Wb[3 * c + 1], fma(-T0, Wb[3 * c], acc[6 * rr + c])));
+                        }
+                    }
+                if (xl)
+                    for (int x = sub; x < npc; x += BW_T / 32) {
+                        const int ta = s_slot[x * BW_FMAX + a2];
+                        if (ta < 0) continue;
+                        double J[12];
+                        ld_rec<12>(s_Jp + ta * 12, J);
+                        const double j0 = r2 == 0 ? J[0] : r2 == 1 ? J[1] : r2 == 2 ? J[2] : r2 == 3 ? J[3] : r2 == 4 ? J[4] : J[5];
+                        const double j1 = r2 == 0 ? J[6] : r2 == 1 ? J[7] : r2 == 2 ? J[8] : r2 == 3 ? J[9] : r2 == 4 ? J[10] : J[11];
+#pragma unroll
+                        for (int c = 0; c < 6; c++) ex[c] = fma(j1, J[6 + c], fma(j0, J[c], ex[c]));
+                        ex[6] += s_gr[ta * 6 + r2];
+                    }
+                __syncthreads();
+                k0 = k1;
+            }
+            BW_CLK(3);
+            // fold the 32 subsets in a fixed order: the two subsets of a wave by a lane exchange, the 16 waves through LDS by wave 0
+#pragma unroll
+            for (int k = 0; k < 18; k++) acc[k] += __shfl_xor(acc[k], 32);
+#pragma unroll
+            for (int k = 0; k < 7; k++) ex[k] += __shfl_xor(ex[k], 32);
+            const int fstride = 32 * 18 + n * 7, wv = tid >> 6;
+            if (wv >= 1 && (tid & 63) < 32) {
+                if (live) st_rec<18>(s_fold + (size_t)(wv - 1) * fstride + wl * 18, acc);
+                if (xl) {
+#pragma unroll
+                    for (int k = 0; k < 7; k++) s_fold[(size_t)(wv - 1) * fstride + 32 * 18 + wl * 7 + k] = ex[k];
+                }
+            }
+            __syncthreads();
+            if (tid < 32) {
+                if (live)
+                    for (int q = 0; q < BW_T / 64 - 1; q++) {
+                        double o[18];
+                        ld_rec<18>(s_fold + (size_t)q * fstride + wl * 18, o);
+#pragma unroll
+                        for (int k = 0; k < 18; k++) acc[k] += o[k];
+                    }
+                if (xl)
+                    for (int q = 0; q < BW_T / 64 - 1; q++) {
+#pragma unroll
+                        for (int k = 0; k < 7; k++) ex[k] += s_fold[(size_t)q * fstride + 32 * 18 + wl * 7 + k];
+                    }
+            }
+            __syncthreads();                                   // the fold buffer is read: the system goes where no partial lives (s_A)
+            // ---- S: wave 0 alone assembles and solves (wave-synchronous LDS: a wave's DS instructions execute in order)
+            if (tid < 64) {
+                if (tid < 32 && xl) {
+                    const double ud = r2 == 0 ? ex[0] : r2 == 1 ? ex[1] : r2 == 2 ? ex[2] : r2 == 3 ? ex[3] : r2 == 4 ? ex[4] : ex[5];
+                    s_A[n * n + wl] = ex[6];                   // right-hand side row
+                    s_ud[wl] = ud;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) s_fold[a2 * 36 + r2 * 6 + c] = ex[c];      // Jp'Jp row r2 of slot a2 -> the diagonal block
+                }
+                bw_wave_sync();
+                if (tid < 32 && live) {
+                    if (ba_ == bb_) {
+#pragma unroll
+                        for (int k = 0; k < 18; k++) acc[k] += s_fold[ba_ * 36 + 6 * rh + k];
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                        for (int c = 0; c < 6; c++) {
+                            s_A[(6 * ba_ + rh + rr) * n + 6 * bb_ + c] = acc[6 * rr + c];
+                            if (ba_ != bb_) s_A[(6 * bb_ + c) * n + 6 * ba_ + rh + rr] = acc[6 * rr + c];
+                        }
+                }
+                bw_wave_sync();
+                BW_CLK(4);
+                // damped Cholesky A = L L': lane i keeps row i of the lower triangle in REGISTERS (lane n: the right-hand side row -- the forward
+                // substitution comes for free); the entries of row jc a step needs are lane broadcasts (v_readlane), not LDS round trips
+                // (a first version walked the rows in LDS: 79 k cycles per solve, every multiply-add behind an exposed LDS latency)
+                if (tid < n) s_A[tid * n + tid] += fmin(fmax(s_ud[tid], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+                bw_wave_sync();
+                double a[6 * BW_FMAX];
+#pragma unroll
+                for (int k = 0; k < 6 * BW_FMAX; k++) a[k] = (tid <= n && k < n) ? s_A[tid * n + k] : 0.0;
+                bool bad = false;
+#pragma unroll
+                for (int jc = 0; jc < 6 * BW_FMAX; jc++) {
+                    if (jc < n) {
+                        double sum = a[jc];
+#pragma unroll
+                        for (int k = 0; k < jc; k++)
+                            sum -= a[k] * __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[k]), jc), __builtin_amdgcn_readlane(__double2loint(a[k]), jc));
+                        const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sum), jc), __builtin_amdgcn_readlane(__double2loint(sum), jc));
+                        if (!(piv > 0.0)) bad = true;
+                        const double ljj = sqrt(piv);
+                        a[jc] = tid == jc ? ljj : sum / ljj;
+                    }
+                }
+                // L (rows 0 .. n - 1) and y' = (L^-1 g)' (row n) back to LDS; then lane i takes COLUMN i of L and the back-substitution
+                // L' dp = y runs in registers too
+                if (tid <= n) {
+#pragma unroll
+                    for (int k = 0; k < 6 * BW_FMAX; k++) if (k < n) s_A[tid * n + k] = a[k];
+                }
+                bw_wave_sync();
+                double y = tid < n ? s_A[n * n + tid] : 0.0;
+                const double dg = tid < n ? s_A[tid * n + tid] : 1.0;
+#pragma unroll
+                for (int k = 0; k < 6 * BW_FMAX; k++) a[k] = (tid < n && k < n && k > tid) ? s_A[k * n + tid] : 0.0;      // a[k] = L[k][tid]
+#pragma unroll
+                for (int jc = 6 * BW_FMAX - 1; jc >= 0; jc--) {
+                    if (jc < n) {
+                        const double yj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y), jc), __builtin_amdgcn_readlane(__double2loint(y), jc));
+                        const double dj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dg), jc), __builtin_amdgcn_readlane(__double2loint(dg), jc));
+                        const double xj = yj / dj;
+                        if (tid == jc) y = xj;
+                        if (tid < jc) y -= a[jc] * xj;
+                    }
+                }
+                if (tid < n) s_dp[tid] = y;
+                if (tid == 0) s_flag[0] = bad ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_flag[0]) { if (tid == 0) s->chol_fail = 1; }
+            BW_CLK(5);
+            // ---- C1: trial poses; thread = map point: dl, trial point
+            double mx = 0.0;
+            if (tid < n) { const int p = p0 + tid / 6, c = tid - 6 * (tid / 6); const double v = s_dp[tid]; pb.pose_t[6 * p + c] = pb.pose[6 * p + c] - v; mx = fabs(v); }
+            for (int p = tid; p < P; p += BW_T) {
+                if (s_const[p]) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) { pb.pose_t[6 * p + c] = pb.pose[6 * p + c]; s_sct[6 * p + c] = s_sc[6 * p + c]; }
+                } else {
+                    const int a = p - p0;
+                    const double tp[3] = {pb.pose[6 * p] - s_dp[6 * a], pb.pose[6 * p + 1] - s_dp[6 * a + 1], pb.pose[6 * p + 2] - s_dp[6 * a + 2]};
+                    pose_sincos(tp, s_sct + 6 * p);
+                }
+            }
+            for (int k = tid; k < M; k += BW_T) {
+                const int j = d.pt_id[k];
+                double bl[3] = {d.bl[j], d.bl[(size_t)M + j], d.bl[(size_t)2 * M + j]};
+                for (int rec = d.pfs[k]; rec < d.pfs[k + 1]; rec++) {      // the point's observations of free poses (host list): bl -= Jl' (Jp dp)
+                    const int i = d.fobs[rec];
+                    if (!d.hasp[i]) continue;
+                    const int a = d.opose[i] - p0;
+                    double jp[12], jl[6];
+                    ld_rec<12>(d.Jp + (size_t)i * 12, jp); ld_rec<6>(d.Jl + (size_t)i * 6, jl);
+                    double ua = 0.0, ub = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) { ua += jp[c] * s_dp[6 * a + c]; ub += jp[6 + c] * s_dp[6 * a + c]; }
+#pragma unroll
+                    for (int c = 0; c < 3; c++) bl[c] -= jl[c] * ua + jl[3 + c] * ub;
+                }
+                double Vi[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) Vi[c] = d.Vinv[(size_t)c * M + j];
+                const double l0 = Vi[0] * bl[0] + Vi[1] * bl[1] + Vi[2] * bl[2];
+                const double l1 = Vi[1] * bl[0] + Vi[3] * bl[1] + Vi[4] * bl[2];
+                const double l2 = Vi[2] * bl[0] + Vi[4] * bl[1] + Vi[5] * bl[2];
+                d.dl[3 * j] = l0; d.dl[3 * j + 1] = l1; d.dl[3 * j + 2] = l2;
+                pb.pts_t[3 * j] = pb.pts[3 * j] - l0; pb.pts_t[3 * j + 1] = pb.pts[3 * j + 1] - l1; pb.pts_t[3 * j + 2] = pb.pts[3 * j + 2] - l2;
+                mx = fmax(mx, fmax(fabs(l0), fmax(fabs(l1), fabs(l2))));
+            }
+            __syncthreads();
+            // ---- C2: thread = observation: trial and predicted residuals
+            double st = 0.0, sp = 0.0;
+            for (int i = tid; i < O; i += BW_T) {
+                const int p = d.opose[i], j = d.opoint[i];
+                const bool active = !(ignore && d.outl[i]);
+                double jl[6], ff[2], r[2] = {0.0, 0.0}, pa = 0.0, pbv = 0.0;
+                ld_rec<6>(d.Jl + (size_t)i * 6, jl); ld_rec<2>(d.f + 2 * (size_t)i, ff);
+                const double l0 = d.dl[3 * j], l1 = d.dl[3 * j + 1], l2 = d.dl[3 * j + 2];
+                const bool fr = !s_const[p];
+                const int a = p - p0;
+                if (d.hasp[i]) {
+                    double jp[12];
+                    ld_rec<12>(d.Jp + (size_t)i * 12, jp);
+#pragma unroll
+                    for (int c = 0; c < 6; c++) { pa += jp[c] * s_dp[6 * a + c]; pbv += jp[6 + c] * s_dp[6 * a + c]; }
+                }
+                if (active) {
+                    const double Xt[3] = {pb.pts_t[3 * j], pb.pts_t[3 * j + 1], pb.pts_t[3 * j + 2]};
+                    const double tr[3] = {s_tr[3 * p] - (fr ? s_dp[6 * a + 3] : 0.0), s_tr[3 * p + 1] - (fr ? s_dp[6 * a + 4] : 0.0), s_tr[3 * p + 2] - (fr ? s_dp[6 * a + 5] : 0.0)};
+                    obs_eval_sc(s_sct + 6 * p, tr, Xt, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, nullptr);
+                }
+                pa += jl[0] * l0 + jl[1] * l1 + jl[2] * l2; pbv += jl[3] * l0 + jl[4] * l1 + jl[5] * l2;
+                pa -= ff[0]; pbv -= ff[1];
+                st += r[0] * r[0] + r[1] * r[1];
+                sp += pa * pa + pbv * pbv;
+            }
+            BW_CLK(6);
+            const double tt = bw_sum(st, s_red), tp = bw_sum(sp, s_red), tm = bw_max(mx, s_red);
+            // ---- D
+            if (tid == 0) { s->trial_ssr = tt; s->pred_ssr = tp; s->maxdx = tm; lm_decide(s, tt, tp, tm); }
+            __syncthreads();
+#ifdef BW_TRACE
+            if (tid == 0 && blockIdx.x == 5 && pass == 0 && it == 3) { bw_clk[7] = clock64();
+                printf("k_ba_window (M %d, O %d, F %d, %d free-pose observations): sincos %lld | A %lld | B chunks %lld | fold %lld | solve %lld | C %lld | reduce + decide %lld cycles\n", M, O, F, NF,
+                       bw_clk[1] - bw_clk[0], bw_clk[2] - bw_clk[1], bw_clk[3] - bw_clk[2], bw_clk[4] - bw_clk[3], bw_clk[5] - bw_clk[4], bw_clk[6] - bw_clk[5], bw_clk[7] - bw_clk[6]); }
+#endif
+        }
+        if (tid == 0) { if (pass == 0) { s->ssr_pass1 = s->ssr; s->iters_pass1 = s->iters; } else { s->ssr_final = s->ssr; s->iters_pass2 = s->iters; } }
+        if (pass == 0) {
+            // ---- _ba_detect_outliers! at theta_1 (bundle_adjustment.jl:90-111)
+            __syncthreads();
+            const ParamBufs pb = param_bufs(d);
+            stage_poses(pb);
+            __syncthreads();
+            double cnt = 0.0;
+            for (int i = tid; i < O; i += BW_T) {
+                const int p = d.opose[i], j = d.opoint[i];
+                const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
+                double r[2], z;
+                obs_eval_sc(s_sc + 6 * p, s_tr + 3 * p, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, &z);
+                const bool out = z < depth_eps || (r[0] * r[0] + r[1] * r[1]) > repr_eps;
+                d.outl[i] = out ? 1 : 0;
+                cnt += out ? 1.0 : 0.0;
+            }
+            const double tc = bw_sum(cnt, s_red);
+            if (tid == 0) s->n_outliers = (int)tc;
+            __syncthreads();
+        }
     }
 }
 
@@ -2304,6 +2785,8 @@ struct BAPlan {
     const double *theta = nullptr; const uint8_t *theta_const_in = nullptr; const double *pixels_yx = nullptr;
     const int64_t *pose_ids = nullptr, *point_ids = nullptr;
     bool may_reorder = false, small_groups = false;
+    bool window = false;         // result: the window fits k_ba_window (<= 5 consecutive free poses, ...): no point groups are built for it
+    int nfree_obs = 0;           // result: observations of free poses
     // results
     slam_ba *ba = nullptr;
     int err = 0; char msg[160] = {0};
@@ -2316,7 +2799,7 @@ struct BAPlan {
     size_t npairs = 0; int nblk = 0, ngrp = 0, wstride = 0, hb = 0, sg_ob = SG_OB, sg_sb = SG_SB;
     int twice_pt = -1, twice_pose = -1;
     // layout: offsets inside the three regions
-    size_t o_pose, o_pts, o_const, o_pix, o_opose, o_opoint, o_start, o_ptid, o_opk, o_ohp, o_grp, o_fgrp, o_pairs, o_bs, o_bpq, up_bytes = 0;
+    size_t o_pose, o_pts, o_const, o_pix, o_opose, o_opoint, o_start, o_ptid, o_opk, o_ohp, o_pfs, o_fobs, o_grp, o_fgrp, o_pairs, o_bs, o_bpq, up_bytes = 0;
     int sg_hp = SG_OB;
     size_t o_st, o_cf, o_outl, zero_bytes = 0;
     size_t o_pose_t, o_pts_t, o_hasp, o_f, o_ft, o_Jp, o_Jl, o_Vinv, o_bl, o_T, o_W, o_red, o_Sw, o_dp, o_dl, o_li, o_lf, o_part, o_band, o_wpart, o_xchg, work_bytes = 0;
@@ -2325,7 +2808,7 @@ struct BAPlan {
     int fail(int code, const char *fmt, long long a = 0, long long b = 0, long long c = 0) { err = code; snprintf(msg, sizeof msg, fmt, a, b, c); return code; }
     // the per-observation arrays (sorted by point): ONE walk over the caller's observations -- the sorted position of observation i is the
     // next free one of its point.  The walk also finds a map point observed twice by one free pose: it has no place in a pose block.
-    void fill_obs(int *opose, int *opoint, int *opk, double *pix, int *ohp = nullptr)
+    void fill_obs(int *opose, int *opoint, int *opk, double *pix, int *ohp = nullptr, int *pfs = nullptr, int *fobs = nullptr)
     {
         std::vector<int> fill(start.begin(), start.end() - 1), seen((size_t)P, -1);     // seen[p]: the last point (sorted position) free pose p observed
         for (int i = 0; i < O; i++) {
@@ -2341,6 +2824,11 @@ struct BAPlan {
                 if (seen[p] == k) { twice_pt = pt_id[k]; twice_pose = new_of.empty() ? p : ba->pose_order[p]; break; }
                 seen[p] = k;
             }
+        if (pfs) {                                              // running count of free-pose observations by sorted point
+            int c = 0;
+            for (int k = 0; k < M; k++) { pfs[k] = c; for (int a = start[k]; a < start[k + 1]; a++) if (!theta_const[opose[a]]) { if (fobs) fobs[c] = a; c++; } }
+            pfs[M] = c;
+        }
         if (ohp) {                                              // index of an observation among its group's observations of free poses
             int mx = 0;
             for (const int4 &G : grp) {
@@ -2367,14 +2855,15 @@ static int ba_plan(BAPlan &pl)
     //     that order (stable).  hb = widest span of free observers of one point = block half-bandwidth of S.
     std::vector<int> &cnt = pl.cnt, &pfirst = pl.pfirst, plast(M), pany(M);
     cnt.assign(M, 0); pfirst.assign(M, 0);
-    int hb = 0, bad_obs = -1;
+    int hb = 0, bad_obs = -1, nfo = 0;
     auto spans = [&]() {                                     // (the first pass also checks the ids: one walk over the observations, not two)
         std::fill(cnt.begin(), cnt.end(), 0); std::fill(pfirst.begin(), pfirst.end(), P); std::fill(plast.begin(), plast.end(), -1); std::fill(pany.begin(), pany.end(), P);
+        nfo = 0;
         for (int i = 0; i < O; i++) {
             if (pose_ids[i] < 1 || pose_ids[i] > P || point_ids[i] < 1 || point_ids[i] > M) { bad_obs = i; return; }
             const int j = (int)point_ids[i] - 1, p = pl.lab(pose_ids[i]);
             cnt[j]++; pany[j] = std::min(pany[j], p);
-            if (!theta_const[p]) { pfirst[j] = std::min(pfirst[j], p); plast[j] = std::max(plast[j], p); }
+            if (!theta_const[p]) { pfirst[j] = std::min(pfirst[j], p); plast[j] = std::max(plast[j], p); nfo++; }
         }
         hb = 0;
         for (int j = 0; j < M; j++) {
@@ -2407,10 +2896,16 @@ static int ba_plan(BAPlan &pl)
     // --- point groups of k_schur_groups: same f, <= SG_SB points, <= SG_OB observations; evenly sized within one f
     static const bool no_groups = getenv("SLAMHIP_NO_GROUPS") != nullptr;
     bool grouped = !no_groups && hb <= BS_MAXHB && M > 0 && O > 0 && sg_fold_fits(hb);
+    pl.nfree_obs = nfo;
+    {   // a window one workgroup can keep to itself (k_ba_window, batches only): the point groups of the launch-per-phase kernels are not built
+        static const bool no_bw = getenv("SLAMHIP_NO_BA_WINDOW") != nullptr;
+        int nfree = 0; for (int p = 0; p < P; p++) nfree += theta_const[p] ? 0 : 1;
+        pl.window = pl.small_groups && !no_bw && grouped && nfree >= 1 && nfree <= 5 && nfree == ba->pspan && P <= 128 && O <= 40000;
+    }
     std::vector<int4> &grp = pl.grp; std::vector<int> &fgrp = pl.fgrp;
     fgrp.assign(P + 1, 0);
     int max_no = 0, max_np = 0;
-    if (grouped) {
+    if (grouped && !pl.window) {
         static const int sg_points = [] { const char *v = getenv("SLAMHIP_SG_POINTS"); return v ? atoi(v) : 0; }();      // (measurement knob)
         // points per group: a small window in full groups occupies a few compute units and each workgroup walks 7 points per subset; with
         // 16-point groups the reference-shaped window (800 points: 18 -> 50 groups) builds in 0.75 instead of 0.83 ms per 15 iterations,
@@ -2497,7 +2992,7 @@ static int ba_plan(BAPlan &pl)
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     pl.o_pose = take(n * 8); pl.o_pts = take((size_t)3 * M * 8 + 8); pl.o_const = take(P); pl.o_pix = take((size_t)2 * O * 8 + 8);
     pl.o_opose = take((size_t)O * 4 + 4); pl.o_opoint = take((size_t)O * 4 + 4); pl.o_start = take((size_t)(M + 1) * 4);
-    pl.o_ptid = take((size_t)M * 4 + 4); pl.o_opk = take((size_t)O * 4 + 4); pl.o_ohp = take((size_t)O * 4 + 4); pl.o_grp = take((size_t)ngrp * 16 + 16); pl.o_fgrp = take((size_t)(P + 1) * 4);
+    pl.o_ptid = take((size_t)M * 4 + 4); pl.o_opk = take((size_t)O * 4 + 4); pl.o_ohp = take(pl.window ? 8 : (size_t)O * 4 + 4); pl.o_pfs = take((size_t)(M + 1) * 4); pl.o_fobs = take((size_t)pl.nfree_obs * 4 + 4); pl.o_grp = take((size_t)ngrp * 16 + 16); pl.o_fgrp = take((size_t)(P + 1) * 4);
     pl.o_pairs = take(npairs * 8 + 8); pl.o_bs = take((size_t)(nblk + 1) * 4); pl.o_bpq = take((size_t)nblk * 8 + 8);
     pl.up_bytes = off; off = 0;
     pl.o_st = take(sizeof(LMState)); pl.o_cf = take(64); pl.o_outl = take((size_t)O + 1);
@@ -2542,7 +3037,7 @@ static int ba_emit(BAPlan &pl, char *Aup, char *Azero, char *Awork, char *stage)
     ba->chol_flag = (int *)(Azero + pl.o_cf); ba->linv = (double *)(Awork + pl.o_li); ba->lfac = (double *)(Awork + pl.o_lf); ba->band = (double *)(Awork + pl.o_band);
     d.pt_id = (const int *)(Aup + pl.o_ptid); d.opk = (const int *)(Aup + pl.o_opk); d.grp = (const int4 *)(Aup + pl.o_grp); d.fgrp = (const int *)(Aup + pl.o_fgrp);
     d.ngrp = pl.ngrp; d.whb = pl.hb; d.wstride = pl.wstride; d.wpart = (double *)(Awork + pl.o_wpart);
-    d.sg_ob = pl.sg_ob; d.sg_sb = pl.sg_sb; d.ohp = (const int *)(Aup + pl.o_ohp);
+    d.sg_ob = pl.sg_ob; d.sg_sb = pl.sg_sb; d.ohp = (const int *)(Aup + pl.o_ohp); d.pfs = (const int *)(Aup + pl.o_pfs); d.fobs = (const int *)(Aup + pl.o_fobs);
     ba->nparts = ba->grouped ? pl.ngrp : ba->nblocks_obs;
     ba->xchg = (double *)(Awork + pl.o_xchg);
 #define UP(o, src, bytes) do { if ((bytes) > 0) memcpy(stage + (o), (src), (bytes)); } while (0)
@@ -2552,7 +3047,7 @@ static int ba_emit(BAPlan &pl, char *Aup, char *Azero, char *Awork, char *stage)
     UP(pl.o_const, pl.theta_const, (size_t)P); UP(pl.o_start, pl.start.data(), (size_t)(M + 1) * 4);
     if (pl.filled) { UP(pl.o_pix, pl.v_pix.data(), (size_t)2 * O * 8); UP(pl.o_opose, pl.v_opose.data(), (size_t)O * 4); UP(pl.o_opoint, pl.v_opoint.data(), (size_t)O * 4); UP(pl.o_opk, pl.v_opk.data(), (size_t)O * 4); }
     else {                                                   // (grouped: nothing on the host needs these arrays) written in place
-        pl.fill_obs((int *)(stage + pl.o_opose), (int *)(stage + pl.o_opoint), (int *)(stage + pl.o_opk), (double *)(stage + pl.o_pix), (int *)(stage + pl.o_ohp));
+        pl.fill_obs((int *)(stage + pl.o_opose), (int *)(stage + pl.o_opoint), (int *)(stage + pl.o_opk), (double *)(stage + pl.o_pix), pl.window ? nullptr : (int *)(stage + pl.o_ohp), (int *)(stage + pl.o_pfs), (int *)(stage + pl.o_fobs));
         if (pl.twice_pt >= 0) return pl.fail(SLAM_ERR_ARG, "slam_ba: map point %lld is observed twice by pose %lld", pl.twice_pt + 1, pl.twice_pose + 1);
     }
     UP(pl.o_pairs, pl.pairs.data(), pl.npairs * 8); UP(pl.o_bs, pl.blk_start.data(), (size_t)(pl.nblk + 1) * 4); UP(pl.o_bpq, pl.blk_pq.data(), (size_t)pl.nblk * 8);
@@ -2972,6 +3467,54 @@ int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy, int
 }
 
 
+} // extern "C"
+
+// Worker threads for the host half of a batch (structure analysis, staging, result scatter of S windows): created once, parked on a
+// condition variable between calls -- starting 15 threads per phase cost more than the work they did (128 windows: 2.3 ms of a 6.3 ms
+// call).  Callers from several contexts take turns (run_mu).  Windows are handed out one at a time from an atomic counter.
+namespace {
+struct BAPool {
+    std::vector<std::thread> th;
+    std::mutex mu, run_mu;
+    std::condition_variable cv, cv_done;
+    const std::function<void(int)> *fn = nullptr;
+    int n = 0, pending = 0; unsigned long gen = 0; bool stop = false;
+    std::atomic<int> next{0};
+    explicit BAPool(int workers)
+    {
+        for (int t = 0; t < workers; t++)
+            th.emplace_back([this] {
+                unsigned long seen = 0;
+                for (;;) {
+                    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
+                    for (int z; (z = next.fetch_add(1)) < n;) (*fn)(z);
+                    { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv_done.notify_one(); }
+                }
+            });
+    }
+    ~BAPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &x : th) x.join(); }
+    void run(int count, const std::function<void(int)> &f)
+    {
+        std::lock_guard<std::mutex> turn(run_mu);
+        if (th.empty() || count <= 1) { for (int z = 0; z < count; z++) f(z); return; }
+        { std::lock_guard<std::mutex> lk(mu); fn = &f; n = count; next.store(0); pending = (int)th.size(); gen++; }
+        cv.notify_all();
+        for (int z; (z = next.fetch_add(1)) < count;) f(z);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+BAPool &ba_pool()
+{
+    static const int env_threads = [] { const char *v = getenv("SLAMHIP_BA_THREADS"); return v ? atoi(v) : 0; }();
+    const int hw = (int)std::thread::hardware_concurrency();
+    static BAPool pool(std::max(0, (env_threads > 0 ? env_threads : std::min(std::max(hw / 4, 4), 32)) - 1));
+    return pool;
+}
+}  // namespace
+
+extern "C" {
+
 // bundle_adjustment! for S windows at once (no reference counterpart, like the other *_batch entry points; the caller is the estimator
 // task of S lock-stepped SlamManagers, estimator.jl:78-99 / :317-347): every kernel of slam_local_ba with the window on blockIdx.y, each
 // window with its own device-side LM state; host set-up (structure analysis, staging) spread over threads; ONE host -> device copy, one
@@ -3002,16 +3545,9 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
         q.pixels_yx = pixels_yx ? pixels_yx + 2 * ob_off[z] : nullptr; q.pose_ids = pose_ids ? pose_ids + ob_off[z] : nullptr; q.point_ids = point_ids ? point_ids + ob_off[z] : nullptr;
         q.may_reorder = true; q.small_groups = true;
     }
-    static const int env_threads = [] { const char *v = getenv("SLAMHIP_BA_THREADS"); return v ? atoi(v) : 0; }();
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int nthr = std::max(1, std::min(S, env_threads > 0 ? env_threads : std::min(hw > 0 ? hw : 4, 16)));
-    auto parallel = [&](auto fn) {                             // fn(z) for z = 0 .. S - 1, windows dealt round-robin
-        if (nthr == 1) { for (int z = 0; z < S; z++) fn(z); return; }
-        std::vector<std::thread> th;
-        for (int t = 1; t < nthr; t++) th.emplace_back([&, t] { for (int z = t; z < S; z += nthr) fn(z); });
-        for (int z = 0; z < S; z += nthr) fn(z);
-        for (auto &x : th) x.join();
-    };
+    BAPool &pool = ba_pool();
+    const int nthr = (int)pool.th.size() + 1;
+    auto parallel = [&](const std::function<void(int)> &fn) { pool.run(S, fn); };
     parallel([&](int z) { ba_plan(pl[z]); });
     const auto tw1 = std::chrono::steady_clock::now();
     std::vector<int> st_code(S, SLAM_OK);
@@ -3029,7 +3565,7 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
     if (NB > 0) {
         // region-major arena: [window table | result table | uploads of every window][zero regions][work regions][results]
         std::vector<size_t> up(NB + 1), ze(NB + 1), wk(NB + 1), rs(NB + 1);
-        const size_t tab_bytes = al((size_t)NB * sizeof(BAWin)), rtab_bytes = al((size_t)NB * sizeof(BARes));
+        const size_t tab_bytes = al((size_t)NB * sizeof(BAWin)), rtab_bytes = al((size_t)NB * sizeof(BARes)) + al((size_t)NB * 4);   // (+ the list of k_ba_window's windows)
         up[0] = tab_bytes + rtab_bytes; ze[0] = 0; wk[0] = 0; rs[0] = 0;
         for (int k = 0; k < NB; k++) {
             const BAPlan &q = pl[batch[k]];
@@ -3066,10 +3602,29 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
             if (q.err) { st_code[batch[k]] = q.err; if (!status) return slam_fail(ctx, q.err, "slam_local_ba_batch: window %d: %s", batch[k], q.msg); }
         }
         // a window whose set-up failed in ba_emit (a point observed twice by one pose) stays in the table as an inert entry: no groups, no blocks
+        // windows one workgroup can keep to itself (k_ba_window): <= 5 free poses, consecutive; the others take the launch-per-phase kernels
+        static const bool no_bw = getenv("SLAMHIP_NO_BA_WINDOW") != nullptr;
+        std::vector<int> small_list;
+        size_t lds_bw = 0;
+        for (int k = 0; k < NB && !no_bw; k++) {
+            BAPlan &q = pl[batch[k]]; BAWin &w = tab_h[k];
+            if (q.err) continue;
+            if (q.window) {
+                small_list.push_back(k); lds_bw = std::max(lds_bw, bw_lds_bytes(q.P));
+                w.pad = 1;
+            }
+        }
+        // (the list travels behind the result table in the same upload)
+        const int NS_ = (int)small_list.size();
+        bool all_small = NS_ == NB;
+        for (int k = 0; k < NB; k++) if (!pl[batch[k]].err && tab_h[k].pad != 1) all_small = false;
+        int *list_h = (int *)(stage + tab_bytes + rtab_bytes - al((size_t)NB * 4));
+        for (int k = 0; k < NS_; k++) list_h[k] = small_list[k];
         int gx_obs = 1, gx_grp = 1, gx_red = 1, max_ob = 0, max_hb = 0; size_t lds_sg = 0, lds_band = 0;
         for (int k = 0; k < NB; k++) {
             BAPlan &q = pl[batch[k]]; BAWin &w = tab_h[k];
             if (q.err) { w.d.ngrp = 0; w.nb_obs = 0; w.n_red = 0; w.d.O = 0; w.d.M = 0; w.d.n = 0; w.B.nb = 0; continue; }
+            if (w.pad) continue;
             gx_obs = std::max(gx_obs, w.nb_obs); gx_grp = std::max(gx_grp, w.d.ngrp); gx_red = std::max(gx_red, w.n_red);
             max_ob = std::max(max_ob, w.d.sg_ob); max_hb = std::max(max_hb, w.d.whb);
             lds_band = std::max(lds_band, (size_t)w.B.lds_bytes);
@@ -3077,7 +3632,7 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
         // small groups everywhere (the reference's window shape: 16 points x 10 observers): 256-thread workgroups, two to three per compute unit
         static const bool no_t256 = getenv("SLAMHIP_BA_BATCH_T512") != nullptr;
         const int TT = (!no_t256 && max_ob <= 256 && (max_hb + 1) * (max_hb + 2) / 2 <= 256) ? 256 : SG_T;
-        for (int k = 0; k < NB; k++) if (!pl[batch[k]].err) lds_sg = std::max(lds_sg, sg_lds_bytes(tab_h[k].d.whb, tab_h[k].d.P, tab_h[k].d.sg_ob, tab_h[k].d.sg_sb, TT, tab_h[k].d.sg_hp));
+        for (int k = 0; k < NB; k++) if (!pl[batch[k]].err && !tab_h[k].pad) lds_sg = std::max(lds_sg, sg_lds_bytes(tab_h[k].d.whb, tab_h[k].d.P, tab_h[k].d.sg_ob, tab_h[k].d.sg_sb, TT, tab_h[k].d.sg_hp));
         const auto tw2 = std::chrono::steady_clock::now();
         hipStream_t st = ctx->stream;
         static std::atomic<bool> attr_set[64];
@@ -3107,11 +3662,19 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
                 hipLaunchKernelGGL(k_control_b, dim3(1, NB), dim3(256), 0, st, tab);
             }
         };
-        if (e == hipSuccess) {
+        if (e == hipSuccess && NS_ > 0) {
+            static std::atomic<bool> bw_attr[64];
+            if (!bw_attr[dv].load(std::memory_order_acquire)) { e = hipFuncSetAttribute((const void *)k_ba_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bw_lds_bytes(BW_PMAX)); bw_attr[dv].store(true, std::memory_order_release); }
+            const int *list_d = (const int *)(A + tab_bytes + rtab_bytes - al((size_t)NB * 4));
+            if (e == hipSuccess) hipLaunchKernelGGL(k_ba_window, dim3(NS_), dim3(BW_T), lds_bw, st, tab, list_d, iters_fast, iterations, repr_eps, 1e-6);
+        }
+        if (e == hipSuccess && !all_small) {
             run_pass(0, iters_fast);
             hipLaunchKernelGGL(k_outliers_b, dim3(gx_obs, NB), dim3(256), 0, st, tab, repr_eps, 1e-6);
             hipLaunchKernelGGL(k_outlier_count_b, dim3(1, NB), dim3(256), 0, st, tab);
             run_pass(1, iterations);
+        }
+        if (e == hipSuccess) {
             hipLaunchKernelGGL(k_results_b, dim3(8, NB), dim3(256), 0, st, tab, rtab, A);
             e = hipGetLastError();
         }
@@ -3165,6 +3728,43 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
     if (status) return SLAM_OK;                                // per-window codes are in status[]
     if (first == SLAM_ERR_NUMERIC) return slam_fail(ctx, SLAM_ERR_NUMERIC, "slam_local_ba_batch: a reduced camera system was not positive definite (that window's theta and outliers are left unchanged)");
     return first;
+}
+
+
+// host-only timing of the batch set-up (no HIP call, no device needed): plan + emit of S windows on `threads` threads into malloc'ed
+// staging; out_us = {plan, emit}.  Measurement aid for tuning the host side on any machine (scripts/probes/ba_host_time.py).
+int slam_debug_ba_host_time(int S, const double *cams, const int32_t *Pn, const int32_t *Mn, const int32_t *On, const double *theta, const uint8_t *theta_const,
+                            const double *pixels_yx, const int64_t *pose_ids, const int64_t *point_ids, int threads, double *out_us)
+{
+    std::vector<size_t> th_off(S + 1, 0), pc_off(S + 1, 0), ob_off(S + 1, 0);
+    for (int z = 0; z < S; z++) { th_off[z + 1] = th_off[z] + 6 * (size_t)Pn[z] + 3 * (size_t)Mn[z]; pc_off[z + 1] = pc_off[z] + Pn[z]; ob_off[z + 1] = ob_off[z] + On[z]; }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<BAPlan> pl(S);
+    for (int z = 0; z < S; z++) {
+        BAPlan &q = pl[z];
+        q.fx = cams[4 * z]; q.fy = cams[4 * z + 1]; q.cx = cams[4 * z + 2]; q.cy = cams[4 * z + 3];
+        q.P = Pn[z]; q.M = Mn[z]; q.O = On[z]; q.theta = theta + th_off[z]; q.theta_const_in = theta_const + pc_off[z];
+        q.pixels_yx = pixels_yx + 2 * ob_off[z]; q.pose_ids = pose_ids + ob_off[z]; q.point_ids = point_ids + ob_off[z];
+        q.may_reorder = true; q.small_groups = true;
+    }
+    auto parallel = [&](auto fn) {
+        if (threads <= 1) { for (int z = 0; z < S; z++) fn(z); return; }
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; t++) th.emplace_back([&, t] { for (int z = t; z < S; z += threads) fn(z); });
+        for (int z = 0; z < S; z += threads) fn(z);
+        for (auto &x : th) x.join();
+    };
+    parallel([&](int z) { ba_plan(pl[z]); });
+    const auto t1 = std::chrono::steady_clock::now();
+    std::vector<size_t> up(S + 1, 0);
+    for (int z = 0; z < S; z++) up[z + 1] = up[z] + pl[z].up_bytes;
+    std::vector<char> stage(up[S] + 64);
+    char *fake = (char *)(uintptr_t)0x100000000ull;
+    parallel([&](int z) { if (!pl[z].err) ba_emit(pl[z], fake, fake, fake, stage.data() + up[z]); });
+    const auto t2 = std::chrono::steady_clock::now();
+    out_us[0] = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() * 1e-3;
+    out_us[1] = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count() * 1e-3;
+    return 0;
 }
 
 } // extern "C"
