@@ -2992,7 +2992,7 @@ static int ba_plan(BAPlan &pl)
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     pl.o_pose = take(n * 8); pl.o_pts = take((size_t)3 * M * 8 + 8); pl.o_const = take(P); pl.o_pix = take((size_t)2 * O * 8 + 8);
     pl.o_opose = take((size_t)O * 4 + 4); pl.o_opoint = take((size_t)O * 4 + 4); pl.o_start = take((size_t)(M + 1) * 4);
-    pl.o_ptid = take((size_t)M * 4 + 4); pl.o_opk = take((size_t)O * 4 + 4); pl.o_ohp = take(pl.window ? 8 : (size_t)O * 4 + 4); pl.o_pfs = take((size_t)(M + 1) * 4); pl.o_fobs = take((size_t)pl.nfree_obs * 4 + 4); pl.o_grp = take((size_t)ngrp * 16 + 16); pl.o_fgrp = take((size_t)(P + 1) * 4);
+    pl.o_ptid = take((size_t)M * 4 + 4); pl.o_opk = take((size_t)O * 4 + 4); pl.o_ohp = take(pl.window ? 8 : (size_t)O * 4 + 4); pl.o_pfs = take(pl.small_groups ? (size_t)(M + 1) * 4 : 8); pl.o_fobs = take(pl.small_groups ? (size_t)pl.nfree_obs * 4 + 4 : 8); pl.o_grp = take((size_t)ngrp * 16 + 16); pl.o_fgrp = take((size_t)(P + 1) * 4);      // (pfs / fobs: k_ba_window's lists, batches only)
     pl.o_pairs = take(npairs * 8 + 8); pl.o_bs = take((size_t)(nblk + 1) * 4); pl.o_bpq = take((size_t)nblk * 8 + 8);
     pl.up_bytes = off; off = 0;
     pl.o_st = take(sizeof(LMState)); pl.o_cf = take(64); pl.o_outl = take((size_t)O + 1);
@@ -3047,7 +3047,7 @@ static int ba_emit(BAPlan &pl, char *Aup, char *Azero, char *Awork, char *stage)
     UP(pl.o_const, pl.theta_const, (size_t)P); UP(pl.o_start, pl.start.data(), (size_t)(M + 1) * 4);
     if (pl.filled) { UP(pl.o_pix, pl.v_pix.data(), (size_t)2 * O * 8); UP(pl.o_opose, pl.v_opose.data(), (size_t)O * 4); UP(pl.o_opoint, pl.v_opoint.data(), (size_t)O * 4); UP(pl.o_opk, pl.v_opk.data(), (size_t)O * 4); }
     else {                                                   // (grouped: nothing on the host needs these arrays) written in place
-        pl.fill_obs((int *)(stage + pl.o_opose), (int *)(stage + pl.o_opoint), (int *)(stage + pl.o_opk), (double *)(stage + pl.o_pix), pl.window ? nullptr : (int *)(stage + pl.o_ohp), (int *)(stage + pl.o_pfs), (int *)(stage + pl.o_fobs));
+        pl.fill_obs((int *)(stage + pl.o_opose), (int *)(stage + pl.o_opoint), (int *)(stage + pl.o_opk), (double *)(stage + pl.o_pix), pl.window ? nullptr : (int *)(stage + pl.o_ohp), pl.small_groups ? (int *)(stage + pl.o_pfs) : nullptr, pl.small_groups ? (int *)(stage + pl.o_fobs) : nullptr);
         if (pl.twice_pt >= 0) return pl.fail(SLAM_ERR_ARG, "slam_ba: map point %lld is observed twice by pose %lld", pl.twice_pt + 1, pl.twice_pose + 1);
     }
     UP(pl.o_pairs, pl.pairs.data(), pl.npairs * 8); UP(pl.o_bs, pl.blk_start.data(), (size_t)(pl.nblk + 1) * 4); UP(pl.o_bpq, pl.blk_pq.data(), (size_t)pl.nblk * 8);

@@ -92,3 +92,22 @@ def test_batch_reports_a_bad_window_and_solves_the_others(slam, syn):
     ref = _cache(slam, good); slam.bundle_adjustment_(ref, good["cam"])
     assert np.abs(caches[0].theta - ref.theta).max() <= 1e-9 and np.array_equal(caches[2].theta, caches[0].theta)
     assert np.array_equal(caches[1].theta, bad["theta0"])                                          # untouched
+
+
+def test_batch_calls_from_two_threads_at_once(slam, syn):
+    """two estimator threads, each with its own context, call slam_local_ba_batch concurrently (the host half shares one worker pool):
+    both get what a serial call gives"""
+    import threading
+    sc = [syn.ba_scene(P=25, M=400, seed=200 + z, n_const=20) for z in range(6)] + [syn.ba_scene(P=10, M=300, seed=210)]
+    ref = slam.BABatch([_cache(slam, s) for s in sc], sc[0]["cam"]); ref.solve()
+    out = {}
+    def run(tag):
+        ctx = slam.Context(0)
+        for _ in range(5):
+            b = slam.BABatch([_cache(slam, s) for s in sc], sc[0]["cam"]); b.solve(ctx=ctx)
+        out[tag] = b; ctx.close()
+    th = [threading.Thread(target=run, args=(t,)) for t in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for t in range(2):
+        assert not out[t].status.any()
+        assert np.array_equal(out[t].theta, ref.theta) and np.array_equal(out[t].outl, ref.outl), t
