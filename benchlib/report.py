@@ -77,7 +77,10 @@ def compact_line(out):
     if cb:
         c["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:120]}
         if out.get("value"):
-            c["cpu_baseline"]["gpu_over_cpu"] = _r(out["value"] / cb["value"])
+            c["cpu_baseline"]["gpu_over_cpu"] = _r(out["value"] / cb["value"])      # 128 lock-stepped streams vs ONE CPU stream
+        live = (out.get("single_stream") or {}).get("by_builds_in_flight", {}).get("1")
+        if live:
+            c["cpu_baseline"]["gpu_over_cpu_one_live_stream"] = _r(live / cb["value"])      # like for like: one stream, next frame only
     ba = out.get("ba")
     if ba:
         c["ba"] = {"ms_per_iter": _r(ba.get("ms_per_iter")), "window_kf": 50, "observations": ba.get("observations"),

@@ -2366,34 +2366,51 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
             stage_poses(pb);
             __syncthreads();
             BW_CLK(1);
-            // ---- A1: thread = observation
-            for (int i = tid; i < O; i += BW_T) {
-                const int p = d.opose[i], j = d.opoint[i];
-                const bool active = !(ignore && d.outl[i]);
-                const bool hp = active && !s_const[p];
-                double r[2] = {0.0, 0.0}, Jp[12], Jl[6] = {0, 0, 0, 0, 0, 0};
-                if (active) {
-                    const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
-                    obs_eval_sc(s_sc + 6 * p, s_tr + 3 * p, X, d.pix[i], d.pix[O + i], d.cam, r, hp ? Jp : nullptr, Jl, nullptr);
+            // ---- A1: thread = observation, two per trip: the loads of both are requested before either is evaluated (two waves per SIMD
+            //      hide little; a wave waited 66 % of its cycles with one observation per trip)
+            for (int i0 = tid; i0 < O; i0 += 2 * BW_T) {
+                const int i1 = i0 + BW_T;
+                const bool two = i1 < O;
+                const int ib = two ? i1 : i0;
+                const int pA = d.opose[i0], jA = d.opoint[i0], pB = d.opose[ib], jB = d.opoint[ib];
+                const bool actA = !(ignore && d.outl[i0]), actB = two && !(ignore && d.outl[ib]);
+                const double pyA = d.pix[i0], pxA = d.pix[O + i0], pyB = d.pix[ib], pxB = d.pix[O + ib];
+                const double XA[3] = {pb.pts[3 * jA], pb.pts[3 * jA + 1], pb.pts[3 * jA + 2]};
+                const double XB[3] = {pb.pts[3 * jB], pb.pts[3 * jB + 1], pb.pts[3 * jB + 2]};
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (u == 1 && !two) break;
+                    const int i = u ? i1 : i0, p = u ? pB : pA;
+                    const bool active = u ? actB : actA;
+                    const bool hp = active && !s_const[p];
+                    double r[2] = {0.0, 0.0}, Jp[12], Jl[6] = {0, 0, 0, 0, 0, 0};
+                    if (active) obs_eval_sc(s_sc + 6 * p, s_tr + 3 * p, u ? XB : XA, u ? pyB : pyA, u ? pxB : pxA, d.cam, r, hp ? Jp : nullptr, Jl, nullptr);
+                    d.hasp[i] = hp ? 1 : 0;
+                    st_rec<2>(d.f + 2 * (size_t)i, r);
+                    st_rec<6>(d.Jl + (size_t)i * 6, Jl);
+                    if (hp) st_rec<12>(d.Jp + (size_t)i * 12, Jp);
                 }
-                d.hasp[i] = hp ? 1 : 0;
-                st_rec<2>(d.f + 2 * (size_t)i, r);
-                st_rec<6>(d.Jl + (size_t)i * 6, Jl);
-                if (hp) st_rec<12>(d.Jp + (size_t)i * 12, Jp);
             }
             __syncthreads();
+            BW_CLK(8);
             // ---- A2: thread = map point (sorted order k): V, V^-1, bl from the stored Jl / f of its observations
             for (int k = tid; k < M; k += BW_T) {
                 const int j = d.pt_id[k];
                 double V[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
                 const int t0 = d.pt_start[k], t1 = d.pt_start[k + 1];
-                for (int i = t0; i < t1; i++) {
-                    double Jl[6], r[2];
-                    ld_rec<6>(d.Jl + (size_t)i * 6, Jl); ld_rec<2>(d.f + 2 * (size_t)i, r);
-                    V[0] += Jl[0] * Jl[0] + Jl[3] * Jl[3]; V[1] += Jl[0] * Jl[1] + Jl[3] * Jl[4]; V[2] += Jl[0] * Jl[2] + Jl[3] * Jl[5];
-                    V[3] += Jl[1] * Jl[1] + Jl[4] * Jl[4]; V[4] += Jl[1] * Jl[2] + Jl[4] * Jl[5]; V[5] += Jl[2] * Jl[2] + Jl[5] * Jl[5];
+                for (int ib = t0; ib < t1; ib += 4) {                    // four observations' records requested together, summed in order
+                    double Jq[4][6], rq[4][2];
 #pragma unroll
-                    for (int c = 0; c < 3; c++) bl[c] += Jl[c] * r[0] + Jl[3 + c] * r[1];
+                    for (int u = 0; u < 4; u++) { const int i = min(ib + u, t1 - 1); ld_rec<6>(d.Jl + (size_t)i * 6, Jq[u]); ld_rec<2>(d.f + 2 * (size_t)i, rq[u]); }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (ib + u >= t1) break;
+                        const double *Jl = Jq[u], *r = rq[u];
+                        V[0] += Jl[0] * Jl[0] + Jl[3] * Jl[3]; V[1] += Jl[0] * Jl[1] + Jl[3] * Jl[4]; V[2] += Jl[0] * Jl[2] + Jl[3] * Jl[5];
+                        V[3] += Jl[1] * Jl[1] + Jl[4] * Jl[4]; V[4] += Jl[1] * Jl[2] + Jl[4] * Jl[5]; V[5] += Jl[2] * Jl[2] + Jl[5] * Jl[5];
+#pragma unroll
+                        for (int c = 0; c < 3; c++) bl[c] += Jl[c] * r[0] + Jl[3 + c] * r[1];
+                    }
                 }
                 V[0] += fmin(fmax(V[0], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
                 V[3] += fmin(fmax(V[3], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
@@ -2665,8 +2682,8 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
             __syncthreads();
 #ifdef BW_TRACE
             if (tid == 0 && blockIdx.x == 5 && pass == 0 && it == 3) { bw_clk[7] = clock64();
-                printf("k_ba_window (M %d, O %d, F %d, %d free-pose observations): sincos %lld | A %lld | B chunks %lld | fold %lld | solve %lld | C %lld | reduce + decide %lld cycles\n", M, O, F, NF,
-                       bw_clk[1] - bw_clk[0], bw_clk[2] - bw_clk[1], bw_clk[3] - bw_clk[2], bw_clk[4] - bw_clk[3], bw_clk[5] - bw_clk[4], bw_clk[6] - bw_clk[5], bw_clk[7] - bw_clk[6]); }
+                printf("k_ba_window (M %d, O %d, F %d, %d free-pose observations): sincos %lld | A1 %lld A2 %lld | B chunks %lld | fold %lld | solve %lld | C %lld | reduce + decide %lld cycles\n", M, O, F, NF,
+                       bw_clk[1] - bw_clk[0], bw_clk[8] - bw_clk[1], bw_clk[2] - bw_clk[8], bw_clk[3] - bw_clk[2], bw_clk[4] - bw_clk[3], bw_clk[5] - bw_clk[4], bw_clk[6] - bw_clk[5], bw_clk[7] - bw_clk[6]); }
 #endif
         }
         if (tid == 0) { if (pass == 0) { s->ssr_pass1 = s->ssr; s->iters_pass1 = s->iters; } else { s->ssr_final = s->ssr; s->iters_pass2 = s->iters; } }
