@@ -2255,6 +2255,7 @@ __global__ __launch_bounds__(256) void k_results_b(const BAWin *tab, const BARes
 #define BW_OMAX 40000
 #define BW_HC 336                   // free-pose observation records (W 18, Jp 12, gradient 6 doubles) per chunk
 #define BW_PC 256                   // points per chunk
+#define BW_WOB 168                  // phase A: observations per wave and trip (BW_WOB x 9 doubles x 8 waves = the record region)
 #define BW_FIXED_DBL(P) ((size_t)15 * (P) + 31 * 30 + 32 + 32 + 32 + 2 + (size_t)BW_PC * 10)
 static size_t bw_lds_bytes(int P)
 {
@@ -2322,6 +2323,8 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
     const bool live = w2 < nwin, xl = wl < n;
     const int a2 = xl ? wl / 6 : 0, r2 = wl - 6 * (wl / 6);
     for (int p = tid; p < P; p += BW_T) s_const[p] = d.pconst[p];
+    // phase A's chunks: npc consecutive map points (sorted order) per wave and trip, at most BW_WOB observations (d.sg_ob = most observations of one point)
+    const int npc_a = max(1, min(64, BW_WOB / d.sg_ob));
 #ifdef BW_TRACE
     long long bw_clk[12];
 #endif
@@ -2366,61 +2369,57 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
             stage_poses(pb);
             __syncthreads();
             BW_CLK(1);
-            // ---- A1: thread = observation, two per trip: the loads of both are requested before either is evaluated (two waves per SIMD
-            //      hide little; a wave waited 66 % of its cycles with one observation per trip)
-            for (int i0 = tid; i0 < O; i0 += 2 * BW_T) {
-                const int i1 = i0 + BW_T;
-                const bool two = i1 < O;
-                const int ib = two ? i1 : i0;
-                const int pA = d.opose[i0], jA = d.opoint[i0], pB = d.opose[ib], jB = d.opoint[ib];
-                const bool actA = !(ignore && d.outl[i0]), actB = two && !(ignore && d.outl[ib]);
-                const double pyA = d.pix[i0], pxA = d.pix[O + i0], pyB = d.pix[ib], pxB = d.pix[O + ib];
-                const double XA[3] = {pb.pts[3 * jA], pb.pts[3 * jA + 1], pb.pts[3 * jA + 2]};
-                const double XB[3] = {pb.pts[3 * jB], pb.pts[3 * jB + 1], pb.pts[3 * jB + 2]};
+            // ---- A: every WAVE takes chunks of npc_a consecutive map points (their observations are contiguous: coalesced loads, lane = observation):
+            //      residual + Jacobians (stored for the later phases), the nine products Jl'Jl / Jl'f into the wave's own LDS block; then lane = map
+            //      point of the chunk: V = sum + D, V^-1, bl in the observations' order.  Wave-synchronous -- no workgroup barrier inside the phase,
+            //      the eight waves overlap each other's latencies.  (Versions before: thread = point summing from the stored records -- 64 cache
+            //      lines per load instruction, 127 k cycles; workgroup-wide tiles with two barriers each -- 171 k.)  V^-1 / bl / dl: SORTED point order.
+            {
+                const int wvA = tid >> 6, ln = tid & 63;
+                double *s_w9 = s_W + (size_t)wvA * BW_WOB * 9;
+                for (int k0 = wvA * npc_a; k0 < M; k0 += (BW_T / 64) * npc_a) {
+                    const int k1 = min(M, k0 + npc_a), o0 = d.pt_start[k0], nobs = d.pt_start[k1] - o0;
+                    for (int t = ln; t < nobs; t += 64) {
+                        const int i = o0 + t;
+                        const int p = d.opose[i], j = d.opoint[i];
+                        const bool active = !(ignore && d.outl[i]);
+                        const bool hp = active && !s_const[p];
+                        double r[2] = {0.0, 0.0}, Jp[12], Jl[6] = {0, 0, 0, 0, 0, 0};
+                        if (active) {
+                            const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
+                            obs_eval_sc(s_sc + 6 * p, s_tr + 3 * p, X, d.pix[i], d.pix[O + i], d.cam, r, hp ? Jp : nullptr, Jl, nullptr);
+                        }
+                        d.hasp[i] = hp ? 1 : 0;
+                        st_rec<2>(d.f + 2 * (size_t)i, r);
+                        st_rec<6>(d.Jl + (size_t)i * 6, Jl);
+                        if (hp) st_rec<12>(d.Jp + (size_t)i * 12, Jp);
+                        double *v = s_w9 + t * 9;
+                        v[0] = Jl[0] * Jl[0] + Jl[3] * Jl[3]; v[1] = Jl[0] * Jl[1] + Jl[3] * Jl[4]; v[2] = Jl[0] * Jl[2] + Jl[3] * Jl[5];
+                        v[3] = Jl[1] * Jl[1] + Jl[4] * Jl[4]; v[4] = Jl[1] * Jl[2] + Jl[4] * Jl[5]; v[5] = Jl[2] * Jl[2] + Jl[5] * Jl[5];
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    if (u == 1 && !two) break;
-                    const int i = u ? i1 : i0, p = u ? pB : pA;
-                    const bool active = u ? actB : actA;
-                    const bool hp = active && !s_const[p];
-                    double r[2] = {0.0, 0.0}, Jp[12], Jl[6] = {0, 0, 0, 0, 0, 0};
-                    if (active) obs_eval_sc(s_sc + 6 * p, s_tr + 3 * p, u ? XB : XA, u ? pyB : pyA, u ? pxB : pxA, d.cam, r, hp ? Jp : nullptr, Jl, nullptr);
-                    d.hasp[i] = hp ? 1 : 0;
-                    st_rec<2>(d.f + 2 * (size_t)i, r);
-                    st_rec<6>(d.Jl + (size_t)i * 6, Jl);
-                    if (hp) st_rec<12>(d.Jp + (size_t)i * 12, Jp);
-                }
-            }
-            __syncthreads();
-            BW_CLK(8);
-            // ---- A2: thread = map point (sorted order k): V, V^-1, bl from the stored Jl / f of its observations
-            for (int k = tid; k < M; k += BW_T) {
-                const int j = d.pt_id[k];
-                double V[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-                const int t0 = d.pt_start[k], t1 = d.pt_start[k + 1];
-                for (int ib = t0; ib < t1; ib += 4) {                    // four observations' records requested together, summed in order
-                    double Jq[4][6], rq[4][2];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { const int i = min(ib + u, t1 - 1); ld_rec<6>(d.Jl + (size_t)i * 6, Jq[u]); ld_rec<2>(d.f + 2 * (size_t)i, rq[u]); }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (ib + u >= t1) break;
-                        const double *Jl = Jq[u], *r = rq[u];
-                        V[0] += Jl[0] * Jl[0] + Jl[3] * Jl[3]; V[1] += Jl[0] * Jl[1] + Jl[3] * Jl[4]; V[2] += Jl[0] * Jl[2] + Jl[3] * Jl[5];
-                        V[3] += Jl[1] * Jl[1] + Jl[4] * Jl[4]; V[4] += Jl[1] * Jl[2] + Jl[4] * Jl[5]; V[5] += Jl[2] * Jl[2] + Jl[5] * Jl[5];
-#pragma unroll
-                        for (int c = 0; c < 3; c++) bl[c] += Jl[c] * r[0] + Jl[3 + c] * r[1];
+                        for (int c = 0; c < 3; c++) v[6 + c] = Jl[c] * r[0] + Jl[3 + c] * r[1];
                     }
+                    bw_wave_sync();
+                    if (ln < k1 - k0) {
+                        const int k = k0 + ln;
+                        double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        const int t0 = d.pt_start[k] - o0, t1 = d.pt_start[k + 1] - o0;
+                        for (int t = t0; t < t1; t++) {
+#pragma unroll
+                            for (int c = 0; c < 9; c++) V[c] += s_w9[t * 9 + c];
+                        }
+                        V[0] += fmin(fmax(V[0], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+                        V[3] += fmin(fmax(V[3], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+                        V[5] += fmin(fmax(V[5], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+                        double Vi[6];
+                        inv3_sym(V, Vi);
+#pragma unroll
+                        for (int c = 0; c < 6; c++) d.Vinv[(size_t)c * M + k] = Vi[c];
+#pragma unroll
+                        for (int c = 0; c < 3; c++) d.bl[(size_t)c * M + k] = V[6 + c];
+                    }
+                    bw_wave_sync();
                 }
-                V[0] += fmin(fmax(V[0], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
-                V[3] += fmin(fmax(V[3], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
-                V[5] += fmin(fmax(V[5], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
-                double Vi[6];
-                inv3_sym(V, Vi);
-#pragma unroll
-                for (int c = 0; c < 6; c++) d.Vinv[(size_t)c * M + j] = Vi[c];
-#pragma unroll
-                for (int c = 0; c < 3; c++) d.bl[(size_t)c * M + j] = bl[c];
             }
             __syncthreads();
             BW_CLK(2);
@@ -2438,11 +2437,11 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
                 const int k1 = lo, npc = k1 - k0, nrec = d.pfs[k1] - base;
                 if (nrec == 0) { k0 = k1; continue; }                    // no point of the chunk sees a free pose
                 for (int x = tid; x < npc; x += BW_T) {
-                    const int j = d.pt_id[k0 + x];
+                    const int kk = k0 + x;
 #pragma unroll
-                    for (int c = 0; c < 6; c++) s_pt[x * 10 + c] = d.Vinv[(size_t)c * M + j];
+                    for (int c = 0; c < 6; c++) s_pt[x * 10 + c] = d.Vinv[(size_t)c * M + kk];
 #pragma unroll
-                    for (int c = 0; c < 3; c++) s_pt[x * 10 + 6 + c] = d.bl[(size_t)c * M + j];
+                    for (int c = 0; c < 3; c++) s_pt[x * 10 + 6 + c] = d.bl[(size_t)c * M + kk];
 #pragma unroll
                     for (int a = 0; a < BW_FMAX; a++) s_slot[x * BW_FMAX + a] = -1;
                 }
@@ -2625,7 +2624,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
             }
             for (int k = tid; k < M; k += BW_T) {
                 const int j = d.pt_id[k];
-                double bl[3] = {d.bl[j], d.bl[(size_t)M + j], d.bl[(size_t)2 * M + j]};
+                double bl[3] = {d.bl[k], d.bl[(size_t)M + k], d.bl[(size_t)2 * M + k]};
                 for (int rec = d.pfs[k]; rec < d.pfs[k + 1]; rec++) {      // the point's observations of free poses (host list): bl -= Jl' (Jp dp)
                     const int i = d.fobs[rec];
                     if (!d.hasp[i]) continue;
@@ -2640,11 +2639,11 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
                 }
                 double Vi[6];
 #pragma unroll
-                for (int c = 0; c < 6; c++) Vi[c] = d.Vinv[(size_t)c * M + j];
+                for (int c = 0; c < 6; c++) Vi[c] = d.Vinv[(size_t)c * M + k];
                 const double l0 = Vi[0] * bl[0] + Vi[1] * bl[1] + Vi[2] * bl[2];
                 const double l1 = Vi[1] * bl[0] + Vi[3] * bl[1] + Vi[4] * bl[2];
                 const double l2 = Vi[2] * bl[0] + Vi[4] * bl[1] + Vi[5] * bl[2];
-                d.dl[3 * j] = l0; d.dl[3 * j + 1] = l1; d.dl[3 * j + 2] = l2;
+                d.dl[3 * k] = l0; d.dl[3 * k + 1] = l1; d.dl[3 * k + 2] = l2;
                 pb.pts_t[3 * j] = pb.pts[3 * j] - l0; pb.pts_t[3 * j + 1] = pb.pts[3 * j + 1] - l1; pb.pts_t[3 * j + 2] = pb.pts[3 * j + 2] - l2;
                 mx = fmax(mx, fmax(fabs(l0), fmax(fabs(l1), fabs(l2))));
             }
@@ -2656,7 +2655,8 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
                 const bool active = !(ignore && d.outl[i]);
                 double jl[6], ff[2], r[2] = {0.0, 0.0}, pa = 0.0, pbv = 0.0;
                 ld_rec<6>(d.Jl + (size_t)i * 6, jl); ld_rec<2>(d.f + 2 * (size_t)i, ff);
-                const double l0 = d.dl[3 * j], l1 = d.dl[3 * j + 1], l2 = d.dl[3 * j + 2];
+                const int ks = d.opk[i];
+                const double l0 = d.dl[3 * ks], l1 = d.dl[3 * ks + 1], l2 = d.dl[3 * ks + 2];
                 const bool fr = !s_const[p];
                 const int a = p - p0;
                 if (d.hasp[i]) {
@@ -2682,8 +2682,8 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
             __syncthreads();
 #ifdef BW_TRACE
             if (tid == 0 && blockIdx.x == 5 && pass == 0 && it == 3) { bw_clk[7] = clock64();
-                printf("k_ba_window (M %d, O %d, F %d, %d free-pose observations): sincos %lld | A1 %lld A2 %lld | B chunks %lld | fold %lld | solve %lld | C %lld | reduce + decide %lld cycles\n", M, O, F, NF,
-                       bw_clk[1] - bw_clk[0], bw_clk[8] - bw_clk[1], bw_clk[2] - bw_clk[8], bw_clk[3] - bw_clk[2], bw_clk[4] - bw_clk[3], bw_clk[5] - bw_clk[4], bw_clk[6] - bw_clk[5], bw_clk[7] - bw_clk[6]); }
+                printf("k_ba_window (M %d, O %d, F %d, %d free-pose observations): sincos %lld | A %lld | B chunks %lld | fold %lld | solve %lld | C %lld | reduce + decide %lld cycles\n", M, O, F, NF,
+                       bw_clk[1] - bw_clk[0], bw_clk[2] - bw_clk[1], bw_clk[3] - bw_clk[2], bw_clk[4] - bw_clk[3], bw_clk[5] - bw_clk[4], bw_clk[6] - bw_clk[5], bw_clk[7] - bw_clk[6]); }
 #endif
         }
         if (tid == 0) { if (pass == 0) { s->ssr_pass1 = s->ssr; s->iters_pass1 = s->iters; } else { s->ssr_final = s->ssr; s->iters_pass2 = s->iters; } }
@@ -2917,7 +2917,9 @@ static int ba_plan(BAPlan &pl)
     {   // a window one workgroup can keep to itself (k_ba_window, batches only): the point groups of the launch-per-phase kernels are not built
         static const bool no_bw = getenv("SLAMHIP_NO_BA_WINDOW") != nullptr;
         int nfree = 0; for (int p = 0; p < P; p++) nfree += theta_const[p] ? 0 : 1;
-        pl.window = pl.small_groups && !no_bw && grouped && nfree >= 1 && nfree <= 5 && nfree == ba->pspan && P <= 128 && O <= 40000;
+        int cmax = 0; for (int j = 0; j < M; j++) cmax = std::max(cmax, cnt[j]);
+        pl.window = pl.small_groups && !no_bw && grouped && nfree >= 1 && nfree <= 5 && nfree == ba->pspan && P <= 128 && O <= 40000 && cmax <= 168;
+        if (pl.window) pl.sg_ob = std::max(cmax, 1);               // k_ba_window's tiles are sized from it (no point groups are built for such a window)
     }
     std::vector<int4> &grp = pl.grp; std::vector<int> &fgrp = pl.fgrp;
     fgrp.assign(P + 1, 0);
@@ -2953,7 +2955,7 @@ static int ba_plan(BAPlan &pl)
         fgrp[P] = (int)grp.size();
     }
     ba->grouped = grouped;
-    if (grouped && pl.small_groups) { pl.sg_ob = std::max(64, (max_no + 7) & ~7); pl.sg_sb = std::max(8, (max_np + 1) & ~1); }
+    if (grouped && pl.small_groups && !pl.window) { pl.sg_ob = std::max(64, (max_no + 7) & ~7); pl.sg_sb = std::max(8, (max_np + 1) & ~1); }
     const int *opose = nullptr;                              // sorted observation -> pose, host copy (needed by the pair lists)
     if (!grouped) {
         pl.v_opose.resize(O); pl.v_opoint.resize(O); pl.v_opk.resize(O); pl.v_pix.resize(2 * (size_t)O);
