@@ -1093,6 +1093,13 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
             get_tile(stage, 0, u);
             if (!CFX(0)) io.tile_store(rb, u, lo, hi, !(lo <= rb && hi >= rb + 15));
             if (two && hi >= rb + 16) { get_tile(stage, 1, u); if (!CFX(0)) io.tile_store(rb + 16, u, lo, hi, !(lo <= rb + 16 && hi >= rb + 31)); }
+#ifdef CF4_ROWFWD_EXP      /* cost experiment (DESIGN 3.2 d): the dim-2 forward recurrence of the block's 32 rows over the strip's 62 columns, lanes = rows */
+            if (lane < 32) {
+                double g1 = x[0], g2 = x[1], g3 = x[2];
+                for (int c = 1; c <= CF4_COLS; c++) { const double xv = stage[c * CF4_GS + lane]; const double t = ((xv + a1 * g1) + a2 * g2) + a3 * g3; g3 = g2; g2 = g1; g1 = t; }
+                if (g1 == 1.2345e300) ck[lineid] = g1;               // (keeps the chain alive)
+            }
+#endif
             __builtin_amdgcn_wave_barrier();
         }
     }
