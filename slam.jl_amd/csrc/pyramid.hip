@@ -717,7 +717,26 @@ __device__ __forceinline__ double wave_next(double v)
 
 // x[0..N) holds the lane's layer samples of rows rb .. rb+N-1 on entry, the recurrence inputs of its role on exit
 // (ROLE 1: Iy^2, 2: Ix^2, 3: Iy Ix); g receives Iy (ROLE 1) / Ix (ROLE 2).  top / bot: the layer at rows rb-1 / rb+N.
-template <int ROLE, int N>
+// one step of the third-order recurrence: the reference's operation order, or (tolerance build, mode 3) three fused multiply-adds whose
+// dependent chain is the single operation that takes the newest state
+template <bool TOL>
+__device__ __forceinline__ double iir3(double x, double a1, double w1, double a2, double w2, double a3, double w3)
+{
+    if (TOL) return __builtin_fma(a1, w1, __builtin_fma(a2, w2, __builtin_fma(a3, w3, x)));
+    return ((x + a1 * w1) + a2 * w2) + a3 * w3;
+}
+// the two factors of the separable Scharr pair along one line: derivative (-1, 0, 1) / 2 and smoothing (3, 10, 3) / 16 of (a, b, c).
+// Bit-exact build: imfilter's accumulation from 0.0, term by term; tolerance build: the same sums in 2 + 3 operations
+template <bool TOL>
+__device__ __forceinline__ void scharr_pair(double a, double b, double c, double &d, double &s)
+{
+    const double dk[3] = {-1.0 / 2, 0.0 / 2, 1.0 / 2}, sk[3] = {3.0 / 16, 10.0 / 16, 3.0 / 16};
+    if (TOL) { d = 0.5 * (c - a); s = __builtin_fma(sk[0], a + c, sk[1] * b); return; }
+    double dd = 0.0; dd += a * dk[0]; dd += b * dk[1]; dd += c * dk[2];
+    double ss = 0.0; ss += a * sk[0]; ss += b * sk[1]; ss += c * sk[2];
+    d = dd; s = ss;
+}
+template <int ROLE, int N, bool TOL = false>
 __device__ __forceinline__ void cf4_inputs(double *x, double top, double bot, int rb, int H, bool edgeL, bool edgeR, double *g)
 {
     const double dk[3] = {-1.0 / 2, 0.0 / 2, 1.0 / 2}, sk[3] = {3.0 / 16, 10.0 / 16, 3.0 / 16};
@@ -730,17 +749,19 @@ __device__ __forceinline__ void cf4_inputs(double *x, double top, double bot, in
         const double aa = row == 0 ? b : a;                       // replicate border (scharr_col, border 0)
         c = row == H - 1 ? b : c;
         double iy = 0.0, ix = 0.0;
+        double d, s;
+        scharr_pair<TOL>(aa, b, c, d, s);
         if (ROLE == 1 || ROLE == 3) {
-            double d = 0.0; d += aa * dk[0]; d += b * dk[1]; d += c * dk[2];
             double dl = wave_prev(d), dr = wave_next(d);
             dl = edgeL ? d : dl; dr = edgeR ? d : dr;
-            iy += dl * sk[0]; iy += d * sk[1]; iy += dr * sk[2];
+            if (TOL) iy = __builtin_fma(sk[0], dl + dr, sk[1] * d);
+            else { iy += dl * sk[0]; iy += d * sk[1]; iy += dr * sk[2]; }
         }
         if (ROLE == 2 || ROLE == 3) {
-            double s = 0.0; s += aa * sk[0]; s += b * sk[1]; s += c * sk[2];
             double sl = wave_prev(s), sr = wave_next(s);
             sl = edgeL ? s : sl; sr = edgeR ? s : sr;
-            ix += sl * dk[0]; ix += s * dk[1]; ix += sr * dk[2];
+            if (TOL) ix = 0.5 * (sr - sl);
+            else { ix += sl * dk[0]; ix += s * dk[1]; ix += sr * dk[2]; }
         }
         double prod;
         if (ROLE == 1) { prod = iy * iy; g[e] = iy; }
@@ -779,6 +800,7 @@ __device__ int cf4_exp;
 #define CF4_LDS_DOUBLES (64 * CF4_LS + 3 * 64 * CF4_GS + 3 * 64)      // + the blur wave's three trailing rows (tolerance build, halved layer)
 
 // phase 2: wave w forms Iy, Ix of rows rb + 8w .. rb + 8w + 7 for the 64 columns (lane = column) from the shared layer block
+template <bool TOL>
 __device__ __forceinline__ void cf4_scharr8(const double *LB, double *IYB, double *IXB, int w, int rb, int H, bool edgeL, bool edgeR)
 {
     const double dk[3] = {-1.0 / 2, 0.0 / 2, 1.0 / 2}, sk[3] = {3.0 / 16, 10.0 / 16, 3.0 / 16};
@@ -794,13 +816,16 @@ __device__ __forceinline__ void cf4_scharr8(const double *LB, double *IYB, doubl
         const double b = v[2 + e];
         const double a = row == 0 ? b : v[1 + e];                 // replicate border (scharr_col, border 0)
         const double c = row == H - 1 ? b : v[3 + e];
-        double d = 0.0; d += a * dk[0]; d += b * dk[1]; d += c * dk[2];
-        double s = 0.0; s += a * sk[0]; s += b * sk[1]; s += c * sk[2];
+        double d, s;
+        scharr_pair<TOL>(a, b, c, d, s);
         double dl = wave_prev(d), dr = wave_next(d), sl = wave_prev(s), sr = wave_next(s);
         dl = edgeL ? d : dl; dr = edgeR ? d : dr; sl = edgeL ? s : sl; sr = edgeR ? s : sr;
         double iy = 0.0, ix = 0.0;
-        iy += dl * sk[0]; iy += d * sk[1]; iy += dr * sk[2];
-        ix += sl * dk[0]; ix += s * dk[1]; ix += sr * dk[2];
+        if (TOL) { iy = __builtin_fma(sk[0], dl + dr, sk[1] * d); ix = 0.5 * (sr - sl); }
+        else {
+            iy += dl * sk[0]; iy += d * sk[1]; iy += dr * sk[2];
+            ix += sl * dk[0]; ix += s * dk[1]; ix += sr * dk[2];
+        }
         asm volatile("" : "+v"(iy), "+v"(ix));                    // finish the row here (keeps the shuffle results from piling up in registers)
         iy8[e] = iy; ix8[e] = ix;
     }
@@ -893,15 +918,15 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     auto brow_at = [&](int y) { return y <= 3 ? (y == 0 ? brow[0] : y == 1 ? brow[1] : y == 2 ? brow[2] : brow[3]) : (y == n - 2 ? brow[4] : brow[5]); };
     auto in_row = [&](int y) {
         double v[1] = {brow_at(y)};
-        if (ROLE != 0) { double gdummy[1]; cf4_inputs<ROLE, 1>(v, brow_at(y > 0 ? y - 1 : 0), brow_at(y + 1 < H ? y + 1 : H - 1), y, H, edgeL, edgeR, gdummy); }
+        if (ROLE != 0) { double gdummy[1]; cf4_inputs<ROLE, 1, TOL>(v, brow_at(y > 0 ? y - 1 : 0), brow_at(y + 1 < H ? y + 1 : H - 1), y, H, edgeL, edgeR, gdummy); }
         return v[0];
     };
     const double x0 = in_row(0);
     const double iminus = x0, iplus = in_row(n - 1);
     const double uminus = iminus / k.inv1masum;
-    const double o0 = ((x0 + a1 * uminus) + a2 * uminus) + a3 * uminus;
-    const double o1 = ((in_row(1) + a1 * o0) + a2 * uminus) + a3 * uminus;
-    const double o2 = ((in_row(2) + a1 * o1) + a2 * o0) + a3 * uminus;
+    const double o0 = iir3<TOL>(x0, a1, uminus, a2, uminus, a3, uminus);
+    const double o1 = iir3<TOL>(in_row(1), a1, o0, a2, uminus, a3, uminus);
+    const double o2 = iir3<TOL>(in_row(2), a1, o1, a2, o0, a3, uminus);
     double w3 = o0, w2 = o1, w1 = o2;
     const int NBk = ((n - 1) >> 5) + 1;                           // 32-row blocks of the plane
     const int ntile = P >> 4;
@@ -965,7 +990,7 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
         publish();
         if (!CFX(5)) lds_barrier();  
         if (b + 1 < NBk) prefetch(b + 1);
-        if (!CFX(2)) cf4_scharr8(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
+        if (!CFX(2)) cf4_scharr8<TOL>(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
         if (!CFX(5)) lds_barrier();  
         if (!active) continue;
         read_inputs();
@@ -973,10 +998,10 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
         if (CFX(1)) { w1 += x[0] + x[31]; }
         else if (rb >= 3 && rb + 31 <= n - 1) {
 #pragma unroll
-            for (int e = 0; e < 32; e++) { const double tt = ((x[e] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; }
+            for (int e = 0; e < 32; e++) { const double tt = iir3<TOL>(x[e], a1, w1, a2, w2, a3, w3); w3 = w2; w2 = w1; w1 = tt; }
         } else {
 #pragma unroll
-            for (int e = 0; e < 32; e++) { const int row = rb + e; if (row >= 3 && row <= n - 1) { const double tt = ((x[e] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; } }
+            for (int e = 0; e < 32; e++) { const int row = rb + e; if (row >= 3 && row <= n - 1) { const double tt = iir3<TOL>(x[e], a1, w1, a2, w2, a3, w3); w3 = w2; w2 = w1; w1 = tt; } }
         }
     }
     // ---- Triggs-Sdika right boundary (as iir_line) ----
@@ -986,8 +1011,8 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     const double vr1 = ((k.M[3] * d0 + k.M[4] * d1) + k.M[5] * d2) + vplus;
     const double vr2 = ((k.M[6] * d0 + k.M[7] * d1) + k.M[8] * d2) + vplus;
     const double vA = vr0;
-    const double vB = ((w2 + a1 * vA) + a2 * vr1) + a3 * vr2;
-    const double vC = ((w3 + a1 * vB) + a2 * vA) + a3 * vr1;
+    const double vB = iir3<TOL>(w2, a1, vA, a2, vr1, a3, vr2);
+    const double vC = iir3<TOL>(w3, a1, vB, a2, vA, a3, vr1);
     double v1 = vC, v2 = vB, v3 = vA;
     io.fence();
     // ---- pass B: blocks bottom to top.  Every block is visited (the gradient planes need all rows); rows [3, n-4] carry the
@@ -1008,14 +1033,14 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     if (active && !SFX && !dec) { io.st(n - 1, vA * scale); io.st(n - 2, vB * scale); io.st(n - 3, vC * scale); }
     double *tailv = QB + 64 * CF4_GS + 3 * lane;                  // (dec) rows n-1, n-2, n-3 wait here for their block: not in registers across the loop
     if (active && dec) { tailv[0] = vA * scale; tailv[1] = vB * scale; tailv[2] = vC * scale; }
-    if (active && SFX) { io.st(n - 1, sfx); sfx = sfx + vA * scale; io.st(n - 2, sfx); sfx = sfx + vB * scale; io.st(n - 3, sfx); sfx = sfx + vC * scale; }
+    if (active && SFX) { io.st(n - 1, sfx); sfx = __builtin_fma(vA, scale, sfx); io.st(n - 2, sfx); sfx = __builtin_fma(vB, scale, sfx); io.st(n - 3, sfx); sfx = __builtin_fma(vC, scale, sfx); }
     for (int b = NBk - 1; b >= 0; b--) {
         const int rb = b << 5, lo = rb > 3 ? rb : 3, hi = rb + 31 < n - 4 ? rb + 31 : n - 4;     // recurrence rows of the block (may be empty: lo > hi)
         const bool two = 2 * b + 1 < ntile;
         if (!CFX(5)) lds_barrier();  
         publish();
         if (!CFX(5)) lds_barrier();  
-        if (!CFX(2)) cf4_scharr8(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
+        if (!CFX(2)) cf4_scharr8<TOL>(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
         if (!CFX(5)) lds_barrier();  
         if (active) read_inputs();
         if (ROLE == 0 && skind) {                                 // fused ingest: the block's layer rows -> the pitched layer plane
@@ -1044,16 +1069,16 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
         else if (lo > hi) {}
         else if (lo == rb && hi == rb + 31) {
 #pragma unroll
-            for (int e = 0; e < 32; e++) { const double tt = ((x[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = tt; x[e] = tt; }
+            for (int e = 0; e < 32; e++) { const double tt = iir3<TOL>(x[e], a1, f1, a2, f2, a3, f3); f3 = f2; f2 = f1; f1 = tt; x[e] = tt; }
 #pragma unroll
-            for (int e = 31; e >= 0; e--) { const double tt = ((x[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt;
-                                            if (SFX) { x[e] = sfx; sfx = sfx + tt * scale; } else x[e] = tt * scale; }
+            for (int e = 31; e >= 0; e--) { const double tt = iir3<TOL>(x[e], a1, v1, a2, v2, a3, v3); v3 = v2; v2 = v1; v1 = tt;
+                                            if (SFX) { x[e] = sfx; sfx = __builtin_fma(tt, scale, sfx); } else x[e] = tt * scale; }
         } else {
 #pragma unroll
-            for (int e = 0; e < 32; e++) { const int row = rb + e; if (row >= lo && row <= hi) { const double tt = ((x[e] + a1 * f1) + a2 * f2) + a3 * f3; f3 = f2; f2 = f1; f1 = tt; x[e] = tt; } }
+            for (int e = 0; e < 32; e++) { const int row = rb + e; if (row >= lo && row <= hi) { const double tt = iir3<TOL>(x[e], a1, f1, a2, f2, a3, f3); f3 = f2; f2 = f1; f1 = tt; x[e] = tt; } }
 #pragma unroll
-            for (int e = 31; e >= 0; e--) { const int row = rb + e; if (row >= lo && row <= hi) { const double tt = ((x[e] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt;
-                                                                                             if (SFX) { x[e] = sfx; sfx = sfx + tt * scale; } else x[e] = tt * scale; } }
+            for (int e = 31; e >= 0; e--) { const int row = rb + e; if (row >= lo && row <= hi) { const double tt = iir3<TOL>(x[e], a1, v1, a2, v2, a3, v3); v3 = v2; v2 = v1; v1 = tt;
+                                                                                             if (SFX) { x[e] = sfx; sfx = __builtin_fma(tt, scale, sfx); } else x[e] = tt * scale; } }
         }
         if (dec) {
             // the block's 32 rows go to the staging block as in the plain path; the three rows below the recurrence and (block 0) the three
@@ -1068,9 +1093,9 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
                 if (n - 3 >= rb) q[n - 3 - rb] = tailv[2];
             }
             if (b == 0) {
-                double tt = ((o2 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; q[2] = tt * scale;
-                tt = ((o1 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; q[1] = tt * scale;
-                tt = ((o0 + a1 * v1) + a2 * v2) + a3 * v3; q[0] = tt * scale;
+                double tt = iir3<TOL>(o2, a1, v1, a2, v2, a3, v3); v3 = v2; v2 = v1; v1 = tt; q[2] = tt * scale;
+                tt = iir3<TOL>(o1, a1, v1, a2, v2, a3, v3); v3 = v2; v2 = v1; v1 = tt; q[1] = tt * scale;
+                tt = iir3<TOL>(o0, a1, v1, a2, v2, a3, v3); q[0] = tt * scale;
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) {                         // in place: pair j writes q[2j], q[2j+1] < the next pair's reads q[4j+4 ..]
@@ -1096,7 +1121,7 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
 #ifdef CF4_ROWFWD_EXP      /* cost experiment (DESIGN 3.2 d): the dim-2 forward recurrence of the block's 32 rows over the strip's 62 columns, lanes = rows */
             if (lane < 32) {
                 double g1 = x[0], g2 = x[1], g3 = x[2];
-                for (int c = 1; c <= CF4_COLS; c++) { const double xv = stage[c * CF4_GS + lane]; const double t = ((xv + a1 * g1) + a2 * g2) + a3 * g3; g3 = g2; g2 = g1; g1 = t; }
+                for (int c = 1; c <= CF4_COLS; c++) { const double xv = stage[c * CF4_GS + lane]; const double t = iir3<TOL>(xv, a1, g1, a2, g2, a3, g3); g3 = g2; g2 = g1; g1 = t; }
                 if (g1 == 1.2345e300) ck[lineid] = g1;               // (keeps the chain alive)
             }
 #endif
@@ -1104,14 +1129,14 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
         }
     }
     if (active && !SFX && !dec) {   // rows 2, 1, 0: forward values o2, o1, o0
-        double tt = ((o2 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(2, tt * scale);
-        tt = ((o1 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(1, tt * scale);
-        tt = ((o0 + a1 * v1) + a2 * v2) + a3 * v3; io.st(0, tt * scale);
+        double tt = iir3<TOL>(o2, a1, v1, a2, v2, a3, v3); v3 = v2; v2 = v1; v1 = tt; io.st(2, tt * scale);
+        tt = iir3<TOL>(o1, a1, v1, a2, v2, a3, v3); v3 = v2; v2 = v1; v1 = tt; io.st(1, tt * scale);
+        tt = iir3<TOL>(o0, a1, v1, a2, v2, a3, v3); io.st(0, tt * scale);
     }
     if (active && SFX) {
-        double tt = ((o2 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(2, sfx); sfx = sfx + tt * scale;
-        tt = ((o1 + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; io.st(1, sfx); sfx = sfx + tt * scale;
-        tt = ((o0 + a1 * v1) + a2 * v2) + a3 * v3; io.st(0, sfx); sfx = sfx + tt * scale;
+        double tt = iir3<TOL>(o2, a1, v1, a2, v2, a3, v3); v3 = v2; v2 = v1; v1 = tt; io.st(2, sfx); sfx = __builtin_fma(tt, scale, sfx);
+        tt = iir3<TOL>(o1, a1, v1, a2, v2, a3, v3); v3 = v2; v2 = v1; v1 = tt; io.st(1, sfx); sfx = __builtin_fma(tt, scale, sfx);
+        tt = iir3<TOL>(o0, a1, v1, a2, v2, a3, v3); io.st(0, sfx); sfx = __builtin_fma(tt, scale, sfx);
         if (io.valid()) A.tot[((size_t)blockIdx.z * 3 + (ROLE - 1)) * A.tot_stride + io.xown()] = sfx;
     }
 }
@@ -1307,46 +1332,53 @@ struct SegPow { double P[2][PAR_G][9]; double Plast[2][9]; };   // M^(SL*q), q =
 
 __device__ __forceinline__ void mv3(const double *P, double &a, double &b, double &c, double za, double zb, double zc)
 {
-    const double n1 = ((P[0] * a + P[1] * b) + P[2] * c) + za;
-    const double n2 = ((P[3] * a + P[4] * b) + P[5] * c) + zb;
-    const double n3 = ((P[6] * a + P[7] * b) + P[8] * c) + zc;
+    const double n1 = __builtin_fma(P[0], a, __builtin_fma(P[1], b, __builtin_fma(P[2], c, za)));      // (mode-3 kernels only: contracted)
+    const double n2 = __builtin_fma(P[3], a, __builtin_fma(P[4], b, __builtin_fma(P[5], c, zb)));
+    const double n3 = __builtin_fma(P[6], a, __builtin_fma(P[7], b, __builtin_fma(P[8], c, zc)));
     a = n1; b = n2; c = n3;
 }
 
 // entry state of segment index `k` (0-based in fold order) of line l: two-level fold.
 // Z: zero-state end states [3][nslots][LPW] indexed by fold order through `slot(k)`.
-template <int LPW, class Slot>
-__device__ __forceinline__ void fold_entry(const SegPow &sp, int cs, double (*Z)[PAR_T / LPW][LPW], double (*GT)[PAR_T / LPW / PAR_G + 1][LPW],
+template <int ZG, int ZL, int GG, int GL, int ZN, int GN, class Slot>
+__device__ __forceinline__ void fold_entry(const SegPow &sp, int cs, double (*Z)[ZN], double (*GT)[GN],
                                            int l, int k, bool has, Slot slot, double s0a, double s0b, double s0c,
                                            double &ea, double &eb, double &ec)
 {
     const int q = k % PAR_G, grp = k / PAR_G;
     const double *P1 = sp.P[cs][0], *P8 = sp.P[cs][PAR_G - 1];
     double a = 0.0, b = 0.0, c = 0.0;
-    if (has) for (int i = 0; i < q; i++) { const int s = slot(grp * PAR_G + i); mv3(P1, a, b, c, Z[0][s][l], Z[1][s][l], Z[2][s][l]); }
+    if (has) for (int i = 0; i < q; i++) { const int s = slot(grp * PAR_G + i); mv3(P1, a, b, c, Z[0][s * ZG + l * ZL], Z[1][s * ZG + l * ZL], Z[2][s * ZG + l * ZL]); }
     if (has && q == PAR_G - 1) {
         double ta = a, tb = b, tc = c; const int s = slot(k);
-        mv3(P1, ta, tb, tc, Z[0][s][l], Z[1][s][l], Z[2][s][l]);
-        GT[0][grp][l] = ta; GT[1][grp][l] = tb; GT[2][grp][l] = tc;
+        mv3(P1, ta, tb, tc, Z[0][s * ZG + l * ZL], Z[1][s * ZG + l * ZL], Z[2][s * ZG + l * ZL]);
+        GT[0][grp * GG + l * GL] = ta; GT[1][grp * GG + l * GL] = tb; GT[2][grp * GG + l * GL] = tc;
     }
     __syncthreads();
     double Sa = s0a, Sb = s0b, Sc = s0c;
     if (has) {
-        for (int h = 0; h < grp; h++) mv3(P8, Sa, Sb, Sc, GT[0][h][l], GT[1][h][l], GT[2][h][l]);
+        for (int h = 0; h < grp; h++) mv3(P8, Sa, Sb, Sc, GT[0][h * GG + l * GL], GT[1][h * GG + l * GL], GT[2][h * GG + l * GL]);
         if (q > 0) mv3(sp.P[cs][q - 1], Sa, Sb, Sc, 0.0, 0.0, 0.0);
     }
     ea = Sa + a; eb = Sb + b; ec = Sc + c;
 }
 
-template <bool COLS>
-__global__ __launch_bounds__(PAR_T) void k_iir_seg(PlaneSet ps, const double *src0, int H, int W, int P, IIRPair cf, SegPow sp, int SL)
+// T threads own LPW lines of T / LPW segment slots each (1024 / 8: up to 128 segments per line; 256 / 8: 32 segments of <= 16 samples, the
+// variant of a single image's columns -- a segment's share of the two folds costs more instructions than its samples, and with four
+// waves per SIMD the kernel is bound by instruction issue, not by the dependent chain)
+template <bool COLS, int T = PAR_T, int LPW = 8>
+__global__ __launch_bounds__(T) void k_iir_seg(PlaneSet ps, const double *src0, int H, int W, int P, IIRPair cf, SegPow sp, int SL, int cum_mask)
 {
     if (src0) src0 += (size_t)blockIdx.z * ps.zs;
-    constexpr int LPW = 8, NSEG = PAR_T / LPW;
-    __shared__ double Z[3][NSEG][LPW];
-    __shared__ double GT[3][NSEG / PAR_G + 1][LPW];
+    constexpr int NSEG = T / LPW, ZN = T + 8, GN = T / PAR_G + 16;
+    // lanes -> (line, segment): along columns consecutive lanes take consecutive segments of ONE column (contiguous memory: a wave reads
+    // 64 x SL consecutive samples); along rows consecutive lanes take the same segment of consecutive rows.  The [segment][line] LDS
+    // arrays are laid out to match (segment-fastest with a pad / line-fastest): conflict-free either way
+    constexpr int ZG = COLS ? 1 : LPW, ZL = COLS ? NSEG + 1 : 1, GG = COLS ? 1 : LPW, GL = COLS ? NSEG / PAR_G + 2 : 1;
+    __shared__ double Z[3][ZN];
+    __shared__ double GT[3][GN];
     __shared__ double Fin[3][LPW];
-    const int t = threadIdx.x, l = t % LPW, g = t / LPW, pl = blockIdx.y;
+    const int t = threadIdx.x, l = COLS ? t / NSEG : t % LPW, g = COLS ? t % NSEG : t / LPW, pl = blockIdx.y;
     const int nlines = COLS ? W : H, n = COLS ? H : W;
     const int line = blockIdx.x * LPW + l;
     const bool valid = line < nlines;
@@ -1371,16 +1403,16 @@ __global__ __launch_bounds__(PAR_T) void k_iir_seg(PlaneSet ps, const double *sr
     {
         double w1 = 0.0, w2 = 0.0, w3 = 0.0;
 #pragma unroll
-        for (int j = 0; j < PAR_SLMAX; j++) if (j < len) { const double tt = ((x[j] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; }
-        if (has) { Z[0][g][l] = w1; Z[1][g][l] = w2; Z[2][g][l] = w3; }
+        for (int j = 0; j < PAR_SLMAX; j++) if (j < len) { const double tt = iir3<true>(x[j], a1, w1, a2, w2, a3, w3); w3 = w2; w2 = w1; w1 = tt; }
+        if (has) { Z[0][g * ZG + l * ZL] = w1; Z[1][g * ZG + l * ZL] = w2; Z[2][g * ZG + l * ZL] = w3; }
     }
     __syncthreads();
     // ---------------- forward: B, C ----------------
     {
         double w1, w2, w3;
-        fold_entry<LPW>(sp, cs, Z, GT, l, g, has, [](int kk) { return kk; }, uminus, uminus, uminus, w1, w2, w3);
+        fold_entry<ZG, ZL, GG, GL, ZN, GN>(sp, cs, Z, GT, l, g, has, [](int kk) { return kk; }, uminus, uminus, uminus, w1, w2, w3);
 #pragma unroll
-        for (int j = 0; j < PAR_SLMAX; j++) if (j < len) { const double tt = ((x[j] + a1 * w1) + a2 * w2) + a3 * w3; w3 = w2; w2 = w1; w1 = tt; x[j] = tt; }
+        for (int j = 0; j < PAR_SLMAX; j++) if (j < len) { const double tt = iir3<true>(x[j], a1, w1, a2, w2, a3, w3); w3 = w2; w2 = w1; w1 = tt; x[j] = tt; }
         if (lastseg) { Fin[0][l] = w1; Fin[1][l] = w2; Fin[2][l] = w3; }
     }
     __syncthreads();
@@ -1396,24 +1428,45 @@ __global__ __launch_bounds__(PAR_T) void k_iir_seg(PlaneSet ps, const double *sr
     {
         double v1 = 0.0, v2 = 0.0, v3 = 0.0;
 #pragma unroll
-        for (int j = PAR_SLMAX - 1; j >= 0; j--) if (j < blen) { const double tt = ((x[j] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; }
-        if (has) { Z[0][g][l] = v1; Z[1][g][l] = v2; Z[2][g][l] = v3; }
+        for (int j = PAR_SLMAX - 1; j >= 0; j--) if (j < blen) { const double tt = iir3<true>(x[j], a1, v1, a2, v2, a3, v3); v3 = v2; v2 = v1; v1 = tt; }
+        if (has) { Z[0][g * ZG + l * ZL] = v1; Z[1][g * ZG + l * ZL] = v2; Z[2][g * ZG + l * ZL] = v3; }
     }
     __syncthreads();
     // ---------------- backward: B', C' ----------------
     {
         // state after the (short) last segment, then fold the full segments right-to-left
         double s0a = vr0, s0b = vr1, s0c = vr2;
-        mv3(sp.Plast[cs], s0a, s0b, s0c, Z[0][nseg - 1][l], Z[1][nseg - 1][l], Z[2][nseg - 1][l]);
+        mv3(sp.Plast[cs], s0a, s0b, s0c, Z[0][(nseg - 1) * ZG + l * ZL], Z[1][(nseg - 1) * ZG + l * ZL], Z[2][(nseg - 1) * ZG + l * ZL]);
         double v1, v2, v3;
         const int kq = nseg - 2 - g;                        // fold order of the full segments
         const bool hasq = has && !lastseg;
-        fold_entry<LPW>(sp, cs, Z, GT, l, hasq ? kq : 0, hasq, [nseg](int kk) { return nseg - 2 - kk; }, s0a, s0b, s0c, v1, v2, v3);
+        fold_entry<ZG, ZL, GG, GL, ZN, GN>(sp, cs, Z, GT, l, hasq ? kq : 0, hasq, [nseg](int kk) { return nseg - 2 - kk; }, s0a, s0b, s0c, v1, v2, v3);
         if (lastseg) { v1 = vr0; v2 = vr1; v3 = vr2; }
 #pragma unroll
-        for (int j = PAR_SLMAX - 1; j >= 0; j--) if (j < blen) { const double tt = ((x[j] + a1 * v1) + a2 * v2) + a3 * v3; v3 = v2; v2 = v1; v1 = tt; x[j] = tt * scale; }
+        for (int j = PAR_SLMAX - 1; j >= 0; j--) if (j < blen) { const double tt = iir3<true>(x[j], a1, v1, a2, v2, a3, v3); v3 = v2; v2 = v1; v1 = tt; x[j] = tt * scale; }
 #pragma unroll
         for (int j = 0; j < PAR_SLMAX; j++) if (lastseg && j == len - 1) x[j] = vr0 * scale;
+    }
+    // planes of cum_mask: the running sum along the line follows in registers (k_cum_seg's arithmetic on the same values: segment totals
+    // folded in two levels through LDS) -- the product planes of a single image leave with their dim-1 integral, one kernel and one
+    // read + write of three planes less per level
+    if ((cum_mask >> pl) & 1) {                                   // workgroup-uniform
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < PAR_SLMAX; j++) if (j < len) acc = acc + x[j];
+        __syncthreads();                                          // the backward fold's LDS arrays are free
+        if (has) Z[0][g * ZG + l * ZL] = acc;
+        __syncthreads();
+        const int q = g % PAR_G, grp = g / PAR_G;
+        double pre = 0.0;
+        if (has) for (int i = 0; i < q; i++) pre = pre + Z[0][(grp * PAR_G + i) * ZG + l * ZL];
+        if (has && q == PAR_G - 1) GT[0][grp * GG + l * GL] = pre + Z[0][g * ZG + l * ZL];
+        __syncthreads();
+        double base = 0.0;
+        if (has) for (int h = 0; h < grp; h++) base = base + GT[0][h * GG + l * GL];
+        acc = base + pre;
+#pragma unroll
+        for (int j = 0; j < PAR_SLMAX; j++) if (j < len) { acc = acc + x[j]; x[j] = acc; }
     }
     if (valid) {
 #pragma unroll
@@ -1421,13 +1474,14 @@ __global__ __launch_bounds__(PAR_T) void k_iir_seg(PlaneSet ps, const double *sr
     }
 }
 
-template <bool COLS>
-__global__ __launch_bounds__(PAR_T) void k_cum_seg(PlaneSet ps, int H, int W, int P, int SL)
+template <bool COLS, int T = PAR_T, int LPW = 8>
+__global__ __launch_bounds__(T) void k_cum_seg(PlaneSet ps, int H, int W, int P, int SL)
 {
-    constexpr int LPW = 8, NSEG = PAR_T / LPW;
-    __shared__ double Zs[NSEG][LPW];
-    __shared__ double Gs[NSEG / PAR_G + 1][LPW];
-    const int t = threadIdx.x, l = t % LPW, g = t / LPW, pl = blockIdx.y;
+    constexpr int NSEG = T / LPW;
+    constexpr int ZG = COLS ? 1 : LPW, ZL = COLS ? NSEG + 1 : 1, GG = COLS ? 1 : LPW, GL = COLS ? NSEG / PAR_G + 2 : 1;   // k_iir_seg's lane mapping and LDS layouts
+    __shared__ double Zs[T + 8];
+    __shared__ double Gs[T / PAR_G + 16];
+    const int t = threadIdx.x, l = COLS ? t / NSEG : t % LPW, g = COLS ? t % NSEG : t / LPW, pl = blockIdx.y;
     const int nlines = COLS ? W : H, n = COLS ? H : W;
     const int line = blockIdx.x * LPW + l;
     const bool valid = line < nlines;
@@ -1443,15 +1497,15 @@ __global__ __launch_bounds__(PAR_T) void k_cum_seg(PlaneSet ps, int H, int W, in
     double acc = 0.0;
 #pragma unroll
     for (int j = 0; j < PAR_SLMAX; j++) if (j < len) acc = acc + x[j];
-    if (has) Zs[g][l] = acc;
+    if (has) Zs[g * ZG + l * ZL] = acc;
     __syncthreads();
     const int q = g % PAR_G, grp = g / PAR_G;
     double pre = 0.0;
-    if (has) for (int i = 0; i < q; i++) pre = pre + Zs[grp * PAR_G + i][l];
-    if (has && q == PAR_G - 1) Gs[grp][l] = pre + Zs[g][l];
+    if (has) for (int i = 0; i < q; i++) pre = pre + Zs[(grp * PAR_G + i) * ZG + l * ZL];
+    if (has && q == PAR_G - 1) Gs[grp * GG + l * GL] = pre + Zs[g * ZG + l * ZL];
     __syncthreads();
     double base = 0.0;
-    if (has) for (int h = 0; h < grp; h++) base = base + Gs[h][l];
+    if (has) for (int h = 0; h < grp; h++) base = base + Gs[h * GG + l * GL];
     acc = base + pre;
     if (valid) {
 #pragma unroll
@@ -1824,6 +1878,12 @@ __global__ __launch_bounds__(256) void k_fill(double *p, size_t n, double v)
     if (i < n) p[i] = v;
 }
 
+// smallest batch whose tolerance build (mode 3) takes the batch kernels (k_cols_fused<TOL> + k_rows_tol) instead of the segmented single-image ones
+static inline int tol_batch_min_s()
+{
+    static const int v = [] { const char *e = getenv("SLAMHIP_TOL_BATCH_MIN_S"); return e ? atoi(e) : 4; }();
+    return v;
+}
 static inline size_t ck_min_bytes()
 {
     const char *e = getenv("SLAMHIP_CK_MIN_MB");          // test / tuning hook; read per build (graphs are keyed on it below)
@@ -1969,7 +2029,7 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         if (target && l >= 1) {                                   // the layer chain only: blur (dim 1, dim 2) -> resize
             if (!has_next) return;
             PlaneSet pt = {}; pt.p[0] = T; pt.coef[0] = 0; pt.fill0[0] = (mode == 0); pt.nrm[0] = nullptr; pt.n = 1; pt.zs = zs;
-            const bool ckr = (mode != 3 || Sall >= 4) && p->ck != nullptr && mode != 0 && W >= 64 && H >= 64 && (size_t)Sall * 4 * H * W * 8 >= ck_min_bytes();
+            const bool ckr = (mode != 3 || Sall >= tol_batch_min_s()) && p->ck != nullptr && mode != 0 && W >= 64 && H >= 64 && (size_t)Sall * 4 * H * W * 8 >= ck_min_bytes();
             if (ckr) B.launch(k_iir_cols_ck, lines_grid(W, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, pt, (const double *)v.L, H, W, P, cf, p->ck);
             else B.launch(k_iir_cols<2>, lines_grid(W, 1, S), dim3(LINE_THREADS), 0, LN_MAIN, pt, (const double *)v.L, H, W, P, cf);
             static const bool no_rr = getenv("SLAMHIP_NO_ROWS_RESIZE") != nullptr;
@@ -2001,19 +2061,23 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         // MEASURED (round 5, one 370 x 1226 image, builds back to back): tolerance mode 243 us per build with the topology, 218 without; bit-exact
         // 450 vs 369 -- the split launches and the extra graph branches cost more than the shorter chain saves (the runtime serialises
         // branch nodes onto few hardware queues), as the round-1 experiment on the bit-exact kernels had found.  Off unless SLAMHIP_TOPOLOGY=1.
+        // A two-lane variant (layer chain of every level on the main lane, the gradient / product work of levels 0-1 on the aux lane, of the
+        // coarser levels behind the chain) was measured too: one isolated build 181 vs 198 us under the profiler, but 178-220 vs 152 us back to
+        // back -- every cross-queue dependency of the graph costs ~10 us, and consecutive builds no longer overlap.  Not kept.
         static const bool no_topo = getenv("SLAMHIP_TOPOLOGY") == nullptr;
         const bool topo = S == 1 && Sall == 1 && has_next && !cols_fused && B.lanes() && !no_topo;
         const int side = topo ? LN_SIDE0 + l : LN_MAIN;            // lane of the gradients / products (non-topology: the main chain)
         const int side_cum = topo ? LN_SIDE0 + l : LN_AUX;         // lane of the integral images
         if (topo) B.fork(side);
-        {
+        auto emit_scharr = [&](int lane_) {
             static const int sch1 = [] { const char *e = getenv("SLAMHIP_SCHARR_XC1"); return e ? atoi(e) : 2; }();      // (measurement knob) columns per thread for a single image: 16 / 8 / 4 / 2 / 1 -> 216 / 200 / 192 / 189 / 189 us per tolerance-mode build
-            if (!cols_fused && S == 1 && sch1 == 4) B.launch(k_scharr_products<4>, dim3((H + 63) / 64, (W + 3) / 4, S), dim3(64), 0, side, v, border_mode, zs, fuse_sq ? 0 : 1);
-            else if (!cols_fused && S == 1 && sch1 == 2) B.launch(k_scharr_products<2>, dim3((H + 63) / 64, (W + 1) / 2, S), dim3(64), 0, side, v, border_mode, zs, fuse_sq ? 0 : 1);
-            else if (!cols_fused && S == 1 && sch1 == 1) B.launch(k_scharr_products<1>, dim3((H + 63) / 64, W, S), dim3(64), 0, side, v, border_mode, zs, fuse_sq ? 0 : 1);
-            else if (!cols_fused && S == 1 && sch1 == 8) B.launch(k_scharr_products<8>, dim3((H + 63) / 64, (W + 7) / 8, S), dim3(64), 0, side, v, border_mode, zs, fuse_sq ? 0 : 1);
-            else if (!cols_fused) B.launch(k_scharr_products<SCH_XC>, dim3((H + 63) / 64, (W + SCH_XC - 1) / SCH_XC, S), dim3(64), 0, side, v, border_mode, zs, fuse_sq ? 0 : 1);
-        }
+            if (!cols_fused && S == 1 && sch1 == 4) B.launch(k_scharr_products<4>, dim3((H + 63) / 64, (W + 3) / 4, S), dim3(64), 0, lane_, v, border_mode, zs, fuse_sq ? 0 : 1);
+            else if (!cols_fused && S == 1 && sch1 == 2) B.launch(k_scharr_products<2>, dim3((H + 63) / 64, (W + 1) / 2, S), dim3(64), 0, lane_, v, border_mode, zs, fuse_sq ? 0 : 1);
+            else if (!cols_fused && S == 1 && sch1 == 1) B.launch(k_scharr_products<1>, dim3((H + 63) / 64, W, S), dim3(64), 0, lane_, v, border_mode, zs, fuse_sq ? 0 : 1);
+            else if (!cols_fused && S == 1 && sch1 == 8) B.launch(k_scharr_products<8>, dim3((H + 63) / 64, (W + 7) / 8, S), dim3(64), 0, lane_, v, border_mode, zs, fuse_sq ? 0 : 1);
+            else if (!cols_fused) B.launch(k_scharr_products<SCH_XC>, dim3((H + 63) / 64, (W + SCH_XC - 1) / SCH_XC, S), dim3(64), 0, lane_, v, border_mode, zs, fuse_sq ? 0 : 1);
+        };
+        emit_scharr(side);
         // dim-1 IIR: [blur: L -> T], Iyy, Ixx, Iyx in place
         PlaneSet ps = {};
         int np = 0;
@@ -2036,19 +2100,31 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             SegPow spc, spr;
             seg_pow(cf, H, slc, spc); seg_pow(cf, W, slr, spr);
             const dim3 gc((W + 7) / 8, np, S), gr((H + 7) / 8, np, S), gc3((W + 7) / 8, 3, S), gr3((H + 7) / 8, 3, S);
+            // columns of up to 512 samples: 32 segments of <= 16 samples per column in 256-thread workgroups (see k_iir_seg); SLAMHIP_SEG_WIDE=1: the 128-segment variant
+            static const bool seg_wide = getenv("SLAMHIP_SEG_WIDE") != nullptr;
+            const int slc32 = seg_len(H, 32);
+            const bool c32 = slc32 <= PAR_SLMAX && !seg_wide;
+            SegPow spc32;
+            if (c32) seg_pow(cf, H, slc32, spc32);
+            int rns = RT_NS;
+            const int slt = rt_seg_len(W, &rns);
+            static const bool no_rt1 = getenv("SLAMHIP_NO_ROWS_TOL_SINGLE") != nullptr;
+            const bool rt1 = slt > 0 && rns == RT_NS && !no_rt1;      // the dim-2 stage runs through k_rows_tol (below)
+            // ... then the product planes take their running sum along y inside the dim-1 kernel (SLAMHIP_NO_SEG_CUM=1: a k_cum_seg launch of their own)
+            static const bool no_seg_cum = getenv("SLAMHIP_NO_SEG_CUM") != nullptr;
+            const bool seg_cum = rt1 && !topo && !no_seg_cum;
+            const int cmask = seg_cum ? (has_next ? 0xE : 0x7) : 0;
             if (topo) {
-                B.launch(k_iir_seg<true>, dim3((W + 7) / 8, 1, S), dim3(PAR_T), 0, LN_MAIN, psT, src0, H, W, P, cf, spc, slc);
-                B.launch(k_iir_seg<true>, gc3, dim3(PAR_T), 0, side, psQ, (const double *)nullptr, H, W, P, cf, spc, slc);
+                B.launch(k_iir_seg<true>, dim3((W + 7) / 8, 1, S), dim3(PAR_T), 0, LN_MAIN, psT, src0, H, W, P, cf, spc, slc, 0);
+                B.launch(k_iir_seg<true>, gc3, dim3(PAR_T), 0, side, psQ, (const double *)nullptr, H, W, P, cf, spc, slc, 0);
             }
-            else B.launch(k_iir_seg<true>, gc, dim3(PAR_T), 0, LN_MAIN, ps, src0, H, W, P, cf, spc, slc);
+            else if (c32) B.launch((k_iir_seg<true, 256, 8>), gc, dim3(256), 0, LN_MAIN, ps, src0, H, W, P, cf, spc32, slc32, cmask);
+            else B.launch(k_iir_seg<true>, gc, dim3(PAR_T), 0, LN_MAIN, ps, src0, H, W, P, cf, spc, slc, cmask);
             // round 4: the dim-2 stage of a single image through k_rows_tol as well -- the blurred layer (filter along x + imresize!, one launch on
             // the main chain instead of k_iir_seg + k_resize) and, on the branch, the product planes (running sum along y first: the two
             // directions commute; then filter + running sum along x in one launch instead of k_iir_seg + k_cum_seg): 5 launches per level, 3 of
             // them on the chain the next level waits for (6 / 4 before)
-            int rns = RT_NS;
-            const int slt = rt_seg_len(W, &rns);
-            static const bool no_rt1 = getenv("SLAMHIP_NO_ROWS_TOL_SINGLE") != nullptr;
-            if (slt > 0 && rns == RT_NS && !no_rt1) {
+            if (rt1) {
                 SegPow spt; rt_seg_pow(cf, slt, spt);
                 auto rows_tol = [&](RowsTolArgs &ra, int nplanes, int lane_) {
                     const dim3 g2((H + RT_R - 1) / RT_R, nplanes, S), b2(RT_R * RT_NS);
@@ -2068,7 +2144,9 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
                         B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
                                            nextL, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
                 }
-                B.launch(k_cum_seg<true>, gc3, dim3(PAR_T), 0, side_cum, pc, H, W, P, slc);
+                if (seg_cum) {}
+                else if (c32) B.launch((k_cum_seg<true, 256, 8>), gc3, dim3(256), 0, side_cum, pc, H, W, P, slc32);
+                else B.launch(k_cum_seg<true>, gc3, dim3(PAR_T), 0, side_cum, pc, H, W, P, slc);
                 RowsTolArgs rq = {};
                 rq.p[0] = v.Iyy; rq.p[1] = v.Ixx; rq.p[2] = v.Iyx;
                 for (int q = 0; q < 3; q++) { rq.coef[q] = 1; rq.kind[q] = 2; }
@@ -2077,17 +2155,18 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
                 return;
             }
             if (topo) {
-                B.launch(k_iir_seg<false>, dim3((H + 7) / 8, 1, S), dim3(PAR_T), 0, LN_MAIN, psT, (const double *)nullptr, H, W, P, cf, spr, slr);
-                B.launch(k_iir_seg<false>, gr3, dim3(PAR_T), 0, side, psQ, (const double *)nullptr, H, W, P, cf, spr, slr);
+                B.launch(k_iir_seg<false>, dim3((H + 7) / 8, 1, S), dim3(PAR_T), 0, LN_MAIN, psT, (const double *)nullptr, H, W, P, cf, spr, slr, 0);
+                B.launch(k_iir_seg<false>, gr3, dim3(PAR_T), 0, side, psQ, (const double *)nullptr, H, W, P, cf, spr, slr, 0);
             }
             else if (spans) { ProfScope span(ctx, "k_iir_rows");
-                B.launch(k_iir_seg<false>, gr, dim3(PAR_T), 0, LN_MAIN, ps, (const double *)nullptr, H, W, P, cf, spr, slr); }
-            else B.launch(k_iir_seg<false>, gr, dim3(PAR_T), 0, LN_MAIN, ps, (const double *)nullptr, H, W, P, cf, spr, slr);
+                B.launch(k_iir_seg<false>, gr, dim3(PAR_T), 0, LN_MAIN, ps, (const double *)nullptr, H, W, P, cf, spr, slr, 0); }
+            else B.launch(k_iir_seg<false>, gr, dim3(PAR_T), 0, LN_MAIN, ps, (const double *)nullptr, H, W, P, cf, spr, slr, 0);
             if (!topo) B.fork();
             if (has_next)
                 B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
                                    nextL, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
-            B.launch(k_cum_seg<true>, gc3, dim3(PAR_T), 0, side_cum, pc, H, W, P, slc);
+            if (c32) B.launch((k_cum_seg<true, 256, 8>), gc3, dim3(256), 0, side_cum, pc, H, W, P, slc32);
+            else B.launch(k_cum_seg<true>, gc3, dim3(PAR_T), 0, side_cum, pc, H, W, P, slc);
             B.launch(k_cum_seg<false>, gr3, dim3(PAR_T), 0, side_cum, pc, H, W, P, slr);
             return;
         }
@@ -2096,7 +2175,7 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
         static const bool no_tol_batch = getenv("SLAMHIP_NO_TOL_BATCH") != nullptr;
         int rt_ns = RT_NS;
         const int slr_t = rt_seg_len(W, &rt_ns);
-        const bool tolb = mode == 3 && Sall >= 4 && cols_fused && p->alloc->tot != nullptr && slr_t > 0 && !no_tol_batch;
+        const bool tolb = mode == 3 && Sall >= tol_batch_min_s() && cols_fused && p->alloc->tot != nullptr && slr_t > 0 && !no_tol_batch;
         if (cols_fused) {
             ColsFusedArgs ca;
             ca.L = v.L; ca.T = has_next ? T : nullptr; ca.Iy = v.Iy; ca.Ix = v.Ix; ca.Qyy = v.Iyy; ca.Qxx = v.Ixx; ca.Qyx = v.Iyx;
@@ -2192,7 +2271,7 @@ static void launch_build(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
 {
     bool fast = mode == 3;
     if (fast && (seg_len(p->H[0], PAR_T / 8) > PAR_SLMAX || seg_len(p->W[0], PAR_T / 8) > PAR_SLMAX)) fast = false;   // lines > 2048 samples: exact kernels
-    if (fast && S >= 4) fast = false;   // the segmented kernels buy latency for ONE image; with several images per launch the exact kernels are faster (and trivially within the tolerance)
+    if (fast && S >= tol_batch_min_s()) fast = false;   // the segmented kernels buy latency for ONE image; with several images per launch the exact kernels are faster (and trivially within the tolerance)
     static const int chunk_mb = [] { const char *v = getenv("SLAMHIP_PYR_CHUNK_MB"); return v ? atoi(v) : 0; }();      // intermediate planes of a sub-batch, MB (0: no sub-batches)
     for (int l = 0; l < p->levels; l++) {
         int C = S;
@@ -2211,7 +2290,7 @@ static bool level0_fused(const slam_pyr *p, int mode, int S)
     static const bool off = getenv("SLAMHIP_NO_COLS_FUSED") != nullptr || getenv("SLAMHIP_NO_SQ_FUSE") != nullptr || getenv("SLAMHIP_NO_CK_COLS") != nullptr ||
                             getenv("SLAMHIP_NO_FUSED_INGEST") != nullptr;
     if (off || mode == 0 || p->ck == nullptr || p->alloc->srctab == nullptr || p->H[0] < 64) return false;
-    if (mode == 3 && S < 4 && !(seg_len(p->H[0], PAR_T / 8) > PAR_SLMAX || seg_len(p->W[0], PAR_T / 8) > PAR_SLMAX)) return false;   // the segmented kernels
+    if (mode == 3 && S < tol_batch_min_s() && !(seg_len(p->H[0], PAR_T / 8) > PAR_SLMAX || seg_len(p->W[0], PAR_T / 8) > PAR_SLMAX)) return false;   // the segmented kernels
     const int np_ = p->levels > 1 ? 4 : 3;
     return (size_t)S * np_ * p->H[0] * p->W[0] * 8 >= ck_min_bytes();
 }

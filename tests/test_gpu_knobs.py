@@ -42,6 +42,13 @@ else:
         for l in range(4):
             for nm in PL:
                 assert np.array_equal(p.plane(nm, l), ref.plane(nm, l)), (mode, nm, l)
+    p = slam.LKPyramid(shape=(H, W), levels=3)                 # tolerance mode of a single image (segmented recurrences)
+    slam.update_(p, img, fast=True); slam.update_(p, img, fast=True)
+    ref = orc.pyr_build(img, 3, 1.0, 1)
+    for l in range(4):
+        for nm in PL:
+            g, r = p.plane(nm, l), ref.plane(nm, l)
+            assert np.abs(g - r).max() <= 1e-11 * max(np.abs(r).max(), 1e-300), ("mode 3", nm, l, np.abs(g - r).max())
 print("OK")
 '''
 
@@ -65,6 +72,16 @@ def test_latency_topology_of_a_single_image_is_bit_exact():
 def test_single_image_scharr_columns_per_thread_are_bit_exact():
     for xc in ("1", "4", "16"):
         _run({"SLAMHIP_SCHARR_XC1": xc}, 121, 163, 1)
+
+
+def test_single_image_segment_variants_stay_within_tolerance():
+    """mode 3, one image: the 128-segment column kernels (SLAMHIP_SEG_WIDE), the running sum along y as a launch of its own
+    (SLAMHIP_NO_SEG_CUM) and the defaults (32 segments of <= 16 samples, running sum fused), at sizes on both sides of the
+    32 x 16-sample limit"""
+    for env in ({}, {"SLAMHIP_SEG_WIDE": "1"}, {"SLAMHIP_NO_SEG_CUM": "1"}, {"SLAMHIP_SEG_WIDE": "1", "SLAMHIP_NO_SEG_CUM": "1"}):
+        _run(env, 370, 1226, 1)
+    _run({}, 540, 700, 1)                                   # columns of 540 samples: 32 segments would need 17 samples -> the 128-segment variant
+    _run({}, 121, 163, 1)
 
 
 def test_contexts_recycle_their_streams(slam):
