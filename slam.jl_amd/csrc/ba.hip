@@ -1824,6 +1824,228 @@ __device__ __forceinline__ void band_solve_body(const BADev &d, const BandArgs &
 }
 __global__ __launch_bounds__(BS_T) void k_band_solve(BADev d, BandArgs B, int use_state) { band_solve_body(d, B, use_state); }
 
+// ---- small windows that NO pose order makes banded (half-bandwidth > BS_MAXHB: every map point seen by almost every key-frame): the
+//      damped reduced system of <= DS_MAXF free-span poses is factored DENSE by one workgroup, lower triangle of 6 x 6 blocks resident in
+//      LDS (block (i, j), j <= i, at i (i + 1) / 2 + j; 134 KB at 30 poses), the right-hand side riding along as one more row:
+//        per block column k:  wave 0 factors A_kk in place (wave-synchronous, six pivots);
+//                             thread (i, r) forms row r of the panel block L_ik = A_ik L_kk^-T by forward substitution (and y_k likewise);
+//                             thread (pair (i, j), r) updates row r of A_ij -= L_ik L_jk^T (the right-hand side: y_j -= L_jk y_k);
+//        then L^T dp = y block row by block row, bottom up.
+//      (P = 26, 25 free poses: 81 us -- factor wave 2.8 k cycles per column beside a trailing update of 4.2 k, bound by the LDS pipe; load 6 us,
+//      back-substitution 9 us.)  One launch instead of the 7 + n / 32 of the tiled path (k_chol_prepare ... k_chol_backsolve: 164 us); the build of such a window goes
+//      through the point groups like a banded one (window = the whole triangle).  Same damping rule as k_chol_prepare / k_band_solve.
+#define DS_T 512
+#define DS_MAXF 30
+static size_t dense_lds_bytes(int F) { return ((size_t)F * (F + 1) / 2 * 36 + (size_t)6 * F * 2 + (size_t)36 * F + 64) * 8; }
+__device__ __forceinline__ void ds_barrier() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
+__global__ __launch_bounds__(DS_T) void k_dense_solve(BADev d, BandArgs B, int use_state)
+{
+    if (use_state && d.st->converged) return;
+    extern __shared__ __attribute__((aligned(16))) double ds_sm[];
+    __shared__ int s_bad;
+    const int F = B.nb, n = d.n, ns = 6 * F, tid = threadIdx.x, nblk = F * (F + 1) / 2;
+    double *A = ds_sm;                                   // [nblk][36]
+    double *y = A + (size_t)nblk * 36;                   // [ns]: g -> y -> dp
+    double *idg = y + ns;                                // [ns]: 1 / L_jj
+    const double inv_delta = use_state ? 1.0 / d.st->delta : B.inv_delta_host;
+    if (tid == 0) s_bad = 0;
+    // ---- load: EVERY element is requested before the first one is stored (S was written by other kernels from all eight XCDs: first
+    //      touches are trips to memory, and a load-store loop pays one after the other -- 25 round trips were half of the kernel).  Block
+    //      (i, j) entry (r, c) is read through its symmetric twin S[6 j + c, 6 i + r] so that consecutive lanes read consecutive addresses
+    constexpr int NL = (DS_MAXF * (DS_MAXF + 1) / 2 * 36 + DS_T - 1) / DS_T;
+    {
+        double v[NL];
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+            const int e = tid + u * DS_T;
+            v[u] = 0.0;
+            if (e < nblk * 36) {
+                const int blk = e / 36, q = e - 36 * blk, r = q / 6, c = q - 6 * r;
+                int i = (int)((sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
+                while (i * (i + 1) / 2 > blk) i--;
+                while ((i + 1) * (i + 2) / 2 <= blk) i++;
+                const int j = blk - i * (i + 1) / 2;
+                v[u] = B.S[(size_t)(6 * j + c) + (size_t)(6 * i + r) * n];
+            }
+        }
+        const double udv = tid < ns ? B.ud[tid] : 0.0, gv = tid < ns ? B.g[tid] : 0.0;
+#pragma unroll
+        for (int u = 0; u < NL; u++) { const int e = tid + u * DS_T; if (e < nblk * 36) A[e] = v[u]; }
+        if (tid < ns) y[tid] = gv;
+        ds_barrier();
+        if (tid < ns) { const int k = tid / 6, r = tid - 6 * k; A[(size_t)(k * (k + 1) / 2 + k) * 36 + 7 * r] += fmin(fmax(udv, LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta; }
+    }
+    ds_barrier();
+    // Cholesky of the diagonal block (k, k) by wave 0.  upd: the block first loses L_{k,k-1} L_{k,k-1}^T (the previous column's trailing update
+    // for this one block -- the look-ahead: the wave factors block k while the other waves update the rest), lane q < 21 forms lower entry q.
+    // Every lane then holds the whole triangle (42 v_readlane) and eliminates it division-free on scaled entries, k_band_solve's scheme:
+    // m_ik <- m_ik p_j - m_ij m_kj (two dependent operations per pivot; every second pivot a power-of-two rescale), the six 1 / sqrt from
+    // v_rsq_f64 + one Newton step, independent of each other: ~1.5 k cycles per block instead of ~5 k for the textbook loop on one wave
+    // (a dependent Float64 operation of a lone wave costs 36 cycles).
+    auto factor_diag = [&](int k, bool upd) {
+#pragma clang fp contract(fast)
+        double *D = A + (size_t)(k * (k + 1) / 2 + k) * 36;
+        const int q = tid < 21 ? tid : 20;
+        int r = 0; while ((r + 1) * (r + 2) / 2 <= q) r++;
+        const int c = q - r * (r + 1) / 2;
+        double e = D[6 * r + c];
+        if (upd) {
+            const double *Lp = A + (size_t)(k * (k + 1) / 2 + k - 1) * 36;
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < 6; m++) acc += Lp[6 * r + m] * Lp[6 * c + m];
+            e -= acc;
+        }
+        double M[21], ps[6], sj[6], Lr[21];
+#pragma unroll
+        for (int t = 0; t < 21; t++) M[t] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(e), t), __builtin_amdgcn_readlane(__double2loint(e), t));
+        double sc = 1.0; bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double pj = M[j * (j + 1) / 2 + j];
+            bad = bad || !(pj > 0.0 && pj < 1e300);
+            pj = (pj > 0.0 && pj < 1e300) ? pj : 1.0;
+            ps[j] = pj * sc; sj[j] = sc;
+            Lr[j * (j + 1) / 2 + j] = pj;
+#pragma unroll
+            for (int i = j + 1; i < 6; i++) Lr[i * (i + 1) / 2 + j] = M[i * (i + 1) / 2 + j];      // (unscaled column: times rsqrt(p_j s_j) below)
+            if ((j & 1) == 0) {
+                const int ex = -__builtin_amdgcn_frexp_exp(pj);
+                sc *= __builtin_amdgcn_frexp_mant(pj);
+#pragma unroll
+                for (int i = j + 1; i < 6; i++)
+#pragma unroll
+                    for (int k2 = j + 1; k2 <= i; k2++)
+                        M[i * (i + 1) / 2 + k2] = __builtin_amdgcn_ldexp(M[i * (i + 1) / 2 + k2] * pj - M[i * (i + 1) / 2 + j] * M[k2 * (k2 + 1) / 2 + j], ex);
+            } else {
+                sc *= pj;
+#pragma unroll
+                for (int i = j + 1; i < 6; i++)
+#pragma unroll
+                    for (int k2 = j + 1; k2 <= i; k2++)
+                        M[i * (i + 1) / 2 + k2] = M[i * (i + 1) / 2 + k2] * pj - M[i * (i + 1) / 2 + j] * M[k2 * (k2 + 1) / 2 + j];
+            }
+        }
+        double out = 0.0, iq = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const double y0 = __builtin_amdgcn_rsq(ps[j]);
+            const double r0 = fma(-(ps[j] * y0), y0, 1.0), rd = fma(y0 * 0.5, r0, y0);
+            if (tid == j) iq = sj[j] * rd;                        // 1 / L_jj = s_j rsqrt(p_j s_j)
+#pragma unroll
+            for (int i = j; i < 6; i++) if (q == i * (i + 1) / 2 + j) out = Lr[i * (i + 1) / 2 + j] * rd;
+        }
+        if (tid < 21) D[6 * r + c] = out;
+        if (tid < 6) idg[6 * k + tid] = iq;
+        if (bad && tid == 0) s_bad = 1;
+    };
+    if (tid < 64) factor_diag(0, false);
+    ds_barrier();
+    for (int k = 0; k < F; k++) {
+        const double *D = A + (size_t)(k * (k + 1) / 2 + k) * 36;
+        // (1) panel rows: x L_kk^T = a (forward substitution), item = (block row i > k, row r) or the right-hand side's block k
+        const int npan = (F - 1 - k) * 6 + 1;
+        for (int it = tid; it < npan; it += DS_T) {
+            double *row = it < npan - 1 ? A + (size_t)((k + 1 + it / 6) * (k + 2 + it / 6) / 2 + k) * 36 + 6 * (it % 6) : y + 6 * k;
+            double x[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double a = row[c];
+#pragma unroll
+                for (int m = 0; m < 6; m++) if (m < c) a -= x[m] * D[6 * c + m];
+                x[c] = a * idg[6 * k + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) row[c] = x[c];
+        }
+        ds_barrier();
+        // (2) wave 0: the next diagonal block, updated and factored (look-ahead); waves 1-7: the trailing update A_ij -= L_ik L_jk^T of every
+        //     other pair k < j <= i, item = (pair, row), and the right-hand side y_j -= L_jk y_k, item = block row j
+        if (tid < 64) { if (k + 1 < F) factor_diag(k + 1, true); }
+        else {
+            // (measured: items of one whole block pair -- L_jk in registers for its six rows, 144 instead of 324 LDS accesses per block -- are
+            //  slower: 126 k vs 104 k cycles per solve; past the first columns there are fewer pairs than lanes and a thread's six rows are a chain)
+            const int m1 = F - 1 - k, npair = m1 * (m1 + 1) / 2, nupd = npair * 6 + m1;
+            for (int it = tid - 64 + 6; it < nupd; it += DS_T - 64) {      // (items 0 .. 5 are the rows of pair (k + 1, k + 1): wave 0's)
+                if (it < npair * 6) {
+                    const int pr = it / 6, r = it - 6 * pr;
+                    int a = (int)((sqrtf(8.0f * (float)pr + 1.0f) - 1.0f) * 0.5f);
+                    while (a * (a + 1) / 2 > pr) a--;
+                    while ((a + 1) * (a + 2) / 2 <= pr) a++;
+                    const int b = pr - a * (a + 1) / 2, i = k + 1 + a, j = k + 1 + b;          // b <= a: j <= i
+                    const double *Li = A + (size_t)(i * (i + 1) / 2 + k) * 36 + 6 * r, *Lj = A + (size_t)(j * (j + 1) / 2 + k) * 36;
+                    double *T = A + (size_t)(i * (i + 1) / 2 + j) * 36 + 6 * r;
+                    double li[6];
+#pragma unroll
+                    for (int m = 0; m < 6; m++) li[m] = Li[m];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int m = 0; m < 6; m++) acc += li[m] * Lj[6 * c + m];
+                        T[c] -= acc;
+                    }
+                } else {
+                    const int j = k + 1 + (it - npair * 6);
+                    const double *Lj = A + (size_t)(j * (j + 1) / 2 + k) * 36;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int m = 0; m < 6; m++) acc += Lj[6 * c + m] * y[6 * k + m];
+                        y[6 * j + c] -= acc;
+                    }
+                }
+            }
+        }
+        ds_barrier();
+    }
+    // ---- L^T dp = y, bottom up: dp_k = L_kk^-T (y_k - sum_{i > k} L_ik^T dp_i).  The diagonal blocks are inverted all at once first
+    //      (thread = (block, column of the inverse): six forward substitutions each, in parallel), then wave 0 alone walks the block rows --
+    //      lane c forms dp_k[c] from the inverse, the lanes share out the 6 k entries of y above it: no workgroup barrier in the chain
+    double *Linv = idg + ns;                             // [F][36] L_kk^-1 (lower, row-major)
+    for (int it = tid; it < 6 * F; it += DS_T) {
+        const int k = it / 6, c = it - 6 * k;
+        const double *D = A + (size_t)(k * (k + 1) / 2 + k) * 36;
+        double x[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            double a = r == c ? 1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < 6; m++) if (m < r) a -= D[6 * r + m] * x[m];
+            x[r] = r < c ? 0.0 : a * idg[6 * k + r];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++) Linv[36 * k + 6 * r + c] = x[r];
+    }
+    ds_barrier();
+    if (tid < 64) {
+        for (int k = F - 1; k >= 0; k--) {
+            if (tid < 6) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < 6; m++) acc += Linv[36 * k + 6 * m + tid] * y[6 * k + m];      // (L^-T y)[c] = sum_m Linv[m][c] y[m]
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                y[6 * k + tid] = acc;
+            } else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int it = tid; it < 6 * k; it += 64) {        // y_j[c] -= sum_m L_kj[m][c] dp_k[m], j < k
+                const int j = it / 6, c = it - 6 * j;
+                const double *Lk = A + (size_t)(k * (k + 1) / 2 + j) * 36;
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < 6; m++) acc += Lk[6 * m + c] * y[6 * k + m];
+                y[it] -= acc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    ds_barrier();
+    double *const dpo = d.dp + 6 * B.p0;
+    for (int a = tid; a < ns; a += DS_T) dpo[a] = y[a];
+    if (tid == 0) { *B.fail = s_bad; if (s_bad) d.st->chol_fail = 1; }
+}
+
 __global__ __launch_bounds__(256) void k_backsub(BADev d, int use_state)
 {
     const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
@@ -2912,7 +3134,11 @@ static int ba_plan(BAPlan &pl)
     ba->perm.assign(O, 0);
     // --- point groups of k_schur_groups: same f, <= SG_SB points, <= SG_OB observations; evenly sized within one f
     static const bool no_groups = getenv("SLAMHIP_NO_GROUPS") != nullptr;
-    bool grouped = !no_groups && hb <= BS_MAXHB && M > 0 && O > 0 && sg_fold_fits(hb);
+    // (windows no order makes banded, hb > BS_MAXHB: the point groups still build the system -- their window is the whole block triangle -- when
+    //  the free span is small enough for the dense one-workgroup solver, k_dense_solve, and the group's LDS layout fits)
+    static const bool no_dense = getenv("SLAMHIP_NO_DENSE") != nullptr;
+    const bool dense_ok = !no_dense && hb > BS_MAXHB && ba->pspan >= 2 && ba->pspan <= DS_MAXF && P <= DS_MAXF + 8 && sg_lds_bytes(hb, P) <= 150 * 1024;
+    bool grouped = !no_groups && (hb <= BS_MAXHB || dense_ok) && M > 0 && O > 0 && sg_fold_fits(hb);
     pl.nfree_obs = nfo;
     {   // a window one workgroup can keep to itself (k_ba_window, batches only): the point groups of the launch-per-phase kernels are not built
         static const bool no_bw = getenv("SLAMHIP_NO_BA_WINDOW") != nullptr;
@@ -3131,7 +3357,7 @@ static int ba_enqueue_build(slam_ctx *ctx, slam_ba *ba, int ignore_outliers, dou
         // (the reference's three tasks call the library concurrently, SLAM.jl:166: the flag is atomic; setting the attribute twice is harmless)
         static std::atomic<bool> attr_set[64];
         const int dv = ctx->device & 63;
-        if (!attr_set[dv].load(std::memory_order_acquire)) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB, SOLVE_MAX_N / 6))); attr_set[dv].store(true, std::memory_order_release); }
+        if (!attr_set[dv].load(std::memory_order_acquire)) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(sg_lds_bytes(BS_MAXHB, SOLVE_MAX_N / 6), (size_t)150 * 1024))); attr_set[dv].store(true, std::memory_order_release); }
         hipLaunchKernelGGL(k_schur_groups, dim3(d.ngrp), dim3(SG_T), sg_lds_bytes(d.whb, d.P, d.sg_ob, d.sg_sb, 512, d.sg_hp), st, d, inv_delta, ignore_outliers, use_state);
         if (!use_state) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, st, d, 0, d.ngrp, ba->nblocks_pts, 0, red + (size_t)n * n + 2 * n);
         const int nthr = d.P * (d.whb + 1) * 36 + d.P * 12;
@@ -3156,6 +3382,14 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
     const int Ps = ba->pspan > 0 ? ba->pspan : d.P, p0 = ba->pspan > 0 ? ba->p0 : 0;       // the poses the banded solve covers: first .. last free pose
     const int hb = std::min(std::max(ba->hb, 1), Ps - 1);      // >= 1: the factor wave reads block row k + 1 while row k + 1 + hb enters the ring
     const size_t band_lds = band_lds_bytes(n, Ps, hb);
+    if (ba->grouped && hb > BS_MAXHB && Ps <= DS_MAXF) {       // not banded, small: dense one-workgroup solve (ba_plan admitted the groups for exactly this case)
+        BandArgs B = {}; B.S = red + (size_t)6 * p0 * (n + 1); B.g = red + (size_t)n * n + 6 * p0; B.ud = red + (size_t)n * n + n + 6 * p0; B.Lg = nullptr; B.nb = Ps; B.hb = hb; B.p0 = p0;
+        B.inv_delta_host = inv_delta; B.fail = ba->chol_flag;
+        static std::atomic<bool> ds_attr[64];
+        const int dv = ctx->device & 63;
+        if (!ds_attr[dv].load(std::memory_order_acquire)) { HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dense_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dense_lds_bytes(DS_MAXF))); ds_attr[dv].store(true, std::memory_order_release); }
+        hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(DS_T), dense_lds_bytes(Ps), st, d, B, use_state);
+    } else
     if (!no_band && hb <= BS_MAXHB && band_lds <= 150 * 1024) {
         BandArgs B; B.S = red + (size_t)6 * p0 * (n + 1); B.g = red + (size_t)n * n + 6 * p0; B.ud = red + (size_t)n * n + n + 6 * p0; B.Lg = ba->band; B.nb = Ps; B.hb = hb; B.p0 = p0;
         B.inv_delta_host = inv_delta; B.fail = ba->chol_flag; B.lds_bytes = (int)band_lds;

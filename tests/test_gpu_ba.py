@@ -44,6 +44,21 @@ def test_local_ba_matches_oracle_schur(slam, orc, syn, P, M, seed):
     _check_recall(cache.outliers, s)
 
 
+@pytest.mark.parametrize("P,M,opp,n_const", [(26, 1500, 24, 1), (30, 1200, 28, 2), (24, 900, 23, 1), (27, 700, 25, 5)])
+def test_windows_no_pose_order_makes_banded_take_the_dense_solver(slam, orc, syn, P, M, opp, n_const):
+    """every map point seen by (almost) every key-frame: half-bandwidth > 20 in any order -> point groups over the whole block triangle +
+    k_dense_solve (one workgroup, lower triangle in LDS) instead of pair lists + the tiled Cholesky; same answers as the oracle's Schur-LM"""
+    s = syn.ba_scene(P=P, M=M, seed=40 + P, obs_per_point=opp, n_const=n_const)
+    cache, th, ol, st = _run(slam, orc, s)
+    assert np.array_equal(cache.outliers, ol)
+    assert cache.stats["iters_pass1"] == st["iters_pass1"] and cache.stats["iters_pass2"] == st["iters_pass2"]
+    for k in ("ssr_init", "ssr_pass1", "ssr_final"):
+        assert abs(cache.stats[k] - st[k]) <= RTOL_SSR * st[k], k
+    assert np.abs(cache.theta - th).max() <= RTOL_THETA * max(1.0, np.abs(th).max())
+    c = s["theta_const"].astype(bool)
+    assert np.array_equal(cache.theta[:6 * P].reshape(P, 6)[c], s["theta0"][:6 * P].reshape(P, 6)[c])
+
+
 def test_local_ba_vs_reference_style_lsmr(slam, orc, syn):
     s = syn.ba_scene(P=6, M=500, seed=3)
     cache, th, ol, st = _run(slam, orc, s)
