@@ -14,8 +14,8 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 u8 = len(sys.argv) > 3 and sys.argv[3] == "u8"
 fast = len(sys.argv) > 4 and sys.argv[4] == "tol"        # mode 3: the tolerance-mode batch kernels
-H, W = syn.SHAPES['kitti05']
-left, right, flows = syn.stereo_stream('kitti05', 8, seed=0, disparity=12.4)
+H, W = syn.SHAPES[os.environ.get('SHAPE', 'kitti05')]
+left, right, flows = syn.stereo_stream(os.environ.get('SHAPE', 'kitti05'), 8, seed=0, disparity=12.4)
 dev = torch.device("cuda", 0)
 ld = [torch.from_numpy(np.ascontiguousarray((np.round(im * 255).astype(np.uint8) if u8 else im).T)).to(dev) for im in left]
 torch.cuda.synchronize()

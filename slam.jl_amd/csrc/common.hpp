@@ -56,7 +56,7 @@ struct slam_pyr {
     int H[SLAM_MAX_LEVELS], W[SLAM_MAX_LEVELS];
     int P[SLAM_MAX_LEVELS];               // column pitch in doubles (H rounded up to 16)
     int64_t off[SLAM_MAX_LEVELS + 1];     // plane offsets in doubles (sum of P_l * W_l)
-    struct Alloc { double *base = nullptr; double *ck = nullptr; double *tot = nullptr; const void **srctab = nullptr; int refs = 0; std::mutex graph_mu; };   // shared by the members of a batch; srctab: 64 source-image pointers (fused ingest)
+    struct Alloc { double *base = nullptr; double *ck = nullptr; double *tot = nullptr; const void **srctab = nullptr; double *xc = nullptr; int *xf = nullptr; int xseg = 0; int refs = 0; std::mutex graph_mu; };   // xc / xf / xseg: carry rows and flags of k_cum_fused's row segments (frames taller than 512 rows)   // shared by the members of a batch; srctab: 64 source-image pointers (fused ingest)
     Alloc *alloc = nullptr;
     size_t zstride = 0;                   // doubles between consecutive images of a batch (7 * off[levels])
     int batch_index = 0, batch_size = 1;

@@ -1190,6 +1190,7 @@ __global__ __launch_bounds__(LINE_THREADS) void k_cum_rows(PlaneSet ps, int H, i
 #define CF_LS 66                         // Cb column stride in doubles (even: ds_*_b128 alignment)
 #define CF_W 32                          // columns per block
 #define CF_MAXW 8                        // bands (waves) per workgroup: H <= 512 (2 waves per SIMD -> 256 VGPRs each)
+#define CF_SEGW 4                        // bands per row segment of taller planes (chained workgroups, see k_cum_fused)
 // block of 64 rows x 32 columns as aligned lines: sub-tile s, column group r -> rows 2rp, 2rp+1 of column 8r + cg.  Rows past
 // H inside the pitch and columns past W are read as well (in-bounds by the layout, never stored).
 __device__ __forceinline__ void cf_load_block(const double *plane, int P, int x0, int r0, unsigned voff, double (&raw)[4][8])
@@ -1205,7 +1206,13 @@ __device__ __forceinline__ void cf_load_block(const double *plane, int P, int x0
 #endif
     }
 }
-__global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, int W, int P)
+// Planes taller than CF_MAXW bands (1080-row frames) are cut into row SEGMENTS of CF_SEGW bands (256 rows: 68 KB of LDS, two workgroups per
+// compute unit -- the 5 x 3 x 32 workgroups of a 32-image FHD launch are resident at once), one workgroup each (blockIdx.x): the band
+// chain continues across the workgroups -- the last wave of segment g publishes its bottom row's column sums, block by block, in global
+// memory (xc, agent-scope stores + a counting flag per (image, plane, boundary)), wave 0 of segment g + 1 takes them as its carry.  A
+// segment only ever waits for a workgroup with a smaller blockIdx.x (dispatched before it); the consumer zeroes the flag when it is done,
+// so a replay of the launch finds it clear.  Same sums in the same order as one workgroup would form them.
+__global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, int W, int P, double *xc, int *xf)
 {
     extern __shared__ __attribute__((aligned(16))) double cf_lds[];          // [nw][CF_W * CF_LS] blocks, then [nw][2][CF_W] column carries
     __shared__ int s_ready[CF_MAXW], s_done[CF_MAXW];            // read and written with relaxed workgroup-scope atomics: plain ds_read / ds_write (as `volatile` they were
@@ -1224,7 +1231,14 @@ __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, 
     auto flag_st = [](int *f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     if (lane == 0) { flag_st(&s_ready[w], 0); flag_st(&s_done[w], 0); }
     __syncthreads();
-    const int r0 = w * 64, hr = H - r0 < 64 ? H - r0 : 64;       // rows of this band that exist (>= 1 by the launch)
+    const int seg = blockIdx.x, nseg = gridDim.x;
+    const int nwh = min(nw, (H - seg * nw * 64 + 63) / 64);           // bands of this segment: nw = blockDim.x / 64 per segment, the last one may be short
+    if (w >= nwh) return;                                         // (after the one workgroup barrier of the kernel)
+    const int r0 = (seg * nw + w) * 64, hr = H - r0 < 64 ? H - r0 : 64;       // rows of this band that exist (>= 1 by the launch)
+    // hand-over between row segments: carry row of W doubles and a flag per (image, plane, boundary)
+    const size_t xslot = ((size_t)blockIdx.z * 3 + pl) * (size_t)(nseg > 1 ? nseg - 1 : 1);
+    double *xc_out = xc + (xslot + seg) * (size_t)W; int *xf_out = xf + xslot + seg;                  // published by this segment's last wave (seg + 1 < nseg)
+    const double *xc_in = xc + (xslot + seg - 1) * (size_t)W; int *xf_in = xf + xslot + seg - 1;       // taken by this segment's wave 0 (seg > 0)
     const int ncb = (W + CF_W - 1) / CF_W;
     const unsigned voff = (unsigned)(cg * P + 2 * rp);
     double raw[4][8];
@@ -1240,6 +1254,14 @@ __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, 
         cf_load_block(plane, P, cb + 1 < ncb ? x0 + CF_W : x0, r0, voff, raw);       // next block (the last iteration re-reads, unused)
         // column sums of the band above
         double acc = 0.0;
+        if (w == 0 && seg > 0) {
+            // (no agent-scope fences: an acquire would invalidate the XCD's L2 under every workgroup on it, a release write it back, once per
+            //  block -- measured 6.5 vs 5.0 ms per 32-image build.  The carries and the flag are agent-scope atomics, which are performed at the
+            //  memory side; the producer's s_waitcnt vmcnt(0) orders them)
+            if (lane == 0) while (__hip_atomic_load(xf_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= cb) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (lane < CF_W && x0 + lane < W) acc = __hip_atomic_load(xc_in + x0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (w > 0) {
             while (flag_ld(&s_ready[w - 1]) <= cb) __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -1251,7 +1273,7 @@ __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, 
         // (b) column sums, lane = column
         if (lane < CF_W) {
             ldsd *c = Cb + lane * CF_LS;
-            if (hr == 64 && w > 0) {
+            if (hr == 64 && r0 > 0) {
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     double v[32];
@@ -1266,11 +1288,16 @@ __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, 
                 for (int e = 0; e < hr; e++) { acc = (r0 + e == 0) ? c[e] : acc + c[e]; c[e] = acc; }
             }
         }
-        if (w + 1 < nw) {                                         // publish the bottom row's sums to the band below
+        if (w + 1 < nwh) {                                        // publish the bottom row's sums to the band below
             while (flag_ld(&s_done[w + 1]) + 2 <= cb) __builtin_amdgcn_s_sleep(1);
             if (lane < CF_W) carry_out[(cb & 1) * CF_W + lane] = acc;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             if (lane == 0) flag_st(&s_ready[w], cb + 1);
+        }
+        else if (seg + 1 < nseg) {                                // ... or to the segment below, through global memory
+            if (lane < CF_W && x0 + lane < W) __hip_atomic_store(xc_out + x0 + lane, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the carries have arrived before the flag leaves
+            if (lane == 0) __hip_atomic_store(xf_out, cb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         // (c) row sums across the block's columns, lane = row
@@ -1308,6 +1335,7 @@ __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
+    if (w == 0 && seg > 0 && lane == 0) __hip_atomic_store(xf_in, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every block consumed: clear for the next launch
 }
 
 // ---- tolerance mode ("fast", mode 3): parallel recurrences -------------------------
@@ -2251,10 +2279,13 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             B.launch(k_resize, dim3(((size_t)p->H[l + 1] * p->W[l + 1] + 255) / 256, 1, S), dim3(256), 0, LN_MAIN,
                                nextL, p->H[l + 1], p->W[l + 1], p->P[l + 1], (const double *)T, H, W, P, zs);
         static const bool no_fused_cum = getenv("SLAMHIP_NO_FUSED_CUM") != nullptr;
-        if (Sall >= 8 && !no_fused_cum && H <= CF_MAXW * 64) {                 // batches: one-pass integral image
-            const int nw = (H + 63) / 64;
+        const int cf_bands = (H + 63) / 64;
+        const int cf_seg = cf_bands <= CF_MAXW ? 1 : (cf_bands + CF_SEGW - 1) / CF_SEGW;      // taller planes: row segments of CF_SEGW bands, one workgroup each, chained through p->alloc->xc
+        if (Sall >= 8 && !no_fused_cum && (cf_seg == 1 || (p->alloc->xc != nullptr && cf_seg <= p->alloc->xseg))) {      // batches: one-pass integral image
+            const int nw = cf_seg == 1 ? cf_bands : CF_SEGW;
             const size_t lds = ((size_t)nw * CF_W * CF_LS + (size_t)nw * 2 * CF_W) * sizeof(double);
-            B.launch(k_cum_fused, dim3(1, 3, S), dim3(nw * 64), lds, LN_AUX, pc, H, W, P);
+            const size_t xo = (size_t)z0 * 3 * (size_t)(cf_seg > 1 ? cf_seg - 1 : 1);
+            B.launch(k_cum_fused, dim3(cf_seg, 3, S), dim3(nw * 64), lds, LN_AUX, pc, H, W, P, p->alloc->xc ? p->alloc->xc + xo * W : (double *)nullptr, p->alloc->xf ? p->alloc->xf + xo : (int *)nullptr);
             return;
         }
         if (S == 1) B.launch(k_cum_cols<3>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, side_cum, pc, H, W, P);
@@ -2412,6 +2443,14 @@ static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, 
         // column totals of the tolerance build's suffix-sum planes: 3 planes x S images x W_l doubles per level
         size_t wsum = 0; for (int l = 0; l < levels; l++) wsum += (size_t)Ws[l];
         if (hipMalloc((void **)&al->tot, (size_t)3 * S * wsum * 8) != hipSuccess) { (void)hipGetLastError(); al->tot = nullptr; }
+        // frames taller than one k_cum_fused workgroup (512 rows): carry rows + flags of its row segments (level 0 sizes them; the coarser levels fit)
+        const int xbands = (Hs[0] + 63) / 64, xseg = xbands <= CF_MAXW ? 1 : (xbands + CF_SEGW - 1) / CF_SEGW;
+        if (xseg > 1) {
+            const size_t nslot = (size_t)S * 3 * (xseg - 1);
+            if (hipMalloc((void **)&al->xc, nslot * Ws[0] * 8) != hipSuccess) { (void)hipGetLastError(); al->xc = nullptr; }
+            if (al->xc && (hipMalloc((void **)&al->xf, nslot * 4) != hipSuccess || hipMemset(al->xf, 0, nslot * 4) != hipSuccess)) { (void)hipGetLastError(); (void)hipFree(al->xc); al->xc = nullptr; al->xf = nullptr; }
+            if (al->xc) al->xseg = xseg;
+        }
     }
     for (int s = 0; s < S; s++) {
         slam_pyr *p = new slam_pyr();
@@ -2485,7 +2524,7 @@ int slam_pyr_destroy(slam_pyr *p)
     if (!p) return SLAM_OK;
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
-    if (p->alloc && --p->alloc->refs == 0) { (void)hipFree(p->alloc->base); if (p->alloc->ck) (void)hipFree(p->alloc->ck); if (p->alloc->tot) (void)hipFree(p->alloc->tot); if (p->alloc->srctab) (void)hipFree(p->alloc->srctab); delete p->alloc; }
+    if (p->alloc && --p->alloc->refs == 0) { (void)hipFree(p->alloc->base); if (p->alloc->ck) (void)hipFree(p->alloc->ck); if (p->alloc->tot) (void)hipFree(p->alloc->tot); if (p->alloc->xc) (void)hipFree(p->alloc->xc); if (p->alloc->xf) (void)hipFree(p->alloc->xf); if (p->alloc->srctab) (void)hipFree(p->alloc->srctab); delete p->alloc; }
     if (p->norm) (void)hipFree(p->norm);
     for (auto &g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     delete p;

@@ -170,8 +170,8 @@ def test_batch_u8_ingest_equals_float_ingest(slam, syn):
 
 
 def test_batch_at_fhd_size_stays_exact(slam):
-    """BASELINE config 5 shape (1080 x 1920): above the 512-row limit of the one-pass integral kernel (falls back to
-    k_cum_cols + k_cum_rows) and far above the bandwidth threshold (checkpointed IIR kernels at levels 0-2)."""
+    """BASELINE config 5 shape (1080 x 1920): above the 512 rows one workgroup of the one-pass integral kernel covers (levels 0 and 1 run
+    it as chained row segments) and far above the bandwidth threshold (checkpointed IIR kernels at levels 0-2)."""
     import torch
     H, W, S = 1080, 1920, 8
     rng = np.random.default_rng(5)
@@ -190,6 +190,27 @@ def test_batch_at_fhd_size_stays_exact(slam):
         for l in range(4):
             for name in PLANES:
                 assert np.array_equal(batch.pyramids[s].plane(name, l), single.plane(name, l)), (s, name, l)
+
+
+@pytest.mark.parametrize("H,W", [(513, 70), (577, 33), (777, 96), (1025, 130), (1100, 64), (2000, 40)])
+def test_tall_planes_take_the_integral_kernel_in_chained_row_segments(slam, orc, H, W):
+    """k_cum_fused beyond 512 rows: row segments of 256 rows, one workgroup each, the band chain carried through global memory -- every
+    plane of every level against the oracle, twice (the hand-over flags must be clear again for the replay), incl. a one-band last segment"""
+    import torch
+    S = 8
+    rng = np.random.default_rng(H + W)
+    imgs = [np.asfortranarray(np.round(rng.random((H, W)) * 255).astype(np.uint8)) for _ in range(S)]
+    dev = [torch.from_numpy(np.ascontiguousarray(im.T)).cuda() for im in imgs]
+    torch.cuda.synchronize()
+    levels = 3
+    batch = slam.PyramidBatch((H, W), levels=levels, S=S)
+    for rep in range(2):
+        batch.update_([d.data_ptr() for d in dev], u8=True)
+        for s in (0, S - 1):
+            ref = orc.pyr_build(np.asfortranarray(imgs[s].astype(np.float64) / 255.0), levels, 1.0, 1)
+            for l in range(levels + 1):
+                for name in PLANES:
+                    assert np.array_equal(batch.pyramids[s].plane(name, l), ref.plane(name, l)), (rep, s, name, l)
 
 
 def test_flow_match_batch_kept_is_the_compaction_of_flow_match_batch(slam, texture):
