@@ -1212,6 +1212,8 @@ __device__ __forceinline__ void cf_load_block(const double *plane, int P, int x0
 // memory (xc, agent-scope stores + a counting flag per (image, plane, boundary)), wave 0 of segment g + 1 takes them as its carry.  A
 // segment only ever waits for a workgroup with a smaller blockIdx.x (dispatched before it); the consumer zeroes the flag when it is done,
 // so a replay of the launch finds it clear.  Same sums in the same order as one workgroup would form them.
+// (SEG = false: the single-workgroup kernel, compiled without the hand-over code -- with it the 6-band launches of the 370-row frames ran 1-3 % slower)
+template <bool SEG>
 __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, int W, int P, double *xc, int *xf)
 {
     extern __shared__ __attribute__((aligned(16))) double cf_lds[];          // [nw][CF_W * CF_LS] blocks, then [nw][2][CF_W] column carries
@@ -1231,9 +1233,9 @@ __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, 
     auto flag_st = [](int *f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     if (lane == 0) { flag_st(&s_ready[w], 0); flag_st(&s_done[w], 0); }
     __syncthreads();
-    const int seg = blockIdx.x, nseg = gridDim.x;
-    const int nwh = min(nw, (H - seg * nw * 64 + 63) / 64);           // bands of this segment: nw = blockDim.x / 64 per segment, the last one may be short
-    if (w >= nwh) return;                                         // (after the one workgroup barrier of the kernel)
+    const int seg = SEG ? (int)blockIdx.x : 0, nseg = SEG ? (int)gridDim.x : 1;
+    const int nwh = SEG ? min(nw, (H - seg * nw * 64 + 63) / 64) : nw;           // bands of this segment: nw = blockDim.x / 64 per segment, the last one may be short
+    if (SEG && w >= nwh) return;                                  // (after the one workgroup barrier of the kernel)
     const int r0 = (seg * nw + w) * 64, hr = H - r0 < 64 ? H - r0 : 64;       // rows of this band that exist (>= 1 by the launch)
     // hand-over between row segments: carry row of W doubles and a flag per (image, plane, boundary)
     const size_t xslot = ((size_t)blockIdx.z * 3 + pl) * (size_t)(nseg > 1 ? nseg - 1 : 1);
@@ -1254,7 +1256,7 @@ __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, 
         cf_load_block(plane, P, cb + 1 < ncb ? x0 + CF_W : x0, r0, voff, raw);       // next block (the last iteration re-reads, unused)
         // column sums of the band above
         double acc = 0.0;
-        if (w == 0 && seg > 0) {
+        if (SEG && w == 0 && seg > 0) {
             // (no agent-scope fences: an acquire would invalidate the XCD's L2 under every workgroup on it, a release write it back, once per
             //  block -- measured 6.5 vs 5.0 ms per 32-image build.  The carries and the flag are agent-scope atomics, which are performed at the
             //  memory side; the producer's s_waitcnt vmcnt(0) orders them)
@@ -1273,7 +1275,7 @@ __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, 
         // (b) column sums, lane = column
         if (lane < CF_W) {
             ldsd *c = Cb + lane * CF_LS;
-            if (hr == 64 && r0 > 0) {
+            if (hr == 64 && (SEG ? r0 > 0 : w > 0)) {
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     double v[32];
@@ -1294,7 +1296,7 @@ __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             if (lane == 0) flag_st(&s_ready[w], cb + 1);
         }
-        else if (seg + 1 < nseg) {                                // ... or to the segment below, through global memory
+        else if (SEG && seg + 1 < nseg) {                         // ... or to the segment below, through global memory
             if (lane < CF_W && x0 + lane < W) __hip_atomic_store(xc_out + x0 + lane, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the carries have arrived before the flag leaves
             if (lane == 0) __hip_atomic_store(xf_out, cb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1335,7 +1337,7 @@ __global__ __launch_bounds__(CF_MAXW * 64) void k_cum_fused(PlaneSet ps, int H, 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
-    if (w == 0 && seg > 0 && lane == 0) __hip_atomic_store(xf_in, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every block consumed: clear for the next launch
+    if (SEG && w == 0 && seg > 0 && lane == 0) __hip_atomic_store(xf_in, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every block consumed: clear for the next launch
 }
 
 // ---- tolerance mode ("fast", mode 3): parallel recurrences -------------------------
@@ -2285,7 +2287,8 @@ static void launch_level(slam_ctx *ctx, slam_pyr *p, int mode, const IIRPair &cf
             const int nw = cf_seg == 1 ? cf_bands : CF_SEGW;
             const size_t lds = ((size_t)nw * CF_W * CF_LS + (size_t)nw * 2 * CF_W) * sizeof(double);
             const size_t xo = (size_t)z0 * 3 * (size_t)(cf_seg > 1 ? cf_seg - 1 : 1);
-            B.launch(k_cum_fused, dim3(cf_seg, 3, S), dim3(nw * 64), lds, LN_AUX, pc, H, W, P, p->alloc->xc ? p->alloc->xc + xo * W : (double *)nullptr, p->alloc->xf ? p->alloc->xf + xo : (int *)nullptr);
+            if (cf_seg == 1) B.launch(k_cum_fused<false>, dim3(1, 3, S), dim3(nw * 64), lds, LN_AUX, pc, H, W, P, (double *)nullptr, (int *)nullptr);
+            else B.launch(k_cum_fused<true>, dim3(cf_seg, 3, S), dim3(nw * 64), lds, LN_AUX, pc, H, W, P, p->alloc->xc + xo * W, p->alloc->xf + xo);
             return;
         }
         if (S == 1) B.launch(k_cum_cols<3>, lines_grid(W, 3, S), dim3(LINE_THREADS), 0, side_cum, pc, H, W, P);
@@ -2428,7 +2431,8 @@ static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, 
     if (S > 1 && hipMalloc((void **)&al->srctab, BATCH_MAX * sizeof(void *)) != hipSuccess) { (void)hipGetLastError(); al->srctab = nullptr; }
     // once per creation, outside any stream capture: k_cum_fused needs the > 64 KB dynamic-LDS opt-in
     {
-        const hipError_t ea = hipFuncSetAttribute((const void *)k_cum_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipError_t ea = hipFuncSetAttribute((const void *)k_cum_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (ea == hipSuccess) ea = hipFuncSetAttribute((const void *)k_cum_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (ea != hipSuccess) { (void)hipFree(al->base); delete al; return slam_fail(ctx, SLAM_ERR_HIP, "slam_pyr_create: hipFuncSetAttribute(k_cum_fused): %s", hipGetErrorString(ea)); }
     }
     double *ckbuf = nullptr;
