@@ -2343,7 +2343,7 @@ __global__ __launch_bounds__(256) void k_outlier_count(BADev d, int nb_obs) { ou
 // kernel argument lives (a generic pointer into the table moved the plane pointers into VGPRs and reloaded them after every store) --
 // and the grid's x extent is the largest window's: workgroups beyond a window's own count leave at once.  Every window runs its own
 // device-side LM state; a converged window's workgroups early-out as in the single-window path.
-struct BAWin { BADev d; BandArgs B; int nb_obs, nb_pts, n_red, pad; };      // pad = 1: the window runs in k_ba_window (one workgroup, all iterations)
+struct BAWin { BADev d; BandArgs B; int nb_obs, nb_pts, n_red, pad; int ksplit, pad2; double *bwx; };   // ksplit / bwx: k_ba_window on TWO workgroups -- the first map point (sorted order) of the second one, their exchange area      // pad = 1: the window runs in k_ba_window (one workgroup, all iterations)
 static_assert(sizeof(BAWin) % 8 == 0, "BAWin is copied as 64-bit words");
 __device__ __forceinline__ BAWin ba_win(const BAWin *tab)
 {
@@ -2475,9 +2475,10 @@ __global__ __launch_bounds__(256) void k_results_b(const BAWin *tab, const BARes
 #define BW_FMAX 5
 #define BW_PMAX 128
 #define BW_OMAX 40000
-#define BW_HC 336                   // free-pose observation records (W 18, Jp 12, gradient 6 doubles) per chunk
+#define BW_HC 352                   // free-pose observation records (W 18, Jp 12, gradient 6 doubles) per chunk (the reference's window: ~690 records = two chunks)
 #define BW_PC 256                   // points per chunk
 #define BW_WOB 168                  // phase A: observations per wave and trip (BW_WOB x 9 doubles x 8 waves = the record region)
+#define BWX_DOUBLES (8 + 2 * 2 * 832)  // exchange area of a window on two workgroups: flags, then [half][buffer][32 lanes x 25 + scalars]
 #define BW_FIXED_DBL(P) ((size_t)15 * (P) + 31 * 30 + 32 + 32 + 32 + 2 + (size_t)BW_PC * 10)
 static size_t bw_lds_bytes(int P)
 {
@@ -2508,11 +2509,20 @@ __device__ __forceinline__ double bw_max(double v, double *sh)
     return t;
 }
 __device__ __forceinline__ void bw_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
-__global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int *list, int iters_fast, int iterations, double repr_eps, double depth_eps)
+// TWO WORKGROUPS PER WINDOW (two != 0; 128 windows then use all 256 compute units): workgroups b and b + 8 (same XCD) share window
+// (b & 7) + 8 (b >> 4); half h takes the map points [0, ksplit) / [ksplit, M) and their observations through every phase, and the two
+// exchange (a) the folded partials of the reduced system once per iteration -- both then assemble and solve it, identically --, (b) the
+// three sums behind the step decision, (c) the cost at the start of a pass and the outlier count.  The LM state is a copy in LDS that
+// both advance identically (half 0 writes it back at the end).  Exchanges go through a double-buffered area in global memory: values and
+// a counting flag as agent-scope atomics (performed at the memory side), ordered by s_waitcnt vmcnt(0) -- no cache write-back or invalidate.
+__global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int *list, int ns, int two, int iters_fast, int iterations, double repr_eps, double depth_eps)
 {
+    const int half = two ? (int)((blockIdx.x >> 3) & 1) : 0;
+    const int widx = two ? (int)((blockIdx.x & 7) + 8 * (blockIdx.x >> 4)) : (int)blockIdx.x;
+    if (widx >= ns) return;
     BAWin w;
     {   typedef const __attribute__((address_space(4))) unsigned long long *cq_t;
-        cq_t q = (cq_t)(const void *)(tab + list[blockIdx.x]);
+        cq_t q = (cq_t)(const void *)(tab + list[widx]);
         unsigned long long raw[sizeof(BAWin) / 8];
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(BAWin) / 8); k++) raw[k] = q[k];
@@ -2521,7 +2531,6 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
     extern __shared__ __attribute__((aligned(16))) double bw_sm[];
     const int tid = threadIdx.x;
     const int P = d.P, M = d.M, O = d.O, p0 = w.B.p0, F = w.B.nb, n = 6 * F, nwin = F * (F + 1) / 2, NF = d.pfs[M];
-    LMState *s = d.st;
     double *s_sc = bw_sm;                              // [P][6] sin / cos of the committed poses' angles
     double *s_sct = s_sc + 6 * P;                      // [P][6] of the trial poses
     double *s_tr = s_sct + 6 * P;                      // [P][3] committed translations
@@ -2544,6 +2553,44 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
     { int r = w2; while (ba_ < F && r >= F - ba_) { r -= F - ba_; ba_++; } bb_ = ba_ + r; }
     const bool live = w2 < nwin, xl = wl < n;
     const int a2 = xl ? wl / 6 : 0, r2 = wl - 6 * (wl / 6);
+    __shared__ LMState s_lm;                           // the LM state lives HERE for the whole solve (both halves of a split window advance their copies identically)
+    LMState *s = &s_lm;
+    if (tid == 0) s_lm = *d.st;
+    // this workgroup's map points [kLo, kHi) (sorted order) and observations [oLo, oHi)
+    const int kLo = two && half ? w.ksplit : 0, kHi = two && !half ? w.ksplit : M;
+    const int oLo = d.pt_start[kLo], oHi = d.pt_start[kHi];
+    // exchange with the other half: own values -> area [half][e & 1], flag[half] = e; wait for flag[1 - half] >= e; the sums are own + other
+    int xe = 0;
+    int *xflag = (int *)w.bwx;
+    auto xarea = [&](int h, int e) { return w.bwx + 8 + (size_t)(2 * h + (e & 1)) * 832; };
+    auto xpost = [&](int e) {          // (called by the wave that wrote the values)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((tid & 63) == 0) __hip_atomic_store(xflag + half, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto xwait = [&](int e) {
+        if ((tid & 63) == 0) while (__hip_atomic_load(xflag + (1 - half), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    };
+    // three scalars (two sums, one maximum) across the halves; every thread holds the workgroup's values on entry and the window's on return
+    auto xscal = [&](double &a, double &b, double &c) {
+        if (!two) return;
+        const int e = ++xe;
+        if (tid == 0) {
+            double *o = xarea(half, e) + 800;
+            __hip_atomic_store(o, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(o + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(o + 2, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid < 64) {
+            xpost(e); xwait(e);
+            if (tid == 0) {
+                const double *q = xarea(1 - half, e) + 800;
+                const double a1 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c1 = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_red[8] = half ? a1 + a : a + a1; s_red[9] = half ? b1 + b : b + b1; s_red[10] = fmax(c, c1);      // (half 0's value first on both sides: the same bits)
+            }
+        }
+        __syncthreads();
+        a = s_red[8]; b = s_red[9]; c = s_red[10];
+        __syncthreads();
+    };
     for (int p = tid; p < P; p += BW_T) s_const[p] = d.pconst[p];
     // phase A's chunks: npc consecutive map points (sorted order) per wave and trip, at most BW_WOB observations (d.sg_ob = most observations of one point)
     const int npc_a = max(1, min(64, BW_WOB / d.sg_ob));
@@ -2558,16 +2605,18 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
         }
     };
 
+    auto pbufs = [&]() { const bool sw = s->cur != 0; return ParamBufs{sw ? d.pose_t : d.pose, sw ? d.pts_t : d.pts, sw ? d.pose : d.pose_t, sw ? d.pts : d.pts_t}; };
+    __syncthreads();
     for (int pass = 0; pass < 2; pass++) {
         const int ignore = pass, iters = pass ? iterations : iters_fast;
         // ---- cost at the committed parameters (LeastSquaresOptim evaluates f!(fcur, x) first)
         {
-            const ParamBufs pb = param_bufs(d);
+            const ParamBufs pb = pbufs();
             __syncthreads();
             stage_poses(pb);
             __syncthreads();
             double ss = 0.0;
-            for (int i = tid; i < O; i += BW_T) {
+            for (int i = oLo + tid; i < oHi; i += BW_T) {
                 if (ignore && d.outl[i]) continue;
                 const int p = d.opose[i], j = d.opoint[i];
                 const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
@@ -2575,7 +2624,8 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
                 obs_eval_sc(s_sc + 6 * p, s_tr + 3 * p, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, nullptr);
                 ss += r[0] * r[0] + r[1] * r[1];
             }
-            const double t = bw_sum(ss, s_red);
+            double t = bw_sum(ss, s_red), tz1 = 0.0, tz2 = 0.0;
+            xscal(t, tz1, tz2);
             if (tid == 0) {
                 s->ssr = t;
                 if (pass == 0) { s->ssr_init = t; s->chol_fail = 0; s->n_outliers = 0; }
@@ -2585,7 +2635,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
         }
         for (int it = 1; it <= iters; it++) {
             if (s->converged) break;                           // (uniform: every thread reads the flag after a barrier)
-            const ParamBufs pb = param_bufs(d);
+            const ParamBufs pb = pbufs();
             const double inv_delta = 1.0 / s->delta;
             BW_CLK(0);
             stage_poses(pb);
@@ -2599,8 +2649,8 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
             {
                 const int wvA = tid >> 6, ln = tid & 63;
                 double *s_w9 = s_W + (size_t)wvA * BW_WOB * 9;
-                for (int k0 = wvA * npc_a; k0 < M; k0 += (BW_T / 64) * npc_a) {
-                    const int k1 = min(M, k0 + npc_a), o0 = d.pt_start[k0], nobs = d.pt_start[k1] - o0;
+                for (int k0 = kLo + wvA * npc_a; k0 < kHi; k0 += (BW_T / 64) * npc_a) {
+                    const int k1 = min(kHi, k0 + npc_a), o0 = d.pt_start[k0], nobs = d.pt_start[k1] - o0;
                     for (int t = ln; t < nobs; t += 64) {
                         const int i = o0 + t;
                         const int p = d.opose[i], j = d.opoint[i];
@@ -2651,10 +2701,10 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
             for (int k = 0; k < 18; k++) acc[k] = 0.0;
 #pragma unroll
             for (int k = 0; k < 7; k++) ex[k] = 0.0;
-            for (int k0 = 0; k0 < M;) {
+            for (int k0 = kLo; k0 < kHi;) {
                 // the chunk [k0, k1): <= BW_PC points, <= BW_HC records (pfs = running count of free-pose observations by sorted point)
                 const int base = d.pfs[k0];
-                int lo = k0 + 1, hi = min(M, k0 + BW_PC);
+                int lo = k0 + 1, hi = min(kHi, k0 + BW_PC);
                 while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (d.pfs[mid] - base <= BW_HC) lo = mid; else hi = mid - 1; }
                 const int k1 = lo, npc = k1 - k0, nrec = d.pfs[k1] - base;
                 if (nrec == 0) { k0 = k1; continue; }                    // no point of the chunk sees a free pose
@@ -2756,6 +2806,26 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
                         for (int k = 0; k < 7; k++) ex[k] += s_fold[(size_t)q * fstride + 32 * 18 + wl * 7 + k];
                     }
             }
+            if (two) {                                         // ... and the other half's: own + other, lane by lane (wave 0; every lane of the 32 writes all its 25 values)
+                const int e = ++xe;
+                if (tid < 64) {
+                    if (tid < 32) {
+                        double *o = xarea(half, e) + wl * 25;
+#pragma unroll
+                        for (int k = 0; k < 18; k++) __hip_atomic_store(o + k, acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int k = 0; k < 7; k++) __hip_atomic_store(o + 18 + k, ex[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    xpost(e); xwait(e);
+                    if (tid < 32) {
+                        const double *q = xarea(1 - half, e) + wl * 25;
+#pragma unroll
+                        for (int k = 0; k < 18; k++) { const double v = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); acc[k] = half ? v + acc[k] : acc[k] + v; }
+#pragma unroll
+                        for (int k = 0; k < 7; k++) { const double v = __hip_atomic_load(q + 18 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ex[k] = half ? v + ex[k] : ex[k] + v; }
+                    }
+                }
+            }
             __syncthreads();                                   // the fold buffer is read: the system goes where no partial lives (s_A)
             // ---- S: wave 0 alone assembles and solves (wave-synchronous LDS: a wave's DS instructions execute in order)
             if (tid < 64) {
@@ -2844,7 +2914,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
                     pose_sincos(tp, s_sct + 6 * p);
                 }
             }
-            for (int k = tid; k < M; k += BW_T) {
+            for (int k = kLo + tid; k < kHi; k += BW_T) {
                 const int j = d.pt_id[k];
                 double bl[3] = {d.bl[k], d.bl[(size_t)M + k], d.bl[(size_t)2 * M + k]};
                 for (int rec = d.pfs[k]; rec < d.pfs[k + 1]; rec++) {      // the point's observations of free poses (host list): bl -= Jl' (Jp dp)
@@ -2872,7 +2942,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
             __syncthreads();
             // ---- C2: thread = observation: trial and predicted residuals
             double st = 0.0, sp = 0.0;
-            for (int i = tid; i < O; i += BW_T) {
+            for (int i = oLo + tid; i < oHi; i += BW_T) {
                 const int p = d.opose[i], j = d.opoint[i];
                 const bool active = !(ignore && d.outl[i]);
                 double jl[6], ff[2], r[2] = {0.0, 0.0}, pa = 0.0, pbv = 0.0;
@@ -2898,12 +2968,13 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
                 sp += pa * pa + pbv * pbv;
             }
             BW_CLK(6);
-            const double tt = bw_sum(st, s_red), tp = bw_sum(sp, s_red), tm = bw_max(mx, s_red);
+            double tt = bw_sum(st, s_red), tp = bw_sum(sp, s_red), tm = bw_max(mx, s_red);
+            xscal(tt, tp, tm);
             // ---- D
             if (tid == 0) { s->trial_ssr = tt; s->pred_ssr = tp; s->maxdx = tm; lm_decide(s, tt, tp, tm); }
             __syncthreads();
 #ifdef BW_TRACE
-            if (tid == 0 && blockIdx.x == 5 && pass == 0 && it == 3) { bw_clk[7] = clock64();
+            if (tid == 0 && (blockIdx.x == 5 || blockIdx.x == 13) && pass == 0 && it == 3) { bw_clk[7] = clock64();
                 printf("k_ba_window (M %d, O %d, F %d, %d free-pose observations): sincos %lld | A %lld | B chunks %lld | fold %lld | solve %lld | C %lld | reduce + decide %lld cycles\n", M, O, F, NF,
                        bw_clk[1] - bw_clk[0], bw_clk[2] - bw_clk[1], bw_clk[3] - bw_clk[2], bw_clk[4] - bw_clk[3], bw_clk[5] - bw_clk[4], bw_clk[6] - bw_clk[5], bw_clk[7] - bw_clk[6]); }
 #endif
@@ -2912,11 +2983,11 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
         if (pass == 0) {
             // ---- _ba_detect_outliers! at theta_1 (bundle_adjustment.jl:90-111)
             __syncthreads();
-            const ParamBufs pb = param_bufs(d);
+            const ParamBufs pb = pbufs();
             stage_poses(pb);
             __syncthreads();
             double cnt = 0.0;
-            for (int i = tid; i < O; i += BW_T) {
+            for (int i = oLo + tid; i < oHi; i += BW_T) {
                 const int p = d.opose[i], j = d.opoint[i];
                 const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
                 double r[2], z;
@@ -2925,11 +2996,14 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
                 d.outl[i] = out ? 1 : 0;
                 cnt += out ? 1.0 : 0.0;
             }
-            const double tc = bw_sum(cnt, s_red);
+            double tc = bw_sum(cnt, s_red), tz1 = 0.0, tz2 = 0.0;
+            xscal(tc, tz1, tz2);
             if (tid == 0) s->n_outliers = (int)tc;
             __syncthreads();
         }
     }
+    __syncthreads();
+    if (tid == 0 && half == 0) *d.st = s_lm;
 }
 
 // ---------------------------------------------------------------------------------
@@ -3040,7 +3114,8 @@ struct BAPlan {
     // layout: offsets inside the three regions
     size_t o_pose, o_pts, o_const, o_pix, o_opose, o_opoint, o_start, o_ptid, o_opk, o_ohp, o_pfs, o_fobs, o_grp, o_fgrp, o_pairs, o_bs, o_bpq, up_bytes = 0;
     int sg_hp = SG_OB;
-    size_t o_st, o_cf, o_outl, zero_bytes = 0;
+    size_t o_st, o_cf, o_outl, o_bwx = 0, zero_bytes = 0;
+    int ksplit = 0;
     size_t o_pose_t, o_pts_t, o_hasp, o_f, o_ft, o_Jp, o_Jl, o_Vinv, o_bl, o_T, o_W, o_red, o_Sw, o_dp, o_dl, o_li, o_lf, o_part, o_band, o_wpart, o_xchg, work_bytes = 0;
     ~BAPlan() { delete ba; }
     int lab(int64_t id) const { return new_of.empty() ? (int)id - 1 : new_of[id - 1]; }
@@ -3242,6 +3317,11 @@ static int ba_plan(BAPlan &pl)
     pl.up_bytes = off; off = 0;
     pl.o_st = take(sizeof(LMState)); pl.o_cf = take(64); pl.o_outl = take((size_t)O + 1);
     pl.o_dp = take(n * 8);                                       // dp of the constant poses outside the solve's span stays zero
+    if (pl.window) {                                             // k_ba_window on two workgroups: flags + two double-buffered partials of 32 x 25 doubles each (zeroed: the flags count exchanges)
+        pl.o_bwx = take(BWX_DOUBLES * 8);
+        pl.ksplit = (int)(std::lower_bound(start.begin(), start.end(), (O + 1) / 2) - start.begin());
+        pl.ksplit = std::min(std::max(pl.ksplit, 0), M);
+    }
     pl.o_red = take(((size_t)n * n + 2 * n + 8) * 8);            // the private reduce buffer: only its band is ever rewritten
     pl.zero_bytes = off; off = 0;
     pl.o_pose_t = take(n * 8); pl.o_pts_t = take((size_t)3 * M * 8 + 8); pl.o_hasp = take((size_t)O + 1);
@@ -3847,6 +3927,16 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
             w.B.nb = Ps; w.B.hb = hb; w.B.p0 = p0; w.B.inv_delta_host = 0.0; w.B.fail = b->chol_flag; w.B.trace = nullptr;
             w.B.lds_bytes = (int)band_lds_bytes(n, Ps, hb); w.B.xchg = b->xchg; w.B.epoch = 1; w.B.shift = 0;
             w.nb_obs = b->nblocks_obs; w.nb_pts = b->nblocks_pts; w.n_red = (w.d.P * (w.d.whb + 1) * 36 + w.d.P * 12 + 255) / 256;
+            w.ksplit = q.ksplit; w.bwx = q.window ? (double *)(A + zero_base + ze[k] + q.o_bwx) : nullptr;
+            if (q.window && q.M > 1) {
+                // the split point of k_ba_window's two workgroups: an observation costs the evaluation phases ~24 cycles, an observation of a FREE
+                // pose ~6.5 times that in the Schur phase (phase clocks, BW_TRACE) -- and those sit at one end of the sorted points: split by cost
+                const int *pfs = (const int *)(stage + up[k] + q.o_pfs);
+                const long total = 2L * q.O + 13L * pfs[q.M];
+                int kk = 0;
+                while (kk < q.M && 2 * (2L * q.start[kk] + 13L * pfs[kk]) < total) kk++;
+                w.ksplit = std::min(std::max(kk, 1), q.M - 1);
+            }
             BARes &r = rtab_h[k];
             r.off_state = res_base + rs[k]; r.off_theta = r.off_state + al(sizeof(LMState)); r.off_outl = r.off_theta + al((6 * (size_t)q.P + 3 * (size_t)q.M) * 8 + 8);
         });
@@ -3919,7 +4009,12 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
             static std::atomic<bool> bw_attr[64];
             if (!bw_attr[dv].load(std::memory_order_acquire)) { e = hipFuncSetAttribute((const void *)k_ba_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bw_lds_bytes(BW_PMAX)); bw_attr[dv].store(true, std::memory_order_release); }
             const int *list_d = (const int *)(A + tab_bytes + rtab_bytes - al((size_t)NB * 4));
-            if (e == hipSuccess) hipLaunchKernelGGL(k_ba_window, dim3(NS_), dim3(BW_T), lds_bw, st, tab, list_d, iters_fast, iterations, repr_eps, 1e-6);
+            // two workgroups per window while both halves of every window are resident at once (one workgroup per compute unit: 2 NS <= the
+            // context's compute units; the halves wait for each other), SLAMHIP_BA_WINDOW_ONE=1: always one
+            static const bool bw_one = getenv("SLAMHIP_BA_WINDOW_ONE") != nullptr;
+            const int cus_avail = ctx->cus > 0 ? ctx->cus : 256;
+            const int two = (!bw_one && 16 * ((NS_ + 7) / 8) <= cus_avail) ? 1 : 0;
+            if (e == hipSuccess) hipLaunchKernelGGL(k_ba_window, dim3(two ? 16 * ((NS_ + 7) / 8) : NS_), dim3(BW_T), lds_bw, st, tab, list_d, NS_, two, iters_fast, iterations, repr_eps, 1e-6);
         }
         if (e == hipSuccess && !all_small) {
             run_pass(0, iters_fast);

@@ -42,6 +42,33 @@ def test_batch_equals_single_calls_and_oracle_on_ragged_windows(slam, orc, syn):
         assert np.array_equal(c.theta[:6 * P].reshape(P, 6)[cst], s["theta0"][:6 * P].reshape(P, 6)[cst]), z      # constant poses never move
 
 
+def test_window_kernel_on_one_and_on_two_workgroups_agree(slam, orc, syn):
+    """k_ba_window runs a window on TWO workgroups while both halves of every window fit the chip (<= 128 such windows per call), on one
+    otherwise: the same reference-shaped windows in a call of 9 and in a call of 137 (ragged: 5 / 3 / 1 free poses, few points, one
+    point) give the same outlier sets and iteration counts, costs and parameters to rounding; first and last against the oracle"""
+    base = [syn.ba_scene(P=25, M=800, seed=5, n_const=20), syn.ba_scene(P=25, M=300, seed=6, n_const=22), syn.ba_scene(P=12, M=90, seed=7, n_const=11),
+            syn.ba_scene(P=9, M=33, seed=8, n_const=4), syn.ba_scene(P=25, M=500, seed=9, n_const=21), syn.ba_scene(P=6, M=2, seed=10, n_const=3),
+            syn.ba_scene(P=7, M=1, seed=11, n_const=2), syn.ba_scene(P=30, M=1000, seed=12, n_const=25), syn.ba_scene(P=10, M=700, seed=13, n_const=5)]
+    few = [_cache(slam, s) for s in base]
+    st = slam.bundle_adjustment_batch_(few, [s["cam"] for s in base])
+    assert not st.any(), st
+    many_sc = [base[z % len(base)] for z in range(137)]
+    many = [_cache(slam, s) for s in many_sc]
+    st = slam.bundle_adjustment_batch_(many, [s["cam"] for s in many_sc])
+    assert not st.any(), st
+    for z, c in enumerate(many):
+        ref = few[z % len(base)]
+        assert np.array_equal(c.outliers, ref.outliers), z
+        assert c.stats["iters_pass1"] == ref.stats["iters_pass1"] and c.stats["iters_pass2"] == ref.stats["iters_pass2"], z
+        assert abs(c.stats["ssr_final"] - ref.stats["ssr_final"]) <= 1e-9 * ref.stats["ssr_final"], z
+        assert np.abs(c.theta - ref.theta).max() <= 1e-9 * max(1.0, np.abs(ref.theta).max()), z
+    for z in (0, len(base) - 1):
+        s = base[z]
+        th, ol, so = orc.bundle_adjustment(s["cam"], s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"], 5, 10, 5.0, solver=1)
+        assert np.array_equal(few[z].outliers, ol) and abs(few[z].stats["ssr_final"] - so["ssr_final"]) <= 1e-8 * so["ssr_final"], z
+        assert np.abs(few[z].theta - th).max() <= 1e-6 * max(1.0, np.abs(th).max()), z
+
+
 def test_batch_with_windows_outside_the_batch_kernels(slam, orc, syn):
     """a dense window (half-bandwidth 23: the general path), a loop-closure window (solved on relabelled poses), an all-constant window,
     an empty one and a regular one in the same call"""
