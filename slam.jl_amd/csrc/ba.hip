@@ -2864,14 +2864,20 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
 #pragma unroll
                 for (int jc = 0; jc < 6 * BW_FMAX; jc++) {
                     if (jc < n) {
-                        double sum = a[jc];
+                        // (four partial sums: a lone wave pays 36 cycles for a DEPENDENT Float64 operation, 9.5 for an independent one; 1 / sqrt from
+                        //  v_rsq_f64 + one Newton step, 4e-15 relative, as in k_band_solve -- the solve: 31 k -> 20 k cycles)
+                        double sq[4] = {a[jc], 0.0, 0.0, 0.0};
 #pragma unroll
                         for (int k = 0; k < jc; k++)
-                            sum -= a[k] * __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[k]), jc), __builtin_amdgcn_readlane(__double2loint(a[k]), jc));
+                            sq[k & 3] -= a[k] * __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[k]), jc), __builtin_amdgcn_readlane(__double2loint(a[k]), jc));
+                        const double sum = (sq[0] + sq[1]) + (sq[2] + sq[3]);
                         const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sum), jc), __builtin_amdgcn_readlane(__double2loint(sum), jc));
-                        if (!(piv > 0.0)) bad = true;
-                        const double ljj = sqrt(piv);
-                        a[jc] = tid == jc ? ljj : sum / ljj;
+                        const bool okp = piv > 0.0 && piv < 1e300;
+                        if (!okp) bad = true;
+                        const double pv = okp ? piv : 1.0;
+                        const double y0 = __builtin_amdgcn_rsq(pv);
+                        const double r0 = __builtin_fma(-(pv * y0), y0, 1.0), rd = __builtin_fma(y0 * 0.5, r0, y0);
+                        a[jc] = tid == jc ? pv * rd : sum * rd;
                     }
                 }
                 // L (rows 0 .. n - 1) and y' = (L^-1 g)' (row n) back to LDS; then lane i takes COLUMN i of L and the back-substitution
@@ -2882,7 +2888,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
                 }
                 bw_wave_sync();
                 double y = tid < n ? s_A[n * n + tid] : 0.0;
-                const double dg = tid < n ? s_A[tid * n + tid] : 1.0;
+                const double dg = 1.0 / (tid < n ? s_A[tid * n + tid] : 1.0);      // (one division per lane, all at once; the chain multiplies)
 #pragma unroll
                 for (int k = 0; k < 6 * BW_FMAX; k++) a[k] = (tid < n && k < n && k > tid) ? s_A[k * n + tid] : 0.0;      // a[k] = L[k][tid]
 #pragma unroll
@@ -2890,7 +2896,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
                     if (jc < n) {
                         const double yj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y), jc), __builtin_amdgcn_readlane(__double2loint(y), jc));
                         const double dj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dg), jc), __builtin_amdgcn_readlane(__double2loint(dg), jc));
-                        const double xj = yj / dj;
+                        const double xj = yj * dj;
                         if (tid == jc) y = xj;
                         if (tid < jc) y -= a[jc] * xj;
                     }
