@@ -602,7 +602,7 @@ def main():
             #      thread (third context), as SlamManager's task #3 does (estimator.jl:78-99) ----
             if head is not None or "headline" not in legs:
                 try:
-                    worker = BAWorker(slam, syn, local_rank, S, prio=int(os.environ.get("SLAM_BENCH_BA_PRIO", "0")))
+                    worker = BAWorker(slam, syn, local_rank, S, prio=int(os.environ.get("SLAM_BENCH_BA_PRIO", "1")))      # the estimator's context in the HIGH class: its short solve gets its compute units at once and is gone (0.93 -> 0.95-0.97 of the headline, A/B/A/B/A)
                     wb = run_lockstep_kpset(slam, torch, local_rank, wl, max(8, args.steps // 2), 2, world, dist, dev, "host_u8", ba=worker)
                     worker.close()
                     out["frontend_with_ba"] = {"value": wb["value"], "unit": "frames/sec", "ms_per_step": wb["ms_per_step"], "steps": wb["steps"], "local_ba": wb["local_ba"],
