@@ -2452,7 +2452,7 @@ __global__ __launch_bounds__(256) void k_results_b(const BAWin *tab, const BARes
 // ---- small windows: the WHOLE two-pass Levenberg-Marquardt of one window in ONE workgroup, one launch for the batch -------------------
 // The reference's window is at most 5 free key-frames and their constant observers (estimator.jl:327-331): the reduced camera system is
 // 30 x 30, a few hundred map points see a free pose at all, and the rest only move themselves.  Spread over the chip kernel by kernel
-// (above) such a window costs 5 launches per iteration whose workgroups are mostly latency; here a 1024-thread workgroup keeps the
+// (above) such a window costs 5 launches per iteration whose workgroups are mostly latency; here a 512-thread workgroup (or two: below) keeps the
 // window to itself for all 5 + 10 iterations -- no launch boundaries, the LM state never leaves the compute unit:
 //   A1 thread = observation (coalesced loads, pose data from LDS): residual + Jacobians, stored for the later phases
 //   A2 thread = map point: V = sum Jl'Jl + D, V^-1, bl over its (contiguous) observations -- loads only, no evaluation
@@ -2462,7 +2462,7 @@ __global__ __launch_bounds__(256) void k_results_b(const BAWin *tab, const BARes
 //   S  dense damped Cholesky of the <= 30 x 30 system by ONE wave (wave-synchronous LDS, no workgroup barriers), L y = g, L' dp = y
 //   C1 thread = map point: dl = V^-1 (bl - W' dp), trial point;  C2 thread = observation: trial and predicted residuals
 //   D  LeastSquaresOptim's accept / reject (lm_decide), on the device as everywhere
-// then the outlier flags between the passes.  128 such windows occupy 128 compute units at once.  Windows with more free poses, free
+// then the outlier flags between the passes.  128 such windows occupy 128 compute units at once (256 on two workgroups each).  Windows with more free poses, free
 // poses that are not consecutive, > 128 poses or > BW_OMAX observations take the batch kernels above.
 // (First version, thread = map point with a serial loop over its observations at 512 threads: 235 us per iteration -- two waves per
 //  SIMD cannot hide the dependent loads and the Float64 latency of ten evaluations in a row; slower than the kernels it replaces.)
