@@ -69,6 +69,26 @@ def test_window_kernel_on_one_and_on_two_workgroups_agree(slam, orc, syn):
         assert np.abs(few[z].theta - th).max() <= 1e-6 * max(1.0, np.abs(th).max()), z
 
 
+@pytest.mark.parametrize("ns", [1, 2, 7, 8, 9, 17, 64, 128])
+def test_window_kernel_at_every_batch_size(slam, syn, ns):
+    """the two-workgroup grid of k_ba_window is 16 x ceil(ns / 8) workgroups (pairs b, b + 8): every window count up to 128 leaves the
+    surplus workgroups idle and solves each window as a call of its own does"""
+    base = [syn.ba_scene(P=25, M=200 + 40 * z, seed=60 + z, n_const=20 + (z % 3)) for z in range(5)]
+    ref = []
+    for s in base:
+        c = _cache(slam, s); slam.bundle_adjustment_(c, s["cam"]); ref.append(c)
+    sc = [base[z % len(base)] for z in range(ns)]
+    caches = [_cache(slam, s) for s in sc]
+    st = slam.bundle_adjustment_batch_(caches, [s["cam"] for s in sc])
+    assert not st.any(), st
+    for z, c in enumerate(caches):
+        r = ref[z % len(base)]
+        assert np.array_equal(c.outliers, r.outliers), z
+        assert c.stats["iters_pass1"] == r.stats["iters_pass1"] and c.stats["iters_pass2"] == r.stats["iters_pass2"], z
+        assert abs(c.stats["ssr_final"] - r.stats["ssr_final"]) <= 1e-8 * r.stats["ssr_final"], z
+        assert np.abs(c.theta - r.theta).max() <= 1e-6 * max(1.0, np.abs(r.theta).max()), z
+
+
 def test_batch_with_windows_outside_the_batch_kernels(slam, orc, syn):
     """a dense window (half-bandwidth 23: the general path), a loop-closure window (solved on relabelled poses), an all-constant window,
     an empty one and a regular one in the same call"""
