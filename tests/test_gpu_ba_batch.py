@@ -89,6 +89,28 @@ def test_window_kernel_at_every_batch_size(slam, syn, ns):
         assert np.abs(c.theta - r.theta).max() <= 1e-6 * max(1.0, np.abs(r.theta).max()), z
 
 
+def test_two_full_batches_at_once_share_the_chip(slam, syn):
+    """two contexts launch k_ba_window for 128 windows each at the same time: 2 x 256 workgroups whose halves wait for each other compete
+    for 256 compute units -- workgroups are dispatched in order, so a waiting half's partner is at most eight places behind it and every
+    pair gets its turn (no deadlock); results as a call alone gives them"""
+    import threading
+    base = [syn.ba_scene(P=25, M=300, seed=300 + z, n_const=20) for z in range(4)]
+    sc = [base[z % 4] for z in range(128)]
+    ref = slam.BABatch([_cache(slam, s) for s in sc], sc[0]["cam"]); ref.solve()
+    out = {}
+    def run(tag):
+        ctx = slam.Context(0)
+        for _ in range(6):
+            b = slam.BABatch([_cache(slam, s) for s in sc], sc[0]["cam"]); b.solve(ctx=ctx)
+        out[tag] = b; ctx.close()
+    th = [threading.Thread(target=run, args=(t,)) for t in range(3)]
+    [t.start() for t in th]; [t.join(timeout=120) for t in th]
+    assert not any(t.is_alive() for t in th), "a batch did not return within two minutes"
+    for t in range(3):
+        assert not out[t].status.any()
+        assert np.array_equal(out[t].theta, ref.theta) and np.array_equal(out[t].outl, ref.outl), t
+
+
 def test_batch_with_windows_outside_the_batch_kernels(slam, orc, syn):
     """a dense window (half-bandwidth 23: the general path), a loop-closure window (solved on relabelled poses), an all-constant window,
     an empty one and a regular one in the same call"""
