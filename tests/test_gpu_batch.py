@@ -213,6 +213,33 @@ def test_tall_planes_take_the_integral_kernel_in_chained_row_segments(slam, orc,
                     assert np.array_equal(batch.pyramids[s].plane(name, l), ref.plane(name, l)), (rep, s, name, l)
 
 
+def test_two_tall_batches_built_at_once(slam):
+    """two contexts build 1080-row batches at the same time: the chained row segments of k_cum_fused (a segment waits for the one above
+    it, dispatched before it) of two launches share the chip; planes as a build alone gives them"""
+    import threading, torch
+    H, W, S = 1080, 640, 8
+    rng = np.random.default_rng(11)
+    imgs = [np.asfortranarray(np.round(rng.random((H, W)) * 255).astype(np.uint8)) for _ in range(S)]
+    dev = [torch.from_numpy(np.ascontiguousarray(im.T)).cuda() for im in imgs]
+    torch.cuda.synchronize()
+    ref = slam.PyramidBatch((H, W), levels=3, S=S); ref.update_([d.data_ptr() for d in dev], u8=True)
+    want = {(s, nm, l): ref.pyramids[s].plane(nm, l) for s in (0, S - 1) for nm in ("Iyy", "Iyx", "layers") for l in range(4)}
+    out = {}
+    def run(tag):
+        ctx = slam.Context(0)
+        b = slam.PyramidBatch((H, W), levels=3, S=S, ctx=ctx)
+        for _ in range(8):
+            b.update_([d.data_ptr() for d in dev], u8=True, ctx=ctx)
+        out[tag] = {k: b.pyramids[k[0]].plane(k[1], k[2]) for k in want}
+        ctx.close()
+    th = [threading.Thread(target=run, args=(t,)) for t in range(2)]
+    [t.start() for t in th]; [t.join(timeout=120) for t in th]
+    assert not any(t.is_alive() for t in th)
+    for t in range(2):
+        for k, v in want.items():
+            assert np.array_equal(out[t][k], v), (t, k)
+
+
 def test_flow_match_batch_kept_is_the_compaction_of_flow_match_batch(slam, texture):
     import torch
     H, W, S = 120, 160, 3
