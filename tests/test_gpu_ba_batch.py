@@ -111,6 +111,21 @@ def test_two_full_batches_at_once_share_the_chip(slam, syn):
         assert np.array_equal(out[t].theta, ref.theta) and np.array_equal(out[t].outl, ref.outl), t
 
 
+def test_window_kernel_on_a_context_confined_to_few_compute_units(slam, syn):
+    """a stream confined to 32 compute units (slam_ctx_create_cumask) can hold 32 of k_ba_window's workgroups at once: 16 windows still run on
+    two workgroups each (both halves resident), 24 fall back to one -- the halves of a window must never wait for a workgroup that cannot start"""
+    base = [syn.ba_scene(P=25, M=250, seed=400 + z, n_const=20) for z in range(3)]
+    ctx = slam.Context(0, cu_mask=[1 if c < 32 else 0 for c in range(256)])
+    for ns in (16, 24):
+        sc = [base[z % 3] for z in range(ns)]
+        ref = slam.BABatch([_cache(slam, s) for s in sc], sc[0]["cam"]); ref.solve()
+        b = slam.BABatch([_cache(slam, s) for s in sc], sc[0]["cam"]); b.solve(ctx=ctx)
+        assert not b.status.any()
+        assert np.array_equal(b.outl, ref.outl)
+        assert np.abs(b.theta - ref.theta).max() <= 1e-9 * max(1.0, np.abs(ref.theta).max()), ns
+    ctx.close()
+
+
 def test_batch_with_windows_outside_the_batch_kernels(slam, orc, syn):
     """a dense window (half-bandwidth 23: the general path), a loop-closure window (solved on relabelled poses), an all-constant window,
     an empty one and a regular one in the same call"""
