@@ -60,6 +60,9 @@ def spawn_ranks(args):
             env["SLAM_BENCH_BACKEND"] = "gloo"
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    part = os.path.join(ROOT, "bench_headline_partial.json")
+    if os.path.exists(part):                                 # a stale record of an earlier run must never be printed for this one
+        os.remove(part)
     deadline = time.time() + float(os.environ.get("SLAM_BENCH_SPAWN_TIMEOUT_S", "3600"))
     t_start = time.time() - 1.0
     rc = 0
@@ -75,8 +78,8 @@ def spawn_ranks(args):
                 p.kill()
             for p in live:
                 p.wait()
-            part = os.path.join(ROOT, "bench_headline_partial.json")
-            if os.path.exists(part) and os.path.getmtime(part) >= t_start:      # rank 0 had measured the headline before a rank was lost: one line, marked
+            rank0_done = procs[0] not in live and procs[0].returncode == 0     # rank 0 already printed its full line: a second, degraded one would be what `tail -1` reads
+            if not rank0_done and os.path.exists(part) and os.path.getmtime(part) >= t_start:      # rank 0 had measured the headline before a rank was lost: one line, marked
                 try:
                     j = json.load(open(part))
                     j["leg_error"] = {"after_leg": "headline", "error": f"a rank process exited with status {rc or 124}: the remaining ranks were stopped; the line is rank 0's headline as measured before that"}
@@ -85,6 +88,8 @@ def spawn_ranks(args):
                     pass
             return rc or 124
         time.sleep(0.2)
+    if rc == 0 and os.path.exists(part):
+        os.remove(part)
     return rc
 
 

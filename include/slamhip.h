@@ -431,11 +431,18 @@ int slam_local_ba(slam_ctx *ctx, double fx, double fy, double cx, double cy,
  * camera cams[4 z ..] = fx, fy, cx, cy; the arrays of the windows are stored back to back in window order: theta (6 Pn[z] + 3 Mn[z]
  * doubles each, in / out), theta_const (Pn[z] bytes), pixels_yx (2 On[z] doubles), pose_ids / point_ids (On[z], 1-based, local to the
  * window), outliers (On[z] bytes, out), stats (8 doubles per window as slam_local_ba's, may be NULL).  Each window runs its own
- * device-side Levenberg-Marquardt state (a converged window idles) and its results equal slam_local_ba's on its arrays; windows the
+ * device-side Levenberg-Marquardt state (a converged window idles) and its results equal slam_local_ba's on its arrays TO ROUNDING
+ * (theta <= 1e-6 relative, costs 1e-8; the batch kernels sum a window's points in a different order and solve the reduced system with
+ * another elimination, so the outlier flag of an observation whose squared residual lies within rounding of repr_eps may differ
+ * between the two entry points -- none does in the test suite's windows); windows the
  * banded group kernels do not cover (no banded pose order, a point with > 448 observations, no observations) are solved one by one
  * after the batch.  status (S ints, may be NULL): per-window code -- 0, SLAM_ERR_NUMERIC (reduced system not positive definite: that
  * window's theta / outliers are left unchanged) or SLAM_ERR_ARG; with status the call returns SLAM_OK unless the batch itself failed,
- * without it the first window error is returned.  Host set-up runs on up to 16 threads (SLAMHIP_BA_THREADS overrides). */
+ * without it the first window error is returned.  stats[6] of every window is the device time of the WHOLE batch (one set of
+ * launches).  Host set-up runs on a parked pool of min(max(hardware threads / 4, 4), 32) threads (SLAMHIP_BA_THREADS overrides).
+ * Windows of <= 5 consecutive free poses are solved by one launch with one or two workgroups each; the two-workgroup form waits
+ * for its partner with a bound and, should the partner not show up (compute units held by other processes), the call is solved
+ * again with one workgroup per window -- a slow call, never a hung queue. */
 int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t *Pn, const int32_t *Mn, const int32_t *On,
                         double *theta, const uint8_t *theta_const, const double *pixels_yx,
                         const int64_t *pose_ids, const int64_t *point_ids, uint8_t *outliers,

@@ -2515,7 +2515,7 @@ __device__ __forceinline__ void bw_wave_sync() { __builtin_amdgcn_fence(__ATOMIC
 // three sums behind the step decision, (c) the cost at the start of a pass and the outlier count.  The LM state is a copy in LDS that
 // both advance identically (half 0 writes it back at the end).  Exchanges go through a double-buffered area in global memory: values and
 // a counting flag as agent-scope atomics (performed at the memory side), ordered by s_waitcnt vmcnt(0) -- no cache write-back or invalidate.
-__global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int *list, int ns, int two, int iters_fast, int iterations, double repr_eps, double depth_eps)
+__global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int *list, int ns, int two, int iters_fast, int iterations, double repr_eps, double depth_eps, long long xlimit)
 {
     const int half = two ? (int)((blockIdx.x >> 3) & 1) : 0;
     const int widx = two ? (int)((blockIdx.x & 7) + 8 * (blockIdx.x >> 4)) : (int)blockIdx.x;
@@ -2560,15 +2560,32 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
     const int kLo = two && half ? w.ksplit : 0, kHi = two && !half ? w.ksplit : M;
     const int oLo = d.pt_start[kLo], oHi = d.pt_start[kHi];
     // exchange with the other half: own values -> area [half][e & 1], flag[half] = e; wait for flag[1 - half] >= e; the sums are own + other
-    int xe = 0;
+    int xe = 0, xdead = 0;             // xdead: this half gave up waiting (lane 0 of wave 0 keeps it)
     int *xflag = (int *)w.bwx;
     auto xarea = [&](int h, int e) { return w.bwx + 8 + (size_t)(2 * h + (e & 1)) * 832; };
     auto xpost = [&](int e) {          // (called by the wave that wrote the values)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if ((tid & 63) == 0) __hip_atomic_store(xflag + half, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((tid & 63) == 0 && !xdead) __hip_atomic_store(xflag + half, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    // The wait is BOUNDED (xlimit ticks of the 100 MHz wall clock): the launch is not cooperative, so nothing but the host's count of
+    // compute units promises that the partner workgroup is resident.  A half that runs out of patience marks the window (xflag[2]), posts a
+    // flag no later wait can miss (the partner never waits for it again) and goes on WITHOUT waiting -- it only ever exchanges doubles, every
+    // loop bound is an iteration count, so the garbage it then computes ends by itself -- and half 0 reports chol_fail = 2: the host solves
+    // the call again on one workgroup per window.  A missing partner is an error code, never a hung queue.
     auto xwait = [&](int e) {
-        if ((tid & 63) == 0) while (__hip_atomic_load(xflag + (1 - half), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) __builtin_amdgcn_s_sleep(2);
+        if ((tid & 63) == 0 && !xdead) {
+            const long long t0 = (long long)wall_clock64();
+            while (__hip_atomic_load(xflag + (1 - half), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) {
+                if ((long long)wall_clock64() - t0 > xlimit) {
+                    xdead = 1;
+                    __hip_atomic_store(xflag + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(xflag + half, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier();
     };
     // three scalars (two sums, one maximum) across the halves; every thread holds the workgroup's values on entry and the window's on return
@@ -3009,7 +3026,10 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
         }
     }
     __syncthreads();
-    if (tid == 0 && half == 0) *d.st = s_lm;
+    if (tid == 0 && half == 0) {
+        if (two && (xdead || __hip_atomic_load(xflag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) s_lm.chol_fail = 2;     // a half gave up waiting: nothing of this window is valid
+        *d.st = s_lm;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -3500,7 +3520,7 @@ static int ba_enqueue_solve(slam_ctx *ctx, slam_ba *ba, const double *red, int i
         static const bool no_twist = getenv("SLAMHIP_NO_TWIST") != nullptr;
         // (the two workgroups wait for each other: both must be resident, which a stream confined to one compute unit cannot promise)
         static const int twist_min = [] { const char *v = getenv("SLAMHIP_TWIST_MIN"); return v ? atoi(v) : 0; }();    // (measurement knob)
-        const bool twist = !no_twist && hb * 6 <= 58 && Ps >= (twist_min > 0 ? std::max(twist_min, hb + 8) : std::max(2 * (hb + 1) - 1, hb + 8))      /* measured: pays from 19 free poses at hb = 9 (19: 92.1 -> 89.3 us per iteration, 18: equal) since the hand-overs stay in one L2 (24 before) */ && (ctx->cus == 0 || ctx->cus >= 2);
+        const bool twist = !no_twist && hb * 6 <= 58 && Ps >= (twist_min > 0 ? std::max(twist_min, hb + 8) : std::max(2 * (hb + 1) - 1, hb + 8))      /* measured: pays from 19 free poses at hb = 9 (19: 92.1 -> 89.3 us per iteration, 18: equal) since the hand-overs stay in one L2 (24 before) */ && ctx->xwg_ok;
         static long long *trace_dev = nullptr; static int trace_n = 0;
         static const bool trace_on = getenv("SLAMHIP_BAND_TRACE") != nullptr;
         if (trace_on && !trace_dev) (void)hipHostMalloc((void **)&trace_dev, 1024);
@@ -3858,6 +3878,7 @@ struct BAPool {
         cv_done.wait(lk, [&] { return pending == 0; });
     }
 };
+std::atomic<long> n_xretry{0};       // calls that were solved again on one workgroup per window (slam_debug_ba_xretries)
 BAPool &ba_pool()
 {
     static const int env_threads = [] { const char *v = getenv("SLAMHIP_BA_THREADS"); return v ? atoi(v) : 0; }();
@@ -4007,11 +4028,6 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
             HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_band_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             attr_set[dv].store(true, std::memory_order_release);
         }
-        hipEvent_t e0, e1;
-        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        hipError_t e = hipMemcpyAsync(A, stage, up_total, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemsetAsync(A + zero_base, 0, ze[NB], st);
-        (void)hipEventRecord(e0, st);
         const BAWin *tab = (const BAWin *)A; const BARes *rtab = (const BARes *)(A + tab_bytes);
         auto run_pass = [&](int ignore, int iters) {
             hipLaunchKernelGGL(k_linearize_b, dim3(gx_obs, NB), dim3(256), 0, st, tab, ignore, 0);
@@ -4026,32 +4042,56 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
                 hipLaunchKernelGGL(k_control_b, dim3(1, NB), dim3(256), 0, st, tab);
             }
         };
-        if (e == hipSuccess && NS_ > 0) {
+        if (NS_ > 0) {                                             // (the flag is set on success only: a failed attribute call is tried again by the next call)
             static std::atomic<bool> bw_attr[64];
-            if (!bw_attr[dv].load(std::memory_order_acquire)) { e = hipFuncSetAttribute((const void *)k_ba_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bw_lds_bytes(BW_PMAX)); bw_attr[dv].store(true, std::memory_order_release); }
-            const int *list_d = (const int *)(A + tab_bytes + rtab_bytes - al((size_t)NB * 4));
-            // two workgroups per window while both halves of every window are resident at once (one workgroup per compute unit: 2 NS <= the
-            // context's compute units; the halves wait for each other), SLAMHIP_BA_WINDOW_ONE=1: always one
-            static const bool bw_one = getenv("SLAMHIP_BA_WINDOW_ONE") != nullptr;
-            const int cus_avail = ctx->cus > 0 ? ctx->cus : 256;
-            const int two = (!bw_one && 16 * ((NS_ + 7) / 8) <= cus_avail) ? 1 : 0;
-            if (e == hipSuccess) hipLaunchKernelGGL(k_ba_window, dim3(two ? 16 * ((NS_ + 7) / 8) : NS_), dim3(BW_T), lds_bw, st, tab, list_d, NS_, two, iters_fast, iterations, repr_eps, 1e-6);
+            if (!bw_attr[dv].load(std::memory_order_acquire)) {
+                HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_ba_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bw_lds_bytes(BW_PMAX)));
+                bw_attr[dv].store(true, std::memory_order_release);
+            }
         }
-        if (e == hipSuccess && !all_small) {
-            run_pass(0, iters_fast);
-            hipLaunchKernelGGL(k_outliers_b, dim3(gx_obs, NB), dim3(256), 0, st, tab, repr_eps, 1e-6);
-            hipLaunchKernelGGL(k_outlier_count_b, dim3(1, NB), dim3(256), 0, st, tab);
-            run_pass(1, iterations);
-        }
-        if (e == hipSuccess) {
+        // two workgroups per window (k_ba_window) only while BOTH halves of EVERY window are resident at once -- they wait for each other: one
+        // workgroup per compute unit (136-148 KB of LDS), so 2 x NS workgroups must fit the device's compute units (hipDeviceProp_t, not a
+        // constant), the stream must not be CU-masked (a mask says nothing about how many of an XCD's units are left, and the halves b / b + 8
+        // need two on the SAME XCD) and the architecture must be the one the memory-side hand-over was validated on (ctx->xwg_ok).  Other
+        // processes' kernels can still hold LDS the count knows nothing about: the kernel's wait is bounded (xlimit) and a window whose halves
+        // missed each other comes back with chol_fail = 2 -- the call is then solved again with one workgroup per window.
+        // SLAMHIP_BA_WINDOW_ONE=1: always one; SLAMHIP_BA_XWAIT_US: the bound (default 500 000 us; 0 in the tests = give up at once).
+        static const bool bw_one = getenv("SLAMHIP_BA_WINDOW_ONE") != nullptr;
+        static const long long xlimit = [] { const char *v = getenv("SLAMHIP_BA_XWAIT_US"); return (v ? atoll(v) : 500000LL) * 100; }();
+        const int two_grid = 16 * ((NS_ + 7) / 8);
+        int two = (!bw_one && ctx->xwg_ok && two_grid <= ctx->dev_cus) ? 1 : 0;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        hipError_t e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        for (int attempt = 0; e == hipSuccess && attempt < 2; attempt++) {
+            e = hipMemcpyAsync(A, stage, up_total, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemsetAsync(A + zero_base, 0, ze[NB], st);
+            if (e != hipSuccess) break;
+            (void)hipEventRecord(e0, st);
+            if (NS_ > 0) {
+                const int *list_d = (const int *)(A + tab_bytes + rtab_bytes - al((size_t)NB * 4));
+                hipLaunchKernelGGL(k_ba_window, dim3(two ? two_grid : NS_), dim3(BW_T), lds_bw, st, tab, list_d, NS_, two, iters_fast, iterations, repr_eps, 1e-6, xlimit);
+            }
+            if (!all_small) {
+                run_pass(0, iters_fast);
+                hipLaunchKernelGGL(k_outliers_b, dim3(gx_obs, NB), dim3(256), 0, st, tab, repr_eps, 1e-6);
+                hipLaunchKernelGGL(k_outlier_count_b, dim3(1, NB), dim3(256), 0, st, tab);
+                run_pass(1, iterations);
+            }
             hipLaunchKernelGGL(k_results_b, dim3(8, NB), dim3(256), 0, st, tab, rtab, A);
             e = hipGetLastError();
+            (void)hipEventRecord(e1, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(res_host, A + res_base, rs[NB], hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = slam_stream_wait(st);
+            if (e == hipSuccess) (void)hipEventElapsedTime(&dev_ms, e0, e1);
+            if (e != hipSuccess || !two) break;
+            bool missed = false;                                   // did the halves of some window miss each other?
+            for (int k : small_list) if (((const LMState *)(res_host + (rtab_h[k].off_state - res_base)))->chol_fail == 2) { missed = true; break; }
+            if (!missed) break;
+            two = 0; n_xretry.fetch_add(1);
         }
-        (void)hipEventRecord(e1, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(res_host, A + res_base, rs[NB], hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = slam_stream_wait(st);
-        if (e == hipSuccess) (void)hipEventElapsedTime(&dev_ms, e0, e1);
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
         if (e != hipSuccess) return slam_fail(ctx, SLAM_ERR_HIP, "slam_local_ba_batch: %s", hipGetErrorString(e));
         const auto tw3 = std::chrono::steady_clock::now();
         // results -> the caller's arrays (its pose order, its observation order); a failed factorisation leaves a window's arrays untouched
@@ -4099,6 +4139,9 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
     return first;
 }
 
+
+// how many slam_local_ba_batch calls of this process had to be solved again because the two workgroups of a window missed each other
+long slam_debug_ba_xretries(void) { return n_xretry.load(); }
 
 // host-only timing of the batch set-up (no HIP call, no device needed): plan + emit of S windows on `threads` threads into malloc'ed
 // staging; out_us = {plan, emit}.  Measurement aid for tuning the host side on any machine (scripts/probes/ba_host_time.py).

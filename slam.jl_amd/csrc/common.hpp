@@ -15,6 +15,10 @@ struct slam_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int cus = 0;                          // compute units the stream may use (0: all of the device)
+    int dev_cus = 0;                      // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+    bool arch_ok = false;                 // gfx942 / gfx950: atomics with agent scope are performed at the memory side (k_cum_fused's row segments rely on it)
+    bool xwg_ok = false;                  // cross-workgroup hand-overs through memory-side atomics are relied on only where they were validated:
+                                          // gfx942 / gfx950 (workgroups b and b + 8 share an XCD's L2), stream not CU-masked (ctx_probe_device)
     int pool_class = 99;                  // scheduling class the stream is parked under when the context goes (ctx.hip); 99: not pooled (CU-masked)
     std::string err;
     // grow-only device scratch and pinned host staging
@@ -31,6 +35,8 @@ struct slam_ctx {
     std::vector<double> prof_ms;
     std::vector<long long> prof_cnt;
 };
+
+extern "C" void ctx_probe_device(slam_ctx *c);      // fills dev_cus / xwg_ok (ctx.hip)
 
 // RAII span: records a hipEvent pair around the enclosed launches when profiling is on
 struct ProfScope {

@@ -128,6 +128,19 @@ hipStream_t take_parked(int device, int prio)
 }
 }  // namespace
 
+// What the device is, once per context: the kernels whose workgroups wait for one another (k_ba_window's two halves, the twisted band
+// solve, k_cum_fused's row segments) need to know how many workgroups the chip really holds and that it is the architecture their
+// memory-side hand-overs were validated on (no hard-coded 256, no assumption about other architectures).
+void ctx_probe_device(slam_ctx *c)
+{
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, c->device) != hipSuccess) { c->dev_cus = 0; c->arch_ok = c->xwg_ok = false; return; }
+    c->dev_cus = pr.multiProcessorCount;
+    const bool arch = strncmp(pr.gcnArchName, "gfx950", 6) == 0 || strncmp(pr.gcnArchName, "gfx942", 6) == 0;
+    c->arch_ok = arch;
+    c->xwg_ok = arch && c->cus == 0 && c->dev_cus >= 16;
+}
+
 int slam_ctx_create(int device, slam_ctx **out)
 {
     if (!out) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_ctx_create: out is NULL");
@@ -142,6 +155,7 @@ int slam_ctx_create(int device, slam_ctx **out)
     c->pool_class = 0;
     if (e == hipSuccess && (c->stream = take_parked(device, 0)) == nullptr) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create: %s", hipGetErrorString(e)); }
+    ctx_probe_device(c);
     *out = c;
     return SLAM_OK;
 }
@@ -162,6 +176,7 @@ int slam_ctx_create_cumask(int device, const uint32_t *cu_mask, int n_words, sla
     if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)n_words, cu_mask);
     for (int w = 0; w < n_words; w++) c->cus += __builtin_popcount(cu_mask[w]);
     if (e != hipSuccess) { delete c; return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create_cumask: %s", hipGetErrorString(e)); }
+    ctx_probe_device(c);
     *out = c;
     return SLAM_OK;
 }
@@ -187,6 +202,7 @@ int slam_ctx_create_priority(int device, int priority, slam_ctx **out)
     c->pool_class = priority > 0 ? 1 : priority < 0 ? -1 : 0;
     if (e == hipSuccess && (c->stream = take_parked(device, c->pool_class)) == nullptr) e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, p);
     if (e != hipSuccess) { delete c; return slam_fail(nullptr, SLAM_ERR_HIP, "slam_ctx_create_priority: %s", hipGetErrorString(e)); }
+    ctx_probe_device(c);
     *out = c;
     return SLAM_OK;
 }

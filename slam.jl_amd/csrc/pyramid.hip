@@ -2449,7 +2449,7 @@ static int pyr_create_n(slam_ctx *ctx, int H, int W, int pyramid_levels, int S, 
         if (hipMalloc((void **)&al->tot, (size_t)3 * S * wsum * 8) != hipSuccess) { (void)hipGetLastError(); al->tot = nullptr; }
         // frames taller than one k_cum_fused workgroup (512 rows): carry rows + flags of its row segments (level 0 sizes them; the coarser levels fit)
         const int xbands = (Hs[0] + 63) / 64, xseg = xbands <= CF_MAXW ? 1 : (xbands + CF_SEGW - 1) / CF_SEGW;
-        if (xseg > 1) {
+        if (xseg > 1 && ctx->arch_ok) {                          // (elsewhere: k_cum_cols + k_cum_rows, no cross-workgroup hand-over)
             const size_t nslot = (size_t)S * 3 * (xseg - 1);
             if (hipMalloc((void **)&al->xc, nslot * Ws[0] * 8) != hipSuccess) { (void)hipGetLastError(); al->xc = nullptr; }
             if (al->xc && (hipMalloc((void **)&al->xf, nslot * 4) != hipSuccess || hipMemset(al->xf, 0, nslot * 4) != hipSuccess)) { (void)hipGetLastError(); (void)hipFree(al->xc); al->xc = nullptr; al->xf = nullptr; }

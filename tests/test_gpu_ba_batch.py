@@ -195,3 +195,37 @@ def test_batch_calls_from_two_threads_at_once(slam, syn):
     for t in range(2):
         assert not out[t].status.any()
         assert np.array_equal(out[t].theta, ref.theta) and np.array_equal(out[t].outl, ref.outl), t
+
+
+_XWAIT = r'''
+import sys, ctypes, numpy as np
+sys.path.insert(0, %(root)r)
+import slam_jl_amd as slam
+from slam_jl_amd import synthetic as syn, _lib
+sc = [syn.ba_scene(P=25, M=300, seed=700 + z, n_const=20) for z in range(%(S)d)]
+def cache(s):
+    return slam.LocalBACache(s["theta0"], s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+b = slam.BABatch([cache(s) for s in sc], sc[0]["cam"]); b.solve()
+lib = _lib.load(); lib.slam_debug_ba_xretries.restype = ctypes.c_long
+print("RETRIES", lib.slam_debug_ba_xretries())
+assert not b.status.any(), b.status
+np.save(%(out)r, np.concatenate([b.theta.ravel(), b.outl.ravel().astype(np.float64)]))
+print("OK")
+'''
+
+
+def test_halves_that_miss_each_other_fall_back_to_one_workgroup(tmp_path):
+    """k_ba_window's wait for the partner workgroup is bounded: with the bound at 0 us (SLAMHIP_BA_XWAIT_US=0) a half whose partner has not
+    posted yet gives up at once, the window comes back flagged and slam_local_ba_batch solves the call again on one workgroup per window --
+    the results are those of SLAMHIP_BA_WINDOW_ONE=1 to the bit and no call hangs"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("giveup", {"SLAMHIP_BA_XWAIT_US": "0"}), ("one", {"SLAMHIP_BA_WINDOW_ONE": "1"})):
+        out = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([sys.executable, "-c", _XWAIT % dict(root=root, S=24, out=out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-800:] + r.stderr[-1500:]
+        outs[tag] = (np.load(out), int(r.stdout.split("RETRIES")[1].split()[0]))
+    assert outs["giveup"][1] >= 1, "the bound of 0 us never triggered: the test does not exercise the fallback"
+    assert outs["one"][1] == 0
+    assert np.array_equal(outs["giveup"][0], outs["one"][0])
