@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 from benchlib.common import (KF_EVERY, RIGHT_TARGET_ONLY, CULL_FRACTION, N_FRAMES, HBM_PEAK_GBS, HBM_ACHIEVABLE_GBS,      # noqa: E402,F401
                              frame_sequence, frame_sequence_n, pyramid_bytes, iir_rows_bytes)
 from benchlib.backends import Stream, GpuBackend, GpuPeriodBackend, CpuBackend                                           # noqa: E402,F401
-from benchlib.lockstep import run_lockstep, run_lockstep_kpset, kernel_spans, make_workload, WORKLOADS, leg_ctx, peek, BAWorker   # noqa: E402,F401
+from benchlib.lockstep import run_lockstep, run_lockstep_kpset, kernel_spans, make_workload, WORKLOADS, leg_ctx, peek, BAWorker, BA_WINDOW_SHAPES   # noqa: E402,F401
 from benchlib.checkers import replay_stream_on_oracle                                                                    # noqa: E402
 from benchlib.report import compact_line, write_detail, frame_and_lk_rooflines, newest_pmc                               # noqa: E402
 
@@ -527,6 +527,24 @@ def main():
                                      "frac_isolated": pb2 / (iso2 * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
                     if r2["pose"] is not None and not r2["pose"]["pose_ok"]:
                         pose_fails.append(f"configs.{name}: pose check failed ({r2['pose']['max_translation_error_m']:.3f} m, accepted {r2['pose']['accepted_fraction']:.3f})")
+                    if "ba" in legs:
+                        # the config AS BASELINE NAMES IT: the front-end loop with one local-BA window of the config's size per stream and key-frame period
+                        # on the estimator's context + host thread (SlamManager task #3, estimator.jl:78-99, :317-347); a hand-over waits for the previous solve
+                        try:
+                            worker = BAWorker(slam, syn, local_rank, w2["S"], prio=int(os.environ.get("SLAM_BENCH_BA_PRIO", "1")), window=w2["ba_window"])
+                            rb = run_lockstep_kpset(slam, torch, local_rank, w2, max(6, args.steps // 4), 2, world, dist, dev, "host_u8", pose=mono, ba=worker)
+                            worker.close()
+                            lb = rb["local_ba"]
+                            out["configs"][name]["with_ba"] = {"value": rb["value"], "unit": "frames/sec", "fraction_of_front_end_only": rb["value"] / r2["value"],
+                                                               "ba_call_ms": lb["mean_call_ms"], "ba_device_ms": lb["device_ms_per_call"], "ba_window": lb["window_name"],
+                                                               "windows_per_call": lb["windows_per_call"], "calls": lb["calls"],
+                                                               "front_end_waited_ms_per_call": lb["front_end_waited_ms_per_call"], "all_windows_ok": lb["all_windows_ok"],
+                                                               "ms_per_step": rb["ms_per_step"], "window": lb["window"]}
+                            if not lb["all_windows_ok"]:
+                                fails.append(f"configs.{name}.with_ba: a window of the last batch did not solve")
+                            del worker, rb
+                        except Exception as ex:                               # noqa: BLE001
+                            out["configs"][name]["with_ba"] = {"error": repr(ex)[:300]}
                     if "tolbatch" in legs:                                # the same shape on tolerance-mode pyramids (planes <= 1e-11 relative)
                         w2t = dict(w2); w2t["tolerance"] = True
                         r2t = run_lockstep_kpset(slam, torch, local_rank, w2t, max(5, args.steps // 5), 2, world, dist, dev, "host_u8", pose=mono)
@@ -567,7 +585,8 @@ def main():
                          "lm_iterations": iters, "ms_per_iter": cache.stats["device_ms"] / max(iters, 1), "wall_ms_total": wall * 1e3,
                          "ssr_final": cache.stats["ssr_final"], "half_bandwidth": hbw, "half_bandwidth_in_key_frame_order": hbw0, "poses_reordered": reordered,
                          "solver_path": ("banded: k_schur_groups + k_band_solve" + (" on relabelled poses (folded ring, slam_ba_plan_order)" if reordered else ""))
-                                        if hbw <= 20 else "general: pair lists (k_blocks) + tiled Cholesky"}
+                                        if hbw <= 20 else ("dense: point groups over the whole block triangle (k_schur_groups) + one-workgroup Cholesky from LDS (k_dense_solve)"
+                                                           if int((np.asarray(s["theta_const"]) == 0).sum()) <= 30 else "general: pair lists (k_blocks) + tiled Cholesky")}
                     if best is None or r["ms_per_iter"] < best["ms_per_iter"]:
                         best = r
                 bytes_iter = 33 * s["O"] + 96 * s["P"] + 48 * s["M"] + 8 * (6 * s["P"]) ** 2
@@ -577,13 +596,14 @@ def main():
                 out["ba"]["windows"][name] = best
             # ---- S windows per call (slam_local_ba_batch): what S lock-stepped streams owe per key-frame period ----
             out["ba"]["batch"] = {}
-            for bname, mk in (("P5_free_20_const", lambda z: syn.ba_scene(P=25, M=800, seed=100 + z, n_const=20)), ("P20", lambda z: syn.ba_scene(P=20, M=4000, seed=300 + z))):
-                base = [mk(z) for z in range(8)]
-                bb = slam.BABatch([slam.LocalBACache(base[z % 8]["theta0"].copy(), base[z % 8]["theta_const"], base[z % 8]["pixels_yx"], base[z % 8]["pose_ids"],
-                                                     base[z % 8]["point_ids"]) for z in range(S)], base[0]["cam"])
+            for bname, Sb in (("P5_free_20_const", S), ("P20", S), ("P50", S), ("P100", min(S, 32))):      # (P100: configs[4] runs 32 streams per GPU)
+                mk, _, nbase = BA_WINDOW_SHAPES[bname]
+                base = [mk(syn, z) for z in range(nbase)]
+                bb = slam.BABatch([slam.LocalBACache(base[z % nbase]["theta0"].copy(), base[z % nbase]["theta_const"], base[z % nbase]["pixels_yx"], base[z % nbase]["pose_ids"],
+                                                     base[z % nbase]["point_ids"]) for z in range(Sb)], base[0]["cam"])
                 bb.solve(ctx=ctx, reset=True)
                 walls = []
-                for _ in range(5):
+                for _ in range(5 if bname in ("P5_free_20_const", "P20") else 3):
                     bb.theta[:] = bb.theta0
                     t0 = time.perf_counter(); bb.solve(ctx=ctx); walls.append(time.perf_counter() - t0)
                 one = slam.LocalBACache(base[0]["theta0"].copy(), base[0]["theta_const"], base[0]["pixels_yx"], base[0]["pose_ids"], base[0]["point_ids"])
@@ -593,12 +613,13 @@ def main():
                 if not same:
                     fails.append(f"ba.batch {bname}: window 0 of the batch differs from slam_local_ba on the same arrays")
                 its = float(np.mean(bb.stats[:, 3] + bb.stats[:, 4]))
-                out["ba"]["batch"][bname] = {"windows": S, "observations_per_window": int(base[0]["O"]), "wall_ms_per_call": min(walls) * 1e3, "device_ms_per_call": float(bb.stats[0, 6]),
-                                             "windows_per_s": S / min(walls), "mean_lm_iterations": its, "device_ms_per_iter_of_S_windows": float(bb.stats[0, 6]) / max(its, 1),
+                out["ba"]["batch"][bname] = {"windows": Sb, "observations_per_window": int(base[0]["O"]), "wall_ms_per_call": min(walls) * 1e3, "device_ms_per_call": float(bb.stats[0, 6]),
+                                             "windows_per_s": Sb / min(walls), "mean_lm_iterations": its, "device_ms_per_iter_of_S_windows": float(bb.stats[0, 6]) / max(its, 1),
                                              "all_windows_ok": bool((bb.status == 0).all()), "window_0_equals_single_call": same,
                                              "single_window_call_ms": None if bname not in out["ba"]["windows"] else out["ba"]["windows"][bname]["wall_ms_total"],
                                              "what": "slam_local_ba_batch: host set-up of the S windows (threads), one H2D copy, 5 launches per LM iteration for all windows, one D2H copy; "
                                                      "wall clock of the whole call, arrays already concatenated"}
+                del bb, base
             p50 = out["ba"]["windows"]["P50"]
             out["ba"].update({"window_kf": 50, "observations": p50["observations"], "points": p50["points"], "lm_iterations": p50["lm_iterations"],
                               "ms_per_iter": p50["ms_per_iter"], "wall_ms_total": p50["wall_ms_total"], "ssr_final": p50["ssr_final"]})

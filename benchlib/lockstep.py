@@ -145,15 +145,15 @@ POSE_TOL_M = 0.1            # recovered camera translation vs the frames' image 
 
 WORKLOADS = {
     # name: shape (slam_jl_amd.synthetic.SHAPES), keypoints per frame, stereo, streams per GPU, camera (fx, fy, cx, cy), image step per frame
-    "kitti05_1000": dict(shape="kitti05", kpts=1000, stereo=True, S=128, cam=None, step=(1.3, -2.1), n_frames=8,
+    "kitti05_1000": dict(ba_window="P5_free_20_const", shape="kitti05", kpts=1000, stereo=True, S=128, cam=None, step=(1.3, -2.1), n_frames=8,
                          what="BASELINE configs[1]: KITTI 05 stereo 370x1226, 1000 kpts/frame (the headline)"),
-    "kitti00_2000": dict(shape="kitti00", kpts=2000, stereo=True, S=128, cam=None, step=(1.3, -2.1), n_frames=8,
-                         what="BASELINE configs[2]: KITTI 00 stereo 376x1241 (example/kitty/main.jl:21-22), 2000 kpts/frame; its 20-KF BA is ba.windows.P20"),
-    "euroc_mono": dict(shape="euroc", kpts=1000, stereo=False, S=128, cam=(458.654, 457.296, 367.215, 248.375), step=(2.6, -4.2), n_frames=8,
+    "kitti00_2000": dict(ba_window="P20", shape="kitti00", kpts=2000, stereo=True, S=128, cam=None, step=(1.3, -2.1), n_frames=8,
+                         what="BASELINE configs[2]: KITTI 00 stereo 376x1241 (example/kitty/main.jl:21-22), 2000 kpts/frame; one 20-KF local BA window per stream and key-frame: configs.kitti00_2000.with_ba (window alone: ba.windows.P20, ba.batch.P20)"),
+    "euroc_mono": dict(ba_window="P50", shape="euroc", kpts=1000, stereo=False, S=128, cam=(458.654, 457.296, 367.215, 248.375), step=(2.6, -4.2), n_frames=8,
                        what="BASELINE configs[3]: monocular 480x640, PnP-tracking path (front_end.jl:132-219: five-point filter + P3P RANSAC + PnP "
-                            "refinement every frame, no right image), new keypoints by triangulate_temporal!; its 50-KF BA is ba.windows.P50"),
-    "fhd_4000": dict(shape="fhd", kpts=4000, stereo=True, S=32, cam=(910.0, 910.0, 960.0, 540.0), step=(1.3, -2.1), n_frames=4,
-                     what="BASELINE configs[4] on one GPU: 1080x1920 stereo (example/uni/main.jl:11-13), 4000 kpts/frame; its 100-KF BA is ba.windows.P100"),
+                            "refinement every frame, no right image), new keypoints by triangulate_temporal!; one 50-KF BA window per stream and key-frame: configs.euroc_mono.with_ba (alone: ba.windows.P50, ba.batch.P50)"),
+    "fhd_4000": dict(ba_window="P100", shape="fhd", kpts=4000, stereo=True, S=32, cam=(910.0, 910.0, 960.0, 540.0), step=(1.3, -2.1), n_frames=4,
+                     what="BASELINE configs[4] on one GPU: 1080x1920 stereo (example/uni/main.jl:11-13), 4000 kpts/frame; one 100-KF BA window per stream and key-frame: configs.fhd_4000.with_ba (alone: ba.windows.P100, ba.batch.P100)"),
 }
 
 
@@ -529,6 +529,17 @@ def run_lockstep_kpset(slam, torch, local_rank, wl, periods, warm_periods, world
     return res
 
 
+# the local-BA windows a stream owes per key-frame: the reference's own cap (5 free key-frames + their constant observers,
+# estimator.jl:327-331) and the window sizes BASELINE's configs name (every point seen by 10 consecutive key-frames, the first pose constant)
+BA_WINDOW_SHAPES = {
+    "P5_free_20_const": (lambda syn, z: syn.ba_scene(P=25, M=800, seed=100 + z, n_const=20),
+                         "5 free + 20 constant key-frames, 800 points, 8000 observations (estimator.jl:327-331), 5 + 10 LM iterations", 8),
+    "P20": (lambda syn, z: syn.ba_scene(P=20, M=4000, seed=300 + z), "20 key-frames (19 free), 4000 points, 40 000 observations, 5 + 10 LM iterations", 8),
+    "P50": (lambda syn, z: syn.ba_scene(P=50, M=10000, seed=500 + z), "50 key-frames (49 free), 10 000 points, 100 000 observations, 5 + 10 LM iterations", 4),
+    "P100": (lambda syn, z: syn.ba_scene(P=100, M=40000, seed=700 + z), "100 key-frames (99 free), 40 000 points, 400 000 observations, 5 + 10 LM iterations", 2),
+}
+
+
 class BAWorker:
     """The reference's estimator task (#3, estimator.jl:78-99) for S lock-stepped streams: every key-frame step hands the S windows of the
     streams (reference-shaped: 5 free + 20 constant key-frames, estimator.jl:327-331) to slam_local_ba_batch on a context and a host thread
@@ -536,14 +547,16 @@ class BAWorker:
     so a solve slower than a key-frame period shows in the loop's frame rate.  The windows are synthetic (the array contract of
     _get_ba_parameters, estimator.jl:143-266, filled by synthetic.ba_scene): map bookkeeping stays on the host in the reference."""
 
-    def __init__(self, slam, syn, local_rank, S, prio=0):
+    def __init__(self, slam, syn, local_rank, S, prio=0, window="P5_free_20_const"):
         import threading
         self.threading = threading
         self.ctx = leg_ctx(slam, local_rank, prio)
-        base = [syn.ba_scene(P=25, M=800, seed=100 + z, n_const=20) for z in range(8)]
-        caches = [slam.LocalBACache(base[z % 8]["theta0"].copy(), base[z % 8]["theta_const"], base[z % 8]["pixels_yx"], base[z % 8]["pose_ids"],
-                                    base[z % 8]["point_ids"]) for z in range(S)]
+        mk, self.window_text, nbase = BA_WINDOW_SHAPES[window]
+        base = [mk(syn, z) for z in range(nbase)]
+        caches = [slam.LocalBACache(base[z % nbase]["theta0"].copy(), base[z % nbase]["theta_const"], base[z % nbase]["pixels_yx"], base[z % nbase]["pose_ids"],
+                                    base[z % nbase]["point_ids"]) for z in range(S)]
         self.batch = slam.BABatch(caches, base[0]["cam"])
+        self.window = window
         self.S = S; self.th = None; self.calls = 0; self.wall = 0.0; self.wait = 0.0; self.err = None
         self.batch.solve(ctx=self.ctx, reset=True)                  # warm-up: scratch, pinned block, function attributes
 
@@ -573,7 +586,7 @@ class BAWorker:
         ok = bool((self.batch.status == 0).all())
         return {"windows_per_call": self.S, "calls": self.calls, "mean_call_ms": self.wall / max(self.calls, 1) * 1e3,
                 "front_end_waited_ms_per_call": self.wait / max(self.calls, 1) * 1e3, "all_windows_ok": ok,
-                "window": "5 free + 20 constant key-frames, 800 points, 8000 observations (estimator.jl:327-331), 5 + 10 LM iterations"}
+                "device_ms_per_call": float(self.batch.stats[0, 6]), "window_name": self.window, "window": self.window_text}
 
     def close(self):
         self.join(); self.ctx.close()

@@ -117,6 +117,11 @@ def compact_line(out):
             c["tolerance_mode"]["roofline"] = {k: _r(b["roofline"].get(k)) for k in ("frac", "frac_isolated", "avg_launch_us", "isolated_launch_us", "traffic", "traffic_over_algorithmic")}
     if out.get("configs"):
         c["configs"] = {k: (_r(v.get("value")) if "value" in v else "error") for k, v in out["configs"].items()}
+        wb = {k: ({"value": _r(v["with_ba"]["value"]), "fraction_of_front_end_only": _r(v["with_ba"]["fraction_of_front_end_only"]), "ba_call_ms": _r(v["with_ba"]["ba_call_ms"]),
+                   "ba_window": v["with_ba"]["ba_window"], "all_windows_ok": v["with_ba"]["all_windows_ok"]} if "value" in v["with_ba"] else {"error": v["with_ba"].get("error", "")[:100]})
+              for k, v in out["configs"].items() if isinstance(v.get("with_ba"), dict)}
+        if wb:
+            c["with_ba"] = wb                                      # each BASELINE config as named: the front-end loop with its 20 / 50 / 100-KF local BA per stream and key-frame
         if any("tolerance_value" in v for v in out["configs"].values()):
             c["configs_tolerance_mode"] = {k: _r(v.get("tolerance_value")) for k, v in out["configs"].items() if "tolerance_value" in v}
     if out.get("pose", {}).get("frontend_with_pose"):
