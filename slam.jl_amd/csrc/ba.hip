@@ -482,10 +482,12 @@ __device__ __forceinline__ double sg_fold(double v, int NS)
 #define SG_CLK_DECL long long sg_clk[12]; const long long sg_t0 = clock64()
 #define SG_CLK(k) sg_clk[k] = clock64() - sg_t0
 #define SG_DUMP() do { if (threadIdx.x == 0 && blockIdx.x == (gridDim.y > 1 ? 10 : 100) && blockIdx.y == (gridDim.y > 1 ? 5 : 0) && d.st->iters == 3) printf("schur group: npts %d nobs %d | init %lld ph0 %lld bar %lld ph1 %lld ph2 %lld ph3 %lld bar %lld fold %lld tail %lld cycles\n", npts, nobs, sg_clk[0], sg_clk[1] - sg_clk[0], sg_clk[2] - sg_clk[1], sg_clk[3] - sg_clk[2], sg_clk[4] - sg_clk[3], sg_clk[8] - sg_clk[4], sg_clk[9] - sg_clk[8], sg_clk[5] - sg_clk[9], sg_clk[6] - sg_clk[5]); } while (0)
+#define SGM_DUMP() do { if (threadIdx.x == 0 && blockIdx.x == 10 && blockIdx.y == 5 && d.st->iters == 3) printf("schur group (mfma): npts %d nobs %d | init %lld ph0 %lld bar %lld ph1 %lld ph2a %lld ph2x %lld ph2b %lld mfma+out %lld cycles\n", npts, nobs, sg_clk[0], sg_clk[1] - sg_clk[0], sg_clk[2] - sg_clk[1], sg_clk[3] - sg_clk[2], sg_clk[4] - sg_clk[3], sg_clk[5] - sg_clk[4], sg_clk[6] - sg_clk[5], sg_clk[7] - sg_clk[6]); } while (0)
 #else
 #define SG_CLK_DECL
 #define SG_CLK(k)
 #define SG_DUMP()
+#define SGM_DUMP()
 #endif
 // the fold buffers of phase 3 (the partial blocks and slot rows of the subsets 1 .. NS - 1) overlay everything below s_dg
 static bool sg_fold_fits(int whb)
@@ -706,6 +708,258 @@ __device__ __forceinline__ void schur_groups_body(const BADev &d, double inv_del
     SG_DUMP();
 }
 __global__ __launch_bounds__(SG_T) void k_schur_groups(BADev d, double inv_delta_host, int ignore_outliers, int use_state) { schur_groups_body<SG_T>(d, inv_delta_host, ignore_outliers, use_state); }
+
+// ---- the same build for a BATCH of windows, with the Schur products on the matrix cores (round 6) -------------------------------------------
+// For a group of map points the window blocks are  S_ab -= sum_x W_xa V_x^-1 W_xb'  over every pair a <= b of window slots.  With the Cholesky
+// factor V_x^-1 = L_x L_x' and Y_xa = W_xa L_x (6 x 3) this is  -(Y Y')  for the matrix Y whose rows are (slot, pose parameter) and whose columns are
+// (point, coordinate): a symmetric rank-k update with k = 3 x points -- the one place of the path that IS a dense contraction.  It runs as
+// v_mfma_f64_16x16x4_f64 tiles (A[i][k] from lane i + 16 k, B[k][j] from lane j + 16 k, D[4 r + lane / 16][lane % 16] in accumulator r:
+// scripts/ubench/mfma_f64_layout.hip), upper-triangular tiles dealt to the waves, no partial blocks to fold.  The peak of the matrix cores in
+// Float64 equals the vector peak on this chip (64 cycles per 2048 multiply-adds); what the instruction removes is the issue and LDS traffic of
+// the vector form (42 LDS doubles per 162 multiply-adds and lane, a quarter of them re-forming W V^-1 in every lane of a slot row) and the
+// fold of four partial block sets through LDS: phase 3 + fold 30 k -> ~5 k cycles of a group's 68 k, and the workgroup needs 47 instead of
+// 80 KB of LDS (three per compute unit).  Association differs from the vector kernel (Y Y' instead of (W V^-1) W'): results to rounding.
+// LDS: one region R, used in turn as [ob][9] products Jl'Jl / Jl'f, as [hp][18] records (Jp, gradient) of the free-pose observations, and as
+// the matrix Y -- element (row, k) at ((k >> 1) RP + row) 2 + (k & 1): the 32 lanes of a half-wave read 256 contiguous bytes.
+typedef double sgm_d4 __attribute__((ext_vector_type(4)));
+__host__ __device__ __forceinline__ int sgm_rp(int whb) { return 16 * ((6 * (whb + 1) + 15) / 16); }
+__host__ __device__ __forceinline__ size_t sgm_r_doubles(int whb, int ob, int sb, int hp)
+{
+    const size_t a = (size_t)ob * 9, b = (size_t)hp * 18, c = (size_t)((3 * sb + 3) & ~3) * sgm_rp(whb);
+    return ((a > b ? (a > c ? a : c) : (b > c ? b : c)) + 1) & ~(size_t)1;
+}
+static size_t sgm_lds_bytes(int whb, int P, int ob, int sb, int hp)
+{
+    return (sgm_r_doubles(whb, ob, sb, hp) + (size_t)sb * 16 + 8 + (size_t)(whb + 1) * 36 + (size_t)P * 6) * 8 + (size_t)sb * (whb + 1) * 2 + 16;
+}
+template <int TT>
+__device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignore_outliers)
+{
+    extern __shared__ __attribute__((aligned(16))) double sg_lds[];
+    SG_CLK_DECL;
+    if (d.st->converged) return;
+    const ParamBufs pb = param_bufs(d);
+    const int tid = threadIdx.x, M = d.M, O = d.O, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // (the wave index in a scalar register: the tile loop branches on it)
+    constexpr int NW = TT / 64;
+    const int4 G = d.grp[blockIdx.x];                       // first point, first observation, f | points << 16, observations
+    const int k0 = __builtin_amdgcn_readfirstlane(G.x), o0 = __builtin_amdgcn_readfirstlane(G.y), f = __builtin_amdgcn_readfirstlane(G.z & 0xffff),
+              npts = __builtin_amdgcn_readfirstlane(G.z >> 16), nobs = __builtin_amdgcn_readfirstlane(G.w);      // (uniform by construction; told to the compiler: scalar loop counters)
+    const int hbw = d.whb + 1, nwin = hbw * (hbw + 1) / 2, RP = sgm_rp(d.whb), nrow = 6 * hbw;
+    const int OBc = d.sg_ob, SBc = d.sg_sb, HPc = d.sg_hp;
+    double *s_R = sg_lds;
+    double *s_pt = s_R + sgm_r_doubles(d.whb, OBc, SBc, HPc);   // [SBc][16]  V^-1 (6), bl (3), L (6: l00 l10 l20 l11 l21 l22)
+    double *s_dg = s_pt + SBc * 16 + 8;                          // [hbw][36]  Jp'Jp per window slot
+    double *s_sc = s_dg + hbw * 36;                              // [P][6]     sin / cos of every pose's angles
+    short *s_slot = (short *)(s_sc + 6 * d.P);                   // [SBc][hbw] record of point x in window slot y, or -1
+    // the observation's scalars are requested BEFORE the set-up work below (their latency hides behind the sin / cos of the poses)
+    int i = 0, p = 0, j = 0, pl = 0, hpi = -1; bool active = false, hp = false; double py = 0.0, px = 0.0;
+    if (tid < nobs) {
+        i = o0 + tid; p = d.opose[i]; j = d.opoint[i]; pl = d.opk[i] - k0; hpi = d.ohp[i];
+        active = !(ignore_outliers && d.outl[i]); hp = active && !d.pconst[p];
+        py = d.pix[i]; px = d.pix[O + i];
+    }
+    for (int q2 = tid; q2 < d.P; q2 += TT) pose_sincos(pb.pose + 6 * q2, s_sc + 6 * q2);
+    for (int x = tid; x < npts * hbw; x += TT) s_slot[x] = -1;
+    lds_sync();
+    SG_CLK(0);
+    // ---- phase 0: residual + Jacobians of the observation, Jl'Jl / Jl'f -> R
+    double r2[2] = {0.0, 0.0}, Jp[12], Jl[6];
+#pragma unroll
+    for (int k = 0; k < 12; k++) Jp[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) Jl[k] = 0.0;
+    if (tid < nobs) {
+        if (active) {
+            const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
+            double sc[6], tr[3];
+#pragma unroll
+            for (int k = 0; k < 6; k++) sc[k] = s_sc[6 * p + k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) tr[k] = pb.pose[6 * p + 3 + k];
+            obs_eval_sc(sc, tr, X, py, px, d.cam, r2, Jp, Jl, nullptr);
+            if (!hp) {
+#pragma unroll
+                for (int k = 0; k < 12; k++) Jp[k] = 0.0;
+            }
+        }
+        d.hasp[i] = hp ? 1 : 0;
+        st_rec<2>(d.f + 2 * (size_t)i, r2);
+        if (hp) st_rec<12>(d.Jp + (size_t)i * 12, Jp);
+        st_rec<6>(d.Jl + (size_t)i * 6, Jl);
+        if (hp) s_slot[pl * hbw + (p - f)] = (short)hpi; else hpi = -1;
+        double *v = s_R + tid * 9;
+        v[0] = Jl[0] * Jl[0] + Jl[3] * Jl[3]; v[1] = Jl[0] * Jl[1] + Jl[3] * Jl[4]; v[2] = Jl[0] * Jl[2] + Jl[3] * Jl[5];
+        v[3] = Jl[1] * Jl[1] + Jl[4] * Jl[4]; v[4] = Jl[1] * Jl[2] + Jl[4] * Jl[5]; v[5] = Jl[2] * Jl[2] + Jl[5] * Jl[5];
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[6 + k] = Jl[k] * r2[0] + Jl[3 + k] * r2[1];
+    }
+    SG_CLK(1);
+    lds_sync();
+    SG_CLK(2);
+    // ---- phase 1: thread = map point: V = sum + D, V^-1, its Cholesky factor, bl
+    if (tid < npts) {
+        const int k = k0 + tid, jj = d.pt_id[k];
+        const double inv_delta = 1.0 / d.st->delta;
+        double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const int t0 = d.pt_start[k] - o0, t1 = d.pt_start[k + 1] - o0;
+        for (int t = t0; t < t1; t++) {
+#pragma unroll
+            for (int c = 0; c < 9; c++) V[c] += s_R[t * 9 + c];
+        }
+        V[0] += fmin(fmax(V[0], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+        V[3] += fmin(fmax(V[3], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+        V[5] += fmin(fmax(V[5], LM_MIN_DIAGONAL), LM_MAX_DIAGONAL) * inv_delta;
+        double Vi[6];
+        inv3_sym(V, Vi);
+#pragma unroll
+        for (int c = 0; c < 6; c++) { d.Vinv[(size_t)c * M + jj] = Vi[c]; s_pt[tid * 16 + c] = Vi[c]; }
+#pragma unroll
+        for (int c = 0; c < 3; c++) { d.bl[(size_t)c * M + jj] = V[6 + c]; s_pt[tid * 16 + 6 + c] = V[6 + c]; }
+        // V^-1 = L L' (V^-1 is positive definite with V; a breakdown gives NaN, which the solve reports as a failed factorisation)
+        const double l00 = sqrt(Vi[0]), l10 = Vi[1] / l00, l20 = Vi[2] / l00;
+        const double l11 = sqrt(Vi[3] - l10 * l10), l21 = (Vi[4] - l20 * l10) / l11;
+        const double l22 = sqrt(Vi[5] - l20 * l20 - l21 * l21);
+        double *L = s_pt + tid * 16 + 9;
+        L[0] = l00; L[1] = l10; L[2] = l20; L[3] = l11; L[4] = l21; L[5] = l22;
+    }
+    lds_sync();
+    SG_CLK(3);
+    // ---- phase 2a: free-pose observations: W = Jp'Jl, the gradient term, Y = W L (kept in registers), record (Jp, gradient) -> R
+    double Y[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) Y[k] = 0.0;
+    if (hpi >= 0) {
+        double Vi[6], bl[3], L[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) Vi[c] = s_pt[pl * 16 + c];
+#pragma unroll
+        for (int c = 0; c < 3; c++) bl[c] = s_pt[pl * 16 + 6 + c];
+#pragma unroll
+        for (int c = 0; c < 6; c++) L[c] = s_pt[pl * 16 + 9 + c];
+        const double vb0 = Vi[0] * bl[0] + Vi[1] * bl[1] + Vi[2] * bl[2];
+        const double vb1 = Vi[1] * bl[0] + Vi[3] * bl[1] + Vi[4] * bl[2];
+        const double vb2 = Vi[2] * bl[0] + Vi[4] * bl[1] + Vi[5] * bl[2];
+        double *E = s_R + hpi * 18;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            const double w0 = Jp[a] * Jl[0] + Jp[6 + a] * Jl[3];
+            const double w1 = Jp[a] * Jl[1] + Jp[6 + a] * Jl[4];
+            const double w2 = Jp[a] * Jl[2] + Jp[6 + a] * Jl[5];
+            Y[3 * a] = w0 * L[0] + w1 * L[1] + w2 * L[2]; Y[3 * a + 1] = w1 * L[3] + w2 * L[4]; Y[3 * a + 2] = w2 * L[5];
+            E[12 + a] = (Jp[a] * r2[0] + Jp[6 + a] * r2[1]) - (w0 * vb0 + w1 * vb1 + w2 * vb2);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) E[k] = Jp[k];
+    }
+    lds_sync();
+    SG_CLK(4);
+    // ---- phase 2x: Jp'Jp, the gradient and diag U per window slot: lane = (slot a2, row rr, point class xq); no partials through LDS --
+    //      the XQ lanes of a task sit next to each other and are folded by DPP
+    double *out = d.wpart + (size_t)blockIdx.x * d.wstride;
+    {
+        const int TPW = (nrow + NW - 1) / NW, XQ = TPW <= 16 ? 4 : TPW <= 32 ? 2 : 1;
+        const int task = wv * TPW + lane / XQ, xq = lane - (lane / XQ) * XQ;
+        const bool xl = lane / XQ < TPW && task < nrow;
+        const int a2 = xl ? task / 6 : 0, rr = task - 6 * (task / 6);
+        double ex[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) ex[k] = 0.0;
+        if (xl)
+            for (int x = xq; x < npts; x += XQ) {
+                const int ta = s_slot[x * hbw + a2];
+                if (ta < 0) continue;
+                double J[12];
+                ld_rec<12>(s_R + ta * 18, J);
+                const double j0 = rr == 0 ? J[0] : rr == 1 ? J[1] : rr == 2 ? J[2] : rr == 3 ? J[3] : rr == 4 ? J[4] : J[5];
+                const double j1 = rr == 0 ? J[6] : rr == 1 ? J[7] : rr == 2 ? J[8] : rr == 3 ? J[9] : rr == 4 ? J[10] : J[11];
+#pragma unroll
+                for (int c = 0; c < 6; c++) ex[c] = fma(j1, J[6 + c], fma(j0, J[c], ex[c]));
+                ex[6] += s_R[ta * 18 + 12 + rr];
+            }
+#pragma unroll
+        for (int k = 0; k < 7; k++) ex[k] = sg_fold(ex[k], XQ);
+        if (xl && xq == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) s_dg[a2 * 36 + rr * 6 + c] = ex[c];
+            const double ud = rr == 0 ? ex[0] : rr == 1 ? ex[1] : rr == 2 ? ex[2] : rr == 3 ? ex[3] : rr == 4 ? ex[4] : ex[5];
+            out[nwin * 36 + a2 * 12 + rr] = ex[6]; out[nwin * 36 + a2 * 12 + 6 + rr] = ud;
+        }
+    }
+    lds_sync();                                               // every record is read: R becomes the matrix Y
+    SG_CLK(5);
+    // ---- phase 2b: Y -> R; cells nobody owns (a slot without observation, the padding rows and columns) are zeroed by whoever comes by
+    const int K3 = 3 * npts, K4 = (K3 + 3) & ~3;
+    if (hpi >= 0) {
+        const int rb = 6 * (p - f);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int k = 3 * pl + c;
+            double *col = s_R + ((size_t)(k >> 1) * RP + rb) * 2 + (k & 1);
+#pragma unroll
+            for (int r = 0; r < 6; r++) col[2 * r] = Y[3 * r + c];
+        }
+    }
+    for (int c = tid; c < npts * hbw; c += TT)
+        if (s_slot[c] < 0) {
+            const int x = c / hbw, rb = 6 * (c - x * hbw);
+            for (int cc = 0; cc < 3; cc++) {
+                const int k = 3 * x + cc;
+                double *col = s_R + ((size_t)(k >> 1) * RP + rb) * 2 + (k & 1);
+#pragma unroll
+                for (int r = 0; r < 6; r++) col[2 * r] = 0.0;
+            }
+        }
+    for (int c = tid; c < (RP - nrow) * K4; c += TT) { const int k = c / (RP - nrow), row = nrow + (c - k * (RP - nrow)); s_R[((size_t)(k >> 1) * RP + row) * 2 + (k & 1)] = 0.0; }
+    for (int c = tid; c < (K4 - K3) * nrow; c += TT) { const int k = K3 + c / nrow, row = c - (c / nrow) * nrow; s_R[((size_t)(k >> 1) * RP + row) * 2 + (k & 1)] = 0.0; }
+    lds_sync();
+    SG_CLK(6);
+    // ---- phase 3: -(Y Y') on the matrix cores: the upper-triangular 16 x 16 tiles dealt to the waves, three tiles (three independent
+    //      accumulator chains) at a time
+    {
+        const int NT = RP / 16, ntiles = NT * (NT + 1) / 2, q = lane >> 4, c16 = lane & 15, nks = K4 >> 2;
+        const size_t lane_off = ((size_t)(q >> 1) * RP + c16) * 2 + (q & 1), kstep = (size_t)4 * RP;
+        auto emit = [&](int I, int J, const sgm_d4 &acc) {
+            const int col = J * 16 + c16, b = col / 6, cc = col - 6 * b;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = I * 16 + 4 * r + q, a = row / 6, rr = row - 6 * a;
+                if (a >= hbw || b >= hbw || a > b) continue;
+                const int w = a * hbw - a * (a - 1) / 2 + (b - a);
+                if (a < b) out[w * 36 + rr * 6 + cc] = -acc[r];
+                else {
+                    const double v = s_dg[a * 36 + rr * 6 + cc] - acc[r];
+                    out[w * 36 + rr * 6 + cc] = v;
+                    if (I < J) out[w * 36 + cc * 6 + rr] = v;      // a diagonal block cut by a tile boundary: its mirror half lies in a tile below the diagonal, which nobody computes
+                }
+            }
+        };
+        for (int t0 = wv; t0 < ntiles; t0 += 3 * NW) {
+            int I[3], J[3]; bool ok[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                int t = t0 + u * NW; ok[u] = t < ntiles; if (!ok[u]) t = 0;
+                int ii = 0; while (t >= NT - ii) { t -= NT - ii; ii++; }
+                I[u] = ii; J[u] = ii + t;
+            }
+            const double *pa0 = s_R + lane_off + (size_t)I[0] * 32, *pb0 = s_R + lane_off + (size_t)J[0] * 32;
+            const double *pa1 = s_R + lane_off + (size_t)I[1] * 32, *pb1 = s_R + lane_off + (size_t)J[1] * 32;
+            const double *pa2 = s_R + lane_off + (size_t)I[2] * 32, *pb2 = s_R + lane_off + (size_t)J[2] * 32;
+            sgm_d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0, c2 = c0;
+            for (int ks = 0; ks < nks; ks++) {
+                const size_t o = (size_t)ks * kstep;
+                const double a0 = pa0[o], b0 = pb0[o], a1 = pa1[o], b1 = pb1[o], a2m = pa2[o], b2 = pb2[o];
+                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2m, b2, c2, 0, 0, 0);
+            }
+            emit(I[0], J[0], c0);
+            if (ok[1]) emit(I[1], J[1], c1);
+            if (ok[2]) emit(I[2], J[2], c2);
+        }
+    }
+    SG_CLK(7);
+    SGM_DUMP();
+}
 
 // S, g, diag(U) from the window partials: thread = (band block (p, p + dq), entry) / (pose, gradient or diagonal entry)
 __device__ __forceinline__ void schur_reduce_body(const BADev &d, int use_state)
@@ -2382,6 +2636,13 @@ template <int TT> __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_p
     if ((int)blockIdx.x >= w.d.ngrp) return;
     schur_groups_body<TT>(w.d, 0.0, ignore_outliers, 1);
 }
+template <int TT> __global__ __launch_bounds__(TT) void k_schur_groups_m(const BAWin *tab, int ignore_outliers)
+{
+    const BAWin w = ba_win(tab);
+    if (w.pad) return;                                       // the window is k_ba_window's
+    if ((int)blockIdx.x >= w.d.ngrp) return;
+    schur_groups_mfma_body<TT>(w.d, ignore_outliers);
+}
 __global__ __launch_bounds__(256) void k_schur_reduce_b(const BAWin *tab)
 {
     const BAWin w = ba_win(tab);
@@ -4018,6 +4279,12 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
         static const bool no_t256 = getenv("SLAMHIP_BA_BATCH_T512") != nullptr;
         const int TT = (!no_t256 && max_ob <= 256 && (max_hb + 1) * (max_hb + 2) / 2 <= 256) ? 256 : SG_T;
         for (int k = 0; k < NB; k++) if (!pl[batch[k]].err && !tab_h[k].pad) lds_sg = std::max(lds_sg, sg_lds_bytes(tab_h[k].d.whb, tab_h[k].d.P, tab_h[k].d.sg_ob, tab_h[k].d.sg_sb, TT, tab_h[k].d.sg_hp));
+        // the Schur products on the matrix cores (k_schur_groups_m): 256-thread groups whose matrix Y (3 x points columns, 6 x window slots rows) fits
+        // LDS beside two more workgroups; SLAMHIP_BA_NO_MFMA=1 keeps the vector kernel (A/B timing, and the parity reference of the tests)
+        static const bool no_mfma = getenv("SLAMHIP_BA_NO_MFMA") != nullptr;
+        size_t lds_m = 0;
+        for (int k = 0; k < NB; k++) if (!pl[batch[k]].err && !tab_h[k].pad) lds_m = std::max(lds_m, sgm_lds_bytes(tab_h[k].d.whb, tab_h[k].d.P, tab_h[k].d.sg_ob, tab_h[k].d.sg_sb, tab_h[k].d.sg_hp));
+        const bool use_mfma = !no_mfma && TT == 256 && lds_m > 0 && lds_m <= 64 * 1024;
         const auto tw2 = std::chrono::steady_clock::now();
         hipStream_t st = ctx->stream;
         static std::atomic<bool> attr_set[64];
@@ -4026,6 +4293,7 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
             HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups_b<SG_T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB, SOLVE_MAX_N / 6)));
             HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups_b<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB, SOLVE_MAX_N / 6)));
             HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_band_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups_m<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
             attr_set[dv].store(true, std::memory_order_release);
         }
         const BAWin *tab = (const BAWin *)A; const BARes *rtab = (const BARes *)(A + tab_bytes);
@@ -4033,7 +4301,8 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
             hipLaunchKernelGGL(k_linearize_b, dim3(gx_obs, NB), dim3(256), 0, st, tab, ignore, 0);
             hipLaunchKernelGGL(k_pass_start_b, dim3(1, NB), dim3(256), 0, st, tab, ignore ? 1 : 0);
             for (int it = 1; it <= iters; it++) {
-                if (TT == 256) hipLaunchKernelGGL(k_schur_groups_b<256>, dim3(gx_grp, NB), dim3(256), lds_sg, st, tab, ignore);
+                if (use_mfma) hipLaunchKernelGGL(k_schur_groups_m<256>, dim3(gx_grp, NB), dim3(256), lds_m, st, tab, ignore);
+                else if (TT == 256) hipLaunchKernelGGL(k_schur_groups_b<256>, dim3(gx_grp, NB), dim3(256), lds_sg, st, tab, ignore);
                 else hipLaunchKernelGGL(k_schur_groups_b<SG_T>, dim3(gx_grp, NB), dim3(SG_T), lds_sg, st, tab, ignore);
                 hipLaunchKernelGGL(k_schur_reduce_b, dim3(gx_red, NB), dim3(256), 0, st, tab);
                 hipLaunchKernelGGL(k_band_solve_b, dim3(1, NB), dim3(BS_T), lds_band, st, tab);
