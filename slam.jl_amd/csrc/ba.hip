@@ -80,15 +80,17 @@ struct BADev {
     double *wpart;
     double *S, *g, *udiag;       // reduce buffer views
     double *Swork, *dp, *dl;
+    double *sc0, *sc1;           // [P][6] each: sin / cos of the angles of the poses in d.pose / in d.pose_t (batches: formed once per window and iteration by
+                                 // k_pass_start_b / k_trial_poses_b and swapped with the parameter buffers; every point group used to form them for itself)
     double *part;                // reduction partials
     LMState *st;
 };
 // the committed parameters and the trial ones: d.pose / d.pts hold the committed set while st->cur == 0, d.pose_t / d.pts_t while it is 1
-struct ParamBufs { double *pose, *pts, *pose_t, *pts_t; };
+struct ParamBufs { double *pose, *pts, *pose_t, *pts_t; double *sc, *sc_t; };     // sc / sc_t: sin / cos of the committed / trial poses (batches)
 __device__ __forceinline__ ParamBufs param_bufs(const BADev &d)
 {
     const bool sw = d.st->cur != 0;
-    return ParamBufs{sw ? d.pose_t : d.pose, sw ? d.pts_t : d.pts, sw ? d.pose : d.pose_t, sw ? d.pts : d.pts_t};
+    return ParamBufs{sw ? d.pose_t : d.pose, sw ? d.pts_t : d.pts, sw ? d.pose : d.pose_t, sw ? d.pts : d.pts_t, sw ? d.sc1 : d.sc0, sw ? d.sc0 : d.sc1};
 }
 
 
@@ -247,6 +249,7 @@ template <int N> __device__ __forceinline__ void st_rec(double *p, const double 
     for (int k = 0; k < N / 2; k++) q[k] = make_double2(v[2 * k], v[2 * k + 1]);
 }
 
+template <bool STORE = true>          // STORE = false (batches): the cost only -- the grouped build evaluates every observation again and keeps what it needs
 __device__ __forceinline__ void linearize_body(const BADev &d, int ignore_outliers, int respect_done)
 {
     const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
@@ -268,16 +271,19 @@ __device__ __forceinline__ void linearize_body(const BADev &d, int ignore_outlie
             double pose[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) pose[k] = pb.pose[6 * p + k];
-            obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r, Jp, Jl, nullptr);
+            if (STORE) obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r, Jp, Jl, nullptr);
+            else obs_eval(pose, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, nullptr);
             if (!hp) {
 #pragma unroll
                 for (int k = 0; k < 12; k++) Jp[k] = 0.0;
             }
         }
-        d.hasp[i] = hp ? 1 : 0;
-        st_rec<2>(d.f + 2 * (size_t)i, r);
-        st_rec<12>(d.Jp + (size_t)i * 12, Jp);
-        st_rec<6>(d.Jl + (size_t)i * 6, Jl);
+        if (STORE) {
+            d.hasp[i] = hp ? 1 : 0;
+            st_rec<2>(d.f + 2 * (size_t)i, r);
+            st_rec<12>(d.Jp + (size_t)i * 12, Jp);
+            st_rec<6>(d.Jl + (size_t)i * 6, Jl);
+        }
         ss = r[0] * r[0] + r[1] * r[1];
     }
     const double t = block_sum(ss, sh);
@@ -758,7 +764,7 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
         active = !(ignore_outliers && d.outl[i]); hp = active && !d.pconst[p];
         py = d.pix[i]; px = d.pix[O + i];
     }
-    for (int q2 = tid; q2 < d.P; q2 += TT) pose_sincos(pb.pose + 6 * q2, s_sc + 6 * q2);
+    for (int a = tid; a < 6 * d.P; a += TT) s_sc[a] = pb.sc[a];      // (formed once per window: k_pass_start_b / k_trial_poses_b)
     for (int x = tid; x < npts * hbw; x += TT) s_slot[x] = -1;
     lds_sync();
     SG_CLK(0);
@@ -782,10 +788,7 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
                 for (int k = 0; k < 12; k++) Jp[k] = 0.0;
             }
         }
-        d.hasp[i] = hp ? 1 : 0;
-        st_rec<2>(d.f + 2 * (size_t)i, r2);
-        if (hp) st_rec<12>(d.Jp + (size_t)i * 12, Jp);
-        st_rec<6>(d.Jl + (size_t)i * 6, Jl);
+        // (nothing of the evaluation is stored: k_update_groups_b<.., RECOMP> forms it again -- 160 bytes per observation not written here, not read there)
         if (hp) s_slot[pl * hbw + (p - f)] = (short)hpi; else hpi = -1;
         double *v = s_R + tid * 9;
         v[0] = Jl[0] * Jl[0] + Jl[3] * Jl[3]; v[1] = Jl[0] * Jl[1] + Jl[3] * Jl[4]; v[2] = Jl[0] * Jl[2] + Jl[3] * Jl[5];
@@ -2369,25 +2372,29 @@ __global__ __launch_bounds__(256) void k_trial(BADev d, int ignore_outliers, int
 // k_backsub + k_trial on the point groups of k_schur_groups (one workgroup per group, dp in LDS): thread = observation forms
 // Jl' (Jp dp), thread = point sums them in observation order, dl = V^-1 (bl - sum), trial point; thread = observation again: trial
 // and predicted residual.  Partials: part[g] = max |dx|, part[ngrp + 2 g] = trial cost, part[ngrp + 2 g + 1] = predicted cost.
-template <int TT>
-__device__ __forceinline__ void update_groups_body(const BADev &d, int ignore_outliers, int use_state)
+// s_dp [n], s_u [observations x 3], s_dl [points x 6: dl (3), trial point (3)], s_red [8], s_sct [n: sin / cos of every TRIAL pose's angles]: LDS of the
+// caller (static arrays of the largest sizes in the single-window kernel; a batch carves them from dynamic LDS at its own sizes -- 36 KB of static
+// arrays held k_update_groups_b to four workgroups per compute unit).  sct_ready: pb.sc_t holds the trial poses' sin / cos already (k_trial_poses_b).
+// RECOMP (batches on the matrix-core build): the Jacobians and the residual at the committed parameters are formed HERE again instead of being stored by the
+// build and read back (160 bytes per observation each way: the kernel was bound by those reads, 0.97 GB per launch of 128 x P20); s_sc = the committed poses'
+// sin / cos.  Same function of the same arguments as in the build: the same bits.
+template <int TT, bool RECOMP = false>
+__device__ __forceinline__ void update_groups_body(const BADev &d, int ignore_outliers, int use_state, double *s_dp, double *s_u, double *s_dl, double *s_red, double *s_sct, bool sct_ready, double *s_sc = nullptr)
 {
     const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
-    __shared__ double s_dp[SOLVE_MAX_N];
-    __shared__ double s_u[SG_OB * 3];
-    __shared__ double s_dl[SG_SB * 6];                      // dl (3), trial point (3)
-    __shared__ double s_red[8];
     if (use_state && d.st->converged) return;
     const int tid = threadIdx.x, M = d.M, O = d.O, n = d.n;
     const int4 G = d.grp[blockIdx.x];
     const int k0 = G.x, o0 = G.y, npts = G.z >> 16, nobs = G.w;
-    __shared__ double s_sct[SOLVE_MAX_N];                  // sin / cos of every TRIAL pose's angles
     for (int a = tid; a < n; a += TT) s_dp[a] = d.dp[a];
+    if (sct_ready) { for (int a = tid; a < n; a += TT) s_sct[a] = pb.sc_t[a]; }
+    if (RECOMP) { for (int a = tid; a < n; a += TT) s_sc[a] = pb.sc[a]; }
     lds_sync();
-    for (int q = tid; q < d.P; q += TT) {
-        const double tp[3] = {pb.pose[6 * q] - s_dp[6 * q], pb.pose[6 * q + 1] - s_dp[6 * q + 1], pb.pose[6 * q + 2] - s_dp[6 * q + 2]};
-        pose_sincos(tp, s_sct + 6 * q);
-    }
+    if (!sct_ready)
+        for (int q = tid; q < d.P; q += TT) {
+            const double tp[3] = {pb.pose[6 * q] - s_dp[6 * q], pb.pose[6 * q + 1] - s_dp[6 * q + 1], pb.pose[6 * q + 2] - s_dp[6 * q + 2]};
+            pose_sincos(tp, s_sct + 6 * q);
+        }
     double mx = 0.0;
     if (blockIdx.x == 0)
         for (int a = tid; a < n; a += TT) { const double v = s_dp[a]; pb.pose_t[a] = pb.pose[a] - v; mx = fmax(mx, fabs(v)); }
@@ -2398,12 +2405,33 @@ __device__ __forceinline__ void update_groups_body(const BADev &d, int ignore_ou
     if (tid < nobs) {
         p = d.opose[i]; pl = d.opk[i] - k0;
         active = !(ignore_outliers && d.outl[i]);
+        if (RECOMP) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) jp[k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) jl[k] = 0.0;
+            if (active) {
+                const int j = d.opoint[i];
+                const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
+                double sc[6], tr[3];
+#pragma unroll
+                for (int k = 0; k < 6; k++) sc[k] = s_sc[6 * p + k];
+#pragma unroll
+                for (int k = 0; k < 3; k++) tr[k] = pb.pose[6 * p + 3 + k];
+                obs_eval_sc(sc, tr, X, d.pix[i], d.pix[O + i], d.cam, ff, jp, jl, nullptr);
+                if (d.pconst[p]) {
+#pragma unroll
+                    for (int k = 0; k < 12; k++) jp[k] = 0.0;
+                }
+            }
+        } else {
         if (d.hasp[i]) ld_rec<12>(d.Jp + (size_t)i * 12, jp);
         else {
 #pragma unroll
             for (int k = 0; k < 12; k++) jp[k] = 0.0;                                                           // Jp = 0 unless the observation has a free pose (not stored then)
         }
         ld_rec<6>(d.Jl + (size_t)i * 6, jl); ld_rec<2>(d.f + 2 * (size_t)i, ff);
+        }
 #pragma unroll
         for (int k = 0; k < 6; k++) { a += jp[k] * s_dp[6 * p + k]; b += jp[6 + k] * s_dp[6 * p + k]; }
 #pragma unroll
@@ -2456,7 +2484,11 @@ __device__ __forceinline__ void update_groups_body(const BADev &d, int ignore_ou
     const double t3 = block_max_lds(mx, s_red);
     if (tid == 0) { d.part[blockIdx.x] = t3; d.part[d.ngrp + 2 * blockIdx.x] = t1; d.part[d.ngrp + 2 * blockIdx.x + 1] = t2; }
 }
-__global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outliers, int use_state) { update_groups_body<SG_T>(d, ignore_outliers, use_state); }
+__global__ __launch_bounds__(SG_T) void k_update_groups(BADev d, int ignore_outliers, int use_state)
+{
+    __shared__ double s_dp[SOLVE_MAX_N], s_u[SG_OB * 3], s_dl[SG_SB * 6], s_red[8], s_sct[SOLVE_MAX_N];
+    update_groups_body<SG_T>(d, ignore_outliers, use_state, s_dp, s_u, s_dl, s_red, s_sct, false);
+}
 
 // Sums the partials (fixed order) and, in the single-GPU path, runs the
 // LeastSquaresOptim accept/reject logic.  mode 0: ssr of the current residuals
@@ -2615,7 +2647,7 @@ __global__ __launch_bounds__(256) void k_linearize_b(const BAWin *tab, int ignor
     const BAWin w = ba_win(tab);
     if (w.pad) return;                                       // the window is k_ba_window's
     if ((int)blockIdx.x >= w.nb_obs) return;
-    linearize_body(w.d, ignore_outliers, respect_done);
+    linearize_body<false>(w.d, ignore_outliers, respect_done);
 }
 // start of a pass: ssr of the current residuals (k_control mode 0) + the reset of the LM state (k_lm_reset), one launch
 __global__ __launch_bounds__(256) void k_pass_start_b(const BAWin *tab, int pass)
@@ -2623,6 +2655,8 @@ __global__ __launch_bounds__(256) void k_pass_start_b(const BAWin *tab, int pass
     const BAWin w = ba_win(tab);
     if (w.pad) return;                                       // the window is k_ba_window's
     control_body(w.d, 0, w.nb_obs, w.nb_pts, 0, nullptr);
+    {   const ParamBufs pb = param_bufs(w.d);                 // the committed poses' sin / cos for the pass's first build (later ones: the accepted trial's, k_trial_poses_b)
+        for (int q = threadIdx.x; q < w.d.P; q += 256) pose_sincos(pb.pose + 6 * q, pb.sc + 6 * q); }
     __syncthreads();
     if (threadIdx.x != 0) return;
     LMState *s = w.d.st;
@@ -2656,12 +2690,29 @@ __global__ __launch_bounds__(BS_T) void k_band_solve_b(const BAWin *tab)
     if (w.pad) return;                                       // the window is k_ba_window's
     band_solve_body(w.d, w.B, 1);
 }
-template <int TT> __global__ __launch_bounds__(TT) void k_update_groups_b(const BAWin *tab, int ignore_outliers)
+// the trial poses' sin / cos, once per window and iteration (one wave; behind k_band_solve_b, ahead of k_update_groups_b)
+__global__ __launch_bounds__(64) void k_trial_poses_b(const BAWin *tab)
 {
     const BAWin w = ba_win(tab);
     if (w.pad) return;                                       // the window is k_ba_window's
+    const BADev &d = w.d;
+    if (d.st->converged) return;
+    const ParamBufs pb = param_bufs(d);
+    for (int q = threadIdx.x; q < d.P; q += 64) {
+        const double tp[3] = {pb.pose[6 * q] - d.dp[6 * q], pb.pose[6 * q + 1] - d.dp[6 * q + 1], pb.pose[6 * q + 2] - d.dp[6 * q + 2]};
+        pose_sincos(tp, pb.sc_t + 6 * q);
+    }
+}
+// dynamic LDS: [n] dp, [n] + [n] sin / cos of the trial / committed poses, [cap_ob x 3], [cap_sb x 6], [8] (ug_lds_bytes)
+static size_t ug_lds_bytes(int n, int cap_ob, int cap_sb) { return ((size_t)3 * n + (size_t)cap_ob * 3 + (size_t)cap_sb * 6 + 8) * 8; }
+template <int TT, bool RECOMP> __global__ __launch_bounds__(TT) void k_update_groups_b(const BAWin *tab, int ignore_outliers, int n_cap, int cap_ob, int cap_sb)
+{
+    extern __shared__ __attribute__((aligned(16))) double ug_lds[];
+    const BAWin w = ba_win(tab);
+    if (w.pad) return;                                       // the window is k_ba_window's
     if ((int)blockIdx.x >= w.d.ngrp) return;
-    update_groups_body<TT>(w.d, ignore_outliers, 1);
+    double *s_dp = ug_lds, *s_sct = s_dp + n_cap, *s_sc = s_sct + n_cap, *s_u = s_sc + n_cap, *s_dl = s_u + (size_t)cap_ob * 3, *s_red = s_dl + (size_t)cap_sb * 6;
+    update_groups_body<TT, RECOMP>(w.d, ignore_outliers, 1, s_dp, s_u, s_dl, s_red, s_sct, true, s_sc);
 }
 __global__ __launch_bounds__(256) void k_control_b(const BAWin *tab)
 {
@@ -2883,7 +2934,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
         }
     };
 
-    auto pbufs = [&]() { const bool sw = s->cur != 0; return ParamBufs{sw ? d.pose_t : d.pose, sw ? d.pts_t : d.pts, sw ? d.pose : d.pose_t, sw ? d.pts : d.pts_t}; };
+    auto pbufs = [&]() { const bool sw = s->cur != 0; return ParamBufs{sw ? d.pose_t : d.pose, sw ? d.pts_t : d.pts, sw ? d.pose : d.pose_t, sw ? d.pts : d.pts_t, nullptr, nullptr}; };
     __syncthreads();
     for (int pass = 0; pass < 2; pass++) {
         const int ignore = pass, iters = pass ? iterations : iters_fast;
@@ -3403,7 +3454,7 @@ struct BAPlan {
     int sg_hp = SG_OB;
     size_t o_st, o_cf, o_outl, o_bwx = 0, zero_bytes = 0;
     int ksplit = 0;
-    size_t o_pose_t, o_pts_t, o_hasp, o_f, o_ft, o_Jp, o_Jl, o_Vinv, o_bl, o_T, o_W, o_red, o_Sw, o_dp, o_dl, o_li, o_lf, o_part, o_band, o_wpart, o_xchg, work_bytes = 0;
+    size_t o_sc0, o_sc1, o_pose_t, o_pts_t, o_hasp, o_f, o_ft, o_Jp, o_Jl, o_Vinv, o_bl, o_T, o_W, o_red, o_Sw, o_dp, o_dl, o_li, o_lf, o_part, o_band, o_wpart, o_xchg, work_bytes = 0;
     ~BAPlan() { delete ba; }
     int lab(int64_t id) const { return new_of.empty() ? (int)id - 1 : new_of[id - 1]; }
     int fail(int code, const char *fmt, long long a = 0, long long b = 0, long long c = 0) { err = code; snprintf(msg, sizeof msg, fmt, a, b, c); return code; }
@@ -3626,6 +3677,7 @@ static int ba_plan(BAPlan &pl)
     }
     pl.o_red = take(((size_t)n * n + 2 * n + 8) * 8);            // the private reduce buffer: only its band is ever rewritten
     pl.zero_bytes = off; off = 0;
+    pl.o_sc0 = take(n * 8); pl.o_sc1 = take(n * 8);
     pl.o_pose_t = take(n * 8); pl.o_pts_t = take((size_t)3 * M * 8 + 8); pl.o_hasp = take((size_t)O + 1);
     pl.o_f = take((size_t)2 * O * 8 + 8); pl.o_ft = take(8);    // (trial residuals are not kept: every build re-evaluates d.f)
     pl.o_Jp = take((size_t)12 * O * 8 + 8); pl.o_Jl = take((size_t)6 * O * 8 + 8);
@@ -3649,6 +3701,7 @@ static int ba_emit(BAPlan &pl, char *Aup, char *Azero, char *Awork, char *stage)
     const int P = pl.P, M = pl.M, O = pl.O, n = 6 * P;
     BADev &d = ba->d;
     d.cam = {pl.fx, pl.fy, pl.cx, pl.cy}; d.P = P; d.M = M; d.O = O; d.n = n;
+    d.sc0 = (double *)(Awork + pl.o_sc0); d.sc1 = (double *)(Awork + pl.o_sc1);
     d.pose = (double *)(Aup + pl.o_pose); d.pose_t = (double *)(Awork + pl.o_pose_t); d.pts = (double *)(Aup + pl.o_pts); d.pts_t = (double *)(Awork + pl.o_pts_t);
     d.pconst = (const uint8_t *)(Aup + pl.o_const); d.pix = (const double *)(Aup + pl.o_pix);
     d.opose = (const int *)(Aup + pl.o_opose); d.opoint = (const int *)(Aup + pl.o_opoint); d.pt_start = (const int *)(Aup + pl.o_start);
@@ -4281,6 +4334,9 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
         for (int k = 0; k < NB; k++) if (!pl[batch[k]].err && !tab_h[k].pad) lds_sg = std::max(lds_sg, sg_lds_bytes(tab_h[k].d.whb, tab_h[k].d.P, tab_h[k].d.sg_ob, tab_h[k].d.sg_sb, TT, tab_h[k].d.sg_hp));
         // the Schur products on the matrix cores (k_schur_groups_m): 256-thread groups whose matrix Y (3 x points columns, 6 x window slots rows) fits
         // LDS beside two more workgroups; SLAMHIP_BA_NO_MFMA=1 keeps the vector kernel (A/B timing, and the parity reference of the tests)
+        int ug_n = 6, ug_ob = 8, ug_sb = 8;                     // k_update_groups_b's LDS arrays at the batch's own sizes
+        for (int k = 0; k < NB; k++) if (!pl[batch[k]].err && !tab_h[k].pad) { ug_n = std::max(ug_n, tab_h[k].d.n); ug_ob = std::max(ug_ob, tab_h[k].d.sg_ob); ug_sb = std::max(ug_sb, tab_h[k].d.sg_sb); }
+        const size_t lds_ug = ug_lds_bytes(ug_n, ug_ob, ug_sb);
         static const bool no_mfma = getenv("SLAMHIP_BA_NO_MFMA") != nullptr;
         size_t lds_m = 0;
         for (int k = 0; k < NB; k++) if (!pl[batch[k]].err && !tab_h[k].pad) lds_m = std::max(lds_m, sgm_lds_bytes(tab_h[k].d.whb, tab_h[k].d.P, tab_h[k].d.sg_ob, tab_h[k].d.sg_sb, tab_h[k].d.sg_hp));
@@ -4294,6 +4350,9 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
             HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups_b<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg_lds_bytes(BS_MAXHB, SOLVE_MAX_N / 6)));
             HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_band_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_schur_groups_m<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_update_groups_b<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_update_groups_b<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_update_groups_b<SG_T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
             attr_set[dv].store(true, std::memory_order_release);
         }
         const BAWin *tab = (const BAWin *)A; const BARes *rtab = (const BARes *)(A + tab_bytes);
@@ -4306,8 +4365,10 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
                 else hipLaunchKernelGGL(k_schur_groups_b<SG_T>, dim3(gx_grp, NB), dim3(SG_T), lds_sg, st, tab, ignore);
                 hipLaunchKernelGGL(k_schur_reduce_b, dim3(gx_red, NB), dim3(256), 0, st, tab);
                 hipLaunchKernelGGL(k_band_solve_b, dim3(1, NB), dim3(BS_T), lds_band, st, tab);
-                if (TT == 256) hipLaunchKernelGGL(k_update_groups_b<256>, dim3(gx_grp, NB), dim3(256), 0, st, tab, ignore);
-                else hipLaunchKernelGGL(k_update_groups_b<SG_T>, dim3(gx_grp, NB), dim3(SG_T), 0, st, tab, ignore);
+                hipLaunchKernelGGL(k_trial_poses_b, dim3(1, NB), dim3(64), 0, st, tab);
+                if (use_mfma) hipLaunchKernelGGL((k_update_groups_b<256, true>), dim3(gx_grp, NB), dim3(256), lds_ug, st, tab, ignore, ug_n, ug_ob, ug_sb);
+                else if (TT == 256) hipLaunchKernelGGL((k_update_groups_b<256, false>), dim3(gx_grp, NB), dim3(256), lds_ug, st, tab, ignore, ug_n, ug_ob, ug_sb);
+                else hipLaunchKernelGGL((k_update_groups_b<SG_T, false>), dim3(gx_grp, NB), dim3(SG_T), lds_ug, st, tab, ignore, ug_n, ug_ob, ug_sb);
                 hipLaunchKernelGGL(k_control_b, dim3(1, NB), dim3(256), 0, st, tab);
             }
         };
