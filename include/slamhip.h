@@ -448,6 +448,18 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
                         const int64_t *pose_ids, const int64_t *point_ids, uint8_t *outliers,
                         int iters_fast, int iterations, double repr_eps, double *stats, int32_t *status);
 
+/* The same call in two halves (round 6): _begin hands everything -- structure analysis, staging, upload, solve, download, scatter into the
+ * caller's arrays -- to a thread of the library's own and returns at once; _end waits for it and returns the call's code (message:
+ * slam_last_error).  The estimator task (src/estimator.jl:78-99) prepares the next key-frame's windows while this one's are planned and
+ * solved, without a host thread of its own.  Between the two calls the context belongs to the job -- no other call on it; one job per
+ * context, several contexts for several batches in flight -- and every array passed to _begin stays valid and untouched (theta, outliers,
+ * stats and status are written by the job).  slam_ctx_destroy waits for a job still in flight. */
+int slam_local_ba_batch_begin(slam_ctx *ctx, int S, const double *cams, const int32_t *Pn, const int32_t *Mn, const int32_t *On,
+                              double *theta, const uint8_t *theta_const, const double *pixels_yx,
+                              const int64_t *pose_ids, const int64_t *point_ids, uint8_t *outliers,
+                              int iters_fast, int iterations, double repr_eps, double *stats, int32_t *status);
+int slam_local_ba_batch_end(slam_ctx *ctx);
+
 /* pnp_bundle_adjustment(camera, pose, pixels, points; iterations, depth_eps,
  * repr_eps) -- src/bundle_adjustment.jl:113-171.  pose_cw/out_pose: 4x4
  * column-major.  out_pose = identity when fewer than 5 inliers remain (:157-161). */

@@ -85,6 +85,8 @@ SIGNATURES = {
     "slam_kpset_compute_pose": (cint, [vp, vp, f64p, dbl, cint, C.c_uint64, cint, cint, dbl, dbl, f64p, i32p, i32p, i32p]),
     "slam_local_ba": (cint, [vp, dbl, dbl, dbl, dbl, cint, cint, cint, f64p, u8p, f64p, i64p, i64p, u8p, cint, cint, dbl, f64p]),
     "slam_local_ba_batch": (cint, [vp, cint, f64p, i32p, i32p, i32p, f64p, u8p, f64p, i64p, i64p, u8p, cint, cint, dbl, f64p, i32p]),
+    "slam_local_ba_batch_begin": (cint, [vp, cint, f64p, i32p, i32p, i32p, f64p, u8p, f64p, i64p, i64p, u8p, cint, cint, dbl, f64p, i32p]),
+    "slam_local_ba_batch_end": (cint, [vp]),
     "slam_pnp_ba": (cint, [vp, dbl, dbl, dbl, dbl, f64p, f64p, f64p, cint, cint, cint, dbl, dbl, f64p, f64p, f64p, u8p, C.POINTER(cint)]),
     "slam_ba_create": (cint, [vp, dbl, dbl, dbl, dbl, cint, cint, cint, f64p, u8p, f64p, i64p, i64p, C.POINTER(vp)]),
     "slam_ba_destroy": (cint, [vp]),

@@ -86,6 +86,23 @@ class BABatch:
                                               L.ptr(self.status, L.i32p)))
         return self.status
 
+    def begin(self, iterations=10, repr_eps=5.0, iters_fast=5, ctx=None, reset=False):
+        """`slam_local_ba_batch_begin`: the call proceeds on a thread of the library; `end()` waits for it.  Until then the context is the
+        job's and the packed arrays must not be touched."""
+        ctx = ctx or L.default_context()
+        if reset:
+            self.theta[:] = self.theta0
+        ctx.check(ctx.lib.slam_local_ba_batch_begin(ctx.h, self.S, L.ptr(self.cams), L.ptr(self.Pn, L.i32p), L.ptr(self.Mn, L.i32p), L.ptr(self.On, L.i32p),
+                                                    L.ptr(self.theta), L.ptr(self.tc, L.u8p), L.ptr(self.px), L.ptr(self.pi, L.i64p), L.ptr(self.li, L.i64p),
+                                                    L.ptr(self.outl, L.u8p), int(iters_fast), int(iterations), float(repr_eps), L.ptr(self.stats),
+                                                    L.ptr(self.status, L.i32p)))
+        self._job_ctx = ctx
+
+    def end(self):
+        ctx = self._job_ctx; self._job_ctx = None
+        ctx.check(ctx.lib.slam_local_ba_batch_end(ctx.h))
+        return self.status
+
     def window(self, z):
         """(theta, outliers, stats dict) of window z after solve()"""
         st = self.stats[z]

@@ -4470,6 +4470,51 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
 }
 
 
+// slam_local_ba_batch in two halves: _begin hands the whole call (structure analysis, staging, upload, solve, download, scatter) to a thread of the
+// library's own and returns; _end waits for it and returns its code.  The estimator task of a host (estimator.jl:78-99) thereby prepares key-frame
+// k + 1's windows -- or does anything else -- while key-frame k's are planned and solved, without a thread of its own.  Between the two calls the
+// context belongs to the job (one outstanding job per context; the arrays passed to _begin are read AND written by the job: they stay valid and
+// untouched until _end returns).  A host that wants several batches in flight uses several contexts.
+struct BABatchJob { std::thread th; int rc = SLAM_OK; bool active = false; };
+static std::mutex g_job_mu;
+static std::vector<std::pair<slam_ctx *, BABatchJob *>> g_jobs;
+static BABatchJob *job_of(slam_ctx *ctx, bool create)
+{
+    std::lock_guard<std::mutex> lk(g_job_mu);
+    for (auto &e : g_jobs) if (e.first == ctx) return e.second;
+    if (!create) return nullptr;
+    g_jobs.emplace_back(ctx, new BABatchJob());
+    return g_jobs.back().second;
+}
+int slam_local_ba_batch_begin(slam_ctx *ctx, int S, const double *cams, const int32_t *Pn, const int32_t *Mn, const int32_t *On,
+                              double *theta, const uint8_t *theta_const, const double *pixels_yx,
+                              const int64_t *pose_ids, const int64_t *point_ids, uint8_t *outliers,
+                              int iters_fast, int iterations, double repr_eps, double *stats, int32_t *status)
+{
+    ARG_TRY(ctx, ctx != nullptr);
+    BABatchJob *j = job_of(ctx, true);
+    if (j->active) return slam_fail(ctx, SLAM_ERR_ARG, "slam_local_ba_batch_begin: the context already has a batch in flight (call slam_local_ba_batch_end first)");
+    j->active = true; j->rc = SLAM_OK;
+    j->th = std::thread([=] { j->rc = slam_local_ba_batch(ctx, S, cams, Pn, Mn, On, theta, theta_const, pixels_yx, pose_ids, point_ids, outliers, iters_fast, iterations, repr_eps, stats, status); });
+    return SLAM_OK;
+}
+int slam_local_ba_batch_end(slam_ctx *ctx)
+{
+    ARG_TRY(ctx, ctx != nullptr);
+    BABatchJob *j = job_of(ctx, false);
+    if (!j || !j->active) return slam_fail(ctx, SLAM_ERR_ARG, "slam_local_ba_batch_end: no batch in flight on this context");
+    j->th.join(); j->active = false;
+    return j->rc;                                              // (the message of a failure is the context's: slam_last_error)
+}
+// a context that goes away takes its job record along (called by slam_ctx_destroy; a job still in flight is waited for)
+extern "C" void ba_forget_jobs(slam_ctx *ctx)
+{
+    BABatchJob *j = nullptr;
+    {   std::lock_guard<std::mutex> lk(g_job_mu);
+        for (size_t i = 0; i < g_jobs.size(); i++) if (g_jobs[i].first == ctx) { j = g_jobs[i].second; g_jobs.erase(g_jobs.begin() + (long)i); break; } }
+    if (j) { if (j->active) j->th.join(); delete j; }
+}
+
 // how many slam_local_ba_batch calls of this process had to be solved again because the two workgroups of a window missed each other
 long slam_debug_ba_xretries(void) { return n_xretry.load(); }
 

@@ -207,9 +207,11 @@ int slam_ctx_create_priority(int device, int priority, slam_ctx **out)
     return SLAM_OK;
 }
 
+extern "C" void ba_forget_jobs(slam_ctx *ctx);          // ba.hip: a batch job still in flight on the context is waited for
 int slam_ctx_destroy(slam_ctx *ctx)
 {
     if (!ctx) return SLAM_OK;
+    ba_forget_jobs(ctx);
     (void)hipSetDevice(ctx->device);
     (void)slam_stream_wait(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);

@@ -251,4 +251,35 @@ function bundle_adjustment_batch!(caches::AbstractVector, cameras::AbstractVecto
     status
 end
 
+# The same in two halves (slam_local_ba_batch_begin / _end): `begin` packs the caches and hands the call to a thread of the library -- the
+# estimator task goes on (e.g. packs the next key-frame's caches) --, `finish!` waits and writes θ / outliers back.  The packed arrays live in the
+# returned job until then; `jctx` is a context of the job's own (one job per context).
+struct BABatchJob; jctx::Ptr{Cvoid}; caches; Pn; Mn; On; cams; θ; tc; px; pid; lid; outl; status; end
+function bundle_adjustment_batch_begin(jctx::Ptr{Cvoid}, caches::AbstractVector, cameras::AbstractVector; iterations::Int = 10, repr_ϵ::Real = 5.0)
+    S = length(caches)
+    Pn = Int32[length(c.poses_remap) for c in caches]; Mn = Int32[length(c.points_remap) for c in caches]; On = Int32[length(c.observations) for c in caches]
+    cams = Float64[]; for cam in cameras; append!(cams, (cam.fx, cam.fy, cam.cx, cam.cy)); end
+    θ = reduce(vcat, [Vector{Float64}(c.θ) for c in caches]); tc = reduce(vcat, [Vector{UInt8}(c.θconst) for c in caches])
+    px = reduce(vcat, [vec(Matrix{Float64}(c.pixels)) for c in caches])
+    pid = reduce(vcat, [Vector{Int64}(c.poses_ids) for c in caches]); lid = reduce(vcat, [Vector{Int64}(c.points_ids) for c in caches])
+    outl = zeros(UInt8, max(sum(On), 1)); status = zeros(Int32, S)
+    job = BABatchJob(jctx, caches, Pn, Mn, On, cams, θ, tc, px, pid, lid, outl, status)       # (the job keeps every array alive until finish!)
+    check(ccall((:slam_local_ba_batch_begin, LIB[]), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{UInt8},
+         Cint, Cint, Cdouble, Ptr{Float64}, Ptr{Int32}),
+        jctx, S, cams, Pn, Mn, On, θ, tc, px, pid, lid, outl, 5, iterations, Float64(repr_ϵ), C_NULL, status))
+    job
+end
+function finish!(job::BABatchJob)
+    check(ccall((:slam_local_ba_batch_end, LIB[]), Cint, (Ptr{Cvoid},), job.jctx))
+    to = 0; oo = 0
+    for (z, c) in enumerate(job.caches)
+        n = 6 * job.Pn[z] + 3 * job.Mn[z]
+        copyto!(c.θ, 1, job.θ, to + 1, n); to += n
+        for i in 1:job.On[z]; c.outliers[i] = job.outl[oo + i] != 0; end
+        oo += job.On[z]
+    end
+    job.status
+end
+
 end # module

@@ -229,3 +229,25 @@ def test_halves_that_miss_each_other_fall_back_to_one_workgroup(tmp_path):
     assert outs["giveup"][1] >= 1, "the bound of 0 us never triggered: the test does not exercise the fallback"
     assert outs["one"][1] == 0
     assert np.array_equal(outs["giveup"][0], outs["one"][0])
+
+
+def test_begin_end_equals_the_blocking_call_and_overlaps_other_work(slam, syn):
+    """slam_local_ba_batch_begin / _end: the job runs on the library's thread while the caller does other device work on another context (here:
+    a second batch, blocking); the results are the blocking call's to the bit; a second _begin on a busy context and an _end without a job are
+    argument errors"""
+    sc = [syn.ba_scene(P=20, M=600, seed=900 + z) for z in range(6)] + [syn.ba_scene(P=25, M=300, seed=910, n_const=20)]
+    ref = slam.BABatch([_cache(slam, s) for s in sc], sc[0]["cam"]); ref.solve()
+    a = slam.BABatch([_cache(slam, s) for s in sc], sc[0]["cam"]); b = slam.BABatch([_cache(slam, s) for s in sc], sc[0]["cam"])
+    ctx_a, ctx_b = slam.Context(0), slam.Context(0)
+    a.begin(ctx=ctx_a)
+    with pytest.raises(slam.SlamHipError, match="already has a batch in flight"):
+        b.begin(ctx=ctx_a)
+    b.solve(ctx=ctx_b)                                   # other work while the job runs
+    st = a.end()
+    assert not st.any() and not b.status.any()
+    assert np.array_equal(a.theta, ref.theta) and np.array_equal(a.outl, ref.outl) and np.array_equal(b.theta, ref.theta)
+    with pytest.raises(slam.SlamHipError, match="no batch in flight"):
+        ctx_a.check(ctx_a.lib.slam_local_ba_batch_end(ctx_a.h))
+    a.begin(ctx=ctx_a, reset=True)                       # a context that is closed with a job in flight waits for it
+    ctx_a.close(); ctx_b.close()
+    assert np.array_equal(a.theta, ref.theta)
