@@ -170,6 +170,8 @@ int slam_pyr_update_dev(slam_ctx *ctx, slam_pyr *pyr, const double *image_dev, i
  * `Gray{Float64}.(frame)` (example/kitty/main.jl:39-41): the conversion raw/255 runs on the device,
  * so the host link carries 1 byte per pixel instead of 8. */
 int slam_pyr_update_u8(slam_ctx *ctx, slam_pyr *pyr, const uint8_t *image_u8, int mode, double sigma);
+/* the same from an 8-bit image already resident in HBM; returns after enqueueing when sync == 0 */
+int slam_pyr_update_u8_dev(slam_ctx *ctx, slam_pyr *pyr, const uint8_t *image_u8_dev, int mode, double sigma, int sync);
 /* copy!(dst, src) pyramid.jl:28-38 (same shape required) */
 int slam_pyr_copy(slam_ctx *ctx, slam_pyr *dst, const slam_pyr *src);
 /* deepcopy(lk) SLAM.jl:218 */
@@ -344,6 +346,46 @@ int slam_kpset_download_keyframe(slam_ctx *ctx, slam_kpset *ks, int s, double *k
 int slam_kpset_compute_pose_5pt(slam_ctx *ctx, slam_kpset *ks, const double *params, double min_parallax, double max_repr_error,
                                 int iters, uint64_t seed, double *P, int32_t *status, int32_t *n_inliers, double *parallax,
                                 int32_t *counts);
+
+/* ---- one live stream, one call per frame (round 6) -----------------------------------------------------------------------------------
+ * What run!() does per frame (src/front_end.jl:58-113: preprocess! :454-470 = copy!(previous_pyramid, current_pyramid) + update!,
+ * klt_tracking! -> optical_flow_matching! map_manager.jl:451-564; at a key-frame create_keyframe! -> extract_keypoints!
+ * map_manager.jl:98-113 and the mapper's right pyramid + stereo matching + triangulate_stereo! mapper.jl:51-66, :142-183) as ONE entry:
+ * the frame's bytes are copied to HBM, the single-image build graph, the 3-D / 2-D matching passes, the removal of lost keypoints and
+ * (key-frame) detection, right build, stereo match and triangulation are ENQUEUED back to back -- no host code between them -- and the call
+ * returns with the one number a front-end needs per frame, the length of the keypoint list.  The lists live in HBM (a slam_kpset with one
+ * stream); three left pyramids rotate (copy! = a handle rotation).
+ *   lookahead = 0: step(frame t) returns frame t's list: latency = build + match.
+ *   lookahead = 1: step(frame t + 1) starts that frame's build on the build stream and returns frame t's list (whose build ran during the
+ *                  call before): one frame of latency buys the overlap of build and matching -- a recorded sequence, or a camera whose
+ *                  next frame has arrived while the current one is processed (the "next frame only" figure of bench.py).
+ * config: plain scalars mirroring Params (params.jl:58-82) and the Extractor (extractor.jl:7-22).  Per-call: params / stereo_params =
+ * 32 doubles each as for slam_kpset_flow_match / _stereo_match (prior as there); tri = P1 (16), P2 (16), T21 (16), cam1 (4), cam2 (4),
+ * Twc (16) as for slam_kpset_triangulate (read at key-frames with a right image); cull_flags_dev (nullable): cap bytes in HBM, 1 = remove
+ * before detection (map culling).  right_u8 != NULL marks the fed frame as a key-frame.  frame_out: index (0-based, feed order) of the frame
+ * whose list length count_out reports, -1 while the pipeline fills (first call with lookahead = 1); slam_frontend_flush processes the
+ * frame still in flight.  The per-frame arguments describe the frame that is PROCESSED by the call. */
+typedef struct slam_frontend slam_frontend;
+typedef struct slam_frontend_config {
+    int32_t H, W, pyramid_levels, pyramid_levels_3d, window, iterations;
+    int32_t max_points, radius, grid_rows, grid_cols, cell_size, cap;
+    int32_t pyr_mode;            /* 1: bit-exact update!, 3: tolerance mode */
+    int32_t lookahead;           /* 0 / 1 */
+    int32_t right_target_only;   /* build the right pyramid with SLAM_PYR_TARGET_ONLY */
+    int32_t reserved;
+    double eig_thr, eps, max_distance, sigma_mask, min_response, epipolar_error, max_error, min_depth, pyr_sigma;
+} slam_frontend_config;
+int slam_frontend_create(int device, const slam_frontend_config *cfg, slam_frontend **out);
+int slam_frontend_destroy(slam_frontend *fe);
+int slam_frontend_step(slam_frontend *fe, const uint8_t *left_u8, const uint8_t *right_u8, const double *params, int prior,
+                       const double *stereo_params, int stereo_prior, const double *tri, const uint8_t *cull_flags_dev,
+                       int32_t *frame_out, int32_t *count_out);
+int slam_frontend_flush(slam_frontend *fe, const double *params, int prior, const double *stereo_params, int stereo_prior,
+                        const double *tri, const uint8_t *cull_flags_dev, int32_t *frame_out, int32_t *count_out);
+/* the stream's keypoint set (slam_kpset_download ...) and its tracking context (owned by the front-end) */
+slam_kpset *slam_frontend_keypoints(slam_frontend *fe);
+slam_ctx   *slam_frontend_ctx(slam_frontend *fe);
+const char *slam_frontend_last_error(slam_frontend *fe);
 
 /* ---- bundle adjustment ------------------------------------------------------ */
 /* Array-level body of triangulate_stereo! (parallax == NULL: every gate applies, src/mapper.jl:142-183) and

@@ -17,6 +17,7 @@ from .bundle_adjustment import LocalBACache, bundle_adjustment_, bundle_adjustme
 from .triangulation import triangulate, projection_matrices  # noqa: F401
 from .pose import p3p_ransac, five_point_ransac, draw_samples, p3p_ransac_batch, five_point_ransac_batch  # noqa: F401
 from .kitti import KittyDataset  # noqa: F401
+from .frontend import FrontEnd, FrontEndConfig  # noqa: F401
 from .saver import ReplaySaver  # noqa: F401
 from .keypoint_set import (KeypointSet, stream_params, pose_samples, pose_inputs, pose_samples5, pose_5pt_inputs,  # noqa: F401
                            pose_5pt_compose)

@@ -51,6 +51,14 @@ SIGNATURES = {
     "slam_pyr_update": (cint, [vp, vp, f64p, cint, dbl]),
     "slam_pyr_update_u8": (cint, [vp, vp, u8p, cint, dbl]),
     "slam_pyr_update_dev": (cint, [vp, vp, vp, cint, dbl, cint]),
+    "slam_pyr_update_u8_dev": (cint, [vp, vp, vp, cint, dbl, cint]),
+    "slam_frontend_create": (cint, [cint, vp, C.POINTER(vp)]),
+    "slam_frontend_destroy": (cint, [vp]),
+    "slam_frontend_step": (cint, [vp, u8p, u8p, f64p, cint, f64p, cint, f64p, vp, i32p, i32p]),
+    "slam_frontend_flush": (cint, [vp, f64p, cint, f64p, cint, f64p, vp, i32p, i32p]),
+    "slam_frontend_keypoints": (vp, [vp]),
+    "slam_frontend_ctx": (vp, [vp]),
+    "slam_frontend_last_error": (C.c_char_p, [vp]),
     "slam_pyr_copy": (cint, [vp, vp, vp]),
     "slam_pyr_clone": (cint, [vp, vp, C.POINTER(vp)]),
     "slam_pyr_shape": (cint, [vp, cint, C.POINTER(cint), C.POINTER(cint)]),

@@ -2577,6 +2577,19 @@ int slam_pyr_update_u8(slam_ctx *ctx, slam_pyr *p, const uint8_t *image_u8, int 
     return SLAM_OK;
 }
 
+// the same from an 8-bit image already in HBM (e.g. copied there by the caller from pinned memory on ctx's stream); sync == 0: enqueue only
+int slam_pyr_update_u8_dev(slam_ctx *ctx, slam_pyr *p, const uint8_t *image_u8_dev, int mode, double sigma, int sync)
+{
+    ARG_TRY(ctx, ctx != nullptr && p != nullptr && image_u8_dev != nullptr && (mode == 0 || (mode & ~SLAM_PYR_FLAGS) == 1 || (mode & ~SLAM_PYR_FLAGS) == 3) && sigma > 0);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)p->H[0] * p->W[0];
+    hipLaunchKernelGGL(k_u8_to_f64, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, p->plane(0, 0), (const unsigned char *)image_u8_dev, p->H[0], p->W[0], p->P[0]);
+    int rc = enqueue_build(ctx, p, mode, sigma);
+    if (rc) return rc;
+    if (sync) HIP_TRY(ctx, slam_stream_wait(ctx->stream));
+    return SLAM_OK;
+}
+
 int slam_pyr_copy(slam_ctx *ctx, slam_pyr *dst, const slam_pyr *src)
 {
     ARG_TRY(ctx, ctx != nullptr && dst != nullptr && src != nullptr);
