@@ -272,6 +272,49 @@ def main():
             dt = max_over_ranks(time.perf_counter() - t0)
             return be, stream, c3, dt, stream.n_tracked - kp_before
 
+        def live_step(fast, lookahead):
+            """ONE stream through slam_frontend_step: one C call per frame (u8 frame from host memory -> upload, build graph, matching passes, key-frame work,
+            list length), keypoint list resident in HBM; lookahead: the call builds the frame it is given while it matches the one before
+            (front_end.jl:58-113, :454-470; mapper.jl:51-66)"""
+            u8 = lambda im: np.ascontiguousarray(np.round(np.clip(im, 0, 1) * 255).astype(np.uint8).T)
+            L8 = [u8(x) for x in left]; R8 = [u8(x) for x in right]
+            fe = slam.FrontEnd((H, W), params, extractor, fast=fast, lookahead=lookahead, right_target_only=RIGHT_TARGET_ONLY, device=local_rank)
+            camt = tuple(syn.KITTI_CAM)
+            T21 = np.eye(4); T21[0, 3] = -0.54
+            tri = slam.FrontEnd.tri_params(camt, camt, T21, np.eye(4))
+            sps = slam.stream_params(1, cam=camt, shift_yx=(0.0, -disparity))
+            g = torch.Generator(device=dev); g.manual_seed(77 + rank)
+            culls = [(torch.rand(fe.cap, device=dev, generator=g) < CULL_FRACTION).to(torch.uint8) for _ in range(8)]
+            torch.cuda.synchronize()
+            rngl = np.random.default_rng(5 + rank)
+            fl = np.array(flows)
+            total = w1 + n1 + 2
+            # the per-frame arguments are INPUT (motion-model prior ~0.5 px off): prepared before the timed region
+            pr = [slam.stream_params(1, cam=camt, shift_yx=(fl[seq[t]] - fl[seq[t - 1]] + rngl.normal(0, 0.5, 2)) if t > 0 else (0.0, 0.0)) for t in range(total)]
+            def call(t):
+                due = t - 1 if lookahead else t
+                kfd = due >= 0 and due % KF_EVERY == 0
+                return fe.step(L8[seq[t]], R8[seq[t]] if t % KF_EVERY == 0 else None, params=pr[max(due, 0)], prior=2, stereo_params=sps, stereo_prior=2, tri=tri,
+                               cull_flags_dev=culls[(due // KF_EVERY) % 8].data_ptr() if kfd and due > 0 else None)
+            tracked = 0
+            for t in range(w1):
+                call(t)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for t in range(w1, w1 + n1):
+                fr, cnt = call(t)
+                if fr >= 0 and fr % KF_EVERY != 0:
+                    tracked += cnt
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt = max_over_ranks(time.perf_counter() - t0)
+            kp = fe.keypoints()
+            fe.close()
+            return world * n1 / dt, tracked / max(n1 - n1 // KF_EVERY, 1), len(kp["yx"])
+
     if "single" in legs:
         # ---- the same workload as ONE stream (latency view): 3 contexts, pipelined next-frame pyramid ----
         # builds in flight ahead of the tracking: 1 = the next frame only (rounds 1-2), 3 .. 5 = that many unforked builds (SLAM_PYR_CHAIN) on as
@@ -335,6 +378,17 @@ def main():
                                             "frac": pyr_bytes / (pyr_ms / pyr_n * 1e-3) / 1e9 / HBM_PEAK_GBS}}
             single["device_ms_per_frame"] = {"pyr_update_serial_launches": pyr_ms / prof_steps, "fb_track": fb_ms / prof_steps, "detect": det_ms / prof_steps,
                                              "spans_over_steps": prof_steps, "launches": {"pyr_update": pyr_n, "fb_track": fb_n, "detect": det_n}}
+        # the live stream as ONE C call per frame (slam_frontend_step, keypoint list in HBM): no Python between the enqueues of a frame
+        try:
+            v1, trk1, _ = live_step(False, True)
+            v0, _, _ = live_step(False, False)
+            single["by_builds_in_flight"]["1_python_protocol"] = single["by_builds_in_flight"]["1"]
+            single["by_builds_in_flight"]["1"] = v1
+            single["live_step"] = {"value": v1, "no_lookahead": v0, "tracked_kpts_per_frame": round(trk1, 1), "unit": "frames/sec",
+                                   "what": "slam_frontend_step: one call per frame, frame bytes from host memory, list in HBM; value = the call builds the frame it is given "
+                                           "while matching the one before (next frame only); no_lookahead = build + match of the same frame inside the call"}
+        except Exception as ex:                                   # noqa: BLE001
+            single["live_step"] = {"error": repr(ex)[:300]}
         out["single_stream"] = single
         be.close()
         for c in c3:
@@ -356,6 +410,14 @@ def main():
         be.close()
         for c in c3:
             c.close()
+        try:
+            v1, trk1, _ = live_step(True, True)
+            v0, _, _ = live_step(True, False)
+            out["tolerance_mode"]["single_stream_live_python_protocol"] = out["tolerance_mode"]["single_stream_live"]
+            out["tolerance_mode"]["single_stream_live"] = {"value": v1, "no_lookahead": v0, "unit": "frames/sec", "ms_per_frame": 1e3 * world / v1, "builds_in_flight": 1,
+                                                           "tracked_kpts_per_frame": round(trk1, 1), "what": "slam_frontend_step (one C call per frame), tolerance-mode pyramids"}
+        except Exception as ex:                                   # noqa: BLE001
+            out["tolerance_mode"]["single_stream_live_step_error"] = repr(ex)[:300]
         leg_done("tolerance_mode")
 
     # ---- headline: S lock-stepped streams per GPU, keypoints resident in HBM, bit-exact planes; frames arrive in host memory as the

@@ -100,6 +100,9 @@ def compact_line(out):
     ss = out.get("single_stream")
     if ss and "by_builds_in_flight" in ss:
         c["single_stream"] = {"live": _r(ss["by_builds_in_flight"].get("1")), "lookahead": _r(ss.get("value")), "unit": "frames/sec"}
+        if isinstance(ss.get("live_step"), dict) and "value" in ss["live_step"]:
+            c["single_stream"]["live_no_lookahead"] = _r(ss["live_step"]["no_lookahead"])
+            c["single_stream"]["live_python_protocol"] = _r(ss["by_builds_in_flight"].get("1_python_protocol"))
         if ss.get("live_graph") is not None:
             c["single_stream"]["live_graph"] = _r(ss["live_graph"])
     elif ss:

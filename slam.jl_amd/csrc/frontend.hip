@@ -3,6 +3,7 @@
 // on the library's streams with the keypoint list resident in HBM.  Host code only: every kernel it launches belongs to the seams it calls
 // (slam_pyr_update_u8_dev, slam_kpset_*).  Round 5's live loop paid ~200 us of synchronous Python per frame for the same enqueues.
 #include "common.hpp"
+#include <chrono>
 
 struct slam_frontend {
     slam_frontend_config c;
@@ -16,6 +17,7 @@ struct slam_frontend {
     bool has_right[3] = {false, false, false};
     int n_bound = 0;
     std::string err;
+    double us_feed = 0, us_enq = 0, us_wait = 0; long ncalls = 0;   // host time of the three parts of a call (SLAMHIP_FE_HOSTTIME=1 prints the means at destroy)
 };
 
 namespace {
@@ -34,18 +36,25 @@ int fe_feed(slam_frontend *fe, const uint8_t *left_u8, const uint8_t *right_u8)
     const size_t n = fe->npix;
     // the slot's buffers are free: the frame that used them (t - 3) was processed two calls ago, and slam_frontend_step waits for the
     // tracking stream's read-back before it returns
-    memcpy(fe->pin + (size_t)sl * n, left_u8, n);
+    // a frame that already lies in pinned (page-locked) host memory -- hipHostMalloc / hipHostRegister, e.g. a capture buffer the application
+    // registered once -- is copied from where it is; the caller then keeps it unchanged until the NEXT call returns.  Anything else goes through
+    // the front-end's own pinned ring first (450 KB: ~45 us of the calling thread per KITTI frame).
+    auto pinned = [](const void *q) { hipPointerAttribute_t a; if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; } return a.type == hipMemoryTypeHost; };
+    const uint8_t *lsrc = left_u8;
+    if (!pinned(left_u8)) { memcpy(fe->pin + (size_t)sl * n, left_u8, n); lsrc = fe->pin + (size_t)sl * n; }
     hipStream_t sb = (hipStream_t)slam_ctx_stream(fe->ctx_build);
-    if (fe->tracked) FE_TRY(fe, fe->ctx_build, slam_ctx_wait_event(fe->ctx_build, fe->tracked));      // the pyramid being rebuilt is no longer read by a match
-    if (hipMemcpyAsync(fe->dev8 + (size_t)sl * n, fe->pin + (size_t)sl * n, n, hipMemcpyHostToDevice, sb) != hipSuccess) { fe->err = "slam_frontend: copy of the left frame failed"; return SLAM_ERR_HIP; }
-    FE_TRY(fe, fe->ctx_build, slam_pyr_update_u8_dev(fe->ctx_build, fe->left[sl], fe->dev8 + (size_t)sl * n, fe->c.pyr_mode, fe->c.pyr_sigma, 0));
-    FE_TRY(fe, fe->ctx_build, slam_event_record(fe->ctx_build, fe->built[sl]));
+    if (fe->tracked && fe->ctx_build != fe->ctx) FE_TRY(fe, fe->ctx_build, slam_ctx_wait_event(fe->ctx_build, fe->tracked));      // the pyramid being rebuilt is no longer read by a match
+    if (hipMemcpyAsync(fe->dev8 + (size_t)sl * n, lsrc, n, hipMemcpyHostToDevice, sb) != hipSuccess) { fe->err = "slam_frontend: copy of the left frame failed"; return SLAM_ERR_HIP; }
+    static const int chain = getenv("SLAMHIP_FE_CHAIN") ? SLAM_PYR_CHAIN : 0;                                       // (measurement knob: the build as one chain)
+    FE_TRY(fe, fe->ctx_build, slam_pyr_update_u8_dev(fe->ctx_build, fe->left[sl], fe->dev8 + (size_t)sl * n, fe->c.pyr_mode | chain, fe->c.pyr_sigma, 0));
+    if (fe->ctx_build != fe->ctx) FE_TRY(fe, fe->ctx_build, slam_event_record(fe->ctx_build, fe->built[sl]));
     fe->has_right[sl] = right_u8 != nullptr;
     if (right_u8) {
-        memcpy(fe->pin + (size_t)(3 + sr) * n, right_u8, n);
+        const uint8_t *rsrc = right_u8;
+        if (!pinned(right_u8)) { memcpy(fe->pin + (size_t)(3 + sr) * n, right_u8, n); rsrc = fe->pin + (size_t)(3 + sr) * n; }
         hipStream_t sr_ = (hipStream_t)slam_ctx_stream(fe->ctx_right);
         if (fe->tracked) FE_TRY(fe, fe->ctx_right, slam_ctx_wait_event(fe->ctx_right, fe->tracked));
-        if (hipMemcpyAsync(fe->dev8 + (size_t)(3 + sr) * n, fe->pin + (size_t)(3 + sr) * n, n, hipMemcpyHostToDevice, sr_) != hipSuccess) { fe->err = "slam_frontend: copy of the right frame failed"; return SLAM_ERR_HIP; }
+        if (hipMemcpyAsync(fe->dev8 + (size_t)(3 + sr) * n, rsrc, n, hipMemcpyHostToDevice, sr_) != hipSuccess) { fe->err = "slam_frontend: copy of the right frame failed"; return SLAM_ERR_HIP; }
         FE_TRY(fe, fe->ctx_right, slam_pyr_update_u8_dev(fe->ctx_right, fe->right[sr], fe->dev8 + (size_t)(3 + sr) * n,
                                                          fe->c.pyr_mode | (fe->c.right_target_only ? SLAM_PYR_TARGET_ONLY : 0), fe->c.pyr_sigma, 0));
         FE_TRY(fe, fe->ctx_right, slam_event_record(fe->ctx_right, fe->rbuilt[sr]));
@@ -54,14 +63,15 @@ int fe_feed(slam_frontend *fe, const uint8_t *left_u8, const uint8_t *right_u8)
     return SLAM_OK;
 }
 
-// the oldest fed frame: matching against the frame before it, key-frame work, the list length (the call's one device -> host copy)
+// the oldest fed frame: matching against the frame before it and the key-frame work, enqueued ...
 int fe_track(slam_frontend *fe, const double *params, int prior, const double *stereo_params, int stereo_prior, const double *tri,
-             const uint8_t *cull_flags_dev, int32_t *frame_out, int32_t *count_out)
+             const uint8_t *cull_flags_dev)
 {
     const long t = fe->done;
     const int sl = (int)(t % 3), sp = (int)((t + 2) % 3), sr = (int)(t % 2);
     const slam_frontend_config &c = fe->c;
-    FE_TRY(fe, fe->ctx, slam_ctx_wait_event(fe->ctx, fe->built[sl]));
+    const auto h0t = std::chrono::steady_clock::now();
+    if (fe->ctx_build != fe->ctx) FE_TRY(fe, fe->ctx, slam_ctx_wait_event(fe->ctx, fe->built[sl]));
     if (t > 0 && fe->n_bound > 0) {
         if (!params) { fe->err = "slam_frontend_step: params is NULL"; return SLAM_ERR_ARG; }
         FE_TRY(fe, fe->ctx, slam_kpset_flow_match(fe->ctx, fe->ks, fe->left[sp], fe->left[sl], params, prior, c.pyramid_levels, c.pyramid_levels_3d, c.window,
@@ -79,8 +89,18 @@ int fe_track(slam_frontend *fe, const double *params, int prior, const double *s
         }
     }
     FE_TRY(fe, fe->ctx, slam_event_record(fe->ctx, fe->tracked));
+    fe->us_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0t).count();
+    return SLAM_OK;
+}
+
+// ... and the frame's list length: the call's one device -> host copy (synchronises the tracking stream)
+int fe_finish(slam_frontend *fe, int32_t *frame_out, int32_t *count_out)
+{
+    const long t = fe->done;
+    const auto h1 = std::chrono::steady_clock::now();
     int32_t cnt = 0;
     FE_TRY(fe, fe->ctx, slam_kpset_counts(fe->ctx, fe->ks, &cnt));   // synchronises the tracking stream
+    fe->us_wait += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h1).count();
     fe->n_bound = cnt;
     fe->done++;
     if (frame_out) *frame_out = (int32_t)t;
@@ -98,8 +118,14 @@ int slam_frontend_create(int device, const slam_frontend_config *cfg, slam_front
         return slam_fail(nullptr, SLAM_ERR_ARG, "slam_frontend_create: bad configuration (cap must hold max_points + grid_rows x grid_cols keypoints, pyr_mode 1 or 3)");
     slam_frontend *fe = new slam_frontend();
     fe->c = *cfg; fe->npix = (size_t)cfg->H * cfg->W;
-    int rc = slam_ctx_create_priority(device, -1, &fe->ctx);          // (the tracking stream in its own scheduling class: DESIGN 4)
-    if (!rc) rc = slam_ctx_create(device, &fe->ctx_build);
+    // every stream in the DEFAULT scheduling class: once a stream of another class exists in the process the runtime maps the default-class
+    // queues differently and a latency-bound single stream loses ~40 % (measured twice: bench.py's single-stream legs, and this entry with its
+    // tracking stream in the low class: 1 536 instead of 2 5xx frames/s).  Without look-ahead the build runs on the tracking stream itself:
+    // nothing to overlap, and every cross-queue dependency costs ~10 us.
+    static const int fe_prio = [] { const char *v = getenv("SLAMHIP_FE_PRIO"); return v ? atoi(v) : 0; }();      // (measurement knob: scheduling class of the tracking stream)
+    int rc = fe_prio ? slam_ctx_create_priority(device, fe_prio, &fe->ctx) : slam_ctx_create(device, &fe->ctx);
+    if (!rc && cfg->lookahead) rc = slam_ctx_create(device, &fe->ctx_build);
+    if (!rc && !cfg->lookahead) fe->ctx_build = fe->ctx;
     if (!rc) rc = slam_ctx_create(device, &fe->ctx_right);
     for (int k = 0; k < 3 && !rc; k++) { rc = slam_pyr_create(fe->ctx_build, cfg->H, cfg->W, cfg->pyramid_levels, &fe->left[k]); if (!rc) rc = slam_event_create(fe->ctx_build, &fe->built[k]); }
     for (int k = 0; k < 2 && !rc; k++) { rc = slam_pyr_create(fe->ctx_right, cfg->H, cfg->W, cfg->pyramid_levels, &fe->right[k]); if (!rc) rc = slam_event_create(fe->ctx_right, &fe->rbuilt[k]); }
@@ -114,8 +140,9 @@ int slam_frontend_create(int device, const slam_frontend_config *cfg, slam_front
 int slam_frontend_destroy(slam_frontend *fe)
 {
     if (!fe) return SLAM_OK;
+    if (getenv("SLAMHIP_FE_HOSTTIME") && fe->ncalls) fprintf(stderr, "slam_frontend host time per call: feed %.1f us, enqueue of the frame's work %.1f us, wait for the list length %.1f us (%ld calls)\n", fe->us_feed / fe->ncalls, fe->us_enq / fe->ncalls, fe->us_wait / fe->ncalls, fe->ncalls);
     if (fe->ctx) (void)slam_ctx_synchronize(fe->ctx);
-    if (fe->ctx_build) (void)slam_ctx_synchronize(fe->ctx_build);
+    if (fe->ctx_build && fe->ctx_build != fe->ctx) (void)slam_ctx_synchronize(fe->ctx_build);
     if (fe->ctx_right) (void)slam_ctx_synchronize(fe->ctx_right);
     if (fe->ks) slam_kpset_destroy(fe->ks);
     for (int k = 0; k < 3; k++) { if (fe->left[k]) slam_pyr_destroy(fe->left[k]); if (fe->built[k]) slam_event_destroy(fe->built[k]); }
@@ -124,7 +151,7 @@ int slam_frontend_destroy(slam_frontend *fe)
     if (fe->pin) (void)hipHostFree(fe->pin);
     if (fe->dev8) (void)hipFree(fe->dev8);
     if (fe->ctx_right) slam_ctx_destroy(fe->ctx_right);
-    if (fe->ctx_build) slam_ctx_destroy(fe->ctx_build);
+    if (fe->ctx_build && fe->ctx_build != fe->ctx) slam_ctx_destroy(fe->ctx_build);
     if (fe->ctx) slam_ctx_destroy(fe->ctx);
     delete fe;
     return SLAM_OK;
@@ -136,10 +163,22 @@ int slam_frontend_step(slam_frontend *fe, const uint8_t *left_u8, const uint8_t 
 {
     if (!fe || !left_u8) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_frontend_step: NULL argument");
     if (!fe->tracked) { const int rc = slam_event_create(fe->ctx, &fe->tracked); if (rc) return fe_fail(fe, rc, fe->ctx, "slam_event_create"); (void)slam_event_record(fe->ctx, fe->tracked); }
-    int rc = fe_feed(fe, left_u8, right_u8);
+    // look-ahead: the new frame's copy and build are enqueued FIRST, then the work of the frame whose build ran during the call before, then the
+    // read-back.  (The other order -- tracking first, so that it runs during the 80-150 us of host time the build graph's launch takes -- is SLOWER:
+    // 3 610 instead of 5 250 frames/s in tolerance mode, 2 060 instead of 2 470 bit-exact; the read-back then sits behind the graph's packets on
+    // the hardware queue the runtime gave both streams.  SLAMHIP_FE_TRACK_FIRST=1 selects it.  The tracking stream in another scheduling class,
+    // low or high, costs more still: 1 550-2 200 frames/s.)
+    int rc = SLAM_OK;
+    const bool due = fe->c.lookahead ? fe->fed - fe->done >= 1 : true;
+    static const bool track_first = getenv("SLAMHIP_FE_TRACK_FIRST") != nullptr;                                  // (measurement knob; default: feed first)
+    if (fe->c.lookahead && due && track_first) { rc = fe_track(fe, params, prior, stereo_params, stereo_prior, tri, cull_flags_dev); if (rc) return rc; }
+    const auto h0 = std::chrono::steady_clock::now();
+    rc = fe_feed(fe, left_u8, right_u8);
     if (rc) return rc;
-    if (fe->c.lookahead && fe->fed - fe->done < 2) { if (frame_out) *frame_out = -1; if (count_out) *count_out = 0; return SLAM_OK; }
-    return fe_track(fe, params, prior, stereo_params, stereo_prior, tri, cull_flags_dev, frame_out, count_out);
+    fe->us_feed += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count(); fe->ncalls++;
+    if (!due) { if (frame_out) *frame_out = -1; if (count_out) *count_out = 0; return SLAM_OK; }
+    if (!fe->c.lookahead || !track_first) { rc = fe_track(fe, params, prior, stereo_params, stereo_prior, tri, cull_flags_dev); if (rc) return rc; }
+    return fe_finish(fe, frame_out, count_out);
 }
 
 int slam_frontend_flush(slam_frontend *fe, const double *params, int prior, const double *stereo_params, int stereo_prior,
@@ -147,7 +186,8 @@ int slam_frontend_flush(slam_frontend *fe, const double *params, int prior, cons
 {
     if (!fe) return slam_fail(nullptr, SLAM_ERR_ARG, "slam_frontend_flush: NULL argument");
     if (fe->fed == fe->done) { if (frame_out) *frame_out = -1; if (count_out) *count_out = fe->n_bound; return SLAM_OK; }
-    return fe_track(fe, params, prior, stereo_params, stereo_prior, tri, cull_flags_dev, frame_out, count_out);
+    const int rc = fe_track(fe, params, prior, stereo_params, stereo_prior, tri, cull_flags_dev);
+    return rc ? rc : fe_finish(fe, frame_out, count_out);
 }
 
 slam_kpset *slam_frontend_keypoints(slam_frontend *fe) { return fe ? fe->ks : nullptr; }

@@ -72,6 +72,14 @@ class FrontEnd:
                                                 C.c_void_p(int(cull_flags_dev)) if cull_flags_dev else None, C.byref(self._frame), C.byref(self._count)))
         return self._frame.value, self._count.value
 
+    def step_ptr(self, left_ptr, right_ptr, params_ptr, prior, stereo_params_ptr, stereo_prior, tri_ptr, cull_flags_dev=None):
+        """the same with raw addresses (ints) prepared by the caller -- no array conversion per frame: what a C / Julia host passes"""
+        self._check(self.lib.slam_frontend_step(self.h, C.cast(left_ptr, L.u8p), C.cast(right_ptr, L.u8p) if right_ptr else None,
+                                                C.cast(params_ptr, L.f64p) if params_ptr else None, prior, C.cast(stereo_params_ptr, L.f64p) if stereo_params_ptr else None,
+                                                stereo_prior, C.cast(tri_ptr, L.f64p) if tri_ptr else None, C.c_void_p(int(cull_flags_dev)) if cull_flags_dev else None,
+                                                C.byref(self._frame), C.byref(self._count)))
+        return self._frame.value, self._count.value
+
     def flush(self, params=None, prior=2, stereo_params=None, stereo_prior=2, tri=None, cull_flags_dev=None):
         p = None if params is None else np.ascontiguousarray(params, dtype=np.float64)
         sp = None if stereo_params is None else np.ascontiguousarray(stereo_params, dtype=np.float64)
