@@ -744,6 +744,9 @@ def main():
                                              "adds host partitioning, shard set-up and the RCCL communicator",
                                      "collectives_us": st.get("collectives_us"),
                                      "worth_sharding": bool(sharded_ba.worth_sharding(sP, s2["O"], world)), "ssr_final": st["ssr_final"],
+                                     "model_us_per_iter": sharded_ba.sharding_model(sP, s2["O"], max(world, 2)),
+                                     "predicted_crossover_keyframes": {str(n_): sharded_ba.predicted_crossover(n_) for n_ in (2, 4, 8)},          # at 2000 observations per key-frame
+                                     "predicted_crossover_keyframes_4000_obs_per_kf": {str(n_): sharded_ba.predicted_crossover(n_, 4000) for n_ in (2, 4, 8)},
                                      "rccl_ranks_seen": world if os.environ.get("SLAM_BENCH_BACKEND", "nccl") == "nccl" else 1,
                                      "rccl_note": "the library's RCCL communicator (slam_comm_*) has only ever run with ONE rank in the build environment (1-GPU boxes); "
                                                   "N > 1 ran over gloo with two processes on one GPU (tests/test_gpu_two_process_shards.py)" if world == 1 or os.environ.get("SLAM_BENCH_BACKEND") == "gloo" else None}

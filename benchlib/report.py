@@ -97,6 +97,8 @@ def compact_line(out):
     bs = out.get("ba_sharded")
     if bs:
         c["ba_sharded"] = {k: _r(bs.get(k)) for k in ("world_size", "window_kf", "ms_per_iter_wall", "worth_sharding", "rccl_ranks_seen", "error") if bs.get(k) is not None}
+        if bs.get("predicted_crossover_keyframes"):
+            c["ba_sharded"]["predicted_crossover_keyframes"] = bs["predicted_crossover_keyframes"]      # the worth_sharding model's window size from which N GPUs pay, per N
     ss = out.get("single_stream")
     if ss and "by_builds_in_flight" in ss:
         c["single_stream"] = {"live": _r(ss["by_builds_in_flight"].get("1")), "lookahead": _r(ss.get("value")), "unit": "frames/sec"}

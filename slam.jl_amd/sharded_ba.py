@@ -42,6 +42,23 @@ def worth_sharding(P, O, world_size):
     return saved_us > 1.5 * overhead_us          # margin: the model is per iteration, set-up (pair lists, upload) is not sharded away
 
 
+def sharding_model(P, O, world_size):
+    """the numbers behind worth_sharding, per LM iteration (us): what N ranks save on the observation-proportional part and what the exchange costs"""
+    build_us = 1.45e-3 * O
+    saved_us = build_us * (1.0 - 1.0 / max(world_size, 1))
+    allreduce_us = 25.0 + 2.0 * (world_size - 1) / max(world_size, 1) * 8.0 * (6 * P) ** 2 / 150e3
+    return {"build_us_one_gpu": build_us, "saved_us": saved_us, "exchange_us": allreduce_us + 15.0 + 20.0, "margin": 1.5}
+
+
+def predicted_crossover(world_size, obs_per_keyframe=2000):
+    """smallest window (key-frames P, with obs_per_keyframe observations each: 2000 in the 20 / 50-KF windows of bench.py, 4000 in the 100-KF one) for which worth_sharding says yes at this
+    world size, or None below 512 key-frames -- the model's prediction, to be held against the first measured multi-GPU curve"""
+    for P in range(2, 513):
+        if worth_sharding(P, obs_per_keyframe * P, world_size):
+            return P
+    return None
+
+
 def partition_points(point_ids, M, world_size):
     """Contiguous point ranges balanced by observation count.
     Returns a list of (m_lo, m_hi) 0-based half-open ranges, one per rank."""
