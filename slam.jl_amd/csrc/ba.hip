@@ -4518,8 +4518,8 @@ extern "C" void ba_forget_jobs(slam_ctx *ctx)
 // how many slam_local_ba_batch calls of this process had to be solved again because the two workgroups of a window missed each other
 long slam_debug_ba_xretries(void) { return n_xretry.load(); }
 
-// host-only timing of the batch set-up (no HIP call, no device needed): plan + emit of S windows on `threads` threads into malloc'ed
-// staging; out_us = {plan, emit}.  Measurement aid for tuning the host side on any machine (scripts/probes/ba_host_time.py).
+// host-only timing of the batch set-up (no HIP call, no device needed): plan + emit of S windows on `threads` threads (0: the library's parked
+// worker pool, as slam_local_ba_batch uses it) into malloc'ed staging; out_us = {plan, emit}; returns the number of windows whose set-up failed.  Measurement aid for tuning the host side on any machine (scripts/probes/ba_host_time.py).
 int slam_debug_ba_host_time(int S, const double *cams, const int32_t *Pn, const int32_t *Mn, const int32_t *On, const double *theta, const uint8_t *theta_const,
                             const double *pixels_yx, const int64_t *pose_ids, const int64_t *point_ids, int threads, double *out_us)
 {
@@ -4535,6 +4535,7 @@ int slam_debug_ba_host_time(int S, const double *cams, const int32_t *Pn, const 
         q.may_reorder = true; q.small_groups = true;
     }
     auto parallel = [&](auto fn) {
+        if (threads == 0) { ba_pool().run(S, fn); return; }      // the parked worker pool of slam_local_ba_batch itself (callers from several threads take turns)
         if (threads <= 1) { for (int z = 0; z < S; z++) fn(z); return; }
         std::vector<std::thread> th;
         for (int t = 1; t < threads; t++) th.emplace_back([&, t] { for (int z = t; z < S; z += threads) fn(z); });
@@ -4551,7 +4552,9 @@ int slam_debug_ba_host_time(int S, const double *cams, const int32_t *Pn, const 
     const auto t2 = std::chrono::steady_clock::now();
     out_us[0] = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() * 1e-3;
     out_us[1] = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count() * 1e-3;
-    return 0;
+    int bad = 0;
+    for (int z = 0; z < S; z++) bad += pl[z].err != 0;
+    return bad;
 }
 
 } // extern "C"
