@@ -92,7 +92,6 @@ __device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned 
         for (int j = 0; j < NK; j++) k[j] = taps[j];
         // dim-1 pass: T(y, tx) = sum_j m0(y+j, tx) * k[j]; thread = (column tx, strip of DET_SL rows)
         const int ns = (h + DET_SL - 1) / DET_SL;
-#ifndef DET_SKIP1
         for (int it = tid; it < mw * ns; it += DET_THREADS) {
             const int tx = it / ns, ys = (it - tx * ns) * DET_SL;
             double v[DET_SL + NK - 1];
@@ -108,11 +107,9 @@ __device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned 
                 }
             }
         }
-#endif
         __syncthreads();
         // dim-2 pass and image .* mask; thread = (row y, strip of DET_SL columns)
         const int nsx = (w + DET_SL - 1) / DET_SL;
-#ifndef DET_SKIP2
         for (int it = tid; it < h * nsx; it += DET_THREADS) {
             const int sx = it / h, y = it - sx * h, xs = sx * DET_SL;
             double v[DET_SL + NK - 1];
@@ -128,7 +125,6 @@ __device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned 
                 }
             }
         }
-#endif
         return;
     }
     // dim-1 pass: T(y, tx) = sum_j m0(y+j, tx) * k[j]

@@ -47,12 +47,8 @@ extern "C" int slam_debug_lk_ticks(unsigned long long *out)
 
 // occupancy target of the tracking kernels: 3 waves per SIMD (<= 168 VGPRs) for the 3- / 6-slot instantiations, 2 for the 9-slot one.
 // Left to itself the register allocator lands on 167 or on 183 registers for the 6-slot kernel depending on unrelated details of the
-// source (a wave per SIMD and 15 % of the kernel's speed); the bound makes it 168.  LK_WAVES overrides it for experiments.
-#ifdef LK_WAVES
-#define LK_OCC __attribute__((amdgpu_waves_per_eu(LK_WAVES, LK_WAVES)))
-#else
+// source (a wave per SIMD and 15 % of the kernel's speed); the bound makes it 168.
 #define LK_OCC __attribute__((amdgpu_waves_per_eu(LK_MAXE == 9 ? 2 : 3, LK_MAXE == 9 ? 2 : 3)))
-#endif
 #define LK_PM 4
 struct Offs { int up, down, left, right; };
 
@@ -202,15 +198,8 @@ __device__ __forceinline__ bool lies_in(int H, int W, double a, double b)
 // (Rounds 1-2 kept the template samples in an LDS spill area -- 115 VGPRs, 4 waves per SIMD -- because every iteration waited for
 // its footprint loads from global memory; since round 3 the iteration samples an LDS-resident target patch instead (below), the
 // template lives in registers, and the kernel is VALU-bound: ~3 300 VALU instructions per point in the bench's launches, ~90 % busy.)
-// LK_TMPL_LDS: template samples in an LDS spill area ([plane][slot][lane], 9 KB for 6 slots; round 1 / 2 layout: 105 VGPRs,
-// 4 waves per SIMD, needed while every iteration waited for global loads); default since round 3: template in registers
-// (36 VGPRs for 6 slots) -- the iteration reads the target from an LDS patch, and the LDS port is what it is bound by.
 template <int LK_MAXE> struct Tmpl {
-#ifdef LK_TMPL_LDS
-    double (*s)[LK_MAXE][64];      // LDS: s[0] = template samples, s[1] = Iy, s[2] = Ix
-#else
     double t0[LK_MAXE], t1[LK_MAXE], t2[LK_MAXE];
-#endif
     int pq[LK_MAXE];               // window coordinates p | q << 16 of slot k (0 | 0 past the window)
     int ne, kmax;
 };
@@ -245,11 +234,7 @@ __device__ __forceinline__ void load_template(Tmpl<LK_MAXE> &T, const LevelView 
         const size_t a = (size_t)(p0 - o.up + p - 1) + (size_t)(p1 - o.left + q - 1) * pitch;
         double v0 = 0.0, v1 = 0.0, v2 = 0.0;
         if (in) { v0 = first.L[a]; v1 = first.Iy[a]; v2 = first.Ix[a]; }
-#ifdef LK_TMPL_LDS
-        T.s[0][k][lane] = in ? v0 : 0.0; T.s[1][k][lane] = in ? v1 : 0.0; T.s[2][k][lane] = in ? v2 : 0.0;
-#else
         T.t0[k] = in ? v0 : 0.0; T.t1[k] = in ? v1 : 0.0; T.t2[k] = in ? v2 : 0.0;
-#endif
         // tolerance mode: the element's offset inside the LDS patch (its window coordinates are not needed: the bilinear weights are
         // the estimate's own fractions there)
         T.pq[k] = TOL ? p + q * (2 * (LK_MAXE == 3 ? 6 : LK_MAXE == 6 ? 9 : 11) + 2 + 2 * LK_PM) : (p | (q << 16));
@@ -317,10 +302,6 @@ __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView
     LKT_BEGIN;
     const bool cached = (2 * window + 1) * (2 * window + 1) <= 64 * LK_MAXE;
     Tmpl<LK_MAXE> T;
-#ifdef LK_TMPL_LDS
-    __shared__ double lds_tmpl[3][LK_MAXE][64];
-    T.s = lds_tmpl;
-#endif
     constexpr int PS = PatchGeom<LK_MAXE>::PS;
     __shared__ __attribute__((aligned(16))) double lds_patch[PS * PS];
     int pry = 0, prx = 0;
@@ -389,13 +370,8 @@ __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView
                         if (k < LK_MAXE && k < T.kmax) {
                             const double t0 = __builtin_fma(fx, c1v[j].a - c0v[j].a, c0v[j].a);
                             const double t1 = __builtin_fma(fx, c1v[j].b - c0v[j].b, c0v[j].b);
-#ifdef LK_TMPL_LDS
-                            const double dI = T.s[0][k][lane] - __builtin_fma(fy, t1 - t0, t0);
-                            ay = __builtin_fma(dI, T.s[1][k][lane], ay); ax = __builtin_fma(dI, T.s[2][k][lane], ax);
-#else
                             const double dI = T.t0[k] - __builtin_fma(fy, t1 - t0, t0);
                             ay = __builtin_fma(dI, T.t1[k], ay); ax = __builtin_fma(dI, T.t2[k], ax);
-#endif
                         }
                     }
                 }
@@ -419,15 +395,9 @@ __device__ __forceinline__ bool lk_level(const LevelView &first, const LevelView
                         const double fy = (r0 + dp) - (fr0 + dp), fx = (r1 + dq) - (fr1 + dq);
                         const double t0 = (1 - fx) * c0v[j].a + fx * c1v[j].a;
                         const double t1 = (1 - fx) * c0v[j].b + fx * c1v[j].b;
-#ifdef LK_TMPL_LDS
-                        const double dI = T.s[0][k][lane] - ((1 - fy) * t0 + fy * t1);
-                        ay += dI * T.s[1][k][lane];
-                        ax += dI * T.s[2][k][lane];
-#else
                         const double dI = T.t0[k] - ((1 - fy) * t0 + fy * t1);
                         ay += dI * T.t1[k];
                         ax += dI * T.t2[k];
-#endif
                     }
                 }
             }

@@ -403,13 +403,8 @@ __device__ __forceinline__ double dpp_pair_next(double v)        // lanes 2k and
 }
 // every sample of this kernel is touched once per sweep by one wave, and the two sweeps of a line are ~2 GB of other lines' traffic
 // apart: nontemporal loads and stores (no line kept for a reuse that cannot happen) -- k_iir_rows_ck -10 % (same-box A/B, S = 64)
-#ifdef ROWS_PLAIN
-#define RCK_LD(ptr) (*(ptr))
-#define RCK_ST(ptr, v) (*(ptr) = (v))
-#else
 #define RCK_LD(ptr) __builtin_nontemporal_load(ptr)
 #define RCK_ST(ptr, v) __builtin_nontemporal_store(v, ptr)
-#endif
 // (the checkpoints stay plain accesses: nontemporal ones measured 1-2 % slower per build)
 #define CK_LD(ptr) (*(ptr))
 #define CK_ST(ptr, v) (*(ptr) = (v))
@@ -786,15 +781,7 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-#ifdef CF4_EXP          /* scripts/ubench/rows_ck_bench.hip: parts of k_cols_fused switched off at run time to see what each costs */
-__device__ int cf4_exp;
-#define CFX(bit) ((cf4_exp >> (bit)) & 1)
-#else
-#define CFX(bit) false
-#endif
-#ifndef CF4_DEFER_U8
 #define CF4_DEFER_U8 1
-#endif
 #define CF4_LS 38
 #define CF4_GS 34
 #define CF4_LDS_DOUBLES (64 * CF4_LS + 3 * 64 * CF4_GS + 3 * 64)      // + the blur wave's three trailing rows (tolerance build, halved layer)
@@ -935,7 +922,6 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     // layer row above the block, wave 3 the row below it
     auto prefetch = [&](int b) {
         const int rb = b << 5;
-        if (CFX(4)) { for (int e = 0; e < 16; e++) pre[e] = 0.5; return; }
         if (ROLE == 0) tile_layer(rb, pre);
         else if (ROLE == 1) {
             if (2 * b + 1 < ntile) tile_layer(rb + 16, pre);
@@ -986,16 +972,15 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     prefetch(0);
     for (int b = 0; b < NBk; b++) {
         const int rb = b << 5;
-        if (!CFX(5)) lds_barrier();                                            // the previous block's shared data has been consumed
+        lds_barrier();                                            // the previous block's shared data has been consumed
         publish();
-        if (!CFX(5)) lds_barrier();  
+        lds_barrier();  
         if (b + 1 < NBk) prefetch(b + 1);
-        if (!CFX(2)) cf4_scharr8<TOL>(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
-        if (!CFX(5)) lds_barrier();  
+        cf4_scharr8<TOL>(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
+        lds_barrier();  
         if (!active) continue;
         read_inputs();
-        if (b >= 1 && !CFX(0)) { double *c = ck + ((size_t)b * 3) * nlines + lineid; c[0] = w1; c[nlines] = w2; c[2 * nlines] = w3; }
-        if (CFX(1)) { w1 += x[0] + x[31]; }
+        if (b >= 1) { double *c = ck + ((size_t)b * 3) * nlines + lineid; c[0] = w1; c[nlines] = w2; c[2 * nlines] = w3; }
         else if (rb >= 3 && rb + 31 <= n - 1) {
 #pragma unroll
             for (int e = 0; e < 32; e++) { const double tt = iir3<TOL>(x[e], a1, w1, a2, w2, a3, w3); w3 = w2; w2 = w1; w1 = tt; }
@@ -1022,7 +1007,7 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     // lines and the previous block's results -- and the stores would never overlap the recurrences
     double f1n = o2, f2n = o1, f3n = o0;
     auto load_ck = [&](int b) {
-        if (b > 0 && !CFX(3)) { const double *c = ck + ((size_t)b * 3) * nlines + lineid; f1n = c[0]; f2n = c[nlines]; f3n = c[2 * nlines]; }
+        if (b > 0) { const double *c = ck + ((size_t)b * 3) * nlines + lineid; f1n = c[0]; f2n = c[nlines]; f3n = c[2 * nlines]; }
         else { f1n = o2; f2n = o1; f3n = o0; }
     };
     prefetch(NBk - 1);
@@ -1037,11 +1022,11 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
     for (int b = NBk - 1; b >= 0; b--) {
         const int rb = b << 5, lo = rb > 3 ? rb : 3, hi = rb + 31 < n - 4 ? rb + 31 : n - 4;     // recurrence rows of the block (may be empty: lo > hi)
         const bool two = 2 * b + 1 < ntile;
-        if (!CFX(5)) lds_barrier();  
+        lds_barrier();  
         publish();
-        if (!CFX(5)) lds_barrier();  
-        if (!CFX(2)) cf4_scharr8<TOL>(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
-        if (!CFX(5)) lds_barrier();  
+        lds_barrier();  
+        cf4_scharr8<TOL>(LB, IYB, IXB, w, rb, H, edgeL, edgeR);
+        lds_barrier();  
         if (active) read_inputs();
         if (ROLE == 0 && skind) {                                 // fused ingest: the block's layer rows -> the pitched layer plane
             ColIO<2> iol = io; iol.dst = const_cast<double *>(A.L) + z;
@@ -1051,21 +1036,20 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
                 if (t == 0 || (two && rb + 16 <= ghi)) {
 #pragma unroll
                     for (int r = 0; r < 8; r++) { const double2 q = *(const double2 *)(LB + (8 * r + cg) * CF4_LS + 2 + 16 * t + 2 * rp); u[2 * r] = q.x; u[2 * r + 1] = q.y; }
-                    if (!CFX(0)) iol.tile_store(rb + 16 * t, u, rb + 16 * t, ghi, rb + 16 * t + 15 > ghi);
+                    iol.tile_store(rb + 16 * t, u, rb + 16 * t, ghi, rb + 16 * t + 15 > ghi);
                 }
             }
         }
         if (ROLE == 1 || ROLE == 2) {                             // Iy / Ix of the block -> their planes
             const double *blk = ROLE == 1 ? IYB : IXB;
             const int ghi = H - 1;
-            get_tile(blk, 0, u); if (!CFX(0)) iog.tile_store(rb, u, rb, ghi, rb + 15 > ghi);
-            if (two && rb + 16 <= ghi) { get_tile(blk, 1, u); if (!CFX(0)) iog.tile_store(rb + 16, u, rb + 16, ghi, rb + 31 > ghi); }
+            get_tile(blk, 0, u); iog.tile_store(rb, u, rb, ghi, rb + 15 > ghi);
+            if (two && rb + 16 <= ghi) { get_tile(blk, 1, u); iog.tile_store(rb + 16, u, rb + 16, ghi, rb + 31 > ghi); }
         }
-        if (!CFX(5)) lds_barrier();                                            // inputs consumed: the shared blocks become output staging
+        lds_barrier();                                            // inputs consumed: the shared blocks become output staging
         double f1 = f1n, f2 = f2n, f3 = f3n;
         if (b > 0) { prefetch(b - 1); if (active) load_ck(b - 1); }
         if (!active || (lo > hi && !dec)) continue;               // (a trailing block may hold rows n-3 .. n-1 only)
-        if (CFX(1)) { v1 += f1 + x[0]; }
         else if (lo > hi) {}
         else if (lo == rb && hi == rb + 31) {
 #pragma unroll
@@ -1106,7 +1090,7 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
             get_tile(stage, 0, u);
             const int rbh = rb >> 1, hih = (H >> 1) - 1;
             ColIO<2> iod = io; iod.P = P >> 1; iod.H = H >> 1;    // the half-height plane Th (same memory as T)
-            if (!CFX(0)) iod.tile_store(rbh, u, rbh, hih, rbh + 15 > hih);
+            iod.tile_store(rbh, u, rbh, hih, rbh + 15 > hih);
             __builtin_amdgcn_wave_barrier();
             continue;
         }
@@ -1116,15 +1100,8 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
             for (int j = 0; j < 16; j++) *(double2 *)(q + 2 * j) = make_double2(x[2 * j], x[2 * j + 1]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
             get_tile(stage, 0, u);
-            if (!CFX(0)) io.tile_store(rb, u, lo, hi, !(lo <= rb && hi >= rb + 15));
-            if (two && hi >= rb + 16) { get_tile(stage, 1, u); if (!CFX(0)) io.tile_store(rb + 16, u, lo, hi, !(lo <= rb + 16 && hi >= rb + 31)); }
-#ifdef CF4_ROWFWD_EXP      /* cost experiment (DESIGN 3.2 d): the dim-2 forward recurrence of the block's 32 rows over the strip's 62 columns, lanes = rows */
-            if (lane < 32) {
-                double g1 = x[0], g2 = x[1], g3 = x[2];
-                for (int c = 1; c <= CF4_COLS; c++) { const double xv = stage[c * CF4_GS + lane]; const double t = iir3<TOL>(xv, a1, g1, a2, g2, a3, g3); g3 = g2; g2 = g1; g1 = t; }
-                if (g1 == 1.2345e300) ck[lineid] = g1;               // (keeps the chain alive)
-            }
-#endif
+            io.tile_store(rb, u, lo, hi, !(lo <= rb && hi >= rb + 15));
+            if (two && hi >= rb + 16) { get_tile(stage, 1, u); io.tile_store(rb + 16, u, lo, hi, !(lo <= rb + 16 && hi >= rb + 31)); }
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -1199,11 +1176,7 @@ __device__ __forceinline__ void cf_load_block(const double *plane, int P, int x0
     for (int sub = 0; sub < 4; sub++) {
         const int rb = min(r0 + sub * 16, P - 16);
 #pragma unroll
-#ifndef CUM_PLAIN                  // every sample is read once: nontemporal (isolated 64-image build 1 956 -> 1 885 us, same-box A/B)
         for (int r = 0; r < 4; r++) { const v2d q = __builtin_nontemporal_load((const v2d *)(plane + ((size_t)(x0 + 8 * r) * P + rb) + voff)); raw[sub][2 * r] = q.x; raw[sub][2 * r + 1] = q.y; }
-#else
-        for (int r = 0; r < 4; r++) { const double2 q = *(const double2 *)(plane + ((size_t)(x0 + 8 * r) * P + rb) + voff); raw[sub][2 * r] = q.x; raw[sub][2 * r + 1] = q.y; }
-#endif
     }
 }
 // Planes taller than CF_MAXW bands (1080-row frames) are cut into row SEGMENTS of CF_SEGW bands (256 rows: 68 KB of LDS, two workgroups per

@@ -78,3 +78,23 @@ def test_bench_batch_sizes_fit_the_library_limit():
     b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
     assert all(w["S"] <= limit for w in b.WORKLOADS.values())
     assert int(re.search(r'"--streams", type=int, default=(\d+)', open(os.path.join(root, "bench.py")).read()).group(1)) <= limit
+
+
+def test_no_unbuilt_conditional_code_in_the_sources():
+    """The library's only conditionally compiled bodies are its tracing macros (csrc/Makefile: TRACE_DEFS); every one of them still compiles
+    (syntax check of host + device code with all of them defined), and no other #ifdef / #ifndef names a macro nobody defines."""
+    import subprocess
+    csrc = os.path.join(ROOT, "slam.jl_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    trace = re.search(r"TRACE_DEFS = (.*)", mk).group(1).replace("-D", "").split()
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".hpp")):
+            continue
+        for name in re.findall(r"^\s*#\s*(?:ifdef|ifndef)\s+(\w+)", open(os.path.join(csrc, f)).read(), flags=re.M):
+            assert name in trace, f"{f}: #ifdef {name} is neither a tracing macro of the Makefile nor built by anything"
+    jobs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function", "-fsyntax-only"]
+                             + ["-D" + t for t in trace] + [os.path.join(csrc, f)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            for f in ("ba.hip", "lk.hip", "detect.hip")]
+    for j in jobs:
+        out, _ = j.communicate(timeout=900)
+        assert j.returncode == 0 and "error" not in out, out[-3000:]
