@@ -981,7 +981,7 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
         if (!active) continue;
         read_inputs();
         if (b >= 1) { double *c = ck + ((size_t)b * 3) * nlines + lineid; c[0] = w1; c[nlines] = w2; c[2 * nlines] = w3; }
-        else if (rb >= 3 && rb + 31 <= n - 1) {
+        if (rb >= 3 && rb + 31 <= n - 1) {
 #pragma unroll
             for (int e = 0; e < 32; e++) { const double tt = iir3<TOL>(x[e], a1, w1, a2, w2, a3, w3); w3 = w2; w2 = w1; w1 = tt; }
         } else {
@@ -1050,7 +1050,7 @@ __device__ __forceinline__ void cols_fused_wave(const ColsFusedArgs &A, const II
         double f1 = f1n, f2 = f2n, f3 = f3n;
         if (b > 0) { prefetch(b - 1); if (active) load_ck(b - 1); }
         if (!active || (lo > hi && !dec)) continue;               // (a trailing block may hold rows n-3 .. n-1 only)
-        else if (lo > hi) {}
+        if (lo > hi) {}
         else if (lo == rb && hi == rb + 31) {
 #pragma unroll
             for (int e = 0; e < 32; e++) { const double tt = iir3<TOL>(x[e], a1, f1, a2, f2, a3, f3); f3 = f2; f2 = f1; f1 = tt; x[e] = tt; }
