@@ -575,35 +575,46 @@ __global__ __launch_bounds__(FP_TPB * FP_TEAM) void k_5pt_solve(FPArgs T)
 __global__ __launch_bounds__(FP_SCORE_T) void k_5pt_score(FPArgs T)
 {
     // one workgroup per 5-tuple scores ALL its poses (a grid of iters x FP_MAXE x S workgroups, most of them for poses that do not
-    // exist, each with its own reduction, took 385 us per 32-stream call): pose by pose (wave-uniform: the 12 numbers arrive by
-    // scalar loads), the threads stride over the correspondences, which stay in L1 / L2 between the poses
-    __shared__ int s_part[FP_SCORE_T / 64][FP_MAXE];
-    const int it = blockIdx.x, z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // exist, each with its own reduction, took 385 us per 32-stream call).  Round 6: a WAVE takes whole poses (pose e on wave e % 4; the 12
+    // numbers arrive by scalar loads, the 64 lanes stride over the correspondences, which stay in L1 / L2 between the poses) and counts
+    // with ballots, so that the count is wave-uniform and a pose can be DROPPED as soon as it cannot win any more: best[z] (behind the counts:
+    // the largest count of a completely scored pose of stream z so far, raised by atomicMax) is an incumbent, and a pose whose count plus the
+    // correspondences still to come stays strictly below it is neither the winner nor a tie -- k_5pt_select's winner (most inliers, ties to the
+    // earlier tuple, then root), its mask and its summed error are untouched, bit for bit; only the counts of losers are partial.  Nine of a
+    // tuple's ten essential matrices are wrong and most tuples are worse than the best one: they now stop after the first 256 correspondences.
+    const int it = blockIdx.x, z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t slot = (size_t)z * T.iters + it;
     const int ne = T.ne[slot];                                  // workgroup-uniform
-    if (ne > 0) {
-        const int base = T.cnt ? z * T.stride : T.off[z], n = T.cnt ? T.cnt[z] : T.off[z + 1] - base;
-        const double *px1 = T.px1 + 2 * (size_t)base, *px2 = T.px2 + 2 * (size_t)base;
-        double k1[4], k2[4];
-        for (int j = 0; j < 4; j++) { k1[j] = T.ks[8 * z + j]; k2[j] = T.ks[8 * z + 4 + j]; }
-        for (int e = 0; e < ne; e++) {
-            double Rt[12];
-            for (int j = 0; j < 12; j++) Rt[j] = T.poses[(slot * FP_MAXE + e) * 12 + j];
-            int cnt = 0;
-            for (int i = tid; i < n; i += FP_SCORE_T) {
+    int *bestp = T.counts + (size_t)gridDim.y * T.iters * FP_MAXE + z;
+    if (tid < FP_MAXE && tid >= ne) T.counts[slot * FP_MAXE + tid] = 0;
+    if (ne <= 0) return;
+    const int base = T.cnt ? z * T.stride : T.off[z], n = T.cnt ? T.cnt[z] : T.off[z + 1] - base;
+    const double *px1 = T.px1 + 2 * (size_t)base, *px2 = T.px2 + 2 * (size_t)base;
+    double k1[4], k2[4];
+    for (int j = 0; j < 4; j++) { k1[j] = T.ks[8 * z + j]; k2[j] = T.ks[8 * z + 4 + j]; }
+    for (int e = wave; e < ne; e += FP_SCORE_T / 64) {
+        double Rt[12];
+        for (int j = 0; j < 12; j++) Rt[j] = T.poses[(slot * FP_MAXE + e) * 12 + j];
+        int best = __hip_atomic_load(bestp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int cnt = 0; bool dropped = false;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            bool ok = false;
+            if (i < n) {
                 const double a[2] = {px1[2 * i], px1[2 * i + 1]}, b[2] = {px2[2 * i], px2[2 * i + 1]};
                 double e1, e2;
-                if (two_view_errors(k1, k2, Rt, a, b, &e1, &e2)) cnt += (e1 < T.thr && e2 < T.thr) ? 1 : 0;
+                if (two_view_errors(k1, k2, Rt, a, b, &e1, &e2)) ok = e1 < T.thr && e2 < T.thr;
             }
-            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-            if (lane == 0) s_part[wave][e] = cnt;
+            cnt += __builtin_popcountll(__ballot(ok));
+            if ((i0 & 192) == 192) {                              // every 256 correspondences: can this pose still reach the incumbent?
+                best = max(best, __hip_atomic_load(bestp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (cnt + max(n - i0 - 64, 0) < best) { dropped = true; break; }
+            }
         }
-    }
-    __syncthreads();
-    if (tid < FP_MAXE) {
-        int c = 0;
-        if (tid < ne) for (int w = 0; w < FP_SCORE_T / 64; w++) c += s_part[w][tid];
-        T.counts[slot * FP_MAXE + tid] = c;
+        if (lane == 0) {
+            T.counts[slot * FP_MAXE + e] = cnt;
+            if (!dropped) (void)__hip_atomic_fetch_max(bestp, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -695,7 +706,7 @@ static int fp_run(slam_ctx *ctx, int S, const int32_t *off, const double *px1_xy
     memcpy(h + o_smp, samples, (size_t)S * iters * 20);
     const size_t slots = (size_t)S * iters;
     const size_t s_ne = up(slots * 4), s_es = up(slots * FP_MAXE * 72), s_po = up(slots * FP_MAXE * 96);
-    const size_t s_cn = up(slots * FP_MAXE * 4), s_er = up((size_t)ntot * 8);
+    const size_t s_cn = up(slots * FP_MAXE * 4 + (size_t)S * 4), s_er = up((size_t)ntot * 8);
     char *scr;
     rc = slam_scratch(ctx, s_ne + s_es + s_po + s_cn + s_er, (void **)&scr);
     if (rc) return rc;
@@ -710,6 +721,7 @@ static int fp_run(slam_ctx *ctx, int S, const int32_t *off, const double *px1_xy
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_5pt_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     { ProfScope span(ctx, "five_point_ransac");
       hipLaunchKernelGGL(k_5pt_solve, dim3((iters + FP_TPB - 1) / FP_TPB, S), dim3(FP_TPB * FP_TEAM), lds, ctx->stream, T);
+      (void)hipMemsetAsync(T.counts + (size_t)S * iters * FP_MAXE, 0, (size_t)S * 4, ctx->stream);      // the incumbent counts
       hipLaunchKernelGGL(k_5pt_score, dim3(iters, S), dim3(FP_SCORE_T), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_5pt_select, dim3(S), dim3(FP_SEL_T), 0, ctx->stream, T); }
     HIP_TRY(ctx, hipGetLastError());
@@ -916,7 +928,7 @@ extern "C" int slam_kpset_compute_pose_5pt(slam_ctx *ctx, slam_kpset *ks, const 
     auto take = [&](size_t bytes) { const size_t at = o; o += up(bytes); return at; };
     const size_t o_px1 = take(nc * 16), o_px2 = take(nc * 16), o_pd1 = take(nc * 16), o_pd2 = take(nc * 16), o_slot = take(nc * 4);
     const size_t o_n5 = take((size_t)S * 4), o_ps = take((size_t)S * 8), o_ks = take((size_t)S * 64), o_smp = take(slots * 20);
-    const size_t o_ne = take(slots * 4), o_es = take(slots * FP_MAXE * 72), o_po = take(slots * FP_MAXE * 96), o_cn = take(slots * FP_MAXE * 4);
+    const size_t o_ne = take(slots * 4), o_es = take(slots * FP_MAXE * 72), o_po = take(slots * FP_MAXE * 96), o_cn = take(slots * FP_MAXE * 4 + (size_t)S * 4);      // (+ the incumbent count per stream: k_5pt_score)
     const size_t o_er = take(nc * 8), o_out = take((size_t)S * 256), o_inl = take(nc), o_fl = take(nc);
     const size_t o_P = take((size_t)S * 96), o_st = take((size_t)S * 4), o_ni = take((size_t)S * 4), o_pa = take((size_t)S * 8);
     char *scr;
@@ -945,6 +957,7 @@ extern "C" int slam_kpset_compute_pose_5pt(slam_ctx *ctx, slam_kpset *ks, const 
       hipLaunchKernelGGL(k_kfive_gather, dim3(S), dim3(256), 0, ctx->stream, A);
       hipLaunchKernelGGL(k_kfive_samples, dim3((iters + 255) / 256, S), dim3(256), 0, ctx->stream, A);
       hipLaunchKernelGGL(k_5pt_solve, dim3((iters + FP_TPB - 1) / FP_TPB, S), dim3(FP_TPB * FP_TEAM), lds, ctx->stream, T);
+      (void)hipMemsetAsync(T.counts + (size_t)S * iters * FP_MAXE, 0, (size_t)S * 4, ctx->stream);      // the incumbent counts
       hipLaunchKernelGGL(k_5pt_score, dim3(iters, S), dim3(FP_SCORE_T), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_5pt_select, dim3(S), dim3(FP_SEL_T), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_kfive_finish, dim3(S), dim3(256), 0, ctx->stream, A); }
