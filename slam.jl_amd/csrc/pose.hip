@@ -227,44 +227,29 @@ __global__ __launch_bounds__(64) void k_p3p_score(P3PArgs T)
         ns = p3p_solve<true>(X, F, -1, Pd, (p3p_lds *)s_P);             // all lanes hold the same values: the LDS stores coincide
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    // Round 6: counts by ballots (wave-uniform), and a pose is dropped as soon as its count plus the map points still to come stays strictly below
-    // the incumbent of its stream (best[z] behind the counts: the largest count of a completely scored pose so far) -- such a pose is neither
-    // the winner nor a tie, so k_p3p_select's winner, mask and error sum are untouched; of a triple's up to four poses at most one is right
+    // (Round 6 tried the incumbent bound of k_5pt_score here -- counts by ballots, a pose dropped once it cannot reach the best completely scored
+    //  count of its stream: 0.9 -> 1.3 ms per 128-stream call.  Most triples of a rigid scene give a pose near the best one, so little is dropped,
+    //  and four ballots + scalar adds per round cost more than the per-lane counters.  Not kept.)
     int cnt[4] = {0, 0, 0, 0};
-    int *bestp = T.counts + (size_t)gridDim.y * T.iters * 4 + z;
-    bool alive[4] = {ns > 0, ns > 1, ns > 2, ns > 3};
     if (ns > 0) {
         double P[4][12];
 #pragma unroll
         for (int k = 0; k < 4; k++)
 #pragma unroll
             for (int j = 0; j < 12; j++) P[k][j] = k < ns ? s_P[12 * k + j] : 0.0;
-        int best = __hip_atomic_load(bestp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int i = i0 + lane;
-            const bool in = i < n;
-            const int ic = in ? i : 0;
-            const double X[3] = {pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2]};
-            const double q[2] = {px[2 * ic], px[2 * ic + 1]};
+        for (int i = lane; i < n; i += 64) {
+            const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+            const double q[2] = {px[2 * i], px[2 * i + 1]};
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (alive[k]) {                                    // (wave-uniform)
+                if (k < ns) {
                     const double e = p3p_reproj(P[k], K, X, q);
-                    cnt[k] += __builtin_popcountll(__ballot(in && e >= 0.0 && e < T.thr));
+                    cnt[k] += (e >= 0.0 && e < T.thr) ? 1 : 0;
                 }
-            if ((i0 & 192) == 192) {                              // every 256 map points
-                best = max(best, __hip_atomic_load(bestp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                const int rest = max(n - i0 - 64, 0);
-                bool any = false;
-#pragma unroll
-                for (int k = 0; k < 4; k++) { if (alive[k] && cnt[k] + rest < best) alive[k] = false; any = any || alive[k]; }
-                if (!any) break;
-            }
         }
-        int done = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (alive[k]) done = max(done, cnt[k]);
-        if (lane == 0 && done > 0) (void)__hip_atomic_fetch_max(bestp, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 4; k++)
+            for (int o = 32; o > 0; o >>= 1) cnt[k] += __shfl_xor(cnt[k], o, 64);
     }
     if (lane < 4) {
         const int k = lane;
@@ -358,7 +343,7 @@ static int p3p_run(slam_ctx *ctx, int S, const int32_t *off, const double *pts3d
     memcpy(h + o_off, off, (size_t)(S + 1) * 4); memcpy(h + o_K, K, (size_t)S * 72);
     memcpy(h + o_pts, pts3d, (size_t)ntot * 24); memcpy(h + o_px, px_xy, (size_t)ntot * 16); memcpy(h + o_pdn, pdn, (size_t)ntot * 24);
     memcpy(h + o_smp, samples, (size_t)S * iters * 12);
-    const size_t s_cnt = up((size_t)S * iters * 16 + (size_t)S * 4), s_pose = up((size_t)S * iters * 4 * 96), s_err = up((size_t)ntot * 8);
+    const size_t s_cnt = up((size_t)S * iters * 16), s_pose = up((size_t)S * iters * 4 * 96), s_err = up((size_t)ntot * 8);
     char *scr;
     rc = slam_scratch(ctx, s_cnt + s_pose + s_err, (void **)&scr);
     if (rc) return rc;
@@ -369,7 +354,6 @@ static int p3p_run(slam_ctx *ctx, int S, const int32_t *off, const double *pts3d
     T.counts = (int *)scr; T.poses = (double *)(scr + s_cnt); T.errs = (double *)(scr + s_cnt + s_pose);
     T.out = (double *)(d + o_out); T.inliers = (uint8_t *)(d + o_inl);
     { ProfScope span(ctx, "p3p_ransac");
-      (void)hipMemsetAsync(T.counts + (size_t)S * iters * 4, 0, (size_t)S * 4, ctx->stream);      // the incumbent counts (k_p3p_score)
       hipLaunchKernelGGL(k_p3p_score, dim3(iters, S), dim3(64), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_p3p_select, dim3(S), dim3(256), 0, ctx->stream, T); }
     HIP_TRY(ctx, hipGetLastError());
@@ -617,7 +601,7 @@ extern "C" int slam_kpset_compute_pose(slam_ctx *ctx, slam_kpset *ks, const doub
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += up(bytes); return at; };
     const size_t o_pts = take(nc * 24), o_px = take(nc * 16), o_pdn = take(nc * 24), o_slot = take(nc * 4), o_n3 = take((size_t)S * 4);
-    const size_t o_smp = take((size_t)S * iters * 12), o_cnt = take((size_t)S * iters * 16 + (size_t)S * 4), o_pose = take((size_t)S * iters * 4 * 96);
+    const size_t o_smp = take((size_t)S * iters * 12), o_cnt = take((size_t)S * iters * 16), o_pose = take((size_t)S * iters * 4 * 96);
     const size_t o_err = take(nc * 8), o_out = take((size_t)S * 256), o_inl = take(nc);
     const size_t o_bpx = take(nc * 16), o_bpts = take(nc * 24), o_bslot = take(nc * 4), o_outl = take(nc), o_pnp = take((size_t)S * sizeof(PnPArgs));
     const size_t o_res = take((size_t)S * 128), o_flags = take(nc), o_T = take((size_t)S * 128), o_st = take((size_t)S * 4), o_ni = take((size_t)S * 4);
@@ -660,7 +644,6 @@ extern "C" int slam_kpset_compute_pose(slam_ctx *ctx, slam_kpset *ks, const doub
     { ProfScope span(ctx, "kpset_compute_pose");
       hipLaunchKernelGGL(k_kpose_gather, dim3(S), dim3(256), 0, ctx->stream, A);
       hipLaunchKernelGGL(k_kpose_samples, dim3((iters + 255) / 256, S), dim3(256), 0, ctx->stream, A);
-      (void)hipMemsetAsync(T.counts + (size_t)S * iters * 4, 0, (size_t)S * 4, ctx->stream);      // the incumbent counts (k_p3p_score)
       hipLaunchKernelGGL(k_p3p_score, dim3(iters, S), dim3(64), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_p3p_select, dim3(S), dim3(256), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_kpose_prep, dim3(S), dim3(256), 0, ctx->stream, A);
