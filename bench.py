@@ -277,7 +277,7 @@ def main():
             list length), keypoint list resident in HBM; lookahead: the call builds the frame it is given while it matches the one before
             (front_end.jl:58-113, :454-470; mapper.jl:51-66)"""
             u8 = lambda im: np.ascontiguousarray(np.round(np.clip(im, 0, 1) * 255).astype(np.uint8).T)
-            L8 = [u8(x) for x in left]; R8 = [u8(x) for x in right]
+            L8 = [torch.from_numpy(u8(x)).pin_memory() for x in left]; R8 = [torch.from_numpy(u8(x)).pin_memory() for x in right]      # frames in page-locked host memory (a capture buffer registered once): copied from where they lie
             fe = slam.FrontEnd((H, W), params, extractor, fast=fast, lookahead=lookahead, right_target_only=RIGHT_TARGET_ONLY, device=local_rank)
             camt = tuple(syn.KITTI_CAM)
             T21 = np.eye(4); T21[0, 3] = -0.54
@@ -294,8 +294,8 @@ def main():
             def call(t):
                 due = t - 1 if lookahead else t
                 kfd = due >= 0 and due % KF_EVERY == 0
-                return fe.step(L8[seq[t]], R8[seq[t]] if t % KF_EVERY == 0 else None, params=pr[max(due, 0)], prior=2, stereo_params=sps, stereo_prior=2, tri=tri,
-                               cull_flags_dev=culls[(due // KF_EVERY) % 8].data_ptr() if kfd and due > 0 else None)
+                return fe.step_ptr(L8[seq[t]].data_ptr(), R8[seq[t]].data_ptr() if t % KF_EVERY == 0 else 0, pr[max(due, 0)].ctypes.data, 2, sps.ctypes.data, 2, tri.ctypes.data,
+                                   culls[(due // KF_EVERY) % 8].data_ptr() if kfd and due > 0 else None)      # raw addresses, as a C / Julia host passes them
             tracked = 0
             for t in range(w1):
                 call(t)
