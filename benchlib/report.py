@@ -103,8 +103,12 @@ def compact_line(out):
     if ss and "by_builds_in_flight" in ss:
         c["single_stream"] = {"live": _r(ss["by_builds_in_flight"].get("1")), "lookahead": _r(ss.get("value")), "unit": "frames/sec"}
         if isinstance(ss.get("live_step"), dict) and "value" in ss["live_step"]:
-            c["single_stream"]["live_no_lookahead"] = _r(ss["live_step"]["no_lookahead"])
+            # "next frame only" has two implementations: one C call per frame on device-resident lists (slam_frontend_step) and the six seams called from
+            # Python on host lists; `live` is the better of the two, both are on the line
+            c["single_stream"]["live_one_call_per_frame"] = _r(ss["live_step"]["value"])
+            c["single_stream"]["live_one_call_no_lookahead"] = _r(ss["live_step"]["no_lookahead"])
             c["single_stream"]["live_python_protocol"] = _r(ss["by_builds_in_flight"].get("1_python_protocol"))
+            c["single_stream"]["live"] = _r(max(ss["live_step"]["value"], ss["by_builds_in_flight"].get("1_python_protocol") or 0.0))
         if ss.get("live_graph") is not None:
             c["single_stream"]["live_graph"] = _r(ss["live_graph"])
     elif ss:
