@@ -1,7 +1,7 @@
-// Cycle count of the BA's 32x32 tile factorisation + inverse (tile_potrf_inv, csrc/ba.hip) on one workgroup.
+// Cycle count of the BA's 32x32 tile factorisation + inverse (tile_potrf_inv, csrc/ba_device.hpp) on one workgroup.
 //   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -I slam.jl_amd/csrc scripts/ubench/potrf.hip -o scripts/ubench/potrf && scripts/ubench/potrf
 #include "../../slam.jl_amd/csrc/ctx.hip"
-#include "../../slam.jl_amd/csrc/ba.hip"
+#include "../../slam.jl_amd/csrc/ba_device.hpp"
 #include <vector>
 #include <cstdio>
 

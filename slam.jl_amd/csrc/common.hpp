@@ -145,7 +145,7 @@ struct IIRCoef {
 IIRCoef slam_iir_coef(double sigma);
 int slam_gaussian_taps(double sigma, double *w);   // Kernel.gaussian 1-D factor
 
-// pinhole intrinsics; the argument block of one single-pose refinement (k_pnp / k_pnp_batch in ba.hip; filled on the device by
+// pinhole intrinsics; the argument block of one single-pose refinement (k_pnp / k_pnp_batch in ba_single.hip; filled on the device by
 // the keypoint-set pose seam in pose.hip)
 struct Cam { double fx, fy, cx, cy; };
 struct PnPArgs {

@@ -207,7 +207,7 @@ int slam_ctx_create_priority(int device, int priority, slam_ctx **out)
     return SLAM_OK;
 }
 
-extern "C" void ba_forget_jobs(slam_ctx *ctx);          // ba.hip: a batch job still in flight on the context is waited for
+extern "C" void ba_forget_jobs(slam_ctx *ctx);          // ba_batch.hip: a batch job still in flight on the context is waited for
 int slam_ctx_destroy(slam_ctx *ctx)
 {
     if (!ctx) return SLAM_OK;

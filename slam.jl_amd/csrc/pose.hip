@@ -417,7 +417,7 @@ extern "C" int slam_p3p_ransac_batch(slam_ctx *ctx, int S, const int32_t *offset
 // =====================================================================================================================
 // compute_pose! on the device-resident keypoint set (src/front_end.jl:132-219): for every stream, the 3-D keypoints of the
 // set -> P3P RANSAC (k_p3p_score / k_p3p_select above) -> removal of its outliers -> PnP refinement of the inliers
-// (k_pnp_batch, ba.hip) -> removal of its outliers, acceptance tests of :136, :179-183, :207-211.  Nothing but the S poses,
+// (k_pnp_batch, ba_single.hip) -> removal of its outliers, acceptance tests of :136, :179-183, :207-211.  Nothing but the S poses,
 // the S status words and the S list lengths travels to the host; the gather of :139-160 (ordered, is_3d keypoints only),
 // the inlier compaction of :190-201 and the observation removals are kernels on the set's arrays.
 // The reference draws its triples from Julia's global RNG inside RecoverPose; here they come from a counter-based generator

@@ -94,7 +94,7 @@ def test_no_unbuilt_conditional_code_in_the_sources():
             assert name in trace, f"{f}: #ifdef {name} is neither a tracing macro of the Makefile nor built by anything"
     jobs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function", "-fsyntax-only"]
                              + ["-D" + t for t in trace] + [os.path.join(csrc, f)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-            for f in ("ba.hip", "lk.hip", "detect.hip")]
+            for f in ("ba_single.hip", "ba_batch.hip", "ba_window.hip", "lk.hip", "detect.hip")]
     for j in jobs:
         out, _ = j.communicate(timeout=900)
         assert j.returncode == 0 and "error" not in out, out[-3000:]

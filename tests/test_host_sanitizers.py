@@ -1,6 +1,6 @@
 """CPU: the host half of the local-BA batch path -- ba_plan / ba_emit (structure analysis, pose re-ordering, point groups, staging layout) and
 the parked worker pool two estimator threads share -- under AddressSanitizer + UndefinedBehaviorSanitizer and under ThreadSanitizer
-(tests/host_sanitize/: csrc/ba.hip + csrc/ctx.hip compiled with the sanitizers on the host code, driven by two caller threads on ragged random
+(tests/host_sanitize/: csrc/ba_host.hip, ba_batch.hip, ba_single.hip, ba_window.hip + csrc/ctx.hip compiled with the sanitizers on the host code, driven by two caller threads on ragged random
 windows incl. loop closures, all-constant, empty and duplicate-observation windows; no GPU, nothing is launched).  It is the only
 multi-threaded C++ of the product (reference: the arrays are those of src/estimator.jl:143-266)."""
 import os
