@@ -674,9 +674,33 @@ def main():
                 same = bool(np.array_equal(ol0, one.outliers) and np.abs(th0 - one.theta).max() <= 1e-6 * max(1.0, np.abs(one.theta).max()))
                 if not same:
                     fails.append(f"ba.batch {bname}: window 0 of the batch differs from slam_local_ba on the same arrays")
-                its = float(np.mean(bb.stats[:, 3] + bb.stats[:, 4]))
-                out["ba"]["batch"][bname] = {"windows": Sb, "observations_per_window": int(base[0]["O"]), "wall_ms_per_call": min(walls) * 1e3, "device_ms_per_call": float(bb.stats[0, 6]),
-                                             "windows_per_s": Sb / min(walls), "mean_lm_iterations": its, "device_ms_per_iter_of_S_windows": float(bb.stats[0, 6]) / max(its, 1),
+                # two batches in flight on two contexts through slam_local_ba_batch_begin / _end: plan + staging + upload of one call behind the solve of the other
+                dev_ms_blocking = float(bb.stats[0, 6]); its_blocking = float(np.mean(bb.stats[:, 3] + bb.stats[:, 4]))      # (of the blocking calls above: the two-in-flight calls below share the chip)
+                piped = None
+                if bname in ("P5_free_20_const", "P20"):
+                    try:
+                        ctx2 = slam.Context(local_rank)
+                        b2 = slam.BABatch([slam.LocalBACache(base[z % nbase]["theta0"].copy(), base[z % nbase]["theta_const"], base[z % nbase]["pixels_yx"], base[z % nbase]["pose_ids"],
+                                                             base[z % nbase]["point_ids"]) for z in range(Sb)], base[0]["cam"])
+                        b2.solve(ctx=ctx2, reset=True)
+                        jobs = [(bb, ctx), (b2, ctx2)]
+                        ncall = 8
+                        t0 = time.perf_counter()
+                        jobs[0][0].begin(ctx=jobs[0][1], reset=True)
+                        for c_ in range(1, ncall):
+                            jobs[c_ % 2][0].begin(ctx=jobs[c_ % 2][1], reset=True)
+                            jobs[(c_ - 1) % 2][0].end()
+                        jobs[(ncall - 1) % 2][0].end()
+                        piped = Sb * ncall / (time.perf_counter() - t0)
+                        ok2 = bool((b2.status == 0).all() and np.array_equal(b2.theta, bb.theta))
+                        if not ok2:
+                            fails.append(f"ba.batch {bname}: the pipelined begin / end calls differ from the blocking call")
+                        ctx2.close(); del b2
+                    except Exception as ex:                           # noqa: BLE001
+                        piped = repr(ex)[:120]
+                its = its_blocking
+                out["ba"]["batch"][bname] = {"windows": Sb, "observations_per_window": int(base[0]["O"]), "wall_ms_per_call": min(walls) * 1e3, "device_ms_per_call": dev_ms_blocking,
+                                             "windows_per_s": Sb / min(walls), "windows_per_s_two_calls_in_flight": piped, "mean_lm_iterations": its, "device_ms_per_iter_of_S_windows": dev_ms_blocking / max(its, 1),
                                              "all_windows_ok": bool((bb.status == 0).all()), "window_0_equals_single_call": same,
                                              "single_window_call_ms": None if bname not in out["ba"]["windows"] else out["ba"]["windows"][bname]["wall_ms_total"],
                                              "what": "slam_local_ba_batch: host set-up of the S windows (threads), one H2D copy, 5 launches per LM iteration for all windows, one D2H copy; "

@@ -88,7 +88,8 @@ def compact_line(out):
                    "roofline_frac_P50": _r(ba.get("windows", {}).get("P50", {}).get("roofline", {}).get("frac")),
                    "cpu_ms_per_iter_schur": _r(ba.get("cpu_ms_per_iter_schur")), "cpu_ms_per_iter_lm_lsmr": _r(ba.get("cpu_ms_per_iter_reference_style_lm_lsmr"))}
     if ba and ba.get("batch"):
-        c["ba"]["batch"] = {k: {"windows": v["windows"], "wall_ms": _r(v["wall_ms_per_call"]), "device_ms": _r(v["device_ms_per_call"]), "windows_per_s": _r(v["windows_per_s"])}
+        c["ba"]["batch"] = {k: {"windows": v["windows"], "wall_ms": _r(v["wall_ms_per_call"]), "device_ms": _r(v["device_ms_per_call"]), "windows_per_s": _r(v["windows_per_s"]),
+                                **({"windows_per_s_two_in_flight": _r(v["windows_per_s_two_calls_in_flight"])} if isinstance(v.get("windows_per_s_two_calls_in_flight"), float) else {})}
                             for k, v in ba["batch"].items()}
     fb = out.get("frontend_with_ba")
     if fb:
