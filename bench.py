@@ -941,6 +941,36 @@ def main():
                                           "what": "the headline loop from empty lists for 7 frames (detect, stereo match, triangulate, 5 temporal matches, cull, detect ...) "
                                                   "with recorded priors / cull flags, replayed per stream through orc.pyr_build / optical_flow_matching / detect / triangulate"}
                 out["parity_vs_oracle"] = par
+            if head is not None and "tolbatch" in legs:
+                # the tolerance twin of replayed_frames: the same recorded 7-frame loop on tolerance-mode pyramids + the contracted tracking kernel, against the
+                # oracle's EXACT replay -- keypoints matched by id: positions <= 1e-6 px, fates (tracked / lost / detected) equal for >= 99.5 % of the keypoints
+                try:
+                    wlt = dict(wl); wlt["tolerance"] = True
+                    rec_t = {"frame_steps": 7, "steps": []}
+                    rrt = run_lockstep_kpset(slam, torch, local_rank, wlt, 0, 0, world, dist, dev, "host_u8", record=rec_t, snapshot=[0, S - 1])
+                    worst_p, n_common, n_union = 0.0, 0, 0
+                    for s_, sn in rrt["snapshot"].items():
+                        kp_ref, is3_ref, ids_ref = replay_stream_on_oracle(orc, slam, wl, rec_t, rrt, s_, threads, with_ids=True)
+                        got = sn["list"]
+                        gid = {int(k): n_ for n_, k in enumerate(got["ids"])}; rid = {int(k): n_ for n_, k in enumerate(ids_ref)}
+                        common = sorted(set(gid) & set(rid))
+                        n_common += len(common); n_union += len(set(gid) | set(rid))
+                        if common:
+                            a_ = got["yx"][[gid[k] for k in common]]; b_ = kp_ref[[rid[k] for k in common]]
+                            same_pt = np.abs(a_ - b_).max(axis=1) <= 0.5          # an id names the same keypoint in both runs unless an earlier fate flip shifted the detections
+                            n_common -= int((~same_pt).sum())
+                            if same_pt.any():
+                                worst_p = max(worst_p, float(np.abs(a_[same_pt] - b_[same_pt]).max()))
+                    flips = 1.0 - n_common / max(n_union, 1)
+                    ok_t = bool(worst_p <= 1e-6 and flips <= 0.005)
+                    out.setdefault("tolerance_mode", {})["replayed_frames"] = {"frames": 7, "key_frames": 2, "streams_checked": sorted(rrt["snapshot"]), "max_abs_position_diff_px": worst_p,
+                                                                               "fate_flip_fraction": flips, "keypoints_compared": n_common, "ok": ok_t,
+                                                                               "what": "the headline loop on tolerance-mode pyramids (mode 3 batches + the contracted tracking kernel) for 7 frames from "
+                                                                                       "empty lists vs the oracle's exact replay with the same recorded priors / cull flags; keypoints matched by id"}
+                    if not ok_t:
+                        fails.append(f"tolerance-mode replay: max |dpx| {worst_p}, fate flips {flips:.4f}")
+                except Exception as ex:                               # noqa: BLE001
+                    out.setdefault("tolerance_mode", {})["replayed_frames"] = {"error": repr(ex)[:300]}
             if tol_snapshot:
                 # the planes the TIMED tolerance-mode run left behind (S streams, default kernel-selection thresholds) against the oracle's exact build
                 u8f = lambda im: np.asfortranarray(np.round(im * 255).astype(np.uint8).astype(np.float64) / 255.0)

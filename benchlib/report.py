@@ -121,6 +121,10 @@ def compact_line(out):
             c["tolerance_mode"]["single_stream"] = _r(tm["single_stream"].get("value"))
         if isinstance(tm.get("single_stream_live"), dict):
             c["tolerance_mode"]["single_stream_live"] = _r(tm["single_stream_live"].get("value"))
+        if isinstance(tm.get("replayed_frames"), dict):
+            rf_ = tm["replayed_frames"]
+            c["tolerance_mode"]["replayed_frames"] = ({"ok": rf_["ok"], "max_dpx": _r(rf_["max_abs_position_diff_px"]), "fate_flips": _r(rf_["fate_flip_fraction"])} if "ok" in rf_
+                                                      else {"error": rf_.get("error", "")[:100]})
         if isinstance(tm.get("batch"), dict):
             b = tm["batch"]
             c["tolerance_mode"].update({"value": _r(b.get("value")), "ms_per_step": _r(b.get("ms_per_step")), "planes_rel_tol": 1e-11})
