@@ -107,7 +107,6 @@ def compact_line(out):
             # "next frame only" has two implementations: one C call per frame on device-resident lists (slam_frontend_step) and the six seams called from
             # Python on host lists; `live` is the better of the two, both are on the line
             c["single_stream"]["live_one_call_per_frame"] = _r(ss["live_step"]["value"])
-            c["single_stream"]["live_one_call_no_lookahead"] = _r(ss["live_step"]["no_lookahead"])
             c["single_stream"]["live_python_protocol"] = _r(ss["by_builds_in_flight"].get("1_python_protocol"))
             c["single_stream"]["live"] = _r(max(ss["live_step"]["value"], ss["by_builds_in_flight"].get("1_python_protocol") or 0.0))
         if ss.get("live_graph") is not None:
@@ -132,7 +131,7 @@ def compact_line(out):
     if out.get("configs"):
         c["configs"] = {k: (_r(v.get("value")) if "value" in v else "error") for k, v in out["configs"].items()}
         wb = {k: ({"value": _r(v["with_ba"]["value"]), "fraction_of_front_end_only": _r(v["with_ba"]["fraction_of_front_end_only"]), "ba_call_ms": _r(v["with_ba"]["ba_call_ms"]),
-                   "ba_window": v["with_ba"]["ba_window"], "all_windows_ok": v["with_ba"]["all_windows_ok"]} if "value" in v["with_ba"] else {"error": v["with_ba"].get("error", "")[:100]})
+                   "ba_window": v["with_ba"]["ba_window"], "ok": v["with_ba"]["all_windows_ok"]} if "value" in v["with_ba"] else {"error": v["with_ba"].get("error", "")[:100]})
               for k, v in out["configs"].items() if isinstance(v.get("with_ba"), dict)}
         if wb:
             c["with_ba"] = wb                                      # each BASELINE config as named: the front-end loop with its 20 / 50 / 100-KF local BA per stream and key-frame
