@@ -45,8 +45,8 @@ int fe_feed(slam_frontend *fe, const uint8_t *left_u8, const uint8_t *right_u8)
     hipStream_t sb = (hipStream_t)slam_ctx_stream(fe->ctx_build);
     if (fe->tracked && fe->ctx_build != fe->ctx) FE_TRY(fe, fe->ctx_build, slam_ctx_wait_event(fe->ctx_build, fe->tracked));      // the pyramid being rebuilt is no longer read by a match
     if (hipMemcpyAsync(fe->dev8 + (size_t)sl * n, lsrc, n, hipMemcpyHostToDevice, sb) != hipSuccess) { fe->err = "slam_frontend: copy of the left frame failed"; return SLAM_ERR_HIP; }
-    static const int chain = getenv("SLAMHIP_FE_CHAIN") ? SLAM_PYR_CHAIN : 0;                                       // (measurement knob: the build as one chain)
-    FE_TRY(fe, fe->ctx_build, slam_pyr_update_u8_dev(fe->ctx_build, fe->left[sl], fe->dev8 + (size_t)sl * n, fe->c.pyr_mode | chain, fe->c.pyr_sigma, 0));
+    // (the build as one chain, SLAM_PYR_CHAIN -- a third of the graph launch's host time, 15 % more device time -- measured slower here: 2 020 / 4 500 frames/s)
+    FE_TRY(fe, fe->ctx_build, slam_pyr_update_u8_dev(fe->ctx_build, fe->left[sl], fe->dev8 + (size_t)sl * n, fe->c.pyr_mode, fe->c.pyr_sigma, 0));
     if (fe->ctx_build != fe->ctx) FE_TRY(fe, fe->ctx_build, slam_event_record(fe->ctx_build, fe->built[sl]));
     fe->has_right[sl] = right_u8 != nullptr;
     if (right_u8) {
@@ -122,8 +122,7 @@ int slam_frontend_create(int device, const slam_frontend_config *cfg, slam_front
     // queues differently and a latency-bound single stream loses ~40 % (measured twice: bench.py's single-stream legs, and this entry with its
     // tracking stream in the low class: 1 536 instead of 2 5xx frames/s).  Without look-ahead the build runs on the tracking stream itself:
     // nothing to overlap, and every cross-queue dependency costs ~10 us.
-    static const int fe_prio = [] { const char *v = getenv("SLAMHIP_FE_PRIO"); return v ? atoi(v) : 0; }();      // (measurement knob: scheduling class of the tracking stream)
-    int rc = fe_prio ? slam_ctx_create_priority(device, fe_prio, &fe->ctx) : slam_ctx_create(device, &fe->ctx);
+    int rc = slam_ctx_create(device, &fe->ctx);
     if (!rc && cfg->lookahead) rc = slam_ctx_create(device, &fe->ctx_build);
     if (!rc && !cfg->lookahead) fe->ctx_build = fe->ctx;
     if (!rc) rc = slam_ctx_create(device, &fe->ctx_right);
@@ -165,19 +164,16 @@ int slam_frontend_step(slam_frontend *fe, const uint8_t *left_u8, const uint8_t 
     if (!fe->tracked) { const int rc = slam_event_create(fe->ctx, &fe->tracked); if (rc) return fe_fail(fe, rc, fe->ctx, "slam_event_create"); (void)slam_event_record(fe->ctx, fe->tracked); }
     // look-ahead: the new frame's copy and build are enqueued FIRST, then the work of the frame whose build ran during the call before, then the
     // read-back.  (The other order -- tracking first, so that it runs during the 80-150 us of host time the build graph's launch takes -- is SLOWER:
-    // 3 610 instead of 5 250 frames/s in tolerance mode, 2 060 instead of 2 470 bit-exact; the read-back then sits behind the graph's packets on
-    // the hardware queue the runtime gave both streams.  SLAMHIP_FE_TRACK_FIRST=1 selects it.  The tracking stream in another scheduling class,
-    // low or high, costs more still: 1 550-2 200 frames/s.)
-    int rc = SLAM_OK;
-    const bool due = fe->c.lookahead ? fe->fed - fe->done >= 1 : true;
-    static const bool track_first = getenv("SLAMHIP_FE_TRACK_FIRST") != nullptr;                                  // (measurement knob; default: feed first)
-    if (fe->c.lookahead && due && track_first) { rc = fe_track(fe, params, prior, stereo_params, stereo_prior, tri, cull_flags_dev); if (rc) return rc; }
+    // 3 610 instead of 5 250 frames/s in tolerance mode, 2 060 instead of 2 470 bit-exact; also with the read-back requested ahead of the
+    // feed; the runtime serves the graph's packets first.  The tracking stream in another scheduling class, low or high, costs more still: 1 550-2 200
+    // frames/s.  Neither variant is kept in the code.)
     const auto h0 = std::chrono::steady_clock::now();
-    rc = fe_feed(fe, left_u8, right_u8);
+    int rc = fe_feed(fe, left_u8, right_u8);
     if (rc) return rc;
     fe->us_feed += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count(); fe->ncalls++;
-    if (!due) { if (frame_out) *frame_out = -1; if (count_out) *count_out = 0; return SLAM_OK; }
-    if (!fe->c.lookahead || !track_first) { rc = fe_track(fe, params, prior, stereo_params, stereo_prior, tri, cull_flags_dev); if (rc) return rc; }
+    if (fe->c.lookahead && fe->fed - fe->done < 2) { if (frame_out) *frame_out = -1; if (count_out) *count_out = 0; return SLAM_OK; }
+    rc = fe_track(fe, params, prior, stereo_params, stereo_prior, tri, cull_flags_dev);
+    if (rc) return rc;
     return fe_finish(fe, frame_out, count_out);
 }
 

@@ -9,6 +9,7 @@
 // host sees one small copy of the per-stream counts per step (slam_kpset_counts).  Compaction is stable (a stream's
 // keypoints keep their order) and is done with wave ballots + prefix counts, one workgroup per stream.
 #include "common.hpp"
+#include <algorithm>
 #include "tri_device.hpp"
 #include <cmath>
 
@@ -450,7 +451,7 @@ int slam_kpset_counts(slam_ctx *ctx, slam_kpset *ks, int32_t *counts)
     ARG_TRY(ctx, ctx != nullptr && ks != nullptr && counts != nullptr);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     void *h;
-    int rc = slam_pinned(ctx, 256, &h);
+    int rc = slam_pinned(ctx, std::max<size_t>(256, (size_t)ks->S * 4), &h);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(h, ks->count, (size_t)ks->S * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, slam_stream_wait(ctx->stream));
