@@ -251,3 +251,41 @@ def test_begin_end_equals_the_blocking_call_and_overlaps_other_work(slam, syn):
     a.begin(ctx=ctx_a, reset=True)                       # a context that is closed with a job in flight waits for it
     ctx_a.close(); ctx_b.close()
     assert np.array_equal(a.theta, ref.theta)
+
+
+_MFMA = r'''
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+import slam_jl_amd as slam
+from slam_jl_amd import synthetic as syn
+def cache(s):
+    return slam.LocalBACache(s["theta0"].copy(), s["theta_const"], s["pixels_yx"], s["pose_ids"], s["point_ids"])
+# windows of 8 .. 40 poses whose points are seen by 3 .. 20 key-frames (window half-bandwidths 2 .. 19: 2 .. 8 MFMA tiles per dimension), constant
+# poses at the start and ragged ones (dropped observations, constant poses anywhere, loop closures, shuffled order)
+sc = [syn.ba_scene(P=12, M=500, seed=1, obs_per_point=3), syn.ba_scene(P=16, M=700, seed=2, obs_per_point=6, n_const=4),
+      syn.ba_scene(P=24, M=900, seed=3, obs_per_point=12), syn.ba_scene(P=40, M=600, seed=4, obs_per_point=20, n_const=2),
+      syn.ba_scene(P=20, M=4000, seed=5), syn.ba_scene(P=9, M=60, seed=6, obs_per_point=8)]
+sc += [syn.ba_scene_ragged(seed=40 + k) for k in range(3)]          # (ragged windows the matrix-core build takes; a batch with a window it cannot take -- a group of more
+                                                                     #  than 256 observations, a matrix Y beyond 64 KB -- keeps the vector kernel for all of its windows)
+b = slam.BABatch([cache(s) for s in sc], sc[0]["cam"]); b.solve()
+np.save(%(out)r, np.concatenate([b.theta.ravel(), b.outl.ravel().astype(np.float64), b.stats[:, :6].ravel(), b.status.astype(np.float64)]))
+print("OK")
+'''
+
+
+def test_matrix_core_schur_build_equals_the_vector_kernel(tmp_path):
+    """k_schur_groups_m (the Schur products as Float64 MFMA tiles, Y = W chol(V^-1)) against the vector kernel k_schur_groups_b (SLAMHIP_BA_NO_MFMA=1) on
+    windows of half-bandwidth 2 .. 19 incl. constant poses, ragged observation sets and the bench's P20 shape: outlier sets and iteration counts equal,
+    theta to 1e-9 relative, costs to 1e-10 -- only the association of the block products differs"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("mfma", {}), ("vector", {"SLAMHIP_BA_NO_MFMA": "1"})):
+        out = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([sys.executable, "-c", _MFMA % dict(root=root, out=out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-800:] + r.stderr[-1500:]
+        res[tag] = np.load(out)
+    a, b = res["mfma"], res["vector"]
+    assert a.shape == b.shape and not np.array_equal(a, b), "the two builds gave bit-identical results: is the matrix-core path taken at all?"
+    rel = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    assert rel.max() <= 1e-9, rel.max()
