@@ -282,4 +282,40 @@ function finish!(job::BABatchJob)
     job.status
 end
 
+# ---- one live stream, one call per frame (slam_frontend_*, include/slamhip.h): what run!()'s front-end task does per frame
+# (front_end.jl:58-113, :454-470) and, at a key-frame, create_keyframe! + the mapper's stereo step (map_manager.jl:98-113, mapper.jl:51-66, :142-183),
+# enqueued by ONE ccall; the keypoint list stays in HBM.  FrontEndConfig mirrors slam_frontend_config field for field (16 Int32, 9 Float64).
+mutable struct FrontEndConfig
+    H::Int32; W::Int32; pyramid_levels::Int32; pyramid_levels_3d::Int32; window::Int32; iterations::Int32
+    max_points::Int32; radius::Int32; grid_rows::Int32; grid_cols::Int32; cell_size::Int32; cap::Int32
+    pyr_mode::Int32; lookahead::Int32; right_target_only::Int32; reserved::Int32
+    eig_thr::Float64; eps::Float64; max_distance::Float64; sigma_mask::Float64; min_response::Float64
+    epipolar_error::Float64; max_error::Float64; min_depth::Float64; pyr_sigma::Float64
+end
+function FrontEndConfig(params, e; H::Integer, W::Integer, tolerance::Bool = false, lookahead::Bool = false)
+    cells = e.grid_resolution[1] * e.grid_resolution[2]
+    FrontEndConfig(H, W, params.pyramid_levels, 1, params.window_size, 30, e.max_points, e.radius, e.grid_resolution[1], e.grid_resolution[2], e.cell_size,
+                   e.max_points + cells + 64, tolerance ? 3 : 1, lookahead ? 1 : 0, 1, 0,
+                   1e-4, 1e-2, params.max_ktl_distance, 3.0, 1e-4, 2.0, params.max_reprojection_error, 0.1, params.pyramid_sigma)
+end
+struct LiveFrontEnd; h::Ptr{Cvoid}; cfg::FrontEndConfig; end
+function LiveFrontEnd(cfg::FrontEndConfig; device::Integer = 0)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:slam_frontend_create, LIB[]), Cint, (Cint, Ref{FrontEndConfig}, Ref{Ptr{Cvoid}}), device, cfg, r))
+    LiveFrontEnd(r[], cfg)
+end
+close!(fe::LiveFrontEnd) = ccall((:slam_frontend_destroy, LIB[]), Cint, (Ptr{Cvoid},), fe.h)
+# left / right: Matrix{UInt8} as the KITTI reader decodes them (column-major H x W); right === nothing unless the frame is a key-frame.  params /
+# stereo_params: 32 Float64 each (stream_params of one stream); tri: 72 Float64 (P1, P2, T21, cam1, cam2, Twc).  Returns (frame index or -1, list length).
+function step!(fe::LiveFrontEnd, left::Matrix{UInt8}, right::Union{Nothing, Matrix{UInt8}}, params::Vector{Float64}; prior::Integer = 1,
+               stereo_params::Union{Nothing, Vector{Float64}} = nothing, stereo_prior::Integer = 2, tri::Union{Nothing, Vector{Float64}} = nothing)
+    frame = Ref{Int32}(-1); n = Ref{Int32}(0)
+    rc = GC.@preserve left right params stereo_params tri ccall((:slam_frontend_step, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{UInt8}, Ref{Int32}, Ref{Int32}),
+        fe.h, left, right === nothing ? Ptr{UInt8}(C_NULL) : pointer(right), params, prior,
+        stereo_params === nothing ? Ptr{Float64}(C_NULL) : pointer(stereo_params), stereo_prior, tri === nothing ? Ptr{Float64}(C_NULL) : pointer(tri), C_NULL, frame, n)
+    rc == 0 || error("slam_frontend_step ($rc): ", unsafe_string(ccall((:slam_frontend_last_error, LIB[]), Cstring, (Ptr{Cvoid},), fe.h)))
+    Int(frame[]), Int(n[])
+end
+
 end # module
