@@ -27,14 +27,14 @@ __global__ __launch_bounds__(256) void k_pass_start_b(const BAWin *tab, int pass
 template <int TT> __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(4))) void k_schur_groups_b(const BAWin *tab, int ignore_outliers)
 {
     const BAWin w = ba_win(tab);
-    if (w.pad) return;                                       // the window is k_ba_window's
+    if (w.pad || w.pad2) return;                             // the window is k_ba_window's / k_schur_groups_m's (pad2: the matrix-core build takes it)
     if ((int)blockIdx.x >= w.d.ngrp) return;
     schur_groups_body<TT>(w.d, 0.0, ignore_outliers, 1);
 }
 template <int TT> __global__ __launch_bounds__(TT) void k_schur_groups_m(const BAWin *tab, int ignore_outliers)
 {
     const BAWin w = ba_win(tab);
-    if (w.pad) return;                                       // the window is k_ba_window's
+    if (w.pad || !w.pad2) return;                            // the window is k_ba_window's / the vector build's
     if ((int)blockIdx.x >= w.d.ngrp) return;
     schur_groups_mfma_body<TT>(w.d, ignore_outliers);
 }
@@ -71,7 +71,7 @@ template <int TT, bool RECOMP> __global__ __launch_bounds__(TT) void k_update_gr
     extern __shared__ __attribute__((aligned(16))) double ug_lds[];
     const BAWin w = ba_win(tab);
     if (w.pad) return;                                       // the window is k_ba_window's
-    if ((int)blockIdx.x >= w.d.ngrp) return;
+    if ((int)blockIdx.x >= w.d.ngrp || (w.pad2 != 0) != RECOMP) return;      // (a window of the matrix-core build stores nothing of its evaluation: RECOMP forms it again; the others read it back)
     double *s_dp = ug_lds, *s_sct = s_dp + n_cap, *s_sc = s_sct + n_cap, *s_u = s_sc + n_cap, *s_dl = s_u + (size_t)cap_ob * 3, *s_red = s_dl + (size_t)cap_sb * 6;
     update_groups_body<TT, RECOMP>(w.d, ignore_outliers, 1, s_dp, s_u, s_dl, s_red, s_sct, true, s_sc);
 }
@@ -299,14 +299,20 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
         const int TT = (!no_t256 && max_ob <= 256 && (max_hb + 1) * (max_hb + 2) / 2 <= 256) ? 256 : SG_T;
         for (int k = 0; k < NB; k++) if (!pl[batch[k]].err && !tab_h[k].pad) lds_sg = std::max(lds_sg, sg_lds_bytes(tab_h[k].d.whb, tab_h[k].d.P, tab_h[k].d.sg_ob, tab_h[k].d.sg_sb, TT, tab_h[k].d.sg_hp));
         // the Schur products on the matrix cores (k_schur_groups_m): 256-thread groups whose matrix Y (3 x points columns, 6 x window slots rows) fits
-        // LDS beside two more workgroups; SLAMHIP_BA_NO_MFMA=1 keeps the vector kernel (A/B timing, and the parity reference of the tests)
+        // LDS beside two more workgroups; SLAMHIP_BA_NO_MFMA=1 keeps the vector kernel (A/B timing, and the parity reference of the tests).  The vector kernel's lds_sg
+        // and the cost-only linearisation are shared: the vector build stores its own evaluation, the matrix-core build none
         int ug_n = 6, ug_ob = 8, ug_sb = 8;                     // k_update_groups_b's LDS arrays at the batch's own sizes
         for (int k = 0; k < NB; k++) if (!pl[batch[k]].err && !tab_h[k].pad) { ug_n = std::max(ug_n, tab_h[k].d.n); ug_ob = std::max(ug_ob, tab_h[k].d.sg_ob); ug_sb = std::max(ug_sb, tab_h[k].d.sg_sb); }
         const size_t lds_ug = ug_lds_bytes(ug_n, ug_ob, ug_sb);
         static const bool no_mfma = getenv("SLAMHIP_BA_NO_MFMA") != nullptr;
-        size_t lds_m = 0;
-        for (int k = 0; k < NB; k++) if (!pl[batch[k]].err && !tab_h[k].pad) lds_m = std::max(lds_m, sgm_lds_bytes(tab_h[k].d.whb, tab_h[k].d.P, tab_h[k].d.sg_ob, tab_h[k].d.sg_sb, tab_h[k].d.sg_hp));
-        const bool use_mfma = !no_mfma && TT == 256 && lds_m > 0 && lds_m <= 64 * 1024;
+        // per window (BAWin::pad2): one window whose matrix Y does not fit (a wide band with few observations per point) does not take the matrix cores from the others
+        size_t lds_m = 0; int n_mfma = 0, n_vec = 0;
+        for (int k = 0; k < NB; k++) if (!pl[batch[k]].err && !tab_h[k].pad) {
+            const size_t b = sgm_lds_bytes(tab_h[k].d.whb, tab_h[k].d.P, tab_h[k].d.sg_ob, tab_h[k].d.sg_sb, tab_h[k].d.sg_hp);
+            const bool m = !no_mfma && TT == 256 && b <= 64 * 1024;
+            tab_h[k].pad2 = m ? 1 : 0;
+            if (m) { lds_m = std::max(lds_m, b); n_mfma++; } else n_vec++;
+        }
         const auto tw2 = std::chrono::steady_clock::now();
         hipStream_t st = ctx->stream;
         static std::atomic<bool> attr_set[64];
@@ -326,15 +332,15 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
             hipLaunchKernelGGL(k_linearize_b, dim3(gx_obs, NB), dim3(256), 0, st, tab, ignore, 0);
             hipLaunchKernelGGL(k_pass_start_b, dim3(1, NB), dim3(256), 0, st, tab, ignore ? 1 : 0);
             for (int it = 1; it <= iters; it++) {
-                if (use_mfma) hipLaunchKernelGGL(k_schur_groups_m<256>, dim3(gx_grp, NB), dim3(256), lds_m, st, tab, ignore);
-                else if (TT == 256) hipLaunchKernelGGL(k_schur_groups_b<256>, dim3(gx_grp, NB), dim3(256), lds_sg, st, tab, ignore);
-                else hipLaunchKernelGGL(k_schur_groups_b<SG_T>, dim3(gx_grp, NB), dim3(SG_T), lds_sg, st, tab, ignore);
+                if (n_mfma) hipLaunchKernelGGL(k_schur_groups_m<256>, dim3(gx_grp, NB), dim3(256), lds_m, st, tab, ignore);
+                if (n_vec && TT == 256) hipLaunchKernelGGL(k_schur_groups_b<256>, dim3(gx_grp, NB), dim3(256), lds_sg, st, tab, ignore);
+                else if (n_vec) hipLaunchKernelGGL(k_schur_groups_b<SG_T>, dim3(gx_grp, NB), dim3(SG_T), lds_sg, st, tab, ignore);
                 hipLaunchKernelGGL(k_schur_reduce_b, dim3(gx_red, NB), dim3(256), 0, st, tab);
                 hipLaunchKernelGGL(k_band_solve_b, dim3(1, NB), dim3(BS_T), lds_band, st, tab);
                 hipLaunchKernelGGL(k_trial_poses_b, dim3(1, NB), dim3(64), 0, st, tab);
-                if (use_mfma) hipLaunchKernelGGL((k_update_groups_b<256, true>), dim3(gx_grp, NB), dim3(256), lds_ug, st, tab, ignore, ug_n, ug_ob, ug_sb);
-                else if (TT == 256) hipLaunchKernelGGL((k_update_groups_b<256, false>), dim3(gx_grp, NB), dim3(256), lds_ug, st, tab, ignore, ug_n, ug_ob, ug_sb);
-                else hipLaunchKernelGGL((k_update_groups_b<SG_T, false>), dim3(gx_grp, NB), dim3(SG_T), lds_ug, st, tab, ignore, ug_n, ug_ob, ug_sb);
+                if (n_mfma) hipLaunchKernelGGL((k_update_groups_b<256, true>), dim3(gx_grp, NB), dim3(256), lds_ug, st, tab, ignore, ug_n, ug_ob, ug_sb);
+                if (n_vec && TT == 256) hipLaunchKernelGGL((k_update_groups_b<256, false>), dim3(gx_grp, NB), dim3(256), lds_ug, st, tab, ignore, ug_n, ug_ob, ug_sb);
+                else if (n_vec) hipLaunchKernelGGL((k_update_groups_b<SG_T, false>), dim3(gx_grp, NB), dim3(SG_T), lds_ug, st, tab, ignore, ug_n, ug_ob, ug_sb);
                 hipLaunchKernelGGL(k_control_b, dim3(1, NB), dim3(256), 0, st, tab);
             }
         };

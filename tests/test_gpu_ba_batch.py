@@ -265,8 +265,8 @@ def cache(s):
 sc = [syn.ba_scene(P=12, M=500, seed=1, obs_per_point=3), syn.ba_scene(P=16, M=700, seed=2, obs_per_point=6, n_const=4),
       syn.ba_scene(P=24, M=900, seed=3, obs_per_point=12), syn.ba_scene(P=40, M=600, seed=4, obs_per_point=20, n_const=2),
       syn.ba_scene(P=20, M=4000, seed=5), syn.ba_scene(P=9, M=60, seed=6, obs_per_point=8)]
-sc += [syn.ba_scene_ragged(seed=40 + k) for k in range(3)]          # (ragged windows the matrix-core build takes; a batch with a window it cannot take -- a group of more
-                                                                     #  than 256 observations, a matrix Y beyond 64 KB -- keeps the vector kernel for all of its windows)
+sc += [syn.ba_scene_ragged(seed=40 + k) for k in range(6)]          # (three of these have a matrix Y beyond 64 KB -- a wide band with few observations per point -- and keep
+                                                                     #  the vector kernel, window by window: both builds run in the same launch sets)
 b = slam.BABatch([cache(s) for s in sc], sc[0]["cam"]); b.solve()
 np.save(%(out)r, np.concatenate([b.theta.ravel(), b.outl.ravel().astype(np.float64), b.stats[:, :6].ravel(), b.status.astype(np.float64)]))
 print("OK")
