@@ -328,22 +328,33 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
             attr_set[dv].store(true, std::memory_order_release);
         }
         const BAWin *tab = (const BAWin *)A; const BARes *rtab = (const BARes *)(A + tab_bytes);
-        auto run_pass = [&](int ignore, int iters) {
-            hipLaunchKernelGGL(k_linearize_b, dim3(gx_obs, NB), dim3(256), 0, st, tab, ignore, 0);
-            hipLaunchKernelGGL(k_pass_start_b, dim3(1, NB), dim3(256), 0, st, tab, ignore ? 1 : 0);
+        // the launch-per-phase windows [n0, n0 + nb) on stream q: both passes.  A batch of >= 32 such windows runs as TWO halves on two streams: while one half sits
+        // in its latency-bound kernels (k_band_solve_b: one workgroup per window, k_trial_poses_b, k_control_b -- ~75 us of an iteration) the other half's builds fill the chip
+        auto run_pass = [&](hipStream_t q, int n0, int nb, int ignore, int iters) {
+            const BAWin *tb = tab + n0;
+            hipLaunchKernelGGL(k_linearize_b, dim3(gx_obs, nb), dim3(256), 0, q, tb, ignore, 0);
+            hipLaunchKernelGGL(k_pass_start_b, dim3(1, nb), dim3(256), 0, q, tb, ignore ? 1 : 0);
             for (int it = 1; it <= iters; it++) {
-                if (n_mfma) hipLaunchKernelGGL(k_schur_groups_m<256>, dim3(gx_grp, NB), dim3(256), lds_m, st, tab, ignore);
-                if (n_vec && TT == 256) hipLaunchKernelGGL(k_schur_groups_b<256>, dim3(gx_grp, NB), dim3(256), lds_sg, st, tab, ignore);
-                else if (n_vec) hipLaunchKernelGGL(k_schur_groups_b<SG_T>, dim3(gx_grp, NB), dim3(SG_T), lds_sg, st, tab, ignore);
-                hipLaunchKernelGGL(k_schur_reduce_b, dim3(gx_red, NB), dim3(256), 0, st, tab);
-                hipLaunchKernelGGL(k_band_solve_b, dim3(1, NB), dim3(BS_T), lds_band, st, tab);
-                hipLaunchKernelGGL(k_trial_poses_b, dim3(1, NB), dim3(64), 0, st, tab);
-                if (n_mfma) hipLaunchKernelGGL((k_update_groups_b<256, true>), dim3(gx_grp, NB), dim3(256), lds_ug, st, tab, ignore, ug_n, ug_ob, ug_sb);
-                if (n_vec && TT == 256) hipLaunchKernelGGL((k_update_groups_b<256, false>), dim3(gx_grp, NB), dim3(256), lds_ug, st, tab, ignore, ug_n, ug_ob, ug_sb);
-                else if (n_vec) hipLaunchKernelGGL((k_update_groups_b<SG_T, false>), dim3(gx_grp, NB), dim3(SG_T), lds_ug, st, tab, ignore, ug_n, ug_ob, ug_sb);
-                hipLaunchKernelGGL(k_control_b, dim3(1, NB), dim3(256), 0, st, tab);
+                if (n_mfma) hipLaunchKernelGGL(k_schur_groups_m<256>, dim3(gx_grp, nb), dim3(256), lds_m, q, tb, ignore);
+                if (n_vec && TT == 256) hipLaunchKernelGGL(k_schur_groups_b<256>, dim3(gx_grp, nb), dim3(256), lds_sg, q, tb, ignore);
+                else if (n_vec) hipLaunchKernelGGL(k_schur_groups_b<SG_T>, dim3(gx_grp, nb), dim3(SG_T), lds_sg, q, tb, ignore);
+                hipLaunchKernelGGL(k_schur_reduce_b, dim3(gx_red, nb), dim3(256), 0, q, tb);
+                hipLaunchKernelGGL(k_band_solve_b, dim3(1, nb), dim3(BS_T), lds_band, q, tb);
+                hipLaunchKernelGGL(k_trial_poses_b, dim3(1, nb), dim3(64), 0, q, tb);
+                if (n_mfma) hipLaunchKernelGGL((k_update_groups_b<256, true>), dim3(gx_grp, nb), dim3(256), lds_ug, q, tb, ignore, ug_n, ug_ob, ug_sb);
+                if (n_vec && TT == 256) hipLaunchKernelGGL((k_update_groups_b<256, false>), dim3(gx_grp, nb), dim3(256), lds_ug, q, tb, ignore, ug_n, ug_ob, ug_sb);
+                else if (n_vec) hipLaunchKernelGGL((k_update_groups_b<SG_T, false>), dim3(gx_grp, nb), dim3(SG_T), lds_ug, q, tb, ignore, ug_n, ug_ob, ug_sb);
+                hipLaunchKernelGGL(k_control_b, dim3(1, nb), dim3(256), 0, q, tb);
             }
         };
+        auto both_passes = [&](hipStream_t q, int n0, int nb) {
+            run_pass(q, n0, nb, 0, iters_fast);
+            hipLaunchKernelGGL(k_outliers_b, dim3(gx_obs, nb), dim3(256), 0, q, tab + n0, repr_eps, 1e-6);
+            hipLaunchKernelGGL(k_outlier_count_b, dim3(1, nb), dim3(256), 0, q, tab + n0);
+            run_pass(q, n0, nb, 1, iterations);
+        };
+        static const bool one_stream = getenv("SLAMHIP_BA_ONE_STREAM") != nullptr;      // (measurement knob)
+        hipStream_t st2 = (!all_small && NB >= 32 && !one_stream) ? ctx_aux_stream(ctx) : nullptr;
         if (NS_ > 0) {                                             // (the flag is set on success only: a failed attribute call is tried again by the next call)
             static std::atomic<bool> bw_attr[64];
             if (!bw_attr[dv].load(std::memory_order_acquire)) {
@@ -374,12 +385,13 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
                 const int *list_d = (const int *)(A + tab_bytes + rtab_bytes - al((size_t)NB * 4));
                 hipLaunchKernelGGL(k_ba_window, dim3(two ? two_grid : NS_), dim3(BW_T), lds_bw, st, tab, list_d, NS_, two, iters_fast, iterations, repr_eps, 1e-6, xlimit);
             }
-            if (!all_small) {
-                run_pass(0, iters_fast);
-                hipLaunchKernelGGL(k_outliers_b, dim3(gx_obs, NB), dim3(256), 0, st, tab, repr_eps, 1e-6);
-                hipLaunchKernelGGL(k_outlier_count_b, dim3(1, NB), dim3(256), 0, st, tab);
-                run_pass(1, iterations);
-            }
+            if (!all_small && st2) {
+                const int nA = NB / 2;
+                (void)hipEventRecord(ctx->fork_ev, st); (void)hipStreamWaitEvent(st2, ctx->fork_ev, 0);
+                both_passes(st2, nA, NB - nA);
+                both_passes(st, 0, nA);
+                (void)hipEventRecord(ctx->join_ev, st2); (void)hipStreamWaitEvent(st, ctx->join_ev, 0);
+            } else if (!all_small) both_passes(st, 0, NB);
             hipLaunchKernelGGL(k_results_b, dim3(8, NB), dim3(256), 0, st, tab, rtab, A);
             e = hipGetLastError();
             (void)hipEventRecord(e1, st);

@@ -26,6 +26,8 @@ struct slam_ctx {
     void *scratch2 = nullptr; size_t scratch2_bytes = 0;
     void *pinned = nullptr; size_t pinned_bytes = 0;
     hipEvent_t wait_event = nullptr;      // slam_ctx_wait_for
+    hipStream_t stream2 = nullptr;        // a second stream of the same scheduling class (ctx_aux_stream: the second half of a batch of BA windows), with its fork / join events
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     // optional device-side timing (hipEvents on ctx->stream), see slam_prof_*
     bool prof_on = false;
     struct ProfSpan { int id; hipEvent_t a, b; };
@@ -36,6 +38,7 @@ struct slam_ctx {
     std::vector<long long> prof_cnt;
 };
 
+extern "C" hipStream_t ctx_aux_stream(slam_ctx *c);          // nullptr if it cannot be created (ctx.hip)
 extern "C" void ctx_probe_device(slam_ctx *c);      // fills dev_cus / xwg_ok (ctx.hip)
 
 // RAII span: records a hipEvent pair around the enclosed launches when profiling is on

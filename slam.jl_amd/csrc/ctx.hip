@@ -128,6 +128,21 @@ hipStream_t take_parked(int device, int prio)
 }
 }  // namespace
 
+// the context's second stream (created on first use, in the scheduling class of the first; CU-masked contexts have none) and its two events
+hipStream_t ctx_aux_stream(slam_ctx *c)
+{
+    if (c->stream2) return c->stream2;
+    if (c->cus > 0) return nullptr;
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const int p = c->pool_class == 1 ? greatest : c->pool_class == -1 ? least : 0;
+    if (e == hipSuccess) e = c->pool_class == 0 || c->pool_class == 99 ? hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) : hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, p);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming);
+    if (e != hipSuccess) { (void)hipGetLastError(); if (c->stream2) (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; return nullptr; }
+    return c->stream2;
+}
+
 // What the device is, once per context: the kernels whose workgroups wait for one another (k_ba_window's two halves, the twisted band
 // solve, k_cum_fused's row segments) need to know how many workgroups the chip really holds and that it is the architecture their
 // memory-side hand-overs were validated on (no hard-coded 256, no assumption about other architectures).
@@ -218,6 +233,9 @@ int slam_ctx_destroy(slam_ctx *ctx)
     if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
     for (auto &sp : ctx->prof_pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (stream_pool_on() && ctx->pool_class != 99) { std::lock_guard<std::mutex> lk(g_park_mu); g_parked.push_back({ctx->device, ctx->pool_class, ctx->stream}); }
