@@ -203,70 +203,60 @@ __device__ static inline double p3p_reproj(const double *P, const double *K, con
     return sqrt(dx * dx + dy * dy);
 }
 
-#define P3P_G 8                         // triples per wave of k_p3p_score
 __global__ __launch_bounds__(64) void k_p3p_score(P3PArgs T)
 {
-    // one wave per P3P_G triples.  The minimal solver is a latency chain of ~20 k cycles of dependent f64 divisions and square roots that does not use the
-    // wave's width: lane l solves triple l % P3P_G (every triple on eight lanes, identical values, coinciding LDS stores), so the wave pays the chain once
-    // for eight triples; their up to four poses each go to LDS, then the 64 lanes stride over the map points and score one triple's poses after the other.
-    // (Round 5: one wave per triple -- the chain was two thirds of a wave's time; four waves per triple, each repeating the solver for "its" pose, took
-    // 190 us per 32-stream call.)  Same operations per triple: poses and counts are bit-identical.
-    __shared__ double s_P[P3P_G * 48];
-    __shared__ int s_ns[P3P_G];
-    const int it0 = blockIdx.x * P3P_G, z = blockIdx.y, lane = threadIdx.x, g = lane & (P3P_G - 1);
+    // one wave per triple: the (wave-uniform, latency-bound: ~20 k cycles of dependent f64 divisions and square roots) minimal
+    // solver runs ONCE, its up to four poses go to LDS, then the 64 lanes stride over the map points and score every pose on
+    // each point they load.  (Four waves per triple, each repeating the solver for "its" pose, took 190 us per 32-stream call.)
+    __shared__ double s_P[48];
+    const int it = blockIdx.x, z = blockIdx.y, lane = threadIdx.x;
     const int base = T.cnt ? z * T.stride : T.off[z], n = T.cnt ? T.cnt[z] : T.off[z + 1] - base;
     const double *pts = T.pts + 3 * (size_t)base, *px = T.px + 2 * (size_t)base, *pdn = T.pdn + 3 * (size_t)base;
+    const int32_t *sm = T.samples + 3 * ((size_t)z * T.iters + it);
+    const int i0 = sm[0], i1 = sm[1], i2 = sm[2];
     double K[9];
     for (int j = 0; j < 9; j++) K[j] = T.Ks[9 * z + j];
-    {
-        const int it = it0 + g;
-        int ns = 0;
-        if (it < T.iters) {
-            const int32_t *sm = T.samples + 3 * ((size_t)z * T.iters + it);
-            const int i0 = sm[0], i1 = sm[1], i2 = sm[2];
-            const bool valid = !(i0 < 0 || i1 < 0 || i2 < 0 || i0 >= n || i1 >= n || i2 >= n || i0 == i1 || i0 == i2 || i1 == i2);
-            if (valid) {
-                double X[9], F[9], Pd[12];
-                for (int j = 0; j < 3; j++) {
-                    X[j] = pts[3 * i0 + j]; X[3 + j] = pts[3 * i1 + j]; X[6 + j] = pts[3 * i2 + j];
-                    F[j] = pdn[3 * i0 + j]; F[3 + j] = pdn[3 * i1 + j]; F[6 + j] = pdn[3 * i2 + j];
-                }
-                ns = p3p_solve<true>(X, F, -1, Pd, (p3p_lds *)(s_P + 48 * g));
-            }
+    int ns = 0;
+    const bool valid = !(i0 < 0 || i1 < 0 || i2 < 0 || i0 >= n || i1 >= n || i2 >= n || i0 == i1 || i0 == i2 || i1 == i2);
+    if (valid) {
+        double X[9], F[9], Pd[12];
+        for (int j = 0; j < 3; j++) {
+            X[j] = pts[3 * i0 + j]; X[3 + j] = pts[3 * i1 + j]; X[6 + j] = pts[3 * i2 + j];
+            F[j] = pdn[3 * i0 + j]; F[3 + j] = pdn[3 * i1 + j]; F[6 + j] = pdn[3 * i2 + j];
         }
-        if (lane < P3P_G) s_ns[g] = ns;
+        ns = p3p_solve<true>(X, F, -1, Pd, (p3p_lds *)s_P);             // all lanes hold the same values: the LDS stores coincide
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int h = 0; h < P3P_G && it0 + h < T.iters; h++) {
-        const int ns = s_ns[h];                                   // wave-uniform
-        int cnt[4] = {0, 0, 0, 0};
-        if (ns > 0) {
-            double P[4][12];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    // (Round 6 tried the incumbent bound of k_5pt_score here -- counts by ballots, a pose dropped once it cannot reach the best completely scored
+    //  count of its stream: 0.9 -> 1.3 ms per 128-stream call.  Most triples of a rigid scene give a pose near the best one, so little is dropped,
+    //  and four ballots + scalar adds per round cost more than the per-lane counters.  Not kept.)
+    int cnt[4] = {0, 0, 0, 0};
+    if (ns > 0) {
+        double P[4][12];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int j = 0; j < 12; j++) P[k][j] = k < ns ? s_P[12 * k + j] : 0.0;
+        for (int i = lane; i < n; i += 64) {
+            const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+            const double q[2] = {px[2 * i], px[2 * i + 1]};
 #pragma unroll
             for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int j = 0; j < 12; j++) P[k][j] = k < ns ? s_P[48 * h + 12 * k + j] : 0.0;
-            for (int i = lane; i < n; i += 64) {
-                const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
-                const double q[2] = {px[2 * i], px[2 * i + 1]};
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (k < ns) {
-                        const double e = p3p_reproj(P[k], K, X, q);
-                        cnt[k] += (e >= 0.0 && e < T.thr) ? 1 : 0;
-                    }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                for (int o = 32; o > 0; o >>= 1) cnt[k] += __shfl_xor(cnt[k], o, 64);
+                if (k < ns) {
+                    const double e = p3p_reproj(P[k], K, X, q);
+                    cnt[k] += (e >= 0.0 && e < T.thr) ? 1 : 0;
+                }
         }
-        if (lane < 4) {
-            const int k = lane;
-            const size_t e = ((size_t)z * T.iters + it0 + h) * 4 + k;
-            T.counts[e] = k == 0 ? cnt[0] : k == 1 ? cnt[1] : k == 2 ? cnt[2] : cnt[3];
-            if (k < ns)
-                for (int j = 0; j < 12; j++) T.poses[e * 12 + j] = s_P[48 * h + 12 * k + j];
-        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            for (int o = 32; o > 0; o >>= 1) cnt[k] += __shfl_xor(cnt[k], o, 64);
+    }
+    if (lane < 4) {
+        const int k = lane;
+        const size_t e = ((size_t)z * T.iters + it) * 4 + k;
+        T.counts[e] = k == 0 ? cnt[0] : k == 1 ? cnt[1] : k == 2 ? cnt[2] : cnt[3];
+        if (k < ns)
+            for (int j = 0; j < 12; j++) T.poses[e * 12 + j] = s_P[12 * k + j];
     }
 }
 
@@ -364,7 +354,7 @@ static int p3p_run(slam_ctx *ctx, int S, const int32_t *off, const double *pts3d
     T.counts = (int *)scr; T.poses = (double *)(scr + s_cnt); T.errs = (double *)(scr + s_cnt + s_pose);
     T.out = (double *)(d + o_out); T.inliers = (uint8_t *)(d + o_inl);
     { ProfScope span(ctx, "p3p_ransac");
-      hipLaunchKernelGGL(k_p3p_score, dim3((iters + P3P_G - 1) / P3P_G, S), dim3(64), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_p3p_score, dim3(iters, S), dim3(64), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_p3p_select, dim3(S), dim3(256), 0, ctx->stream, T); }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, slam_stream_wait(ctx->stream));
@@ -654,7 +644,7 @@ extern "C" int slam_kpset_compute_pose(slam_ctx *ctx, slam_kpset *ks, const doub
     { ProfScope span(ctx, "kpset_compute_pose");
       hipLaunchKernelGGL(k_kpose_gather, dim3(S), dim3(256), 0, ctx->stream, A);
       hipLaunchKernelGGL(k_kpose_samples, dim3((iters + 255) / 256, S), dim3(256), 0, ctx->stream, A);
-      hipLaunchKernelGGL(k_p3p_score, dim3((iters + P3P_G - 1) / P3P_G, S), dim3(64), 0, ctx->stream, T);
+      hipLaunchKernelGGL(k_p3p_score, dim3(iters, S), dim3(64), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_p3p_select, dim3(S), dim3(256), 0, ctx->stream, T);
       hipLaunchKernelGGL(k_kpose_prep, dim3(S), dim3(256), 0, ctx->stream, A);
       rc = pnp_launch_device(ctx, S, A.pnp);
