@@ -512,7 +512,9 @@ __device__ static inline void ray_depths(const double *Rt, const double *q1, con
     *l2 = *l1 * r2 + Rt[11];
 }
 
-__global__ __launch_bounds__(FP_TPB * FP_TEAM) void k_5pt_solve(FPArgs T)
+// (three waves per SIMD: left to itself the allocator takes 244 registers -- one or two waves per SIMD for a kernel that is a latency chain of eliminations and
+//  root brackets; capped at 168 it spills 191 registers to scratch and is still 21 % faster: 1.02 -> 0.80 ms per 128-stream call; four waves per SIMD, 128 registers: 0.97)
+__global__ __launch_bounds__(FP_TPB * FP_TEAM) __attribute__((amdgpu_waves_per_eu(3))) void k_5pt_solve(FPArgs T)
 {
     extern __shared__ double s_fp[];
     const int team = threadIdx.x / FP_TEAM, l = threadIdx.x % FP_TEAM, z = blockIdx.y;
