@@ -1,7 +1,7 @@
 #!/bin/bash
 # tracing build of detect.hip (per-phase clocks of one cell printed from the device): slam.jl_amd/libslamhip_dett.so, used via SLAMHIP_LIB
 set -e
-cd "$(dirname "$0")/../slam.jl_amd/csrc"
+cd "$(dirname "$0")/../../slam.jl_amd/csrc"
 make >/dev/null
 mkdir -p /tmp/bas
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -DDET_TRACE -c detect.hip -o /tmp/bas/detect.t.o

@@ -127,22 +127,38 @@ __global__ __launch_bounds__(256) void k_results_b(const BAWin *tab, const BARes
 // condition variable between calls -- starting 15 threads per phase cost more than the work they did (128 windows: 2.3 ms of a 6.3 ms
 // call).  Callers from several contexts take turns (run_mu).  Windows are handed out one at a time from an atomic counter.
 namespace {
+// A run hands out task indices from one atomic word tagged with the run's generation, so that a worker only ever executes a task with the function of
+// the run the index belongs to; only as many workers are woken as there are tasks beside the caller's (a one-window set-up of four tasks does not
+// wake and collect 31 threads), and a worker that wakes late finds nothing to claim and goes back to sleep.
 struct BAPool {
     std::vector<std::thread> th;
     std::mutex mu, run_mu;
     std::condition_variable cv, cv_done;
     const std::function<void(int)> *fn = nullptr;
-    int n = 0, pending = 0; unsigned long gen = 0; bool stop = false;
-    std::atomic<int> next{0};
+    int n = 0; unsigned gen = 0; bool stop = false;
+    std::atomic<unsigned long long> next{0};      // generation << 32 | next task index
+    std::atomic<int> done{0};
+    // claims are one fetch_add each (no retry under contention).  A worker that read run g's function and then draws an index of a LATER run g' (it was
+    // late: run g is over) owns that task of run g' -- which therefore cannot have completed -- and reads g's successor under the mutex before executing it.
+    void take(const std::function<void(int)> *f, int count, unsigned g)
+    {
+        for (;;) {
+            const unsigned long long cur = next.fetch_add(1, std::memory_order_acq_rel);
+            if ((unsigned)(cur >> 32) != g) { std::lock_guard<std::mutex> lk(mu); f = fn; count = n; g = gen; if ((unsigned)(cur >> 32) != g) return; }
+            if ((int)(unsigned)cur >= count) return;
+            (*f)((int)(unsigned)cur);
+            if (done.fetch_add(1, std::memory_order_acq_rel) + 1 == count) { std::lock_guard<std::mutex> lk(mu); cv_done.notify_one(); }
+        }
+    }
     explicit BAPool(int workers)
     {
         for (int t = 0; t < workers; t++)
             th.emplace_back([this] {
-                unsigned long seen = 0;
+                unsigned seen = 0;
                 for (;;) {
-                    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
-                    for (int z; (z = next.fetch_add(1)) < n;) (*fn)(z);
-                    { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv_done.notify_one(); }
+                    const std::function<void(int)> *f; int count;
+                    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; f = fn; count = n; }
+                    take(f, count, seen);
                 }
             });
     }
@@ -151,11 +167,12 @@ struct BAPool {
     {
         std::lock_guard<std::mutex> turn(run_mu);
         if (th.empty() || count <= 1) { for (int z = 0; z < count; z++) f(z); return; }
-        { std::lock_guard<std::mutex> lk(mu); fn = &f; n = count; next.store(0); pending = (int)th.size(); gen++; }
-        cv.notify_all();
-        for (int z; (z = next.fetch_add(1)) < count;) f(z);
+        unsigned g;
+        { std::lock_guard<std::mutex> lk(mu); fn = &f; n = count; g = ++gen; done.store(0, std::memory_order_relaxed); next.store((unsigned long long)g << 32, std::memory_order_release); }
+        if (count - 1 >= (int)th.size()) cv.notify_all(); else for (int k = 0; k < count - 1; k++) cv.notify_one();
+        take(&f, count, g);
         std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [&] { return pending == 0; });
+        cv_done.wait(lk, [&] { return done.load(std::memory_order_acquire) >= count; });
     }
 };
 std::atomic<long> n_xretry{0};       // calls that were solved again on one workgroup per window (slam_debug_ba_xretries)
@@ -167,6 +184,8 @@ BAPool &ba_pool()
     return pool;
 }
 }  // namespace
+void ba_parallel_for(int count, const std::function<void(int)> &fn) { ba_pool().run(count, fn); }
+int ba_pool_threads() { return (int)ba_pool().th.size() + 1; }
 
 extern "C" {
 
@@ -503,7 +522,7 @@ extern "C" void ba_forget_jobs(slam_ctx *ctx)
 long slam_debug_ba_xretries(void) { return n_xretry.load(); }
 
 // host-only timing of the batch set-up (no HIP call, no device needed): plan + emit of S windows on `threads` threads (0: the library's parked
-// worker pool, as slam_local_ba_batch uses it) into malloc'ed staging; out_us = {plan, emit}; returns the number of windows whose set-up failed.  Measurement aid for tuning the host side on any machine (scripts/probes/ba_host_time.py).
+// worker pool, as slam_local_ba_batch uses it; -N: one window at a time with its passes over the observations split into <= N tasks of the pool, as slam_local_ba does; -1: the same on the calling thread) into malloc'ed staging; out_us = {plan, emit, a 52-bit hash of everything staged and of the observation orders}; returns the number of windows whose set-up failed.  Measurement aid for tuning the host side on any machine (scripts/probes/ba_host_time.py).
 int slam_debug_ba_host_time(int S, const double *cams, const int32_t *Pn, const int32_t *Mn, const int32_t *On, const double *theta, const uint8_t *theta_const,
                             const double *pixels_yx, const int64_t *pose_ids, const int64_t *point_ids, int threads, double *out_us)
 {
@@ -526,16 +545,23 @@ int slam_debug_ba_host_time(int S, const double *cams, const int32_t *Pn, const 
         for (int z = 0; z < S; z += threads) fn(z);
         for (auto &x : th) x.join();
     };
-    parallel([&](int z) { ba_plan(pl[z]); });
+    if (threads < 0) for (int z = 0; z < S; z++) { pl[z].small_groups = false; pl[z].nthreads = -threads; ba_plan(pl[z]); }     // slam_local_ba's way: one window at a time, its passes split over the pool
+    else parallel([&](int z) { ba_plan(pl[z]); });
     const auto t1 = std::chrono::steady_clock::now();
     std::vector<size_t> up(S + 1, 0);
     for (int z = 0; z < S; z++) up[z + 1] = up[z] + pl[z].up_bytes;
-    std::vector<char> stage(up[S] + 64);
+    std::vector<char> stage(up[S] + 64);                       // (allocated and zero-filled outside the two timed spans)
     char *fake = (char *)(uintptr_t)0x100000000ull;
-    parallel([&](int z) { if (!pl[z].err) ba_emit(pl[z], fake, fake, fake, stage.data() + up[z]); });
+    const auto t1b = std::chrono::steady_clock::now();
+    if (threads < 0) { for (int z = 0; z < S; z++) if (!pl[z].err) ba_emit(pl[z], fake, fake, fake, stage.data() + up[z]); }
+    else parallel([&](int z) { if (!pl[z].err) ba_emit(pl[z], fake, fake, fake, stage.data() + up[z]); });
     const auto t2 = std::chrono::steady_clock::now();
     out_us[0] = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() * 1e-3;
-    out_us[1] = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count() * 1e-3;
+    out_us[1] = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1b).count() * 1e-3;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+    for (int z = 0; z < S; z++) if (!pl[z].err) { mix(stage.data() + up[z], pl[z].up_bytes); mix(pl[z].ba->perm.data(), pl[z].ba->perm.size() * sizeof(int)); }
+    out_us[2] = (double)(h >> 12);
     int bad = 0;
     for (int z = 0; z < S; z++) bad += pl[z].err != 0;
     return bad;

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <thread>
 #include <functional>
+#include <memory>
 #include <condition_variable>
 #include <mutex>
 #include <cmath>

@@ -97,7 +97,36 @@ int ba_plan(BAPlan &pl)
     std::vector<int> &cnt = pl.cnt, &pfirst = pl.pfirst, plast(M), pany(M);
     cnt.assign(M, 0); pfirst.assign(M, 0);
     int hb = 0, bad_obs = -1, nfo = 0;
+    const int T = pl.nchunk = pl.chunks();
     auto spans = [&]() {                                     // (the first pass also checks the ids: one walk over the observations, not two)
+        if (T > 1) {
+            // one large window: chunk t of the observations counts into its own arrays (the per-chunk counts are kept: fill_obs places the
+            // observations of a chunk behind those of the chunks before it), merged by ranges of points
+            const size_t Ms = (size_t)M;
+            pl.ccnt.reset(new int[T * Ms]);
+            std::unique_ptr<int[]> cf(new int[T * Ms]), cl(new int[T * Ms]), ca(new int[T * Ms]);
+            std::vector<int> cbad(T, -1), cnfo(T, 0);
+            ba_parallel_for(T, [&](int t) {
+                int *c = pl.ccnt.get() + t * Ms, *f = cf.get() + t * Ms, *l = cl.get() + t * Ms, *a = ca.get() + t * Ms, nf = 0;
+                std::fill(c, c + M, 0); std::fill(f, f + M, P); std::fill(l, l + M, -1); std::fill(a, a + M, P);
+                for (int i = (int)((long long)O * t / T), i1 = (int)((long long)O * (t + 1) / T); i < i1; i++) {
+                    if (pose_ids[i] < 1 || pose_ids[i] > P || point_ids[i] < 1 || point_ids[i] > M) { cbad[t] = i; break; }
+                    const int j = (int)point_ids[i] - 1, p = pl.lab(pose_ids[i]);
+                    c[j]++; a[j] = std::min(a[j], p);
+                    if (!theta_const[p]) { f[j] = std::min(f[j], p); l[j] = std::max(l[j], p); nf++; }
+                }
+                cnfo[t] = nf;
+            });
+            for (int t = 0; t < T; t++) if (cbad[t] >= 0) { bad_obs = cbad[t]; return; }
+            nfo = 0; for (int t = 0; t < T; t++) nfo += cnfo[t];
+            ba_parallel_for(T, [&](int c) {
+                for (int j = (int)((long long)M * c / T), j1 = (int)((long long)M * (c + 1) / T); j < j1; j++) {
+                    int n = 0, f = P, l = -1, a = P;
+                    for (int t = 0; t < T; t++) { n += pl.ccnt[t * Ms + j]; f = std::min(f, cf[t * Ms + j]); l = std::max(l, cl[t * Ms + j]); a = std::min(a, ca[t * Ms + j]); }
+                    cnt[j] = n; pfirst[j] = f; plast[j] = l; pany[j] = a;
+                }
+            });
+        } else {
         std::fill(cnt.begin(), cnt.end(), 0); std::fill(pfirst.begin(), pfirst.end(), P); std::fill(plast.begin(), plast.end(), -1); std::fill(pany.begin(), pany.end(), P);
         nfo = 0;
         for (int i = 0; i < O; i++) {
@@ -105,6 +134,7 @@ int ba_plan(BAPlan &pl)
             const int j = (int)point_ids[i] - 1, p = pl.lab(pose_ids[i]);
             cnt[j]++; pany[j] = std::min(pany[j], p);
             if (!theta_const[p]) { pfirst[j] = std::min(pfirst[j], p); plast[j] = std::max(plast[j], p); nfo++; }
+        }
         }
         hb = 0;
         for (int j = 0; j < M; j++) {

@@ -681,6 +681,7 @@ static int ba_setup(slam_ctx *ctx, double fx, double fy, double cx, double cy, i
     BAPlan pl;
     pl.fx = fx; pl.fy = fy; pl.cx = cx; pl.cy = cy; pl.P = P; pl.M = M; pl.O = O; pl.theta = theta; pl.theta_const_in = theta_const_in;
     pl.pixels_yx = pixels_yx; pl.pose_ids = pose_ids; pl.point_ids = point_ids; pl.may_reorder = may_reorder;
+    pl.nthreads = ba_pool_threads();                          // a large window splits its passes over the observations (BAPlan::chunks)
     if (ba_plan(pl)) return slam_fail(ctx, pl.err, "%s", pl.msg);
     slam_ba *ba = pl.ba;
     ba->device = ctx->device;

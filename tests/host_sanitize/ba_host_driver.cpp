@@ -4,6 +4,7 @@
 // windows incl. degenerate ones; plus slam_ba_plan_order on loop-closure windows.  Built twice by tests/host_sanitize/Makefile:
 // -fsanitize=address,undefined and -fsanitize=thread.  Exit status 0 = the sanitizers had nothing to say.  (reference: src/estimator.jl:143-266
 // fills these arrays; the planner itself has no counterpart there.)
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
@@ -48,14 +49,48 @@ static Windows make(int S, unsigned seed, bool duplicate_obs)
     return w;
 }
 
+// ONE large window (160 k observations in random order, a few constant poses, optionally one map point seen twice by a pose / one observation
+// with a pose id out of range): slam_local_ba splits its passes over the observations into tasks of the pool (BAPlan::chunks)
+static Windows big(unsigned seed, int flaw)
+{
+    std::mt19937 g(seed);
+    auto ri = [&](int a, int b) { return a + (int)(g() % (unsigned)(b - a + 1)); };
+    const int P = 30, M = 20000, span = 8;
+    Windows w;
+    w.cams.insert(w.cams.end(), {700.0, 700.0, 600.0, 180.0});
+    for (int p = 0; p < P; p++) { for (int k = 0; k < 6; k++) w.theta.push_back(0.01 * ri(-9, 9)); w.tc.push_back(p < 3); }
+    std::vector<int64_t> pi, li; std::vector<double> px;
+    for (int m = 0; m < M; m++) {
+        for (int k = 0; k < 3; k++) w.theta.push_back(1.0 + 0.1 * ri(0, 50));
+        const int first = ri(0, P - span);
+        for (int q = 0; q < span; q++) { pi.push_back(first + q + 1); li.push_back(m + 1); px.push_back(10.0 + ri(0, 300)); px.push_back(10.0 + ri(0, 1000)); }
+    }
+    if (flaw == 1) { pi.push_back(pi[8 * 15000 + 5]); li.push_back(15001); px.push_back(1.0); px.push_back(1.0); }
+    if (flaw == 2) pi[8 * 12345] = P + 7;
+    std::vector<int> ord(pi.size());
+    for (size_t i = 0; i < ord.size(); i++) ord[i] = (int)i;
+    std::shuffle(ord.begin(), ord.end(), g);
+    for (int i : ord) { w.pi.push_back(pi[i]); w.li.push_back(li[i]); w.px.push_back(px[2 * i]); w.px.push_back(px[2 * i + 1]); }
+    w.Pn.push_back(P); w.Mn.push_back(M); w.On.push_back((int)pi.size());
+    return w;
+}
+
 int main()
 {
     std::atomic<int> bad{0};
+    // the split passes give the serial passes' staging and observation order, byte for byte, and the same verdict on flawed windows
+    for (int flaw = 0; flaw < 3; flaw++) {
+        Windows w = big(77u + (unsigned)flaw, flaw);
+        double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+        const int fa = slam_debug_ba_host_time(1, w.cams.data(), w.Pn.data(), w.Mn.data(), w.On.data(), w.theta.data(), w.tc.data(), w.px.data(), w.pi.data(), w.li.data(), -1, a);
+        const int fb = slam_debug_ba_host_time(1, w.cams.data(), w.Pn.data(), w.Mn.data(), w.On.data(), w.theta.data(), w.tc.data(), w.px.data(), w.pi.data(), w.li.data(), -4, b);
+        if (fa != (flaw ? 1 : 0) || fb != fa || a[2] != b[2]) { fprintf(stderr, "large window, flaw %d: serial %d (hash %.0f) vs split %d (hash %.0f)\n", flaw, fa, a[2], fb, b[2]); bad++; }
+    }
     auto caller = [&](unsigned seed) {
         for (int round = 0; round < 12; round++) {
             const bool dup = round == 5;
             Windows w = make(24, seed * 100 + (unsigned)round, dup);
-            double us[2] = {0, 0};
+            double us[3] = {0, 0, 0};
             const int failed = slam_debug_ba_host_time(24, w.cams.data(), w.Pn.data(), w.Mn.data(), w.On.data(), w.theta.data(), w.tc.data(), w.px.data(), w.pi.data(), w.li.data(),
                                                        round % 3 == 2 ? 3 : 0, us);
             if (failed != (dup ? 1 : 0)) { fprintf(stderr, "caller %u round %d: %d windows failed their set-up (expected %d)\n", seed, round, failed, dup ? 1 : 0); bad++; }
