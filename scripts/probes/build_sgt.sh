@@ -1,7 +1,7 @@
 #!/bin/bash
 # tracing build of the BA sources (per-phase clocks of the point-group builds printed from the device; `make -C slam.jl_amd/csrc trace` builds all tracing macros): slam.jl_amd/libslamhip_sgt.so, used via SLAMHIP_LIB
 set -e
-cd "$(dirname "$0")/../../../slam.jl_amd/csrc"
+cd "$(dirname "$0")/../../slam.jl_amd/csrc"
 make >/dev/null
 mkdir -p /tmp/bas
 for f in ba_single ba_batch; do hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -mllvm -amdgpu-mfma-vgpr-form=1 -DSG_TRACE -c $f.hip -o /tmp/bas/$f.sgt.o; done

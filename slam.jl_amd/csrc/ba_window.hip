@@ -63,7 +63,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
     const BADev &d = w.d;
     extern __shared__ __attribute__((aligned(16))) double bw_sm[];
     const int tid = threadIdx.x;
-    const int P = d.P, M = d.M, O = d.O, p0 = w.B.p0, F = w.B.nb, n = 6 * F, nwin = F * (F + 1) / 2, NF = d.pfs[M];
+    const int P = d.P, M = d.M, O = d.O, p0 = w.B.p0, F = w.B.nb, n = 6 * F, nwin = F * (F + 1) / 2;
     double *s_sc = bw_sm;                              // [P][6] sin / cos of the committed poses' angles
     double *s_sct = s_sc + 6 * P;                      // [P][6] of the trial poses
     double *s_tr = s_sct + 6 * P;                      // [P][3] committed translations
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
             __syncthreads();
 #ifdef BW_TRACE
             if (tid == 0 && (blockIdx.x == 5 || blockIdx.x == 13) && pass == 0 && it == 3) { bw_clk[7] = clock64();
-                printf("k_ba_window (M %d, O %d, F %d, %d free-pose observations): sincos %lld | A %lld | B chunks %lld | fold %lld | solve %lld | C %lld | reduce + decide %lld cycles\n", M, O, F, NF,
+                printf("k_ba_window (M %d, O %d, F %d, %d free-pose observations): sincos %lld | A %lld | B chunks %lld | fold %lld | solve %lld | C %lld | reduce + decide %lld cycles\n", M, O, F, d.pfs[M],
                        bw_clk[1] - bw_clk[0], bw_clk[2] - bw_clk[1], bw_clk[3] - bw_clk[2], bw_clk[4] - bw_clk[3], bw_clk[5] - bw_clk[4], bw_clk[6] - bw_clk[5], bw_clk[7] - bw_clk[6]); }
 #endif
         }
