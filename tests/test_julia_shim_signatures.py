@@ -8,6 +8,7 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "slamhip.h")
 SHIMS = [os.path.join(ROOT, "slam.jl_amd", "julia", f) for f in ("SLAMHip.jl", "SLAMHipStreams.jl")]
+DOCS = [os.path.join(ROOT, "INTEGRATION.md")]                        # the binding snippets a maintainer would paste
 
 
 def split_top(s, sep=","):
@@ -132,10 +133,12 @@ def jl_class(t):
     raise AssertionError(f"Julia ccall type not understood: {t!r}")
 
 
-def shim_ccalls():
+def shim_ccalls(paths=None):
     calls = []
-    for path in SHIMS:
+    for path in (paths or SHIMS):
         src = open(path).read()
+        if path.endswith(".md"):                                      # only the fenced code blocks
+            src = "\n".join(b if k % 2 else "\n" * b.count("\n") for k, b in enumerate(src.split("```")))
         src = "\n".join(line.split("#", 1)[0] if '"' not in line else line for line in src.split("\n"))     # comments (lines with strings kept whole)
         for m in re.finditer(r"\bccall\(", src):
             end = matching(src, m.end() - 1)
@@ -185,6 +188,28 @@ def test_every_ccall_matches_its_prototype():
         if len(types) != len(cparams):
             bad.append(f"{where}: {len(types)} argument types, the header declares {len(cparams)}"); continue
         if len(values) != len(types):
+            bad.append(f"{where}: {len(values)} values passed for {len(types)} argument types")
+        for k, (t, cp) in enumerate(zip(types, cparams)):
+            if not compatible(cp, jl_class(t)):
+                bad.append(f"{where}: argument {k + 1} is {t}, the header declares {cp}")
+    assert not bad, "\n".join(bad)
+
+
+def test_integration_md_snippets_match_the_header():
+    protos = header_prototypes()
+    calls = shim_ccalls(DOCS)
+    assert len(calls) >= 10, len(calls)
+    bad = []
+    for fname, line, sym, ret, types, values in calls:
+        where = f"{fname}:{line} {sym}"
+        if sym not in protos:
+            bad.append(f"{where}: not declared in include/slamhip.h"); continue
+        cret, cparams = protos[sym]
+        if not compatible(cret, jl_class(ret)):
+            bad.append(f"{where}: return type {ret} vs header {cret}")
+        if len(types) != len(cparams):
+            bad.append(f"{where}: {len(types)} argument types, the header declares {len(cparams)}"); continue
+        if values and values != ["..."] and len(values) != len(types):
             bad.append(f"{where}: {len(values)} values passed for {len(types)} argument types")
         for k, (t, cp) in enumerate(zip(types, cparams)):
             if not compatible(cp, jl_class(t)):
