@@ -335,13 +335,17 @@ __device__ __forceinline__ double sg_fold(double v, int NS)
 }
 
 #ifdef SG_TRACE
-#define SG_CLK_DECL long long sg_clk[12]; const long long sg_t0 = clock64()
+#define SG_CLK_DECL long long sg_clk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const long long sg_t0 = clock64()
 #define SG_CLK(k) sg_clk[k] = clock64() - sg_t0
+#define SG_NOW() clock64()
+#define SG_ADD(k, t) sg_clk[k] += clock64() - (t)
 #define SG_DUMP() do { if (threadIdx.x == 0 && blockIdx.x == (gridDim.y > 1 ? 10 : 100) && blockIdx.y == (gridDim.y > 1 ? 5 : 0) && d.st->iters == 3) printf("schur group: npts %d nobs %d | init %lld ph0 %lld bar %lld ph1 %lld ph2 %lld ph3 %lld bar %lld fold %lld tail %lld cycles\n", npts, nobs, sg_clk[0], sg_clk[1] - sg_clk[0], sg_clk[2] - sg_clk[1], sg_clk[3] - sg_clk[2], sg_clk[4] - sg_clk[3], sg_clk[8] - sg_clk[4], sg_clk[9] - sg_clk[8], sg_clk[5] - sg_clk[9], sg_clk[6] - sg_clk[5]); } while (0)
-#define SGM_DUMP() do { if (threadIdx.x == 0 && blockIdx.x == 10 && blockIdx.y == 5 && d.st->iters == 3) printf("schur group (mfma): npts %d nobs %d | init %lld ph0 %lld bar %lld ph1 %lld ph2a %lld ph2x %lld ph2b %lld mfma+out %lld cycles\n", npts, nobs, sg_clk[0], sg_clk[1] - sg_clk[0], sg_clk[2] - sg_clk[1], sg_clk[3] - sg_clk[2], sg_clk[4] - sg_clk[3], sg_clk[5] - sg_clk[4], sg_clk[6] - sg_clk[5], sg_clk[7] - sg_clk[6]); } while (0)
+#define SGM_DUMP() do { if (threadIdx.x == 0 && blockIdx.x == 10 && blockIdx.y == 5 && d.st->iters == 3) printf("schur group (mfma): npts %d nobs %d | init %lld ph0 %lld bar %lld ph1 %lld ph2a %lld ph2x %lld ph2b %lld mfma+out %lld (products %lld, output %lld) cycles\n", npts, nobs, sg_clk[0], sg_clk[1] - sg_clk[0], sg_clk[2] - sg_clk[1], sg_clk[3] - sg_clk[2], sg_clk[4] - sg_clk[3], sg_clk[5] - sg_clk[4], sg_clk[6] - sg_clk[5], sg_clk[7] - sg_clk[6], sg_clk[8], sg_clk[9]); } while (0)
 #else
 #define SG_CLK_DECL
 #define SG_CLK(k)
+#define SG_NOW() 0
+#define SG_ADD(k, t) (void)(t)
 #define SG_DUMP()
 #define SGM_DUMP()
 #endif
@@ -585,7 +589,7 @@ __host__ __device__ __forceinline__ size_t sgm_r_doubles(int whb, int ob, int sb
 }
 static size_t sgm_lds_bytes(int whb, int P, int ob, int sb, int hp)
 {
-    return (sgm_r_doubles(whb, ob, sb, hp) + (size_t)sb * 16 + 8 + (size_t)(whb + 1) * 36 + (size_t)P * 6) * 8 + (size_t)sb * (whb + 1) * 2 + 16;
+    return (sgm_r_doubles(whb, ob, sb, hp) + (size_t)sb * 16 + 8 + (size_t)(whb + 1) * 36 + (size_t)P * 6 + (size_t)sgm_rp(whb)) * 8 + (size_t)sb * (whb + 1) * 2 + 16;
 }
 template <int TT>
 __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignore_outliers)
@@ -605,7 +609,8 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
     double *s_pt = s_R + sgm_r_doubles(d.whb, OBc, SBc, HPc);   // [SBc][16]  V^-1 (6), bl (3), L (6: l00 l10 l20 l11 l21 l22)
     double *s_dg = s_pt + SBc * 16 + 8;                          // [hbw][36]  Jp'Jp per window slot
     double *s_sc = s_dg + hbw * 36;                              // [P][6]     sin / cos of every pose's angles
-    short *s_slot = (short *)(s_sc + 6 * d.P);                   // [SBc][hbw] record of point x in window slot y, or -1
+    unsigned *s_tr = (unsigned *)(s_sc + 6 * d.P), *s_tc = s_tr + RP;   // [RP] each: where row / column i of Y Y' goes in the group's output (phase 3)
+    short *s_slot = (short *)(s_tr + 2 * RP);                    // [SBc][hbw] record of point x in window slot y, or -1
     // the observation's scalars are requested BEFORE the set-up work below (their latency hides behind the sin / cos of the poses)
     int i = 0, p = 0, j = 0, pl = 0, hpi = -1; bool active = false, hp = false; double py = 0.0, px = 0.0;
     if (tid < nobs) {
@@ -613,8 +618,19 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
         active = !(ignore_outliers && d.outl[i]); hp = active && !d.pconst[p];
         py = d.pix[i]; px = d.pix[O + i];
     }
+    // ... and so is what phase 1's lanes (one per map point) read from global memory: behind the barriers below these loads were a memory round trip of their own
+    int p1_jj = 0, p1_t0 = 0, p1_t1 = 0;
+    if (tid < npts) { p1_jj = d.pt_id[k0 + tid]; p1_t0 = d.pt_start[k0 + tid] - o0; p1_t1 = d.pt_start[k0 + tid + 1] - o0; }
+    const double inv_delta = 1.0 / d.st->delta;
     for (int a = tid; a < 6 * d.P; a += TT) s_sc[a] = pb.sc[a];      // (formed once per window: k_pass_start_b / k_trial_poses_b)
     for (int x = tid; x < npts * hbw; x += TT) s_slot[x] = -1;
+    // element (row, col) of Y Y' is entry (rr, cc) of window block (a, b) = (row / 6, col / 6), stored at (a hbw - a (a - 1) / 2 + b - a) 36 + rr 6 + cc:
+    // slot << 26 | the row's / the column's share of that offset, once per group instead of once per accumulator element
+    for (int x = tid; x < RP; x += TT) {
+        const int a = x / 6, rr = x - 6 * a;
+        s_tr[x] = a < hbw ? ((unsigned)a << 26) | (unsigned)((a * hbw - a * (a - 1) / 2 - a) * 36 + rr * 6) : 0xfc000000u;      // (a row past the window: slot 63 is above every column's)
+        s_tc[x] = a < hbw ? ((unsigned)a << 26) | (unsigned)(a * 36 + rr) : 0u;                                                  // (a column past the window: slot 0 with the offset bits 0 -- told apart from block 0's column 0 by x)
+    }
     lds_sync();
     SG_CLK(0);
     // ---- phase 0: residual + Jacobians of the observation, Jl'Jl / Jl'f -> R
@@ -650,10 +666,8 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
     SG_CLK(2);
     // ---- phase 1: thread = map point: V = sum + D, V^-1, its Cholesky factor, bl
     if (tid < npts) {
-        const int k = k0 + tid, jj = d.pt_id[k];
-        const double inv_delta = 1.0 / d.st->delta;
+        const int jj = p1_jj, t0 = p1_t0, t1 = p1_t1;
         double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const int t0 = d.pt_start[k] - o0, t1 = d.pt_start[k + 1] - o0;
         for (int t = t0; t < t1; t++) {
 #pragma unroll
             for (int c = 0; c < 9; c++) V[c] += s_R[t * 9 + c];
@@ -709,9 +723,9 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
     //      the XQ lanes of a task sit next to each other and are folded by DPP
     double *out = d.wpart + (size_t)blockIdx.x * d.wstride;
     {
-        const int TPW = (nrow + NW - 1) / NW, XQ = TPW <= 16 ? 4 : TPW <= 32 ? 2 : 1;
-        const int task = wv * TPW + lane / XQ, xq = lane - (lane / XQ) * XQ;
-        const bool xl = lane / XQ < TPW && task < nrow;
+        const int TPW = (nrow + NW - 1) / NW, xs = TPW <= 16 ? 2 : TPW <= 32 ? 1 : 0, XQ = 1 << xs;      // (a shift, not a run-time division)
+        const int task = wv * TPW + (lane >> xs), xq = lane & (XQ - 1);
+        const bool xl = (lane >> xs) < TPW && task < nrow;
         const int a2 = xl ? task / 6 : 0, rr = task - 6 * (task / 6);
         double ex[7];
 #pragma unroll
@@ -721,12 +735,12 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
                 const int ta = s_slot[x * hbw + a2];
                 if (ta < 0) continue;
                 double J[12];
-                ld_rec<12>(s_R + ta * 18, J);
-                const double j0 = rr == 0 ? J[0] : rr == 1 ? J[1] : rr == 2 ? J[2] : rr == 3 ? J[3] : rr == 4 ? J[4] : J[5];
-                const double j1 = rr == 0 ? J[6] : rr == 1 ? J[7] : rr == 2 ? J[8] : rr == 3 ? J[9] : rr == 4 ? J[10] : J[11];
+                const double *rec = s_R + ta * 18;
+                ld_rec<12>(rec, J);
+                const double j0 = rec[rr], j1 = rec[6 + rr];      // (two more LDS reads instead of two five-deep select chains over J)
 #pragma unroll
                 for (int c = 0; c < 6; c++) ex[c] = fma(j1, J[6 + c], fma(j0, J[c], ex[c]));
-                ex[6] += s_R[ta * 18 + 12 + rr];
+                ex[6] += rec[12 + rr];
             }
 #pragma unroll
         for (int k = 0; k < 7; k++) ex[k] = sg_fold(ex[k], XQ);
@@ -761,8 +775,11 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
                 for (int r = 0; r < 6; r++) col[2 * r] = 0.0;
             }
         }
-    for (int c = tid; c < (RP - nrow) * K4; c += TT) { const int k = c / (RP - nrow), row = nrow + (c - k * (RP - nrow)); s_R[((size_t)(k >> 1) * RP + row) * 2 + (k & 1)] = 0.0; }
-    for (int c = tid; c < (K4 - K3) * nrow; c += TT) { const int k = K3 + c / nrow, row = c - (c / nrow) * nrow; s_R[((size_t)(k >> 1) * RP + row) * 2 + (k & 1)] = 0.0; }
+    // the padding rows nrow .. RP (fewer than 16: a 16-lane group per column) and the padding columns K3 .. K4 (fewer than 4), without a run-time division
+    if ((tid & 15) < RP - nrow)
+        for (int k = tid >> 4; k < K4; k += TT / 16) s_R[((size_t)(k >> 1) * RP + nrow + (tid & 15)) * 2 + (k & 1)] = 0.0;
+    for (int k = K3; k < K4; k++)
+        for (int row = tid; row < nrow; row += TT) s_R[((size_t)(k >> 1) * RP + row) * 2 + (k & 1)] = 0.0;
     lds_sync();
     SG_CLK(6);
     // ---- phase 3: -(Y Y') on the matrix cores: the upper-triangular 16 x 16 tiles dealt to the waves, three tiles (three independent
@@ -770,18 +787,24 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
     {
         const int NT = RP / 16, ntiles = NT * (NT + 1) / 2, q = lane >> 4, c16 = lane & 15, nks = K4 >> 2;
         const size_t lane_off = ((size_t)(q >> 1) * RP + c16) * 2 + (q & 1), kstep = (size_t)4 * RP;
+        __attribute__((address_space(1))) double *outg = (__attribute__((address_space(1))) double *)out;      // (a pointer read from the window table: told to be global memory, not flat)
         auto emit = [&](int I, int J, const sgm_d4 &acc) {
-            const int col = J * 16 + c16, b = col / 6, cc = col - 6 * b;
+            const int col = J * 16 + c16;
+            const unsigned tc = s_tc[col];
+            const int b = (int)(tc >> 26), oc = (int)(tc & 0x3ffffffu);
+            if (col >= nrow) return;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int row = I * 16 + 4 * r + q, a = row / 6, rr = row - 6 * a;
-                if (a >= hbw || b >= hbw || a > b) continue;
-                const int w = a * hbw - a * (a - 1) / 2 + (b - a);
-                if (a < b) out[w * 36 + rr * 6 + cc] = -acc[r];
+                const unsigned tr = s_tr[I * 16 + 4 * r + q];
+                const int a = (int)(tr >> 26);
+                if (a > b) continue;                                 // (below the block diagonal, or a row past the window)
+                const int o = (int)(tr & 0x3ffffffu) + oc;           // (w 36 + rr 6) + (b 36 + cc) - ... see the table: the row's share carries -a 36
+                if (a < b) outg[o] = -acc[r];
                 else {
-                    const double v = s_dg[a * 36 + rr * 6 + cc] - acc[r];
-                    out[w * 36 + rr * 6 + cc] = v;
-                    if (I < J) out[w * 36 + cc * 6 + rr] = v;      // a diagonal block cut by a tile boundary: its mirror half lies in a tile below the diagonal, which nobody computes
+                    const int rr6 = (int)(tr & 0x3ffffffu) - (a * hbw - a * (a - 1) / 2 - a) * 36, cc = oc - b * 36;
+                    const double v = s_dg[a * 36 + rr6 + cc] - acc[r];
+                    outg[o] = v;
+                    if (I < J) outg[o - rr6 - cc + cc * 6 + rr6 / 6] = v;      // a diagonal block cut by a tile boundary: its mirror half lies in a tile below the diagonal, which nobody computes
                 }
             }
         };
@@ -797,16 +820,36 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
             const double *pa1 = s_R + lane_off + (size_t)I[1] * 32, *pb1 = s_R + lane_off + (size_t)J[1] * 32;
             const double *pa2 = s_R + lane_off + (size_t)I[2] * 32, *pb2 = s_R + lane_off + (size_t)J[2] * 32;
             sgm_d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0, c2 = c0;
-            for (int ks = 0; ks < nks; ks++) {
-                const size_t o = (size_t)ks * kstep;
-                const double a0 = pa0[o], b0 = pb0[o], a1 = pa1[o], b1 = pb1[o], a2m = pa2[o], b2 = pb2[o];
-                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c1, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2m, b2, c2, 0, 0, 0);
-            }
+            const long long sg_tm = SG_NOW();
+            // (an instruction occupies the matrix pipe for 64 cycles whether or not it depends on the one before: a wave's last round of tiles -- one or two
+            //  of them -- must not run dummy chains beside them)
+            if (ok[2])
+                for (int ks = 0; ks < nks; ks++) {
+                    const size_t o = (size_t)ks * kstep;
+                    const double a0 = pa0[o], b0 = pb0[o], a1 = pa1[o], b1 = pb1[o], a2m = pa2[o], b2 = pb2[o];
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c1, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2m, b2, c2, 0, 0, 0);
+                }
+            else if (ok[1])
+                for (int ks = 0; ks < nks; ks++) {
+                    const size_t o = (size_t)ks * kstep;
+                    const double a0 = pa0[o], b0 = pb0[o], a1 = pa1[o], b1 = pb1[o];
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c1, 0, 0, 0);
+                }
+            else
+                for (int ks = 0; ks < nks; ks++) {
+                    const size_t o = (size_t)ks * kstep;
+                    const double a0 = pa0[o], b0 = pb0[o];
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
+                }
+            SG_ADD(8, sg_tm);
+            const long long sg_te = SG_NOW();
             emit(I[0], J[0], c0);
             if (ok[1]) emit(I[1], J[1], c1);
             if (ok[2]) emit(I[2], J[2], c2);
+            SG_ADD(9, sg_te);
         }
     }
     SG_CLK(7);
@@ -1775,10 +1818,29 @@ __device__ __forceinline__ void update_groups_body(const BADev &d, int ignore_ou
     const int tid = threadIdx.x, M = d.M, O = d.O, n = d.n;
     const int4 G = d.grp[blockIdx.x];
     const int k0 = G.x, o0 = G.y, npts = G.z >> 16, nobs = G.w;
+    // everything a lane reads from global memory at an address it already knows is requested HERE, in front of the barriers: behind them the observation's
+    // scalars and the point's index / range were memory round trips of their own (~1 us each on a loaded device), three of them per group
+    const int i = o0 + tid;
+    int p = 0, pl = 0, jo = 0; bool active = false; double py = 0.0, px = 0.0;
+    if (tid < nobs) {
+        p = d.opose[i]; pl = d.opk[i] - k0; jo = d.opoint[i];
+        active = !(ignore_outliers && d.outl[i]);
+        py = d.pix[i]; px = d.pix[O + i];
+    }
+    int p2_j = 0, p2_t0 = 0, p2_t1 = 0;
+    if (tid < npts) { p2_j = d.pt_id[k0 + tid]; p2_t0 = d.pt_start[k0 + tid] - o0; p2_t1 = d.pt_start[k0 + tid + 1] - o0; }
     for (int a = tid; a < n; a += TT) s_dp[a] = d.dp[a];
     if (sct_ready) { for (int a = tid; a < n; a += TT) s_sct[a] = pb.sc_t[a]; }
     if (RECOMP) { for (int a = tid; a < n; a += TT) s_sc[a] = pb.sc[a]; }
     lds_sync();
+    // (the point's own records -- their address needs its index -- travel while the observations are evaluated)
+    double p2_bl[3] = {0.0, 0.0, 0.0}, p2_Vi[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, p2_X[3] = {0.0, 0.0, 0.0};
+    if (tid < npts) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { p2_bl[k] = d.bl[(size_t)k * M + p2_j]; p2_X[k] = pb.pts[3 * p2_j + k]; }
+#pragma unroll
+        for (int k = 0; k < 6; k++) p2_Vi[k] = d.Vinv[(size_t)k * M + p2_j];
+    }
     if (!sct_ready)
         for (int q = tid; q < d.P; q += TT) {
             const double tp[3] = {pb.pose[6 * q] - s_dp[6 * q], pb.pose[6 * q + 1] - s_dp[6 * q + 1], pb.pose[6 * q + 2] - s_dp[6 * q + 2]};
@@ -1787,27 +1849,22 @@ __device__ __forceinline__ void update_groups_body(const BADev &d, int ignore_ou
     double mx = 0.0;
     if (blockIdx.x == 0)
         for (int a = tid; a < n; a += TT) { const double v = s_dp[a]; pb.pose_t[a] = pb.pose[a] - v; mx = fmax(mx, fabs(v)); }
-    const int i = o0 + tid;
-    int p = 0, pl = 0;
     double jp[12], jl[6], ff[2] = {0.0, 0.0}, a = 0.0, b = 0.0;
-    bool active = false;
     if (tid < nobs) {
-        p = d.opose[i]; pl = d.opk[i] - k0;
-        active = !(ignore_outliers && d.outl[i]);
         if (RECOMP) {
 #pragma unroll
             for (int k = 0; k < 12; k++) jp[k] = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; k++) jl[k] = 0.0;
             if (active) {
-                const int j = d.opoint[i];
+                const int j = jo;
                 const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
                 double sc[6], tr[3];
 #pragma unroll
                 for (int k = 0; k < 6; k++) sc[k] = s_sc[6 * p + k];
 #pragma unroll
                 for (int k = 0; k < 3; k++) tr[k] = pb.pose[6 * p + 3 + k];
-                obs_eval_sc(sc, tr, X, d.pix[i], d.pix[O + i], d.cam, ff, jp, jl, nullptr);
+                obs_eval_sc(sc, tr, X, py, px, d.cam, ff, jp, jl, nullptr);
                 if (d.pconst[p]) {
 #pragma unroll
                     for (int k = 0; k < 12; k++) jp[k] = 0.0;
@@ -1828,20 +1885,18 @@ __device__ __forceinline__ void update_groups_body(const BADev &d, int ignore_ou
     }
     lds_sync();
     if (tid < npts) {
-        const int kk = k0 + tid, j = d.pt_id[kk];
-        double bl[3] = {d.bl[j], d.bl[(size_t)M + j], d.bl[(size_t)2 * M + j]};
-        const int t0 = d.pt_start[kk] - o0, t1 = d.pt_start[kk + 1] - o0;
+        const int j = p2_j;
+        double bl[3] = {p2_bl[0], p2_bl[1], p2_bl[2]};
+        const int t0 = p2_t0, t1 = p2_t1;
         for (int t = t0; t < t1; t++) {
 #pragma unroll
             for (int k = 0; k < 3; k++) bl[k] -= s_u[t * 3 + k];
         }
-        double Vi[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) Vi[k] = d.Vinv[(size_t)k * M + j];
+        const double *Vi = p2_Vi;
         const double l0 = Vi[0] * bl[0] + Vi[1] * bl[1] + Vi[2] * bl[2];
         const double l1 = Vi[1] * bl[0] + Vi[3] * bl[1] + Vi[4] * bl[2];
         const double l2 = Vi[2] * bl[0] + Vi[4] * bl[1] + Vi[5] * bl[2];
-        const double X0 = pb.pts[3 * j] - l0, X1 = pb.pts[3 * j + 1] - l1, X2 = pb.pts[3 * j + 2] - l2;
+        const double X0 = p2_X[0] - l0, X1 = p2_X[1] - l1, X2 = p2_X[2] - l2;
         d.dl[3 * j] = l0; d.dl[3 * j + 1] = l1; d.dl[3 * j + 2] = l2;
         pb.pts_t[3 * j] = X0; pb.pts_t[3 * j + 1] = X1; pb.pts_t[3 * j + 2] = X2;
         s_dl[tid * 6] = l0; s_dl[tid * 6 + 1] = l1; s_dl[tid * 6 + 2] = l2;
@@ -1860,7 +1915,7 @@ __device__ __forceinline__ void update_groups_body(const BADev &d, int ignore_ou
             for (int k = 0; k < 6; k++) sc[k] = s_sct[6 * p + k];
 #pragma unroll
             for (int k = 0; k < 3; k++) tr[k] = pb.pose[6 * p + 3 + k] - s_dp[6 * p + 3 + k];
-            obs_eval_sc(sc, tr, X, d.pix[i], d.pix[O + i], d.cam, r, nullptr, nullptr, nullptr);
+            obs_eval_sc(sc, tr, X, py, px, d.cam, r, nullptr, nullptr, nullptr);
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) { a += jl[k] * dl[k]; b += jl[3 + k] * dl[k]; }
