@@ -34,44 +34,68 @@ struct LMState {
 };
 
 
-struct BADev {
+// BADevT<PlainP> = BADev: what the host fills and every kernel receives.  BADevT<GlobP> = BADevG: the same bytes with every pointer typed as GLOBAL memory -- a
+// kernel that reads the structure out of the window table (batches) sees generic pointers otherwise, and every access through one is a FLAT instruction, which
+// also counts against the LDS counter (an LDS wait then waits for the outstanding global loads).
+template <class T> struct PlainP { typedef T *type; };
+template <class T> struct GlobP { typedef __attribute__((address_space(1))) T *type; };
+template <template <class> class Q> struct BADevT {
+#define BP(T) typename Q<T>::type
     Cam cam;
     int P, M, O, n;              // n = 6P
-    double *pose, *pose_t, *pts, *pts_t;
-    const uint8_t *pconst;
-    const double *pix;           // SoA: py[O], px[O]
-    const int *opose, *opoint, *pt_start;
-    uint8_t *outl, *hasp;
-    double *f, *ft;              // AoS O x 2
-    double *Jp, *Jl;             // AoS O x 12, O x 6 (a lane reads its observation's block contiguously)
-    double *Vinv, *bl;           // SoA 6 x M, 3 x M
-    double *T, *Wm;              // AoS O x 18 each
-    const int2 *pairs; const int *blk_start; const int2 *blk_pq; int nblk;
+    BP(double) pose, pose_t, pts, pts_t;
+    BP(const uint8_t) pconst;
+    BP(const double) pix;         // SoA: py[O], px[O]
+    BP(const int) opose, opoint, pt_start;
+    BP(uint8_t) outl, hasp;
+    BP(double) f, ft;            // AoS O x 2
+    BP(double) Jp, Jl;           // AoS O x 12, O x 6 (a lane reads its observation's block contiguously)
+    BP(double) Vinv, bl;         // SoA 6 x M, 3 x M
+    BP(double) T, Wm;            // AoS O x 18 each
+    BP(const int2) pairs; BP(const int) blk_start; BP(const int2) blk_pq; int nblk;
     // pt_start / pt_id: observations are sorted by map point, the map points by (first free observing pose, id); opk = the
     // sorted position of an observation's point.  grp / fgrp / wpart: the point groups of k_schur_groups (below).
-    const int *pt_id, *opk;
-    const int4 *grp; const int *fgrp; int ngrp, whb, wstride;
-    const int *fobs;             // the observations of free poses, grouped by map point in sorted order (pfs[M] entries)
-    const int *pfs;              // pfs[k]: observations of free poses of the map points (sorted order) before point k, M + 1 entries (k_ba_window's chunks)
-    const int *ohp; int sg_hp;   // ohp[i]: index of observation i among its group's observations of FREE poses (or -1): the phase 2-3 records (W, Jp, gradient:
+    BP(const int) pt_id, opk;
+    BP(const int4) grp; BP(const int) fgrp; int ngrp, whb, wstride;
+    BP(const int) fobs;           // the observations of free poses, grouped by map point in sorted order (pfs[M] entries)
+    BP(const int) pfs;            // pfs[k]: observations of free poses of the map points (sorted order) before point k, M + 1 entries (k_ba_window's chunks)
+    BP(const int) ohp; int sg_hp;   // ohp[i]: index of observation i among its group's observations of FREE poses (or -1): the phase 2-3 records (W, Jp, gradient:
                                  // 36 doubles) exist for those only -- the reference's window is 80 % observations of constant poses; sg_hp: room for that many
     int sg_ob, sg_sb;            // k_schur_groups' LDS layout: room for sg_ob observations / sg_sb points per group (SG_OB / SG_SB; a batch of small
                                  // windows sizes it to its largest group, so that several workgroups share a compute unit)
-    double *wpart;
-    double *S, *g, *udiag;       // reduce buffer views
-    double *Swork, *dp, *dl;
-    double *sc0, *sc1;           // [P][6] each: sin / cos of the angles of the poses in d.pose / in d.pose_t (batches: formed once per window and iteration by
+    BP(double) wpart;
+    BP(double) S, g, udiag;     // reduce buffer views
+    BP(double) Swork, dp, dl;
+    BP(double) sc0, sc1;         // [P][6] each: sin / cos of the angles of the poses in d.pose / in d.pose_t (batches: formed once per window and iteration by
                                  // k_pass_start_b / k_trial_poses_b and swapped with the parameter buffers; every point group used to form them for itself)
-    double *part;                // reduction partials
-    LMState *st;
+    BP(double) part;              // reduction partials
+    BP(LMState) st;
+#undef BP
 };
+typedef BADevT<PlainP> BADev;
+typedef BADevT<GlobP> BADevG;
+static_assert(sizeof(BADev) == sizeof(BADevG), "BADevG re-types BADev's pointers, nothing else");
 // the committed parameters and the trial ones: d.pose / d.pts hold the committed set while st->cur == 0, d.pose_t / d.pts_t while it is 1
-struct ParamBufs { double *pose, *pts, *pose_t, *pts_t; double *sc, *sc_t; };     // sc / sc_t: sin / cos of the committed / trial poses (batches)
+template <template <class> class Q> struct ParamBufsT { typename Q<double>::type pose, pts, pose_t, pts_t, sc, sc_t; };
+typedef ParamBufsT<PlainP> ParamBufs; typedef ParamBufsT<GlobP> ParamBufsG;     // sc / sc_t: sin / cos of the committed / trial poses (batches)
 __device__ __forceinline__ ParamBufs param_bufs(const BADev &d)
 {
     const bool sw = d.st->cur != 0;
     return ParamBufs{sw ? d.pose_t : d.pose, sw ? d.pts_t : d.pts, sw ? d.pose : d.pose_t, sw ? d.pts : d.pts_t, sw ? d.sc1 : d.sc0, sw ? d.sc0 : d.sc1};
 }
+__device__ __forceinline__ ParamBufsG param_bufs(const BADevG &d)
+{
+    const bool sw = d.st->cur != 0;
+    return ParamBufsG{sw ? d.pose_t : d.pose, sw ? d.pts_t : d.pts, sw ? d.pose : d.pose_t, sw ? d.pts : d.pts_t, sw ? d.sc1 : d.sc0, sw ? d.sc0 : d.sc1};
+}
+// a group record through a pointer typed as global memory (the vector type's copy constructor wants a generic reference: component by component)
+__device__ __forceinline__ int4 ld_grp(__attribute__((address_space(1))) const int4 *g, int k)
+{
+    __attribute__((address_space(1))) const int *q = (__attribute__((address_space(1))) const int *)(g + k);
+    return make_int4(q[0], q[1], q[2], q[3]);
+}
+// the same window with its pointers typed as global memory (see BADevT)
+__device__ __forceinline__ BADevG ba_global(const BADev &d) { BADevG g; __builtin_memcpy(&g, &d, sizeof g); return g; }
 
 
 struct slam_ba {
@@ -228,11 +252,28 @@ template <int N> __device__ __forceinline__ void st_rec(double *p, const double 
 #pragma unroll
     for (int k = 0; k < N / 2; k++) q[k] = make_double2(v[2 * k], v[2 * k + 1]);
 }
+// (the same through pointers typed as global memory: BADevG)
+typedef double sg_d2 __attribute__((ext_vector_type(2)));
+template <int N> __device__ __forceinline__ void ld_rec(__attribute__((address_space(1))) const double *p, double *v)
+{
+    static_assert(N % 2 == 0, "even record length");
+    __attribute__((address_space(1))) const sg_d2 *q = (__attribute__((address_space(1))) const sg_d2 *)p;
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) { const sg_d2 t = q[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+}
+template <int N> __device__ __forceinline__ void st_rec(__attribute__((address_space(1))) double *p, const double *v)
+{
+    static_assert(N % 2 == 0, "even record length");
+    __attribute__((address_space(1))) sg_d2 *q = (__attribute__((address_space(1))) sg_d2 *)p;
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) { sg_d2 t; t.x = v[2 * k]; t.y = v[2 * k + 1]; q[k] = t; }
+}
 
 template <bool STORE = true>          // STORE = false (batches): the cost only -- the grouped build evaluates every observation again and keeps what it needs
-__device__ __forceinline__ void linearize_body(const BADev &d, int ignore_outliers, int respect_done)
+__device__ __forceinline__ void linearize_body(const BADev &d0, int ignore_outliers, int respect_done)
 {
-    const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
+    const BADevG d = ba_global(d0);                          // (global_load / global_store, not flat accesses, where the caller read the window out of the batch's table)
+    const ParamBufsG pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
     __shared__ double sh[4];
     if (respect_done && d.st->converged) return;
     const int i = blockIdx.x * 256 + threadIdx.x, O = d.O;
@@ -358,14 +399,15 @@ static bool sg_fold_fits(int whb)
 }
 
 template <int TT>      // threads per workgroup: SG_T, or 256 for a batch of windows whose groups all have <= 256 observations (two to three workgroups per compute unit)
-__device__ __forceinline__ void schur_groups_body(const BADev &d, double inv_delta_host, int ignore_outliers, int use_state)
+__device__ __forceinline__ void schur_groups_body(const BADev &d0, double inv_delta_host, int ignore_outliers, int use_state)
 {
-    const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
+    const BADevG d = ba_global(d0);                          // (global_load / global_store, not flat accesses, where the caller read the window out of the batch's table)
+    const ParamBufsG pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
     extern __shared__ __attribute__((aligned(16))) double sg_lds[];
     SG_CLK_DECL;
     if (use_state && d.st->converged) return;
     const int tid = threadIdx.x, M = d.M, O = d.O;
-    const int4 G = d.grp[blockIdx.x];                       // first point, first observation, f | points << 16, observations
+    const int4 G = ld_grp(d.grp, blockIdx.x);               // first point, first observation, f | points << 16, observations
     const int k0 = G.x, o0 = G.y, f = G.z & 0xffff, npts = G.z >> 16, nobs = G.w;
     const int hbw = d.whb + 1, nwin = hbw * (hbw + 1) / 2;
     const int OBc = d.sg_ob, SBc = d.sg_sb;        // layout capacities (SG_OB / SG_SB, or the largest group of a batch of small windows)
@@ -379,7 +421,7 @@ __device__ __forceinline__ void schur_groups_body(const BADev &d, double inv_del
     unsigned char *s_ab = (unsigned char *)(s_slot + SBc * hbw);   // [nwin][2]
     double *s_dg = sg_lds + (sg_dg_off(d.whb, OBc, SBc, TT, HPc) >> 3);     // [hbw][36] Jp'Jp per window slot
     double *s_sc = s_dg + hbw * 36;                                    // [P][6] sin / cos of every pose's angles (pose_sincos)
-    for (int p = tid; p < d.P; p += TT) pose_sincos(pb.pose + 6 * p, s_sc + 6 * p);
+    for (int p = tid; p < d.P; p += TT) { const double ang[3] = {pb.pose[6 * p], pb.pose[6 * p + 1], pb.pose[6 * p + 2]}; pose_sincos(ang, s_sc + 6 * p); }
     for (int x = tid; x < npts * hbw; x += TT) s_slot[x] = -1;
     for (int w = tid; w < nwin; w += TT) {
         int a = 0, r = w;
@@ -474,7 +516,7 @@ __device__ __forceinline__ void schur_groups_body(const BADev &d, double inv_del
     }
     lds_sync();
     SG_CLK(4);
-    double *out = d.wpart + (size_t)blockIdx.x * d.wstride;
+    __attribute__((address_space(1))) double *out = d.wpart + (size_t)blockIdx.x * d.wstride;
     // ---- phase 3: the window blocks.  A wave (a run of LPS lanes) is one point subset: its lanes are the blocks, all on the same
     //      point at the same time -- V^-1 and the slot row are broadcast reads, the W_a rows are shared by up to hb + 1 lanes, the
     //      W_b rows of neighbouring lanes are neighbouring records (conflict-free b128 reads).  The whole 6 x 6 block stays in
@@ -592,15 +634,25 @@ static size_t sgm_lds_bytes(int whb, int P, int ob, int sb, int hp)
     return (sgm_r_doubles(whb, ob, sb, hp) + (size_t)sb * 16 + 8 + (size_t)(whb + 1) * 36 + (size_t)P * 6 + (size_t)sgm_rp(whb)) * 8 + (size_t)sb * (whb + 1) * 2 + 16;
 }
 template <int TT>
-__device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignore_outliers)
+__device__ __forceinline__ void schur_groups_mfma_body(const BADev &d0, int ignore_outliers)
 {
+    const BADevG d = ba_global(d0);                          // (global_load / global_store, not flat accesses, where the caller read the window out of the batch's table)
     extern __shared__ __attribute__((aligned(16))) double sg_lds[];
     SG_CLK_DECL;
     if (d.st->converged) return;
-    const ParamBufs pb = param_bufs(d);
+    const ParamBufsG pb = param_bufs(d);
+    // (the window's arrays through pointers typed as global memory: a pointer that a batch kernel reads out of the window table is a generic pointer to the
+    //  compiler, every access a FLAT instruction -- which also counts against the LDS counter, so that an LDS wait waits for the outstanding global loads)
+#define SGM_G(T, name, src) __attribute__((address_space(1))) T *name = (__attribute__((address_space(1))) T *)(src)
+    SGM_G(const int, g_opose, d.opose); SGM_G(const int, g_opoint, d.opoint); SGM_G(const int, g_opk, d.opk); SGM_G(const int, g_ohp, d.ohp);
+    SGM_G(const uint8_t, g_outl, d.outl); SGM_G(const uint8_t, g_pconst, d.pconst); SGM_G(const double, g_pix, d.pix);
+    SGM_G(const int, g_pt_id, d.pt_id); SGM_G(const int, g_pt_start, d.pt_start); SGM_G(const int, g_grp, d.grp); SGM_G(const LMState, g_st, d.st);
+    SGM_G(const double, g_sc, pb.sc); SGM_G(const double, g_pts, pb.pts); SGM_G(const double, g_pose, pb.pose);
+    SGM_G(double, g_Vinv, d.Vinv); SGM_G(double, g_bl, d.bl);
+#undef SGM_G
     const int tid = threadIdx.x, M = d.M, O = d.O, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // (the wave index in a scalar register: the tile loop branches on it)
     constexpr int NW = TT / 64;
-    const int4 G = d.grp[blockIdx.x];                       // first point, first observation, f | points << 16, observations
+    const int4 G = make_int4(g_grp[4 * blockIdx.x], g_grp[4 * blockIdx.x + 1], g_grp[4 * blockIdx.x + 2], g_grp[4 * blockIdx.x + 3]);                       // first point, first observation, f | points << 16, observations
     const int k0 = __builtin_amdgcn_readfirstlane(G.x), o0 = __builtin_amdgcn_readfirstlane(G.y), f = __builtin_amdgcn_readfirstlane(G.z & 0xffff),
               npts = __builtin_amdgcn_readfirstlane(G.z >> 16), nobs = __builtin_amdgcn_readfirstlane(G.w);      // (uniform by construction; told to the compiler: scalar loop counters)
     const int hbw = d.whb + 1, nwin = hbw * (hbw + 1) / 2, RP = sgm_rp(d.whb), nrow = 6 * hbw;
@@ -614,15 +666,15 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
     // the observation's scalars are requested BEFORE the set-up work below (their latency hides behind the sin / cos of the poses)
     int i = 0, p = 0, j = 0, pl = 0, hpi = -1; bool active = false, hp = false; double py = 0.0, px = 0.0;
     if (tid < nobs) {
-        i = o0 + tid; p = d.opose[i]; j = d.opoint[i]; pl = d.opk[i] - k0; hpi = d.ohp[i];
-        active = !(ignore_outliers && d.outl[i]); hp = active && !d.pconst[p];
-        py = d.pix[i]; px = d.pix[O + i];
+        i = o0 + tid; p = g_opose[i]; j = g_opoint[i]; pl = g_opk[i] - k0; hpi = g_ohp[i];
+        active = !(ignore_outliers && g_outl[i]); hp = active && !g_pconst[p];
+        py = g_pix[i]; px = g_pix[O + i];
     }
     // ... and so is what phase 1's lanes (one per map point) read from global memory: behind the barriers below these loads were a memory round trip of their own
     int p1_jj = 0, p1_t0 = 0, p1_t1 = 0;
-    if (tid < npts) { p1_jj = d.pt_id[k0 + tid]; p1_t0 = d.pt_start[k0 + tid] - o0; p1_t1 = d.pt_start[k0 + tid + 1] - o0; }
-    const double inv_delta = 1.0 / d.st->delta;
-    for (int a = tid; a < 6 * d.P; a += TT) s_sc[a] = pb.sc[a];      // (formed once per window: k_pass_start_b / k_trial_poses_b)
+    if (tid < npts) { p1_jj = g_pt_id[k0 + tid]; p1_t0 = g_pt_start[k0 + tid] - o0; p1_t1 = g_pt_start[k0 + tid + 1] - o0; }
+    const double inv_delta = 1.0 / g_st->delta;
+    for (int a = tid; a < 6 * d.P; a += TT) s_sc[a] = g_sc[a];      // (formed once per window: k_pass_start_b / k_trial_poses_b)
     for (int x = tid; x < npts * hbw; x += TT) s_slot[x] = -1;
     // element (row, col) of Y Y' is entry (rr, cc) of window block (a, b) = (row / 6, col / 6), stored at (a hbw - a (a - 1) / 2 + b - a) 36 + rr 6 + cc:
     // slot << 26 | the row's / the column's share of that offset, once per group instead of once per accumulator element
@@ -641,12 +693,12 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
     for (int k = 0; k < 6; k++) Jl[k] = 0.0;
     if (tid < nobs) {
         if (active) {
-            const double X[3] = {pb.pts[3 * j], pb.pts[3 * j + 1], pb.pts[3 * j + 2]};
+            const double X[3] = {g_pts[3 * j], g_pts[3 * j + 1], g_pts[3 * j + 2]};
             double sc[6], tr[3];
 #pragma unroll
             for (int k = 0; k < 6; k++) sc[k] = s_sc[6 * p + k];
 #pragma unroll
-            for (int k = 0; k < 3; k++) tr[k] = pb.pose[6 * p + 3 + k];
+            for (int k = 0; k < 3; k++) tr[k] = g_pose[6 * p + 3 + k];
             obs_eval_sc(sc, tr, X, py, px, d.cam, r2, Jp, Jl, nullptr);
             if (!hp) {
 #pragma unroll
@@ -678,9 +730,9 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
         double Vi[6];
         inv3_sym(V, Vi);
 #pragma unroll
-        for (int c = 0; c < 6; c++) { d.Vinv[(size_t)c * M + jj] = Vi[c]; s_pt[tid * 16 + c] = Vi[c]; }
+        for (int c = 0; c < 6; c++) { g_Vinv[(size_t)c * M + jj] = Vi[c]; s_pt[tid * 16 + c] = Vi[c]; }
 #pragma unroll
-        for (int c = 0; c < 3; c++) { d.bl[(size_t)c * M + jj] = V[6 + c]; s_pt[tid * 16 + 6 + c] = V[6 + c]; }
+        for (int c = 0; c < 3; c++) { g_bl[(size_t)c * M + jj] = V[6 + c]; s_pt[tid * 16 + 6 + c] = V[6 + c]; }
         // V^-1 = L L' (V^-1 is positive definite with V; a breakdown gives NaN, which the solve reports as a failed factorisation)
         const double l00 = sqrt(Vi[0]), l10 = Vi[1] / l00, l20 = Vi[2] / l00;
         const double l11 = sqrt(Vi[3] - l10 * l10), l21 = (Vi[4] - l20 * l10) / l11;
@@ -721,7 +773,7 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
     SG_CLK(4);
     // ---- phase 2x: Jp'Jp, the gradient and diag U per window slot: lane = (slot a2, row rr, point class xq); no partials through LDS --
     //      the XQ lanes of a task sit next to each other and are folded by DPP
-    double *out = d.wpart + (size_t)blockIdx.x * d.wstride;
+    __attribute__((address_space(1))) double *out = (__attribute__((address_space(1))) double *)d.wpart + (size_t)blockIdx.x * d.wstride;
     {
         const int TPW = (nrow + NW - 1) / NW, xs = TPW <= 16 ? 2 : TPW <= 32 ? 1 : 0, XQ = 1 << xs;      // (a shift, not a run-time division)
         const int task = wv * TPW + (lane >> xs), xq = lane & (XQ - 1);
@@ -787,7 +839,6 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
     {
         const int NT = RP / 16, ntiles = NT * (NT + 1) / 2, q = lane >> 4, c16 = lane & 15, nks = K4 >> 2;
         const size_t lane_off = ((size_t)(q >> 1) * RP + c16) * 2 + (q & 1), kstep = (size_t)4 * RP;
-        __attribute__((address_space(1))) double *outg = (__attribute__((address_space(1))) double *)out;      // (a pointer read from the window table: told to be global memory, not flat)
         auto emit = [&](int I, int J, const sgm_d4 &acc) {
             const int col = J * 16 + c16;
             const unsigned tc = s_tc[col];
@@ -799,12 +850,12 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
                 const int a = (int)(tr >> 26);
                 if (a > b) continue;                                 // (below the block diagonal, or a row past the window)
                 const int o = (int)(tr & 0x3ffffffu) + oc;           // (w 36 + rr 6) + (b 36 + cc) - ... see the table: the row's share carries -a 36
-                if (a < b) outg[o] = -acc[r];
+                if (a < b) out[o] = -acc[r];
                 else {
                     const int rr6 = (int)(tr & 0x3ffffffu) - (a * hbw - a * (a - 1) / 2 - a) * 36, cc = oc - b * 36;
                     const double v = s_dg[a * 36 + rr6 + cc] - acc[r];
-                    outg[o] = v;
-                    if (I < J) outg[o - rr6 - cc + cc * 6 + rr6 / 6] = v;      // a diagonal block cut by a tile boundary: its mirror half lies in a tile below the diagonal, which nobody computes
+                    out[o] = v;
+                    if (I < J) out[o - rr6 - cc + cc * 6 + rr6 / 6] = v;      // a diagonal block cut by a tile boundary: its mirror half lies in a tile below the diagonal, which nobody computes
                 }
             }
         };
@@ -857,8 +908,9 @@ __device__ __forceinline__ void schur_groups_mfma_body(const BADev &d, int ignor
 }
 
 // S, g, diag(U) from the window partials: thread = (band block (p, p + dq), entry) / (pose, gradient or diagonal entry)
-__device__ __forceinline__ void schur_reduce_body(const BADev &d, int use_state)
+__device__ __forceinline__ void schur_reduce_body(const BADev &d0, int use_state)
 {
+    const BADevG d = ba_global(d0);                          // (global_load / global_store instead of flat accesses where the caller read the window out of the batch's table)
     if (use_state && d.st->converged) return;
     const int idx = blockIdx.x * 256 + threadIdx.x, P = d.P, n = d.n;
     const int hbw = d.whb + 1, nwin = hbw * (hbw + 1) / 2;
@@ -1015,7 +1067,10 @@ __device__ __forceinline__ void tile_mask_lower(double (*t)[CT + 1], int h, int 
 // Back-substitution L' dp = y then walks the block columns right to left with the stored L_ik and L_kk^-1.
 // Systems whose half-bandwidth exceeds BS_MAXHB blocks (dense windows of > 21 poses) keep the tiled path.
 #define BS_MAXHB 20
-struct BandArgs { const double *S, *g, *ud; double *Lg; int nb, hb; double inv_delta_host; int *fail; long long *trace; int lds_bytes; double *xchg; int epoch; int shift; int p0; };
+template <template <class> class Q> struct BandArgsT { typename Q<const double>::type S, g, ud; typename Q<double>::type Lg; int nb, hb; double inv_delta_host; typename Q<int>::type fail; typename Q<long long>::type trace; int lds_bytes; typename Q<double>::type xchg; int epoch; int shift; int p0; };
+typedef BandArgsT<PlainP> BandArgs; typedef BandArgsT<GlobP> BandArgsG;
+static_assert(sizeof(BandArgs) == sizeof(BandArgsG), "BandArgsG re-types BandArgs' pointers, nothing else");
+__device__ __forceinline__ BandArgsG band_global(const BandArgs &b) { BandArgsG g; __builtin_memcpy(&g, &b, sizeof g); return g; }
 #define BS_PF 6      // prefetch registers per prefetch thread: ceil(((BS_MAXHB + 1) * 36 + 6) / BS_PT)
 #define BS_WS 38     // doubles per 6 x 6 block in the window ring and the panel: 36 + 2, so that the blocks the lanes of a wave read at the
                      // same time start 12 banks apart (a stride of 36 doubles = 8 banks puts every fourth block on the same ones)
@@ -1031,8 +1086,10 @@ __device__ __forceinline__ void bs_barrier()
 #define BS_T 512      /* eight waves, two per SIMD (256 registers each, no spills); roles in the column loop: see there */
 #define BS_PT 128     /* threads of the prefetch waves (3 and 7) */
 #define BS_UT 128     /* threads of the update waves (1-2) */
-__device__ __forceinline__ void band_solve_body(const BADev &d, const BandArgs &B, int use_state)
+__device__ __forceinline__ void band_solve_body(const BADev &d0, const BandArgs &B0, int use_state)
 {
+    const BADevG d = ba_global(d0);                          // (global_load / global_store, not flat accesses, where the caller read the window out of the batch's table)
+    const BandArgsG B = band_global(B0);
     if (use_state && d.st->converged) return;
     extern __shared__ __attribute__((aligned(16))) double bs_sm[];
     __shared__ int s_bad, s_step;
@@ -1072,8 +1129,8 @@ __device__ __forceinline__ void band_solve_body(const BADev &d, const BandArgs &
     unsigned char *ptab = (unsigned char *)(Dn + 36);    // [hb (hb+1) / 2][2] pair table (di, dj), dj <= di, ordered by di
     const double inv_delta = use_state ? 1.0 / d.st->delta : B.inv_delta_host;
     const size_t lgs = (size_t)hb1 * 36 + 8;             // doubles per block column in the global factor store
-    double *const Lg = B.Lg + (size_t)side * nbT * lgs;
-    double *const dpo = d.dp + 6 * B.p0;                   // dp of the solve's first pose (the span of the free poses)
+    __attribute__((address_space(1))) double *const Lg = B.Lg + (size_t)side * nbT * lgs;
+    __attribute__((address_space(1))) double *const dpo = d.dp + 6 * B.p0;                   // dp of the solve's first pose (the span of the free poses)
     // The two sides of a twisted solve hand data to each other through global memory.  On the same XCD (the normal case, see above) the
     // L2 is common: the producer's stores only have to have arrived there (s_waitcnt vmcnt(0)) and the consumer reads with sc1 loads, past
     // its own L1 -- no agent-scope fence, whose L2 write-back / invalidate costs microseconds.  Each side publishes its XCC_ID (tagged
@@ -1164,7 +1221,7 @@ __device__ __forceinline__ void band_solve_body(const BADev &d, const BandArgs &
         const int di = i - (hb + 1);
 #pragma unroll
         for (int q = 0; q < BS_PF; q++) {
-            const double *src = e[q].x >= 0 ? B.S + (e[q].y + di * strideS) : B.g + (e[q].y + di * strideG);
+            __attribute__((address_space(1))) const double *src = e[q].x >= 0 ? B.S + (e[q].y + di * strideS) : B.g + (e[q].y + di * strideG);
             pf[q] = 0.0;
             if (e[q].x > -1000) pf[q] = *src;
         }
@@ -1318,7 +1375,7 @@ __device__ __forceinline__ void band_solve_body(const BADev &d, const BandArgs &
     for (int phase = 0; ; phase++) {
     for (int k = kbeg; k < kend; k++, kk = kk + 1 == hb1 ? 0 : kk + 1) {
         const int np = nb - 1 - k < hb ? nb - 1 - k : hb;        // blocks below the diagonal in this column
-        double *Lgk = Lg + (size_t)k * lgs;
+        auto Lgk = Lg + (size_t)k * lgs;
         const bool stamp = B.trace && side == 0 && k == 10 && (tid & 63) == 0;
         if (stamp) B.trace[32 + (tid >> 6)] = clock64();
         if (fwave) {
@@ -1584,7 +1641,7 @@ __device__ __forceinline__ void band_solve_body(const BADev &d, const BandArgs &
     double lreg[6], lic[6];
     auto fetch_back = [&](int k) {
         const int np = nb - 1 - k < hb ? nb - 1 - k : hb;
-        const double *Lgk = B.Lg + (size_t)k * lgs;
+        __attribute__((address_space(1))) const double *Lgk = B.Lg + (size_t)k * lgs;
         if (tid < np * 6) {
             const int di = tid / 6 + 1, c = tid - 6 * (di - 1);
 #pragma unroll
@@ -1811,12 +1868,13 @@ __device__ __forceinline__ void ds_barrier() { __builtin_amdgcn_fence(__ATOMIC_R
 // build and read back (160 bytes per observation each way: the kernel was bound by those reads, 0.97 GB per launch of 128 x P20); s_sc = the committed poses'
 // sin / cos.  Same function of the same arguments as in the build: the same bits.
 template <int TT, bool RECOMP = false>
-__device__ __forceinline__ void update_groups_body(const BADev &d, int ignore_outliers, int use_state, double *s_dp, double *s_u, double *s_dl, double *s_red, double *s_sct, bool sct_ready, double *s_sc = nullptr)
+__device__ __forceinline__ void update_groups_body(const BADev &d0, int ignore_outliers, int use_state, double *s_dp, double *s_u, double *s_dl, double *s_red, double *s_sct, bool sct_ready, double *s_sc = nullptr)
 {
-    const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
+    const BADevG d = ba_global(d0);                          // (global_load / global_store instead of flat accesses where the caller read the window out of the batch's table)
+    const ParamBufsG pb = param_bufs(d);                     // committed / trial parameters (LMState::cur)
     if (use_state && d.st->converged) return;
     const int tid = threadIdx.x, M = d.M, O = d.O, n = d.n;
-    const int4 G = d.grp[blockIdx.x];
+    const int4 G = ld_grp(d.grp, blockIdx.x);
     const int k0 = G.x, o0 = G.y, npts = G.z >> 16, nobs = G.w;
     // everything a lane reads from global memory at an address it already knows is requested HERE, in front of the barriers: behind them the observation's
     // scalars and the point's index / range were memory round trips of their own (~1 us each on a loaded device), three of them per group
@@ -1933,13 +1991,13 @@ __device__ __forceinline__ void update_groups_body(const BADev &d, int ignore_ou
 // LeastSquaresOptim accept/reject logic.  mode 0: ssr of the current residuals
 // (after k_linearize); mode 1: trial/predicted/maxdx -> state (+ LM decision if lm).
 // fixed-order strided sum / max of a partials array by one 256-thread workgroup
-__device__ __forceinline__ double ctl_sum(const double *p, int n, int stride, double *sh)
+__device__ __forceinline__ double ctl_sum(__attribute__((address_space(1))) const double *p, int n, int stride, double *sh)
 {
     double t = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) t += p[(size_t)i * stride];
     return block_sum(t, sh);
 }
-__device__ __forceinline__ double ctl_max(const double *p, int n, double *sh)
+__device__ __forceinline__ double ctl_max(__attribute__((address_space(1))) const double *p, int n, double *sh)
 {
     double t = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) t = fmax(t, p[i]);
@@ -1947,7 +2005,8 @@ __device__ __forceinline__ double ctl_max(const double *p, int n, double *sh)
 }
 // LeastSquaresOptim's accept / reject of a trial step (trust-region radius update, step-quality test): t = trial cost,
 // p = predicted cost, mx = max |dx|
-__device__ __forceinline__ void lm_decide(LMState *s, double t, double p, double mx)
+template <class SP>      // LMState * (k_ba_window's copy in LDS) or a pointer typed as global memory
+__device__ __forceinline__ void lm_decide(SP s, double t, double p, double mx)
 {
     s->iters++;
     if (s->chol_fail) { s->converged = 1; s->accept = 0; return; }
@@ -1970,10 +2029,11 @@ __device__ __forceinline__ void lm_decide(LMState *s, double t, double p, double
         s->converged = mx <= LM_XTOL;
     }
 }
-__device__ __forceinline__ void control_body(const BADev &d, int mode, int nb_obs, int nb_pts, int lm, double *out4)
+__device__ __forceinline__ void control_body(const BADev &d0, int mode, int nb_obs, int nb_pts, int lm, double *out4)
 {
+    const BADevG d = ba_global(d0);                          // (global_load / global_store, not flat accesses, where the caller read the window out of the batch's table)
     __shared__ double sh[4];
-    LMState *s = d.st;
+    __attribute__((address_space(1))) LMState *s = d.st;
     if (mode == 0) {
         const double t = ctl_sum(d.part, nb_obs, 1, sh);
         if (threadIdx.x == 0) { s->ssr = t; if (out4) out4[0] = t; }
@@ -2001,9 +2061,10 @@ __device__ __forceinline__ void control_body(const BADev &d, int mode, int nb_ob
 
 
 // _ba_detect_outliers!, bundle_adjustment.jl:90-111
-__device__ __forceinline__ void outliers_body(const BADev &d, double repr_eps, double depth_eps)
+__device__ __forceinline__ void outliers_body(const BADev &d0, double repr_eps, double depth_eps)
 {
-    const ParamBufs pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
+    const BADevG d = ba_global(d0);                          // (global_load / global_store, not flat accesses, where the caller read the window out of the batch's table)
+    const ParamBufsG pb = param_bufs(d);                      // committed / trial parameters (LMState::cur)
     __shared__ double sh[4];
     const int i = blockIdx.x * 256 + threadIdx.x, O = d.O;
     double c = 0.0;
@@ -2021,8 +2082,9 @@ __device__ __forceinline__ void outliers_body(const BADev &d, double repr_eps, d
     const double t = block_sum(c, sh);
     if (threadIdx.x == 0) d.part[blockIdx.x] = t;
 }
-__device__ __forceinline__ void outlier_count_body(const BADev &d, int nb_obs)
+__device__ __forceinline__ void outlier_count_body(const BADev &d0, int nb_obs)
 {
+    const BADevG d = ba_global(d0);                          // (global_load / global_store, not flat accesses, where the caller read the window out of the batch's table)
     __shared__ double sh[4];
     const double t = ctl_sum(d.part, nb_obs, 1, sh);           // counts: exact in any order
     if (threadIdx.x == 0) d.st->n_outliers = (int)t;

@@ -60,7 +60,9 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(BAWin) / 8); k++) raw[k] = q[k];
         __builtin_memcpy(&w, raw, sizeof w); }
-    const BADev &d = w.d;
+    BADevG dg;                                                 // the window's arrays as GLOBAL-memory pointers (global_load / global_store, not flat accesses: ba_device.hpp)
+    __builtin_memcpy(&dg, &w.d, sizeof dg);
+    const BADevG &d = dg;
     extern __shared__ __attribute__((aligned(16))) double bw_sm[];
     const int tid = threadIdx.x;
     const int P = d.P, M = d.M, O = d.O, p0 = w.B.p0, F = w.B.nb, n = 6 * F, nwin = F * (F + 1) / 2;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
     const int a2 = xl ? wl / 6 : 0, r2 = wl - 6 * (wl / 6);
     __shared__ LMState s_lm;                           // the LM state lives HERE for the whole solve (both halves of a split window advance their copies identically)
     LMState *s = &s_lm;
-    if (tid == 0) s_lm = *d.st;
+    if (tid == 0) s_lm = *(const LMState *)d.st;
     // this workgroup's map points [kLo, kHi) (sorted order) and observations [oLo, oHi)
     const int kLo = two && half ? w.ksplit : 0, kHi = two && !half ? w.ksplit : M;
     const int oLo = d.pt_start[kLo], oHi = d.pt_start[kHi];
@@ -148,20 +150,20 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
     long long bw_clk[12];
 #endif
     // committed pose data -> LDS (sin / cos of the angles, translation)
-    auto stage_poses = [&](const ParamBufs &pb) {
+    auto stage_poses = [&](const ParamBufsG &pb) {
         for (int p = tid; p < P; p += BW_T) {
-            pose_sincos(pb.pose + 6 * p, s_sc + 6 * p);
+            { const double ang[3] = {pb.pose[6 * p], pb.pose[6 * p + 1], pb.pose[6 * p + 2]}; pose_sincos(ang, s_sc + 6 * p); }
             s_tr[3 * p] = pb.pose[6 * p + 3]; s_tr[3 * p + 1] = pb.pose[6 * p + 4]; s_tr[3 * p + 2] = pb.pose[6 * p + 5];
         }
     };
 
-    auto pbufs = [&]() { const bool sw = s->cur != 0; return ParamBufs{sw ? d.pose_t : d.pose, sw ? d.pts_t : d.pts, sw ? d.pose : d.pose_t, sw ? d.pts : d.pts_t, nullptr, nullptr}; };
+    auto pbufs = [&]() { const bool sw = s->cur != 0; return ParamBufsG{sw ? d.pose_t : d.pose, sw ? d.pts_t : d.pts, sw ? d.pose : d.pose_t, sw ? d.pts : d.pts_t, nullptr, nullptr}; };
     __syncthreads();
     for (int pass = 0; pass < 2; pass++) {
         const int ignore = pass, iters = pass ? iterations : iters_fast;
         // ---- cost at the committed parameters (LeastSquaresOptim evaluates f!(fcur, x) first)
         {
-            const ParamBufs pb = pbufs();
+            const ParamBufsG pb = pbufs();
             __syncthreads();
             stage_poses(pb);
             __syncthreads();
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
         }
         for (int it = 1; it <= iters; it++) {
             if (s->converged) break;                           // (uniform: every thread reads the flag after a barrier)
-            const ParamBufs pb = pbufs();
+            const ParamBufsG pb = pbufs();
             const double inv_delta = 1.0 / s->delta;
             BW_CLK(0);
             stage_poses(pb);
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
         if (pass == 0) {
             // ---- _ba_detect_outliers! at theta_1 (bundle_adjustment.jl:90-111)
             __syncthreads();
-            const ParamBufs pb = pbufs();
+            const ParamBufsG pb = pbufs();
             stage_poses(pb);
             __syncthreads();
             double cnt = 0.0;
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
     __syncthreads();
     if (tid == 0 && half == 0) {
         if (two && (xdead || __hip_atomic_load(xflag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) s_lm.chol_fail = 2;     // a half gave up waiting: nothing of this window is valid
-        *d.st = s_lm;
+        *(LMState *)d.st = s_lm;
     }
 }
 
