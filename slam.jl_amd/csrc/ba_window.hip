@@ -320,8 +320,7 @@ __global__ __launch_bounds__(BW_T) void k_ba_window(const BAWin *tab, const int 
                         if (ta < 0) continue;
                         double J[12];
                         ld_rec<12>(s_Jp + ta * 12, J);
-                        const double j0 = r2 == 0 ? J[0] : r2 == 1 ? J[1] : r2 == 2 ? J[2] : r2 == 3 ? J[3] : r2 == 4 ? J[4] : J[5];
-                        const double j1 = r2 == 0 ? J[6] : r2 == 1 ? J[7] : r2 == 2 ? J[8] : r2 == 3 ? J[9] : r2 == 4 ? J[10] : J[11];
+                        const double j0 = s_Jp[ta * 12 + r2], j1 = s_Jp[ta * 12 + 6 + r2];      // (two more LDS reads instead of two five-deep select chains over J)
 #pragma unroll
                         for (int c = 0; c < 6; c++) ex[c] = fma(j1, J[6 + c], fma(j0, J[c], ex[c]));
                         ex[6] += s_gr[ta * 6 + r2];
