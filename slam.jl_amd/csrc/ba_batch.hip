@@ -254,7 +254,15 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
         if (rc) return rc;
         char *res_host = stage + up_total;
         BAWin *tab_h = (BAWin *)stage; BARes *rtab_h = (BARes *)(stage + tab_bytes);
-        parallel([&](int zz) {
+        // a large upload travels in parts: the staged bytes of the first windows go out while the pool stages the next ones (128 x P20: 203 MB = 4 ms of PCIe
+        // beside 2.5 ms of staging); the tables and the last part follow with the launch sequence below
+        // (a part keeps every thread of the pool busy -- one window per task -- and a small upload is not worth the extra runs of the pool: measured, 128 reference-shaped
+        //  windows = 33 MB gained 0.2 ms per call and lost 25 % with two calls in flight; 32 x P100 in four parts of eight windows lost 4 ms)
+        static const int parts_cap = [] { const char *v = getenv("SLAMHIP_BA_UPLOAD_PARTS"); return v ? atoi(v) : 4; }();      // (measurement knob)
+        const int n_parts = up_total < ((size_t)64 << 20) ? 1 : std::max(1, std::min(parts_cap, NB / std::max(nthr, 1)));
+        const int n_early = n_parts > 1 ? NB - (NB + n_parts - 1) / n_parts : 0;            // windows whose bytes leave before the launch sequence: all but the last part
+        const int early_step = n_parts > 1 ? std::max(1, (n_early + n_parts - 2) / (n_parts - 1)) : NB;
+        auto emit_window = [&](int zz) {
             if (zz >= NB) return;
             const int k = zz; BAPlan &q = pl[batch[k]];
             if (ba_emit(q, A + up[k], A + zero_base + ze[k], A + work_base + wk[k], stage + up[k])) return;
@@ -280,7 +288,17 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
             }
             BARes &r = rtab_h[k];
             r.off_state = res_base + rs[k]; r.off_theta = r.off_state + al(sizeof(LMState)); r.off_outl = r.off_theta + al((6 * (size_t)q.P + 3 * (size_t)q.M) * 8 + 8);
-        });
+        };
+        bool early_sent = false;
+        if (n_early > 0) {
+            early_sent = true;
+            for (int b0 = 0; b0 < NB;) {
+                const int b1 = b0 < n_early ? std::min(n_early, b0 + early_step) : NB;
+                pool.run(b1 - b0, [&](int zz) { emit_window(b0 + zz); });
+                if (b1 <= n_early && early_sent) early_sent = hipMemcpyAsync(A + up[b0], stage + up[b0], up[b1] - up[b0], hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+                b0 = b1;
+            }
+        } else pool.run(S, emit_window);
         for (int k = 0; k < NB; k++) {
             BAPlan &q = pl[batch[k]];
             if (q.err) { st_code[batch[k]] = q.err; if (!status) return slam_fail(ctx, q.err, "slam_local_ba_batch: window %d: %s", batch[k], q.msg); }
@@ -396,7 +414,10 @@ int slam_local_ba_batch(slam_ctx *ctx, int S, const double *cams, const int32_t 
         hipError_t e = hipEventCreate(&e0);
         if (e == hipSuccess) e = hipEventCreate(&e1);
         for (int attempt = 0; e == hipSuccess && attempt < 2; attempt++) {
-            e = hipMemcpyAsync(A, stage, up_total, hipMemcpyHostToDevice, st);
+            if (attempt == 0 && early_sent) {                      // (the first half of the windows' bytes is on its way already)
+                e = hipMemcpyAsync(A, stage, up[0], hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(A + up[n_early], stage + up[n_early], up_total - up[n_early], hipMemcpyHostToDevice, st);
+            } else e = hipMemcpyAsync(A, stage, up_total, hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = hipMemsetAsync(A + zero_base, 0, ze[NB], st);
             if (e != hipSuccess) break;
             (void)hipEventRecord(e0, st);
