@@ -81,8 +81,17 @@ __device__ __forceinline__ double sep3(const double *src, int h, int w, int y, i
 // registers (NT known at compile time) -- 3.4 instead of 13 LDS reads per output; every output is still acc = 0; acc += v[j] * k[j]
 // with j ascending.
 #define DET_SL 5
+// i / d and i % d for a divisor that is only known at run time (cell height, strips per column, disk rows): the compiler expands such a division into
+// ~25 instructions at every site.  One multiplication by m = ceil(2^32 / d), formed once per workgroup, is exact for i < 2^16 <= 2^32 / d (every index of a
+// cell tile is far below that).
+struct DetDiv {
+    unsigned m, d;
+    __device__ __forceinline__ explicit DetDiv(int dd) : m(0xffffffffu / (unsigned)(dd > 0 ? dd : 1) + 1u), d((unsigned)(dd > 0 ? dd : 1)) {}
+    __device__ __forceinline__ int div(int i) const { return d == 1 ? i : (int)__umulhi((unsigned)i, m); }
+    __device__ __forceinline__ int mod(int i) const { return i - div(i) * (int)d; }
+};
 template <int NT>
-__device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned char *m0, const double *taps, int h, int w, int mh, int mw, int tid, int ntaps = NT)
+__device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned char *m0, const double *taps, int h, int w, int mh, int mw, int tid, const DetDiv &dns, const DetDiv &dh, int ntaps = NT)
 {
     const int nt = NT > 0 ? NT : ntaps;
     if (NT > 0) {
@@ -93,7 +102,7 @@ __device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned 
         // dim-1 pass: T(y, tx) = sum_j m0(y+j, tx) * k[j]; thread = (column tx, strip of DET_SL rows)
         const int ns = (h + DET_SL - 1) / DET_SL;
         for (int it = tid; it < mw * ns; it += DET_THREADS) {
-            const int tx = it / ns, ys = (it - tx * ns) * DET_SL;
+            const int tx = dns.div(it), ys = (it - tx * ns) * DET_SL;
             double v[DET_SL + NK - 1];
 #pragma unroll
             for (int i = 0; i < DET_SL + NK - 1; i++) { const int yy = ys + i < mh ? ys + i : mh - 1; v[i] = (double)m0[yy + tx * mh]; }
@@ -111,7 +120,7 @@ __device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned 
         // dim-2 pass and image .* mask; thread = (row y, strip of DET_SL columns)
         const int nsx = (w + DET_SL - 1) / DET_SL;
         for (int it = tid; it < h * nsx; it += DET_THREADS) {
-            const int sx = it / h, y = it - sx * h, xs = sx * DET_SL;
+            const int sx = dh.div(it), y = it - sx * h, xs = sx * DET_SL;
             double v[DET_SL + NK - 1];
 #pragma unroll
             for (int i = 0; i < DET_SL + NK - 1; i++) { const int xx = xs + i < mw ? xs + i : mw - 1; v[i] = T[y + xx * h]; }
@@ -129,7 +138,7 @@ __device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned 
     }
     // dim-1 pass: T(y, tx) = sum_j m0(y+j, tx) * k[j]
     for (int i = tid; i < h * mw; i += DET_THREADS) {
-        const int y = i % h, tx = i / h;
+        const int tx = dh.div(i), y = i - tx * h;
         double acc = 0.0;
         for (int j = 0; j < nt; j++) acc += (double)m0[(y + j) + tx * mh] * taps[j];
         T[i] = acc;
@@ -137,7 +146,7 @@ __device__ __forceinline__ void blur_mask(double *bA, double *T, const unsigned 
     __syncthreads();
     // dim-2 pass and image .* mask
     for (int i = tid; i < h * w; i += DET_THREADS) {
-        const int y = i % h, x = i / h;
+        const int x = dh.div(i), y = i - x * h;
         double acc = 0.0;
         for (int j = 0; j < nt; j++) acc += T[y + (x + j) * h] * taps[j];
         bA[i] = bA[i] * acc;
@@ -221,12 +230,14 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         s_taps[tid] = kt[tid];
     }
     // ---- image tile -> bA ---------------------------------------------------
+    const DetDiv dvh(h), dnstr((h + DET_SL - 1) / DET_SL);
     for (int i0 = tid; i0 < h * w; i0 += 5 * DET_THREADS) {          // five loads per thread in flight (a 35 x 35 cell: one trip)
         double v[5];
 #pragma unroll
         for (int u = 0; u < 5; u++) {
             const int i = i0 + u * DET_THREADS, ic = i < h * w ? i : i0;
-            v[u] = a_img[(size_t)(y0 + ic % h) + (size_t)(x0 + ic / h) * A.pitch];
+            const int icx = dvh.div(ic);
+            v[u] = a_img[(size_t)(y0 + ic - icx * h) + (size_t)(x0 + icx) * A.pitch];
         }
 #pragma unroll
         for (int u = 0; u < 5; u++) { const int i = i0 + u * DET_THREADS; if (i < h * w) bA[i] = v[u]; }
@@ -284,8 +295,9 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
             for (int i = tid; i < mh * mw; i += DET_THREADS) m0[i] = 1;
             __syncthreads();
             const int nrow = 2 * r + 1, ty0 = y0 - hw, tx0 = x0 - hw;
+            const DetDiv dnrow(nrow), dmh(mh);
             for (int q = tid; q < ncand * nrow; q += DET_THREADS) {
-                const int c = q / nrow, dyi = q % nrow - r;
+                const int c = dnrow.div(q), dyi = q - c * nrow - r;
                 const int yy = s_cand[2 * c] + dyi, px = s_cand[2 * c + 1];      // 1-based image coordinates
                 const int lim = s_lim[abs(dyi)];
                 const int ty = (yy - 1) - ty0;
@@ -297,7 +309,8 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
             __syncthreads();
             if (ty0 < 0 || ty0 + mh - 1 > H - 1 || tx0 < 0 || tx0 + mw - 1 > W - 1) {        // border cell: replicate
                 for (int i = tid; i < mh * mw; i += DET_THREADS) {
-                    const int uy = ty0 + i % mh, ux = tx0 + i / mh;
+                    const int imx = dmh.div(i);
+                    const int uy = ty0 + i - imx * mh, ux = tx0 + imx;
                     if (uy < 0 || uy > H - 1 || ux < 0 || ux > W - 1)
                         m0[i] = m0[(clampi(uy, 0, H - 1) - ty0) + (clampi(ux, 0, W - 1) - tx0) * mh];
                 }
@@ -318,11 +331,11 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
         __syncthreads();
         if (A.ntaps > 0) {
             double *T = bB;                                   // h*mw doubles: bB, bC and the part of bD below the byte mask (checked on host)
-            if (A.ntaps == 13) blur_mask<13>(bA, T, m0, s_taps, h, w, mh, mw, tid);      // sigma_mask = 3 (the default): unrolled
-            else blur_mask<0>(bA, T, m0, s_taps, h, w, mh, mw, tid, A.ntaps);
+            if (A.ntaps == 13) blur_mask<13>(bA, T, m0, s_taps, h, w, mh, mw, tid, dnstr, dvh);      // sigma_mask = 3 (the default): unrolled
+            else blur_mask<0>(bA, T, m0, s_taps, h, w, mh, mw, tid, dnstr, dvh, A.ntaps);
         } else {
             for (int i = tid; i < h * w; i += DET_THREADS) {
-                int y = i % h, x = i / h;
+                const int x = dvh.div(i), y = i - x * h;
                 bA[i] = bA[i] * (double)m0[(y + hw) + (x + hw) * mh];
             }
         }
@@ -336,7 +349,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     // thread = (column x, strip of DET_SL rows): 21 LDS reads per DET_SL pixels and plane instead of 9 per pixel
     const int nstr = (h + DET_SL - 1) / DET_SL;
     for (int it = tid; it < w * nstr; it += DET_THREADS) {
-        const int x = it / nstr, ys = (it - x * nstr) * DET_SL;
+        const int x = dnstr.div(it), ys = (it - x * nstr) * DET_SL;
         DetStrip S;
         det_strip_load(S, bA, h, w, ys, x);
 #pragma unroll
@@ -354,7 +367,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     // 3x3 box mean of the products (1/3 x 1/3, two-pass arithmetic) and the min-eigenvalue response -> bA
     double *resp = bA;
     for (int it = tid; it < w * nstr; it += DET_THREADS) {
-        const int x = it / nstr, ys = (it - x * nstr) * DET_SL;
+        const int x = dnstr.div(it), ys = (it - x * nstr) * DET_SL;
         double xx[DET_SL], xy[DET_SL], yy[DET_SL];
         DetStrip S;
         det_strip_load(S, bB, h, w, ys, x);
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_cells(DetectArgs A)
     for (int it0 = 0; it0 < w * nstr; it0 += DET_THREADS) {   // (whole waves enter every pass: the ballots need them)
         const int it = it0 + tid;
         const bool act = it < w * nstr;
-        const int x = act ? it / nstr : 0, ys = act ? (it - x * nstr) * DET_SL : 0;
+        const int x = act ? dnstr.div(it) : 0, ys = act ? (it - x * nstr) * DET_SL : 0;
         DetStrip S;
         det_strip_load(S, resp, h, w, ys, x);
         const bool cl = x > 0, cr = x < w - 1;
