@@ -608,10 +608,10 @@ __global__ __launch_bounds__(FP_SCORE_T) void k_5pt_score(FPArgs T)
                 if (two_view_errors(k1, k2, Rt, a, b, &e1, &e2)) ok = e1 < T.thr && e2 < T.thr;
             }
             cnt += __builtin_popcountll(__ballot(ok));
-            if ((i0 & 192) == 192) {                              // every 256 correspondences: can this pose still reach the incumbent?
-                best = max(best, __hip_atomic_load(bestp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (cnt + max(n - i0 - 64, 0) < best) { dropped = true; break; }
-            }
+            // can this pose still reach the incumbent?  Tested after every 64 correspondences against the copy in a register (a wrong pose with 5 % inliers
+            // falls behind a 70 % incumbent after ~0.32 n of them: at 320, not at 512); the incumbent itself is read again every 256 (an L2 round trip)
+            if ((i0 & 192) == 192) best = max(best, __hip_atomic_load(bestp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (cnt + max(n - i0 - 64, 0) < best) { dropped = true; break; }
         }
         if (lane == 0) {
             T.counts[slot * FP_MAXE + e] = cnt;
